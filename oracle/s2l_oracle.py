@@ -1,0 +1,244 @@
+"""CPU ORACLE for the Speech2Lip lip-render hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only `tests/`, `__graft_entry__.smoke()`, `tools/make_goldens.py` and `bench.py`'s
+`cpu_baseline` leg may import this module.  `speech2lip_amd/` never does: the product path
+runs hand-written HIP kernels through the C-ABI in `include/s2l_hip.h` and fails loudly
+when that library is missing.
+
+This is our own functional restatement (PyTorch-CPU ops, fp32 by default, fp64 on request)
+of the reference algorithm, written from the maths in SURVEY.md §3.3/§8a.  Each function
+cites the reference lines it follows.  Parity is PINNED: `tools/make_goldens.py` imports
+the reference itself (in the build container, where /root/reference exists), checks every
+function here against it, and commits the resulting vectors under `tests/golden/`;
+`tests/test_oracle_golden.py` re-checks this file against those vectors everywhere.
+
+State dicts are plain {name: tensor} with the reference's state-dict key names
+(`tf_nerf.py:91-172`).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+PAD_MODE_MAY = 0      # 'may' / 'macron' / 'obama_adnerf' / 'obama2_face_crop' paths (tf_nerf.py:345-348)
+PAD_MODE_DEFAULT = 1  # everything else (tf_nerf.py:349-350): paste origin one pixel up-left
+
+
+def to_sd(np_sd, dtype=torch.float32) -> SD:
+    return {k: torch.as_tensor(v).to(dtype) for k, v in np_sd.items()}
+
+
+# --------------------------------------------------------------------------- A1
+def get_coords(width: int, height: int, dtype=torch.float32) -> torch.Tensor:
+    """Row-major (u,v) pixel grid in [0,1], endpoints inclusive -> [H*W, 2].
+    Reference: src/face_simple/rendering.py:9-28 (linspace x, linspace y, meshgrid ij,
+    stack [u, v])."""
+    x = torch.linspace(0.0, 1.0, width, dtype=dtype)
+    y = torch.linspace(0.0, 1.0, height, dtype=dtype)
+    u = x.unsqueeze(0).expand(height, width)
+    v = y.unsqueeze(1).expand(height, width)
+    return torch.stack([u, v], dim=-1).reshape(-1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------- A2
+def embed_uv(uv: torch.Tensor, multires: int = 10) -> torch.Tensor:
+    """[N,d] -> [N, d + 2*L*d]: [x, sin(1x), cos(1x), sin(2x), cos(2x), ..., cos(2^(L-1) x)],
+    every block carrying all d channels.  Reference: tf_nerf.py:391-425 (Embedder,
+    include_input, log-sampled bands 2**linspace(0, L-1, L) which are exact powers of two)."""
+    blocks = [uv]
+    for k in range(multires):
+        f = float(2 ** k)
+        blocks.append(torch.sin(uv * f))
+        blocks.append(torch.cos(uv * f))
+    return torch.cat(blocks, dim=-1)
+
+
+# --------------------------------------------------------------------------- A3
+def time_div_term(out_dims: int = 20) -> torch.Tensor:
+    """fp32 constant of PositionalEncodingTime.__init__ (tf_nerf.py:431-432)."""
+    return torch.exp(torch.arange(0, out_dims, 2, dtype=torch.float32) * -(math.log(10000.0) / out_dims))
+
+
+def time_pe(index: int, out_dims: int = 20, dtype=torch.float32) -> torch.Tensor:
+    """1-D [out_dims] encoding of ONE frame index: pe[0::2]=sin(i*div), pe[1::2]=cos(i*div).
+    Reference: tf_nerf.py:434-442 (uses position[0] only, returns a vector that fc_time
+    broadcasts over all pixels)."""
+    div = time_div_term(out_dims).to(dtype)
+    pos = torch.tensor(float(int(index)), dtype=torch.float32).to(dtype)
+    pe = torch.zeros(out_dims, dtype=dtype)
+    pe[0::2] = torch.sin(pos * div)
+    pe[1::2] = torch.cos(pos * div)
+    return pe
+
+
+# --------------------------------------------------------------------------- A4
+def audio_encode(sd: SD, windows: torch.Tensor) -> torch.Tensor:
+    """DeepSpeech windows [B,16,29] -> audio feature [B,64].
+    Reference: tf_nerf.py:197-213 with layers :91-109 -- permute to [B,29,16], four
+    Conv1d(k3,s2,p1)+LeakyReLU(0.02) (T 16->8->4->2->1), squeeze, Linear+LeakyReLU+Linear."""
+    x = windows.permute(0, 2, 1)
+    for i in (0, 2, 4, 6):
+        x = F.conv1d(x, sd[f"encoder_conv.{i}.weight"], sd[f"encoder_conv.{i}.bias"], stride=2, padding=1)
+        x = F.leaky_relu(x, 0.02)
+    x = x.squeeze(-1)
+    x = F.leaky_relu(F.linear(x, sd["encoder_fc1.0.weight"], sd["encoder_fc1.0.bias"]), 0.02)
+    return F.linear(x, sd["encoder_fc1.2.weight"], sd["encoder_fc1.2.bias"])
+
+
+# --------------------------------------------------------------------------- A5
+def rgb_forward(sd: SD, uv_audio: torch.Tensor, time_index: int) -> torch.Tensor:
+    """As-written v2 MLP: rows [N, 2+64] (+ one frame index) -> [N,3], no output activation.
+    Reference: tf_nerf.py:225-285 under the May flags (audio_net, audio_not_embed, use_time):
+    net = fc_uv(E(uv)) + fc_audio(a) + fc_time(PE(t)); 8x relu(Linear); after layer 4
+    h = cat([skip, h]) with skip = fc_uv_skip + fc_audio_skip + fc_time_skip; output_linear."""
+    dt = uv_audio.dtype
+    e = embed_uv(uv_audio[:, :2])
+    a = uv_audio[:, 2:]
+    t = time_pe(time_index, 20, dt)
+    lin = lambda n, x: F.linear(x, sd[n + ".weight"], sd[n + ".bias"])
+    h = lin("fc_uv", e) + lin("fc_audio", a) + lin("fc_time", t)
+    for i in range(8):
+        h = F.relu(lin(f"pts_linears.{i}", h))
+        if i == 4:
+            skip = lin("fc_uv_skip", e) + lin("fc_audio_skip", a) + lin("fc_time_skip", t)
+            h = torch.cat([skip, h], dim=-1)
+    return lin("output_linear", h)
+
+
+# --------------------------------------------------------------------------- A6
+def render_frame_as_shipped(sd: SD, window: torch.Tensor, index: int, height: int, width: int) -> torch.Tensor:
+    """One lip frame exactly as the shipped driver computes it: the audio window is tiled
+    to H*W rows and the encoder runs on every copy.  Reference: inference.py:144-159.
+    window [16,29] -> [H,W,3]."""
+    hw = height * width
+    audio = window.unsqueeze(0).expand(hw, 16, 29).contiguous()
+    coords = get_coords(width, height, window.dtype)
+    feat = audio_encode(sd, audio)
+    out = rgb_forward(sd, torch.cat([coords, feat], dim=-1), index)
+    return out[:, :3].reshape(height, width, 3)
+
+
+def render_clip(sd: SD, windows: torch.Tensor, indices, height: int, width: int) -> torch.Tensor:
+    """Batched/factored CPU variant (encoder once per frame).  Same function of the inputs
+    as `render_frame_as_shipped`; used as the fair CPU baseline and the large-case oracle.
+    windows [F,16,29] -> [F,H,W,3]."""
+    coords = get_coords(width, height, windows.dtype)
+    feats = audio_encode(sd, windows)
+    frames = []
+    for f in range(windows.shape[0]):
+        row = torch.cat([coords, feats[f].unsqueeze(0).expand(coords.shape[0], -1)], dim=-1)
+        frames.append(rgb_forward(sd, row, int(indices[f])).reshape(height, width, 3))
+    return torch.stack(frames)
+
+
+# --------------------------------------------------------------------------- A7
+def _grid_sample_bilinear_zeros(img: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """Own restatement of bilinear grid sampling, zero padding, align_corners=False.
+    img [B,C,H,W], grid [B,Ho,Wo,2] (x,y in [-1,1]) -> [B,C,Ho,Wo].  Semantics of
+    F.grid_sample as called at tf_nerf.py:366-367."""
+    B, C, H, W = img.shape
+    x = ((grid[..., 0] + 1) * W - 1) / 2
+    y = ((grid[..., 1] + 1) * H - 1) / 2
+    x0 = torch.floor(x)
+    y0 = torch.floor(y)
+    x1 = x0 + 1
+    y1 = y0 + 1
+    w_nw = (x1 - x) * (y1 - y)
+    w_ne = (x - x0) * (y1 - y)
+    w_sw = (x1 - x) * (y - y0)
+    w_se = (x - x0) * (y - y0)
+    flat = img.reshape(B, C, H * W)
+
+    def tap(xi, yi, w):
+        ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+        idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long().reshape(B, 1, -1).expand(B, C, -1)
+        val = torch.gather(flat, 2, idx).reshape(B, C, *xi.shape[1:])
+        return val * (w * ok.to(w.dtype)).unsqueeze(1)
+
+    return tap(x0, y0, w_nw) + tap(x1, y0, w_ne) + tap(x0, y1, w_sw) + tap(x1, y1, w_se)
+
+
+def composite(lip: torch.Tensor, face_canon: torch.Tensor, rgb_gt: torch.Tensor, mask: torch.Tensor,
+              x0: int, y0: int, coord: torch.Tensor, pad_mode: int = PAD_MODE_MAY,
+              expand_lip_mask: bool = True, pad_div: int = 5,
+              use_builtin_grid_sample: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Paste + head-pose-warp composite up to (not including) the U-Net.
+    lip [B,h,w,3]; face_canon/rgb_gt/mask [B,FH,FW,3]; coord [B,FH,FW,2]
+    -> (rgb_merged_new [B,FH,FW,3], rgb_merged_canonical [B,FH,FW,3]).
+
+    Reference: tf_nerf.py:320-389 -- (1) zero-pad the lip into the face frame at
+    (x0,y0) [pad_mode may] or (x0-1,y0-1) [default] (:339-350); (2) lerp with the soft lip
+    mask (:352); (3) rectangular expanded mask rows [y0-p, y0+h+2p), cols [x0-p, x0+w+p),
+    p = w // pad_div (:354-364); (4) bilinear zero-padded grid_sample of image and mask,
+    mask binarised by !=0 (:366-369); (6) blend with the observed frame (:386)."""
+    B, h, w, _ = lip.shape
+    FH, FW = face_canon.shape[1:3]
+    ox, oy = (x0, y0) if pad_mode == PAD_MODE_MAY else (x0 - 1, y0 - 1)
+    lip_pad = torch.zeros_like(face_canon)
+    lip_pad[:, oy:oy + h, ox:ox + w, :] = lip
+    merged_c = mask * lip_pad + (1 - mask) * face_canon
+    if expand_lip_mask:
+        p = w // pad_div
+        m = torch.zeros_like(mask)
+        m[:, y0 - p:y0 + h + 2 * p, x0 - p:x0 + w + p, :] = 1
+    else:
+        m = mask.clone()
+    gs = (lambda im: F.grid_sample(im, coord, mode="bilinear", padding_mode="zeros", align_corners=False)) \
+        if use_builtin_grid_sample else (lambda im: _grid_sample_bilinear_zeros(im, coord))
+    warped = gs(merged_c.permute(0, 3, 1, 2))
+    mw = gs(m.permute(0, 3, 1, 2))
+    mw = (mw != 0).to(lip.dtype)
+    merged_new = mw * warped + (1 - mw) * rgb_gt.permute(0, 3, 1, 2)
+    return merged_new.permute(0, 2, 3, 1).contiguous(), merged_c
+
+
+# --------------------------------------------------------------------------- T1/T2
+def predict_lip_image(sd: SD, coords: torch.Tensor, window: torch.Tensor, index: int,
+                      height: int, width: int, eps_u01: float) -> torch.Tensor:
+    """4-tap local-ensemble forward of training (one frame) -> [HW,3].
+    Reference: src/face_simple/training.py:158-251.  `eps_u01` is the single U(0,1) draw
+    of :200 (the reference draws it with torch.rand; callers pass it in for determinism).
+    Taps at clamp(coords + (vx*0.5/W + eps, vy*0.5/H + eps), 0, 1); areas |du*dv|+1e-9,
+    swapped 0<->3, 1<->2; area-weighted sum."""
+    dt = coords.dtype
+    feat = audio_encode(sd, window.unsqueeze(0))[0]
+    rx, ry = 0.5 / width, 0.5 / height
+    eps = torch.tensor(ry, dtype=torch.float32) * torch.tensor(eps_u01, dtype=torch.float32) / 2.0
+    eps = eps.to(dt)
+    preds, areas = [], []
+    for vx in (-1, 1):
+        for vy in (-1, 1):
+            c = coords.clone()
+            c[:, 0] += vx * rx + eps
+            c[:, 1] += vy * ry + eps
+            c.clamp_(0, 1)
+            row = torch.cat([c, feat.unsqueeze(0).expand(c.shape[0], -1)], dim=-1)
+            preds.append(rgb_forward(sd, row, index))
+            areas.append(torch.abs((c[:, 0] - coords[:, 0]) * (c[:, 1] - coords[:, 1])) + 1e-9)
+    tot = torch.stack(areas).sum(dim=0)
+    areas[0], areas[3] = areas[3], areas[0]
+    areas[1], areas[2] = areas[2], areas[1]
+    ret = 0
+    for p, a in zip(preds, areas):
+        ret = ret + p * (a / tot).unsqueeze(-1)
+    return ret[:, :3]
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """Photometric loss mean((pred-target)^2)*w.  Reference: training.py:605-619."""
+    return ((pred - target) ** 2).mean() * weight
+
+
+# --------------------------------------------------------------------------- metrics
+def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+def rmse(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float(((a.double() - b.double()) ** 2).mean().sqrt())

@@ -1,0 +1,128 @@
+"""Deterministic synthetic weights ("G0" of SURVEY.md §8c) for the lip-render hot path.
+
+There is no network on the build or GPU boxes, so no real Speech2Lip checkpoint exists
+here.  Parity tests, goldens and the bench all use weights produced by this generator:
+a counter-based splitmix64 stream (pure integer arithmetic -> bit-identical on every
+host, independent of torch/numpy RNG versions) mapped to U(-b, b).
+
+The tensor names and shapes are the state-dict keys the reference model creates under the
+May flag set (`/root/reference/src/face_simple/models/tf_nerf.py:91-109` audio encoder,
+`:131-135` dead `coord_linears`, `:144` output layer, `:146-172` v2 MLP).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+# (name, shape) in the order the packer consumes them.  Linear weights are [out, in],
+# Conv1d weights are [out, in, k] exactly as torch stores them.
+HOT_PATH_TENSORS = [
+    ("encoder_conv.0.weight", (32, 29, 3)), ("encoder_conv.0.bias", (32,)),
+    ("encoder_conv.2.weight", (32, 32, 3)), ("encoder_conv.2.bias", (32,)),
+    ("encoder_conv.4.weight", (64, 32, 3)), ("encoder_conv.4.bias", (64,)),
+    ("encoder_conv.6.weight", (64, 64, 3)), ("encoder_conv.6.bias", (64,)),
+    ("encoder_fc1.0.weight", (64, 64)), ("encoder_fc1.0.bias", (64,)),
+    ("encoder_fc1.2.weight", (64, 64)), ("encoder_fc1.2.bias", (64,)),
+    ("fc_uv.weight", (256, 42)), ("fc_uv.bias", (256,)),
+    ("fc_audio.weight", (256, 64)), ("fc_audio.bias", (256,)),
+    ("fc_time.weight", (256, 20)), ("fc_time.bias", (256,)),
+    ("fc_uv_skip.weight", (256, 42)), ("fc_uv_skip.bias", (256,)),
+    ("fc_audio_skip.weight", (256, 64)), ("fc_audio_skip.bias", (256,)),
+    ("fc_time_skip.weight", (256, 20)), ("fc_time_skip.bias", (256,)),
+    ("pts_linears.0.weight", (256, 256)), ("pts_linears.0.bias", (256,)),
+    ("pts_linears.1.weight", (256, 256)), ("pts_linears.1.bias", (256,)),
+    ("pts_linears.2.weight", (256, 256)), ("pts_linears.2.bias", (256,)),
+    ("pts_linears.3.weight", (256, 256)), ("pts_linears.3.bias", (256,)),
+    ("pts_linears.4.weight", (256, 256)), ("pts_linears.4.bias", (256,)),
+    ("pts_linears.5.weight", (256, 512)), ("pts_linears.5.bias", (256,)),
+    ("pts_linears.6.weight", (256, 256)), ("pts_linears.6.bias", (256,)),
+    ("pts_linears.7.weight", (256, 256)), ("pts_linears.7.bias", (256,)),
+    ("output_linear.weight", (3, 256)), ("output_linear.bias", (3,)),
+]
+
+# Present in reference checkpoints, never read by any forward (tf_nerf.py:131-135).
+DEAD_TENSORS = [
+    ("coord_linears.0.weight", (256, 2)), ("coord_linears.0.bias", (256,)),
+    ("coord_linears.1.weight", (256, 256)), ("coord_linears.1.bias", (256,)),
+    ("coord_linears.2.weight", (256, 256)), ("coord_linears.2.bias", (256,)),
+    ("coord_linears.3.weight", (256, 256)), ("coord_linears.3.bias", (256,)),
+    ("coord_linears.4.weight", (64, 256)), ("coord_linears.4.bias", (64,)),
+]
+
+HOT_PATH_PARAM_COUNT = sum(int(np.prod(s)) for _, s in HOT_PATH_TENSORS)  # 691,491
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(counter: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser over a uint64 counter array."""
+    with np.errstate(over="ignore"):
+        z = (counter + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(n: int, stream: int) -> np.ndarray:
+    """n float64 values in [0,1) from stream `stream` (53 mantissa bits each)."""
+    with np.errstate(over="ignore"):
+        base = splitmix64(np.array([stream], dtype=np.uint64))[0]
+        ctr = base + np.arange(n, dtype=np.uint64)
+    return (splitmix64(ctr) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def _stream_id(name: str, seed: int) -> int:
+    return ((zlib.crc32(name.encode()) & 0xFFFFFFFF) << 20) ^ (seed & 0xFFFFF)
+
+
+def make_state_dict(seed: int = 0, gain: str = "he", include_dead: bool = False) -> "OrderedDict[str, np.ndarray]":
+    """Seeded fp32 weights for every hot-path tensor.
+
+    gain="he":     weights U(+-sqrt(6/fan_in)) -- keeps hidden activations O(1) through the 8
+                   ReLU layers; `output_linear.weight` is scaled by a further 1/8 so the RGB
+                   output has RMS ~0.5 like a trained model, which makes the absolute 1e-4
+                   RMSE / 50 dB PSNR bars meaningful (with "torch" gain the output RMS is
+                   0.03 and any kernel passes an absolute bar).
+    gain="torch":  weights U(+-1/sqrt(fan_in)), torch.nn.Linear's default scale.
+    Biases are U(+-1/sqrt(fan_in)) in both modes.
+    """
+    if gain not in ("he", "torch"):
+        raise ValueError(f"unknown gain {gain!r}")
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    fan_in = {}
+    specs = HOT_PATH_TENSORS + (DEAD_TENSORS if include_dead else [])
+    for name, shape in specs:
+        if name.endswith(".weight"):
+            fan_in[name[: -len(".weight")]] = int(np.prod(shape[1:]))
+    for name, shape in specs:
+        layer = name.rsplit(".", 1)[0]
+        fi = fan_in[layer]
+        if name.endswith(".weight"):
+            bound = np.sqrt(6.0 / fi) if gain == "he" else 1.0 / np.sqrt(fi)
+            if gain == "he" and layer == "output_linear":
+                bound /= 8.0
+        else:
+            bound = 1.0 / np.sqrt(fi)
+        u = uniform01(int(np.prod(shape)), _stream_id(name, seed))
+        out[name] = ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shape)
+    return out
+
+
+def synthetic_audio(n_frames: int, seed: int = 1) -> np.ndarray:
+    """Surrogate `audio.npy`: float64 [N,16,29] log-softmax of seeded normals, with the
+    clip-end zero padding of the DeepSpeech windowing
+    (`/root/reference/preprocess/deepspeech_features/deepspeech_features.py:65-75`:
+    8 zero feature rows each side, 16-row windows at stride 2).  SURVEY.md §8d.
+    """
+    n_feat = 2 * n_frames
+    u1 = uniform01(n_feat * 29, _stream_id("audio.u1", seed))
+    u2 = uniform01(n_feat * 29, _stream_id("audio.u2", seed))
+    z = np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)  # Box-Muller
+    z = z.reshape(n_feat, 29)
+    logits = z - z.max(axis=1, keepdims=True)
+    logp = logits - np.log(np.exp(logits).sum(axis=1, keepdims=True))
+    padded = np.concatenate([np.zeros((8, 29)), logp, np.zeros((8, 29))], axis=0)
+    idx = (2 * np.arange(n_frames))[:, None] + np.arange(16)[None, :]
+    return padded[idx]  # [N,16,29] float64

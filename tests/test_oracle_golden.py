@@ -1,0 +1,118 @@
+"""CPU: the oracle (oracle/s2l_oracle.py) against the golden vectors that
+tools/make_goldens.py captured from the reference itself."""
+import numpy as np
+import torch
+
+from oracle import s2l_oracle as O
+from speech2lip_amd import weights as W
+
+T = torch.from_numpy
+
+
+def _sd():
+    return O.to_sd(W.make_state_dict(seed=0, gain="he"))
+
+
+def _maxerr(a, b):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+def test_g0_weight_generator_is_reproducible(golden):
+    sums = golden("g0_weight_checksums.npz")
+    sd = W.make_state_dict(seed=0, gain="he")
+    assert set(sums) == set(sd)
+    for k, v in sd.items():
+        assert abs(float(np.abs(v).astype(np.float64).sum()) - float(sums[k])) == 0.0, k
+    assert W.HOT_PATH_PARAM_COUNT == 691_491
+    assert not np.array_equal(W.make_state_dict(1)["fc_uv.weight"], sd["fc_uv.weight"])
+
+
+def test_g1_coords_embed_time(golden):
+    g = golden("g1_embed.npz")
+    for key in g:
+        if key.startswith("coords_"):
+            w, h = map(int, key[len("coords_"):].split("x"))
+            assert np.array_equal(O.get_coords(w, h).numpy(), g[key]), key
+    assert _maxerr(O.embed_uv(T(g["uv"])), g["embed"]) <= 1e-6
+    assert O.embed_uv(T(g["uv"])).shape == (64, 42)
+    for k, i in enumerate(g["time_idx"]):
+        assert _maxerr(O.time_pe(int(i)), g["time_pe"][k]) <= 1e-6
+    assert np.array_equal(O.time_div_term(20).numpy(), g["div_term"])
+
+
+def test_g2_audio_encoder(golden):
+    g = golden("g2_audio.npz")
+    with torch.no_grad():
+        out = O.audio_encode(_sd(), T(g["windows"]))
+    assert out.shape == (8, 64)
+    assert _maxerr(out, g["feat"]) <= 1e-5
+
+
+def test_g3_rgb_forward_frames_and_rows(golden):
+    g = golden("g3_rgb.npz")
+    sd = _sd()
+    with torch.no_grad():
+        for h, w, idx in [(16, 16, 7), (64, 64, 7), (12, 20, 597)]:
+            ref = g[f"frame_{h}x{w}_idx{idx}"]
+            got = O.render_frame_as_shipped(sd, T(g["window"]), idx, h, w).reshape(-1, 3)
+            assert _maxerr(got, ref) <= 1e-5, (h, w)
+            fact = O.render_clip(sd, T(g["window"])[None], [idx], h, w).reshape(-1, 3)
+            assert O.rmse(fact, T(ref)) <= 5e-6 and O.psnr(fact, T(ref)) >= 90.0
+        feat = O.audio_encode(sd, T(g["window5"])[None])
+        for h, w in [(96, 96), (128, 128)]:
+            coords = O.get_coords(w, h)[T(g[f"rows_{h}x{w}_sel"])]
+            rows = torch.cat([coords, feat.expand(512, -1)], -1)
+            assert _maxerr(O.rgb_forward(sd, rows, 41), g[f"rows_{h}x{w}_out"]) <= 1e-5
+        assert _maxerr(O.rgb_forward(sd, T(g["gen_rows"]), 12345), g["gen_out"]) <= 1e-5
+
+
+def test_g3_fp64_truth_is_close():
+    """The fp32 reference path sits ~1e-6 RMSE from an fp64 evaluation: that is the noise
+    floor any correct fp32 implementation (ours included) is expected to share."""
+    sd64 = O.to_sd(W.make_state_dict(0, "he"), torch.float64)
+    sd32 = _sd()
+    win = T(W.synthetic_audio(2, 1))
+    with torch.no_grad():
+        a = O.render_clip(sd32, win.float(), [0, 1], 16, 16)
+        b = O.render_clip(sd64, win, [0, 1], 16, 16)
+    assert O.rmse(a, b) <= 5e-6
+    assert 0.2 <= float(b.pow(2).mean().sqrt()) <= 2.0  # output RMS is O(0.5)
+
+
+def test_g4_composite_both_pad_modes(golden):
+    g = golden("g4_composite.npz")
+    args = [T(g[k]) for k in ("lip", "face", "gt", "mask")]
+    for mode in (O.PAD_MODE_MAY, O.PAD_MODE_DEFAULT):
+        for builtin in (True, False):
+            new, can = O.composite(*args, int(g["x0"]), int(g["y0"]), T(g["coord"]), pad_mode=mode,
+                                   use_builtin_grid_sample=builtin)
+            assert _maxerr(new, g[f"merged_new_mode{mode}"]) <= 1e-6
+            assert _maxerr(can, g[f"merged_canonical_mode{mode}"]) <= 1e-6
+    assert not np.array_equal(g["merged_new_mode0"], g["merged_new_mode1"])
+
+
+def test_g5_ensemble_and_loss(golden):
+    g = golden("g5_ensemble.npz")
+    with torch.no_grad():
+        pred = O.predict_lip_image(_sd(), O.get_coords(16, 16), T(g["window"]), int(g["idx"]), 16, 16,
+                                   float(g["eps_u01"]))
+        assert _maxerr(pred, g["pred"]) <= 1e-5
+        assert abs(float(O.mse_loss(pred, T(g["target"]))) - float(g["loss"])) <= 1e-6
+
+
+def test_g5_gradients_by_autograd_through_the_oracle(golden):
+    g = golden("g5_ensemble.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd().items()}
+    pred = O.predict_lip_image(sd, O.get_coords(16, 16), T(g["window"]), int(g["idx"]), 16, 16, float(g["eps_u01"]))
+    O.mse_loss(pred, T(g["target"])).backward()
+    assert _maxerr(sd["output_linear.weight"].grad, g["g_output_w"]) <= 1e-5
+    assert _maxerr(sd["pts_linears.5.weight"].grad[:, :8], g["g_pts5_w_cols8"]) <= 1e-5
+    assert _maxerr(sd["pts_linears.7.bias"].grad, g["g_pts7_b"]) <= 1e-5
+    assert _maxerr(sd["fc_time.bias"].grad, g["g_fc_time_b"]) <= 1e-5
+
+
+def test_synthetic_audio_shape_and_padding():
+    a = W.synthetic_audio(16, seed=1)
+    assert a.shape == (16, 16, 29) and a.dtype == np.float64
+    assert np.all(a[0, :8] == 0) and np.all(a[-1, -6:] == 0) and np.all(a[8] != 0)
+    assert np.allclose(np.exp(a[8]).sum(-1), 1.0)
