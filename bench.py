@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered lip frames/s on MI355X (BASELINE.json metric), one rank per GPU.
+
+A "step" renders one clip of FRAMES synthetic audio windows at 96x96 (BASELINE config 2:
+8-layer x 256 MLP, 1000 frames) from inputs already resident in HBM: audio encoder ->
+per-frame vectors -> fused MLP render -> [FRAMES,96,96,3] fp32 in HBM.  With N > 1 every rank
+renders its own FRAMES (weak scaling) and the clip is reassembled on every rank with chunked
+all-gathers (RCCL) overlapped with rendering.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the fused
+MLP kernel (MFMA-bound, fp32 MFMA peak 157.3 TFLOP/s; algorithmic FLOPs per SURVEY.md §8d) and
+`cpu_baseline` (the oracle -- our PyTorch-CPU port of the reference path -- on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W_ = 96
+HW = H * W_
+FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
+FP32_MFMA_PEAK = 157.3e12
+
+
+def cpu_baseline(frames_budget_s: float = 15.0):
+    """Oracle (kind 'port'): the as-shipped per-frame path (encoder on H*W tiled copies +
+    unfactored MLP, inference.py:144-159) on the host cores, bounded sample."""
+    from oracle import s2l_oracle as O
+    from speech2lip_amd import weights as W
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.to_sd(W.make_state_dict(0, "he"))
+    win = torch.from_numpy(W.synthetic_audio(8, seed=1).astype(np.float32))
+    with torch.no_grad():
+        for i in range(2):
+            O.render_frame_as_shipped(sd, win[i], i, H, W_)
+        n, t0 = 0, time.perf_counter()
+        while n < 60 and (time.perf_counter() - t0) < frames_budget_s:
+            O.render_frame_as_shipped(sd, win[n % 8], n, H, W_)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames 96x96, as-shipped per-frame path (oracle.render_frame_as_shipped), fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
+    ap.add_argument("--chunks", type=int, default=4, help="all-gather chunks per step (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import speech2lip_amd as s2l
+    from speech2lip_amd import sharded, weights as W
+
+    F = args.frames
+    model = s2l.TalkingFace(dev, s2l.may_config(H, W_), mode="eval").eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
+    gids = sharded.global_frame_ids(F, rank, world, args.chunks).to(dev)
+    audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
+    clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    kernel_events = []
+
+    def render(off, cnt, out):
+        model.render_clip(audio[off:off + cnt], gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
+
+    def step():
+        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=args.chunks if world > 1 else 1, clip=clip)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, local = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant-kernel time from HIP events recorded on the launch stream around s2l_render_lip
+    torch.cuda.synchronize()
+    k_ms = [s.elapsed_time(e) for s, e in kernel_events]
+    frames_per_launch = F / (args.chunks if world > 1 else 1)
+    k_avg_s = (sum(k_ms) / len(k_ms)) * 1e-3
+    achieved = FLOPS_PER_FRAME * frames_per_launch / k_avg_s
+
+    if rank == 0:
+        # parity spot-check outside the timed region: frame 0 against the CPU oracle
+        from oracle import s2l_oracle as O
+        with torch.no_grad():
+            ref = O.render_clip(O.to_sd(W.make_state_dict(0, "he")), audio[:1].cpu(), [int(gids[0])], H, W_)[0]
+        got = local[0].cpu()
+        line = {
+            "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step",
+                       "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
+                       (f" + {args.chunks}-chunk all-gather" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": None,
+                         "kernel": "s2l::mlp_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
+                         "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
+            "parity": {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/*
+ * s2l_hip.h -- C-ABI of libs2l_hip.so: the MI355X (gfx950) lip-render hot path of Speech2Lip.
+ *
+ * The reference (CVMI-Lab/Speech2Lip) has no FFI layer: its boundary for this path is the Python
+ * nn.Module surface of `TalkingFace` (src/face_simple/models/tf_nerf.py).  Each entry point below
+ * replaces the ATen op sequence behind one reference method; `speech2lip_amd/talking_face.py`
+ * binds them with ctypes (INTEGRATION.md shows the stub) and re-provides the module surface.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative S2L_E_* for argument errors, a positive hipError_t otherwise;
+ *   - every pointer is DEVICE memory unless the name ends in `_host`; all tensors are dense fp32,
+ *     row-major, 16-byte aligned; the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); calls are
+ *     asynchronous on that stream and re-entrant across streams.
+ */
+#ifndef S2L_HIP_H
+#define S2L_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* s2l_stream_t;
+
+enum {
+  S2L_OK = 0,
+  S2L_E_NULL = -1,     /* a required pointer is NULL            */
+  S2L_E_SIZE = -2,     /* a size / count argument is invalid    */
+  S2L_E_ALIGN = -3,    /* a pointer is not 16-byte aligned      */
+  S2L_E_GEOMETRY = -4  /* composite: lip box / mask rectangle leaves the face frame */
+};
+
+/* Index of each state-dict tensor in the pointer table handed to s2l_pack_weights.  Names are
+ * the reference's state-dict keys (tf_nerf.py:91-109, :144, :149-172); torch layouts
+ * ([out,in] for Linear, [out,in,k] for Conv1d). */
+enum {
+  S2L_T_CONV0_W = 0, S2L_T_CONV0_B, S2L_T_CONV2_W, S2L_T_CONV2_B, S2L_T_CONV4_W, S2L_T_CONV4_B,
+  S2L_T_CONV6_W, S2L_T_CONV6_B, S2L_T_FC1_0_W, S2L_T_FC1_0_B, S2L_T_FC1_2_W, S2L_T_FC1_2_B,
+  S2L_T_FC_UV_W, S2L_T_FC_UV_B, S2L_T_FC_AUDIO_W, S2L_T_FC_AUDIO_B, S2L_T_FC_TIME_W, S2L_T_FC_TIME_B,
+  S2L_T_FC_UV_SKIP_W, S2L_T_FC_UV_SKIP_B, S2L_T_FC_AUDIO_SKIP_W, S2L_T_FC_AUDIO_SKIP_B,
+  S2L_T_FC_TIME_SKIP_W, S2L_T_FC_TIME_SKIP_B,
+  S2L_T_PTS0_W, S2L_T_PTS0_B, S2L_T_PTS1_W, S2L_T_PTS1_B, S2L_T_PTS2_W, S2L_T_PTS2_B,
+  S2L_T_PTS3_W, S2L_T_PTS3_B, S2L_T_PTS4_W, S2L_T_PTS4_B, S2L_T_PTS5_W, S2L_T_PTS5_B,
+  S2L_T_PTS6_W, S2L_T_PTS6_B, S2L_T_PTS7_W, S2L_T_PTS7_B, S2L_T_OUT_W, S2L_T_OUT_B,
+  S2L_NUM_TENSORS
+};
+
+/* Pad modes of the paste step (tf_nerf.py:345-350 keys them off substrings of cfg.data.path). */
+enum { S2L_PAD_MAY = 0, S2L_PAD_DEFAULT = 1 };
+
+/* Library / build identification: "s2l_hip <version> gfx950". */
+const char* s2l_version(void);
+
+/* Number of floats in the packed weight blob. */
+int64_t s2l_packed_floats(void);
+
+/* Pack the 42 hot-path state-dict tensors into the device blob the kernels read (MFMA operand
+ * order for the 256x256 layers, transposed copies for the small per-frame/per-pixel products,
+ * folded first-layer/skip matrices for s2l_rgb_forward).  Re-run after any weight update.
+ *   tensors_host : HOST array of S2L_NUM_TENSORS DEVICE pointers, indexed by S2L_T_*
+ *   div_term_host: HOST array of 10 floats, PositionalEncodingTime.div_term (tf_nerf.py:431-432)
+ *   packed       : device, s2l_packed_floats() floats
+ * Replaces: nothing in the reference (it keeps nn.Parameters); this is load-time layout work. */
+int s2l_pack_weights(const float* const* tensors_host, const float* div_term_host, float* packed,
+                     s2l_stream_t stream);
+
+/* Audio encoder.  windows [B,16,29] -> feat [B,64].
+ * Replaces TalkingFace.audio_merge_forward (tf_nerf.py:197-213; layers :91-109). */
+int s2l_audio_encode(const float* packed, const float* windows, float* feat, int64_t n_windows,
+                     s2l_stream_t stream);
+
+/* Per-frame (pixel-invariant) halves of the first and skip layers for the batched renderer:
+ *   q0[f] = W0 (Wa a_f + Wt PE(idx_f) + b_uv + b_a + b_t) + b0
+ *   q5[f] = W5[:, :256] (Wa' a_f + Wt' PE(idx_f) + b_uv' + b_a' + b_t') + b5
+ * feat [F,64], frame_idx [F] int64 -> q0, q5 [F,256].
+ * Replaces the frame-only terms of rgb_forward (tf_nerf.py:247, :252-258, :269-281) including
+ * PositionalEncodingTime.__call__ (:434-442).  SURVEY.md §3.3. */
+int s2l_frame_vectors(const float* packed, const float* feat, const int64_t* frame_idx, float* q0,
+                      float* q5, int64_t n_frames, s2l_stream_t stream);
+
+/* Per-pixel (frame-invariant) halves:  p0[p] = W0 Wuv E(uv_p),  p5[p] = W5[:, :256] Wuv' E(uv_p).
+ * coords [HW,2] (u,v) -> p0, p5 [HW,256].  Replaces Embedder.__call__ (tf_nerf.py:404-425) and
+ * the fc_uv / fc_uv_skip terms (:252, :269) for a fixed pixel grid (rendering.py:9-28). */
+int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float* p5, int64_t hw,
+                     s2l_stream_t stream);
+
+/* Fused render of a clip: for every frame f and pixel p
+ *   h0 = relu(p0[p] + q0[f]); h1..h4 = relu(W h + b); h5 = relu(p5[p] + q5[f] + W5[:,256:] h4);
+ *   h6, h7; rgb = Wout h7 + bout          (no output activation, tf_nerf.py:283)
+ * out [F,HW,3].  Activations never leave registers; fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
+int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
+                   const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
+
+/* Exact drop-in for TalkingFace.rgb_forward on arbitrary rows (tf_nerf.py:225-285, May flags):
+ * uv_audio [N,66] = (u, v, 64 audio features) per row, one frame index for the call -> out [N,3].
+ * xbuf is caller-provided scratch of N*128 floats (embedded rows).  Used by the training-time
+ * 4-tap ensemble (training.py:158-251) where coordinates move every step. */
+int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf,
+                    float* out, int64_t n_rows, s2l_stream_t stream);
+
+/* Paste + head-pose warp composite, up to but not including the U-Net
+ * (TalkingFace.post_fusion2_onlylip_light, tf_nerf.py:320-386):
+ *   merged_c = mask * pad(lip) + (1-mask) * face_canon                        (:339-352)
+ *   M        = expanded rectangle rows [y0-p, y0+h+2p) x cols [x0-p, x0+w+p) (:354-364), or `mask`
+ *              itself when expand_pad < 0
+ *   out      = (gs(M) != 0) ? gs(merged_c) : rgb_gt     gs = bilinear, zeros, align_corners=False
+ * lip [F,h,w,3]; face_canon, mask [FH,FW,3] when *_stride == 0 (per-clip constants) or
+ * [F,FH,FW,3] when stride == FH*FW*3; rgb_gt [F,FH,FW,3]; coord [F,FH,FW,2];
+ * out_new [F,FH,FW,3]; out_canonical [F,FH,FW,3] or NULL (rgb_merged_canonical, :352).
+ * expand_pad = p (lip_w/5, or lip_w/12 for obama2, :357-360); pad_mode S2L_PAD_*. */
+int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
+                  int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
+                  float* out_canonical, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
+                  int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2L_HIP_H */

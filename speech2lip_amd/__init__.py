@@ -1,0 +1,6 @@
+"""speech2lip_amd -- MI355X-native lip-render hot path of Speech2Lip."""
+from .config import load_config, may_config
+from .rendering import get_coords
+from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
+
+__all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config"]

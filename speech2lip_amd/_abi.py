@@ -1,0 +1,75 @@
+"""ctypes binding of libs2l_hip.so (the C-ABI declared in include/s2l_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+from .build import LIB
+
+S2L_NUM_TENSORS = 42
+S2L_PAD_MAY, S2L_PAD_DEFAULT = 0, 1
+
+# order of the pointer table of s2l_pack_weights == enum S2L_T_* in include/s2l_hip.h
+TENSOR_ORDER = [
+    "encoder_conv.0.weight", "encoder_conv.0.bias", "encoder_conv.2.weight", "encoder_conv.2.bias",
+    "encoder_conv.4.weight", "encoder_conv.4.bias", "encoder_conv.6.weight", "encoder_conv.6.bias",
+    "encoder_fc1.0.weight", "encoder_fc1.0.bias", "encoder_fc1.2.weight", "encoder_fc1.2.bias",
+    "fc_uv.weight", "fc_uv.bias", "fc_audio.weight", "fc_audio.bias", "fc_time.weight", "fc_time.bias",
+    "fc_uv_skip.weight", "fc_uv_skip.bias", "fc_audio_skip.weight", "fc_audio_skip.bias",
+    "fc_time_skip.weight", "fc_time_skip.bias",
+    "pts_linears.0.weight", "pts_linears.0.bias", "pts_linears.1.weight", "pts_linears.1.bias",
+    "pts_linears.2.weight", "pts_linears.2.bias", "pts_linears.3.weight", "pts_linears.3.bias",
+    "pts_linears.4.weight", "pts_linears.4.bias", "pts_linears.5.weight", "pts_linears.5.bias",
+    "pts_linears.6.weight", "pts_linears.6.bias", "pts_linears.7.weight", "pts_linears.7.bias",
+    "output_linear.weight", "output_linear.bias",
+]
+assert len(TENSOR_ORDER) == S2L_NUM_TENSORS
+
+_ERRORS = {-1: "S2L_E_NULL (null pointer)", -2: "S2L_E_SIZE (bad size)", -3: "S2L_E_ALIGN (pointer not 16-byte aligned)",
+           -4: "S2L_E_GEOMETRY (lip box / mask rectangle leaves the face frame)"}
+
+EXPORTS = {
+    "s2l_version": (c_char_p, []),
+    "s2l_packed_floats": (c_int64, []),
+    "s2l_pack_weights": (c_int, [POINTER(c_void_p), POINTER(c_float), c_void_p, c_void_p]),
+    "s2l_audio_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_frame_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_pixel_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_render_lip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_rgb_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_composite": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class S2LError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libs2l_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise S2LError(f"{LIB} not found: build it with `python -m speech2lip_amd.build` "
+                           "(there is no CPU fallback for the lip-render path)")
+        lib = ctypes.CDLL(LIB)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise S2LError(f"{what}: {_ERRORS.get(rc, rc)}")
+    raise S2LError(f"{what}: hipError_t {rc}")

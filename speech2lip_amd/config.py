@@ -1,0 +1,70 @@
+"""Config surface of the hot path (reference: src/config.py:14-63 and the YAML keys read by
+inference.py:78-93 / tf_nerf.py:26-66).  `load_config` understands the reference's YAML files
+(single-parent `inherit_from`, recursive merge) so an existing `may.yaml` can be used as-is;
+`may_config` builds the same dictionary without any file."""
+from __future__ import annotations
+
+import copy
+import os
+
+import yaml
+
+
+def merge_into(base: dict, override: dict) -> dict:
+    """Recursive dict merge; scalars and lists in `override` replace those in `base`."""
+    for key, val in override.items():
+        if isinstance(val, dict):
+            node = base.get(key)
+            if not isinstance(node, dict):
+                node = base[key] = {}
+            merge_into(node, val)
+        else:
+            base[key] = val
+    return base
+
+
+def load_config(path, default_path=None, abs_path=None):
+    """Load `path`; its `inherit_from` parent (or `default_path` when it has none) is loaded
+    first and overridden.  `abs_path` prefixes every relative path, as in the reference."""
+    def full(p):
+        return os.path.join(abs_path, p) if (abs_path is not None and p is not None) else p
+
+    with open(full(path), "r") as fh:
+        special = yaml.safe_load(fh) or {}
+    parent = special.get("inherit_from")
+    if parent is not None:
+        cfg = load_config(parent, default_path, abs_path)
+    elif default_path is not None:
+        with open(full(default_path), "r") as fh:
+            cfg = yaml.safe_load(fh) or {}
+    else:
+        cfg = {}
+    return merge_into(cfg, special)
+
+
+_MAY = {
+    "method": "face_simple",
+    "data": {"dataset": "lip_someone", "path": "dataset/may_face_crop_lip", "extension": ".jpg",
+             "width": 96, "height": 96, "face_img_focal": 1200},
+    "model": {
+        "audio_embed": 6, "uv_embed": 10, "audio_net": True, "use_uv_audio_sep": True, "audio_not_embed": True,
+        "use_attention": False, "use_audio": True, "use_audio_mel": False, "use_head_pose": False,
+        "use_head_pose_net": False, "head_pose_multires": 10, "MLP_version": "v2", "use_time": True,
+        "use_lms": False, "use_text": False, "use_coords2audio": False, "use_delta_uv": False,
+        "use_post_fusion": True, "use_post_fusion_wface": False, "use_post_fusion_blackaug": True,
+        "use_light_unet": True, "use_resnet": False, "post_fusion_channel": 3, "expand_lip_mask": True,
+        "use_canonical_depth": False, "canonical_depth_height": 500, "canonical_depth_width": 500,
+    },
+    "training": {"out_dir": "log/face_simple/may", "batch_rays": 96 * 96, "n_sample_points": 16,
+                 "use_coords_mapping": False, "fusion_lip_only": True, "use_local_ensemble": True,
+                 "multi_gpu": True, "add_noise_audio": False, "add_noise_uv": False},
+}
+
+
+def may_config(height: int = 96, width: int = 96, data_path: str = "dataset/may_face_crop_lip") -> dict:
+    """The May flag set (configs/face_simple_configs/may/may.yaml over its defaults) restricted
+    to the keys the hot path reads, for a `height` x `width` lip crop."""
+    cfg = copy.deepcopy(_MAY)
+    cfg["data"].update(height=int(height), width=int(width), path=data_path)
+    cfg["training"]["batch_rays"] = int(height) * int(width)
+    return cfg

@@ -1,0 +1,76 @@
+"""Frame-sharded clip rendering across the GPUs of one node.
+
+Every frame is a pure function of (weights, audio window, frame index): ranks render disjoint
+frames with NO data-path dependency, and the only collective is the all-gather that reassembles
+the clip on every rank (RCCL over xGMI when the backend is "nccl").  The clip is cut into
+`n_chunks` chunks; inside a chunk rank r owns the contiguous block
+    [chunk_start + r*per, chunk_start + (r+1)*per),
+so each chunk's `all_gather_into_tensor` lands directly in global frame order, and chunk c's
+gather (issued asynchronously, on the process group's own stream) overlaps chunk c+1's render.
+Because frames are independent the assembled clip is bit-identical to a 1-GPU render.
+
+The reference has no inference sharding (inference.py is single-process); this is the build's
+multi-GPU counterpart of its per-frame loop (inference.py:140).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def chunk_plan(frames_per_rank: int, world: int, n_chunks: int) -> List[Tuple[int, int]]:
+    """[(local_offset, count)] per chunk: `frames_per_rank` split into <= n_chunks nearly equal
+    chunks (earlier chunks get the remainder).  Identical on every rank."""
+    if frames_per_rank < 0 or world < 1 or n_chunks < 1:
+        raise ValueError("bad shard plan arguments")
+    n_chunks = max(1, min(n_chunks, frames_per_rank)) if frames_per_rank else 1
+    base, rem = divmod(frames_per_rank, n_chunks)
+    plan, off = [], 0
+    for c in range(n_chunks):
+        cnt = base + (1 if c < rem else 0)
+        plan.append((off, cnt))
+        off += cnt
+    return plan
+
+
+def global_frame_ids(frames_per_rank: int, rank: int, world: int, n_chunks: int) -> torch.Tensor:
+    """Global frame index of each of this rank's local frames, in local order."""
+    ids = []
+    start = 0
+    for off, cnt in chunk_plan(frames_per_rank, world, n_chunks):
+        ids.append(torch.arange(start + rank * cnt, start + (rank + 1) * cnt, dtype=torch.int64))
+        start += cnt * world
+    return torch.cat(ids) if ids else torch.zeros(0, dtype=torch.int64)
+
+
+def render_sharded(render_fn: Callable[[int, int, torch.Tensor], None], frames_per_rank: int, frame_shape,
+                   device, n_chunks: int = 4, group=None, clip: torch.Tensor = None, gather: bool = True):
+    """Render this rank's frames chunk by chunk and all-gather each chunk into `clip`.
+
+    render_fn(local_offset, count, out) renders local frames [local_offset, local_offset+count)
+    into `out` ([count, *frame_shape], a view of the local buffer).
+    Returns (clip [world*frames_per_rank, *frame_shape] in global frame order, local buffer).
+    With world == 1 (or gather=False) no collective is issued and clip aliases the local buffer.
+    """
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    local = torch.empty((frames_per_rank, *frame_shape), dtype=torch.float32, device=device)
+    plan = chunk_plan(frames_per_rank, world, n_chunks)
+    if world == 1 or not gather:
+        for off, cnt in plan:
+            if cnt:
+                render_fn(off, cnt, local[off:off + cnt])
+        return local, local
+    if clip is None:
+        clip = torch.empty((frames_per_rank * world, *frame_shape), dtype=torch.float32, device=device)
+    works, start = [], 0
+    for off, cnt in plan:
+        if cnt:
+            render_fn(off, cnt, local[off:off + cnt])
+            works.append(dist.all_gather_into_tensor(clip[start:start + cnt * world], local[off:off + cnt],
+                                                     group=group, async_op=True))
+        start += cnt * world
+    for w in works:
+        w.wait()
+    return clip, local

@@ -1,0 +1,322 @@
+"""`TalkingFace` -- drop-in for the reference module on the lip-render hot path.
+
+Mirrors `src/face_simple/models/tf_nerf.py` of CVMI-Lab/Speech2Lip for the May flag set
+(v2 MLP, audio_net, audio_not_embed, use_time; no head pose / landmarks / text):
+
+  * same constructor signature (tf_nerf.py:13-18), same attributes read by callers
+    (`audio_dims`, `data_path`, ...), same state-dict keys (`encoder_conv.N.*`,
+    `encoder_fc1.N.*`, `fc_*`, `pts_linears.N.*`, `output_linear.*`, and the dead
+    `coord_linears.*`), so reference checkpoints load with `load_state_dict(strict=False)`;
+  * same method signatures and return shapes: `audio_merge_forward` (:197), `rgb_forward`
+    (:225-228), `post_fusion2_onlylip` (:287-304);
+  * every method runs hand-written HIP kernels through the C-ABI of libs2l_hip.so.  There is
+    no eager/CPU path: a missing library or a non-GPU tensor raises.
+
+Beyond the reference surface, `render_clip` is the batched driver that replaces the per-frame
+loop of inference.py:140-159 (audio encoder once per frame, one fused launch per clip).
+
+Not in this path: the post-fusion U-Net (`post_fusion_unet`), the canonical
+depth head, training autograd.  `post_fusion2_onlylip` returns `None` for the U-Net output.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+
+_UNSUPPORTED_TRUE = ("use_attention", "use_audio_mel", "use_head_pose", "use_head_pose_net", "use_lms", "use_text")
+
+
+class Embedder:
+    """Sin/cos positional encoding descriptor (tf_nerf.py:391-425).  Only the metadata lives
+    here; the encoding itself is evaluated inside the HIP kernels."""
+
+    def __init__(self, multires, input_dims=29, include_input=True, log_sampling=True):
+        self.multires = multires
+        self.input_dims = input_dims
+        self.include_input = include_input
+        self.log_sampling = log_sampling
+        self.max_freq_log2 = multires - 1
+        self.num_freqs = multires
+        self.out_dims = (input_dims if include_input else 0) + 2 * multires * input_dims
+
+
+class PositionalEncodingTime:
+    """Frame-index encoding descriptor (tf_nerf.py:427-442); holds the fp32 `div_term`."""
+
+    def __init__(self, device, out_dims):
+        self.out_dims = out_dims
+        self.device = device
+        self.div_term = torch.exp(torch.arange(0, out_dims, 2, dtype=torch.float) * -(math.log(10000.0) / out_dims))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t: torch.Tensor, device, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a tensor")
+    if t.device.type != "cuda":
+        raise _abi.S2LError(f"{what}: tensor is on {t.device}; the lip-render path runs on the GPU only (no CPU fallback)")
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+class TalkingFace(nn.Module):
+    def __init__(self, device, cfg, mode="train",
+                 use_viewdirs=False, coord_merge_audio=False,
+                 W=256, D=8, coord_D=4, skips=[4],
+                 uv_audio_dims=66, uv_dims=2, audio_dims=29, head_pose_dims=3,
+                 time_multires=10, output_ch=3, **args):
+        super().__init__()
+        m = cfg["model"]
+        for key in _UNSUPPORTED_TRUE:
+            if m.get(key, False):
+                raise NotImplementedError(f"model.{key}=True is outside the MI355X hot path (May flag set only)")
+        if not (m.get("audio_net") and m.get("audio_not_embed") and m.get("use_audio", True) and m.get("use_time")
+                and m.get("MLP_version") == "v2"):
+            raise NotImplementedError("hot path supports audio_net + audio_not_embed + use_time + MLP_version 'v2'")
+        if (W, D, list(skips), uv_dims, time_multires, output_ch) != (256, 8, [4], 2, 10, 3) or m.get("uv_embed", 10) != 10:
+            raise NotImplementedError("kernels are specialised for W=256, D=8, skips=[4], uv_embed=10, time 20, rgb out")
+
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.use_viewdirs = use_viewdirs
+        self.coord_merge_audio = coord_merge_audio
+        self.uv_audio_dims = uv_audio_dims
+        self.use_attention = False
+        self.use_audio_net = True
+        self.use_uv_audio_sep = m.get("use_uv_audio_sep", True)
+        self.audio_not_embed = True
+        self.skips = list(skips)
+        self.uv_dims = uv_dims
+        self.audio_dims = 64  # with audio_net (tf_nerf.py:64-65)
+        self.head_pose_dims = head_pose_dims
+        self.use_audio = True
+        self.N_sample = cfg["training"].get("n_sample_points", 16)
+        self.use_head_pose = False
+        self.use_head_pose_net = False
+        self.use_time = True
+        self.use_post_fusion = bool(m.get("use_post_fusion", False))
+        self.use_lms = False
+        self.use_text = False
+        self.data_path = cfg["data"]["path"]
+        self.use_light_unet = bool(m.get("use_light_unet", True))
+        self.expand_lip_mask = bool(m.get("expand_lip_mask", False))
+        self.MLP_version = "v2"
+
+        self.uv_embedder = Embedder(10, input_dims=2)
+        self.time_embedder_new = PositionalEncodingTime(self.device, 2 * time_multires)
+
+        # Parameters: identical names/shapes to the reference so checkpoints interchange.
+        self.encoder_conv = nn.Sequential(
+            nn.Conv1d(29, 32, 3, stride=2, padding=1), nn.LeakyReLU(0.02, True),
+            nn.Conv1d(32, 32, 3, stride=2, padding=1), nn.LeakyReLU(0.02, True),
+            nn.Conv1d(32, 64, 3, stride=2, padding=1), nn.LeakyReLU(0.02, True),
+            nn.Conv1d(64, 64, 3, stride=2, padding=1), nn.LeakyReLU(0.02, True))
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02, True), nn.Linear(64, 64))
+        self.coord_linears = nn.ModuleList(  # constructed but never used by any forward (tf_nerf.py:131-135)
+            [nn.Linear(2, W)] + [nn.Linear(W, W) for _ in range(coord_D - 1)] + [nn.Linear(W, 64)])
+        self.output_linear = nn.Linear(W, output_ch)
+        self.fc_uv = nn.Linear(42, W)
+        self.fc_uv_skip = nn.Linear(42, W)
+        self.fc_audio = nn.Linear(64, W)
+        self.fc_audio_skip = nn.Linear(64, W)
+        self.fc_time = nn.Linear(20, W)
+        self.fc_time_skip = nn.Linear(20, W)
+        self.pts_linears = nn.ModuleList([nn.Linear(W, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(2 * W, W)
+                                                             for i in range(D - 1)])
+        self.to(self.device)
+
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._tables = {}
+
+    # ------------------------------------------------------------------ weights
+    def _hot_tensors(self):
+        sd = dict(self.named_parameters())
+        return [sd[name] for name in _abi.TENSOR_ORDER]
+
+    def packed_weights(self) -> torch.Tensor:
+        """Device blob in kernel layout; rebuilt whenever a parameter was modified in place,
+        replaced or moved (tracked through tensor identity + version counters)."""
+        lib = _abi.load()
+        tensors = self._hot_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is None or key != self._packed_key:
+            dev = tensors[0].device
+            if dev.type != "cuda":
+                raise _abi.S2LError(f"TalkingFace parameters are on {dev}; the lip-render path needs a GPU (no CPU fallback)")
+            holders = [_dev_f32(t, dev, "parameter") for t in tensors]
+            table = (ctypes.c_void_p * len(holders))(*[h.data_ptr() for h in holders])
+            div = (ctypes.c_float * 10)(*[float(v) for v in self.time_embedder_new.div_term.tolist()])
+            packed = torch.empty(int(lib.s2l_packed_floats()), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_pack_weights(table, div, _ptr(packed), _stream()), "s2l_pack_weights")
+            self._packed, self._packed_key = packed, key
+            self._tables = {}
+        return self._packed
+
+    def load_state_dict(self, state_dict, strict=False, **kw):
+        """Reference loader is strict=False (checkpoints.py:106): U-Net / depth-head keys that
+        are outside this path are ignored rather than fatal."""
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    # ------------------------------------------------------------------ A4
+    def audio_merge_forward(self, audio):
+        """[B,16,29] DeepSpeech windows (or already-permuted [B,29,16]) -> [B,64].
+        Reference: tf_nerf.py:197-213."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        a = _dev_f32(audio, packed.device, "audio")
+        if a.dim() != 3:
+            raise ValueError(f"audio must be [B,16,29], got {tuple(a.shape)}")
+        if a.shape[2] == 16 and a.shape[1] == 29:      # already channel-major (tf_nerf.py:203-204)
+            a = a.permute(0, 2, 1).contiguous()
+        if a.shape[1:] != (16, 29):
+            raise ValueError(f"audio must be [B,16,29], got {tuple(a.shape)}")
+        out = torch.empty(a.shape[0], 64, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _abi.check(lib.s2l_audio_encode(_ptr(packed), _ptr(a), _ptr(out), a.shape[0], _stream()), "s2l_audio_encode")
+        return out
+
+    # ------------------------------------------------------------------ A5
+    def rgb_forward(self, uv_audio_pts, time_pts=None, head_pose_pts=None, rgb_pts=None, lms_pts=None, text_pts=None):
+        """rows [N, 2+64] + one frame index -> [N,3] (no output activation).
+        Reference: tf_nerf.py:225-285.  `head_pose_pts`, `rgb_pts`, `lms_pts`, `text_pts` are
+        accepted and ignored exactly as the reference ignores them under the May flags."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        rows = _dev_f32(uv_audio_pts, packed.device, "uv_audio_pts")
+        if rows.dim() != 2 or rows.shape[1] != 66:
+            raise ValueError(f"uv_audio_pts must be [N,66], got {tuple(rows.shape)}")
+        if time_pts is None:
+            raise ValueError("time_pts is required (model.use_time)")
+        # PositionalEncodingTime uses position[0] only (tf_nerf.py:437-440)
+        t = int(time_pts.reshape(-1)[0].item()) if isinstance(time_pts, torch.Tensor) else int(time_pts)
+        n = rows.shape[0]
+        out = torch.empty(n, 3, dtype=torch.float32, device=rows.device)
+        xbuf = torch.empty(max(n, 1) * 128, dtype=torch.float32, device=rows.device)
+        with torch.cuda.device(rows.device):
+            _abi.check(lib.s2l_rgb_forward(_ptr(packed), _ptr(rows), t, _ptr(xbuf), _ptr(out), n, _stream()),
+                       "s2l_rgb_forward")
+        return out
+
+    # ------------------------------------------------------------------ A7
+    def _pad_mode(self) -> int:
+        p = self.data_path
+        if "macron" in p or "obama_adnerf" in p or "obama2_face_crop" in p or "may" in p:   # tf_nerf.py:345-348
+            return _abi.S2L_PAD_MAY
+        return _abi.S2L_PAD_DEFAULT
+
+    def post_fusion2_onlylip(self, rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
+                             lip_lefttop_y, coord, use_canonical_space=False, change_pose=-1, mask_face_canonical=None,
+                             wav2lip=None, mask_head_observed=None, use_post_fusion_blackaug=False):
+        """Paste the lip into the canonical face, warp by `coord`, blend with the observed frame.
+        Reference: tf_nerf.py:287-304 -> post_fusion2_onlylip_light :320-389.
+        Returns (None, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; the first slot is
+        the U-Net output in the reference (out of this path)."""
+        if not self.use_light_unet:
+            return None  # the reference method falls through and returns None as well (:299-304)
+        if use_post_fusion_blackaug:
+            raise NotImplementedError("black-hole augmentation is training-only (tf_nerf.py:371-384)")
+        lib = _abi.load()
+        dev = self.packed_weights().device
+        lip = _dev_f32(rgb_lip_warped, dev, "rgb_lip_warped")
+        face = _dev_f32(rgb_face_canonical, dev, "rgb_face_canonical")
+        gt = _dev_f32(rgb_gt, dev, "rgb_gt")
+        mask = _dev_f32(mask_lip_canonical, dev, "mask_lip_canonical")
+        grid = _dev_f32(coord, dev, "coord")
+        B, lh, lw = lip.shape[0], lip.shape[1], lip.shape[2]
+        FH, FW = face.shape[1], face.shape[2]
+        if gt.shape != (B, FH, FW, 3) or grid.shape != (B, FH, FW, 2) or lip.shape[3] != 3:
+            raise ValueError("composite: inconsistent shapes")
+
+        def stride(t, name):
+            if t.shape == (B, FH, FW, 3):
+                return FH * FW * 3
+            if t.shape == (1, FH, FW, 3) or t.shape == (FH, FW, 3):
+                return 0
+            raise ValueError(f"composite: {name} must be [B,FH,FW,3] or [1,FH,FW,3]")
+
+        x0 = int(lip_lefttop_x.reshape(-1)[0].item()) if isinstance(lip_lefttop_x, torch.Tensor) else int(lip_lefttop_x)
+        y0 = int(lip_lefttop_y.reshape(-1)[0].item()) if isinstance(lip_lefttop_y, torch.Tensor) else int(lip_lefttop_y)
+        if self.expand_lip_mask:
+            pad = lw // 12 if "obama2_face_crop" in self.data_path else lw // 5   # tf_nerf.py:357-360
+        else:
+            pad = -1
+        new = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
+        can = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_composite(_ptr(lip), _ptr(face), stride(face, "rgb_face_canonical"), _ptr(mask),
+                                         stride(mask, "mask_lip_canonical"), _ptr(gt), _ptr(grid), _ptr(new), _ptr(can),
+                                         lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B, _stream()), "s2l_composite")
+        return None, new, can
+
+    # ------------------------------------------------------------------ A6 (batched driver)
+    def pixel_tables(self, height: int, width: int):
+        """Per-clip tables p0/p5 [HW,256] for the regular pixel grid (cached per size)."""
+        from .rendering import get_coords
+        lib = _abi.load()
+        packed = self.packed_weights()
+        key = (int(height), int(width))
+        if key not in self._tables:
+            coords = get_coords(width, height, packed.device)
+            hw = coords.shape[0]
+            p0 = torch.empty(hw, 256, dtype=torch.float32, device=packed.device)
+            p5 = torch.empty_like(p0)
+            with torch.cuda.device(packed.device):
+                _abi.check(lib.s2l_pixel_tables(_ptr(packed), _ptr(coords), _ptr(p0), _ptr(p5), hw, _stream()),
+                           "s2l_pixel_tables")
+            self._tables[key] = (p0, p5)
+        return self._tables[key]
+
+    def render_clip(self, audio, frame_idx, height: int, width: int, out: Optional[torch.Tensor] = None, _events=None):
+        """audio [F,16,29] + frame indices [F] -> lip frames [F,H,W,3].
+
+        Same function of its inputs as running the reference's per-frame loop
+        (inference.py:140-159) F times, without its redundancy: the encoder runs once per frame
+        (not once per pixel), coordinates/embeddings once per clip, and one fused launch renders
+        all F*H*W samples."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        dev = packed.device
+        a = _dev_f32(audio, dev, "audio")
+        if a.dim() != 3 or a.shape[1:] != (16, 29):
+            raise ValueError(f"audio must be [F,16,29], got {tuple(a.shape)}")
+        F = a.shape[0]
+        idx = torch.as_tensor(frame_idx, device=dev).to(torch.int64).reshape(-1).contiguous()
+        if idx.numel() != F:
+            raise ValueError("frame_idx must have one entry per audio window")
+        hw = int(height) * int(width)
+        p0, p5 = self.pixel_tables(height, width)
+        if out is None:
+            out = torch.empty(F, int(height), int(width), 3, dtype=torch.float32, device=dev)
+        elif out.shape != (F, int(height), int(width), 3) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 [F,H,W,3] tensor")
+        feat = torch.empty(F, 64, dtype=torch.float32, device=dev)
+        q0 = torch.empty(F, 256, dtype=torch.float32, device=dev)
+        q5 = torch.empty_like(q0)
+        st = _stream()
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_audio_encode(_ptr(packed), _ptr(a), _ptr(feat), F, st), "s2l_audio_encode")
+            _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat), _ptr(idx), _ptr(q0), _ptr(q5), F, st),
+                       "s2l_frame_vectors")
+            if _events is not None:   # bench: HIP events on the launch stream around the dominant kernel
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            _abi.check(lib.s2l_render_lip(_ptr(packed), _ptr(p0), _ptr(p5), _ptr(q0), _ptr(q5), _ptr(out), hw, F, st),
+                       "s2l_render_lip")
+            if _events is not None:
+                ev1.record()
+                _events.append((ev0, ev1))
+        return out

@@ -1,0 +1,129 @@
+"""CPU: the C-ABI library loads and exports every symbol include/s2l_hip.h declares; host-side
+logic (config, module surface, loud failure without a GPU).  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from speech2lip_amd import _abi, build, weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return _abi.load()
+
+
+def test_header_symbols_are_all_exported(lib):
+    header = open(os.path.join(ROOT, "include", "s2l_hip.h")).read()
+    declared = set(re.findall(r"\b(s2l_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    raw = ctypes.CDLL(build.LIB)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.s2l_version().decode().startswith("s2l_hip") and b"gfx950" in lib.s2l_version()
+    assert lib.s2l_packed_floats() > W.HOT_PATH_PARAM_COUNT  # blob holds every weight at least once
+
+
+def test_tensor_order_matches_header_enum():
+    header = open(os.path.join(ROOT, "include", "s2l_hip.h")).read()
+    body = header[header.index("S2L_T_CONV0_W"):header.index("S2L_NUM_TENSORS")]
+    enum = re.findall(r"S2L_T_([A-Z0-9_]+)", body)
+    assert len(enum) == len(_abi.TENSOR_ORDER) == 42
+    canon = lambda k: k.replace("encoder_conv.", "conv").replace("encoder_fc1.", "fc1_").replace("pts_linears.", "pts") \
+        .replace("output_linear", "out").replace(".weight", "_w").replace(".bias", "_b").upper()
+    assert [canon(k) for k in _abi.TENSOR_ORDER] == enum
+    assert [n for n, _ in W.HOT_PATH_TENSORS] == _abi.TENSOR_ORDER
+
+
+def test_argument_errors_do_not_need_a_gpu(lib):
+    null = ctypes.c_void_p(0)
+    assert lib.s2l_audio_encode(null, null, null, 4, null) == -1           # S2L_E_NULL
+    assert lib.s2l_render_lip(null, null, null, null, null, null, 16, 1, null) == -1
+    one = ctypes.c_void_p(16)
+    assert lib.s2l_audio_encode(one, one, one, -1, null) == -2              # S2L_E_SIZE
+    assert lib.s2l_audio_encode(null, null, null, 0, null) == 0             # empty batch: pointers may be null
+    assert lib.s2l_audio_encode(one, one, one, 0, null) == 0                # empty batch is a no-op
+    assert lib.s2l_rgb_forward(one, one, 0, one, one, 0, null) == 0
+    assert lib.s2l_render_lip(one, one, one, one, one, one, 16, 0, null) == 0
+    odd = ctypes.c_void_p(20)
+    assert lib.s2l_render_lip(one, odd, one, one, one, one, 16, 1, null) == -3   # S2L_E_ALIGN
+    # composite geometry: lip box outside the face frame / negative rectangle start
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, 16, 24, 64, 64, 50, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, 16, 24, 64, 64, 2, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 7, one, 0, one, one, one, null, 16, 24, 64, 64, 20, 30, 0, 4, 1, null) == -2
+
+
+def test_config_inherit_and_merge(tmp_path):
+    (tmp_path / "base.yaml").write_text("model:\n  a: 1\n  b: {x: 1, y: 2}\ndata:\n  path: p\n")
+    (tmp_path / "mid.yaml").write_text("inherit_from: base.yaml\nmodel:\n  b: {y: 3}\n  c: 4\n")
+    (tmp_path / "leaf.yaml").write_text("inherit_from: mid.yaml\nmodel:\n  a: 9\ntraining:\n  k: [1, 2]\n")
+    (tmp_path / "default.yaml").write_text("zzz: 1\n")
+    cfg = s2l.load_config("leaf.yaml", "default.yaml", abs_path=str(tmp_path))
+    assert cfg["model"] == {"a": 9, "b": {"x": 1, "y": 3}, "c": 4}
+    assert cfg["data"]["path"] == "p" and cfg["training"]["k"] == [1, 2] and cfg["zzz"] == 1
+    solo = s2l.load_config(str(tmp_path / "default.yaml"))
+    assert solo == {"zzz": 1}
+
+
+def test_may_config_surface():
+    cfg = s2l.may_config(64, 48)
+    assert cfg["data"]["height"] == 64 and cfg["data"]["width"] == 48 and cfg["training"]["batch_rays"] == 64 * 48
+    assert cfg["model"]["MLP_version"] == "v2" and "may" in cfg["data"]["path"]
+
+
+def test_module_surface_and_state_dict_keys():
+    m = s2l.TalkingFace(torch.device("cpu"), s2l.may_config(16, 16), mode="eval")
+    keys = set(m.state_dict().keys())
+    assert set(n for n, _ in W.HOT_PATH_TENSORS) <= keys
+    assert set(n for n, _ in W.DEAD_TENSORS) <= keys
+    assert m.audio_dims == 64 and m.uv_embedder.out_dims == 42 and m.time_embedder_new.out_dims == 20
+    sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()}
+    sd["post_fusion_unet.inc.double_conv.0.weight"] = torch.zeros(1)   # out-of-path keys are ignored
+    res = m.load_state_dict(sd)
+    assert not res.missing_keys
+    assert torch.equal(m.fc_uv.weight.detach(), sd["fc_uv.weight"])
+
+
+def test_unsupported_flags_raise():
+    cfg = s2l.may_config()
+    cfg["model"]["use_head_pose"] = True
+    with pytest.raises(NotImplementedError):
+        s2l.TalkingFace(torch.device("cpu"), cfg)
+    cfg = s2l.may_config()
+    cfg["model"]["MLP_version"] = "v1"
+    with pytest.raises(NotImplementedError):
+        s2l.TalkingFace(torch.device("cpu"), cfg)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses to run without the GPU instead of silently computing on CPU."""
+    m = s2l.TalkingFace(torch.device("cpu"), s2l.may_config(16, 16), mode="eval")
+    with pytest.raises(_abi.S2LError):
+        m.audio_merge_forward(torch.zeros(2, 16, 29))
+    with pytest.raises(_abi.S2LError):
+        m.rgb_forward(torch.zeros(4, 66), time_pts=torch.tensor([0]))
+    with pytest.raises(_abi.S2LError):
+        m.render_clip(torch.zeros(1, 16, 29), [0], 16, 16)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "speech2lip_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "s2l_oracle" not in text, f
+
+
+def test_get_coords_matches_reference_grid(golden):
+    g = golden("g1_embed.npz")
+    for key in g:
+        if key.startswith("coords_"):
+            w, h = map(int, key[len("coords_"):].split("x"))
+            assert torch.equal(s2l.get_coords(w, h, torch.device("cpu")), torch.from_numpy(g[key])), key
