@@ -33,17 +33,29 @@ FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.
 FP32_MFMA_PEAK = 157.3e12
 
 
-def cpu_baseline(frames_budget_s: float = 15.0):
+def cpu_baseline(frames_budget_s: float = 12.0):
     """Oracle (kind 'port'): the as-shipped per-frame path (encoder on H*W tiled copies +
     unfactored MLP, inference.py:144-159) on the host cores, bounded sample."""
     from oracle import s2l_oracle as O
     from speech2lip_amd import weights as W
-    torch.set_num_threads(os.cpu_count() or 1)
     sd = O.to_sd(W.make_state_dict(0, "he"))
     win = torch.from_numpy(W.synthetic_audio(8, seed=1).astype(np.float32))
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
-        for i in range(2):
-            O.render_frame_as_shipped(sd, win[i], i, H, W_)
+        # these are many small ATen ops: every core of a big host is slower than a few.  Calibrate
+        # the thread count on one frame each (bounded), keep the fastest.
+        best_nt, best_t = 1, float("inf")
+        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            O.render_frame_as_shipped(sd, win[0], 0, H, W_)
+            t0 = time.perf_counter()
+            O.render_frame_as_shipped(sd, win[1], 1, H, W_)
+            t = time.perf_counter() - t0
+            if t < best_t:
+                best_nt, best_t = nt, t
+            if t > 3.0:
+                break
+        torch.set_num_threads(best_nt)
         n, t0 = 0, time.perf_counter()
         while n < 60 and (time.perf_counter() - t0) < frames_budget_s:
             O.render_frame_as_shipped(sd, win[n % 8], n, H, W_)

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 RMSE_TOL = 1e-5
 MAX_TOL = 1e-4
+AUDIO_RMSE, AUDIO_MAX = 1e-5, 5e-5   # audio features are O(5) on these weights: ~2e-6 relative
 T = torch.from_numpy
 
 
@@ -62,9 +63,9 @@ def test_native_library_is_loaded(model):
 
 def test_audio_encoder_golden(model, golden, dev):
     g = golden("g2_audio.npz")
-    close(model.audio_merge_forward(T(g["windows"]).to(dev)), g["feat"], 1e-6, 1e-5)
+    close(model.audio_merge_forward(T(g["windows"]).to(dev)), g["feat"], AUDIO_RMSE, AUDIO_MAX)
     # channel-major input ([B,29,16]) takes the no-permute branch of tf_nerf.py:203-204
-    close(model.audio_merge_forward(T(g["windows"]).permute(0, 2, 1).contiguous().to(dev)), g["feat"], 1e-6, 1e-5)
+    close(model.audio_merge_forward(T(g["windows"]).permute(0, 2, 1).contiguous().to(dev)), g["feat"], AUDIO_RMSE, AUDIO_MAX)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 257])
@@ -72,7 +73,7 @@ def test_audio_encoder_ragged_batches(model, sd, dev, n):
     win = T(W.synthetic_audio(n, seed=3).astype(np.float32))
     with torch.no_grad():
         ref = O.audio_encode(sd, win)
-    close(model.audio_merge_forward(win.to(dev)), ref, 1e-6, 1e-5)
+    close(model.audio_merge_forward(win.to(dev)), ref, AUDIO_RMSE, AUDIO_MAX)
 
 
 def test_rgb_forward_golden_rows(model, golden, sd, dev):
