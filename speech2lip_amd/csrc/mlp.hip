@@ -196,6 +196,222 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(MlpArgs a) {
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Table-mode kernel, v2: the 113 weight slabs (7 layers x 16 M-blocks + the output block, 16 KiB
+// each, contiguous in the packed blob) stream L2 -> LDS through an NBUF-deep ring filled by
+// LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass); all 4 waves of the workgroup
+// consume the same slab, each for its own 48 samples.  One s_barrier per slab:
+//     wait own DMA parts of slab s  ->  barrier  ->  issue DMA of slab s+NBUF-1  ->  64x3 MFMAs
+// The barrier both publishes slab s (every wave waited for its own quarter) and retires the
+// buffer of slab s-1, which is the one the new DMA overwrites.  DMA is issued from inline asm, so
+// hipcc neither counts nor drains it (cdna_hip_programming.md §5.7); vmcnt is counted by hand.
+constexpr int kRing = 8;                 // slabs in the LDS ring (8 x 16 KiB = 128 KiB)
+constexpr int kDepth = kRing - 1;        // slabs in flight ahead of the one being consumed
+constexpr int kSlabBytes = kSlab * 4;    // 16384
+constexpr int kNumSlabs = kHidden * 16 + 1;
+constexpr int kBiasFloats = kHidden * kW + 4;   // OFF_BIAS .. OFF_BOUT+4 are contiguous in the blob
+constexpr int kLdsBytes = kRing * kSlabBytes + kBiasFloats * 4;
+static_assert(OFF_WOUT == OFF_WMLP + int64_t(kHidden) * 16 * kSlab, "slabs must be contiguous");
+static_assert(OFF_BOUT == OFF_BIAS + kHidden * kW, "bias block must be contiguous");
+static_assert(16 % kRing == 0, "ring index must be a compile-time function of the M-block");
+
+// Each wave moves one quarter (4 x 1 KiB) of a slab.  gsrc = this lane's source address of the
+// first KiB (wave-quarter base + lane*16); lds_dst = wave-uniform LDS byte address of that KiB.
+__device__ __forceinline__ void dma_quarter_slab(const char* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int G>
+__device__ __forceinline__ void mfma_quad(const f4& w, const float (&in)[G][64], int j4, f4 (&acc)[G]) {
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16(w[jj], in[g][j4 * 4 + jj], acc[g]);
+}
+
+template <int G>
+__device__ __forceinline__ void mfma_quad_mb(const f4& w, const float (&in)[G][64], int j4, f4 (&acc)[G][16], int mb) {
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g][mb] = mfma16(w[jj], in[g][j4 * 4 + jj], acc[g][mb]);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, px = lane & 15;
+  const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * (G * 16);
+  const float* __restrict__ packed = a.packed;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  const float* lds_bias = reinterpret_cast<const float*>(smem + kRing * kSlabBytes) + 4 * q;
+  const f4* ring = reinterpret_cast<const f4*>(smem) + lane;   // this lane's A-operand quads
+
+  // this wave's quarter of slab 0: global source (per lane) and LDS destination (uniform)
+  const char* gq = reinterpret_cast<const char*>(packed + OFF_WMLP) + wave * 4096 + lane * 16;
+  const uint32_t lq = lds_base + wave * 4096;
+  auto issue = [&](int slab, int buf) {   // slab index clamps to the last one: tail DMAs are dummies
+    const int sl = slab < kNumSlabs ? slab : kNumSlabs - 1;
+    dma_quarter_slab(gq + (int64_t)sl * kSlabBytes, lq + buf * kSlabBytes);
+  };
+#pragma unroll
+  for (int s = 0; s < kDepth; ++s) issue(s, s);
+
+  // biases -> LDS (ordinary loads; nothing of the ring is read before the first barrier)
+  for (int i = threadIdx.x; i < kBiasFloats; i += 256)
+    reinterpret_cast<float*>(smem + kRing * kSlabBytes)[i] = packed[OFF_BIAS + i];
+
+  float in[G][64];
+  f4 acc[G][16];
+  int pix[G], frm[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    int64_t n = nbase + g * 16 + px;
+    n = n < a.total ? n : a.total - 1;
+    frm[g] = (int)(n / a.hw);
+    pix[g] = (int)(n - (int64_t)frm[g] * a.hw);
+  }
+  // h0 = relu(p0[pixel] + q0[frame])
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const f4* P = reinterpret_cast<const f4*>(a.p0 + (int64_t)pix[g] * kW + 4 * q);
+    const f4* Q = reinterpret_cast<const f4*>(a.q0 + (int64_t)frm[g] * kW + 4 * q);
+#pragma unroll
+    for (int mb = 0; mb < 16; ++mb) {
+      const f4 s = P[mb * 4] + Q[mb * 4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(s[r], 0.f);
+    }
+  }
+
+  // slab 0: landed + published; then keep the ring full
+  wait_vmcnt<4 * (kDepth - 1)>();
+  wg_barrier();
+  issue(kDepth, kDepth % kRing);
+  f4 w = ring[0];   // quad 0 of slab 0; from here on the next quad is always in flight
+
+  for (int layer = 0; layer < kHidden; ++layer) {
+#pragma unroll
+    for (int mb = 0; mb < 16; ++mb) {
+      const f4* sl = ring + (mb % kRing) * (kSlabBytes / 16);
+      {
+        const f4 b = *reinterpret_cast<const f4*>(lds_bias + layer * kW + mb * 16);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g][mb] = b;
+      }
+#pragma unroll
+      for (int j4 = 0; j4 < 15; ++j4) {
+        const f4 wn = sl[(j4 + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad_mb<G>(w, in, j4, acc, mb);
+        __builtin_amdgcn_sched_barrier(0);
+        w = wn;
+      }
+      // quad 15 is in registers: this wave is done READING slab s.  Publish/retire, refill the
+      // freed buffer, and fetch quad 0 of slab s+1 underneath the last 12 MFMAs of slab s.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<4 * (kDepth - 1)>();
+      wg_barrier();
+      issue(layer * 16 + mb + 1 + kDepth, mb % kRing);
+      const f4 wn = ring[((mb + 1) % kRing) * (kSlabBytes / 16)];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_quad_mb<G>(w, in, 15, acc, mb);
+      __builtin_amdgcn_sched_barrier(0);
+      w = wn;
+    }
+    if (layer == 4) {
+      // pts_linears[5] on cat([skip, h4]): add the skip half p5[pixel] + q5[frame] (q5 carries b5;
+      // the packed bias row of this layer is zero).  `in` is dead here, so the loads are free.
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f4* P = reinterpret_cast<const f4*>(a.p5 + (int64_t)pix[g] * kW + 4 * q);
+        const f4* Q = reinterpret_cast<const f4*>(a.q5 + (int64_t)frm[g] * kW + 4 * q);
+#pragma unroll
+        for (int mb = 0; mb < 16; ++mb) {
+          const f4 s = P[mb * 4] + Q[mb * 4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(acc[g][mb][r] + s[r], 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mb = 0; mb < 16; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(acc[g][mb][r], 0.f);
+    }
+  }
+
+  // output_linear: slab 112 (ring buffer 0, already published; w = its quad 0); no activation
+  f4 rgb[G];
+  {
+    const f4 b = *reinterpret_cast<const f4*>(smem + kRing * kSlabBytes + kHidden * kW * 4);
+#pragma unroll
+    for (int g = 0; g < G; ++g) rgb[g] = b;
+    const f4* sl = ring + ((kNumSlabs - 1) % kRing) * (kSlabBytes / 16);
+#pragma unroll
+    for (int j4 = 0; j4 < 16; ++j4) {
+      f4 wn = w;
+      if (j4 < 15) wn = sl[(j4 + 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_quad<G>(w, in, j4, rgb);
+      __builtin_amdgcn_sched_barrier(0);
+      w = wn;
+    }
+  }
+  if (q == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t n = nbase + g * 16 + px;
+      if (n < a.total) {
+        float* o = a.out + n * 3;
+        o[0] = rgb[g][0];
+        o[1] = rgb[g][1];
+        o[2] = rgb[g][2];
+      }
+    }
+  }
+  wait_vmcnt<0>();   // tail (dummy) DMAs must land before the workgroup's LDS is released
+}
+
+static int launch_mlp_ring(const MlpArgs& a, hipStream_t st) {
+  constexpr int G = 3;
+  const int64_t per_block = (int64_t)G * 16 * 4;
+  const int64_t blocks = (a.total + per_block - 1) / per_block;
+  if (blocks > 0x7fffffff) return S2L_E_SIZE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ring_kernel<G>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mlp_ring_kernel<G>), dim3((unsigned)blocks), dim3(256), kLdsBytes, st, a);
+  return (int)hipGetLastError();
+}
+
 template <int G, int NW, bool GENERAL>
 static int launch_mlp(const MlpArgs& a, hipStream_t st) {
   const int64_t per_block = (int64_t)G * 16 * NW;
@@ -219,7 +435,7 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
       s2l::misaligned16(q5))
     return S2L_E_ALIGN;
   s2l::MlpArgs a{packed, p0, p5, q0, q5, out, hw * n_frames, (int)hw};
-  return s2l::launch_mlp<3, 4, false>(a, static_cast<hipStream_t>(stream));
+  return s2l::launch_mlp_ring(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf, float* out,

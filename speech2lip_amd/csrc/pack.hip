@@ -73,7 +73,8 @@ __global__ void pack_small(TensorTable tab, DivTerm div, float* __restrict__ pac
         tab.t[S2L_T_FC_UV_SKIP_B][n] + tab.t[S2L_T_FC_AUDIO_SKIP_B][n] + tab.t[S2L_T_FC_TIME_SKIP_B][n];
     packed[OFF_B0 + n] = tab.t[S2L_T_PTS0_B][n];
     packed[OFF_B5 + n] = tab.t[S2L_T_PTS5_B][n];
-    for (int l = 0; l < kHidden; ++l) packed[OFF_BIAS + l * kW + n] = tab.t[S2L_T_PTS0_B + 2 * (l + 1)][n];
+    // row 4 (pts_linears[5]) is zero: its bias travels inside q5 (table mode) / BG5 (general mode)
+    for (int l = 0; l < kHidden; ++l) packed[OFF_BIAS + l * kW + n] = l == 4 ? 0.f : tab.t[S2L_T_PTS0_B + 2 * (l + 1)][n];
   }
   for (int i = tid; i < 16; i += nt) packed[OFF_DIV + i] = i < 10 ? div.v[i] : 0.f;
   for (int i = tid; i < 4; i += nt) packed[OFF_BOUT + i] = i < 3 ? tab.t[S2L_T_OUT_B][i] : 0.f;
