@@ -56,10 +56,11 @@ def load() -> ctypes.CDLL:
     """Load libs2l_hip.so; raise (never fall back) when it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            raise S2LError(f"{LIB} not found: build it with `python -m speech2lip_amd.build` "
+        path = os.environ.get("S2L_LIB", LIB)   # A/B builds of the same ABI (kernel experiments)
+        if not os.path.exists(path):
+            raise S2LError(f"{path} not found: build it with `python -m speech2lip_amd.build` "
                            "(there is no CPU fallback for the lip-render path)")
-        lib = ctypes.CDLL(LIB)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
             fn.restype, fn.argtypes = res, args

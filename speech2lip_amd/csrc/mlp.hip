@@ -238,7 +238,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {
+#ifndef S2L_EXP_NO_BARRIER   // timing experiment only (results invalid without the barrier)
+  asm volatile("s_barrier" ::: "memory");
+#endif
+}
 
 template <int G>
 __device__ __forceinline__ void mfma_quad(const f4& w, const float (&in)[G][64], int j4, f4 (&acc)[G]) {
@@ -256,9 +260,23 @@ __device__ __forceinline__ void mfma_quad_mb(const f4& w, const float (&in)[G][6
     for (int g = 0; g < G; ++g) acc[g][mb] = mfma16(w[jj], in[g][j4 * 4 + jj], acc[g][mb]);
 }
 
+#ifdef S2L_EXP_TRACE   // experiment build only: per-workgroup phase timestamps (s_memtime)
+__device__ long long* g_trace = nullptr;
+#define S2L_TRACE(slot)                                                              \
+  do {                                                                               \
+    if (g_trace && threadIdx.x == 0) g_trace[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define S2L_TRACE(slot) do { } while (0)
+#endif
+
 template <int G>
 __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  S2L_TRACE(0);
+#ifdef S2L_EXP_TRACE
+  if (g_trace && threadIdx.x == 0) g_trace[(int64_t)blockIdx.x * 16 + 14] = wall_clock64();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, px = lane & 15;
@@ -272,6 +290,9 @@ __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
   const char* gq = reinterpret_cast<const char*>(packed + OFF_WMLP) + wave * 4096 + lane * 16;
   const uint32_t lq = lds_base + wave * 4096;
   auto issue = [&](int slab, int buf) {   // slab index clamps to the last one: tail DMAs are dummies
+#ifdef S2L_EXP_NO_DMA
+    if (slab >= kRing) return;
+#endif
     const int sl = slab < kNumSlabs ? slab : kNumSlabs - 1;
     dma_quarter_slab(gq + (int64_t)sl * kSlabBytes, lq + buf * kSlabBytes);
   };
@@ -306,39 +327,54 @@ __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
   }
 
   // slab 0: landed + published; then keep the ring full
+  S2L_TRACE(1);
   wait_vmcnt<4 * (kDepth - 1)>();
   wg_barrier();
+  S2L_TRACE(2);
   issue(kDepth, kDepth % kRing);
-  f4 w = ring[0];   // quad 0 of slab 0; from here on the next quad is always in flight
+  // A-operand quads are prefetched TWO ahead into three rotating register sets: a ds_read never
+  // overwrites registers that MFMAs issued in the last ~400 cycles are still reading (the WAR
+  // interlock on a 2-set rotation costs ~40 cycles per quad = 11 % of the kernel).
+  f4 w0 = ring[0], w1 = ring[64];
 
   for (int layer = 0; layer < kHidden; ++layer) {
 #pragma unroll
     for (int mb = 0; mb < 16; ++mb) {
       const f4* sl = ring + (mb % kRing) * (kSlabBytes / 16);
+      const f4* sn = ring + ((mb + 1) % kRing) * (kSlabBytes / 16);
       {
+#ifdef S2L_EXP_NO_BIAS
+        const f4 b = (f4){0.f, 0.f, 0.f, 0.f};
+#else
         const f4 b = *reinterpret_cast<const f4*>(lds_bias + layer * kW + mb * 16);
+#endif
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g][mb] = b;
       }
 #pragma unroll
-      for (int j4 = 0; j4 < 15; ++j4) {
-        const f4 wn = sl[(j4 + 1) * 64];
+      for (int j4 = 0; j4 < 16; ++j4) {
+#ifndef S2L_EXP_NO_BOUNDARY
+        if (j4 == 14) {
+          // quads 14 and 15 are in registers: this wave is done READING slab s.  Publish slab s+1,
+          // retire slab s, refill its buffer; the next two reads come from slab s+1.
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wait_vmcnt<4 * (kDepth - 1)>();
+          wg_barrier();
+          issue(layer * 16 + mb + 1 + kDepth, mb % kRing);
+        }
+#endif
+#ifdef S2L_EXP_NO_DSREAD
+        f4 w2 = w0;
+        asm volatile("" : "+v"(w2));
+#else
+        const f4 w2 = j4 < 14 ? sl[(j4 + 2) * 64] : sn[(j4 - 14) * 64];
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        mfma_quad_mb<G>(w, in, j4, acc, mb);
+        mfma_quad_mb<G>(w0, in, j4, acc, mb);
         __builtin_amdgcn_sched_barrier(0);
-        w = wn;
+        w0 = w1;
+        w1 = w2;
       }
-      // quad 15 is in registers: this wave is done READING slab s.  Publish/retire, refill the
-      // freed buffer, and fetch quad 0 of slab s+1 underneath the last 12 MFMAs of slab s.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_vmcnt<4 * (kDepth - 1)>();
-      wg_barrier();
-      issue(layer * 16 + mb + 1 + kDepth, mb % kRing);
-      const f4 wn = ring[((mb + 1) % kRing) * (kSlabBytes / 16)];
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_quad_mb<G>(w, in, 15, acc, mb);
-      __builtin_amdgcn_sched_barrier(0);
-      w = wn;
     }
     if (layer == 4) {
       // pts_linears[5] on cat([skip, h4]): add the skip half p5[pixel] + q5[frame] (q5 carries b5;
@@ -355,16 +391,24 @@ __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
         }
       }
     } else {
+#ifdef S2L_EXP_NO_EPILOGUE   // timing experiment only: skip the per-layer ReLU/move (keeps acc alive)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mb = 0; mb < 16; ++mb) asm volatile("" ::"a"(acc[g][mb]));
+#else
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int mb = 0; mb < 16; ++mb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(acc[g][mb][r], 0.f);
+#endif
     }
+    S2L_TRACE(3 + layer);
   }
 
-  // output_linear: slab 112 (ring buffer 0, already published; w = its quad 0); no activation
+  // output_linear: slab 112 (ring buffer 0, already published; w0/w1 = its quads 0/1); no activation
   f4 rgb[G];
   {
     const f4 b = *reinterpret_cast<const f4*>(smem + kRing * kSlabBytes + kHidden * kW * 4);
@@ -373,12 +417,13 @@ __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
     const f4* sl = ring + ((kNumSlabs - 1) % kRing) * (kSlabBytes / 16);
 #pragma unroll
     for (int j4 = 0; j4 < 16; ++j4) {
-      f4 wn = w;
-      if (j4 < 15) wn = sl[(j4 + 1) * 64];
+      f4 w2 = w1;
+      if (j4 < 14) w2 = sl[(j4 + 2) * 64];
       __builtin_amdgcn_sched_barrier(0);
-      mfma_quad<G>(w, in, j4, rgb);
+      mfma_quad<G>(w0, in, j4, rgb);
       __builtin_amdgcn_sched_barrier(0);
-      w = wn;
+      w0 = w1;
+      w1 = w2;
     }
   }
   if (q == 0) {
@@ -393,8 +438,27 @@ __global__ __launch_bounds__(256) void mlp_ring_kernel(MlpArgs a) {
       }
     }
   }
+  S2L_TRACE(10);
   wait_vmcnt<0>();   // tail (dummy) DMAs must land before the workgroup's LDS is released
+  S2L_TRACE(11);
+#ifdef S2L_EXP_TRACE
+  if (g_trace && threadIdx.x == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_trace[(int64_t)blockIdx.x * 16 + 12] = hwid;
+    g_trace[(int64_t)blockIdx.x * 16 + 13] = xcc;
+    g_trace[(int64_t)blockIdx.x * 16 + 15] = wall_clock64();
+  }
+#endif
 }
+
+#ifdef S2L_EXP_TRACE
+extern "C" int s2l_debug_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p));
+}
+#endif
 
 static int launch_mlp_ring(const MlpArgs& a, hipStream_t st) {
   constexpr int G = 3;
