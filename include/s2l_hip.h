@@ -81,15 +81,18 @@ int s2l_frame_vectors(const float* packed, const float* feat, const int64_t* fra
                       float* q5, int64_t n_frames, s2l_stream_t stream);
 
 /* Per-pixel (frame-invariant) halves:  p0[p] = W0 Wuv E(uv_p),  p5[p] = W5[:, :256] Wuv' E(uv_p).
- * coords [HW,2] (u,v) -> p0, p5 [HW,256].  Replaces Embedder.__call__ (tf_nerf.py:404-425) and
- * the fc_uv / fc_uv_skip terms (:252, :269) for a fixed pixel grid (rendering.py:9-28). */
+ * coords [HW,2] (u,v) -> p0, p5: opaque tables for s2l_render_lip, each ceil(HW/16)*16*256 floats
+ * (16-pixel groups in the renderer's LDS-DMA order).  Replaces Embedder.__call__
+ * (tf_nerf.py:404-425) and the fc_uv / fc_uv_skip terms (:252, :269) for a fixed pixel grid
+ * (rendering.py:9-28). */
 int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float* p5, int64_t hw,
                      s2l_stream_t stream);
 
 /* Fused render of a clip: for every frame f and pixel p
  *   h0 = relu(p0[p] + q0[f]); h1..h4 = relu(W h + b); h5 = relu(p5[p] + q5[f] + W5[:,256:] h4);
  *   h6, h7; rgb = Wout h7 + bout          (no output activation, tf_nerf.py:283)
- * out [F,HW,3].  Activations never leave registers; fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * out [F,HW,3]; p0/p5 from s2l_pixel_tables, q0/q5 [F,256] from s2l_frame_vectors.  One persistent
+ * launch; activations never leave registers; fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);

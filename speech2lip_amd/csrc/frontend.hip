@@ -151,7 +151,7 @@ __device__ inline float embed_feature(float u, float v, int i) {
   return (blk & 1) ? cosf(x) : sinf(x);
 }
 
-constexpr int kPB = 16;  // pixels per block in pixel_tables_kernel
+constexpr int kPB = 16;  // pixels per block in pixel_tables_kernel == pixels per render tile
 
 __global__ __launch_bounds__(256) void pixel_tables_kernel(const float* __restrict__ packed,
                                                           const float* __restrict__ coords, float* __restrict__ p0,
@@ -193,12 +193,16 @@ __global__ __launch_bounds__(256) void pixel_tables_kernel(const float* __restri
       acc5[pb] = fmaf(w5, s5[pb][k], acc5[pb]);
     }
   }
+  // tile layout of render.hip: [pixel group][mb 16][q 4][px 16][4]; feature tid = mb*16 + q*4 + r.
+  // kPB == 16 == one pixel group per block; rows past hw repeat the last pixel (never stored).
+  const int mb = tid >> 4, qq = (tid >> 2) & 3, r = tid & 3;
+  float* d0 = p0 + (int64_t)blockIdx.x * 4096 + ((mb * 4 + qq) * 16) * 4 + r;
+  float* d5 = p5 + (int64_t)blockIdx.x * 4096 + ((mb * 4 + qq) * 16) * 4 + r;
 #pragma unroll
-  for (int pb = 0; pb < kPB; ++pb)
-    if (pbase + pb < hw) {
-      p0[(pbase + pb) * 256 + tid] = acc0[pb];
-      p5[(pbase + pb) * 256 + tid] = acc5[pb];
-    }
+  for (int pb = 0; pb < kPB; ++pb) {
+    d0[pb * 4] = acc0[pb];
+    d5[pb * 4] = acc5[pb];
+  }
 }
 
 // General rows: x[row] = [E(u,v) (42) | a (64) | PE(t) (20) | 0 0].  128 threads per row pair.

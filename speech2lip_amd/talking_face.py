@@ -272,7 +272,8 @@ class TalkingFace(nn.Module):
         if key not in self._tables:
             coords = get_coords(width, height, packed.device)
             hw = coords.shape[0]
-            p0 = torch.empty(hw, 256, dtype=torch.float32, device=packed.device)
+            rows = (hw + 15) // 16 * 16   # opaque renderer layout: 16-pixel groups
+            p0 = torch.empty(rows, 256, dtype=torch.float32, device=packed.device)
             p5 = torch.empty_like(p0)
             with torch.cuda.device(packed.device):
                 _abi.check(lib.s2l_pixel_tables(_ptr(packed), _ptr(coords), _ptr(p0), _ptr(p5), hw, _stream()),
