@@ -113,11 +113,18 @@ int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_ind
  * lip [F,h,w,3]; face_canon, mask [FH,FW,3] when *_stride == 0 (per-clip constants) or
  * [F,FH,FW,3] when stride == FH*FW*3; rgb_gt [F,FH,FW,3]; coord [F,FH,FW,2];
  * out_new [F,FH,FW,3]; out_canonical [F,FH,FW,3] or NULL (rgb_merged_canonical, :352).
+ * bgm: NULL, or the per-clip table of s2l_composite_tables for these face_canon/mask (used only
+ * when both strides are 0): halves the gather traffic, results are bit-identical.
  * expand_pad = p (lip_w/5, or lip_w/12 for obama2, :357-360); pad_mode S2L_PAD_*. */
 int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
                   int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
-                  float* out_canonical, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
-                  int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream);
+                  float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w,
+                  int x0, int y0, int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream);
+
+/* Optional per-clip precompute for s2l_composite: bgm [FH,FW,4] = ((1-mask)*face_canon, 0), the
+ * background term of tf_nerf.py:352 as one 16-byte-aligned gather target (16-byte aligned). */
+int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm, int face_h, int face_w,
+                         s2l_stream_t stream);
 
 #ifdef __cplusplus
 }

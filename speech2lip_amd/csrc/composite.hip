@@ -21,102 +21,214 @@ struct CompArgs {
   const float* coord;  // [F,FH,FW,2]
   float* out_new;      // [F,FH,FW,3]
   float* out_can;      // [F,FH,FW,3] or null
+  const float* bgm;    // optional per-clip table [FH,FW,4] = ((1-mask)*face, 0) from s2l_composite_tables, or null
   int64_t face_stride, mask_stride, total;
   int h, w, FH, FW;
   int ox, oy;          // paste origin of the lip in the face frame
   int ry0, ry1, rx0, rx1;  // expanded-mask rectangle [ry0,ry1) x [rx0,rx1); ry0 < 0 => use `mask`
+  int rsize, chunks;       // pixels per XCD region, 256-pixel chunks per region
 };
 
 struct Px {
   float c[3];
 };
 
-// merged canonical image at integer (yy, xx) of frame f.  Separate roundings on purpose: the
+// 12-byte pixel accessed as one dwordx3 (pixels are only 4-byte aligned: offset = 12 * index)
+struct __attribute__((packed, aligned(4))) F3 {
+  float x, y, z;
+};
+__device__ __forceinline__ Px load_px(const float* p) {
+  const F3 v = *reinterpret_cast<const F3*>(p);
+  return Px{{v.x, v.y, v.z}};
+}
+__device__ __forceinline__ void store_px(float* p, const float (&c)[3]) {
+  *reinterpret_cast<F3*>(p) = F3{c[0], c[1], c[2]};
+}
+// streaming (touched once) variants: keep the per-clip tables in L2, not the frame streams
+__device__ __forceinline__ Px load_px_stream(const float* p) {
+  return Px{{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2)}};
+}
+__device__ __forceinline__ void store_px_stream(float* p, const float (&c)[3]) {
+  __builtin_nontemporal_store(c[0], p);
+  __builtin_nontemporal_store(c[1], p + 1);
+  __builtin_nontemporal_store(c[2], p + 2);
+}
+
+// merged canonical image at in-range integer (yy, xx).  Separate roundings on purpose: the
 // reference evaluates mul, rsub, mul, add as four ATen ops (tf_nerf.py:352), so no FMA here.
-__device__ inline Px merged_c(const CompArgs& a, const float* face, const float* mask, const float* lip, int yy, int xx,
-                              Px* mask_out) {
-  const int64_t o = ((int64_t)yy * a.FW + xx) * 3;
-  const int ly = yy - a.oy, lx = xx - a.ox;
-  const bool in_lip = (unsigned)ly < (unsigned)a.h && (unsigned)lx < (unsigned)a.w;
-  const float* lp = lip + ((int64_t)ly * a.w + lx) * 3;
+__device__ __forceinline__ Px blend_px(const Px& m, const Px& l, const Px& fv) {
   Px r;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float m = mask[o + c];
-    const float l = in_lip ? lp[c] : 0.f;
-    r.c[c] = __fadd_rn(__fmul_rn(m, l), __fmul_rn(__fsub_rn(1.f, m), face[o + c]));
-    if (mask_out) mask_out->c[c] = m;
-  }
+  for (int c = 0; c < 3; ++c) r.c[c] = __fadd_rn(__fmul_rn(m.c[c], l.c[c]), __fmul_rn(__fsub_rn(1.f, m.c[c]), fv.c[c]));
   return r;
 }
 
-__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.total) return;
-  const int64_t per = (int64_t)a.FH * a.FW;
-  const int64_t f = idx / per;
-  const float* face = a.face + f * a.face_stride;
-  const float* mask = a.mask + f * a.mask_stride;
-  const float* lip = a.lip + f * (int64_t)a.h * a.w * 3;
-  const bool rect = a.ry0 >= 0;
+// One thread per output pixel; grid.y = frame.  All eight table gathers (mask + face at the four
+// bilinear taps) are issued up front with clamped addresses and zeroed weights for out-of-range
+// taps -- no per-tap branches, so the loads overlap instead of serialising on L2 latency.  The
+// lip is fetched only by waves that touch its box (wave-uniform test).
+constexpr int kPPT = 1;   // pixels per thread (256 apart): the second pixel's streaming loads overlap the first's gathers
 
-  const float2 g = reinterpret_cast<const float2*>(a.coord)[idx];
+template <bool BGM>
+__device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* face, const float* mask, const float* lip,
+                                                int64_t idx, int pix, float2 g, const Px& gt) {
+  const bool rect = a.ry0 >= 0;
   // grid_sample(align_corners=False): unnormalise as (x+1)*(size/2) - 0.5, bilinear weights from
   // the distances to the four neighbours, zero padding outside [0,size-1].
   const float ix = __fsub_rn(__fmul_rn(__fadd_rn(g.x, 1.f), 0.5f * (float)a.FW), 0.5f);
   const float iy = __fsub_rn(__fmul_rn(__fadd_rn(g.y, 1.f), 0.5f * (float)a.FH), 0.5f);
   const float xw = floorf(ix), yn = floorf(iy);
   const float wx = ix - xw, ex = 1.f - wx, ny = iy - yn, sy = 1.f - ny;
-  const float wgt[4] = {__fmul_rn(sy, ex), __fmul_rn(sy, wx), __fmul_rn(ny, ex), __fmul_rn(ny, wx)};
+  const float wraw[4] = {__fmul_rn(sy, ex), __fmul_rn(sy, wx), __fmul_rn(ny, ex), __fmul_rn(ny, wx)};
+  // integer tap origin; the float clamp keeps the conversion defined for wild / non-finite coords
+  const int x0 = (int)fminf(fmaxf(xw, -2.f), (float)a.FW + 1.f);
+  const int y0 = (int)fminf(fmaxf(yn, -2.f), (float)a.FH + 1.f);
+
+  Px m[4], fv[4], l[4];
+  float wgt[4];
+  int lipoff[4], moff[4];
+  bool inlip[4];
+  bool anylip = false;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const bool ok = (unsigned)xx < (unsigned)a.FW && (unsigned)yy < (unsigned)a.FH && xw + (float)(t & 1) == (float)xx &&
+                    yn + (float)(t >> 1) == (float)yy;
+    wgt[t] = ok ? wraw[t] : 0.f;
+    const int xc = min(max(xx, 0), a.FW - 1), yc = min(max(yy, 0), a.FH - 1);
+    const int o = (yc * a.FW + xc) * 3;
+    const int ly = yc - a.oy, lx = xc - a.ox;
+    inlip[t] = ok && (unsigned)ly < (unsigned)a.h && (unsigned)lx < (unsigned)a.w;
+    lipoff[t] = (ly * a.w + lx) * 3;
+    anylip |= inlip[t];
+    l[t] = Px{{0.f, 0.f, 0.f}};
+    if (BGM) {
+      const f4 b = *reinterpret_cast<const f4*>(a.bgm + (yc * a.FW + xc) * 4);   // one aligned 16-byte gather
+      fv[t] = Px{{b[0], b[1], b[2]}};           // (1-mask)*face, already rounded as the reference rounds it
+      moff[t] = o;
+      m[t] = Px{{0.f, 0.f, 0.f}};
+    } else {
+      m[t] = load_px(mask + o);
+      fv[t] = load_px(face + o);
+    }
+  }
+  if (__any(anylip || (BGM && !rect))) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (BGM && (inlip[t] || !rect)) m[t] = load_px(mask + moff[t]);   // mask only matters where the lip is (or as warp mask)
+      if (inlip[t]) l[t] = load_px(lip + lipoff[t]);
+    }
+  }
 
   float acc[3] = {0.f, 0.f, 0.f}, macc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const float fx = xw + (float)(t & 1), fy = yn + (float)(t >> 1);
-    const bool ok = fx >= 0.f && fx <= (float)(a.FW - 1) && fy >= 0.f && fy <= (float)(a.FH - 1);
-    if (ok) {
-      const int xx = (int)fx, yy = (int)fy;
-      Px m;
-      const Px v = merged_c(a, face, mask, lip, yy, xx, rect ? nullptr : &m);
-      const float mr = (rect && yy >= a.ry0 && yy < a.ry1 && xx >= a.rx0 && xx < a.rx1) ? 1.f : 0.f;
+    Px v;
+    if (BGM) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        acc[c] = fmaf(v.c[c], wgt[t], acc[c]);
-        macc[c] = fmaf(rect ? mr : m.c[c], wgt[t], macc[c]);
-      }
+      for (int c = 0; c < 3; ++c) v.c[c] = __fadd_rn(__fmul_rn(m[t].c[c], l[t].c[c]), fv[t].c[c]);
+    } else {
+      v = blend_px(m[t], l[t], fv[t]);
+    }
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const float mr = (yy >= a.ry0 && yy < a.ry1 && xx >= a.rx0 && xx < a.rx1) ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc[c] = fmaf(v.c[c], wgt[t], acc[c]);
+      macc[c] = fmaf(rect ? mr : m[t].c[c], wgt[t], macc[c]);
     }
   }
-  const float* gt = a.gt + idx * 3;
-  float* o = a.out_new + idx * 3;
+  float res[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = macc[c] != 0.f ? acc[c] : gt[c];
+  for (int c = 0; c < 3; ++c) res[c] = macc[c] != 0.f ? acc[c] : gt.c[c];
+  store_px_stream(a.out_new + idx * 3, res);
 
   if (a.out_can) {
-    const int64_t r = idx - f * per;
-    const int y = (int)(r / a.FW), x = (int)(r - (int64_t)y * a.FW);
-    const Px v = merged_c(a, face, mask, lip, y, x, nullptr);
-    float* oc = a.out_can + idx * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) oc[c] = v.c[c];
+    const int y = pix / a.FW, x = pix - y * a.FW;
+    const int o = pix * 3;
+    const int ly = y - a.oy, lx = x - a.ox;
+    Px lc = Px{{0.f, 0.f, 0.f}};
+    if ((unsigned)ly < (unsigned)a.h && (unsigned)lx < (unsigned)a.w) lc = load_px(lip + (ly * a.w + lx) * 3);
+    const Px v = blend_px(load_px(mask + o), lc, load_px(face + o));
+    store_px(a.out_can + idx * 3, v.c);
   }
+}
+
+// One thread per kPPT output pixels.  All table gathers of a pixel (mask + face, or the fused
+// per-clip table, at the four bilinear taps) are issued up front with clamped addresses and
+// zeroed weights for out-of-range taps -- no per-tap branches, so the loads overlap instead of
+// serialising on L2 latency.  The lip is fetched only by waves that touch its box.
+template <bool BGM>
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+  // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; speed only, not
+  // correctness).  XCD r owns the r-th eighth of the face for EVERY frame, so its slice of the
+  // per-clip constants stays resident in its 4 MiB L2 across frames.
+  const int per = a.FH * a.FW;
+  const int region = blockIdx.x & 7;
+  const int k = blockIdx.x >> 3;
+  const int chunk = k % a.chunks;
+  const int64_t f = k / a.chunks;
+  const float* face = a.face + f * a.face_stride;
+  const float* mask = a.mask + f * a.mask_stride;
+  const float* lip = a.lip + f * (int64_t)a.h * a.w * 3;
+  int pix[kPPT];
+  bool live[kPPT];
+  float2 g[kPPT];
+  Px gt[kPPT];
+#pragma unroll
+  for (int i = 0; i < kPPT; ++i) {   // streaming loads of every pixel first
+    const int in_region = (chunk * kPPT + i) * 256 + threadIdx.x;
+    pix[i] = region * a.rsize + in_region;
+    live[i] = in_region < a.rsize && pix[i] < per;
+    const int64_t idx = f * per + (live[i] ? pix[i] : 0);
+    g[i] = float2{__builtin_nontemporal_load(a.coord + 2 * idx), __builtin_nontemporal_load(a.coord + 2 * idx + 1)};
+    gt[i] = load_px_stream(a.gt + idx * 3);
+  }
+#pragma unroll
+  for (int i = 0; i < kPPT; ++i)
+    if (live[i]) composite_pixel<BGM>(a, face, mask, lip, f * per + pix[i], pix[i], g[i], gt[i]);
+}
+
+// Per-clip table for the fast path: bgm[p] = ((1-mask[p]) * face[p] (3 floats), 0): 16-byte pixels.
+__global__ void composite_tables_kernel(const float* __restrict__ face, const float* __restrict__ mask,
+                                        float* __restrict__ bgm, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Px m = load_px(mask + 3 * i), f = load_px(face + 3 * i);
+  f4 bg;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bg[c] = __fmul_rn(__fsub_rn(1.f, m.c[c]), f.c[c]);
+  bg[3] = 0.f;
+  *reinterpret_cast<f4*>(bgm + 4 * i) = bg;
 }
 
 }  // namespace s2l
 
+extern "C" int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm, int face_h, int face_w,
+                                    s2l_stream_t stream) {
+  if (face_h <= 0 || face_w <= 0 || (int64_t)face_h * face_w * 6 > 0x7fffffff) return S2L_E_SIZE;
+  if (!face_canon || !mask || !bgm) return S2L_E_NULL;
+  const int n = face_h * face_w;
+  hipLaunchKernelGGL(s2l::composite_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     face_canon, mask, bgm, n);
+  return (int)hipGetLastError();
+}
+
 extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
                              int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
-                             float* out_canonical, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
-                             int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
+                             float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w, int x0,
+                             int y0, int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
   if (n_frames > 0 && (!lip || !face_canon || !mask || !rgb_gt || !coord || !out_new)) return S2L_E_NULL;
   if (lip_h <= 0 || lip_w <= 0 || face_h <= 0 || face_w <= 0 || n_frames < 0) return S2L_E_SIZE;
   const int64_t per = (int64_t)face_h * face_w;
   if ((face_stride != 0 && face_stride != per * 3) || (mask_stride != 0 && mask_stride != per * 3)) return S2L_E_SIZE;
   if (pad_mode != S2L_PAD_MAY && pad_mode != S2L_PAD_DEFAULT) return S2L_E_SIZE;
   if (n_frames == 0) return S2L_OK;
-  if (reinterpret_cast<uintptr_t>(coord) & 7) return S2L_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(coord) & 7) || s2l::misaligned16(bgm)) return S2L_E_ALIGN;
   s2l::CompArgs a;
   a.lip = lip; a.face = face_canon; a.mask = mask; a.gt = rgb_gt; a.coord = coord;
   a.out_new = out_new; a.out_can = out_canonical;
+  a.bgm = (face_stride == 0 && mask_stride == 0) ? bgm : nullptr;   // the table is per clip
   a.face_stride = face_stride; a.mask_stride = mask_stride; a.total = per * n_frames;
   a.h = lip_h; a.w = lip_w; a.FH = face_h; a.FW = face_w;
   a.ox = pad_mode == S2L_PAD_MAY ? x0 : x0 - 1;
@@ -132,8 +244,14 @@ extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t 
   } else {
     a.ry0 = a.ry1 = a.rx0 = a.rx1 = -1;
   }
-  const int64_t blocks = (a.total + 255) / 256;
+  if (per * 6 > 0x7fffffff) return S2L_E_SIZE;   // 32-bit in-frame offsets
+  a.rsize = (int)((per + 7) / 8);
+  a.chunks = (a.rsize + 256 * s2l::kPPT - 1) / (256 * s2l::kPPT);
+  const int64_t blocks = 8 * (int64_t)a.chunks * n_frames;
   if (blocks > 0x7fffffff) return S2L_E_SIZE;
-  hipLaunchKernelGGL(s2l::composite_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (a.bgm)
+    hipLaunchKernelGGL(s2l::composite_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(s2l::composite_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }

@@ -229,23 +229,33 @@ class TalkingFace(nn.Module):
             return None  # the reference method falls through and returns None as well (:299-304)
         if use_post_fusion_blackaug:
             raise NotImplementedError("black-hole augmentation is training-only (tf_nerf.py:371-384)")
+        new, can = self.composite_clip(rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
+                                       lip_lefttop_y, coord, want_canonical=True)
+        return None, new, can
+
+    def composite_clip(self, rgb_lip, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
+                       coord, want_canonical=False, out=None):
+        """Batched composite (tf_nerf.py:320-386 without the U-Net) for F frames at once:
+        rgb_lip [F,h,w,3], rgb_gt [F,FH,FW,3], coord [F,FH,FW,2]; rgb_face_canonical and
+        mask_lip_canonical either per frame [F,FH,FW,3] or per clip [1,FH,FW,3] / [FH,FW,3].
+        Returns (rgb_merged_new [F,FH,FW,3], rgb_merged_canonical or None)."""
         lib = _abi.load()
         dev = self.packed_weights().device
-        lip = _dev_f32(rgb_lip_warped, dev, "rgb_lip_warped")
+        lip = _dev_f32(rgb_lip, dev, "rgb_lip")
         face = _dev_f32(rgb_face_canonical, dev, "rgb_face_canonical")
         gt = _dev_f32(rgb_gt, dev, "rgb_gt")
         mask = _dev_f32(mask_lip_canonical, dev, "mask_lip_canonical")
         grid = _dev_f32(coord, dev, "coord")
         B, lh, lw = lip.shape[0], lip.shape[1], lip.shape[2]
-        FH, FW = face.shape[1], face.shape[2]
+        FH, FW = gt.shape[1], gt.shape[2]
         if gt.shape != (B, FH, FW, 3) or grid.shape != (B, FH, FW, 2) or lip.shape[3] != 3:
             raise ValueError("composite: inconsistent shapes")
 
         def stride(t, name):
-            if t.shape == (B, FH, FW, 3):
-                return FH * FW * 3
             if t.shape == (1, FH, FW, 3) or t.shape == (FH, FW, 3):
                 return 0
+            if t.shape == (B, FH, FW, 3):
+                return FH * FW * 3
             raise ValueError(f"composite: {name} must be [B,FH,FW,3] or [1,FH,FW,3]")
 
         x0 = int(lip_lefttop_x.reshape(-1)[0].item()) if isinstance(lip_lefttop_x, torch.Tensor) else int(lip_lefttop_x)
@@ -254,13 +264,19 @@ class TalkingFace(nn.Module):
             pad = lw // 12 if "obama2_face_crop" in self.data_path else lw // 5   # tf_nerf.py:357-360
         else:
             pad = -1
-        new = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
-        can = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
+        new = out if out is not None else torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
+        can = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev) if want_canonical else None
+        fs, ms = stride(face, "rgb_face_canonical"), stride(mask, "mask_lip_canonical")
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_composite(_ptr(lip), _ptr(face), stride(face, "rgb_face_canonical"), _ptr(mask),
-                                         stride(mask, "mask_lip_canonical"), _ptr(gt), _ptr(grid), _ptr(new), _ptr(can),
-                                         lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B, _stream()), "s2l_composite")
-        return None, new, can
+            bgm = None
+            if fs == 0 and ms == 0 and B >= 2:   # per-clip constants: fuse them once, gather half as much per frame
+                bgm = torch.empty(FH, FW, 4, dtype=torch.float32, device=dev)
+                _abi.check(lib.s2l_composite_tables(_ptr(face), _ptr(mask), _ptr(bgm), FH, FW, _stream()),
+                           "s2l_composite_tables")
+            _abi.check(lib.s2l_composite(_ptr(lip), _ptr(face), fs, _ptr(mask), ms, _ptr(gt), _ptr(grid), _ptr(new),
+                                         _ptr(can), _ptr(bgm), lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B, _stream()),
+                       "s2l_composite")
+        return new, can
 
     # ------------------------------------------------------------------ A6 (batched driver)
     def pixel_tables(self, height: int, width: int):

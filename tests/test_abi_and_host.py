@@ -54,9 +54,9 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     odd = ctypes.c_void_p(20)
     assert lib.s2l_render_lip(one, odd, one, one, one, one, 16, 1, null) == -3   # S2L_E_ALIGN
     # composite geometry: lip box outside the face frame / negative rectangle start
-    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, 16, 24, 64, 64, 50, 30, 0, 4, 1, null) == -4
-    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, 16, 24, 64, 64, 2, 30, 0, 4, 1, null) == -4
-    assert lib.s2l_composite(one, one, 7, one, 0, one, one, one, null, 16, 24, 64, 64, 20, 30, 0, 4, 1, null) == -2
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 50, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 2, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 7, one, 0, one, one, one, null, null, 16, 24, 64, 64, 20, 30, 0, 4, 1, null) == -2
 
 
 def test_config_inherit_and_merge(tmp_path):

@@ -216,19 +216,41 @@ def test_composite_batched_shared_constants(dev):
 
 
 def test_composite_without_mask_expansion(dev):
+    """expand_lip_mask off: the (soft) lip mask itself is warped and binarised, per channel.
+    F=1 takes the direct path, F=2 the per-clip fused-table path; both must match the oracle."""
     rng = np.random.default_rng(6)
     FH, FW, lh, lw, x0, y0 = 32, 32, 8, 8, 10, 9
     cfg_m = make_model(dev, lh, lw)
     cfg_m.expand_lip_mask = False
-    lip = T(rng.random((1, lh, lw, 3), dtype=np.float32))
-    face = T(rng.random((1, FH, FW, 3), dtype=np.float32))
-    mask = torch.zeros(1, FH, FW, 3)
-    mask[:, y0:y0 + lh, x0:x0 + lw] = 1
-    gt = T(rng.random((1, FH, FW, 3), dtype=np.float32))
-    coord = T((rng.random((1, FH, FW, 2), dtype=np.float32) * 2 - 1))
-    _, new, _ = cfg_m.post_fusion2_onlylip(lip.to(dev), face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev))
-    rn, _ = O.composite(lip, face, gt, mask, x0, y0, coord, expand_lip_mask=False)
-    close(new, rn, 1e-6, 5e-6)
+    for F in (1, 2):
+        lip = T(rng.random((F, lh, lw, 3), dtype=np.float32))
+        face = T(rng.random((1, FH, FW, 3), dtype=np.float32))
+        mask = torch.zeros(1, FH, FW, 3)
+        mask[:, y0:y0 + lh, x0:x0 + lw] = T(rng.random((lh, lw, 3), dtype=np.float32))
+        gt = T(rng.random((F, FH, FW, 3), dtype=np.float32))
+        coord = T((rng.random((F, FH, FW, 2), dtype=np.float32) * 2 - 1))
+        new, can = cfg_m.composite_clip(lip.to(dev), face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev),
+                                        want_canonical=True)
+        for f in range(F):
+            rn, rc = O.composite(lip[f:f + 1], face, gt[f:f + 1], mask, x0, y0, coord[f:f + 1], expand_lip_mask=False)
+            close(new[f:f + 1], rn, 1e-6, 5e-6)
+            close(can[f:f + 1], rc, 1e-9, 0.0)
+
+
+def test_composite_fused_table_path_is_bit_identical(dev):
+    """s2l_composite with and without the per-clip bgm table returns the same bits."""
+    rng = np.random.default_rng(8)
+    F, FH, FW, lh, lw, x0, y0 = 4, 48, 40, 12, 10, 14, 16
+    m = make_model(dev, lh, lw)
+    lip = T(rng.random((F, lh, lw, 3), dtype=np.float32)).to(dev)
+    face = T(rng.random((1, FH, FW, 3), dtype=np.float32)).to(dev)
+    mask = T(rng.random((1, FH, FW, 3), dtype=np.float32)).to(dev)
+    gt = T(rng.random((F, FH, FW, 3), dtype=np.float32)).to(dev)
+    coord = T((rng.random((F, FH, FW, 2), dtype=np.float32) * 2.2 - 1.1)).to(dev)
+    fast, _ = m.composite_clip(lip, face, gt, mask, x0, y0, coord)                      # per-clip constants -> table path
+    slow, _ = m.composite_clip(lip, face.expand(F, -1, -1, -1).contiguous(), gt,
+                               mask.expand(F, -1, -1, -1).contiguous(), x0, y0, coord)   # per-frame copies -> direct path
+    assert torch.equal(fast, slow)
 
 
 def test_empty_inputs(model, dev):
