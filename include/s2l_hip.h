@@ -104,6 +104,17 @@ int s2l_render_lip(const float* packed, const float* p0, const float* p5, const 
 int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf,
                     float* out, int64_t n_rows, s2l_stream_t stream);
 
+/* 4-tap local-ensemble forward of the training step for one frame
+ * (Trainer.predict_lip_image, src/face_simple/training.py:158-251): the MLP at
+ * clamp(coords + (vx*0.5/W + eps, vy*0.5/H + eps), 0, 1), vx,vy in {-1,1}, eps = (0.5/H)*u01/2,
+ * area-weighted with the diagonal swap of :240-245.  coords [N,2]; feat [64] = the frame's audio
+ * feature (s2l_audio_encode); u01 = the U(0,1) draw of :200; work = scratch of
+ * s2l_predict_lip_image_work_floats(N) floats; out [N,3]. */
+int64_t s2l_predict_lip_image_work_floats(int64_t n_pixels);
+int s2l_predict_lip_image(const float* packed, const float* coords, const float* feat,
+                          int64_t time_index, int width, int height, float u01, float* work,
+                          float* out, int64_t n_pixels, s2l_stream_t stream);
+
 /* Paste + head-pose warp composite, up to but not including the U-Net
  * (TalkingFace.post_fusion2_onlylip_light, tf_nerf.py:320-386):
  *   merged_c = mask * pad(lip) + (1-mask) * face_canon                        (:339-352)

@@ -2,5 +2,7 @@
 from .config import load_config, may_config
 from .rendering import get_coords
 from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
+from .training import Trainer, predict_lip_image
 
-__all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config"]
+__all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
+           "predict_lip_image"]

@@ -43,6 +43,9 @@ EXPORTS = {
     "s2l_rgb_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_composite": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_predict_lip_image_work_floats": (c_int64, [c_int64]),
+    "s2l_predict_lip_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p,
+                                      c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

@@ -207,6 +207,11 @@ static int launch_mlp(const MlpArgs& a, hipStream_t st) {
 int launch_embed_rows(const float* packed, const float* uv_audio, int64_t time_index, float* x, int64_t n_rows,
                       hipStream_t st);
 
+int launch_general_mlp(const float* packed, const float* x, float* out, int64_t n_rows, hipStream_t st) {
+  MlpArgs a{packed, x, nullptr, nullptr, nullptr, out, n_rows, 1};
+  return launch_mlp<2, 4, true>(a, st);
+}
+
 }  // namespace s2l
 
 extern "C" int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf, float* out,
@@ -218,6 +223,5 @@ extern "C" int s2l_rgb_forward(const float* packed, const float* uv_audio, int64
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = s2l::launch_embed_rows(packed, uv_audio, time_index, xbuf, n_rows, st);
   if (rc) return rc;
-  s2l::MlpArgs a{packed, xbuf, nullptr, nullptr, nullptr, out, n_rows, 1};
-  return s2l::launch_mlp<2, 4, true>(a, st);
+  return s2l::launch_general_mlp(packed, xbuf, out, n_rows, st);
 }

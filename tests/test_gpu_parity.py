@@ -253,6 +253,38 @@ def test_composite_fused_table_path_is_bit_identical(dev):
     assert torch.equal(fast, slow)
 
 
+def test_predict_lip_image_golden(golden, dev):
+    """T1: the 4-tap local ensemble (training.py:158-251) against the reference's own output (G5)."""
+    g = golden("g5_ensemble.npz")
+    m = make_model(dev, 16, 16)
+    coords = s2l.get_coords(16, 16, dev)
+    pred = s2l.predict_lip_image(m, coords, T(g["window"])[None].to(dev), int(g["idx"]), 16, 16, float(g["eps_u01"]))
+    close(pred, g["pred"])
+    # through the Trainer-shaped wrapper with torch.rand pinned the way the golden was captured
+    tr = s2l.Trainer(m)
+    real = torch.rand
+    torch.rand = lambda *a, **k: torch.full((1,), float(g["eps_u01"]), device=dev)
+    try:
+        pred2 = tr.predict_lip_image(0, coords, T(g["window"])[None].to(dev), None, {"index": torch.tensor([int(g["idx"])])},
+                                     None, None, None)
+    finally:
+        torch.rand = real
+    close(pred2, g["pred"])
+    loss = float(((pred2.cpu() - T(g["target"])) ** 2).mean())
+    assert abs(loss - float(g["loss"])) <= 1e-6
+
+
+@pytest.mark.parametrize("h,w,u", [(12, 20, 0.0), (5, 7, 0.999), (96, 96, 0.5)])
+def test_predict_lip_image_vs_oracle(sd, dev, h, w, u):
+    m = make_model(dev, h, w)
+    win = T(W.synthetic_audio(3, seed=13).astype(np.float32))
+    coords = O.get_coords(w, h)
+    with torch.no_grad():
+        ref = O.predict_lip_image(sd, coords, win[1], 321, h, w, u)
+    got = s2l.predict_lip_image(m, coords.to(dev), win[1:2].to(dev), 321, h, w, u)
+    close(got, ref)
+
+
 def test_empty_inputs(model, dev):
     assert model.audio_merge_forward(torch.zeros(0, 16, 29, device=dev)).shape == (0, 64)
     assert model.rgb_forward(torch.zeros(0, 66, device=dev), time_pts=0).shape == (0, 3)
