@@ -31,6 +31,7 @@ H = W_ = 96
 HW = H * W_
 FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
 FP32_MFMA_PEAK = 157.3e12
+TRAFFIC_BYTES_PER_FRAME = 9.14e8 / 1000   # measured with PMC counters, see profiles/r01c_rocprofv3_summary.txt
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -93,7 +94,8 @@ def main():
     F = args.frames
     model = s2l.TalkingFace(dev, s2l.may_config(H, W_), mode="eval").eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
-    gids = sharded.global_frame_ids(F, rank, world, args.chunks).to(dev)
+    QUANTUM = 48   # frames: keeps each chunk launch a whole number of 256-tile waves at 96x96
+    gids = sharded.global_frame_ids(F, rank, world, args.chunks if world > 1 else 1, QUANTUM).to(dev)
     audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
     clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if world > 1 else None
     kernel_events = []
@@ -102,7 +104,8 @@ def main():
         model.render_clip(audio[off:off + cnt], gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
 
     def step():
-        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=args.chunks if world > 1 else 1, clip=clip)
+        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=args.chunks if world > 1 else 1, clip=clip,
+                                      quantum=QUANTUM)
 
     def fence():
         torch.cuda.synchronize()
@@ -127,7 +130,9 @@ def main():
     # dominant-kernel time from HIP events recorded on the launch stream around s2l_render_lip
     torch.cuda.synchronize()
     k_ms = [s.elapsed_time(e) for s, e in kernel_events]
-    frames_per_launch = F / (args.chunks if world > 1 else 1)
+    # several launches per step when chunked: total algorithmic FLOPs of a step / total kernel time of a step
+    launches_per_step = len(k_ms) / args.steps
+    frames_per_launch = F / launches_per_step
     k_avg_s = (sum(k_ms) / len(k_ms)) * 1e-3
     achieved = FLOPS_PER_FRAME * frames_per_launch / k_avg_s
 
@@ -145,8 +150,11 @@ def main():
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
                        (f" + {args.chunks}-chunk all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4), "traffic": None,
-                         "kernel": "s2l::mlp_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
+                         # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):
+                         # profiles/r01c_rocprofv3_summary.txt measured 9.14e8 B per 1000-frame launch
+                         "traffic": round(TRAFFIC_BYTES_PER_FRAME * frames_per_launch),
+                         "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
             "parity": {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1)},
         }

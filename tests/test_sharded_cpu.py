@@ -15,10 +15,13 @@ def test_chunk_plan_covers_everything_once():
     for fpr in (0, 1, 5, 7, 1000):
         for world in (1, 2, 8):
             for nc in (1, 3, 4, 16):
-                plan = sharded.chunk_plan(fpr, world, nc)
-                assert sum(c for _, c in plan) == fpr
-                ids = torch.cat([sharded.global_frame_ids(fpr, r, world, nc) for r in range(world)])
-                assert sorted(ids.tolist()) == list(range(fpr * world))
+                for quantum in (1, 48):
+                    plan = sharded.chunk_plan(fpr, world, nc, quantum)
+                    assert sum(c for _, c in plan) == fpr
+                    assert all(c % quantum == 0 for _, c in plan[:-1]) or fpr < quantum * len(plan)
+                    ids = torch.cat([sharded.global_frame_ids(fpr, r, world, nc, quantum) for r in range(world)])
+                    assert sorted(ids.tolist()) == list(range(fpr * world))
+    assert [c for _, c in sharded.chunk_plan(1000, 8, 4, 48)] == [240, 240, 240, 280]
 
 
 def _stamp(gid):

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for a round on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r01'
+# Kernel-trace stats and each PMC group are separate runs (PMC is never combined with sys/hip traces).
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+C="python $R/tools/bench_composite.py 256"
+$B > $O/bench_line.json 2> $O/bench.err
+$C > $O/composite_line.json 2> $O/composite.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $B > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma -o s -- $B > $O/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o s -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o s -- $B > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/pmc_sq -o s -- $B > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o s -- $C > $O/cstats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_fetch -o s -- $C > $O/cpmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/cpmc_write -o s -- $C > $O/cpmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
+ls $O

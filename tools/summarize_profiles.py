@@ -1,0 +1,46 @@
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into profiles/<tag>_rocprofv3_summary.txt."""
+import collections, csv, json, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+out = []
+def pmc(dirname, kernel_substr):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    path = f"{src}/{dirname}/s_counter_collection.csv"
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        if kernel_substr in r["Kernel_Name"]:
+            agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {c: sum(d.values()) / len(d) for c, d in agg.items()}
+def stats(dirname):
+    path = f"{src}/{dirname}/s_kernel_stats.csv"
+    return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+out.append(f"# rocprofv3 evidence, {tag}, MI355X (collected by tools/profile_round.sh; PMC groups are separate runs)\n")
+for name in ("bench_line.json", "composite_line.json"):
+    p = f"{src}/{name}"
+    if os.path.exists(p):
+        out.append(f"\n## {name}\n{open(p).read().strip()}\n")
+out.append("\n## render path: rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
+for r in stats("stats"):
+    out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
+out.append("\n## render kernel PMC, per dispatch (1000 frames 96x96)\n")
+vals = {}
+for d in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_sq"):
+    vals.update(pmc(d, "render_tiles_kernel"))
+for k, v in vals.items():
+    out.append("%-34s %.6g\n" % (k, v))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
+    out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes\n" % traffic)
+out.append("\n## composite: rocprofv3 --kernel-trace --stats -- python tools/bench_composite.py 256\n")
+for r in stats("cstats"):
+    out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
+out.append("\n## composite kernel PMC, per dispatch (256 frames 500x500, 128x128 lip)\n")
+cv = {}
+for d in ("cpmc_fetch", "cpmc_write", "cpmc_sq"):
+    cv.update(pmc(d, "composite_kernel"))
+for k, v in cv.items():
+    out.append("%-34s %.6g\n" % (k, v))
+os.makedirs("profiles", exist_ok=True)
+open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
+print("".join(out))
