@@ -58,7 +58,7 @@ def cpu_baseline(frames_budget_s: float = 12.0):
                 break
         torch.set_num_threads(best_nt)
         n, t0 = 0, time.perf_counter()
-        while n < 60 and (time.perf_counter() - t0) < frames_budget_s:
+        while n < 600 and (time.perf_counter() - t0) < frames_budget_s:
             O.render_frame_as_shipped(sd, win[n % 8], n, H, W_)
             n += 1
         dt = time.perf_counter() - t0
@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
     ap.add_argument("--chunks", type=int, default=4, help="all-gather chunks per step (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,7 +96,8 @@ def main():
     model = s2l.TalkingFace(dev, s2l.may_config(H, W_), mode="eval").eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
     QUANTUM = 48   # frames: keeps each chunk launch a whole number of 256-tile waves at 96x96
-    gids = sharded.global_frame_ids(F, rank, world, args.chunks if world > 1 else 1, QUANTUM).to(dev)
+    n_chunks = args.chunks if (world > 1 or args.force_chunks) else 1
+    gids = sharded.global_frame_ids(F, rank, world, n_chunks, QUANTUM).to(dev)
     audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
     clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if world > 1 else None
     kernel_events = []
@@ -104,7 +106,7 @@ def main():
         model.render_clip(audio[off:off + cnt], gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
 
     def step():
-        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=args.chunks if world > 1 else 1, clip=clip,
+        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip,
                                       quantum=QUANTUM)
 
     def fence():
@@ -148,7 +150,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step",
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
-                       (f" + {args.chunks}-chunk all-gather" if world > 1 else "")},
+                       (f" + {n_chunks}-chunk all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):

@@ -115,6 +115,44 @@ int s2l_predict_lip_image(const float* packed, const float* coords, const float*
                           int64_t time_index, int width, int height, float u01, float* work,
                           float* out, int64_t n_pixels, s2l_stream_t stream);
 
+/* ---- training step (BASELINE config 5; fp32 exact-parity mode) -------------------------------
+ * The reference gets these from torch autograd (training.py:559 `loss.backward()`); the entry
+ * points below are the forward-with-saved-activations and the hand-written backward of the same
+ * functions.  Row order is caller-defined; x rows are [E(uv) 42 | audio 64 | PE(t) 20 | 0 0]. */
+
+/* Halves of s2l_predict_lip_image: x [4N,128] rows + areas [4N] for one frame; area-weighted
+ * reduce pred [4N,3] -> out [N,3] (training.py:204-249). */
+int s2l_ensemble_rows(const float* packed, const float* coords, const float* feat, int64_t time_index,
+                      int width, int height, float u01, float* x, float* areas, int64_t n_pixels,
+                      s2l_stream_t stream);
+int s2l_ensemble_reduce(const float* pred, const float* areas, float* out, int64_t n_pixels,
+                        s2l_stream_t stream);
+/* d pred [N,3] -> d rgb of the four taps [4N,3]. */
+int s2l_ensemble_backward(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
+                          s2l_stream_t stream);
+/* MLP on rows x [N,128] -> rgb [N,3], saving the post-ReLU activations h0..h7 in hsave [8,N,256]
+ * (tf_nerf.py:252-283 with the first/skip projections folded at pack time). */
+int s2l_train_forward(const float* packed, const float* x, float* hsave, float* rgb, int64_t n_rows,
+                      s2l_stream_t stream);
+/* Backward chain: drgb [N,3] -> dzsave [8,N,256] (gradient w.r.t. the pre-activation of h0..h7) and
+ * dxa [N,64] (gradient w.r.t. the audio columns of x). */
+int s2l_train_backward(const float* packed, const float* drgb, const float* hsave, float* dzsave,
+                       float* dxa, int64_t n_rows, s2l_stream_t stream);
+/* Scratch floats for the split reductions below, for a result of n_elems elements. */
+int64_t s2l_split_work_floats(int64_t n_elems);
+/* dw [256,k_in] = dz[:, :256]^T in[:, :k_in] over n_rows rows (k_in = 128 or 256; ld* = row strides
+ * in floats); fp32 MFMA, deterministic two-stage reduction; work: s2l_split_work_floats(256*k_in). */
+int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, float* work, float* dw,
+              int64_t n_rows, s2l_stream_t stream);
+/* out [m,c] = a[:, :m]^T b[:, :c] (m <= 4, c <= 256); a == NULL with m == 1: column sums of b
+ * (bias gradients).  work: s2l_split_work_floats(m*c). */
+int s2l_small_outer(const float* a, int lda, int m, const float* b, int ldb, int c, float* work,
+                    float* out, int64_t n_rows, s2l_stream_t stream);
+/* loss = weight * mean((pred - target)^2) over n_elems (training.py:605-619); dpred (optional) =
+ * d loss / d pred; work: 1024 floats; loss: 1 float (device). */
+int s2l_mse(const float* pred, const float* target, float weight, float* dpred, float* work,
+            float* loss, int64_t n_elems, s2l_stream_t stream);
+
 /* Paste + head-pose warp composite, up to but not including the U-Net
  * (TalkingFace.post_fusion2_onlylip_light, tf_nerf.py:320-386):
  *   merged_c = mask * pad(lip) + (1-mask) * face_canon                        (:339-352)

@@ -2,7 +2,8 @@
 from .config import load_config, may_config
 from .rendering import get_coords
 from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
-from .training import Trainer, predict_lip_image
+from . import training
+from .training import LipTrainStep, Trainer, predict_lip_image
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
-           "predict_lip_image"]
+           "predict_lip_image", "LipTrainStep", "training"]

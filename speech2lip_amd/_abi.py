@@ -46,6 +46,16 @@ EXPORTS = {
     "s2l_predict_lip_image_work_floats": (c_int64, [c_int64]),
     "s2l_predict_lip_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p,
                                       c_int64, c_void_p]),
+    "s2l_ensemble_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
+                                  c_void_p]),
+    "s2l_ensemble_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_ensemble_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_split_work_floats": (c_int64, [c_int64]),
+    "s2l_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_small_outer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_mse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

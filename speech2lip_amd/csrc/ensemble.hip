@@ -62,9 +62,44 @@ __global__ __launch_bounds__(256) void ensemble_reduce_kernel(const float* __res
   out[i] = r;
 }
 
-int launch_general_mlp(const float* packed, const float* x, float* out, int64_t n_rows, hipStream_t st);
+int launch_general_mlp(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
 
 }  // namespace s2l
+
+// The two halves of s2l_predict_lip_image on their own (the training step runs the MLP in between
+// over many frames at once and keeps x / areas for the backward).
+static s2l::TapShifts tap_shifts(int width, int height, float u01) {
+  // shifts exactly as the reference forms them: python doubles rounded to fp32, plus the fp32 eps
+  const double rx = 0.5 / width, ry = 0.5 / height;
+  const float eps = (float)ry * u01 / 2.0f;
+  s2l::TapShifts sh;
+  for (int ix = 0; ix < 2; ++ix)
+    for (int iy = 0; iy < 2; ++iy) {
+      sh.dx[2 * ix + iy] = (float)((ix ? 1 : -1) * rx) + eps;
+      sh.dy[2 * ix + iy] = (float)((iy ? 1 : -1) * ry) + eps;
+    }
+  return sh;
+}
+
+extern "C" int s2l_ensemble_rows(const float* packed, const float* coords, const float* feat, int64_t time_index, int width,
+                                 int height, float u01, float* x, float* areas, int64_t n_pixels, s2l_stream_t stream) {
+  if (n_pixels < 0 || width <= 0 || height <= 0) return S2L_E_SIZE;
+  if (n_pixels == 0) return S2L_OK;
+  if (!packed || !coords || !feat || !x || !areas) return S2L_E_NULL;
+  hipLaunchKernelGGL(s2l::ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 1) / 2)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), packed, coords, feat, (float)time_index,
+                     tap_shifts(width, height, u01), x, areas, n_pixels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_reduce(const float* pred, const float* areas, float* out, int64_t n_pixels, s2l_stream_t stream) {
+  if (n_pixels < 0) return S2L_E_SIZE;
+  if (n_pixels == 0) return S2L_OK;
+  if (!pred || !areas || !out) return S2L_E_NULL;
+  hipLaunchKernelGGL(s2l::ensemble_reduce_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pred, areas, out, n_pixels);
+  return (int)hipGetLastError();
+}
 
 extern "C" int64_t s2l_predict_lip_image_work_floats(int64_t n_pixels) {
   return n_pixels < 0 ? 0 : n_pixels * (4 * s2l::kGenK + 4 * 3 + 4);
@@ -79,21 +114,13 @@ extern "C" int s2l_predict_lip_image(const float* packed, const float* coords, c
   if (!packed || !coords || !feat || !work || !out) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(work)) return S2L_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // shifts exactly as the reference forms them: python doubles rounded to fp32, plus the fp32 eps
-  const double rx = 0.5 / width, ry = 0.5 / height;
-  const float eps = (float)ry * u01 / 2.0f;
-  TapShifts sh;
-  for (int ix = 0; ix < 2; ++ix)
-    for (int iy = 0; iy < 2; ++iy) {
-      sh.dx[2 * ix + iy] = (float)((ix ? 1 : -1) * rx) + eps;
-      sh.dy[2 * ix + iy] = (float)((iy ? 1 : -1) * ry) + eps;
-    }
+  const TapShifts sh = tap_shifts(width, height, u01);
   float* x = work;
   float* pred = x + 4 * n_pixels * kGenK;
   float* areas = pred + 4 * n_pixels * 3;
   hipLaunchKernelGGL(ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 1) / 2)), dim3(256), 0, st, packed, coords, feat,
                      (float)time_index, sh, x, areas, n_pixels);
-  int rc = launch_general_mlp(packed, x, pred, 4 * n_pixels, st);
+  int rc = launch_general_mlp(packed, x, pred, nullptr, 4 * n_pixels, st);
   if (rc) return rc;
   hipLaunchKernelGGL(ensemble_reduce_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0, st, pred, areas,
                      out, n_pixels);

@@ -132,10 +132,40 @@ __global__ void pack_fold_general(TensorTable tab, float* __restrict__ packed) {
     return;
   }
   if (kk >= 128) return;
+  packed[(skip ? OFF_G5 : OFF_G0) + n * kGenK + kk] = acc;   // plain copy (transposed-packed below for the backward)
   // A layout, K=128: slab(mb)[(j4*64 + lane)*4 + jj], lane = q*16 + (n&15), kin(j, q) = 32*q + j
   const int j = kk & 31, q = kk >> 5;
   const int mb = n >> 4, lane = q * 16 + (n & 15);
   packed[(skip ? OFF_WG5 : OFF_WG0) + (int64_t)mb * (kSlab / 2) + ((j >> 2) * 64 + lane) * 4 + (j & 3)] = acc;
+}
+
+// Backward-pass operand copies: transposed hidden layers / output layer (dgrad), audio columns of
+// the folded matrices (gradient of the per-frame audio feature).  Runs after pack_fold_general.
+__global__ void pack_backward(TensorTable tab, float* __restrict__ packed) {
+  const int lane = threadIdx.x & 63;
+  const int j4 = (threadIdx.x >> 6) + 4 * (blockIdx.x & 3);
+  const int mb = (blockIdx.x >> 2) & 15;
+  const int layer = blockIdx.x >> 6;      // 0..6 hidden, 7: output + audio columns
+  const int i = lane & 15, q = lane >> 4;
+  if (layer < kHidden) {
+    const int pts = layer + 1;
+    const float* w = tab.t[S2L_T_PTS0_W + 2 * pts];
+    const int ld = pts == 5 ? 512 : 256;
+    const int c0 = pts == 5 ? 256 : 0;
+    float* dst = packed + OFF_WMLPT + ((int64_t)(layer * 16 + mb) * 16 + j4) * 256 + lane * 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dst[jj] = w[(int64_t)kfeat(j4 * 4 + jj, q) * ld + c0 + mb * 16 + i];
+  } else {
+    if (j4 == 0) packed[OFF_WOUTT + mb * 64 + lane] = q < 3 ? tab.t[S2L_T_OUT_W][q * 256 + mb * 16 + i] : 0.f;
+    if (mb < 4) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int krow = kfeat(j4 * 4 + jj, q);
+        packed[OFF_G0AT + (int64_t)(mb * 16 + j4) * 256 + lane * 4 + jj] = packed[OFF_G0 + krow * kGenK + kEmb + mb * 16 + i];
+        packed[OFF_G5AT + (int64_t)(mb * 16 + j4) * 256 + lane * 4 + jj] = packed[OFF_G5 + krow * kGenK + kEmb + mb * 16 + i];
+      }
+    }
+  }
 }
 
 }  // namespace s2l
@@ -159,5 +189,6 @@ extern "C" int s2l_pack_weights(const float* const* tensors_host, const float* d
   hipLaunchKernelGGL(s2l::pack_mlp_slabs, dim3(8 * 16 * 4), dim3(256), 0, st, tab, packed);
   hipLaunchKernelGGL(s2l::pack_small, dim3(64), dim3(256), 0, st, tab, div, packed);
   hipLaunchKernelGGL(s2l::pack_fold_general, dim3(512), dim3(192), 0, st, tab, packed);
+  hipLaunchKernelGGL(s2l::pack_backward, dim3(8 * 16 * 4), dim3(256), 0, st, tab, packed);
   return (int)hipGetLastError();
 }

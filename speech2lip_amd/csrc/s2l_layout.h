@@ -57,7 +57,19 @@ constexpr int64_t OFF_F0W = OFF_C6B + 64;                          // [64][64]
 constexpr int64_t OFF_F0B = OFF_F0W + 64 * 64;
 constexpr int64_t OFF_F2W = OFF_F0B + 64;
 constexpr int64_t OFF_F2B = OFF_F2W + 64 * 64;
-constexpr int64_t PACKED_FLOATS = OFF_F2B + 64;
+// ---- training (backward) sections -------------------------------------------------------------
+// plain folded first/skip matrices G0 = W0 [Wuv|Wa|Wt|0], G5 = W5a [Wuv'|Wa'|Wt'|0]: [256][128]
+constexpr int64_t OFF_G0 = OFF_F2B + 64;
+constexpr int64_t OFF_G5 = OFF_G0 + kW * kGenK;
+// transposed hidden layers in A-operand order for dgrad: slab(L, mb)[(j4*64+lane)*4+jj] =
+//   W_L[kfeat(j4*4+jj, lane>>4)][mb*16 + (lane&15)]   (dh_in[mb-block] = W^T dz, k runs over OUT features)
+constexpr int64_t OFF_WMLPT = OFF_G5 + kW * kGenK;                  // [7][16][16][64][4]
+// output layer transposed, K = 4 (3 used): [16 mb][64 lanes] one float per lane: Wout[lane>>4][mb*16+(lane&15)]
+constexpr int64_t OFF_WOUTT = OFF_WMLPT + int64_t(kHidden) * 16 * kSlab;
+// audio columns (42..105) of G0 / G5 transposed: d a = G[:, 42:106]^T dz: [4 mb][16 j4][64][4]
+constexpr int64_t OFF_G0AT = OFF_WOUTT + 16 * 64;
+constexpr int64_t OFF_G5AT = OFF_G0AT + 4 * kSlab;
+constexpr int64_t PACKED_FLOATS = OFF_G5AT + 4 * kSlab;
 
 static_assert(OFF_WOUT % 4 == 0 && OFF_BIAS % 4 == 0 && OFF_W0T % 4 == 0 && OFF_C0B % 4 == 0, "16B sections");
 

@@ -1,0 +1,222 @@
+// Training-step kernels (BASELINE config 5: MLP forward + backward).
+//
+//   s2l_train_forward   general-row MLP forward that also saves h0..h7      (tf_nerf.py:225-285)
+//   s2l_train_backward  dz7..dz0 chain + audio-column gradient              (autograd of the above)
+//   s2l_wgrad           dW[256,K] = dz^T in, K in {128, 256}: fp32 MFMA, split over rows, two-stage
+//                       deterministic reduction
+//   s2l_colsum          bias gradients / small outer products (output layer)
+//   s2l_ensemble_*      4-tap ensemble rows, area-weighted reduce and its backward (training.py:158-251)
+//   s2l_mse             photometric loss + its gradient                     (training.py:605-619)
+// All fp32 (exact-parity mode).  The reference reaches these through torch autograd
+// (training.py:559 loss.backward()); there is no reference source to mirror line by line.
+#include "s2l_common.h"
+
+namespace s2l {
+
+int launch_general_mlp(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
+int launch_general_mlp_bwd(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa,
+                           int64_t n_rows, hipStream_t st);
+
+__device__ inline f4 mfma16w(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---- weight gradient: partial[blk][out 256][in K] = sum over the block's rows of dz[row][out] * in[row][k] --------
+// MFMA 16x16x4 with k = row: A[i = out feature][k = row] = dz[row][out], B[k = row][j = in feature] = in[row][in].
+// Wave w of 4 owns out-feature blocks 4w..4w+3 x all KB in-feature blocks: 4*KB accumulators of 4 registers.
+template <int KB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ in,
+                                                    int ldin, float* __restrict__ partial, int64_t n_rows,
+                                                    int64_t rows_per_block) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i = lane & 15;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n_rows) r1 = n_rows;
+  f4 acc[4][KB];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < KB; ++n) acc[m][n] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0; r < r1; r += 4) {
+    const int64_t row = r + q;
+    const bool ok = row < r1;
+    const float* dzr = dz + (ok ? row : r0) * ldz + wave * 64 + i;
+    const float* inr = in + (ok ? row : r0) * ldin + i;
+    float a[4], b[KB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = ok ? dzr[m * 16] : 0.f;
+#pragma unroll
+    for (int n = 0; n < KB; ++n) b[n] = ok ? inr[n * 16] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < KB; ++n) acc[m][n] = mfma16w(a[m], b[n], acc[m][n]);
+  }
+  // D[row = 4q + r -> out feature][col = i -> in feature]
+  float* p = partial + (int64_t)blockIdx.x * 256 * (KB * 16);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < KB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[(int64_t)(wave * 64 + m * 16 + 4 * q + r) * (KB * 16) + n * 16 + i] = acc[m][n][r];
+}
+
+// out[e] = sum over blocks (fixed order) of partial[blk][e]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int n_blocks, int64_t n_elems) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elems) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * n_elems + e];
+  out[e] = s;
+}
+
+// partial[blk][m][c] = sum over the block's rows of a[row][m] * b[row][c], m < M <= 4, c < C <= 256 (thread = c).
+// M = 1 with a = nullptr is a plain column sum (bias gradient).
+__global__ __launch_bounds__(256) void small_outer_kernel(const float* __restrict__ a, int lda, int M,
+                                                         const float* __restrict__ b, int ldb, int C,
+                                                         float* __restrict__ partial, int64_t n_rows,
+                                                         int64_t rows_per_block) {
+  const int c = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n_rows) r1 = n_rows;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int64_t r = r0; r < r1; ++r) {
+      const float v = b[r * ldb + c];
+      if (a) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < M) acc[m] = fmaf(a[r * lda + m], v, acc[m]);
+      } else {
+        acc[0] += v;
+      }
+    }
+    for (int m = 0; m < M; ++m) partial[((int64_t)blockIdx.x * M + m) * C + c] = acc[m];
+  }
+}
+
+// ---- ensemble / loss elementwise ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ensemble_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ areas,
+                                                          float* __restrict__ drgb, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 3) return;
+  const int64_t p = i / 3;
+  const float a0 = areas[p], a1 = areas[n + p], a2 = areas[2 * n + p], a3 = areas[3 * n + p];
+  const float tot = ((a0 + a1) + a2) + a3;
+  const float g = dpred[i];
+  drgb[i] = g * (a3 / tot);               // tap t is weighted by the diagonally opposite area (training.py:244-245)
+  drgb[n * 3 + i] = g * (a2 / tot);
+  drgb[2 * n * 3 + i] = g * (a1 / tot);
+  drgb[3 * n * 3 + i] = g * (a0 / tot);
+}
+
+// dpred = scale * (pred - target); block partial of sum (pred - target)^2
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                 float scale, float* __restrict__ dpred, float* __restrict__ partial,
+                                                 int64_t n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = pred[i] - target[i];
+    s = fmaf(d, d, s);
+    if (dpred) dpred[i] = scale * d;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void mse_final_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *loss = s * scale;
+  }
+}
+
+constexpr int kSplitBlocks = 512;   // row blocks of the split reductions (2 per CU)
+
+}  // namespace s2l
+
+using namespace s2l;
+
+extern "C" int s2l_train_forward(const float* packed, const float* x, float* hsave, float* rgb, int64_t n_rows,
+                                 s2l_stream_t stream) {
+  if (n_rows < 0) return S2L_E_SIZE;
+  if (n_rows == 0) return S2L_OK;
+  if (!packed || !x || !hsave || !rgb) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(x) || misaligned16(hsave)) return S2L_E_ALIGN;
+  return launch_general_mlp(packed, x, rgb, hsave, n_rows, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int s2l_train_backward(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa,
+                                  int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows < 0) return S2L_E_SIZE;
+  if (n_rows == 0) return S2L_OK;
+  if (!packed || !drgb || !hsave || !dzsave || !dxa) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(hsave) || misaligned16(dzsave) || misaligned16(dxa)) return S2L_E_ALIGN;
+  return launch_general_mlp_bwd(packed, drgb, hsave, dzsave, dxa, n_rows, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t s2l_split_work_floats(int64_t n_elems) { return n_elems < 0 ? 0 : n_elems * kSplitBlocks; }
+
+extern "C" int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, float* work, float* dw,
+                         int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows <= 0 || (k_in != 128 && k_in != 256) || ldz < 256 || ldin < k_in) return S2L_E_SIZE;
+  if (!dz || !in || !work || !dw) return S2L_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t rpb = (n_rows + kSplitBlocks - 1) / kSplitBlocks;
+  rpb = (rpb + 3) / 4 * 4;
+  const int nblk = (int)((n_rows + rpb - 1) / rpb);
+  if (k_in == 256)
+    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, n_rows, rpb);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<8>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, n_rows, rpb);
+  const int64_t ne = 256 * (int64_t)k_in;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, work, dw, nblk, ne);
+  return (int)hipGetLastError();
+}
+
+// out[m][c] = sum_rows a[row][m] * b[row][c]  (a == NULL, M == 1: column sums of b).  M <= 4, C <= 256.
+extern "C" int s2l_small_outer(const float* a, int lda, int m, const float* b, int ldb, int c, float* work, float* out,
+                               int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows <= 0 || m < 1 || m > 4 || c < 1 || c > 256 || (!a && m != 1)) return S2L_E_SIZE;
+  if (!b || !work || !out) return S2L_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t rpb = (n_rows + kSplitBlocks - 1) / kSplitBlocks;
+  const int nblk = (int)((n_rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(small_outer_kernel, dim3(nblk), dim3(256), 0, st, a, lda, m, b, ldb, c, work, n_rows, rpb);
+  const int64_t ne = (int64_t)m * c;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, work, out, nblk, ne);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_backward(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
+                                     s2l_stream_t stream) {
+  if (n_pixels < 0) return S2L_E_SIZE;
+  if (n_pixels == 0) return S2L_OK;
+  if (!dpred || !areas || !drgb) return S2L_E_NULL;
+  hipLaunchKernelGGL(ensemble_bwd_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dpred, areas, drgb, n_pixels);
+  return (int)hipGetLastError();
+}
+
+// loss = weight * mean((pred - target)^2) over n elements; dpred (optional) = d loss / d pred.  work: 1024 floats.
+extern "C" int s2l_mse(const float* pred, const float* target, float weight, float* dpred, float* work, float* loss,
+                       int64_t n_elems, s2l_stream_t stream) {
+  if (n_elems <= 0) return S2L_E_SIZE;
+  if (!pred || !target || !work || !loss) return S2L_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nblk = (int)((n_elems + 255) / 256 < 1024 ? (n_elems + 255) / 256 : 1024);
+  hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, st, pred, target, 2.f * weight / (float)n_elems, dpred, work,
+                     n_elems);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, work, nblk, weight / (float)n_elems, loss);
+  return (int)hipGetLastError();
+}

@@ -60,3 +60,111 @@ class Trainer:
         time_pts = data["index"] if seed is None else data["index"] + seed
         u01 = float(torch.rand(1, device=self.device))          # eps_shift draw (training.py:200)
         return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
+
+
+class LipTrainStep:
+    """Forward + backward of the lip-MLP training objective (BASELINE config 5, fp32 parity mode):
+
+        loss = weight * mean_{frames, pixels, rgb} (predict_lip_image(frame) - target)^2
+
+    i.e. `Trainer.predict_lip_image` (training.py:158-251) + `add_photometric_loss` (:605-619) and
+    their autograd, as hand-written HIP kernels: rows -> forward with saved activations -> ensemble
+    reduce -> MSE -> ensemble backward -> dz chain -> weight-gradient GEMMs.  Returns gradients
+    keyed by the reference's state-dict names.  The tiny un-folding of the pack-time folds
+    (G0 = W0 [Wuv|Wa|Wt] etc., four 256x256x126 products) uses torch.matmul on the device.
+    """
+
+    def __init__(self, model: TalkingFace, height: int, width: int):
+        from .rendering import get_coords
+        self.model, self.h, self.w = model, int(height), int(width)
+        self.lib = _abi.load()
+        self.coords = get_coords(width, height, model.packed_weights().device)
+
+    def _f(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.coords.device)
+
+    def loss_and_grads(self, audio, frame_idx, targets, u01, weight: float = 1.0):
+        lib, m = self.lib, self.model
+        packed = m.packed_weights()
+        dev = packed.device
+        B, P = audio.shape[0], self.h * self.w
+        N = 4 * P * B
+        tgt = _dev_f32(targets, dev, "targets").reshape(B * P, 3)
+        idx = [int(i) for i in (frame_idx.tolist() if isinstance(frame_idx, torch.Tensor) else frame_idx)]
+        u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
+        st = _stream()
+        ck = _abi.check
+        feat = m.audio_merge_forward(audio)                                  # [B,64]
+        x, areas = self._f(N, 128), self._f(N)
+        hsave, dzsave = self._f(8, N, 256), self._f(8, N, 256)
+        rgb, drgb, dxa = self._f(N, 3), self._f(N, 3), self._f(N, 64)
+        pred, dpred = self._f(B * P, 3), self._f(B * P, 3)
+        loss, mwork = self._f(1), self._f(1024)
+        with torch.cuda.device(dev):
+            for b in range(B):   # rows of frame b: [b*4P, (b+1)*4P), tap-major inside
+                ck(lib.s2l_ensemble_rows(_ptr(packed), _ptr(self.coords), _ptr(feat[b]), idx[b], self.w, self.h,
+                                         ctypes.c_float(u[b]), _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, st),
+                   "s2l_ensemble_rows")
+            ck(lib.s2l_train_forward(_ptr(packed), _ptr(x), _ptr(hsave), _ptr(rgb), N, st), "s2l_train_forward")
+            for b in range(B):
+                ck(lib.s2l_ensemble_reduce(_ptr(rgb[b * 4 * P:]), _ptr(areas[b * 4 * P:]), _ptr(pred[b * P:]), P, st),
+                   "s2l_ensemble_reduce")
+            ck(lib.s2l_mse(_ptr(pred), _ptr(tgt), ctypes.c_float(weight), _ptr(dpred), _ptr(mwork), _ptr(loss),
+                           B * P * 3, st), "s2l_mse")
+            for b in range(B):
+                ck(lib.s2l_ensemble_backward(_ptr(dpred[b * P:]), _ptr(areas[b * 4 * P:]), _ptr(drgb[b * 4 * P:]), P, st),
+                   "s2l_ensemble_backward")
+            ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(hsave), _ptr(dzsave), _ptr(dxa), N, st),
+               "s2l_train_backward")
+            work = self._f(int(lib.s2l_split_work_floats(256 * 256)))
+
+            def wgrad(dz, inp, ldin, k_in):
+                out = self._f(256, k_in)
+                ck(lib.s2l_wgrad(_ptr(dz), 256, _ptr(inp), ldin, k_in, _ptr(work), _ptr(out), N, st), "s2l_wgrad")
+                return out
+
+            def colsum(src, c):
+                out = self._f(c)
+                ck(lib.s2l_small_outer(None, 0, 1, _ptr(src), c, c, _ptr(work), _ptr(out), N, st), "s2l_small_outer")
+                return out
+
+            g = {}
+            for k in range(1, 8):                          # pts_linears[k]: h_{k-1} -> h_k
+                dw = wgrad(dzsave[k], hsave[k - 1], 256, 256)
+                db = colsum(dzsave[k], 256)
+                if k == 5:
+                    dw5b, dc5 = dw, db
+                else:
+                    g[f"pts_linears.{k}.weight"], g[f"pts_linears.{k}.bias"] = dw, db
+            dG0, dc0 = wgrad(dzsave[0], x, 128, 128), colsum(dzsave[0], 256)
+            dG5 = wgrad(dzsave[5], x, 128, 128)
+            dwout = self._f(3, 256)
+            ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
+               "s2l_small_outer")
+            g["output_linear.weight"], g["output_linear.bias"] = dwout, colsum(drgb, 3)
+            # per-frame gradient of the audio feature: rows of frame b are contiguous
+            da = dxa.reshape(B, 4 * P, 64).sum(dim=1)
+
+        # un-fold G0 = W0 [Wuv|Wa|Wt], c0 = W0 (buv+ba+bt) + b0 (and the skip twins) -- tiny device GEMMs
+        sd = dict(m.named_parameters())
+
+        def unfold(w_first, names, dG, dc):
+            C = torch.cat([sd[f"{n}.weight"].detach() for n in names], dim=1)             # [256,126]
+            bsum = sum(sd[f"{n}.bias"].detach() for n in names)
+            dW = dG[:, :126] @ C.t() + torch.outer(dc, bsum)
+            dC = w_first.t() @ dG[:, :126]
+            dbs = w_first.t() @ dc
+            out = {}
+            for n, (lo, hi) in zip(names, ((0, 42), (42, 106), (106, 126))):
+                out[f"{n}.weight"], out[f"{n}.bias"] = dC[:, lo:hi].contiguous(), dbs.clone()
+            return dW, out
+
+        W0 = sd["pts_linears.0.weight"].detach()
+        W5a = sd["pts_linears.5.weight"].detach()[:, :256]
+        dW0, part = unfold(W0, ("fc_uv", "fc_audio", "fc_time"), dG0, dc0)
+        g.update(part)
+        g["pts_linears.0.weight"], g["pts_linears.0.bias"] = dW0, dc0
+        dW5a, part = unfold(W5a, ("fc_uv_skip", "fc_audio_skip", "fc_time_skip"), dG5, dc5)
+        g.update(part)
+        g["pts_linears.5.weight"], g["pts_linears.5.bias"] = torch.cat([dW5a, dw5b], dim=1), dc5
+        return loss, g, {"pred": pred.reshape(B, P, 3), "d_audio_feat": da}

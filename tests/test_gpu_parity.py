@@ -289,3 +289,57 @@ def test_empty_inputs(model, dev):
     assert model.audio_merge_forward(torch.zeros(0, 16, 29, device=dev)).shape == (0, 64)
     assert model.rgb_forward(torch.zeros(0, 66, device=dev), time_pts=0).shape == (0, 3)
     assert model.render_clip(torch.zeros(0, 16, 29, device=dev), [], 16, 16).shape == (0, 16, 16, 3)
+
+
+def _oracle_grads(sd_np, win, idx, targets, u01, h, w, weight=1.0):
+    sd_ = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    coords = O.get_coords(w, h)
+    total = 0
+    preds, feats = [], []
+    for b in range(win.shape[0]):
+        preds.append(O.predict_lip_image(sd_, coords, win[b], idx[b], h, w, u01[b]))
+    pred = torch.stack(preds)
+    loss = O.mse_loss(pred, targets, weight)
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in sd_.items()}, pred.detach()
+
+
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
+def test_train_step_gradients_vs_oracle_autograd(dev, h, w, B):
+    """BASELINE config 5 (fp32 parity mode): loss and every MLP gradient of the 4-tap ensemble + MSE
+    objective against torch autograd through the CPU oracle."""
+    np_sd = W.make_state_dict(0, "he")
+    m = make_model(dev, h, w)
+    rng = np.random.default_rng(21)
+    win = T(W.synthetic_audio(B, seed=17).astype(np.float32))
+    idx = [5 + 11 * b for b in range(B)]
+    u01 = [0.37, 0.81, 0.05][:B]
+    targets = T(rng.random((B, h * w, 3), dtype=np.float32))
+    ref_loss, ref, ref_pred = _oracle_grads(np_sd, win, idx, targets, u01, h, w, weight=1.0)
+    step = s2l.training.LipTrainStep(m, h, w)
+    loss, g, aux = step.loss_and_grads(win.to(dev), idx, targets.to(dev), u01, weight=1.0)
+    close(aux["pred"], ref_pred)
+    assert abs(float(loss) - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss))
+    mlp_keys = [k for k in ref if not k.startswith("encoder_")]
+    assert set(mlp_keys) <= set(g), set(mlp_keys) - set(g)
+    for k in mlp_keys:
+        r = ref[k]
+        scale = float(r.abs().max()) + 1e-12
+        err = float((g[k].cpu() - r).abs().max())
+        assert err <= 2e-4 * scale + 1e-9, f"{k}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_train_step_golden_gradients(golden, dev):
+    """The four gradient tensors captured from the reference's own backward (G5)."""
+    g5 = golden("g5_ensemble.npz")
+    m = make_model(dev, 16, 16)
+    step = s2l.training.LipTrainStep(m, 16, 16)
+    loss, g, _ = step.loss_and_grads(T(g5["window"])[None].to(dev), [int(g5["idx"])], T(g5["target"])[None].to(dev),
+                                     [float(g5["eps_u01"])])
+    assert abs(float(loss) - float(g5["loss"])) <= 1e-6
+    for name, ref in [("output_linear.weight", g5["g_output_w"]), ("pts_linears.7.bias", g5["g_pts7_b"]),
+                      ("fc_time.bias", g5["g_fc_time_b"])]:
+        scale = float(np.abs(ref).max())
+        assert float((g[name].cpu() - T(ref)).abs().max()) <= 2e-4 * scale, name
+    scale = float(np.abs(g5["g_pts5_w_cols8"]).max())
+    assert float((g["pts_linears.5.weight"][:, :8].cpu() - T(g5["g_pts5_w_cols8"])).abs().max()) <= 2e-4 * scale
