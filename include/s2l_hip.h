@@ -148,6 +148,12 @@ int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, flo
  * (bias gradients).  work: s2l_split_work_floats(m*c). */
 int s2l_small_outer(const float* a, int lda, int m, const float* b, int ldb, int c, float* work,
                     float* out, int64_t n_rows, s2l_stream_t stream);
+/* Audio-encoder backward (autograd of tf_nerf.py:197-213): windows [B,16,29], dfeat [B,64] ->
+ * grads [s2l_audio_grad_floats()]: encoder_conv.{0,2,4,6}.{weight,bias}, encoder_fc1.{0,2}.{weight,bias}
+ * concatenated in that order, torch layouts.  work: ceil(B/4) * s2l_audio_grad_floats() floats. */
+int64_t s2l_audio_grad_floats(void);
+int s2l_audio_backward(const float* packed, const float* windows, const float* dfeat, float* work,
+                       float* grads, int64_t n_windows, s2l_stream_t stream);
 /* loss = weight * mean((pred - target)^2) over n_elems (training.py:605-619); dpred (optional) =
  * d loss / d pred; work: 1024 floats; loss: 1 float (device). */
 int s2l_mse(const float* pred, const float* target, float weight, float* dpred, float* work,

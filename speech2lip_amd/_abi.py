@@ -55,6 +55,8 @@ EXPORTS = {
     "s2l_split_work_floats": (c_int64, [c_int64]),
     "s2l_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_small_outer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_audio_grad_floats": (c_int64, []),
+    "s2l_audio_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_mse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }

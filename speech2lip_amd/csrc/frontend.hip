@@ -71,6 +71,144 @@ __global__ __launch_bounds__(256) void audio_encode_kernel(const float* __restri
   }
 }
 
+// ---- audio encoder backward (training) --------------------------------------------------------
+// Gradient sections of one block's partial, torch layouts, in state-dict order.
+constexpr int kAG_C0W = 0, kAG_C0B = kAG_C0W + 32 * 29 * 3, kAG_C2W = kAG_C0B + 32, kAG_C2B = kAG_C2W + 32 * 32 * 3,
+              kAG_C4W = kAG_C2B + 32, kAG_C4B = kAG_C4W + 64 * 32 * 3, kAG_C6W = kAG_C4B + 64,
+              kAG_C6B = kAG_C6W + 64 * 64 * 3, kAG_F0W = kAG_C6B + 64, kAG_F0B = kAG_F0W + 64 * 64,
+              kAG_F2W = kAG_F0B + 64, kAG_F2B = kAG_F2W + 64 * 64, kAudioGradFloats = kAG_F2B + 64;
+
+__device__ inline float lrelu_slope(float post) { return post > 0.f ? 1.f : 0.02f; }
+
+// Backward of one Conv1d(k3,s2,p1)+LeakyReLU stage over kFB frames in LDS.
+//   xin [kFB][CIN][TIN] = stage input (post-activation of the previous stage)
+//   gy  [kFB][COUT][TIN/2] = gradient w.r.t. this stage's PRE-activation
+//   -> dw [COUT][CIN][3], db [COUT] (block partials); gx [kFB][CIN][TIN] = gradient w.r.t. the previous
+//      stage's pre-activation (skipped when gx == nullptr)
+template <int CIN, int COUT, int TIN>
+__device__ inline void conv_stage_bwd(const float* __restrict__ wT, const float* xin, const float* gy, float* dw, float* db,
+                                      float* gx, int nvalid) {
+  constexpr int TOUT = TIN / 2;
+  for (int item = threadIdx.x; item < COUT * CIN * 3; item += blockDim.x) {
+    const int k = item % 3, c = (item / 3) % CIN, o = item / (3 * CIN);
+    float acc = 0.f;
+    for (int fb = 0; fb < nvalid; ++fb)
+#pragma unroll
+      for (int tau = 0; tau < TOUT; ++tau) {
+        const int t = 2 * tau + k - 1;
+        if (t >= 0 && t < TIN) acc = fmaf(gy[(fb * COUT + o) * TOUT + tau], xin[(fb * CIN + c) * TIN + t], acc);
+      }
+    dw[item] = acc;
+  }
+  for (int o = threadIdx.x; o < COUT; o += blockDim.x) {
+    float acc = 0.f;
+    for (int fb = 0; fb < nvalid; ++fb)
+      for (int tau = 0; tau < TOUT; ++tau) acc += gy[(fb * COUT + o) * TOUT + tau];
+    db[o] = acc;
+  }
+  if (gx) {
+    for (int item = threadIdx.x; item < kFB * CIN * TIN; item += blockDim.x) {
+      const int t = item % TIN, c = (item / TIN) % CIN, fb = item / (TIN * CIN);
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int num = t + 1 - k;                 // t = 2*tau + k - 1
+        if (num >= 0 && (num & 1) == 0 && (num >> 1) < TOUT) {
+          const int tau = num >> 1;
+          for (int o = 0; o < COUT; ++o) acc = fmaf(wT[(c * 3 + k) * COUT + o], gy[(fb * COUT + o) * TOUT + tau], acc);
+        }
+      }
+      gx[item] = acc * lrelu_slope(xin[item]);
+    }
+  }
+  __syncthreads();
+}
+
+// Recomputes the encoder forward for kFB frames in LDS, then back-propagates dfeat [B,64] to every
+// encoder parameter; writes this block's partial sums (reduced over blocks by reduce_rows_kernel).
+__global__ __launch_bounds__(256) void audio_backward_kernel(const float* __restrict__ packed,
+                                                            const float* __restrict__ windows,
+                                                            const float* __restrict__ dfeat, float* __restrict__ partial,
+                                                            int64_t n) {
+  __shared__ float x0[kFB * 29 * 16];
+  __shared__ float y1[kFB * 32 * 8], g1[kFB * 32 * 8];
+  __shared__ float y2[kFB * 32 * 4], g2[kFB * 32 * 4];
+  __shared__ float y3[kFB * 64 * 2], g3[kFB * 64 * 2];
+  __shared__ float y4[kFB * 64], g4[kFB * 64];
+  __shared__ float f1[kFB * 64], gf1[kFB * 64], gout[kFB * 64];
+  const int64_t f0 = (int64_t)blockIdx.x * kFB;
+  const int nvalid = (int)((n - f0) < kFB ? (n - f0) : kFB);
+  float* P = partial + (int64_t)blockIdx.x * kAudioGradFloats;
+  for (int i = threadIdx.x; i < kFB * 16 * 29; i += blockDim.x) {
+    const int fb = i / (16 * 29), r = i - fb * 16 * 29;
+    const int t = r / 29, c = r - t * 29;
+    const int64_t f = f0 + fb < n ? f0 + fb : n - 1;
+    x0[(fb * 29 + c) * 16 + t] = windows[f * 16 * 29 + r];
+  }
+  __syncthreads();
+  conv_stage<29, 32, 16>(packed + OFF_C0W, packed + OFF_C0B, x0, y1);
+  conv_stage<32, 32, 8>(packed + OFF_C2W, packed + OFF_C2B, y1, y2);
+  conv_stage<32, 64, 4>(packed + OFF_C4W, packed + OFF_C4B, y2, y3);
+  conv_stage<64, 64, 2>(packed + OFF_C6W, packed + OFF_C6B, y3, y4);
+  const int fb = threadIdx.x >> 6, o = threadIdx.x & 63;
+  {
+    float acc = packed[OFF_F0B + o];
+    for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + k * 64 + o], y4[fb * 64 + k], acc);
+    f1[fb * 64 + o] = lrelu(acc);
+    gout[fb * 64 + o] = fb < nvalid ? dfeat[(f0 + fb) * 64 + o] : 0.f;
+  }
+  __syncthreads();
+  // Linear(64,64) #2: y = W2 f1 + b2.  packed F2W is [in k][out o].
+  for (int item = threadIdx.x; item < 64 * 64; item += blockDim.x) {
+    const int oo = item >> 6, kk = item & 63;
+    float acc = 0.f;
+    for (int b = 0; b < nvalid; ++b) acc = fmaf(gout[b * 64 + oo], f1[b * 64 + kk], acc);
+    P[kAG_F2W + item] = acc;
+  }
+  if (threadIdx.x < 64) {
+    float acc = 0.f;
+    for (int b = 0; b < nvalid; ++b) acc += gout[b * 64 + threadIdx.x];
+    P[kAG_F2B + threadIdx.x] = acc;
+  }
+  {
+    float acc = 0.f;   // d f1[fb][o] = sum_out W2[out][o] gout[fb][out], then through the LeakyReLU
+    for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F2W + o * 64 + k], gout[fb * 64 + k], acc);
+    gf1[fb * 64 + o] = acc * lrelu_slope(f1[fb * 64 + o]);
+  }
+  __syncthreads();
+  // Linear(64,64) #1: f1_pre = W1 y4 + b1
+  for (int item = threadIdx.x; item < 64 * 64; item += blockDim.x) {
+    const int oo = item >> 6, kk = item & 63;
+    float acc = 0.f;
+    for (int b = 0; b < nvalid; ++b) acc = fmaf(gf1[b * 64 + oo], y4[b * 64 + kk], acc);
+    P[kAG_F0W + item] = acc;
+  }
+  if (threadIdx.x < 64) {
+    float acc = 0.f;
+    for (int b = 0; b < nvalid; ++b) acc += gf1[b * 64 + threadIdx.x];
+    P[kAG_F0B + threadIdx.x] = acc;
+  }
+  {
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + o * 64 + k], gf1[fb * 64 + k], acc);
+    g4[fb * 64 + o] = acc * lrelu_slope(y4[fb * 64 + o]);   // gradient w.r.t. conv6 pre-activation (T = 1)
+  }
+  __syncthreads();
+  conv_stage_bwd<64, 64, 2>(packed + OFF_C6W, y3, g4, P + kAG_C6W, P + kAG_C6B, g3, nvalid);
+  conv_stage_bwd<32, 64, 4>(packed + OFF_C4W, y2, g3, P + kAG_C4W, P + kAG_C4B, g2, nvalid);
+  conv_stage_bwd<32, 32, 8>(packed + OFF_C2W, y1, g2, P + kAG_C2W, P + kAG_C2B, g1, nvalid);
+  conv_stage_bwd<29, 32, 16>(packed + OFF_C0W, x0, g1, P + kAG_C0W, P + kAG_C0B, nullptr, nvalid);
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                         int n_blocks, int n_elems) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elems) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * n_elems + e];
+  out[e] = s;
+}
+
 // q0[f] = W0 (Wa a_f + Wt PE(idx_f) + bsum0) + b0 ; q5[f] likewise with the skip projections.
 // 256 threads: thread n owns output feature n for kFB frames.
 __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restrict__ packed,
@@ -256,6 +394,23 @@ extern "C" int s2l_pixel_tables(const float* packed, const float* coords, float*
   const int64_t blocks = (hw + s2l::kPB - 1) / s2l::kPB;
   hipLaunchKernelGGL(s2l::pixel_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      packed, coords, p0, p5, hw);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t s2l_audio_grad_floats(void) { return s2l::kAudioGradFloats; }
+
+// Encoder backward: windows [B,16,29], dfeat [B,64] -> grads [s2l_audio_grad_floats()] = the 12 encoder
+// tensors in state-dict order and torch layout (encoder_conv.{0,2,4,6}.{weight,bias}, encoder_fc1.{0,2}.*).
+// work: ceil(B/4) * s2l_audio_grad_floats() floats.
+extern "C" int s2l_audio_backward(const float* packed, const float* windows, const float* dfeat, float* work, float* grads,
+                                  int64_t n, s2l_stream_t stream) {
+  if (n <= 0) return S2L_E_SIZE;
+  if (!packed || !windows || !dfeat || !work || !grads) return S2L_E_NULL;
+  const int blocks = (int)((n + s2l::kFB - 1) / s2l::kFB);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(s2l::audio_backward_kernel, dim3(blocks), dim3(256), 0, st, packed, windows, dfeat, work, n);
+  hipLaunchKernelGGL(s2l::reduce_rows_kernel, dim3((s2l::kAudioGradFloats + 255) / 256), dim3(256), 0, st, work, grads,
+                     blocks, (int)s2l::kAudioGradFloats);
   return (int)hipGetLastError();
 }
 

@@ -142,8 +142,18 @@ class LipTrainStep:
             ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
                "s2l_small_outer")
             g["output_linear.weight"], g["output_linear.bias"] = dwout, colsum(drgb, 3)
-            # per-frame gradient of the audio feature: rows of frame b are contiguous
-            da = dxa.reshape(B, 4 * P, 64).sum(dim=1)
+            # per-frame gradient of the audio feature (rows of frame b are contiguous), then the encoder backward
+            da = dxa.reshape(B, 4 * P, 64).sum(dim=1).contiguous()
+            na = int(lib.s2l_audio_grad_floats())
+            awork, agrads = self._f(((B + 3) // 4) * na), self._f(na)
+            a32 = _dev_f32(audio, dev, "audio")
+            ck(lib.s2l_audio_backward(_ptr(packed), _ptr(a32), _ptr(da), _ptr(awork), _ptr(agrads), B, st),
+               "s2l_audio_backward")
+            off = 0
+            for name in _abi.TENSOR_ORDER[:12]:
+                p_ = dict(m.named_parameters())[name]
+                g[name] = agrads[off:off + p_.numel()].reshape(p_.shape)
+                off += p_.numel()
 
         # un-fold G0 = W0 [Wuv|Wa|Wt], c0 = W0 (buv+ba+bt) + b0 (and the skip twins) -- tiny device GEMMs
         sd = dict(m.named_parameters())

@@ -320,9 +320,8 @@ def test_train_step_gradients_vs_oracle_autograd(dev, h, w, B):
     loss, g, aux = step.loss_and_grads(win.to(dev), idx, targets.to(dev), u01, weight=1.0)
     close(aux["pred"], ref_pred)
     assert abs(float(loss) - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss))
-    mlp_keys = [k for k in ref if not k.startswith("encoder_")]
-    assert set(mlp_keys) <= set(g), set(mlp_keys) - set(g)
-    for k in mlp_keys:
+    assert set(ref) <= set(g), set(ref) - set(g)      # every hot-path tensor, audio encoder included
+    for k in ref:
         r = ref[k]
         scale = float(r.abs().max()) + 1e-12
         err = float((g[k].cpu() - r).abs().max())
