@@ -178,3 +178,12 @@ class LipTrainStep:
         g.update(part)
         g["pts_linears.5.weight"], g["pts_linears.5.bias"] = torch.cat([dW5a, dw5b], dim=1), dc5
         return loss, g, {"pred": pred.reshape(B, P, 3), "d_audio_feat": da}
+
+
+def apply_grads(model: TalkingFace, grads) -> None:
+    """Install the gradients returned by `LipTrainStep.loss_and_grads` as `.grad` of the matching
+    parameters, so a stock optimizer (the reference uses Adam(lr=1e-4), train.py:128) can step."""
+    params = dict(model.named_parameters())
+    for name, g in grads.items():
+        p = params[name]
+        p.grad = g.reshape(p.shape).to(p.dtype).contiguous()
