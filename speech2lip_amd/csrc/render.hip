@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
     }
   };
 
-  // first step (q0 of the first tile) landed and published; top the ring up to kDepth in flight
+  // first step (q0 of the first tile) landed and published (and the bias block written by every
+  // wave); top the ring up to kDepth in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   wait_vmcnt<4 * (kDepth - 1)>();
   asm volatile("s_barrier" ::: "memory");
   issue_w(kDepth - kStepW0, kDepth);
