@@ -141,9 +141,10 @@ int s2l_train_backward(const float* packed, const float* drgb, const float* hsav
 /* Scratch floats for the split reductions below, for a result of n_elems elements. */
 int64_t s2l_split_work_floats(int64_t n_elems);
 /* dw [256,k_in] = dz[:, :256]^T in[:, :k_in] over n_rows rows (k_in = 128 or 256; ld* = row strides
- * in floats); fp32 MFMA, deterministic two-stage reduction; work: s2l_split_work_floats(256*k_in). */
+ * in floats) and, when db != NULL, db [256] = column sums of dz (the bias gradient, free in the same
+ * pass); fp32 MFMA, deterministic two-stage reduction; work: s2l_split_work_floats(256*k_in). */
 int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, float* work, float* dw,
-              int64_t n_rows, s2l_stream_t stream);
+              float* db, int64_t n_rows, s2l_stream_t stream);
 /* out [m,c] = a[:, :m]^T b[:, :c] (m <= 4, c <= 256); a == NULL with m == 1: column sums of b
  * (bias gradients).  work: s2l_split_work_floats(m*c). */
 int s2l_small_outer(const float* a, int lda, int m, const float* b, int ldb, int c, float* work,

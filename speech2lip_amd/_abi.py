@@ -53,7 +53,7 @@ EXPORTS = {
     "s2l_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_split_work_floats": (c_int64, [c_int64]),
-    "s2l_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_small_outer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_audio_grad_floats": (c_int64, []),
     "s2l_audio_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -24,8 +24,8 @@ __device__ inline f4 mfma16w(float a, float b, f4 c) { return __builtin_amdgcn_m
 // Wave w of 4 owns out-feature blocks 4w..4w+3 x all KB in-feature blocks: 4*KB accumulators of 4 registers.
 template <int KB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ in,
-                                                    int ldin, float* __restrict__ partial, int64_t n_rows,
-                                                    int64_t rows_per_block) {
+                                                    int ldin, float* __restrict__ partial, float* __restrict__ bias_partial,
+                                                    int64_t n_rows, int64_t rows_per_block) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int q = lane >> 4, i = lane & 15;
@@ -33,24 +33,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
   int64_t r1 = r0 + rows_per_block;
   if (r1 > n_rows) r1 = n_rows;
   f4 acc[4][KB];
+  float asum[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of dz (bias gradient) ride along for free
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < KB; ++n) acc[m][n] = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = r0; r < r1; r += 4) {
+  // branch-free operand loads: rows past the block's end read a valid (clamped) row and are
+  // cancelled by zeroing the A operand only (inputs are finite)
+  auto load = [&](int64_t r, float (&a)[4], float (&b)[KB]) {
     const int64_t row = r + q;
-    const bool ok = row < r1;
-    const float* dzr = dz + (ok ? row : r0) * ldz + wave * 64 + i;
-    const float* inr = in + (ok ? row : r0) * ldin + i;
-    float a[4], b[KB];
+    const float okf = row < r1 ? 1.f : 0.f;
+    const int64_t rc = row < n_rows ? row : n_rows - 1;
+    const float* dzr = dz + rc * ldz + wave * 64 + i;
+    const float* inr = in + rc * ldin + i;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = ok ? dzr[m * 16] : 0.f;
+    for (int m = 0; m < 4; ++m) a[m] = dzr[m * 16] * okf;
 #pragma unroll
-    for (int n = 0; n < KB; ++n) b[n] = ok ? inr[n * 16] : 0.f;
+    for (int n = 0; n < KB; ++n) b[n] = inr[n * 16];
+  };
+  float a0[4], b0[KB], a1[4], b1[KB];
+  load(r0, a0, b0);
+  for (int64_t r = r0; r < r1; r += 8) {   // two 4-row k-steps per iteration, operands loaded one step ahead
+    load(r + 4, a1, b1);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      asum[m] += a0[m];
 #pragma unroll
-      for (int n = 0; n < KB; ++n) acc[m][n] = mfma16w(a[m], b[n], acc[m][n]);
+      for (int n = 0; n < KB; ++n) acc[m][n] = mfma16w(a0[m], b0[n], acc[m][n]);
+    }
+    load(r + 8, a0, b0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      asum[m] += a1[m];
+#pragma unroll
+      for (int n = 0; n < KB; ++n) acc[m][n] = mfma16w(a1[m], b1[n], acc[m][n]);
+    }
   }
   // D[row = 4q + r -> out feature][col = i -> in feature]
   float* p = partial + (int64_t)blockIdx.x * 256 * (KB * 16);
@@ -60,6 +77,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
     for (int n = 0; n < KB; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[(int64_t)(wave * 64 + m * 16 + 4 * q + r) * (KB * 16) + n * 16 + i] = acc[m][n][r];
+  if (bias_partial) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float v = asum[m];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (q == 0) bias_partial[(int64_t)blockIdx.x * 256 + wave * 64 + m * 16 + i] = v;
+    }
+  }
 }
 
 // out[e] = sum over blocks (fixed order) of partial[blk][e]
@@ -165,22 +191,24 @@ extern "C" int s2l_train_backward(const float* packed, const float* drgb, const 
   return launch_general_mlp_bwd(packed, drgb, hsave, dzsave, dxa, n_rows, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int64_t s2l_split_work_floats(int64_t n_elems) { return n_elems < 0 ? 0 : n_elems * kSplitBlocks; }
+extern "C" int64_t s2l_split_work_floats(int64_t n_elems) { return n_elems < 0 ? 0 : (n_elems + 256) * kSplitBlocks; }
 
-extern "C" int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, float* work, float* dw,
+extern "C" int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, float* work, float* dw, float* db,
                          int64_t n_rows, s2l_stream_t stream) {
   if (n_rows <= 0 || (k_in != 128 && k_in != 256) || ldz < 256 || ldin < k_in) return S2L_E_SIZE;
   if (!dz || !in || !work || !dw) return S2L_E_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int64_t rpb = (n_rows + kSplitBlocks - 1) / kSplitBlocks;
-  rpb = (rpb + 3) / 4 * 4;
+  rpb = (rpb + 7) / 8 * 8;
   const int nblk = (int)((n_rows + rpb - 1) / rpb);
-  if (k_in == 256)
-    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, n_rows, rpb);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<8>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, n_rows, rpb);
   const int64_t ne = 256 * (int64_t)k_in;
+  float* bwork = db ? work + (int64_t)kSplitBlocks * ne : nullptr;   // bias partials behind the dW partials
+  if (k_in == 256)
+    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, bwork, n_rows, rpb);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<8>, dim3(nblk), dim3(256), 0, st, dz, ldz, in, ldin, work, bwork, n_rows, rpb);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, work, dw, nblk, ne);
+  if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, bwork, db, nblk, (int64_t)256);
   return (int)hipGetLastError();
 }
 

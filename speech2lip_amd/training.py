@@ -118,10 +118,10 @@ class LipTrainStep:
                "s2l_train_backward")
             work = self._f(int(lib.s2l_split_work_floats(256 * 256)))
 
-            def wgrad(dz, inp, ldin, k_in):
-                out = self._f(256, k_in)
-                ck(lib.s2l_wgrad(_ptr(dz), 256, _ptr(inp), ldin, k_in, _ptr(work), _ptr(out), N, st), "s2l_wgrad")
-                return out
+            def wgrad(dz, inp, ldin, k_in, want_bias=True):
+                out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
+                ck(lib.s2l_wgrad(_ptr(dz), 256, _ptr(inp), ldin, k_in, _ptr(work), _ptr(out), _ptr(db), N, st), "s2l_wgrad")
+                return out, db
 
             def colsum(src, c):
                 out = self._f(c)
@@ -130,14 +130,13 @@ class LipTrainStep:
 
             g = {}
             for k in range(1, 8):                          # pts_linears[k]: h_{k-1} -> h_k
-                dw = wgrad(dzsave[k], hsave[k - 1], 256, 256)
-                db = colsum(dzsave[k], 256)
+                dw, db = wgrad(dzsave[k], hsave[k - 1], 256, 256)
                 if k == 5:
                     dw5b, dc5 = dw, db
                 else:
                     g[f"pts_linears.{k}.weight"], g[f"pts_linears.{k}.bias"] = dw, db
-            dG0, dc0 = wgrad(dzsave[0], x, 128, 128), colsum(dzsave[0], 256)
-            dG5 = wgrad(dzsave[5], x, 128, 128)
+            dG0, dc0 = wgrad(dzsave[0], x, 128, 128)
+            dG5, _ = wgrad(dzsave[5], x, 128, 128, want_bias=False)
             dwout = self._f(3, 256)
             ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
                "s2l_small_outer")
