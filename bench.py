@@ -72,7 +72,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
-    ap.add_argument("--chunks", type=int, default=4, help="all-gather chunks per step (N > 1)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="all-gather chunks per step (N > 1).  1 = render the clip in one persistent launch, then one "
+                         "all-gather: the renderer fills every CU (151 KiB LDS + all registers per workgroup), so an "
+                         "RCCL kernel overlapped with it can only start on CUs a finished workgroup has released and "
+                         "then delays the statically-striped workgroups of the next launch; >1 enables the overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
     args = ap.parse_args()
