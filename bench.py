@@ -31,7 +31,7 @@ H = W_ = 96
 HW = H * W_
 FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
 FP32_MFMA_PEAK = 157.3e12
-TRAFFIC_BYTES_PER_FRAME = 9.14e8 / 1000   # measured with PMC counters, see profiles/r01c_rocprofv3_summary.txt
+TRAFFIC_BYTES_PER_FRAME = 9.14e8 / 1000   # measured with PMC counters, see profiles/r01d_rocprofv3_summary.txt
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -158,7 +158,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):
-                         # profiles/r01c_rocprofv3_summary.txt measured 9.14e8 B per 1000-frame launch
+                         # profiles/r01d_rocprofv3_summary.txt measured 9.14e8 B per 1000-frame launch
                          "traffic": round(TRAFFIC_BYTES_PER_FRAME * frames_per_launch),
                          "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
