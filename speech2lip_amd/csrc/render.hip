@@ -331,18 +331,23 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   a.ntiles = (int)ntiles;
 
-  static int n_cu = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  // per-device one-time setup (CU count, >64 KiB dynamic-LDS opt-in); one process per GPU is the
+  // normal deployment, but nothing here assumes it
+  static int n_cu_of[64] = {0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= 64) return S2L_E_SIZE;
+  if (n_cu_of[dev] == 0) {
+    int n = 0;
+    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_kernel<G>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    n_cu_of[dev] = n;
   }
+  const int n_cu = n_cu_of[dev];
   // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
   hipLaunchKernelGGL((render_tiles_kernel<G>), dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);

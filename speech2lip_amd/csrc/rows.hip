@@ -370,16 +370,20 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(RowsBwdArgs a) {
 }
 
 static int rows_grid(int ntiles, const void* kernel, int* grid) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  static int n_cu_of[64] = {0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  *grid = ntiles < n_cu ? ntiles : n_cu;
+  if (dev < 0 || dev >= 64) return S2L_E_SIZE;
+  if (n_cu_of[dev] == 0) {
+    int n = 0;
+    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    n_cu_of[dev] = n;
+  }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);   // idempotent, per device
+  if (e != hipSuccess) return (int)e;
+  *grid = ntiles < n_cu_of[dev] ? ntiles : n_cu_of[dev];
   return 0;
 }
 
