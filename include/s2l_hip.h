@@ -182,6 +182,20 @@ int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride
 int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm, int face_h, int face_w,
                          s2l_stream_t stream);
 
+/* ---- post-fusion U-Net: eval-mode SimpleUnetLight --------------------------------
+ * Replaces src/face_simple/models/SimpleUnetLight.py:99-111 as called at tf_nerf.py:387.
+ * s2l_unet_pack: tensors_host = HOST array of 52 DEVICE pointers: for each of the ten 3x3 convolutions
+ * in execution order (inc.0, inc.3, down1.0, down1.3, down2.0, down2.3, up1.0, up1.3, up2.0, up2.3)
+ * {conv.weight [co,ci,3,3], bn.weight, bn.bias, bn.running_mean, bn.running_var}, then
+ * outc.conv.weight [3,64,1,1], outc.conv.bias [3].  BatchNorm (eps = bn_eps) is folded into the packed
+ * weights.  s2l_unet_forward: x [F,H,W,3] NHWC -> out [F,H,W,3]; H, W >= 4;
+ * work: s2l_unet_work_floats(H, W, F) floats of scratch for the activations. */
+int64_t s2l_unet_packed_floats(void);
+int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames);
+int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
+int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height,
+                     int width, int64_t n_frames, s2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,40 @@ def mse_loss(pred: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> t
     return ((pred - target) ** 2).mean() * weight
 
 
+# --------------------------------------------------------------------------- §8f-1 U-Net
+def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet.", eps: float = 1e-5) -> torch.Tensor:
+    """Eval-mode `SimpleUnetLight` on NHWC input [B,H,W,3] -> [B,H,W,3].
+    Reference: src/face_simple/models/SimpleUnetLight.py:16-111 (DoubleConv = (conv3x3 no bias -> BatchNorm
+    -> ReLU) x2; Down = MaxPool2d(2) + DoubleConv; Up = bilinear x2 (align_corners=True), pad to the
+    skip's size, cat([skip, up]) + DoubleConv(in, out, in//2); outc = conv1x1), called from
+    tf_nerf.py:387 on `rgb_merged_new`."""
+    def cbr(x, name):
+        head, idx = name.rsplit(".", 1)
+        bn = f"{prefix}{head}.{int(idx) + 1}"
+        y = F.conv2d(x, sd[f"{prefix}{name}.weight"], None, padding=1)
+        scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + eps)
+        y = (y - sd[bn + ".running_mean"].view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + sd[bn + ".bias"].view(1, -1, 1, 1)
+        return F.relu(y)
+
+    def double(x, stem):
+        return cbr(cbr(x, stem + ".0"), stem + ".3")
+
+    def up(xlow, skip, stem):
+        xu = F.interpolate(xlow, scale_factor=2, mode="bilinear", align_corners=True)
+        dy, dx = skip.shape[2] - xu.shape[2], skip.shape[3] - xu.shape[3]
+        xu = F.pad(xu, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return double(torch.cat([skip, xu], dim=1), stem)
+
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x1 = double(x, "inc.double_conv")
+    x2 = double(F.max_pool2d(x1, 2), "down1.maxpool_conv.1.double_conv")
+    x3 = double(F.max_pool2d(x2, 2), "down2.maxpool_conv.1.double_conv")
+    y = up(x3, x2, "up1.conv.double_conv")
+    y = up(y, x1, "up2.conv.double_conv")
+    y = F.conv2d(y, sd[prefix + "outc.conv.weight"], sd[prefix + "outc.conv.bias"])
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
 # --------------------------------------------------------------------------- metrics
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
     mse = float(((a.double() - b.double()) ** 2).mean())

@@ -4,6 +4,8 @@ from .rendering import get_coords
 from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
 from . import training
 from .training import LipTrainStep, Trainer, predict_lip_image
+from .unet import SimpleUnetLight
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
-           "predict_lip_image", "LipTrainStep", "training"]
+           "predict_lip_image", "LipTrainStep", "training",
+           "SimpleUnetLight"]

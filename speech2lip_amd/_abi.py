@@ -58,6 +58,10 @@ EXPORTS = {
     "s2l_audio_grad_floats": (c_int64, []),
     "s2l_audio_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_mse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_unet_packed_floats": (c_int64, []),
+    "s2l_unet_work_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),
+    "s2l_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

@@ -1,0 +1,395 @@
+// Post-fusion U-Net (the first "next" row after the hot path): eval-mode
+// SimpleUnetLight (src/face_simple/models/SimpleUnetLight.py:16-111), the network
+// TalkingFace.post_fusion2_onlylip_light applies to the composite (tf_nerf.py:387).
+//
+//   x1 = DoubleConv(3->64)(x)                      @ H x W
+//   x2 = DoubleConv(64->128)(maxpool2(x1))         @ H/2
+//   x3 = DoubleConv(128->128)(maxpool2(x2))        @ H/4
+//   y  = DoubleConv(256->64, mid 128)(cat[x2, up2(x3)])
+//   y  = DoubleConv(128->64, mid 64)(cat[x1, up2(y)])
+//   out = conv1x1(64->3)(y)
+// DoubleConv = (conv3x3 no bias -> BatchNorm -> ReLU) x 2; BatchNorm is folded into the weights at
+// pack time (eval mode: running statistics).  up2 = bilinear x2 with align_corners=True, zero-padded
+// to the skip's size.  Activations are NHWC fp32 in HBM.
+//
+// conv3x3 is an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32): a workgroup computes a 16x16
+// pixel tile x 64 output channels; input channels go through LDS 16 at a time (18x18 halo tile,
+// 20.7 KB) together with that chunk's weights in A-operand order (9 taps x 4 M-blocks, 36.9 KB);
+// per tap a wave issues 4 + 4 ds_read_b128 for 64 MFMAs.  57.6 KB of LDS per workgroup -> two
+// workgroups per CU overlap one another's staging.  The concat is virtual (two input pointers), the
+// final 1x1 convolution is fused into the last conv's epilogue.
+#include "s2l_common.h"
+
+namespace s2l {
+
+// ---- packed layout ---------------------------------------------------------------------------------
+struct ConvSpec {
+  int cin, cout;
+};
+constexpr ConvSpec kUnetConvs[10] = {{3, 64},    {64, 64},   {64, 128}, {128, 128}, {128, 128},
+                                     {128, 128}, {256, 128}, {128, 64}, {128, 64},  {64, 64}};
+constexpr int kChunkFloats = 9 * 4 * 64 * 4;   // one (cout tile of 64, cin chunk of 16): 9 taps x 4 M-blocks x 64 lanes x 4
+
+__host__ __device__ constexpr int64_t unet_w_off(int layer) {
+  int64_t off = 0;
+  for (int l = 0; l < layer; ++l)
+    off += l == 0 ? 64 * 27 : (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
+  return off;
+}
+constexpr int64_t kUnetBiasOff = unet_w_off(10);                   // folded biases, layer by layer
+__host__ __device__ constexpr int64_t unet_b_off(int layer) {
+  int64_t off = kUnetBiasOff;
+  for (int l = 0; l < layer; ++l) off += kUnetConvs[l].cout;
+  return off;
+}
+constexpr int64_t kUnetOutW = unet_b_off(10);                      // outc weight [3][64]
+constexpr int64_t kUnetOutB = kUnetOutW + 192;                     // outc bias [4]
+constexpr int64_t kUnetPackedFloats = kUnetOutB + 4;
+
+struct UnetTensors {
+  const float* w[10];
+  const float* gamma[10];
+  const float* beta[10];
+  const float* mean[10];
+  const float* var[10];
+  const float* outw;
+  const float* outb;
+};
+
+// one thread per packed weight element of a 3x3 layer (layer >= 1): BatchNorm folded in
+__global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
+  const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
+  const int64_t n = (int64_t)(cout / 64) * (cin / 16) * kChunkFloats;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int ks = e & 3, lane = (e >> 2) & 63, mb = (e >> 8) & 3;
+  const int tap = (int)((e >> 10) % 9);
+  const int64_t chunk = e / kChunkFloats;
+  const int cc = (int)(chunk % (cin / 16)), ct = (int)(chunk / (cin / 16));
+  const int co = ct * 64 + mb * 16 + (lane & 15);
+  const int ci = cc * 16 + 4 * (lane >> 4) + ks;
+  const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  packed[unet_w_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + tap] * scale;
+}
+
+__global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float eps) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt = gridDim.x * blockDim.x;
+  for (int i = tid; i < 64 * 27; i += nt) {   // first conv, plain [co][ci*9 + tap], folded
+    const int co = i / 27;
+    packed[unet_w_off(0) + i] = t.w[0][i] * (t.gamma[0][co] / sqrtf(t.var[0][co] + eps));
+  }
+  int64_t off = kUnetBiasOff;
+  for (int l = 0; l < 10; ++l) {
+    for (int co = tid; co < kUnetConvs[l].cout; co += nt) {
+      const float scale = t.gamma[l][co] / sqrtf(t.var[l][co] + eps);
+      packed[off + co] = t.beta[l][co] - t.mean[l][co] * scale;
+    }
+    off += kUnetConvs[l].cout;
+  }
+  for (int i = tid; i < 192; i += nt) packed[kUnetOutW + i] = t.outw[i];
+  for (int i = tid; i < 4; i += nt) packed[kUnetOutB + i] = i < 3 ? t.outb[i] : 0.f;
+}
+
+// ---- first conv: 3 -> 64, direct (0.5 % of the FLOPs) -------------------------------------------------
+// thread = (pixel, 4 output channels); block = 16 pixels x 16 channel quads
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int H, int W) {
+  __shared__ float ws[64 * 27];
+  for (int i = threadIdx.x; i < 64 * 27; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int64_t frame = blockIdx.y;
+  const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int cq = threadIdx.x & 15;
+  if (pix >= H * W) return;
+  const int py = pix / W, px = pix - py * W;
+  const float* xf = x + frame * (int64_t)H * W * 3;
+  float in[27];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+    const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) in[c * 9 + t] = ok ? xf[((int64_t)yy * W + xx) * 3 + c] : 0.f;
+  }
+  f4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = cq * 4 + r;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc = fmaf(ws[co * 27 + k], in[k], acc);
+    o[r] = fmaxf(acc + b[co], 0.f);
+  }
+  *reinterpret_cast<f4*>(y + (frame * (int64_t)H * W + pix) * 64 + cq * 4) = o;
+}
+
+// ---- conv3x3 implicit GEMM ---------------------------------------------------------------------------
+struct ConvArgs {
+  const float* inA;   // [F,H,W,CA]
+  const float* inB;   // [F,H,W,CB] or null (virtual concat: channels of A first)
+  const float* w;     // packed chunks [cout/64][cin/16][kChunkFloats]
+  const float* bias;  // [cout]
+  float* out;         // [F,H,W,cout]                   (unused when FUSE_OUT)
+  const float* outw;  // FUSE_OUT: [3][64], outb [3], out3 [F,H,W,3]
+  const float* outb;
+  float* out3;
+  int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
+};
+
+__device__ __forceinline__ f4 mfma16u(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <bool FUSE_OUT>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_in[18 * 18 * 16];
+  __shared__ __attribute__((aligned(16))) float lds_w[kChunkFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, px = lane & 15;
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  const int ct = blockIdx.z % a.n_ct;
+  const int64_t frame = blockIdx.z / a.n_ct;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int cin = a.CA + a.CB;
+  const int nchunks = cin / 16;
+  const float* inA = a.inA + frame * (int64_t)a.H * a.W * a.CA;
+  const float* inB = a.inB ? a.inB + frame * (int64_t)a.H * a.W * a.CB : nullptr;
+
+  f4 acc[4][4];   // [M-block][pixel group = tile row 4*wave + g]
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const f4 b = *reinterpret_cast<const f4*>(a.bias + ct * 64 + mb * 16 + 4 * q);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[mb][g] = b;
+  }
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    // stage the 18x18 halo tile of this 16-channel chunk (zero outside the image) and its weights
+    const bool fromA = cc * 16 < a.CA;
+    const float* src = fromA ? inA : inB;
+    const int C = fromA ? a.CA : a.CB;
+    const int coff = fromA ? cc * 16 : cc * 16 - a.CA;
+    for (int i = threadIdx.x; i < 18 * 18 * 4; i += 256) {
+      const int pi = i >> 2, qq = i & 3;
+      const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        v = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * qq);
+      *reinterpret_cast<f4*>(lds_in + pi * 16 + 4 * qq) = v;
+    }
+    const f4* wsrc = reinterpret_cast<const f4*>(a.w + ((int64_t)ct * nchunks + cc) * kChunkFloats);
+    for (int i = threadIdx.x; i < kChunkFloats / 4; i += 256) reinterpret_cast<f4*>(lds_w)[i] = wsrc[i];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t % 3;
+      f4 B4[4], A4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        B4[g] = *reinterpret_cast<const f4*>(lds_in + ((4 * wave + g + dy) * 18 + px + dx) * 16 + 4 * q);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) A4[mb] = *reinterpret_cast<const f4*>(lds_w + ((t * 4 + mb) * 64 + lane) * 4);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[mb][g] = mfma16u(A4[mb][ks], B4[g][ks], acc[mb][g]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: ReLU (bias is already in), store NHWC; D[row = 4q + r -> channel][col = px -> pixel]
+  const int gx = x0 + px;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int gy = y0 + 4 * wave + g;
+    const bool ok = gy < a.H && gx < a.W;
+    const int64_t pix = frame * (int64_t)a.H * a.W + (int64_t)gy * a.W + gx;
+    if (FUSE_OUT) {
+      // outc (conv1x1 64 -> 3) on the 64 channels of this pixel: lane partial over its 16, reduce over q
+      float p3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float h = fmaxf(acc[mb][g][r], 0.f);
+          const int c = mb * 16 + 4 * q + r;
+#pragma unroll
+          for (int o = 0; o < 3; ++o) p3[o] = fmaf(a.outw[o * 64 + c], h, p3[o]);
+        }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+        p3[o] += __shfl_xor(p3[o], 16);
+        p3[o] += __shfl_xor(p3[o], 32);
+      }
+      if (q == 0 && ok) {
+        float* o3 = a.out3 + pix * 3;
+        o3[0] = p3[0] + a.outb[0];
+        o3[1] = p3[1] + a.outb[1];
+        o3[2] = p3[2] + a.outb[2];
+      }
+    } else if (ok) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        f4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mb][g][r], 0.f);
+        *reinterpret_cast<f4*>(a.out + pix * a.cout + ct * 64 + mb * 16 + 4 * q) = h;
+      }
+    }
+  }
+}
+
+// ---- pooling / upsampling ------------------------------------------------------------------------------
+// MaxPool2d(2): [F,H,W,C] -> [F,H/2,W/2,C]; thread = (out pixel, channel quad)
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                      int64_t n_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const int cq = C / 4;
+  const int c4 = (int)(i % cq);
+  int64_t p = i / cq;
+  const int Wo = W / 2, Ho = H / 2;
+  const int xo = (int)(p % Wo);
+  p /= Wo;
+  const int yo = (int)(p % Ho);
+  const int64_t f = p / Ho;
+  const float* s = x + ((f * H + 2 * yo) * (int64_t)W + 2 * xo) * C + c4 * 4;
+  const f4 a = *reinterpret_cast<const f4*>(s), b = *reinterpret_cast<const f4*>(s + C);
+  const f4 c = *reinterpret_cast<const f4*>(s + (int64_t)W * C), d = *reinterpret_cast<const f4*>(s + (int64_t)W * C + C);
+  f4 m;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = fmaxf(fmaxf(a[r], b[r]), fmaxf(c[r], d[r]));
+  *reinterpret_cast<f4*>(y + i * 4) = m;
+}
+
+// bilinear x2, align_corners=True, then zero padding to (Ho, Wo) (SimpleUnetLight.py:57-66)
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int C,
+                                                       int Ho, int Wo, int64_t n_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const int cq = C / 4;
+  const int c4 = (int)(i % cq);
+  int64_t p = i / cq;
+  const int xo = (int)(p % Wo);
+  p /= Wo;
+  const int yo = (int)(p % Ho);
+  const int64_t f = p / Ho;
+  const int padT = (Ho - 2 * h) / 2, padL = (Wo - 2 * w) / 2;
+  const int yu = yo - padT, xu = xo - padL;
+  f4 o = (f4){0.f, 0.f, 0.f, 0.f};
+  if ((unsigned)yu < (unsigned)(2 * h) && (unsigned)xu < (unsigned)(2 * w)) {
+    const float sy = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sx = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    const float fy = sy * (float)yu, fx = sx * (float)xu;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* s = x + f * (int64_t)h * w * C + c4 * 4;
+    const f4 v00 = *reinterpret_cast<const f4*>(s + ((int64_t)y0 * w + x0) * C);
+    const f4 v01 = *reinterpret_cast<const f4*>(s + ((int64_t)y0 * w + x1) * C);
+    const f4 v10 = *reinterpret_cast<const f4*>(s + ((int64_t)y1 * w + x0) * C);
+    const f4 v11 = *reinterpret_cast<const f4*>(s + ((int64_t)y1 * w + x1) * C);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = hy * (hx * v00[r] + lx * v01[r]) + ly * (hx * v10[r] + lx * v11[r]);
+  }
+  *reinterpret_cast<f4*>(y + i * 4) = o;
+}
+
+static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
+                       float* out3, int H, int W, int64_t F, hipStream_t st) {
+  ConvArgs a;
+  a.inA = inA; a.inB = inB; a.CA = CA; a.CB = CB;
+  a.cout = kUnetConvs[layer].cout;
+  a.w = packed + unet_w_off(layer);
+  a.bias = packed + unet_b_off(layer);
+  a.out = out; a.out3 = out3;
+  a.outw = packed + kUnetOutW; a.outb = packed + kUnetOutB;
+  a.H = H; a.W = W;
+  a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+  a.n_ct = a.cout / 64;
+  const int64_t gz = F * a.n_ct;
+  if (gz > 65535) return S2L_E_SIZE;
+  dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
+  if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace s2l
+
+using namespace s2l;
+
+extern "C" int64_t s2l_unet_packed_floats(void) { return kUnetPackedFloats; }
+
+// Workspace floats for n_frames frames of height x width (all intermediate activations).
+extern "C" int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 0) return 0;
+  const int64_t p1 = (int64_t)height * width, p2 = (int64_t)(height / 2) * (width / 2),
+                p4 = (int64_t)(height / 4) * (width / 4);
+  // t64a, x1, t64b (H) | pool1(64), t128a, x2, up1in(128), t128b, u1(64) (H/2) | pool2, t128c, x3 (H/4)
+  return n_frames * (p1 * (64 + 64 + 64) + p2 * (64 + 128 + 128 + 128 + 128 + 64) + p4 * (128 + 128 + 128));
+}
+
+// tensors_host: 52 DEVICE pointers: for each of the ten 3x3 convs (execution order, see weights.UNET_CONVS)
+// {conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var}, then outc.conv.weight, outc.conv.bias.
+extern "C" int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream) {
+  if (!tensors_host || !packed) return S2L_E_NULL;
+  UnetTensors t;
+  for (int l = 0; l < 10; ++l) {
+    for (int k = 0; k < 5; ++k)
+      if (!tensors_host[l * 5 + k]) return S2L_E_NULL;
+    t.w[l] = tensors_host[l * 5];
+    t.gamma[l] = tensors_host[l * 5 + 1];
+    t.beta[l] = tensors_host[l * 5 + 2];
+    t.mean[l] = tensors_host[l * 5 + 3];
+    t.var[l] = tensors_host[l * 5 + 4];
+  }
+  if (!tensors_host[50] || !tensors_host[51]) return S2L_E_NULL;
+  t.outw = tensors_host[50];
+  t.outb = tensors_host[51];
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 1; l < 10; ++l) {
+    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
+    hipLaunchKernelGGL(unet_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, bn_eps);
+  }
+  hipLaunchKernelGGL(unet_pack_misc, dim3(16), dim3(256), 0, st, t, packed, bn_eps);
+  return (int)hipGetLastError();
+}
+
+// x [F,H,W,3] NHWC -> out [F,H,W,3].  H, W >= 4.  work: s2l_unet_work_floats(H, W, F) floats.
+extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height, int width,
+                                int64_t n_frames, s2l_stream_t stream) {
+  if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!packed || !x || !work || !out) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(work)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+  const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
+  float* t64a = work;              float* x1 = t64a + p1 * 64;      float* t64b = x1 + p1 * 64;
+  float* pool1 = t64b + p1 * 64;   float* t128a = pool1 + p2 * 64;  float* x2 = t128a + p2 * 128;
+  float* up1in = x2 + p2 * 128;    float* t128b = up1in + p2 * 128; float* u1 = t128b + p2 * 128;
+  float* pool2 = u1 + p2 * 64;     float* t128c = pool2 + p4 * 128; float* x3 = t128c + p4 * 128;
+  int rc;
+  if (F > 65535) return S2L_E_SIZE;
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 15) / 16), (unsigned)F), dim3(256), 0, st, x,
+                     packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
+  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st))) return rc;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((p2 * 16 + 255) / 256)), dim3(256), 0, st, x1, pool1, H, W, 64, p2 * 16);
+  if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st))) return rc;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((p4 * 32 + 255) / 256)), dim3(256), 0, st, x2, pool2, H2, W2, 128, p4 * 32);
+  if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st))) return rc;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2,
+                     W2, p2 * 32);
+  if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st))) return rc;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
+                     p1 * 16);   // t64a is free again: it becomes up(u1)
+  if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st))) return rc;
+  if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st))) return rc;
+  return (int)hipGetLastError();
+}

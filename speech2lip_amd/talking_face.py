@@ -15,8 +15,8 @@ Mirrors `src/face_simple/models/tf_nerf.py` of CVMI-Lab/Speech2Lip for the May f
 Beyond the reference surface, `render_clip` is the batched driver that replaces the per-frame
 loop of inference.py:140-159 (audio encoder once per frame, one fused launch per clip).
 
-Not in this path: the post-fusion U-Net (`post_fusion_unet`), the canonical
-depth head, training autograd.  `post_fusion2_onlylip` returns `None` for the U-Net output.
+The post-fusion U-Net (`post_fusion_unet`) is `speech2lip_amd.unet.SimpleUnetLight`
+(eval mode).  Not in this path: the canonical depth head, training of the U-Net.
 """
 from __future__ import annotations
 
@@ -135,6 +135,11 @@ class TalkingFace(nn.Module):
         self.fc_time_skip = nn.Linear(20, W)
         self.pts_linears = nn.ModuleList([nn.Linear(W, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(2 * W, W)
                                                              for i in range(D - 1)])
+        if self.use_post_fusion:   # tf_nerf.py:55-59
+            from .unet import SimpleUnetLight
+            self.use_resnet = bool(m.get("use_resnet", False))
+            self.post_fusion_channel = int(m.get("post_fusion_channel", 3))
+            self.post_fusion_unet = SimpleUnetLight(cfg=cfg, n_channels=self.post_fusion_channel)
         self.to(self.device)
 
         self._packed: Optional[torch.Tensor] = None
@@ -223,15 +228,20 @@ class TalkingFace(nn.Module):
                              wav2lip=None, mask_head_observed=None, use_post_fusion_blackaug=False):
         """Paste the lip into the canonical face, warp by `coord`, blend with the observed frame.
         Reference: tf_nerf.py:287-304 -> post_fusion2_onlylip_light :320-389.
-        Returns (None, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; the first slot is
-        the U-Net output in the reference (out of this path)."""
+        Returns (rgb_recon, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; rgb_recon is the
+        post-fusion U-Net output (csrc/unet.hip) in eval mode, None in train mode or when
+        model.use_post_fusion is off."""
         if not self.use_light_unet:
             return None  # the reference method falls through and returns None as well (:299-304)
         if use_post_fusion_blackaug:
             raise NotImplementedError("black-hole augmentation is training-only (tf_nerf.py:371-384)")
         new, can = self.composite_clip(rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
                                        lip_lefttop_y, coord, want_canonical=True)
-        return None, new, can
+        # rgb_recon = post_fusion_unet(rgb_merged_new) (tf_nerf.py:387); eval mode only on this path
+        recon = None
+        if getattr(self, "post_fusion_unet", None) is not None and not self.training:
+            recon = self.post_fusion_unet.forward_nhwc(new)
+        return recon, new, can
 
     def composite_clip(self, rgb_lip, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
                        coord, want_canonical=False, out=None):

@@ -1,0 +1,109 @@
+"""`SimpleUnetLight` -- drop-in for the reference's post-fusion U-Net.
+
+Same module tree and state-dict keys as `src/face_simple/models/SimpleUnetLight.py:16-111`
+(`inc.double_conv.{0,1,3,4}`, `down{1,2}.maxpool_conv.1.double_conv.*`, `up{1,2}.conv.double_conv.*`,
+`outc.conv.*`), so `post_fusion_unet.*` keys of a reference checkpoint load unchanged.  `forward`
+(NCHW, as in the reference) and `forward_nhwc` run the HIP implicit-GEMM path of `csrc/unet.hip`
+in eval mode (BatchNorm folded with its running statistics at pack time).  Inference only.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .weights import UNET_CONVS
+
+
+def _double_conv(cin, cout, mid=None):
+    mid = mid or cout
+    seq = nn.Sequential(nn.Conv2d(cin, mid, 3, padding=1, bias=False), nn.BatchNorm2d(mid), nn.ReLU(inplace=True),
+                        nn.Conv2d(mid, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+    holder = nn.Module()
+    holder.double_conv = seq
+    return holder
+
+
+class SimpleUnetLight(nn.Module):
+    def __init__(self, cfg=None, n_channels=3, n_classes=3, bilinear=True):
+        super().__init__()
+        if n_channels != 3 or n_classes != 3 or not bilinear:
+            raise NotImplementedError("HIP path is specialised for the 3 -> 3 channel bilinear U-Net of the May config")
+        self.cfg, self.n_channels, self.n_classes, self.bilinear = cfg, n_channels, n_classes, bilinear
+        self.inc = _double_conv(3, 64)
+        self.down1 = nn.Module()
+        self.down1.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), _double_conv(64, 128))
+        self.down2 = nn.Module()
+        self.down2.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), _double_conv(128, 128))
+        self.up1 = nn.Module()
+        self.up1.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.up1.conv = _double_conv(256, 64, 128)
+        self.up2 = nn.Module()
+        self.up2.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.up2.conv = _double_conv(128, 64, 64)
+        self.outc = nn.Module()
+        self.outc.conv = nn.Conv2d(64, 3, kernel_size=1)
+        self._packed = None
+        self._packed_key = None
+
+    def _tensors(self):
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        out = []
+        for name, _, _ in UNET_CONVS:
+            head, idx = name.rsplit(".", 1)
+            bn = f"{head}.{int(idx) + 1}"
+            out += [sd[f"{name}.weight"], sd[f"{bn}.weight"], sd[f"{bn}.bias"], sd[f"{bn}.running_mean"],
+                    sd[f"{bn}.running_var"]]
+        return out + [sd["outc.conv.weight"], sd["outc.conv.bias"]]
+
+    def packed_weights(self) -> torch.Tensor:
+        lib = _abi.load()
+        tensors = self._tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is None or key != self._packed_key:
+            dev = tensors[0].device
+            if dev.type != "cuda":
+                raise _abi.S2LError(f"U-Net parameters are on {dev}; the HIP path needs a GPU (no CPU fallback)")
+            hold = [t.detach().to(torch.float32).contiguous() for t in tensors]
+            table = (ctypes.c_void_p * len(hold))(*[h.data_ptr() for h in hold])
+            packed = torch.empty(int(lib.s2l_unet_packed_floats()), dtype=torch.float32, device=dev)
+            eps = float(self.inc.double_conv[1].eps)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_unet_pack(table, ctypes.c_float(eps), ctypes.c_void_p(packed.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_pack")
+            self._packed, self._packed_key = packed, key
+        return self._packed
+
+    def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """x [F,H,W,3] -> [F,H,W,3] (the layout the composite produces and the caller wants)."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        if x.device.type != "cuda":
+            raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
+        if self.training:
+            raise NotImplementedError("the HIP U-Net is eval-mode only (BatchNorm uses its running statistics)")
+        x = x.detach().to(torch.float32).contiguous()
+        F_, H, W, C = x.shape
+        if C != 3 or H < 4 or W < 4:
+            raise ValueError(f"U-Net input must be [F,H>=4,W>=4,3], got {tuple(x.shape)}")
+        if out is None:
+            out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # frames go through in groups that keep the activation workspace around 2 GiB
+        per_frame = int(lib.s2l_unet_work_floats(H, W, 1))
+        group = max(1, min(F_, (1 << 29) // max(per_frame, 1)))
+        work = torch.empty(per_frame * group, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            for s in range(0, F_, group):
+                n = min(group, F_ - s)
+                _abi.check(lib.s2l_unet_forward(ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(x[s:].data_ptr()),
+                                                ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(out[s:].data_ptr()),
+                                                H, W, n, st), "s2l_unet_forward")
+        return out
+
+    def forward(self, x, x_level1=None, x_level2=None):
+        """NCHW in, NCHW out, as the reference's forward (SimpleUnetLight.py:99-111)."""
+        return self.forward_nhwc(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

@@ -126,3 +126,42 @@ def synthetic_audio(n_frames: int, seed: int = 1) -> np.ndarray:
     padded = np.concatenate([np.zeros((8, 29)), logp, np.zeros((8, 29))], axis=0)
     idx = (2 * np.arange(n_frames))[:, None] + np.arange(16)[None, :]
     return padded[idx]  # [N,16,29] float64
+
+
+# ---- post-fusion U-Net (SimpleUnetLight) ---------------------------------------
+# (prefix, cin, cout) of the ten 3x3 convolutions, in execution order; each is followed by a BatchNorm.
+UNET_CONVS = [
+    ("inc.double_conv.0", 3, 64), ("inc.double_conv.3", 64, 64),
+    ("down1.maxpool_conv.1.double_conv.0", 64, 128), ("down1.maxpool_conv.1.double_conv.3", 128, 128),
+    ("down2.maxpool_conv.1.double_conv.0", 128, 128), ("down2.maxpool_conv.1.double_conv.3", 128, 128),
+    ("up1.conv.double_conv.0", 256, 128), ("up1.conv.double_conv.3", 128, 64),
+    ("up2.conv.double_conv.0", 128, 64), ("up2.conv.double_conv.3", 64, 64),
+]
+
+
+def _bn_name(conv_name: str) -> str:
+    head, idx = conv_name.rsplit(".", 1)
+    return f"{head}.{int(idx) + 1}"
+
+
+def make_unet_state_dict(seed: int = 0, prefix: str = "post_fusion_unet.") -> "OrderedDict[str, np.ndarray]":
+    """Seeded weights for `SimpleUnetLight` (reference: src/face_simple/models/SimpleUnetLight.py:82-111),
+    state-dict keys as in a reference checkpoint.  He-uniform convolutions, BatchNorm affine and
+    running statistics drawn away from the identity so that the eval-mode fold is exercised."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def u(name, n, lo, hi):
+        return (lo + (hi - lo) * uniform01(n, _stream_id("unet." + name, seed))).astype(np.float32)
+
+    for name, cin, cout in UNET_CONVS:
+        b = np.sqrt(6.0 / (cin * 9))
+        out[f"{prefix}{name}.weight"] = u(name + ".w", cout * cin * 9, -b, b).reshape(cout, cin, 3, 3)
+        bn = _bn_name(name)
+        out[f"{prefix}{bn}.weight"] = u(bn + ".g", cout, 0.5, 1.5)
+        out[f"{prefix}{bn}.bias"] = u(bn + ".b", cout, -0.1, 0.1)
+        out[f"{prefix}{bn}.running_mean"] = u(bn + ".m", cout, -0.1, 0.1)
+        out[f"{prefix}{bn}.running_var"] = u(bn + ".v", cout, 0.5, 1.5)
+        out[f"{prefix}{bn}.num_batches_tracked"] = np.array(100, dtype=np.int64)
+    out[f"{prefix}outc.conv.weight"] = u("outc.w", 3 * 64, -0.15, 0.15).reshape(3, 64, 1, 1)
+    out[f"{prefix}outc.conv.bias"] = u("outc.b", 3, -0.1, 0.1)
+    return out

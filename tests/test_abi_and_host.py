@@ -84,9 +84,11 @@ def test_module_surface_and_state_dict_keys():
     assert set(n for n, _ in W.DEAD_TENSORS) <= keys
     assert m.audio_dims == 64 and m.uv_embedder.out_dims == 42 and m.time_embedder_new.out_dims == 20
     sd = {k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()}
-    sd["post_fusion_unet.inc.double_conv.0.weight"] = torch.zeros(1)   # out-of-path keys are ignored
+    sd.update({k: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})   # post_fusion_unet.* (§8f-1)
+    sd["canonical_depth_head"] = torch.zeros(500, 500)                                    # out-of-path keys are ignored
     res = m.load_state_dict(sd)
-    assert not res.missing_keys
+    assert not res.missing_keys and res.unexpected_keys == ["canonical_depth_head"]
+    assert set(W.make_unet_state_dict(0)) <= keys
     assert torch.equal(m.fc_uv.weight.detach(), sd["fc_uv.weight"])
 
 

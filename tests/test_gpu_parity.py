@@ -193,7 +193,7 @@ def test_composite_golden_both_pad_modes(golden, dev):
     for mode, path in [(0, "dataset/may_face_crop_lip"), (1, "dataset/someone_else")]:
         m = make_model(dev, 16, 24, path=path)
         recon, new, can = m.post_fusion2_onlylip(*args, int(g["x0"]), int(g["y0"]), T(g["coord"]).to(dev))
-        assert recon is None
+        assert recon is not None and recon.shape == new.shape
         close(can, g[f"merged_canonical_mode{mode}"], 1e-9, 0.0)           # elementwise: bit-exact
         close(new, g[f"merged_new_mode{mode}"], 1e-6, 2e-6)
 
@@ -283,6 +283,48 @@ def test_predict_lip_image_vs_oracle(sd, dev, h, w, u):
         ref = O.predict_lip_image(sd, coords, win[1], 321, h, w, u)
     got = s2l.predict_lip_image(m, coords.to(dev), win[1:2].to(dev), 321, h, w, u)
     close(got, ref)
+
+
+def _unet(dev):
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    sd = {k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()}
+    res = u.load_state_dict(sd, strict=True)
+    return u
+
+
+def test_unet_golden(golden, dev):
+    """§8f-1: the HIP U-Net against the reference's own outputs (odd quarter sizes exercise the Up padding)."""
+    g = golden("g7_unet.npz")
+    u = _unet(dev)
+    for fh, fw in [(24, 20), (36, 44), (30, 26)]:
+        y = u.forward_nhwc(T(g[f"x_{fh}x{fw}"]).to(dev))
+        close(y, g[f"y_{fh}x{fw}"], 2e-6, 2e-5)
+    # NCHW entry point, as the reference's forward
+    x = T(g["x_24x20"]).to(dev)
+    close(u(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), g["y_24x20"], 2e-6, 2e-5)
+
+
+def test_post_fusion_returns_unet_output(golden, dev):
+    """post_fusion2_onlylip's first return value = U-Net(rgb_merged_new), as tf_nerf.py:387-389."""
+    g4, g7 = golden("g4_composite.npz"), golden("g7_unet.npz")
+    m = make_model(dev, 16, 24)
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    recon, new, _ = m.post_fusion2_onlylip(*[T(g4[k]).to(dev) for k in ("lip", "face", "gt", "mask")], int(g4["x0"]),
+                                           int(g4["y0"]), T(g4["coord"]).to(dev))
+    close(recon, g7["recon_after_composite_mode0"], 2e-6, 2e-5)
+
+
+def test_unet_full_size_vs_oracle(dev):
+    """500x500 (the reference's face frame), 2 frames, against the CPU oracle; and batch independence."""
+    u = _unet(dev)
+    usd = O.to_sd(W.make_unet_state_dict(0))
+    rng = np.random.default_rng(3)
+    x = T(rng.random((2, 500, 500, 3), dtype=np.float32))
+    with torch.no_grad():
+        ref = O.unet_forward(usd, x)
+    y = u.forward_nhwc(x.to(dev))
+    close(y, ref, 2e-6, 5e-5)
+    assert torch.equal(u.forward_nhwc(x[1:].to(dev)), y[1:])
 
 
 def test_empty_inputs(model, dev):

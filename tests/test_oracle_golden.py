@@ -111,6 +111,20 @@ def test_g5_gradients_by_autograd_through_the_oracle(golden):
     assert _maxerr(sd["fc_time.bias"].grad, g["g_fc_time_b"]) <= 1e-5
 
 
+def test_g7_unet(golden):
+    """§8f-1: eval-mode SimpleUnetLight restatement against the reference's own outputs."""
+    g = golden("g7_unet.npz")
+    usd = O.to_sd(W.make_unet_state_dict(seed=0))
+    with torch.no_grad():
+        for fh, fw in [(24, 20), (36, 44), (30, 26)]:
+            y = O.unet_forward(usd, T(g[f"x_{fh}x{fw}"]))
+            assert y.shape == (2, fh, fw, 3)
+            assert _maxerr(y, g[f"y_{fh}x{fw}"]) <= 1e-5
+        g4 = golden("g4_composite.npz")
+        new, _ = O.composite(*[T(g4[k]) for k in ("lip", "face", "gt", "mask")], int(g4["x0"]), int(g4["y0"]), T(g4["coord"]))
+        assert _maxerr(O.unet_forward(usd, new), g["recon_after_composite_mode0"]) <= 1e-5
+
+
 def test_synthetic_audio_shape_and_padding():
     a = W.synthetic_audio(16, seed=1)
     assert a.shape == (16, 16, 29) and a.dtype == np.float64

@@ -200,6 +200,33 @@ def main():
         g_pts7_b=model.pts_linears[7].bias.grad.numpy(),
         g_fc_time_b=model.fc_time.bias.grad.numpy())
 
+    # ---- G7: post-fusion U-Net, eval mode, through post_fusion2_onlylip's first output
+    with torch.no_grad():
+        usd = W.make_unet_state_dict(seed=0)
+        g7 = {}
+        for (fh, fw) in [(24, 20), (36, 44), (30, 26)]:      # multiples of 4, and sizes that need the Up padding
+            model, cfg = ref_model(ref_config, TalkingFace, 8, 8)
+            res = model.load_state_dict({k: torch.from_numpy(v) for k, v in usd.items()}, strict=False)
+            assert not res.unexpected_keys
+            assert not [k for k in res.missing_keys if k.startswith("post_fusion_unet")]
+            model.eval()
+            xin = torch.from_numpy(rng.random((2, fh, fw, 3), dtype=np.float32))
+            y_ref = model.post_fusion_unet(xin.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+            y_or = O.unet_forward(O.to_sd(usd), xin)
+            report[f"unet_{fh}x{fw}"] = maxerr(y_ref, y_or)
+            g7[f"x_{fh}x{fw}"] = xin.numpy(); g7[f"y_{fh}x{fw}"] = y_ref.numpy()
+        # and as the first return value of the composite call (tf_nerf.py:387-389)
+        FH = FW = 64
+        model, cfg = ref_model(ref_config, TalkingFace, 16, 24)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in usd.items()}, strict=False)
+        model.eval()
+        g4 = dict(np.load(os.path.join(GOLD, "g4_composite.npz")))
+        recon, new_ref, _ = model.post_fusion2_onlylip(*[torch.from_numpy(g4[k]) for k in ("lip", "face", "gt", "mask")],
+                                                       int(g4["x0"]), int(g4["y0"]), torch.from_numpy(g4["coord"]))
+        report["unet_after_composite"] = maxerr(recon, O.unet_forward(O.to_sd(usd), new_ref))
+        g7["recon_after_composite_mode0"] = recon.numpy()
+        np.savez_compressed(os.path.join(GOLD, "g7_unet.npz"), **g7)
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     worst = 0.0
