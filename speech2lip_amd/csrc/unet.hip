@@ -162,23 +162,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     for (int g = 0; g < 4; ++g) acc[mb][g] = b;
   }
 
-  for (int cc = 0; cc < nchunks; ++cc) {
-    // stage the 18x18 halo tile of this 16-channel chunk (zero outside the image) and its weights
+  // Register-prefetch pipeline over the 16-channel chunks: the global loads of chunk cc+1 are in
+  // flight while chunk cc's 576 MFMAs run; they are committed to LDS between two barriers.
+  constexpr int kInQuads = 18 * 18 * 4;                 // f4 elements of the halo tile
+  constexpr int kInPer = (kInQuads + 255) / 256;        // 6 (the last pass is partial)
+  constexpr int kWPer = kChunkFloats / 4 / 256;         // 9
+  f4 pin[kInPer], pw[kWPer];
+  auto fetch = [&](int cc) {
     const bool fromA = cc * 16 < a.CA;
     const float* src = fromA ? inA : inB;
     const int C = fromA ? a.CA : a.CB;
     const int coff = fromA ? cc * 16 : cc * 16 - a.CA;
-    for (int i = threadIdx.x; i < 18 * 18 * 4; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) {
+      const int i = threadIdx.x + k * 256;
       const int pi = i >> 2, qq = i & 3;
       const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-        v = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * qq);
-      *reinterpret_cast<f4*>(lds_in + pi * 16 + 4 * qq) = v;
+      pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        pin[k] = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * qq);
     }
     const f4* wsrc = reinterpret_cast<const f4*>(a.w + ((int64_t)ct * nchunks + cc) * kChunkFloats);
-    for (int i = threadIdx.x; i < kChunkFloats / 4; i += 256) reinterpret_cast<f4*>(lds_w)[i] = wsrc[i];
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWPer; ++k) pw[k] = wsrc[threadIdx.x + k * 256];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < kInQuads) *reinterpret_cast<f4*>(lds_in + (i >> 2) * 16 + 4 * (i & 3)) = pin[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kWPer; ++k) reinterpret_cast<f4*>(lds_w)[threadIdx.x + k * 256] = pw[k];
+  };
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (cc + 1 < nchunks) fetch(cc + 1);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3, dx = t % 3;
@@ -195,7 +216,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[mb][g] = mfma16u(A4[mb][ks], B4[g][ks], acc[mb][g]);
     }
-    __syncthreads();
+    __syncthreads();            // everyone is done reading chunk cc
+    if (cc + 1 < nchunks) {
+      commit();
+      __syncthreads();
+    }
   }
 
   // epilogue: ReLU (bias is already in), store NHWC; D[row = 4q + r -> channel][col = px -> pixel]
