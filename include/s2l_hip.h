@@ -49,6 +49,11 @@ enum {
 
 /* Pad modes of the paste step (tf_nerf.py:345-350 keys them off substrings of cfg.data.path). */
 enum { S2L_PAD_MAY = 0, S2L_PAD_DEFAULT = 1 };
+/* relative pose of s2l_rel_pose: OBS2CAN = Tc.inv(T) (utils.py:54-58, face_tracker.py:583-584: the pose behind
+ * coords/%05d.npy); CAN2OBS = T.inv(Tc) (utils.py:60-71, training.py:263-268); CAN2OBS_INV = inv(T.inv(Tc))
+ * (utils.py:73-77, training.py:270-275), which is Tc.inv(T) again and is computed as such. */
+enum { S2L_POSE_OBS2CAN = 0, S2L_POSE_CAN2OBS = 1, S2L_POSE_CAN2OBS_INV = 2 };
+enum { S2L_SAMPLE_ZEROS = 0, S2L_SAMPLE_BORDER = 1 };
 
 /* Library / build identification: "s2l_hip <version> gfx950". */
 const char* s2l_version(void);
@@ -195,6 +200,25 @@ int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames);
 int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
 int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height,
                      int width, int64_t n_frames, s2l_stream_t stream);
+
+/* ---- pose -> warp grid -----------------------------------------------------------
+ * s2l_rel_pose replaces prepare_transform_matrix + compute_rel_pose* (src/face_simple/models/utils.py:36-77;
+ * Trainer.compute_rel_pose*, src/face_simple/training.py:263-275): euler, trans [F,3]; canon_euler,
+ * canon_trans [3] (data['canonical_euler'/'canonical_trans']); T [F,16] row-major 4x4; mode S2L_POSE_*.
+ * s2l_warp_grid replaces BackprojectDepth.forward + Project3D.forward (utils.py:131-169) with
+ * K = [[focal,0,W/2],[0,focal,H/2],[0,0,1]] (training.py:298-302): depth [H,W] when depth_stride == 0 (one
+ * canonical depth map for the clip) or [F,H,W] when depth_stride == H*W (per-frame depth, face_tracker.py:
+ * 586-603); grid [F,H,W,2] in grid_sample units, clamped to [-1,1] when clamp != 0 (face_tracker.py:606);
+ * z NULL or [F,H,W] = projected depth (Project3D return_z).
+ * s2l_grid_sample: F.grid_sample(bilinear, align_corners=False) on NHWC 3-channel images, padding
+ * S2L_SAMPLE_ZEROS or S2L_SAMPLE_BORDER (training.py:312): img [img_h,img_w,3] (img_stride 0) or
+ * [F,img_h,img_w,3]; grid [F,out_h,out_w,2]; out [F,out_h,out_w,3]. */
+int s2l_rel_pose(const float* euler, const float* trans, const float* canon_euler, const float* canon_trans,
+                 int mode, float* T, int64_t n_frames, s2l_stream_t stream);
+int s2l_warp_grid(const float* depth, int64_t depth_stride, const float* T, float focal, int clamp,
+                  float* grid, float* z, int height, int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_grid_sample(const float* img, int64_t img_stride, const float* grid, float* out, int img_h, int img_w,
+                    int out_h, int out_w, int padding, int64_t n_frames, s2l_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -269,6 +269,73 @@ def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet."
 
 
 # --------------------------------------------------------------------------- metrics
+# --------------------------------------------------------------------------- §8f-3: pose -> warp grid
+POSE_OBS2CAN = 0   # Tc . inv(T): the grid written to coords/*.npy (face_tracker.py:583-584, utils.py:54-58)
+POSE_CAN2OBS = 1   # T . inv(Tc): training.py:263-268, utils.py:60-71
+POSE_CAN2OBS_INV = 2   # inv(T . inv(Tc)): training.py:270-275 (the rel_pose of the depth photo loss)
+
+
+def euler2rot(euler: torch.Tensor) -> torch.Tensor:
+    """[B,3] (theta, phi, psi) -> Rx(theta) Ry(phi) Rz(psi) with the reference's sign layout (utils.py:8-34)."""
+    th, ph, ps = euler[:, 0], euler[:, 1], euler[:, 2]
+    o, z = torch.ones_like(th), torch.zeros_like(th)
+    rx = torch.stack([o, z, z, z, th.cos(), -th.sin(), z, th.sin(), th.cos()], -1).reshape(-1, 3, 3)
+    ry = torch.stack([ph.cos(), z, ph.sin(), z, o, z, -ph.sin(), z, ph.cos()], -1).reshape(-1, 3, 3)
+    rz = torch.stack([ps.cos(), ps.sin(), z, -ps.sin(), ps.cos(), z, z, z, o], -1).reshape(-1, 3, 3)
+    return rx @ ry @ rz
+
+
+def prepare_transform_matrix(euler: torch.Tensor, trans: torch.Tensor) -> torch.Tensor:
+    """[B,3],[B,3] -> [B,4,4] = [R(e0,-e1,-e2) | (t0,-t1,-t2)] (utils.py:36-52)."""
+    sgn = torch.tensor([1.0, -1.0, -1.0], dtype=euler.dtype)
+    T = torch.zeros(euler.shape[0], 4, 4, dtype=euler.dtype)
+    T[:, :3, :3] = euler2rot(euler * sgn)
+    T[:, :3, 3] = trans * sgn
+    T[:, 3, 3] = 1
+    return T
+
+
+def rel_pose(canonical_euler, canonical_trans, euler, trans, mode: int) -> torch.Tensor:
+    Tc = prepare_transform_matrix(canonical_euler.reshape(1, 3), canonical_trans.reshape(1, 3)).expand(euler.shape[0], 4, 4)
+    T = prepare_transform_matrix(euler, trans)
+    if mode == POSE_OBS2CAN:
+        return Tc @ torch.inverse(T)
+    out = T @ torch.inverse(Tc)
+    return out if mode == POSE_CAN2OBS else torch.inverse(out)
+
+
+def warp_grid(depth: torch.Tensor, T: torch.Tensor, focal: float, clamp: bool = False, eps: float = 1e-7):
+    """depth [B or 1,H,W], T [B,4,4] -> (grid [B,H,W,2] in grid_sample units, z [B,H,W]).
+    BackprojectDepth (utils.py:115-143): X = depth * pinv(K)[:3,:3] (x, y, 1), K = [[f,0,W/2],[0,f,H/2],[0,0,1]]
+    (training.py:296-304); Project3D (utils.py:145-169): p = (K T)[:3] (X,1); pix = p.xy / (p.z + eps);
+    pix.x /= W-1; pix.y /= H-1; grid = (pix - 0.5) * 2.  `clamp` = the [-1,1] clamp of face_tracker.py:606."""
+    B = T.shape[0]
+    H, W = depth.shape[-2:]
+    dt = depth.dtype
+    K = torch.tensor([[focal, 0, W / 2, 0], [0, focal, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=dt)
+    inv_K = torch.linalg.pinv(K)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, dtype=dt)], 0)           # [3,HW]
+    cam = depth.reshape(-1, 1, H * W).expand(B, 1, H * W) * (inv_K[:3, :3] @ pix)                  # [B,3,HW]
+    cam = torch.cat([cam, torch.ones(B, 1, H * W, dtype=dt)], 1)
+    P = (K @ T)[:, :3, :]
+    p = P @ cam
+    g = (p[:, :2] / (p[:, 2:3] + eps)).reshape(B, 2, H, W).permute(0, 2, 3, 1).clone()
+    g[..., 0] /= W - 1
+    g[..., 1] /= H - 1
+    g = (g - 0.5) * 2
+    if clamp:
+        g = g.clamp(-1, 1)
+    return g, p[:, 2].reshape(B, H, W)
+
+
+def inverse_warping(depth: torch.Tensor, T: torch.Tensor, src_nhwc: torch.Tensor, focal: float):
+    """training.py:296-314: grid from (depth, rel_pose), then border-padded bilinear sampling of src."""
+    g, z = warp_grid(depth[None], T, focal)
+    img = F.grid_sample(src_nhwc.permute(0, 3, 1, 2), g, mode="bilinear", padding_mode="border", align_corners=False)
+    return img, z[:, None]
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
     mse = float(((a.double() - b.double()) ** 2).mean())
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

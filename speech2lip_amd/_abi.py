@@ -12,6 +12,8 @@ from .build import LIB
 
 S2L_NUM_TENSORS = 42
 S2L_PAD_MAY, S2L_PAD_DEFAULT = 0, 1
+S2L_POSE_OBS2CAN, S2L_POSE_CAN2OBS, S2L_POSE_CAN2OBS_INV = 0, 1, 2
+S2L_SAMPLE_ZEROS, S2L_SAMPLE_BORDER = 0, 1
 
 # order of the pointer table of s2l_pack_weights == enum S2L_T_* in include/s2l_hip.h
 TENSOR_ORDER = [
@@ -63,6 +65,11 @@ EXPORTS = {
     "s2l_unet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),
     "s2l_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "s2l_rel_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "s2l_warp_grid": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_int, c_int64,
+                              c_void_p]),
+    "s2l_grid_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64,
+                                c_void_p]),
 }
 
 _lib = None

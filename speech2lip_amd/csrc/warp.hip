@@ -1,0 +1,211 @@
+// Pose -> warp grid on the device: the 2 MB/frame `coords/%05d.npy` grid the composite
+// consumes is a pure function of a depth map and a 4x4 relative pose, so it is regenerated in HBM from
+// 24 B/frame of pose instead of being read from disk and pushed over PCIe.
+//
+//   s2l_rel_pose     euler/trans -> T [B,4,4]   (utils.py:8-77, face_tracker.py:583-584, training.py:263-275)
+//   s2l_warp_grid    depth, T -> grid [B,H,W,2] (+ z)   (BackprojectDepth + Project3D, utils.py:115-169)
+//   s2l_grid_sample  bilinear NHWC gather with zero / border padding (F.grid_sample as training.py:312 calls it)
+//
+// All three are HBM-bound streaming kernels: the grid kernel writes 8 B and reads 4 B (0 when the depth map is
+// a per-clip constant and stays in L2) per pixel, one pixel per lane so that a wave's stores are one contiguous
+// 512-byte run.
+#include "s2l_common.h"
+
+namespace s2l {
+
+// ---- rel pose: B threads, fp64 inside (the composition cancels two ~10-unit translations) ------
+struct M34 {
+  double r[3][3];
+  double t[3];
+};
+
+__device__ M34 transform_of(const float* e, const float* tr) {
+  // prepare_transform_matrix (utils.py:36-52): euler (e0,-e1,-e2), trans (t0,-t1,-t2); euler2rot = Rx Ry Rz with
+  // Rx = [1 0 0; 0 c -s; 0 s c], Ry = [c 0 s; 0 1 0; -s 0 c], Rz = [c s 0; -s c 0; 0 0 1]   (utils.py:19-33)
+  const double th = (double)e[0], ph = -(double)e[1], ps = -(double)e[2];
+  const double ct = cos(th), st = sin(th), cp = cos(ph), sp = sin(ph), cs = cos(ps), ss = sin(ps);
+  const double ry_rz[3][3] = {{cp * cs, cp * ss, sp}, {-ss, cs, 0.0}, {-sp * cs, -sp * ss, cp}};
+  M34 m;
+  for (int j = 0; j < 3; ++j) {
+    m.r[0][j] = ry_rz[0][j];
+    m.r[1][j] = ct * ry_rz[1][j] - st * ry_rz[2][j];
+    m.r[2][j] = st * ry_rz[1][j] + ct * ry_rz[2][j];
+  }
+  m.t[0] = (double)tr[0];
+  m.t[1] = -(double)tr[1];
+  m.t[2] = -(double)tr[2];
+  return m;
+}
+
+__device__ M34 rigid_inverse(const M34& a) {
+  M34 o;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o.r[i][j] = a.r[j][i];
+    o.t[i] = -(a.r[0][i] * a.t[0] + a.r[1][i] * a.t[1] + a.r[2][i] * a.t[2]);
+  }
+  return o;
+}
+
+__device__ M34 compose(const M34& a, const M34& b) {  // a . b
+  M34 o;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o.r[i][j] = a.r[i][0] * b.r[0][j] + a.r[i][1] * b.r[1][j] + a.r[i][2] * b.r[2][j];
+    o.t[i] = a.r[i][0] * b.t[0] + a.r[i][1] * b.t[1] + a.r[i][2] * b.t[2] + a.t[i];
+  }
+  return o;
+}
+
+__global__ void rel_pose_kernel(const float* __restrict__ euler, const float* __restrict__ trans,
+                                const float* __restrict__ canon_euler, const float* __restrict__ canon_trans, int mode,
+                                float* __restrict__ T, int64_t n) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const M34 tc = transform_of(canon_euler, canon_trans);
+  const M34 tf = transform_of(euler + 3 * f, trans + 3 * f);
+  // obs->can: Tc . inv(T); can->obs: T . inv(Tc); its inverse is Tc . inv(T) again (training.py:270-275)
+  const M34 o = mode == S2L_POSE_CAN2OBS ? compose(tf, rigid_inverse(tc)) : compose(tc, rigid_inverse(tf));
+  float* out = T + 16 * f;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)o.r[i][j];
+    out[4 * i + 3] = (float)o.t[i];
+  }
+  out[12] = 0.f, out[13] = 0.f, out[14] = 0.f, out[15] = 1.f;
+}
+
+// ---- warp grid --------------------------------------------------------------------------------------------------
+constexpr int kGridThreads = 256;
+constexpr int kGridPix = 4;  // pixels per lane, strided by the block so every store instruction stays contiguous
+
+__global__ __launch_bounds__(kGridThreads) void warp_grid_kernel(const float* __restrict__ depth, int64_t depth_stride,
+                                                                 const float* __restrict__ T, float focal, float cx, float cy,
+                                                                 int clamp, float eps, float* __restrict__ grid,
+                                                                 float* __restrict__ zout, int H, int W) {
+  const int f = blockIdx.y;
+  const int hw = H * W;
+  const float* t = T + 16 * (int64_t)f;  // wave-uniform: scalar loads
+  // P = (K T)[:3]  (utils.py:157): row0 = f*T0 + cx*T2, row1 = f*T1 + cy*T2, row2 = T2
+  float p0[4], p1[4], p2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p2[j] = t[8 + j];
+    p0[j] = fmaf(focal, t[j], cx * p2[j]);
+    p1[j] = fmaf(focal, t[4 + j], cy * p2[j]);
+  }
+  // pinv(K)[:3,:3] = [1/f 0 -cx/f; 0 1/f -cy/f; 0 0 1]   (utils.py:136)
+  const float inv_f = 1.f / focal, ncx = -cx / focal, ncy = -cy / focal;
+  const float sx = (float)(W - 1), sy = (float)(H - 1);
+  const float* dsrc = depth + depth_stride * f;
+  float2* gdst = reinterpret_cast<float2*>(grid) + (int64_t)f * hw;
+  const int base = blockIdx.x * (kGridThreads * kGridPix) + threadIdx.x;
+  float d[kGridPix];
+#pragma unroll
+  for (int k = 0; k < kGridPix; ++k) {
+    const int i = base + k * kGridThreads;
+    d[k] = i < hw ? dsrc[i] : 1.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kGridPix; ++k) {
+    const int i = base + k * kGridThreads;
+    if (i >= hw) break;
+    const int y = i / W, x = i - y * W;
+    const float X = d[k] * fmaf((float)x, inv_f, ncx), Y = d[k] * fmaf((float)y, inv_f, ncy), Z = d[k];
+    const float px = fmaf(p0[0], X, fmaf(p0[1], Y, fmaf(p0[2], Z, p0[3])));
+    const float py = fmaf(p1[0], X, fmaf(p1[1], Y, fmaf(p1[2], Z, p1[3])));
+    const float pz = fmaf(p2[0], X, fmaf(p2[1], Y, fmaf(p2[2], Z, p2[3])));
+    const float den = pz + eps;
+    float gx = (px / den / sx - 0.5f) * 2.f;  // utils.py:158-163
+    float gy = (py / den / sy - 0.5f) * 2.f;
+    if (clamp) {  // face_tracker.py:606
+      gx = fminf(fmaxf(gx, -1.f), 1.f);
+      gy = fminf(fmaxf(gy, -1.f), 1.f);
+    }
+    gdst[i] = make_float2(gx, gy);
+    if (zout) zout[(int64_t)f * hw + i] = pz;
+  }
+}
+
+// ---- grid sample ------------------------------------------------------------------------------------------------
+template <int BORDER>
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ img, int64_t img_stride,
+                                                          const float* __restrict__ grid, float* __restrict__ out, int IH,
+                                                          int IW, int64_t opix) {
+  const int f = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= opix) return;
+  const float2 g = reinterpret_cast<const float2*>(grid)[(int64_t)f * opix + i];
+  // grid_sampler_unnormalize(align_corners=False): ((g + 1) * size - 1) / 2
+  float ix = ((g.x + 1.f) * (float)IW - 1.f) / 2.f;
+  float iy = ((g.y + 1.f) * (float)IH - 1.f) / 2.f;
+  if (BORDER) {  // clip_coordinates
+    ix = fminf((float)(IW - 1), fmaxf(ix, 0.f));
+    iy = fminf((float)(IH - 1), fmaxf(iy, 0.f));
+  }
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float wx = ix - xw, ex = 1.f - wx, ny = iy - yn, sy = 1.f - ny;
+  const float wraw[4] = {sy * ex, sy * wx, ny * ex, ny * wx};
+  const int x0 = (int)fminf(fmaxf(xw, -2.f), (float)IW + 1.f);
+  const int y0 = (int)fminf(fmaxf(yn, -2.f), (float)IH + 1.f);
+  const float* src = img + img_stride * f;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const bool ok = (unsigned)xx < (unsigned)IW && (unsigned)yy < (unsigned)IH && xw + (float)(t & 1) == (float)xx &&
+                    yn + (float)(t >> 1) == (float)yy;
+    const float w = ok ? wraw[t] : 0.f;
+    const int xc = min(max(xx, 0), IW - 1), yc = min(max(yy, 0), IH - 1);
+    const float* p = src + ((int64_t)yc * IW + xc) * 3;
+    // ATen accumulates nw, ne, sw, se in this order (GridSampler.cpp bilinear branch)
+    acc[0] = acc[0] + p[0] * w;
+    acc[1] = acc[1] + p[1] * w;
+    acc[2] = acc[2] + p[2] * w;
+  }
+  float* o = out + ((int64_t)f * opix + i) * 3;
+  o[0] = acc[0], o[1] = acc[1], o[2] = acc[2];
+}
+
+}  // namespace s2l
+
+extern "C" int s2l_rel_pose(const float* euler, const float* trans, const float* canon_euler, const float* canon_trans,
+                            int mode, float* T, int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames < 0) return S2L_E_SIZE;
+  if (mode != S2L_POSE_OBS2CAN && mode != S2L_POSE_CAN2OBS && mode != S2L_POSE_CAN2OBS_INV) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!euler || !trans || !canon_euler || !canon_trans || !T) return S2L_E_NULL;
+  hipLaunchKernelGGL(s2l::rel_pose_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), euler, trans, canon_euler, canon_trans, mode, T, n_frames);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_warp_grid(const float* depth, int64_t depth_stride, const float* T, float focal, int clamp, float* grid,
+                             float* z, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames < 0 || height < 2 || width < 2 || (int64_t)height * width > (1 << 28) || n_frames > 65535) return S2L_E_SIZE;
+  if (!(focal > 0.f) || (depth_stride != 0 && depth_stride != (int64_t)height * width)) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!depth || !T || !grid) return S2L_E_NULL;
+  if (reinterpret_cast<uintptr_t>(grid) & 7) return S2L_E_ALIGN;
+  const int hw = height * width;
+  const int per_block = s2l::kGridThreads * s2l::kGridPix;
+  hipLaunchKernelGGL(s2l::warp_grid_kernel, dim3((unsigned)((hw + per_block - 1) / per_block), (unsigned)n_frames),
+                     dim3(s2l::kGridThreads), 0, static_cast<hipStream_t>(stream), depth, depth_stride, T, focal,
+                     0.5f * (float)width, 0.5f * (float)height, clamp, 1e-7f, grid, z, height, width);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_grid_sample(const float* img, int64_t img_stride, const float* grid, float* out, int img_h, int img_w,
+                               int out_h, int out_w, int padding, int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames < 0 || img_h < 1 || img_w < 1 || out_h < 1 || out_w < 1 || n_frames > 65535) return S2L_E_SIZE;
+  if (padding != S2L_SAMPLE_ZEROS && padding != S2L_SAMPLE_BORDER) return S2L_E_SIZE;
+  if (img_stride != 0 && img_stride != (int64_t)img_h * img_w * 3) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!img || !grid || !out) return S2L_E_NULL;
+  if (reinterpret_cast<uintptr_t>(grid) & 7) return S2L_E_ALIGN;
+  const int64_t opix = (int64_t)out_h * out_w;
+  const dim3 g((unsigned)((opix + 255) / 256), (unsigned)n_frames);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (padding == S2L_SAMPLE_BORDER)
+    hipLaunchKernelGGL(s2l::grid_sample_kernel<1>, g, dim3(256), 0, st, img, img_stride, grid, out, img_h, img_w, opix);
+  else
+    hipLaunchKernelGGL(s2l::grid_sample_kernel<0>, g, dim3(256), 0, st, img, img_stride, grid, out, img_h, img_w, opix);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,80 @@
+"""CPU: the dataset wire-format reader on a synthetic folder written here in the
+reference's on-disk layout (src/data/someones_lip_dataset.py).  Parity of this row is pinned on the
+reference's documented conventions, not on golden pixels: its reader needs cv2/imageio, which this
+image does not have."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from speech2lip_amd import data as D
+
+
+def _write_folder(root, n=20, fh=40, fw=48, lh=10, lw=12, name="may_face_crop_lip"):
+    from PIL import Image
+    folder = os.path.join(root, name)
+    rng = np.random.default_rng(0)
+    for sub in ("audio", "audio_test", "coords", "ori_images_face", "images", "landmarks"):
+        os.makedirs(os.path.join(folder, sub))
+    np.save(os.path.join(folder, "audio", "audio.npy"), rng.standard_normal((n, 16, 29)))             # float64
+    np.save(os.path.join(folder, "audio_test", "audio.npy"), rng.standard_normal((7, 16, 29)))
+    for i in range(n):
+        np.save(os.path.join(folder, "coords", "%05d.npy" % (i + 1)), (rng.random((fh, fw, 2)) * 2 - 1).astype(np.float32))
+        # flat colours survive JPEG exactly enough to identify frames
+        Image.fromarray(np.full((fh, fw, 3), 10 * i % 250, np.uint8)).save(os.path.join(folder, "ori_images_face", "%05d.jpg" % (i + 1)), quality=100)
+        Image.fromarray(np.full((lh, lw, 3), 100, np.uint8)).save(os.path.join(folder, "images", "%05d.jpg" % (i + 1)), quality=100)
+    mask = np.zeros((fh, fw, 3), np.uint8); mask[15:25, 18:30] = 255
+    Image.fromarray(mask).save(os.path.join(folder, "canonical_lip_mask.jpg"), quality=100)
+    lms = np.zeros((68, 2), np.float32); lms[:, 0] = 5; lms[:, 1] = 5
+    lms[48:, 0] = np.linspace(18.4, 29.6, 20); lms[48:, 1] = np.linspace(16.2, 23.7, 20)
+    np.savetxt(os.path.join(folder, "landmarks", "00001.lms"), lms)
+    return folder
+
+
+def test_bounding_rect_and_mouth_bbox():
+    pts = np.array([[18.4, 16.2], [29.6, 23.7], [20.0, 20.0]], np.float32)
+    assert D.bounding_rect(pts) == (18, 16, 12, 8)
+    lms = np.zeros((68, 2), np.float32); lms[48:] = pts[[0, 1] * 10]
+    # centre x = 18 + 6 = 24, centre y = (16 + 4) * 1.02 = 20.4 -> x = int(24 - 6) = 18, y = int(20.4 - 5) = 15
+    assert D.compute_mouth_bbox(lms, 12, 10, "dataset/may_face_crop_lip") == (18, 15, 12, 10)
+    assert D.compute_mouth_bbox(lms, 12, 10, "dataset/obama_adnerf")[1] == 15          # no 1.02 factor: int(20 - 5)
+    assert D.compute_mouth_bbox(lms, 12, 10, "dataset/macron", 1.1)[1] == int(22.0 - 5)
+
+
+def test_split_slices():
+    assert D.split_slice(1000, "train", "dataset/may_face_crop_lip") == slice(None, 900)
+    assert D.split_slice(1000, "val", "dataset/may_face_crop_lip") == slice(-598, None)
+    assert D.split_slice(1000, "val", "dataset/obama2_face_crop") == slice(-650, None)
+    assert D.split_slice(1000, "val", "dataset/someone") == slice(900, None)
+    assert D.split_slice(1000, "train", "dataset/lip_train_x") == slice(None, 1000)
+
+
+def test_clip_reader_on_synthetic_folder(tmp_path):
+    folder = _write_folder(str(tmp_path), n=20, name="someone_face_crop_lip")
+    ds = D.SomeonesLipClip(folder, "val")
+    assert len(ds) == 2 and (ds.face_h, ds.face_w, ds.lip_h, ds.lip_w) == (40, 48, 10, 12)     # frames 18, 19 of 20
+    assert (ds.lefttop_x, ds.lefttop_y) == D.compute_mouth_bbox(np.loadtxt(os.path.join(folder, "landmarks", "00001.lms")), 12, 10, folder)[:2]
+    clip = ds.load("cpu")
+    assert clip.audio.shape == (2, 16, 29) and clip.audio.dtype == torch.float32
+    assert torch.equal(clip.audio, torch.from_numpy(np.load(os.path.join(folder, "audio", "audio.npy"))[18:].astype(np.float32)))
+    assert clip.index.tolist() == [0, 1] and clip.names == ["00001", "00002"]                   # index is relative to the split
+    assert torch.equal(clip.coord[1], torch.from_numpy(np.load(os.path.join(folder, "coords", "00020.npy"))))
+    assert abs(float(clip.rgb_face_ori[0].mean()) - (180 / 255.0)) < 2 / 255 and clip.rgb_face_ori.shape == (2, 40, 48, 3)
+    assert clip.rgb_face_zero.shape == (1, 40, 48, 3) and abs(float(clip.rgb_face_zero.mean())) < 2 / 255
+    m = clip.mask_lip_canonical[0]
+    assert m.shape == (40, 48, 3) and float(m[20, 24].min()) > 0.98 and float(m[2, 2].max()) < 0.02
+    tr = D.SomeonesLipClip(folder, "train")
+    assert len(tr) == 18
+    te = D.SomeonesLipClip(folder, "test")
+    c = te.load("cpu", first=2, count=3)
+    assert len(te) == 7 and c.audio.shape == (3, 16, 29) and c.coord is None and c.index.tolist() == [2, 3, 4]
+
+
+def test_write_frames_roundtrip(tmp_path):
+    from PIL import Image
+    frames = torch.rand(2, 8, 8, 3)
+    frames[0] = 0.5
+    D.write_frames(frames, ["00001", "00002"], str(tmp_path / "out"))
+    back = np.asarray(Image.open(tmp_path / "out" / "00001.jpg"))
+    assert back.shape == (8, 8, 3) and abs(int(back.mean()) - 127) <= 1

@@ -6,6 +6,8 @@ against the reference frames.  The fp32 noise floor of the reference itself is ~
 these weights (tests/test_oracle_golden.py::test_g3_fp64_truth_is_close), so the tests hold the
 kernels to a 10x tighter bar: RMSE <= 1e-5, max |err| <= 1e-4 on outputs of RMS ~0.5.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -384,3 +386,90 @@ def test_train_step_golden_gradients(golden, dev):
         assert float((g[name].cpu() - T(ref)).abs().max()) <= 2e-4 * scale, name
     scale = float(np.abs(g5["g_pts5_w_cols8"]).max())
     assert float((g["pts_linears.5.weight"][:, :8].cpu() - T(g5["g_pts5_w_cols8"])).abs().max()) <= 2e-4 * scale
+
+
+def test_clip_driver_on_dataset_folder(dev, tmp_path):
+    """§8f-2: dataset folder -> SomeonesLipClip -> render_clip_frames, against the oracle run frame by frame
+    on the same decoded arrays (inference.py:140-172)."""
+    from speech2lip_amd import data as D
+    from tests.test_data_reader import _write_folder
+    folder = _write_folder(str(tmp_path), n=30, fh=40, fw=48, lh=10, lw=12, name="someone_face_crop_lip")
+    ds = D.SomeonesLipClip(folder, "val")
+    clip = ds.load(dev)
+    m = make_model(dev, ds.lip_h, ds.lip_w, path=folder)
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    lip, recon, new = D.render_clip_frames(m, clip)
+    sd_ = O.to_sd(W.make_state_dict(0, "he"))
+    usd = O.to_sd(W.make_unet_state_dict(0))
+    c = D.SomeonesLipClip(folder, "val").load("cpu")
+    from speech2lip_amd import _abi
+    pad = O.PAD_MODE_MAY if m._pad_mode() == _abi.S2L_PAD_MAY else O.PAD_MODE_DEFAULT
+    with torch.no_grad():
+        ref_lip = O.render_clip(sd_, c.audio, c.index.tolist(), c.height, c.width)
+        close(lip, ref_lip)
+        for f in range(len(ds)):
+            ref_new, _ = O.composite(ref_lip[f:f + 1], c.rgb_face_zero, c.rgb_face_ori[f:f + 1], c.mask_lip_canonical,
+                                     c.lip_lefttop_x, c.lip_lefttop_y, c.coord[f:f + 1], pad_mode=pad)
+            close(new[f:f + 1], ref_new)
+            close(recon[f:f + 1], O.unet_forward(usd, ref_new), 1e-5, 1e-4)
+    D.write_frames(recon, clip.names, str(tmp_path / "out"))
+    assert sorted(os.listdir(tmp_path / "out")) == [n + ".jpg" for n in clip.names]
+
+
+def test_rel_pose_and_warp_grid_golden(golden, dev):
+    """§8f-3 against the reference's own utils.py outputs (tools/make_goldens.py G8)."""
+    from speech2lip_amd import geometry as G
+    g = golden("g8_warp.npz")
+    ce, ct, eul, trn, depth = (T(g[k]).to(dev) for k in ("canonical_euler", "canonical_trans", "euler", "trans", "depth"))
+    focal = float(g["focal"])
+    fns = {0: G.compute_rel_pose_from_obs2can, 1: G.compute_rel_pose, 2: G.compute_rel_pose_inverse}
+    for mode, fn in fns.items():
+        Tm = fn(ce, ct, eul, trn)
+        close(Tm, g[f"T_mode{mode}"], 1e-6, 3e-6)       # the reference inverts T with an fp32 LU; the device path composes in fp64
+        grid, z = G.warp_grid(depth, T(g[f"T_mode{mode}"]).to(dev), focal, return_z=True)
+        close(grid, g[f"grid_mode{mode}"], 5e-6, 1e-5)      # fp32 conditioning of the formula: tests/test_oracle_golden.py
+        close(z[:, 0], g[f"z_mode{mode}"], 5e-6, 1e-5)
+        # against the fp64 evaluation of the formula the device path is at least as close as the reference is
+        g64, _ = O.warp_grid(T(g["depth"]).double(), T(g[f"T_mode{mode}"]).double(), focal)
+        e_dev = float((grid.cpu().double() - g64).abs().max())
+        e_ref = float((T(g[f"grid_mode{mode}"]).double() - g64).abs().max())
+        assert e_dev <= max(e_ref, 2e-6), (e_dev, e_ref)
+    cfg = {"data": {"face_img_focal": focal}}
+    img = G.inverse_warping(cfg, depth[0], T(g["iw_T"]).to(dev), T(g["iw_src"]).to(dev))
+    close(img, g["iw_out_nchw"], 2e-5, 1e-4)
+
+
+@pytest.mark.parametrize("H,W,F,shared", [(500, 500, 3, True), (500, 500, 2, False), (7, 9, 5, False), (2, 2, 1, True), (33, 1000, 2, True)])
+def test_warp_grid_vs_oracle_sizes(dev, H, W, F, shared):
+    """Full-size and ragged frames; shared canonical depth and per-frame depth; clamp as face_tracker.py:606."""
+    from speech2lip_amd import geometry as G
+    rng = np.random.default_rng(H * 1000 + W + F)
+    ce = T(np.array([[0.03, 0.01, -0.02]], np.float32)); ct = T(np.array([[0.2, 0.1, -9.0]], np.float32))
+    eul = ce + T(rng.normal(0, 0.1, (F, 3)).astype(np.float32))
+    trn = ct + T(rng.normal(0, 0.3, (F, 3)).astype(np.float32))
+    depth = T((9.0 + rng.normal(0, 0.4, (H, W) if shared else (F, H, W))).astype(np.float32))
+    Tm = G.compute_rel_pose_from_obs2can(ce.to(dev), ct.to(dev), eul.to(dev), trn.to(dev))
+    T64 = O.rel_pose(ce.double(), ct.double(), eul.double(), trn.double(), O.POSE_OBS2CAN)
+    close(Tm, T64.float(), 2e-7, 6e-7)
+    for clamp in (False, True):
+        grid = G.warp_grid(depth.to(dev), Tm, 1200.0, clamp=clamp)
+        ref, _ = O.warp_grid(depth.double(), Tm.cpu().double(), 1200.0, clamp=clamp)
+        close(grid, ref.float(), 2e-6, 1e-5)
+    # coords_for_clip == rel pose + clamped grid, and feeds the composite unchanged
+    c = G.coords_for_clip(depth.to(dev), ce.to(dev), ct.to(dev), eul.to(dev), trn.to(dev), 1200.0)
+    assert torch.equal(c, grid) and float(c.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_grid_sample_vs_torch(dev, pad):
+    """The border/zero-padded bilinear gather against ATen's CPU grid_sample, incl. out-of-range and edge coordinates."""
+    from speech2lip_amd import geometry as G
+    rng = np.random.default_rng(5)
+    img = T(rng.random((3, 37, 53, 3), dtype=np.float32))
+    grid = T((rng.random((3, 29, 31, 2), dtype=np.float32) * 2.6 - 1.3))
+    grid[0, 0, :4] = T(np.array([[-1, -1], [1, 1], [-1, 1], [0, 0]], np.float32))
+    ref = torch.nn.functional.grid_sample(img.permute(0, 3, 1, 2), grid, mode="bilinear", padding_mode=pad, align_corners=False)
+    got = G.grid_sample(img.to(dev), grid.to(dev), pad)
+    close(got.permute(0, 3, 1, 2), ref, 1e-7, 1e-6)
+    shared = G.grid_sample(img[1].to(dev), grid.to(dev), pad)
+    assert torch.equal(shared[1], got[1])

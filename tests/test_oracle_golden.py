@@ -130,3 +130,25 @@ def test_synthetic_audio_shape_and_padding():
     assert a.shape == (16, 16, 29) and a.dtype == np.float64
     assert np.all(a[0, :8] == 0) and np.all(a[-1, -6:] == 0) and np.all(a[8] != 0)
     assert np.allclose(np.exp(a[8]).sum(-1), 1.0)
+
+
+def test_g8_pose_and_warp_grid(golden):
+    """§8f-3: relative poses, BackprojectDepth+Project3D grids and inverse_warping of the reference's utils.py.
+    The grid is ill-conditioned in fp32 (two ~9.5-unit translations cancel inside K.T; the reference's own result sits
+    ~5e-6 from the fp64 evaluation), hence 1e-5 on grids and 1e-4 after the image gradient multiplies it."""
+    g = golden("g8_warp.npz")
+    ce, ct, eul, trn, depth = (T(g[k]) for k in ("canonical_euler", "canonical_trans", "euler", "trans", "depth"))
+    focal = float(g["focal"])
+    for mode in (O.POSE_OBS2CAN, O.POSE_CAN2OBS, O.POSE_CAN2OBS_INV):
+        Tm = O.rel_pose(ce, ct, eul, trn, mode)
+        assert float((Tm - T(g[f"T_mode{mode}"])).abs().max()) <= 1e-6
+        grid, z = O.warp_grid(depth, T(g[f"T_mode{mode}"]), focal)
+        assert float((grid - T(g[f"grid_mode{mode}"])).abs().max()) <= 1e-5
+        assert float((z - T(g[f"z_mode{mode}"])).abs().max()) <= 1e-5
+        # the fp64 evaluation of the whole chain agrees with the reference's fp32 numbers to the same level
+        g64, _ = O.warp_grid(depth.double(), O.rel_pose(ce.double(), ct.double(), eul.double(), trn.double(), mode), focal)
+        assert float((g64 - T(g[f"grid_mode{mode}"]).double()).abs().max()) <= 1e-5
+    # obs->can and the inverse of can->obs are the same transform
+    assert float((O.rel_pose(ce, ct, eul, trn, 0) - O.rel_pose(ce, ct, eul, trn, 2)).abs().max()) <= 2e-6
+    img, _ = O.inverse_warping(depth[0], T(g["iw_T"]), T(g["iw_src"]), focal)
+    assert float((img - T(g["iw_out_nchw"])).abs().max()) <= 1e-4

@@ -227,13 +227,54 @@ def main():
         g7["recon_after_composite_mode0"] = recon.numpy()
         np.savez_compressed(os.path.join(GOLD, "g7_unet.npz"), **g7)
 
+    # ---- G8: pose -> warp grid: utils.py geometry, as face_tracker.py:583-606 and training.py:296-314 use it
+    with torch.no_grad():
+        import src.face_simple.models.utils as U
+        B, H, Wd, focal = 5, 28, 36, 1200.0
+        ce = torch.tensor([[0.05, -0.02, 0.01]]); ct = torch.tensor([[0.3, -0.2, -9.5]])
+        eul = ce + torch.from_numpy(rng.normal(0, 0.08, (B, 3)).astype(np.float32))
+        trn = ct + torch.from_numpy(rng.normal(0, 0.25, (B, 3)).astype(np.float32))
+        depth = torch.from_numpy((9.5 + rng.normal(0, 0.3, (B, H, Wd))).astype(np.float32))
+        g8 = dict(canonical_euler=ce.numpy(), canonical_trans=ct.numpy(), euler=eul.numpy(), trans=trn.numpy(),
+                  depth=depth.numpy(), focal=np.array(focal, np.float32))
+        Ts = {O.POSE_OBS2CAN: U.compute_rel_pose_from_obs2can, O.POSE_CAN2OBS: U.compute_rel_pose,
+              O.POSE_CAN2OBS_INV: U.compute_rel_pose_inverse}
+        K = np.array([[focal, 0, Wd / 2, 0], [0, focal, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+        inv_K = torch.from_numpy(np.linalg.pinv(K)).unsqueeze(0)
+        K = torch.from_numpy(K).unsqueeze(0)
+        for mode, fn in Ts.items():
+            T_ref = fn(ce.repeat(B, 1), ct.repeat(B, 1), eul, trn, img_batch_size=B, device=torch.device("cpu"))
+            report[f"rel_pose_mode{mode}"] = maxerr(T_ref, O.rel_pose(ce, ct, eul, trn, mode))
+            g8[f"T_mode{mode}"] = T_ref.numpy()
+            cam = U.BackprojectDepth(B, H, Wd, device=torch.device("cpu"))(depth, inv_K)
+            grid_ref, z_ref = U.Project3D(B, H, Wd)(cam, K, T_ref, return_z=True)
+            g_or, z_or = O.warp_grid(depth, T_ref, focal)
+            report[f"warp_grid_mode{mode}"] = max(maxerr(grid_ref, g_or), maxerr(z_ref[:, 0], z_or) * 1e-1)
+            g8[f"grid_mode{mode}"] = grid_ref.numpy(); g8[f"z_mode{mode}"] = z_ref[:, 0].numpy()
+            g64, _ = O.warp_grid(depth.double(), O.rel_pose(ce.double(), ct.double(), eul.double(), trn.double(), mode), focal)
+            print(f"  [info] mode {mode}: reference fp32 grid vs fp64 evaluation {maxerr(grid_ref, g64):.3e}; oracle fp32 vs fp64 {maxerr(g_or, g64):.3e}")
+        # inverse_warping with one shared (canonical) depth map, batch 1, as the depth photo loss calls it
+        cfg_w = {"data": {"face_img_focal": focal}, "model": {"canonical_depth_height": H, "canonical_depth_width": Wd}}
+        src = torch.from_numpy(rng.random((1, H, Wd, 3), dtype=np.float32))
+        T1 = torch.from_numpy(g8[f"T_mode{O.POSE_CAN2OBS_INV}"][2:3])
+        img_ref = U.inverse_warping(cfg_w, depth[0], T1, src, None, torch.device("cpu"))
+        img_or, _ = O.inverse_warping(depth[0], T1, src, focal)
+        report["inverse_warping"] = maxerr(img_ref, img_or)
+        g8["iw_src"] = src.numpy(); g8["iw_T"] = T1.numpy(); g8["iw_out_nchw"] = img_ref.numpy()
+        np.savez_compressed(os.path.join(GOLD, "g8_warp.npz"), **g8)
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
-    worst = 0.0
+    # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
+    # sits ~4e-6 from the fp64 evaluation of the same formula), and inverse_warping multiplies that by the image gradient.
+    limits = {"inverse_warping": 1e-4}
+    limits.update({k: 1e-5 for k in report if k.startswith("warp_grid")})
+    bad = []
     for k, v in report.items():
         print(f"  {k:40s} {v:.3e}")
-        worst = max(worst, v)
-    assert worst <= 5e-6, f"oracle deviates from the reference: {worst}"
+        if v > limits.get(k, 5e-6):
+            bad.append(k)
+    assert not bad, f"oracle deviates from the reference: {bad}"
     print("OK: oracle pinned; goldens written to", GOLD)
 
 
