@@ -220,6 +220,35 @@ int s2l_warp_grid(const float* depth, int64_t depth_stride, const float* T, floa
 int s2l_grid_sample(const float* img, int64_t img_stride, const float* grid, float* out, int img_h, int img_w,
                     int out_h, int out_w, int padding, int64_t n_frames, s2l_stream_t stream);
 
+/* ---- T3: lip-sync expert loss ---------------------------------------------------
+ * Replaces SyncNet_color.forward (src/face_simple/models/syncnet.py:57-67, conv.py:5-19) in eval mode, and
+ * Trainer.cosine_loss / get_sync_contrastive_loss (src/face_simple/training.py:576-603) with the gradient the
+ * reference gets from autograd for the generated window (the net is frozen, training.py:85-90).
+ * s2l_syncnet_pack: tensors_host = HOST array of 31*6 DEVICE pointers: for the 17 face_encoder blocks then the
+ * 14 audio_encoder blocks {conv_block.0.weight [co,ci,kh,kw], conv_block.0.bias, conv_block.1.weight, .bias,
+ * .running_mean, .running_var}; BatchNorm (eps = bn_eps) is folded.
+ * s2l_syncnet_forward: mel [B,80,16] (= [B,1,80,16]); face [B,48,96,15] NHWC (channel 3t+c, BGR, lower half
+ * rows: build it with s2l_sync_window); audio_emb, face_emb [B,512], L2-normalised (:63-64); work:
+ * s2l_syncnet_work_floats(B) floats, keeps the activations s2l_syncnet_face_backward needs.
+ * s2l_sync_loss: BCELoss(cosine_similarity(a, v), y) * weight (mean over B); y [B]; scratch [B]; *loss is
+ * overwritten, or added to when accumulate != 0; d_face_emb NULL or [B,512] = d loss / d face_emb.
+ * s2l_syncnet_face_backward: d_face [B,48,96,15] = d loss / d face, from d_face_emb and the `work` of the forward.
+ * s2l_sync_window: g_rgb [B,3,T,H,W] (RGB, the reference's rgb_window layout) -> face [B,H-H/2,W,3T]
+ * (training.py:588-590); s2l_sync_window_backward is its adjoint (rows above H/2 get zero). */
+int64_t s2l_syncnet_packed_floats(void);
+int64_t s2l_syncnet_work_floats(int64_t batch);
+int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
+int s2l_syncnet_forward(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                        float* face_emb, int64_t batch, s2l_stream_t stream);
+int s2l_sync_loss(const float* audio_emb, const float* face_emb, const float* y, float weight, float* scratch,
+                  float* loss, int accumulate, float* d_face_emb, int64_t batch, s2l_stream_t stream);
+int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
+                              float* d_face, int64_t batch, s2l_stream_t stream);
+int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,
+                    s2l_stream_t stream);
+int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width,
+                             int64_t batch, s2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,6 +336,51 @@ def inverse_warping(depth: torch.Tensor, T: torch.Tensor, src_nhwc: torch.Tensor
     return img, z[:, None]
 
 
+# --------------------------------------------------------------------------- T3: lip-sync expert loss
+def syncnet_encoder(sd: SD, x: torch.Tensor, prefix: str, blocks, eps: float = 1e-5) -> torch.Tensor:
+    """One encoder of SyncNet_color (syncnet.py:11-54) in eval mode: per block conv -> BatchNorm(running stats) ->
+    (+ x if residual) -> ReLU (conv.py:5-19).  `blocks` = speech2lip_amd.weights.SYNCNET_FACE / SYNCNET_AUDIO."""
+    for i, (cin, cout, k, stride, pad, res) in enumerate(blocks):
+        p = f"{prefix}.{i}.conv_block."
+        y = F.conv2d(x, sd[p + "0.weight"], sd[p + "0.bias"], stride=stride, padding=pad)
+        y = F.batch_norm(y, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"],
+                         training=False, eps=eps)
+        x = F.relu(y + x if res else y)
+    return x
+
+
+def syncnet_forward(sd: SD, audio_sequences: torch.Tensor, face_sequences: torch.Tensor, blocks_face, blocks_audio):
+    """SyncNet_color.forward (syncnet.py:57-67): ([B,1,80,16], [B,15,48,96]) -> L2-normalised ([B,512], [B,512])."""
+    f = syncnet_encoder(sd, face_sequences, "face_encoder", blocks_face)
+    a = syncnet_encoder(sd, audio_sequences, "audio_encoder", blocks_audio)
+    a, f = a.reshape(a.shape[0], -1), f.reshape(f.shape[0], -1)
+    return F.normalize(a, p=2, dim=1), F.normalize(f, p=2, dim=1)
+
+
+def sync_window(g_rgb: torch.Tensor, syncnet_T: int = 5) -> torch.Tensor:
+    """[B,3,T,H,W] RGB -> [B,3T,H-H//2,W]: BGR, lower half rows, frames stacked on channels (training.py:588-590)."""
+    g = g_rgb[:, [2, 1, 0]]
+    g = g[:, :, :, g.size(3) // 2:]
+    return torch.cat([g[:, :, i] for i in range(syncnet_T)], dim=1)
+
+
+def cosine_loss(a: torch.Tensor, v: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """training.py:576-579."""
+    d = F.cosine_similarity(a, v)
+    return F.binary_cross_entropy(d.unsqueeze(1), y)
+
+
+def sync_contrastive_loss(sd: SD, mel, g_rgb_pos, g_rgb_neg, blocks_face, blocks_audio, syncnet_T: int = 5):
+    """Trainer.get_sync_contrastive_loss (training.py:581-603): BCE(cos, 1) on the generated window + BCE(cos, 0) on the
+    negative window."""
+    B = mel.shape[0]
+    a, v = syncnet_forward(sd, mel, sync_window(g_rgb_pos, syncnet_T), blocks_face, blocks_audio)
+    pos = cosine_loss(a, v, torch.ones(B, 1, dtype=mel.dtype))
+    a, v = syncnet_forward(sd, mel, sync_window(g_rgb_neg, syncnet_T), blocks_face, blocks_audio)
+    neg = cosine_loss(a, v, torch.zeros(B, 1, dtype=mel.dtype))
+    return pos + neg
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
     mse = float(((a.double() - b.double()) ** 2).mean())
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

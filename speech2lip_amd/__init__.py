@@ -6,7 +6,9 @@ from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
 from . import training
 from .training import LipTrainStep, Trainer, predict_lip_image
 from .unet import SimpleUnetLight
+from .syncnet import SyncLoss, SyncNet_color
+from . import geometry
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
            "predict_lip_image", "LipTrainStep", "training",
-           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames"]
+           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "SyncNet_color", "SyncLoss", "geometry"]

@@ -70,6 +70,14 @@ EXPORTS = {
                               c_void_p]),
     "s2l_grid_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64,
                                 c_void_p]),
+    "s2l_syncnet_packed_floats": (c_int64, []),
+    "s2l_syncnet_work_floats": (c_int64, [c_int64]),
+    "s2l_syncnet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),
+    "s2l_syncnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_sync_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "s2l_syncnet_face_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_sync_window": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_sync_window_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,555 @@
+// T3: the "lipsync_expert" loss -- SyncNet_color (src/face_simple/models/syncnet.py:7-67, conv.py:5-19)
+// in eval mode, cosine similarity + BCE (training.py:576-603), and the gradient of that loss with respect to the
+// generated face window (SyncNet itself is frozen, training.py:85-90, so no weight gradients exist).
+//
+// Every convolution of both encoders -- kernels 1/3/5/7, strides (1|2|3) x (1|2|3), padding 0/1/3, 1..512 channels, with
+// the eval-mode BatchNorm folded into the packed weights, optional residual add and ReLU -- is ONE implicit-GEMM kernel on
+// v_mfma_f32_16x16x4_f32 (exact fp32):  D[row][col] = sum_k A[row][k] B[k][col]
+//   forward : rows = output channels, cols = output pixels (b,oy,ox), k = (ky,kx,ci), B gathered from the NHWC input
+//   dgrad   : rows = input channels,  cols = input pixels  (b,iy,ix), k = (ky,kx,co), B gathered from the masked output
+//             gradient at oy = (iy + pad - ky) / stride where that division is exact
+// A workgroup (4 waves, 2x2) owns a 64x64 tile; K advances in chunks of 16 through LDS with the next chunk's global loads
+// in flight during the MFMAs.  The deep layers have 1..36 pixels and K up to 4608, so K is also split across
+// gridDim.z into partial tiles that a second kernel reduces in a fixed order (deterministic) before the epilogue.
+// The whole net is ~1.2 GMAC per window: launch- and weight-read-bound (65 MB of fp32 weights per pass), not MFMA-bound.
+#include "s2l_common.h"
+
+namespace s2l {
+
+struct LayerSpec {
+  int cin, cout, kh, kw, sy, sx, py, px, res;
+};
+
+// syncnet.py:11-33
+static const LayerSpec kFace[] = {
+    {15, 32, 7, 7, 1, 1, 3, 3, 0},    {32, 64, 5, 5, 1, 2, 1, 1, 0},    {64, 64, 3, 3, 1, 1, 1, 1, 1},
+    {64, 64, 3, 3, 1, 1, 1, 1, 1},    {64, 128, 3, 3, 2, 2, 1, 1, 0},   {128, 128, 3, 3, 1, 1, 1, 1, 1},
+    {128, 128, 3, 3, 1, 1, 1, 1, 1},  {128, 128, 3, 3, 1, 1, 1, 1, 1},  {128, 256, 3, 3, 2, 2, 1, 1, 0},
+    {256, 256, 3, 3, 1, 1, 1, 1, 1},  {256, 256, 3, 3, 1, 1, 1, 1, 1},  {256, 512, 3, 3, 2, 2, 1, 1, 0},
+    {512, 512, 3, 3, 1, 1, 1, 1, 1},  {512, 512, 3, 3, 1, 1, 1, 1, 1},  {512, 512, 3, 3, 2, 2, 1, 1, 0},
+    {512, 512, 3, 3, 1, 1, 0, 0, 0},  {512, 512, 1, 1, 1, 1, 0, 0, 0}};
+// syncnet.py:35-54
+static const LayerSpec kAudio[] = {
+    {1, 32, 3, 3, 1, 1, 1, 1, 0},     {32, 32, 3, 3, 1, 1, 1, 1, 1},    {32, 32, 3, 3, 1, 1, 1, 1, 1},
+    {32, 64, 3, 3, 3, 1, 1, 1, 0},    {64, 64, 3, 3, 1, 1, 1, 1, 1},    {64, 64, 3, 3, 1, 1, 1, 1, 1},
+    {64, 128, 3, 3, 3, 3, 1, 1, 0},   {128, 128, 3, 3, 1, 1, 1, 1, 1},  {128, 128, 3, 3, 1, 1, 1, 1, 1},
+    {128, 256, 3, 3, 3, 2, 1, 1, 0},  {256, 256, 3, 3, 1, 1, 1, 1, 1},  {256, 256, 3, 3, 1, 1, 1, 1, 1},
+    {256, 512, 3, 3, 1, 1, 0, 0, 0},  {512, 512, 1, 1, 1, 1, 0, 0, 0}};
+constexpr int kNumFace = 17, kNumAudio = 14, kNumLayers = kNumFace + kNumAudio, kSyncEmb = 512;
+constexpr int kFaceH = 48, kFaceW = 96, kMelH = 80, kMelW = 16;
+
+inline int ceil_to(int a, int m) { return (a + m - 1) / m * m; }
+inline const LayerSpec& spec_of(int l) { return l < kNumFace ? kFace[l] : kAudio[l - kNumFace]; }
+
+// packed blob: per layer {forward weights [kh*kw*ceil16(cin)][ceil64(cout)], bias [ceil64(cout)]}, then for the face
+// encoder the dgrad weights [kh*kw*ceil16(cout)][ceil64(cin)].
+struct PackedLayout {
+  int64_t w[kNumLayers], b[kNumLayers], wt[kNumFace], total;
+};
+inline PackedLayout packed_layout() {
+  PackedLayout p;
+  int64_t o = 0;
+  for (int l = 0; l < kNumLayers; ++l) {
+    const LayerSpec& s = spec_of(l);
+    p.w[l] = o;
+    o += (int64_t)s.kh * s.kw * ceil_to(s.cin, 16) * ceil_to(s.cout, 64);
+    p.b[l] = o;
+    o += ceil_to(s.cout, 64);
+  }
+  for (int l = 0; l < kNumFace; ++l) {
+    const LayerSpec& s = kFace[l];
+    p.wt[l] = o;
+    o += (int64_t)s.kh * s.kw * ceil_to(s.cout, 16) * ceil_to(s.cin, 64);
+  }
+  p.total = o;
+  return p;
+}
+
+// ---- packing: fold BatchNorm (eval), lay out for the implicit GEMM ----------------------------------------------------
+// forward:  dst[(tap*cinp + ci)*RP + co] = w[co][ci][ky][kx] * g[co]/sqrt(var[co]+eps)
+// dgrad:    dst[(tap*coutp + co)*RP + ci] = the same number, K and row roles swapped
+__global__ void syncnet_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
+                                    float eps, float* __restrict__ dst, int cin, int cout, int kh, int kw, int kcp, int RP,
+                                    int dgrad, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = (int)(i % RP);
+  const int64_t kidx = i / RP;
+  const int kc = (int)(kidx % kcp), tap = (int)(kidx / kcp);
+  const int ky = tap / kw, kx = tap % kw;
+  const int co = dgrad ? kc : row, ci = dgrad ? row : kc;
+  float v = 0.f;
+  if (co < cout && ci < cin) v = w[(((int64_t)co * cin + ci) * kh + ky) * kw + kx] * (gamma[co] / sqrtf(var[co] + eps));
+  dst[i] = v;
+}
+
+__global__ void syncnet_pack_bias_kernel(const float* __restrict__ b, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                         const float* __restrict__ var, float eps, float* __restrict__ dst, int cout, int RP) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RP) return;
+  dst[i] = i < cout ? (b[i] - mean[i]) * (gamma[i] / sqrtf(var[i] + eps)) + beta[i] : 0.f;
+}
+
+// ---- the implicit-GEMM convolution --------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;    // fwd: a_{L-1} [B,hin,win,cin];  dgrad: g_L [B,hout,wout,cout] (gradient w.r.t. the pre-ReLU sum)
+  const float* w;     // packed A operand [K/16][16][RP]
+  const float* bias;  // fwd: folded bias [RP]
+  const float* res;   // fwd: residual source (a_{L-1}) or null;  dgrad: g_L when the layer is residual (pass-through) or null
+  const float* mask;  // dgrad: a_{L-1}; the result is multiplied by (a_{L-1} > 0) (ReLU of the layer below) -- or null
+  float* out;         // fwd: a_L [B,hout,wout,cout];  dgrad: g_{L-1} [B,hin,win,cin]
+  float* partial;     // split-K: [splits][ncols][RP] partial sums, else null
+  int hin, win, cin, hout, wout, cout, kh, kw, sy, sx, py, px;
+  int rows, RP, kc, kcp, ncols, nchunks, chunks_per_split;
+};
+
+constexpr int kLd = 80;  // LDS row stride in floats: 80 % 32 == 16 keeps the four k-rows of an operand read on distinct banks
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+  __shared__ float As[16 * kLd];
+  __shared__ float Bs[16 * kLd];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
+  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+  const int chunk_lo = blockIdx.z * a.chunks_per_split;
+  const int chunk_hi = min(a.nchunks, chunk_lo + a.chunks_per_split);
+
+  // B-load role: pixel pl of the tile, channel quad cq of the chunk
+  const int pl = t >> 2, cq = t & 3;
+  const int col = col0 + pl;
+  const bool col_ok = col < a.ncols;
+  const int cw = DGRAD ? a.win : a.wout, chw = DGRAD ? a.hin * a.win : a.hout * a.wout;
+  const int cc = col_ok ? col : 0;
+  const int n = cc / chw, rem = cc - n * chw;
+  const int cy = rem / cw, cx = rem - cy * cw;
+  // A-load role
+  const int ak = t >> 4, ar4 = t & 15;
+  const bool vec = (a.kc & 3) == 0;
+
+  f4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int chunk, f4& av, f4& bv) {
+    av = *reinterpret_cast<const f4*>(a.w + ((int64_t)chunk * 16 + ak) * a.RP + row0 + ar4 * 4);
+    const int kidx0 = chunk * 16;
+    const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp + 4 * cq;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    bool ok = col_ok && c0 < a.kc;
+    const float* src;
+    if (!DGRAD) {
+      const int iy = cy * a.sy - a.py + ky, ix = cx * a.sx - a.px + kx;
+      ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      src = a.in + (((int64_t)n * a.hin + iy) * a.win + ix) * a.cin + c0;
+    } else {
+      const int ty = cy + a.py - ky, tx = cx + a.px - kx;
+      const int oy = ty / a.sy, ox = tx / a.sx;
+      ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
+      src = a.in + (((int64_t)n * a.hout + oy) * a.wout + ox) * a.cout + c0;
+    }
+    bv = f4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      if (vec) {
+        bv = *reinterpret_cast<const f4*>(src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < a.kc) bv[j] = src[j];
+      }
+    }
+  };
+
+  f4 av, bv;
+  if (chunk_lo < chunk_hi) fetch(chunk_lo, av, bv);
+  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+    __syncthreads();  // the previous chunk's operand reads are done
+    *reinterpret_cast<f4*>(&As[ak * kLd + ar4 * 4]) = av;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bs[(4 * cq + j) * kLd + pl] = bv[j];
+    __syncthreads();
+    if (chunk + 1 < chunk_hi) fetch(chunk + 1, av, bv);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = As[(4 * kk + q) * kLd + 32 * wm + 16 * i + l16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = Bs[(4 * kk + q) * kLd + 32 * wn + 16 * j + l16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  // D[row = 4q + r][col = l16] of sub-tile (i, j)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = col0 + 32 * wn + 16 * j + l16;
+    if (c >= a.ncols) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r0 = row0 + 32 * wm + 16 * i + 4 * q;
+      if (a.partial) {
+        *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.RP + r0) = acc[i][j];
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + r;
+        if (row >= a.rows) continue;
+        const int64_t o = (int64_t)c * a.rows + row;
+        float v = acc[i][j][r];
+        if (!DGRAD) {
+          v += a.bias[row];
+          if (a.res) v += a.res[o];
+          v = fmaxf(v, 0.f);
+        } else {
+          if (a.res) v += a.res[o];
+          if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+        }
+        a.out[o] = v;
+      }
+    }
+  }
+}
+
+// split-K: sum the partial tiles in split order, then the same epilogue.  thread = (col, row quad)
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int rq = a.RP / 4;
+  if (i >= (int64_t)a.ncols * rq) return;
+  const int c = (int)(i / rq), r0 = (int)(i % rq) * 4;
+  f4 s = *reinterpret_cast<const f4*>(a.partial + (int64_t)c * a.RP + r0);
+  for (int k = 1; k < splits; ++k) {
+    const f4 p = *reinterpret_cast<const f4*>(a.partial + ((int64_t)k * a.ncols + c) * a.RP + r0);
+    s += p;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + r;
+    if (row >= a.rows) continue;
+    const int64_t o = (int64_t)c * a.rows + row;
+    float v = s[r];
+    if (!DGRAD) {
+      v += a.bias[row];
+      if (a.res) v += a.res[o];
+      v = fmaxf(v, 0.f);
+    } else {
+      if (a.res) v += a.res[o];
+      if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+    }
+    a.out[o] = v;
+  }
+}
+
+// ---- embeddings, loss ---------------------------------------------------------------------------------------------------
+// F.normalize(x, p=2, dim=1): x / max(||x||, 1e-12)   (syncnet.py:63-64).  One wave per row.
+__global__ __launch_bounds__(64) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int dim) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  float s = 0.f;
+  for (int i = l; i < dim; i += 64) s = fmaf(x[(int64_t)b * dim + i], x[(int64_t)b * dim + i], s);
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int i = l; i < dim; i += 64) y[(int64_t)b * dim + i] = x[(int64_t)b * dim + i] * inv;
+}
+
+// cosine_loss (training.py:576-579): d = cosine_similarity(a, v) (eps 1e-8), loss = BCELoss(d, y) (mean over the batch, log
+// clamped at -100), times `weight`; optional gradient with respect to v.  ATen: d = a.v / sqrt(max(|a|^2 |v|^2, eps^2));
+// binary_cross_entropy_backward = (d - y) / max((1 - d) d, 1e-12).  One wave per row; losses[b] summed by the host kernel below.
+__global__ __launch_bounds__(64) void cosine_bce_kernel(const float* __restrict__ a, const float* __restrict__ v,
+                                                        const float* __restrict__ y, float scale, float* __restrict__ losses,
+                                                        float* __restrict__ dv, int dim) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  const float* ab = a + (int64_t)b * dim;
+  const float* vb = v + (int64_t)b * dim;
+  float saa = 0.f, svv = 0.f, sav = 0.f;
+  for (int i = l; i < dim; i += 64) {
+    saa = fmaf(ab[i], ab[i], saa);
+    svv = fmaf(vb[i], vb[i], svv);
+    sav = fmaf(ab[i], vb[i], sav);
+  }
+  for (int o = 32; o; o >>= 1) {
+    saa += __shfl_xor(saa, o);
+    svv += __shfl_xor(svv, o);
+    sav += __shfl_xor(sav, o);
+  }
+  const float den2 = fmaxf(saa * svv, 1e-16f);
+  const float inv_den = 1.f / sqrtf(den2);
+  const float d = sav * inv_den;
+  const float yy = y[b];
+  const float loss = -(yy * fmaxf(logf(d), -100.f) + (1.f - yy) * fmaxf(logf(1.f - d), -100.f));
+  if (l == 0) losses[b] = loss * scale;
+  if (dv) {
+    const float gd = (d - yy) / fmaxf((1.f - d) * d, 1e-12f) * scale;
+    // dd/dv = a / den - d * v / |v|^2   (the eps clamp is inactive for unit vectors)
+    const float c1 = gd * inv_den, c2 = gd * d / fmaxf(svv, 1e-30f);
+    for (int i = l; i < dim; i += 64) dv[(int64_t)b * dim + i] = c1 * ab[i] - c2 * vb[i];
+  }
+}
+
+__global__ void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int accumulate) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += x[i];
+    out[0] = accumulate ? out[0] + s : s;
+  }
+}
+
+// backward of F.normalize followed by the ReLU of the last layer: g_top = ((dvn - vn (vn . dvn)) / max(|v|, 1e-12)) * (v > 0)
+__global__ __launch_bounds__(64) void normalize_bwd_kernel(const float* __restrict__ vraw, const float* __restrict__ dvn,
+                                                           float* __restrict__ g, int dim) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  const float* vb = vraw + (int64_t)b * dim;
+  const float* db = dvn + (int64_t)b * dim;
+  float svv = 0.f, svd = 0.f;
+  for (int i = l; i < dim; i += 64) {
+    svv = fmaf(vb[i], vb[i], svv);
+    svd = fmaf(vb[i], db[i], svd);
+  }
+  for (int o = 32; o; o >>= 1) {
+    svv += __shfl_xor(svv, o);
+    svd += __shfl_xor(svd, o);
+  }
+  const float inv = 1.f / fmaxf(sqrtf(svv), 1e-12f);
+  const float dot = svd * inv * inv;  // (vn . dvn) / |v| with vn = v * inv
+  for (int i = l; i < dim; i += 64) {
+    const float v = vb[i];
+    g[(int64_t)b * dim + i] = v > 0.f ? (db[i] - v * dot) * inv : 0.f;
+  }
+}
+
+// ---- window assembly (training.py:588-590): g [B,3,T,H,W] RGB -> face [B,H-H/2,W,3T], channel 3t+c = BGR channel c of
+// frame t, rows H/2..H-1; and its adjoint (the upper rows of the gradient are zero).
+__global__ __launch_bounds__(256) void sync_window_kernel(const float* __restrict__ g, float* __restrict__ face, int T, int H,
+                                                          int W, int64_t n, int adjoint, float* __restrict__ dg) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int top = H / 2, hh = H - top;
+  if (!adjoint) {  // i indexes face [B,hh,W,3T]
+    const int ch = (int)(i % (3 * T));
+    int64_t r = i / (3 * T);
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % hh);
+    const int b = (int)(r / hh);
+    const int t = ch / 3, c = ch % 3;
+    face[i] = g[((((int64_t)b * 3 + (2 - c)) * T + t) * H + (top + y)) * W + x];
+  } else {  // i indexes dg [B,3,T,H,W]
+    const int x = (int)(i % W);
+    int64_t r = i / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int t = (int)(r % T);
+    r /= T;
+    const int c_rgb = (int)(r % 3);
+    const int b = (int)(r / 3);
+    const int y2 = y - top;
+    dg[i] = y2 >= 0 ? face[(((int64_t)b * hh + y2) * W + x) * (3 * T) + 3 * t + (2 - c_rgb)] : 0.f;
+  }
+}
+
+// ---- host-side plan -------------------------------------------------------------------------------------------------------
+struct Shape {
+  int h, w;
+};
+inline Shape out_shape(const LayerSpec& s, Shape in) {
+  return Shape{(in.h + 2 * s.py - s.kh) / s.sy + 1, (in.w + 2 * s.px - s.kw) / s.sx + 1};
+}
+
+// work buffer: face activations a_0..a_16, audio activations a_0..a_13, two gradient ping-pong buffers, split-K partials
+constexpr int64_t kPartialFloats = 1 << 21;
+struct WorkLayout {
+  int64_t act[kNumLayers];
+  Shape in_shape[kNumLayers], out_shape_[kNumLayers];
+  int64_t grad[2], partial, total;
+};
+inline WorkLayout work_layout(int64_t B) {
+  WorkLayout wl;
+  int64_t o = 0, max_act = (int64_t)kFaceH * kFaceW * 16;
+  Shape sh{kFaceH, kFaceW};
+  for (int l = 0; l < kNumLayers; ++l) {
+    if (l == kNumFace) sh = Shape{kMelH, kMelW};
+    const LayerSpec& s = spec_of(l);
+    wl.in_shape[l] = sh;
+    sh = out_shape(s, sh);
+    wl.out_shape_[l] = sh;
+    wl.act[l] = o;
+    const int64_t n = B * sh.h * sh.w * s.cout;
+    o += (n + 3) / 4 * 4;
+    if (l < kNumFace && n / B > max_act) max_act = n / B;
+  }
+  for (int k = 0; k < 2; ++k) {
+    wl.grad[k] = o;
+    o += (B * max_act + 3) / 4 * 4;
+  }
+  wl.partial = o;
+  o += kPartialFloats;
+  wl.total = o;
+  return wl;
+}
+
+template <bool DGRAD>
+int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
+  a.ncols = (int)(B * (DGRAD ? a.hin * a.win : a.hout * a.wout));
+  a.rows = DGRAD ? a.cin : a.cout;
+  a.RP = ceil_to(a.rows, 64);
+  a.kc = DGRAD ? a.cout : a.cin;
+  a.kcp = ceil_to(a.kc, 16);
+  a.nchunks = a.kh * a.kw * a.kcp / 16;
+  const int tiles = ((a.ncols + 63) / 64) * (a.RP / 64);
+  int splits = 1;
+  if (tiles < 128 && a.nchunks >= 16) {
+    splits = min(min(256 / tiles, a.nchunks / 8), 64);
+    while (splits > 1 && (int64_t)splits * a.ncols * a.RP > kPartialFloats) --splits;
+  }
+  a.chunks_per_split = (a.nchunks + splits - 1) / splits;
+  splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  float* partial = a.partial;
+  a.partial = splits > 1 ? partial : nullptr;
+  hipLaunchKernelGGL(conv_gemm_kernel<DGRAD>, dim3((a.ncols + 63) / 64, a.RP / 64, splits), dim3(256), 0, st, a);
+  if (splits > 1) {
+    const int64_t n = (int64_t)a.ncols * (a.RP / 4);
+    hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
+  }
+  return (int)hipGetLastError();
+}
+
+inline ConvArgs base_args(const LayerSpec& s, Shape in, Shape out) {
+  ConvArgs a{};
+  a.hin = in.h, a.win = in.w, a.cin = s.cin, a.hout = out.h, a.wout = out.w, a.cout = s.cout;
+  a.kh = s.kh, a.kw = s.kw, a.sy = s.sy, a.sx = s.sx, a.py = s.py, a.px = s.px;
+  return a;
+}
+
+}  // namespace s2l
+
+using namespace s2l;
+
+extern "C" int64_t s2l_syncnet_packed_floats(void) { return packed_layout().total; }
+extern "C" int64_t s2l_syncnet_work_floats(int64_t batch) { return batch < 1 ? 0 : work_layout(batch).total; }
+
+extern "C" int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream) {
+  if (!tensors_host || !packed) return S2L_E_NULL;
+  for (int i = 0; i < kNumLayers * 6; ++i)
+    if (!tensors_host[i]) return S2L_E_NULL;
+  if (misaligned16(packed)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const PackedLayout pl = packed_layout();
+  for (int l = 0; l < kNumLayers; ++l) {
+    const LayerSpec& s = spec_of(l);
+    const float* const* t = tensors_host + 6 * l;  // conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var
+    const int RP = ceil_to(s.cout, 64), kcp = ceil_to(s.cin, 16);
+    const int64_t n = (int64_t)s.kh * s.kw * kcp * RP;
+    hipLaunchKernelGGL(syncnet_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
+                       packed + pl.w[l], s.cin, s.cout, s.kh, s.kw, kcp, RP, 0, n);
+    hipLaunchKernelGGL(syncnet_pack_bias_kernel, dim3((RP + 255) / 256), dim3(256), 0, st, t[1], t[2], t[3], t[4], t[5], bn_eps,
+                       packed + pl.b[l], s.cout, RP);
+    if (l < kNumFace) {
+      const int RPt = ceil_to(s.cin, 64), kcpt = ceil_to(s.cout, 16);
+      const int64_t nt = (int64_t)s.kh * s.kw * kcpt * RPt;
+      hipLaunchKernelGGL(syncnet_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
+                         packed + pl.wt[l], s.cin, s.cout, s.kh, s.kw, kcpt, RPt, 1, nt);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_syncnet_forward(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                   float* face_emb, int64_t batch, s2l_stream_t stream) {
+  if (batch < 0 || batch > 4096) return S2L_E_SIZE;
+  if (batch == 0) return S2L_OK;
+  if (!packed || !mel || !face || !work || !audio_emb || !face_emb) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(work) || misaligned16(face) || misaligned16(mel)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const PackedLayout pl = packed_layout();
+  const WorkLayout wl = work_layout(batch);
+  for (int l = 0; l < kNumLayers; ++l) {
+    const LayerSpec& s = spec_of(l);
+    ConvArgs a = base_args(s, wl.in_shape[l], wl.out_shape_[l]);
+    a.in = l == 0 ? face : l == kNumFace ? mel : work + wl.act[l - 1];
+    a.w = packed + pl.w[l];
+    a.bias = packed + pl.b[l];
+    a.res = s.res ? a.in : nullptr;
+    a.out = work + wl.act[l];
+    a.partial = work + wl.partial;
+    const int rc = launch_conv<false>(a, batch, st);
+    if (rc) return rc;
+  }
+  // both encoders end 1x1x512 (syncnet.py:59-60 flattens them): normalise
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumFace - 1], face_emb, kSyncEmb);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumLayers - 1], audio_emb, kSyncEmb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_sync_loss(const float* audio_emb, const float* face_emb, const float* y, float weight, float* scratch,
+                             float* loss, int accumulate, float* d_face_emb, int64_t batch, s2l_stream_t stream) {
+  if (batch < 0 || batch > 4096) return S2L_E_SIZE;
+  if (batch == 0) return S2L_OK;
+  if (!audio_emb || !face_emb || !y || !scratch || !loss) return S2L_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cosine_bce_kernel, dim3((unsigned)batch), dim3(64), 0, st, audio_emb, face_emb, y, weight / (float)batch,
+                     scratch, d_face_emb, kSyncEmb);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(64), 0, st, scratch, loss, (int)batch, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                         float* d_face, int64_t batch, s2l_stream_t stream) {
+  if (batch < 0 || batch > 4096) return S2L_E_SIZE;
+  if (batch == 0) return S2L_OK;
+  if (!packed || !face || !work || !d_face_emb || !d_face) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(work)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const PackedLayout pl = packed_layout();
+  const WorkLayout wl = work_layout(batch);
+  float* g_cur = work + wl.grad[0];
+  float* g_nxt = work + wl.grad[1];
+  hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumFace - 1], d_face_emb, g_cur,
+                     kSyncEmb);
+  for (int l = kNumFace - 1; l >= 0; --l) {
+    const LayerSpec& s = kFace[l];
+    ConvArgs a = base_args(s, wl.in_shape[l], wl.out_shape_[l]);
+    a.in = g_cur;
+    a.w = packed + pl.wt[l];
+    a.res = s.res ? g_cur : nullptr;
+    a.mask = l > 0 ? work + wl.act[l - 1] : nullptr;
+    a.out = l > 0 ? g_nxt : d_face;
+    a.partial = work + wl.partial;
+    const int rc = launch_conv<true>(a, batch, st);
+    if (rc) return rc;
+    float* tmp = g_cur;
+    g_cur = g_nxt;
+    g_nxt = tmp;
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,
+                               s2l_stream_t stream) {
+  if (batch < 0 || n_frames_t < 1 || height < 2 || width < 1) return S2L_E_SIZE;
+  if (batch == 0) return S2L_OK;
+  if (!g_rgb || !face) return S2L_E_NULL;
+  const int64_t n = batch * (height - height / 2) * width * 3 * n_frames_t;
+  hipLaunchKernelGGL(sync_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g_rgb,
+                     face, n_frames_t, height, width, n, 0, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width, int64_t batch,
+                                        s2l_stream_t stream) {
+  if (batch < 0 || n_frames_t < 1 || height < 2 || width < 1) return S2L_E_SIZE;
+  if (batch == 0) return S2L_OK;
+  if (!d_face || !d_g_rgb) return S2L_E_NULL;
+  const int64_t n = batch * 3 * n_frames_t * height * width;
+  hipLaunchKernelGGL(sync_window_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)nullptr, const_cast<float*>(d_face), n_frames_t, height, width, n, 1, d_g_rgb);
+  return (int)hipGetLastError();
+}

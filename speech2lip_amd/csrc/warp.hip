@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kGridThreads) void warp_grid_kernel(const float* __
   }
   // pinv(K)[:3,:3] = [1/f 0 -cx/f; 0 1/f -cy/f; 0 0 1]   (utils.py:136)
   const float inv_f = 1.f / focal, ncx = -cx / focal, ncy = -cy / focal;
-  const float sx = (float)(W - 1), sy = (float)(H - 1);
+  const float isx = 1.f / (float)(W - 1), isy = 1.f / (float)(H - 1), inv_w = 1.f / (float)W;
   const float* dsrc = depth + depth_stride * f;
   float2* gdst = reinterpret_cast<float2*>(grid) + (int64_t)f * hw;
   const int base = blockIdx.x * (kGridThreads * kGridPix) + threadIdx.x;
@@ -107,14 +107,20 @@ __global__ __launch_bounds__(kGridThreads) void warp_grid_kernel(const float* __
   for (int k = 0; k < kGridPix; ++k) {
     const int i = base + k * kGridThreads;
     if (i >= hw) break;
-    const int y = i / W, x = i - y * W;
+    // (y, x) = divmod(i, W) by a float reciprocal and one fix-up step (hw <= 2^24, so (float)i is exact)
+    int y = (int)(((float)i + 0.5f) * inv_w);
+    int x = i - y * W;
+    if (x < 0) x += W, --y;
+    if (x >= W) x -= W, ++y;
     const float X = d[k] * fmaf((float)x, inv_f, ncx), Y = d[k] * fmaf((float)y, inv_f, ncy), Z = d[k];
     const float px = fmaf(p0[0], X, fmaf(p0[1], Y, fmaf(p0[2], Z, p0[3])));
     const float py = fmaf(p1[0], X, fmaf(p1[1], Y, fmaf(p1[2], Z, p1[3])));
     const float pz = fmaf(p2[0], X, fmaf(p2[1], Y, fmaf(p2[2], Z, p2[3])));
-    const float den = pz + eps;
-    float gx = (px / den / sx - 0.5f) * 2.f;  // utils.py:158-163
-    float gy = (py / den / sy - 0.5f) * 2.f;
+    // utils.py:158-163: pix = p.xy / (p.z + eps); pix /= (size - 1); (pix - 0.5) * 2.  One correctly rounded
+    // reciprocal replaces the four divisions (<= 2 ulp on a result in [-1,1]; the kernel was VALU-bound on them).
+    const float inv = 1.f / (pz + eps);
+    float gx = fmaf(px * inv * isx, 2.f, -1.f);
+    float gy = fmaf(py * inv * isy, 2.f, -1.f);
     if (clamp) {  // face_tracker.py:606
       gx = fminf(fmaxf(gx, -1.f), 1.f);
       gy = fminf(fmaxf(gy, -1.f), 1.f);
@@ -179,7 +185,7 @@ extern "C" int s2l_rel_pose(const float* euler, const float* trans, const float*
 
 extern "C" int s2l_warp_grid(const float* depth, int64_t depth_stride, const float* T, float focal, int clamp, float* grid,
                              float* z, int height, int width, int64_t n_frames, s2l_stream_t stream) {
-  if (n_frames < 0 || height < 2 || width < 2 || (int64_t)height * width > (1 << 28) || n_frames > 65535) return S2L_E_SIZE;
+  if (n_frames < 0 || height < 2 || width < 2 || (int64_t)height * width > (1 << 24) || n_frames > 65535) return S2L_E_SIZE;
   if (!(focal > 0.f) || (depth_stride != 0 && depth_stride != (int64_t)height * width)) return S2L_E_SIZE;
   if (n_frames == 0) return S2L_OK;
   if (!depth || !T || !grid) return S2L_E_NULL;

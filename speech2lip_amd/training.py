@@ -52,6 +52,30 @@ class Trainer:
         self.use_audio = self.use_audio_net = self.use_time = True
         self.use_delta_uv = self.add_noise_audio = False
         self.audio_dims = model.audio_dims
+        # T3 (training.py:83-91): the frozen lip-sync expert, only when the config asks for the sync loss
+        self.use_syncloss = bool(kwargs.get("use_syncloss", self.cfg["training"].get("use_syncloss", False)))
+        self.w_syncloss = float(kwargs.get("w_syncloss", self.cfg["training"].get("w_syncloss", 0.01)))
+        self.syncnet = kwargs.get("syncnet")
+        if self.use_syncloss and self.syncnet is None:
+            from .syncnet import SyncNet_color
+            self.syncnet = SyncNet_color().to(self.device)
+
+    def load_checkpoint_syncnet(self, path, model=None):
+        """training.py:130-138: `lipsync_expert.pth` holds {'state_dict': ...}, keys possibly prefixed by 'module.'."""
+        ckpt = torch.load(path, map_location="cpu")
+        sd = {k.replace("module.", ""): v for k, v in ckpt["state_dict"].items()}
+        (model or self.syncnet).load_state_dict(sd)
+        return model or self.syncnet
+
+    def cosine_loss(self, a, v, y):
+        """training.py:576-579."""
+        from .syncnet import SyncLoss
+        return SyncLoss(self.syncnet).cosine_loss(a, v, y)
+
+    def get_sync_contrastive_loss(self, mel, g_rgb_pos, g_rgb_neg, syncnet_T=5, want_grad=False):
+        """training.py:581-603.  want_grad=True also returns d loss / d g_rgb_pos (what autograd hands to the renderer)."""
+        from .syncnet import SyncLoss
+        return SyncLoss(self.syncnet, syncnet_T).get_sync_contrastive_loss(mel, g_rgb_pos, g_rgb_neg, want_grad=want_grad)
 
     def predict_lip_image(self, i, coords, audio, pose, data, rgb_zero, lms, seed):
         """Same arguments as the reference method; `pose`, `rgb_zero`, `lms` are unused under the

@@ -165,3 +165,66 @@ def make_unet_state_dict(seed: int = 0, prefix: str = "post_fusion_unet.") -> "O
     out[f"{prefix}outc.conv.weight"] = u("outc.w", 3 * 64, -0.15, 0.15).reshape(3, 64, 1, 1)
     out[f"{prefix}outc.conv.bias"] = u("outc.b", 3, -0.1, 0.1)
     return out
+
+
+# ---- SyncNet_color (the lip-sync expert of the T3 loss) ---------------------------
+# (cin, cout, (kh, kw), (sy, sx), (py, px), residual) per block, as src/face_simple/models/syncnet.py:11-54.
+SYNCNET_FACE = [
+    (15, 32, (7, 7), (1, 1), (3, 3), False), (32, 64, (5, 5), (1, 2), (1, 1), False),
+    (64, 64, (3, 3), (1, 1), (1, 1), True), (64, 64, (3, 3), (1, 1), (1, 1), True),
+    (64, 128, (3, 3), (2, 2), (1, 1), False), (128, 128, (3, 3), (1, 1), (1, 1), True),
+    (128, 128, (3, 3), (1, 1), (1, 1), True), (128, 128, (3, 3), (1, 1), (1, 1), True),
+    (128, 256, (3, 3), (2, 2), (1, 1), False), (256, 256, (3, 3), (1, 1), (1, 1), True),
+    (256, 256, (3, 3), (1, 1), (1, 1), True), (256, 512, (3, 3), (2, 2), (1, 1), False),
+    (512, 512, (3, 3), (1, 1), (1, 1), True), (512, 512, (3, 3), (1, 1), (1, 1), True),
+    (512, 512, (3, 3), (2, 2), (1, 1), False), (512, 512, (3, 3), (1, 1), (0, 0), False),
+    (512, 512, (1, 1), (1, 1), (0, 0), False),
+]
+SYNCNET_AUDIO = [
+    (1, 32, (3, 3), (1, 1), (1, 1), False), (32, 32, (3, 3), (1, 1), (1, 1), True), (32, 32, (3, 3), (1, 1), (1, 1), True),
+    (32, 64, (3, 3), (3, 1), (1, 1), False), (64, 64, (3, 3), (1, 1), (1, 1), True), (64, 64, (3, 3), (1, 1), (1, 1), True),
+    (64, 128, (3, 3), (3, 3), (1, 1), False), (128, 128, (3, 3), (1, 1), (1, 1), True), (128, 128, (3, 3), (1, 1), (1, 1), True),
+    (128, 256, (3, 3), (3, 2), (1, 1), False), (256, 256, (3, 3), (1, 1), (1, 1), True), (256, 256, (3, 3), (1, 1), (1, 1), True),
+    (256, 512, (3, 3), (1, 1), (0, 0), False), (512, 512, (1, 1), (1, 1), (0, 0), False),
+]
+SYNCNET_BLOCKS = [("face_encoder", i, s) for i, s in enumerate(SYNCNET_FACE)] + \
+                 [("audio_encoder", i, s) for i, s in enumerate(SYNCNET_AUDIO)]
+SYNCNET_TENSORS = ("conv_block.0.weight", "conv_block.0.bias", "conv_block.1.weight", "conv_block.1.bias",
+                   "conv_block.1.running_mean", "conv_block.1.running_var")
+
+
+def make_syncnet_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded SyncNet_color weights with the reference's state-dict keys.  The real `lipsync_expert.pth` is not in the
+    reference repository (training.py:88), so parity of this net is structural: same generator on both sides.
+    He-uniform convolutions (halved on residual blocks so the trunk does not explode), BatchNorm affine and running
+    statistics away from the identity so that the eval-mode fold is exercised."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def u(name, n, lo, hi):
+        return (lo + (hi - lo) * uniform01(n, _stream_id("syncnet." + name, seed))).astype(np.float32)
+
+    for enc, i, (cin, cout, (kh, kw), _, _, res) in SYNCNET_BLOCKS:
+        p = f"{enc}.{i}."
+        b = np.sqrt(6.0 / (cin * kh * kw)) * (0.5 if res else 1.0)
+        out[p + "conv_block.0.weight"] = u(p + "w", cout * cin * kh * kw, -b, b).reshape(cout, cin, kh, kw)
+        out[p + "conv_block.0.bias"] = u(p + "cb", cout, -0.05, 0.05)
+        out[p + "conv_block.1.weight"] = u(p + "g", cout, 0.7, 1.3)
+        out[p + "conv_block.1.bias"] = u(p + "b", cout, -0.1, 0.1)
+        out[p + "conv_block.1.running_mean"] = u(p + "m", cout, -0.1, 0.1)
+        out[p + "conv_block.1.running_var"] = u(p + "v", cout, 0.7, 1.3)
+        out[p + "conv_block.1.num_batches_tracked"] = np.array(100, dtype=np.int64)
+    return out
+
+
+def synthetic_sync_batch(batch: int, seed: int = 0, frames_t: int = 5, height: int = 96, width: int = 96):
+    """(mel [B,1,80,16], rgb_window_pos [B,3,T,H,W], rgb_window_neg [B,3,T,H,W]) in the layouts of
+    someones_lip_dataset.py:331 / training.py:548-553.  Smooth images plus noise, so that the two windows are
+    neither identical nor orthogonal in embedding space."""
+    def u(name, n):
+        return uniform01(n, _stream_id("syncbatch." + name, seed)).astype(np.float32)
+    mel = (u("mel", batch * 80 * 16).reshape(batch, 1, 80, 16) * 4.0 - 2.0).astype(np.float32)
+    yy, xx = np.meshgrid(np.linspace(0, 1, height, dtype=np.float32), np.linspace(0, 1, width, dtype=np.float32), indexing="ij")
+    base = 0.5 + 0.3 * np.sin(6.0 * xx + 3.0 * yy)
+    pos = np.clip(base[None, None, None] + 0.4 * (u("pos", batch * 3 * frames_t * height * width).reshape(batch, 3, frames_t, height, width) - 0.5), 0, 1)
+    neg = np.clip(base[None, None, None, ::-1] + 0.4 * (u("neg", batch * 3 * frames_t * height * width).reshape(batch, 3, frames_t, height, width) - 0.5), 0, 1)
+    return mel, pos.astype(np.float32), np.ascontiguousarray(neg).astype(np.float32)

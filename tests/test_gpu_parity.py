@@ -454,7 +454,8 @@ def test_warp_grid_vs_oracle_sizes(dev, H, W, F, shared):
     for clamp in (False, True):
         grid = G.warp_grid(depth.to(dev), Tm, 1200.0, clamp=clamp)
         ref, _ = O.warp_grid(depth.double(), Tm.cpu().double(), 1200.0, clamp=clamp)
-        close(grid, ref.float(), 2e-6, 1e-5)
+        mag = max(1.0, float(ref.abs().max()))          # tiny frames put the grid far outside [-1,1]: relative bar
+        close(grid, ref.float(), 2e-6 * mag, 1e-5 * mag)
     # coords_for_clip == rel pose + clamped grid, and feeds the composite unchanged
     c = G.coords_for_clip(depth.to(dev), ce.to(dev), ct.to(dev), eul.to(dev), trn.to(dev), 1200.0)
     assert torch.equal(c, grid) and float(c.abs().max()) <= 1.0
@@ -470,6 +471,80 @@ def test_grid_sample_vs_torch(dev, pad):
     grid[0, 0, :4] = T(np.array([[-1, -1], [1, 1], [-1, 1], [0, 0]], np.float32))
     ref = torch.nn.functional.grid_sample(img.permute(0, 3, 1, 2), grid, mode="bilinear", padding_mode=pad, align_corners=False)
     got = G.grid_sample(img.to(dev), grid.to(dev), pad)
-    close(got.permute(0, 3, 1, 2), ref, 1e-7, 1e-6)
+    close(got.permute(0, 3, 1, 2), ref, 2e-7, 5e-6)     # ATen's CPU kernel unnormalises with a different rounding order
     shared = G.grid_sample(img[1].to(dev), grid.to(dev), pad)
     assert torch.equal(shared[1], got[1])
+
+
+@pytest.fixture(scope="module")
+def syncnet(dev):
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: T(v) for k, v in W.make_syncnet_state_dict(0).items()}, strict=True)
+    return net
+
+
+def test_syncnet_golden_embeddings_loss_and_gradient(golden, syncnet, dev):
+    """T3 against the reference's own SyncNet_color / get_sync_contrastive_loss / autograd (tools/make_goldens.py G9)."""
+    g = golden("g9_syncnet.npz")
+    mel, pos, neg = (T(x).to(dev) for x in W.synthetic_sync_batch(int(g["batch"]), seed=int(g["seed"])))
+    from speech2lip_amd.syncnet import sync_window
+    a, v = syncnet.embed_nhwc(mel, sync_window(pos))
+    close(a, g["audio_emb"], 2e-7, 2e-6)
+    close(v, g["face_emb_pos"], 2e-7, 2e-6)
+    # NCHW forward, as the reference's forward(audio_sequences, face_sequences)
+    a2, v2 = syncnet(mel, sync_window(neg).permute(0, 3, 1, 2))
+    close(v2, g["face_emb_neg"], 2e-7, 2e-6)
+    tr = s2l.Trainer(make_model(dev), syncnet=syncnet)
+    loss, dpos = tr.get_sync_contrastive_loss(mel, pos, neg, want_grad=True)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6, (float(loss), float(g["loss"]))
+    ref = T(g["grad_pos_stride7"])
+    scale = float(ref.abs().max())
+    got = dpos.reshape(-1)[::7].cpu()
+    # A ReLU whose pre-activation is within rounding of zero can switch between two fp32 evaluations of the net, which
+    # changes the gradient inside that unit's receptive field only: bound the bulk tightly and the outliers loosely.
+    err = (got - ref).abs() / scale
+    assert float((err > 2e-4).float().mean()) <= 0.01 and float(err.max()) <= 2e-2, (float(err.max()), float((err > 2e-4).float().mean()))
+    assert O.rmse(got, ref) <= 2e-4 * scale
+    assert abs(float(dpos.abs().double().sum()) - float(g["grad_pos_abs_sum"])) <= 1e-4 * float(g["grad_pos_abs_sum"])
+    assert float(dpos[:, :, :, :48].abs().max()) == 0.0
+    # loss only
+    assert abs(float(tr.get_sync_contrastive_loss(mel, pos, neg)) - float(g["loss"])) <= 2e-6
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_sync_loss_vs_oracle_autograd(syncnet, dev, B):
+    """Other batch sizes / seeds against the CPU oracle and its autograd; cosine_loss alone with mixed labels."""
+    sd_ = O.to_sd(W.make_syncnet_state_dict(0))
+    mel, pos, neg = (T(x) for x in W.synthetic_sync_batch(B, seed=10 + B))
+    pos_o = pos.clone().requires_grad_(True)
+    loss_o = O.sync_contrastive_loss(sd_, mel, pos_o, neg, W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+    loss_o.backward()
+    sl = s2l.SyncLoss(syncnet)
+    loss, dpos = sl.get_sync_contrastive_loss(mel.to(dev), pos.to(dev), neg.to(dev), want_grad=True, weight=0.01)
+    assert abs(float(loss) - 0.01 * float(loss_o)) <= 1e-7
+    scale = 0.01 * float(pos_o.grad.abs().max())
+    err = (dpos.cpu() - 0.01 * pos_o.grad).abs() / scale
+    assert float((err > 2e-4).float().mean()) <= 0.01 and float(err.max()) <= 2e-2
+    rng = np.random.default_rng(B)
+    a = torch.nn.functional.normalize(T(rng.random((5, 512), dtype=np.float32)), dim=1)
+    v = torch.nn.functional.normalize(T(rng.random((5, 512), dtype=np.float32)), dim=1).requires_grad_(True)
+    y = T(np.array([1, 0, 1, 0, 0], np.float32))[:, None]
+    ref = O.cosine_loss(a, v, y)
+    ref.backward()
+    got, dv = sl.cosine_loss(a.to(dev), v.detach().to(dev), y.to(dev), want_grad=True)
+    assert abs(float(got) - float(ref)) <= 1e-6
+    close(dv, v.grad, 1e-7, 1e-6)
+
+
+def test_sync_window_layout_and_adjoint(dev):
+    from speech2lip_amd.syncnet import sync_window, sync_window_backward
+    rng = np.random.default_rng(0)
+    g = T(rng.random((2, 3, 5, 96, 96), dtype=np.float32))
+    face = sync_window(g.to(dev))
+    assert torch.equal(face.cpu().permute(0, 3, 1, 2), O.sync_window(g))
+    d = T(rng.random((2, 48, 96, 15), dtype=np.float32))
+    back = sync_window_backward(d.to(dev), 5, 96, 96).cpu()
+    # adjoint: <window(g), d> == <g, window^T(d)>
+    lhs = float((O.sync_window(g).permute(0, 2, 3, 1).double() * d.double()).sum())
+    rhs = float((g.double() * back.double()).sum())
+    assert abs(lhs - rhs) <= 1e-9 * abs(lhs)

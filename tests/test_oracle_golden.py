@@ -152,3 +152,26 @@ def test_g8_pose_and_warp_grid(golden):
     assert float((O.rel_pose(ce, ct, eul, trn, 0) - O.rel_pose(ce, ct, eul, trn, 2)).abs().max()) <= 2e-6
     img, _ = O.inverse_warping(depth[0], T(g["iw_T"]), T(g["iw_src"]), focal)
     assert float((img - T(g["iw_out_nchw"])).abs().max()) <= 1e-4
+
+
+def test_g9_syncnet_and_sync_loss(golden):
+    """T3: SyncNet_color embeddings, the sync contrastive loss and its gradient w.r.t. the generated window, against the
+    reference run on the same seeded weights (lipsync_expert.pth is not in the reference repository)."""
+    g = golden("g9_syncnet.npz")
+    sd = O.to_sd(W.make_syncnet_state_dict(int(g["seed"])))
+    mel, pos, neg = (T(x) for x in W.synthetic_sync_batch(int(g["batch"]), seed=int(g["seed"])))
+    with torch.no_grad():
+        a, v = O.syncnet_forward(sd, mel, O.sync_window(pos), W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+        _, vn = O.syncnet_forward(sd, mel, O.sync_window(neg), W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+    assert float((a - T(g["audio_emb"])).abs().max()) <= 1e-6
+    assert float((v - T(g["face_emb_pos"])).abs().max()) <= 1e-6
+    assert float((vn - T(g["face_emb_neg"])).abs().max()) <= 1e-6
+    assert torch.allclose(a.norm(dim=1), torch.ones(a.shape[0]), atol=1e-5)
+    pos.requires_grad_(True)
+    loss = O.sync_contrastive_loss(sd, mel, pos, neg, W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    gr = pos.grad.reshape(-1)[::7]
+    scale = float(T(g["grad_pos_stride7"]).abs().max())
+    assert float((gr - T(g["grad_pos_stride7"])).abs().max()) <= 1e-5 * scale
+    assert float(pos.grad[:, :, :, :48].abs().max()) == 0.0        # only the lower half of each frame is seen (training.py:589)

@@ -263,6 +263,42 @@ def main():
         g8["iw_src"] = src.numpy(); g8["iw_T"] = T1.numpy(); g8["iw_out_nchw"] = img_ref.numpy()
         np.savez_compressed(os.path.join(GOLD, "g8_warp.npz"), **g8)
 
+    # ---- G9: SyncNet_color + sync contrastive loss.  lipsync_expert.pth is not in the reference
+    # repository, so both sides load the same seeded weights (speech2lip_amd.weights.make_syncnet_state_dict).
+    import types as _types
+    from src.face_simple.models.syncnet import SyncNet_color
+    ssd = W.make_syncnet_state_dict(0)
+    net = SyncNet_color()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()}, strict=True)
+    net.eval()
+    for p_ in net.parameters():
+        p_.requires_grad = False                                     # training.py:86-87
+    mel, pos, neg = (torch.from_numpy(x) for x in W.synthetic_sync_batch(2, seed=0))
+    fake = _types.SimpleNamespace(syncnet=net, device=torch.device("cpu"))
+    fake.cosine_loss = lambda a, v, y: ref_training.Trainer.cosine_loss(fake, a, v, y)
+    pos_g = pos.clone().requires_grad_(True)
+    loss_ref = ref_training.Trainer.get_sync_contrastive_loss(fake, mel, pos_g, neg)
+    loss_ref.backward()
+    osd = O.to_sd(ssd)
+    pos_o = pos.clone().requires_grad_(True)
+    loss_or = O.sync_contrastive_loss(osd, mel, pos_o, neg, W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+    loss_or.backward()
+    with torch.no_grad():
+        a_ref, v_ref = net(mel, O.sync_window(pos))
+        a_or, v_or = O.syncnet_forward(osd, mel, O.sync_window(pos), W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+        an_ref, vn_ref = net(mel, O.sync_window(neg))
+    gscale = float(pos_g.grad.abs().max())
+    report["syncnet_audio_emb"] = maxerr(a_ref, a_or)
+    report["syncnet_face_emb"] = maxerr(v_ref, v_or)
+    report["sync_loss"] = maxerr(loss_ref.detach(), loss_or.detach())
+    report["sync_grad_rel"] = maxerr(pos_g.grad, pos_o.grad) / gscale
+    print(f"  [info] sync loss {float(loss_ref):.6f}; cos(pos) {float((a_ref * v_ref).sum(1)[0]):.4f}; |grad|max {gscale:.3e}")
+    gr = pos_g.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g9_syncnet.npz"), seed=np.array(0), batch=np.array(2),
+                        audio_emb=a_ref.numpy(), face_emb_pos=v_ref.numpy(), face_emb_neg=vn_ref.numpy(),
+                        loss=np.array(float(loss_ref)), grad_pos_stride7=gr.reshape(-1)[::7].copy(),
+                        grad_pos_abs_sum=np.array(np.abs(gr).astype(np.float64).sum()))
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
