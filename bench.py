@@ -79,6 +79,8 @@ def main():
                          "then delays the statically-striped workgroups of the next launch; >1 enables the overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the RCCL path (process group, all-gather, barriers) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,9 +91,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import speech2lip_amd as s2l
     from speech2lip_amd import sharded, weights as W
@@ -103,7 +107,7 @@ def main():
     n_chunks = args.chunks if (world > 1 or args.force_chunks) else 1
     gids = sharded.global_frame_ids(F, rank, world, n_chunks, QUANTUM).to(dev)
     audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
-    clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if use_dist else None
     kernel_events = []
 
     def render(off, cnt, out):
@@ -111,11 +115,11 @@ def main():
 
     def step():
         return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip,
-                                      quantum=QUANTUM)
+                                      quantum=QUANTUM, force_collective=args.force_dist)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -128,7 +132,7 @@ def main():
         out, local = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -167,7 +171,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -52,7 +52,7 @@ def global_frame_ids(frames_per_rank: int, rank: int, world: int, n_chunks: int,
 
 def render_sharded(render_fn: Callable[[int, int, torch.Tensor], None], frames_per_rank: int, frame_shape,
                    device, n_chunks: int = 4, group=None, clip: torch.Tensor = None, gather: bool = True,
-                   quantum: int = 1):
+                   quantum: int = 1, force_collective: bool = False):
     """Render this rank's frames chunk by chunk and all-gather each chunk into `clip`.
 
     render_fn(local_offset, count, out) renders local frames [local_offset, local_offset+count)
@@ -63,7 +63,7 @@ def render_sharded(render_fn: Callable[[int, int, torch.Tensor], None], frames_p
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     local = torch.empty((frames_per_rank, *frame_shape), dtype=torch.float32, device=device)
     plan = chunk_plan(frames_per_rank, world, n_chunks, quantum)
-    if world == 1 or not gather:
+    if (world == 1 and not force_collective) or not gather:
         for off, cnt in plan:
             if cnt:
                 render_fn(off, cnt, local[off:off + cnt])
