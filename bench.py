@@ -31,7 +31,7 @@ H = W_ = 96
 HW = H * W_
 FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
 FP32_MFMA_PEAK = 157.3e12
-TRAFFIC_BYTES_PER_FRAME = 9.14e8 / 1000   # measured with PMC counters, see profiles/r01d_rocprofv3_summary.txt
+TRAFFIC_BYTES_PER_FRAME = 8.98e8 / 1000   # measured with PMC counters, see profiles/r01d_rocprofv3_summary.txt
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -62,8 +62,17 @@ def cpu_baseline(frames_budget_s: float = 12.0):
             O.render_frame_as_shipped(sd, win[n % 8], n, H, W_)
             n += 1
         dt = time.perf_counter() - t0
+        # for fairness (SURVEY.md §8d ii): the same oracle with the encoder run once per frame and 8 frames per call
+        O.render_clip(sd, win, list(range(8)), H, W_)
+        nb, tb0 = 0, time.perf_counter()
+        while nb < 64 and (time.perf_counter() - tb0) < 6.0:
+            O.render_clip(sd, win, list(range(nb, nb + 8)), H, W_)
+            nb += 8
+        dtb = time.perf_counter() - tb0
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} frames 96x96, as-shipped per-frame path (oracle.render_frame_as_shipped), fp32, {dt:.1f} s"}
+            "sample": f"{n} frames 96x96, as-shipped per-frame path (oracle.render_frame_as_shipped), fp32, {dt:.1f} s",
+            "batched_value": round(nb / dtb, 3),
+            "batched_sample": f"{nb} frames 96x96 in clips of 8 (oracle.render_clip: encoder once per frame), {dtb:.1f} s"}
 
 
 def main():
@@ -162,7 +171,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):
-                         # profiles/r01d_rocprofv3_summary.txt measured 9.14e8 B per 1000-frame launch
+                         # profiles/r01d_rocprofv3_summary.txt measured 8.98e8 B per 1000-frame launch
                          "traffic": round(TRAFFIC_BYTES_PER_FRAME * frames_per_launch),
                          "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
