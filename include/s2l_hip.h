@@ -249,6 +249,22 @@ int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height,
 int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width,
                              int64_t batch, s2l_stream_t stream);
 
+/* ---- bf16 mode of the training step (BASELINE config 5; same mathematics as s2l_train_forward / _backward /
+ * s2l_wgrad, operands and saved state in bf16, fp32 accumulation, fp32 master weights and gradients) -------------
+ * Replaces, like the fp32 entry points, the autograd of Trainer.predict_lip_image + add_photometric_loss
+ * (src/face_simple/training.py:158-251, 605-619) through TalkingFace.rgb_forward (tf_nerf.py:225-285).
+ * s2l_pack_bf16: bf16 operand images from the state-dict tensors (table as s2l_pack_weights) and the fp32 blob of
+ * s2l_pack_weights (folded first/skip matrices, biases); packed_bf16: s2l_bf16_packed_halves() uint16.
+ * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/64][256][64]
+ * ([layer][tile of 64 rows][feature][row]); masks: uint64 [8][Np/64][256] ReLU ballots; x: fp32 [N,128] embedded rows
+ * (s2l_ensemble_rows); rgb, drgb: fp32 [N,3]; dxa: fp32 [N,64]. */
+int64_t s2l_bf16_packed_halves(void);
+int64_t s2l_bf16_rows_padded(int64_t n_rows);
+int s2l_pack_bf16(const float* const* tensors_host, const float* packed_f32, uint16_t* packed_bf16,
+                  s2l_stream_t stream);
+int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const float* x, uint16_t* hT,
+                           uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

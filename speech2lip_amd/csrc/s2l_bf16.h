@@ -1,0 +1,47 @@
+// Layout of the bf16 training blob and of the bf16 activation / gradient tiles (BASELINE config 5 names bf16 for the
+// training step).  Built by train_bf16.hip:pack, read by the bf16 forward / backward / weight-gradient kernels.
+// All offsets are in bf16 elements ("halves").
+//
+// MFMA: v_mfma_f32_32x32x16_bf16.  A: lane l holds A[row l&31][k = 8*(l>>5) + j], j = 0..7 (one ds_read_b128);
+// B: lane l holds B[k = 8*(l>>5) + j][col l&31]; D: reg r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+// (checked on the device by tools/ubench/mfma_bf16_layout.hip).  With D[feature][row of the batch], a lane's
+// registers 8s..8s+7 of output block R are, after conversion to bf16, exactly its B operand for k-step 2R+s of the
+// next layer if that layer's weights are packed with the K permutation
+//     kfeat16(t, hh, j) = 32*(t>>1) + 8*(2*(t&1) + (j>>2)) + 4*hh + (j&3)
+// so activations and gradients never leave registers between layers.
+#pragma once
+#include <cstdint>
+
+namespace s2l {
+namespace b16 {
+
+__host__ __device__ constexpr int kfeat16(int t, int hh, int j) { return 32 * (t >> 1) + 8 * (2 * (t & 1) + (j >> 2)) + 4 * hh + (j & 3); }
+
+constexpr int kSlabH = 32 * 256;   // 32 output rows x K=256: A image [t 16][lane 64][8]       (16 KiB)
+constexpr int kSlabX = 32 * 128;   // 32 output rows x K=128 (embedding rows x): [t 8][lane 64][8] (8 KiB)
+// forward stage s = 4*layer + quarter: the weights of output blocks R = 2q, 2q+1 of that layer:
+//   [X slab R0][X slab R1][H slab R0][H slab R1]; X = folded G0 (layer 0) / G5 (layer 5), plain K order 16t + 8hh + j;
+//   H = pts_linears[layer] (layer 5: columns 256..511), K order kfeat16; unused parts are zero and are never loaded.
+//   The X part of stage 31 holds the output layer (one H-format slab, rows >= 3 zero).
+constexpr int kStageF = 2 * kSlabX + 2 * kSlabH;        // 24576 halves = 48 KiB
+constexpr int kFwdStages = 32;
+constexpr int64_t OFF_FWD = 0;
+// backward: U0 = output_linear^T (K = 16, 3 used): 8 slabs [lane 64][8]; then for l = 7,6,5b,4,3,2,1 four stages of two
+// H slabs of W_l^T (rows = input feature, K = output feature in kfeat16 order); then the audio columns of G5 and G0
+// transposed (rows = 64 audio dims: two H slabs each).
+constexpr int kSlabU0 = 64 * 8;
+constexpr int kStageB = 2 * kSlabH;                      // 16384 halves = 32 KiB
+constexpr int64_t OFF_BWD_U0 = OFF_FWD + int64_t(kFwdStages) * kStageF;
+constexpr int64_t OFF_BWD_H = OFF_BWD_U0 + 8 * kSlabU0;
+constexpr int64_t OFF_BWD_G5A = OFF_BWD_H + int64_t(7 * 4) * kStageB;
+constexpr int64_t OFF_BWD_G0A = OFF_BWD_G5A + kStageB;
+constexpr int64_t PACKED_HALVES = OFF_BWD_G0A + kStageB;
+
+// Activation / gradient tiles for the weight-gradient GEMMs: [layer][tile of 64 rows][feature][64 rows] bf16, i.e. every
+// feature's 64 rows are 128 contiguous bytes (the reduction index of dW = dz^T h runs along them).
+constexpr int kTileRows = 64;
+constexpr int kWgRows = 256;       // rows per workgroup tile of the forward / backward kernels
+// ReLU masks: uint64 [layer 8][tile64][R 8][32]: entry g*16 + r = ballot of (h > 0) for accumulator register r of group g
+
+}  // namespace b16
+}  // namespace s2l

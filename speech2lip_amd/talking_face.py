@@ -169,7 +169,23 @@ class TalkingFace(nn.Module):
                 _abi.check(lib.s2l_pack_weights(table, div, _ptr(packed), _stream()), "s2l_pack_weights")
             self._packed, self._packed_key = packed, key
             self._tables = {}
+            self._packed_bf16 = None
         return self._packed
+
+    def packed_weights_bf16(self) -> torch.Tensor:
+        """bf16 operand images of the MLP for the bf16 training mode (csrc/s2l_bf16.h), rebuilt with the fp32 blob."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        if getattr(self, "_packed_bf16", None) is None:
+            dev = packed.device
+            holders = [_dev_f32(t, dev, "parameter") for t in self._hot_tensors()]
+            table = (ctypes.c_void_p * len(holders))(*[h.data_ptr() for h in holders])
+            pb = torch.empty(int(lib.s2l_bf16_packed_halves()), dtype=torch.int16, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_pack_bf16(table, _ptr(packed), _ptr(pb), _stream()), "s2l_pack_bf16")
+                torch.cuda.current_stream().synchronize()
+            self._packed_bf16 = pb
+        return self._packed_bf16
 
     def load_state_dict(self, state_dict, strict=False, **kw):
         """Reference loader is strict=False (checkpoints.py:106): U-Net / depth-head keys that

@@ -1,0 +1,104 @@
+"""Helpers for the bf16 training-mode tests: decode the device layouts (csrc/s2l_bf16.h) and emulate the kernels'
+arithmetic on the CPU (bf16-rounded operands, fp32 accumulation), so that the kernels can be checked tightly."""
+import numpy as np
+import torch
+
+
+def bf(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def tiles_to_rows(tiles_i16: torch.Tensor, n_layers: int, np_rows: int, feats: int = 256) -> torch.Tensor:
+    """int16 view of bf16 [L][np/64][feats][64] -> fp32 [L][np][feats]."""
+    t = tiles_i16.cpu().view(torch.bfloat16).to(torch.float32).reshape(n_layers, np_rows // 64, feats, 64)
+    return t.permute(0, 1, 3, 2).reshape(n_layers, np_rows, feats)
+
+
+def masks_to_rows(masks_i64: torch.Tensor, np_rows: int) -> torch.Tensor:
+    """uint64 ballots [8][np/64][R 8][g*16 + r] -> bool [8][np][256] (bit lane = 32*hh + n)."""
+    m = masks_i64.cpu().numpy().view(np.uint64).reshape(8, np_rows // 64, 8, 2, 16)
+    bits = ((m[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool)     # [8,T,R,g,r,lane]
+    out = np.zeros((8, np_rows // 64, 64, 256), dtype=bool)
+    for R in range(8):
+        for r in range(16):
+            for hh in range(2):
+                f = 32 * R + 8 * (r >> 2) + 4 * hh + (r & 3)
+                for g in range(2):
+                    out[:, :, 32 * g:32 * g + 32, f] = bits[:, :, R, g, r, 32 * hh:32 * hh + 32]
+    return torch.from_numpy(out.reshape(8, np_rows, 256))
+
+
+def blob_offsets():
+    """Offsets (in floats) of the fp32 blob sections, evaluated from csrc/s2l_layout.h."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech2lip_amd", "csrc", "s2l_layout.h")
+    env = {"align4": lambda v: (v + 3) & ~3}
+    for m in re.finditer(r"constexpr\s+(?:int64_t|int)\s+(\w+)\s*=\s*([^;]+);", open(path).read()):
+        env[m.group(1)] = eval(m.group(2).replace("int64_t(", "(").replace("/", "//"), {}, env)
+    return env
+
+
+def folded_from_blob(packed: torch.Tensor):
+    """G0, c0, G5, c5 exactly as the device folded them (fp32 blob of s2l_pack_weights)."""
+    o = blob_offsets()
+    p = packed.cpu()
+    G0 = p[o["OFF_G0"]:o["OFF_G0"] + 256 * 128].reshape(256, 128)[:, :126]
+    G5 = p[o["OFF_G5"]:o["OFF_G5"] + 256 * 128].reshape(256, 128)[:, :126]
+    return G0, p[o["OFF_BG0"]:o["OFF_BG0"] + 256], G5, p[o["OFF_BG5"]:o["OFF_BG5"] + 256]
+
+
+def folded(sd):
+    """G0, c0, G5, c5 and the hidden matrices from a state dict of fp32 tensors (what pack_fold_general builds)."""
+    def fold(w_first, names):
+        C = torch.cat([sd[f"{n}.weight"] for n in names], dim=1)                     # [256,126]
+        bsum = sum(sd[f"{n}.bias"] for n in names)
+        return w_first @ C, w_first @ bsum
+    W0, W5 = sd["pts_linears.0.weight"], sd["pts_linears.5.weight"]
+    G0, c0 = fold(W0, ("fc_uv", "fc_audio", "fc_time"))
+    G5, c5 = fold(W5[:, :256], ("fc_uv_skip", "fc_audio_skip", "fc_time_skip"))
+    return G0, c0 + sd["pts_linears.0.bias"], G5, c5 + sd["pts_linears.5.bias"]
+
+
+def forward_emu(sd, x):
+    """x fp32 [N,128] (126 used) -> (rgb [N,3], h [8,N,256] as stored (bf16 values), pre-activation list)."""
+    G0, c0, G5, c5 = folded(sd)
+    xb = bf(x[:, :126])
+    hs, zs = [], []
+    z = xb @ bf(G0).t() + c0
+    for L in range(8):
+        if L > 0:
+            W = sd[f"pts_linears.{L}.weight"]
+            if L == 5:
+                z = hs[-1] @ bf(W[:, 256:]).t() + xb @ bf(G5).t() + c5
+            else:
+                z = hs[-1] @ bf(W).t() + sd[f"pts_linears.{L}.bias"]
+        zs.append(z)
+        hs.append(bf(torch.relu(z)))
+    rgb = hs[-1] @ bf(sd["output_linear.weight"]).t() + sd["output_linear.bias"]
+    return rgb, torch.stack(hs), zs
+
+
+def forward_teacher_forced(sd, x, h_dev, fold=None):
+    """Per-layer expectation given the DEVICE's previous-layer activations (so that bf16 rounding flips do not cascade):
+    returns expected h [8,N,256].  fold = folded_from_blob(packed) uses the device's own folded first/skip matrices."""
+    G0, c0, G5, c5 = fold if fold is not None else folded(sd)
+    xb = bf(x[:, :126])
+    out = [bf(torch.relu(xb @ bf(G0).t() + c0))]
+    for L in range(1, 8):
+        W = sd[f"pts_linears.{L}.weight"]
+        if L == 5:
+            z = h_dev[L - 1] @ bf(W[:, 256:]).t() + xb @ bf(G5).t() + c5
+        else:
+            z = h_dev[L - 1] @ bf(W).t() + sd[f"pts_linears.{L}.bias"]
+        out.append(bf(torch.relu(z)))
+    return torch.stack(out)
+
+
+def assert_bf16_close(got, exp, what, frac=3e-3):
+    """Equal up to fp32 summation noise, except that a value within that noise of a bf16 rounding tie (or of the ReLU
+    threshold) may land on the neighbouring bf16 value: a small fraction, by at most one bf16 ulp."""
+    d = (got - exp).abs()
+    off = d > 1e-5 * (1 + exp.abs())
+    assert float(off.float().mean()) < frac, (what, float(off.float().mean()))
+    assert bool((d <= 2.0 ** -7 * exp.abs() * 1.01 + 2e-5).all()), (what, float(d.max()))

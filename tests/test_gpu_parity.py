@@ -548,3 +548,60 @@ def test_sync_window_layout_and_adjoint(dev):
     lhs = float((O.sync_window(g).permute(0, 2, 3, 1).double() * d.double()).sum())
     rhs = float((g.double() * back.double()).sum())
     assert abs(lhs - rhs) <= 1e-9 * abs(lhs)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 training mode
+def _bf16_inputs(dev, h, w, B, seed=0):
+    import ctypes
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    m = make_model(dev, h, w)
+    lib = _abi.load()
+    P = h * w
+    N = 4 * P * B
+    audio = T(W.synthetic_audio(B, seed=3 + seed).astype(np.float32)).to(dev)
+    feat = m.audio_merge_forward(audio)
+    coords = s2l.get_coords(w, h, dev)
+    x = torch.empty(N, 128, device=dev)
+    areas = torch.empty(N, device=dev)
+    packed = m.packed_weights()
+    for b in range(B):
+        _abi.check(lib.s2l_ensemble_rows(_ptr(packed), _ptr(coords), _ptr(feat[b]), 7 + b, w, h, ctypes.c_float(0.3 + 0.1 * b),
+                                         _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, _stream()), "s2l_ensemble_rows")
+    return m, lib, x, N
+
+
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
+def test_bf16_forward_matches_emulation(dev, h, w, B):
+    """bf16 training forward: rgb, the saved activation tiles and the ReLU ballots against a CPU emulation of the same
+    arithmetic (bf16 operands, fp32 accumulation), and rgb against the fp32 path within bf16 accuracy."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    from tests import bf16_util as U
+    m, lib, x, N = _bf16_inputs(dev, h, w, B)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+    rgb = torch.empty(N, 3, device=dev)
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(m.packed_weights_bf16()), _ptr(m.packed_weights()), _ptr(x), _ptr(hT), _ptr(masks),
+                                          _ptr(rgb), N, _stream()), "s2l_train_forward_bf16")
+    sd_ = O.to_sd(W.make_state_dict(0, "he"))
+    with torch.no_grad():
+        rgb_e, h_e, z_e = U.forward_emu(sd_, x.cpu())
+    h_d = U.tiles_to_rows(hT, 8, Np)[:, :N]
+    with torch.no_grad():
+        h_tf = U.forward_teacher_forced(sd_, x.cpu(), h_d, U.folded_from_blob(m.packed_weights()))
+    for L in range(8):
+        U.assert_bf16_close(h_d[L], h_tf[L], f"h{L}")
+        assert float((h_d[L] - h_e[L]).pow(2).mean().sqrt() / h_e[L].pow(2).mean().sqrt()) < 4e-3   # free-running: flips cascade
+    mk = U.masks_to_rows(masks, Np)[:, :N]
+    assert bool((mk == (h_d > 0)).all())                     # the ballots are the sign bits of what was stored
+    with torch.no_grad():
+        rgb_tf = h_d[7] @ U.bf(sd_["output_linear.weight"]).t() + sd_["output_linear.bias"]
+    close(rgb, rgb_tf, 1e-6, 1e-5)
+    assert O.rmse(rgb.cpu(), rgb_e) <= 2e-3
+    # and against the fp32 rows path: bf16-level agreement on outputs of RMS ~0.4
+    ref32 = torch.empty(N, 3, device=dev)
+    hs = torch.empty(8, N, 256, device=dev)
+    _abi.check(lib.s2l_train_forward(_ptr(m.packed_weights()), _ptr(x), _ptr(hs), _ptr(ref32), N, _stream()), "s2l_train_forward")
+    assert O.rmse(rgb.cpu(), ref32.cpu()) <= 2e-2
