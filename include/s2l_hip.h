@@ -264,6 +264,8 @@ int s2l_pack_bf16(const float* const* tensors_host, const float* packed_f32, uin
                   s2l_stream_t stream);
 int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const float* x, uint16_t* hT,
                            uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream);
+int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
+                            float* dxa, int64_t n_rows, s2l_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ EXPORTS = {
     "s2l_bf16_rows_padded": (c_int64, [c_int64]),
     "s2l_pack_bf16": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     "s2l_train_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_train_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

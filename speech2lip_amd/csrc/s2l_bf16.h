@@ -26,16 +26,20 @@ constexpr int kSlabX = 32 * 128;   // 32 output rows x K=128 (embedding rows x):
 constexpr int kStageF = 2 * kSlabX + 2 * kSlabH;        // 24576 halves = 48 KiB
 constexpr int kFwdStages = 32;
 constexpr int64_t OFF_FWD = 0;
-// backward: U0 = output_linear^T (K = 16, 3 used): 8 slabs [lane 64][8]; then for l = 7,6,5b,4,3,2,1 four stages of two
-// H slabs of W_l^T (rows = input feature, K = output feature in kfeat16 order); then the audio columns of G5 and G0
-// transposed (rows = 64 audio dims: two H slabs each).
+// backward: U0 = output_linear^T (K = 16, 3 used): 8 slabs [lane 64][8]; then 30 stages of two H slabs in consumption
+// order: W_7^T (4 stages), W_6^T (4), the audio columns of G5 transposed (1: rows = 64 audio dims), W_5b^T, W_4^T, W_3^T,
+// W_2^T, W_1^T (4 each), the audio columns of G0 transposed (1).  W_l^T: rows = input feature, K = output feature in
+// kfeat16 order.
 constexpr int kSlabU0 = 64 * 8;
 constexpr int kStageB = 2 * kSlabH;                      // 16384 halves = 32 KiB
+constexpr int kBwdStages = 30;
 constexpr int64_t OFF_BWD_U0 = OFF_FWD + int64_t(kFwdStages) * kStageF;
 constexpr int64_t OFF_BWD_H = OFF_BWD_U0 + 8 * kSlabU0;
-constexpr int64_t OFF_BWD_G5A = OFF_BWD_H + int64_t(7 * 4) * kStageB;
-constexpr int64_t OFF_BWD_G0A = OFF_BWD_G5A + kStageB;
-constexpr int64_t PACKED_HALVES = OFF_BWD_G0A + kStageB;
+constexpr int64_t PACKED_HALVES = OFF_BWD_H + int64_t(kBwdStages) * kStageB;
+// stage u -> (layer l whose W_l^T it holds, quarter), or the audio stages
+__host__ __device__ constexpr bool bwd_stage_is_audio(int u) { return u == 8 || u == 29; }
+__host__ __device__ constexpr int bwd_stage_layer(int u) { return u < 8 ? 7 - (u >> 2) : 5 - ((u - 9) >> 2); }
+__host__ __device__ constexpr int bwd_stage_quarter(int u) { return u < 8 ? (u & 3) : ((u - 9) & 3); }
 
 // Activation / gradient tiles for the weight-gradient GEMMs: [layer][tile of 64 rows][feature][64 rows] bf16, i.e. every
 // feature's 64 rows are 128 contiguous bytes (the reduction index of dW = dz^T h runs along them).

@@ -74,18 +74,17 @@ __global__ void pack_bf16_kernel(Tab16 tab, const float* __restrict__ pf, uint16
     lane = (e >> 3) & 63, j = e & 7;
     const int k = 8 * (lane >> 5) + j;
     if (k < 3) v = tab.t[S2L_T_OUT_W][k * 256 + 32 * R + (lane & 31)];
-  } else if (i < OFF_BWD_G5A) {
-    const int e = (int)(i - OFF_BWD_H);
-    const int st = e / kStageB, o = e % kStageB;
-    const int layer = 7 - (st >> 2), R = 2 * (st & 3) + o / kSlabH;
-    slab_idx(o % kSlabH, t, lane, j);
-    v = hidden_w(tab, layer, kfeat16(t, lane >> 5, j), 32 * R + (lane & 31));
   } else {
-    const int e = (int)(i - OFF_BWD_G5A);
-    const int which = e / kStageB, o = e % kStageB;
-    const int R = o / kSlabH;
+    const int e = (int)(i - OFF_BWD_H);
+    const int u = e / kStageB, o = e % kStageB;
     slab_idx(o % kSlabH, t, lane, j);
-    v = pf[(which == 0 ? OFF_G5 : OFF_G0) + (int64_t)kfeat16(t, lane >> 5, j) * kGenK + kEmb + 32 * R + (lane & 31)];
+    if (bwd_stage_is_audio(u)) {
+      const int R = o / kSlabH;
+      v = pf[(u == 8 ? OFF_G5 : OFF_G0) + (int64_t)kfeat16(t, lane >> 5, j) * kGenK + kEmb + 32 * R + (lane & 31)];
+    } else {
+      const int R = 2 * bwd_stage_quarter(u) + o / kSlabH;
+      v = hidden_w(tab, bwd_stage_layer(u), kfeat16(t, lane >> 5, j), 32 * R + (lane & 31));
+    }
   }
   dst[i] = bf1(v);
 }
@@ -298,6 +297,199 @@ __global__ __launch_bounds__(256, 1) void fwd_bf16_kernel(FwdArgs a) {
   }
 }
 
+// ---- backward dz chain ------------------------------------------------------------------------------------------------------
+// g_7 = (Wout^T drgb) . m_7;  g_{l-1} = (W_l^T g_l) . m_{l-1} for l = 7..1 (l = 5: the h_4 half of pts_linears[5]);
+// d audio = G5[:, audio]^T g_5 + G0[:, audio]^T g_0.  Every g_l is stored as a [feature][64 rows] bf16 tile (dzT) for the
+// weight-gradient GEMMs; the masks are the forward's ballots, read back as wave-uniform SGPR pairs (one v_cndmask per value).
+constexpr int kLdsBwdW = 2 * kStageB * 2;
+constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2 + 4 * kTrBytes;
+
+struct StageB {
+  u4 h[8];
+};
+
+struct BwdArgs {
+  const uint16_t* wb;
+  const float* drgb;
+  const uint64_t* masks;
+  uint16_t* dzT;
+  float* dxa;
+  int64_t n_rows, layer_stride, mask_layer_stride;
+  int n_tiles;
+};
+
+__device__ __forceinline__ float mask_sel(float v, uint64_t m) {
+  float o;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
+  return o;
+}
+
+// masked gradient block -> bf16 pairs; mrow = the 32 ballots of this (layer, 64-row tile, R): one coalesced 256-byte load,
+// then each word is broadcast into an SGPR pair with v_readlane
+__device__ __forceinline__ void mask_block(const f16v (&acc)[2], const uint64_t* __restrict__ mrow, int lane,
+                                           uint32_t (&vals)[2][4][2]) {
+  const uint64_t mv = mrow[lane & 31];
+  const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = g * 16 + 4 * a4 + c;
+        const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, idx) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, idx) << 32);
+        v[c] = mask_sel(acc[g][4 * a4 + c], m);
+      }
+      vals[g][a4][0] = pk2(v[0], v[1]);
+      vals[g][a4][1] = pk2(v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void bwd_bf16_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* wbuf = reinterpret_cast<uint16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hh = lane >> 5;
+  u4* u0 = reinterpret_cast<u4*>(smem + kLdsBwdW);
+  char* tr = smem + kLdsBwdW + 8 * kSlabU0 * 2 + wave * kTrBytes;
+  for (int i = tid; i < 8 * 64; i += 256) u0[i] = reinterpret_cast<const u4*>(a.wb + OFF_BWD_U0)[i];
+
+  StageB st;
+  auto gload = [&](int u) {
+    const u4* p = reinterpret_cast<const u4*>(a.wb + OFF_BWD_H + (int64_t)u * kStageB) + tid;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st.h[k] = p[256 * k];
+  };
+  auto lstore = [&](int u) {
+    u4* p = reinterpret_cast<u4*>(wbuf + (u & 1) * kStageB) + tid;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[256 * k] = st.h[k];
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  u4 bcur[2][16], bnext[2][16];
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t w0 = (int64_t)tile * kWgRows + 64 * wave;
+    const int64_t tile64 = (int64_t)tile * 4 + wave;
+    // drgb as a K = 16 B operand: k = 8 hh + j, k < 3 used
+    u4 b0[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int64_t row = w0 + 32 * g + n;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      if (hh == 0 && row < a.n_rows) d0 = a.drgb[row * 3], d1 = a.drgb[row * 3 + 1], d2 = a.drgb[row * 3 + 2];
+      b0[g] = u4{pk2(d0, d1), pk2(d2, 0.f), 0u, 0u};
+    }
+    f16v acc_a[2][2];   // d audio: [audio block][row group]
+#pragma unroll
+    for (int R = 0; R < 2; ++R)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_a[R][g][r] = 0.f;
+
+    // U0: g_7
+#pragma unroll
+    for (int R = 0; R < 8; ++R) {
+      f16v acc[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        acc[g] = mfma32(u0[R * 64 + lane], b0[g], acc[g]);
+      }
+      uint32_t vals[2][4][2];
+      mask_block(acc, a.masks + 7 * a.mask_layer_stride + tile64 * 256 + R * 32, lane, vals);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bcur[g][2 * R] = u4{vals[g][0][0], vals[g][0][1], vals[g][1][0], vals[g][1][1]};
+        bcur[g][2 * R + 1] = u4{vals[g][2][0], vals[g][2][1], vals[g][3][0], vals[g][3][1]};
+      }
+      tile_store(vals, tr, a.dzT + 7 * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows, lane);
+    }
+
+    int u = 0;
+    auto audio_stage = [&]() {   // one stage: two 32-dim blocks of G[:, audio]^T against bcur
+      const int nxt = u + 1 == kBwdStages ? 0 : u + 1;
+      gload(nxt);
+      const uint16_t* wl = wbuf + (u & 1) * kStageB;
+#pragma unroll
+      for (int R = 0; R < 2; ++R) {
+        const u4* ah = reinterpret_cast<const u4*>(wl + R * kSlabH) + lane;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const u4 av = ah[64 * t];
+          acc_a[R][0] = mfma32(av, bcur[0][t], acc_a[R][0]);
+          acc_a[R][1] = mfma32(av, bcur[1][t], acc_a[R][1]);
+        }
+      }
+      lstore(nxt);
+      __syncthreads();
+      u = nxt;
+    };
+
+    for (int l = 7; l >= 1; --l) {   // W_l^T g_l -> g_{l-1}
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nxt = u + 1 == kBwdStages ? 0 : u + 1;
+        gload(nxt);
+        const uint16_t* wl = wbuf + (u & 1) * kStageB;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const int R = 2 * q + which;
+          f16v acc[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+          const u4* ah = reinterpret_cast<const u4*>(wl + which * kSlabH) + lane;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const u4 av = ah[64 * t];
+            acc[0] = mfma32(av, bcur[0][t], acc[0]);
+            acc[1] = mfma32(av, bcur[1][t], acc[1]);
+          }
+          uint32_t vals[2][4][2];
+          mask_block(acc, a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + R * 32, lane, vals);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            bnext[g][2 * R] = u4{vals[g][0][0], vals[g][0][1], vals[g][1][0], vals[g][1][1]};
+            bnext[g][2 * R + 1] = u4{vals[g][2][0], vals[g][2][1], vals[g][3][0], vals[g][3][1]};
+          }
+          tile_store(vals, tr, a.dzT + (l - 1) * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows, lane);
+        }
+        lstore(nxt);
+        __syncthreads();
+        u = nxt;
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bcur[g][t] = bnext[g][t];
+      if (l == 6) audio_stage();   // bcur = g_5
+    }
+    audio_stage();                 // bcur = g_0; u wraps to 0 for the next tile
+    // d audio [row][64]: lane holds dims 32R + 8a + 4hh + c of row 32g + n
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int64_t row = w0 + 32 * g + n;
+      if (row < a.n_rows) {
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4)
+            *reinterpret_cast<f4*>(a.dxa + row * kAud + 32 * R + 8 * a4 + 4 * hh) =
+                f4{acc_a[R][g][4 * a4], acc_a[R][g][4 * a4 + 1], acc_a[R][g][4 * a4 + 2], acc_a[R][g][4 * a4 + 3]};
+      }
+    }
+  }
+}
+
 }  // namespace b16
 }  // namespace s2l
 
@@ -340,7 +532,7 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   if (misaligned16(packed_bf16) || misaligned16(x) || misaligned16(hT) || misaligned16(masks)) return S2L_E_ALIGN;
   static bool attr_set[64];
   int dev = 0;
-  hipGetDevice(&dev);
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kLdsFwd);
@@ -354,5 +546,30 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   a.n_tiles = (int)(np / kWgRows);
   const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
   hipLaunchKernelGGL(fwd_bf16_kernel, dim3(grid), dim3(256), kLdsFwd, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
+                                       float* dxa, int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows < 0) return S2L_E_SIZE;
+  if (n_rows == 0) return S2L_OK;
+  if (!packed_bf16 || !drgb || !masks || !dzT || !dxa) return S2L_E_NULL;
+  if (misaligned16(packed_bf16) || misaligned16(dzT) || misaligned16(dxa) || misaligned16(masks)) return S2L_E_ALIGN;
+  static bool attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kLdsBwd);
+    if (e != hipSuccess) return (int)e;
+    attr_set[dev] = true;
+  }
+  BwdArgs a;
+  const int64_t np = s2l_bf16_rows_padded(n_rows);
+  a.wb = packed_bf16, a.drgb = drgb, a.masks = masks, a.dzT = dzT, a.dxa = dxa;
+  a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
+  a.n_tiles = (int)(np / kWgRows);
+  const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
+  hipLaunchKernelGGL(bwd_bf16_kernel, dim3(grid), dim3(256), kLdsBwd, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }

@@ -102,3 +102,18 @@ def assert_bf16_close(got, exp, what, frac=3e-3):
     off = d > 1e-5 * (1 + exp.abs())
     assert float(off.float().mean()) < frac, (what, float(off.float().mean()))
     assert bool((d <= 2.0 ** -7 * exp.abs() * 1.01 + 2e-5).all()), (what, float(d.max()))
+
+
+def backward_teacher_forced(sd, drgb, masks, g_dev, fold):
+    """Expected dz tiles g_7..g_0 [8,N,256] (index = layer) and d audio [N,64], each step from the DEVICE's previous
+    gradient (bf16 values) so that rounding flips do not cascade."""
+    G0, _, G5, _ = fold
+    m = masks.to(torch.float32)
+    exp = [None] * 8
+    exp[7] = bf((bf(drgb) @ bf(sd["output_linear.weight"])) * m[7])
+    for l in range(7, 0, -1):
+        W = sd[f"pts_linears.{l}.weight"]
+        W = W[:, 256:] if l == 5 else W
+        exp[l - 1] = bf((g_dev[l] @ bf(W)) * m[l - 1])
+    dxa = g_dev[5] @ bf(G5[:, 42:106]) + g_dev[0] @ bf(G0[:, 42:106])
+    return torch.stack(exp), dxa

@@ -605,3 +605,38 @@ def test_bf16_forward_matches_emulation(dev, h, w, B):
     hs = torch.empty(8, N, 256, device=dev)
     _abi.check(lib.s2l_train_forward(_ptr(m.packed_weights()), _ptr(x), _ptr(hs), _ptr(ref32), N, _stream()), "s2l_train_forward")
     assert O.rmse(rgb.cpu(), ref32.cpu()) <= 2e-2
+
+
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
+def test_bf16_backward_matches_emulation(dev, h, w, B):
+    """bf16 dz chain: every saved gradient tile and the audio-feature gradient against the step-wise CPU emulation."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    from tests import bf16_util as U
+    m, lib, x, N = _bf16_inputs(dev, h, w, B)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    dzT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+    rgb = torch.empty(N, 3, device=dev)
+    pb, pf = m.packed_weights_bf16(), m.packed_weights()
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    drgb = (torch.randn(N, 3, generator=g) * 1e-3)
+    dxa = torch.full((N, 64), float("nan"), device=dev)
+    _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb.to(dev)), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()), "bwd")
+    sd_ = O.to_sd(W.make_state_dict(0, "he"))
+    g_d = U.tiles_to_rows(dzT, 8, Np)[:, :N]
+    mk = U.masks_to_rows(masks, Np)[:, :N]
+    with torch.no_grad():
+        g_e, dxa_e = U.backward_teacher_forced(sd_, drgb, mk, g_d, U.folded_from_blob(pf))
+    for l in range(8):
+        d = (g_d[l] - g_e[l]).abs()
+        scale = float(g_e[l].abs().max())
+        off = d > 1e-5 * (scale * 1e-2 + g_e[l].abs())
+        assert float(off.float().mean()) < 3e-3, (l, float(off.float().mean()))
+        assert bool((d <= 2.0 ** -7 * g_e[l].abs() * 1.01 + 1e-6 * scale).all()), (l, float(d.max()), scale)
+    sc = float(dxa_e.abs().max())
+    assert float((dxa.cpu() - dxa_e).abs().max()) <= 1e-5 * sc
+    # padded rows of the last tile carry zero gradient (they must not reach the weight gradients)
+    assert float(U.tiles_to_rows(dzT, 8, Np)[:, N:].abs().max()) == 0.0 if Np > N else True
