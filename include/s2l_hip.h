@@ -266,6 +266,16 @@ int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32,
                            uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream);
 int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
                             float* dxa, int64_t n_rows, s2l_stream_t stream);
+/* Weight gradients from the tiles: dw [256,k_in] = dzT_layer^T . inT (k_in = 256: inT = the hT layer below; k_in = 128:
+ * inT = the embedded rows as tiles, s2l_rows_to_tiles_bf16), db NULL or [256] = column sums of dz; work:
+ * s2l_wgrad_bf16_work_floats() floats (per-workgroup partial sums, reduced in a fixed order).  s2l_out_grad_bf16:
+ * dwout [3,256] = drgb^T h7, dbout [3] = column sums of drgb (output_linear). */
+int64_t s2l_wgrad_bf16_work_floats(void);
+int s2l_wgrad_bf16(const uint16_t* dzT_layer, const uint16_t* inT, int k_in, float* work, float* dw, float* db,
+                   int64_t n_rows, s2l_stream_t stream);
+int s2l_rows_to_tiles_bf16(const float* x, int k, uint16_t* xT, int64_t n_rows, s2l_stream_t stream);
+int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* work, float* dwout, float* dbout,
+                      int64_t n_rows, s2l_stream_t stream);
 
 #ifdef __cplusplus
 }

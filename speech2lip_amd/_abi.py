@@ -83,6 +83,10 @@ EXPORTS = {
     "s2l_pack_bf16": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     "s2l_train_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_train_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_wgrad_bf16_work_floats": (c_int64, []),
+    "s2l_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_rows_to_tiles_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "s2l_out_grad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -14,6 +14,13 @@
 #include "s2l_common.h"
 #include "s2l_bf16.h"
 
+#ifndef S2L_KDEPTH
+#define S2L_KDEPTH 3
+#endif
+#ifndef S2L_EXP
+#define S2L_EXP 0   // tools/ubench experiments only: 1 no tile store, 2 no masks, 4 no MFMA k-loops (results wrong)
+#endif
+
 namespace s2l {
 namespace b16 {
 
@@ -31,6 +38,23 @@ __device__ __forceinline__ uint32_t pk2(float lo, float hi) {  // round-to-neare
 __device__ __forceinline__ uint16_t bf1(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ __forceinline__ f16v mfma32(u4 a, u4 b, f16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+// K loop of TWO 32-row output blocks (independent accumulators) against one B operand set: the A quads are read from LDS
+// S2L_KDEPTH - 1 k-steps ahead into rotating registers; the sched_barrier pins that order.
+template <int T>
+__device__ __forceinline__ void kloop2(const u4* ap0, const u4* ap1, const u4 (&b)[T], f16v& acc0, f16v& acc1) {
+  constexpr int D = S2L_KDEPTH;
+  u4 a0[D], a1[D];
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) a0[t] = ap0[64 * t], a1[t] = ap1[64 * t];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + D - 1 < T) a0[(t + D - 1) % D] = ap0[64 * (t + D - 1)], a1[(t + D - 1) % D] = ap1[64 * (t + D - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = mfma32(a0[t % D], b[t], acc0);
+    acc1 = mfma32(a1[t % D], b[t], acc1);
+  }
 }
 
 struct Tab16 {
@@ -90,60 +114,64 @@ __global__ void pack_bf16_kernel(Tab16 tab, const float* __restrict__ pf, uint16
 }
 
 // ---- shared pieces of the forward / backward kernels ----------------------------------------------------------------------
-constexpr int kTrStride = 144;                  // bytes per feature row of the transposer: 64 rows bf16 + 16 pad
-constexpr int kTrBytes = 32 * kTrStride;        // per wave
+// Eight waves per workgroup, two per SIMD (<= 256 registers each): while one wave of a SIMD runs the VALU epilogue of a
+// block the other one issues MFMAs.  Wave w owns rows 32 w .. 32 w + 31 of the workgroup's 256; waves 2i, 2i+1 share the
+// 64-row tile 4 tile + i (each writes its 64-byte half of every 128-byte feature row).
+constexpr int kTrStride = 80;                   // bytes per feature row of the per-wave transposer: 32 rows bf16 + 16 pad
+constexpr int kTrBytes = 32 * kTrStride;
+constexpr int kWaves = 8;
 constexpr int kLdsW = 2 * kStageF * 2;          // two stage buffers, bytes
-constexpr int kLdsFwd = kLdsW + 4 * kTrBytes + (8 * 256 + 4) * 4;
+constexpr int kLdsFwd = kLdsW + kWaves * kTrBytes + (8 * 256 + 4) * 4;
 
 struct Stage {
-  u4 x[4], h[8];   // 16 B pieces of the X part (16 KiB) and the H part (32 KiB), piece = tid + 256 k
+  u4 x[2], h[4];   // 16 B pieces of the X part (16 KiB) and the H part (32 KiB), piece = tid + 512 k
 };
 __device__ __forceinline__ void stage_gload(Stage& st, const uint16_t* src, int tid, bool ld_x, bool ld_h) {
   const u4* p = reinterpret_cast<const u4*>(src) + tid;
   if (ld_x) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) st.x[k] = p[256 * k];
+    for (int k = 0; k < 2; ++k) st.x[k] = p[512 * k];
   }
   if (ld_h) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) st.h[k] = p[1024 + 256 * k];
+    for (int k = 0; k < 4; ++k) st.h[k] = p[1024 + 512 * k];
   }
 }
 __device__ __forceinline__ void stage_lstore(const Stage& st, uint16_t* dst, int tid, bool ld_x, bool ld_h) {
   u4* p = reinterpret_cast<u4*>(dst) + tid;
   if (ld_x) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p[256 * k] = st.x[k];
+    for (int k = 0; k < 2; ++k) p[512 * k] = st.x[k];
   }
   if (ld_h) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[1024 + 256 * k] = st.h[k];
+    for (int k = 0; k < 4; ++k) p[1024 + 512 * k] = st.h[k];
   }
 }
 
-// Write one finished 32-feature block (both row groups, already bf16 pairs) through the wave's transposer to the
-// [feature][64 rows] tile: vals[g][a][0] = features (8a+4hh+0, +1), vals[g][a][1] = (+2, +3) of row 32g + n.
-__device__ __forceinline__ void tile_store(const uint32_t (&vals)[2][4][2], char* tr, uint16_t* gdst, int lane) {
+// Write one finished 32-feature block of this wave's 32 rows (bf16 pairs) through the wave's transposer into its half of
+// the [feature][64 rows] tile: vals[a][0] = features (8a+4hh+0, +1), vals[a][1] = (+2, +3) of row n; gdst = tile + 32 R
+// feature rows + this wave's 64-byte half.
+__device__ __forceinline__ void tile_store(const uint32_t (&vals)[4][2], char* tr, uint16_t* gdst, int lane) {
   const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int fl = 8 * a + 4 * hh + 2 * d;
-        uint16_t* p = reinterpret_cast<uint16_t*>(tr + fl * kTrStride) + 32 * g + n;
-        p[0] = (uint16_t)(vals[g][a][d] & 0xffffu);
-        p[kTrStride / 2] = (uint16_t)(vals[g][a][d] >> 16);
-      }
+    for (int d = 0; d < 2; ++d) {
+      const int fl = 8 * a + 4 * hh + 2 * d;
+      uint16_t* p = reinterpret_cast<uint16_t*>(tr + fl * kTrStride) + n;
+      p[0] = (uint16_t)(vals[a][d] & 0xffffu);
+      p[kTrStride / 2] = (uint16_t)(vals[a][d] >> 16);
+    }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  u4* g4 = reinterpret_cast<u4*>(gdst);
+  char* g = reinterpret_cast<char*>(gdst);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 2; ++k) {
     const int p = lane + 64 * k;
-    g4[p] = *reinterpret_cast<const u4*>(tr + (p >> 3) * kTrStride + (p & 7) * 16);
+    *reinterpret_cast<u4*>(g + (p >> 2) * (kTileRows * 2) + (p & 3) * 16) =
+        *reinterpret_cast<const u4*>(tr + (p >> 2) * kTrStride + (p & 3) * 16);
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -159,15 +187,15 @@ struct FwdArgs {
   int n_tiles;
 };
 
-__global__ __launch_bounds__(256, 1) void fwd_bf16_kernel(FwdArgs a) {
+__global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* wbuf = reinterpret_cast<uint16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 31, hh = lane >> 5;
+  const int n = lane & 31, hh = lane >> 5, g = wave & 1;
   char* tr = smem + kLdsW + wave * kTrBytes;
-  float* bias = reinterpret_cast<float*>(smem + kLdsW + 4 * kTrBytes);
-  for (int i = tid; i < 8 * 256; i += 256) {
+  float* bias = reinterpret_cast<float*>(smem + kLdsW + kWaves * kTrBytes);
+  for (int i = tid; i < 8 * 256; i += 512) {
     const int L = i >> 8, f = i & 255;
     bias[i] = L == 0 ? a.pf[OFF_BG0 + f] : L == 5 ? a.pf[OFF_BG5 + f] : a.pf[OFF_BIAS + (L - 1) * 256 + f];
   }
@@ -177,26 +205,21 @@ __global__ __launch_bounds__(256, 1) void fwd_bf16_kernel(FwdArgs a) {
   stage_gload(st, a.wb + OFF_FWD, tid, true, false);
   stage_lstore(st, wbuf, tid, true, false);
   __syncthreads();
-
-  u4 bx[2][8], bcur[2][16], bnext[2][16];
+  u4 bx[8], bcur[16], bnext[16];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) bcur[g][t] = u4{0u, 0u, 0u, 0u};
+  for (int t = 0; t < 16; ++t) bcur[t] = u4{0u, 0u, 0u, 0u};
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int64_t w0 = (int64_t)tile * kWgRows + 64 * wave;
-    const int64_t tile64 = (int64_t)tile * 4 + wave;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int64_t row = w0 + 32 * g + n;
+    const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
+    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1);
+    {
       const bool ok = row < a.n_rows;
       const f4* xr = reinterpret_cast<const f4*>(a.x + (ok ? row : 0) * kGenK + 8 * hh);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         f4 lo = xr[4 * t], hi = xr[4 * t + 1];
         if (!ok) lo = hi = f4{0.f, 0.f, 0.f, 0.f};
-        bx[g][t] = u4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+        bx[t] = u4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
       }
     }
     for (int L = 0; L < 8; ++L) {
@@ -208,91 +231,61 @@ __global__ __launch_bounds__(256, 1) void fwd_bf16_kernel(FwdArgs a) {
         const bool nx = nL == 0 || nL == 5 || nxt == 31, nh = nL != 0;
         stage_gload(st, a.wb + OFF_FWD + (int64_t)nxt * kStageF, tid, nx, nh);
         const uint16_t* wl = wbuf + (q & 1) * kStageF;
+        f16v acc[2];   // blocks R = 2q, 2q + 1
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[w2][r] = 0.f;
+        if (use_x && !(S2L_EXP & 4))
+          kloop2<8>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabX) + lane, bx, acc[0], acc[1]);
+        if (use_h && !(S2L_EXP & 4))
+          kloop2<16>(reinterpret_cast<const u4*>(wl + 2 * kSlabX) + lane, reinterpret_cast<const u4*>(wl + 2 * kSlabX + kSlabH) + lane,
+                     bcur, acc[0], acc[1]);
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
           const int R = 2 * q + which;
-          f16v acc[2];
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-          if (use_x) {
-            const u4* ax = reinterpret_cast<const u4*>(wl + which * kSlabX) + lane;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const u4 av = ax[64 * t];
-              acc[0] = mfma32(av, bx[0][t], acc[0]);
-              acc[1] = mfma32(av, bx[1][t], acc[1]);
-            }
-          }
-          if (use_h) {
-            const u4* ah = reinterpret_cast<const u4*>(wl + 2 * kSlabX + which * kSlabH) + lane;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              const u4 av = ah[64 * t];
-              acc[0] = mfma32(av, bcur[0][t], acc[0]);
-              acc[1] = mfma32(av, bcur[1][t], acc[1]);
-            }
-          }
           // epilogue: bias, ReLU, masks, bf16; features 32R + 8a + 4hh + c
-          uint32_t vals[2][4][2];
+          uint32_t vals[4][2];
           uint64_t mymask = 0;
           const float* bl = bias + L * 256 + 32 * R + 4 * hh;
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
             const f4 bv = *reinterpret_cast<const f4*>(bl + 8 * a4);
+            float v[4];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              float v[4];
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                v[c] = fmaxf(acc[g][4 * a4 + c] + bv[c], 0.f);
+            for (int c = 0; c < 4; ++c) {
+              v[c] = fmaxf(acc[which][4 * a4 + c] + bv[c], 0.f);
+              if (!(S2L_EXP & 2)) {
                 const uint64_t b = __ballot(v[c] > 0.f);
-                if (lane == g * 16 + 4 * a4 + c) mymask = b;
+                if (lane == 4 * a4 + c) mymask = b;
               }
-              vals[g][a4][0] = pk2(v[0], v[1]);
-              vals[g][a4][1] = pk2(v[2], v[3]);
             }
+            vals[a4][0] = pk2(v[0], v[1]);
+            vals[a4][1] = pk2(v[2], v[3]);
           }
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            bnext[g][2 * R] = u4{vals[g][0][0], vals[g][0][1], vals[g][1][0], vals[g][1][1]};
-            bnext[g][2 * R + 1] = u4{vals[g][2][0], vals[g][2][1], vals[g][3][0], vals[g][3][1]};
-          }
-          tile_store(vals, tr, a.hT + L * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows, lane);
-          if (lane < 32) a.masks[L * a.mask_layer_stride + tile64 * 256 + R * 32 + lane] = mymask;
+          bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
+          bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
+          if (!(S2L_EXP & 1))
+            tile_store(vals, tr, a.hT + L * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
+          if (!(S2L_EXP & 2) && lane < 16) a.masks[L * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g + lane] = mymask;
         }
-        if (s == 31) {  // output layer on h7 (= bnext), weights in the X part of this stage
-          const u4* ao = reinterpret_cast<const u4*>(wl) + lane;
-          f16v acc[2];
+        if (s == 31) {  // output layer on h7 (= bnext), weights in the X part of this stage; rows 0..2 of block 0
+          f16v ao;
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+          for (int r = 0; r < 16; ++r) ao[r] = 0.f;
+          const u4* ap = reinterpret_cast<const u4*>(wl) + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+          for (int t = 0; t < 16; ++t) ao = mfma32(ap[64 * t], bnext[t], ao);
+          if (hh == 0 && row < a.n_rows) {
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const u4 av = ao[64 * t];
-            acc[0] = mfma32(av, bnext[0][t], acc[0]);
-            acc[1] = mfma32(av, bnext[1][t], acc[1]);
-          }
-          if (hh == 0) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              const int64_t row = w0 + 32 * g + n;
-              if (row < a.n_rows) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) a.rgb[row * 3 + c] = acc[g][c] + bias[2048 + c];
-              }
-            }
+            for (int c = 0; c < 3; ++c) a.rgb[row * 3 + c] = ao[c] + bias[2048 + c];
           }
         }
         stage_lstore(st, wbuf + ((q + 1) & 1) * kStageF, tid, nx, nh);
         __syncthreads();
       }
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) bcur[g][t] = bnext[g][t];
+      for (int t = 0; t < 16; ++t) bcur[t] = bnext[t];
     }
   }
 }
@@ -302,11 +295,7 @@ __global__ __launch_bounds__(256, 1) void fwd_bf16_kernel(FwdArgs a) {
 // d audio = G5[:, audio]^T g_5 + G0[:, audio]^T g_0.  Every g_l is stored as a [feature][64 rows] bf16 tile (dzT) for the
 // weight-gradient GEMMs; the masks are the forward's ballots, read back as wave-uniform SGPR pairs (one v_cndmask per value).
 constexpr int kLdsBwdW = 2 * kStageB * 2;
-constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2 + 4 * kTrBytes;
-
-struct StageB {
-  u4 h[8];
-};
+constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2 + kWaves * kTrBytes;
 
 struct BwdArgs {
   const uint16_t* wb;
@@ -324,109 +313,100 @@ __device__ __forceinline__ float mask_sel(float v, uint64_t m) {
   return o;
 }
 
-// masked gradient block -> bf16 pairs; mrow = the 32 ballots of this (layer, 64-row tile, R): one coalesced 256-byte load,
+// masked gradient block -> bf16 pairs; mrow = the 16 ballots of this (layer, 64-row tile, R, wave of the pair): one load,
 // then each word is broadcast into an SGPR pair with v_readlane
-__device__ __forceinline__ void mask_block(const f16v (&acc)[2], const uint64_t* __restrict__ mrow, int lane,
-                                           uint32_t (&vals)[2][4][2]) {
-  const uint64_t mv = mrow[lane & 31];
+__device__ __forceinline__ void mask_block(const f16v& acc, const uint64_t* __restrict__ mrow, int lane, uint32_t (&vals)[4][2]) {
+  const uint64_t mv = mrow[lane & 15];
   const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int a4 = 0; a4 < 4; ++a4) {
+    float v[4];
 #pragma unroll
-    for (int a4 = 0; a4 < 4; ++a4) {
-      float v[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int idx = g * 16 + 4 * a4 + c;
-        const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, idx) |
-                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, idx) << 32);
-        v[c] = mask_sel(acc[g][4 * a4 + c], m);
-      }
-      vals[g][a4][0] = pk2(v[0], v[1]);
-      vals[g][a4][1] = pk2(v[2], v[3]);
+    for (int c = 0; c < 4; ++c) {
+      const int idx = 4 * a4 + c;
+      const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, idx) |
+                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, idx) << 32);
+      v[c] = mask_sel(acc[4 * a4 + c], m);
     }
+    vals[a4][0] = pk2(v[0], v[1]);
+    vals[a4][1] = pk2(v[2], v[3]);
+  }
 }
 
-__global__ __launch_bounds__(256, 1) void bwd_bf16_kernel(BwdArgs a) {
+__global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* wbuf = reinterpret_cast<uint16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 31, hh = lane >> 5;
+  const int n = lane & 31, hh = lane >> 5, g = wave & 1;
   u4* u0 = reinterpret_cast<u4*>(smem + kLdsBwdW);
   char* tr = smem + kLdsBwdW + 8 * kSlabU0 * 2 + wave * kTrBytes;
-  for (int i = tid; i < 8 * 64; i += 256) u0[i] = reinterpret_cast<const u4*>(a.wb + OFF_BWD_U0)[i];
+  if (tid < 8 * 64) u0[tid] = reinterpret_cast<const u4*>(a.wb + OFF_BWD_U0)[tid];
 
-  StageB st;
+  u4 st[4];
   auto gload = [&](int u) {
     const u4* p = reinterpret_cast<const u4*>(a.wb + OFF_BWD_H + (int64_t)u * kStageB) + tid;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) st.h[k] = p[256 * k];
+    for (int k = 0; k < 4; ++k) st[k] = p[512 * k];
   };
   auto lstore = [&](int u) {
     u4* p = reinterpret_cast<u4*>(wbuf + (u & 1) * kStageB) + tid;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p[256 * k] = st.h[k];
+    for (int k = 0; k < 4; ++k) p[512 * k] = st[k];
   };
   gload(0);
   lstore(0);
   __syncthreads();
 
-  u4 bcur[2][16], bnext[2][16];
+  u4 bcur[16], bnext[16];
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int64_t w0 = (int64_t)tile * kWgRows + 64 * wave;
-    const int64_t tile64 = (int64_t)tile * 4 + wave;
+    const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
+    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1);
     // drgb as a K = 16 B operand: k = 8 hh + j, k < 3 used
-    u4 b0[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int64_t row = w0 + 32 * g + n;
+    u4 b0;
+    {
       float d0 = 0.f, d1 = 0.f, d2 = 0.f;
       if (hh == 0 && row < a.n_rows) d0 = a.drgb[row * 3], d1 = a.drgb[row * 3 + 1], d2 = a.drgb[row * 3 + 2];
-      b0[g] = u4{pk2(d0, d1), pk2(d2, 0.f), 0u, 0u};
+      b0 = u4{pk2(d0, d1), pk2(d2, 0.f), 0u, 0u};
     }
-    f16v acc_a[2][2];   // d audio: [audio block][row group]
-#pragma unroll
-    for (int R = 0; R < 2; ++R)
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_a[R][g][r] = 0.f;
-
     // U0: g_7
 #pragma unroll
     for (int R = 0; R < 8; ++R) {
-      f16v acc[2];
+      f16v acc;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        acc[g] = mfma32(u0[R * 64 + lane], b0[g], acc[g]);
-      }
-      uint32_t vals[2][4][2];
-      mask_block(acc, a.masks + 7 * a.mask_layer_stride + tile64 * 256 + R * 32, lane, vals);
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        bcur[g][2 * R] = u4{vals[g][0][0], vals[g][0][1], vals[g][1][0], vals[g][1][1]};
-        bcur[g][2 * R + 1] = u4{vals[g][2][0], vals[g][2][1], vals[g][3][0], vals[g][3][1]};
-      }
-      tile_store(vals, tr, a.dzT + 7 * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows, lane);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = mfma32(u0[R * 64 + lane], b0, acc);
+      uint32_t vals[4][2];
+      mask_block(acc, a.masks + 7 * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
+      bcur[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
+      bcur[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
+      tile_store(vals, tr, a.dzT + 7 * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
     }
 
     int u = 0;
-    auto audio_stage = [&]() {   // one stage: two 32-dim blocks of G[:, audio]^T against bcur
-      const int nxt = u + 1 == kBwdStages ? 0 : u + 1;
+    auto next_of = [](int v) { return v + 1 == kBwdStages ? 0 : v + 1; };
+    // one stage: two 32-dim blocks of G[:, audio]^T against bcur; the result goes to (first = g_5) or is added to (g_0) dxa
+    // [row][64]: lane holds dims 32R + 8a + 4hh + c of row n
+    auto audio_stage = [&](bool first) {
+      const int nxt = next_of(u);
       gload(nxt);
       const uint16_t* wl = wbuf + (u & 1) * kStageB;
+      f16v acc_a[2];
 #pragma unroll
-      for (int R = 0; R < 2; ++R) {
-        const u4* ah = reinterpret_cast<const u4*>(wl + R * kSlabH) + lane;
+      for (int R = 0; R < 2; ++R)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const u4 av = ah[64 * t];
-          acc_a[R][0] = mfma32(av, bcur[0][t], acc_a[R][0]);
-          acc_a[R][1] = mfma32(av, bcur[1][t], acc_a[R][1]);
-        }
+        for (int r = 0; r < 16; ++r) acc_a[R][r] = 0.f;
+      kloop2<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc_a[0], acc_a[1]);
+      if (row < a.n_rows) {
+#pragma unroll
+        for (int R = 0; R < 2; ++R)
+#pragma unroll
+          for (int a4 = 0; a4 < 4; ++a4) {
+            f4* dst = reinterpret_cast<f4*>(a.dxa + row * kAud + 32 * R + 8 * a4 + 4 * hh);
+            f4 v = f4{acc_a[R][4 * a4], acc_a[R][4 * a4 + 1], acc_a[R][4 * a4 + 2], acc_a[R][4 * a4 + 3]};
+            if (!first) v += *dst;
+            *dst = v;
+          }
       }
       lstore(nxt);
       __syncthreads();
@@ -436,58 +416,220 @@ __global__ __launch_bounds__(256, 1) void bwd_bf16_kernel(BwdArgs a) {
     for (int l = 7; l >= 1; --l) {   // W_l^T g_l -> g_{l-1}
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nxt = u + 1 == kBwdStages ? 0 : u + 1;
+        const int nxt = next_of(u);
         gload(nxt);
         const uint16_t* wl = wbuf + (u & 1) * kStageB;
+        f16v acc[2];
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[w2][r] = 0.f;
+        kloop2<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc[0], acc[1]);
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
           const int R = 2 * q + which;
-          f16v acc[2];
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-          const u4* ah = reinterpret_cast<const u4*>(wl + which * kSlabH) + lane;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const u4 av = ah[64 * t];
-            acc[0] = mfma32(av, bcur[0][t], acc[0]);
-            acc[1] = mfma32(av, bcur[1][t], acc[1]);
-          }
-          uint32_t vals[2][4][2];
-          mask_block(acc, a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + R * 32, lane, vals);
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            bnext[g][2 * R] = u4{vals[g][0][0], vals[g][0][1], vals[g][1][0], vals[g][1][1]};
-            bnext[g][2 * R + 1] = u4{vals[g][2][0], vals[g][2][1], vals[g][3][0], vals[g][3][1]};
-          }
-          tile_store(vals, tr, a.dzT + (l - 1) * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows, lane);
+          uint32_t vals[4][2];
+          mask_block(acc[which], a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
+          bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
+          bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
+          tile_store(vals, tr, a.dzT + (l - 1) * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
         }
         lstore(nxt);
         __syncthreads();
         u = nxt;
       }
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) bcur[g][t] = bnext[g][t];
-      if (l == 6) audio_stage();   // bcur = g_5
+      for (int t = 0; t < 16; ++t) bcur[t] = bnext[t];
+      if (l == 6) audio_stage(true);   // bcur = g_5
     }
-    audio_stage();                 // bcur = g_0; u wraps to 0 for the next tile
-    // d audio [row][64]: lane holds dims 32R + 8a + 4hh + c of row 32g + n
+    audio_stage(false);              // bcur = g_0; u wraps to 0 for the next tile
+  }
+}
+
+// ---- weight gradients ---------------------------------------------------------------------------------------------------------
+// dW[m][k] = sum_rows dz[row][m] in[row][k] from the [feature][64 rows] tiles: both MFMA operands want "8 consecutive rows of
+// one feature" per lane, which is 16 contiguous bytes of a tile.  A workgroup streams 64-row tile pairs (dz: 32 KiB, in: 32 or
+// 16 KiB) through a padded LDS image (144-byte feature rows: conflict-free ds_read_b128), double-buffered through registers;
+// its 4 waves own 128 x (K/2) of the 256 x K result each.  The kernel is HBM-bound by construction (64 KiB per 64 MFMAs per
+// wave); partial sums per workgroup are reduced in a fixed order by wgrad_reduce_kernel (deterministic).  The bias gradient
+// (column sums of dz) rides along on the A operands.
+constexpr int kWgParts = 256;                      // max workgroups = partial results
+constexpr int kOpStride = 144;                     // bytes per feature row in LDS
+template <int KB>
+struct WgCfg {
+  static constexpr int kNB = KB / 64;              // 32-column blocks per wave
+  static constexpr int kBPieces = KB * 8 / 256;    // 16-byte pieces of the B tile per thread
+  static constexpr int kBufBytes = (256 + KB) * kOpStride;
+  static constexpr int kLds = 2 * kBufBytes;
+};
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <int KB>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __restrict__ dzT, const uint16_t* __restrict__ inT,
+                                                            float* __restrict__ part, float* __restrict__ bpart, int n_tiles) {
+  using C = WgCfg<KB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1, n = lane & 31, hh = lane >> 5;
+  u4 sa[8], sb[C::kBPieces];
+  auto gload = [&](int tile) {
+    const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 256 * kTileRows) + tid;
+    const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * KB * kTileRows) + tid;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int64_t row = w0 + 32 * g + n;
-      if (row < a.n_rows) {
+    for (int k = 0; k < 8; ++k) sa[k] = pa[256 * k];
 #pragma unroll
-        for (int R = 0; R < 2; ++R)
+    for (int k = 0; k < C::kBPieces; ++k) sb[k] = pb[256 * k];
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * C::kBufBytes;
 #pragma unroll
-          for (int a4 = 0; a4 < 4; ++a4)
-            *reinterpret_cast<f4*>(a.dxa + row * kAud + 32 * R + 8 * a4 + 4 * hh) =
-                f4{acc_a[R][g][4 * a4], acc_a[R][g][4 * a4 + 1], acc_a[R][g][4 * a4 + 2], acc_a[R][g][4 * a4 + 3]};
+    for (int k = 0; k < 8; ++k) {
+      const int p = tid + 256 * k;
+      *reinterpret_cast<u4*>(base + (p >> 3) * kOpStride + (p & 7) * 16) = sa[k];
+    }
+#pragma unroll
+    for (int k = 0; k < C::kBPieces; ++k) {
+      const int p = tid + 256 * k;
+      *reinterpret_cast<u4*>(base + 256 * kOpStride + (p >> 3) * kOpStride + (p & 7) * 16) = sb[k];
+    }
+  };
+  f16v acc[4][C::kNB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < C::kNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) {
+    gload(tile);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < n_tiles) gload(nxt);
+    const char* abase = smem + buf * C::kBufBytes + (128 * wm + n) * kOpStride + 16 * hh;
+    const char* bbase = smem + buf * C::kBufBytes + (256 + (KB / 2) * wn + n) * kOpStride + 16 * hh;
+    u4 av[4], bv[C::kNB], an[4], bn[C::kNB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const u4*>(abase + 32 * i * kOpStride);
+#pragma unroll
+    for (int j = 0; j < C::kNB; ++j) bv[j] = *reinterpret_cast<const u4*>(bbase + 32 * j * kOpStride);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u4*>(abase + 32 * i * kOpStride + 32 * (s + 1));
+#pragma unroll
+        for (int j = 0; j < C::kNB; ++j) bn[j] = *reinterpret_cast<const u4*>(bbase + 32 * j * kOpStride + 32 * (s + 1));
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < C::kNB; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+      if (wn == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) bsum[i] += bf_lo(av[i][d]) + bf_hi(av[i][d]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = an[i];
+#pragma unroll
+      for (int j = 0; j < C::kNB; ++j) bv[j] = bn[j];
+    }
+    if (nxt < n_tiles) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // partial result of this workgroup: D[m = 8(r>>2) + 4hh + (r&3)][col n] of block (i, j)
+  float* po = part + (int64_t)blockIdx.x * 256 * KB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < C::kNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 128 * wm + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3);
+        po[m * KB + (KB / 2) * wn + 32 * j + n] = acc[i][j][r];
+      }
+  if (wn == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (hh == 0) bpart[blockIdx.x * 256 + 128 * wm + 32 * i + n] = t;
     }
   }
+}
+
+// out[i] = sum over the parts, in part order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f4 s = *reinterpret_cast<const f4*>(part + i);
+  for (int p = 1; p < parts; ++p) s += *reinterpret_cast<const f4*>(part + (int64_t)p * n + i);
+  *reinterpret_cast<f4*>(out + i) = s;
+}
+
+// x fp32 [N,K] -> bf16 tiles [tile64][K][64] (K = 128: the embedded rows, for dG0 / dG5).  One block per tile.
+__global__ __launch_bounds__(256) void rows_to_tiles_kernel(const float* __restrict__ x, uint16_t* __restrict__ xT, int K,
+                                                            int64_t n_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kTileRows;
+  const int kq = K / 4;
+  for (int i = tid; i < kTileRows * kq; i += 256) {
+    const int row = i / kq, c4 = i - row * kq;
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < n_rows) v = *reinterpret_cast<const f4*>(x + (r0 + row) * K + 4 * c4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint16_t*>(smem + (4 * c4 + c) * kOpStride + 2 * row) = bf1(v[c]);
+  }
+  __syncthreads();
+  u4* dst = reinterpret_cast<u4*>(xT + (int64_t)blockIdx.x * K * kTileRows);
+  for (int p = tid; p < K * 8; p += 256) dst[p] = *reinterpret_cast<const u4*>(smem + (p >> 3) * kOpStride + (p & 7) * 16);
+}
+
+// output layer: dWout[c][k] = sum_rows drgb[row][c] h7[row][k], dbout[c] = sum_rows drgb[row][c].  thread = feature k.
+__global__ __launch_bounds__(256) void out_grad_kernel(const float* __restrict__ drgb, const uint16_t* __restrict__ h7T,
+                                                       float* __restrict__ part, int n_tiles, int64_t n_rows) {
+  __shared__ float d[kTileRows * 3];
+  const int k = threadIdx.x;
+  float s[3] = {0.f, 0.f, 0.f}, sb = 0.f;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    if (k < kTileRows * 3) {
+      const int64_t idx = (int64_t)tile * kTileRows * 3 + k;
+      d[k] = idx < n_rows * 3 ? drgb[idx] : 0.f;
+    }
+    __syncthreads();
+    const u4* hp = reinterpret_cast<const u4*>(h7T + ((int64_t)tile * 256 + k) * kTileRows);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const u4 w = hp[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 8 * q + 2 * e;
+        const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] = fmaf(d[(row + 1) * 3 + c], hi, fmaf(d[row * 3 + c], lo, s[c]));
+      }
+    }
+    if (k < 3)
+      for (int row = 0; row < kTileRows; ++row) sb += d[row * 3 + k];
+  }
+  float* po = part + (int64_t)blockIdx.x * (3 * 256 + 4);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) po[c * 256 + k] = s[c];
+  if (k < 4) po[768 + k] = k < 3 ? sb : 0.f;
 }
 
 }  // namespace b16
@@ -545,7 +687,7 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
   a.n_tiles = (int)(np / kWgRows);
   const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
-  hipLaunchKernelGGL(fwd_bf16_kernel, dim3(grid), dim3(256), kLdsFwd, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(fwd_bf16_kernel, dim3(grid), dim3(512), kLdsFwd, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
 
@@ -570,6 +712,66 @@ extern "C" int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float*
   a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
   a.n_tiles = (int)(np / kWgRows);
   const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
-  hipLaunchKernelGGL(bwd_bf16_kernel, dim3(grid), dim3(256), kLdsBwd, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(bwd_bf16_kernel, dim3(grid), dim3(512), kLdsBwd, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t s2l_wgrad_bf16_work_floats(void) { return (int64_t)kWgParts * (256 * 256 + 256); }
+
+extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in, float* work, float* dw, float* db,
+                              int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows <= 0 || (k_in != 256 && k_in != 128)) return S2L_E_SIZE;
+  if (!dzT || !inT || !work || !dw) return S2L_E_NULL;
+  if (misaligned16(dzT) || misaligned16(inT) || misaligned16(work) || misaligned16(dw)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
+  const int parts = n_tiles < kWgParts ? n_tiles : kWgParts;
+  float* bpart = work + (int64_t)kWgParts * 256 * 256;
+  static bool attr_set[64][2];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const int which = k_in == 256 ? 0 : 1;
+  if (dev >= 0 && dev < 64 && !attr_set[dev][which]) {
+    hipError_t e = which == 0 ? hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<256>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<256>::kLds)
+                              : hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<128>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<128>::kLds);
+    if (e != hipSuccess) return (int)e;
+    attr_set[dev][which] = true;
+  }
+  if (k_in == 256)
+    hipLaunchKernelGGL(wgrad_bf16_kernel<256>, dim3(parts), dim3(256), WgCfg<256>::kLds, st, dzT, inT, work, bpart, n_tiles);
+  else
+    hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(parts), dim3(256), WgCfg<128>::kLds, st, dzT, inT, work, bpart, n_tiles);
+  const int n = 256 * k_in;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, work, dw, n, parts);
+  if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, db, 256, parts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_rows_to_tiles_bf16(const float* x, int k, uint16_t* xT, int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows <= 0 || k < 4 || k > 256 || (k & 3)) return S2L_E_SIZE;
+  if (!x || !xT) return S2L_E_NULL;
+  if (misaligned16(x) || misaligned16(xT)) return S2L_E_ALIGN;
+  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
+  hipLaunchKernelGGL(rows_to_tiles_kernel, dim3(n_tiles), dim3(256), k * kOpStride, static_cast<hipStream_t>(stream), x, xT, k,
+                     n_rows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* work, float* dwout, float* dbout, int64_t n_rows,
+                                 s2l_stream_t stream) {
+  if (n_rows <= 0) return S2L_E_SIZE;
+  if (!drgb || !h7T || !work || !dwout || !dbout) return S2L_E_NULL;
+  if (misaligned16(h7T) || misaligned16(work) || misaligned16(dwout)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
+  const int parts = n_tiles < kWgParts ? n_tiles : kWgParts;
+  hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_tiles, n_rows);
+  // parts x [772] -> [768] + [4]: reduce into a scratch row behind the partials, then split
+  float* sum = work + (int64_t)kWgParts * 772;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, work, sum, 772, parts);
+  (void)hipMemcpyAsync(dwout, sum, 768 * sizeof(float), hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(dbout, sum + 768, 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   return (int)hipGetLastError();
 }

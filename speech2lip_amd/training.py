@@ -98,8 +98,13 @@ class LipTrainStep:
     (G0 = W0 [Wuv|Wa|Wt] etc., four 256x256x126 products) uses torch.matmul on the device.
     """
 
-    def __init__(self, model: TalkingFace, height: int, width: int):
+    def __init__(self, model: TalkingFace, height: int, width: int, precision: str = "fp32"):
+        """precision: 'fp32' (parity mode: exact-fp32 MFMA, saved state in fp32) or 'bf16' (BASELINE config 5: bf16 MFMA
+        operands and saved state, fp32 accumulation / master weights / gradients; csrc/train_bf16.hip)."""
         from .rendering import get_coords
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
         self.model, self.h, self.w = model, int(height), int(width)
         self.lib = _abi.load()
         self.coords = get_coords(width, height, model.packed_weights().device)
@@ -120,7 +125,15 @@ class LipTrainStep:
         ck = _abi.check
         feat = m.audio_merge_forward(audio)                                  # [B,64]
         x, areas = self._f(N, 128), self._f(N)
-        hsave, dzsave = self._f(8, N, 256), self._f(8, N, 256)
+        bf16 = self.precision == "bf16"
+        if bf16:
+            Np = int(lib.s2l_bf16_rows_padded(N))
+            pb = m.packed_weights_bf16()
+            i16 = lambda n: torch.empty(n, dtype=torch.int16, device=dev)
+            hT, dzT, xT = i16(8 * Np * 256), i16(8 * Np * 256), i16(Np * 128)
+            masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+        else:
+            hsave, dzsave = self._f(8, N, 256), self._f(8, N, 256)
         rgb, drgb, dxa = self._f(N, 3), self._f(N, 3), self._f(N, 64)
         pred, dpred = self._f(B * P, 3), self._f(B * P, 3)
         loss, mwork = self._f(1), self._f(1024)
@@ -129,7 +142,11 @@ class LipTrainStep:
                 ck(lib.s2l_ensemble_rows(_ptr(packed), _ptr(self.coords), _ptr(feat[b]), idx[b], self.w, self.h,
                                          ctypes.c_float(u[b]), _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, st),
                    "s2l_ensemble_rows")
-            ck(lib.s2l_train_forward(_ptr(packed), _ptr(x), _ptr(hsave), _ptr(rgb), N, st), "s2l_train_forward")
+            if bf16:
+                ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(packed), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, st),
+                   "s2l_train_forward_bf16")
+            else:
+                ck(lib.s2l_train_forward(_ptr(packed), _ptr(x), _ptr(hsave), _ptr(rgb), N, st), "s2l_train_forward")
             for b in range(B):
                 ck(lib.s2l_ensemble_reduce(_ptr(rgb[b * 4 * P:]), _ptr(areas[b * 4 * P:]), _ptr(pred[b * P:]), P, st),
                    "s2l_ensemble_reduce")
@@ -138,14 +155,30 @@ class LipTrainStep:
             for b in range(B):
                 ck(lib.s2l_ensemble_backward(_ptr(dpred[b * P:]), _ptr(areas[b * 4 * P:]), _ptr(drgb[b * 4 * P:]), P, st),
                    "s2l_ensemble_backward")
-            ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(hsave), _ptr(dzsave), _ptr(dxa), N, st),
-               "s2l_train_backward")
-            work = self._f(int(lib.s2l_split_work_floats(256 * 256)))
+            if bf16:
+                ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, st),
+                   "s2l_train_backward_bf16")
+                ck(lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, st), "s2l_rows_to_tiles_bf16")
+                work = self._f(int(lib.s2l_wgrad_bf16_work_floats()))
+                lay = Np * 256
 
-            def wgrad(dz, inp, ldin, k_in, want_bias=True):
-                out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
-                ck(lib.s2l_wgrad(_ptr(dz), 256, _ptr(inp), ldin, k_in, _ptr(work), _ptr(out), _ptr(db), N, st), "s2l_wgrad")
-                return out, db
+                def wgrad(k, inp, ldin, k_in, want_bias=True):          # dz of layer k against hT[inp] or the x tiles
+                    out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
+                    src = xT if inp is None else hT[inp * lay:]
+                    ck(lib.s2l_wgrad_bf16(_ptr(dzT[k * lay:]), _ptr(src), k_in, _ptr(work), _ptr(out), _ptr(db), N, st),
+                       "s2l_wgrad_bf16")
+                    return out, db
+            else:
+                ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(hsave), _ptr(dzsave), _ptr(dxa), N, st),
+                   "s2l_train_backward")
+                work = self._f(int(lib.s2l_split_work_floats(256 * 256)))
+
+                def wgrad(k, inp, ldin, k_in, want_bias=True):
+                    out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
+                    src = x if inp is None else hsave[inp]
+                    ck(lib.s2l_wgrad(_ptr(dzsave[k]), 256, _ptr(src), ldin, k_in, _ptr(work), _ptr(out), _ptr(db), N, st),
+                       "s2l_wgrad")
+                    return out, db
 
             def colsum(src, c):
                 out = self._f(c)
@@ -154,17 +187,23 @@ class LipTrainStep:
 
             g = {}
             for k in range(1, 8):                          # pts_linears[k]: h_{k-1} -> h_k
-                dw, db = wgrad(dzsave[k], hsave[k - 1], 256, 256)
+                dw, db = wgrad(k, k - 1, 256, 256)
                 if k == 5:
                     dw5b, dc5 = dw, db
                 else:
                     g[f"pts_linears.{k}.weight"], g[f"pts_linears.{k}.bias"] = dw, db
-            dG0, dc0 = wgrad(dzsave[0], x, 128, 128)
-            dG5, _ = wgrad(dzsave[5], x, 128, 128, want_bias=False)
+            dG0, dc0 = wgrad(0, None, 128, 128)
+            dG5, _ = wgrad(5, None, 128, 128, want_bias=False)
             dwout = self._f(3, 256)
-            ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
-               "s2l_small_outer")
-            g["output_linear.weight"], g["output_linear.bias"] = dwout, colsum(drgb, 3)
+            if bf16:
+                dbout = self._f(3)
+                ck(lib.s2l_out_grad_bf16(_ptr(drgb), _ptr(hT[7 * lay:]), _ptr(work), _ptr(dwout), _ptr(dbout), N, st),
+                   "s2l_out_grad_bf16")
+                g["output_linear.weight"], g["output_linear.bias"] = dwout, dbout
+            else:
+                ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
+                   "s2l_small_outer")
+                g["output_linear.weight"], g["output_linear.bias"] = dwout, colsum(drgb, 3)
             # per-frame gradient of the audio feature (rows of frame b are contiguous), then the encoder backward
             da = dxa.reshape(B, 4 * P, 64).sum(dim=1).contiguous()
             na = int(lib.s2l_audio_grad_floats())
