@@ -22,3 +22,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_fetch -
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/cpmc_write -o s -- $C > $O/cpmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
 ls $O
+# ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
+for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16" \
+            "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet"; do
+  name=${spec%%:*}; cmd=${spec#*:}
+  python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1
+done
+ls $O

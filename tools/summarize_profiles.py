@@ -41,6 +41,21 @@ for d in ("cpmc_fetch", "cpmc_write", "cpmc_sq"):
     cv.update(pmc(d, "composite_kernel"))
 for k, v in cv.items():
     out.append("%-34s %.6g\n" % (k, v))
+for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench_train.py 64 bf16"),
+                    ("train_fp32", "training step, fp32 parity mode: python tools/bench_train.py 64 fp32"),
+                    ("unet", "post-fusion U-Net: python tools/bench_unet.py 16"),
+                    ("syncnet", "sync loss (T3): python tools/bench_syncnet.py 16"),
+                    ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
+                    ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet")):
+    rows = stats("x_" + name)
+    if not rows:
+        continue
+    out.append(f"\n## {title}\n")
+    p = f"{src}/{name}_line.txt"
+    if os.path.exists(p):
+        out.append(open(p).read().strip() + "\n")
+    for r in rows[:8]:
+        out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
 print("".join(out))
