@@ -570,13 +570,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   }
 }
 
-// out[i] = sum over the parts, in part order
+// out[i] = sum over the parts in a fixed order: 64 float4 columns per block, the parts split over the block's 4 waves
+// (each sums its quarter in part order), then the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts) {
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  f4 s = *reinterpret_cast<const f4*>(part + i);
-  for (int p = 1; p < parts; ++p) s += *reinterpret_cast<const f4*>(part + (int64_t)p * n + i);
-  *reinterpret_cast<f4*>(out + i) = s;
+  __shared__ f4 red[4][64];
+  const int col = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = (blockIdx.x * 64 + col) * 4;
+  f4 s = f4{0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const int per = (parts + 3) / 4;
+    const int p1 = min(parts, (w + 1) * per);
+    for (int p = w * per; p < p1; ++p) s += *reinterpret_cast<const f4*>(part + (int64_t)p * n + i);
+  }
+  red[w][col] = s;
+  __syncthreads();
+  if (w == 0 && i < n) *reinterpret_cast<f4*>(out + i) = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
 }
 
 // x fp32 [N,K] -> bf16 tiles [tile64][K][64] (K = 128: the embedded rows, for dG0 / dG5).  One block per tile.
@@ -744,7 +752,7 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
   else
     hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(parts), dim3(256), WgCfg<128>::kLds, st, dzT, inT, work, bpart, n_tiles);
   const int n = 256 * k_in;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, work, dw, n, parts);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, st, work, dw, n, parts);
   if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, db, 256, parts);
   return (int)hipGetLastError();
 }
@@ -770,7 +778,7 @@ extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* 
   hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_tiles, n_rows);
   // parts x [772] -> [768] + [4]: reduce into a scratch row behind the partials, then split
   float* sum = work + (int64_t)kWgParts * 772;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, work, sum, 772, parts);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts);
   (void)hipMemcpyAsync(dwout, sum, 768 * sizeof(float), hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(dbout, sum + 768, 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   return (int)hipGetLastError();
