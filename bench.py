@@ -105,6 +105,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        # RCCL sets up its rings lazily on the first collective of each kind: do that here, outside any step, so that a
+        # run with --warmup 0 does not time communicator setup
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)
+        g = torch.zeros(world * 4, device=dev)
+        dist.all_gather_into_tensor(g, g[rank * 4:rank * 4 + 4].clone())
+        torch.cuda.synchronize()
 
     import speech2lip_amd as s2l
     from speech2lip_amd import sharded, weights as W
