@@ -75,6 +75,14 @@ def cpu_baseline(frames_budget_s: float = 12.0):
             "batched_sample": f"{nb} frames 96x96 in clips of 8 (oracle.render_clip: encoder once per frame), {dtb:.1f} s"}
 
 
+def _flush_c_stdout():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +120,7 @@ def main():
         g = torch.zeros(world * 4, device=dev)
         dist.all_gather_into_tensor(g, g[rank * 4:rank * 4 + 4].clone())
         torch.cuda.synchronize()
+        _flush_c_stdout()      # RCCL's version banner (NCCL_DEBUG=VERSION) leaves every rank's C stdio buffer now, not at exit
 
     import speech2lip_amd as s2l
     from speech2lip_amd import sharded, weights as W
@@ -186,10 +195,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
     if use_dist:
+        _flush_c_stdout()
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        _flush_c_stdout()      # the JSON line must be the LAST line on stdout
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
