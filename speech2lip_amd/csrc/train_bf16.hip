@@ -231,33 +231,42 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
         const bool nx = nL == 0 || nL == 5 || nxt == 31, nh = nL != 0;
         stage_gload(st, a.wb + OFF_FWD + (int64_t)nxt * kStageF, tid, nx, nh);
         const uint16_t* wl = wbuf + (q & 1) * kStageF;
-        f16v acc[2];   // blocks R = 2q, 2q + 1
+        f16v acc[2];   // blocks R = 2q, 2q + 1, initialised with the bias (feature 32R + 8a + 4hh + c <-> register 4a + c)
 #pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2)
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const float* bl = bias + L * 256 + 32 * (2 * q + w2) + 4 * hh;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[w2][r] = 0.f;
+          for (int a4 = 0; a4 < 4; ++a4) {
+            const f4 bv = *reinterpret_cast<const f4*>(bl + 8 * a4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[w2][4 * a4 + c] = bv[c];
+          }
+        }
         if (use_x && !(S2L_EXP & 4))
           kloop2<8>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabX) + lane, bx, acc[0], acc[1]);
         if (use_h && !(S2L_EXP & 4))
           kloop2<16>(reinterpret_cast<const u4*>(wl + 2 * kSlabX) + lane, reinterpret_cast<const u4*>(wl + 2 * kSlabX + kSlabH) + lane,
                      bcur, acc[0], acc[1]);
+        // epilogue: ReLU, masks, bf16.  The 32 ballots of the two blocks (64 dwords) are collected one dword per lane with
+        // v_writelane: lane 32 which + 2 r + half holds that half of ballot r of block `which`.
+        int mword = 0;
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
           const int R = 2 * q + which;
-          // epilogue: bias, ReLU, masks, bf16; features 32R + 8a + 4hh + c
           uint32_t vals[4][2];
-          uint64_t mymask = 0;
-          const float* bl = bias + L * 256 + 32 * R + 4 * hh;
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
-            const f4 bv = *reinterpret_cast<const f4*>(bl + 8 * a4);
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              v[c] = fmaxf(acc[which][4 * a4 + c] + bv[c], 0.f);
+              v[c] = fmaxf(acc[which][4 * a4 + c], 0.f);
               if (!(S2L_EXP & 2)) {
                 const uint64_t b = __ballot(v[c] > 0.f);
-                if (lane == 4 * a4 + c) mymask = b;
+                const int r = 4 * a4 + c;
+                // s_nop: gfx940+ needs 2 wait states between a VALU write of an SGPR (the compare) and a VALU read of it;
+                // the compiler's hazard recogniser does not look inside inline asm
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mword) : "s"((uint32_t)b), "n"(32 * which + 2 * r));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(mword) : "s"((uint32_t)(b >> 32)), "n"(32 * which + 2 * r + 1));
               }
             }
             vals[a4][0] = pk2(v[0], v[1]);
@@ -267,8 +276,9 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
           bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
           if (!(S2L_EXP & 1))
             tile_store(vals, tr, a.hT + L * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
-          if (!(S2L_EXP & 2) && lane < 16) a.masks[L * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g + lane] = mymask;
         }
+        if (!(S2L_EXP & 2))   // uint64 index R*32 + 16g + r  ->  dword index 2*(...) + half
+          reinterpret_cast<int*>(a.masks + L * a.mask_layer_stride + tile64 * 256 + (2 * q + (lane >> 5)) * 32 + 16 * g)[lane & 31] = mword;
         if (s == 31) {  // output layer on h7 (= bnext), weights in the X part of this stage; rows 0..2 of block 0
           f16v ao;
 #pragma unroll
