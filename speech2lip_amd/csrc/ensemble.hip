@@ -19,13 +19,14 @@ struct TapShifts {
   float dx[4], dy[4];   // tap t = 2*ix + iy: (vx, vy) = ((-1,-1), (-1,1), (1,-1), (1,1))
 };
 
-// 128 threads per (tap, pixel) row: x[t*N + n] = [E(c) | feat | PE(time) | 0 0]; thread 0 also writes the area.
+// 32 threads per (tap, pixel) row, one 16-byte store each: x[t*N + n] = [E(c) | feat | PE(time) | 0 0]; the thread of
+// columns 0..3 also writes the area.
 __global__ __launch_bounds__(256) void ensemble_rows_kernel(const float* __restrict__ packed,
                                                            const float* __restrict__ coords,
                                                            const float* __restrict__ feat, float time_pos, TapShifts sh,
                                                            float* __restrict__ x, float* __restrict__ areas, int64_t n) {
-  const int64_t row = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
-  const int k = threadIdx.x & 127;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int k0 = (threadIdx.x & 31) * 4;
   if (row >= 4 * n) return;
   const int t = (int)(row / n);
   const int64_t p = row - (int64_t)t * n;
@@ -33,16 +34,22 @@ __global__ __launch_bounds__(256) void ensemble_rows_kernel(const float* __restr
   // coord_ = clamp(coords + shift, 0, 1): one fp32 add, then clamp (training.py:207-210)
   const float cu = fminf(fmaxf(u0 + sh.dx[t], 0.f), 1.f);
   const float cv = fminf(fmaxf(v0 + sh.dy[t], 0.f), 1.f);
-  float val;
-  if (k < kEmb) val = embed_feature_f(cu, cv, k);
-  else if (k < kEmb + kAud) val = feat[k - kEmb];
-  else if (k < kEmb + kAud + kTime) {
-    const int i = k - kEmb - kAud;
-    const float arg = time_pos * packed[OFF_DIV + (i >> 1)];
-    val = (i & 1) ? cosf(arg) : sinf(arg);
-  } else val = 0.f;
-  x[row * kGenK + k] = val;
-  if (k == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;   // training.py:240-241
+  f4 val;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    float v;
+    if (k < kEmb) v = embed_feature_f(cu, cv, k);
+    else if (k < kEmb + kAud) v = feat[k - kEmb];
+    else if (k < kEmb + kAud + kTime) {
+      const int i = k - kEmb - kAud;
+      const float arg = time_pos * packed[OFF_DIV + (i >> 1)];
+      v = (i & 1) ? cosf(arg) : sinf(arg);
+    } else v = 0.f;
+    val[j] = v;
+  }
+  *reinterpret_cast<f4*>(x + row * kGenK + k0) = val;
+  if (k0 == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;   // training.py:240-241
 }
 
 __global__ __launch_bounds__(256) void ensemble_reduce_kernel(const float* __restrict__ pred,
@@ -86,7 +93,7 @@ extern "C" int s2l_ensemble_rows(const float* packed, const float* coords, const
   if (n_pixels < 0 || width <= 0 || height <= 0) return S2L_E_SIZE;
   if (n_pixels == 0) return S2L_OK;
   if (!packed || !coords || !feat || !x || !areas) return S2L_E_NULL;
-  hipLaunchKernelGGL(s2l::ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 1) / 2)), dim3(256), 0,
+  hipLaunchKernelGGL(s2l::ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 7) / 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), packed, coords, feat, (float)time_index,
                      tap_shifts(width, height, u01), x, areas, n_pixels);
   return (int)hipGetLastError();
@@ -118,7 +125,7 @@ extern "C" int s2l_predict_lip_image(const float* packed, const float* coords, c
   float* x = work;
   float* pred = x + 4 * n_pixels * kGenK;
   float* areas = pred + 4 * n_pixels * 3;
-  hipLaunchKernelGGL(ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 1) / 2)), dim3(256), 0, st, packed, coords, feat,
+  hipLaunchKernelGGL(ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 7) / 8)), dim3(256), 0, st, packed, coords, feat,
                      (float)time_index, sh, x, areas, n_pixels);
   int rc = launch_general_mlp(packed, x, pred, nullptr, 4 * n_pixels, st);
   if (rc) return rc;
