@@ -198,6 +198,11 @@ def test_composite_golden_both_pad_modes(golden, dev):
         assert recon is not None and recon.shape == new.shape
         close(can, g[f"merged_canonical_mode{mode}"], 1e-9, 0.0)           # elementwise: bit-exact
         close(new, g[f"merged_new_mode{mode}"], 1e-6, 2e-6)
+    # obama2_face_crop folders: rectangle padding w // 12 instead of w // 5 (tf_nerf.py:356-358)
+    m = make_model(dev, 16, 24, path="dataset/obama2_face_crop_lip")
+    _, new, _ = m.post_fusion2_onlylip(*args, int(g["x0"]), int(g["y0"]), T(g["coord"]).to(dev))
+    close(new, g["merged_new_obama2"], 1e-6, 2e-6)
+    assert not np.array_equal(g["merged_new_obama2"], g["merged_new_mode0"])
 
 
 def test_composite_batched_shared_constants(dev):

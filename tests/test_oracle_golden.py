@@ -89,6 +89,8 @@ def test_g4_composite_both_pad_modes(golden):
             assert _maxerr(new, g[f"merged_new_mode{mode}"]) <= 1e-6
             assert _maxerr(can, g[f"merged_canonical_mode{mode}"]) <= 1e-6
     assert not np.array_equal(g["merged_new_mode0"], g["merged_new_mode1"])
+    new, _ = O.composite(*args, int(g["x0"]), int(g["y0"]), T(g["coord"]), pad_mode=O.PAD_MODE_MAY, pad_div=12)
+    assert _maxerr(new, g["merged_new_obama2"]) <= 1e-6          # the obama2_face_crop rectangle (w // 12)
 
 
 def test_g5_ensemble_and_loss(golden):

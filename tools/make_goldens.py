@@ -165,6 +165,13 @@ def main():
                 report[f"composite_can_mode{mode}_builtin{int(builtin)}"] = maxerr(can_ref, can_o)
             g4[f"merged_new_mode{mode}"] = new_ref.numpy()
             g4[f"merged_canonical_mode{mode}"] = can_ref.numpy()
+        # the obama2_face_crop rule: rectangle padding w // 12 (tf_nerf.py:356-358), 'may'-style paste origin
+        model, cfg = ref_model(ref_config, TalkingFace, lh, lw, data_path="dataset/obama2_face_crop_lip")
+        _, new_ref, can_ref = model.post_fusion2_onlylip(lip, face, gt, m, x0, y0, coord)
+        new_o, can_o = O.composite(lip, face, gt, m, x0, y0, coord, pad_mode=O.PAD_MODE_MAY, pad_div=12)
+        report["composite_new_obama2"] = maxerr(new_ref, new_o)
+        report["composite_can_obama2"] = maxerr(can_ref, can_o)
+        g4["merged_new_obama2"] = new_ref.numpy()
         g4.update(lip=lip.numpy(), face=face.numpy(), gt=gt.numpy(), mask=m.numpy(), coord=coord.numpy(),
                   x0=np.array(x0), y0=np.array(y0))
         np.savez_compressed(os.path.join(GOLD, "g4_composite.npz"), **g4)
