@@ -4,8 +4,8 @@
 A "step" renders one clip of FRAMES synthetic audio windows at 96x96 (BASELINE config 2:
 8-layer x 256 MLP, 1000 frames) from inputs already resident in HBM: audio encoder ->
 per-frame vectors -> fused MLP render -> [FRAMES,96,96,3] fp32 in HBM.  With N > 1 every rank
-renders its own FRAMES (weak scaling) and the clip is reassembled on every rank with chunked
-all-gathers (RCCL) overlapped with rendering.
+renders its own FRAMES (weak scaling) and the clip is reassembled on every rank with an RCCL all-gather
+(one per step by default; --chunks > 1 splits it into per-chunk gathers issued while the next chunk renders).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
