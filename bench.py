@@ -94,6 +94,9 @@ def main():
                          "all-gather: the renderer fills every CU (151 KiB LDS + all registers per workgroup), so an "
                          "RCCL kernel overlapped with it can only start on CUs a finished workgroup has released and "
                          "then delays the statically-striped workgroups of the next launch; >1 enables the overlap")
+    ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
+                    help="dtype of the reassembled clip (N > 1): f32 = bit-identical to a 1-GPU render (default); u8 = the 8-bit "
+                         "frames the reference writes (cv2.imwrite semantics), quantised per rank, 4x less all-gather traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
     ap.add_argument("--force-dist", action="store_true",
@@ -132,7 +135,8 @@ def main():
     n_chunks = args.chunks if (world > 1 or args.force_chunks) else 1
     gids = sharded.global_frame_ids(F, rank, world, n_chunks, QUANTUM).to(dev)
     audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
-    clip = torch.empty((F * world, H, W_, 3), dtype=torch.float32, device=dev) if use_dist else None
+    quant = s2l.to8b if args.gather == "u8" else None
+    clip = torch.empty((F * world, H, W_, 3), dtype=torch.uint8 if quant else torch.float32, device=dev) if use_dist else None
     kernel_events = []
 
     def render(off, cnt, out):
@@ -140,7 +144,7 @@ def main():
 
     def step():
         return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip,
-                                      quantum=QUANTUM, force_collective=args.force_dist)
+                                      quantum=QUANTUM, force_collective=args.force_dist, quantize=quant if use_dist else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -183,7 +187,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step",
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
-                       (f" + {n_chunks}-chunk all-gather" if world > 1 else "")},
+                       (f" + {n_chunks}-chunk {args.gather} all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):

@@ -277,6 +277,12 @@ int s2l_rows_to_tiles_bf16(const float* x, int k, uint16_t* xT, int64_t n_rows, 
 int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* work, float* dwout, float* dbout,
                       int64_t n_rows, s2l_stream_t stream);
 
+/* ---- 8-bit output (inference.py:172-178) ---------------------------------------------------------------
+ * out[i] = saturate_cast<uchar>(rgb[i] * 255) as cv2.imwrite converts the float image the reference hands it
+ * (round to nearest even, clamp to [0,255]); n = number of floats.  Channel order is untouched (the reference's
+ * RGB->BGR swap only undoes cv2's BGR file convention). */
+int s2l_to8b(const float* rgb, uint8_t* out, int64_t n, s2l_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

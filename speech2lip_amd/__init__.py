@@ -1,6 +1,6 @@
 """speech2lip_amd -- MI355X-native lip-render hot path of Speech2Lip."""
 from .config import load_config, may_config
-from .data import ClipTensors, SomeonesLipClip, render_clip_frames, write_frames
+from .data import ClipTensors, SomeonesLipClip, render_clip_frames, to8b, write_frames
 from .rendering import get_coords
 from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
 from . import training
@@ -11,4 +11,4 @@ from . import geometry
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
            "predict_lip_image", "LipTrainStep", "training",
-           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "SyncNet_color", "SyncLoss", "geometry"]
+           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "SyncNet_color", "SyncLoss", "geometry"]

@@ -177,11 +177,26 @@ def render_clip_frames(model, clip: ClipTensors, use_post_fusion: bool = True):
     return lip, recon, new
 
 
+def to8b(frames: torch.Tensor) -> torch.Tensor:
+    """float frames -> uint8 with cv2.imwrite's conversion (round to nearest even, saturate): on the GPU through
+    s2l_to8b (so that only a quarter of the bytes cross PCIe), with torch ops for host tensors."""
+    if frames.device.type != "cuda":
+        return (frames.detach().to(torch.float32) * 255.0).round().clamp(0, 255).to(torch.uint8)
+    import ctypes
+    from . import _abi
+    x = frames.detach().to(torch.float32).contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _abi.check(_abi.load().s2l_to8b(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), x.numel(),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_to8b")
+    return out
+
+
 def write_frames(frames: torch.Tensor, names, out_dir: str, ext: str = ".jpg") -> None:
     """rgb*255 -> 8-bit image files named %05d (inference.py:172-178; the reference converts to BGR only
-    because cv2.imwrite expects it: the files hold the same RGB picture)."""
+    because cv2.imwrite expects it: the files hold the same RGB picture).  cv2.imwrite rounds and saturates."""
     from PIL import Image
     os.makedirs(out_dir, exist_ok=True)
-    arr = (frames.detach().clamp(0, 1) * 255.0).to(torch.uint8).cpu().numpy()   # cv2.imwrite saturates and truncates likewise
+    arr = to8b(frames).cpu().numpy()
     for a, name in zip(arr, names):
         Image.fromarray(a, "RGB").save(os.path.join(out_dir, name + ext), quality=95)

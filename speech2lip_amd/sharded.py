@@ -52,13 +52,17 @@ def global_frame_ids(frames_per_rank: int, rank: int, world: int, n_chunks: int,
 
 def render_sharded(render_fn: Callable[[int, int, torch.Tensor], None], frames_per_rank: int, frame_shape,
                    device, n_chunks: int = 4, group=None, clip: torch.Tensor = None, gather: bool = True,
-                   quantum: int = 1, force_collective: bool = False):
+                   quantum: int = 1, force_collective: bool = False, quantize: Callable = None):
     """Render this rank's frames chunk by chunk and all-gather each chunk into `clip`.
 
     render_fn(local_offset, count, out) renders local frames [local_offset, local_offset+count)
-    into `out` ([count, *frame_shape], a view of the local buffer).
-    Returns (clip [world*frames_per_rank, *frame_shape] in global frame order, local buffer).
-    With world == 1 (or gather=False) no collective is issued and clip aliases the local buffer.
+    into `out` ([count, *frame_shape], a view of the local fp32 buffer).
+    quantize: None -> the clip is gathered as fp32 (bit-identical to a 1-GPU render); or a function
+    fp32 tensor -> uint8 tensor (speech2lip_amd.to8b: the 8-bit frames the reference writes to disk,
+    inference.py:177), in which case each chunk is quantised on its rank and gathered as uint8 (4x less xGMI traffic).
+    Returns (clip [world*frames_per_rank, *frame_shape] in global frame order, local fp32 buffer).
+    With world == 1 (or gather=False) no collective is issued and clip aliases the local buffer
+    (quantised when `quantize` is given).
     """
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     local = torch.empty((frames_per_rank, *frame_shape), dtype=torch.float32, device=device)
@@ -67,15 +71,19 @@ def render_sharded(render_fn: Callable[[int, int, torch.Tensor], None], frames_p
         for off, cnt in plan:
             if cnt:
                 render_fn(off, cnt, local[off:off + cnt])
-        return local, local
-    if clip is None:
-        clip = torch.empty((frames_per_rank * world, *frame_shape), dtype=torch.float32, device=device)
-    works, start = [], 0
+        return (quantize(local) if quantize is not None else local), local
+    out_dtype = torch.uint8 if quantize is not None else torch.float32
+    if clip is None or clip.dtype != out_dtype:
+        clip = torch.empty((frames_per_rank * world, *frame_shape), dtype=out_dtype, device=device)
+    works, start, keep = [], 0, []
     for off, cnt in plan:
         if cnt:
             render_fn(off, cnt, local[off:off + cnt])
-            works.append(dist.all_gather_into_tensor(clip[start:start + cnt * world], local[off:off + cnt],
-                                                     group=group, async_op=True))
+            src = local[off:off + cnt]
+            if quantize is not None:
+                src = quantize(src)
+                keep.append(src)                  # stays alive until its gather has completed
+            works.append(dist.all_gather_into_tensor(clip[start:start + cnt * world], src, group=group, async_op=True))
         start += cnt * world
     for w in works:
         w.wait()

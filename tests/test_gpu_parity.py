@@ -711,3 +711,13 @@ def test_bf16_train_step_vs_fp32(dev, h, w, B):
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         assert rel <= 5e-2 and cos >= 0.999, f"{k}: rel {rel:.3e} cos {cos:.6f}"
+
+
+def test_to8b_matches_cv2_conversion(dev):
+    """s2l_to8b = saturate_cast<uchar>(x * 255): round half to even, clamp; ragged length; host variant agrees."""
+    x = torch.cat([torch.linspace(-0.2, 1.2, 4099), torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 127.5 / 255, float("inf"), -float("inf")])])
+    ref = (x * 255.0).round().clamp(0, 255).to(torch.uint8)
+    got = s2l.to8b(x.to(dev))
+    assert got.dtype == torch.uint8 and torch.equal(got.cpu(), ref)
+    assert ref[4099:4103].tolist() == [0, 2, 2, 128]
+    assert torch.equal(s2l.to8b(x), ref)

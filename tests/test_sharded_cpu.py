@@ -40,6 +40,11 @@ def _worker(rank, world, port, fpr, nc, ret):
         clip, local = sharded.render_sharded(render, fpr, (2, 3), torch.device("cpu"), n_chunks=nc)
         expect = _stamp(torch.arange(fpr * world)).view(-1, 1, 1).expand(-1, 2, 3)
         ok = torch.equal(clip, expect) and local.shape[0] == fpr
+        # uint8 gather: every rank quantises its own chunk (cv2.imwrite rounding), the clip arrives as uint8
+        from speech2lip_amd.data import to8b
+        clip8, _ = sharded.render_sharded(lambda off, cnt, out: out.copy_((_stamp(gids[off:off + cnt]) / 16).view(-1, 1, 1).expand(cnt, 2, 3)),
+                                          fpr, (2, 3), torch.device("cpu"), n_chunks=nc, quantize=to8b)
+        ok = ok and clip8.dtype == torch.uint8 and torch.equal(clip8, to8b((expect / 16).contiguous()))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
