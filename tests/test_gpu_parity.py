@@ -721,3 +721,24 @@ def test_to8b_matches_cv2_conversion(dev):
     assert got.dtype == torch.uint8 and torch.equal(got.cpu(), ref)
     assert ref[4099:4103].tolist() == [0, 2, 2, 128]
     assert torch.equal(s2l.to8b(x), ref)
+
+
+def test_infer_clip_script_end_to_end(dev, tmp_path):
+    """tools/infer_clip.py: YAML config + dataset folder in, numbered 8-bit frames out (the shape of inference.py:78-178)."""
+    import subprocess
+    import sys
+    import yaml
+    from PIL import Image
+    from tests.test_data_reader import _write_folder
+    folder = _write_folder(str(tmp_path), n=24, fh=40, fw=48, lh=10, lw=12, name="someone_face_crop_lip")
+    cfg = s2l.may_config(10, 12, folder)
+    cfg["training"]["out_dir"] = str(tmp_path / "run")
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "infer_clip.py"), "--config", str(tmp_path / "cfg.yaml"),
+                        "--default", str(tmp_path / "cfg.yaml"), "--batch", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = tmp_path / "run" / "test_post"
+    names = sorted(os.listdir(out))
+    assert names == ["00001.jpg", "00002.jpg", "00003.jpg"]          # val split of 24 windows: the last 10 %
+    assert np.asarray(Image.open(out / names[0])).shape == (40, 48, 3)
