@@ -17,6 +17,9 @@
 #ifndef S2L_KDEPTH
 #define S2L_KDEPTH 3
 #endif
+#ifndef S2L_ALWAYS_X
+#define S2L_ALWAYS_X 0   // experiment: 1 copies both parts of every stage unconditionally (straight-line code, exact vmcnt scoreboard): measured neutral
+#endif
 #ifndef S2L_EXP
 #define S2L_EXP 0   // tools/ubench experiments only: 1 no tile store, 2 no masks, 4 no MFMA k-loops (results wrong)
 #endif
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
         const int s = 4 * L + q, nxt = (s + 1) & 31;
         const int nL = nxt >> 2;
         const bool nx = nL == 0 || nL == 5 || nxt == 31, nh = nL != 0;
-        stage_gload(st, a.wb + OFF_FWD + (int64_t)nxt * kStageF, tid, nx, nh);
+        stage_gload(st, a.wb + OFF_FWD + (int64_t)nxt * kStageF, tid, S2L_ALWAYS_X || nx, S2L_ALWAYS_X || nh);
         const uint16_t* wl = wbuf + (q & 1) * kStageF;
         f16v acc[2];   // blocks R = 2q, 2q + 1, initialised with the bias (feature 32R + 8a + 4hh + c <-> register 4a + c)
 #pragma unroll
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
             for (int c = 0; c < 3; ++c) a.rgb[row * 3 + c] = ao[c] + bias[2048 + c];
           }
         }
-        stage_lstore(st, wbuf + ((q + 1) & 1) * kStageF, tid, nx, nh);
+        stage_lstore(st, wbuf + ((q + 1) & 1) * kStageF, tid, S2L_ALWAYS_X || nx, S2L_ALWAYS_X || nh);
         __syncthreads();
       }
 #pragma unroll
