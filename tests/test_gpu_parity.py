@@ -690,7 +690,7 @@ def test_bf16_wgrad_matches_tiles(dev):
     assert float((dbo.cpu().double() - drgb.cpu().double().sum(0)).abs().max()) <= 1e-6 * float(drgb.abs().sum(0).max())
 
 
-@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3), (96, 96, 2)])   # 96x96x2 = 288 row tiles: workgroups loop over tiles
 def test_bf16_train_step_vs_fp32(dev, h, w, B):
     """BASELINE config 5 in its named precision: loss, prediction and all 42 gradients of the bf16 step against the fp32
     parity-mode step (itself pinned to the oracle's autograd and the reference's golden gradients).  bf16 carries 8
@@ -742,3 +742,40 @@ def test_infer_clip_script_end_to_end(dev, tmp_path):
     names = sorted(os.listdir(out))
     assert names == ["00001.jpg", "00002.jpg", "00003.jpg"]          # val split of 24 windows: the last 10 %
     assert np.asarray(Image.open(out / names[0])).shape == (40, 48, 3)
+
+
+def test_bf16_kernels_multi_tile_workgroups(dev):
+    """More row tiles than CUs (persistent workgroups take several tiles, the weight stages wrap around): forward and backward
+    against the step-wise emulation on a sample of rows from every part of the batch."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    from tests import bf16_util as U
+    m, lib, x, N = _bf16_inputs(dev, 96, 96, 2)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    assert Np // 256 > 256
+    hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    dzT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+    rgb, dxa = torch.empty(N, 3, device=dev), torch.empty(N, 64, device=dev)
+    pb, pf = m.packed_weights_bf16(), m.packed_weights()
+    drgb = torch.randn(N, 3, generator=torch.Generator().manual_seed(3)) * 1e-3
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb.to(dev)), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()), "bwd")
+    # sample 64-row tiles: first, one in the middle handled as a second tile of some workgroup, the last
+    tiles = [0, 5, 256 * 4 + 7, 270 * 4 + 1, Np // 64 - 1]
+    rows = torch.cat([torch.arange(t * 64, t * 64 + 64) for t in tiles])
+    h_d = U.tiles_to_rows(hT, 8, Np)[:, rows]
+    g_d = U.tiles_to_rows(dzT, 8, Np)[:, rows]
+    mk = U.masks_to_rows(masks, Np)[:, rows]
+    sd_ = O.to_sd(W.make_state_dict(0, "he"))
+    fold = U.folded_from_blob(pf)
+    with torch.no_grad():
+        h_tf = U.forward_teacher_forced(sd_, x[rows.to(dev)].cpu(), h_d, fold)
+        g_e, dxa_e = U.backward_teacher_forced(sd_, drgb[rows], mk, g_d, fold)
+    for L in range(8):
+        U.assert_bf16_close(h_d[L], h_tf[L], f"h{L}")
+        d = (g_d[L] - g_e[L]).abs()
+        scale = float(g_e[L].abs().max())
+        assert bool((d <= 2.0 ** -7 * g_e[L].abs() * 1.01 + 1e-6 * scale).all()), (L, float(d.max()), scale)
+    assert bool((mk == (h_d > 0)).all())
+    assert float((dxa.cpu()[rows] - dxa_e).abs().max()) <= 1e-5 * float(dxa_e.abs().max())
