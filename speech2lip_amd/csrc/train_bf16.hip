@@ -322,7 +322,9 @@ struct BwdArgs {
 
 __device__ __forceinline__ float mask_sel(float v, uint64_t m) {
   float o;
-  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
+  // s_nop: the mask reaches its SGPR pair through v_readlane (a VALU write); gfx940+ wants two wait states before a VALU
+  // reads it, and the hazard recogniser does not look inside inline asm
+  asm("s_nop 1\n\tv_cndmask_b32 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
   return o;
 }
 
