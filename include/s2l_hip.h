@@ -255,8 +255,8 @@ int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t
  * (src/face_simple/training.py:158-251, 605-619) through TalkingFace.rgb_forward (tf_nerf.py:225-285).
  * s2l_pack_bf16: bf16 operand images from the state-dict tensors (table as s2l_pack_weights) and the fp32 blob of
  * s2l_pack_weights (folded first/skip matrices, biases); packed_bf16: s2l_bf16_packed_halves() uint16.
- * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/64][256][64]
- * ([layer][tile of 64 rows][feature][row]); masks: uint64 [8][Np/64][256] ReLU ballots; x: fp32 [N,128] embedded rows
+ * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/32][8][64][16]
+ * ([layer][group of 32 rows][32-feature block][lane n + 32 hh][4a + c] = feature 32R + 8a + 4hh + c of row n); masks: uint64 [8][Np/64][256] ReLU ballots; x: fp32 [N,128] embedded rows
  * (s2l_ensemble_rows); rgb, drgb: fp32 [N,3]; dxa: fp32 [N,64]. */
 int64_t s2l_bf16_packed_halves(void);
 int64_t s2l_bf16_rows_padded(int64_t n_rows);
@@ -267,7 +267,7 @@ int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32,
 int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
                             float* dxa, int64_t n_rows, s2l_stream_t stream);
 /* Weight gradients from the tiles: dw [256,k_in] = dzT_layer^T . inT (k_in = 256: inT = the hT layer below; k_in = 128:
- * inT = the embedded rows as tiles, s2l_rows_to_tiles_bf16), db NULL or [256] = column sums of dz; work:
+ * inT = the embedded rows in the same image layout, s2l_rows_to_tiles_bf16), db NULL or [256] = column sums of dz; work:
  * s2l_wgrad_bf16_work_floats() floats (per-workgroup partial sums, reduced in a fixed order).  s2l_out_grad_bf16:
  * dwout [3,256] = drgb^T h7, dbout [3] = column sums of drgb (output_linear). */
 int64_t s2l_wgrad_bf16_work_floats(void);

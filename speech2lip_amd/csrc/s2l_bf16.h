@@ -41,11 +41,19 @@ __host__ __device__ constexpr bool bwd_stage_is_audio(int u) { return u == 8 || 
 __host__ __device__ constexpr int bwd_stage_layer(int u) { return u < 8 ? 7 - (u >> 2) : 5 - ((u - 9) >> 2); }
 __host__ __device__ constexpr int bwd_stage_quarter(int u) { return u < 8 ? (u & 3) : ((u - 9) & 3); }
 
-// Activation / gradient tiles for the weight-gradient GEMMs: [layer][tile of 64 rows][feature][64 rows] bf16, i.e. every
-// feature's 64 rows are 128 contiguous bytes (the reduction index of dW = dz^T h runs along them).
-constexpr int kTileRows = 64;
+// Saved activations / gradients ("images"): exactly what a lane holds after a 32-feature block's epilogue, so the forward
+// and backward kernels store them with two 16-byte stores per lane and no transposition:
+//     image[row group of 32][block R = F/32][lane = n + 32 hh][16 bf16],  element 4a + c  =  feature 32R + 8a + 4hh + c
+// of row n.  For a fixed hh this is a row-major [32 rows][16 features] bf16 matrix with 32-byte rows whose 8-byte groups
+// are 4 consecutive features -- the shape ds_read_b64_tr_b16 turns into "8 consecutive rows of one feature per lane",
+// which is what BOTH operands of the weight-gradient GEMM dW = dz^T h need (the reduction runs over rows).
+constexpr int kGroupRows = 32;
 constexpr int kWgRows = 256;       // rows per workgroup tile of the forward / backward kernels
-// ReLU masks: uint64 [layer 8][tile64][R 8][32]: entry g*16 + r = ballot of (h > 0) for accumulator register r of group g
+__host__ __device__ constexpr int64_t image_off(int64_t group, int n_blocks, int R, int lane) {   // in halves
+  return ((group * n_blocks + R) * 64 + lane) * 16;
+}
+// ReLU masks: uint64 [layer 8][64-row tile][R 8][32]: entry 16*g + r = ballot of (h > 0) over the lanes of the wave that owns
+// rows 32g..32g+31 of the tile, for accumulator register r
 
 }  // namespace b16
 }  // namespace s2l

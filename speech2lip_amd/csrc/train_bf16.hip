@@ -8,9 +8,9 @@
 // = two B operands per A read).  A layer's weights pass through LDS in four 2-block stages; the next stage's global loads
 // are in flight in registers while the current one computes (one barrier per stage).  Activations stay in registers
 // between layers (kfeat16 trick); per 32-feature block the epilogue adds bias, applies ReLU, records the ReLU bit masks
-// (64-bit ballots, 32 B per row per layer) and converts to bf16 twice: into the next layer's B operands and, through a
-// 4.5 KiB per-wave LDS transposer, into the [feature][64 rows] tiles the weight-gradient GEMM consumes, stored with
-// full-line 1 KiB wave stores.
+// (64-bit ballots, 32 B per row per layer) and converts to bf16; the eight dwords a lane then holds ARE its next-layer B
+// operands, and they are stored as they are (two 16-byte stores per lane, 2 KiB contiguous per wave and block): the
+// weight-gradient GEMM reads these row-major images back with the LDS transpose read (ds_read_b64_tr_b16).
 #include "s2l_common.h"
 #include "s2l_bf16.h"
 
@@ -120,11 +120,8 @@ __global__ void pack_bf16_kernel(Tab16 tab, const float* __restrict__ pf, uint16
 // Eight waves per workgroup, two per SIMD (<= 256 registers each): while one wave of a SIMD runs the VALU epilogue of a
 // block the other one issues MFMAs.  Wave w owns rows 32 w .. 32 w + 31 of the workgroup's 256; waves 2i, 2i+1 share the
 // 64-row tile 4 tile + i (each writes its 64-byte half of every 128-byte feature row).
-constexpr int kTrStride = 80;                   // bytes per feature row of the per-wave transposer: 32 rows bf16 + 16 pad
-constexpr int kTrBytes = 32 * kTrStride;
-constexpr int kWaves = 8;
 constexpr int kLdsW = 2 * kStageF * 2;          // two stage buffers, bytes
-constexpr int kLdsFwd = kLdsW + kWaves * kTrBytes + (8 * 256 + 4) * 4;
+constexpr int kLdsFwd = kLdsW + (8 * 256 + 4) * 4;
 
 struct Stage {
   u4 x[2], h[4];   // 16 B pieces of the X part (16 KiB) and the H part (32 KiB), piece = tid + 512 k
@@ -152,31 +149,11 @@ __device__ __forceinline__ void stage_lstore(const Stage& st, uint16_t* dst, int
   }
 }
 
-// Write one finished 32-feature block of this wave's 32 rows (bf16 pairs) through the wave's transposer into its half of
-// the [feature][64 rows] tile: vals[a][0] = features (8a+4hh+0, +1), vals[a][1] = (+2, +3) of row n; gdst = tile + 32 R
-// feature rows + this wave's 64-byte half.
-__device__ __forceinline__ void tile_store(const uint32_t (&vals)[4][2], char* tr, uint16_t* gdst, int lane) {
-  const int n = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const int fl = 8 * a + 4 * hh + 2 * d;
-      uint16_t* p = reinterpret_cast<uint16_t*>(tr + fl * kTrStride) + n;
-      p[0] = (uint16_t)(vals[a][d] & 0xffffu);
-      p[kTrStride / 2] = (uint16_t)(vals[a][d] >> 16);
-    }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  char* g = reinterpret_cast<char*>(gdst);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int p = lane + 64 * k;
-    *reinterpret_cast<u4*>(g + (p >> 2) * (kTileRows * 2) + (p & 3) * 16) =
-        *reinterpret_cast<const u4*>(tr + (p >> 2) * kTrStride + (p & 3) * 16);
-  }
-  __builtin_amdgcn_wave_barrier();
+// Store one finished 32-feature block of this wave's 32 rows: the lane's eight bf16 pairs, as held (s2l_bf16.h image).
+__device__ __forceinline__ void image_store(const uint32_t (&vals)[4][2], uint16_t* gdst, int lane) {
+  u4* g = reinterpret_cast<u4*>(gdst) + 2 * lane;
+  g[0] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
+  g[1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
 }
 
 struct FwdArgs {
@@ -196,8 +173,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hh = lane >> 5, g = wave & 1;
-  char* tr = smem + kLdsW + wave * kTrBytes;
-  float* bias = reinterpret_cast<float*>(smem + kLdsW + kWaves * kTrBytes);
+  float* bias = reinterpret_cast<float*>(smem + kLdsW);
   for (int i = tid; i < 8 * 256; i += 512) {
     const int L = i >> 8, f = i & 255;
     bias[i] = L == 0 ? a.pf[OFF_BG0 + f] : L == 5 ? a.pf[OFF_BG5 + f] : a.pf[OFF_BIAS + (L - 1) * 256 + f];
@@ -214,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
-    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1);
+    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1), group = (int64_t)tile * 8 + wave;
     {
       const bool ok = row < a.n_rows;
       const f4* xr = reinterpret_cast<const f4*>(a.x + (ok ? row : 0) * kGenK + 8 * hh);
@@ -278,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
           bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
           bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
           if (!(S2L_EXP & 1))
-            tile_store(vals, tr, a.hT + L * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
+            image_store(vals, a.hT + L * a.layer_stride + image_off(group, 8, R, 0), lane);
         }
         if (!(S2L_EXP & 2))   // uint64 index R*32 + 16g + r  ->  dword index 2*(...) + half
           reinterpret_cast<int*>(a.masks + L * a.mask_layer_stride + tile64 * 256 + (2 * q + (lane >> 5)) * 32 + 16 * g)[lane & 31] = mword;
@@ -308,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
 // d audio = G5[:, audio]^T g_5 + G0[:, audio]^T g_0.  Every g_l is stored as a [feature][64 rows] bf16 tile (dzT) for the
 // weight-gradient GEMMs; the masks are the forward's ballots, read back as wave-uniform SGPR pairs (one v_cndmask per value).
 constexpr int kLdsBwdW = 2 * kStageB * 2;
-constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2 + kWaves * kTrBytes;
+constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2;
 
 struct BwdArgs {
   const uint16_t* wb;
@@ -355,7 +331,6 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hh = lane >> 5, g = wave & 1;
   u4* u0 = reinterpret_cast<u4*>(smem + kLdsBwdW);
-  char* tr = smem + kLdsBwdW + 8 * kSlabU0 * 2 + wave * kTrBytes;
   if (tid < 8 * 64) u0[tid] = reinterpret_cast<const u4*>(a.wb + OFF_BWD_U0)[tid];
 
   u4 st[4];
@@ -376,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
   u4 bcur[16], bnext[16];
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
-    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1);
+    const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1), group = (int64_t)tile * 8 + wave;
     // drgb as a K = 16 B operand: k = 8 hh + j, k < 3 used
     u4 b0;
     {
@@ -395,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
       mask_block(acc, a.masks + 7 * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
       bcur[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
       bcur[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
-      tile_store(vals, tr, a.dzT + 7 * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
+      image_store(vals, a.dzT + 7 * a.layer_stride + image_off(group, 8, R, 0), lane);
     }
 
     int u = 0;
@@ -447,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
           mask_block(acc[which], a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
           bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
           bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
-          tile_store(vals, tr, a.dzT + (l - 1) * a.layer_stride + tile64 * (256 * kTileRows) + (32 * R) * kTileRows + 32 * g, lane);
+          image_store(vals, a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, R, 0), lane);
         }
         lstore(nxt);
         __syncthreads();
@@ -462,24 +437,55 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
 }
 
 // ---- weight gradients ---------------------------------------------------------------------------------------------------------
-// dW[m][k] = sum_rows dz[row][m] in[row][k] from the [feature][64 rows] tiles: both MFMA operands want "8 consecutive rows of
-// one feature" per lane, which is 16 contiguous bytes of a tile.  A workgroup streams 64-row tile pairs (dz: 32 KiB, in: 32 or
-// 16 KiB) through a padded LDS image (144-byte feature rows: conflict-free ds_read_b128), double-buffered through registers;
-// its 4 waves own 128 x (K/2) of the 256 x K result each.  The kernel is HBM-bound by construction (64 KiB per 64 MFMAs per
-// wave); partial sums per workgroup are reduced in a fixed order by wgrad_reduce_kernel (deterministic).  The bias gradient
-// (column sums of dz) rides along on the A operands.
+// dW[m][k] = sum_rows dz[row][m] in[row][k]: both MFMA operands want "8 consecutive rows of one feature" per lane.  The images
+// are row-major per (block, hh): [32 rows][16 features], 32-byte rows; ds_read_b64_tr_b16 reads a [4 rows][16 features] block
+// per 16-lane group (lane i passes the address of row i>>2, feature group i&3 and receives column i: that feature's 4 rows),
+// so two of them give a lane its 8 rows.  A 16-lane group G = lane>>4 serves operand rows mu = 16 (G&1) + i of k-half G>>1;
+// it reads the hh = G&1 half of the block, hence operand row mu is feature fperm(mu) of the block -- a fixed permutation that
+// is undone when the result is stored.  A workgroup streams 64 rows (two row groups: dz 32 KiB, in 32 or 16 KiB) per step
+// through LDS, double-buffered through registers (halves padded to 1152 B so the two groups of an LDS cycle hit different
+// banks); its 4 waves own 128 x (K/2) of the 256 x K result each.  The kernel is HBM-bound by construction; per-workgroup
+// partial sums are reduced in a fixed order by wgrad_reduce_kernel (deterministic).  The bias gradient (column sums of dz)
+// rides along on the A operands.
 constexpr int kWgParts = 256;                      // max workgroups = partial results
-constexpr int kOpStride = 144;                     // bytes per feature row in LDS
+constexpr int kHalfBytes = 1024 + 128;             // one (block, hh) half in LDS: 32 rows x 32 B + pad
+__host__ __device__ constexpr int fperm(int mu) { return 8 * ((mu & 15) >> 2) + 4 * (mu >> 4) + (mu & 3); }
 template <int KB>
 struct WgCfg {
   static constexpr int kNB = KB / 64;              // 32-column blocks per wave
-  static constexpr int kBPieces = KB * 8 / 256;    // 16-byte pieces of the B tile per thread
-  static constexpr int kBufBytes = (256 + KB) * kOpStride;
+  static constexpr int kBBlocks = KB / 32;         // blocks of the B image
+  static constexpr int kBPieces = KB * 8 / 256;    // 16-byte pieces of the B chunk per thread
+  static constexpr int kBufBytes = 2 * (8 + kBBlocks) * 2 * kHalfBytes;   // two row groups of A and B
   static constexpr int kLds = 2 * kBufBytes;
 };
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+// 8 rows (n0..n0+7) of this lane's operand feature: two transpose reads 4 rows apart (128 bytes).  The compiler does not
+// track inline-asm LDS reads: the results may only be touched after tr_wait(), which names them as in/out operands so that
+// no use can be scheduled above the s_waitcnt.
+struct TrPair {
+  u2 lo, hi;
+};
+__device__ __forceinline__ void tr_read8(TrPair& t, uint32_t lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128" : "=&v"(t.lo), "=&v"(t.hi) : "v"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(TrPair (&t)[N]) {
+  if constexpr (N == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0].lo), "+v"(t[0].hi), "+v"(t[1].lo), "+v"(t[1].hi), "+v"(t[2].lo), "+v"(t[2].hi), "+v"(t[3].lo), "+v"(t[3].hi),
+                   "+v"(t[4].lo), "+v"(t[4].hi), "+v"(t[5].lo), "+v"(t[5].hi), "+v"(t[6].lo), "+v"(t[6].hi), "+v"(t[7].lo), "+v"(t[7].hi)
+                 :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0].lo), "+v"(t[0].hi), "+v"(t[1].lo), "+v"(t[1].hi), "+v"(t[2].lo), "+v"(t[2].hi), "+v"(t[3].lo), "+v"(t[3].hi),
+                   "+v"(t[4].lo), "+v"(t[4].hi), "+v"(t[5].lo), "+v"(t[5].hi)
+                 :: "memory");
+}
+__device__ __forceinline__ u4 tr_u4(const TrPair& t) { return u4{t.lo[0], t.lo[1], t.hi[0], t.hi[1]}; }
 
 template <int KB>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __restrict__ dzT, const uint16_t* __restrict__ inT,
@@ -490,9 +496,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1, n = lane & 31, hh = lane >> 5;
   u4 sa[8], sb[C::kBPieces];
+  // a 64-row chunk of an image with NBLK blocks: piece p = ((rg * NBLK + R) * 64 + L) * 2 + h16 (linear in memory)
+  auto lds_of = [](int p, int nblk, int base_half) {
+    const int h16 = p & 1, L = (p >> 1) & 63, rR = p >> 7;   // rR = rg * nblk + R
+    return (base_half + rR * 2 + (L >> 5)) * kHalfBytes + (L & 31) * 32 + h16 * 16;
+  };
   auto gload = [&](int tile) {
-    const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 256 * kTileRows) + tid;
-    const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * KB * kTileRows) + tid;
+    const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 64 * 256) + tid;
+    const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * 64 * KB) + tid;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sa[k] = pa[256 * k];
 #pragma unroll
@@ -501,15 +512,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   auto lstore = [&](int buf) {
     char* base = smem + buf * C::kBufBytes;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int p = tid + 256 * k;
-      *reinterpret_cast<u4*>(base + (p >> 3) * kOpStride + (p & 7) * 16) = sa[k];
-    }
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<u4*>(base + lds_of(tid + 256 * k, 8, 0)) = sa[k];
 #pragma unroll
-    for (int k = 0; k < C::kBPieces; ++k) {
-      const int p = tid + 256 * k;
-      *reinterpret_cast<u4*>(base + 256 * kOpStride + (p >> 3) * kOpStride + (p & 7) * 16) = sb[k];
-    }
+    for (int k = 0; k < C::kBPieces; ++k) *reinterpret_cast<u4*>(base + lds_of(tid + 256 * k, C::kBBlocks, 2 * 8 * 2)) = sb[k];
   };
   f16v acc[4][C::kNB];
 #pragma unroll
@@ -519,6 +524,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // per-lane byte offset inside a (row group, block) of the LDS image: 16-lane group G reads half G&1, rows 8 (G>>1) + (i>>2)
+  const int i16 = lane & 15, G = lane >> 4;
+  const uint32_t lane_off = (uint32_t)((G & 1) * kHalfBytes + (8 * (G >> 1) + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   int tile = blockIdx.x;
   if (tile < n_tiles) {
@@ -530,22 +540,23 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   for (; tile < n_tiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
     if (nxt < n_tiles) gload(nxt);
-    const char* abase = smem + buf * C::kBufBytes + (128 * wm + n) * kOpStride + 16 * hh;
-    const char* bbase = smem + buf * C::kBufBytes + (256 + (KB / 2) * wn + n) * kOpStride + 16 * hh;
-    u4 av[4], bv[C::kNB], an[4], bn[C::kNB];
+    const uint32_t bb = lds0 + buf * C::kBufBytes + lane_off;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const u4*>(abase + 32 * i * kOpStride);
+    for (int s = 0; s < 4; ++s) {   // k-step: row group s>>1, rows 16 (s&1) .. +15
+      const int rg = s >> 1;
+      const uint32_t row_off = (uint32_t)(16 * (s & 1) * 32);
+      TrPair tp[4 + C::kNB];
 #pragma unroll
-    for (int j = 0; j < C::kNB; ++j) bv[j] = *reinterpret_cast<const u4*>(bbase + 32 * j * kOpStride);
+      for (int i = 0; i < 4; ++i) tr_read8(tp[i], bb + ((rg * 8 + 4 * wm + i) * 2) * kHalfBytes + row_off);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
+      for (int j = 0; j < C::kNB; ++j)
+        tr_read8(tp[4 + j], bb + (2 * 8 * 2 + (rg * C::kBBlocks + C::kNB * wn + j) * 2) * kHalfBytes + row_off);
+      tr_wait(tp);
+      u4 av[4], bv[C::kNB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) an[i] = *reinterpret_cast<const u4*>(abase + 32 * i * kOpStride + 32 * (s + 1));
+      for (int i = 0; i < 4; ++i) av[i] = tr_u4(tp[i]);
 #pragma unroll
-        for (int j = 0; j < C::kNB; ++j) bn[j] = *reinterpret_cast<const u4*>(bbase + 32 * j * kOpStride + 32 * (s + 1));
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < C::kNB; ++j) bv[j] = tr_u4(tp[4 + j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -556,16 +567,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
 #pragma unroll
           for (int d = 0; d < 4; ++d) bsum[i] += bf_lo(av[i][d]) + bf_hi(av[i][d]);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = an[i];
-#pragma unroll
-      for (int j = 0; j < C::kNB; ++j) bv[j] = bn[j];
     }
     if (nxt < n_tiles) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-  // partial result of this workgroup: D[m = 8(r>>2) + 4hh + (r&3)][col n] of block (i, j)
+  // partial result of this workgroup: D[mu = 8(r>>2) + 4hh + (r&3)][nu = n] of block (i, j); operand rows are permuted features
   float* po = part + (int64_t)blockIdx.x * 256 * KB;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -573,14 +580,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
     for (int j = 0; j < C::kNB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = 128 * wm + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3);
-        po[m * KB + (KB / 2) * wn + 32 * j + n] = acc[i][j][r];
+        const int m = 128 * wm + 32 * i + fperm(8 * (r >> 2) + 4 * hh + (r & 3));
+        po[m * KB + (KB / 2) * wn + 32 * j + fperm(n)] = acc[i][j][r];
       }
   if (wn == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float t = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (hh == 0) bpart[blockIdx.x * 256 + 128 * wm + 32 * i + n] = t;
+      if (hh == 0) bpart[blockIdx.x * 256 + 128 * wm + 32 * i + fperm(n)] = t;
     }
   }
 }
@@ -602,57 +609,65 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (w == 0 && i < n) *reinterpret_cast<f4*>(out + i) = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
 }
 
-// x fp32 [N,K] -> bf16 tiles [tile64][K][64] (K = 128: the embedded rows, for dG0 / dG5).  One block per tile.
-__global__ __launch_bounds__(256) void rows_to_tiles_kernel(const float* __restrict__ x, uint16_t* __restrict__ xT, int K,
-                                                            int64_t n_rows) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * kTileRows;
+// x fp32 [N,K] -> bf16 image (K/32 blocks; K = 128: the embedded rows, for dG0 / dG5).  thread = (row, 4 features).
+__global__ __launch_bounds__(256) void rows_to_image_kernel(const float* __restrict__ x, uint16_t* __restrict__ xT, int K,
+                                                            int64_t n_rows, int64_t n_padded) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int kq = K / 4;
-  for (int i = tid; i < kTileRows * kq; i += 256) {
-    const int row = i / kq, c4 = i - row * kq;
-    f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    if (r0 + row < n_rows) v = *reinterpret_cast<const f4*>(x + (r0 + row) * K + 4 * c4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint16_t*>(smem + (4 * c4 + c) * kOpStride + 2 * row) = bf1(v[c]);
-  }
-  __syncthreads();
-  u4* dst = reinterpret_cast<u4*>(xT + (int64_t)blockIdx.x * K * kTileRows);
-  for (int p = tid; p < K * 8; p += 256) dst[p] = *reinterpret_cast<const u4*>(smem + (p >> 3) * kOpStride + (p & 7) * 16);
+  const int64_t row = t / kq;
+  if (row >= n_padded) return;
+  const int f = (int)(t - row * kq) * 4;
+  f4 v = f4{0.f, 0.f, 0.f, 0.f};
+  if (row < n_rows) v = *reinterpret_cast<const f4*>(x + row * K + f);
+  const int R = f >> 5, a4 = (f & 31) >> 3, hh = (f >> 2) & 1;
+  uint16_t* dst = xT + image_off(row >> 5, K / 32, R, (int)(row & 31) + 32 * hh) + 4 * a4;
+  *reinterpret_cast<u2*>(dst) = u2{pk2(v[0], v[1]), pk2(v[2], v[3])};
 }
 
-// output layer: dWout[c][k] = sum_rows drgb[row][c] h7[row][k], dbout[c] = sum_rows drgb[row][c].  thread = feature k.
+// output layer: dWout[c][f] = sum_rows drgb[row][c] h7[row][f], dbout[c] = sum_rows drgb[row][c].  thread = (4-feature group,
+// quarter of the rows of a row group); the four row quarters are combined through LDS at the end.
 __global__ __launch_bounds__(256) void out_grad_kernel(const float* __restrict__ drgb, const uint16_t* __restrict__ h7T,
-                                                       float* __restrict__ part, int n_tiles, int64_t n_rows) {
-  __shared__ float d[kTileRows * 3];
-  const int k = threadIdx.x;
-  float s[3] = {0.f, 0.f, 0.f}, sb = 0.f;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+                                                       float* __restrict__ part, int n_groups, int64_t n_rows) {
+  __shared__ float d[kGroupRows * 3];
+  __shared__ float red[4][64][12];
+  const int gq = threadIdx.x & 63, rs = threadIdx.x >> 6;    // feature group 4 gq .. +3, rows 8 rs .. +7
+  const int f = 4 * gq, R = f >> 5, a4 = (f & 31) >> 3, hh = (f >> 2) & 1;
+  float s[4][3] = {};
+  float sb = 0.f;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     __syncthreads();
-    if (k < kTileRows * 3) {
-      const int64_t idx = (int64_t)tile * kTileRows * 3 + k;
-      d[k] = idx < n_rows * 3 ? drgb[idx] : 0.f;
+    if (threadIdx.x < kGroupRows * 3) {
+      const int64_t idx = (int64_t)grp * kGroupRows * 3 + threadIdx.x;
+      d[threadIdx.x] = idx < n_rows * 3 ? drgb[idx] : 0.f;
     }
     __syncthreads();
-    const u4* hp = reinterpret_cast<const u4*>(h7T + ((int64_t)tile * 256 + k) * kTileRows);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const u4 w = hp[q];
+    for (int r = 0; r < 8; ++r) {
+      const int row = 8 * rs + r;
+      const u2 w = *reinterpret_cast<const u2*>(h7T + image_off(grp, 8, R, row + 32 * hh) + 4 * a4);
+      const float h[4] = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = 8 * q + 2 * e;
-        const float lo = bf_lo(w[e]), hi = bf_hi(w[e]);
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s[c] = fmaf(d[(row + 1) * 3 + c], hi, fmaf(d[row * 3 + c], lo, s[c]));
-      }
+        for (int c = 0; c < 3; ++c) s[e][c] = fmaf(d[row * 3 + c], h[e], s[e][c]);
     }
-    if (k < 3)
-      for (int row = 0; row < kTileRows; ++row) sb += d[row * 3 + k];
+    if (threadIdx.x < 3)
+      for (int row = 0; row < kGroupRows; ++row) sb += d[row * 3 + threadIdx.x];
   }
-  float* po = part + (int64_t)blockIdx.x * (3 * 256 + 4);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) po[c * 256 + k] = s[c];
-  if (k < 4) po[768 + k] = k < 3 ? sb : 0.f;
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[rs][gq][e * 3 + c] = s[e][c];
+  __syncthreads();
+  float* po = part + (int64_t)blockIdx.x * (3 * 256 + 4);
+  if (rs == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        po[c * 256 + f + e] = ((red[0][gq][e * 3 + c] + red[1][gq][e * 3 + c]) + red[2][gq][e * 3 + c]) + red[3][gq][e * 3 + c];
+  }
+  if (threadIdx.x < 4) po[768 + threadIdx.x] = threadIdx.x < 3 ? sb : 0.f;
 }
 
 }  // namespace b16
@@ -747,7 +762,7 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
   if (!dzT || !inT || !work || !dw) return S2L_E_NULL;
   if (misaligned16(dzT) || misaligned16(inT) || misaligned16(work) || misaligned16(dw)) return S2L_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
+  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / 64);
   const int parts = n_tiles < kWgParts ? n_tiles : kWgParts;
   float* bpart = work + (int64_t)kWgParts * 256 * 256;
   static bool attr_set[64][2];
@@ -773,12 +788,13 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
 }
 
 extern "C" int s2l_rows_to_tiles_bf16(const float* x, int k, uint16_t* xT, int64_t n_rows, s2l_stream_t stream) {
-  if (n_rows <= 0 || k < 4 || k > 256 || (k & 3)) return S2L_E_SIZE;
+  if (n_rows <= 0 || k < 32 || k > 256 || (k & 31)) return S2L_E_SIZE;
   if (!x || !xT) return S2L_E_NULL;
   if (misaligned16(x) || misaligned16(xT)) return S2L_E_ALIGN;
-  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
-  hipLaunchKernelGGL(rows_to_tiles_kernel, dim3(n_tiles), dim3(256), k * kOpStride, static_cast<hipStream_t>(stream), x, xT, k,
-                     n_rows);
+  const int64_t np = s2l_bf16_rows_padded(n_rows);
+  const int64_t threads = np * (k / 4);
+  hipLaunchKernelGGL(rows_to_image_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, xT,
+                     k, n_rows, np);
   return (int)hipGetLastError();
 }
 
@@ -788,9 +804,9 @@ extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* 
   if (!drgb || !h7T || !work || !dwout || !dbout) return S2L_E_NULL;
   if (misaligned16(h7T) || misaligned16(work) || misaligned16(dwout)) return S2L_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / kTileRows);
-  const int parts = n_tiles < kWgParts ? n_tiles : kWgParts;
-  hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_tiles, n_rows);
+  const int n_groups = (int)(s2l_bf16_rows_padded(n_rows) / kGroupRows);
+  const int parts = n_groups < kWgParts ? n_groups : kWgParts;
+  hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_groups, n_rows);
   // parts x [772] -> [768] + [4]: reduce into a scratch row behind the partials, then split
   float* sum = work + (int64_t)kWgParts * 772;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts);

@@ -8,10 +8,13 @@ def bf(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def tiles_to_rows(tiles_i16: torch.Tensor, n_layers: int, np_rows: int, feats: int = 256) -> torch.Tensor:
-    """int16 view of bf16 [L][np/64][feats][64] -> fp32 [L][np][feats]."""
-    t = tiles_i16.cpu().view(torch.bfloat16).to(torch.float32).reshape(n_layers, np_rows // 64, feats, 64)
-    return t.permute(0, 1, 3, 2).reshape(n_layers, np_rows, feats)
+def tiles_to_rows(img_i16: torch.Tensor, n_layers: int, np_rows: int, feats: int = 256) -> torch.Tensor:
+    """int16 view of the bf16 image [L][np/32][feats/32][lane = n + 32 hh][4a + c] (feature 32R + 8a + 4hh + c of row n,
+    csrc/s2l_bf16.h) -> fp32 [L][np][feats]."""
+    nb = feats // 32
+    t = img_i16.cpu().view(torch.bfloat16).to(torch.float32).reshape(n_layers, np_rows // 32, nb, 2, 32, 4, 4)   # L,G,R,hh,n,a,c
+    t = t.permute(0, 1, 4, 2, 5, 3, 6)                                                                           # L,G,n,R,a,hh,c
+    return t.reshape(n_layers, np_rows, feats)
 
 
 def masks_to_rows(masks_i64: torch.Tensor, np_rows: int) -> torch.Tensor:
