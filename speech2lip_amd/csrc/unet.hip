@@ -91,37 +91,57 @@ __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float 
   for (int i = tid; i < 4; i += nt) packed[kUnetOutB + i] = i < 3 ? t.outb[i] : 0.f;
 }
 
-// ---- first conv: 3 -> 64, direct (0.5 % of the FLOPs) -------------------------------------------------
-// thread = (pixel, 4 output channels); block = 16 pixels x 16 channel quads
+// ---- first conv: 3 -> 64 on MFMA (0.5 % of the FLOPs, but 64 MB of output per frame: write-bound) -----------------------
+// D[co][pixel] = sum_k W[co][k] in[k][pixel], k = c*9 + tap (27, zero-padded to 28 = 7 k-steps of v_mfma_f32_16x16x4_f32): the
+// same fma chain, in the same order, as a scalar loop over k.  A wave owns 16 consecutive pixels per iteration: lane
+// (q = lane>>4, px = lane&15) gathers the 7 inputs k = 4j + q of its pixel (28 loads per pixel instead of 27 per output-channel
+// quad), the 28 weight operands per lane stay in registers, and each lane stores 4 x 16 bytes (4 consecutive channels per M-block).
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int H, int W) {
-  __shared__ float ws[64 * 27];
-  for (int i = threadIdx.x; i < 64 * 27; i += 256) ws[i] = w[i];
-  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, px = lane & 15;
   const int64_t frame = blockIdx.y;
-  const int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int cq = threadIdx.x & 15;
-  if (pix >= H * W) return;
-  const int py = pix / W, px = pix - py * W;
   const float* xf = x + frame * (int64_t)H * W * 3;
-  float in[27];
+  float* yf = y + frame * (int64_t)H * W * 64;
+  // A operands: lane holds W[co = 16 mb + px][k = 4j + q]
+  float wa[4][7];
+  f4 bias[4];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-    const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+  for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) in[c * 9 + t] = ok ? xf[((int64_t)yy * W + xx) * 3 + c] : 0.f;
+    for (int j = 0; j < 7; ++j) {
+      const int k = 4 * j + q;
+      wa[mb][j] = k < 27 ? w[(16 * mb + px) * 27 + k] : 0.f;
+    }
+    bias[mb] = *reinterpret_cast<const f4*>(b + 16 * mb + 4 * q);
   }
-  f4 o;
+  const int npix = H * W;
+  for (int p0 = (blockIdx.x * 4 + wave) * 16; p0 < npix; p0 += gridDim.x * 64) {
+    const int pix = p0 + px;
+    const bool live = pix < npix;
+    const int py = live ? pix / W : 0, pxx = live ? pix - py * W : 0;
+    float in[7];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = cq * 4 + r;
-    float acc = 0.f;
+    for (int j = 0; j < 7; ++j) {
+      const int k = 4 * j + q;
+      const int c = k / 9, t = k - 9 * c;
+      const int yy = py + t / 3 - 1, xx = pxx + t % 3 - 1;
+      const bool ok = live && k < 27 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      in[j] = ok ? xf[((int64_t)yy * W + xx) * 3 + c] : 0.f;
+    }
 #pragma unroll
-    for (int k = 0; k < 27; ++k) acc = fmaf(ws[co * 27 + k], in[k], acc);
-    o[r] = fmaxf(acc + b[co], 0.f);
+    for (int mb = 0; mb < 4; ++mb) {
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mb][j], in[j], acc, 0, 0, 0);
+      if (live) {
+        f4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[mb][r], 0.f);
+        *reinterpret_cast<f4*>(yf + (int64_t)pix * 64 + 16 * mb + 4 * q) = o;
+      }
+    }
   }
-  *reinterpret_cast<f4*>(y + (frame * (int64_t)H * W + pix) * 64 + cq * 4) = o;
 }
 
 // ---- conv3x3 implicit GEMM ---------------------------------------------------------------------------
@@ -399,7 +419,7 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   float* pool2 = u1 + p2 * 64;     float* t128c = pool2 + p4 * 128; float* x3 = t128c + p4 * 128;
   int rc;
   if (F > 65535) return S2L_E_SIZE;
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 15) / 16), (unsigned)F), dim3(256), 0, st, x,
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((((int64_t)H * W + 63) / 64 + 3) / 4), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
   if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st))) return rc;
   hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((p2 * 16 + 255) / 256)), dim3(256), 0, st, x1, pool1, H, W, 64, p2 * 16);
