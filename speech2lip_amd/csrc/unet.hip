@@ -154,6 +154,7 @@ struct ConvArgs {
   const float* outw;  // FUSE_OUT: [3][64], outb [3], out3 [F,H,W,3]
   const float* outb;
   float* out3;
+  float* pool;        // or null: MaxPool2d(2) of the output, [F,H/2,W/2,cout], written by the same epilogue
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
 };
 
@@ -283,31 +284,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
       }
     }
   }
-}
-
-// ---- pooling / upsampling ------------------------------------------------------------------------------
-// MaxPool2d(2): [F,H,W,C] -> [F,H/2,W/2,C]; thread = (out pixel, channel quad)
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
-                                                      int64_t n_out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_out) return;
-  const int cq = C / 4;
-  const int c4 = (int)(i % cq);
-  int64_t p = i / cq;
-  const int Wo = W / 2, Ho = H / 2;
-  const int xo = (int)(p % Wo);
-  p /= Wo;
-  const int yo = (int)(p % Ho);
-  const int64_t f = p / Ho;
-  const float* s = x + ((f * H + 2 * yo) * (int64_t)W + 2 * xo) * C + c4 * 4;
-  const f4 a = *reinterpret_cast<const f4*>(s), b = *reinterpret_cast<const f4*>(s + C);
-  const f4 c = *reinterpret_cast<const f4*>(s + (int64_t)W * C), d = *reinterpret_cast<const f4*>(s + (int64_t)W * C + C);
-  f4 m;
+  if (!FUSE_OUT && a.pool) {
+    // MaxPool2d(2) in the same epilogue: tile rows 4*wave+g pair up as (0,1), (2,3) in registers, columns px, px^1 across lanes
+    const int H2 = a.H / 2, W2 = a.W / 2;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) m[r] = fmaxf(fmaxf(a[r], b[r]), fmaxf(c[r], d[r]));
-  *reinterpret_cast<f4*>(y + i * 4) = m;
+    for (int gp = 0; gp < 2; ++gp) {
+      const int py2 = (y0 + 4 * wave + 2 * gp) / 2, px2 = gx / 2;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        f4 m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaxf(fmaxf(acc[mb][2 * gp][r], acc[mb][2 * gp + 1][r]), 0.f);
+          m[r] = fmaxf(v, __shfl_xor(v, 1));
+        }
+        if (!(px & 1) && py2 < H2 && px2 < W2)
+          *reinterpret_cast<f4*>(a.pool + ((frame * H2 + py2) * (int64_t)W2 + px2) * a.cout + ct * 64 + mb * 16 + 4 * q) = m;
+      }
+    }
+  }
 }
 
+// ---- upsampling (MaxPool2d(2) lives in the conv epilogue) ------------------------------------------------------------------------------
 // bilinear x2, align_corners=True, then zero padding to (Ho, Wo) (SimpleUnetLight.py:57-66)
 __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int C,
                                                        int Ho, int Wo, int64_t n_out) {
@@ -343,13 +341,13 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
-                       float* out3, int H, int W, int64_t F, hipStream_t st) {
+                       float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr) {
   ConvArgs a;
   a.inA = inA; a.inB = inB; a.CA = CA; a.CB = CB;
   a.cout = kUnetConvs[layer].cout;
   a.w = packed + unet_w_off(layer);
   a.bias = packed + unet_b_off(layer);
-  a.out = out; a.out3 = out3;
+  a.out = out; a.out3 = out3; a.pool = pool;
   a.outw = packed + kUnetOutW; a.outb = packed + kUnetOutB;
   a.H = H; a.W = W;
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
@@ -421,11 +419,9 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   if (F > 65535) return S2L_E_SIZE;
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((((int64_t)H * W + 63) / 64 + 3) / 4), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
-  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st))) return rc;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((p2 * 16 + 255) / 256)), dim3(256), 0, st, x1, pool1, H, W, 64, p2 * 16);
+  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1))) return rc;   // + MaxPool2d(2)
   if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st))) return rc;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((p4 * 32 + 255) / 256)), dim3(256), 0, st, x2, pool2, H2, W2, 128, p4 * 32);
+  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2))) return rc;   // + MaxPool2d(2)
   if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st))) return rc;
   if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2,
