@@ -76,3 +76,26 @@ def test_single_process_needs_no_collective():
     clip, local = sharded.render_sharded(render, 9, (1,), torch.device("cpu"), n_chunks=4)
     assert clip.data_ptr() == local.data_ptr()
     assert torch.equal(clip.view(-1), _stamp(torch.arange(9)))
+
+
+def _grad_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = {"b.weight": torch.full((3, 4), float(rank + 1)), "a.bias": torch.arange(5.0) * (rank + 1), "c": torch.tensor([2.0 * rank])}
+        out = sharded.allreduce_grads(dict(g))
+        ok = torch.equal(out["b.weight"], torch.full((3, 4), 1.5)) and torch.equal(out["a.bias"], torch.arange(5.0) * 1.5) \
+            and torch.equal(out["c"], torch.tensor([1.0])) and out["b.weight"].shape == (3, 4)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_bucket_allreduce():
+    """Config 5 data parallelism: one flattened bucket, averaged, same result on both ranks."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
+    g = {"x": torch.ones(2)}
+    assert sharded.allreduce_grads(g) is g            # no process group: untouched
