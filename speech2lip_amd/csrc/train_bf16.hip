@@ -156,6 +156,18 @@ __device__ __forceinline__ void image_store(const uint32_t (&vals)[4][2], uint16
   g[1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
 }
 
+#ifdef S2L_TRACE16   // experiment build: per-stage phase timestamps of waves 0 and 4 of workgroup 0 (s_memtime)
+__device__ unsigned long long* g_trace16 = nullptr;
+#define T16(slot)                                                                                               \
+  do {                                                                                                          \
+    if (g_trace16 && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && tile == 0)                                  \
+      g_trace16[((threadIdx.x >> 8) * 32 + s) * 8 + (slot)] = __builtin_readcyclecounter();                     \
+  } while (0)
+extern "C" void s2l_trace16_set(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_trace16), &p, sizeof p); }
+#else
+#define T16(slot) do { } while (0)
+#endif
+
 struct FwdArgs {
   const uint16_t* wb;
   const float* pf;
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
         const int s = 4 * L + q, nxt = (s + 1) & 31;
         const int nL = nxt >> 2;
         const bool nx = nL == 0 || nL == 5 || nxt == 31, nh = nL != 0;
+        T16(0);
         stage_gload(st, a.wb + OFF_FWD + (int64_t)nxt * kStageF, tid, S2L_ALWAYS_X || nx, S2L_ALWAYS_X || nh);
         const uint16_t* wl = wbuf + (q & 1) * kStageF;
         f16v acc[2];   // blocks R = 2q, 2q + 1, initialised with the bias (feature 32R + 8a + 4hh + c <-> register 4a + c)
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
         if (use_h && !(S2L_EXP & 4))
           kloop2<16>(reinterpret_cast<const u4*>(wl + 2 * kSlabX) + lane, reinterpret_cast<const u4*>(wl + 2 * kSlabX + kSlabH) + lane,
                      bcur, acc[0], acc[1]);
+        T16(1);
         // epilogue: ReLU, masks, bf16.  The 32 ballots of the two blocks (64 dwords) are collected one dword per lane with
         // v_writelane: lane 32 which + 2 r + half holds that half of ballot r of block `which`.
         int mword = 0;
@@ -270,8 +284,11 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
             for (int c = 0; c < 3; ++c) a.rgb[row * 3 + c] = ao[c] + bias[2048 + c];
           }
         }
+        T16(2);
         stage_lstore(st, wbuf + ((q + 1) & 1) * kStageF, tid, S2L_ALWAYS_X || nx, S2L_ALWAYS_X || nh);
+        T16(3);
         __syncthreads();
+        T16(4);
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) bcur[t] = bnext[t];
