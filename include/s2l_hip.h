@@ -135,6 +135,12 @@ int s2l_ensemble_reduce(const float* pred, const float* areas, float* out, int64
 /* d pred [N,3] -> d rgb of the four taps [4N,3]. */
 int s2l_ensemble_backward(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
                           s2l_stream_t stream);
+/* The same two kernels over a whole batch of frames in one launch: frame f owns rows [4 f HW, 4 (f+1) HW) of the per-tap
+ * arrays (pred rows / drgb [F*4*HW,3], areas [F*4*HW]) and [f HW, (f+1) HW) of the per-pixel ones. */
+int s2l_ensemble_reduce_batch(const float* pred, const float* areas, float* out, int64_t n_pixels, int64_t n_frames,
+                              s2l_stream_t stream);
+int s2l_ensemble_backward_batch(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
+                                int64_t n_frames, s2l_stream_t stream);
 /* MLP on rows x [N,128] -> rgb [N,3], saving the post-ReLU activations h0..h7 in hsave [8,N,256]
  * (tf_nerf.py:252-283 with the first/skip projections folded at pack time). */
 int s2l_train_forward(const float* packed, const float* x, float* hsave, float* rgb, int64_t n_rows,
@@ -256,13 +262,18 @@ int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t
  * s2l_pack_bf16: bf16 operand images from the state-dict tensors (table as s2l_pack_weights) and the fp32 blob of
  * s2l_pack_weights (folded first/skip matrices, biases); packed_bf16: s2l_bf16_packed_halves() uint16.
  * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/32][8][64][16]
- * ([layer][group of 32 rows][32-feature block][lane n + 32 hh][4a + c] = feature 32R + 8a + 4hh + c of row n); masks: uint64 [8][Np/64][256] ReLU ballots; x: fp32 [N,128] embedded rows
- * (s2l_ensemble_rows); rgb, drgb: fp32 [N,3]; dxa: fp32 [N,64]. */
+ * ([layer][group of 32 rows][32-feature block][lane n + 32 hh][4a + c] = feature 32R + 8a + 4hh + c of row n); masks: uint64 [8][Np/64][256] ReLU ballots; xT: the embedded
+ * rows in the same image layout with 4 blocks, bf16 [Np/32][4][64][16] (s2l_ensemble_rows_bf16 for a whole batch of frames:
+ * feat [F,64], time_index int64 [F] and u01 fp32 [F] on the device, areas fp32 [4*HW*F]; or s2l_rows_to_tiles_bf16 from
+ * fp32 rows); rgb, drgb: fp32 [N,3]; dxa: fp32 [N,64]. */
 int64_t s2l_bf16_packed_halves(void);
 int64_t s2l_bf16_rows_padded(int64_t n_rows);
 int s2l_pack_bf16(const float* const* tensors_host, const float* packed_f32, uint16_t* packed_bf16,
                   s2l_stream_t stream);
-int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const float* x, uint16_t* hT,
+int s2l_ensemble_rows_bf16(const float* packed, const float* coords, const float* feat, const int64_t* time_index,
+                           const float* u01, int width, int height, uint16_t* xT, float* areas, int64_t n_pixels,
+                           int64_t n_frames, s2l_stream_t stream);
+int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const uint16_t* xT, uint16_t* hT,
                            uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream);
 int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
                             float* dxa, int64_t n_rows, s2l_stream_t stream);

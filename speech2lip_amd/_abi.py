@@ -52,6 +52,8 @@ EXPORTS = {
                                   c_void_p]),
     "s2l_ensemble_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_ensemble_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_ensemble_reduce_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_ensemble_backward_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_split_work_floats": (c_int64, [c_int64]),
@@ -81,6 +83,8 @@ EXPORTS = {
     "s2l_bf16_packed_halves": (c_int64, []),
     "s2l_bf16_rows_padded": (c_int64, [c_int64]),
     "s2l_pack_bf16": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
+    "s2l_ensemble_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                       c_int64, c_void_p]),
     "s2l_train_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_train_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_wgrad_bf16_work_floats": (c_int64, []),

@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256) void ensemble_rows_kernel(const float* __restr
 __global__ __launch_bounds__(256) void ensemble_reduce_kernel(const float* __restrict__ pred,
                                                              const float* __restrict__ areas, float* __restrict__ out,
                                                              int64_t n) {
+  // blockIdx.y = frame: frame f owns rows [4 f n, 4 (f+1) n) of pred / areas and [f n, (f+1) n) of out
+  pred += (int64_t)blockIdx.y * n * 12;
+  areas += (int64_t)blockIdx.y * n * 4;
+  out += (int64_t)blockIdx.y * n * 3;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n * 3) return;
   const int64_t p = i / 3;
@@ -104,6 +108,16 @@ extern "C" int s2l_ensemble_reduce(const float* pred, const float* areas, float*
   if (n_pixels == 0) return S2L_OK;
   if (!pred || !areas || !out) return S2L_E_NULL;
   hipLaunchKernelGGL(s2l::ensemble_reduce_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pred, areas, out, n_pixels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_reduce_batch(const float* pred, const float* areas, float* out, int64_t n_pixels, int64_t n_frames,
+                                        s2l_stream_t stream) {
+  if (n_pixels < 0 || n_frames < 0 || n_frames > 65535) return S2L_E_SIZE;
+  if (n_pixels == 0 || n_frames == 0) return S2L_OK;
+  if (!pred || !areas || !out) return S2L_E_NULL;
+  hipLaunchKernelGGL(s2l::ensemble_reduce_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256), (unsigned)n_frames), dim3(256), 0,
                      static_cast<hipStream_t>(stream), pred, areas, out, n_pixels);
   return (int)hipGetLastError();
 }

@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void small_outer_kernel(const float* __restric
 // ---- ensemble / loss elementwise ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ensemble_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ areas,
                                                           float* __restrict__ drgb, int64_t n) {
+  // blockIdx.y = frame: frame f owns rows [4 f n, 4 (f+1) n) of drgb / areas and [f n, (f+1) n) of dpred
+  dpred += (int64_t)blockIdx.y * n * 3;
+  areas += (int64_t)blockIdx.y * n * 4;
+  drgb += (int64_t)blockIdx.y * n * 12;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n * 3) return;
   const int64_t p = i / 3;
@@ -232,6 +236,16 @@ extern "C" int s2l_ensemble_backward(const float* dpred, const float* areas, flo
   if (n_pixels == 0) return S2L_OK;
   if (!dpred || !areas || !drgb) return S2L_E_NULL;
   hipLaunchKernelGGL(ensemble_bwd_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dpred, areas, drgb, n_pixels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_backward_batch(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
+                                           int64_t n_frames, s2l_stream_t stream) {
+  if (n_pixels < 0 || n_frames < 0 || n_frames > 65535) return S2L_E_SIZE;
+  if (n_pixels == 0 || n_frames == 0) return S2L_OK;
+  if (!dpred || !areas || !drgb) return S2L_E_NULL;
+  hipLaunchKernelGGL(ensemble_bwd_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256), (unsigned)n_frames), dim3(256), 0,
                      static_cast<hipStream_t>(stream), dpred, areas, drgb, n_pixels);
   return (int)hipGetLastError();
 }

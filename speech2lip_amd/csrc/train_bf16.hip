@@ -87,7 +87,7 @@ __global__ void pack_bf16_kernel(Tab16 tab, const float* __restrict__ pf, uint16
       } else if (L == 0 || L == 5) {
         const int R = 2 * q + o / kSlabX;
         slab_idx(o % kSlabX, t, lane, j);
-        v = pf[(L == 0 ? OFF_G0 : OFF_G5) + (int64_t)(32 * R + (lane & 31)) * kGenK + 16 * t + 8 * (lane >> 5) + j];
+        v = pf[(L == 0 ? OFF_G0 : OFF_G5) + (int64_t)(32 * R + (lane & 31)) * kGenK + kfeat16(t, lane >> 5, j)];
       }
     } else if (L != 0) {
       const int o2 = o - 2 * kSlabX;
@@ -171,7 +171,7 @@ extern "C" void s2l_trace16_set(unsigned long long* p) { hipMemcpyToSymbol(HIP_S
 struct FwdArgs {
   const uint16_t* wb;
   const float* pf;
-  const float* x;
+  const uint16_t* xT;   // embedded rows as a bf16 image (4 blocks), padded rows zero
   uint16_t* hT;
   uint64_t* masks;
   float* rgb;
@@ -203,14 +203,12 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
     const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1), group = (int64_t)tile * 8 + wave;
-    {
-      const bool ok = row < a.n_rows;
-      const f4* xr = reinterpret_cast<const f4*>(a.x + (ok ? row : 0) * kGenK + 8 * hh);
+    {   // B operands of the embedded rows: the image's two 16-byte halves of block R are k-steps 2R and 2R + 1
+      const u4* xi = reinterpret_cast<const u4*>(a.xT + image_off(group, 4, 0, lane));
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        f4 lo = xr[4 * t], hi = xr[4 * t + 1];
-        if (!ok) lo = hi = f4{0.f, 0.f, 0.f, 0.f};
-        bx[t] = u4{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])};
+      for (int R = 0; R < 4; ++R) {
+        bx[2 * R] = xi[R * 128];
+        bx[2 * R + 1] = xi[R * 128 + 1];
       }
     }
     for (int L = 0; L < 8; ++L) {
@@ -641,6 +639,56 @@ __global__ __launch_bounds__(256) void rows_to_image_kernel(const float* __restr
   *reinterpret_cast<u2*>(dst) = u2{pk2(v[0], v[1]), pk2(v[2], v[3])};
 }
 
+// 4-tap ensemble rows of a whole batch of frames, straight to the bf16 image (no fp32 x, no second pass): the same values as
+// ensemble_rows_kernel (ensemble.hip; training.py:198-210, 240-241) rounded to bf16.  Row of (frame b, tap t, pixel p) =
+// (4 b + t) * n_pixels + p.  thread = (row, 4 features).
+struct EnsBatch {
+  float dx[2], dy[2], ry;   // (float)(-rx), (float)(+rx), (float)(-ry), (float)(+ry), (float)ry: the host's python-double shifts
+};
+__device__ __forceinline__ float embed16(float u, float v, int i) {
+  if (i < 2) return i == 0 ? u : v;
+  const int blk = (i - 2) >> 1;
+  const float x = ((i & 1) ? v : u) * (float)(1 << (blk >> 1));
+  return (blk & 1) ? cosf(x) : sinf(x);
+}
+__global__ __launch_bounds__(256) void ensemble_rows_bf16_kernel(const float* __restrict__ packed, const float* __restrict__ coords,
+                                                                const float* __restrict__ feat, const int64_t* __restrict__ tidx,
+                                                                const float* __restrict__ u01, EnsBatch sh, uint16_t* __restrict__ xT,
+                                                                float* __restrict__ areas, int64_t n_pix, int64_t n_rows,
+                                                                int64_t n_padded) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t >> 5;
+  if (row >= n_padded) return;
+  const int k0 = (int)(t & 31) * 4;
+  f4 val = f4{0.f, 0.f, 0.f, 0.f};
+  if (row < n_rows) {
+    const int64_t bt = row / n_pix, p = row - bt * n_pix;
+    const int tap = (int)(bt & 3);
+    const int64_t b = bt >> 2;
+    const float eps = sh.ry * u01[b] / 2.0f;
+    const float u0 = coords[2 * p], v0 = coords[2 * p + 1];
+    const float cu = fminf(fmaxf(u0 + (sh.dx[tap >> 1] + eps), 0.f), 1.f);
+    const float cv = fminf(fmaxf(v0 + (sh.dy[tap & 1] + eps), 0.f), 1.f);
+    const float time_pos = (float)tidx[b];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      float v;
+      if (k < kEmb) v = embed16(cu, cv, k);
+      else if (k < kEmb + kAud) v = feat[b * kAud + (k - kEmb)];
+      else if (k < kEmb + kAud + kTime) {
+        const int i = k - kEmb - kAud;
+        const float arg = time_pos * packed[OFF_DIV + (i >> 1)];
+        v = (i & 1) ? cosf(arg) : sinf(arg);
+      } else v = 0.f;
+      val[j] = v;
+    }
+    if (k0 == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;
+  }
+  const int R = k0 >> 5, a4 = (k0 & 31) >> 3, hh = (k0 >> 2) & 1;
+  *reinterpret_cast<u2*>(xT + image_off(row >> 5, 4, R, (int)(row & 31) + 32 * hh) + 4 * a4) = u2{pk2(val[0], val[1]), pk2(val[2], val[3])};
+}
+
 // output layer: dWout[c][f] = sum_rows drgb[row][c] h7[row][f], dbout[c] = sum_rows drgb[row][c].  thread = (4-feature group,
 // quarter of the rows of a row group); the four row quarters are combined through LDS at the end.
 __global__ __launch_bounds__(256) void out_grad_kernel(const float* __restrict__ drgb, const uint16_t* __restrict__ h7T,
@@ -721,12 +769,12 @@ static int n_cu_of_device() {
   return cache[dev];
 }
 
-extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const float* x, uint16_t* hT,
+extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const uint16_t* xT, uint16_t* hT,
                                       uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream) {
   if (n_rows < 0) return S2L_E_SIZE;
   if (n_rows == 0) return S2L_OK;
-  if (!packed_bf16 || !packed_f32 || !x || !hT || !masks || !rgb) return S2L_E_NULL;
-  if (misaligned16(packed_bf16) || misaligned16(x) || misaligned16(hT) || misaligned16(masks)) return S2L_E_ALIGN;
+  if (!packed_bf16 || !packed_f32 || !xT || !hT || !masks || !rgb) return S2L_E_NULL;
+  if (misaligned16(packed_bf16) || misaligned16(xT) || misaligned16(hT) || misaligned16(masks)) return S2L_E_ALIGN;
   static bool attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -738,7 +786,7 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   }
   FwdArgs a;
   const int64_t np = s2l_bf16_rows_padded(n_rows);
-  a.wb = packed_bf16, a.pf = packed_f32, a.x = x, a.hT = hT, a.masks = masks, a.rgb = rgb;
+  a.wb = packed_bf16, a.pf = packed_f32, a.xT = xT, a.hT = hT, a.masks = masks, a.rgb = rgb;
   a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
   a.n_tiles = (int)(np / kWgRows);
   const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
@@ -829,5 +877,20 @@ extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts);
   (void)hipMemcpyAsync(dwout, sum, 768 * sizeof(float), hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(dbout, sum + 768, 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_rows_bf16(const float* packed, const float* coords, const float* feat, const int64_t* time_index,
+                                      const float* u01, int width, int height, uint16_t* xT, float* areas, int64_t n_pixels,
+                                      int64_t n_frames, s2l_stream_t stream) {
+  if (n_pixels <= 0 || n_frames <= 0 || width <= 0 || height <= 0) return S2L_E_SIZE;
+  if (!packed || !coords || !feat || !time_index || !u01 || !xT || !areas) return S2L_E_NULL;
+  if (misaligned16(xT)) return S2L_E_ALIGN;
+  const double rx = 0.5 / width, ry = 0.5 / height;   // as s2l_ensemble_rows forms them (python doubles rounded to fp32)
+  EnsBatch sh;
+  sh.dx[0] = (float)(-rx), sh.dx[1] = (float)rx, sh.dy[0] = (float)(-ry), sh.dy[1] = (float)ry, sh.ry = (float)ry;
+  const int64_t n_rows = 4 * n_pixels * n_frames, np = s2l_bf16_rows_padded(n_rows);
+  hipLaunchKernelGGL(ensemble_rows_bf16_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     packed, coords, feat, time_index, u01, sh, xT, areas, n_pixels, n_rows, np);
   return (int)hipGetLastError();
 }

@@ -124,7 +124,7 @@ class LipTrainStep:
         st = _stream()
         ck = _abi.check
         feat = m.audio_merge_forward(audio)                                  # [B,64]
-        x, areas = self._f(N, 128), self._f(N)
+        areas = self._f(N)
         bf16 = self.precision == "bf16"
         if bf16:
             Np = int(lib.s2l_bf16_rows_padded(N))
@@ -132,33 +132,36 @@ class LipTrainStep:
             i16 = lambda n: torch.empty(n, dtype=torch.int16, device=dev)
             hT, dzT, xT = i16(8 * Np * 256), i16(8 * Np * 256), i16(Np * 128)
             masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+            x = None
         else:
+            x = self._f(N, 128)
             hsave, dzsave = self._f(8, N, 256), self._f(8, N, 256)
         rgb, drgb, dxa = self._f(N, 3), self._f(N, 3), self._f(N, 64)
         pred, dpred = self._f(B * P, 3), self._f(B * P, 3)
         loss, mwork = self._f(1), self._f(1024)
         with torch.cuda.device(dev):
-            for b in range(B):   # rows of frame b: [b*4P, (b+1)*4P), tap-major inside
-                ck(lib.s2l_ensemble_rows(_ptr(packed), _ptr(self.coords), _ptr(feat[b]), idx[b], self.w, self.h,
-                                         ctypes.c_float(u[b]), _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, st),
-                   "s2l_ensemble_rows")
+            if bf16:     # the embedded rows of the whole batch in one launch, straight to the bf16 operand image
+                t_idx = torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
+                t_u = torch.tensor(u, dtype=torch.float32).to(dev, non_blocking=True)
+                ck(lib.s2l_ensemble_rows_bf16(_ptr(packed), _ptr(self.coords), _ptr(feat), _ptr(t_idx), _ptr(t_u), self.w, self.h,
+                                              _ptr(xT), _ptr(areas), P, B, st), "s2l_ensemble_rows_bf16")
+            else:
+                for b in range(B):   # rows of frame b: [b*4P, (b+1)*4P), tap-major inside
+                    ck(lib.s2l_ensemble_rows(_ptr(packed), _ptr(self.coords), _ptr(feat[b]), idx[b], self.w, self.h,
+                                             ctypes.c_float(u[b]), _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, st),
+                       "s2l_ensemble_rows")
             if bf16:
-                ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(packed), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, st),
+                ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(packed), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, st),
                    "s2l_train_forward_bf16")
             else:
                 ck(lib.s2l_train_forward(_ptr(packed), _ptr(x), _ptr(hsave), _ptr(rgb), N, st), "s2l_train_forward")
-            for b in range(B):
-                ck(lib.s2l_ensemble_reduce(_ptr(rgb[b * 4 * P:]), _ptr(areas[b * 4 * P:]), _ptr(pred[b * P:]), P, st),
-                   "s2l_ensemble_reduce")
+            ck(lib.s2l_ensemble_reduce_batch(_ptr(rgb), _ptr(areas), _ptr(pred), P, B, st), "s2l_ensemble_reduce_batch")
             ck(lib.s2l_mse(_ptr(pred), _ptr(tgt), ctypes.c_float(weight), _ptr(dpred), _ptr(mwork), _ptr(loss),
                            B * P * 3, st), "s2l_mse")
-            for b in range(B):
-                ck(lib.s2l_ensemble_backward(_ptr(dpred[b * P:]), _ptr(areas[b * 4 * P:]), _ptr(drgb[b * 4 * P:]), P, st),
-                   "s2l_ensemble_backward")
+            ck(lib.s2l_ensemble_backward_batch(_ptr(dpred), _ptr(areas), _ptr(drgb), P, B, st), "s2l_ensemble_backward_batch")
             if bf16:
                 ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, st),
                    "s2l_train_backward_bf16")
-                ck(lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, st), "s2l_rows_to_tiles_bf16")
                 work = self._f(int(lib.s2l_wgrad_bf16_work_floats()))
                 lay = Np * 256
 

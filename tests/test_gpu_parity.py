@@ -573,7 +573,33 @@ def _bf16_inputs(dev, h, w, B, seed=0):
     for b in range(B):
         _abi.check(lib.s2l_ensemble_rows(_ptr(packed), _ptr(coords), _ptr(feat[b]), 7 + b, w, h, ctypes.c_float(0.3 + 0.1 * b),
                                          _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, _stream()), "s2l_ensemble_rows")
+    # the same rows as the bf16 operand image, from the batched kernel the bf16 step uses
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    xT = torch.zeros(Np * 128, dtype=torch.int16, device=dev)
+    areas16 = torch.empty(N, device=dev)
+    t_idx = torch.tensor([7 + b for b in range(B)], dtype=torch.int64, device=dev)
+    t_u = torch.tensor([0.3 + 0.1 * b for b in range(B)], dtype=torch.float32, device=dev)
+    _abi.check(lib.s2l_ensemble_rows_bf16(_ptr(packed), _ptr(coords), _ptr(feat), _ptr(t_idx), _ptr(t_u), w, h, _ptr(xT), _ptr(areas16),
+                                          P, B, _stream()), "s2l_ensemble_rows_bf16")
+    _bf16_inputs.last = (xT, areas, areas16)
     return m, lib, x, N
+
+
+def test_bf16_embedded_rows_image(dev):
+    """s2l_ensemble_rows_bf16 (whole batch, straight to the operand image) == bf16 of the per-frame fp32 rows, same areas;
+    s2l_rows_to_tiles_bf16 builds the identical image from the fp32 rows."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    from tests import bf16_util as U
+    m, lib, x, N = _bf16_inputs(dev, 12, 20, 3)
+    xT, areas, areas16 = _bf16_inputs.last
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    got = U.tiles_to_rows(xT, 1, Np, 128)[0]
+    assert torch.equal(got[:N], U.bf(x.cpu())) and float(got[N:].abs().max()) == 0.0
+    assert torch.equal(areas16.cpu(), areas.cpu())
+    x2 = torch.zeros_like(xT)
+    _abi.check(lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(x2), N, _stream()), "s2l_rows_to_tiles_bf16")
+    assert torch.equal(x2, xT)
 
 
 @pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
@@ -588,7 +614,7 @@ def test_bf16_forward_matches_emulation(dev, h, w, B):
     hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
     masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
     rgb = torch.empty(N, 3, device=dev)
-    _abi.check(lib.s2l_train_forward_bf16(_ptr(m.packed_weights_bf16()), _ptr(m.packed_weights()), _ptr(x), _ptr(hT), _ptr(masks),
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(m.packed_weights_bf16()), _ptr(m.packed_weights()), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks),
                                           _ptr(rgb), N, _stream()), "s2l_train_forward_bf16")
     sd_ = O.to_sd(W.make_state_dict(0, "he"))
     with torch.no_grad():
@@ -625,7 +651,7 @@ def test_bf16_backward_matches_emulation(dev, h, w, B):
     masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
     rgb = torch.empty(N, 3, device=dev)
     pb, pf = m.packed_weights_bf16(), m.packed_weights()
-    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
     g = torch.Generator(device="cpu").manual_seed(5)
     drgb = (torch.randn(N, 3, generator=g) * 1e-3)
     dxa = torch.full((N, 64), float("nan"), device=dev)
@@ -659,17 +685,15 @@ def test_bf16_wgrad_matches_tiles(dev):
     lay = Np * 256
     hT = torch.zeros(8 * lay, dtype=torch.int16, device=dev)
     dzT = torch.zeros(8 * lay, dtype=torch.int16, device=dev)
-    xT = torch.zeros(Np * 128, dtype=torch.int16, device=dev)
+    xT = _bf16_inputs.last[0]
     masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
     rgb, dxa = torch.empty(N, 3, device=dev), torch.empty(N, 64, device=dev)
     pb, pf = m.packed_weights_bf16(), m.packed_weights()
     drgb = (torch.randn(N, 3, generator=torch.Generator().manual_seed(9)) * 1e-3).to(dev)
     ck = _abi.check
-    ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
     ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()), "bwd")
-    ck(lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, _stream()), "tiles")
     x_d = U.tiles_to_rows(xT, 1, Np, 128)[0]
-    assert torch.equal(x_d[:N], U.bf(x.cpu())) and float(x_d[N:].abs().max() if Np > N else 0.0) == 0.0
     h_d, g_d = U.tiles_to_rows(hT, 8, Np), U.tiles_to_rows(dzT, 8, Np)
     work = torch.empty(int(lib.s2l_wgrad_bf16_work_floats()), device=dev)
     for k, inp in ((7, 6), (1, 0), (5, 4)):
@@ -759,7 +783,7 @@ def test_bf16_kernels_multi_tile_workgroups(dev):
     rgb, dxa = torch.empty(N, 3, device=dev), torch.empty(N, 64, device=dev)
     pb, pf = m.packed_weights_bf16(), m.packed_weights()
     drgb = torch.randn(N, 3, generator=torch.Generator().manual_seed(3)) * 1e-3
-    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
     _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb.to(dev)), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()), "bwd")
     # sample 64-row tiles: first, one in the middle handled as a second tile of some workgroup, the last
     tiles = [0, 5, 256 * 4 + 7, 270 * 4 + 1, Np // 64 - 1]

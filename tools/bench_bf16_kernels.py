@@ -15,7 +15,6 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he",
 lib = _abi.load()
 N = 4 * 96 * 96 * B
 Np = int(lib.s2l_bf16_rows_padded(N)); lay = Np * 256
-x = torch.randn(N, 128, device=dev) * 0.5
 hT = torch.empty(8 * lay, dtype=torch.int16, device=dev); dzT = torch.empty_like(hT)
 masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
 rgb, drgb, dxa = torch.empty(N, 3, device=dev), torch.randn(N, 3, device=dev) * 1e-3, torch.empty(N, 64, device=dev)
@@ -32,7 +31,7 @@ def timed(fn, it=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
 
-tf = timed(lambda: lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()))
+tf = timed(lambda: lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()))
 tb = timed(lambda: lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()))
 tw = timed(lambda: lib.s2l_wgrad_bf16(_ptr(dzT[3 * lay:]), _ptr(hT[2 * lay:]), 256, _ptr(work), _ptr(dw), _ptr(db), N, _stream()))
 gb = 8 * lay * 2 / 1e9

@@ -15,6 +15,8 @@ raw = ctypes.CDLL(os.environ["S2L_LIB"])
 N = 4 * 96 * 96 * 16
 Np = int(lib.s2l_bf16_rows_padded(N)); lay = Np * 256
 x = torch.randn(N, 128, device=dev) * 0.5
+xT = torch.empty(Np * 128, dtype=torch.int16, device=dev)
+lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, _stream())
 hT = torch.empty(8 * lay, dtype=torch.int16, device=dev)
 masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
 rgb = torch.empty(N, 3, device=dev)
@@ -22,7 +24,7 @@ tr = torch.zeros(2 * 32 * 8, dtype=torch.int64, device=dev)
 pb, pf = m.packed_weights_bf16(), m.packed_weights()
 for it in range(2):
     raw.s2l_trace16_set(ctypes.c_void_p(tr.data_ptr() if it else 0))
-    lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(x), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream())
+    lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream())
     torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(2, 32, 8)
 for w in range(2):
