@@ -60,6 +60,24 @@ __device__ __forceinline__ void kloop2(const u4* ap0, const u4* ap1, const u4 (&
   }
 }
 
+// kloop2 with a per-k-step callback issued right after the step's two MFMAs: the callback's VALU work (one slice of the
+// PREVIOUS stage's epilogue) executes in their shadow.
+template <int T, typename F>
+__device__ __forceinline__ void kloop2e(const u4* ap0, const u4* ap1, const u4 (&b)[T], f16v& acc0, f16v& acc1, F&& slice) {
+  constexpr int D = S2L_KDEPTH;
+  u4 a0[D], a1[D];
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) a0[t] = ap0[64 * t], a1[t] = ap1[64 * t];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + D - 1 < T) a0[(t + D - 1) % D] = ap0[64 * (t + D - 1)], a1[(t + D - 1) % D] = ap1[64 * (t + D - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = mfma32(a0[t % D], b[t], acc0);
+    acc1 = mfma32(a1[t % D], b[t], acc1);
+    slice(t);
+  }
+}
+
 struct Tab16 {
   const float* t[S2L_NUM_TENSORS];
 };
@@ -418,26 +436,68 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
       u = nxt;
     };
 
+    // Software pipeline inside a layer: the masked-ReLU / bf16 / store epilogue of stage q-1 is sliced over the 16 k-steps
+    // of stage q (two accumulator sets ping-pong), so its VALU work runs in the shadow of that stage's MFMAs; only the first
+    // stage's k-loops and the last stage's epilogue of a layer run alone (the next layer needs all 256 outputs).
     for (int l = 7; l >= 1; --l) {   // W_l^T g_l -> g_{l-1}
+      f16v accs[2][2];
+      const uint64_t* mbase = a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + 16 * g;
+      uint16_t* dbase = a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, 0, 0);
+      uint32_t pv[2][4][2];          // bf16 pairs of the stage whose epilogue is in flight
+      uint32_t pmlo[2], pmhi[2];     // its two mask rows (lane r holds ballot r)
+      float hold[2];
+      // one value (register r of block `which`) of the pending epilogue
+      auto slice_of = [&](const f16v (&accp)[2], int which, int r) {
+        const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(pmlo[which], r) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(pmhi[which], r) << 32);
+        const float v = mask_sel(accp[which][r], m);
+        if (r & 1) pv[which][r >> 2][(r >> 1) & 1] = pk2(hold[which], v);
+        else hold[which] = v;
+      };
+      auto finish = [&](int qp) {    // bnext entries and image stores of stage qp
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const int R = 2 * qp + which;
+          bnext[2 * R] = u4{pv[which][0][0], pv[which][0][1], pv[which][1][0], pv[which][1][1]};
+          bnext[2 * R + 1] = u4{pv[which][2][0], pv[which][2][1], pv[which][3][0], pv[which][3][1]};
+          image_store(pv[which], dbase + image_off(0, 8, R, 0), lane);
+        }
+      };
+      auto load_masks = [&](int qp) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const uint64_t mv = mbase[(2 * qp + which) * 32 + (lane & 15)];
+          pmlo[which] = (uint32_t)mv, pmhi[which] = (uint32_t)(mv >> 32);
+        }
+      };
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nxt = next_of(u);
         gload(nxt);
         const uint16_t* wl = wbuf + (u & 1) * kStageB;
-        f16v acc[2];
+        f16v (&acc)[2] = accs[q & 1];
+        const f16v (&accp)[2] = accs[(q & 1) ^ 1];
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[w2][r] = 0.f;
-        kloop2<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc[0], acc[1]);
+        if (q > 0) load_masks(q - 1);
+        kloop2e<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc[0], acc[1],
+                    [&](int t) {
+                      if (q > 0) {
+                        slice_of(accp, 0, t);
+                        slice_of(accp, 1, t);
+                      }
+                    });
+        if (q > 0) finish(q - 1);
+        if (q == 3) {                // this layer's last stage: its own epilogue now
+          load_masks(3);
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-          const int R = 2 * q + which;
-          uint32_t vals[4][2];
-          mask_block(acc[which], a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
-          bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
-          bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
-          image_store(vals, a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, R, 0), lane);
+          for (int r = 0; r < 16; ++r) {
+            slice_of(acc, 0, r);
+            slice_of(acc, 1, r);
+          }
+          finish(3);
         }
         lstore(nxt);
         __syncthreads();

@@ -15,6 +15,9 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he",
 lib = _abi.load()
 N = 4 * 96 * 96 * B
 Np = int(lib.s2l_bf16_rows_padded(N)); lay = Np * 256
+x = torch.randn(N, 128, device=dev) * 0.5
+xT = torch.empty(Np * 128, dtype=torch.int16, device=dev)
+lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, _stream())
 hT = torch.empty(8 * lay, dtype=torch.int16, device=dev); dzT = torch.empty_like(hT)
 masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
 rgb, drgb, dxa = torch.empty(N, 3, device=dev), torch.randn(N, 3, device=dev) * 1e-3, torch.empty(N, 64, device=dev)
