@@ -116,29 +116,37 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     bias[mb] = *reinterpret_cast<const f4*>(b + 16 * mb + 4 * q);
   }
   const int npix = H * W;
-  for (int p0 = (blockIdx.x * 4 + wave) * 16; p0 < npix; p0 += gridDim.x * 64) {
-    const int pix = p0 + px;
-    const bool live = pix < npix;
-    const int py = live ? pix / W : 0, pxx = live ? pix - py * W : 0;
-    float in[7];
+  constexpr int kGroups = 4;   // 16-pixel groups per wave iteration: all 28 gathers are issued before the first MFMA
+  for (int p0 = (blockIdx.x * 4 + wave) * 16 * kGroups; p0 < npix; p0 += gridDim.x * 64 * kGroups) {
+    float in[kGroups][7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int k = 4 * j + q;
-      const int c = k / 9, t = k - 9 * c;
-      const int yy = py + t / 3 - 1, xx = pxx + t % 3 - 1;
-      const bool ok = live && k < 27 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-      in[j] = ok ? xf[((int64_t)yy * W + xx) * 3 + c] : 0.f;
+    for (int u = 0; u < kGroups; ++u) {
+      const int pix = p0 + 16 * u + px;
+      const bool live = pix < npix;
+      const int py = live ? pix / W : 0, pxx = live ? pix - py * W : 0;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int k = 4 * j + q;
+        const int c = k / 9, t = k - 9 * c;
+        const int yy = py + t / 3 - 1, xx = pxx + t % 3 - 1;
+        const bool ok = live && k < 27 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        in[u][j] = ok ? xf[((int64_t)yy * W + xx) * 3 + c] : 0.f;
+      }
     }
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < kGroups; ++u) {
+      const int pix = p0 + 16 * u + px;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mb][j], in[j], acc, 0, 0, 0);
-      if (live) {
-        f4 o;
+      for (int mb = 0; mb < 4; ++mb) {
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[mb][r], 0.f);
-        *reinterpret_cast<f4*>(yf + (int64_t)pix * 64 + 16 * mb + 4 * q) = o;
+        for (int j = 0; j < 7; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mb][j], in[u][j], acc, 0, 0, 0);
+        if (pix < npix) {
+          f4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[mb][r], 0.f);
+          *reinterpret_cast<f4*>(yf + (int64_t)pix * 64 + 16 * mb + 4 * q) = o;
+        }
       }
     }
   }
@@ -417,7 +425,7 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   float* pool2 = u1 + p2 * 64;     float* t128c = pool2 + p4 * 128; float* x3 = t128c + p4 * 128;
   int rc;
   if (F > 65535) return S2L_E_SIZE;
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((((int64_t)H * W + 63) / 64 + 3) / 4), (unsigned)F), dim3(256), 0, st, x,
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
   if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1))) return rc;   // + MaxPool2d(2)
   if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st))) return rc;
