@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
                     help="dtype of the reassembled clip (N > 1): f32 = bit-identical to a 1-GPU render (default); u8 = the 8-bit "
                          "frames the reference writes (cv2.imwrite semantics), quantised per rank, 4x less all-gather traffic")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="leave this many CUs to RCCL (use with --chunks > 1): the renderer launches CUs - k persistent workgroups, "
+                         "so the all-gather of one chunk can run while the next chunk renders.  Default 0 = no overlap attempted")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
     ap.add_argument("--force-dist", action="store_true",
@@ -132,6 +135,10 @@ def main():
     from speech2lip_amd import sharded, weights as W
 
     F = args.frames
+    if args.reserve_cus > 0:
+        from speech2lip_amd import _abi
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        _abi.check(_abi.load().s2l_set_render_cus(max(1, n_cu - args.reserve_cus)), "s2l_set_render_cus")
     model = s2l.TalkingFace(dev, s2l.may_config(H, W_), mode="eval").eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
     QUANTUM = 48   # frames: keeps each chunk launch a whole number of 256-tile waves at 96x96
@@ -190,7 +197,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step",
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
-                       (f" + {n_chunks}-chunk {args.gather} all-gather" if world > 1 else "")},
+                       (f" + {n_chunks}-chunk {args.gather} all-gather" if world > 1 else "") +
+                       (f", {args.reserve_cus} CUs left to RCCL" if args.reserve_cus else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):

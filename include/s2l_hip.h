@@ -101,6 +101,9 @@ int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float*
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
+/* Process-wide cap on the persistent renderer's workgroups (0 = one per CU, the default).  A multi-GPU host that overlaps
+ * RCCL with rendering passes CUs - k so that k CUs stay free for RCCL's kernels; results do not depend on it. */
+int s2l_set_render_cus(int n_workgroups);
 
 /* Exact drop-in for TalkingFace.rgb_forward on arbitrary rows (tf_nerf.py:225-285, May flags):
  * uv_audio [N,66] = (u, v, 64 audio features) per row, one frame index for the call -> out [N,3].

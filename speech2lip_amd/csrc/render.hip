@@ -314,6 +314,16 @@ extern "C" int s2l_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_
 
 }  // namespace s2l
 
+// Workgroups the persistent renderer may occupy (0 = one per CU).  A multi-GPU host that overlaps the RCCL all-gather of
+// chunk c with the render of chunk c+1 sets this to CUs - k: the renderer fills a CU completely (151 KiB LDS, every register),
+// so RCCL's workgroups can only run on CUs it leaves free.
+static int g_render_cu_limit = 0;
+extern "C" int s2l_set_render_cus(int n_workgroups) {
+  if (n_workgroups < 0) return S2L_E_SIZE;
+  g_render_cu_limit = n_workgroups;
+  return S2L_OK;
+}
+
 extern "C" int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0, const float* q5,
                               float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream) {
   using namespace s2l;
@@ -347,7 +357,8 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
     if (e != hipSuccess) return (int)e;
     n_cu_of[dev] = n;
   }
-  const int n_cu = n_cu_of[dev];
+  int n_cu = n_cu_of[dev];
+  if (g_render_cu_limit > 0 && g_render_cu_limit < n_cu) n_cu = g_render_cu_limit;
   // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
   hipLaunchKernelGGL((render_tiles_kernel<G>), dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);
