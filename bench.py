@@ -7,8 +7,12 @@ per-frame vectors -> fused MLP render -> [FRAMES,96,96,3] fp32 in HBM.  With N >
 renders its own FRAMES (weak scaling) and the clip is reassembled on every rank with an RCCL all-gather
 (one per step by default; --chunks > 1 splits it into per-chunk gathers issued while the next chunk renders).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without torchrun: spawns its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N = 1 is BASELINE config 2 (1000 frames per step).  N > 1 is config 4's workload: 5 000 frames per GPU per step (40 000 at 8
+GPUs), reassembled on every rank; after the timed steps rank 0 re-renders another rank's block locally and
+requires the gathered frames to be bit-identical (frames are pure functions of (audio window, frame index)).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the fused
 MLP kernel (MFMA-bound, fp32 MFMA peak 157.3 TFLOP/s; algorithmic FLOPs per SURVEY.md §8d) and
@@ -86,12 +90,64 @@ def _flush_c_stdout():
         pass
 
 
+def spawn_ranks(args) -> int:
+    """`--gpus N` (N > 1) outside torchrun: start one rank per GPU ourselves (same env contract as
+    torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Rank 0 owns stdout (the JSON
+    line); the other ranks' stdout goes to stderr.  Never prints a line whose n_gpus differs from --gpus: with fewer
+    visible GPUs than requested this is an error, not a silent 1-GPU run."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:          # a failed rank must not leave the others waiting in a collective forever
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def extra_measurements(dev):
+    """Configs 3 and 5 (and the composite kernel alone), measured after and outside the headline's timed region so that
+    they are in the driver-timed record too.  Each entry is what the matching tools/bench_*.py prints."""
+    from tools import benchlib
+    out = {}
+    for name, fn in (("composite", lambda: benchlib.bench_composite(dev, 256)),
+                     ("config3", lambda: benchlib.bench_config3(dev, 5000, 500)),
+                     ("config3_with_unet", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True)),
+                     ("train_bf16", lambda: benchlib.bench_train(dev, 64, "bf16")),
+                     ("train_fp32", lambda: benchlib.bench_train(dev, 64, "fp32", steps=3))):
+        try:
+            r = fn()
+            out[name] = {k: v for k, v in r.items() if not k.startswith("_")}
+        except Exception as e:      # an extra must never cost the headline line
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (BASELINE config 2: 1000)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per GPU per step; default 1000 at N = 1 (BASELINE config 2), 5000 at N > 1 (config 4: 40k / 8)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="all-gather chunks per step (N > 1).  1 = render the clip in one persistent launch, then one "
                          "all-gather: the renderer fills every CU (151 KiB LDS + all registers per workgroup), so an "
@@ -104,15 +160,20 @@ def main():
                     help="leave this many CUs to RCCL (use with --chunks > 1): the renderer launches CUs - k persistent workgroups, "
                          "so the all-gather of one chunk can run while the next chunk renders.  Default 0 = no overlap attempted")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-5 `extra` measurements (N = 1)")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the RCCL path (process group, all-gather, barriers) even with one rank")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:      # the line's n_gpus must be what --gpus asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
@@ -134,7 +195,7 @@ def main():
     import speech2lip_amd as s2l
     from speech2lip_amd import sharded, weights as W
 
-    F = args.frames
+    F = args.frames if args.frames is not None else (1000 if world == 1 else 5000)
     if args.reserve_cus > 0:
         from speech2lip_amd import _abi
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -143,8 +204,12 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
     QUANTUM = 48   # frames: keeps each chunk launch a whole number of 256-tile waves at 96x96
     n_chunks = args.chunks if (world > 1 or args.force_chunks) else 1
-    gids = sharded.global_frame_ids(F, rank, world, n_chunks, QUANTUM).to(dev)
-    audio = torch.from_numpy(W.synthetic_audio(F, seed=1 + rank).astype(np.float32)).to(dev)   # resident in HBM
+
+    def rank_inputs(r):      # audio windows and global frame ids of rank r (any rank can rebuild any other rank's)
+        ids = sharded.global_frame_ids(F, r, world, n_chunks, QUANTUM).to(dev)
+        return torch.from_numpy(W.synthetic_audio(F, seed=1 + r).astype(np.float32)).to(dev), ids
+
+    audio, gids = rank_inputs(rank)                                                               # resident in HBM
     quant = s2l.to8b if args.gather == "u8" else None
     clip = torch.empty((F * world, H, W_, 3), dtype=torch.uint8 if quant else torch.float32, device=dev) if use_dist else None
     kernel_events = []
@@ -152,8 +217,8 @@ def main():
     def render(off, cnt, out):
         model.render_clip(audio[off:off + cnt], gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
 
-    def step():
-        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip,
+    def step(gather=True):
+        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip, gather=gather,
                                       quantum=QUANTUM, force_collective=args.force_dist, quantize=quant if use_dist else None)
 
     def fence():
@@ -162,19 +227,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n, fn):        # barrier + sync on both sides, MAX over ranks
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r
+
     for _ in range(args.warmup):
         step()
     fence()
     kernel_events.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, local = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, (out, local) = timed(args.steps, step)
 
     # dominant-kernel time from HIP events recorded on the launch stream around s2l_render_lip
     torch.cuda.synchronize()
@@ -184,6 +254,35 @@ def main():
     frames_per_launch = F / launches_per_step
     k_avg_s = (sum(k_ms) / len(k_ms)) * 1e-3
     achieved = FLOPS_PER_FRAME * frames_per_launch / k_avg_s
+
+    multi = None
+    if use_dist:
+        # where the step goes: the same steps without the gather, and the gather alone (both barrier-bracketed, MAX over ranks)
+        n_aux = max(1, min(args.steps, 5))
+        dt_render, _ = timed(n_aux, lambda: step(gather=False))
+        src = quant(local) if quant else local
+
+        def gather_only():
+            dist.all_gather_into_tensor(clip, src)
+        dt_gather, _ = timed(n_aux, gather_only)
+        # cross-rank verification: rank 0 re-renders the LAST rank's block itself and compares with what the gather delivered
+        verified = None
+        if n_chunks == 1:
+            step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                r = world - 1
+                a_r, ids_r = rank_inputs(r)
+                mine = model.render_clip(a_r, ids_r, H, W_)
+                theirs = clip[r * F:(r + 1) * F]
+                verified = bool(torch.equal(quant(mine) if quant else mine, theirs))
+                if not verified:
+                    raise SystemExit(f"bench.py: gathered frames of rank {r} differ from a local re-render of the same frame ids")
+        multi = {"render_only_ms": round(dt_render / n_aux * 1e3, 3), "gather_only_ms": round(dt_gather / n_aux * 1e3, 3),
+                 "gather_bytes_per_rank": int(src.numel() * src.element_size()),
+                 "per_gpu_rate_with_gather_over_without": round((dt_render / n_aux) / (dt / args.steps), 4),
+                 "remote_block_bit_identical_to_local_render": verified,
+                 "note": "weak-scaling efficiency = value_N / (N * value_1) is computed by the driver from its own runs"}
 
     if rank == 0:
         # parity spot-check outside the timed region: frame 0 against the CPU oracle
@@ -195,26 +294,34 @@ def main():
             "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step",
+            "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step"
+                       + (" (BASELINE config 2)" if world == 1 and F == 1000 else "")
+                       + (f" (BASELINE config 4 workload: {F * world} frames over {world} GPUs)" if world > 1 else ""),
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
                        (f" + {n_chunks}-chunk {args.gather} all-gather" if world > 1 else "") +
                        (f", {args.reserve_cus} CUs left to RCCL" if args.reserve_cus else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
-                         # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes):
-                         # profiles/r01d_rocprofv3_summary.txt measured 8.98e8 B per 1000-frame launch
+                         # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), see profiles/
                          "traffic": round(TRAFFIC_BYTES_PER_FRAME * frames_per_launch),
                          "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
             "parity": {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if multi:
+            line["multi_gpu"] = multi
     if use_dist:
         _flush_c_stdout()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if world == 1:
+            del out, local, clip
+            torch.cuda.empty_cache()
+            if not args.no_extra:
+                line["extra"] = extra_measurements(dev)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
         _flush_c_stdout()      # the JSON line must be the LAST line on stdout
         print(json.dumps(line), flush=True)
 

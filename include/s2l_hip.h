@@ -101,8 +101,10 @@ int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float*
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
-/* Process-wide cap on the persistent renderer's workgroups (0 = one per CU, the default).  A multi-GPU host that overlaps
- * RCCL with rendering passes CUs - k so that k CUs stay free for RCCL's kernels; results do not depend on it. */
+/* Cap on the persistent renderer's workgroups ON THE CURRENT DEVICE (hipGetDevice of the calling thread; 0 = one per CU, the
+ * default).  A multi-GPU host that overlaps RCCL with rendering passes CUs - k so that k CUs stay free for RCCL's kernels;
+ * results do not depend on it.  Per-device state held in atomics: safe with one host thread per GPU.  All other one-time
+ * per-device launch setup inside the library (CU counts, dynamic-LDS opt-ins) is atomic-guarded the same way. */
 int s2l_set_render_cus(int n_workgroups);
 
 /* Exact drop-in for TalkingFace.rgb_forward on arbitrary rows (tf_nerf.py:225-285, May flags):
@@ -294,7 +296,8 @@ int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* work, float
 /* ---- 8-bit output (inference.py:172-178) ---------------------------------------------------------------
  * out[i] = saturate_cast<uchar>(rgb[i] * 255) as cv2.imwrite converts the float image the reference hands it
  * (round to nearest even, clamp to [0,255]); n = number of floats.  Channel order is untouched (the reference's
- * RGB->BGR swap only undoes cv2's BGR file convention). */
+ * RGB->BGR swap only undoes cv2's BGR file convention).  rgb needs 4-byte alignment only (a frame slice of a clip starts at
+ * any multiple of H*W*3 floats), out none. */
 int s2l_to8b(const float* rgb, uint8_t* out, int64_t n, s2l_stream_t stream);
 
 #ifdef __cplusplus

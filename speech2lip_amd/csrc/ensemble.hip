@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void ensemble_reduce_kernel(const float* __res
   out[i] = r;
 }
 
-int launch_general_mlp(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
+int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
 
 }  // namespace s2l
 
@@ -141,7 +141,7 @@ extern "C" int s2l_predict_lip_image(const float* packed, const float* coords, c
   float* areas = pred + 4 * n_pixels * 3;
   hipLaunchKernelGGL(ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 7) / 8)), dim3(256), 0, st, packed, coords, feat,
                      (float)time_index, sh, x, areas, n_pixels);
-  int rc = launch_general_mlp(packed, x, pred, nullptr, 4 * n_pixels, st);
+  int rc = launch_rows_fwd(packed, x, pred, nullptr, 4 * n_pixels, st);
   if (rc) return rc;
   hipLaunchKernelGGL(ensemble_reduce_kernel, dim3((unsigned)((n_pixels * 3 + 255) / 256)), dim3(256), 0, st, pred, areas,
                      out, n_pixels);

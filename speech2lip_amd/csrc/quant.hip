@@ -10,11 +10,22 @@ __device__ __forceinline__ uint32_t q8(float x) {
   return (uint32_t)fminf(fmaxf(r, 0.f), 255.f);     // saturate; NaN -> 0 like the integer conversion of a clamped value
 }
 
-__global__ __launch_bounds__(256) void to8b_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t n) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+// head: elements before the first 16-byte-aligned float of x (0..3); they are converted one by one by the first threads, the
+// aligned body four at a time.  `out` only needs byte alignment for the head; the body stores bytes when out+head is not
+// 4-byte aligned (ALIGNED_OUT false).
+template <bool ALIGNED_OUT>
+__global__ __launch_bounds__(256) void to8b_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t n, int head) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < head) out[t] = (uint8_t)q8(x[t]);
+  const int64_t i = head + t * 4;
   if (i + 3 < n) {
     const f4 v = *reinterpret_cast<const f4*>(x + i);
-    *reinterpret_cast<uint32_t*>(out + i) = q8(v[0]) | (q8(v[1]) << 8) | (q8(v[2]) << 16) | (q8(v[3]) << 24);
+    if (ALIGNED_OUT) {
+      *reinterpret_cast<uint32_t*>(out + i) = q8(v[0]) | (q8(v[1]) << 8) | (q8(v[2]) << 16) | (q8(v[3]) << 24);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[i + k] = (uint8_t)q8(v[k]);
+    }
   } else {
     for (int64_t j = i; j < n; ++j) out[j] = (uint8_t)q8(x[j]);
   }
@@ -26,7 +37,16 @@ extern "C" int s2l_to8b(const float* rgb, uint8_t* out, int64_t n, s2l_stream_t 
   if (n < 0) return S2L_E_SIZE;
   if (n == 0) return S2L_OK;
   if (!rgb || !out) return S2L_E_NULL;
-  if (s2l::misaligned16(rgb) || (reinterpret_cast<uintptr_t>(out) & 3)) return S2L_E_ALIGN;
-  hipLaunchKernelGGL(s2l::to8b_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), rgb, out, n);
+  if (reinterpret_cast<uintptr_t>(rgb) & 3) return S2L_E_ALIGN;   // floats
+  // a frame slice of a clip starts at base + k*H*W*3 floats: any 4-byte phase of the 16-byte vector loads is legal
+  int head = (int)((16 - (reinterpret_cast<uintptr_t>(rgb) & 15)) & 15) / 4;
+  if (head > n) head = (int)n;
+  const int64_t body = n - head;
+  const unsigned blocks = (unsigned)((body + 1023) / 1024 > 0 ? (body + 1023) / 1024 : 1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (((reinterpret_cast<uintptr_t>(out) + head) & 3) == 0)
+    hipLaunchKernelGGL(s2l::to8b_kernel<true>, dim3(blocks), dim3(256), 0, st, rgb, out, n, head);
+  else
+    hipLaunchKernelGGL(s2l::to8b_kernel<false>, dim3(blocks), dim3(256), 0, st, rgb, out, n, head);
   return (int)hipGetLastError();
 }

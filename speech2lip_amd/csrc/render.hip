@@ -314,13 +314,17 @@ extern "C" int s2l_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_
 
 }  // namespace s2l
 
-// Workgroups the persistent renderer may occupy (0 = one per CU).  A multi-GPU host that overlaps the RCCL all-gather of
-// chunk c with the render of chunk c+1 sets this to CUs - k: the renderer fills a CU completely (151 KiB LDS, every register),
-// so RCCL's workgroups can only run on CUs it leaves free.
-static int g_render_cu_limit = 0;
+// Workgroups the persistent renderer may occupy on each device (0 = one per CU).  A multi-GPU host that overlaps the RCCL
+// all-gather of chunk c with the render of chunk c+1 sets this to CUs - k on its device: the renderer fills a CU completely
+// (151 KiB LDS, every register), so RCCL's workgroups can only run on CUs it leaves free.  Per device, atomics: a host with
+// one thread per GPU can set and use its own limit without racing the others.
+static std::atomic<int> g_render_cu_limit[s2l::kMaxDevices];
 extern "C" int s2l_set_render_cus(int n_workgroups) {
   if (n_workgroups < 0) return S2L_E_SIZE;
-  g_render_cu_limit = n_workgroups;
+  int dev = 0, n_cu = 0;
+  const int rc = s2l::current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  g_render_cu_limit[dev].store(n_workgroups, std::memory_order_relaxed);
   return S2L_OK;
 }
 
@@ -341,24 +345,14 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   a.ntiles = (int)ntiles;
 
-  // per-device one-time setup (CU count, >64 KiB dynamic-LDS opt-in); one process per GPU is the
-  // normal deployment, but nothing here assumes it
-  static int n_cu_of[64] = {0};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return (int)e;
-  if (dev < 0 || dev >= 64) return S2L_E_SIZE;
-  if (n_cu_of[dev] == 0) {
-    int n = 0;
-    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_kernel<G>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    n_cu_of[dev] = n;
-  }
-  int n_cu = n_cu_of[dev];
-  if (g_render_cu_limit > 0 && g_render_cu_limit < n_cu) n_cu = g_render_cu_limit;
+  // per-device one-time setup (CU count, >64 KiB dynamic-LDS opt-in), thread-safe: s2l_common.h
+  static LdsOptIn lds_flags;
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&render_tiles_kernel<G>), kLdsBytes, lds_flags, dev))) return rc;
+  const int limit = g_render_cu_limit[dev].load(std::memory_order_relaxed);
+  if (limit > 0 && limit < n_cu) n_cu = limit;
   // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
   hipLaunchKernelGGL((render_tiles_kernel<G>), dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);

@@ -369,21 +369,12 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(RowsBwdArgs a) {
   wait_vmcnt_r<0>();
 }
 
-static int rows_grid(int ntiles, const void* kernel, int* grid) {
-  static int n_cu_of[64] = {0};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return (int)e;
-  if (dev < 0 || dev >= 64) return S2L_E_SIZE;
-  if (n_cu_of[dev] == 0) {
-    int n = 0;
-    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
-    n_cu_of[dev] = n;
-  }
-  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);   // idempotent, per device
-  if (e != hipSuccess) return (int)e;
-  *grid = ntiles < n_cu_of[dev] ? ntiles : n_cu_of[dev];
+static int rows_grid(int ntiles, const void* kernel, LdsOptIn& flags, int* grid) {
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  if ((rc = ensure_dynamic_lds(kernel, kLdsBytes, flags, dev))) return rc;
+  *grid = ntiles < n_cu ? ntiles : n_cu;
   return 0;
 }
 
@@ -393,7 +384,8 @@ int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsav
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   RowsFwdArgs a{packed, x, out, hsave, n_rows, (int)ntiles};
   int grid = 0;
-  int rc = rows_grid(a.ntiles, reinterpret_cast<const void*>(&rows_fwd_kernel<G>), &grid);
+  static LdsOptIn flags;
+  int rc = rows_grid(a.ntiles, reinterpret_cast<const void*>(&rows_fwd_kernel<G>), flags, &grid);
   if (rc) return rc;
   hipLaunchKernelGGL((rows_fwd_kernel<G>), dim3(grid), dim3(256), kLdsBytes, st, a);
   return (int)hipGetLastError();
@@ -406,10 +398,30 @@ int launch_rows_bwd(const float* packed, const float* drgb, const float* hsave, 
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   RowsBwdArgs a{packed, drgb, hsave, dzsave, dxa, n_rows, (int)ntiles};
   int grid = 0;
-  int rc = rows_grid(a.ntiles, reinterpret_cast<const void*>(&rows_bwd_kernel<G>), &grid);
+  static LdsOptIn flags;
+  int rc = rows_grid(a.ntiles, reinterpret_cast<const void*>(&rows_bwd_kernel<G>), flags, &grid);
   if (rc) return rc;
   hipLaunchKernelGGL((rows_bwd_kernel<G>), dim3(grid), dim3(256), kLdsBytes, st, a);
   return (int)hipGetLastError();
 }
 
 }  // namespace s2l
+
+// s2l_rgb_forward: the exact drop-in for TalkingFace.rgb_forward (tf_nerf.py:225-285) on arbitrary [N,66] rows: embed the
+// rows (frontend.hip), then the general-row MLP above.  The clip renderer (s2l_render_lip) lives in render.hip.
+namespace s2l {
+int launch_embed_rows(const float* packed, const float* uv_audio, int64_t time_index, float* x, int64_t n_rows,
+                      hipStream_t st);
+}
+
+extern "C" int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf, float* out,
+                               int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows < 0) return S2L_E_SIZE;
+  if (n_rows == 0) return S2L_OK;
+  if (!packed || !uv_audio || !xbuf || !out) return S2L_E_NULL;
+  if (s2l::misaligned16(packed) || s2l::misaligned16(xbuf)) return S2L_E_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = s2l::launch_embed_rows(packed, uv_audio, time_index, xbuf, n_rows, st);
+  if (rc) return rc;
+  return s2l::launch_rows_fwd(packed, xbuf, out, nullptr, n_rows, st);
+}

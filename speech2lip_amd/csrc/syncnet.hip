@@ -285,10 +285,16 @@ __global__ __launch_bounds__(64) void cosine_bce_kernel(const float* __restrict_
   const float inv_den = 1.f / sqrtf(den2);
   const float d = sav * inv_den;
   const float yy = y[b];
-  const float loss = -(yy * fmaxf(logf(d), -100.f) + (1.f - yy) * fmaxf(logf(1.f - d), -100.f));
+  // nn.BCELoss rejects inputs outside [0,1] (ATen: "all elements of input should be between 0 and 1" on the CPU, a device-side
+  // assert on CUDA): a negative cosine -- embeddings that are not post-ReLU, a corrupted checkpoint -- must not train silently
+  // against a clamped target.  A kernel cannot raise, so the loss AND its gradient become NaN, which the trainer's NaN scan
+  // (check_weights, training.py:560) turns into the same hard stop.  (fmaxf would drop the NaN of logf(d<0): test first.)
+  const bool in_range = d >= 0.f && d <= 1.f;
+  const float nan = __builtin_nanf("");
+  const float loss = in_range ? -(yy * fmaxf(logf(d), -100.f) + (1.f - yy) * fmaxf(logf(1.f - d), -100.f)) : nan;
   if (l == 0) losses[b] = loss * scale;
   if (dv) {
-    const float gd = (d - yy) / fmaxf((1.f - d) * d, 1e-12f) * scale;
+    const float gd = in_range ? (d - yy) / fmaxf((1.f - d) * d, 1e-12f) * scale : nan;
     // dd/dv = a / den - d * v / |v|^2   (the eps clamp is inactive for unit vectors)
     const float c1 = gd * inv_den, c2 = gd * d / fmaxf(svv, 1e-30f);
     for (int i = l; i < dim; i += 64) dv[(int64_t)b * dim + i] = c1 * ab[i] - c2 * vb[i];

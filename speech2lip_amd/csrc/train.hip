@@ -13,8 +13,8 @@
 
 namespace s2l {
 
-int launch_general_mlp(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
-int launch_general_mlp_bwd(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa,
+int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st);
+int launch_rows_bwd(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa,
                            int64_t n_rows, hipStream_t st);
 
 __device__ inline f4 mfma16w(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -183,7 +183,7 @@ extern "C" int s2l_train_forward(const float* packed, const float* x, float* hsa
   if (n_rows == 0) return S2L_OK;
   if (!packed || !x || !hsave || !rgb) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(x) || misaligned16(hsave)) return S2L_E_ALIGN;
-  return launch_general_mlp(packed, x, rgb, hsave, n_rows, static_cast<hipStream_t>(stream));
+  return launch_rows_fwd(packed, x, rgb, hsave, n_rows, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int s2l_train_backward(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa,
@@ -192,7 +192,7 @@ extern "C" int s2l_train_backward(const float* packed, const float* drgb, const 
   if (n_rows == 0) return S2L_OK;
   if (!packed || !drgb || !hsave || !dzsave || !dxa) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(hsave) || misaligned16(dzsave) || misaligned16(dxa)) return S2L_E_ALIGN;
-  return launch_general_mlp_bwd(packed, drgb, hsave, dzsave, dxa, n_rows, static_cast<hipStream_t>(stream));
+  return launch_rows_bwd(packed, drgb, hsave, dzsave, dxa, n_rows, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t s2l_split_work_floats(int64_t n_elems) { return n_elems < 0 ? 0 : (n_elems + 256) * kSplitBlocks; }

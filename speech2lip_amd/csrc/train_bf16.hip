@@ -818,15 +818,14 @@ extern "C" int s2l_pack_bf16(const float* const* tensors_host, const float* pack
   return (int)hipGetLastError();
 }
 
-static int n_cu_of_device() {
-  static int cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cache[dev]) {
-    hipDeviceProp_t p;
-    cache[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }
-  return cache[dev];
+// grid size of the persistent kernels + the >64 KiB dynamic-LDS opt-in, per device and thread-safe (s2l_common.h)
+static int persistent_grid(const void* kernel, int lds_bytes, LdsOptIn& flags, int n_tiles, int* grid) {
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  if ((rc = ensure_dynamic_lds(kernel, lds_bytes, flags, dev))) return rc;
+  *grid = n_tiles < n_cu ? n_tiles : n_cu;
+  return 0;
 }
 
 extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const uint16_t* xT, uint16_t* hT,
@@ -835,21 +834,15 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   if (n_rows == 0) return S2L_OK;
   if (!packed_bf16 || !packed_f32 || !xT || !hT || !masks || !rgb) return S2L_E_NULL;
   if (misaligned16(packed_bf16) || misaligned16(xT) || misaligned16(hT) || misaligned16(masks)) return S2L_E_ALIGN;
-  static bool attr_set[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kLdsFwd);
-    if (e != hipSuccess) return (int)e;
-    attr_set[dev] = true;
-  }
   FwdArgs a;
   const int64_t np = s2l_bf16_rows_padded(n_rows);
   a.wb = packed_bf16, a.pf = packed_f32, a.xT = xT, a.hT = hT, a.masks = masks, a.rgb = rgb;
   a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
   a.n_tiles = (int)(np / kWgRows);
-  const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
+  static LdsOptIn flags;
+  int grid = 0;
+  const int rc = persistent_grid(reinterpret_cast<const void*>(fwd_bf16_kernel), kLdsFwd, flags, a.n_tiles, &grid);
+  if (rc) return rc;
   hipLaunchKernelGGL(fwd_bf16_kernel, dim3(grid), dim3(512), kLdsFwd, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
@@ -860,21 +853,15 @@ extern "C" int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float*
   if (n_rows == 0) return S2L_OK;
   if (!packed_bf16 || !drgb || !masks || !dzT || !dxa) return S2L_E_NULL;
   if (misaligned16(packed_bf16) || misaligned16(dzT) || misaligned16(dxa) || misaligned16(masks)) return S2L_E_ALIGN;
-  static bool attr_set[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kLdsBwd);
-    if (e != hipSuccess) return (int)e;
-    attr_set[dev] = true;
-  }
   BwdArgs a;
   const int64_t np = s2l_bf16_rows_padded(n_rows);
   a.wb = packed_bf16, a.drgb = drgb, a.masks = masks, a.dzT = dzT, a.dxa = dxa;
   a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
   a.n_tiles = (int)(np / kWgRows);
-  const int grid = a.n_tiles < n_cu_of_device() ? a.n_tiles : n_cu_of_device();
+  static LdsOptIn flags;
+  int grid = 0;
+  const int rc = persistent_grid(reinterpret_cast<const void*>(bwd_bf16_kernel), kLdsBwd, flags, a.n_tiles, &grid);
+  if (rc) return rc;
   hipLaunchKernelGGL(bwd_bf16_kernel, dim3(grid), dim3(512), kLdsBwd, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
@@ -890,18 +877,13 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
   const int n_tiles = (int)(s2l_bf16_rows_padded(n_rows) / 64);
   const int parts = n_tiles < kWgParts ? n_tiles : kWgParts;
   float* bpart = work + (int64_t)kWgParts * 256 * 256;
-  static bool attr_set[64][2];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  const int which = k_in == 256 ? 0 : 1;
-  if (dev >= 0 && dev < 64 && !attr_set[dev][which]) {
-    hipError_t e = which == 0 ? hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<256>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<256>::kLds)
-                              : hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<128>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<128>::kLds);
-    if (e != hipSuccess) return (int)e;
-    attr_set[dev][which] = true;
-  }
+  static LdsOptIn flags256, flags128;
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  rc = k_in == 256 ? ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_bf16_kernel<256>), WgCfg<256>::kLds, flags256, dev)
+                   : ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_bf16_kernel<128>), WgCfg<128>::kLds, flags128, dev);
+  if (rc) return rc;
   if (k_in == 256)
     hipLaunchKernelGGL(wgrad_bf16_kernel<256>, dim3(parts), dim3(256), WgCfg<256>::kLds, st, dzT, inT, work, bpart, n_tiles);
   else

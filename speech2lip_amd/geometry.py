@@ -26,8 +26,9 @@ def _rel_pose(canonical_euler, canonical_trans, euler, trans, mode: int) -> torc
     if e.shape != t.shape or ce.numel() < 3 or ct.numel() < 3:
         raise ValueError("euler/trans must be [F,3]; canonical_euler/canonical_trans [3] or [1,3]")
     out = torch.empty(e.shape[0], 4, 4, device=dev, dtype=torch.float32)
-    _abi.check(_abi.load().s2l_rel_pose(_ptr(e), _ptr(t), _ptr(ce), _ptr(ct), mode, _ptr(out), e.shape[0], _stream()),
-               "s2l_rel_pose")
+    with torch.cuda.device(dev):   # launch on the tensors' device and ITS current stream, whatever torch's current device is
+        _abi.check(_abi.load().s2l_rel_pose(_ptr(e), _ptr(t), _ptr(ce), _ptr(ct), mode, _ptr(out), e.shape[0], _stream()),
+                   "s2l_rel_pose")
     return out
 
 
@@ -67,8 +68,11 @@ def warp_grid(depth: torch.Tensor, rel_pose: torch.Tensor, focal: float, clamp: 
     if grid.shape != (F, H, W, 2) or not grid.is_contiguous() or grid.dtype != torch.float32:
         raise ValueError("out must be a contiguous fp32 [F,H,W,2] tensor")
     z = torch.empty(F, 1, H, W, device=dev, dtype=torch.float32) if return_z else None
-    _abi.check(_abi.load().s2l_warp_grid(_ptr(d), stride, _ptr(T), float(focal), int(bool(clamp)), _ptr(grid), _ptr(z), H, W, F,
-                                         _stream()), "s2l_warp_grid")
+    if grid.device != dev:
+        raise ValueError(f"out is on {grid.device}, rel_pose on {dev}")
+    with torch.cuda.device(dev):
+        _abi.check(_abi.load().s2l_warp_grid(_ptr(d), stride, _ptr(T), float(focal), int(bool(clamp)), _ptr(grid), _ptr(z), H, W,
+                                             F, _stream()), "s2l_warp_grid")
     return (grid, z) if return_z else grid
 
 
@@ -86,8 +90,9 @@ def grid_sample(img_nhwc: torch.Tensor, grid: torch.Tensor, padding_mode: str = 
     IH, IW = im.shape[-3:-1]
     pad = {"zeros": _abi.S2L_SAMPLE_ZEROS, "border": _abi.S2L_SAMPLE_BORDER}[padding_mode]
     out = torch.empty(F, Ho, Wo, 3, device=dev, dtype=torch.float32)
-    _abi.check(_abi.load().s2l_grid_sample(_ptr(im), 0 if im.dim() == 3 else IH * IW * 3, _ptr(g), _ptr(out), IH, IW, Ho, Wo,
-                                           pad, F, _stream()), "s2l_grid_sample")
+    with torch.cuda.device(dev):
+        _abi.check(_abi.load().s2l_grid_sample(_ptr(im), 0 if im.dim() == 3 else IH * IW * 3, _ptr(g), _ptr(out), IH, IW, Ho,
+                                               Wo, pad, F, _stream()), "s2l_grid_sample")
     return out
 
 

@@ -290,6 +290,9 @@ class TalkingFace(nn.Module):
             pad = lw // 12 if "obama2_face_crop" in self.data_path else lw // 5   # tf_nerf.py:357-360
         else:
             pad = -1
+        if out is not None and (out.shape != (B, FH, FW, 3) or out.dtype != torch.float32 or not out.is_contiguous()
+                                or out.device != dev):
+            raise ValueError(f"out must be a contiguous fp32 [{B},{FH},{FW},3] tensor on {dev}")
         new = out if out is not None else torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev)
         can = torch.empty(B, FH, FW, 3, dtype=torch.float32, device=dev) if want_canonical else None
         fs, ms = stride(face, "rgb_face_canonical"), stride(mask, "mask_lip_canonical")
@@ -344,13 +347,14 @@ class TalkingFace(nn.Module):
         p0, p5 = self.pixel_tables(height, width)
         if out is None:
             out = torch.empty(F, int(height), int(width), 3, dtype=torch.float32, device=dev)
-        elif out.shape != (F, int(height), int(width), 3) or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError("out must be a contiguous fp32 [F,H,W,3] tensor")
+        elif (out.shape != (F, int(height), int(width), 3) or out.dtype != torch.float32 or not out.is_contiguous()
+              or out.device != dev):
+            raise ValueError(f"out must be a contiguous fp32 [F,H,W,3] tensor on {dev}")
         feat = torch.empty(F, 64, dtype=torch.float32, device=dev)
         q0 = torch.empty(F, 256, dtype=torch.float32, device=dev)
         q5 = torch.empty_like(q0)
-        st = _stream()
         with torch.cuda.device(dev):
+            st = _stream()      # the current stream OF dev: read it inside the guard
             _abi.check(lib.s2l_audio_encode(_ptr(packed), _ptr(a), _ptr(feat), F, st), "s2l_audio_encode")
             _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat), _ptr(idx), _ptr(q0), _ptr(q5), F, st),
                        "s2l_frame_vectors")

@@ -228,3 +228,26 @@ def synthetic_sync_batch(batch: int, seed: int = 0, frames_t: int = 5, height: i
     pos = np.clip(base[None, None, None] + 0.4 * (u("pos", batch * 3 * frames_t * height * width).reshape(batch, 3, frames_t, height, width) - 0.5), 0, 1)
     neg = np.clip(base[None, None, None, ::-1] + 0.4 * (u("neg", batch * 3 * frames_t * height * width).reshape(batch, 3, frames_t, height, width) - 0.5), 0, 1)
     return mel, pos.astype(np.float32), np.ascontiguousarray(neg).astype(np.float32)
+
+
+def synthetic_warp_coords(n_frames: int, face_h: int = 500, face_w: int = 500, seed: int = 4) -> np.ndarray:
+    """Surrogate `coords/%05d.npy`: float32 [N,FH,FW,2] = the identity grid of
+    F.grid_sample(align_corners=False) + a per-frame rigid perturbation (rotation <= 3 deg, shift <= 0.02) + N(0,1e-3)
+    jitter, clamped to [-1,1] as /root/reference/preprocess/face_tracker.py:606 clamps the real grids."""
+    def u(name, n):
+        return uniform01(n, _stream_id("warp." + name, seed))
+    ys, xs = np.meshgrid(np.arange(face_h), np.arange(face_w), indexing="ij")
+    ident = np.stack([(2 * xs + 1) / face_w - 1, (2 * ys + 1) / face_h - 1], -1)          # [FH,FW,2] (x, y)
+    ang = (u("angle", n_frames) - 0.5) * (6.0 * np.pi / 180.0)
+    rot = np.stack([np.stack([np.cos(ang), -np.sin(ang)], -1), np.stack([np.sin(ang), np.cos(ang)], -1)], -2)   # [N,2,2]
+    shift = (u("shift", n_frames * 2).reshape(n_frames, 1, 1, 2) - 0.5) * 0.04
+    n = n_frames * face_h * face_w * 2
+    jitter = np.sqrt(-2.0 * np.log(1.0 - u("j1", n))) * np.cos(2.0 * np.pi * u("j2", n)) * 1e-3
+    grid = np.einsum("hwk,fjk->fhwj", ident, rot) + shift + jitter.reshape(n_frames, face_h, face_w, 2)
+    return np.clip(grid, -1.0, 1.0).astype(np.float32)
+
+
+def synthetic_image(shape, seed: int, name: str = "img") -> np.ndarray:
+    """uniform(0,1) float32 image(s) of `shape` from the same counter-based generator (seeds 2, 3)."""
+    n = int(np.prod(shape))
+    return uniform01(n, _stream_id("image." + name, seed)).astype(np.float32).reshape(shape)

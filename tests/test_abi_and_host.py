@@ -129,3 +129,32 @@ def test_get_coords_matches_reference_grid(golden):
         if key.startswith("coords_"):
             w, h = map(int, key[len("coords_"):].split("x"))
             assert torch.equal(s2l.get_coords(w, h, torch.device("cpu")), torch.from_numpy(g[key])), key
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_requested():
+    """`bench.py --gpus N` outside torchrun spawns its own ranks; with fewer visible GPUs than N it must fail loudly instead
+    of printing a line whose n_gpus differs from --gpus (this container has no GPU at all)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--gpus 2 requested but only" in (r.stderr + r.stdout)
+    assert "n_gpus" not in r.stdout
+    # under a launcher whose world size disagrees with --gpus the line is refused as well
+    env.update(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_synthetic_generators_are_deterministic():
+    a, b = W.synthetic_warp_coords(2, 20, 24, seed=4), W.synthetic_warp_coords(2, 20, 24, seed=4)
+    assert a.shape == (2, 20, 24, 2) and a.dtype == "float32" and (a == b).all() and abs(a).max() <= 1.0
+    assert not (W.synthetic_warp_coords(2, 20, 24, seed=5) == a).all()
+    # near the identity grid of grid_sample(align_corners=False): centre of pixel (y,x) -> ((2x+1)/W-1, (2y+1)/H-1)
+    assert abs(a[0, 10, 12, 0] - (25 / 24 - 1)) < 0.08 and abs(a[0, 10, 12, 1] - (21 / 20 - 1)) < 0.08
+    img = W.synthetic_image((3, 4, 3), 2)
+    assert img.min() >= 0 and img.max() < 1 and (img == W.synthetic_image((3, 4, 3), 2)).all()

@@ -1,0 +1,238 @@
+"""BASELINE.json's configurations at their stated sizes, through the C-ABI on the GPU.
+
+  C2  96x96, 1000 synthetic audio frames (the bench workload): frames incl. the partial last frame tile vs the oracle,
+      sub-clip bit-equality.
+  C3  128x128 lip + paste/head-pose-warp composite into 500x500, per-clip constants (table path, XCD regions),
+      then the U-Net on the same frames, against the oracle chain.
+  C4  frame indices near 40 000 (the 40k-frame clip of the 8-GPU configuration).
+  C5  the bf16 training step at batch 64, 96x96: vs the fp32 parity-mode step, a teacher-forced sample of its rows vs
+      the CPU emulation, and -- at a size the oracle's autograd finishes in seconds -- bf16 gradients directly vs the oracle.
+
+Sizes the oracle cannot finish in seconds are covered through size-independent properties (determinism, frame
+independence: any sub-clip renders to the same bits) plus sampled frames.  Tolerances as tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from oracle import s2l_oracle as O
+from speech2lip_amd import weights as W
+from tests.test_gpu_parity import close, make_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return O.to_sd(W.make_state_dict(0, "he"))
+
+
+def test_config2_1000_frames_96(sd, dev):
+    """1000 = 83 x 12 + 4: the last frame tile of every pixel group is partial."""
+    h = w = 96
+    f = 1000
+    m = make_model(dev, h, w)
+    win = T(W.synthetic_audio(f, seed=1).astype(np.float32)).to(dev)
+    idx = torch.arange(f, device=dev)
+    clip = m.render_clip(win, idx, h, w)
+    assert torch.equal(clip, m.render_clip(win, idx, h, w))                         # deterministic
+    assert torch.equal(m.render_clip(win[990:], idx[990:], h, w), clip[990:])       # 10-frame tail: other tiling, same bits
+    assert torch.equal(m.render_clip(win[492:504], idx[492:504], h, w), clip[492:504])
+    with torch.no_grad():
+        for k in (0, 499, 995, 996, 999):
+            ref = O.render_clip(sd, win[k:k + 1].cpu(), [k], h, w)[0]
+            close(clip[k], ref)
+            assert O.psnr(clip[k].cpu(), ref) >= 90.0
+
+
+def test_config4_frame_indices_near_40000(sd, dev):
+    """The time encoding at the far end of a 40 000-frame clip (sin/cos arguments up to 4e4): golden G1 pins the
+    oracle there on the CPU; this is the device path."""
+    h = w = 96
+    m = make_model(dev, h, w)
+    idx = list(range(39990, 40000))
+    win = T(W.synthetic_audio(len(idx), seed=4).astype(np.float32))
+    out = m.render_clip(win.to(dev), idx, h, w)
+    with torch.no_grad():
+        for k in (0, 4, 9):
+            ref = O.render_clip(sd, win[k:k + 1], [idx[k]], h, w)[0]
+            close(out[k], ref)
+    # the general-row path at the same index
+    feat = m.audio_merge_forward(win[9:10].to(dev))
+    rows = torch.cat([s2l.get_coords(w, h, dev), feat.expand(h * w, -1)], -1)
+    close(m.rgb_forward(rows, time_pts=torch.tensor([39999])), out[9].reshape(-1, 3).cpu())
+
+
+def _config3_inputs(dev, F, seed=0):
+    h = w = 128
+    FH = FW = 500
+    x0, y0 = 186, 300
+    face = T(W.synthetic_image((1, FH, FW, 3), 2, "face"))
+    gt = T(W.synthetic_image((F, FH, FW, 3), 3, "gt"))
+    mask = torch.zeros(1, FH, FW, 3)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    # a soft band like the JPEG-decoded mask of the dataset (someones_lip_dataset.py:72): the blend must lerp
+    mask[:, y0:y0 + 3, x0:x0 + w] = T(W.synthetic_image((3, w, 3), 5, "soft"))
+    coord = T(W.synthetic_warp_coords(F, FH, FW, seed=4 + seed))
+    return h, w, FH, FW, x0, y0, face, gt, mask, coord
+
+
+def test_config3_composite_500_with_128_lip(sd, dev):
+    """128x128 lip pasted at (186,300) into 500x500 faces, 8 frames, per-clip face/mask -> fused-table path with the
+    XCD-region block mapping at its real size."""
+    F = 8
+    h, w, FH, FW, x0, y0, face, gt, mask, coord = _config3_inputs(dev, F)
+    m = make_model(dev, h, w)
+    win = T(W.synthetic_audio(F, seed=1).astype(np.float32))
+    idx = list(range(100, 100 + F))
+    lip = m.render_clip(win.to(dev), idx, h, w)
+    with torch.no_grad():
+        ref_lip = O.render_clip(sd, win, idx, h, w)
+    close(lip, ref_lip)
+    new, can = m.composite_clip(lip, face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev), want_canonical=True)
+    ref_new, ref_can = O.composite(lip.cpu(), face.expand(F, -1, -1, -1), gt, mask.expand(F, -1, -1, -1), x0, y0, coord)
+    assert torch.equal(can.cpu(), ref_can)                       # elementwise: bit-exact
+    close(new, ref_new, 1e-6, 2e-5)                              # bilinear weights of fp32 coordinates at 500x500
+    assert O.psnr(new.cpu(), ref_new) >= 100.0
+    # batched == single frame, table path == per-frame-constants path
+    one, _ = m.composite_clip(lip[5:6], face.to(dev), gt[5:6].to(dev), mask.to(dev), x0, y0, coord[5:6].to(dev))
+    assert torch.equal(one[0], new[5])
+    slow, _ = m.composite_clip(lip, face.expand(F, -1, -1, -1).contiguous().to(dev), gt.to(dev),
+                               mask.expand(F, -1, -1, -1).contiguous().to(dev), x0, y0, coord.to(dev))
+    assert torch.equal(slow, new)
+    # every pixel outside the warped rectangle is the observed frame, untouched
+    changed = (new.cpu() != gt).any(-1)
+    assert 0.05 < float(changed.float().mean()) < 0.25
+
+
+def test_config3_chain_render_composite_unet_vs_oracle(sd, dev):
+    """The whole inference output of inference.py:140-178 for two frames at config-3 size: render -> composite -> U-Net
+    through the drop-in `post_fusion2_onlylip`, against the oracle chain."""
+    F = 2
+    h, w, FH, FW, x0, y0, face, gt, mask, coord = _config3_inputs(dev, F, seed=1)
+    m = make_model(dev, h, w)
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    win = T(W.synthetic_audio(F, seed=2).astype(np.float32))
+    lip = m.render_clip(win.to(dev), [7, 8], h, w)
+    recon, new, can = m.post_fusion2_onlylip(lip, face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev))
+    usd = O.to_sd(W.make_unet_state_dict(0))
+    with torch.no_grad():
+        ref_lip = O.render_clip(sd, win, [7, 8], h, w)
+        ref_new, ref_can = O.composite(ref_lip, face.expand(F, -1, -1, -1), gt, mask.expand(F, -1, -1, -1), x0, y0, coord)
+        ref_recon = O.unet_forward(usd, ref_new)
+    close(new, ref_new, 2e-6, 3e-5)
+    close(can, ref_can, 1e-6, 1e-4)          # the lip itself carries the MLP's fp32 re-association here
+    close(recon, ref_recon, 1e-5, 1e-4)
+    assert O.psnr(recon.cpu(), ref_recon) >= 90.0
+
+
+def test_config5_bf16_step_batch64_96(dev):
+    """BASELINE config 5 at its stated size: 64 frames, 96x96 (9 216 row tiles of 256, 20 GB of saved state) in bf16,
+    against the fp32 parity-mode step on the same inputs (itself pinned to oracle autograd + the reference's gradients)."""
+    h = w = 96
+    B = 64
+    m = make_model(dev, h, w)
+    rng = np.random.default_rng(64)
+    win = T(W.synthetic_audio(B, seed=17).astype(np.float32)).to(dev)
+    idx = [3 + 7 * b for b in range(B)]
+    u01 = [float(v) for v in rng.random(B)]
+    targets = T(rng.random((B, h * w, 3), dtype=np.float32)).to(dev)
+    loss16, g16, aux16 = s2l.LipTrainStep(m, h, w, precision="bf16").loss_and_grads(win, idx, targets, u01)
+    pred16 = aux16["pred"].cpu()
+    g16 = {k: v.cpu() for k, v in g16.items()}
+    del aux16
+    torch.cuda.empty_cache()
+    loss32, g32, aux32 = s2l.LipTrainStep(m, h, w).loss_and_grads(win, idx, targets, u01)
+    assert abs(float(loss16) - float(loss32)) <= 5e-3 * abs(float(loss32))
+    assert O.rmse(pred16, aux32["pred"].cpu()) <= 1e-2
+    assert set(g16) == set(g32)
+    for k in g32:
+        a, b = g16[k].double().flatten(), g32[k].cpu().double().flatten()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert rel <= 5e-2 and cos >= 0.999, f"{k}: rel {rel:.3e} cos {cos:.6f}"
+    # frames are independent in the forward: frame 40 of the batch == the same frame alone (bit for bit)
+    _, _, aux1 = s2l.LipTrainStep(m, h, w, precision="bf16").loss_and_grads(win[40:41], idx[40:41], targets[40:41], u01[40:41])
+    assert torch.equal(aux1["pred"].cpu()[0], pred16[40])
+
+
+def test_config5_bf16_kernels_batch64_sampled_rows(dev):
+    """Forward and backward bf16 kernels at the batch-64 row count (2.36 M rows): 64-row tiles sampled from the whole range
+    against the step-wise CPU emulation of the same arithmetic (as test_bf16_kernels_multi_tile_workgroups at 2 frames)."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    from tests import bf16_util as U
+    from tests.test_gpu_parity import _bf16_inputs
+    m, lib, x, N = _bf16_inputs(dev, 96, 96, 64)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    assert Np // 256 == 9216
+    hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    dzT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+    rgb, dxa = torch.empty(N, 3, device=dev), torch.empty(N, 64, device=dev)
+    pb, pf = m.packed_weights_bf16(), m.packed_weights()
+    drgb = (torch.randn(N, 3, generator=torch.Generator().manual_seed(3)) * 1e-3).to(dev)
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()), "bwd")
+    tiles = [0, 255 * 4 + 1, 256 * 4 + 2, 5000 * 4 + 3, 9215 * 4, Np // 64 - 1]
+    rows = torch.cat([torch.arange(t * 64, t * 64 + 64) for t in tiles])
+
+    def sample(buf, nl):     # rows `rows` of every layer without converting the whole 9.7 GB buffer
+        lay = Np * 256
+        out = []
+        for L in range(nl):
+            per = []
+            for t in tiles:
+                g32 = (t * 64) // 32
+                seg = buf[L * lay + g32 * 8192: L * lay + (g32 + 2) * 8192]
+                per.append(U.tiles_to_rows(seg, 1, 64)[0])
+            out.append(torch.cat(per))
+        return torch.stack(out)
+
+    h_d, g_d = sample(hT, 8), sample(dzT, 8)
+    mk_all = masks.reshape(8, Np // 64, 256)
+    mk = torch.cat([U.masks_to_rows(mk_all[:, t].reshape(-1), 64) for t in tiles], dim=1)        # [8, rows, 256]
+    sd_ = O.to_sd(W.make_state_dict(0, "he"))
+    fold = U.folded_from_blob(pf)
+    with torch.no_grad():
+        h_tf = U.forward_teacher_forced(sd_, x[rows.to(dev)].cpu(), h_d, fold)
+        g_e, dxa_e = U.backward_teacher_forced(sd_, drgb[rows.to(dev)].cpu(), mk, g_d, fold)
+    for L in range(8):
+        U.assert_bf16_close(h_d[L], h_tf[L], f"h{L}")
+        d = (g_d[L] - g_e[L]).abs()
+        scale = float(g_e[L].abs().max())
+        assert bool((d <= 2.0 ** -7 * g_e[L].abs() * 1.01 + 1e-6 * scale).all()), (L, float(d.max()), scale)
+    assert bool((mk == (h_d > 0)).all())
+    assert float((dxa.cpu()[rows] - dxa_e).abs().max()) <= 1e-5 * float(dxa_e.abs().max())
+
+
+@pytest.mark.parametrize("h,w,B", [(12, 20, 3)])
+def test_bf16_step_gradients_directly_vs_oracle_autograd(dev, h, w, B):
+    """bf16 mode one hop from the oracle (not via the HIP fp32 mode): loss, prediction and all 42 gradients against torch
+    autograd through the CPU oracle.  bf16 carries 8 significant bits: relative L2 <= 5 %, cosine >= 0.999."""
+    from tests.test_gpu_parity import _oracle_grads
+    np_sd = W.make_state_dict(0, "he")
+    m = make_model(dev, h, w)
+    rng = np.random.default_rng(21)
+    win = T(W.synthetic_audio(B, seed=17).astype(np.float32))
+    idx = [5 + 11 * b for b in range(B)]
+    u01 = [0.37, 0.81, 0.05][:B]
+    targets = T(rng.random((B, h * w, 3), dtype=np.float32))
+    ref_loss, ref, ref_pred = _oracle_grads(np_sd, win, idx, targets, u01, h, w, weight=1.0)
+    loss, g, aux = s2l.LipTrainStep(m, h, w, precision="bf16").loss_and_grads(win.to(dev), idx, targets.to(dev), u01)
+    assert abs(float(loss) - ref_loss) <= 5e-3 * abs(ref_loss)
+    assert O.rmse(aux["pred"].cpu(), ref_pred) <= 1e-2
+    assert set(ref) <= set(g)
+    for k in ref:
+        a, b = g[k].cpu().double().flatten(), ref[k].double().flatten()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert rel <= 5e-2 and cos >= 0.999, f"{k}: rel {rel:.3e} cos {cos:.6f}"

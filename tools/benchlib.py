@@ -1,0 +1,181 @@
+"""Measurement functions shared by bench.py (`extra` object, configs 3 and 5) and the per-row CLI tools under tools/.
+Every function takes a device, runs on synthetic inputs resident in HBM (SURVEY.md §8d recipe, generators in
+speech2lip_amd/weights.py), times with HIP events on the current stream and returns a JSON-able dict."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import speech2lip_amd as s2l  # noqa: E402
+from speech2lip_amd import weights as W  # noqa: E402
+
+HBM_PEAK = 8.0e12
+FP32_MFMA_PEAK = 157.3e12
+BF16_MFMA_PEAK = 2.5e15
+
+
+def lip_flops_per_frame(hw: int) -> int:
+    """SURVEY.md §8d official (factored) figure."""
+    return 2 * 459_520 * hw + 2 * (67_328 + 43_008 + 131_072)
+
+
+def make_model(dev, h, w, unet=False, train=False):
+    m = s2l.TalkingFace(dev, s2l.may_config(h, w))
+    m = m.train() if train else m.eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
+    if unet:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
+    return m
+
+
+def device_warp_coords(dev, n, FH=500, FW=500, seed=2):
+    """Device-side twin of weights.synthetic_warp_coords (same recipe, torch generator) for sizes where 2 MB/frame of
+    host-generated grids would dominate the set-up time."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(FH, device=dev), torch.arange(FW, device=dev), indexing="ij")
+    ident = torch.stack([(2 * xs + 1) / FW - 1, (2 * ys + 1) / FH - 1], -1).float()
+    ang = (torch.rand(n, device=dev, generator=g) - 0.5) * (6 * np.pi / 180)          # rotation <= 3 deg
+    rot = torch.stack([torch.stack([ang.cos(), -ang.sin()], -1), torch.stack([ang.sin(), ang.cos()], -1)], -2)
+    shift = (torch.rand(n, 1, 1, 2, device=dev, generator=g) - 0.5) * 0.04
+    jit = torch.randn(n, FH, FW, 2, device=dev, generator=g) * 1e-3
+    return (torch.einsum("hwk,fjk->fhwj", ident, rot) + shift + jit).clamp(-1, 1).contiguous(), g
+
+
+def _median_ms(fn, reps=6, inner=10):
+    """Median over `reps` event pairs, each around `inner` back-to-back calls (host launch latency stays out)."""
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs])) / inner
+
+
+def bench_composite(dev, frames=256, check=True):
+    """A7 alone at BASELINE config 3 geometry: 128x128 lip in a 500x500 face.  HBM-bound: 8,000,000 + 12 h w B/frame."""
+    h = w = 128
+    FH = FW = 500
+    x0, y0 = 186, 300
+    m = make_model(dev, h, w)
+    coord, g = device_warp_coords(dev, frames)
+    lip = torch.rand(frames, h, w, 3, device=dev, generator=g)
+    face = torch.rand(1, FH, FW, 3, device=dev, generator=g)
+    gt = torch.rand(frames, FH, FW, 3, device=dev, generator=g)
+    mask = torch.zeros(1, FH, FW, 3, device=dev)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    out = torch.empty(frames, FH, FW, 3, device=dev)
+    run = lambda: m.composite_clip(lip, face, gt, mask, x0, y0, coord, out=out)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ms = _median_ms(run)
+    bpf = 8_000_000 + 12 * h * w
+    gbs = bpf * frames / (ms * 1e-3) / 1e9
+    res = {"kernel": "s2l::composite_kernel", "frames": frames, "ms": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": round(gbs * 1e9 / HBM_PEAK, 4), "algorithmic_bytes_per_frame": bpf}}
+    if check:
+        from oracle import s2l_oracle as O
+        rn, _ = O.composite(lip[:1].cpu(), face.cpu(), gt[:1].cpu(), mask.cpu(), x0, y0, coord[:1].cpu())
+        d = (out[:1].cpu() - rn).abs()
+        res["parity_frame0"] = {"max_abs_err": float(d.max()), "pixels_off_by_more_than_1e-5": int((d > 1e-5).sum())}
+    return res
+
+
+def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
+    """BASELINE config 3 end to end: 128x128 lip render for n frames + composite into 500x500 (+ optionally the U-Net)."""
+    h = w = 128
+    FH = FW = 500
+    x0, y0 = 186, 300
+    m = make_model(dev, h, w, unet=True)
+    audio = torch.from_numpy(W.synthetic_audio(n, 1).astype(np.float32)).to(dev)
+    coord, g = device_warp_coords(dev, batch)      # one batch of pose grids / observed frames, reused (content-independent timing)
+    face = torch.rand(1, FH, FW, 3, device=dev, generator=g)
+    gt = torch.rand(batch, FH, FW, 3, device=dev, generator=g)
+    mask = torch.zeros(1, FH, FW, 3, device=dev)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    lip = torch.empty(batch, h, w, 3, device=dev)
+    out = torch.empty(batch, FH, FW, 3, device=dev)
+    recon = torch.empty(batch, FH, FW, 3, device=dev) if unet else None
+
+    def run():
+        for s in range(0, n, batch):
+            k = min(batch, n - s)
+            m.render_clip(audio[s:s + k], torch.arange(s, s + k, device=dev), h, w, out=lip[:k])
+            m.composite_clip(lip[:k], face, gt[:k], mask, x0, y0, coord[:k], out=out[:k])
+            if unet:
+                m.post_fusion_unet.forward_nhwc(out[:k], out=recon[:k])
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fl = lip_flops_per_frame(h * w)
+    res = {"config": f"config 3: {n} frames, 128x128 lip + composite into 500x500" + (" + post-fusion U-Net" if unet else "")
+           + f", batches of {batch}", "seconds": round(dt, 3), "frames_per_s": round(n / dt, 1),
+           "lip_gflop_per_frame": round(fl / 1e9, 3), "lip_tflops": round(fl * n / dt / 1e12, 1)}
+    if check:
+        from oracle import s2l_oracle as O
+        s = (n - 1) // batch * batch
+        sd = O.to_sd(W.make_state_dict(0, "he"))
+        with torch.no_grad():
+            ref_lip = O.render_clip(sd, audio[s:s + 1].cpu(), [s], h, w)
+            ref_new, _ = O.composite(ref_lip, face.cpu(), gt[:1].cpu(), mask.cpu(), x0, y0, coord[:1].cpu())
+        par = {"lip_rmse": float(f"{O.rmse(lip[0].cpu(), ref_lip[0]):.3e}"),
+               "composite_rmse": float(f"{O.rmse(out[0].cpu(), ref_new[0]):.3e}"),
+               "composite_psnr_db": round(O.psnr(out[0].cpu(), ref_new[0]), 1)}
+        if unet:
+            with torch.no_grad():
+                ref_recon = O.unet_forward(O.to_sd(W.make_unet_state_dict(0)), ref_new)
+            par["unet_rmse"] = float(f"{O.rmse(recon[0].cpu(), ref_recon[0]):.3e}")
+            par["unet_psnr_db"] = round(O.psnr(recon[0].cpu(), ref_recon[0]), 1)
+        res["parity"] = par
+    return res
+
+
+def train_flops(B, hw=96 * 96):
+    """as-written model, fwd + dgrad + wgrad, 4 ensemble taps."""
+    return 3 * 4 * 2 * 644_864 * hw * B
+
+
+def bench_train(dev, B=64, precision="bf16", steps=5):
+    """BASELINE config 5: one step = 4-tap ensemble forward + MSE + full backward + Adam for B frames at 96x96."""
+    H = Wd = 96
+    m = make_model(dev, H, Wd, train=True)
+    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith("coord_linears")], lr=1e-4)
+    audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
+    target = torch.rand(B, H * Wd, 3, device=dev)
+    step = s2l.LipTrainStep(m, H, Wd, precision=precision)
+    u01 = [0.5] * B
+
+    def one():
+        loss, g, _ = step.loss_and_grads(audio, list(range(B)), target, u01)
+        s2l.training.apply_grads(m, g)
+        opt.step()
+        return loss
+    l0 = float(one())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = train_flops(B, H * Wd)
+    peak = BF16_MFMA_PEAK if precision == "bf16" else FP32_MFMA_PEAK
+    return {"config": f"training step, {B} frames 96x96, {precision}" + (" parity mode" if precision == "fp32" else
+            " MFMA, fp32 accumulate + master weights") + ", Adam", "ms_per_step": round(dt * 1e3, 2),
+            "frames_per_s": round(B / dt, 1), "as_written_tflop_per_step": round(fl / 1e12, 3),
+            "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / peak, 4), "loss_first": l0,
+            "loss_last": float(l), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "_step": step,
+            "_one": one}

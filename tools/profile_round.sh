@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 C="python $R/tools/bench_composite.py 256"
 $B > $O/bench_line.json 2> $O/bench.err
 $C > $O/composite_line.json 2> $O/composite.err
