@@ -114,6 +114,12 @@ int s2l_set_render_cus(int n_workgroups);
 int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf,
                     float* out, int64_t n_rows, s2l_stream_t stream);
 
+/* The embedding half of s2l_rgb_forward on its own: x [N,128] = [E(uv) 42 | audio 64 | PE(time_index) 20 | 0 0] per row
+ * (Embedder.__call__ tf_nerf.py:404-425 on the uv columns, PositionalEncodingTime :434-442), for callers that run
+ * s2l_train_forward / _backward on it (the autograd of rgb_forward). */
+int s2l_embed_rows(const float* packed, const float* uv_audio, int64_t time_index, float* x, int64_t n_rows,
+                   s2l_stream_t stream);
+
 /* 4-tap local-ensemble forward of the training step for one frame
  * (Trainer.predict_lip_image, src/face_simple/training.py:158-251): the MLP at
  * clamp(coords + (vx*0.5/W + eps, vy*0.5/H + eps), 0, 1), vx,vy in {-1,1}, eps = (0.5/H)*u01/2,
@@ -137,6 +143,11 @@ int s2l_ensemble_rows(const float* packed, const float* coords, const float* fea
                       s2l_stream_t stream);
 int s2l_ensemble_reduce(const float* pred, const float* areas, float* out, int64_t n_pixels,
                         s2l_stream_t stream);
+/* s2l_ensemble_rows for a whole batch of frames in one launch: feat [F,64], time_index int64 [F] and u01 fp32 [F] on the
+ * device; frame f owns rows [4 f HW, 4 (f+1) HW) of x [F*4*HW,128] and areas [F*4*HW]. */
+int s2l_ensemble_rows_batch(const float* packed, const float* coords, const float* feat, const int64_t* time_index,
+                            const float* u01, int width, int height, float* x, float* areas, int64_t n_pixels,
+                            int64_t n_frames, s2l_stream_t stream);
 /* d pred [N,3] -> d rgb of the four taps [4N,3]. */
 int s2l_ensemble_backward(const float* dpred, const float* areas, float* drgb, int64_t n_pixels,
                           s2l_stream_t stream);
@@ -165,6 +176,20 @@ int s2l_wgrad(const float* dz, int ldz, const float* in, int ldin, int k_in, flo
  * (bias gradients).  work: s2l_split_work_floats(m*c). */
 int s2l_small_outer(const float* a, int lda, int m, const float* b, int ldb, int c, float* work,
                     float* out, int64_t n_rows, s2l_stream_t stream);
+/* out [S,c] = column sums of each segment of rows_per_segment consecutive rows of src [S*rows_per_segment, ld] (c <= 256
+ * dividing 256): the per-frame gradient of the audio feature from dxa, i.e. the adjoint of `.tile(1, HW, 1)` (training.py:171).
+ * work: S*32*c floats.  Fixed summation order. */
+int s2l_segment_colsums(const float* src, int ld, int c, int64_t rows_per_segment, int64_t n_segments, float* work,
+                        float* out, s2l_stream_t stream);
+/* Gradients of the tensors behind the pack-time fold of the first / skip layer (G = Wf [Wuv|Wa|Wt], c = Wf (buv+ba+bt) + bf;
+ * tf_nerf.py:252-258, :269-281 followed by pts_linears[0] / the left half of pts_linears[5]): from dG [256,128] and dc [256]
+ * (the weight / bias gradients s2l_wgrad returns for the folded layer) to d_first (the gradient of Wf, written to columns 0..255
+ * of a [256, ld_first] tensor; `right` [256,256], when given with ld_first 512, is copied to columns 256..511), d_w_uv [256,42],
+ * d_w_audio [256,64], d_w_time [256,20] and d_bias [256] (the common gradient of the three fc biases). */
+int s2l_unfold_first_layer(const float* dG, const float* dc, const float* first_w, int ld_first, const float* w_uv,
+                           const float* w_audio, const float* w_time, const float* b_uv, const float* b_audio,
+                           const float* b_time, const float* right, float* d_first, float* d_w_uv, float* d_w_audio,
+                           float* d_w_time, float* d_bias, s2l_stream_t stream);
 /* Audio-encoder backward (autograd of tf_nerf.py:197-213): windows [B,16,29], dfeat [B,64] ->
  * grads [s2l_audio_grad_floats()]: encoder_conv.{0,2,4,6}.{weight,bias}, encoder_fc1.{0,2}.{weight,bias}
  * concatenated in that order, torch layouts.  work: ceil(B/4) * s2l_audio_grad_floats() floats. */
@@ -193,7 +218,26 @@ int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride
                   float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w,
                   int x0, int y0, int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream);
 
-/* Optional per-clip precompute for s2l_composite: bgm [FH,FW,4] = ((1-mask)*face_canon, 0), the
+/* Training branch of the same composite (post_fusion2_onlylip_light with use_post_fusion_blackaug=True, tf_nerf.py:371-384;
+ * called so at training.py:436/445): hole1, hole2 [F,FH,FW] are the two N(0,1) fields `add_black_hole` (:306-318) draws with
+ * torch.randn (channel 0 of a randn of the image shape), passed in by the caller WHEN the coin `random.random() > 0.5` of :371
+ * came up; both NULL = the inference branch (s2l_composite is exactly that).  A hole is punched where the draw is < 1e-6
+ * inside mask_face_observed = (grid_sample(face_canon > 0, coord) == 1): hole pixels of the merged image show rgb_gt and hole
+ * pixels of rgb_gt show the merged image. */
+int s2l_composite_train(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
+                        int64_t mask_stride, const float* rgb_gt, const float* coord, const float* hole1,
+                        const float* hole2, float* out_new, float* out_canonical, const float* bgm, int lip_h, int lip_w,
+                        int face_h, int face_w, int x0, int y0, int pad_mode, int expand_pad, int64_t n_frames,
+                        s2l_stream_t stream);
+/* d lip of either branch: what loss.backward() (training.py:559) propagates from rgb_merged_new into rgb_lip_warped through
+ * tf_nerf.py:339-386 (F.pad, the mask lerp, F.grid_sample, the blends).  d_new [F,FH,FW,3] -> d_lip [F,h,w,3] (overwritten).
+ * The scatter into the lip box uses hardware float atomics: the summation order is not fixed (as ATen's grid_sample backward). */
+int s2l_composite_backward_lip(const float* d_new, const float* face_canon, int64_t face_stride, const float* mask,
+                               int64_t mask_stride, const float* coord, const float* hole1, const float* hole2,
+                               float* d_lip, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0, int pad_mode,
+                               int expand_pad, int64_t n_frames, s2l_stream_t stream);
+
+/* Optional per-clip precompute for s2l_composite: bgm [FH,FW,4] = ((1-mask)*face_canon, bits of face_canon > 0), the
  * background term of tf_nerf.py:352 as one 16-byte-aligned gather target (16-byte aligned). */
 int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm, int face_h, int face_w,
                          s2l_stream_t stream);
@@ -211,6 +255,29 @@ int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames);
 int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
 int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height,
                      int width, int64_t n_frames, s2l_stream_t stream);
+
+/* Training: the same network keeping every activation (saved: s2l_unet_saved_floats(H, W, F) floats), and
+ * its INPUT gradient d_out [F,H,W,3] -> d_x [F,H,W,3] (work: s2l_unet_backward_work_floats(H, W, F) floats of scratch) -- what
+ * autograd propagates through the frozen eval-mode post_fusion_unet once `it > 100000` (train.py:188-197) from the sync loss
+ * (training.py:491-557) and the face photometric loss (:458-459) back to the composite.  Needs the pack of this library
+ * version (s2l_unet_pack also writes the transposed, tap-mirrored chunks the input-gradient convolutions read). */
+int64_t s2l_unet_saved_floats(int height, int width, int64_t n_frames);
+int64_t s2l_unet_backward_work_floats(int height, int width, int64_t n_frames);
+int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, float* out, int height, int width,
+                           int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x, int height,
+                      int width, int64_t n_frames, s2l_stream_t stream);
+
+/* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
+ * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with
+ * F.interpolate(mode='bilinear', align_corners=False), no antialiasing).  src [F,src_h,src_w,3]; box = data['canonical_face_bbox'];
+ * dst [F,out_h,out_w,3] when window_t == 0, or the rgb_window layout [F/T,3,T,out_h,out_w] (:547-548) with frame f = s*T + t
+ * when window_t == T > 0.  s2l_crop_resize_backward: d_dst (same layout) -> d_src [F,src_h,src_w,3], zero outside the box
+ * (deterministic gather, no atomics). */
+int s2l_crop_resize(const float* src, int src_h, int src_w, int x, int y, int x2, int y2, float* dst, int out_h, int out_w,
+                    int window_t, int64_t n_frames, s2l_stream_t stream);
+int s2l_crop_resize_backward(const float* d_dst, int src_h, int src_w, int x, int y, int x2, int y2, float* d_src, int out_h,
+                             int out_w, int window_t, int64_t n_frames, s2l_stream_t stream);
 
 /* ---- pose -> warp grid -----------------------------------------------------------
  * s2l_rel_pose replaces prepare_transform_matrix + compute_rel_pose* (src/face_simple/models/utils.py:36-77;

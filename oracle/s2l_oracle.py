@@ -166,7 +166,7 @@ def _grid_sample_bilinear_zeros(img: torch.Tensor, grid: torch.Tensor) -> torch.
 def composite(lip: torch.Tensor, face_canon: torch.Tensor, rgb_gt: torch.Tensor, mask: torch.Tensor,
               x0: int, y0: int, coord: torch.Tensor, pad_mode: int = PAD_MODE_MAY,
               expand_lip_mask: bool = True, pad_div: int = 5,
-              use_builtin_grid_sample: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+              use_builtin_grid_sample: bool = True, blackaug=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Paste + head-pose-warp composite up to (not including) the U-Net.
     lip [B,h,w,3]; face_canon/rgb_gt/mask [B,FH,FW,3]; coord [B,FH,FW,2]
     -> (rgb_merged_new [B,FH,FW,3], rgb_merged_canonical [B,FH,FW,3]).
@@ -175,7 +175,11 @@ def composite(lip: torch.Tensor, face_canon: torch.Tensor, rgb_gt: torch.Tensor,
     (x0,y0) [pad_mode may] or (x0-1,y0-1) [default] (:339-350); (2) lerp with the soft lip
     mask (:352); (3) rectangular expanded mask rows [y0-p, y0+h+2p), cols [x0-p, x0+w+p),
     p = w // pad_div (:354-364); (4) bilinear zero-padded grid_sample of image and mask,
-    mask binarised by !=0 (:366-369); (6) blend with the observed frame (:386)."""
+    mask binarised by !=0 (:366-369); (5) training only, `blackaug` = (n1, n2): the two N(0,1) fields [B,FH,FW] that
+    `add_black_hole` (:306-318) draws with torch.randn (channel 0 of a randn of the image shape), when the coin
+    `random.random() > 0.5` of :371 came up -- holes are punched where a draw is < 1e-6 inside the warped canonical face
+    (grid_sample of `face_canon > 0` equal to exactly 1): hole pixels of the merged image show the observed frame and
+    hole pixels of the observed frame show the merged image (:371-384); (6) blend with the observed frame (:386)."""
     B, h, w, _ = lip.shape
     FH, FW = face_canon.shape[1:3]
     ox, oy = (x0, y0) if pad_mode == PAD_MODE_MAY else (x0 - 1, y0 - 1)
@@ -193,7 +197,18 @@ def composite(lip: torch.Tensor, face_canon: torch.Tensor, rgb_gt: torch.Tensor,
     warped = gs(merged_c.permute(0, 3, 1, 2))
     mw = gs(m.permute(0, 3, 1, 2))
     mw = (mw != 0).to(lip.dtype)
-    merged_new = mw * warped + (1 - mw) * rgb_gt.permute(0, 3, 1, 2)
+    gt = rgb_gt.permute(0, 3, 1, 2)
+    if blackaug is not None:
+        face_obs = gs((face_canon > 0).to(lip.dtype).permute(0, 3, 1, 2))
+        face_obs = (face_obs == 1).to(lip.dtype)                                    # :374
+        keep = []
+        for n in blackaug:
+            noise = (n.unsqueeze(1) >= 0.000001).to(lip.dtype)                      # :309-310: 0 = hole, 1 = keep
+            keep.append(noise * face_obs + torch.ones_like(noise) * (1 - face_obs))  # :315 (then `!= 0 -> 1`, a no-op on 0/1)
+        before = warped
+        warped = keep[0] * before + (1 - keep[0]) * gt                              # :382
+        gt = keep[1] * gt + (1 - keep[1]) * before                                  # :383
+    merged_new = mw * warped + (1 - mw) * gt
     return merged_new.permute(0, 2, 3, 1).contiguous(), merged_c
 
 
@@ -379,6 +394,72 @@ def sync_contrastive_loss(sd: SD, mel, g_rgb_pos, g_rgb_neg, blocks_face, blocks
     a, v = syncnet_forward(sd, mel, sync_window(g_rgb_neg, syncnet_T), blocks_face, blocks_audio)
     neg = cosine_loss(a, v, torch.zeros(B, 1, dtype=mel.dtype))
     return pos + neg
+
+
+# --------------------------------------------------------------------------- §8f-4 (light half): sync loss into the MLP
+def crop_resize(img_nhwc: torch.Tensor, bbox, size=(96, 96)) -> torch.Tensor:
+    """training.py:541-544: `rgb_merged[:, y:y2, x:x2, :]`, then `transforms.Resize([96, 96])` on the NCHW tensor.
+    torchvision 0.9.0 (requirement.txt:34) resizes TENSORS with functional_tensor.resize ->
+    torch.nn.functional.interpolate(img, size=[h, w], mode='bilinear', align_corners=False) (no antialiasing in 0.9).
+    torchvision is not installed in this image: this function is the restatement of that one call.
+    bbox = (x, y, x2, y2) of data['canonical_face_bbox'][0].  [B,FH,FW,3] -> [B,96,96,3]."""
+    x, y, x2, y2 = (int(v) for v in bbox[:4])
+    crop = img_nhwc[:, y:y2, x:x2, :].permute(0, 3, 1, 2)
+    return F.interpolate(crop, size=list(size), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+
+def sync_chain_window(sd: SD, unet_sd: SD, coords, audio_window, index: int, total_frame: int, eps_u01, face_canon, rgb_gt,
+                      mask, x0: int, y0: int, coord_window, bbox, height: int, width: int, pad_mode: int = PAD_MODE_MAY,
+                      pad_div: int = 5) -> torch.Tensor:
+    """The generated 5-frame window of the sync loss for ONE sample (training.py:491-548): for t in 0..T-1 the 4-tap
+    ensemble render of audio_window[t] at frame index min(index + t, total_frame - 1) (:515-518), pasted and warped with
+    coord_window[t] against the MAIN frame's observed image (:527-536), through the eval-mode U-Net (the first return
+    value of post_fusion2_onlylip is rgb_recon, tf_nerf.py:387-389; the U-Net is frozen and in eval mode once the sync
+    loss is active, train.py:188-197), cropped to the canonical face box and resized to 96x96 (:541-544).
+    audio_window [T,16,29]; eps_u01: one U(0,1) draw per frame (each predict_lip_image call draws its own, :200);
+    face_canon/rgb_gt/mask [1,FH,FW,3]; coord_window [T,FH,FW,2] -> rgb_window [1,3,T,96,96] (:547-548)."""
+    frames = []
+    for t in range(audio_window.shape[0]):
+        idx = index + t if index + t < total_frame else total_frame - 1
+        lip = predict_lip_image(sd, coords, audio_window[t], idx, height, width, eps_u01[t]).reshape(1, height, width, 3)
+        new, _ = composite(lip, face_canon, rgb_gt, mask, x0, y0, coord_window[t:t + 1], pad_mode=pad_mode, pad_div=pad_div)
+        recon = unet_forward(unet_sd, new)
+        frames.append(crop_resize(recon, bbox))
+    win = torch.stack(frames, 0)                       # T,B,H,W,C
+    return win.permute(1, 4, 0, 2, 3)                  # B,C,T,H,W
+
+
+def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio, data: dict, eps_u01, hole_noise, height: int,
+                     width: int, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, w_syncloss: float = 0.01,
+                     pad_mode: int = PAD_MODE_MAY, pad_div: int = 5) -> dict:
+    """The loss of ONE reference optimisation step after `it > 100000` (Trainer.train_stage1, training.py:347-574) under the
+    May flags with the LPIPS and canonical-depth terms switched off:
+        loss = lambda_rgb * MSE(predict_lip_image, rgb)                                              (:414-418)
+             + lambda_rgb * w_post_fusion * MSE(post_fusion2_onlylip(lip, blackaug=True)[0], rgb_face_ori)   (:436-459)
+             + w_syncloss * get_sync_contrastive_loss(mel, rgb_window, rgb_window_neg)               (:491-557)
+    `data` holds the reference's batch dict entries (batch 1): audio [1,16,29], rgb [1,h,w,3], index, total_frame,
+    rgb_face_zero, rgb_face_ori, mask_lip_canonical [1,FH,FW,3], lip_lefttop_x/y, coord [1,FH,FW,2], audio_window
+    [1,T,16,29], coord_window [1,T,FH,FW,2], canonical_face_bbox [[x,y,x2,y2,score]], mel [1,1,80,16], rgb_window_neg
+    [1,3,T,96,96].  eps_u01: the 1 + T draws of torch.rand in the order the step makes them (main frame first);
+    hole_noise: None when the coin of tf_nerf.py:371 came up tails, else the two randn fields [1,FH,FW].
+    Differentiable w.r.t. `sd` (build it with requires_grad tensors)."""
+    coords = get_coords(width, height)
+    idx = int(data["index"])
+    x0, y0 = int(data["lip_lefttop_x"]), int(data["lip_lefttop_y"])
+    pred = predict_lip_image(sd, coords, data["audio"][0], idx, height, width, eps_u01[0])
+    loss_rgb = mse_loss(pred, data["rgb"].reshape(-1, 3), lambda_rgb)
+    lip = pred.reshape(1, height, width, 3)
+    new, _ = composite(lip, data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0, data["coord"],
+                       pad_mode=pad_mode, pad_div=pad_div, blackaug=hole_noise)
+    recon = unet_forward(unet_sd, new)
+    loss_face = mse_loss(recon, data["rgb_face_ori"], lambda_rgb * w_post_fusion)
+    window = sync_chain_window(sd, unet_sd, coords, data["audio_window"][0], idx, int(data["total_frame"]), eps_u01[1:],
+                               data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0,
+                               data["coord_window"][0], data["canonical_face_bbox"][0], height, width, pad_mode, pad_div)
+    loss_sync = sync_contrastive_loss(sync_sd, data["mel"], window, data["rgb_window_neg"], blocks_face, blocks_audio,
+                                      window.shape[2]) * w_syncloss
+    return {"loss": loss_rgb + loss_face + loss_sync, "loss_rgb": loss_rgb, "loss_face": loss_face, "loss_sync": loss_sync,
+            "pred": pred, "rgb_face_recon": recon, "rgb_window": window}
 
 
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:

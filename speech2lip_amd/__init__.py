@@ -4,11 +4,12 @@ from .data import ClipTensors, SomeonesLipClip, render_clip_frames, to8b, write_
 from .rendering import get_coords
 from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
 from . import training
-from .training import LipTrainStep, Trainer, predict_lip_image
+from .training import LipTrainStep, StageOneStep, SyncChain, Trainer, predict_lip_image
+from . import autograd
 from .unet import SimpleUnetLight
 from .syncnet import SyncLoss, SyncNet_color
 from . import geometry
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
-           "predict_lip_image", "LipTrainStep", "training",
+           "predict_lip_image", "LipTrainStep", "StageOneStep", "SyncChain", "training", "autograd",
            "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "SyncNet_color", "SyncLoss", "geometry"]

@@ -44,13 +44,29 @@ EXPORTS = {
     "s2l_render_lip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_set_render_cus": (c_int, [c_int]),
     "s2l_rgb_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_embed_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "s2l_composite": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_composite_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_composite_backward_lip": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_saved_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_backward_work_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_forward_saved": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_crop_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_crop_resize_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64,
+                                         c_void_p]),
     "s2l_predict_lip_image_work_floats": (c_int64, [c_int64]),
     "s2l_predict_lip_image": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p,
                                       c_int64, c_void_p]),
     "s2l_ensemble_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
                                   c_void_p]),
+    "s2l_ensemble_rows_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                        c_int64, c_void_p]),
+    "s2l_segment_colsums": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "s2l_unfold_first_layer": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 13),
     "s2l_ensemble_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_ensemble_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_ensemble_reduce_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

@@ -1,0 +1,242 @@
+"""`torch.autograd.Function`s over the hand-written forward/backward kernels, so that the reference's training loop --
+forward through the module methods, a loss built with torch ops, `loss["loss"].backward()` (src/face_simple/training.py:559),
+`optimizer.step()` -- runs unchanged on the drop-in module.
+
+Each Function's forward is the same C-ABI call the plain method makes (plus saved activations); its backward is the matching
+hand-written backward kernel.  torch's autograd engine is the plumbing that chains them (its only arithmetic here is scaling a
+stored gradient by the upstream scalar of a loss node).
+The parameters are passed to `apply` as inputs so that the engine delivers their gradients to `.grad`.
+
+    audio_encode          TalkingFace.audio_merge_forward   tf_nerf.py:197-213    backward: s2l_audio_backward
+    rgb_forward           TalkingFace.rgb_forward           tf_nerf.py:225-285    backward: s2l_train_backward + s2l_wgrad + un-fold
+    predict_lip_image     Trainer.predict_lip_image         training.py:158-251   the fused 4-tap ensemble (LipTrainStep)
+    composite             post_fusion2_onlylip_light        tf_nerf.py:320-386    backward: s2l_composite_backward_lip (d lip)
+    unet_eval             post_fusion_unet (frozen, eval)   SimpleUnetLight.py:99-111   backward: s2l_unet_backward (d input)
+    crop_resize           crop + transforms.Resize          training.py:541-544   backward: s2l_crop_resize_backward
+    sync_contrastive_loss get_sync_contrastive_loss         training.py:581-603   backward: s2l_syncnet_face_backward (d window)
+    mse                   add_photometric_loss              training.py:605-619   backward: the gradient s2l_mse returns
+Gradients flow to: the 42 hot-path parameters, the audio columns of `rgb_forward`'s rows, the lip image, the U-Net input, the
+generated sync window, the prediction of the MSE.  Inputs the reference treats as data (audio windows, pixel coordinates,
+observed frames, warp grids) get none.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _abi
+from .talking_face import _dev_f32, _ptr, _stream
+
+_MLP = slice(12, 42)
+_AUD = slice(0, 12)
+
+
+def _f(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _AudioEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, audio, *params):
+        ctx.model = model
+        a = _dev_f32(audio, model.packed_weights().device, "audio")
+        if a.dim() == 3 and a.shape[2] == 16 and a.shape[1] == 29:
+            a = a.permute(0, 2, 1).contiguous()
+        ctx.save_for_backward(a)
+        return model._audio_encode(a)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        from .training import AUDIO_TENSORS, audio_backward
+        (a,) = ctx.saved_tensors
+        with torch.cuda.device(a.device):
+            g = audio_backward(ctx.model, a, dfeat.contiguous().float(), _stream())
+        return (None, None, *[g[n] for n in AUDIO_TENSORS])
+
+
+def audio_encode(model, audio):
+    return _AudioEncode.apply(model, audio, *model._hot_tensors()[_AUD])
+
+
+class _RgbForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, rows, time_index, *params):
+        from .training import MlpState, mlp_forward
+        lib = _abi.load()
+        packed = model.packed_weights()
+        dev = packed.device
+        r = _dev_f32(rows, dev, "uv_audio_pts")
+        if r.dim() != 2 or r.shape[1] != 66:
+            raise ValueError(f"uv_audio_pts must be [N,66], got {tuple(r.shape)}")
+        n = r.shape[0]
+        st = MlpState("fp32", n, dev, lib)
+        out = _f(dev, n, 3)
+        with torch.cuda.device(dev):
+            s = _stream()
+            _abi.check(lib.s2l_embed_rows(_ptr(packed), _ptr(r), int(time_index), _ptr(st.x), n, s), "s2l_embed_rows")
+            mlp_forward(model, st, out, s)
+        ctx.model, ctx.st = model, st
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .training import MLP_TENSORS, mlp_backward
+        st = ctx.st
+        d = dout.contiguous().float()
+        with torch.cuda.device(d.device):
+            g, dxa = mlp_backward(ctx.model, st, d, _stream())
+        ctx.st = None
+        d_rows = torch.cat([torch.zeros(st.N, 2, dtype=torch.float32, device=d.device), dxa], dim=1)   # coordinates are data
+        return (None, d_rows, None, *[g[n] for n in MLP_TENSORS])
+
+
+def rgb_forward(model, rows, time_pts):
+    if time_pts is None:
+        raise ValueError("time_pts is required (model.use_time)")
+    t = int(time_pts.reshape(-1)[0].item()) if isinstance(time_pts, torch.Tensor) else int(time_pts)   # position[0] only
+    return _RgbForward.apply(model, rows, t, *model._hot_tensors()[_MLP])
+
+
+class _PredictLipImage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, audio, index, height, width, u01, *params):
+        from .training import LipTrainStep
+        step = LipTrainStep(model, height, width, "fp32")
+        pred = step.forward(audio, [index], [u01])
+        ctx.step = step
+        return pred[0]
+
+    @staticmethod
+    def backward(ctx, dpred):
+        g, _ = ctx.step.backward(dpred.contiguous().float()[None])
+        ctx.step = None
+        return (None, None, None, None, None, None, *[g[n] for n in _abi.TENSOR_ORDER])
+
+
+def predict_lip_image(model, coords, audio, index, height, width, u01):
+    """The regular-grid 4-tap ensemble of one frame with a graph (fp32 parity mode).  `coords` must be the regular pixel grid
+    of (height, width) -- what Trainer.prepare_coords returns -- because the fused kernels rebuild it."""
+    from .rendering import get_coords
+    if coords.shape[0] != height * width or not torch.equal(coords.to(torch.float32).cpu(), get_coords(width, height, "cpu")):
+        raise ValueError("predict_lip_image with autograd supports the regular pixel grid of (height, width) only")
+    if audio.shape[0] != 1:
+        raise ValueError("predict_lip_image renders one frame: audio must be [1,16,29]")
+    idx = int(index.reshape(-1)[0].item()) if isinstance(index, torch.Tensor) else int(index)
+    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), float(u01), *model._hot_tensors())
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, lip, face, gt, mask, x0, y0, coord, holes):
+        new, can = model.composite_clip(lip, face, gt, mask, x0, y0, coord, want_canonical=True, hole_noise=holes)
+        ctx.model, ctx.args, ctx.lip_hw = model, (face, mask, x0, y0, coord, holes), (lip.shape[1], lip.shape[2])
+        ctx.mark_non_differentiable(can)      # rgb_merged_canonical is a by-product no loss of the reference reads
+        return new, can
+
+    @staticmethod
+    def backward(ctx, d_new, _d_can):
+        face, mask, x0, y0, coord, holes = ctx.args
+        d_lip = ctx.model.composite_backward_lip(d_new, face, mask, x0, y0, coord, ctx.lip_hw[0], ctx.lip_hw[1], hole_noise=holes)
+        return None, d_lip, None, None, None, None, None, None, None
+
+
+def composite(model, lip, face, gt, mask, x0, y0, coord, holes=None):
+    return _Composite.apply(model, lip, face, gt, mask, x0, y0, coord, holes)
+
+
+class _UnetEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, unet, x):
+        out, saved = unet.forward_saved_nhwc(x)
+        ctx.unet, ctx.saved = unet, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dx = ctx.unet.backward_input(ctx.saved, d_out)
+        ctx.saved = None
+        return None, dx
+
+
+def unet_eval(unet, x_nhwc):
+    """Frozen eval-mode post-fusion U-Net with an input gradient (no parameter gradients: the reference has set
+    requires_grad=False on them by the time this path is used, train.py:188-197)."""
+    return _UnetEval.apply(unet, x_nhwc)
+
+
+class _CropResize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bbox, size, window_t):
+        lib = _abi.load()
+        src = x.detach().to(torch.float32).contiguous()
+        if src.device.type != "cuda":
+            raise _abi.S2LError("crop_resize: input must be on the GPU (no CPU fallback)")
+        F_, H, W, _ = src.shape
+        bx, by, bx2, by2 = (int(v) for v in bbox[:4])
+        oh, ow = int(size[0]), int(size[1])
+        out = _f(src.device, F_ // window_t, 3, window_t, oh, ow) if window_t else _f(src.device, F_, oh, ow, 3)
+        with torch.cuda.device(src.device):
+            _abi.check(lib.s2l_crop_resize(_ptr(src), H, W, bx, by, bx2, by2, _ptr(out), oh, ow, int(window_t), F_, _stream()),
+                       "s2l_crop_resize")
+        ctx.geom = (F_, H, W, bx, by, bx2, by2, oh, ow, int(window_t))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        F_, H, W, bx, by, bx2, by2, oh, ow, t = ctx.geom
+        d = d_out.contiguous().float()
+        dx = _f(d.device, F_, H, W, 3)
+        with torch.cuda.device(d.device):
+            _abi.check(_abi.load().s2l_crop_resize_backward(_ptr(d), H, W, bx, by, bx2, by2, _ptr(dx), oh, ow, t, F_, _stream()),
+                       "s2l_crop_resize_backward")
+        return dx, None, None, None
+
+
+def crop_resize(x_nhwc, bbox, size=(96, 96), window_t: int = 0):
+    """x [F,H,W,3] -> [F,oh,ow,3], or with window_t = T the rgb_window layout [F/T,3,T,oh,ow] (frame f = s*T + t)."""
+    return _CropResize.apply(x_nhwc, bbox, size, window_t)
+
+
+class _SyncLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sync, mel, pos, neg, weight):
+        loss, d_pos = sync.get_sync_contrastive_loss(mel, pos, neg, weight=weight, want_grad=True)
+        ctx.save_for_backward(d_pos)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        (d_pos,) = ctx.saved_tensors
+        return None, None, d_pos * d_loss, None, None
+
+
+def sync_contrastive_loss(sync, mel, g_rgb_pos, g_rgb_neg, weight: float = 1.0):
+    return _SyncLoss.apply(sync, mel, g_rgb_pos, g_rgb_neg, float(weight))
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        lib = _abi.load()
+        p = pred.detach().to(torch.float32).contiguous()
+        if p.device.type != "cuda":
+            raise _abi.S2LError("mse: prediction must be on the GPU (no CPU fallback)")
+        t = target.detach().to(torch.float32).contiguous().to(p.device)
+        dp, loss, work = torch.empty_like(p), _f(p.device, 1), _f(p.device, 1024)
+        with torch.cuda.device(p.device):
+            _abi.check(lib.s2l_mse(_ptr(p), _ptr(t), ctypes.c_float(float(weight)), _ptr(dp), _ptr(work), _ptr(loss), p.numel(),
+                                   _stream()), "s2l_mse")
+        ctx.save_for_backward(dp)
+        ctx.shape = pred.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        (dp,) = ctx.saved_tensors
+        return (dp * d_loss).reshape(ctx.shape), None, None
+
+
+def mse(prediction, target, weights: float = 1.0):
+    """mean((prediction - target)^2) * weights (training.py:605-619, mask=None)."""
+    return _Mse.apply(prediction, target, weights)

@@ -21,7 +21,9 @@ struct CompArgs {
   const float* coord;  // [F,FH,FW,2]
   float* out_new;      // [F,FH,FW,3]
   float* out_can;      // [F,FH,FW,3] or null
-  const float* bgm;    // optional per-clip table [FH,FW,4] = ((1-mask)*face, 0) from s2l_composite_tables, or null
+  const float* bgm;    // optional per-clip table [FH,FW,4] = ((1-mask)*face, face>0 bits) from s2l_composite_tables, or null
+  const float* hole1;  // training-time black-hole augmentation (tf_nerf.py:371-384): the two N(0,1) fields [F,FH,FW] that
+  const float* hole2;  //   add_black_hole draws; both null = inference branch
   int64_t face_stride, mask_stride, total;
   int h, w, FH, FW;
   int ox, oy;          // paste origin of the lip in the face frame
@@ -63,6 +65,31 @@ __device__ __forceinline__ Px blend_px(const Px& m, const Px& l, const Px& fv) {
   return r;
 }
 
+// Black-hole augmentation (tf_nerf.py:306-318, 371-384).  mask_face_observed = grid_sample(face_canon > 0) == 1 per channel
+// (the same taps and weights as the image; a 0/1 image makes every product exact, so the fma chain below is the plain
+// left-to-right sum ATen forms); a hole is punched where the pixel's N(0,1) draw is < 1e-6 inside that mask.  With
+// keep_k = !(inside && draw_k < 1e-6):   merged' = keep_1 ? merged : gt,   gt' = keep_2 ? gt : merged,
+// out = M ? merged' : gt'  =>  the warped image shows where (M && keep_1) || (!M && !keep_2).
+struct HoleSel {
+  bool hole1[3], hole2[3];
+};
+__device__ __forceinline__ HoleSel hole_select(const CompArgs& a, int64_t idx, const float (&wgt)[4], const int (&fbits)[4]) {
+  const bool h1 = __builtin_nontemporal_load(a.hole1 + idx) < 0.000001f;
+  const bool h2 = __builtin_nontemporal_load(a.hole2 + idx) < 0.000001f;
+  HoleSel hs;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float fo = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fo = fmaf((fbits[t] >> c) & 1 ? 1.f : 0.f, wgt[t], fo);
+    const bool inside = fo == 1.f;
+    hs.hole1[c] = inside && h1;
+    hs.hole2[c] = inside && h2;
+  }
+  return hs;
+}
+__device__ __forceinline__ bool warped_shows(bool M, const HoleSel& hs, int c) { return M ? !hs.hole1[c] : hs.hole2[c]; }
+
 // One thread per output pixel; grid.y = frame.  All eight table gathers (mask + face at the four
 // bilinear taps) are issued up front with clamped addresses and zeroed weights for out-of-range
 // taps -- no per-tap branches, so the loads overlap instead of serialising on L2 latency.  The
@@ -86,7 +113,7 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
 
   Px m[4], fv[4], l[4];
   float wgt[4];
-  int lipoff[4], moff[4];
+  int lipoff[4], moff[4], fbits[4];
   bool inlip[4];
   bool anylip = false;
 #pragma unroll
@@ -105,11 +132,13 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
     if (BGM) {
       const f4 b = *reinterpret_cast<const f4*>(a.bgm + (yc * a.FW + xc) * 4);   // one aligned 16-byte gather
       fv[t] = Px{{b[0], b[1], b[2]}};           // (1-mask)*face, already rounded as the reference rounds it
+      fbits[t] = (int)b[3];                     // bit c: face_canon[c] > 0 (only the black-hole augmentation reads it)
       moff[t] = o;
       m[t] = Px{{0.f, 0.f, 0.f}};
     } else {
       m[t] = load_px(mask + o);
       fv[t] = load_px(face + o);
+      fbits[t] = (fv[t].c[0] > 0.f ? 1 : 0) | (fv[t].c[1] > 0.f ? 2 : 0) | (fv[t].c[2] > 0.f ? 4 : 0);
     }
   }
   if (__any(anylip || (BGM && !rect))) {
@@ -139,8 +168,14 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
     }
   }
   float res[3];
+  if (a.hole1) {   // training branch (wave-uniform): black holes inside the warped canonical face
+    const HoleSel hs = hole_select(a, idx, wgt, fbits);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) res[c] = macc[c] != 0.f ? acc[c] : gt.c[c];
+    for (int c = 0; c < 3; ++c) res[c] = warped_shows(macc[c] != 0.f, hs, c) ? acc[c] : gt.c[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) res[c] = macc[c] != 0.f ? acc[c] : gt.c[c];
+  }
   store_px_stream(a.out_new + idx * 3, res);
 
   if (a.out_can) {
@@ -189,7 +224,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     if (live[i]) composite_pixel<BGM>(a, face, mask, lip, f * per + pix[i], pix[i], g[i], gt[i]);
 }
 
-// Per-clip table for the fast path: bgm[p] = ((1-mask[p]) * face[p] (3 floats), 0): 16-byte pixels.
+// Per-clip table for the fast path: bgm[p] = ((1-mask[p]) * face[p] (3 floats), bits of face[p] > 0): 16-byte pixels.
 __global__ void composite_tables_kernel(const float* __restrict__ face, const float* __restrict__ mask,
                                         float* __restrict__ bgm, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -198,8 +233,86 @@ __global__ void composite_tables_kernel(const float* __restrict__ face, const fl
   f4 bg;
 #pragma unroll
   for (int c = 0; c < 3; ++c) bg[c] = __fmul_rn(__fsub_rn(1.f, m.c[c]), f.c[c]);
-  bg[3] = 0.f;
+  bg[3] = (float)((f.c[0] > 0.f ? 1 : 0) | (f.c[1] > 0.f ? 2 : 0) | (f.c[2] > 0.f ? 4 : 0));   // for the black-hole mask
   *reinterpret_cast<f4*>(bgm + 4 * i) = bg;
+}
+
+// ---- gradient with respect to the lip (training: the autograd of tf_nerf.py:339-386 for rgb_lip_warped) -----------------
+// out = sel ? sum_t wgt[t] * (mask[t] * lip[t] + (1-mask[t]) * face[t]) : gt   =>   d lip[tap t] += mask[t] * wgt[t] * d out
+// for the taps inside the lip box, where sel is the forward's choice (expanded-rectangle / warped-mask test, black holes).
+// One thread per output pixel; waves that touch no lip pixel leave after the coordinate load (most of the frame).  The
+// scatter is a hardware float atomic (global_atomic_add_f32): the summation order, and so the last bit, is not fixed --
+// as for ATen's grid_sample backward.
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a, const float* __restrict__ d_new, float* __restrict__ d_lip) {
+  const int per = a.FH * a.FW;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  if (pix >= per) return;
+  const int64_t idx = f * per + pix;
+  const float2 g = *reinterpret_cast<const float2*>(a.coord + 2 * idx);
+  const bool rect = a.ry0 >= 0;
+  const float ix = __fsub_rn(__fmul_rn(__fadd_rn(g.x, 1.f), 0.5f * (float)a.FW), 0.5f);
+  const float iy = __fsub_rn(__fmul_rn(__fadd_rn(g.y, 1.f), 0.5f * (float)a.FH), 0.5f);
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float wx = ix - xw, ex = 1.f - wx, ny = iy - yn, sy = 1.f - ny;
+  const float wraw[4] = {__fmul_rn(sy, ex), __fmul_rn(sy, wx), __fmul_rn(ny, ex), __fmul_rn(ny, wx)};
+  const int x0 = (int)fminf(fmaxf(xw, -2.f), (float)a.FW + 1.f);
+  const int y0 = (int)fminf(fmaxf(yn, -2.f), (float)a.FH + 1.f);
+  float wgt[4];
+  int lipoff[4], toff[4];
+  bool inlip[4], anylip = false;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const bool ok = (unsigned)xx < (unsigned)a.FW && (unsigned)yy < (unsigned)a.FH && xw + (float)(t & 1) == (float)xx &&
+                    yn + (float)(t >> 1) == (float)yy;
+    wgt[t] = ok ? wraw[t] : 0.f;
+    const int xc = min(max(xx, 0), a.FW - 1), yc = min(max(yy, 0), a.FH - 1);
+    toff[t] = yc * a.FW + xc;
+    const int ly = yc - a.oy, lx = xc - a.ox;
+    inlip[t] = ok && (unsigned)ly < (unsigned)a.h && (unsigned)lx < (unsigned)a.w;
+    lipoff[t] = (ly * a.w + lx) * 3;
+    anylip |= inlip[t];
+  }
+  if (!anylip) return;
+  const float* face = a.face + f * a.face_stride;
+  const float* mask = a.mask + f * a.mask_stride;
+  Px m[4];
+  int fbits[4];
+  float macc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    m[t] = load_px(mask + toff[t] * 3);
+    fbits[t] = 0;
+    if (a.hole1) {
+      const Px fv = load_px(face + toff[t] * 3);
+      fbits[t] = (fv.c[0] > 0.f ? 1 : 0) | (fv.c[1] > 0.f ? 2 : 0) | (fv.c[2] > 0.f ? 4 : 0);
+    }
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const float mr = (yy >= a.ry0 && yy < a.ry1 && xx >= a.rx0 && xx < a.rx1) ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) macc[c] = fmaf(rect ? mr : m[t].c[c], wgt[t], macc[c]);
+  }
+  const Px d = load_px(d_new + idx * 3);
+  float dw[3];
+  if (a.hole1) {
+    const HoleSel hs = hole_select(a, idx, wgt, fbits);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dw[c] = warped_shows(macc[c] != 0.f, hs, c) ? d.c[c] : 0.f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dw[c] = macc[c] != 0.f ? d.c[c] : 0.f;
+  }
+  float* dl = d_lip + f * (int64_t)a.h * a.w * 3;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (!inlip[t]) continue;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = m[t].c[c] * wgt[t] * dw[c];
+      if (v != 0.f) unsafeAtomicAdd(dl + lipoff[t] + c, v);
+    }
+  }
 }
 
 }  // namespace s2l
@@ -214,21 +327,19 @@ extern "C" int s2l_composite_tables(const float* face_canon, const float* mask, 
   return (int)hipGetLastError();
 }
 
-extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
-                             int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
-                             float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w, int x0,
-                             int y0, int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
-  if (n_frames > 0 && (!lip || !face_canon || !mask || !rgb_gt || !coord || !out_new)) return S2L_E_NULL;
+// shared argument checks + geometry of the forward and backward entry points
+static int composite_args(s2l::CompArgs& a, const float* face_canon, int64_t face_stride, const float* mask, int64_t mask_stride,
+                          const float* coord, const float* hole1, const float* hole2, int lip_h, int lip_w, int face_h,
+                          int face_w, int x0, int y0, int pad_mode, int expand_pad, int64_t n_frames) {
   if (lip_h <= 0 || lip_w <= 0 || face_h <= 0 || face_w <= 0 || n_frames < 0) return S2L_E_SIZE;
   const int64_t per = (int64_t)face_h * face_w;
   if ((face_stride != 0 && face_stride != per * 3) || (mask_stride != 0 && mask_stride != per * 3)) return S2L_E_SIZE;
   if (pad_mode != S2L_PAD_MAY && pad_mode != S2L_PAD_DEFAULT) return S2L_E_SIZE;
+  if ((hole1 == nullptr) != (hole2 == nullptr)) return S2L_E_NULL;
   if (n_frames == 0) return S2L_OK;
-  if ((reinterpret_cast<uintptr_t>(coord) & 7) || s2l::misaligned16(bgm)) return S2L_E_ALIGN;
-  s2l::CompArgs a;
-  a.lip = lip; a.face = face_canon; a.mask = mask; a.gt = rgb_gt; a.coord = coord;
-  a.out_new = out_new; a.out_can = out_canonical;
-  a.bgm = (face_stride == 0 && mask_stride == 0) ? bgm : nullptr;   // the table is per clip
+  if (!face_canon || !mask || !coord) return S2L_E_NULL;
+  if (reinterpret_cast<uintptr_t>(coord) & 7) return S2L_E_ALIGN;
+  a.face = face_canon; a.mask = mask; a.coord = coord; a.hole1 = hole1; a.hole2 = hole2;
   a.face_stride = face_stride; a.mask_stride = mask_stride; a.total = per * n_frames;
   a.h = lip_h; a.w = lip_w; a.FH = face_h; a.FW = face_w;
   a.ox = pad_mode == S2L_PAD_MAY ? x0 : x0 - 1;
@@ -245,6 +356,23 @@ extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t 
     a.ry0 = a.ry1 = a.rx0 = a.rx1 = -1;
   }
   if (per * 6 > 0x7fffffff) return S2L_E_SIZE;   // 32-bit in-frame offsets
+  return S2L_OK;
+}
+
+extern "C" int s2l_composite_train(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
+                                   int64_t mask_stride, const float* rgb_gt, const float* coord, const float* hole1,
+                                   const float* hole2, float* out_new, float* out_canonical, const float* bgm, int lip_h,
+                                   int lip_w, int face_h, int face_w, int x0, int y0, int pad_mode, int expand_pad,
+                                   int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames > 0 && (!lip || !rgb_gt || !out_new)) return S2L_E_NULL;
+  s2l::CompArgs a;
+  const int rc = composite_args(a, face_canon, face_stride, mask, mask_stride, coord, hole1, hole2, lip_h, lip_w, face_h, face_w,
+                                x0, y0, pad_mode, expand_pad, n_frames);
+  if (rc || n_frames == 0) return rc;
+  if (s2l::misaligned16(bgm)) return S2L_E_ALIGN;
+  a.lip = lip; a.gt = rgb_gt; a.out_new = out_new; a.out_can = out_canonical;
+  a.bgm = (face_stride == 0 && mask_stride == 0) ? bgm : nullptr;   // the table is per clip
+  const int64_t per = (int64_t)face_h * face_w;
   a.rsize = (int)((per + 7) / 8);
   a.chunks = (a.rsize + 256 * s2l::kPPT - 1) / (256 * s2l::kPPT);
   const int64_t blocks = 8 * (int64_t)a.chunks * n_frames;
@@ -253,5 +381,33 @@ extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t 
     hipLaunchKernelGGL(s2l::composite_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else
     hipLaunchKernelGGL(s2l::composite_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
+                             int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
+                             float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w, int x0,
+                             int y0, int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
+  return s2l_composite_train(lip, face_canon, face_stride, mask, mask_stride, rgb_gt, coord, nullptr, nullptr, out_new,
+                             out_canonical, bgm, lip_h, lip_w, face_h, face_w, x0, y0, pad_mode, expand_pad, n_frames, stream);
+}
+
+extern "C" int s2l_composite_backward_lip(const float* d_new, const float* face_canon, int64_t face_stride, const float* mask,
+                                          int64_t mask_stride, const float* coord, const float* hole1, const float* hole2,
+                                          float* d_lip, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
+                                          int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames > 0 && (!d_new || !d_lip)) return S2L_E_NULL;
+  s2l::CompArgs a;
+  const int rc = composite_args(a, face_canon, face_stride, mask, mask_stride, coord, hole1, hole2, lip_h, lip_w, face_h, face_w,
+                                x0, y0, pad_mode, expand_pad, n_frames);
+  if (rc || n_frames == 0) return rc;
+  if (n_frames > 65535) return S2L_E_SIZE;
+  a.lip = nullptr; a.gt = nullptr; a.out_new = nullptr; a.out_can = nullptr; a.bgm = nullptr; a.rsize = a.chunks = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(d_lip, 0, sizeof(float) * 3 * (size_t)lip_h * lip_w * n_frames, st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t per = (int64_t)face_h * face_w;
+  hipLaunchKernelGGL(s2l::composite_bwd_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, a, d_new,
+                     d_lip);
   return (int)hipGetLastError();
 }

@@ -52,6 +52,43 @@ __global__ __launch_bounds__(256) void ensemble_rows_kernel(const float* __restr
   if (k0 == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;   // training.py:240-241
 }
 
+// The same rows for a whole batch of frames in one launch (blockIdx.y = frame): frame b owns rows [4 b n, 4 (b+1) n) of x /
+// areas; its audio feature, frame index and U(0,1) draw come from device arrays (no host round trip per frame).
+__global__ __launch_bounds__(256) void ensemble_rows_batch_kernel(const float* __restrict__ packed, const float* __restrict__ coords,
+                                                                 const float* __restrict__ feat, const int64_t* __restrict__ time_index,
+                                                                 const float* __restrict__ u01, float rx, float ry,
+                                                                 float* __restrict__ x, float* __restrict__ areas, int64_t n) {
+  const int64_t b = blockIdx.y;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int k0 = (threadIdx.x & 31) * 4;
+  if (row >= 4 * n) return;
+  const int t = (int)(row / n);
+  const int64_t p = row - (int64_t)t * n;
+  const float eps = ry * u01[b] / 2.0f;                       // (0.5/H) * U / 2 in fp32, as tap_shifts()
+  const float dx = ((t >> 1) ? rx : -rx) + eps, dy = ((t & 1) ? ry : -ry) + eps;
+  const float time_pos = (float)time_index[b];
+  const float u0 = coords[2 * p], v0 = coords[2 * p + 1];
+  const float cu = fminf(fmaxf(u0 + dx, 0.f), 1.f);
+  const float cv = fminf(fmaxf(v0 + dy, 0.f), 1.f);
+  f4 val;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    float v;
+    if (k < kEmb) v = embed_feature_f(cu, cv, k);
+    else if (k < kEmb + kAud) v = feat[b * kAud + k - kEmb];
+    else if (k < kEmb + kAud + kTime) {
+      const int i = k - kEmb - kAud;
+      const float arg = time_pos * packed[OFF_DIV + (i >> 1)];
+      v = (i & 1) ? cosf(arg) : sinf(arg);
+    } else v = 0.f;
+    val[j] = v;
+  }
+  const int64_t grow = b * 4 * n + row;
+  *reinterpret_cast<f4*>(x + grow * kGenK + k0) = val;
+  if (k0 == 0) areas[grow] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;
+}
+
 __global__ __launch_bounds__(256) void ensemble_reduce_kernel(const float* __restrict__ pred,
                                                              const float* __restrict__ areas, float* __restrict__ out,
                                                              int64_t n) {
@@ -100,6 +137,20 @@ extern "C" int s2l_ensemble_rows(const float* packed, const float* coords, const
   hipLaunchKernelGGL(s2l::ensemble_rows_kernel, dim3((unsigned)((4 * n_pixels + 7) / 8)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), packed, coords, feat, (float)time_index,
                      tap_shifts(width, height, u01), x, areas, n_pixels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int s2l_ensemble_rows_batch(const float* packed, const float* coords, const float* feat, const int64_t* time_index,
+                                       const float* u01, int width, int height, float* x, float* areas, int64_t n_pixels,
+                                       int64_t n_frames, s2l_stream_t stream) {
+  if (n_pixels < 0 || n_frames < 0 || n_frames > 65535 || width <= 0 || height <= 0) return S2L_E_SIZE;
+  if (n_pixels == 0 || n_frames == 0) return S2L_OK;
+  if (!packed || !coords || !feat || !time_index || !u01 || !x || !areas) return S2L_E_NULL;
+  if (s2l::misaligned16(x)) return S2L_E_ALIGN;
+  const double rx = 0.5 / width, ry = 0.5 / height;   // python doubles rounded to fp32, as tap_shifts()
+  hipLaunchKernelGGL(s2l::ensemble_rows_batch_kernel, dim3((unsigned)((4 * n_pixels + 7) / 8), (unsigned)n_frames), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), packed, coords, feat, time_index, u01, (float)rx, (float)ry, x, areas,
+                     n_pixels);
   return (int)hipGetLastError();
 }
 

@@ -423,3 +423,14 @@ int launch_embed_rows(const float* packed, const float* uv_audio, int64_t time_i
   return (int)hipGetLastError();
 }
 }  // namespace s2l
+
+// x [N,128] = [E(uv) 42 | audio 64 | PE(time) 20 | 0 0] for arbitrary rows: the first half of s2l_rgb_forward on its own, for
+// callers that keep x and the activations for a backward pass (speech2lip_amd.autograd).
+extern "C" int s2l_embed_rows(const float* packed, const float* uv_audio, int64_t time_index, float* x, int64_t n_rows,
+                              s2l_stream_t stream) {
+  if (n_rows < 0) return S2L_E_SIZE;
+  if (n_rows == 0) return S2L_OK;
+  if (!packed || !uv_audio || !x) return S2L_E_NULL;
+  if (s2l::misaligned16(packed) || s2l::misaligned16(x)) return S2L_E_ALIGN;
+  return s2l::launch_embed_rows(packed, uv_audio, time_index, x, n_rows, static_cast<hipStream_t>(stream));
+}

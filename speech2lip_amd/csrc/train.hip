@@ -171,6 +171,82 @@ __global__ void mse_final_kernel(const float* __restrict__ partial, int n, float
   }
 }
 
+// ---- small reductions / un-folding that used to run through ATen -----------------------------------------------------
+// partial[s][k][c] = sum of rows [k*rpc, (k+1)*rpc) of segment s (rows_per_seg rows of src, row stride ld), c < C <= 256;
+// blockDim 256 = (256 / C) row lanes x C columns, combined in lane order through LDS.
+constexpr int kSegChunks = 32;
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const float* __restrict__ src, int ld, int C, int64_t rows_per_seg,
+                                                            int64_t rpc, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int lanes = 256 / C;
+  const int c = threadIdx.x % C, lane = threadIdx.x / C;
+  const int64_t seg = blockIdx.y, k = blockIdx.x;
+  const int64_t r0 = k * rpc;
+  int64_t r1 = r0 + rpc;
+  if (r1 > rows_per_seg) r1 = rows_per_seg;
+  float acc = 0.f;
+  if (lane < lanes)
+    for (int64_t r = r0 + lane; r < r1; r += lanes) acc += src[(seg * rows_per_seg + r) * ld + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += red[l * C + threadIdx.x];
+    partial[(seg * kSegChunks + k) * C + threadIdx.x] = s;
+  }
+}
+__global__ __launch_bounds__(256) void segment_colsum_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ out,
+                                                                  int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t seg = i / C;
+  const int c = (int)(i - seg * C);
+  float s = 0.f;
+  for (int k = 0; k < kSegChunks; ++k) s += partial[(seg * kSegChunks + k) * C + c];
+  out[i] = s;
+}
+
+// Un-fold of the pack-time fold G = Wf [Wuv|Wa|Wt] (126 columns), c = Wf (buv + ba + bt) + bf  (s2l_layout.h; Wf = W0 or
+// W5[:, :256]):   dWf = dG C^T + dc bsum^T,   dC = Wf^T dG,   d(buv) = d(ba) = d(bt) = Wf^T dc.
+// Block j (256 threads): thread i forms dWf[i][j]; threads k < 126 form dC[j][k]; thread 126 forms the bias gradient j.
+struct UnfoldArgs {
+  const float* dG;       // [256,128], columns 0..125 used
+  const float* dc;       // [256]
+  const float* wf;       // [256, ldwf]
+  int ldwf;
+  const float *wuv, *wa, *wt, *buv, *ba, *bt;      // [256,42] [256,64] [256,20] [256] x3
+  float* dwf;            // [256, ldo] (columns 0..255 written)
+  int ldo;
+  const float* right;    // NULL, or [256,256] copied to columns 256..511 of dwf (the W5[:, 256:] gradient)
+  float *dwuv, *dwa, *dwt, *db;                    // db [256]: the common gradient of the three biases
+};
+__global__ __launch_bounds__(256) void unfold_kernel(UnfoldArgs a) {
+  __shared__ float crow[128], wcol[256], dcs[256];
+  const int j = blockIdx.x, t = threadIdx.x;
+  if (t < 42) crow[t] = a.wuv[j * 42 + t];
+  else if (t < 106) crow[t] = a.wa[j * 64 + t - 42];
+  else if (t < 126) crow[t] = a.wt[j * 20 + t - 106];
+  wcol[t] = a.wf[(int64_t)t * a.ldwf + j];
+  dcs[t] = a.dc[t];
+  __syncthreads();
+  const float bsum = (a.buv[j] + a.ba[j]) + a.bt[j];
+  float acc = 0.f;
+  for (int k = 0; k < 126; ++k) acc = fmaf(a.dG[t * 128 + k], crow[k], acc);
+  a.dwf[(int64_t)t * a.ldo + j] = fmaf(dcs[t], bsum, acc);
+  if (a.right) a.dwf[(int64_t)t * a.ldo + 256 + j] = a.right[t * 256 + j];
+  if (t < 126) {
+    float s = 0.f;
+    for (int i = 0; i < 256; ++i) s = fmaf(wcol[i], a.dG[i * 128 + t], s);
+    if (t < 42) a.dwuv[j * 42 + t] = s;
+    else if (t < 106) a.dwa[j * 64 + t - 42] = s;
+    else a.dwt[j * 20 + t - 106] = s;
+  } else if (t == 126) {
+    float s = 0.f;
+    for (int i = 0; i < 256; ++i) s = fmaf(wcol[i], dcs[i], s);
+    a.db[j] = s;
+  }
+}
+
 constexpr int kSplitBlocks = 512;   // row blocks of the split reductions (2 per CU)
 
 }  // namespace s2l
@@ -260,5 +336,39 @@ extern "C" int s2l_mse(const float* pred, const float* target, float weight, flo
   hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, st, pred, target, 2.f * weight / (float)n_elems, dpred, work,
                      n_elems);
   hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, work, nblk, weight / (float)n_elems, loss);
+  return (int)hipGetLastError();
+}
+
+// out [S,c] = per-segment column sums of src [S*rows_per_segment, ld] (c <= 256 and a divisor of 256): the per-frame gradient
+// of the audio feature from dxa (frame b owns 4*HW consecutive rows).  work: S * 32 * c floats.  Fixed summation order.
+extern "C" int s2l_segment_colsums(const float* src, int ld, int c, int64_t rows_per_segment, int64_t n_segments, float* work,
+                                   float* out, s2l_stream_t stream) {
+  if (c < 1 || c > 256 || 256 % c != 0 || ld < c || rows_per_segment <= 0 || n_segments < 0 || n_segments > 65535) return S2L_E_SIZE;
+  if (n_segments == 0) return S2L_OK;
+  if (!src || !work || !out) return S2L_E_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t rpc = (rows_per_segment + kSegChunks - 1) / kSegChunks;
+  hipLaunchKernelGGL(segment_colsum_kernel, dim3(kSegChunks, (unsigned)n_segments), dim3(256), 0, st, src, ld, c, rows_per_segment,
+                     rpc, work);
+  const int64_t n = n_segments * c;
+  hipLaunchKernelGGL(segment_colsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, c, out, n);
+  return (int)hipGetLastError();
+}
+
+// Gradients of the tensors behind a folded first/skip layer (see unfold_kernel).  first_w [256, ld_first] = pts_linears.0.weight
+// (ld 256) or pts_linears.5.weight (ld 512, its left half is the folded factor); d_first [256, ld_first] receives the gradient of
+// that factor in columns 0..255 and, when right != NULL, `right` [256,256] in columns 256..511.
+extern "C" int s2l_unfold_first_layer(const float* dG, const float* dc, const float* first_w, int ld_first, const float* w_uv,
+                                      const float* w_audio, const float* w_time, const float* b_uv, const float* b_audio,
+                                      const float* b_time, const float* right, float* d_first, float* d_w_uv, float* d_w_audio,
+                                      float* d_w_time, float* d_bias, s2l_stream_t stream) {
+  if (ld_first != 256 && ld_first != 512) return S2L_E_SIZE;
+  if (right && ld_first != 512) return S2L_E_SIZE;
+  if (!dG || !dc || !first_w || !w_uv || !w_audio || !w_time || !b_uv || !b_audio || !b_time || !d_first || !d_w_uv || !d_w_audio ||
+      !d_w_time || !d_bias)
+    return S2L_E_NULL;
+  UnfoldArgs a{dG, dc, first_w, ld_first, w_uv, w_audio, w_time, b_uv, b_audio, b_time, d_first, ld_first, right,
+               d_w_uv, d_w_audio, d_w_time, d_bias};
+  hipLaunchKernelGGL(unfold_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }

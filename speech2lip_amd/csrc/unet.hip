@@ -44,7 +44,15 @@ __host__ __device__ constexpr int64_t unet_b_off(int layer) {
 }
 constexpr int64_t kUnetOutW = unet_b_off(10);                      // outc weight [3][64]
 constexpr int64_t kUnetOutB = kUnetOutW + 192;                     // outc bias [4]
-constexpr int64_t kUnetPackedFloats = kUnetOutB + 4;
+// transposed chunks of layers 1..9 for the input-gradient convolutions (s2l_unet_backward): the same chunk format with the
+// roles of cin / cout swapped and the taps mirrored, dx = conv3x3(dz, W^T flipped)
+constexpr int64_t kUnetWT = kUnetOutB + 4;
+__host__ __device__ constexpr int64_t unet_wT_off(int layer) {
+  int64_t off = kUnetWT;
+  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cin / 64) * (kUnetConvs[l].cout / 16) * kChunkFloats;
+  return off;
+}
+constexpr int64_t kUnetPackedFloats = unet_wT_off(10);
 
 struct UnetTensors {
   const float* w[10];
@@ -70,6 +78,22 @@ __global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ pac
   const int ci = cc * 16 + 4 * (lane >> 4) + ks;
   const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   packed[unet_w_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + tap] * scale;
+}
+
+// the transposed twin: output rows = the layer's INPUT channels, k = its OUTPUT channels, tap t reads forward tap 8 - t
+__global__ void unet_pack_conv_T(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
+  const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;      // forward roles
+  const int64_t n = (int64_t)(cin / 64) * (cout / 16) * kChunkFloats;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int ks = e & 3, lane = (e >> 2) & 63, mb = (e >> 8) & 3;
+  const int tap = (int)((e >> 10) % 9);
+  const int64_t chunk = e / kChunkFloats;
+  const int cc = (int)(chunk % (cout / 16)), ct = (int)(chunk / (cout / 16));
+  const int ci = ct * 64 + mb * 16 + (lane & 15);          // row of the transposed GEMM = forward input channel
+  const int co = cc * 16 + 4 * (lane >> 4) + ks;           // k = forward output channel
+  const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  packed[unet_wT_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + (8 - tap)] * scale;
 }
 
 __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float eps) {
@@ -163,7 +187,9 @@ struct ConvArgs {
   const float* outb;
   float* out3;
   float* pool;        // or null: MaxPool2d(2) of the output, [F,H/2,W/2,cout], written by the same epilogue
+  const float* gate;  // or null: [F,H,W,cout]; the output is zeroed where gate <= 0 (ReLU mask of the backward pass)
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
+  int relu;           // 1: ReLU in the epilogue (forward); 0: linear (input-gradient convolutions)
 };
 
 __device__ __forceinline__ f4 mfma16u(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   f4 acc[4][4];   // [M-block][pixel group = tile row 4*wave + g]
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
-    const f4 b = *reinterpret_cast<const f4*>(a.bias + ct * 64 + mb * 16 + 4 * q);
+    const f4 b = a.bias ? *reinterpret_cast<const f4*>(a.bias + ct * 64 + mb * 16 + 4 * q) : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[mb][g] = b;
   }
@@ -282,13 +308,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
         o3[1] = p3[1] + a.outb[1];
         o3[2] = p3[2] + a.outb[2];
       }
+      if (a.out && ok) {   // training: the last hidden activation is kept for the backward pass
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          f4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mb][g][r], 0.f);
+          *reinterpret_cast<f4*>(a.out + pix * a.cout + ct * 64 + mb * 16 + 4 * q) = h;
+        }
+      }
     } else if (ok) {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         f4 h;
+        float* dst = a.out + pix * a.cout + ct * 64 + mb * 16 + 4 * q;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[mb][g][r], 0.f);
-        *reinterpret_cast<f4*>(a.out + pix * a.cout + ct * 64 + mb * 16 + 4 * q) = h;
+        for (int r = 0; r < 4; ++r) h[r] = a.relu ? fmaxf(acc[mb][g][r], 0.f) : acc[mb][g][r];
+        if (a.gate) {
+          const f4 gt = *reinterpret_cast<const f4*>(a.gate + (dst - a.out));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = gt[r] > 0.f ? h[r] : 0.f;
+        }
+        *reinterpret_cast<f4*>(dst) = h;
       }
     }
   }
@@ -349,13 +390,13 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
-                       float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr) {
+                       float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr) {
   ConvArgs a;
   a.inA = inA; a.inB = inB; a.CA = CA; a.CB = CB;
   a.cout = kUnetConvs[layer].cout;
   a.w = packed + unet_w_off(layer);
   a.bias = packed + unet_b_off(layer);
-  a.out = out; a.out3 = out3; a.pool = pool;
+  a.out = out3 ? keep : out; a.out3 = out3; a.pool = pool; a.gate = nullptr; a.relu = 1;
   a.outw = packed + kUnetOutW; a.outb = packed + kUnetOutB;
   a.H = H; a.W = W;
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
@@ -366,6 +407,180 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
+}
+
+
+// ---- input gradient of the frozen eval-mode network (training: the sync loss and the face photometric loss reach the lip MLP
+// through it, training.py:436-459, 491-559; the network is frozen and in eval mode once the sync loss is on, train.py:188-197) ---
+// dz -> dx of a 3x3 convolution is the same implicit GEMM with the transposed, tap-mirrored chunks (unet_pack_conv_T), no
+// bias, no ReLU, and the ReLU mask of the activation that FED the layer applied in the epilogue (`gate`).
+static int launch_conv_dgrad(const float* dz, const float* packed, int layer, float* dx, const float* gate, int H, int W,
+                             int64_t F, hipStream_t st) {
+  ConvArgs a;
+  a.inA = dz; a.inB = nullptr; a.CA = kUnetConvs[layer].cout; a.CB = 0;
+  a.cout = kUnetConvs[layer].cin;
+  a.w = packed + unet_wT_off(layer);
+  a.bias = nullptr;
+  a.out = dx; a.out3 = nullptr; a.pool = nullptr; a.gate = gate; a.relu = 0;
+  a.outw = a.outb = nullptr;
+  a.H = H; a.W = W;
+  a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+  a.n_ct = a.cout / 64;
+  const int64_t gz = F * a.n_ct;
+  if (gz > 65535) return S2L_E_SIZE;
+  hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)gz), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+// z9[p][c] = (sum_o outw[o][c] * d_out[p][o]) * (y9[p][c] > 0): adjoint of the fused 1x1 output convolution + ReLU mask
+__global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ outw,
+                                                      const float* __restrict__ y9, float* __restrict__ z9, int64_t n_quads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_quads) return;
+  const int c4 = (int)(i & 15) * 4;
+  const int64_t p = i >> 4;
+  const float d0 = d_out[p * 3], d1 = d_out[p * 3 + 1], d2 = d_out[p * 3 + 2];
+  const f4 y = *reinterpret_cast<const f4*>(y9 + p * 64 + c4);
+  f4 z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = fmaf(outw[128 + c4 + r], d2, fmaf(outw[64 + c4 + r], d1, outw[c4 + r] * d0));
+    z[r] = y[r] > 0.f ? v : 0.f;
+  }
+  *reinterpret_cast<f4*>(z9 + p * 64 + c4) = z;
+}
+
+// dx[c](y,x) = sum_{co,t} W0[co][c][t] * z0[co](y - (t/3 - 1), x - (t%3 - 1)): input gradient of the first convolution
+// (64 -> 3 channels; 0.5 % of the FLOPs).  One thread per pixel; the folded weights sit in LDS as [t][c][co].
+__global__ __launch_bounds__(256) void conv_first_bwd_kernel(const float* __restrict__ z0, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float lw[9 * 3 * 64];
+  for (int i = threadIdx.x; i < 9 * 3 * 64; i += 256) {
+    const int co = i & 63, c = (i >> 6) % 3, t = i / 192;
+    lw[i] = w[co * 27 + c * 9 + t];
+  }
+  __syncthreads();
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int64_t frame = blockIdx.y;
+  if (pix >= H * W) return;
+  const int py = pix / W, px = pix - py * W;
+  const float* zf = z0 + frame * (int64_t)H * W * 64;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = py - (t / 3 - 1), xx = px - (t % 3 - 1);
+    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+    const f4* src = reinterpret_cast<const f4*>(zf + ((int64_t)yy * W + xx) * 64);
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const f4 v = src[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const f4 ww = *reinterpret_cast<const f4*>(lw + (t * 3 + c) * 64 + 4 * k);
+        acc[c] = fmaf(v[3], ww[3], fmaf(v[2], ww[2], fmaf(v[1], ww[1], fmaf(v[0], ww[0], acc[c]))));
+      }
+    }
+  }
+  float* o = dx + (frame * (int64_t)H * W + pix) * 3;
+  o[0] = acc[0];
+  o[1] = acc[1];
+  o[2] = acc[2];
+}
+
+// Adjoint of upsample2_kernel as a gather (deterministic): input pixel (yi, xi) collects from the output pixels whose
+// bilinear taps include it; then the ReLU mask of the activation that was upsampled.  g: [F,Ho,Wo,ldg], channels
+// [coff, coff + C) of it; act, z: [F,h,w,C].
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ g, int ldg, int coff,
+                                                           const float* __restrict__ act, float* __restrict__ z, int h, int w, int C,
+                                                           int Ho, int Wo, int64_t n_in) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_in) return;
+  const int cq = C / 4;
+  const int c4 = (int)(i % cq);
+  int64_t p = i / cq;
+  const int xi = (int)(p % w);
+  p /= w;
+  const int yi = (int)(p % h);
+  const int64_t f = p / h;
+  const int padT = (Ho - 2 * h) / 2, padL = (Wo - 2 * w) / 2;
+  const float sy = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+  const float sx = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int yu = max(2 * yi - 3, 0); yu <= min(2 * yi + 4, 2 * h - 1); ++yu) {
+    const float fy = sy * (float)yu;
+    const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - (float)y0;
+    const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int xu = max(2 * xi - 3, 0); xu <= min(2 * xi + 4, 2 * w - 1); ++xu) {
+      const float fx = sx * (float)xu;
+      const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - (float)x0;
+      const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+      if (wx == 0.f) continue;
+      const f4 v = *reinterpret_cast<const f4*>(g + ((f * Ho + yu + padT) * (int64_t)Wo + xu + padL) * ldg + coff + c4 * 4);
+      const float ww = wy * wx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(ww, v[r], acc[r]);
+    }
+  }
+  const f4 a = *reinterpret_cast<const f4*>(act + i * 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = a[r] > 0.f ? acc[r] : 0.f;
+  *reinterpret_cast<f4*>(z + i * 4) = acc;
+}
+
+// z = (g_skip + MaxPool2d(2)^T(g_pool)) * (x > 0) at the resolution of x: g_skip = channels [0, C) of gcat [F,H,W,ldg] (the
+// skip half of the decoder's concat gradient), g_pool [F,H/2,W/2,C] routed to the FIRST maximum of each 2x2 window in scan
+// order (ATen's max_pool2d backward), x / pooled = the forward's activation and its pooled copy.
+__global__ __launch_bounds__(256) void pool_bwd_add_kernel(const float* __restrict__ gcat, int ldg, const float* __restrict__ gpool,
+                                                          const float* __restrict__ x, const float* __restrict__ pooled,
+                                                          float* __restrict__ z, int H, int W, int C, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int cq = C / 4;
+  const int c4 = (int)(i % cq) * 4;
+  int64_t p = i / cq;
+  const int xx = (int)(p % W);
+  p /= W;
+  const int yy = (int)(p % H);
+  const int64_t f = p / H;
+  const int H2 = H / 2, W2 = W / 2;
+  const int64_t pix = (f * H + yy) * (int64_t)W + xx;
+  const f4 xv = *reinterpret_cast<const f4*>(x + pix * C + c4);
+  f4 o = *reinterpret_cast<const f4*>(gcat + pix * ldg + c4);
+  const int py = yy >> 1, px = xx >> 1;
+  if (py < H2 && px < W2) {
+    const int64_t pp = ((f * H2 + py) * (int64_t)W2 + px) * C + c4;
+    const f4 pv = *reinterpret_cast<const f4*>(pooled + pp);
+    const f4 gv = *reinterpret_cast<const f4*>(gpool + pp);
+    const int k = (yy & 1) * 2 + (xx & 1);          // position in the window's scan order
+    bool earlier[4] = {false, false, false, false};
+    for (int j = 0; j < k; ++j) {
+      const f4 ev = *reinterpret_cast<const f4*>(x + ((f * H + 2 * py + (j >> 1)) * (int64_t)W + 2 * px + (j & 1)) * C + c4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) earlier[r] |= ev[r] == pv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (xv[r] == pv[r] && !earlier[r]) o[r] += gv[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = xv[r] > 0.f ? o[r] : 0.f;
+  *reinterpret_cast<f4*>(z + i * 4) = o;
+}
+
+// buffers of the saved forward and the backward scratch (floats per frame at H x W: 320 p1 + 640 p2 + 384 p4 saved,
+// 256 p1 + 768 p2 + 384 p4 scratch)
+struct UnetSaved {
+  float *a0, *x1, *uu, *a8, *y9, *p1, *a2, *x2, *u3, *a6, *u1, *p2, *a4, *x3;
+};
+static UnetSaved unet_saved(float* w, int64_t p1, int64_t p2, int64_t p4) {
+  UnetSaved s;
+  s.a0 = w;               s.x1 = s.a0 + p1 * 64;  s.uu = s.x1 + p1 * 64;  s.a8 = s.uu + p1 * 64;  s.y9 = s.a8 + p1 * 64;
+  s.p1 = s.y9 + p1 * 64;  s.a2 = s.p1 + p2 * 64;  s.x2 = s.a2 + p2 * 128; s.u3 = s.x2 + p2 * 128; s.a6 = s.u3 + p2 * 128;
+  s.u1 = s.a6 + p2 * 128; s.p2 = s.u1 + p2 * 64;  s.a4 = s.p2 + p4 * 128; s.x3 = s.a4 + p4 * 128;
+  return s;
 }
 
 }  // namespace s2l
@@ -404,6 +619,7 @@ extern "C" int s2l_unet_pack(const float* const* tensors_host, float bn_eps, flo
   for (int l = 1; l < 10; ++l) {
     const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
     hipLaunchKernelGGL(unet_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, bn_eps);
+    hipLaunchKernelGGL(unet_pack_conv_T, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, bn_eps);
   }
   hipLaunchKernelGGL(unet_pack_misc, dim3(16), dim3(256), 0, st, t, packed, bn_eps);
   return (int)hipGetLastError();
@@ -440,5 +656,85 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
                      p1 * 16);   // t64a is free again: it becomes up(u1)
   if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st))) return rc;
   if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st))) return rc;
+  return (int)hipGetLastError();
+}
+
+// ---- training: forward that keeps every activation, and the input gradient ----------------------------------------------
+extern "C" int64_t s2l_unet_saved_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 0) return 0;
+  const int64_t p1 = (int64_t)height * width, p2 = (int64_t)(height / 2) * (width / 2), p4 = (int64_t)(height / 4) * (width / 4);
+  return n_frames * (p1 * 320 + p2 * 640 + p4 * 384);
+}
+extern "C" int64_t s2l_unet_backward_work_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 0) return 0;
+  const int64_t p1 = (int64_t)height * width, p2 = (int64_t)(height / 2) * (width / 2), p4 = (int64_t)(height / 4) * (width / 4);
+  return n_frames * (p1 * 256 + p2 * 768 + p4 * 384);
+}
+
+extern "C" int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, float* out, int height, int width,
+                                      int64_t n_frames, s2l_stream_t stream) {
+  if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!packed || !x || !saved || !out) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(saved)) return S2L_E_ALIGN;
+  if (n_frames > 65535) return S2L_E_SIZE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+  const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
+  const UnetSaved s = unet_saved(saved, p1, p2, p4);
+  int rc;
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
+                     packed + unet_w_off(0), packed + unet_b_off(0), s.a0, H, W);
+  if ((rc = launch_conv(s.a0, 64, nullptr, 0, packed, 1, s.x1, nullptr, H, W, F, st, s.p1))) return rc;
+  if ((rc = launch_conv(s.p1, 64, nullptr, 0, packed, 2, s.a2, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(s.a2, 128, nullptr, 0, packed, 3, s.x2, nullptr, H2, W2, F, st, s.p2))) return rc;
+  if ((rc = launch_conv(s.p2, 128, nullptr, 0, packed, 4, s.a4, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv(s.a4, 128, nullptr, 0, packed, 5, s.x3, nullptr, H4, W4, F, st))) return rc;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, s.x3, s.u3, H4, W4, 128, H2, W2,
+                     p2 * 32);
+  if ((rc = launch_conv(s.x2, 128, s.u3, 128, packed, 6, s.a6, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(s.a6, 128, nullptr, 0, packed, 7, s.u1, nullptr, H2, W2, F, st))) return rc;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
+                     p1 * 16);
+  if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st))) return rc;
+  if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9))) return rc;
+  return (int)hipGetLastError();
+}
+
+// d_out [F,H,W,3] -> d_x [F,H,W,3], from the activations s2l_unet_forward_saved kept; work: s2l_unet_backward_work_floats.
+extern "C" int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
+                                 int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
+  if (n_frames == 0) return S2L_OK;
+  if (!packed || !saved || !d_out || !work || !d_x) return S2L_E_NULL;
+  if (misaligned16(packed) || misaligned16(saved) || misaligned16(work)) return S2L_E_ALIGN;
+  if (n_frames > 65535) return S2L_E_SIZE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+  const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
+  const UnetSaved s = unet_saved(const_cast<float*>(saved), p1, p2, p4);
+  float* zA = work;              float* zB = zA + p1 * 64;      float* gcat8 = zB + p1 * 64;                      // @H
+  float* z7 = gcat8 + p1 * 128;  float* z6 = z7 + p2 * 64;      float* gcat6 = z6 + p2 * 128;                     // @H/2
+  float* z3 = gcat6 + p2 * 256;  float* z2 = z3 + p2 * 128;     float* gp1 = z2 + p2 * 128;
+  float* z5 = gp1 + p2 * 64;     float* z4 = z5 + p4 * 128;     float* gp2 = z4 + p4 * 128;                       // @H/4
+  auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  int rc;
+  hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, packed + kUnetOutW, s.y9, zA, p1 * 16);   // z9
+  if ((rc = launch_conv_dgrad(zA, packed, 9, zB, s.a8, H, W, F, st))) return rc;                                          // z8
+  if ((rc = launch_conv_dgrad(zB, packed, 8, gcat8, nullptr, H, W, F, st))) return rc;                                    // [g_x1 | g_uu]
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64, H, W, p2 * 16);
+  if ((rc = launch_conv_dgrad(z7, packed, 7, z6, s.a6, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z6, packed, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                                  // [g_x2 | g_u3]
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, s.x3, z5, H4, W4, 128, H2, W2,
+                     p4 * 32);
+  if ((rc = launch_conv_dgrad(z5, packed, 5, z4, s.a4, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z4, packed, 4, gp2, nullptr, H4, W4, F, st))) return rc;
+  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, s.x2, s.p2, z3, H2, W2, 128, p2 * 32);
+  if ((rc = launch_conv_dgrad(z3, packed, 3, z2, s.a2, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z2, packed, 2, gp1, nullptr, H2, W2, F, st))) return rc;
+  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p1 * 16), dim3(256), 0, st, gcat8, 128, gp1, s.x1, s.p1, zA, H, W, 64, p1 * 16);   // z1
+  if ((rc = launch_conv_dgrad(zA, packed, 1, zB, s.a0, H, W, F, st))) return rc;                                          // z0
+  hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
+                     packed + unet_w_off(0), d_x, H, W);
   return (int)hipGetLastError();
 }

@@ -16,12 +16,13 @@ Beyond the reference surface, `render_clip` is the batched driver that replaces 
 loop of inference.py:140-159 (audio encoder once per frame, one fused launch per clip).
 
 The post-fusion U-Net (`post_fusion_unet`) is `speech2lip_amd.unet.SimpleUnetLight`
-(eval mode).  Not in this path: the canonical depth head, training of the U-Net.
+(eval mode).  Not in this path: training of the U-Net (BatchNorm batch statistics).
 """
 from __future__ import annotations
 
 import ctypes
 import math
+import random
 from typing import Optional
 
 import torch
@@ -195,7 +196,16 @@ class TalkingFace(nn.Module):
     # ------------------------------------------------------------------ A4
     def audio_merge_forward(self, audio):
         """[B,16,29] DeepSpeech windows (or already-permuted [B,29,16]) -> [B,64].
-        Reference: tf_nerf.py:197-213."""
+        Reference: tf_nerf.py:197-213.  With autograd recording the result carries a grad_fn whose backward is
+        s2l_audio_backward (speech2lip_amd.autograd), so the reference's loss.backward() (training.py:559) works."""
+        if torch.is_grad_enabled() and isinstance(audio, torch.Tensor) and audio.shape[0] > 0 and \
+                any(p.requires_grad for p in self._hot_tensors()[:12]):
+            from .autograd import audio_encode
+            return audio_encode(self, audio)
+        return self._audio_encode(audio)
+
+    def _audio_encode(self, audio):
+        """The forward kernel alone (no graph)."""
         lib = _abi.load()
         packed = self.packed_weights()
         a = _dev_f32(audio, packed.device, "audio")
@@ -214,7 +224,16 @@ class TalkingFace(nn.Module):
     def rgb_forward(self, uv_audio_pts, time_pts=None, head_pose_pts=None, rgb_pts=None, lms_pts=None, text_pts=None):
         """rows [N, 2+64] + one frame index -> [N,3] (no output activation).
         Reference: tf_nerf.py:225-285.  `head_pose_pts`, `rgb_pts`, `lms_pts`, `text_pts` are
-        accepted and ignored exactly as the reference ignores them under the May flags."""
+        accepted and ignored exactly as the reference ignores them under the May flags.  With autograd recording the result
+        is differentiable w.r.t. the MLP parameters and the audio columns of the rows (speech2lip_amd.autograd)."""
+        if torch.is_grad_enabled() and isinstance(uv_audio_pts, torch.Tensor) and uv_audio_pts.shape[0] > 0 and \
+                (uv_audio_pts.requires_grad or any(p.requires_grad for p in self._hot_tensors()[12:])):
+            from .autograd import rgb_forward
+            return rgb_forward(self, uv_audio_pts, time_pts)
+        return self._rgb_forward(uv_audio_pts, time_pts)
+
+    def _rgb_forward(self, uv_audio_pts, time_pts):
+        """The forward kernels alone (no graph)."""
         lib = _abi.load()
         packed = self.packed_weights()
         rows = _dev_f32(uv_audio_pts, packed.device, "uv_audio_pts")
@@ -244,26 +263,51 @@ class TalkingFace(nn.Module):
                              wav2lip=None, mask_head_observed=None, use_post_fusion_blackaug=False):
         """Paste the lip into the canonical face, warp by `coord`, blend with the observed frame.
         Reference: tf_nerf.py:287-304 -> post_fusion2_onlylip_light :320-389.
-        Returns (rgb_recon, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; rgb_recon is the
-        post-fusion U-Net output (csrc/unet.hip) in eval mode, None in train mode or when
-        model.use_post_fusion is off."""
+        Returns (rgb_recon, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; rgb_recon is the post-fusion U-Net
+        output (csrc/unet.hip) when `post_fusion_unet` is in eval mode (inference, and training once the net is fixed,
+        train.py:188-197), None while it is in train mode or when model.use_post_fusion is off.
+        use_post_fusion_blackaug=True is the training call (training.py:436/445): with probability 1/2 black holes are
+        punched (tf_nerf.py:371-384).  With autograd recording and a lip that requires grad, the outputs are
+        differentiable w.r.t. the lip (speech2lip_amd.autograd)."""
         if not self.use_light_unet:
             return None  # the reference method falls through and returns None as well (:299-304)
-        if use_post_fusion_blackaug:
-            raise NotImplementedError("black-hole augmentation is training-only (tf_nerf.py:371-384)")
+        holes = None
+        if use_post_fusion_blackaug and random.random() > 0.5:          # the coin of tf_nerf.py:371
+            holes = self.draw_hole_noise(rgb_gt)
+        unet = getattr(self, "post_fusion_unet", None)
+        # rgb_recon = post_fusion_unet(rgb_merged_new) (tf_nerf.py:387).  The HIP U-Net runs the network the way the reference
+        # runs it once it is fixed (`post_fusion_unet.eval()`, train.py:188-197): whenever the SUB-module is in eval mode
+        run_unet = unet is not None and not unet.training
+        if torch.is_grad_enabled() and isinstance(rgb_lip_warped, torch.Tensor) and rgb_lip_warped.requires_grad:
+            from .autograd import composite as composite_with_graph, unet_eval
+            new, can = composite_with_graph(self, rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
+                                            lip_lefttop_y, coord, holes)
+            return (unet_eval(unet, new) if run_unet else None), new, can
         new, can = self.composite_clip(rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
-                                       lip_lefttop_y, coord, want_canonical=True)
-        # rgb_recon = post_fusion_unet(rgb_merged_new) (tf_nerf.py:387); eval mode only on this path
-        recon = None
-        if getattr(self, "post_fusion_unet", None) is not None and not self.training:
-            recon = self.post_fusion_unet.forward_nhwc(new)
-        return recon, new, can
+                                       lip_lefttop_y, coord, want_canonical=True, hole_noise=holes)
+        return (unet.forward_nhwc(new) if run_unet else None), new, can
+
+    @staticmethod
+    def draw_hole_noise(rgb_gt):
+        """The two N(0,1) fields of `add_black_hole` (tf_nerf.py:306-318), drawn the way the reference draws them --
+        `torch.randn(input_img.shape)` on the default (CPU) generator, channel 0 kept, moved to the device -- so that a
+        seeded run consumes the generator exactly like the reference: first for the merged image, then for rgb_gt."""
+        B, FH, FW = rgb_gt.shape[0], rgb_gt.shape[1], rgb_gt.shape[2]
+        n1 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
+        n2 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
+        return n1.to(rgb_gt.device), n2.to(rgb_gt.device)
+
+    def _composite_geometry(self, lw):
+        if self.expand_lip_mask:
+            return lw // 12 if "obama2_face_crop" in self.data_path else lw // 5   # tf_nerf.py:357-360
+        return -1
 
     def composite_clip(self, rgb_lip, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
-                       coord, want_canonical=False, out=None):
+                       coord, want_canonical=False, out=None, hole_noise=None):
         """Batched composite (tf_nerf.py:320-386 without the U-Net) for F frames at once:
         rgb_lip [F,h,w,3], rgb_gt [F,FH,FW,3], coord [F,FH,FW,2]; rgb_face_canonical and
         mask_lip_canonical either per frame [F,FH,FW,3] or per clip [1,FH,FW,3] / [FH,FW,3].
+        hole_noise: None (inference branch) or (n1, n2) [F,FH,FW]: the black-hole augmentation of the training branch.
         Returns (rgb_merged_new [F,FH,FW,3], rgb_merged_canonical or None)."""
         lib = _abi.load()
         dev = self.packed_weights().device
@@ -286,10 +330,12 @@ class TalkingFace(nn.Module):
 
         x0 = int(lip_lefttop_x.reshape(-1)[0].item()) if isinstance(lip_lefttop_x, torch.Tensor) else int(lip_lefttop_x)
         y0 = int(lip_lefttop_y.reshape(-1)[0].item()) if isinstance(lip_lefttop_y, torch.Tensor) else int(lip_lefttop_y)
-        if self.expand_lip_mask:
-            pad = lw // 12 if "obama2_face_crop" in self.data_path else lw // 5   # tf_nerf.py:357-360
-        else:
-            pad = -1
+        pad = self._composite_geometry(lw)
+        h1 = h2 = None
+        if hole_noise is not None:
+            h1, h2 = (_dev_f32(n, dev, "hole_noise") for n in hole_noise)
+            if h1.shape != (B, FH, FW) or h2.shape != (B, FH, FW):
+                raise ValueError(f"hole_noise fields must be [{B},{FH},{FW}]")
         if out is not None and (out.shape != (B, FH, FW, 3) or out.dtype != torch.float32 or not out.is_contiguous()
                                 or out.device != dev):
             raise ValueError(f"out must be a contiguous fp32 [{B},{FH},{FW},3] tensor on {dev}")
@@ -302,10 +348,44 @@ class TalkingFace(nn.Module):
                 bgm = torch.empty(FH, FW, 4, dtype=torch.float32, device=dev)
                 _abi.check(lib.s2l_composite_tables(_ptr(face), _ptr(mask), _ptr(bgm), FH, FW, _stream()),
                            "s2l_composite_tables")
-            _abi.check(lib.s2l_composite(_ptr(lip), _ptr(face), fs, _ptr(mask), ms, _ptr(gt), _ptr(grid), _ptr(new),
-                                         _ptr(can), _ptr(bgm), lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B, _stream()),
-                       "s2l_composite")
+            _abi.check(lib.s2l_composite_train(_ptr(lip), _ptr(face), fs, _ptr(mask), ms, _ptr(gt), _ptr(grid), _ptr(h1), _ptr(h2),
+                                               _ptr(new), _ptr(can), _ptr(bgm), lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B,
+                                               _stream()), "s2l_composite_train")
         return new, can
+
+    def composite_backward_lip(self, d_new, rgb_face_canonical, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord,
+                               lip_h: int, lip_w: int, hole_noise=None):
+        """d loss / d rgb_merged_new [F,FH,FW,3] -> d loss / d rgb_lip [F,h,w,3]: the autograd of tf_nerf.py:339-386 for the lip
+        (same constants and, in the training branch, the same hole_noise as the forward call)."""
+        lib = _abi.load()
+        dev = self.packed_weights().device
+        d = _dev_f32(d_new, dev, "d_new")
+        face = _dev_f32(rgb_face_canonical, dev, "rgb_face_canonical")
+        mask = _dev_f32(mask_lip_canonical, dev, "mask_lip_canonical")
+        grid = _dev_f32(coord, dev, "coord")
+        B, FH, FW = d.shape[0], d.shape[1], d.shape[2]
+        if grid.shape != (B, FH, FW, 2) or d.shape[3] != 3:
+            raise ValueError("composite_backward_lip: inconsistent shapes")
+
+        def stride(t, name):
+            if t.shape == (1, FH, FW, 3) or t.shape == (FH, FW, 3):
+                return 0
+            if t.shape == (B, FH, FW, 3):
+                return FH * FW * 3
+            raise ValueError(f"composite: {name} must be [B,FH,FW,3] or [1,FH,FW,3]")
+
+        x0 = int(lip_lefttop_x.reshape(-1)[0].item()) if isinstance(lip_lefttop_x, torch.Tensor) else int(lip_lefttop_x)
+        y0 = int(lip_lefttop_y.reshape(-1)[0].item()) if isinstance(lip_lefttop_y, torch.Tensor) else int(lip_lefttop_y)
+        h1 = h2 = None
+        if hole_noise is not None:
+            h1, h2 = (_dev_f32(n, dev, "hole_noise") for n in hole_noise)
+        d_lip = torch.empty(B, int(lip_h), int(lip_w), 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_composite_backward_lip(_ptr(d), _ptr(face), stride(face, "rgb_face_canonical"), _ptr(mask),
+                                                      stride(mask, "mask_lip_canonical"), _ptr(grid), _ptr(h1), _ptr(h2), _ptr(d_lip),
+                                                      int(lip_h), int(lip_w), FH, FW, x0, y0, self._pad_mode(),
+                                                      self._composite_geometry(int(lip_w)), B, _stream()), "s2l_composite_backward_lip")
+        return d_lip
 
     # ------------------------------------------------------------------ A6 (batched driver)
     def pixel_tables(self, height: int, width: int):

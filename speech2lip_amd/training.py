@@ -1,29 +1,44 @@
-"""Training-time forward of the lip path: the 4-tap local ensemble.
+"""Training-time side of the lip path (BASELINE config 5, §8f-4 light half).
 
-`Trainer.predict_lip_image` keeps the reference's signature
-(`src/face_simple/training.py:158`) for the May flag set, so a training loop that calls it
-needs no other change; the work happens in `s2l_predict_lip_image` (csrc/ensemble.hip).
-Forward only: the backward kernels (BASELINE config 5) are the next row of the build.
+  * `Trainer` keeps the reference's method signatures (`src/face_simple/training.py:158, 576-603`) for the May flag set, so a
+    training loop that calls them needs no other change; with autograd recording they return tensors that
+    `loss.backward()` (training.py:559) can differentiate (speech2lip_amd.autograd).
+  * `LipTrainStep` is the batched engine underneath: `forward` renders the 4-tap local ensemble of a batch of frames with
+    saved activations, `backward` turns d loss / d pred into the gradients of all 42 hot-path tensors -- fp32 exact-parity
+    mode or the bf16 mode BASELINE config 5 names.
+  * `SyncChain` carries the lip-sync expert's loss back to the rendered lips through the crop/resize, the frozen eval-mode
+    post-fusion U-Net and the paste + head-pose-warp composite (training.py:491-557), and `StageOneStep` adds it (and the
+    optional face photometric term, :458-459) to the MSE step.
+Every arithmetic step is a hand-written HIP kernel behind the C-ABI; torch is device memory, streams and views.
 """
 from __future__ import annotations
 
 import ctypes
+import random
+from typing import Optional
 
 import torch
 
 from . import _abi
 from .talking_face import TalkingFace, _dev_f32, _ptr, _stream
 
+MLP_TENSORS = _abi.TENSOR_ORDER[12:]      # fc_* and pts_linears.* and output_linear.* (30 tensors)
+AUDIO_TENSORS = _abi.TENSOR_ORDER[:12]    # encoder_conv.* and encoder_fc1.*
+
+
+def _f(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
 
 def predict_lip_image(model: TalkingFace, coords, audio, index, height: int, width: int, u01: float):
-    """coords [HW,2], audio [1,16,29], frame index, the U(0,1) draw of training.py:200 -> [HW,3]."""
+    """coords [HW,2], audio [1,16,29], frame index, the U(0,1) draw of training.py:200 -> [HW,3] (no graph)."""
     lib = _abi.load()
     packed = model.packed_weights()
     dev = packed.device
     c = _dev_f32(coords, dev, "coords")
     if c.dim() != 2 or c.shape[1] != 2:
         raise ValueError(f"coords must be [N,2], got {tuple(c.shape)}")
-    feat = model.audio_merge_forward(audio)               # encoder once, then shared by all pixels (:165/:171)
+    feat = model._audio_encode(audio)               # encoder once, then shared by all pixels (:165/:171)
     if feat.shape[0] != 1:
         raise ValueError("predict_lip_image renders one frame: audio must be [1,16,29]")
     n = c.shape[0]
@@ -73,30 +88,162 @@ class Trainer:
         return SyncLoss(self.syncnet).cosine_loss(a, v, y)
 
     def get_sync_contrastive_loss(self, mel, g_rgb_pos, g_rgb_neg, syncnet_T=5, want_grad=False):
-        """training.py:581-603.  want_grad=True also returns d loss / d g_rgb_pos (what autograd hands to the renderer)."""
+        """training.py:581-603.  With autograd recording and a generated window that requires grad the returned loss is
+        differentiable (its backward is s2l_syncnet_face_backward); want_grad=True instead returns (loss, d loss / d g_rgb_pos)."""
         from .syncnet import SyncLoss
+        if not want_grad and torch.is_grad_enabled() and isinstance(g_rgb_pos, torch.Tensor) and g_rgb_pos.requires_grad:
+            from .autograd import sync_contrastive_loss
+            return sync_contrastive_loss(SyncLoss(self.syncnet, syncnet_T), mel, g_rgb_pos, g_rgb_neg)
         return SyncLoss(self.syncnet, syncnet_T).get_sync_contrastive_loss(mel, g_rgb_pos, g_rgb_neg, want_grad=want_grad)
 
+    def prepare_coords(self, coord, b):
+        """training.py:253-261 (use_coords_mapping off): the regular pixel grid, tiled b times."""
+        from .rendering import get_coords
+        return get_coords(int(self.width), int(self.height), self.device).tile(b, 1)
+
     def predict_lip_image(self, i, coords, audio, pose, data, rgb_zero, lms, seed):
-        """Same arguments as the reference method; `pose`, `rgb_zero`, `lms` are unused under the
-        May flags exactly as there.  One chunk = the whole lip image (batch_rays = H*W)."""
+        """Same arguments as the reference method; `pose`, `rgb_zero`, `lms` are unused under the May flags exactly as
+        there.  One chunk = the whole lip image (batch_rays = H*W).  Differentiable when autograd is recording."""
         chunk = coords[i:i + self.batch_rays, :]
         time_pts = data["index"] if seed is None else data["index"] + seed
         u01 = float(torch.rand(1, device=self.device))          # eps_shift draw (training.py:200)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model._hot_tensors()):
+            from .autograd import predict_lip_image as predict_with_graph
+            return predict_with_graph(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
         return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
+
+    def add_photometric_loss(self, prediction, target, loss, coarse=False, mask=None, weights=1.0):
+        """training.py:605-619 (mask=None branch): differentiable through autograd.mse when recording."""
+        from .autograd import mse
+        loss_rgb = mse(prediction, target, weights)
+        loss["loss"] = loss["loss"] + loss_rgb
+        loss["loss_rgb"] = loss["loss_rgb"] + loss_rgb.detach().cpu()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class MlpState:
+    """What one forward of the MLP leaves behind for its backward: fp32 mode x [N,128] + hsave [8,N,256]; bf16 mode the
+    operand image xT, the activation images hT and the ReLU ballots."""
+
+    def __init__(self, precision, N, dev, lib):
+        self.precision, self.N = precision, N
+        if precision == "bf16":
+            self.Np = int(lib.s2l_bf16_rows_padded(N))
+            i16 = lambda n: torch.empty(n, dtype=torch.int16, device=dev)
+            self.hT, self.xT = i16(8 * self.Np * 256), i16(self.Np * 128)
+            self.masks = torch.empty(8 * (self.Np // 64) * 256, dtype=torch.int64, device=dev)
+        else:
+            self.x, self.hsave = _f(dev, N, 128), _f(dev, 8, N, 256)
+
+
+def mlp_forward(model: TalkingFace, st: MlpState, rgb: torch.Tensor, stream) -> None:
+    """rows already embedded in st.x / st.xT -> rgb [N,3], activations kept in `st`."""
+    lib, ck = _abi.load(), _abi.check
+    packed = model.packed_weights()
+    if st.precision == "bf16":
+        ck(lib.s2l_train_forward_bf16(_ptr(model.packed_weights_bf16()), _ptr(packed), _ptr(st.xT), _ptr(st.hT), _ptr(st.masks),
+                                      _ptr(rgb), st.N, stream), "s2l_train_forward_bf16")
+    else:
+        ck(lib.s2l_train_forward(_ptr(packed), _ptr(st.x), _ptr(st.hsave), _ptr(rgb), st.N, stream), "s2l_train_forward")
+
+
+def mlp_backward(model: TalkingFace, st: MlpState, drgb: torch.Tensor, stream):
+    """d loss / d rgb [N,3] -> ({state-dict name: gradient} for the 30 MLP tensors, dxa [N,64] = gradient of the audio columns).
+    dz chain, weight-gradient GEMMs, and the un-fold of the pack-time folds (s2l_unfold_first_layer) -- all HIP."""
+    lib, ck = _abi.load(), _abi.check
+    packed = model.packed_weights()
+    dev, N = packed.device, st.N
+    dxa = _f(dev, N, 64)
+    bf16 = st.precision == "bf16"
+    if bf16:
+        pb = model.packed_weights_bf16()
+        lay = st.Np * 256
+        dzT = torch.empty(8 * lay, dtype=torch.int16, device=dev)
+        ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(st.masks), _ptr(dzT), _ptr(dxa), N, stream),
+           "s2l_train_backward_bf16")
+        work = _f(dev, int(lib.s2l_wgrad_bf16_work_floats()))
+
+        def wgrad(k, inp, k_in, want_bias=True):          # dz of layer k against hT[inp] or the x tiles
+            out, db = _f(dev, 256, k_in), (_f(dev, 256) if want_bias else None)
+            src = st.xT if inp is None else st.hT[inp * lay:]
+            ck(lib.s2l_wgrad_bf16(_ptr(dzT[k * lay:]), _ptr(src), k_in, _ptr(work), _ptr(out), _ptr(db), N, stream), "s2l_wgrad_bf16")
+            return out, db
+    else:
+        dzsave = _f(dev, 8, N, 256)
+        ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(st.hsave), _ptr(dzsave), _ptr(dxa), N, stream), "s2l_train_backward")
+        work = _f(dev, int(lib.s2l_split_work_floats(256 * 256)))
+
+        def wgrad(k, inp, k_in, want_bias=True):
+            out, db = _f(dev, 256, k_in), (_f(dev, 256) if want_bias else None)
+            src, ldin = (st.x, 128) if inp is None else (st.hsave[inp], 256)
+            ck(lib.s2l_wgrad(_ptr(dzsave[k]), 256, _ptr(src), ldin, k_in, _ptr(work), _ptr(out), _ptr(db), N, stream), "s2l_wgrad")
+            return out, db
+
+    g = {}
+    dw5b = dc5 = None
+    for k in range(1, 8):                          # pts_linears[k]: h_{k-1} -> h_k
+        dw, db = wgrad(k, k - 1, 256)
+        if k == 5:
+            dw5b, dc5 = dw, db
+        else:
+            g[f"pts_linears.{k}.weight"], g[f"pts_linears.{k}.bias"] = dw, db
+    dG0, dc0 = wgrad(0, None, 128)
+    dG5, _ = wgrad(5, None, 128, want_bias=False)
+    dwout, dbout = _f(dev, 3, 256), _f(dev, 3)
+    if bf16:
+        ck(lib.s2l_out_grad_bf16(_ptr(drgb), _ptr(st.hT[7 * lay:]), _ptr(work), _ptr(dwout), _ptr(dbout), N, stream), "s2l_out_grad_bf16")
+    else:
+        ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(st.hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, stream), "s2l_small_outer")
+        ck(lib.s2l_small_outer(None, 0, 1, _ptr(drgb), 3, 3, _ptr(work), _ptr(dbout), N, stream), "s2l_small_outer")
+    g["output_linear.weight"], g["output_linear.bias"] = dwout, dbout
+
+    # un-fold G0 = W0 [Wuv|Wa|Wt], c0 = W0 (buv+ba+bt) + b0 (and the skip twins)
+    sd = dict(model.named_parameters())
+    w = lambda name: _dev_f32(sd[name], dev, name)
+
+    def unfold(first, ld, names, dG, dc, right):
+        d_first = _f(dev, 256, ld)
+        outs = [_f(dev, 256, 42), _f(dev, 256, 64), _f(dev, 256, 20), _f(dev, 256)]
+        ck(lib.s2l_unfold_first_layer(_ptr(dG), _ptr(dc), _ptr(w(first)), ld, *[_ptr(w(f"{n}.weight")) for n in names],
+                                      *[_ptr(w(f"{n}.bias")) for n in names], _ptr(right), _ptr(d_first), *[_ptr(o) for o in outs],
+                                      stream), "s2l_unfold_first_layer")
+        for n, o in zip(names, outs[:3]):
+            g[f"{n}.weight"], g[f"{n}.bias"] = o, outs[3].clone()
+        return d_first
+
+    g["pts_linears.0.weight"] = unfold("pts_linears.0.weight", 256, ("fc_uv", "fc_audio", "fc_time"), dG0, dc0, None)
+    g["pts_linears.0.bias"] = dc0
+    g["pts_linears.5.weight"] = unfold("pts_linears.5.weight", 512, ("fc_uv_skip", "fc_audio_skip", "fc_time_skip"), dG5, dc5, dw5b)
+    g["pts_linears.5.bias"] = dc5
+    return g, dxa
+
+
+def audio_backward(model: TalkingFace, audio32: torch.Tensor, dfeat: torch.Tensor, stream):
+    """d loss / d feat [B,64] -> gradients of the 12 audio-encoder tensors (autograd of tf_nerf.py:197-213)."""
+    lib = _abi.load()
+    dev = dfeat.device
+    B = audio32.shape[0]
+    na = int(lib.s2l_audio_grad_floats())
+    awork, agrads = _f(dev, ((B + 3) // 4) * na), _f(dev, na)
+    _abi.check(lib.s2l_audio_backward(_ptr(model.packed_weights()), _ptr(audio32), _ptr(dfeat), _ptr(awork), _ptr(agrads), B, stream),
+               "s2l_audio_backward")
+    params, g, off = dict(model.named_parameters()), {}, 0
+    for name in AUDIO_TENSORS:
+        p_ = params[name]
+        g[name] = agrads[off:off + p_.numel()].reshape(p_.shape)
+        off += p_.numel()
+    return g
 
 
 class LipTrainStep:
-    """Forward + backward of the lip-MLP training objective (BASELINE config 5, fp32 parity mode):
+    """Forward + backward of the lip-MLP training objective (BASELINE config 5) for a batch of frames:
 
-        loss = weight * mean_{frames, pixels, rgb} (predict_lip_image(frame) - target)^2
+        pred[f] = predict_lip_image(frame f)     4-tap local ensemble, training.py:158-251
+        grads   = d loss / d (all 42 hot-path tensors)  given  d loss / d pred
 
-    i.e. `Trainer.predict_lip_image` (training.py:158-251) + `add_photometric_loss` (:605-619) and
-    their autograd, as hand-written HIP kernels: rows -> forward with saved activations -> ensemble
-    reduce -> MSE -> ensemble backward -> dz chain -> weight-gradient GEMMs.  Returns gradients
-    keyed by the reference's state-dict names.  The tiny un-folding of the pack-time folds
-    (G0 = W0 [Wuv|Wa|Wt] etc., four 256x256x126 products) uses torch.matmul on the device.
-    """
+    as hand-written HIP kernels: rows -> forward with saved activations -> ensemble reduce | ensemble backward -> dz
+    chain -> weight-gradient GEMMs -> un-fold -> audio-encoder backward.  `loss_and_grads` closes the loop with the
+    photometric loss (training.py:605-619).  Gradients are keyed by the reference's state-dict names."""
 
     def __init__(self, model: TalkingFace, height: int, width: int, precision: str = "fp32"):
         """precision: 'fp32' (parity mode: exact-fp32 MFMA, saved state in fp32) or 'bf16' (BASELINE config 5: bf16 MFMA
@@ -108,147 +255,237 @@ class LipTrainStep:
         self.model, self.h, self.w = model, int(height), int(width)
         self.lib = _abi.load()
         self.coords = get_coords(width, height, model.packed_weights().device)
+        self._ctx = None
 
-    def _f(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32, device=self.coords.device)
-
-    def loss_and_grads(self, audio, frame_idx, targets, u01, weight: float = 1.0):
-        lib, m = self.lib, self.model
+    def forward(self, audio, frame_idx, u01) -> torch.Tensor:
+        """audio [B,16,29], frame indices [B], U(0,1) draws [B] (training.py:200) -> pred [B,HW,3]; keeps what
+        `backward` needs until the next forward."""
+        lib, m, ck = self.lib, self.model, _abi.check
         packed = m.packed_weights()
         dev = packed.device
-        B, P = audio.shape[0], self.h * self.w
+        a32 = _dev_f32(audio, dev, "audio")
+        B, P = a32.shape[0], self.h * self.w
         N = 4 * P * B
-        tgt = _dev_f32(targets, dev, "targets").reshape(B * P, 3)
         idx = [int(i) for i in (frame_idx.tolist() if isinstance(frame_idx, torch.Tensor) else frame_idx)]
         u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
-        st = _stream()
-        ck = _abi.check
-        feat = m.audio_merge_forward(audio)                                  # [B,64]
-        areas = self._f(N)
-        bf16 = self.precision == "bf16"
-        if bf16:
-            Np = int(lib.s2l_bf16_rows_padded(N))
-            pb = m.packed_weights_bf16()
-            i16 = lambda n: torch.empty(n, dtype=torch.int16, device=dev)
-            hT, dzT, xT = i16(8 * Np * 256), i16(8 * Np * 256), i16(Np * 128)
-            masks = torch.empty(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
-            x = None
-        else:
-            x = self._f(N, 128)
-            hsave, dzsave = self._f(8, N, 256), self._f(8, N, 256)
-        rgb, drgb, dxa = self._f(N, 3), self._f(N, 3), self._f(N, 64)
-        pred, dpred = self._f(B * P, 3), self._f(B * P, 3)
-        loss, mwork = self._f(1), self._f(1024)
+        if len(idx) != B or len(u) != B:
+            raise ValueError("frame_idx and u01 need one entry per audio window")
+        feat = m._audio_encode(a32)                                          # [B,64]
+        st = MlpState(self.precision, N, dev, lib)
+        areas, rgb, pred = _f(dev, N), _f(dev, N, 3), _f(dev, B * P, 3)
+        t_idx = torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
+        t_u = torch.tensor(u, dtype=torch.float32).to(dev, non_blocking=True)
         with torch.cuda.device(dev):
-            if bf16:     # the embedded rows of the whole batch in one launch, straight to the bf16 operand image
-                t_idx = torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
-                t_u = torch.tensor(u, dtype=torch.float32).to(dev, non_blocking=True)
+            s = _stream()
+            if self.precision == "bf16":     # the embedded rows of the whole batch in one launch, straight to the bf16 operand image
                 ck(lib.s2l_ensemble_rows_bf16(_ptr(packed), _ptr(self.coords), _ptr(feat), _ptr(t_idx), _ptr(t_u), self.w, self.h,
-                                              _ptr(xT), _ptr(areas), P, B, st), "s2l_ensemble_rows_bf16")
-            else:
-                for b in range(B):   # rows of frame b: [b*4P, (b+1)*4P), tap-major inside
-                    ck(lib.s2l_ensemble_rows(_ptr(packed), _ptr(self.coords), _ptr(feat[b]), idx[b], self.w, self.h,
-                                             ctypes.c_float(u[b]), _ptr(x[b * 4 * P:]), _ptr(areas[b * 4 * P:]), P, st),
-                       "s2l_ensemble_rows")
-            if bf16:
-                ck(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(packed), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, st),
-                   "s2l_train_forward_bf16")
-            else:
-                ck(lib.s2l_train_forward(_ptr(packed), _ptr(x), _ptr(hsave), _ptr(rgb), N, st), "s2l_train_forward")
-            ck(lib.s2l_ensemble_reduce_batch(_ptr(rgb), _ptr(areas), _ptr(pred), P, B, st), "s2l_ensemble_reduce_batch")
-            ck(lib.s2l_mse(_ptr(pred), _ptr(tgt), ctypes.c_float(weight), _ptr(dpred), _ptr(mwork), _ptr(loss),
-                           B * P * 3, st), "s2l_mse")
-            ck(lib.s2l_ensemble_backward_batch(_ptr(dpred), _ptr(areas), _ptr(drgb), P, B, st), "s2l_ensemble_backward_batch")
-            if bf16:
-                ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, st),
-                   "s2l_train_backward_bf16")
-                work = self._f(int(lib.s2l_wgrad_bf16_work_floats()))
-                lay = Np * 256
+                                              _ptr(st.xT), _ptr(areas), P, B, s), "s2l_ensemble_rows_bf16")
+            else:                            # rows of frame b: [b*4P, (b+1)*4P), tap-major inside
+                ck(lib.s2l_ensemble_rows_batch(_ptr(packed), _ptr(self.coords), _ptr(feat), _ptr(t_idx), _ptr(t_u), self.w, self.h,
+                                               _ptr(st.x), _ptr(areas), P, B, s), "s2l_ensemble_rows_batch")
+            mlp_forward(m, st, rgb, s)
+            ck(lib.s2l_ensemble_reduce_batch(_ptr(rgb), _ptr(areas), _ptr(pred), P, B, s), "s2l_ensemble_reduce_batch")
+        self._ctx = (st, areas, a32, B, P)
+        return pred.reshape(B, P, 3)
 
-                def wgrad(k, inp, ldin, k_in, want_bias=True):          # dz of layer k against hT[inp] or the x tiles
-                    out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
-                    src = xT if inp is None else hT[inp * lay:]
-                    ck(lib.s2l_wgrad_bf16(_ptr(dzT[k * lay:]), _ptr(src), k_in, _ptr(work), _ptr(out), _ptr(db), N, st),
-                       "s2l_wgrad_bf16")
-                    return out, db
-            else:
-                ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(hsave), _ptr(dzsave), _ptr(dxa), N, st),
-                   "s2l_train_backward")
-                work = self._f(int(lib.s2l_split_work_floats(256 * 256)))
-
-                def wgrad(k, inp, ldin, k_in, want_bias=True):
-                    out, db = self._f(256, k_in), (self._f(256) if want_bias else None)
-                    src = x if inp is None else hsave[inp]
-                    ck(lib.s2l_wgrad(_ptr(dzsave[k]), 256, _ptr(src), ldin, k_in, _ptr(work), _ptr(out), _ptr(db), N, st),
-                       "s2l_wgrad")
-                    return out, db
-
-            def colsum(src, c):
-                out = self._f(c)
-                ck(lib.s2l_small_outer(None, 0, 1, _ptr(src), c, c, _ptr(work), _ptr(out), N, st), "s2l_small_outer")
-                return out
-
-            g = {}
-            for k in range(1, 8):                          # pts_linears[k]: h_{k-1} -> h_k
-                dw, db = wgrad(k, k - 1, 256, 256)
-                if k == 5:
-                    dw5b, dc5 = dw, db
-                else:
-                    g[f"pts_linears.{k}.weight"], g[f"pts_linears.{k}.bias"] = dw, db
-            dG0, dc0 = wgrad(0, None, 128, 128)
-            dG5, _ = wgrad(5, None, 128, 128, want_bias=False)
-            dwout = self._f(3, 256)
-            if bf16:
-                dbout = self._f(3)
-                ck(lib.s2l_out_grad_bf16(_ptr(drgb), _ptr(hT[7 * lay:]), _ptr(work), _ptr(dwout), _ptr(dbout), N, st),
-                   "s2l_out_grad_bf16")
-                g["output_linear.weight"], g["output_linear.bias"] = dwout, dbout
-            else:
-                ck(lib.s2l_small_outer(_ptr(drgb), 3, 3, _ptr(hsave[7]), 256, 256, _ptr(work), _ptr(dwout), N, st),
-                   "s2l_small_outer")
-                g["output_linear.weight"], g["output_linear.bias"] = dwout, colsum(drgb, 3)
+    def backward(self, dpred: torch.Tensor):
+        """d loss / d pred [B,HW,3] -> ({name: gradient} for all 42 tensors, {'d_audio_feat': [B,64]})."""
+        if self._ctx is None:
+            raise RuntimeError("LipTrainStep.backward needs a preceding forward")
+        lib, m, ck = self.lib, self.model, _abi.check
+        st, areas, a32, B, P = self._ctx
+        dev = areas.device
+        dp = _dev_f32(dpred, dev, "dpred").reshape(B * P, 3)
+        drgb = _f(dev, st.N, 3)
+        with torch.cuda.device(dev):
+            s = _stream()
+            ck(lib.s2l_ensemble_backward_batch(_ptr(dp), _ptr(areas), _ptr(drgb), P, B, s), "s2l_ensemble_backward_batch")
+            g, dxa = mlp_backward(m, st, drgb, s)
             # per-frame gradient of the audio feature (rows of frame b are contiguous), then the encoder backward
-            da = dxa.reshape(B, 4 * P, 64).sum(dim=1).contiguous()
-            na = int(lib.s2l_audio_grad_floats())
-            awork, agrads = self._f(((B + 3) // 4) * na), self._f(na)
-            a32 = _dev_f32(audio, dev, "audio")
-            ck(lib.s2l_audio_backward(_ptr(packed), _ptr(a32), _ptr(da), _ptr(awork), _ptr(agrads), B, st),
-               "s2l_audio_backward")
-            off = 0
-            for name in _abi.TENSOR_ORDER[:12]:
-                p_ = dict(m.named_parameters())[name]
-                g[name] = agrads[off:off + p_.numel()].reshape(p_.shape)
-                off += p_.numel()
+            da, swork = _f(dev, B, 64), _f(dev, B * 32 * 64)
+            ck(lib.s2l_segment_colsums(_ptr(dxa), 64, 64, 4 * P, B, _ptr(swork), _ptr(da), s), "s2l_segment_colsums")
+            g.update(audio_backward(m, a32, da, s))
+        self._ctx = None
+        return g, {"d_audio_feat": da}
 
-        # un-fold G0 = W0 [Wuv|Wa|Wt], c0 = W0 (buv+ba+bt) + b0 (and the skip twins) -- tiny device GEMMs
-        sd = dict(m.named_parameters())
-
-        def unfold(w_first, names, dG, dc):
-            C = torch.cat([sd[f"{n}.weight"].detach() for n in names], dim=1)             # [256,126]
-            bsum = sum(sd[f"{n}.bias"].detach() for n in names)
-            dW = dG[:, :126] @ C.t() + torch.outer(dc, bsum)
-            dC = w_first.t() @ dG[:, :126]
-            dbs = w_first.t() @ dc
-            out = {}
-            for n, (lo, hi) in zip(names, ((0, 42), (42, 106), (106, 126))):
-                out[f"{n}.weight"], out[f"{n}.bias"] = dC[:, lo:hi].contiguous(), dbs.clone()
-            return dW, out
-
-        W0 = sd["pts_linears.0.weight"].detach()
-        W5a = sd["pts_linears.5.weight"].detach()[:, :256]
-        dW0, part = unfold(W0, ("fc_uv", "fc_audio", "fc_time"), dG0, dc0)
-        g.update(part)
-        g["pts_linears.0.weight"], g["pts_linears.0.bias"] = dW0, dc0
-        dW5a, part = unfold(W5a, ("fc_uv_skip", "fc_audio_skip", "fc_time_skip"), dG5, dc5)
-        g.update(part)
-        g["pts_linears.5.weight"], g["pts_linears.5.bias"] = torch.cat([dW5a, dw5b], dim=1), dc5
-        return loss, g, {"pred": pred.reshape(B, P, 3), "d_audio_feat": da}
+    def loss_and_grads(self, audio, frame_idx, targets, u01, weight: float = 1.0):
+        """loss = weight * mean_{frames, pixels, rgb} (pred - target)^2 and its gradients."""
+        pred = self.forward(audio, frame_idx, u01)
+        dev = pred.device
+        tgt = _dev_f32(targets, dev, "targets").reshape(pred.shape)
+        dpred, loss, mwork = torch.empty_like(pred), _f(dev, 1), _f(dev, 1024)
+        with torch.cuda.device(dev):
+            _abi.check(self.lib.s2l_mse(_ptr(pred), _ptr(tgt), ctypes.c_float(weight), _ptr(dpred), _ptr(mwork), _ptr(loss),
+                                        pred.numel(), _stream()), "s2l_mse")
+        g, aux = self.backward(dpred)
+        aux["pred"] = pred
+        return loss, g, aux
 
 
 def apply_grads(model: TalkingFace, grads) -> None:
-    """Install the gradients returned by `LipTrainStep.loss_and_grads` as `.grad` of the matching
-    parameters, so a stock optimizer (the reference uses Adam(lr=1e-4), train.py:128) can step."""
+    """Install the gradients returned by `LipTrainStep` as `.grad` of the matching parameters, so a stock optimizer (the
+    reference uses Adam(lr=1e-4), train.py:128) can step."""
     params = dict(model.named_parameters())
     for name, g in grads.items():
         p = params[name]
         p.grad = g.reshape(p.shape).to(p.dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class SyncChain:
+    """The path between the rendered lips of a 5-frame window and the lip-sync expert's loss (training.py:491-557):
+
+        lip [S*T,h,w,3] -> paste + head-pose warp against the MAIN frame's observed image (post_fusion2_onlylip, :527-536)
+                        -> frozen eval-mode post-fusion U-Net (its first return value is rgb_recon, tf_nerf.py:387-389)
+                        -> crop to data['canonical_face_bbox'] + Resize([96,96]) (:541-544) -> rgb_window [S,3,T,96,96]
+                        -> get_sync_contrastive_loss(mel, rgb_window, rgb_window_neg) * w_syncloss (:551-552)
+
+    and its adjoint back to d loss / d lip.  Samples go through in groups that bound the U-Net state (about 1 GB per
+    500x500 frame for the saved activations and the backward scratch)."""
+
+    def __init__(self, model: TalkingFace, syncnet, syncnet_T: int = 5, w_syncloss: float = 0.01, out_hw=(96, 96),
+                 max_frames_per_group: int = 40):
+        from .syncnet import SyncLoss
+        if getattr(model, "post_fusion_unet", None) is None:
+            raise ValueError("SyncChain needs model.use_post_fusion (the window is the U-Net's output)")
+        self.model, self.T, self.w = model, int(syncnet_T), float(w_syncloss)
+        self.sync = SyncLoss(syncnet, syncnet_T)
+        self.out_hw = (int(out_hw[0]), int(out_hw[1]))
+        self.group = max(1, int(max_frames_per_group) // self.T)
+
+    def loss_and_dlip(self, lips, rgb_face_canonical, rgb_face_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
+                      coord_window, canonical_face_bbox, mel, rgb_window_neg):
+        """lips [S*T,h,w,3] (sample-major: frame s*T + t); rgb_face_canonical, mask_lip_canonical [1,FH,FW,3] (per clip);
+        rgb_face_gt [S,FH,FW,3] (the main frame of each sample); coord_window [S,T,FH,FW,2]; canonical_face_bbox
+        (x, y, x2, y2[, score]); mel [S,1,80,16]; rgb_window_neg [S,3,T,96,96].
+        Returns (loss = w_syncloss * mean over samples, d loss / d lips, rgb_window [S,3,T,96,96])."""
+        lib, m, ck, T = _abi.load(), self.model, _abi.check, self.T
+        dev = m.packed_weights().device
+        lips = _dev_f32(lips, dev, "lips")
+        S = lips.shape[0] // T
+        if lips.shape[0] != S * T or S == 0:
+            raise ValueError(f"lips must hold {T} frames per sample")
+        gt = _dev_f32(rgb_face_gt, dev, "rgb_face_gt")
+        cw = _dev_f32(coord_window, dev, "coord_window")
+        FH, FW = gt.shape[1], gt.shape[2]
+        if gt.shape[0] != S or cw.shape != (S, T, FH, FW, 2):
+            raise ValueError("rgb_face_gt must be [S,FH,FW,3] and coord_window [S,T,FH,FW,2]")
+        x, y, x2, y2 = (int(v) for v in list(canonical_face_bbox)[:4])
+        oh, ow = self.out_hw
+        mel = _dev_f32(mel, dev, "mel")
+        neg = _dev_f32(rgb_window_neg, dev, "rgb_window_neg")
+        unet = m.post_fusion_unet
+        d_lips = torch.empty_like(lips)
+        window = _f(dev, S, 3, T, oh, ow)
+        total = torch.zeros((), dtype=torch.float32, device=dev)
+        for s0 in range(0, S, self.group):
+            s1 = min(S, s0 + self.group)
+            n, fr = s1 - s0, slice(s0 * T, s1 * T)
+            gt_f = gt[s0:s1].repeat_interleave(T, dim=0)                      # each window frame sees its sample's main frame
+            coord_f = cw[s0:s1].reshape(n * T, FH, FW, 2)
+            new, _ = m.composite_clip(lips[fr], rgb_face_canonical, gt_f, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_f)
+            recon, saved = unet.forward_saved_nhwc(new)
+            win = window[s0:s1]
+            with torch.cuda.device(dev):
+                ck(lib.s2l_crop_resize(_ptr(recon), FH, FW, x, y, x2, y2, _ptr(win), oh, ow, T, n * T, _stream()), "s2l_crop_resize")
+            # BCE is a mean over the batch: this group's share of the mean over all S samples
+            loss, d_win = self.sync.get_sync_contrastive_loss(mel[s0:s1], win, neg[s0:s1], weight=self.w * n / S, want_grad=True)
+            total = total + loss
+            d_recon = torch.empty_like(recon)
+            with torch.cuda.device(dev):
+                ck(lib.s2l_crop_resize_backward(_ptr(d_win), FH, FW, x, y, x2, y2, _ptr(d_recon), oh, ow, T, n * T, _stream()),
+                   "s2l_crop_resize_backward")
+            d_new = unet.backward_input(saved, d_recon)
+            del saved, recon, d_recon
+            d_lips[fr] = m.composite_backward_lip(d_new, rgb_face_canonical, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
+                                                  coord_f, lips.shape[1], lips.shape[2])
+        return total, d_lips, window
+
+
+class StageOneStep:
+    """One optimisation step's loss and gradients as the reference forms them after `it > 100000` (train_stage1,
+    training.py:347-574, May flags; LPIPS terms excluded -- their weights are not in the reference repository):
+
+        loss = lambda_rgb * MSE(lip)                                                        (:417-418)
+             [+ w_post_fusion * MSE(U-Net(composite_blackaug(lip)), rgb_face_ori)]           (:436-459, `face_loss`)
+             + w_syncloss * sync_contrastive(window of T more renders -> composite -> U-Net -> crop/resize)   (:491-557)
+
+    for B main frames (each a sample) of which the first S carry a sync window.  All frames -- B main + S*T window -- go
+    through ONE batched LipTrainStep forward/backward."""
+
+    def __init__(self, model: TalkingFace, height: int, width: int, syncnet=None, precision: str = "bf16", syncnet_T: int = 5,
+                 w_syncloss: float = 0.01, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, face_loss: bool = False):
+        self.model, self.h, self.w = model, int(height), int(width)
+        self.step = LipTrainStep(model, height, width, precision)
+        self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss) if syncnet is not None else None
+        self.T, self.lambda_rgb, self.w_post_fusion, self.face_loss = int(syncnet_T), float(lambda_rgb), float(w_post_fusion), face_loss
+
+    def loss_and_grads(self, audio, frame_idx, targets, u01, sync=None, face=None):
+        """audio [B,16,29], frame_idx [B], targets [B,HW,3], u01 [B]: the main frames.
+        sync (optional): dict(audio_window [S,T,16,29], u01 [S,T], total_frame, rgb_face_canonical, rgb_face_gt [S,...],
+        mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_window [S,T,FH,FW,2], canonical_face_bbox, mel, rgb_window_neg)
+        -- sample s belongs to main frame s.
+        face (optional, `face_loss`): dict(rgb_face_canonical, rgb_face_gt [B,...], mask_lip_canonical, lip_lefttop_x,
+        lip_lefttop_y, coord [B,FH,FW,2], hole_noise=None | (n1, n2) [B,FH,FW])."""
+        lib, m, ck = _abi.load(), self.model, _abi.check
+        dev = m.packed_weights().device
+        a = _dev_f32(audio, dev, "audio")
+        B, P = a.shape[0], self.h * self.w
+        idx = [int(i) for i in (frame_idx.tolist() if isinstance(frame_idx, torch.Tensor) else frame_idx)]
+        u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
+        S = 0
+        if sync is not None:
+            if self.chain is None:
+                raise ValueError("StageOneStep was built without a syncnet")
+            aw = _dev_f32(sync["audio_window"], dev, "audio_window")
+            S, T = aw.shape[0], aw.shape[1]
+            if T != self.T or S > B:
+                raise ValueError("audio_window must be [S<=B,T,16,29]")
+            total = int(sync["total_frame"])
+            uw = sync["u01"].tolist() if isinstance(sync["u01"], torch.Tensor) else sync["u01"]
+            for s in range(S):              # cur_data['index'] = index + t, clamped to the last frame (training.py:515-518)
+                for t in range(T):
+                    idx.append(idx[s] + t if idx[s] + t < total else total - 1)
+                    u.append(float(uw[s][t]))
+            a = torch.cat([a, aw.reshape(S * T, 16, 29)], 0)
+        pred = self.step.forward(a, idx, u)                                   # [B + S*T, P, 3]
+        dpred = torch.zeros_like(pred)
+        losses = {}
+        tgt = _dev_f32(targets, dev, "targets").reshape(B, P, 3)
+        loss, mwork = _f(dev, 1), _f(dev, 1024)
+        with torch.cuda.device(dev):
+            ck(lib.s2l_mse(_ptr(pred[:B]), _ptr(tgt), ctypes.c_float(self.lambda_rgb), _ptr(dpred[:B]), _ptr(mwork), _ptr(loss),
+                           B * P * 3, _stream()), "s2l_mse")
+        losses["loss_rgb"] = loss[0]
+        total_loss = loss[0]
+        if face is not None:
+            if not self.face_loss:
+                raise ValueError("pass face_loss=True to StageOneStep to use the face photometric term")
+            lip = pred[:B].reshape(B, self.h, self.w, 3)
+            holes = face.get("hole_noise")
+            gt = _dev_f32(face["rgb_face_gt"], dev, "rgb_face_gt")
+            args = (face["rgb_face_canonical"], face["mask_lip_canonical"], face["lip_lefttop_x"], face["lip_lefttop_y"], face["coord"])
+            new, _ = m.composite_clip(lip, args[0], gt, args[1], args[2], args[3], args[4], hole_noise=holes)
+            recon, saved = m.post_fusion_unet.forward_saved_nhwc(new)
+            d_recon, floss = torch.empty_like(recon), _f(dev, 1)
+            with torch.cuda.device(dev):
+                ck(lib.s2l_mse(_ptr(recon), _ptr(gt), ctypes.c_float(self.lambda_rgb * self.w_post_fusion), _ptr(d_recon), _ptr(mwork),
+                               _ptr(floss), recon.numel(), _stream()), "s2l_mse")
+            d_new = m.post_fusion_unet.backward_input(saved, d_recon)
+            d_lip = m.composite_backward_lip(d_new, args[0], args[1], args[2], args[3], args[4], self.h, self.w, hole_noise=holes)
+            dpred[:B] += d_lip.reshape(B, P, 3)
+            losses["loss_face"] = floss[0]
+            total_loss = total_loss + floss[0]
+        if S:
+            lips = pred[B:].reshape(S * self.T, self.h, self.w, 3)
+            sl, d_lips, window = self.chain.loss_and_dlip(lips, sync["rgb_face_canonical"], sync["rgb_face_gt"], sync["mask_lip_canonical"],
+                                                          sync["lip_lefttop_x"], sync["lip_lefttop_y"], sync["coord_window"],
+                                                          sync["canonical_face_bbox"], sync["mel"], sync["rgb_window_neg"])
+            dpred[B:] = d_lips.reshape(S * self.T, P, 3)
+            losses["loss_sync"] = sl
+            losses["rgb_window"] = window
+            total_loss = total_loss + sl
+        g, aux = self.step.backward(dpred)
+        aux.update(losses)
+        aux["pred"] = pred
+        return total_loss, g, aux

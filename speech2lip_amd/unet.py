@@ -104,6 +104,47 @@ class SimpleUnetLight(nn.Module):
                                                 H, W, n, st), "s2l_unet_forward")
         return out
 
+    def forward_saved_nhwc(self, x: torch.Tensor):
+        """Training-time forward of the frozen eval-mode network: x [F,H,W,3] -> (out [F,H,W,3], saved), where `saved` holds
+        every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        if x.device.type != "cuda":
+            raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
+        if self.training:
+            raise NotImplementedError("the HIP U-Net is eval-mode only (BatchNorm uses its running statistics)")
+        x = x.detach().to(torch.float32).contiguous()
+        F_, H, W, C = x.shape
+        if C != 3 or H < 4 or W < 4:
+            raise ValueError(f"U-Net input must be [F,H>=4,W>=4,3], got {tuple(x.shape)}")
+        out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
+        saved = torch.empty(int(lib.s2l_unet_saved_floats(H, W, F_)), dtype=torch.float32, device=x.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(x.device):
+            _abi.check(lib.s2l_unet_forward_saved(p(packed), p(x), p(saved), p(out), H, W, F_,
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_forward_saved")
+        return out, (saved, packed, (F_, H, W))
+
+    def backward_input(self, saved_ctx, d_out: torch.Tensor) -> torch.Tensor:
+        """d loss / d x [F,H,W,3] from d loss / d out, through the frozen network (what autograd propagates once the
+        post-fusion net is fixed, train.py:188-197)."""
+        lib = _abi.load()
+        saved, packed, (F_, H, W) = saved_ctx
+        d = d_out.detach().to(torch.float32).contiguous()
+        if d.shape != (F_, H, W, 3) or d.device != saved.device:
+            raise ValueError(f"d_out must be [{F_},{H},{W},3] on {saved.device}")
+        dx = torch.empty_like(d)
+        work = torch.empty(int(lib.s2l_unet_backward_work_floats(H, W, F_)), dtype=torch.float32, device=d.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(d.device):
+            _abi.check(lib.s2l_unet_backward(p(packed), p(saved), p(d), p(work), p(dx), H, W, F_,
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward")
+        return dx
+
     def forward(self, x, x_level1=None, x_level2=None):
-        """NCHW in, NCHW out, as the reference's forward (SimpleUnetLight.py:99-111)."""
+        """NCHW in, NCHW out, as the reference's forward (SimpleUnetLight.py:99-111).  With autograd recording and an input
+        that requires grad, the input gradient is available to loss.backward() (speech2lip_amd.autograd)."""
+        if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+            from .autograd import unet_eval
+            return unet_eval(self, x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         return self.forward_nhwc(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

@@ -1,0 +1,331 @@
+"""GPU parity of the training-side chain (SURVEY.md §8f-4 light half, A7's training branch, the autograd surface):
+composite with black holes and its lip gradient, crop + resize and its adjoint, the frozen U-Net's input gradient, the whole
+stage-1 step against the gradients the reference's own train_stage1 left in .grad (G11), and the torch.autograd.Function
+wrappers driven the way the reference's training loop drives the module."""
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from oracle import s2l_oracle as O
+from speech2lip_amd import weights as W
+from tests.test_gpu_parity import close, make_model
+from tests.test_oracle_golden import g11_inputs
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def syncnet(dev):
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: T(v) for k, v in W.make_syncnet_state_dict(0).items()}, strict=True)
+    return net
+
+
+def full_model(dev, h, w, path="dataset/may_face_crop_lip"):
+    m = make_model(dev, h, w, path=path)
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    return m
+
+
+def relerr(a, b):
+    b = torch.as_tensor(b)
+    return float((a.detach().cpu().double() - b.double()).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------ A7, training branch
+def test_composite_black_holes_golden(golden, dev):
+    """tf_nerf.py:371-384 against the reference's own output (G10).  The hole set hangs on `grid_sample(face > 0) == 1`
+    exactly: a pixel whose four weights sum to 1 within one ulp may fall on the other side on another evaluation order, so
+    the bulk must match to rounding and at most a handful of pixels may differ as whole pixels."""
+    g4, g = golden("g4_composite.npz"), golden("g10_blackaug.npz")
+    m = make_model(dev, 16, 24)
+    args = [T(g4["lip"]).to(dev), T(g["face"]).to(dev), T(g4["gt"]).to(dev), T(g4["mask"]).to(dev), int(g4["x0"]), int(g4["y0"]),
+            T(g4["coord"]).to(dev)]
+    holes = (T(g["hole1"]).to(dev), T(g["hole2"]).to(dev))
+    new, _ = m.composite_clip(*args, hole_noise=holes)
+    d = (new.cpu() - T(g["merged_new"])).abs().amax(-1)
+    assert int((d > 2e-6).sum()) <= 4, int((d > 2e-6).sum())
+    plain, _ = m.composite_clip(*args)
+    assert float((new != plain).any(-1).float().mean()) > 0.2
+    # two frames with per-clip constants take the fused-table path (face > 0 bits ride in the table's 4th component)
+    two = [a.repeat(2, 1, 1, 1) if isinstance(a, torch.Tensor) and k in (0, 2, 6) else a for k, a in enumerate(args)]
+    new2, _ = m.composite_clip(*two, hole_noise=(holes[0].repeat(2, 1, 1), holes[1].repeat(2, 1, 1)))
+    assert torch.equal(new2[0], new[0]) and torch.equal(new2[1], new[0])
+    # through the drop-in method: the coin and the randn fields are drawn like the reference draws them
+    import random
+    real_randn, real_random = torch.randn, random.random
+    q = [T(g["hole1"])[:, None].repeat(1, 3, 1, 1), T(g["hole2"])[:, None].repeat(1, 3, 1, 1)]
+    torch.randn = lambda *a, **k: q.pop(0)
+    random.random = lambda: 0.9
+    try:
+        _, via_method, _ = m.post_fusion2_onlylip(*args, use_post_fusion_blackaug=True)
+    finally:
+        torch.randn, random.random = real_randn, real_random
+    assert torch.equal(via_method, new)
+
+
+@pytest.mark.parametrize("expand,holes,F", [(True, False, 1), (True, True, 3), (False, False, 2), (False, True, 1)])
+def test_composite_lip_gradient_vs_oracle_autograd(dev, expand, holes, F):
+    """d lip of the paste + warp composite against torch autograd through the oracle (soft masks: the blend is a true lerp)."""
+    rng = np.random.default_rng(17 + F)
+    FH, FW, lh, lw, x0, y0 = 40, 56, 10, 15, 18, 12
+    m = make_model(dev, lh, lw)
+    m.expand_lip_mask = expand
+    lip = T(rng.random((F, lh, lw, 3), dtype=np.float32))
+    face = T(rng.random((1, FH, FW, 3), dtype=np.float32))
+    face[:, 5:9] = 0
+    mask = torch.zeros(1, FH, FW, 3)
+    mask[:, y0:y0 + lh, x0:x0 + lw] = T(rng.random((lh, lw, 3), dtype=np.float32))
+    gt = T(rng.random((F, FH, FW, 3), dtype=np.float32))
+    coord = T((rng.random((F, FH, FW, 2), dtype=np.float32) * 2.2 - 1.1))
+    hn = (T(rng.standard_normal((F, FH, FW)).astype(np.float32)), T(rng.standard_normal((F, FH, FW)).astype(np.float32))) if holes else None
+    d_new = T(rng.standard_normal((F, FH, FW, 3)).astype(np.float32))
+    lip_o = lip.clone().requires_grad_(True)
+    outs = [O.composite(lip_o[f:f + 1], face, gt[f:f + 1], mask, x0, y0, coord[f:f + 1], expand_lip_mask=expand,
+                        blackaug=None if hn is None else (hn[0][f:f + 1], hn[1][f:f + 1]))[0] for f in range(F)]
+    (torch.cat(outs) * d_new).sum().backward()
+    hd = None if hn is None else (hn[0].to(dev), hn[1].to(dev))
+    d_lip = m.composite_backward_lip(d_new.to(dev), face.to(dev), mask.to(dev), x0, y0, coord.to(dev), lh, lw, hole_noise=hd)
+    assert float(lip_o.grad.abs().max()) > 0
+    assert relerr(d_lip, lip_o.grad) <= 1e-5
+    # the autograd wrapper hands the same gradient to a lip that requires grad
+    lip_d = lip.to(dev).requires_grad_(True)
+    from speech2lip_amd import autograd as A
+    new, can = A.composite(m, lip_d, face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev), hd)
+    (new * d_new.to(dev)).sum().backward()
+    assert relerr(lip_d.grad, lip_o.grad) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ crop + resize
+@pytest.mark.parametrize("bbox,size,Tw", [((5, 7, 45, 47), (96, 96), 0), ((0, 0, 60, 50), (17, 23), 0), ((10, 3, 14, 9), (96, 96), 0),
+                                          ((8, 6, 56, 58), (96, 96), 5), ((120, 80, 380, 400), (96, 96), 5)])
+def test_crop_resize_and_adjoint_vs_oracle(dev, bbox, size, Tw):
+    from speech2lip_amd import autograd as A
+    rng = np.random.default_rng(sum(bbox))
+    F, H, Wd = (10, 64, 64) if Tw and bbox[2] <= 64 else ((5, 420, 400) if Tw else (3, 50, 60))
+    x = T(rng.random((F, H, Wd, 3), dtype=np.float32))
+    x_o = x.clone().requires_grad_(True)
+    ref = O.crop_resize(x_o, bbox, size)                                   # [F,oh,ow,3]
+    if Tw:
+        ref = ref.reshape(F // Tw, Tw, size[0], size[1], 3).permute(0, 4, 1, 2, 3)      # rgb_window layout, training.py:547-548
+    d = T(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * d).sum().backward()
+    x_d = x.to(dev).requires_grad_(True)
+    got = A.crop_resize(x_d, bbox, size, Tw)
+    close(got, ref.detach(), 1e-7, 5e-7)
+    (got * d.to(dev)).sum().backward()
+    assert relerr(x_d.grad, x_o.grad) <= 2e-6
+    assert float(x_d.grad[:, :bbox[1]].abs().max() if bbox[1] else 0.0) == 0.0          # nothing outside the box
+
+
+# ------------------------------------------------------------------------------------------------ U-Net input gradient
+@pytest.mark.parametrize("F,fh,fw", [(2, 24, 20), (1, 36, 44), (1, 30, 26), (1, 500, 500)])
+def test_unet_input_gradient_vs_oracle_autograd(dev, F, fh, fw):
+    """Frozen eval-mode SimpleUnetLight: the saved forward equals the inference forward bit for bit and its input gradient
+    matches autograd through the oracle (odd quarter sizes exercise the Up padding; 500x500 is the reference's frame)."""
+    from tests.test_gpu_parity import _unet
+    u = _unet(dev)
+    usd = O.to_sd(W.make_unet_state_dict(0))
+    rng = np.random.default_rng(fh * fw)
+    x = T(rng.random((F, fh, fw, 3), dtype=np.float32))
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32))
+    x_o = x.clone().requires_grad_(True)
+    (O.unet_forward(usd, x_o) * d).sum().backward()
+    out, saved = u.forward_saved_nhwc(x.to(dev))
+    assert torch.equal(out, u.forward_nhwc(x.to(dev)))
+    dx = u.backward_input(saved, d.to(dev))
+    scale = float(x_o.grad.abs().max())
+    err = (dx.cpu() - x_o.grad).abs() / scale
+    # a ReLU (or a max-pool winner) within rounding of a tie can resolve differently in two fp32 evaluations and changes the
+    # gradient inside that unit's receptive field only: bound the bulk tightly and the outliers loosely
+    assert float((err > 1e-4).float().mean()) <= 2e-3 and float(err.max()) <= 5e-2, (float(err.max()), float((err > 1e-4).float().mean()))
+    assert O.rmse(dx.cpu(), x_o.grad) <= 1e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------------ the whole step (G11)
+def _g11_device(golden, dev):
+    g, data, eps, holes = g11_inputs(golden)
+    sync = dict(audio_window=data["audio_window"], u01=[eps[1:]], total_frame=data["total_frame"],
+                rgb_face_canonical=data["rgb_face_zero"].to(dev), rgb_face_gt=data["rgb_face_ori"].to(dev),
+                mask_lip_canonical=data["mask_lip_canonical"].to(dev), lip_lefttop_x=data["lip_lefttop_x"],
+                lip_lefttop_y=data["lip_lefttop_y"], coord_window=data["coord_window"].to(dev),
+                canonical_face_bbox=[float(v) for v in data["canonical_face_bbox"][0]], mel=data["mel"].to(dev),
+                rgb_window_neg=data["rgb_window_neg"].to(dev))
+    face = dict(rgb_face_canonical=sync["rgb_face_canonical"], rgb_face_gt=sync["rgb_face_gt"], mask_lip_canonical=sync["mask_lip_canonical"],
+                lip_lefttop_x=sync["lip_lefttop_x"], lip_lefttop_y=sync["lip_lefttop_y"], coord=data["coord"].to(dev),
+                hole_noise=(holes[0].to(dev), holes[1].to(dev)))
+    return g, data, eps, sync, face
+
+
+def test_stage_one_step_golden_fp32(golden, syncnet, dev):
+    """StageOneStep (fp32 parity mode) on the G11 batch: loss, sync term, generated window and gradients against what the
+    reference's own train_stage1 + loss.backward() produced."""
+    g, data, eps, sync, face = _g11_device(golden, dev)
+    m = full_model(dev, 16, 24)
+    step = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="fp32", face_loss=True)
+    loss, grads, aux = step.loss_and_grads(data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev), [eps[0]],
+                                           sync=sync, face=face)
+    assert abs(float(aux["loss_sync"]) - float(g["loss_sync"])) <= 2e-6
+    assert abs(float(aux["loss_rgb"]) + float(aux["loss_face"]) - float(g["loss_rgb"])) <= 2e-6
+    assert abs(float(loss) - float(g["loss"])) <= 3e-6
+    close(aux["rgb_window"], g["rgb_window"], 2e-6, 3e-5)
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            assert relerr(grads[key[2:]], g[key]) <= 5e-4, (key, relerr(grads[key[2:]], g[key]))
+    assert relerr(grads["pts_linears.5.weight"][:, 250:262], g["g_pts5_cols"]) <= 5e-4
+    # the three terms separately: MSE only / + face / + sync change the gradient (each term really reaches the MLP)
+    l0, g0, _ = step.loss_and_grads(data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev), [eps[0]])
+    l1, g1, _ = step.loss_and_grads(data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev), [eps[0]], sync=sync)
+    assert float(l1) > float(l0) and relerr(g1["output_linear.weight"], g0["output_linear.weight"].cpu()) > 1e-5
+
+
+def test_stage_one_step_bf16_vs_fp32(golden, syncnet, dev):
+    """The same step in the precision BASELINE config 5 names: bf16 MLP kernels, fp32 everything else."""
+    g, data, eps, sync, face = _g11_device(golden, dev)
+    m = full_model(dev, 16, 24)
+    a, idx, tgt = data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev)
+    l32, g32, _ = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="fp32", face_loss=True).loss_and_grads(a, idx, tgt, [eps[0]], sync=sync, face=face)
+    l16, g16, _ = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="bf16", face_loss=True).loss_and_grads(a, idx, tgt, [eps[0]], sync=sync, face=face)
+    assert abs(float(l16) - float(l32)) <= 1e-2 * abs(float(l32))
+    for k in g32:
+        x, y = g16[k].double().flatten(), g32[k].double().flatten()
+        cos = float((x @ y) / (x.norm() * y.norm() + 1e-30))
+        assert cos >= 0.995, (k, cos)
+
+
+def test_sync_chain_batched_samples_equal_single_samples(golden, syncnet, dev):
+    """S samples through SyncChain in one call == the samples one by one (the BCE mean over the batch splits as documented),
+    also when the group size forces several U-Net passes."""
+    g, data, eps, sync, _ = _g11_device(golden, dev)
+    m = full_model(dev, 16, 24)
+    rng = np.random.default_rng(3)
+    S, Tn = 3, 5
+    lips = T(rng.random((S * Tn, 16, 24, 3), dtype=np.float32)).to(dev)
+    gt = T(rng.random((S, 64, 64, 3), dtype=np.float32)).to(dev)
+    cw = sync["coord_window"].repeat(S, 1, 1, 1, 1) + T(rng.standard_normal((S, 1, 1, 1, 2)).astype(np.float32)).to(dev) * 0.01
+    mel, _, neg = (T(x).to(dev) for x in W.synthetic_sync_batch(S, seed=5))
+    args = (sync["rgb_face_canonical"], gt, sync["mask_lip_canonical"], sync["lip_lefttop_x"], sync["lip_lefttop_y"], cw,
+            sync["canonical_face_bbox"], mel, neg)
+    loss, d_lips, win = s2l.SyncChain(m, syncnet).loss_and_dlip(lips, *args)
+    loss2, d_lips2, win2 = s2l.SyncChain(m, syncnet, max_frames_per_group=5).loss_and_dlip(lips, *args)
+    assert torch.equal(win, win2) and abs(float(loss) - float(loss2)) <= 1e-7
+    tot = 0.0
+    for s in range(S):
+        l1, d1, w1 = s2l.SyncChain(m, syncnet).loss_and_dlip(lips[s * Tn:(s + 1) * Tn], args[0], gt[s:s + 1], args[2], args[3], args[4],
+                                                             cw[s:s + 1], args[6], mel[s:s + 1], neg[s:s + 1])
+        tot += float(l1) / S
+        assert torch.equal(w1[0], win[s])
+        assert relerr(d_lips[s * Tn:(s + 1) * Tn] * S, d1.cpu()) <= 1e-4
+    assert abs(tot - float(loss)) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ autograd surface
+def test_module_methods_build_a_graph_like_the_reference(dev):
+    """audio_merge_forward -> tile/cat (torch views) -> rgb_forward -> a torch loss -> loss.backward(): the gradients that land
+    in .grad equal autograd through the oracle on the same rows (the reference's own call sequence, training.py:165-229)."""
+    h, w = 8, 10
+    m = make_model(dev, h, w).train()
+    np_sd = W.make_state_dict(0, "he")
+    sd_o = {k: T(v).clone().requires_grad_(True) for k, v in np_sd.items()}
+    win = T(W.synthetic_audio(2, seed=23).astype(np.float32))
+    rng = np.random.default_rng(4)
+    uv = T(rng.random((h * w, 2), dtype=np.float32))
+    tgt = T(rng.random((h * w, 3), dtype=np.float32))
+    feat_o = O.audio_encode(sd_o, win[1:2])
+    rows_o = torch.cat([uv, feat_o.expand(h * w, -1)], -1)
+    loss_o = ((O.rgb_forward(sd_o, rows_o, 31) - tgt) ** 2).mean()
+    loss_o.backward()
+    feat = m.audio_merge_forward(win[1:2].to(dev))
+    assert feat.requires_grad
+    rows = torch.cat([uv.to(dev)[:, None, :], feat.unsqueeze(1).tile(1, h * w, 1).view(-1, 64)[:, None, :]], -1).view(-1, 66)
+    out = m.rgb_forward(rows, time_pts=torch.tensor([31], device=dev))
+    loss = ((out - tgt.to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= 1e-6
+    params = dict(m.named_parameters())
+    for k in np_sd:
+        assert params[k].grad is not None, k
+        assert relerr(params[k].grad, sd_o[k].grad) <= 2e-4, (k, relerr(params[k].grad, sd_o[k].grad))
+    # under no_grad the plain kernels run and nothing is recorded
+    with torch.no_grad():
+        assert not m.rgb_forward(rows.detach(), time_pts=31).requires_grad
+
+
+def test_reference_style_training_loop_matches_the_fused_step(dev):
+    """Trainer.predict_lip_image -> add_photometric_loss -> loss['loss'].backward() -> Adam.step(), the shape of the reference's
+    train_stage1 (training.py:404-561), leaves the gradients LipTrainStep.loss_and_grads returns."""
+    h, w = 12, 20
+    m = make_model(dev, h, w).train()
+    opt = torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("coord_linears")], lr=1e-4)
+    tr = s2l.Trainer(m, optimizer=opt)
+    win = T(W.synthetic_audio(1, seed=29).astype(np.float32)).to(dev)
+    tgt = T(np.random.default_rng(6).random((h * w, 3), dtype=np.float32)).to(dev)
+    data = {"index": torch.tensor([44], device=dev)}
+    real = torch.rand
+    torch.rand = lambda *a, **k: torch.full((1,), 0.62, device=dev)
+    try:
+        opt.zero_grad()
+        loss = {"loss": 0, "loss_rgb": 0}
+        coords = tr.prepare_coords(None, 1)
+        rgb_map = tr.predict_lip_image(0, coords, win, None, data, None, None, seed=0)
+        tr.add_photometric_loss(rgb_map, tgt, loss, weights=1.0)
+        loss["loss"].backward()
+    finally:
+        torch.rand = real
+    ref_loss, ref_g, _ = s2l.LipTrainStep(m, h, w).loss_and_grads(win, [44], tgt[None], [0.62])
+    assert abs(float(loss["loss"]) - float(ref_loss)) <= 1e-7
+    params = dict(m.named_parameters())
+    for k, gk in ref_g.items():
+        assert torch.equal(params[k].grad.reshape(gk.shape), gk), k
+    before = params["output_linear.weight"].detach().clone()
+    opt.step()
+    assert not torch.equal(params["output_linear.weight"].detach(), before)
+
+
+def test_autograd_chain_equals_stage_one_step(golden, syncnet, dev):
+    """The sync chain written with the module methods and torch autograd, in the order of training.py:491-559, gives the
+    gradients of the fused StageOneStep."""
+    from speech2lip_amd import autograd as A
+    g, data, eps, sync, _ = _g11_device(golden, dev)
+    m = full_model(dev, 16, 24).train()
+    m.post_fusion_unet.eval()                                              # train.py:188-197
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    tr = s2l.Trainer(m, syncnet=syncnet, use_syncloss=True)
+    a, tgt = data["audio"].to(dev), data["rgb"].reshape(-1, 3).to(dev)
+    q = list(eps)
+    real = torch.rand
+    torch.rand = lambda *a_, **k: torch.full((1,), q.pop(0), device=dev)
+    try:
+        loss = {"loss": 0, "loss_rgb": 0}
+        coords = tr.prepare_coords(None, 1)
+        rgb_map = tr.predict_lip_image(0, coords, a, None, {"index": torch.tensor([data["index"]])}, None, None, seed=0)
+        tr.add_photometric_loss(rgb_map, tgt, loss, weights=1.0)
+        window = []
+        for t in range(5):
+            idx = min(data["index"] + t, data["total_frame"] - 1)
+            lip = tr.predict_lip_image(0, coords, data["audio_window"][:, t].to(dev), None, {"index": torch.tensor([idx])}, None, None,
+                                       seed=0).reshape(1, 16, 24, 3)
+            merged, _, _ = m.post_fusion2_onlylip(lip, sync["rgb_face_canonical"], sync["rgb_face_gt"], sync["mask_lip_canonical"],
+                                                  sync["lip_lefttop_x"], sync["lip_lefttop_y"], sync["coord_window"][:, t])
+            window.append(A.crop_resize(merged, sync["canonical_face_bbox"], (96, 96)).unsqueeze(0))
+        rgb_window = torch.cat(window, 0).permute(1, 4, 0, 2, 3)           # T,B,H,W,C -> B,C,T,H,W (training.py:547-548)
+        loss_sync = tr.get_sync_contrastive_loss(sync["mel"], rgb_window, sync["rgb_window_neg"]) * tr.w_syncloss
+        loss["loss"] = loss["loss"] + loss_sync
+        loss["loss"].backward()
+    finally:
+        torch.rand = real
+    step = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="fp32")
+    ref_loss, ref_g, aux = step.loss_and_grads(a, [data["index"]], tgt[None], [eps[0]], sync=sync)
+    assert abs(float(loss["loss"]) - float(ref_loss)) <= 2e-6
+    params = dict(m.named_parameters())
+    for k, gk in ref_g.items():
+        assert relerr(params[k].grad.reshape(gk.shape), gk.cpu()) <= 2e-4, (k, relerr(params[k].grad.reshape(gk.shape), gk.cpu()))

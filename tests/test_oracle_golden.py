@@ -177,3 +177,77 @@ def test_g9_syncnet_and_sync_loss(golden):
     scale = float(T(g["grad_pos_stride7"]).abs().max())
     assert float((gr - T(g["grad_pos_stride7"])).abs().max()) <= 1e-5 * scale
     assert float(pos.grad[:, :, :, :48].abs().max()) == 0.0        # only the lower half of each frame is seen (training.py:589)
+
+
+def test_g10_composite_black_hole_augmentation(golden):
+    """Training branch of A7 (tf_nerf.py:371-384) against the reference's own post_fusion2_onlylip(blackaug=True) output,
+    captured with the coin and the two randn fields pinned."""
+    g4, g = golden("g4_composite.npz"), golden("g10_blackaug.npz")
+    args = [T(g4["lip"]), T(g["face"]), T(g4["gt"]), T(g4["mask"]), int(g4["x0"]), int(g4["y0"]), T(g4["coord"])]
+    new, _ = O.composite(*args, blackaug=(T(g["hole1"]), T(g["hole2"])))
+    assert _maxerr(new, g["merged_new"]) == 0.0
+    plain, _ = O.composite(*args)
+    changed = (new != plain).any(-1)
+    assert 0.2 < float(changed.float().mean()) < 0.7          # about half the draws are < 1e-6, inside the warped face only
+    assert not bool(changed[:, 10:12].any())                  # these rows sample only the zeroed band (rows 8..13) of the canonical face: no holes
+
+
+def g11_inputs(golden):
+    """The reference batch dict of the G11 step, rebuilt from the fixture + the shared generators."""
+    g4, g = golden("g4_composite.npz"), golden("g11_stage1.npz")
+    mel, _, neg = (T(x) for x in W.synthetic_sync_batch(1, seed=int(g["sync_seed"])))
+    data = {"audio": T(g["audio"]), "rgb": T(g["rgb"]), "coord": T(g4["coord"]), "index": int(g["index"]),
+            "total_frame": int(g["total_frame"]), "rgb_face_zero": T(g4["face"]), "rgb_face_ori": T(g4["gt"]),
+            "mask_lip_canonical": T(g4["mask"]), "lip_lefttop_x": int(g4["x0"]), "lip_lefttop_y": int(g4["y0"]),
+            "audio_window": T(g["audio_window"]), "coord_window": T(g["coord_window"]), "canonical_face_bbox": T(g["bbox"]),
+            "mel": mel, "rgb_window_neg": neg}
+    return g, data, [float(v) for v in g["eps"]], (T(g["hole1"]), T(g["hole2"]))
+
+
+def test_g11_stage_one_step_loss_and_gradients(golden):
+    """One whole reference optimisation step after it > 100000 (Trainer.train_stage1 itself ran in tools/make_goldens.py):
+    the oracle's restatement reproduces its loss, its sync term, the generated window and the gradients it left in .grad."""
+    g, data, eps, holes = g11_inputs(golden)
+    sd = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    res = O.stage_one_losses(sd, O.to_sd(W.make_unet_state_dict(0)), O.to_sd(W.make_syncnet_state_dict(0)), W.SYNCNET_FACE,
+                             W.SYNCNET_AUDIO, data, eps, holes, 16, 24)
+    res["loss"].backward()
+    assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-6
+    # the reference's loss["loss_rgb"] accumulates BOTH photometric terms (add_photometric_loss is called for the lip and the face)
+    assert abs(float(res["loss_rgb"]) + float(res["loss_face"]) - float(g["loss_rgb"])) <= 1e-6
+    assert abs(float(res["loss_sync"]) - float(g["loss_sync"])) <= 1e-7
+    assert _maxerr(res["rgb_window"].detach(), g["rgb_window"]) == 0.0
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            ref, got = g[key], sd[key[2:]].grad
+            assert _maxerr(got, ref) <= 2e-5 * float(np.abs(ref).max()), key
+    assert _maxerr(sd["pts_linears.5.weight"].grad[:, 250:262], g["g_pts5_cols"]) <= 2e-5 * float(np.abs(g["g_pts5_cols"]).max())
+    # the sync term really reaches the MLP: without it the gradient differs
+    sd2 = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    res2 = O.stage_one_losses(sd2, O.to_sd(W.make_unet_state_dict(0)), O.to_sd(W.make_syncnet_state_dict(0)), W.SYNCNET_FACE,
+                              W.SYNCNET_AUDIO, data, eps, holes, 16, 24, w_syncloss=0.0)
+    res2["loss"].backward()
+    assert _maxerr(sd2["output_linear.weight"].grad, g["g_output_linear.weight"]) > 1e-6
+
+
+def test_crop_resize_formula_is_the_one_aten_evaluates():
+    """crop + Resize([96,96]) (training.py:541-544; torchvision 0.9 tensors -> F.interpolate bilinear, align_corners=False):
+    the explicit per-pixel formula the HIP kernel implements, including the single rounding of scale*(dst+0.5)-0.5."""
+    rng = np.random.default_rng(0)
+    x = T(rng.random((2, 50, 60, 3), dtype=np.float32))
+    for bbox, size in [((5, 7, 45, 47), (96, 96)), ((0, 0, 60, 50), (17, 23)), ((10, 3, 14, 9), (96, 96))]:
+        y = O.crop_resize(x, bbox, size)
+        bx, by, bx2, by2 = bbox
+        crop = x[:, by:by2, bx:bx2].double().numpy()
+        ih, iw = crop.shape[1:3]
+        oh, ow = size
+        sy, sx = np.float32(ih) / np.float32(oh), np.float32(iw) / np.float32(ow)
+        out = np.zeros((2, oh, ow, 3))
+        for oy in range(oh):
+            fy = max(np.float32(np.float64(sy) * (oy + 0.5) - 0.5), np.float32(0))
+            y0 = int(fy); y1 = min(y0 + 1, ih - 1); ly = np.float64(np.float32(fy - np.float32(y0)))
+            for ox in range(ow):
+                fx = max(np.float32(np.float64(sx) * (ox + 0.5) - 0.5), np.float32(0))
+                x0 = int(fx); x1 = min(x0 + 1, iw - 1); lx = np.float64(np.float32(fx - np.float32(x0)))
+                out[:, oy, ox] = (1 - ly) * ((1 - lx) * crop[:, y0, x0] + lx * crop[:, y0, x1]) + ly * ((1 - lx) * crop[:, y1, x0] + lx * crop[:, y1, x1])
+        assert _maxerr(y, out) <= 3e-7, (bbox, size)
