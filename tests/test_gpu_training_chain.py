@@ -127,10 +127,10 @@ def test_crop_resize_and_adjoint_vs_oracle(dev, bbox, size, Tw):
 
 
 # ------------------------------------------------------------------------------------------------ U-Net input gradient
-@pytest.mark.parametrize("F,fh,fw", [(2, 24, 20), (1, 36, 44), (1, 30, 26), (1, 500, 500)])
+@pytest.mark.parametrize("F,fh,fw", [(2, 24, 20), (1, 36, 44), (1, 30, 26), (1, 72, 88)])
 def test_unet_input_gradient_vs_oracle_autograd(dev, F, fh, fw):
     """Frozen eval-mode SimpleUnetLight: the saved forward equals the inference forward bit for bit and its input gradient
-    matches autograd through the oracle (odd quarter sizes exercise the Up padding; 500x500 is the reference's frame)."""
+    matches autograd through the oracle (odd quarter sizes exercise the Up padding, 72x88 several tiles per axis)."""
     from tests.test_gpu_parity import _unet
     u = _unet(dev)
     usd = O.to_sd(W.make_unet_state_dict(0))
@@ -150,10 +150,38 @@ def test_unet_input_gradient_vs_oracle_autograd(dev, F, fh, fw):
     assert O.rmse(dx.cpu(), x_o.grad) <= 1e-4 * scale
 
 
+def test_unet_input_gradient_full_frame_500(dev):
+    """The reference's 500x500 frame (31.25 tiles per axis, 250 -> 125 -> 250 pooling / up-sampling).  With 16 M ReLU units a few
+    sit within fp32 rounding of zero, and each such unit that resolves differently moves the gradient inside its (up to
+    100x100-pixel) receptive field: the CPU oracle's OWN fp32 gradient deviates from its fp64 evaluation by up to 14 % of the
+    maximum on 2.6 % of the pixels (rmse 4.3e-4 of the maximum).  The device gradient is therefore held to the fp64 truth with
+    the bars the fp32 oracle itself meets (x2), plus linearity of the backward in d_out (exact up to rounding)."""
+    from tests.test_gpu_parity import _unet
+    u = _unet(dev)
+    usd64 = {k: v.double() for k, v in O.to_sd(W.make_unet_state_dict(0)).items()}
+    rng = np.random.default_rng(250000)
+    x = T(rng.random((1, 500, 500, 3), dtype=np.float32))
+    d = T(rng.standard_normal((1, 500, 500, 3)).astype(np.float32))
+    x64 = x.double().requires_grad_(True)
+    (O.unet_forward(usd64, x64) * d.double()).sum().backward()
+    out, saved = u.forward_saved_nhwc(x.to(dev))
+    assert torch.equal(out, u.forward_nhwc(x.to(dev)))
+    dx = u.backward_input(saved, d.to(dev))
+    scale = float(x64.grad.abs().max())
+    err = (dx.cpu().double() - x64.grad).abs() / scale
+    assert float((err > 1e-4).float().mean()) <= 0.06 and float(err.max()) <= 0.3, (float(err.max()), float((err > 1e-4).float().mean()))
+    assert float(((dx.cpu().double() - x64.grad) ** 2).mean().sqrt()) <= 1e-3 * scale
+    a, b = dx.cpu().double().flatten(), x64.grad.flatten()
+    assert float((a @ b) / (a.norm() * b.norm())) >= 0.99999
+    d2 = T(rng.standard_normal((1, 500, 500, 3)).astype(np.float32)).to(dev)
+    lin = u.backward_input(saved, d.to(dev) + d2) - dx - u.backward_input(saved, d2)
+    assert float(lin.abs().max()) <= 1e-5 * scale
+
+
 # ------------------------------------------------------------------------------------------------ the whole step (G11)
 def _g11_device(golden, dev):
     g, data, eps, holes = g11_inputs(golden)
-    sync = dict(audio_window=data["audio_window"], u01=[eps[1:]], total_frame=data["total_frame"],
+    sync = dict(audio_window=data["audio_window"].to(dev), u01=[eps[1:]], total_frame=data["total_frame"],
                 rgb_face_canonical=data["rgb_face_zero"].to(dev), rgb_face_gt=data["rgb_face_ori"].to(dev),
                 mask_lip_canonical=data["mask_lip_canonical"].to(dev), lip_lefttop_x=data["lip_lefttop_x"],
                 lip_lefttop_y=data["lip_lefttop_y"], coord_window=data["coord_window"].to(dev),
@@ -223,7 +251,10 @@ def test_sync_chain_batched_samples_equal_single_samples(golden, syncnet, dev):
                                                              cw[s:s + 1], args[6], mel[s:s + 1], neg[s:s + 1])
         tot += float(l1) / S
         assert torch.equal(w1[0], win[s])
-        assert relerr(d_lips[s * Tn:(s + 1) * Tn] * S, d1.cpu()) <= 1e-4
+        # the SyncNet's split-K partial sums depend on the batch size: a ReLU of its 17 layers within rounding of zero may
+        # resolve differently at batch 3 and batch 1 (bulk tight, outliers loose, as in the G9 gradient test)
+        e = (d_lips[s * Tn:(s + 1) * Tn] * S - d1).abs() / float(d1.abs().max())
+        assert float(e.max()) <= 2e-3 and float((e > 1e-3).float().mean()) <= 1e-3, (float(e.max()), float((e > 1e-3).float().mean()))
     assert abs(tot - float(loss)) <= 1e-6
 
 
