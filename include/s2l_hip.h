@@ -237,6 +237,18 @@ int s2l_composite_backward_lip(const float* d_new, const float* face_canon, int6
                                float* d_lip, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0, int pad_mode,
                                int expand_pad, int64_t n_frames, s2l_stream_t stream);
 
+/* The inference composite of a CLIP at streaming speed: same result as s2l_composite (bit-identical out_new) for the common
+ * case -- per-clip face_canon / mask folded into `bgm` (s2l_composite_tables), expanded-rectangle mask (expand_pad >= 0), no
+ * black holes, no canonical output, face_h*face_w a multiple of 4, 16-byte-aligned frame streams.  Two kernels over spans of 256
+ * pixels: quarter spans none of whose bilinear taps can reach the rectangle are copied rgb_gt -> out as 16-byte vectors (about
+ * 77 % of a 500x500 frame with a 128x128 lip); the rest are evaluated one pixel per lane, every tap one aligned 16-byte gather
+ * (the merged lip box of each frame is materialised first, 16 B per lip pixel).  n_frames <= 65535.
+ * work: s2l_composite_stream_work_bytes(...) bytes, 16-byte aligned (span flags + merged lip boxes). */
+int64_t s2l_composite_stream_work_bytes(int lip_h, int lip_w, int face_h, int face_w, int64_t n_frames);
+int s2l_composite_stream(const float* lip, const float* mask, const float* bgm, const float* rgb_gt, const float* coord,
+                         float* out_new, void* work, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
+                         int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream);
+
 /* Optional per-clip precompute for s2l_composite: bgm [FH,FW,4] = ((1-mask)*face_canon, bits of face_canon > 0), the
  * background term of tf_nerf.py:352 as one 16-byte-aligned gather target (16-byte aligned). */
 int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm, int face_h, int face_w,

@@ -47,6 +47,8 @@ EXPORTS = {
     "s2l_embed_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "s2l_composite": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "s2l_composite_stream_work_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int64]),
+    "s2l_composite_stream": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_int64, c_void_p]),
     "s2l_composite_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_composite_backward_lip": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

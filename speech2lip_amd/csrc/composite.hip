@@ -96,10 +96,13 @@ __device__ __forceinline__ bool warped_shows(bool M, const HoleSel& hs, int c) {
 // lip is fetched only by waves that touch its box (wave-uniform test).
 constexpr int kPPT = 1;   // pixels per thread (256 apart): the second pixel's streaming loads overlap the first's gathers
 
-template <bool BGM>
-__device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* face, const float* mask, const float* lip,
-                                                int64_t idx, int pix, float2 g, const Px& gt) {
-  const bool rect = a.ry0 >= 0;
+// value of one output pixel (res); `idx` is only read by the black-hole branch
+// PLAIN: the caller guarantees the expanded-rectangle mask and no black holes (the inference fast path): those branches and
+// the registers they keep alive are compiled out.
+template <bool BGM, bool PLAIN = false>
+__device__ __forceinline__ void composite_value(const CompArgs& a, const float* face, const float* mask, const float* lip,
+                                                int64_t idx, float2 g, const Px& gt, float (&res)[3]) {
+  const bool rect = PLAIN || a.ry0 >= 0;
   // grid_sample(align_corners=False): unnormalise as (x+1)*(size/2) - 0.5, bilinear weights from
   // the distances to the four neighbours, zero padding outside [0,size-1].
   const float ix = __fsub_rn(__fmul_rn(__fadd_rn(g.x, 1.f), 0.5f * (float)a.FW), 0.5f);
@@ -119,20 +122,21 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-    const bool ok = (unsigned)xx < (unsigned)a.FW && (unsigned)yy < (unsigned)a.FH && xw + (float)(t & 1) == (float)xx &&
-                    yn + (float)(t >> 1) == (float)yy;
+    // bitwise & on purpose: short-circuit && turns into per-tap branches that keep the four gathers from being issued together
+    const bool ok = ((unsigned)xx < (unsigned)a.FW) & ((unsigned)yy < (unsigned)a.FH) & (xw + (float)(t & 1) == (float)xx) &
+                    (yn + (float)(t >> 1) == (float)yy);
     wgt[t] = ok ? wraw[t] : 0.f;
     const int xc = min(max(xx, 0), a.FW - 1), yc = min(max(yy, 0), a.FH - 1);
     const int o = (yc * a.FW + xc) * 3;
     const int ly = yc - a.oy, lx = xc - a.ox;
-    inlip[t] = ok && (unsigned)ly < (unsigned)a.h && (unsigned)lx < (unsigned)a.w;
+    inlip[t] = ok & ((unsigned)ly < (unsigned)a.h) & ((unsigned)lx < (unsigned)a.w);
     lipoff[t] = (ly * a.w + lx) * 3;
     anylip |= inlip[t];
     l[t] = Px{{0.f, 0.f, 0.f}};
     if (BGM) {
       const f4 b = *reinterpret_cast<const f4*>(a.bgm + (yc * a.FW + xc) * 4);   // one aligned 16-byte gather
       fv[t] = Px{{b[0], b[1], b[2]}};           // (1-mask)*face, already rounded as the reference rounds it
-      fbits[t] = (int)b[3];                     // bit c: face_canon[c] > 0 (only the black-hole augmentation reads it)
+      fbits[t] = PLAIN ? 0 : (int)b[3];         // bit c: face_canon[c] > 0 (only the black-hole augmentation reads it)
       moff[t] = o;
       m[t] = Px{{0.f, 0.f, 0.f}};
     } else {
@@ -160,15 +164,14 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
       v = blend_px(m[t], l[t], fv[t]);
     }
     const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-    const float mr = (yy >= a.ry0 && yy < a.ry1 && xx >= a.rx0 && xx < a.rx1) ? 1.f : 0.f;
+    const float mr = ((yy >= a.ry0) & (yy < a.ry1) & (xx >= a.rx0) & (xx < a.rx1)) ? 1.f : 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       acc[c] = fmaf(v.c[c], wgt[t], acc[c]);
       macc[c] = fmaf(rect ? mr : m[t].c[c], wgt[t], macc[c]);
     }
   }
-  float res[3];
-  if (a.hole1) {   // training branch (wave-uniform): black holes inside the warped canonical face
+  if (!PLAIN && a.hole1) {   // training branch (wave-uniform): black holes inside the warped canonical face
     const HoleSel hs = hole_select(a, idx, wgt, fbits);
 #pragma unroll
     for (int c = 0; c < 3; ++c) res[c] = warped_shows(macc[c] != 0.f, hs, c) ? acc[c] : gt.c[c];
@@ -176,6 +179,13 @@ __device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* 
 #pragma unroll
     for (int c = 0; c < 3; ++c) res[c] = macc[c] != 0.f ? acc[c] : gt.c[c];
   }
+}
+
+template <bool BGM>
+__device__ __forceinline__ void composite_pixel(const CompArgs& a, const float* face, const float* mask, const float* lip,
+                                                int64_t idx, int pix, float2 g, const Px& gt) {
+  float res[3];
+  composite_value<BGM>(a, face, mask, lip, idx, g, gt, res);
   store_px_stream(a.out_new + idx * 3, res);
 
   if (a.out_can) {
@@ -222,6 +232,155 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
 #pragma unroll
   for (int i = 0; i < kPPT; ++i)
     if (live[i]) composite_pixel<BGM>(a, face, mask, lip, f * per + pix[i], pix[i], g[i], gt[i]);
+}
+
+// ---- the inference fast path: a wave per span of 256 consecutive pixels ------------------------------------------------------
+// Requirements (checked by the launcher): per-clip constants with their fused table, expanded-rectangle mask, no black holes,
+// no canonical output, FH*FW a multiple of 4, 16-byte-aligned streams.
+// The warped image only shows where a bilinear tap falls inside the expanded rectangle; everywhere else out = rgb_gt.
+//   lip_merge_kernel: per frame, the merged canonical image INSIDE the lip box as 16-byte pixels, mask*lip + bgm (0.26 MB per
+//     128x128 lip).  With it every bilinear tap is ONE aligned 16-byte gather -- from this table inside the box, from the per-clip
+//     bgm table outside -- instead of a table gather plus two unaligned 12-byte gathers (mask, lip).
+//   span_kernel: coord = 2 KiB = two 1-KiB vector loads, rgb_gt = 3 KiB = three, out = three vector stores; lane l moves bytes
+//     [16 l, 16 l + 16) of each KiB, so every byte of the frame streams is requested exactly once, perfectly coalesced (the
+//     one-pixel kernel needs 8 scalar stream instructions per 64 pixels with 8- and 12-byte lane strides).  A span none of whose
+//     pixels can touch the rectangle (64 % of the spans of a 500x500 frame with a 128x128 lip; 80 % of its 64-pixel quarters) is a
+//     pure vector copy and the 12-byte pixels are never un-packed.  Otherwise the wave stages its 3 KiB of rgb_gt in LDS
+//     (wave-private, no barrier) and walks the quarters that can touch the rectangle, one pixel per lane: coordinates by
+//     cross-lane shuffle, four aligned gathers, the result written over the staged pixel; then the same three vector stores.
+//     Results are bit-identical to composite_kernel's (same operations on the same values in the same order).
+struct SpanArgs {
+  CompArgs c;
+  float* merged;          // [F][h][w][4]: the merged canonical image inside the lip box, mask*lip + (1-mask)*face (tf_nerf.py:352)
+  int nspans;             // spans per frame = ceil(FH*FW / 256)
+  int64_t n_cand;         // F * nspans
+};
+
+__global__ __launch_bounds__(256) void lip_merge_kernel(SpanArgs sa) {
+  const CompArgs& a = sa.c;
+  const int n = a.h * a.w;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  if (p >= n) return;
+  const int ly = p / a.w, lx = p - ly * a.w;
+  const int o = (a.oy + ly) * a.FW + a.ox + lx;
+  const Px m = load_px(a.mask + o * 3);
+  const Px l = load_px(a.lip + (f * n + p) * 3);
+  const f4 b = *reinterpret_cast<const f4*>(a.bgm + o * 4);
+  f4 v;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = __fadd_rn(__fmul_rn(m.c[c], l.c[c]), b[c]);   // the reference's roundings (tf_nerf.py:352)
+  v[3] = 0.f;
+  *reinterpret_cast<f4*>(sa.merged + (f * n + p) * 4) = v;
+}
+
+// composite_value<true, true> with the lip box read from the merged table
+__device__ __forceinline__ void composite_value_merged(const CompArgs& a, const float* merged_f, float gx, float gy, const Px& gt,
+                                                       float (&res)[3]) {
+  const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f * (float)a.FW), 0.5f);
+  const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f * (float)a.FH), 0.5f);
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float wx = ix - xw, ex = 1.f - wx, ny = iy - yn, sy = 1.f - ny;
+  const float wraw[4] = {__fmul_rn(sy, ex), __fmul_rn(sy, wx), __fmul_rn(ny, ex), __fmul_rn(ny, wx)};
+  const int x0 = (int)fminf(fmaxf(xw, -2.f), (float)a.FW + 1.f);
+  const int y0 = (int)fminf(fmaxf(yn, -2.f), (float)a.FH + 1.f);
+  f4 v[4];
+  float wgt[4], mr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const bool ok = ((unsigned)xx < (unsigned)a.FW) & ((unsigned)yy < (unsigned)a.FH) & (xw + (float)(t & 1) == (float)xx) &
+                    (yn + (float)(t >> 1) == (float)yy);
+    wgt[t] = ok ? wraw[t] : 0.f;
+    mr[t] = ((yy >= a.ry0) & (yy < a.ry1) & (xx >= a.rx0) & (xx < a.rx1)) ? 1.f : 0.f;
+    const int xc = min(max(xx, 0), a.FW - 1), yc = min(max(yy, 0), a.FH - 1);
+    const int ly = yc - a.oy, lx = xc - a.ox;
+    const bool inlip = ((unsigned)ly < (unsigned)a.h) & ((unsigned)lx < (unsigned)a.w);
+    const float* src = inlip ? merged_f + (ly * a.w + lx) * 4 : a.bgm + (yc * a.FW + xc) * 4;
+    v[t] = *reinterpret_cast<const f4*>(src);
+  }
+  float acc[3] = {0.f, 0.f, 0.f}, macc = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = fmaf(v[t][c], wgt[t], acc[c]);
+    macc = fmaf(mr[t], wgt[t], macc);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) res[c] = macc != 0.f ? acc[c] : gt.c[c];
+}
+
+__global__ __launch_bounds__(256) void span_kernel(SpanArgs sa) {
+  __shared__ __attribute__((aligned(16))) float stage[4][768];
+  const CompArgs& a = sa.c;
+  const int per = a.FH * a.FW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 4 + wave;                 // span, frame-major
+  if (c >= sa.n_cand) return;                                       // wave-uniform
+  const int64_t f = c / sa.nspans;
+  const int pix0 = (int)(c - f * sa.nspans) * 256;
+  const int nvalid = min(256, per - pix0);                          // a multiple of 4
+  const int64_t idx0 = f * per + pix0;
+  const float* cbase = a.coord + 2 * idx0;
+  const float* gbase = a.gt + 3 * idx0;
+  f4 cv[2], gv[3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)       // lane holds the coords of pixels 128 s + 2 lane, + 1: quarter 2 s + (lane >> 5)
+    cv[s] = 128 * s + 2 * lane < nvalid ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(cbase + 256 * s + 4 * lane))
+                                        : (f4){-9.f, -9.f, -9.f, -9.f};
+#pragma unroll
+  for (int s = 0; s < 3; ++s)       // lane moves floats [256 s + 4 lane, + 4) of the span's 768: pixel-unaligned on purpose
+    gv[s] = 256 * s + 4 * lane < 3 * nvalid ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(gbase + 256 * s + 4 * lane))
+                                            : (f4){0.f, 0.f, 0.f, 0.f};
+  // conservative rectangle test on the integer tap origins of the lane's four pixels
+  bool hit[2] = {false, false};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float gx = cv[i >> 1][2 * (i & 1)], gy = cv[i >> 1][2 * (i & 1) + 1];
+    const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f * (float)a.FW), 0.5f);
+    const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f * (float)a.FH), 0.5f);
+    const int x0 = (int)fminf(fmaxf(floorf(ix), -2.f), (float)a.FW + 1.f);
+    const int y0 = (int)fminf(fmaxf(floorf(iy), -2.f), (float)a.FH + 1.f);
+    hit[i >> 1] |= (128 * (i >> 1) + 2 * lane < nvalid) & (x0 + 1 >= a.rx0) & (x0 < a.rx1) & (y0 + 1 >= a.ry0) & (y0 < a.ry1);
+  }
+  const unsigned long long b0 = __ballot(hit[0]), b1 = __ballot(hit[1]);
+  unsigned qmask = ((unsigned)b0 != 0 ? 1u : 0u) | ((b0 >> 32) != 0 ? 2u : 0u) | ((unsigned)b1 != 0 ? 4u : 0u) |
+                   ((b1 >> 32) != 0 ? 8u : 0u);
+#ifdef S2L_EXP_COPYONLY
+  qmask = 0;
+#endif
+  if (qmask) {                      // wave-uniform
+    float* sg = stage[wave];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) *reinterpret_cast<f4*>(sg + 256 * s + 4 * lane) = gv[s];
+    const float* merged_f = sa.merged + f * (int64_t)a.h * a.w * 4;
+    while (qmask) {                 // the quarters that can touch the rectangle, one pixel per lane
+      const int q = __builtin_ctz(qmask);
+      qmask &= qmask - 1;
+      // pixel 64 q + lane: its coordinates sit in lane 32 (q & 1) + lane / 2 of cv[q >> 1], components 2 (lane & 1), + 1
+      const f4 cq = (q >> 1) ? cv[1] : cv[0];
+      const int src = 32 * (q & 1) + (lane >> 1);
+      const float e0 = __shfl(cq[0], src), e1 = __shfl(cq[1], src), e2 = __shfl(cq[2], src), e3 = __shfl(cq[3], src);
+      const float gx = (lane & 1) ? e2 : e0, gy = (lane & 1) ? e3 : e1;
+      const int p = 64 * q + lane;
+      if (p < nvalid) {
+        const Px gt = Px{{sg[3 * p], sg[3 * p + 1], sg[3 * p + 2]}};
+        float res[3];
+        composite_value_merged(a, merged_f, gx, gy, gt, res);
+        sg[3 * p] = res[0];
+        sg[3 * p + 1] = res[1];
+        sg[3 * p + 2] = res[2];
+      }
+    }
+    // every pixel is owned by exactly one lane and a wave's LDS operations complete in program order: the vector reads below
+    // see all the per-pixel results without a barrier (other waves of the block never touch this wave's staging area)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) gv[s] = *reinterpret_cast<const f4*>(sg + 256 * s + 4 * lane);
+  }
+  float* obase = a.out_new + 3 * idx0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (256 * s + 4 * lane < 3 * nvalid) __builtin_nontemporal_store(gv[s], reinterpret_cast<f4*>(obase + 256 * s + 4 * lane));
 }
 
 // Per-clip table for the fast path: bgm[p] = ((1-mask[p]) * face[p] (3 floats), bits of face[p] > 0): 16-byte pixels.
@@ -409,5 +568,40 @@ extern "C" int s2l_composite_backward_lip(const float* d_new, const float* face_
   const int64_t per = (int64_t)face_h * face_w;
   hipLaunchKernelGGL(s2l::composite_bwd_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, a, d_new,
                      d_lip);
+  return (int)hipGetLastError();
+}
+
+// ---- inference fast path (lip_merge_kernel + span_kernel) ---------------------------------------------------------------------
+extern "C" int64_t s2l_composite_stream_work_bytes(int lip_h, int lip_w, int face_h, int face_w, int64_t n_frames) {
+  if (lip_h <= 0 || lip_w <= 0 || face_h <= 0 || face_w <= 0 || n_frames < 0) return 0;
+  return n_frames * lip_h * lip_w * 16;      // merged lip boxes
+}
+
+extern "C" int s2l_composite_stream(const float* lip, const float* mask, const float* bgm, const float* rgb_gt, const float* coord,
+                                    float* out_new, void* work, int lip_h, int lip_w, int face_h, int face_w, int x0, int y0,
+                                    int pad_mode, int expand_pad, int64_t n_frames, s2l_stream_t stream) {
+  if (n_frames > 0 && (!lip || !bgm || !rgb_gt || !out_new || !work)) return S2L_E_NULL;
+  if (expand_pad < 0) return S2L_E_SIZE;                       // the rectangle mask is what makes most spans pure copies
+  s2l::SpanArgs sa;
+  s2l::CompArgs& a = sa.c;
+  // `mask` doubles as face_canon for the shared checks: the fused table replaces the face, the mask is read at lip taps only
+  const int rc = composite_args(a, mask, 0, mask, 0, coord, nullptr, nullptr, lip_h, lip_w, face_h, face_w, x0, y0, pad_mode,
+                                expand_pad, n_frames);
+  if (rc || n_frames == 0) return rc;
+  const int64_t per = (int64_t)face_h * face_w;
+  if (per % 4 != 0) return S2L_E_SIZE;
+  if (s2l::misaligned16(bgm) || s2l::misaligned16(coord) || s2l::misaligned16(rgb_gt) || s2l::misaligned16(out_new)) return S2L_E_ALIGN;
+  a.lip = lip; a.gt = rgb_gt; a.out_new = out_new; a.out_can = nullptr; a.bgm = bgm;
+  a.rsize = a.chunks = 0;
+  sa.nspans = (int)((per + 255) / 256);
+  if (s2l::misaligned16(work)) return S2L_E_ALIGN;
+  sa.merged = static_cast<float*>(work);
+  sa.n_cand = n_frames * sa.nspans;
+  if (n_frames > 65535) return S2L_E_SIZE;
+  const int64_t blocks1 = (sa.n_cand + 3) / 4;
+  if (blocks1 > 0x7fffffff) return S2L_E_SIZE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(s2l::lip_merge_kernel, dim3((unsigned)((lip_h * lip_w + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, sa);
+  hipLaunchKernelGGL(s2l::span_kernel, dim3((unsigned)blocks1), dim3(256), 0, st, sa);
   return (int)hipGetLastError();
 }

@@ -348,9 +348,17 @@ class TalkingFace(nn.Module):
                 bgm = torch.empty(FH, FW, 4, dtype=torch.float32, device=dev)
                 _abi.check(lib.s2l_composite_tables(_ptr(face), _ptr(mask), _ptr(bgm), FH, FW, _stream()),
                            "s2l_composite_tables")
-            _abi.check(lib.s2l_composite_train(_ptr(lip), _ptr(face), fs, _ptr(mask), ms, _ptr(gt), _ptr(grid), _ptr(h1), _ptr(h2),
-                                               _ptr(new), _ptr(can), _ptr(bgm), lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B,
-                                               _stream()), "s2l_composite_train")
+            per = FH * FW
+            aligned = all(t.data_ptr() % 16 == 0 for t in (gt, grid, new))
+            if bgm is not None and pad >= 0 and h1 is None and can is None and per % 4 == 0 and aligned and B <= 65535:
+                # inference fast path: spans that cannot touch the rectangle are vector copies, the rest one pixel per thread
+                work = torch.empty(int(lib.s2l_composite_stream_work_bytes(lh, lw, FH, FW, B)), dtype=torch.uint8, device=dev)
+                _abi.check(lib.s2l_composite_stream(_ptr(lip), _ptr(mask), _ptr(bgm), _ptr(gt), _ptr(grid), _ptr(new), _ptr(work), lh, lw,
+                                                    FH, FW, x0, y0, self._pad_mode(), pad, B, _stream()), "s2l_composite_stream")
+            else:
+                _abi.check(lib.s2l_composite_train(_ptr(lip), _ptr(face), fs, _ptr(mask), ms, _ptr(gt), _ptr(grid), _ptr(h1), _ptr(h2),
+                                                   _ptr(new), _ptr(can), _ptr(bgm), lh, lw, FH, FW, x0, y0, self._pad_mode(), pad, B,
+                                                   _stream()), "s2l_composite_train")
         return new, can
 
     def composite_backward_lip(self, d_new, rgb_face_canonical, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord,
