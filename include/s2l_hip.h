@@ -310,6 +310,19 @@ int s2l_warp_grid(const float* depth, int64_t depth_stride, const float* T, floa
 int s2l_grid_sample(const float* img, int64_t img_stride, const float* grid, float* out, int img_h, int img_w,
                     int out_h, int out_w, int padding, int64_t n_frames, s2l_stream_t stream);
 
+/* Canonical-depth photometric loss (Trainer.inverse_warping + add_loss_canonical_depth_photo, src/face_simple/training.py:462-477,
+ * 296-314, 621-634) and its gradient w.r.t. the depth map (model.canonical_depth_head, tf_nerf.py:174-195), which is what
+ * loss.backward() leaves in canonical_depth_head.grad:
+ *   pred = grid_sample(src, Project3D(BackprojectDepth(depth), K, T), padding_mode='border')      src = rgb_face_gt [F,H,W,3]
+ *   loss = weights * sum((pred - target)^2 * mask) / (sum(mask) + 1e-6)     (mask NULL: weights * mean((pred - target)^2))
+ * depth [H,W]; T [F,16] (compute_rel_pose_inverse); target (rgb_face_canonical) and mask [H,W,3] when *_stride == 0, else
+ * [F,H,W,3]; loss: TWO floats (the loss, then an internal scale); d_depth [H,W] or NULL; work:
+ * s2l_depth_photo_work_floats(H, W) floats.  Each output pixel depends on depth at that pixel only: no scatter. */
+int64_t s2l_depth_photo_work_floats(int height, int width);
+int s2l_depth_photo_loss(const float* depth, const float* T, float focal, const float* src, const float* target,
+                         int64_t target_stride, const float* mask, int64_t mask_stride, float weights, float* work,
+                         float* loss, float* d_depth, int height, int width, int64_t n_frames, s2l_stream_t stream);
+
 /* ---- T3: lip-sync expert loss ---------------------------------------------------
  * Replaces SyncNet_color.forward (src/face_simple/models/syncnet.py:57-67, conv.py:5-19) in eval mode, and
  * Trainer.cosine_loss / get_sync_contrastive_loss (src/face_simple/training.py:576-603) with the gradient the

@@ -351,6 +351,18 @@ def inverse_warping(depth: torch.Tensor, T: torch.Tensor, src_nhwc: torch.Tensor
     return img, z[:, None]
 
 
+def depth_photo_loss(depth: torch.Tensor, T: torch.Tensor, src_nhwc: torch.Tensor, target_nhwc: torch.Tensor, mask, focal: float,
+                     weights: float = 1.0) -> torch.Tensor:
+    """Canonical-depth photometric loss (training.py:462-477): the observed frame warped into the canonical view by the depth
+    map (Trainer.inverse_warping, :296-314) against the canonical face, masked mean of the squared error
+    (add_loss_canonical_depth_photo, :621-634).  Differentiable w.r.t. `depth` (model.canonical_depth_head)."""
+    pred, _ = inverse_warping(depth, T, src_nhwc, focal)                      # NCHW
+    pred = pred.permute(0, 2, 3, 1)
+    if mask is not None:
+        return ((pred - target_nhwc) ** 2 * mask).sum() / (mask.sum() + 1e-6) * weights
+    return ((pred - target_nhwc) ** 2).mean() * weights
+
+
 # --------------------------------------------------------------------------- T3: lip-sync expert loss
 def syncnet_encoder(sd: SD, x: torch.Tensor, prefix: str, blocks, eps: float = 1e-5) -> torch.Tensor:
     """One encoder of SyncNet_color (syncnet.py:11-54) in eval mode: per block conv -> BatchNorm(running stats) ->

@@ -91,6 +91,9 @@ EXPORTS = {
                               c_void_p]),
     "s2l_grid_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64,
                                 c_void_p]),
+    "s2l_depth_photo_work_floats": (c_int64, [c_int, c_int]),
+    "s2l_depth_photo_loss": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_syncnet_packed_floats": (c_int64, []),
     "s2l_syncnet_work_floats": (c_int64, [c_int64]),
     "s2l_syncnet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),

@@ -170,6 +170,148 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
   o[0] = acc[0], o[1] = acc[1], o[2] = acc[2];
 }
 
+
+// ---- canonical-depth photometric loss (training.py:462-477, 621-634) ---------------------------------------------------------
+//   pred = grid_sample(rgb_face_gt, Project3D(BackprojectDepth(canonical_depth_head), K, rel_pose), padding_mode='border')
+//   loss = weights * sum((pred - rgb_face_canonical)^2 * mask) / (sum(mask) + 1e-6)
+// and its gradient with respect to the depth map -- the only parameter this term trains.  The whole chain is LOCAL: output pixel
+// p depends on depth[p] alone (the depth moves the sampling position of pixel p in the observed frame), so one thread evaluates
+// pixel p of every frame forward and backward and d_depth needs no scatter.  Forward arithmetic follows warp_grid_kernel and
+// grid_sample_kernel<1>; the backward follows ATen's grid_sampler_2d_backward (border: zero gradient where the coordinate was
+// clipped; bilinear: the four tap values times the opposite-corner distances).
+struct DepthLossArgs {
+  const float* depth;    // [H,W]
+  const float* T;        // [F,16]
+  const float* src;      // [F,H,W,3]  rgb_face_gt
+  const float* target;   // [H,W,3] (stride 0) or [F,H,W,3]  rgb_face_canonical
+  const float* mask;     // NULL, or like target
+  float* d_raw;          // [H,W]: sum over frames of d numerator / d depth
+  float* part;           // [blocks][2]: numerator, denominator partial sums
+  int64_t target_stride, mask_stride;
+  float focal, cx, cy, eps;
+  int H, W, F;
+};
+
+__global__ __launch_bounds__(256) void depth_photo_kernel(DepthLossArgs a) {
+  __shared__ float red[2][256];
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float num = 0.f, den = 0.f, graw = 0.f;
+  if (i < hw) {
+    const int y = i / a.W, x = i - y * a.W;
+    const float inv_f = 1.f / a.focal, ncx = -a.cx / a.focal, ncy = -a.cy / a.focal;
+    const float isx = 1.f / (float)(a.W - 1), isy = 1.f / (float)(a.H - 1);
+    const float d = a.depth[i];
+    const float rx = fmaf((float)x, inv_f, ncx), ry = fmaf((float)y, inv_f, ncy);
+    for (int f = 0; f < a.F; ++f) {
+      const float* t = a.T + 16 * (int64_t)f;
+      float p0[4], p1[4], p2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        p2[j] = t[8 + j];
+        p0[j] = fmaf(a.focal, t[j], a.cx * p2[j]);
+        p1[j] = fmaf(a.focal, t[4 + j], a.cy * p2[j]);
+      }
+      const float X = d * rx, Y = d * ry, Z = d;
+      const float px = fmaf(p0[0], X, fmaf(p0[1], Y, fmaf(p0[2], Z, p0[3])));
+      const float py = fmaf(p1[0], X, fmaf(p1[1], Y, fmaf(p1[2], Z, p1[3])));
+      const float pz = fmaf(p2[0], X, fmaf(p2[1], Y, fmaf(p2[2], Z, p2[3])));
+      const float inv = 1.f / (pz + a.eps);
+      const float gx = fmaf(px * inv * isx, 2.f, -1.f), gy = fmaf(py * inv * isy, 2.f, -1.f);
+      // d (px, py, pz) / d depth
+      const float dpx = fmaf(p0[0], rx, fmaf(p0[1], ry, p0[2])), dpy = fmaf(p1[0], rx, fmaf(p1[1], ry, p1[2]));
+      const float dpz = fmaf(p2[0], rx, fmaf(p2[1], ry, p2[2]));
+      const float dgx = 2.f * isx * (dpx - px * inv * dpz) * inv, dgy = 2.f * isy * (dpy - py * inv * dpz) * inv;
+      // grid_sample(align_corners=False, border)
+      float ix = ((gx + 1.f) * (float)a.W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)a.H - 1.f) / 2.f;
+      float mx = 0.5f * (float)a.W, my = 0.5f * (float)a.H;                      // d ix / d gx, zero where clipped
+      if (!(ix > 0.f)) ix = 0.f, mx = 0.f;
+      else if (!(ix < (float)(a.W - 1))) ix = (float)(a.W - 1), mx = 0.f;
+      if (!(iy > 0.f)) iy = 0.f, my = 0.f;
+      else if (!(iy < (float)(a.H - 1))) iy = (float)(a.H - 1), my = 0.f;
+      const float xw = floorf(ix), yn = floorf(iy);
+      const float wx = ix - xw, ex = 1.f - wx, ny = iy - yn, sy = 1.f - ny;
+      const int x0 = (int)xw, y0 = (int)yn;
+      const float* sf = a.src + (int64_t)f * hw * 3;
+      float v[4][3];
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int xx = x0 + (tq & 1), yy = y0 + (tq >> 1);
+        const bool ok = xx < a.W && yy < a.H;                                    // x0, y0 >= 0 after the clip
+        const float* p = sf + ((int64_t)min(yy, a.H - 1) * a.W + min(xx, a.W - 1)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[tq][c] = ok ? p[c] : 0.f;
+      }
+      const float* tg = a.target + a.target_stride * f + (int64_t)i * 3;
+      const float* mk = a.mask ? a.mask + a.mask_stride * f + (int64_t)i * 3 : nullptr;
+      float gix = 0.f, giy = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // ATen accumulates nw, ne, sw, se in this order (as grid_sample_kernel)
+        float pred = 0.f;
+        pred = pred + v[0][c] * (sy * ex);
+        pred = pred + v[1][c] * (sy * wx);
+        pred = pred + v[2][c] * (ny * ex);
+        pred = pred + v[3][c] * (ny * wx);
+        const float m = mk ? mk[c] : 1.f;
+        const float diff = pred - tg[c];
+        num = fmaf(diff * diff, m, num);
+        den += m;
+        const float go = 2.f * diff * m;
+        gix += go * (sy * (v[1][c] - v[0][c]) + ny * (v[3][c] - v[2][c]));
+        giy += go * (ex * (v[2][c] - v[0][c]) + wx * (v[3][c] - v[1][c]));
+      }
+      graw += gix * mx * dgx + giy * my * dgy;
+    }
+    a.d_raw[i] = graw;
+  }
+  red[0][threadIdx.x] = num;
+  red[1][threadIdx.x] = den;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + k];
+      red[1][threadIdx.x] += red[1][threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.part[2 * blockIdx.x] = red[0][0];
+    a.part[2 * blockIdx.x + 1] = red[1][0];
+  }
+}
+
+// one block: totals of the partials (fixed order), loss = weights * num / (den + 1e-6); scale = weights / (den + 1e-6)
+__global__ __launch_bounds__(256) void depth_photo_final_kernel(const float* __restrict__ part, int n, float weights, int use_mask,
+                                                               float n_elems, float* __restrict__ loss_scale) {
+  __shared__ float red[2][256];
+  float num = 0.f, den = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    num += part[2 * i];
+    den += part[2 * i + 1];
+  }
+  red[0][threadIdx.x] = num;
+  red[1][threadIdx.x] = den;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + k];
+      red[1][threadIdx.x] += red[1][threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float denom = use_mask ? red[1][0] + 1e-6f : n_elems;        // masked mean (training.py:628-629) or torch.mean (:631)
+    loss_scale[0] = red[0][0] / denom * weights;
+    loss_scale[1] = weights / denom;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(float* __restrict__ x, const float* __restrict__ s, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= s[1];
+}
+
 }  // namespace s2l
 
 extern "C" int s2l_rel_pose(const float* euler, const float* trans, const float* canon_euler, const float* canon_trans,
@@ -213,5 +355,38 @@ extern "C" int s2l_grid_sample(const float* img, int64_t img_stride, const float
     hipLaunchKernelGGL(s2l::grid_sample_kernel<1>, g, dim3(256), 0, st, img, img_stride, grid, out, img_h, img_w, opix);
   else
     hipLaunchKernelGGL(s2l::grid_sample_kernel<0>, g, dim3(256), 0, st, img, img_stride, grid, out, img_h, img_w, opix);
+  return (int)hipGetLastError();
+}
+
+// Canonical-depth photometric loss and d loss / d depth (see depth_photo_kernel).  depth [H,W]; T [F,16] row-major 4x4 relative
+// poses (compute_rel_pose_inverse, training.py:270-275); src [F,H,W,3]; target, mask: [H,W,3] when *_stride == 0 or [F,H,W,3]
+// when stride == H*W*3; mask may be NULL (plain mean).  loss: 2 floats (loss, internal scale); d_depth [H,W] (may be NULL);
+// work: s2l_depth_photo_work_floats(H, W) floats.
+extern "C" int64_t s2l_depth_photo_work_floats(int height, int width) {
+  if (height < 2 || width < 2) return 0;
+  const int64_t hw = (int64_t)height * width;
+  return hw + 2 * ((hw + 255) / 256);
+}
+
+extern "C" int s2l_depth_photo_loss(const float* depth, const float* T, float focal, const float* src, const float* target,
+                                    int64_t target_stride, const float* mask, int64_t mask_stride, float weights, float* work,
+                                    float* loss, float* d_depth, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  const int64_t hw = (int64_t)height * width;
+  if (n_frames <= 0 || height < 2 || width < 2 || hw > (1 << 24) || n_frames > 65535 || !(focal > 0.f)) return S2L_E_SIZE;
+  if ((target_stride != 0 && target_stride != hw * 3) || (mask_stride != 0 && mask_stride != hw * 3)) return S2L_E_SIZE;
+  if (!depth || !T || !src || !target || !work || !loss) return S2L_E_NULL;
+  s2l::DepthLossArgs a;
+  a.depth = depth; a.T = T; a.src = src; a.target = target; a.mask = mask;
+  a.target_stride = target_stride; a.mask_stride = mask_stride;
+  a.d_raw = d_depth ? d_depth : work;
+  a.part = work + hw;
+  a.focal = focal; a.cx = 0.5f * (float)width; a.cy = 0.5f * (float)height; a.eps = 1e-7f;
+  a.H = height; a.W = width; a.F = (int)n_frames;
+  const int blocks = (int)((hw + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(s2l::depth_photo_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(s2l::depth_photo_final_kernel, dim3(1), dim3(256), 0, st, a.part, blocks, weights, mask ? 1 : 0,
+                     (float)(hw * 3 * n_frames), loss);
+  if (d_depth) hipLaunchKernelGGL(s2l::scale_by_device_scalar_kernel, dim3(blocks), dim3(256), 0, st, d_depth, loss, (int)hw);
   return (int)hipGetLastError();
 }

@@ -113,3 +113,57 @@ def coords_for_clip(depth: torch.Tensor, canonical_euler, canonical_trans, euler
     """The `coords/%05d.npy` grids of a clip, as face_tracker.py:583-606 computes them (obs->can pose, [-1,1] clamp)."""
     T = compute_rel_pose_from_obs2can(canonical_euler, canonical_trans, euler, trans)
     return warp_grid(depth, T, focal, clamp=True, out=out)
+
+
+def depth_photo_loss(cfg, tgt_depth: torch.Tensor, rel_pose: torch.Tensor, src_img: torch.Tensor, target: torch.Tensor,
+                     mask: Optional[torch.Tensor] = None, weights: float = 1.0, want_grad: bool = False):
+    """Canonical-depth photometric loss (training.py:462-477): `src_img` [F,H,W,3] (rgb_face_gt) warped into the canonical view
+    by `tgt_depth` [H,W] (model.canonical_depth_head) and `rel_pose` [F,4,4] (compute_rel_pose_inverse), against `target`
+    (rgb_face_canonical, [H,W,3] / [1,H,W,3] / [F,H,W,3]) under `mask` (same shapes, or None):
+        weights * sum((pred - target)^2 * mask) / (sum(mask) + 1e-6)          (add_loss_canonical_depth_photo, :621-634)
+    One fused kernel evaluates the projection, the border-padded bilinear sampling, the loss and -- want_grad -- d loss / d depth.
+    With autograd recording and a depth that requires grad the returned loss is differentiable (the reference's
+    loss.backward() then fills canonical_depth_head.grad)."""
+    if not want_grad and torch.is_grad_enabled() and isinstance(tgt_depth, torch.Tensor) and tgt_depth.requires_grad:
+        return _DepthPhotoLoss.apply(tgt_depth, cfg, rel_pose, src_img, target, mask, float(weights))
+    lib = _abi.load()
+    dev = rel_pose.device
+    T = _dev_f32(rel_pose, dev, "rel_pose").reshape(-1, 16)
+    d = _dev_f32(tgt_depth, dev, "tgt_depth")
+    src = _dev_f32(src_img, dev, "src_img")
+    F, H, W = src.shape[0], src.shape[1], src.shape[2]
+    if d.shape != (H, W) or T.shape[0] != F or src.shape[3] != 3:
+        raise ValueError("depth_photo_loss: depth [H,W], rel_pose [F,4,4], src_img [F,H,W,3]")
+
+    def shared(t, name):
+        t = _dev_f32(t, dev, name)
+        if t.shape in ((H, W, 3), (1, H, W, 3)):
+            return t, 0
+        if t.shape == (F, H, W, 3):
+            return t, H * W * 3
+        raise ValueError(f"depth_photo_loss: {name} must be [H,W,3], [1,H,W,3] or [F,H,W,3]")
+
+    tg, ts = shared(target, "target")
+    mk, ms = shared(mask, "mask") if mask is not None else (None, 0)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    dd = torch.empty(H, W, dtype=torch.float32, device=dev) if want_grad else None
+    work = torch.empty(int(lib.s2l_depth_photo_work_floats(H, W)), dtype=torch.float32, device=dev)
+    import ctypes
+    with torch.cuda.device(dev):
+        _abi.check(lib.s2l_depth_photo_loss(_ptr(d), _ptr(T), ctypes.c_float(float(cfg["data"]["face_img_focal"])), _ptr(src), _ptr(tg), ts,
+                                            _ptr(mk), ms, ctypes.c_float(float(weights)), _ptr(work), _ptr(loss), _ptr(dd), H, W, F,
+                                            _stream()), "s2l_depth_photo_loss")
+    return (loss[0], dd) if want_grad else loss[0]
+
+
+class _DepthPhotoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, cfg, rel_pose, src_img, target, mask, weights):
+        loss, dd = depth_photo_loss(cfg, depth.detach(), rel_pose, src_img, target, mask, weights, want_grad=True)
+        ctx.save_for_backward(dd)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        (dd,) = ctx.saved_tensors
+        return dd * d_loss, None, None, None, None, None, None

@@ -16,7 +16,8 @@ Beyond the reference surface, `render_clip` is the batched driver that replaces 
 loop of inference.py:140-159 (audio encoder once per frame, one fused launch per clip).
 
 The post-fusion U-Net (`post_fusion_unet`) is `speech2lip_amd.unet.SimpleUnetLight`
-(eval mode).  Not in this path: training of the U-Net (BatchNorm batch statistics).
+(eval mode); `canonical_depth_head` (tf_nerf.py:174-195) is the parameter the canonical-depth photometric loss trains
+(speech2lip_amd.geometry.depth_photo_loss).  Not in this path: training of the U-Net (BatchNorm batch statistics).
 """
 from __future__ import annotations
 
@@ -141,11 +142,34 @@ class TalkingFace(nn.Module):
             self.use_resnet = bool(m.get("use_resnet", False))
             self.post_fusion_channel = int(m.get("post_fusion_channel", 3))
             self.post_fusion_unet = SimpleUnetLight(cfg=cfg, n_channels=self.post_fusion_channel)
+        if m.get("use_canonical_depth", False):   # tf_nerf.py:174-195
+            self.canonical_depth_head = nn.Parameter(self._init_canonical_depth(cfg), requires_grad=True)
         self.to(self.device)
 
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._tables = {}
+
+    @staticmethod
+    def _init_canonical_depth(cfg) -> torch.Tensor:
+        """tf_nerf.py:174-193: the 3DMM depth of the canonical frame (`canonical_depth_init_path`, .npy), its holes filled with
+        the mean positive depth inside the head mask (`canonical_head_mask.jpg`, cv2.imread(...)/255 binarised, channel 0 of
+        cv2's BGR order = the blue channel), zero outside it; or N(0,1) of (canonical_depth_height, canonical_depth_width) when
+        no init path is configured."""
+        import os
+        import numpy as np
+        m = cfg["model"]
+        if "canonical_depth_init_path" not in m:
+            return torch.randn((int(m["canonical_depth_height"]), int(m["canonical_depth_width"])))
+        init = torch.from_numpy(np.load(m["canonical_depth_init_path"])).float()
+        head = init.clone()
+        head[head == 0] = head[head > 0].mean()
+        from PIL import Image
+        mask = np.asarray(Image.open(os.path.join(cfg["data"]["path"], "canonical_head_mask.jpg")).convert("RGB"))[:, :, 2] / 255
+        mask = torch.from_numpy((mask > 0).astype(np.int32))
+        head[mask == 0] = 0
+        head[init > 0] = init[init > 0]
+        return head
 
     # ------------------------------------------------------------------ weights
     def _hot_tensors(self):

@@ -112,6 +112,31 @@ class Trainer:
             return predict_with_graph(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
         return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
 
+    def compute_rel_pose(self, canonical_euler, canonical_trans, euler, trans, img_batch_size=1, device=None):
+        """training.py:263-268."""
+        from . import geometry
+        return geometry.compute_rel_pose(canonical_euler, canonical_trans, euler, trans)
+
+    def compute_rel_pose_inverse(self, canonical_euler, canonical_trans, euler, trans, img_batch_size=1, device=None):
+        """training.py:270-275."""
+        from . import geometry
+        return geometry.compute_rel_pose_inverse(canonical_euler, canonical_trans, euler, trans)
+
+    def inverse_warping(self, tgt_depth, rel_pose, src_img):
+        """training.py:296-314 -> (predict_img NCHW, cam_points_z [F,1,H,W]) (forward only; the loss below is the
+        differentiable form of the pair)."""
+        from . import geometry
+        return geometry.inverse_warping(self.cfg, tgt_depth, rel_pose, src_img, return_z=True)
+
+    def canonical_depth_photo_loss(self, tgt_depth, rel_pose, src_img, target, loss, mask=None, weights=1.0):
+        """training.py:470-477 in one call: inverse_warping + add_loss_canonical_depth_photo (:621-634), fused on the device
+        and differentiable w.r.t. `tgt_depth` (model.canonical_depth_head) when autograd is recording."""
+        from . import geometry
+        l = geometry.depth_photo_loss(self.cfg, tgt_depth, rel_pose, src_img, target, mask, weights)
+        loss["loss"] = loss["loss"] + l
+        loss["loss_canonical_depth_photo"] = loss.get("loss_canonical_depth_photo", 0) + l.detach().cpu()
+        return l
+
     def add_photometric_loss(self, prediction, target, loss, coarse=False, mask=None, weights=1.0):
         """training.py:605-619 (mask=None branch): differentiable through autograd.mse when recording."""
         from .autograd import mse

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -158,3 +160,29 @@ def test_synthetic_generators_are_deterministic():
     assert abs(a[0, 10, 12, 0] - (25 / 24 - 1)) < 0.08 and abs(a[0, 10, 12, 1] - (21 / 20 - 1)) < 0.08
     img = W.synthetic_image((3, 4, 3), 2)
     assert img.min() >= 0 and img.max() < 1 and (img == W.synthetic_image((3, 4, 3), 2)).all()
+
+
+def test_canonical_depth_head_parameter(tmp_path):
+    """tf_nerf.py:174-195: the parameter exists under the reference's state-dict key when model.use_canonical_depth is on, built
+    from the init depth + head mask the reference reads (holes filled with the mean depth inside the mask, zero outside)."""
+    from PIL import Image
+    cfg = s2l.may_config(16, 16, str(tmp_path / "may_face"))
+    (tmp_path / "may_face").mkdir()
+    init = np.zeros((12, 10), np.float32)
+    init[2:9, 3:8] = 9.0 + np.arange(35, dtype=np.float32).reshape(7, 5) * 0.01
+    init[4, 5] = 0.0                                                     # a hole inside the head
+    np.save(tmp_path / "depth.npy", init)
+    mask = np.zeros((12, 10, 3), np.uint8)
+    mask[1:10, 2:9] = 255
+    Image.fromarray(mask).save(tmp_path / "may_face" / "canonical_head_mask.png")
+    (tmp_path / "may_face" / "canonical_head_mask.png").rename(tmp_path / "may_face" / "canonical_head_mask.jpg")
+    cfg["model"].update(use_canonical_depth=True, canonical_depth_init_path=str(tmp_path / "depth.npy"), canonical_depth_height=12,
+                        canonical_depth_width=10)
+    m = s2l.TalkingFace(torch.device("cpu"), cfg)
+    d = m.canonical_depth_head.detach()
+    assert "canonical_depth_head" in m.state_dict() and d.shape == (12, 10) and m.canonical_depth_head.requires_grad
+    mean = float(init[init > 0].mean())
+    assert abs(float(d[4, 5]) - mean) < 1e-5 and float(d[0, 0]) == 0.0 and abs(float(d[1, 2]) - mean) < 1e-5
+    assert torch.equal(d[2:9, 3:8][init[2:9, 3:8] > 0], torch.from_numpy(init[2:9, 3:8][init[2:9, 3:8] > 0]))
+    cfg["model"].pop("canonical_depth_init_path")
+    assert s2l.TalkingFace(torch.device("cpu"), cfg).canonical_depth_head.shape == (12, 10)

@@ -360,3 +360,47 @@ def test_autograd_chain_equals_stage_one_step(golden, syncnet, dev):
     params = dict(m.named_parameters())
     for k, gk in ref_g.items():
         assert relerr(params[k].grad.reshape(gk.shape), gk.cpu()) <= 2e-4, (k, relerr(params[k].grad.reshape(gk.shape), gk.cpu()))
+
+
+# ------------------------------------------------------------------------------------------------ canonical depth head
+def test_depth_photo_loss_golden_and_oracle(golden, dev):
+    """training.py:462-477 against the reference's own loss and the gradient it left in canonical_depth_head.grad (G12), then
+    500x500 with several frames, shared and per-frame targets, with and without a mask, against autograd through the oracle.
+    The projection is ill-conditioned in fp32 (tests/test_oracle_golden.py, G8): gradients are held to 1e-3 of their maximum."""
+    from speech2lip_amd import geometry as G
+    g = golden("g12_depth_photo.npz")
+    cfg = {"data": {"face_img_focal": float(g["focal"])}}
+    loss, dd = G.depth_photo_loss(cfg, T(g["depth"]).to(dev), T(g["rel_pose"]).to(dev), T(g["src"]).to(dev), T(g["target"]).to(dev),
+                                  T(g["mask"]).to(dev), want_grad=True)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    assert relerr(dd, g["d_depth"]) <= 2e-3
+    # through autograd: a depth parameter that requires grad, the Trainer-shaped call
+    m = make_model(dev, 16, 16)
+    tr = s2l.Trainer(m, cfg={**m.cfg, "data": {**m.cfg["data"], "face_img_focal": float(g["focal"])}})
+    depth_p = torch.nn.Parameter(T(g["depth"]).to(dev))
+    ld = {"loss": 0}
+    tr.canonical_depth_photo_loss(depth_p, T(g["rel_pose"]).to(dev), T(g["src"]).to(dev), T(g["target"]).to(dev), ld, mask=T(g["mask"]).to(dev))
+    ld["loss"].backward()
+    assert torch.equal(depth_p.grad, dd)
+    rng = np.random.default_rng(12)
+    for (H, Wd, F, shared, masked) in [(500, 500, 2, True, True), (40, 56, 3, False, False)]:
+        ce = T(np.array([[0.03, 0.01, -0.02]], np.float32)); ct = T(np.array([[0.2, 0.1, -9.0]], np.float32))
+        eul = ce + T(rng.normal(0, 0.05, (F, 3)).astype(np.float32)); trn = ct + T(rng.normal(0, 0.2, (F, 3)).astype(np.float32))
+        Tm = G.compute_rel_pose_inverse(ce.to(dev), ct.to(dev), eul.to(dev), trn.to(dev))
+        depth = T((9.0 + rng.normal(0, 0.3, (H, Wd))).astype(np.float32))
+        # a smooth source image: the loss gradient is the image gradient, and white noise would make it pure rounding noise
+        yy, xx = np.meshgrid(np.linspace(0, 6, H, dtype=np.float32), np.linspace(0, 6, Wd, dtype=np.float32), indexing="ij")
+        src = T(np.stack([0.5 + 0.4 * np.sin(xx + 0.7 * f + c) * np.cos(yy - c) for f in range(F) for c in range(3)], 0).reshape(F, 3, H, Wd)
+                .transpose(0, 2, 3, 1).astype(np.float32).copy())
+        tgt = T(rng.random((1 if shared else F, H, Wd, 3), dtype=np.float32))
+        msk = T((rng.random((1 if shared else F, H, Wd, 3)) > 0.4).astype(np.float32)) if masked else None
+        d_o = depth.clone().requires_grad_(True)
+        l_o = O.depth_photo_loss(d_o, Tm.cpu(), src, tgt.expand(F, -1, -1, -1), None if msk is None else msk.expand(F, -1, -1, -1), 1200.0,
+                                 weights=0.7)
+        l_o.backward()
+        cfg = {"data": {"face_img_focal": 1200.0}}
+        loss, dd = G.depth_photo_loss(cfg, depth.to(dev), Tm, src.to(dev), tgt.to(dev), None if msk is None else msk.to(dev), weights=0.7,
+                                      want_grad=True)
+        assert abs(float(loss) - float(l_o)) <= 1e-5 * max(1.0, float(l_o)), (float(loss), float(l_o))
+        e = (dd.cpu() - d_o.grad).abs() / float(d_o.grad.abs().max())
+        assert float(e.max()) <= 5e-2 and float((e > 1e-3).float().mean()) <= 1e-2, (float(e.max()), float((e > 1e-3).float().mean()))

@@ -251,3 +251,14 @@ def test_crop_resize_formula_is_the_one_aten_evaluates():
                 x0 = int(fx); x1 = min(x0 + 1, iw - 1); lx = np.float64(np.float32(fx - np.float32(x0)))
                 out[:, oy, ox] = (1 - ly) * ((1 - lx) * crop[:, y0, x0] + lx * crop[:, y0, x1]) + ly * ((1 - lx) * crop[:, y1, x0] + lx * crop[:, y1, x1])
         assert _maxerr(y, out) <= 3e-7, (bbox, size)
+
+
+def test_g12_canonical_depth_photo_loss(golden):
+    """training.py:462-477: loss and d loss / d canonical_depth_head against the reference's Trainer.inverse_warping +
+    add_loss_canonical_depth_photo + autograd."""
+    g = golden("g12_depth_photo.npz")
+    d = T(g["depth"]).clone().requires_grad_(True)
+    loss = O.depth_photo_loss(d, T(g["rel_pose"]), T(g["src"]), T(g["target"]), T(g["mask"]), float(g["focal"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert _maxerr(d.grad, g["d_depth"]) <= 1e-3 * float(np.abs(g["d_depth"]).max())

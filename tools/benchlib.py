@@ -149,6 +149,61 @@ def train_flops(B, hw=96 * 96):
     return 3 * 4 * 2 * 644_864 * hw * B
 
 
+def sync_batch(dev, S, T=5, FH=500, FW=500, h=96, w=96, x0=202, y0=316, seed=11):
+    """Synthetic inputs of the sync-loss window for S samples (SURVEY.md §8d geometry: 96x96 lip at (202,316) in a 500x500
+    face): the dict StageOneStep.loss_and_grads takes as `sync`."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    coord, _ = device_warp_coords(dev, S * T, FH, FW, seed=seed)
+    mask = torch.zeros(1, FH, FW, 3, device=dev)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    mel, _, neg = (torch.from_numpy(x).to(dev) for x in W.synthetic_sync_batch(S, seed=seed))
+    return dict(audio_window=torch.from_numpy(W.synthetic_audio(S * T, seed).astype(np.float32)).reshape(S, T, 16, 29).to(dev),
+                u01=torch.rand(S, T, generator=torch.Generator().manual_seed(seed)).tolist(), total_frame=100000,
+                rgb_face_canonical=torch.rand(1, FH, FW, 3, device=dev, generator=g), rgb_face_gt=torch.rand(S, FH, FW, 3, device=dev, generator=g),
+                mask_lip_canonical=mask, lip_lefttop_x=x0, lip_lefttop_y=y0, coord_window=coord.reshape(S, T, FH, FW, 2),
+                canonical_face_bbox=[110, 90, 390, 420, 1.0], mel=mel, rgb_window_neg=neg)
+
+
+def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
+    """BASELINE config 5 as named -- MLP forward + backward WITH the lipsync_expert loss: B main frames (MSE) of which the
+    first S carry a 5-frame sync window (5 S more renders -> composite -> frozen U-Net @500x500 -> crop/resize -> SyncNet x2 ->
+    BCE, and all of it back to the MLP), bf16 MLP kernels, Adam.  FLOPs counted: the MLP's as-written 3 x 4 x 2 x 644,864 per
+    pixel-frame over B + 5 S frames, plus 3 x 157.6 GFLOP per window frame for the U-Net forward + input gradient (2 passes
+    counted as forward + one backward of equal cost) -- reported separately."""
+    H = Wd = 96
+    m = make_model(dev, H, Wd, unet=True, train=True)
+    m.post_fusion_unet.eval()
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
+    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
+    audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
+    target = torch.rand(B, H * Wd, 3, device=dev)
+    step = s2l.StageOneStep(m, H, Wd, syncnet=net, precision=precision)
+    sync = sync_batch(dev, S) if S else None
+    u01 = [0.5] * B
+
+    def one():
+        loss, g, aux = step.loss_and_grads(audio, list(range(B)), target, u01, sync=sync)
+        s2l.training.apply_grads(m, g)
+        opt.step()
+        return loss, aux
+    l0, aux0 = one()
+    l0 = float(l0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l, aux = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    mlp = train_flops(B + 5 * S, H * Wd)
+    unet = 2 * 157.6e9 * 5 * S
+    return {"config": f"stage-1 step, {B} main frames 96x96 + sync loss on {S} samples ({5 * S} window frames through composite + U-Net "
+                      f"@500x500 + SyncNet), {precision} MLP, Adam", "ms_per_step": round(dt * 1e3, 2),
+            "mlp_frames_per_step": B + 5 * S, "mlp_tflop_per_step": round(mlp / 1e12, 3), "unet_tflop_per_step": round(unet / 1e12, 3),
+            "tflops": round((mlp + unet) / dt / 1e12, 1), "loss_first": l0, "loss_last": float(l),
+            "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
 def bench_train(dev, B=64, precision="bf16", steps=5):
     """BASELINE config 5: one step = 4-tap ensemble forward + MSE + full backward + Adam for B frames at 96x96."""
     H = Wd = 96

@@ -421,11 +421,39 @@ def main():
                                                 "fc_audio_skip.weight", "encoder_conv.0.weight", "encoder_fc1.2.bias")},
         g_pts5_cols=ref_g["pts_linears.5.weight"][:, 250:262].numpy())
 
+    # ---- G12: canonical-depth photometric loss (training.py:462-477): the reference's own Trainer.inverse_warping +
+    # add_loss_canonical_depth_photo and the gradient loss.backward() leaves in canonical_depth_head.grad
+    import src.face_simple.models.utils as U2
+    H_, W_, focal = 28, 36, 1200.0
+    g8 = dict(np.load(os.path.join(GOLD, "g8_warp.npz")))
+    trd = ref_training.Trainer.__new__(ref_training.Trainer)
+    trd.device = torch.device("cpu")
+    trd.cfg = {"data": {"face_img_focal": focal}, "training": {"use_face_photo_loss": True, "use_lip_photo_loss": "v1"}}
+    trd.backproject_depth = {0: U2.BackprojectDepth(1, H_, W_, device=torch.device("cpu"))}
+    trd.project_3d = {0: U2.Project3D(1, H_, W_)}
+    depth_p = torch.nn.Parameter(torch.from_numpy(g8["depth"][1]).clone())
+    rel = torch.from_numpy(g8["T_mode2"][2:3])                       # compute_rel_pose_inverse of frame 2
+    src = torch.from_numpy(rng2.random((1, H_, W_, 3), dtype=np.float32))
+    tgt = torch.from_numpy(rng2.random((1, H_, W_, 3), dtype=np.float32))
+    msk = torch.from_numpy((rng2.random((1, H_, W_, 3)) > 0.3).astype(np.float32))
+    pred, _ = trd.inverse_warping(depth_p, rel, src)
+    lossd = {"loss": 0, "loss_canonical_depth_photo": 0}
+    trd.add_loss_canonical_depth_photo(pred.permute(0, 2, 3, 1), tgt, lossd, mask=msk)
+    lossd["loss"].backward()
+    d_o = torch.from_numpy(g8["depth"][1]).clone().requires_grad_(True)
+    l_o = O.depth_photo_loss(d_o, rel, src, tgt, msk, focal)
+    l_o.backward()
+    report["depth_photo_loss"] = maxerr(lossd["loss"].detach(), l_o.detach())
+    report["depth_photo_grad_rel"] = maxerr(depth_p.grad, d_o.grad) / float(depth_p.grad.abs().max())
+    np.savez_compressed(os.path.join(GOLD, "g12_depth_photo.npz"), depth=g8["depth"][1], rel_pose=rel.numpy(), src=src.numpy(),
+                        target=tgt.numpy(), mask=msk.numpy(), focal=np.array(focal, np.float32), loss=np.array(float(lossd["loss"])),
+                        d_depth=depth_p.grad.numpy())
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
     # sits ~4e-6 from the fp64 evaluation of the same formula), and inverse_warping multiplies that by the image gradient.
-    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5}
+    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3}
     limits.update({k: 1e-5 for k in report if k.startswith("warp_grid")})
     bad = []
     for k, v in report.items():
