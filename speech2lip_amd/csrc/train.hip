@@ -70,13 +70,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dz
     }
   }
   // D[row = 4q + r -> out feature][col = i -> in feature]
-  float* p = partial + (int64_t)blockIdx.x * 256 * (KB * 16);
+  // the accumulators live in AGPRs: move them out and store them one M-block at a time (a scheduling barrier between the
+  // blocks keeps the compiler from reading all 256 of them into VGPRs first, which spilled 36 B per lane)
+  float* p = partial + (int64_t)blockIdx.x * 256 * (KB * 16) + (int64_t)(wave * 64 + 4 * q) * (KB * 16) + i;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 4; ++m) {
 #pragma unroll
     for (int n = 0; n < KB; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[(int64_t)(wave * 64 + m * 16 + 4 * q + r) * (KB * 16) + n * 16 + i] = acc[m][n][r];
+      for (int r = 0; r < 4; ++r) p[(m * 16 + r) * (KB * 16) + n * 16] = acc[m][n][r];
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (bias_partial) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {

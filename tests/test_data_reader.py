@@ -78,3 +78,42 @@ def test_write_frames_roundtrip(tmp_path):
     D.write_frames(frames, ["00001", "00002"], str(tmp_path / "out"))
     back = np.asarray(Image.open(tmp_path / "out" / "00001.jpg"))
     assert back.shape == (8, 8, 3) and abs(int(back.mean()) - 127) <= 1
+
+
+def test_committed_fixture_hand_traced():
+    """tests/golden/dataset_fixture/may_face_crop_lip (tools/make_dataset_fixture.py) read by SomeonesLipClip, against what
+    the reference reader yields for it WHEN ITS CODE IS TRACED BY HAND (someones_lip_dataset.py line numbers in the comments).
+    Unpinned: the decoded JPEG pixels (the reference decodes with cv2 / imageio, absent here) -- flat images make them exact."""
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    # :173-193 compute_mouth_bbox on landmarks 48..67: cv2.boundingRect of float points = (floor(5.5), floor(4.75),
+    #   floor(12.25) - 5 + 1, floor(8.5) - 4 + 1) = (5, 4, 8, 5); centre x = 5 + 8/2 = 9.0; 'may' is neither 'adnerf' nor
+    #   'macron': centre y = (4 + 5/2) * 1.02 = 6.63; w, h = 8, 6 (the lip crop size from images/00001.jpg, :69);
+    #   x = int(9.0 - 4.0) = 5, y = int(6.63 - 3.0) = 3
+    val = D.SomeonesLipClip(folder, "val")
+    assert (val.lip_h, val.lip_w, val.face_h, val.face_w) == (6, 8, 12, 16)
+    assert (val.lefttop_x, val.lefttop_y) == (5, 3)
+    # :122-125 length = int(20 * 0.9) = 18; :139-142 mode 'val' in a 'may' folder: length = -598, so every list is
+    #   sliced [-598:], which for 20 entries is all of them
+    assert len(val) == 20
+    c = val.load("cpu")
+    # :246 audio = aud_features[index] as float32; :247 data['index'] = position inside the split; inference.py:177 names
+    #   the output "%05d" % (index + 1)
+    assert c.audio.dtype == torch.float32 and c.audio[:, 3, 7].tolist() == [float(k) for k in range(20)]
+    assert c.index.tolist() == list(range(20)) and c.names[0] == "00001" and c.names[19] == "00020"
+    # coords/%05d.npy of frame k is file k+1 (sorted listing, :107/:146)
+    assert [round(float(v), 2) for v in c.coord[:, 0, 0, 0]] == [round((k + 1) / 100, 2) for k in range(20)]
+    assert c.coord.shape == (20, 12, 16, 2)
+    # observed frames: flat grey 10 (k+1) / 255; canonical face = frame canonical_idx + 1 = 00001.jpg (:57, canonical_idx 0)
+    assert torch.allclose(c.rgb_face_ori[:, 5, 5, 0], torch.tensor([10.0 * (k + 1) / 255 for k in range(20)]), atol=1.01 / 255)
+    assert abs(float(c.rgb_face_zero.mean()) - 10 / 255) <= 1.01 / 255 and c.rgb_face_zero.shape == (1, 12, 16, 3)
+    # :72 mask = cv2.imread(...)/255: 1 inside rows 4..9 x cols 5..12, 0 far outside (JPEG ringing only next to the edge)
+    m = c.mask_lip_canonical[0]
+    assert float(m[6:8, 7:11].min()) > 0.97 and float(m[0:2, 0:3].max()) < 0.03 and float(m[11, 15].max()) < 0.03
+    # :127-129 train = [:18]
+    tr = D.SomeonesLipClip(folder, "train")
+    assert len(tr) == 18 and tr.load("cpu").audio[:, 0, 0].tolist() == [float(k) for k in range(18)]
+    # :156-161 test: audio_test/audio.npy, every window; no pose grids / observed frames are attached
+    te = D.SomeonesLipClip(folder, "test").load("cpu")
+    assert te.audio[:, 0, 0].tolist() == [100.0, 101.0, 102.0, 103.0, 104.0] and te.coord is None
+    # a folder that is not a named speaker uses the 90/10 split for val (:144-145 falls through with length = 18 -> [18:])
+    assert D.split_slice(20, "val", "dataset/someone_face_crop_lip") == slice(18, None)
