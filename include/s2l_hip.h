@@ -280,6 +280,28 @@ int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, fl
 int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x, int height,
                       int width, int64_t n_frames, s2l_stream_t stream);
 
+/* TRAIN mode of the same network, as the reference runs it until `it > 100000` (train.py:188-197): every BatchNorm2d normalises
+ * with the statistics of the batch (biased variance) and updates its running statistics in place (momentum, unbiased variance:
+ * nn.BatchNorm2d), the weights receive gradients (loss.backward(), training.py:559, through tf_nerf.py:387).
+ * s2l_unet_pack_raw: the RAW (un-folded) weights in the kernels' chunk layout, forward and transposed; same table and blob size as
+ *   s2l_unet_pack; re-run after every optimizer step.
+ * s2l_unet_train_forward: tensors_host = the s2l_unet_pack table (its running_mean / running_var entries are WRITTEN when
+ *   update_running != 0); saved: s2l_unet_train_saved_floats(H, W, F) floats; scratch: 65536 floats.
+ * s2l_unet_train_backward: d_out [F,H,W,3] -> d_x [F,H,W,3] (or NULL) and grads [s2l_unet_grad_floats()]: for each of the ten 3x3
+ *   layers in execution order conv.weight [cout,cin,3,3], bn.weight [cout], bn.bias [cout]; then outc.conv.weight [3,64],
+ *   outc.conv.bias [3].  work: s2l_unet_train_work_floats(H, W, F) floats.  Weight gradients are split-K MFMA GEMMs over the
+ *   pixels, reduced in a fixed order. */
+int64_t s2l_unet_train_saved_floats(int height, int width, int64_t n_frames);
+int64_t s2l_unet_train_work_floats(int height, int width, int64_t n_frames);
+int64_t s2l_unet_grad_floats(void);
+int s2l_unet_pack_raw(const float* const* tensors_host, float* packed, s2l_stream_t stream);
+int s2l_unet_train_forward(const float* packed_raw, const float* const* tensors_host, float bn_eps, float momentum,
+                           int update_running, const float* x, float* saved, float* scratch, float* out, int height, int width,
+                           int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors_host, const float* x, const float* saved,
+                            const float* d_out, float* work, float* d_x, float* grads, int height, int width, int64_t n_frames,
+                            s2l_stream_t stream);
+
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
  * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with
  * F.interpolate(mode='bilinear', align_corners=False), no antialiasing).  src [F,src_h,src_w,3]; box = data['canonical_face_bbox'];

@@ -250,16 +250,32 @@ def mse_loss(pred: torch.Tensor, target: torch.Tensor, weight: float = 1.0) -> t
 
 
 # --------------------------------------------------------------------------- §8f-1 U-Net
-def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet.", eps: float = 1e-5) -> torch.Tensor:
+def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet.", eps: float = 1e-5, training: bool = False,
+                 new_stats: Optional[dict] = None, momentum: float = 0.1) -> torch.Tensor:
     """Eval-mode `SimpleUnetLight` on NHWC input [B,H,W,3] -> [B,H,W,3].
     Reference: src/face_simple/models/SimpleUnetLight.py:16-111 (DoubleConv = (conv3x3 no bias -> BatchNorm
     -> ReLU) x2; Down = MaxPool2d(2) + DoubleConv; Up = bilinear x2 (align_corners=True), pad to the
     skip's size, cat([skip, up]) + DoubleConv(in, out, in//2); outc = conv1x1), called from
-    tf_nerf.py:387 on `rgb_merged_new`."""
+    tf_nerf.py:387 on `rgb_merged_new`.
+    training=True: the network as the reference runs it until `it > 100000` (train.py:188-197: train mode): BatchNorm2d
+    normalises with the statistics of the batch (biased variance) and, when `new_stats` is a dict, the running statistics
+    it would hold afterwards are written there under the state-dict names (momentum 0.1, unbiased variance,
+    num_batches_tracked + 1) -- nn.BatchNorm2d's documented update."""
     def cbr(x, name):
         head, idx = name.rsplit(".", 1)
         bn = f"{prefix}{head}.{int(idx) + 1}"
         y = F.conv2d(x, sd[f"{prefix}{name}.weight"], None, padding=1)
+        if training:
+            mean = y.mean(dim=(0, 2, 3))
+            var = y.var(dim=(0, 2, 3), unbiased=False)
+            if new_stats is not None:
+                n = y.numel() // y.shape[1]
+                new_stats[bn + ".running_mean"] = ((1 - momentum) * sd[bn + ".running_mean"] + momentum * mean).detach()
+                new_stats[bn + ".running_var"] = ((1 - momentum) * sd[bn + ".running_var"] + momentum * var * n / max(n - 1, 1)).detach()
+                new_stats[bn + ".num_batches_tracked"] = sd[bn + ".num_batches_tracked"] + 1 if bn + ".num_batches_tracked" in sd else None
+            y = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * sd[bn + ".weight"].view(1, -1, 1, 1) \
+                + sd[bn + ".bias"].view(1, -1, 1, 1)
+            return F.relu(y)
         scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + eps)
         y = (y - sd[bn + ".running_mean"].view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + sd[bn + ".bias"].view(1, -1, 1, 1)
         return F.relu(y)

@@ -57,6 +57,14 @@ EXPORTS = {
     "s2l_unet_backward_work_floats": (c_int64, [c_int, c_int, c_int64]),
     "s2l_unet_forward_saved": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_saved_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_work_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_grad_floats": (c_int64, []),
+    "s2l_unet_pack_raw": (c_int, [POINTER(c_void_p), c_void_p, c_void_p]),
+    "s2l_unet_train_forward": (c_int, [c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_backward": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int64, c_void_p]),
     "s2l_crop_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_crop_resize_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64,
                                          c_void_p]),

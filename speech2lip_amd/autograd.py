@@ -12,6 +12,7 @@ The parameters are passed to `apply` as inputs so that the engine delivers their
     predict_lip_image     Trainer.predict_lip_image         training.py:158-251   the fused 4-tap ensemble (LipTrainStep)
     composite             post_fusion2_onlylip_light        tf_nerf.py:320-386    backward: s2l_composite_backward_lip (d lip)
     unet_eval             post_fusion_unet (frozen, eval)   SimpleUnetLight.py:99-111   backward: s2l_unet_backward (d input)
+    unet_train            post_fusion_unet (train mode)     SimpleUnetLight.py:99-111   backward: s2l_unet_train_backward (d input + 32 tensors)
     crop_resize           crop + transforms.Resize          training.py:541-544   backward: s2l_crop_resize_backward
     sync_contrastive_loss get_sync_contrastive_loss         training.py:581-603   backward: s2l_syncnet_face_backward (d window)
     mse                   add_photometric_loss              training.py:605-619   backward: the gradient s2l_mse returns
@@ -163,6 +164,27 @@ def unet_eval(unet, x_nhwc):
     """Frozen eval-mode post-fusion U-Net with an input gradient (no parameter gradients: the reference has set
     requires_grad=False on them by the time this path is used, train.py:188-197)."""
     return _UnetEval.apply(unet, x_nhwc)
+
+
+class _UnetTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, unet, x, *params):
+        out, saved = unet.forward_train_nhwc(x, update_running=True)
+        ctx.unet, ctx.saved, ctx.need_dx = unet, saved, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx)
+        ctx.saved = None
+        return (None, dx, *[grads[n] for n in ctx.unet.grad_names()])
+
+
+def unet_train(unet, x_nhwc):
+    """Post-fusion U-Net in TRAIN mode (BatchNorm batch statistics, running statistics updated) with gradients for its input
+    and every parameter -- the network as the reference trains it until `it > 100000` (train.py:188-197)."""
+    params = dict(unet.named_parameters())
+    return _UnetTrain.apply(unet, x_nhwc, *[params[n] for n in unet.grad_names()])
 
 
 class _CropResize(torch.autograd.Function):

@@ -65,6 +65,7 @@ struct UnetTensors {
 };
 
 // one thread per packed weight element of a 3x3 layer (layer >= 1): BatchNorm folded in
+// eps < 0: RAW weights (no BatchNorm fold) for the train-mode network, whose BatchNorm uses batch statistics
 __global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
   const int64_t n = (int64_t)(cout / 64) * (cin / 16) * kChunkFloats;
@@ -76,7 +77,7 @@ __global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ pac
   const int cc = (int)(chunk % (cin / 16)), ct = (int)(chunk / (cin / 16));
   const int co = ct * 64 + mb * 16 + (lane & 15);
   const int ci = cc * 16 + 4 * (lane >> 4) + ks;
-  const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  const float scale = eps < 0.f ? 1.f : t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   packed[unet_w_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + tap] * scale;
 }
 
@@ -92,7 +93,7 @@ __global__ void unet_pack_conv_T(UnetTensors t, int layer, float* __restrict__ p
   const int cc = (int)(chunk % (cout / 16)), ct = (int)(chunk / (cout / 16));
   const int ci = ct * 64 + mb * 16 + (lane & 15);          // row of the transposed GEMM = forward input channel
   const int co = cc * 16 + 4 * (lane >> 4) + ks;           // k = forward output channel
-  const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  const float scale = eps < 0.f ? 1.f : t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   packed[unet_wT_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + (8 - tap)] * scale;
 }
 
@@ -101,13 +102,13 @@ __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float 
   const int nt = gridDim.x * blockDim.x;
   for (int i = tid; i < 64 * 27; i += nt) {   // first conv, plain [co][ci*9 + tap], folded
     const int co = i / 27;
-    packed[unet_w_off(0) + i] = t.w[0][i] * (t.gamma[0][co] / sqrtf(t.var[0][co] + eps));
+    packed[unet_w_off(0) + i] = t.w[0][i] * (eps < 0.f ? 1.f : t.gamma[0][co] / sqrtf(t.var[0][co] + eps));
   }
   int64_t off = kUnetBiasOff;
   for (int l = 0; l < 10; ++l) {
     for (int co = tid; co < kUnetConvs[l].cout; co += nt) {
-      const float scale = t.gamma[l][co] / sqrtf(t.var[l][co] + eps);
-      packed[off + co] = t.beta[l][co] - t.mean[l][co] * scale;
+      const float scale = eps < 0.f ? 0.f : t.gamma[l][co] / sqrtf(t.var[l][co] + eps);
+      packed[off + co] = eps < 0.f ? 0.f : t.beta[l][co] - t.mean[l][co] * scale;
     }
     off += kUnetConvs[l].cout;
   }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       const int k = 4 * j + q;
       wa[mb][j] = k < 27 ? w[(16 * mb + px) * 27 + k] : 0.f;
     }
-    bias[mb] = *reinterpret_cast<const f4*>(b + 16 * mb + 4 * q);
+    bias[mb] = b ? *reinterpret_cast<const f4*>(b + 16 * mb + 4 * q) : (f4){0.f, 0.f, 0.f, 0.f};
   }
   const int npix = H * W;
   constexpr int kGroups = 4;   // 16-pixel groups per wave iteration: all 28 gathers are issued before the first MFMA
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         if (pix < npix) {
           f4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r] + bias[mb][r], 0.f);
+          for (int r = 0; r < 4; ++r) o[r] = b ? fmaxf(acc[r] + bias[mb][r], 0.f) : acc[r];   // b == NULL: raw pre-BatchNorm output
           *reinterpret_cast<f4*>(yf + (int64_t)pix * 64 + 16 * mb + 4 * q) = o;
         }
       }
@@ -583,6 +584,358 @@ static UnetSaved unet_saved(float* w, int64_t p1, int64_t p2, int64_t p4) {
   return s;
 }
 
+// ================================================================================================================================
+// TRAIN mode: the post-fusion U-Net as the reference runs it until `it > 100000` (train.py:188-197) -- every
+// BatchNorm2d normalises with the statistics of the batch and updates its running statistics, the weights receive gradients.
+// Forward per 3x3 layer: z = conv(a_prev, W) with the RAW weights (same implicit-GEMM kernel, no bias, no ReLU) -> per-channel
+// mean / biased variance of z over F*H*W (two-stage, fixed order) -> a = relu(gamma (z - mean) / sqrt(var + eps) + beta)
+// (+ MaxPool2d(2)).  Backward per layer: gy = dL/da * (a > 0) (produced by the same kernels as the eval-mode input gradient),
+// s1 = sum gy, s2 = sum gy * zhat -> dz = gamma * invstd * (gy - s1/n - zhat * s2/n), dgamma = s2, dbeta = s1 -> weight
+// gradient dW[co][ci][tap] = sum_pixels dz[co](p) a_prev[ci](p + tap) (conv_wgrad_kernel, MFMA) and dz -> da_prev (transposed
+// chunks).  nn.BatchNorm2d's running update: momentum 0.1, UNBIASED variance.
+namespace {
+constexpr int kStatBlocks = 256;
+
+// partial[blk][0][c] = sum z, partial[blk][1][c] = sum z^2 over the block's pixels; 256 threads = (256 / C) pixel lanes x C
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ z, int C, int64_t n_pix, int64_t per_block,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const int lanes = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block;
+  int64_t p1 = p0 + per_block;
+  if (p1 > n_pix) p1 = n_pix;
+  float s = 0.f, ss = 0.f;
+  for (int64_t p = p0 + pl; p < p1; p += lanes) {
+    const float v = z[p * C + c];
+    s += v;
+    ss = fmaf(v, v, ss);
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < lanes; ++l) {
+      a += red[0][l * C + threadIdx.x];
+      b += red[1][l * C + threadIdx.x];
+    }
+    partial[((int64_t)blockIdx.x * 2) * C + threadIdx.x] = a;
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
+// per channel: batch mean, biased variance -> st[0..C) = scale = gamma * invstd, st[C..2C) = shift = beta - mean * scale,
+// st[2C..3C) = mean, st[3C..4C) = invstd; running statistics updated in place (momentum, unbiased variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float eps, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ st) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < n_blocks; ++b) {
+    s += (double)partial[((int64_t)b * 2) * C + c];
+    ss += (double)partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  const double mean = s / n;
+  double var = ss / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float scale = gamma[c] * invstd;
+  st[c] = scale;
+  st[C + c] = beta[c] - (float)mean * scale;
+  st[2 * C + c] = (float)mean;
+  st[3 * C + c] = invstd;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+  }
+}
+
+// a = relu(z * scale + shift); pool != NULL: also MaxPool2d(2) of a ([F,H/2,W/2,C]), one thread per (pixel, channel quad)
+__global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ z, const float* __restrict__ st, float* __restrict__ a,
+                                                     int C, int64_t n_quads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_quads) return;
+  const int c4 = (int)(i % (C / 4)) * 4;
+  const f4 v = *reinterpret_cast<const f4*>(z + i * 4);
+  const f4 sc = *reinterpret_cast<const f4*>(st + c4), sh = *reinterpret_cast<const f4*>(st + C + c4);
+  f4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = fmaxf(fmaf(v[r], sc[r], sh[r]), 0.f);
+  *reinterpret_cast<f4*>(a + i * 4) = o;
+}
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ a, float* __restrict__ p, int H, int W, int C,
+                                                      int64_t n_quads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_quads) return;
+  const int cq = C / 4, H2 = H / 2, W2 = W / 2;
+  const int c4 = (int)(i % cq) * 4;
+  int64_t q = i / cq;
+  const int x = (int)(q % W2);
+  q /= W2;
+  const int y = (int)(q % H2);
+  const int64_t f = q / H2;
+  const float* s = a + ((f * H + 2 * y) * (int64_t)W + 2 * x) * C + c4;
+  const f4 v0 = *reinterpret_cast<const f4*>(s), v1 = *reinterpret_cast<const f4*>(s + C);
+  const f4 v2 = *reinterpret_cast<const f4*>(s + (int64_t)W * C), v3 = *reinterpret_cast<const f4*>(s + (int64_t)W * C + C);
+  f4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = fmaxf(fmaxf(v0[r], v1[r]), fmaxf(v2[r], v3[r]));
+  *reinterpret_cast<f4*>(p + i * 4) = o;
+}
+
+// out[p][o] = sum_c w[o][c] a[p][c] + b[o]: the 1x1 output convolution on its own (eval mode fuses it into the last conv)
+__global__ __launch_bounds__(256) void outc_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ b,
+                                                  float* __restrict__ out, int64_t n_pix) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pix) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const f4* s = reinterpret_cast<const f4*>(a + p * 64);
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const f4 v = s[k];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[o] = fmaf(w[o * 64 + 4 * k + r], v[r], acc[o]);
+  }
+  out[p * 3] = acc[0] + b[0];
+  out[p * 3 + 1] = acc[1] + b[1];
+  out[p * 3 + 2] = acc[2] + b[2];
+}
+
+// BatchNorm backward, stage 1: partial[blk][0][c] = sum gy, partial[blk][1][c] = sum gy * zhat  (zhat = (z - mean) * invstd)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ z,
+                                                           const float* __restrict__ st, int C, int64_t n_pix, int64_t per_block,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[2][256];
+  const int lanes = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
+  const float mean = st[2 * C + c], invstd = st[3 * C + c];
+  const int64_t p0 = (int64_t)blockIdx.x * per_block;
+  int64_t p1 = p0 + per_block;
+  if (p1 > n_pix) p1 = n_pix;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t p = p0 + pl; p < p1; p += lanes) {
+    const float g = gy[p * C + c];
+    s1 += g;
+    s2 = fmaf(g, (z[p * C + c] - mean) * invstd, s2);
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < lanes; ++l) {
+      a += red[0][l * C + threadIdx.x];
+      b += red[1][l * C + threadIdx.x];
+    }
+    partial[((int64_t)blockIdx.x * 2) * C + threadIdx.x] = a;
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+// stage 2: totals -> dgamma = s2, dbeta = s1, and the two per-channel means the elementwise stage needs (sums[0..C) = s1/n,
+// sums[C..2C) = s2/n)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < n_blocks; ++b) {
+    s1 += (double)partial[((int64_t)b * 2) * C + c];
+    s2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+  sums[c] = (float)(s1 / n);
+  sums[C + c] = (float)(s2 / n);
+}
+// stage 3 (in place): dz = scale * (gy - s1/n - zhat * s2/n)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ gy, const float* __restrict__ z, const float* __restrict__ st,
+                                                          const float* __restrict__ sums, int C, int64_t n_quads) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_quads) return;
+  const int c4 = (int)(i % (C / 4)) * 4;
+  f4 g = *reinterpret_cast<const f4*>(gy + i * 4);
+  const f4 v = *reinterpret_cast<const f4*>(z + i * 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float zhat = (v[r] - st[2 * C + c4 + r]) * st[3 * C + c4 + r];
+    g[r] = st[c4 + r] * (g[r] - sums[c4 + r] - zhat * sums[C + c4 + r]);
+  }
+  *reinterpret_cast<f4*>(gy + i * 4) = g;
+}
+
+// ---- weight gradient of a 3x3 convolution on MFMA: dW[co][ci][t] = sum_{f,y,x} dz[f,y,x,co] * a[f, y + t/3 - 1, x + t%3 - 1, ci].
+// GEMM per tap with K = pixels: A[i = co][k = pixel] = dz, B[k = pixel][j = ci] = the shifted input.  Workgroup = (64 output
+// channels, 16 input channels, all 9 taps), wave w owns output channels 16 w .. 16 w + 15 (9 accumulators of 4 registers).
+// K runs over chunks of 64 consecutive pixels of one image row; a chunk stages dz [64 px][64 co] and the 3 x 66-pixel halo of
+// the input [3][66][16 ci] in LDS.  The chunks are dealt round-robin to gridDim.z workgroups (split K); their partial results
+// are summed in a fixed order by wgrad_reduce3_kernel.
+struct WgradArgs {
+  const float* dz;     // [F,H,W,cout]
+  const float* inA;    // [F,H,W,CA]
+  const float* inB;    // [F,H,W,CB] or null (virtual concat, channels of A first)
+  float* partial;      // [S][cout][cin][9]
+  int CA, CB, cout, H, W, F, chunks_x;
+  int64_t n_chunks;
+};
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_dz[64 * 68];
+  __shared__ __attribute__((aligned(16))) float lds_a[3 * 66 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ct = blockIdx.x, cc = blockIdx.y;
+  const int cin = a.CA + a.CB;
+  const bool fromA = cc * 16 < a.CA;
+  const float* in = fromA ? a.inA : a.inB;
+  const int Cin = fromA ? a.CA : a.CB;
+  const int coff = fromA ? cc * 16 : cc * 16 - a.CA;
+  f4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t ch = blockIdx.z; ch < a.n_chunks; ch += gridDim.z) {
+    const int cx = (int)(ch % a.chunks_x);
+    const int64_t row = ch / a.chunks_x;                  // f * H + y
+    const int y = (int)(row % a.H);
+    const int64_t f = row / a.H;
+    const int x0 = cx * 64;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                         // dz tile: 64 px x 64 co = 1024 quads
+      const int idx = threadIdx.x + 256 * k;
+      const int px = idx >> 4, c4 = idx & 15;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (x0 + px < a.W) v = *reinterpret_cast<const f4*>(a.dz + ((row * a.W) + x0 + px) * a.cout + ct * 64 + 4 * c4);
+      *reinterpret_cast<f4*>(lds_dz + px * 68 + 4 * c4) = v;
+    }
+    for (int idx = threadIdx.x; idx < 3 * 66 * 4; idx += 256) {   // input halo: 3 rows x 66 px x 16 ci = 792 quads
+      const int c4 = idx & 3, xx = (idx >> 2) % 66, dy = idx / (66 * 4);
+      const int gy = y + dy - 1, gx = x0 + xx - 1;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        v = *reinterpret_cast<const f4*>(in + ((f * a.H + gy) * (int64_t)a.W + gx) * Cin + coff + 4 * c4);
+      *reinterpret_cast<f4*>(lds_a + (dy * 66 + xx) * 16 + 4 * c4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float av = lds_dz[(4 * s + q) * 68 + 16 * wave + i16];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = mfma16u(av, lds_a[((t / 3) * 66 + 4 * s + q + t % 3) * 16 + i16], acc[t]);
+    }
+  }
+  // D[row = 4 q + r -> co][col = i16 -> ci]
+  float* p = a.partial + (int64_t)blockIdx.z * a.cout * cin * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[((int64_t)(ct * 64 + 16 * wave + 4 * q + r) * cin + cc * 16 + i16) * 9 + t] = acc[t][r];
+}
+__global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
+                                                           int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < n_parts; ++b) s += partial[(int64_t)b * n + e];
+  out[e] = s;
+}
+// first convolution (3 input channels): partial[blk][co][c*9 + t]; thread = (co, pixel lane of 4)
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                              float* __restrict__ partial, int H, int W, int64_t n_pix,
+                                                              int64_t per_block) {
+  __shared__ float red[4][64 * 27];
+  const int co = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block;
+  int64_t p1 = p0 + per_block;
+  if (p1 > n_pix) p1 = n_pix;
+  for (int64_t p = p0 + pl; p < p1; p += 4) {
+    const int xx = (int)(p % W);
+    const int64_t r = p / W;
+    const int yy = (int)(r % H);
+    const int64_t f = r / H;
+    const float g = dz[p * 64 + co];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int gy = yy + t / 3 - 1, gx = xx + t % 3 - 1;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        const float* s = x + ((f * H + gy) * (int64_t)W + gx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c * 9 + t] = fmaf(g, s[c], acc[c * 9 + t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) red[pl][co * 27 + k] = acc[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 27; i += 256)
+    partial[(int64_t)blockIdx.x * 64 * 27 + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+}
+// d outc.weight [3][64] = sum_p d_out[p][o] a9[p][c]; d outc.bias [3] = sum_p d_out[p][o]: partial[blk][3*64 + 3]
+__global__ __launch_bounds__(256) void outc_wgrad_kernel(const float* __restrict__ d_out, const float* __restrict__ a9,
+                                                        float* __restrict__ partial, int64_t n_pix, int64_t per_block) {
+  __shared__ float red[4][196];
+  const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  float acc[3] = {0.f, 0.f, 0.f}, bs[3] = {0.f, 0.f, 0.f};
+  const int64_t p0 = (int64_t)blockIdx.x * per_block;
+  int64_t p1 = p0 + per_block;
+  if (p1 > n_pix) p1 = n_pix;
+  for (int64_t p = p0 + pl; p < p1; p += 4) {
+    const float v = a9[p * 64 + c];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float d = d_out[p * 3 + o];
+      acc[o] = fmaf(d, v, acc[o]);
+      bs[o] += d;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) red[pl][o * 64 + c] = acc[o];
+  if (c < 3) red[pl][192 + c] = bs[c];
+  __syncthreads();
+  if (threadIdx.x < 195) partial[(int64_t)blockIdx.x * 195 + threadIdx.x] =
+      ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+struct TrainBufs {
+  float *z[10], *act[10];     // pre-BatchNorm outputs and post-ReLU activations of the ten convolutions
+  float *p1, *p2, *u3, *uu;   // pooled / up-sampled inputs
+  float* st;                  // [10][4][128]: scale, shift, mean, invstd
+};
+static const int kLvl[10] = {0, 0, 1, 1, 2, 2, 1, 1, 0, 0};   // resolution level of each convolution's output
+static TrainBufs train_bufs(float* w, int64_t p1, int64_t p2, int64_t p4) {
+  const int64_t pl[3] = {p1, p2, p4};
+  TrainBufs b;
+  for (int l = 0; l < 10; ++l) {
+    b.z[l] = w;
+    w += pl[kLvl[l]] * kUnetConvs[l].cout;
+    b.act[l] = w;
+    w += pl[kLvl[l]] * kUnetConvs[l].cout;
+  }
+  b.p1 = w;  w += p2 * 64;
+  b.p2 = w;  w += p4 * 128;
+  b.u3 = w;  w += p2 * 128;
+  b.uu = w;  w += p1 * 64;
+  b.st = w;
+  return b;
+}
+static int64_t train_saved_floats(int64_t p1, int64_t p2, int64_t p4) {
+  const int64_t pl[3] = {p1, p2, p4};
+  int64_t n = 0;
+  for (int l = 0; l < 10; ++l) n += 2 * pl[kLvl[l]] * kUnetConvs[l].cout;
+  return n + p2 * 64 + p4 * 128 + p2 * 128 + p1 * 64 + 10 * 512;
+}
+// offsets of the gradients in the flat output of s2l_unet_train_backward: per layer conv.weight, bn.weight, bn.bias; then
+// outc.conv.weight [3,64], outc.conv.bias [3]
+static int64_t grad_off(int layer) {
+  int64_t off = 0;
+  for (int l = 0; l < layer; ++l) off += (int64_t)kUnetConvs[l].cout * kUnetConvs[l].cin * 9 + 2 * kUnetConvs[l].cout;
+  return off;
+}
+}  // namespace
+
 }  // namespace s2l
 
 using namespace s2l;
@@ -736,5 +1089,206 @@ extern "C" int s2l_unet_backward(const float* packed, const float* saved, const 
   if ((rc = launch_conv_dgrad(zA, packed, 1, zB, s.a0, H, W, F, st))) return rc;                                          // z0
   hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
                      packed + unet_w_off(0), d_x, H, W);
+  return (int)hipGetLastError();
+}
+
+// ---- TRAIN mode entry points ------------------------------------------------------------------------------------------------
+static int unet_table(const float* const* th, UnetTensors& t) {
+  if (!th) return S2L_E_NULL;
+  for (int l = 0; l < 10; ++l) {
+    for (int k = 0; k < 5; ++k)
+      if (!th[l * 5 + k]) return S2L_E_NULL;
+    t.w[l] = th[l * 5]; t.gamma[l] = th[l * 5 + 1]; t.beta[l] = th[l * 5 + 2]; t.mean[l] = th[l * 5 + 3]; t.var[l] = th[l * 5 + 4];
+  }
+  if (!th[50] || !th[51]) return S2L_E_NULL;
+  t.outw = th[50]; t.outb = th[51];
+  return 0;
+}
+
+// RAW (un-folded) weights in the chunk layout, forward and transposed: what the train-mode network multiplies with.  Same table
+// and blob size as s2l_unet_pack; re-run after every optimizer step.
+extern "C" int s2l_unet_pack_raw(const float* const* tensors_host, float* packed, s2l_stream_t stream) {
+  if (!packed) return S2L_E_NULL;
+  UnetTensors t;
+  const int rc = unet_table(tensors_host, t);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 1; l < 10; ++l) {
+    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
+    hipLaunchKernelGGL(unet_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, -1.f);
+    hipLaunchKernelGGL(unet_pack_conv_T, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, -1.f);
+  }
+  hipLaunchKernelGGL(unet_pack_misc, dim3(16), dim3(256), 0, st, t, packed, -1.f);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t s2l_unet_train_saved_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 0) return 0;
+  return train_saved_floats((int64_t)height * width * n_frames, (int64_t)(height / 2) * (width / 2) * n_frames,
+                            (int64_t)(height / 4) * (width / 4) * n_frames);
+}
+extern "C" int64_t s2l_unet_train_work_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 0) return 0;
+  const int64_t p1 = (int64_t)height * width, p2 = (int64_t)(height / 2) * (width / 2), p4 = (int64_t)(height / 4) * (width / 4);
+  // gradient scratch of the eval-mode backward | split-K partials of the weight gradients (<= 32 x 256*128*9) | reduction partials
+  return n_frames * (p1 * 256 + p2 * 768 + p4 * 384) + 32 * (int64_t)256 * 128 * 9 + kStatBlocks * 2 * 128 + 4096;
+}
+extern "C" int64_t s2l_unet_grad_floats(void) { return grad_off(10) + 192 + 3; }
+
+static void run_stats(const float* z, int C, int64_t n_pix, float* partial, hipStream_t st, int* n_blocks) {
+  const int64_t per = (n_pix + kStatBlocks - 1) / kStatBlocks;
+  *n_blocks = (int)((n_pix + per - 1) / per);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(*n_blocks), dim3(256), 0, st, z, C, n_pix, per, partial);
+}
+
+// x [F,H,W,3] -> out [F,H,W,3] with batch statistics; running_mean / running_var of the ten BatchNorm layers (entries 3 and 4 of
+// each layer's five pointers in `tensors_host`, the s2l_unet_pack table) are UPDATED IN PLACE when update_running != 0.
+// saved: s2l_unet_train_saved_floats floats (kept for s2l_unet_train_backward); scratch: at least 256*2*128 floats.
+extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* const* tensors_host, float bn_eps, float momentum,
+                                      int update_running, const float* x, float* saved, float* scratch, float* out, int height,
+                                      int width, int64_t n_frames, s2l_stream_t stream) {
+  if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
+  if (!packed_raw || !x || !saved || !scratch || !out) return S2L_E_NULL;
+  if (misaligned16(packed_raw) || misaligned16(saved)) return S2L_E_ALIGN;
+  UnetTensors t;
+  int rc = unet_table(tensors_host, t);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+  const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
+  const int64_t pl[3] = {p1, p2, p4};
+  const int hh[3] = {H, H2, H4}, ww[3] = {W, W2, W4};
+  const TrainBufs b = train_bufs(saved, p1, p2, p4);
+  auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  // input of each convolution: (A, CA, B, CB)
+  const float* inA[10] = {x, b.act[0], b.p1, b.act[2], b.p2, b.act[4], b.act[3], b.act[6], b.act[1], b.act[8]};
+  const float* inB[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, b.u3, nullptr, b.uu, nullptr};
+  const int cA[10] = {3, 64, 64, 128, 128, 128, 128, 128, 64, 64}, cB[10] = {0, 0, 0, 0, 0, 0, 128, 0, 64, 0};
+  for (int l = 0; l < 10; ++l) {
+    const int lv = kLvl[l], C = kUnetConvs[l].cout;
+    if (l == 0) {
+      hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
+                         packed_raw + unet_w_off(0), (const float*)nullptr, b.z[0], H, W);
+    } else {
+      ConvArgs a;
+      a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
+      a.w = packed_raw + unet_w_off(l); a.bias = nullptr; a.out = b.z[l]; a.out3 = nullptr; a.pool = nullptr; a.gate = nullptr; a.relu = 0;
+      a.outw = a.outb = nullptr; a.H = hh[lv]; a.W = ww[lv];
+      a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16; a.n_ct = C / 64;
+      hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)(F * a.n_ct)), dim3(256), 0, st, a);
+    }
+    int nb = 0;
+    run_stats(b.z[l], C, pl[lv], scratch, st, &nb);
+    float* stl = b.st + l * 512;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, scratch, nb, C, (double)pl[lv], bn_eps, momentum, t.gamma[l],
+                       t.beta[l], update_running ? const_cast<float*>(t.mean[l]) : nullptr,
+                       update_running ? const_cast<float*>(t.var[l]) : nullptr, stl);
+    hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4);
+    if (l == 1) hipLaunchKernelGGL(maxpool2_kernel, blocks(p2 * 16), dim3(256), 0, st, b.act[1], b.p1, H, W, 64, p2 * 16);
+    if (l == 3) hipLaunchKernelGGL(maxpool2_kernel, blocks(p4 * 32), dim3(256), 0, st, b.act[3], b.p2, H2, W2, 128, p4 * 32);
+    if (l == 5) hipLaunchKernelGGL(upsample2_kernel, blocks(p2 * 32), dim3(256), 0, st, b.act[5], b.u3, H4, W4, 128, H2, W2, p2 * 32);
+    if (l == 7) hipLaunchKernelGGL(upsample2_kernel, blocks(p1 * 16), dim3(256), 0, st, b.act[7], b.uu, H2, W2, 64, H, W, p1 * 16);
+  }
+  hipLaunchKernelGGL(outc_kernel, blocks(p1), dim3(256), 0, st, b.act[9], t.outw, t.outb, out, p1);
+  return (int)hipGetLastError();
+}
+
+// d_out [F,H,W,3] -> d_x [F,H,W,3] (may be NULL) and grads (s2l_unet_grad_floats floats: per layer conv.weight [cout,cin,3,3],
+// bn.weight [cout], bn.bias [cout] in execution order, then outc.conv.weight [3,64], outc.conv.bias [3]).
+extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors_host, const float* x, const float* saved,
+                                       const float* d_out, float* work, float* d_x, float* grads, int height, int width,
+                                       int64_t n_frames, s2l_stream_t stream) {
+  if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
+  if (!packed_raw || !x || !saved || !d_out || !work || !grads) return S2L_E_NULL;
+  if (misaligned16(packed_raw) || misaligned16(saved) || misaligned16(work)) return S2L_E_ALIGN;
+  UnetTensors t;
+  int rc = unet_table(tensors_host, t);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+  const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
+  const int64_t pl[3] = {p1, p2, p4};
+  const int hh[3] = {H, H2, H4}, ww[3] = {W, W2, W4};
+  const TrainBufs b = train_bufs(const_cast<float*>(saved), p1, p2, p4);
+  float* zA = work;              float* zB = zA + p1 * 64;      float* gcat8 = zB + p1 * 64;                      // @H
+  float* z7 = gcat8 + p1 * 128;  float* z6 = z7 + p2 * 64;      float* gcat6 = z6 + p2 * 128;                     // @H/2
+  float* z3 = gcat6 + p2 * 256;  float* z2 = z3 + p2 * 128;     float* gp1 = z2 + p2 * 128;
+  float* z5 = gp1 + p2 * 64;     float* z4 = z5 + p4 * 128;     float* gp2 = z4 + p4 * 128;                       // @H/4
+  float* wpart = gp2 + p4 * 128;                                 // split-K partials of the weight gradients
+  float* rpart = wpart + 32 * (int64_t)256 * 128 * 9;            // reduction partials + per-channel means
+  float* sums = rpart + kStatBlocks * 2 * 128;
+  auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  const float* inA[10] = {x, b.act[0], b.p1, b.act[2], b.p2, b.act[4], b.act[3], b.act[6], b.act[1], b.act[8]};
+  const float* inB[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, b.u3, nullptr, b.uu, nullptr};
+  const int cA[10] = {3, 64, 64, 128, 128, 128, 128, 128, 64, 64}, cB[10] = {0, 0, 0, 0, 0, 0, 128, 0, 64, 0};
+
+  // BatchNorm backward (in place: gy -> dz) + the layer's weight gradient
+  auto layer_grads = [&](int l, float* gy) {
+    const int lv = kLvl[l], C = kUnetConvs[l].cout, cin = kUnetConvs[l].cin;
+    const int64_t n = pl[lv];
+    const int64_t per = (n + kStatBlocks - 1) / kStatBlocks;
+    const int nb = (int)((n + per - 1) / per);
+    const float* stl = b.st + l * 512;
+    float* g = grads + grad_off(l);
+    float* dgamma = g + (int64_t)C * cin * 9;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(n * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, n * C / 4);
+    if (l == 0) {
+      const int64_t perw = (p1 + 255) / 256;
+      const int nbw = (int)((p1 + perw - 1) / perw);
+      hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(nbw), dim3(256), 0, st, gy, x, wpart, H, W, p1, perw);
+      hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(64 * 27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
+    } else {
+      WgradArgs a;
+      a.dz = gy; a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
+      a.H = hh[lv]; a.W = ww[lv]; a.F = (int)F; a.chunks_x = (a.W + 63) / 64;
+      a.n_chunks = F * a.H * a.chunks_x;
+      a.partial = wpart;
+      const int tiles = (C / 64) * (cin / 16);
+      int S = (int)((2048 + tiles - 1) / tiles);
+      if (S > 32) S = 32;
+      if (S > a.n_chunks) S = (int)a.n_chunks;
+      hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
+      const int64_t ne = (int64_t)C * cin * 9;
+      hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(ne), dim3(256), 0, st, wpart, g, S, ne);
+    }
+  };
+
+  // output convolution: gy9 = outc^T d_out * (a9 > 0); d outc.weight / bias
+  {
+    const int64_t perw = (p1 + 255) / 256;
+    const int nbw = (int)((p1 + perw - 1) / perw);
+    hipLaunchKernelGGL(outc_wgrad_kernel, dim3(nbw), dim3(256), 0, st, d_out, b.act[9], wpart, p1, perw);
+    hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(195), dim3(256), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);
+  }
+  hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, t.outw, b.act[9], zA, p1 * 16);
+  layer_grads(9, zA);
+  if ((rc = launch_conv_dgrad(zA, packed_raw, 9, zB, b.act[8], H, W, F, st))) return rc;
+  layer_grads(8, zB);
+  if ((rc = launch_conv_dgrad(zB, packed_raw, 8, gcat8, nullptr, H, W, F, st))) return rc;                                // [g_x1 | g_uu]
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64, H, W, p2 * 16);
+  layer_grads(7, z7);
+  if ((rc = launch_conv_dgrad(z7, packed_raw, 7, z6, b.act[6], H2, W2, F, st))) return rc;
+  layer_grads(6, z6);
+  if ((rc = launch_conv_dgrad(z6, packed_raw, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                              // [g_x2 | g_u3]
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, b.act[5], z5, H4, W4, 128, H2, W2,
+                     p4 * 32);
+  layer_grads(5, z5);
+  if ((rc = launch_conv_dgrad(z5, packed_raw, 5, z4, b.act[4], H4, W4, F, st))) return rc;
+  layer_grads(4, z4);
+  if ((rc = launch_conv_dgrad(z4, packed_raw, 4, gp2, nullptr, H4, W4, F, st))) return rc;
+  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, b.act[3], b.p2, z3, H2, W2, 128, p2 * 32);
+  layer_grads(3, z3);
+  if ((rc = launch_conv_dgrad(z3, packed_raw, 3, z2, b.act[2], H2, W2, F, st))) return rc;
+  layer_grads(2, z2);
+  if ((rc = launch_conv_dgrad(z2, packed_raw, 2, gp1, nullptr, H2, W2, F, st))) return rc;
+  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p1 * 16), dim3(256), 0, st, gcat8, 128, gp1, b.act[1], b.p1, zA, H, W, 64, p1 * 16);
+  layer_grads(1, zA);
+  if ((rc = launch_conv_dgrad(zA, packed_raw, 1, zB, b.act[0], H, W, F, st))) return rc;
+  layer_grads(0, zB);
+  if (d_x)
+    hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
+                       packed_raw + unet_w_off(0), d_x, H, W);
   return (int)hipGetLastError();
 }

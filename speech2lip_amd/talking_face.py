@@ -17,7 +17,7 @@ loop of inference.py:140-159 (audio encoder once per frame, one fused launch per
 
 The post-fusion U-Net (`post_fusion_unet`) is `speech2lip_amd.unet.SimpleUnetLight`
 (eval mode); `canonical_depth_head` (tf_nerf.py:174-195) is the parameter the canonical-depth photometric loss trains
-(speech2lip_amd.geometry.depth_photo_loss).  Not in this path: training of the U-Net (BatchNorm batch statistics).
+(speech2lip_amd.geometry.depth_photo_loss).
 """
 from __future__ import annotations
 
@@ -288,8 +288,9 @@ class TalkingFace(nn.Module):
         """Paste the lip into the canonical face, warp by `coord`, blend with the observed frame.
         Reference: tf_nerf.py:287-304 -> post_fusion2_onlylip_light :320-389.
         Returns (rgb_recon, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; rgb_recon is the post-fusion U-Net
-        output (csrc/unet.hip) when `post_fusion_unet` is in eval mode (inference, and training once the net is fixed,
-        train.py:188-197), None while it is in train mode or when model.use_post_fusion is off.
+        output (csrc/unet.hip): with the running statistics when `post_fusion_unet` is in eval mode (inference, and training
+        once the net is fixed, train.py:188-197), with batch statistics (and parameter gradients) while it is in train mode;
+        None when model.use_post_fusion is off.
         use_post_fusion_blackaug=True is the training call (training.py:436/445): with probability 1/2 black holes are
         punched (tf_nerf.py:371-384).  With autograd recording and a lip that requires grad, the outputs are
         differentiable w.r.t. the lip (speech2lip_amd.autograd)."""
@@ -299,17 +300,27 @@ class TalkingFace(nn.Module):
         if use_post_fusion_blackaug and random.random() > 0.5:          # the coin of tf_nerf.py:371
             holes = self.draw_hole_noise(rgb_gt)
         unet = getattr(self, "post_fusion_unet", None)
-        # rgb_recon = post_fusion_unet(rgb_merged_new) (tf_nerf.py:387).  The HIP U-Net runs the network the way the reference
-        # runs it once it is fixed (`post_fusion_unet.eval()`, train.py:188-197): whenever the SUB-module is in eval mode
-        run_unet = unet is not None and not unet.training
-        if torch.is_grad_enabled() and isinstance(rgb_lip_warped, torch.Tensor) and rgb_lip_warped.requires_grad:
-            from .autograd import composite as composite_with_graph, unet_eval
+        # rgb_recon = post_fusion_unet(rgb_merged_new) (tf_nerf.py:387): the sub-module's own mode decides -- train mode
+        # (BatchNorm batch statistics, parameter gradients) until the reference fixes it, eval mode afterwards (train.py:188-197)
+        graph = torch.is_grad_enabled() and isinstance(rgb_lip_warped, torch.Tensor) and rgb_lip_warped.requires_grad
+        if graph:
+            from .autograd import composite as composite_with_graph
             new, can = composite_with_graph(self, rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
                                             lip_lefttop_y, coord, holes)
-            return (unet_eval(unet, new) if run_unet else None), new, can
-        new, can = self.composite_clip(rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
-                                       lip_lefttop_y, coord, want_canonical=True, hole_noise=holes)
-        return (unet.forward_nhwc(new) if run_unet else None), new, can
+        else:
+            new, can = self.composite_clip(rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
+                                           lip_lefttop_y, coord, want_canonical=True, hole_noise=holes)
+        if unet is None:
+            return None, new, can
+        if unet.training:
+            if torch.is_grad_enabled():
+                from .autograd import unet_train
+                return unet_train(unet, new), new, can
+            return unet.forward_train_nhwc(new, update_running=True)[0], new, can
+        if graph:
+            from .autograd import unet_eval
+            return unet_eval(unet, new), new, can
+        return unet.forward_nhwc(new), new, can
 
     @staticmethod
     def draw_hole_noise(rgb_gt):

@@ -84,7 +84,8 @@ class SimpleUnetLight(nn.Module):
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         if self.training:
-            raise NotImplementedError("the HIP U-Net is eval-mode only (BatchNorm uses its running statistics)")
+            raise NotImplementedError("forward_nhwc is the eval-mode network (running statistics); in train mode call "
+                                      "forward_train_nhwc / the module itself")
         x = x.detach().to(torch.float32).contiguous()
         F_, H, W, C = x.shape
         if C != 3 or H < 4 or W < 4:
@@ -104,6 +105,82 @@ class SimpleUnetLight(nn.Module):
                                                 H, W, n, st), "s2l_unet_forward")
         return out
 
+    # ------------------------------------------------------------------ train mode (BatchNorm batch statistics)
+    def _table(self, tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def grad_names(self):
+        """state-dict names of the tensors whose gradients s2l_unet_train_backward returns, in its order."""
+        names = []
+        for name, _, _ in UNET_CONVS:
+            head, idx = name.rsplit(".", 1)
+            bn = f"{head}.{int(idx) + 1}"
+            names += [f"{name}.weight", f"{bn}.weight", f"{bn}.bias"]
+        return names + ["outc.conv.weight", "outc.conv.bias"]
+
+    def forward_train_nhwc(self, x: torch.Tensor, update_running: bool = True):
+        """The network in TRAIN mode (the reference until it > 100000, train.py:188-197): x [F,H,W,3] -> (out, ctx).  BatchNorm
+        uses the statistics of the batch; with update_running the running_mean / running_var buffers are updated in place
+        and num_batches_tracked is incremented, as nn.BatchNorm2d does.  ctx feeds backward_train."""
+        lib = _abi.load()
+        if x.device.type != "cuda":
+            raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
+        tensors = self._tensors()
+        dev = tensors[0].device
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise _abi.S2LError("U-Net parameters and buffers must be contiguous fp32 tensors on one GPU")
+        x = x.detach().to(torch.float32).contiguous()
+        F_, H, W, C = x.shape
+        if C != 3 or H < 4 or W < 4:
+            raise ValueError(f"U-Net input must be [F,H>=4,W>=4,3], got {tuple(x.shape)}")
+        table = self._table(tensors)
+        raw = torch.empty(int(lib.s2l_unet_packed_floats()), dtype=torch.float32, device=dev)
+        out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
+        saved = torch.empty(int(lib.s2l_unet_train_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
+        scratch = torch.empty(65536, dtype=torch.float32, device=dev)
+        bn = self.inc.double_conv[1]
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _abi.check(lib.s2l_unet_pack_raw(table, p(raw), st), "s2l_unet_pack_raw")
+            _abi.check(lib.s2l_unet_train_forward(p(raw), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                                  1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                       "s2l_unet_train_forward")
+        if update_running:
+            for mod in self.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.num_batches_tracked += 1
+            self._packed = None        # the folded eval-mode blob is stale now (the kernel rewrote the running statistics)
+        return out, (raw, x, saved, (F_, H, W))
+
+    def backward_train(self, ctx, d_out: torch.Tensor, want_input_grad: bool = True):
+        """d loss / d out [F,H,W,3] -> (d loss / d x or None, {state-dict name: gradient}) for every conv / BatchNorm / outc
+        parameter (what loss.backward() leaves in .grad while the post-fusion net trains)."""
+        lib = _abi.load()
+        raw, x, saved, (F_, H, W) = ctx
+        dev = x.device
+        d = d_out.detach().to(torch.float32).contiguous()
+        if d.shape != (F_, H, W, 3) or d.device != dev:
+            raise ValueError(f"d_out must be [{F_},{H},{W},3] on {dev}")
+        tensors = self._tensors()
+        table = self._table(tensors)
+        dx = torch.empty_like(d) if want_input_grad else None
+        flat = torch.empty(int(lib.s2l_unet_grad_floats()), dtype=torch.float32, device=dev)
+        work = torch.empty(int(lib.s2l_unet_train_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
+        p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_unet_train_backward(p(raw), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_,
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_train_backward")
+        params = dict(self.named_parameters())
+        grads, off = {}, 0
+        for name in self.grad_names():
+            n = params[name].numel()
+            grads[name] = flat[off:off + n].reshape(params[name].shape)
+            off += n
+        return dx, grads
+
     def forward_saved_nhwc(self, x: torch.Tensor):
         """Training-time forward of the frozen eval-mode network: x [F,H,W,3] -> (out [F,H,W,3], saved), where `saved` holds
         every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F."""
@@ -112,7 +189,7 @@ class SimpleUnetLight(nn.Module):
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         if self.training:
-            raise NotImplementedError("the HIP U-Net is eval-mode only (BatchNorm uses its running statistics)")
+            raise NotImplementedError("forward_saved_nhwc is the frozen eval-mode network; in train mode use forward_train_nhwc")
         x = x.detach().to(torch.float32).contiguous()
         F_, H, W, C = x.shape
         if C != 3 or H < 4 or W < 4:
@@ -144,6 +221,9 @@ class SimpleUnetLight(nn.Module):
     def forward(self, x, x_level1=None, x_level2=None):
         """NCHW in, NCHW out, as the reference's forward (SimpleUnetLight.py:99-111).  With autograd recording and an input
         that requires grad, the input gradient is available to loss.backward() (speech2lip_amd.autograd)."""
+        if self.training:        # BatchNorm batch statistics + gradients for every parameter
+            from .autograd import unet_train
+            return unet_train(self, x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
             from .autograd import unet_eval
             return unet_eval(self, x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

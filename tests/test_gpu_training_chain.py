@@ -404,3 +404,84 @@ def test_depth_photo_loss_golden_and_oracle(golden, dev):
         assert abs(float(loss) - float(l_o)) <= 1e-5 * max(1.0, float(l_o)), (float(loss), float(l_o))
         e = (dd.cpu() - d_o.grad).abs() / float(d_o.grad.abs().max())
         assert float(e.max()) <= 5e-2 and float((e > 1e-3).float().mean()) <= 1e-2, (float(e.max()), float((e > 1e-3).float().mean()))
+
+
+# ------------------------------------------------------------------------------------------------ U-Net, train mode
+def _check_unet_train_grads(grads, g):
+    for key in g:
+        if key.startswith("g_"):
+            got = grads[key[2:]].cpu()
+            sub = got if got.numel() <= 4096 else got.reshape(-1)[::13]
+            scale = float(np.abs(g[key]).max())
+            e = (sub.reshape(g[key].shape) - T(g[key])).abs() / scale
+            assert float(e.max()) <= 5e-3 and float((e > 5e-4).float().mean()) <= 0.02, (key, float(e.max()), float((e > 5e-4).float().mean()))
+            assert abs(float(got.abs().double().sum()) - float(g["n_" + key[2:]])) <= 2e-3 * float(g["n_" + key[2:]]), key
+
+
+def test_unet_train_mode_golden(golden, dev):
+    """SimpleUnetLight in TRAIN mode (BatchNorm batch statistics, the reference until it > 100000): forward, input gradient, the
+    gradients of the conv / BatchNorm / outc parameters and the running-statistics update against the reference module's own
+    forward + backward (G13)."""
+    from tests.test_gpu_parity import _unet
+    g = golden("g13_unet_train.npz")
+    u = _unet(dev).train()
+    out, ctx = u.forward_train_nhwc(T(g["x"]).to(dev))
+    close(out, g["y"], 5e-6, 5e-5)
+    dx, grads = u.backward_train(ctx, T(g["d_out"]).to(dev))
+    assert relerr(dx, g["d_x"]) <= 2e-3
+    _check_unet_train_grads(grads, g)
+    sd = u.state_dict()
+    for key in g:
+        if key.startswith("s_"):
+            close(sd[key[2:]], g[key], 1e-6, 1e-5)
+    assert int(sd["inc.double_conv.1.num_batches_tracked"]) == int(g["tracked"])
+    # the eval-mode network now sees the updated running statistics (the folded pack is rebuilt)
+    u.eval()
+    usd = {k[len("post_fusion_unet."):]: v for k, v in O.to_sd(W.make_unet_state_dict(0)).items()}
+    usd.update({k: v.cpu() for k, v in sd.items() if "running" in k})
+    with torch.no_grad():
+        ref_eval = O.unet_forward({"post_fusion_unet." + k: v for k, v in usd.items()}, T(g["x"]))
+    close(u.forward_nhwc(T(g["x"]).to(dev)), ref_eval, 5e-6, 5e-5)
+
+
+def test_unet_train_mode_through_the_module_and_autograd(golden, dev):
+    """`unet.train(); y = unet(x_nchw); loss.backward()` -- what the reference's training loop does (tf_nerf.py:387 inside
+    train_stage1) -- fills .grad of every U-Net parameter and of the input with the G13 values."""
+    from tests.test_gpu_parity import _unet
+    g = golden("g13_unet_train.npz")
+    u = _unet(dev).train()
+    x = T(g["x"]).to(dev).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = u(x)
+    (y.permute(0, 2, 3, 1) * T(g["d_out"]).to(dev)).sum().backward()
+    close(y.permute(0, 2, 3, 1), g["y"], 5e-6, 5e-5)
+    assert relerr(x.grad.permute(0, 2, 3, 1), g["d_x"]) <= 2e-3
+    _check_unet_train_grads({k: p.grad for k, p in u.named_parameters()}, g)
+
+
+@pytest.mark.parametrize("F,fh,fw", [(1, 500, 500), (3, 70, 90)])
+def test_unet_train_mode_vs_oracle_sizes(dev, F, fh, fw):
+    """The reference's 500x500 frame and a multi-frame batch with partial tiles / odd quarter sizes, against autograd through the
+    oracle.  Bars as for the eval-mode input gradient: a ReLU or max-pool tie within fp32 rounding may resolve differently."""
+    from tests.test_gpu_parity import _unet
+    u = _unet(dev).train()
+    usd = {k: v.clone() for k, v in O.to_sd(W.make_unet_state_dict(0)).items()}
+    for v in usd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    rng = np.random.default_rng(fh + fw)
+    x = T(rng.random((F, fh, fw, 3), dtype=np.float32))
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32))
+    x_o = x.clone().requires_grad_(True)
+    y_o = O.unet_forward(usd, x_o, training=True)
+    (y_o * d).sum().backward()
+    out, ctx = u.forward_train_nhwc(x.to(dev), update_running=False)
+    close(out, y_o.detach(), 1e-5, 2e-4)
+    dx, grads = u.backward_train(ctx, d.to(dev))
+    scale = float(x_o.grad.abs().max())
+    e = (dx.cpu() - x_o.grad).abs() / scale
+    assert float((e > 1e-3).float().mean()) <= 0.06 and O.rmse(dx.cpu(), x_o.grad) <= 2e-3 * scale, (float(e.max()), float((e > 1e-3).float().mean()))
+    for name, gk in grads.items():
+        ref = usd["post_fusion_unet." + name].grad
+        a, b = gk.cpu().double().flatten(), ref.double().flatten()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel <= 5e-3, (name, rel)

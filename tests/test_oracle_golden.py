@@ -262,3 +262,29 @@ def test_g12_canonical_depth_photo_loss(golden):
     loss.backward()
     assert abs(float(loss) - float(g["loss"])) <= 1e-6
     assert _maxerr(d.grad, g["d_depth"]) <= 1e-3 * float(np.abs(g["d_depth"]).max())
+
+
+def test_g13_unet_train_mode(golden):
+    """SimpleUnetLight in TRAIN mode (BatchNorm batch statistics): output, input gradient, parameter gradients and the running
+    statistics after the step, against the reference module's own forward / backward (tools/make_goldens.py G13)."""
+    g = golden("g13_unet_train.npz")
+    usd = {k: T(v).clone() for k, v in W.make_unet_state_dict(0).items()}
+    for v in usd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    x = T(g["x"]).clone().requires_grad_(True)
+    stats = {}
+    y = O.unet_forward(usd, x, training=True, new_stats=stats)
+    (y * T(g["d_out"])).sum().backward()
+    assert _maxerr(y.detach(), g["y"]) <= 3e-5
+    assert _maxerr(x.grad, g["d_x"]) <= 1e-3 * float(np.abs(g["d_x"]).max())
+    pre = "post_fusion_unet."
+    for key in g:
+        if key.startswith("g_"):
+            got = usd[pre + key[2:]].grad
+            got = got if got.numel() <= 4096 else got.reshape(-1)[::13]
+            assert _maxerr(got.reshape(g[key].shape), g[key]) <= 1e-3 * float(np.abs(g[key]).max()), key
+            assert abs(float(usd[pre + key[2:]].grad.abs().double().sum()) - float(g["n_" + key[2:]])) <= 1e-3 * float(g["n_" + key[2:]])
+        if key.startswith("s_"):
+            assert _maxerr(stats[pre + key[2:]], g[key]) <= 1e-5, key
+    assert int(g["tracked"]) == int(usd[pre + "inc.double_conv.1.num_batches_tracked"]) + 1

@@ -449,11 +449,53 @@ def main():
                         target=tgt.numpy(), mask=msk.numpy(), focal=np.array(focal, np.float32), loss=np.array(float(lossd["loss"])),
                         d_depth=depth_p.grad.numpy())
 
+    # ---- G13: the post-fusion U-Net in TRAIN mode (BatchNorm batch statistics), as the reference runs it until it > 100000
+    # (train.py:188-197): the reference module's own forward, loss.backward() and running-statistics update
+    usd = W.make_unet_state_dict(seed=0)
+    model, cfg = ref_model(ref_config, TalkingFace, 8, 8)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in usd.items()}, strict=False)
+    unet = model.post_fusion_unet
+    unet.train()
+    xin = torch.from_numpy(rng2.random((2, 20, 24, 3), dtype=np.float32)).requires_grad_(True)
+    dout = torch.from_numpy(rng2.standard_normal((2, 20, 24, 3)).astype(np.float32))
+    y_ref = unet(xin.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    (y_ref * dout).sum().backward()
+    usd_t = {k: torch.from_numpy(v).clone() for k, v in usd.items()}
+    for k, v in usd_t.items():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    x_o = xin.detach().clone().requires_grad_(True)
+    stats_o = {}
+    y_o = O.unet_forward(usd_t, x_o, training=True, new_stats=stats_o)
+    (y_o * dout).sum().backward()
+    report["unet_train_forward"] = maxerr(y_ref.detach(), y_o.detach())
+    report["unet_train_dx_rel"] = maxerr(xin.grad, x_o.grad) / float(xin.grad.abs().max())
+    pre = "post_fusion_unet."
+    refp = dict(unet.named_parameters())
+    worst = 0.0
+    for k, v in refp.items():
+        worst = max(worst, maxerr(v.grad, usd_t[pre + k].grad) / (float(v.grad.abs().max()) + 1e-12))
+    report["unet_train_grads_rel"] = worst
+    refb = dict(unet.named_buffers())
+    report["unet_train_running_stats"] = max(maxerr(refb[k], stats_o[pre + k]) for k in refb if "num_batches" not in k)
+    keep = ["inc.double_conv.0.weight", "inc.double_conv.1.weight", "inc.double_conv.1.bias", "down2.maxpool_conv.1.double_conv.3.weight",
+            "up1.conv.double_conv.0.weight", "up2.conv.double_conv.4.weight", "up2.conv.double_conv.4.bias", "outc.conv.weight", "outc.conv.bias"]
+    np.savez_compressed(os.path.join(GOLD, "g13_unet_train.npz"), x=xin.detach().numpy(), d_out=dout.numpy(), y=y_ref.detach().numpy(),
+                        d_x=xin.grad.numpy(),
+                        # big gradient tensors travel as every 13th element + their L1 norm
+                        **{"g_" + k: (refp[k].grad.numpy() if refp[k].grad.numel() <= 4096 else refp[k].grad.reshape(-1)[::13].numpy().copy())
+                           for k in keep},
+                        **{"n_" + k: np.array(float(refp[k].grad.abs().double().sum())) for k in keep},
+                        **{"s_" + k: refb[k].numpy() for k in ("inc.double_conv.1.running_mean", "inc.double_conv.1.running_var",
+                                                               "up1.conv.double_conv.4.running_mean", "up1.conv.double_conv.4.running_var")},
+                        tracked=refb["inc.double_conv.1.num_batches_tracked"].numpy())
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
     # sits ~4e-6 from the fp64 evaluation of the same formula), and inverse_warping multiplies that by the image gradient.
-    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3}
+    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3, "unet_train_forward": 3e-5, "unet_train_dx_rel": 1e-3,
+              "unet_train_grads_rel": 1e-3, "unet_train_running_stats": 1e-5}
     limits.update({k: 1e-5 for k in report if k.startswith("warp_grid")})
     bad = []
     for k, v in report.items():
