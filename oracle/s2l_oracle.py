@@ -459,7 +459,7 @@ def sync_chain_window(sd: SD, unet_sd: SD, coords, audio_window, index: int, tot
 
 def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio, data: dict, eps_u01, hole_noise, height: int,
                      width: int, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, w_syncloss: float = 0.01,
-                     pad_mode: int = PAD_MODE_MAY, pad_div: int = 5) -> dict:
+                     pad_mode: int = PAD_MODE_MAY, pad_div: int = 5, unet_training: bool = False, with_sync: bool = True) -> dict:
     """The loss of ONE reference optimisation step after `it > 100000` (Trainer.train_stage1, training.py:347-574) under the
     May flags with the LPIPS and canonical-depth terms switched off:
         loss = lambda_rgb * MSE(predict_lip_image, rgb)                                              (:414-418)
@@ -470,7 +470,9 @@ def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio
     [1,T,16,29], coord_window [1,T,FH,FW,2], canonical_face_bbox [[x,y,x2,y2,score]], mel [1,1,80,16], rgb_window_neg
     [1,3,T,96,96].  eps_u01: the 1 + T draws of torch.rand in the order the step makes them (main frame first);
     hole_noise: None when the coin of tf_nerf.py:371 came up tails, else the two randn fields [1,FH,FW].
-    Differentiable w.r.t. `sd` (build it with requires_grad tensors)."""
+    unet_training / with_sync=False: the step BEFORE `it > 100000` -- the post-fusion net in train mode (BatchNorm batch
+    statistics, its parameters trained too) and no sync term (:491 is false).
+    Differentiable w.r.t. `sd` and `unet_sd` (build them with requires_grad tensors)."""
     coords = get_coords(width, height)
     idx = int(data["index"])
     x0, y0 = int(data["lip_lefttop_x"]), int(data["lip_lefttop_y"])
@@ -479,8 +481,10 @@ def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio
     lip = pred.reshape(1, height, width, 3)
     new, _ = composite(lip, data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0, data["coord"],
                        pad_mode=pad_mode, pad_div=pad_div, blackaug=hole_noise)
-    recon = unet_forward(unet_sd, new)
+    recon = unet_forward(unet_sd, new, training=unet_training)
     loss_face = mse_loss(recon, data["rgb_face_ori"], lambda_rgb * w_post_fusion)
+    if not with_sync:
+        return {"loss": loss_rgb + loss_face, "loss_rgb": loss_rgb, "loss_face": loss_face, "pred": pred, "rgb_face_recon": recon}
     window = sync_chain_window(sd, unet_sd, coords, data["audio_window"][0], idx, int(data["total_frame"]), eps_u01[1:],
                                data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0,
                                data["coord_window"][0], data["canonical_face_bbox"][0], height, width, pad_mode, pad_div)

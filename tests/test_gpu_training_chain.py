@@ -485,3 +485,46 @@ def test_unet_train_mode_vs_oracle_sizes(dev, F, fh, fw):
         a, b = gk.cpu().double().flatten(), ref.double().flatten()
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         assert rel <= 5e-3, (name, rel)
+
+
+def test_stage_one_step_before_the_unet_is_fixed_autograd(golden, dev):
+    """The step of the reference's train_stage1 BEFORE it > 100000, written with the drop-in module and torch autograd as the
+    reference writes it (training.py:404-459, 559): predict_lip_image -> MSE(lip); post_fusion2_onlylip(blackaug=True) with the
+    U-Net in TRAIN mode -> MSE(face); loss.backward().  Gradients of the MLP and of the U-Net against what the reference's own
+    run left in .grad (G14)."""
+    import random
+    g, data, _, _, face = _g11_device(golden, dev)
+    e = golden("g14_stage1_early.npz")
+    m = full_model(dev, 16, 24).train()
+    assert m.post_fusion_unet.training
+    tr = s2l.Trainer(m)
+    holes = face["hole_noise"]
+    real_rand, real_randn, real_random = torch.rand, torch.randn, random.random
+    q = [holes[0].cpu()[:, None].repeat(1, 3, 1, 1), holes[1].cpu()[:, None].repeat(1, 3, 1, 1)]
+    torch.rand = lambda *a, **k: torch.full((1,), float(e["eps"][0]), device=dev)
+    torch.randn = lambda *a, **k: q.pop(0)
+    random.random = lambda: 0.9
+    try:
+        loss = {"loss": 0, "loss_rgb": 0}
+        coords = tr.prepare_coords(None, 1)
+        rgb_map = tr.predict_lip_image(0, coords, data["audio"].to(dev), None, {"index": torch.tensor([data["index"]])}, None, None, seed=0)
+        tr.add_photometric_loss(rgb_map, data["rgb"].reshape(-1, 3).to(dev), loss, weights=1.0)
+        rgb_face_recon, _, _ = m.post_fusion2_onlylip(rgb_map.reshape(1, 16, 24, 3), face["rgb_face_canonical"], face["rgb_face_gt"],
+                                                      face["mask_lip_canonical"], face["lip_lefttop_x"], face["lip_lefttop_y"],
+                                                      face["coord"], mask_head_observed=None, use_post_fusion_blackaug=True)
+        tr.add_photometric_loss(rgb_face_recon, face["rgb_face_gt"], loss, weights=1.0)
+        loss["loss"].backward()
+    finally:
+        torch.rand, torch.randn, random.random = real_rand, real_randn, real_random
+    assert abs(float(loss["loss"]) - float(e["loss"])) <= 5e-6
+    params = dict(m.named_parameters())
+    for key in e:
+        if key.startswith("g_"):
+            name = key[2:]
+            got, ref = params[name].grad.cpu(), T(e[key])
+            err = (got - ref).abs() / float(ref.abs().max())
+            if name.startswith("post_fusion_unet"):    # ReLU ties of the fp32 network: bulk tight, outliers loose
+                assert float(err.max()) <= 5e-2 and float((err > 5e-3).float().mean()) <= 0.05, (name, float(err.max()))
+            else:
+                assert float(err.max()) <= 1e-3, (name, float(err.max()))
+    assert int(m.post_fusion_unet.inc.double_conv[1].num_batches_tracked) == 101      # 100 in the seeded state dict + this step

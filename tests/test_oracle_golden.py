@@ -288,3 +288,25 @@ def test_g13_unet_train_mode(golden):
         if key.startswith("s_"):
             assert _maxerr(stats[pre + key[2:]], g[key]) <= 1e-5, key
     assert int(g["tracked"]) == int(usd[pre + "inc.double_conv.1.num_batches_tracked"]) + 1
+
+
+def test_g14_stage_one_step_before_the_unet_is_fixed(golden):
+    """The reference's train_stage1 at it = 50000: post-fusion U-Net in train mode and trained with the MLP, no sync term.
+    MLP gradients to 2e-5; the U-Net encoder gradients carry one ReLU tie of the fp32 evaluation (tools/make_goldens.py, G14),
+    so they are held to 3 % of their maxima."""
+    g, data, _, holes = g11_inputs(golden)
+    e = golden("g14_stage1_early.npz")
+    sd = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    usd = {k: T(v).clone() for k, v in W.make_unet_state_dict(0).items()}
+    for v in usd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    res = O.stage_one_losses(sd, usd, None, None, None, data, [float(e["eps"][0])], holes, 16, 24, unet_training=True, with_sync=False)
+    res["loss"].backward()
+    assert abs(float(res["loss"]) - float(e["loss"])) <= 1e-6
+    for key in e:
+        if key.startswith("g_"):
+            name = key[2:]
+            got = (usd if name.startswith("post_fusion_unet") else sd)[name].grad
+            tol = 3e-2 if name.startswith("post_fusion_unet") else 2e-5
+            assert _maxerr(got, e[key]) <= tol * float(np.abs(e[key]).max()), key

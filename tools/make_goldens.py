@@ -421,6 +421,53 @@ def main():
                                                 "fc_audio_skip.weight", "encoder_conv.0.weight", "encoder_fc1.2.bias")},
         g_pts5_cols=ref_g["pts_linears.5.weight"][:, 250:262].numpy())
 
+    # ---- G14: the same reference train_stage1 BEFORE it > 100000: the post-fusion U-Net in train mode and trained with the MLP
+    # (train.py:188-197 not yet applied), no sync term: MSE(lip) + MSE(face recon through composite-with-black-holes + U-Net)
+    model, cfg = ref_model(ref_config, TalkingFace, h_, w_)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()}, strict=False)
+    model.train()
+    cfg["training"].update(use_canonical_depth_loss_photo_v2=False, use_perceptual_loss=False)
+    tr.model, tr.cfg = model, cfg
+    tr.optimizer = torch.optim.SGD(model.parameters(), lr=0.0)
+    eq, fq = [0.81], [f_.clone() for f_ in fields]
+    torch.rand = lambda *a, **k: torch.full((1,), eq.pop(0))
+    torch.randn = lambda *a, **k: fq.pop(0)
+    _random.random = lambda: 0.9
+    try:
+        _, loss_all = tr.train_stage1(data, it=50000, seed=0)
+    finally:
+        torch.rand, torch.randn, _random.random = real_rand, real_randn, real_random
+    ref_g = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    sd_g = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    usd_g = {k: torch.from_numpy(v).clone() for k, v in W.make_unet_state_dict(0).items()}
+    for v in usd_g.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    res = O.stage_one_losses(sd_g, usd_g, osd, W.SYNCNET_FACE, W.SYNCNET_AUDIO, data, [0.81], (fields[0][:, 0], fields[1][:, 0]), h_, w_,
+                             unet_training=True, with_sync=False)
+    res["loss"].backward()
+    report["stage1_early_loss"] = maxerr(loss_all["loss"].detach(), res["loss"].detach())
+    worst = 0.0
+    for k in sd_g:
+        worst = max(worst, maxerr(ref_g[k], sd_g[k].grad) / (float(ref_g[k].abs().max()) + 1e-12))
+    for k in usd_g:
+        if usd_g[k].grad is not None:
+            dev_ = maxerr(ref_g[k], usd_g[k].grad) / (float(ref_g[k].abs().max()) + 1e-12)
+            if dev_ > 1e-4:
+                print(f"  [info] {k}: rel dev {dev_:.2e}, |grad|max {float(ref_g[k].abs().max()):.3e}")
+            worst = max(worst, dev_)
+    # The MLP and decoder gradients agree to ~1e-5; the encoder layers deviate by 0.2-1.5 % of their maxima: the reference's fused
+    # BatchNorm and the oracle's mean/var composition round differently, one ReLU of the deepest layer whose pre-activation is within
+    # that rounding of zero resolves differently, and every gradient upstream of it (and that layer's BatchNorm bias gradient most
+    # of all) moves with it.  Inherent to fp32 evaluation of this network; the limit for this check is set accordingly.
+    report["stage1_early_grads_rel"] = worst
+    ukeep = ["post_fusion_unet.inc.double_conv.0.weight", "post_fusion_unet.up2.conv.double_conv.4.weight", "post_fusion_unet.outc.conv.weight",
+             "post_fusion_unet.down1.maxpool_conv.1.double_conv.1.bias"]
+    np.savez_compressed(os.path.join(GOLD, "g14_stage1_early.npz"), eps=np.array([0.81], np.float32), loss=np.array(float(loss_all["loss"])),
+                        **{"g_" + k: ref_g[k].numpy() for k in ("output_linear.weight", "pts_linears.3.bias", "fc_uv.weight", "encoder_fc1.0.weight")},
+                        **{"g_" + k: ref_g[k].numpy() for k in ukeep},
+                        n_unet=np.array(sum(float(ref_g[k].abs().double().sum()) for k in ref_g if k.startswith("post_fusion_unet"))))
+
     # ---- G12: canonical-depth photometric loss (training.py:462-477): the reference's own Trainer.inverse_warping +
     # add_loss_canonical_depth_photo and the gradient loss.backward() leaves in canonical_depth_head.grad
     import src.face_simple.models.utils as U2
@@ -494,7 +541,7 @@ def main():
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
     # sits ~4e-6 from the fp64 evaluation of the same formula), and inverse_warping multiplies that by the image gradient.
-    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3, "unet_train_forward": 3e-5, "unet_train_dx_rel": 1e-3,
+    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3, "stage1_early_grads_rel": 3e-2, "unet_train_forward": 3e-5, "unet_train_dx_rel": 1e-3,
               "unet_train_grads_rel": 1e-3, "unet_train_running_stats": 1e-5}
     limits.update({k: 1e-5 for k in report if k.startswith("warp_grid")})
     bad = []
