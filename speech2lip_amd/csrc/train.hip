@@ -167,12 +167,18 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void mse_final_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *loss = s * scale;
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ loss) {
+  // n <= 1024 block partials: four per thread in index order, then a fixed-shape tree (deterministic)
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < n && i < threadIdx.x * 4 + 4; ++i) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *loss = red[0] * scale;
 }
 
 // ---- small reductions / un-folding that used to run through ATen -----------------------------------------------------
@@ -339,7 +345,7 @@ extern "C" int s2l_mse(const float* pred, const float* target, float weight, flo
   const int nblk = (int)((n_elems + 255) / 256 < 1024 ? (n_elems + 255) / 256 : 1024);
   hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, st, pred, target, 2.f * weight / (float)n_elems, dpred, work,
                      n_elems);
-  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, work, nblk, weight / (float)n_elems, loss);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, work, nblk, weight / (float)n_elems, loss);
   return (int)hipGetLastError();
 }
 

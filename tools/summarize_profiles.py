@@ -35,18 +35,23 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
 out.append("\n## composite: rocprofv3 --kernel-trace --stats -- python tools/bench_composite.py 256\n")
 for r in stats("cstats"):
     out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
-out.append("\n## composite kernel PMC, per dispatch (256 frames 500x500, 128x128 lip)\n")
+out.append("\n## composite span_kernel PMC, per dispatch (256 frames 500x500, 128x128 lip)\n")
 cv = {}
 for d in ("cpmc_fetch", "cpmc_write", "cpmc_sq"):
-    cv.update(pmc(d, "composite_kernel"))
+    cv.update(pmc(d, "span_kernel"))
 for k, v in cv.items():
     out.append("%-34s %.6g\n" % (k, v))
+if "FETCH_SIZE" in cv and "WRITE_SIZE" in cv:
+    out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes (algorithmic: 256 x 8,196,608 = 2.098e9)\n"
+               % (cv["FETCH_SIZE"] * 1024 * 2 + cv["WRITE_SIZE"] * 1024))
 for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench_train.py 64 bf16"),
                     ("train_fp32", "training step, fp32 parity mode: python tools/bench_train.py 64 fp32"),
                     ("unet", "post-fusion U-Net: python tools/bench_unet.py 16"),
                     ("syncnet", "sync loss (T3): python tools/bench_syncnet.py 16"),
                     ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
-                    ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet")):
+                    ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
+                    ("config3_nounet", "BASELINE config 3: lip 128x128 + composite, 5000 frames: python tools/bench_config3.py 5000 500"),
+                    ("stage1_sync", "BASELINE config 5 with the sync loss: python tools/bench_train.py 64 bf16 --sync=8")):
     rows = stats("x_" + name)
     if not rows:
         continue
@@ -54,7 +59,7 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
     p = f"{src}/{name}_line.txt"
     if os.path.exists(p):
         out.append(open(p).read().strip() + "\n")
-    for r in rows[:8]:
+    for r in rows[:12]:
         out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
