@@ -80,6 +80,15 @@ __device__ __forceinline__ void dma_1k(const char* gsrc, uint32_t lds_dst) {
       : "memory");
 }
 
+// ReLU as ONE v_max_f32.  fmaxf(x, 0.f) compiles to two (hipcc first canonicalises a possibly-signalling NaN with v_max x, x);
+// with 192 values per wave and layer that second instruction sits on the critical path between two layers.  Same result for
+// every input the hardware max accepts (max(x, 0) in IEEE mode).
+__device__ __forceinline__ float relu1(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(in[g][mb * 4 + r] + v[r], 0.f);
+        for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = relu1(in[g][mb * 4 + r] + v[r]);
     }
   };
 
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
 #pragma unroll
           for (int mb = 0; mb < 16; ++mb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = fmaxf(acc[g][mb][r], 0.f);
+            for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = relu1(acc[g][mb][r]);
       }
       S2L_TRACE(tile, 2 + layer);
     }
