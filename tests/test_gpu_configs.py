@@ -236,3 +236,50 @@ def test_bf16_step_gradients_directly_vs_oracle_autograd(dev, h, w, B):
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         assert rel <= 5e-2 and cos >= 0.999, f"{k}: rel {rel:.3e} cos {cos:.6f}"
+
+
+def test_parity_on_weights_moved_by_training(dev):
+    """Every other parity test runs on the seeded G0 weights.  Here the weights are first MOVED by 40 Adam steps of the bf16
+    training step (lr 1e-3 on a fixed target image: activations saturate differently, the output range grows), then the
+    renderer, the general-row path and the fp32 training gradients are checked against the oracle ON THOSE WEIGHTS."""
+    from tests.test_gpu_parity import _oracle_grads
+    h, w, B = 24, 32, 4
+    m = make_model(dev, h, w).train()
+    opt = torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("coord_linears")], lr=1e-3)
+    rng = np.random.default_rng(77)
+    win = T(W.synthetic_audio(B, seed=31).astype(np.float32)).to(dev)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+    img = np.stack([0.5 + 0.5 * np.sin(9 * xx + k) * np.cos(7 * yy - k) for k in range(3)], -1).reshape(1, h * w, 3)
+    targets = T(np.repeat(img, B, 0).astype(np.float32) * 3.0 - 1.0).to(dev)          # outside [0,1] on purpose
+    step = s2l.LipTrainStep(m, h, w, precision="bf16")
+    first = None
+    for it in range(40):
+        loss, g, _ = step.loss_and_grads(win, list(range(B)), targets, [float(v) for v in rng.random(B)])
+        first = float(loss) if first is None else first
+        s2l.training.apply_grads(m, g)
+        opt.step()
+    assert float(loss) < 0.5 * first                                                    # it did train
+    np_sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if k in W.make_state_dict(0, "he")}
+    moved = max(float(np.abs(np_sd[k] - v).max()) for k, v in W.make_state_dict(0, "he").items())
+    assert moved > 0.02
+    sd = O.to_sd(np_sd)
+    m.eval()
+    idx = [3, 50, 999, 12345]
+    with torch.no_grad():
+        ref = O.render_clip(sd, win.cpu(), idx, h, w)
+    out = m.render_clip(win, idx, h, w)
+    assert float(ref.abs().max()) > 1.0                                                 # a different magnitude regime than G0's
+    scale = float(ref.pow(2).mean().sqrt())
+    assert O.rmse(out.cpu(), ref) <= 2e-5 * scale and float((out.cpu() - ref).abs().max()) <= 2e-4 * scale
+    feat = m.audio_merge_forward(win[1:2])
+    rows = torch.cat([s2l.get_coords(w, h, dev), feat.detach().expand(h * w, -1)], -1)
+    with torch.no_grad():
+        close(m.rgb_forward(rows, time_pts=50), ref[1].reshape(-1, 3), 2e-5 * scale, 2e-4 * scale)
+    # gradients of the fp32 parity step on the moved weights
+    u01 = [0.3, 0.9]
+    ref_loss, ref_g, _ = _oracle_grads(np_sd, win[:2].cpu(), [7, 8], targets[:2].cpu(), u01, h, w)
+    loss, g, _ = s2l.LipTrainStep(m.train(), h, w).loss_and_grads(win[:2], [7, 8], targets[:2], u01)
+    assert abs(float(loss) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss))
+    for k in ref_g:
+        sc = float(ref_g[k].abs().max()) + 1e-12
+        assert float((g[k].cpu() - ref_g[k]).abs().max()) <= 3e-4 * sc, k

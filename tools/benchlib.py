@@ -144,6 +144,19 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
     return res
 
 
+def warm_until_allocator_settles(fn, max_steps=5):
+    """Run `fn` until torch's caching allocator makes no new device allocation during a step (a step that still calls
+    hipMalloc for tens of GB is 5-10x slower and would be timing the allocator, not the kernels).  Returns fn's last result."""
+    r = None
+    for _ in range(max_steps):
+        before = torch.cuda.memory_stats().get("num_device_alloc", 0)
+        r = fn()
+        torch.cuda.synchronize()
+        if torch.cuda.memory_stats().get("num_device_alloc", 0) == before:
+            break
+    return r
+
+
 def train_flops(B, hw=96 * 96):
     """as-written model, fwd + dgrad + wgrad, 4 ensemble taps."""
     return 3 * 4 * 2 * 644_864 * hw * B
@@ -187,9 +200,8 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
         s2l.training.apply_grads(m, g)
         opt.step()
         return loss, aux
-    l0, aux0 = one()
-    l0 = float(l0)
-    torch.cuda.synchronize()
+    l0 = float(one()[0])
+    warm_until_allocator_settles(one)
     t0 = time.perf_counter()
     for _ in range(steps):
         l, aux = one()
@@ -220,7 +232,7 @@ def bench_train(dev, B=64, precision="bf16", steps=5):
         opt.step()
         return loss
     l0 = float(one())
-    torch.cuda.synchronize()
+    warm_until_allocator_settles(one)
     t0 = time.perf_counter()
     for _ in range(steps):
         l = one()
