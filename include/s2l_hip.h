@@ -286,7 +286,7 @@ int s2l_unet_backward(const float* packed, const float* saved, const float* d_ou
  * s2l_unet_pack_raw: the RAW (un-folded) weights in the kernels' chunk layout, forward and transposed; same table and blob size as
  *   s2l_unet_pack; re-run after every optimizer step.
  * s2l_unet_train_forward: tensors_host = the s2l_unet_pack table (its running_mean / running_var entries are WRITTEN when
- *   update_running != 0); saved: s2l_unet_train_saved_floats(H, W, F) floats; scratch: 65536 floats.
+ *   update_running != 0); saved: s2l_unet_train_saved_floats(H, W, F) floats; scratch: 262144 floats.
  * s2l_unet_train_backward: d_out [F,H,W,3] -> d_x [F,H,W,3] (or NULL) and grads [s2l_unet_grad_floats()]: for each of the ten 3x3
  *   layers in execution order conv.weight [cout,cin,3,3], bn.weight [cout], bn.bias [cout]; then outc.conv.weight [3,64],
  *   outc.conv.bias [3].  work: s2l_unet_train_work_floats(H, W, F) floats.  Weight gradients are split-K MFMA GEMMs over the

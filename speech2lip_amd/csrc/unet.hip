@@ -594,7 +594,7 @@ static UnetSaved unet_saved(float* w, int64_t p1, int64_t p2, int64_t p4) {
 // gradient dW[co][ci][tap] = sum_pixels dz[co](p) a_prev[ci](p + tap) (conv_wgrad_kernel, MFMA) and dz -> da_prev (transposed
 // chunks).  nn.BatchNorm2d's running update: momentum 0.1, UNBIASED variance.
 namespace {
-constexpr int kStatBlocks = 256;
+constexpr int kStatBlocks = 1024;   // row blocks of the per-channel reductions (4 per CU keeps the loads in flight)
 
 // partial[blk][0][c] = sum z, partial[blk][1][c] = sum z^2 over the block's pixels; 256 threads = (256 / C) pixel lanes x C
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ z, int C, int64_t n_pix, int64_t per_block,
@@ -605,7 +605,15 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   int64_t p1 = p0 + per_block;
   if (p1 > n_pix) p1 = n_pix;
   float s = 0.f, ss = 0.f;
-  for (int64_t p = p0 + pl; p < p1; p += lanes) {
+  int64_t p = p0 + pl;
+  for (; p + 3 * lanes < p1; p += 4 * lanes) {          // four independent loads in flight per thread
+    const float v0 = z[p * C + c], v1 = z[(p + lanes) * C + c], v2 = z[(p + 2 * lanes) * C + c], v3 = z[(p + 3 * lanes) * C + c];
+    s += v0; ss = fmaf(v0, v0, ss);
+    s += v1; ss = fmaf(v1, v1, ss);
+    s += v2; ss = fmaf(v2, v2, ss);
+    s += v3; ss = fmaf(v3, v3, ss);
+  }
+  for (; p < p1; p += lanes) {
     const float v = z[p * C + c];
     s += v;
     ss = fmaf(v, v, ss);
@@ -715,7 +723,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   int64_t p1 = p0 + per_block;
   if (p1 > n_pix) p1 = n_pix;
   float s1 = 0.f, s2 = 0.f;
-  for (int64_t p = p0 + pl; p < p1; p += lanes) {
+  int64_t p = p0 + pl;
+  for (; p + lanes < p1; p += 2 * lanes) {               // two rows (four loads) in flight per thread
+    const float g0 = gy[p * C + c], z0 = z[p * C + c], g1 = gy[(p + lanes) * C + c], z1 = z[(p + lanes) * C + c];
+    s1 += g0; s2 = fmaf(g0, (z0 - mean) * invstd, s2);
+    s1 += g1; s2 = fmaf(g1, (z1 - mean) * invstd, s2);
+  }
+  for (; p < p1; p += lanes) {
     const float g = gy[p * C + c];
     s1 += g;
     s2 = fmaf(g, (z[p * C + c] - mean) * invstd, s2);
@@ -793,35 +807,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   f4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t ch = blockIdx.z; ch < a.n_chunks; ch += gridDim.z) {
+  // register-prefetch pipeline over the chunks: the global loads of the next chunk are in flight while this chunk's 144 MFMAs
+  // per wave run; they are committed to LDS between two barriers (as conv3x3_kernel does for its channel chunks)
+  f4 pd[4], pa[4];
+  auto fetch = [&](int64_t ch) {
     const int cx = (int)(ch % a.chunks_x);
     const int64_t row = ch / a.chunks_x;                  // f * H + y
     const int y = (int)(row % a.H);
     const int64_t f = row / a.H;
     const int x0 = cx * 64;
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                         // dz tile: 64 px x 64 co = 1024 quads
       const int idx = threadIdx.x + 256 * k;
       const int px = idx >> 4, c4 = idx & 15;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (x0 + px < a.W) v = *reinterpret_cast<const f4*>(a.dz + ((row * a.W) + x0 + px) * a.cout + ct * 64 + 4 * c4);
-      *reinterpret_cast<f4*>(lds_dz + px * 68 + 4 * c4) = v;
+      pd[k] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (x0 + px < a.W) pd[k] = *reinterpret_cast<const f4*>(a.dz + ((row * a.W) + x0 + px) * a.cout + ct * 64 + 4 * c4);
     }
-    for (int idx = threadIdx.x; idx < 3 * 66 * 4; idx += 256) {   // input halo: 3 rows x 66 px x 16 ci = 792 quads
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                         // input halo: 3 rows x 66 px x 16 ci = 792 quads
+      const int idx = threadIdx.x + 256 * k;
       const int c4 = idx & 3, xx = (idx >> 2) % 66, dy = idx / (66 * 4);
       const int gy = y + dy - 1, gx = x0 + xx - 1;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-        v = *reinterpret_cast<const f4*>(in + ((f * a.H + gy) * (int64_t)a.W + gx) * Cin + coff + 4 * c4);
-      *reinterpret_cast<f4*>(lds_a + (dy * 66 + xx) * 16 + 4 * c4) = v;
+      pa[k] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (idx < 3 * 66 * 4 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        pa[k] = *reinterpret_cast<const f4*>(in + ((f * a.H + gy) * (int64_t)a.W + gx) * Cin + coff + 4 * c4);
     }
-    __syncthreads();
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = threadIdx.x + 256 * k;
+      *reinterpret_cast<f4*>(lds_dz + (idx >> 4) * 68 + 4 * (idx & 15)) = pd[k];
+      if (idx < 3 * 66 * 4) *reinterpret_cast<f4*>(lds_a + (idx >> 2) * 16 + 4 * (idx & 3)) = pa[k];
+    }
+  };
+  if ((int64_t)blockIdx.z < a.n_chunks) {
+    fetch(blockIdx.z);
+    commit();
+  }
+  __syncthreads();
+  for (int64_t ch = blockIdx.z; ch < a.n_chunks; ch += gridDim.z) {
+    const bool more = ch + gridDim.z < a.n_chunks;
+    if (more) fetch(ch + gridDim.z);
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const float av = lds_dz[(4 * s + q) * 68 + 16 * wave + i16];
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[t] = mfma16u(av, lds_a[((t / 3) * 66 + 4 * s + q + t % 3) * 16 + i16], acc[t]);
+    }
+    __syncthreads();            // everyone is done reading this chunk
+    if (more) {
+      commit();
+      __syncthreads();
     }
   }
   // D[row = 4 q + r -> co][col = i16 -> ci]
@@ -1235,7 +1272,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(n * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, n * C / 4);
     if (l == 0) {
-      const int64_t perw = (p1 + 255) / 256;
+      const int64_t perw = (p1 + 2047) / 2048;
       const int nbw = (int)((p1 + perw - 1) / perw);
       hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(nbw), dim3(256), 0, st, gy, x, wpart, H, W, p1, perw);
       hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(64 * 27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
@@ -1257,7 +1294,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
 
   // output convolution: gy9 = outc^T d_out * (a9 > 0); d outc.weight / bias
   {
-    const int64_t perw = (p1 + 255) / 256;
+    const int64_t perw = (p1 + 2047) / 2048;
     const int nbw = (int)((p1 + perw - 1) / perw);
     hipLaunchKernelGGL(outc_wgrad_kernel, dim3(nbw), dim3(256), 0, st, d_out, b.act[9], wpart, p1, perw);
     hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(195), dim3(256), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);

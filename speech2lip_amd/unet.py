@@ -138,7 +138,7 @@ class SimpleUnetLight(nn.Module):
         raw = torch.empty(int(lib.s2l_unet_packed_floats()), dtype=torch.float32, device=dev)
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
         saved = torch.empty(int(lib.s2l_unet_train_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
-        scratch = torch.empty(65536, dtype=torch.float32, device=dev)
+        scratch = torch.empty(262144, dtype=torch.float32, device=dev)
         bn = self.inc.double_conv[1]
         momentum = 0.1 if bn.momentum is None else float(bn.momentum)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
