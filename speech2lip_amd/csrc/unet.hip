@@ -634,16 +634,29 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 // per channel: batch mean, biased variance -> st[0..C) = scale = gamma * invstd, st[C..2C) = shift = beta - mean * scale,
 // st[2C..3C) = mean, st[3C..4C) = invstd; running statistics updated in place (momentum, unbiased variance)
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float eps, float momentum,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ st) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < n_blocks; ++b) {
-    s += (double)partial[((int64_t)b * 2) * C + c];
-    ss += (double)partial[((int64_t)b * 2 + 1) * C + c];
+// one 64-lane block per channel: lane t sums the partials of blocks t, t + 64, ... in fp64, then a fixed-shape butterfly
+__device__ __forceinline__ void channel_totals(const float* __restrict__ partial, int n_blocks, int C, int c, double* s0, double* s1) {
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < n_blocks; k += 64) {
+    a += (double)partial[((int64_t)k * 2) * C + c];
+    b += (double)partial[((int64_t)k * 2 + 1) * C + c];
   }
+  for (int o = 32; o; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  *s0 = a;
+  *s1 = b;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float eps,
+                                                        float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        float* __restrict__ st) {
+  const int c = blockIdx.x;
+  double s, ss;
+  channel_totals(partial, n_blocks, C, c, &s, &ss);
+  if (threadIdx.x != 0) return;
   const double mean = s / n;
   double var = ss / n - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -749,15 +762,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 // stage 2: totals -> dgamma = s2, dbeta = s1, and the two per-channel means the elementwise stage needs (sums[0..C) = s1/n,
 // sums[C..2C) = s2/n)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < n_blocks; ++b) {
-    s1 += (double)partial[((int64_t)b * 2) * C + c];
-    s2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ sums) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  channel_totals(partial, n_blocks, C, c, &s1, &s2);
+  if (threadIdx.x != 0) return;
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
   sums[c] = (float)(s1 / n);
@@ -1217,7 +1228,7 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
     int nb = 0;
     run_stats(b.z[l], C, pl[lv], scratch, st, &nb);
     float* stl = b.st + l * 512;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, scratch, nb, C, (double)pl[lv], bn_eps, momentum, t.gamma[l],
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (double)pl[lv], bn_eps, momentum, t.gamma[l],
                        t.beta[l], update_running ? const_cast<float*>(t.mean[l]) : nullptr,
                        update_running ? const_cast<float*>(t.var[l]) : nullptr, stl);
     hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4);
@@ -1269,10 +1280,10 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
     float* g = grads + grad_off(l);
     float* dgamma = g + (int64_t)C * cin * 9;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(n * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, n * C / 4);
     if (l == 0) {
-      const int64_t perw = (p1 + 2047) / 2048;
+      const int64_t perw = (p1 + 1023) / 1024;
       const int nbw = (int)((p1 + perw - 1) / perw);
       hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(nbw), dim3(256), 0, st, gy, x, wpart, H, W, p1, perw);
       hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(64 * 27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
