@@ -279,6 +279,18 @@ int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, fl
                            int64_t n_frames, s2l_stream_t stream);
 int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x, int height,
                       int width, int64_t n_frames, s2l_stream_t stream);
+/* The same pair on a WINDOW of the frame: x / out / d_out / d_x are [F,height,width,3] crops whose top-left corner sits at
+ * (origin_y, origin_x) of a full_h x full_w frame (origins multiples of 4; sizes multiples of 4 unless the crop ends at the frame
+ * edge).  The sync loss only reads the canonical-face box of the U-Net output (training.py:541-544), so the chain runs the network
+ * on that box dilated by the network's dependency radius instead of the whole frame.  The crop is processed like a frame, except
+ * that the align_corners=True up-samplings take their source positions from the FULL frame's geometry: every output and gradient
+ * whose dependency cone (radius <= 32 pixels) stays inside the crop equals the full-frame value bit for bit; values nearer than
+ * that to a crop edge that is not a frame edge must not be used. */
+int s2l_unet_forward_saved_window(const float* packed, const float* x, float* saved, float* out, int height, int width,
+                                  int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_backward_window(const float* packed, const float* saved, const float* d_out, float* work, float* d_x, int height,
+                             int width, int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames,
+                             s2l_stream_t stream);
 
 /* TRAIN mode of the same network, as the reference runs it until `it > 100000` (train.py:188-197): every BatchNorm2d normalises
  * with the statistics of the batch (biased variance) and updates its running statistics in place (momentum, unbiased variance:

@@ -357,8 +357,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 
 // ---- upsampling (MaxPool2d(2) lives in the conv epilogue) ------------------------------------------------------------------------------
 // bilinear x2, align_corners=True, then zero padding to (Ho, Wo) (SimpleUnetLight.py:57-66)
+// Window form (training on a crop of the frame, s2l_unet_forward_saved_window): x and y are CROPS of the full low-resolution /
+// output tensors; the bilinear source position is computed in FULL-frame coordinates (align_corners=True makes the scale depend on
+// the full size) and then shifted into the crop, so every value that does not depend on data outside the crop equals the
+// full-frame value bit for bit.  Without a window: hf = h, wf = w, Hof = Ho, Wof = Wo, origins 0.
+struct UpWin {
+  int hf, wf, Hof, Wof;     // full low-resolution size, full output size
+  int oyi, oxi, oyo, oxo;   // origin of the input crop / output crop inside the full tensors
+};
 __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int C,
-                                                       int Ho, int Wo, int64_t n_out) {
+                                                       int Ho, int Wo, int64_t n_out, UpWin win) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_out) return;
   const int cq = C / 4;
@@ -368,27 +376,30 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
   p /= Wo;
   const int yo = (int)(p % Ho);
   const int64_t f = p / Ho;
-  const int padT = (Ho - 2 * h) / 2, padL = (Wo - 2 * w) / 2;
-  const int yu = yo - padT, xu = xo - padL;
+  const int padT = (win.Hof - 2 * win.hf) / 2, padL = (win.Wof - 2 * win.wf) / 2;
+  const int yu = yo + win.oyo - padT, xu = xo + win.oxo - padL;
   f4 o = (f4){0.f, 0.f, 0.f, 0.f};
-  if ((unsigned)yu < (unsigned)(2 * h) && (unsigned)xu < (unsigned)(2 * w)) {
-    const float sy = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
-    const float sx = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  if ((unsigned)yu < (unsigned)(2 * win.hf) && (unsigned)xu < (unsigned)(2 * win.wf)) {
+    const float sy = 2 * win.hf > 1 ? (float)(win.hf - 1) / (float)(2 * win.hf - 1) : 0.f;
+    const float sx = 2 * win.wf > 1 ? (float)(win.wf - 1) / (float)(2 * win.wf - 1) : 0.f;
     const float fy = sy * (float)yu, fx = sx * (float)xu;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const int y0f = (int)fy, x0f = (int)fx;
+    const int y1f = y0f + (y0f < win.hf - 1 ? 1 : 0), x1f = x0f + (x0f < win.wf - 1 ? 1 : 0);
+    const float ly = fy - (float)y0f, lx = fx - (float)x0f;
     const float hy = 1.f - ly, hx = 1.f - lx;
+    const int y0 = y0f - win.oyi, y1 = y1f - win.oyi, x0 = x0f - win.oxi, x1 = x1f - win.oxi;
     const float* s = x + f * (int64_t)h * w * C + c4 * 4;
-    const f4 v00 = *reinterpret_cast<const f4*>(s + ((int64_t)y0 * w + x0) * C);
-    const f4 v01 = *reinterpret_cast<const f4*>(s + ((int64_t)y0 * w + x1) * C);
-    const f4 v10 = *reinterpret_cast<const f4*>(s + ((int64_t)y1 * w + x0) * C);
-    const f4 v11 = *reinterpret_cast<const f4*>(s + ((int64_t)y1 * w + x1) * C);
+    auto at = [&](int yy, int xx) {          // taps outside the crop only feed outputs nobody reads: zero
+      return ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? *reinterpret_cast<const f4*>(s + ((int64_t)yy * w + xx) * C)
+                                                                        : (f4){0.f, 0.f, 0.f, 0.f};
+    };
+    const f4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = hy * (hx * v00[r] + lx * v01[r]) + ly * (hx * v10[r] + lx * v11[r]);
   }
   *reinterpret_cast<f4*>(y + i * 4) = o;
 }
+static UpWin no_window(int h, int w, int Ho, int Wo) { return UpWin{h, w, Ho, Wo, 0, 0, 0, 0}; }
 
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
                        float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr) {
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(256) void conv_first_bwd_kernel(const float* __rest
 // [coff, coff + C) of it; act, z: [F,h,w,C].
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ g, int ldg, int coff,
                                                            const float* __restrict__ act, float* __restrict__ z, int h, int w, int C,
-                                                           int Ho, int Wo, int64_t n_in) {
+                                                           int Ho, int Wo, int64_t n_in, UpWin win) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_in) return;
   const int cq = C / 4;
@@ -503,23 +514,26 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
   p /= w;
   const int yi = (int)(p % h);
   const int64_t f = p / h;
-  const int padT = (Ho - 2 * h) / 2, padL = (Wo - 2 * w) / 2;
-  const float sy = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
-  const float sx = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  const int yif = yi + win.oyi, xif = xi + win.oxi;          // position in the full low-resolution tensor
+  const int padT = (win.Hof - 2 * win.hf) / 2, padL = (win.Wof - 2 * win.wf) / 2;
+  const float sy = 2 * win.hf > 1 ? (float)(win.hf - 1) / (float)(2 * win.hf - 1) : 0.f;
+  const float sx = 2 * win.wf > 1 ? (float)(win.wf - 1) / (float)(2 * win.wf - 1) : 0.f;
   f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int yu = max(2 * yi - 3, 0); yu <= min(2 * yi + 4, 2 * h - 1); ++yu) {
+  for (int yu = max(2 * yif - 3, 0); yu <= min(2 * yif + 4, 2 * win.hf - 1); ++yu) {
     const float fy = sy * (float)yu;
-    const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const int y0 = (int)fy, y1 = y0 + (y0 < win.hf - 1 ? 1 : 0);
     const float ly = fy - (float)y0;
-    const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
-    if (wy == 0.f) continue;
-    for (int xu = max(2 * xi - 3, 0); xu <= min(2 * xi + 4, 2 * w - 1); ++xu) {
+    const float wy = (y0 == yif ? 1.f - ly : 0.f) + (y1 == yif ? ly : 0.f);
+    const int yo = yu + padT - win.oyo;                       // row of the (cropped) gradient tensor
+    if (wy == 0.f || (unsigned)yo >= (unsigned)Ho) continue;
+    for (int xu = max(2 * xif - 3, 0); xu <= min(2 * xif + 4, 2 * win.wf - 1); ++xu) {
       const float fx = sx * (float)xu;
-      const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const int x0 = (int)fx, x1 = x0 + (x0 < win.wf - 1 ? 1 : 0);
       const float lx = fx - (float)x0;
-      const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
-      if (wx == 0.f) continue;
-      const f4 v = *reinterpret_cast<const f4*>(g + ((f * Ho + yu + padT) * (int64_t)Wo + xu + padL) * ldg + coff + c4 * 4);
+      const float wx = (x0 == xif ? 1.f - lx : 0.f) + (x1 == xif ? lx : 0.f);
+      const int xo = xu + padL - win.oxo;
+      if (wx == 0.f || (unsigned)xo >= (unsigned)Wo) continue;
+      const f4 v = *reinterpret_cast<const f4*>(g + ((f * Ho + yo) * (int64_t)Wo + xo) * ldg + coff + c4 * 4);
       const float ww = wy * wx;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = fmaf(ww, v[r], acc[r]);
@@ -1050,11 +1064,11 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st))) return rc;
   if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2,
-                     W2, p2 * 32);
+                     W2, p2 * 32, no_window(H4, W4, H2, W2));
   if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st))) return rc;
   if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
-                     p1 * 16);   // t64a is free again: it becomes up(u1)
+                     p1 * 16, no_window(H2, W2, H, W));   // t64a is free again: it becomes up(u1)
   if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st))) return rc;
   if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st))) return rc;
   return (int)hipGetLastError();
@@ -1072,9 +1086,25 @@ extern "C" int64_t s2l_unet_backward_work_floats(int height, int width, int64_t 
   return n_frames * (p1 * 256 + p2 * 768 + p4 * 384);
 }
 
-extern "C" int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, float* out, int height, int width,
-                                      int64_t n_frames, s2l_stream_t stream) {
+// A window [origin_y, origin_y + height) x [origin_x, origin_x + width) of a full_h x full_w frame (origins multiples of 4, so
+// that the 2x2 pooling windows and the quarter-resolution grid line up with the full frame's): the crop is processed as a frame of
+// its own, except that the bilinear up-samplings take their source positions from the FULL frame's geometry.  Every output
+// (and, in the backward, every gradient) whose dependency cone stays inside the crop equals the full-frame value bit for bit; the
+// cone has a radius of <= 32 pixels (2 + 4 + 8 through the encoder, 4 + 4 + 2 + 2 back up, pooling alignment).  Values nearer
+// than that to a crop edge that is not a frame edge are NOT the full-frame values: the caller must not use them.
+static int unet_window(int height, int width, int full_h, int full_w, int oy, int ox) {
+  if (full_h < height || full_w < width || oy < 0 || ox < 0 || oy + height > full_h || ox + width > full_w) return S2L_E_GEOMETRY;
+  if ((oy & 3) || (ox & 3)) return S2L_E_GEOMETRY;
+  // a crop that stops short of the frame's bottom / right edge must have a size that pools evenly
+  if ((oy + height != full_h && (height & 3)) || (ox + width != full_w && (width & 3))) return S2L_E_GEOMETRY;
+  return 0;
+}
+
+extern "C" int s2l_unet_forward_saved_window(const float* packed, const float* x, float* saved, float* out, int height, int width,
+                                             int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames,
+                                             s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
+  { const int rcw = unet_window(height, width, full_h, full_w, origin_y, origin_x); if (rcw) return rcw; }
   if (n_frames == 0) return S2L_OK;
   if (!packed || !x || !saved || !out) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(saved)) return S2L_E_ALIGN;
@@ -1091,21 +1121,30 @@ extern "C" int s2l_unet_forward_saved(const float* packed, const float* x, float
   if ((rc = launch_conv(s.a2, 128, nullptr, 0, packed, 3, s.x2, nullptr, H2, W2, F, st, s.p2))) return rc;
   if ((rc = launch_conv(s.p2, 128, nullptr, 0, packed, 4, s.a4, nullptr, H4, W4, F, st))) return rc;
   if ((rc = launch_conv(s.a4, 128, nullptr, 0, packed, 5, s.x3, nullptr, H4, W4, F, st))) return rc;
+  const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
+  const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, s.x3, s.u3, H4, W4, 128, H2, W2,
-                     p2 * 32);
+                     p2 * 32, w21);
   if ((rc = launch_conv(s.x2, 128, s.u3, 128, packed, 6, s.a6, nullptr, H2, W2, F, st))) return rc;
   if ((rc = launch_conv(s.a6, 128, nullptr, 0, packed, 7, s.u1, nullptr, H2, W2, F, st))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
-                     p1 * 16);
+                     p1 * 16, w10);
   if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st))) return rc;
   if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9))) return rc;
   return (int)hipGetLastError();
 }
 
+extern "C" int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, float* out, int height, int width,
+                                      int64_t n_frames, s2l_stream_t stream) {
+  return s2l_unet_forward_saved_window(packed, x, saved, out, height, width, height, width, 0, 0, n_frames, stream);
+}
+
 // d_out [F,H,W,3] -> d_x [F,H,W,3], from the activations s2l_unet_forward_saved kept; work: s2l_unet_backward_work_floats.
-extern "C" int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
-                                 int height, int width, int64_t n_frames, s2l_stream_t stream) {
+extern "C" int s2l_unet_backward_window(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
+                                        int height, int width, int full_h, int full_w, int origin_y, int origin_x,
+                                        int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
+  { const int rcw = unet_window(height, width, full_h, full_w, origin_y, origin_x); if (rcw) return rcw; }
   if (n_frames == 0) return S2L_OK;
   if (!packed || !saved || !d_out || !work || !d_x) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(saved) || misaligned16(work)) return S2L_E_ALIGN;
@@ -1123,11 +1162,13 @@ extern "C" int s2l_unet_backward(const float* packed, const float* saved, const 
   hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, packed + kUnetOutW, s.y9, zA, p1 * 16);   // z9
   if ((rc = launch_conv_dgrad(zA, packed, 9, zB, s.a8, H, W, F, st))) return rc;                                          // z8
   if ((rc = launch_conv_dgrad(zB, packed, 8, gcat8, nullptr, H, W, F, st))) return rc;                                    // [g_x1 | g_uu]
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64, H, W, p2 * 16);
+  const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
+  const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64, H, W, p2 * 16, w10);
   if ((rc = launch_conv_dgrad(z7, packed, 7, z6, s.a6, H2, W2, F, st))) return rc;
   if ((rc = launch_conv_dgrad(z6, packed, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                                  // [g_x2 | g_u3]
   hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, s.x3, z5, H4, W4, 128, H2, W2,
-                     p4 * 32);
+                     p4 * 32, w21);
   if ((rc = launch_conv_dgrad(z5, packed, 5, z4, s.a4, H4, W4, F, st))) return rc;
   if ((rc = launch_conv_dgrad(z4, packed, 4, gp2, nullptr, H4, W4, F, st))) return rc;
   hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, s.x2, s.p2, z3, H2, W2, 128, p2 * 32);
@@ -1138,6 +1179,11 @@ extern "C" int s2l_unet_backward(const float* packed, const float* saved, const 
   hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
                      packed + unet_w_off(0), d_x, H, W);
   return (int)hipGetLastError();
+}
+
+extern "C" int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
+                                 int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  return s2l_unet_backward_window(packed, saved, d_out, work, d_x, height, width, height, width, 0, 0, n_frames, stream);
 }
 
 // ---- TRAIN mode entry points ------------------------------------------------------------------------------------------------
@@ -1234,8 +1280,12 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
     hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4);
     if (l == 1) hipLaunchKernelGGL(maxpool2_kernel, blocks(p2 * 16), dim3(256), 0, st, b.act[1], b.p1, H, W, 64, p2 * 16);
     if (l == 3) hipLaunchKernelGGL(maxpool2_kernel, blocks(p4 * 32), dim3(256), 0, st, b.act[3], b.p2, H2, W2, 128, p4 * 32);
-    if (l == 5) hipLaunchKernelGGL(upsample2_kernel, blocks(p2 * 32), dim3(256), 0, st, b.act[5], b.u3, H4, W4, 128, H2, W2, p2 * 32);
-    if (l == 7) hipLaunchKernelGGL(upsample2_kernel, blocks(p1 * 16), dim3(256), 0, st, b.act[7], b.uu, H2, W2, 64, H, W, p1 * 16);
+    if (l == 5)
+      hipLaunchKernelGGL(upsample2_kernel, blocks(p2 * 32), dim3(256), 0, st, b.act[5], b.u3, H4, W4, 128, H2, W2, p2 * 32,
+                         no_window(H4, W4, H2, W2));
+    if (l == 7)
+      hipLaunchKernelGGL(upsample2_kernel, blocks(p1 * 16), dim3(256), 0, st, b.act[7], b.uu, H2, W2, 64, H, W, p1 * 16,
+                         no_window(H2, W2, H, W));
   }
   hipLaunchKernelGGL(outc_kernel, blocks(p1), dim3(256), 0, st, b.act[9], t.outw, t.outb, out, p1);
   return (int)hipGetLastError();
@@ -1315,13 +1365,14 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
   if ((rc = launch_conv_dgrad(zA, packed_raw, 9, zB, b.act[8], H, W, F, st))) return rc;
   layer_grads(8, zB);
   if ((rc = launch_conv_dgrad(zB, packed_raw, 8, gcat8, nullptr, H, W, F, st))) return rc;                                // [g_x1 | g_uu]
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64, H, W, p2 * 16);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64, H, W, p2 * 16,
+                     no_window(H2, W2, H, W));
   layer_grads(7, z7);
   if ((rc = launch_conv_dgrad(z7, packed_raw, 7, z6, b.act[6], H2, W2, F, st))) return rc;
   layer_grads(6, z6);
   if ((rc = launch_conv_dgrad(z6, packed_raw, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                              // [g_x2 | g_u3]
   hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, b.act[5], z5, H4, W4, 128, H2, W2,
-                     p4 * 32);
+                     p4 * 32, no_window(H4, W4, H2, W2));
   layer_grads(5, z5);
   if ((rc = launch_conv_dgrad(z5, packed_raw, 5, z4, b.act[4], H4, W4, F, st))) return rc;
   layer_grads(4, z4);

@@ -368,8 +368,10 @@ class SyncChain:
     and its adjoint back to d loss / d lip.  Samples go through in groups that bound the U-Net state (about 1 GB per
     500x500 frame for the saved activations and the backward scratch)."""
 
+    UNET_RADIUS = 40   # pixels: >= the U-Net's dependency radius (32: 2 + 4 + 8 down, 4 + 4 + 2 + 2 up, pooling alignment) + slack
+
     def __init__(self, model: TalkingFace, syncnet, syncnet_T: int = 5, w_syncloss: float = 0.01, out_hw=(96, 96),
-                 max_frames_per_group: int = 40):
+                 max_frames_per_group: int = 40, window: bool = True):
         from .syncnet import SyncLoss
         if getattr(model, "post_fusion_unet", None) is None:
             raise ValueError("SyncChain needs model.use_post_fusion (the window is the U-Net's output)")
@@ -377,6 +379,10 @@ class SyncChain:
         self.sync = SyncLoss(syncnet, syncnet_T)
         self.out_hw = (int(out_hw[0]), int(out_hw[1]))
         self.group = max(1, int(max_frames_per_group) // self.T)
+        # window=True: the U-Net runs on the canonical-face box dilated by its dependency radius, not on the whole frame -- the
+        # sync loss reads nothing else of its output (training.py:541-544) and every value it reads, and every gradient that
+        # comes back, is bit-identical to the full-frame evaluation (s2l_unet_forward_saved_window)
+        self.window = bool(window)
 
     def loss_and_dlip(self, lips, rgb_face_canonical, rgb_face_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
                       coord_window, canonical_face_bbox, mel, rgb_window_neg):
@@ -397,6 +403,13 @@ class SyncChain:
             raise ValueError("rgb_face_gt must be [S,FH,FW,3] and coord_window [S,T,FH,FW,2]")
         x, y, x2, y2 = (int(v) for v in list(canonical_face_bbox)[:4])
         oh, ow = self.out_hw
+        r = self.UNET_RADIUS
+        if self.window:       # crop origin / size on the 4-pixel grid of the two pooling levels, clipped to the frame
+            wx0, wy0 = max(0, (x - r) // 4 * 4), max(0, (y - r) // 4 * 4)
+            wx1, wy1 = min(FW, -(-(x2 + r) // 4) * 4), min(FH, -(-(y2 + r) // 4) * 4)
+        else:
+            wx0, wy0, wx1, wy1 = 0, 0, FW, FH
+        win = (FH, FW, wy0, wx0)
         mel = _dev_f32(mel, dev, "mel")
         neg = _dev_f32(rgb_window_neg, dev, "rgb_window_neg")
         unet = m.post_fusion_unet
@@ -409,19 +422,26 @@ class SyncChain:
             gt_f = gt[s0:s1].repeat_interleave(T, dim=0)                      # each window frame sees its sample's main frame
             coord_f = cw[s0:s1].reshape(n * T, FH, FW, 2)
             new, _ = m.composite_clip(lips[fr], rgb_face_canonical, gt_f, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_f)
-            recon, saved = unet.forward_saved_nhwc(new)
-            win = window[s0:s1]
+            crop = new[:, wy0:wy1, wx0:wx1].contiguous() if self.window else new
+            ch, cw_ = crop.shape[1], crop.shape[2]
+            recon, saved = unet.forward_saved_nhwc(crop, window=win)
+            wnd = window[s0:s1]
             with torch.cuda.device(dev):
-                ck(lib.s2l_crop_resize(_ptr(recon), FH, FW, x, y, x2, y2, _ptr(win), oh, ow, T, n * T, _stream()), "s2l_crop_resize")
+                ck(lib.s2l_crop_resize(_ptr(recon), ch, cw_, x - wx0, y - wy0, x2 - wx0, y2 - wy0, _ptr(wnd), oh, ow, T, n * T, _stream()),
+                   "s2l_crop_resize")
             # BCE is a mean over the batch: this group's share of the mean over all S samples
-            loss, d_win = self.sync.get_sync_contrastive_loss(mel[s0:s1], win, neg[s0:s1], weight=self.w * n / S, want_grad=True)
+            loss, d_win = self.sync.get_sync_contrastive_loss(mel[s0:s1], wnd, neg[s0:s1], weight=self.w * n / S, want_grad=True)
             total = total + loss
             d_recon = torch.empty_like(recon)
             with torch.cuda.device(dev):
-                ck(lib.s2l_crop_resize_backward(_ptr(d_win), FH, FW, x, y, x2, y2, _ptr(d_recon), oh, ow, T, n * T, _stream()),
-                   "s2l_crop_resize_backward")
+                ck(lib.s2l_crop_resize_backward(_ptr(d_win), ch, cw_, x - wx0, y - wy0, x2 - wx0, y2 - wy0, _ptr(d_recon), oh, ow, T, n * T,
+                                                _stream()), "s2l_crop_resize_backward")
             d_new = unet.backward_input(saved, d_recon)
             del saved, recon, d_recon
+            if self.window:   # the gradient is exactly zero outside the crop (its support is the box dilated by <= 32 pixels)
+                full = torch.zeros(n * T, FH, FW, 3, dtype=torch.float32, device=dev)
+                full[:, wy0:wy1, wx0:wx1] = d_new
+                d_new = full
             d_lips[fr] = m.composite_backward_lip(d_new, rgb_face_canonical, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
                                                   coord_f, lips.shape[1], lips.shape[2])
         return total, d_lips, window

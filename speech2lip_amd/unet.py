@@ -181,9 +181,11 @@ class SimpleUnetLight(nn.Module):
             off += n
         return dx, grads
 
-    def forward_saved_nhwc(self, x: torch.Tensor):
+    def forward_saved_nhwc(self, x: torch.Tensor, window=None):
         """Training-time forward of the frozen eval-mode network: x [F,H,W,3] -> (out [F,H,W,3], saved), where `saved` holds
-        every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F."""
+        every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F.
+        window = (full_h, full_w, origin_y, origin_x): x is a crop of a full frame (s2l_unet_forward_saved_window); values
+        within 32 pixels of a crop edge that is not a frame edge are not the full-frame values."""
         lib = _abi.load()
         packed = self.packed_weights()
         if x.device.type != "cuda":
@@ -198,15 +200,17 @@ class SimpleUnetLight(nn.Module):
         saved = torch.empty(int(lib.s2l_unet_saved_floats(H, W, F_)), dtype=torch.float32, device=x.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(x.device):
-            _abi.check(lib.s2l_unet_forward_saved(p(packed), p(x), p(saved), p(out), H, W, F_,
-                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_forward_saved")
-        return out, (saved, packed, (F_, H, W))
+            fh, fw, oy, ox = (H, W, 0, 0) if window is None else (int(v) for v in window)
+            _abi.check(lib.s2l_unet_forward_saved_window(p(packed), p(x), p(saved), p(out), H, W, fh, fw, oy, ox, F_,
+                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "s2l_unet_forward_saved_window")
+        return out, (saved, packed, (F_, H, W), (fh, fw, oy, ox))
 
     def backward_input(self, saved_ctx, d_out: torch.Tensor) -> torch.Tensor:
         """d loss / d x [F,H,W,3] from d loss / d out, through the frozen network (what autograd propagates once the
         post-fusion net is fixed, train.py:188-197)."""
         lib = _abi.load()
-        saved, packed, (F_, H, W) = saved_ctx
+        saved, packed, (F_, H, W), (fh, fw, oy, ox) = saved_ctx
         d = d_out.detach().to(torch.float32).contiguous()
         if d.shape != (F_, H, W, 3) or d.device != saved.device:
             raise ValueError(f"d_out must be [{F_},{H},{W},3] on {saved.device}")
@@ -214,8 +218,8 @@ class SimpleUnetLight(nn.Module):
         work = torch.empty(int(lib.s2l_unet_backward_work_floats(H, W, F_)), dtype=torch.float32, device=d.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(d.device):
-            _abi.check(lib.s2l_unet_backward(p(packed), p(saved), p(d), p(work), p(dx), H, W, F_,
-                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward")
+            _abi.check(lib.s2l_unet_backward_window(p(packed), p(saved), p(d), p(work), p(dx), H, W, fh, fw, oy, ox, F_,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward_window")
         return dx
 
     def forward(self, x, x_level1=None, x_level2=None):

@@ -528,3 +528,27 @@ def test_stage_one_step_before_the_unet_is_fixed_autograd(golden, dev):
             else:
                 assert float(err.max()) <= 1e-3, (name, float(err.max()))
     assert int(m.post_fusion_unet.inc.double_conv[1].num_batches_tracked) == 101      # 100 in the seeded state dict + this step
+
+
+def test_sync_chain_unet_window_is_bit_identical_to_full_frames(golden, syncnet, dev):
+    """SyncChain runs the frozen U-Net on the canonical-face box dilated by the network's dependency radius instead of the whole
+    frame.  Same generated window (bit for bit), same loss, same lip gradient as the full-frame evaluation -- at the reference's
+    500x500 frame with a box well inside it, and with a box that touches two frame edges."""
+    rng = np.random.default_rng(8)
+    m = full_model(dev, 96, 96)
+    S, Tn, FH, FW, x0, y0 = 1, 5, 500, 500, 202, 316
+    lips = T(rng.random((S * Tn, 96, 96, 3), dtype=np.float32)).to(dev)
+    face = T(W.synthetic_image((1, FH, FW, 3), 2, "face")).to(dev)
+    gt = T(W.synthetic_image((S, FH, FW, 3), 3, "gt")).to(dev)
+    mask = torch.zeros(1, FH, FW, 3, device=dev)
+    mask[:, y0:y0 + 96, x0:x0 + 96] = 1
+    cw = T(W.synthetic_warp_coords(S * Tn, FH, FW, seed=9)).reshape(S, Tn, FH, FW, 2).to(dev)
+    mel, _, neg = (T(x).to(dev) for x in W.synthetic_sync_batch(S, seed=6))
+    for bbox in ([110, 150, 390, 470, 1.0], [200, 260, 500, 500, 1.0], [0, 0, 500, 500, 1.0]):
+        args = (face, gt, mask, x0, y0, cw, bbox, mel, neg)
+        l_w, d_w, win_w = s2l.SyncChain(m, syncnet, window=True).loss_and_dlip(lips, *args)
+        l_f, d_f, win_f = s2l.SyncChain(m, syncnet, window=False).loss_and_dlip(lips, *args)
+        assert torch.equal(win_w, win_f), bbox
+        assert float(l_w) == float(l_f)
+        assert float(d_f.abs().max()) > 0
+        assert relerr(d_w, d_f.cpu()) <= 1e-5, (bbox, relerr(d_w, d_f.cpu()))      # float atomics in the composite's scatter
