@@ -384,6 +384,15 @@ class SyncChain:
         # comes back, is bit-identical to the full-frame evaluation (s2l_unet_forward_saved_window)
         self.window = bool(window)
 
+    def unet_window(self, bbox, FH: int, FW: int):
+        """(x0, y0, x1, y1) of the crop the U-Net runs on: the box dilated by UNET_RADIUS, on the 4-pixel grid of the two pooling
+        levels, clipped to the frame; the whole frame with window=False."""
+        if not self.window:
+            return 0, 0, FW, FH
+        x, y, x2, y2 = (int(v) for v in list(bbox)[:4])
+        r = self.UNET_RADIUS
+        return (max(0, (x - r) // 4 * 4), max(0, (y - r) // 4 * 4), min(FW, -(-(x2 + r) // 4) * 4), min(FH, -(-(y2 + r) // 4) * 4))
+
     def loss_and_dlip(self, lips, rgb_face_canonical, rgb_face_gt, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y,
                       coord_window, canonical_face_bbox, mel, rgb_window_neg):
         """lips [S*T,h,w,3] (sample-major: frame s*T + t); rgb_face_canonical, mask_lip_canonical [1,FH,FW,3] (per clip);
@@ -403,12 +412,7 @@ class SyncChain:
             raise ValueError("rgb_face_gt must be [S,FH,FW,3] and coord_window [S,T,FH,FW,2]")
         x, y, x2, y2 = (int(v) for v in list(canonical_face_bbox)[:4])
         oh, ow = self.out_hw
-        r = self.UNET_RADIUS
-        if self.window:       # crop origin / size on the 4-pixel grid of the two pooling levels, clipped to the frame
-            wx0, wy0 = max(0, (x - r) // 4 * 4), max(0, (y - r) // 4 * 4)
-            wx1, wy1 = min(FW, -(-(x2 + r) // 4) * 4), min(FH, -(-(y2 + r) // 4) * 4)
-        else:
-            wx0, wy0, wx1, wy1 = 0, 0, FW, FH
+        wx0, wy0, wx1, wy1 = self.unet_window((x, y, x2, y2), FH, FW)
         win = (FH, FW, wy0, wx0)
         mel = _dev_f32(mel, dev, "mel")
         neg = _dev_f32(rgb_window_neg, dev, "rgb_window_neg")

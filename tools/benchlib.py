@@ -181,8 +181,9 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
     """BASELINE config 5 as named -- MLP forward + backward WITH the lipsync_expert loss: B main frames (MSE) of which the
     first S carry a 5-frame sync window (5 S more renders -> composite -> frozen U-Net @500x500 -> crop/resize -> SyncNet x2 ->
     BCE, and all of it back to the MLP), bf16 MLP kernels, Adam.  FLOPs counted: the MLP's as-written 3 x 4 x 2 x 644,864 per
-    pixel-frame over B + 5 S frames, plus 3 x 157.6 GFLOP per window frame for the U-Net forward + input gradient (2 passes
-    counted as forward + one backward of equal cost) -- reported separately."""
+    pixel-frame over B + 5 S frames, plus 2 x 157.6 GFLOP per 500x500 window frame for the U-Net forward + input gradient, scaled
+    by the share of the frame the chain actually evaluates (the face box dilated by the network's dependency radius) --
+    reported separately."""
     H = Wd = 96
     m = make_model(dev, H, Wd, unet=True, train=True)
     m.post_fusion_unet.eval()
@@ -208,10 +209,11 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     mlp = train_flops(B + 5 * S, H * Wd)
-    unet = 2 * 157.6e9 * 5 * S
+    wx0, wy0, wx1, wy1 = step.chain.unet_window(sync["canonical_face_bbox"], 500, 500) if S else (0, 0, 500, 500)
+    unet = 2 * 157.6e9 * 5 * S * ((wx1 - wx0) * (wy1 - wy0) / 250000.0)     # the U-Net runs on the face box + its dependency radius
     return {"config": f"stage-1 step, {B} main frames 96x96 + sync loss on {S} samples ({5 * S} window frames through composite + U-Net "
                       f"@500x500 + SyncNet), {precision} MLP, Adam", "ms_per_step": round(dt * 1e3, 2),
-            "mlp_frames_per_step": B + 5 * S, "mlp_tflop_per_step": round(mlp / 1e12, 3), "unet_tflop_per_step": round(unet / 1e12, 3),
+            "unet_window": [wx0, wy0, wx1, wy1], "mlp_frames_per_step": B + 5 * S, "mlp_tflop_per_step": round(mlp / 1e12, 3), "unet_tflop_per_step": round(unet / 1e12, 3),
             "tflops": round((mlp + unet) / dt / 1e12, 1), "loss_first": l0, "loss_last": float(l),
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
