@@ -37,10 +37,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    # the renderer's kernel body is generated assembly text (csrc/gen_render_body.py), included by render.hip
+    sys.path.insert(0, CSRC)
+    try:
+        import gen_render_body
+        gen_render_body.main(os.path.join(objdir, "render_body.inc"))
+    finally:
+        sys.path.pop(0)
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, "-I", objdir, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1,0 +1,456 @@
+"""Generates render_body.inc: the body of s2l::render_tiles_kernel (csrc/render.hip) as ONE fixed-register gfx950 assembly
+text (build.py runs this before hipcc; the kernel `#include`s the result inside an `asm volatile`).
+
+Why assembly: the renderer runs one wave per SIMD (512 registers), and on CDNA4 a wave's VALU instructions do NOT overlap its
+own MFMAs -- every VALU instruction between two MFMAs costs its 4 cycles plus a ~9-cycle pipe switch
+(tools/ubench/gen_mfma_shadow.py), while LDS reads, LDS-DMA issues and SALU are free.  So the layer body must contain nothing
+but MFMAs, ds_reads and scalar code, with the few unavoidable VALU instructions (ReLU = accvgpr_read + v_max per value, one
+ring-address add per slab) bunched.  hipcc's version of the same loop spends 106.9 k cycles per layer; this schedule spends
+101 k (tools/ubench/gen_layer_asm.py), the MFMAs alone 98.3 k.  The arithmetic -- operands, accumulation order, roundings -- is
+that of the C++ kernel it replaces: frames are bit-identical.
+
+Structure (see render.hip for the tile / ring / table description): 117 ring steps per tile; a layer = 16 slabs of
+16 k-quads x 4 k-steps x 3 sample groups = 3072 MFMAs; A quads come from the ring two quads ahead into four rotating
+register sets; the slab's bias is read straight into AGPRs and enters as srcC of the first three MFMAs; at k-quad 14 the
+slab's buffer is retired (lgkmcnt / vmcnt / s_barrier) and refilled by four LDS-DMA loads tucked behind MFMAs.
+
+Register map (per wave):  v0-191 B operands in[g][k] | v192-207 four A-quad sets | v208.. addresses and temporaries
+                          a0-191 accumulators acc[g][mb][r] | a192-195 bias / srcC | a196-207 output-layer accumulators
+                          s36.. scalar state (ring position, weight-slab pointer, tile coordinates, table pointers)."""
+import os
+import sys
+
+G = 3
+KRING, SLAB, NSLABS, NLAYERS = 9, 16384, 113, 7
+
+# ---- vector registers
+V_IN, V_W = 0, 192
+V_LANE16, V_RING, V_DMAOFF, V_BIAS, V_QADDR, V_TMP, V_BOUT, V_PIXOFF = 208, 209, 210, 211, 212, 213, 214, 215
+V_T0, V_BIAS0, V_PIX = 216, 220, 221          # V_T0..V_T0+3: one f4 of temporaries
+V_LAST = 223
+A_ACC, A_BIAS, A_RGB = 0, 192, 196
+A_LAST = 207
+# ---- scalar registers (all owned by the body; the compiler's operands live elsewhere)
+S = {n: 36 + i for i, n in enumerate(
+    "CUR T LDSBASE CURB WPTR WPTR1 WBASE WBASE1 IS LAYER FG PG NPG GDIV GMOD TILE NTILES GRID NFM1 HW FGN PGN FGL PGL "
+    "Q0 Q01 Q5 Q51 P0 P01 P5 P51 OUT OUT1 WAVE PAD T4 T5 T6 T7 T8 T9 EX EX1 NFRAMES".split())}
+# pairs must be even-aligned
+for pair in ("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX"):
+    assert S[pair] % 2 == 0, pair
+S_LAST = max(S.values())
+
+
+def s(n):
+    return f"s{S[n]}"
+
+
+def s2(n):
+    return f"s[{S[n]}:{S[n] + 1}]"
+
+
+class Body:
+    def __init__(self):
+        self.L, self.lds, self.nlabel = [], [], 0
+
+    def e(self, t):
+        self.L.append(t)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"S2L_{stem}_{self.nlabel}"
+
+    # ---- LDS bookkeeping: ops return in order, lgkmcnt(n) = "at most n still out"
+    def lds_op(self, text, tag):
+        self.e(text)
+        self.lds.append(tag)
+
+    def wait_lds(self, tag):
+        if tag not in self.lds:
+            return
+        newer = len(self.lds) - 1 - self.lds.index(tag)
+        assert newer <= 15, "lgkmcnt is a 4-bit counter"
+        self.e(f"s_waitcnt lgkmcnt({newer})")
+        self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    def wait_all_lds(self):
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.lds = []
+
+    # ---- registers
+    @staticmethod
+    def acc(g, mb):
+        b = A_ACC + (g * 16 + mb) * 4
+        return f"a[{b}:{b + 3}]"
+
+    @staticmethod
+    def inreg(g, k):
+        return V_IN + g * 64 + k
+
+    # ---- ring protocol
+    def advance(self):
+        """Publish the next step, retire the current one: s[T] = LDS address of the retired buffer's quarter owned by this
+        wave, CUR / CURB / v[RING] move on.  Precondition: this wave's LDS reads of the current step have returned."""
+        e = self.e
+        e("s_waitcnt vmcnt(28)")
+        e("s_barrier")
+        e(f"s_add_u32 {s('T')}, {s('CURB')}, {s('LDSBASE')}")
+        e(f"s_add_u32 {s('CUR')}, {s('CUR')}, 1")
+        e(f"s_cmp_eq_u32 {s('CUR')}, {KRING}")
+        e(f"s_cselect_b32 {s('CUR')}, 0, {s('CUR')}")
+        e(f"s_lshl_b32 {s('CURB')}, {s('CUR')}, 14")
+        e(f"v_add_u32 v{V_RING}, {s('CURB')}, v{V_LANE16}")
+
+    def weight_refill_setup(self):
+        """m0 / s[T4:T5] for the four loads of the next weight slab into the retired buffer; moves the slab pointer on."""
+        e = self.e
+        e(f"s_mov_b32 m0, {s('T')}")
+        e(f"s_mov_b64 {s2('T4')}, {s2('WPTR')}")
+        e(f"s_add_u32 {s('WPTR')}, {s('WPTR')}, {SLAB}")
+        e(f"s_addc_u32 {s('WPTR1')}, {s('WPTR1')}, 0")
+        e(f"s_add_u32 {s('IS')}, {s('IS')}, 1")
+        e(f"s_cmp_eq_u32 {s('IS')}, {NSLABS}")
+        e(f"s_cselect_b64 {s2('WPTR')}, {s2('WBASE')}, {s2('WPTR')}")
+        e(f"s_cselect_b32 {s('IS')}, 0, {s('IS')}")
+
+    def dma4(self):
+        return [f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('T4')} offset:{1024 * k}" for k in range(4)]
+
+    def weight_refill(self):
+        self.weight_refill_setup()
+        for t in self.dma4():
+            self.e(t)
+
+    def p_refill(self, ptab, pg):
+        """issue_p: 16 KiB of the pixel table of pixel group `pg` (same shape as a weight slab)."""
+        e = self.e
+        e(f"s_mov_b32 m0, {s('T')}")
+        e(f"s_mov_b32 {s('T8')}, {s(pg)}")
+        e(f"s_mov_b32 {s('T9')}, 0")
+        e(f"s_lshl_b64 {s2('T8')}, {s2('T8')}, 14")
+        e(f"s_add_u32 {s('T4')}, {s(ptab)}, {s('T8')}")
+        e(f"s_addc_u32 {s('T5')}, {s(ptab + '1')}, {s('T9')}")
+        for t in self.dma4():
+            e(t)
+
+    def q_refill(self, qtab, fg):
+        """issue_q: rows of the frame table for frames fg*12 + wave*4 + i, clamped to the last frame; 1 KiB each."""
+        e = self.e
+        e(f"s_mul_i32 {s('T6')}, {s(fg)}, 12")
+        e(f"s_lshl_b32 {s('T7')}, {s('WAVE')}, 2")
+        e(f"s_add_u32 {s('T6')}, {s('T6')}, {s('T7')}")
+        for i in range(4):
+            e(f"s_add_u32 {s('T8')}, {s('T6')}, {i}")
+            e(f"s_min_u32 {s('T8')}, {s('T8')}, {s('NFM1')}")
+            e(f"s_mov_b32 {s('T9')}, 0")
+            e(f"s_lshl_b64 {s2('T8')}, {s2('T8')}, 10")
+            e(f"s_add_u32 {s('T4')}, {s(qtab)}, {s('T8')}")
+            e(f"s_addc_u32 {s('T5')}, {s(qtab + '1')}, {s('T9')}")
+            e(f"s_add_u32 m0, {s('T')}, {1024 * i}")
+            e("s_nop 0")
+            e(f"global_load_lds_dwordx4 v{V_LANE16}, {s2('T4')}")
+
+    # ---- one slab
+    def quad_mfmas(self, mb, j, dst, first_c=None, sprinkle=()):
+        """12 MFMAs of k-quad j; `sprinkle`: instructions tucked behind the MFMAs 0, 3, 6, 9."""
+        sprinkle = list(sprinkle)
+        w = V_W + 4 * (j % 4)
+        for jj in range(4):
+            for g in range(G):
+                c = first_c if (first_c and j == 0 and jj == 0) else dst(g)
+                self.e(f"v_mfma_f32_16x16x4_f32 {dst(g)}, v{w + jj}, v{self.inreg(g, j * 4 + jj)}, {c}")
+                if sprinkle and (jj * G + g) % 3 == 0:
+                    self.e(sprinkle.pop(0))
+        assert not sprinkle
+
+    def a_read(self, slab_tag, tq):
+        wset = V_W + 4 * (tq % 4)
+        self.lds_op(f"ds_read_b128 v[{wset}:{wset + 3}], v{V_RING} offset:{1024 * (tq % 16)}", ("A", slab_tag + tq // 16, tq % 16))
+
+    def slab(self, mb, special=None):
+        """special: list of (layer, out-of-line refill emitter) for the table steps issued from this slab position."""
+        e = self.e
+        dst = lambda g: self.acc(g, mb)
+        for j in range(16):
+            sprinkle = ()
+            if j == 14:
+                self.wait_lds(("A", mb, 15))      # both remaining quads of this slab are in registers
+                self.advance()
+            self.a_read(mb, j + 2)
+            if j == 8:      # next slab's bias (srcC of its first MFMAs); row offset of the next layer for the last slab
+                self.lds_op(f"ds_read_b128 a[{A_BIAS}:{A_BIAS + 3}], v{V_BIAS} offset:{(mb + 1) * 64}", ("B", mb + 1))
+            self.wait_lds(("A", mb, j))
+            if j == 0:
+                self.wait_lds(("B", mb))
+            if j == 14:
+                join = self.label("join")
+                for layer, emit in (special or []):
+                    ol = self.label("table")
+                    e(f"s_cmp_eq_u32 {s('LAYER')}, {layer}")
+                    e(f"s_cbranch_scc1 {ol}")
+                    self.outofline.append((ol, join, emit, mb, j))
+                self.weight_refill_setup()
+                e("s_nop 0")
+                sprinkle = self.dma4()
+            self.quad_mfmas(mb, j, dst, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]", sprinkle=sprinkle)
+            if j == 14:
+                e(f"{join}:")
+
+    def relu_all(self):
+        e = self.e
+        e("s_nop 7")
+        e("s_nop 3")
+        for mb in range(16):
+            for g in range(G):
+                b = A_ACC + (g * 16 + mb) * 4
+                for r in range(4):
+                    e(f"v_accvgpr_read_b32 v{self.inreg(g, mb * 4 + r)}, a{b + r}")
+                for r in range(4):
+                    v = self.inreg(g, mb * 4 + r)
+                    e(f"v_max_f32 v{v}, 0, v{v}")
+
+    # ---- table steps
+    def q_step(self, with_acc):
+        """in[g][k] = (acc[g][k] +) q[frame of g][k].  q step: 16 rows of 1 KiB; this wave's frames are rows wave*3 + g."""
+        e = self.e
+        e(f"v_add_u32 v{V_TMP}, {s('CURB')}, v{V_QADDR}")
+        if not with_acc:
+            for g in range(G):
+                for mb in range(16):
+                    b = self.inreg(g, mb * 4)
+                    self.lds_op(f"ds_read_b128 v[{b}:{b + 3}], v{V_TMP} offset:{g * 1024 + mb * 64}", ("Q", g, mb))
+            self.wait_all_lds()
+            return
+        e("s_nop 7")
+        e("s_nop 3")
+        items = [(g, mb) for g in range(G) for mb in range(16)]
+        for n in range(3):
+            g, mb = items[n]
+            t = V_W + 4 * (n % 4)
+            self.lds_op(f"ds_read_b128 v[{t}:{t + 3}], v{V_TMP} offset:{g * 1024 + mb * 64}", ("Q", g, mb))
+        for n, (g, mb) in enumerate(items):
+            if n + 3 < len(items):
+                g2, mb2 = items[n + 3]
+                t2 = V_W + 4 * ((n + 3) % 4)
+                self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_TMP} offset:{g2 * 1024 + mb2 * 64}", ("Q", g2, mb2))
+            b, a0, t = self.inreg(g, mb * 4), A_ACC + (g * 16 + mb) * 4, V_W + 4 * (n % 4)
+            for r in range(4):
+                e(f"v_accvgpr_read_b32 v{b + r}, a{a0 + r}")
+            self.wait_lds(("Q", g, mb))
+            e(f"v_pk_add_f32 v[{b}:{b + 1}], v[{b}:{b + 1}], v[{t}:{t + 1}]")
+            e(f"v_pk_add_f32 v[{b + 2}:{b + 3}], v[{b + 2}:{b + 3}], v[{t + 2}:{t + 3}]")
+        self.wait_all_lds()
+
+    def p_step(self):
+        """in[g][k] = relu(in[g][k] + p[pixel][k]); p step: [mb][lane] f4, i.e. lane-linear like an A quad."""
+        e = self.e
+        for mb in range(3):
+            t = V_W + 4 * (mb % 4)
+            self.lds_op(f"ds_read_b128 v[{t}:{t + 3}], v{V_RING} offset:{mb * 1024}", ("P", mb))
+        for mb in range(16):
+            if mb + 3 < 16:
+                t2 = V_W + 4 * ((mb + 3) % 4)
+                self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_RING} offset:{(mb + 3) * 1024}", ("P", mb + 3))
+            self.wait_lds(("P", mb))
+            t = V_W + 4 * (mb % 4)
+            for g in range(G):
+                b = self.inreg(g, mb * 4)
+                e(f"v_pk_add_f32 v[{b}:{b + 1}], v[{b}:{b + 1}], v[{t}:{t + 1}]")
+                e(f"v_pk_add_f32 v[{b + 2}:{b + 3}], v[{b + 2}:{b + 3}], v[{t + 2}:{t + 3}]")
+                for r in range(4):
+                    e(f"v_max_f32 v{b + r}, 0, v{b + r}")
+        self.wait_all_lds()
+
+    def prefetch_first_quads(self, with_bias):
+        if with_bias:
+            self.e(f"ds_read_b128 a[{A_BIAS}:{A_BIAS + 3}], v{V_BIAS}")
+            self.wait_all_lds()
+        self.a_read(0, 0)
+        self.a_read(0, 1)
+
+
+def generate():
+    b = Body()
+    b.outofline = []
+    e = b.e
+    # ================= prologue: operands -> owned registers
+    for dst, src in (("LDSBASE", "ldsbase"), ("NPG", "npg"), ("GDIV", "gdiv"), ("GMOD", "gmod"), ("TILE", "tile0"), ("NTILES", "ntiles"),
+                     ("GRID", "grid"), ("NFRAMES", "nframes"), ("HW", "hw"), ("FG", "fg0"), ("PG", "pg0"), ("FGL", "fgl"), ("PGL", "pgl"),
+                     ("WAVE", "wave")):
+        e(f"s_mov_b32 {s(dst)}, %[{src}]")
+    for dst, src in (("WBASE", "wsrc"), ("Q0", "q0"), ("Q5", "q5"), ("P0", "p0"), ("P5", "p5"), ("OUT", "out")):
+        e(f"s_mov_b64 {s2(dst)}, %[{src}]")
+    e(f"s_mov_b64 {s2('WPTR')}, {s2('WBASE')}")
+    e(f"s_sub_u32 {s('NFM1')}, {s('NFRAMES')}, 1")
+    e(f"s_mov_b32 {s('IS')}, 0")
+    e(f"s_mov_b32 {s('CUR')}, 0")
+    e(f"s_mov_b32 {s('CURB')}, 0")
+    for dst, src in ((V_LANE16, "lane16"), (V_DMAOFF, "dmaoff"), (V_BIAS0, "biasaddr"), (V_QADDR, "qaddr"), (V_BOUT, "boutaddr"), (V_PIX, "px")):
+        e(f"v_mov_b32 v{dst}, %[{src}]")
+    e(f"v_mov_b32 v{V_RING}, v{V_LANE16}")
+    # prime the ring: q0 and p0 of the first tile, weight slabs 0..5 (steps 0..7 -> buffers 0..7)
+    e(f"s_mov_b32 {s('T')}, {s('LDSBASE')}")
+    b.q_refill("Q0", "FG")
+    e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB}")
+    b.p_refill("P0", "PG")
+    for st in range(2, KRING - 1):
+        e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB * st}")
+        b.weight_refill_setup()
+        e("s_nop 0")
+        for t in b.dma4():
+            e(t)
+    # step 0 landed and published (with the bias block the C++ prologue wrote); top the ring up
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_waitcnt vmcnt(28)")
+    e("s_barrier")
+    e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB * (KRING - 1)}")
+    b.weight_refill_setup()
+    e("s_nop 0")
+    for t in b.dma4():
+        e(t)
+
+    # ================= tile loop
+    e("S2L_TILE:")
+    # coordinates of the tile whose tables are prefetched during layer 6: this workgroup's next tile, or the last tile
+    e(f"s_add_u32 {s('PGN')}, {s('PG')}, {s('GMOD')}")
+    e(f"s_add_u32 {s('FGN')}, {s('FG')}, {s('GDIV')}")
+    e(f"s_cmp_ge_u32 {s('PGN')}, {s('NPG')}")
+    e(f"s_cselect_b32 {s('T6')}, {s('NPG')}, 0")
+    e(f"s_cselect_b32 {s('T7')}, 1, 0")
+    e(f"s_sub_u32 {s('PGN')}, {s('PGN')}, {s('T6')}")
+    e(f"s_add_u32 {s('FGN')}, {s('FGN')}, {s('T7')}")
+    e(f"s_add_u32 {s('T7')}, {s('TILE')}, {s('GRID')}")
+    e(f"s_cmp_lt_u32 {s('T7')}, {s('NTILES')}")
+    e(f"s_cselect_b32 {s('FGN')}, {s('FGN')}, {s('FGL')}")
+    e(f"s_cselect_b32 {s('PGN')}, {s('PGN')}, {s('PGL')}")
+    # ---- h0 = relu(p0[pixel] + q0[frame])
+    b.q_step(False)
+    b.advance()
+    b.weight_refill()
+    b.p_step()
+    b.advance()
+    b.weight_refill()
+    e(f"v_mov_b32 v{V_BIAS}, v{V_BIAS0}")
+    e(f"s_mov_b32 {s('LAYER')}, 0")
+    b.prefetch_first_quads(True)
+    loop_state = list(b.lds)
+
+    # ---- the layer loop
+    e("S2L_LAYER:")
+    q5 = lambda: b.q_refill("Q5", "FG")
+    p5 = lambda: b.p_refill("P5", "PG")
+    q0n = lambda: b.q_refill("Q0", "FGN")
+    p0n = lambda: b.p_refill("P0", "PGN")
+    for mb in range(16):
+        b.slab(mb, {7: [(4, q5)], 8: [(4, p5), (6, q0n)], 9: [(6, p0n)]}.get(mb))
+    end_state = [(t[0], t[1] - 16) + t[2:] for t in b.lds]
+    assert end_state == loop_state, (end_state, loop_state)
+    e(f"s_cmp_eq_u32 {s('LAYER')}, 4")
+    e("s_cbranch_scc1 S2L_SKIP")
+    b.relu_all()
+    e(f"s_add_u32 {s('LAYER')}, {s('LAYER')}, 1")
+    e(f"v_add_u32 v{V_BIAS}, 1024, v{V_BIAS}")
+    e(f"s_cmp_lt_u32 {s('LAYER')}, {NLAYERS}")
+    e("s_cbranch_scc1 S2L_LAYER")
+
+    # ---- output layer (3 rows padded to one M-block), no activation; quads 0, 1 of its slab are in flight
+    b.lds = list(loop_state)
+    b.lds_op(f"ds_read_b128 a[{A_BIAS}:{A_BIAS + 3}], v{V_BOUT}", ("B", 0))
+    rgb = lambda g: f"a[{A_RGB + 4 * g}:{A_RGB + 4 * g + 3}]"
+    for j in range(16):
+        if j + 2 < 16:
+            b.a_read(0, j + 2)
+        b.wait_lds(("A", 0, j))
+        if j == 0:
+            b.wait_lds(("B", 0))
+        b.quad_mfmas(0, j, rgb, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]")
+    b.wait_all_lds()
+    b.advance()               # publishes the next tile's q0 step
+    b.weight_refill()
+    # ---- store: lanes 0..15 (k-subgroup 0) hold rgb of pixel pg*16 + lane for the wave's three frames
+    e(f"s_lshl_b32 {s('T6')}, {s('PG')}, 4")
+    e(f"v_add_u32 v{V_TMP}, {s('T6')}, v{V_PIX}")
+    e(f"v_cmp_gt_u32 vcc, {s('HW')}, v{V_TMP}")
+    e(f"v_mul_u32_u24 v{V_PIXOFF}, 12, v{V_TMP}")
+    e(f"s_mov_b64 {s2('EX')}, exec")
+    e("s_nop 3")
+    e("s_and_b64 exec, vcc, 0xffff")
+    e(f"s_mul_i32 {s('T6')}, {s('FG')}, 12")
+    e(f"s_mul_i32 {s('T7')}, {s('WAVE')}, {G}")
+    e(f"s_add_u32 {s('T6')}, {s('T6')}, {s('T7')}")      # frame0
+    e("s_nop 7")
+    e("s_nop 7")
+    for g in range(G):
+        skip = b.label("nostore")
+        e(f"s_add_u32 {s('T7')}, {s('T6')}, {g}")
+        e(f"s_cmp_ge_u32 {s('T7')}, {s('NFRAMES')}")
+        e(f"s_cbranch_scc1 {skip}")
+        # byte offset of the frame = frame * hw * 12 (64-bit)
+        e(f"s_mul_hi_u32 {s('T9')}, {s('T7')}, {s('HW')}")
+        e(f"s_mul_i32 {s('T8')}, {s('T7')}, {s('HW')}")
+        e(f"s_mul_i32 {s('T9')}, {s('T9')}, 12")
+        e(f"s_mul_hi_u32 {s('T7')}, {s('T8')}, 12")
+        e(f"s_mul_i32 {s('T8')}, {s('T8')}, 12")
+        e(f"s_add_u32 {s('T9')}, {s('T9')}, {s('T7')}")
+        e(f"s_add_u32 {s('T4')}, {s('OUT')}, {s('T8')}")
+        e(f"s_addc_u32 {s('T5')}, {s('OUT1')}, {s('T9')}")
+        e(f"global_store_dwordx3 v{V_PIXOFF}, a[{A_RGB + 4 * g}:{A_RGB + 4 * g + 2}], {s2('T4')}")
+        e(f"{skip}:")
+    e(f"s_mov_b64 exec, {s2('EX')}")
+    # ---- next tile of this workgroup
+    e(f"s_add_u32 {s('TILE')}, {s('TILE')}, {s('GRID')}")
+    e(f"s_mov_b32 {s('FG')}, {s('FGN')}")
+    e(f"s_mov_b32 {s('PG')}, {s('PGN')}")
+    e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
+    e("s_cbranch_scc1 S2L_TILE")
+    e("s_waitcnt vmcnt(0)")     # run-ahead DMAs must land before the workgroup's LDS is released
+    e("s_branch S2L_END")
+
+    # ================= out of line: pts_linears[5] on cat([skip, h4]): + q5[frame] + p5[pixel], ReLU
+    e("S2L_SKIP:")
+    b.lds = list(loop_state)   # (quads read from the q5 step: discarded)
+    b.wait_all_lds()
+    b.q_step(True)
+    b.advance()
+    b.weight_refill()
+    b.p_step()
+    b.advance()
+    b.weight_refill()
+    e(f"s_mov_b32 {s('LAYER')}, 5")
+    e(f"v_add_u32 v{V_BIAS}, 1024, v{V_BIAS}")
+    b.prefetch_first_quads(False)
+    assert b.lds == loop_state
+    e("s_branch S2L_LAYER")
+    # ================= out of line: the four table refills per tile (the slab's k-quad 14 is repeated here without DMA tucks)
+    for ol, join, emit, mb, j in b.outofline:
+        e(f"{ol}:")
+        emit()
+        b.quad_mfmas(mb, j, lambda g: b.acc(g, mb))
+        e(f"s_branch {join}")
+    e("S2L_END:")
+    return [x for x in b.L if x is not None]
+
+
+OPERANDS = """      :
+      : [ldsbase] "s"(ldsbase), [npg] "s"(a.npg), [gdiv] "s"(gdiv), [gmod] "s"(gmod), [tile0] "s"(tile0), [ntiles] "s"(a.ntiles),
+        [grid] "s"(grid), [nframes] "s"(a.nframes), [hw] "s"(a.hw), [fg0] "s"(fg0), [pg0] "s"(pg0), [fgl] "s"(fgl), [pgl] "s"(pgl),
+        [wave] "s"(wave), [wsrc] "s"(wsrc), [q0] "s"(a.q0), [q5] "s"(a.q5), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [out] "s"(a.out),
+        [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px)
+"""
+
+
+def main(path):
+    lines = generate()
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(36, S_LAST + 1)]
+    clob += ["vcc", "scc", "memory"]   # (m0 and exec: nothing follows the body; exec is restored)
+    out = ["// GENERATED by csrc/gen_render_body.py -- do not edit; the generator is the source.", "asm volatile("]
+    out += [f'    "{x}\\n\\t"' for x in lines]
+    out.append(OPERANDS.rstrip("\n"))
+    out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return len(lines)
+
+
+if __name__ == "__main__":
+    n = main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "render_body.inc"))
+    print(f"render_body.inc: {n} instructions")

@@ -21,6 +21,16 @@
 //     buffer of step s".  The barrier publishes step s+1 and retires step s.
 #include "s2l_common.h"
 
+#ifndef S2L_RENDER_ASM
+#define S2L_RENDER_ASM 1
+#endif
+#ifndef S2L_RENDER_CONV
+#define S2L_RENDER_CONV 0
+#endif
+#ifndef S2L_RENDER_G
+#define S2L_RENDER_G 3
+#endif
+
 namespace s2l {
 
 struct RenderArgs {
@@ -45,7 +55,7 @@ constexpr int kBiasFloats = kHidden * kW + 4;  // OFF_BIAS .. OFF_BOUT+4 are con
 constexpr int kLdsBytes = kRing * kSlabBytes + kBiasFloats * 4;
 static_assert(OFF_WOUT == OFF_WMLP + int64_t(kHidden) * 16 * kSlab, "weight slabs must be contiguous");
 static_assert(OFF_BOUT == OFF_BIAS + kHidden * kW, "bias block must be contiguous");
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(kLdsBytes + 64 <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -105,7 +115,8 @@ __device__ long long* g_trace = nullptr;
 #endif
 
 template <int G>
-__global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
+__global__ __launch_bounds__(12 / G * 64) void render_tiles_kernel(RenderArgs a) {
+  constexpr int kThreads = 12 / G * 64;   // 12 frames per tile, G frames per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,9 +132,11 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   // loop needs no program counter and no branches: only 4 of the 117 issues per tile are tables.
   const char* wsrc = reinterpret_cast<const char*>(a.packed + OFF_WMLP) + wave * 4096 + lane * 16;
   auto dst_of = [&](int buf) { return lds_base + buf * kSlabBytes + wave * 4096; };
-  auto issue_w = [&](int ws, int buf) { dma_4k(wsrc + (int64_t)ws * kSlabBytes, dst_of(buf)); };
+  const bool mover = wave < 4;   // the ring is filled by the first four waves (one per SIMD), 4 KiB each per step
+  auto issue_w = [&](int ws, int buf) { if (mover) dma_4k(wsrc + (int64_t)ws * kSlabBytes, dst_of(buf)); };
   auto issue_q = [&](const float* qtab, int tile, int buf) {
     // 16 rows of q (12 used): row r = frame fg*12 + r, clamped; this wave moves rows 4w..4w+3
+    if (!mover) return;
     const char* qb = reinterpret_cast<const char*>(qtab) + lane * 16;
     const int f0 = (tile / a.npg) * kTileFrames + wave * 4;
 #pragma unroll
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
     }
   };
   auto issue_p = [&](const float* ptab, int tile, int buf) {
-    dma_4k(reinterpret_cast<const char*>(ptab) + wave * 4096 + lane * 16 + (int64_t)(tile % a.npg) * kSlabBytes,
+    if (mover) dma_4k(reinterpret_cast<const char*>(ptab) + wave * 4096 + lane * 16 + (int64_t)(tile % a.npg) * kSlabBytes,
            dst_of(buf));
   };
   // prime: steps 0..kDepth-1 of the first tile = q0, p0, weight slabs 0..kDepth-3
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   for (int s = 2; s < kDepth; ++s) issue_w(s - kStepW0, s);
 
   // biases -> LDS (ordinary loads; the ring is not read before the first barrier)
-  for (int i = threadIdx.x; i < kBiasFloats; i += 256)
+  for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
     reinterpret_cast<float*>(smem + kRing * kSlabBytes)[i] = a.packed[OFF_BIAS + i];
 
   // ---- consumer side ---------------------------------------------------------------------------
@@ -219,8 +232,12 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
 
     for (int layer = 0; layer < kHidden; ++layer) {
       const int cbase = kStepW0 + 16 * layer + (layer >= 5 ? 2 : 0);   // ring step of this layer's first slab
-#pragma unroll
-      for (int mb = 0; mb < 16; ++mb) {
+      // One slab = one M-block of 16 output features: 16 k-quads x 4 k-steps x G MFMAs.  `convert` (last slab of a layer whose
+      // output goes straight to the next layer): once k-quad j has been issued, block j of `in` is dead and block j of the
+      // accumulators has been final since slab j, so in[.][4j..4j+3] = relu(acc[.][j]) is written in place, one value behind
+      // each MFMA of k-quad j+1 -- the accumulator reads and the v_max ride in the shadow of the matrix pipe instead of standing
+      // between two layers.  Only block 15 (which this slab produces) is left for the end.
+      auto slab = [&](const int mb, const bool convert) {
         const f4* sl = ring + cur * kSlabQuads + lane;
         {
           const f4 b = *reinterpret_cast<const f4*>(lds_bias + layer * kW + mb * 16);
@@ -249,12 +266,21 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g][mb] = mfma16(w0[jj], in[g][j4 * 4 + jj], acc[g][mb]);
+            for (int g = 0; g < G; ++g) {
+              acc[g][mb] = mfma16(w0[jj], in[g][j4 * 4 + jj], acc[g][mb]);
+              if (convert && j4 >= 1) {
+                in[g][(j4 - 1) * 4 + jj] = relu1(acc[g][j4 - 1][jj]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
           __builtin_amdgcn_sched_barrier(0);
           w0 = w1;
           w1 = w2;
         }
-      }
+      };
+#pragma unroll
+      for (int mb = 0; mb < 15; ++mb) slab(mb, false);
+      slab(15, S2L_RENDER_CONV != 0);   // (for layer 4 the converted values are overwritten below: harmless, and free in the shadow)
       if (layer == 4) {
         // pts_linears[5] on cat([skip, h4]): + q5[frame] + p5[pixel] (q5 carries b5; bias row 4 is 0)
         add_q(true);
@@ -269,7 +295,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-          for (int mb = 0; mb < 16; ++mb)
+          for (int mb = S2L_RENDER_CONV ? 15 : 0; mb < 16; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) in[g][mb * 4 + r] = relu1(acc[g][mb][r]);
       }
@@ -317,6 +343,29 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   wait_vmcnt<0>();   // run-ahead (dummy) DMAs must land before the workgroup's LDS is released
 }
 
+#if S2L_RENDER_ASM
+// The same kernel with its body as one fixed-register assembly text (csrc/gen_render_body.py explains why and how).
+__global__ __launch_bounds__(256) void render_tiles_asm_kernel(RenderArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int i = threadIdx.x; i < kBiasFloats; i += 256)
+    reinterpret_cast<float*>(smem + kRing * kSlabBytes)[i] = a.packed[OFF_BIAS + i];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, px = lane & 15;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t ldsbase = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
+  const int grid = (int)gridDim.x, tile0 = (int)blockIdx.x;
+  const int gdiv = __builtin_amdgcn_readfirstlane(grid / a.npg), gmod = __builtin_amdgcn_readfirstlane(grid % a.npg);
+  const int fg0 = __builtin_amdgcn_readfirstlane(tile0 / a.npg), pg0 = __builtin_amdgcn_readfirstlane(tile0 % a.npg);
+  const int fgl = __builtin_amdgcn_readfirstlane((a.ntiles - 1) / a.npg), pgl = __builtin_amdgcn_readfirstlane((a.ntiles - 1) % a.npg);
+  const float* wsrc = a.packed + OFF_WMLP;
+  const uint32_t lane16 = lds0 + lane * 16, dmaoff = wave * 4096 + lane * 16;
+  const uint32_t biasaddr = lds0 + kRing * kSlabBytes + 16 * q, boutaddr = lds0 + kRing * kSlabBytes + kHidden * kW * 4;
+  const uint32_t qaddr = lds0 + wave * 3072 + q * 16;
+#include "render_body.inc"
+}
+#endif
+
 #ifdef S2L_EXP_TRACE
 extern "C" int s2l_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
 #endif
@@ -345,7 +394,7 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   if (!packed || !p0 || !p5 || !q0 || !q5 || !out) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(p0) || misaligned16(p5) || misaligned16(q0) || misaligned16(q5))
     return S2L_E_ALIGN;
-  constexpr int G = 3;
+  constexpr int G = S2L_RENDER_G;
   RenderArgs a;
   a.packed = packed; a.p0t = p0; a.p5t = p5; a.q0 = q0; a.q5 = q5; a.out = out;
   a.hw = (int)hw; a.nframes = (int)n_frames;
@@ -364,6 +413,12 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   if (limit > 0 && limit < n_cu) n_cu = limit;
   // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
-  hipLaunchKernelGGL((render_tiles_kernel<G>), dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);
+#if S2L_RENDER_ASM
+  static LdsOptIn lds_flags_asm;
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&render_tiles_asm_kernel), kLdsBytes + 64, lds_flags_asm, dev))) return rc;
+  hipLaunchKernelGGL(render_tiles_asm_kernel, dim3(grid), dim3(256), kLdsBytes + 64, static_cast<hipStream_t>(stream), a);
+#else
+  hipLaunchKernelGGL((render_tiles_kernel<G>), dim3(grid), dim3(12 / G * 64), kLdsBytes, static_cast<hipStream_t>(stream), a);
+#endif
   return (int)hipGetLastError();
 }
