@@ -27,15 +27,17 @@ KRING, SLAB, NSLABS, NLAYERS = 9, 16384, 113, 7
 V_IN, V_W = 0, 192
 V_LANE16, V_RING, V_DMAOFF, V_BIAS, V_QADDR, V_TMP, V_BOUT, V_PIXOFF = 208, 209, 210, 211, 212, 213, 214, 215
 V_T0, V_BIAS0, V_PIX = 216, 220, 221          # V_T0..V_T0+3: one f4 of temporaries
-V_LAST = 223
+V_RA = 224                                      # 17 ring addresses of a layer: slabs 0..15 and the slab after
+V_LAST = 240
 A_ACC, A_BIAS, A_RGB = 0, 192, 196
 A_LAST = 207
 # ---- scalar registers (all owned by the body; the compiler's operands live elsewhere)
 S = {n: 36 + i for i, n in enumerate(
     "CUR T LDSBASE CURB WPTR WPTR1 WBASE WBASE1 IS LAYER FG PG NPG GDIV GMOD TILE NTILES GRID NFM1 HW FGN PGN FGL PGL "
-    "Q0 Q01 Q5 Q51 P0 P01 P5 P51 OUT OUT1 WAVE PAD T4 T5 T6 T7 T8 T9 EX EX1 NFRAMES".split())}
+    "Q0 Q01 Q5 Q51 P0 P01 P5 P51 OUT OUT1 WAVE PAD T4 T5 T6 T7 T8 T9 EX EX1 NFRAMES PAD2 TRACE TRACE1".split())}
+TRACE = os.environ.get("S2L_RENDER_TRACE") == "1"      # experiment builds only (tools/trace_tiles.py): per-tile phase timestamps
 # pairs must be even-aligned
-for pair in ("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX"):
+for pair in ("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX", "TRACE"):
     assert S[pair] % 2 == 0, pair
 S_LAST = max(S.values())
 
@@ -76,6 +78,35 @@ class Body:
         self.e("s_waitcnt lgkmcnt(0)")
         self.lds = []
 
+    def trace(self, slot):
+        """experiment builds: wave 0 lane 0 stores s_memtime to trace[tile*16 + slot] (slot: int, or 'layer' = 2 + LAYER)"""
+        if not TRACE:
+            return
+        e = self.e
+        skip = self.label("notrace")
+        e(f"s_memtime {s2('T8')}")
+        self.wait_all_lds()
+        e(f"s_cmp_eq_u64 {s2('TRACE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u32 {s('WAVE')}, 0")
+        e(f"s_cbranch_scc0 {skip}")
+        e(f"s_lshl_b32 {s('T6')}, {s('TILE')}, 4")
+        e(f"s_add_u32 {s('T6')}, {s('T6')}, {slot}" if isinstance(slot, int) else f"s_add_u32 {s('T6')}, {s('T6')}, {s('LAYER')}")
+        if not isinstance(slot, int):
+            e(f"s_add_u32 {s('T6')}, {s('T6')}, 2")
+        e(f"s_mov_b32 {s('T7')}, 0")
+        e(f"s_lshl_b64 {s2('T6')}, {s2('T6')}, 3")
+        e(f"s_add_u32 {s('T4')}, {s('TRACE')}, {s('T6')}")
+        e(f"s_addc_u32 {s('T5')}, {s('TRACE1')}, {s('T7')}")
+        e(f"v_mov_b32 v{V_T0}, {s('T8')}")
+        e(f"v_mov_b32 v{V_T0 + 1}, {s('T9')}")
+        e(f"v_mov_b32 v{V_T0 + 2}, 0")
+        e(f"s_mov_b64 {s2('EX')}, exec")
+        e("s_mov_b64 exec, 1")
+        e(f"global_store_dwordx2 v{V_T0 + 2}, v[{V_T0}:{V_T0 + 1}], {s2('T4')}")
+        e(f"s_mov_b64 exec, {s2('EX')}")
+        e(f"{skip}:")
+
     # ---- registers
     @staticmethod
     def acc(g, mb):
@@ -89,7 +120,7 @@ class Body:
     # ---- ring protocol
     def advance(self):
         """Publish the next step, retire the current one: s[T] = LDS address of the retired buffer's quarter owned by this
-        wave, CUR / CURB / v[RING] move on.  Precondition: this wave's LDS reads of the current step have returned."""
+        wave, CUR / CURB move on (callers derive the vector addresses they need).  Precondition: this wave's LDS reads of the current step have returned."""
         e = self.e
         e("s_waitcnt vmcnt(28)")
         e("s_barrier")
@@ -98,7 +129,6 @@ class Body:
         e(f"s_cmp_eq_u32 {s('CUR')}, {KRING}")
         e(f"s_cselect_b32 {s('CUR')}, 0, {s('CUR')}")
         e(f"s_lshl_b32 {s('CURB')}, {s('CUR')}, 14")
-        e(f"v_add_u32 v{V_RING}, {s('CURB')}, v{V_LANE16}")
 
     def weight_refill_setup(self):
         """m0 / s[T4:T5] for the four loads of the next weight slab into the retired buffer; moves the slab pointer on."""
@@ -150,32 +180,38 @@ class Body:
             e(f"global_load_lds_dwordx4 v{V_LANE16}, {s2('T4')}")
 
     # ---- one slab
-    def quad_mfmas(self, mb, j, dst, first_c=None, sprinkle=()):
-        """12 MFMAs of k-quad j; `sprinkle`: instructions tucked behind the MFMAs 0, 3, 6, 9."""
-        sprinkle = list(sprinkle)
+    def quad_mfmas(self, mb, j, dst, first_c=None, sprinkle=None):
+        """12 MFMAs of k-quad j; sprinkle[n]: instructions tucked behind MFMA n (scalar, LDS and DMA issue is free there)."""
+        sprinkle = dict(sprinkle or {})
         w = V_W + 4 * (j % 4)
         for jj in range(4):
             for g in range(G):
                 c = first_c if (first_c and j == 0 and jj == 0) else dst(g)
                 self.e(f"v_mfma_f32_16x16x4_f32 {dst(g)}, v{w + jj}, v{self.inreg(g, j * 4 + jj)}, {c}")
-                if sprinkle and (jj * G + g) % 3 == 0:
-                    self.e(sprinkle.pop(0))
+                for t in sprinkle.pop(jj * G + g, []):
+                    self.e(t)
         assert not sprinkle
 
-    def a_read(self, slab_tag, tq):
+    def a_read(self, slab_tag, tq, areg):
         wset = V_W + 4 * (tq % 4)
-        self.lds_op(f"ds_read_b128 v[{wset}:{wset + 3}], v{V_RING} offset:{1024 * (tq % 16)}", ("A", slab_tag + tq // 16, tq % 16))
+        self.lds_op(f"ds_read_b128 v[{wset}:{wset + 3}], v{areg} offset:{1024 * (tq % 16)}", ("A", slab_tag + tq // 16, tq % 16))
 
     def slab(self, mb, special=None):
         """special: list of (layer, out-of-line refill emitter) for the table steps issued from this slab position."""
         e = self.e
         dst = lambda g: self.acc(g, mb)
         for j in range(16):
-            sprinkle = ()
+            sprinkle = {}
+            if j == 13:     # the scalar side of `advance`, ahead of the barrier and behind MFMAs
+                pre = [f"s_add_u32 {s('T')}, {s('CURB')}, {s('LDSBASE')}", f"s_add_u32 {s('CUR')}, {s('CUR')}, 1",
+                       f"s_cmp_eq_u32 {s('CUR')}, {KRING}", f"s_cselect_b32 {s('CUR')}, 0, {s('CUR')}",
+                       f"s_lshl_b32 {s('CURB')}, {s('CUR')}, 14", f"s_mov_b32 m0, {s('T')}", f"s_mov_b64 {s2('T4')}, {s2('WPTR')}"]
+                sprinkle = {2 + n: [t] for n, t in enumerate(pre)}
             if j == 14:
                 self.wait_lds(("A", mb, 15))      # both remaining quads of this slab are in registers
-                self.advance()
-            self.a_read(mb, j + 2)
+                e("s_waitcnt vmcnt(28)")
+                e("s_barrier")
+            self.a_read(mb, j + 2, V_RA + mb + (j + 2) // 16)
             if j == 8:      # next slab's bias (srcC of its first MFMAs); row offset of the next layer for the last slab
                 self.lds_op(f"ds_read_b128 a[{A_BIAS}:{A_BIAS + 3}], v{V_BIAS} offset:{(mb + 1) * 64}", ("B", mb + 1))
             self.wait_lds(("A", mb, j))
@@ -188,12 +224,26 @@ class Body:
                     e(f"s_cmp_eq_u32 {s('LAYER')}, {layer}")
                     e(f"s_cbranch_scc1 {ol}")
                     self.outofline.append((ol, join, emit, mb, j))
-                self.weight_refill_setup()
-                e("s_nop 0")
-                sprinkle = self.dma4()
+                dma = self.dma4()
+                ptr = [f"s_add_u32 {s('WPTR')}, {s('WPTR')}, {SLAB}", f"s_addc_u32 {s('WPTR1')}, {s('WPTR1')}, 0",
+                       f"s_add_u32 {s('IS')}, {s('IS')}, 1", f"s_cmp_eq_u32 {s('IS')}, {NSLABS}",
+                       f"s_cselect_b64 {s2('WPTR')}, {s2('WBASE')}, {s2('WPTR')}", f"s_cselect_b32 {s('IS')}, 0, {s('IS')}"]
+                sprinkle = {0: [dma[0]], 3: [dma[1]], 6: [dma[2]], 9: [dma[3], *ptr]}
             self.quad_mfmas(mb, j, dst, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]", sprinkle=sprinkle)
             if j == 14:
                 e(f"{join}:")
+
+    def ring_table(self):
+        """v[RA + i] = LDS address of this lane's A quads in the buffer i steps after the current one, i = 0..16"""
+        e = self.e
+        e(f"s_mov_b32 {s('T6')}, {s('CURB')}")
+        for i in range(17):
+            if i:
+                e(f"s_add_u32 {s('T6')}, {s('T6')}, {SLAB}")
+                e(f"s_cmp_ge_u32 {s('T6')}, {KRING * SLAB}")
+                e(f"s_cselect_b32 {s('T7')}, {KRING * SLAB}, 0")
+                e(f"s_sub_u32 {s('T6')}, {s('T6')}, {s('T7')}")
+            e(f"v_add_u32 v{V_RA + i}, {s('T6')}, v{V_LANE16}")
 
     def relu_all(self):
         e = self.e
@@ -243,6 +293,7 @@ class Body:
     def p_step(self):
         """in[g][k] = relu(in[g][k] + p[pixel][k]); p step: [mb][lane] f4, i.e. lane-linear like an A quad."""
         e = self.e
+        e(f"v_add_u32 v{V_RING}, {s('CURB')}, v{V_LANE16}")
         for mb in range(3):
             t = V_W + 4 * (mb % 4)
             self.lds_op(f"ds_read_b128 v[{t}:{t + 3}], v{V_RING} offset:{mb * 1024}", ("P", mb))
@@ -261,11 +312,12 @@ class Body:
         self.wait_all_lds()
 
     def prefetch_first_quads(self, with_bias):
+        self.ring_table()
         if with_bias:
             self.e(f"ds_read_b128 a[{A_BIAS}:{A_BIAS + 3}], v{V_BIAS}")
             self.wait_all_lds()
-        self.a_read(0, 0)
-        self.a_read(0, 1)
+        self.a_read(0, 0, V_RA)
+        self.a_read(0, 1, V_RA)
 
 
 def generate():
@@ -277,7 +329,7 @@ def generate():
                      ("GRID", "grid"), ("NFRAMES", "nframes"), ("HW", "hw"), ("FG", "fg0"), ("PG", "pg0"), ("FGL", "fgl"), ("PGL", "pgl"),
                      ("WAVE", "wave")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
-    for dst, src in (("WBASE", "wsrc"), ("Q0", "q0"), ("Q5", "q5"), ("P0", "p0"), ("P5", "p5"), ("OUT", "out")):
+    for dst, src in (("WBASE", "wsrc"), ("Q0", "q0"), ("Q5", "q5"), ("P0", "p0"), ("P5", "p5"), ("OUT", "out")) + ((("TRACE", "trace"),) if TRACE else ()):
         e(f"s_mov_b64 {s2(dst)}, %[{src}]")
     e(f"s_mov_b64 {s2('WPTR')}, {s2('WBASE')}")
     e(f"s_sub_u32 {s('NFM1')}, {s('NFRAMES')}, 1")
@@ -286,7 +338,6 @@ def generate():
     e(f"s_mov_b32 {s('CURB')}, 0")
     for dst, src in ((V_LANE16, "lane16"), (V_DMAOFF, "dmaoff"), (V_BIAS0, "biasaddr"), (V_QADDR, "qaddr"), (V_BOUT, "boutaddr"), (V_PIX, "px")):
         e(f"v_mov_b32 v{dst}, %[{src}]")
-    e(f"v_mov_b32 v{V_RING}, v{V_LANE16}")
     # prime the ring: q0 and p0 of the first tile, weight slabs 0..5 (steps 0..7 -> buffers 0..7)
     e(f"s_mov_b32 {s('T')}, {s('LDSBASE')}")
     b.q_refill("Q0", "FG")
@@ -323,6 +374,7 @@ def generate():
     e(f"s_cselect_b32 {s('FGN')}, {s('FGN')}, {s('FGL')}")
     e(f"s_cselect_b32 {s('PGN')}, {s('PGN')}, {s('PGL')}")
     # ---- h0 = relu(p0[pixel] + q0[frame])
+    b.trace(0)
     b.q_step(False)
     b.advance()
     b.weight_refill()
@@ -331,6 +383,7 @@ def generate():
     b.weight_refill()
     e(f"v_mov_b32 v{V_BIAS}, v{V_BIAS0}")
     e(f"s_mov_b32 {s('LAYER')}, 0")
+    b.trace(1)
     b.prefetch_first_quads(True)
     loop_state = list(b.lds)
 
@@ -347,6 +400,12 @@ def generate():
     e(f"s_cmp_eq_u32 {s('LAYER')}, 4")
     e("s_cbranch_scc1 S2L_SKIP")
     b.relu_all()
+    b.ring_table()
+    if TRACE:
+        b.lds = list(loop_state)
+        b.trace("layer")
+        e("s_nop 0")      # (the first quads are waited for as "in flight": already complete, which is stronger)
+        b.lds = list(loop_state)
     e(f"s_add_u32 {s('LAYER')}, {s('LAYER')}, 1")
     e(f"v_add_u32 v{V_BIAS}, 1024, v{V_BIAS}")
     e(f"s_cmp_lt_u32 {s('LAYER')}, {NLAYERS}")
@@ -358,7 +417,7 @@ def generate():
     rgb = lambda g: f"a[{A_RGB + 4 * g}:{A_RGB + 4 * g + 3}]"
     for j in range(16):
         if j + 2 < 16:
-            b.a_read(0, j + 2)
+            b.a_read(0, j + 2, V_RA)
         b.wait_lds(("A", 0, j))
         if j == 0:
             b.wait_lds(("B", 0))
@@ -396,6 +455,7 @@ def generate():
         e(f"global_store_dwordx3 v{V_PIXOFF}, a[{A_RGB + 4 * g}:{A_RGB + 4 * g + 2}], {s2('T4')}")
         e(f"{skip}:")
     e(f"s_mov_b64 exec, {s2('EX')}")
+    b.trace(9)
     # ---- next tile of this workgroup
     e(f"s_add_u32 {s('TILE')}, {s('TILE')}, {s('GRID')}")
     e(f"s_mov_b32 {s('FG')}, {s('FGN')}")
@@ -415,6 +475,7 @@ def generate():
     b.p_step()
     b.advance()
     b.weight_refill()
+    b.trace("layer")
     e(f"s_mov_b32 {s('LAYER')}, 5")
     e(f"v_add_u32 v{V_BIAS}, 1024, v{V_BIAS}")
     b.prefetch_first_quads(False)
@@ -434,7 +495,7 @@ OPERANDS = """      :
       : [ldsbase] "s"(ldsbase), [npg] "s"(a.npg), [gdiv] "s"(gdiv), [gmod] "s"(gmod), [tile0] "s"(tile0), [ntiles] "s"(a.ntiles),
         [grid] "s"(grid), [nframes] "s"(a.nframes), [hw] "s"(a.hw), [fg0] "s"(fg0), [pg0] "s"(pg0), [fgl] "s"(fgl), [pgl] "s"(pgl),
         [wave] "s"(wave), [wsrc] "s"(wsrc), [q0] "s"(a.q0), [q5] "s"(a.q5), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [out] "s"(a.out),
-        [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px)
+        [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px)TRACE_OPERAND
 """
 
 
@@ -444,7 +505,7 @@ def main(path):
     clob += ["vcc", "scc", "memory"]   # (m0 and exec: nothing follows the body; exec is restored)
     out = ["// GENERATED by csrc/gen_render_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]
-    out.append(OPERANDS.rstrip("\n"))
+    out.append(OPERANDS.rstrip("\n").replace("TRACE_OPERAND", ', [trace] "s"(g_trace)' if TRACE else ""))
     out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -186,3 +186,21 @@ def test_canonical_depth_head_parameter(tmp_path):
     assert torch.equal(d[2:9, 3:8][init[2:9, 3:8] > 0], torch.from_numpy(init[2:9, 3:8][init[2:9, 3:8] > 0]))
     cfg["model"].pop("canonical_depth_init_path")
     assert s2l.TalkingFace(torch.device("cpu"), cfg).canonical_depth_head.shape == (12, 10)
+
+
+def test_render_body_generator_is_deterministic_and_complete(tmp_path):
+    """csrc/gen_render_body.py writes the renderer's assembly body at build time.  Its own assertions check the LDS wait
+    bookkeeping at every loop edge; here: two runs give the same text, and the text holds exactly the MFMAs of the schedule --
+    16 slabs x 192 in the layer loop, 192 in the output layer, 12 in each of the four out-of-line table refills."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_render_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_render_body.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a, b = str(tmp_path / "a.inc"), str(tmp_path / "b.inc")
+    gen.main(a)
+    gen.main(b)
+    text = open(a).read()
+    assert text == open(b).read()
+    assert text.count("v_mfma_f32_16x16x4_f32") == 16 * 192 + 192 + 4 * 12
+    assert text.count("s_barrier") == 1 + 16 + 2 + 2 + 1          # prime, slabs, q0/p0, q5/p5, output layer
+    assert text.count("global_load_lds_dwordx4") >= 9 * 4
