@@ -29,6 +29,10 @@ for d in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_sq"):
     vals.update(pmc(d, "render_tiles_kernel"))
 for k, v in vals.items():
     out.append("%-34s %.6g\n" % (k, v))
+if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+    out.append("MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.4f of the kernel's cycles\n"
+               % (vals["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (vals["GRBM_GUI_ACTIVE"] / 8)))
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
     out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes\n" % traffic)
