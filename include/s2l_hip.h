@@ -386,6 +386,26 @@ int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height,
 int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width,
                              int64_t batch, s2l_stream_t stream);
 
+/* ---- perceptual loss: lpips.LPIPS(net='alex', version='0.1') as Trainer.add_perceptual_loss calls it
+ * (src/face_simple/training.py:76, 655-674; requirement.txt:11 pins the third-party package lpips==0.1.4, whose published
+ * forward pass csrc/lpips.hip restates) and the gradient the reference gets from autograd for the generated image.
+ * s2l_lpips_pack: tensors_host = HOST array of 17 DEVICE pointers: conv1..conv5 {weight [co,ci,kh,kw], bias [co]}
+ * (net.slice1.0, slice2.3, slice3.6, slice4.8, slice5.10), lin0..lin4 model.1.weight [1,C,1,1], scaling_layer.shift [3],
+ * scaling_layer.scale [3].
+ * s2l_lpips_forward: in0, in1 [N,H,W,3] NHWC in [-1,1], or in [0,1] with from01 != 0 (then (x - 0.5) * 2 is applied first,
+ * as add_perceptual_loss does, training.py:669-670); out [N] = the package's [N,1,1,1] distance; work:
+ * s2l_lpips_work_floats(H, W, N) floats, keeps the activations s2l_lpips_backward needs.
+ * s2l_lpips_backward: d_out [N] -> d_in0 [N,H,W,3], overwritten or (accumulate != 0) added to; same from01 as the forward
+ * (in1 is the ground truth: no gradient).
+ * H, W >= 31 (AlexNet's two 3x3/2 poolings after the 11x11/4 convolution): smaller -> S2L_E_GEOMETRY. */
+int64_t s2l_lpips_packed_floats(void);
+int64_t s2l_lpips_work_floats(int height, int width, int64_t batch);
+int s2l_lpips_pack(const float* const* tensors_host, float* packed, s2l_stream_t stream);
+int s2l_lpips_forward(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
+                      int height, int width, int64_t batch, s2l_stream_t stream);
+int s2l_lpips_backward(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
+                       int height, int width, int64_t batch, s2l_stream_t stream);
+
 /* ---- bf16 mode of the training step (BASELINE config 5; same mathematics as s2l_train_forward / _backward /
  * s2l_wgrad, operands and saved state in bf16, fp32 accumulation, fp32 master weights and gradients) -------------
  * Replaces, like the fp32 entry points, the autograd of Trainer.predict_lip_image + add_photometric_loss

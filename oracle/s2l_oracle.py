@@ -7,7 +7,8 @@ when that library is missing.
 
 This is our own functional restatement (PyTorch-CPU ops, fp32 by default, fp64 on request)
 of the reference algorithm, written from the maths in SURVEY.md §3.3/§8a.  Each function
-cites the reference lines it follows.  Parity is PINNED: `tools/make_goldens.py` imports
+cites the reference lines it follows.  Parity is PINNED (except `lpips_alex`, which restates a third-party package
+that is not available here and says so in its header): `tools/make_goldens.py` imports
 the reference itself (in the build container, where /root/reference exists), checks every
 function here against it, and commits the resulting vectors under `tests/golden/`;
 `tests/test_oracle_golden.py` re-checks this file against those vectors everywhere.
@@ -297,6 +298,42 @@ def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet."
     y = up(y, x1, "up2.conv.double_conv")
     y = F.conv2d(y, sd[prefix + "outc.conv.weight"], sd[prefix + "outc.conv.bias"])
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+# --------------------------------------------------------------------------- §8f-4: perceptual term (LPIPS, AlexNet)
+# PARITY UNPINNED: `lpips` (requirement.txt:11, lpips==0.1.4) and torchvision are third-party packages that are neither in the
+# reference repository nor installed here, so this restatement of their PUBLISHED forward pass (lpips/lpips.py LPIPS.forward,
+# lpips/pretrained_networks.py alexnet, lpips/__init__.py normalize_tensor / spatial_average) cannot be checked against the
+# package itself; it is anchored on the reference's call site (training.py:76, 655-674) and exercised with seeded weights.
+LPIPS_ALEX = (("net.slice1.0", 4, 2, False), ("net.slice2.3", 1, 2, True), ("net.slice3.6", 1, 1, True), ("net.slice4.8", 1, 1, False),
+              ("net.slice5.10", 1, 1, False))       # (conv, stride, padding, MaxPool2d(3, 2) in front)
+
+
+def lpips_alex(sd: SD, in0: torch.Tensor, in1: torch.Tensor, eps: float = 1e-10) -> torch.Tensor:
+    """lpips.LPIPS(net='alex', version='0.1', lpips=True, spatial=False)(in0, in1): NCHW images in [-1,1] -> [N,1,1,1]."""
+    def feats(x):
+        x = (x - sd["scaling_layer.shift"].to(x)) / sd["scaling_layer.scale"].to(x)
+        outs = []
+        for name, stride, pad, pool in LPIPS_ALEX:
+            if pool:
+                x = F.max_pool2d(x, kernel_size=3, stride=2)
+            x = F.relu(F.conv2d(x, sd[name + ".weight"].to(x), sd[name + ".bias"].to(x), stride=stride, padding=pad))
+            outs.append(x)
+        return outs
+    val = 0
+    for kk, (f0, f1) in enumerate(zip(feats(in0), feats(in1))):
+        n0 = f0 / (torch.sqrt(torch.sum(f0 ** 2, dim=1, keepdim=True)) + eps)
+        n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + eps)
+        lin = F.conv2d((n0 - n1) ** 2, sd[f"lin{kk}.model.1.weight"].to(f0))
+        val = val + lin.mean([2, 3], keepdim=True)
+    return val
+
+
+def perceptual_loss(sd: SD, prediction_nhwc: torch.Tensor, target_nhwc: torch.Tensor, weights: float = 1.0) -> torch.Tensor:
+    """Trainer.add_perceptual_loss (training.py:655-674), mask = ones: (x - 0.5) * 2, LPIPS, mean over the batch, * weights."""
+    recon_x = (prediction_nhwc.permute(0, 3, 1, 2) - 0.5) * 2
+    x = (target_nhwc.permute(0, 3, 1, 2) - 0.5) * 2
+    return lpips_alex(sd, recon_x, x).mean() * weights
 
 
 # --------------------------------------------------------------------------- metrics

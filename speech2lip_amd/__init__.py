@@ -8,8 +8,9 @@ from .training import LipTrainStep, StageOneStep, SyncChain, Trainer, predict_li
 from . import autograd
 from .unet import SimpleUnetLight
 from .syncnet import SyncLoss, SyncNet_color
+from .lpips import LPIPS
 from . import geometry
 
 __all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "Trainer",
            "predict_lip_image", "LipTrainStep", "StageOneStep", "SyncChain", "training", "autograd",
-           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "SyncNet_color", "SyncLoss", "geometry"]
+           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "SyncNet_color", "SyncLoss", "LPIPS", "geometry"]

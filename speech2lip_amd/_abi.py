@@ -106,6 +106,11 @@ EXPORTS = {
     "s2l_depth_photo_work_floats": (c_int64, [c_int, c_int]),
     "s2l_depth_photo_loss": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_lpips_packed_floats": (c_int64, []),
+    "s2l_lpips_work_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_lpips_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "s2l_lpips_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_lpips_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_syncnet_packed_floats": (c_int64, []),
     "s2l_syncnet_work_floats": (c_int64, [c_int64]),
     "s2l_syncnet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),

@@ -262,3 +262,27 @@ class _Mse(torch.autograd.Function):
 def mse(prediction, target, weights: float = 1.0):
     """mean((prediction - target)^2) * weights (training.py:605-619, mask=None)."""
     return _Mse.apply(prediction, target, weights)
+
+
+class _LpipsDistance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, in0, in1, from01):
+        need = in0.requires_grad
+        if in1.requires_grad:
+            raise NotImplementedError("LPIPS on the HIP path differentiates with respect to its first image only (the second is the "
+                                      "ground truth in training.py:655-674)")
+        if need:
+            out, ctx.state = module.distance_nhwc(in0, in1, from01, keep=True)
+        else:
+            out = module.distance_nhwc(in0, in1, from01)
+        ctx.module, ctx.shape = module, in0.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return None, ctx.module.backward_nhwc(ctx.state, d_out).reshape(ctx.shape), None, None
+
+
+def lpips_distance(module, in0_nhwc, in1_nhwc, from01: bool = False):
+    """lpips.LPIPS(net='alex')(in0, in1) for NHWC images -> [N]; differentiable in in0 (csrc/lpips.hip)."""
+    return _LpipsDistance.apply(module, in0_nhwc, in1_nhwc, bool(from01))

@@ -9,7 +9,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libs2l_hip.so")
-SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "syncchain.hip", "train_bf16.hip", "quant.hip"]
+SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip"]
 # -ffp-contract=off: parity needs the reference's separate roundings (x*y then +z); FMAs are explicit fmaf()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]

@@ -3,22 +3,11 @@
 // generated face window (SyncNet itself is frozen, training.py:85-90, so no weight gradients exist).
 //
 // Every convolution of both encoders -- kernels 1/3/5/7, strides (1|2|3) x (1|2|3), padding 0/1/3, 1..512 channels, with
-// the eval-mode BatchNorm folded into the packed weights, optional residual add and ReLU -- is ONE implicit-GEMM kernel on
-// v_mfma_f32_16x16x4_f32 (exact fp32):  D[row][col] = sum_k A[row][k] B[k][col]
-//   forward : rows = output channels, cols = output pixels (b,oy,ox), k = (ky,kx,ci), B gathered from the NHWC input
-//   dgrad   : rows = input channels,  cols = input pixels  (b,iy,ix), k = (ky,kx,co), B gathered from the masked output
-//             gradient at oy = (iy + pad - ky) / stride where that division is exact
-// A workgroup (4 waves, 2x2) owns a 64x64 tile; K advances in chunks of 16 through LDS with the next chunk's global loads
-// in flight during the MFMAs.  The deep layers have 1..36 pixels and K up to 4608, so K is also split across
-// gridDim.z into partial tiles that a second kernel reduces in a fixed order (deterministic) before the epilogue.
-// The whole net is ~1.2 GMAC per window: launch- and weight-read-bound (65 MB of fp32 weights per pass), not MFMA-bound.
-#include "s2l_common.h"
+// the eval-mode BatchNorm folded into the packed weights, optional residual add and ReLU -- is the implicit-GEMM kernel of
+// csrc/conv_gemm.h.  The whole net is ~1.2 GMAC per window: launch- and weight-read-bound (65 MB of fp32 weights per pass).
+#include "conv_gemm.h"
 
 namespace s2l {
-
-struct LayerSpec {
-  int cin, cout, kh, kw, sy, sx, py, px, res;
-};
 
 // syncnet.py:11-33
 static const LayerSpec kFace[] = {
@@ -38,7 +27,6 @@ static const LayerSpec kAudio[] = {
 constexpr int kNumFace = 17, kNumAudio = 14, kNumLayers = kNumFace + kNumAudio, kSyncEmb = 512;
 constexpr int kFaceH = 48, kFaceW = 96, kMelH = 80, kMelW = 16;
 
-inline int ceil_to(int a, int m) { return (a + m - 1) / m * m; }
 inline const LayerSpec& spec_of(int l) { return l < kNumFace ? kFace[l] : kAudio[l - kNumFace]; }
 
 // packed blob: per layer {forward weights [kh*kw*ceil16(cin)][ceil64(cout)], bias [ceil64(cout)]}, then for the face
@@ -63,191 +51,6 @@ inline PackedLayout packed_layout() {
   }
   p.total = o;
   return p;
-}
-
-// ---- packing: fold BatchNorm (eval), lay out for the implicit GEMM ----------------------------------------------------
-// forward:  dst[(tap*cinp + ci)*RP + co] = w[co][ci][ky][kx] * g[co]/sqrt(var[co]+eps)
-// dgrad:    dst[(tap*coutp + co)*RP + ci] = the same number, K and row roles swapped
-__global__ void syncnet_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ var,
-                                    float eps, float* __restrict__ dst, int cin, int cout, int kh, int kw, int kcp, int RP,
-                                    int dgrad, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int row = (int)(i % RP);
-  const int64_t kidx = i / RP;
-  const int kc = (int)(kidx % kcp), tap = (int)(kidx / kcp);
-  const int ky = tap / kw, kx = tap % kw;
-  const int co = dgrad ? kc : row, ci = dgrad ? row : kc;
-  float v = 0.f;
-  if (co < cout && ci < cin) v = w[(((int64_t)co * cin + ci) * kh + ky) * kw + kx] * (gamma[co] / sqrtf(var[co] + eps));
-  dst[i] = v;
-}
-
-__global__ void syncnet_pack_bias_kernel(const float* __restrict__ b, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, const float* __restrict__ mean,
-                                         const float* __restrict__ var, float eps, float* __restrict__ dst, int cout, int RP) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= RP) return;
-  dst[i] = i < cout ? (b[i] - mean[i]) * (gamma[i] / sqrtf(var[i] + eps)) + beta[i] : 0.f;
-}
-
-// ---- the implicit-GEMM convolution --------------------------------------------------------------------------------------
-struct ConvArgs {
-  const float* in;    // fwd: a_{L-1} [B,hin,win,cin];  dgrad: g_L [B,hout,wout,cout] (gradient w.r.t. the pre-ReLU sum)
-  const float* w;     // packed A operand [K/16][16][RP]
-  const float* bias;  // fwd: folded bias [RP]
-  const float* res;   // fwd: residual source (a_{L-1}) or null;  dgrad: g_L when the layer is residual (pass-through) or null
-  const float* mask;  // dgrad: a_{L-1}; the result is multiplied by (a_{L-1} > 0) (ReLU of the layer below) -- or null
-  float* out;         // fwd: a_L [B,hout,wout,cout];  dgrad: g_{L-1} [B,hin,win,cin]
-  float* partial;     // split-K: [splits][ncols][RP] partial sums, else null
-  int hin, win, cin, hout, wout, cout, kh, kw, sy, sx, py, px;
-  int rows, RP, kc, kcp, ncols, nchunks, chunks_per_split;
-};
-
-constexpr int kLd = 80;  // LDS row stride in floats: 80 % 32 == 16 keeps the four k-rows of an operand read on distinct banks
-
-__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-template <bool DGRAD>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
-  __shared__ float As[16 * kLd];
-  __shared__ float Bs[16 * kLd];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
-  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
-  const int chunk_lo = blockIdx.z * a.chunks_per_split;
-  const int chunk_hi = min(a.nchunks, chunk_lo + a.chunks_per_split);
-
-  // B-load role: pixel pl of the tile, channel quad cq of the chunk
-  const int pl = t >> 2, cq = t & 3;
-  const int col = col0 + pl;
-  const bool col_ok = col < a.ncols;
-  const int cw = DGRAD ? a.win : a.wout, chw = DGRAD ? a.hin * a.win : a.hout * a.wout;
-  const int cc = col_ok ? col : 0;
-  const int n = cc / chw, rem = cc - n * chw;
-  const int cy = rem / cw, cx = rem - cy * cw;
-  // A-load role
-  const int ak = t >> 4, ar4 = t & 15;
-  const bool vec = (a.kc & 3) == 0;
-
-  f4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-  auto fetch = [&](int chunk, f4& av, f4& bv) {
-    av = *reinterpret_cast<const f4*>(a.w + ((int64_t)chunk * 16 + ak) * a.RP + row0 + ar4 * 4);
-    const int kidx0 = chunk * 16;
-    const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp + 4 * cq;
-    const int ky = tap / a.kw, kx = tap - ky * a.kw;
-    bool ok = col_ok && c0 < a.kc;
-    const float* src;
-    if (!DGRAD) {
-      const int iy = cy * a.sy - a.py + ky, ix = cx * a.sx - a.px + kx;
-      ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-      src = a.in + (((int64_t)n * a.hin + iy) * a.win + ix) * a.cin + c0;
-    } else {
-      const int ty = cy + a.py - ky, tx = cx + a.px - kx;
-      const int oy = ty / a.sy, ox = tx / a.sx;
-      ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
-      src = a.in + (((int64_t)n * a.hout + oy) * a.wout + ox) * a.cout + c0;
-    }
-    bv = f4{0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      if (vec) {
-        bv = *reinterpret_cast<const f4*>(src);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < a.kc) bv[j] = src[j];
-      }
-    }
-  };
-
-  f4 av, bv;
-  if (chunk_lo < chunk_hi) fetch(chunk_lo, av, bv);
-  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-    __syncthreads();  // the previous chunk's operand reads are done
-    *reinterpret_cast<f4*>(&As[ak * kLd + ar4 * 4]) = av;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Bs[(4 * cq + j) * kLd + pl] = bv[j];
-    __syncthreads();
-    if (chunk + 1 < chunk_hi) fetch(chunk + 1, av, bv);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = As[(4 * kk + q) * kLd + 32 * wm + 16 * i + l16];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = Bs[(4 * kk + q) * kLd + 32 * wn + 16 * j + l16];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
-    }
-  }
-
-  // D[row = 4q + r][col = l16] of sub-tile (i, j)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = col0 + 32 * wn + 16 * j + l16;
-    if (c >= a.ncols) continue;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r0 = row0 + 32 * wm + 16 * i + 4 * q;
-      if (a.partial) {
-        *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.RP + r0) = acc[i][j];
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + r;
-        if (row >= a.rows) continue;
-        const int64_t o = (int64_t)c * a.rows + row;
-        float v = acc[i][j][r];
-        if (!DGRAD) {
-          v += a.bias[row];
-          if (a.res) v += a.res[o];
-          v = fmaxf(v, 0.f);
-        } else {
-          if (a.res) v += a.res[o];
-          if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-        }
-        a.out[o] = v;
-      }
-    }
-  }
-}
-
-// split-K: sum the partial tiles in split order, then the same epilogue.  thread = (col, row quad)
-template <bool DGRAD>
-__global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int splits) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int rq = a.RP / 4;
-  if (i >= (int64_t)a.ncols * rq) return;
-  const int c = (int)(i / rq), r0 = (int)(i % rq) * 4;
-  f4 s = *reinterpret_cast<const f4*>(a.partial + (int64_t)c * a.RP + r0);
-  for (int k = 1; k < splits; ++k) {
-    const f4 p = *reinterpret_cast<const f4*>(a.partial + ((int64_t)k * a.ncols + c) * a.RP + r0);
-    s += p;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r0 + r;
-    if (row >= a.rows) continue;
-    const int64_t o = (int64_t)c * a.rows + row;
-    float v = s[r];
-    if (!DGRAD) {
-      v += a.bias[row];
-      if (a.res) v += a.res[o];
-      v = fmaxf(v, 0.f);
-    } else {
-      if (a.res) v += a.res[o];
-      if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-    }
-    a.out[o] = v;
-  }
 }
 
 // ---- embeddings, loss ---------------------------------------------------------------------------------------------------
@@ -363,15 +166,7 @@ __global__ __launch_bounds__(256) void sync_window_kernel(const float* __restric
 }
 
 // ---- host-side plan -------------------------------------------------------------------------------------------------------
-struct Shape {
-  int h, w;
-};
-inline Shape out_shape(const LayerSpec& s, Shape in) {
-  return Shape{(in.h + 2 * s.py - s.kh) / s.sy + 1, (in.w + 2 * s.px - s.kw) / s.sx + 1};
-}
-
 // work buffer: face activations a_0..a_16, audio activations a_0..a_13, two gradient ping-pong buffers, split-K partials
-constexpr int64_t kPartialFloats = 1 << 21;
 struct WorkLayout {
   int64_t act[kNumLayers];
   Shape in_shape[kNumLayers], out_shape_[kNumLayers];
@@ -402,39 +197,6 @@ inline WorkLayout work_layout(int64_t B) {
   return wl;
 }
 
-template <bool DGRAD>
-int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
-  a.ncols = (int)(B * (DGRAD ? a.hin * a.win : a.hout * a.wout));
-  a.rows = DGRAD ? a.cin : a.cout;
-  a.RP = ceil_to(a.rows, 64);
-  a.kc = DGRAD ? a.cout : a.cin;
-  a.kcp = ceil_to(a.kc, 16);
-  a.nchunks = a.kh * a.kw * a.kcp / 16;
-  const int tiles = ((a.ncols + 63) / 64) * (a.RP / 64);
-  int splits = 1;
-  if (tiles < 128 && a.nchunks >= 16) {
-    splits = min(min(256 / tiles, a.nchunks / 8), 64);
-    while (splits > 1 && (int64_t)splits * a.ncols * a.RP > kPartialFloats) --splits;
-  }
-  a.chunks_per_split = (a.nchunks + splits - 1) / splits;
-  splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-  float* partial = a.partial;
-  a.partial = splits > 1 ? partial : nullptr;
-  hipLaunchKernelGGL(conv_gemm_kernel<DGRAD>, dim3((a.ncols + 63) / 64, a.RP / 64, splits), dim3(256), 0, st, a);
-  if (splits > 1) {
-    const int64_t n = (int64_t)a.ncols * (a.RP / 4);
-    hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
-  }
-  return (int)hipGetLastError();
-}
-
-inline ConvArgs base_args(const LayerSpec& s, Shape in, Shape out) {
-  ConvArgs a{};
-  a.hin = in.h, a.win = in.w, a.cin = s.cin, a.hout = out.h, a.wout = out.w, a.cout = s.cout;
-  a.kh = s.kh, a.kw = s.kw, a.sy = s.sy, a.sx = s.sx, a.py = s.py, a.px = s.px;
-  return a;
-}
-
 }  // namespace s2l
 
 using namespace s2l;
@@ -454,14 +216,14 @@ extern "C" int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, 
     const float* const* t = tensors_host + 6 * l;  // conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var
     const int RP = ceil_to(s.cout, 64), kcp = ceil_to(s.cin, 16);
     const int64_t n = (int64_t)s.kh * s.kw * kcp * RP;
-    hipLaunchKernelGGL(syncnet_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
                        packed + pl.w[l], s.cin, s.cout, s.kh, s.kw, kcp, RP, 0, n);
-    hipLaunchKernelGGL(syncnet_pack_bias_kernel, dim3((RP + 255) / 256), dim3(256), 0, st, t[1], t[2], t[3], t[4], t[5], bn_eps,
+    hipLaunchKernelGGL(conv_pack_bias_kernel, dim3((RP + 255) / 256), dim3(256), 0, st, t[1], t[2], t[3], t[4], t[5], bn_eps,
                        packed + pl.b[l], s.cout, RP);
     if (l < kNumFace) {
       const int RPt = ceil_to(s.cin, 64), kcpt = ceil_to(s.cout, 16);
       const int64_t nt = (int64_t)s.kh * s.kw * kcpt * RPt;
-      hipLaunchKernelGGL(syncnet_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
+      hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
                          packed + pl.wt[l], s.cin, s.cout, s.kh, s.kw, kcpt, RPt, 1, nt);
     }
   }

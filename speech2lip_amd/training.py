@@ -145,6 +145,20 @@ class Trainer:
         loss["loss_rgb"] = loss["loss_rgb"] + loss_rgb.detach().cpu()
 
 
+    def add_perceptual_loss(self, prediction, target, loss, mask=None, weights=1.0):
+        """training.py:655-674: prediction, target [B,H,W,3] in [0,1] -> (x - 0.5) * 2 -> LPIPS(alex).mean() * weights.
+        `mask` is the reference's [B,1|3,H,W] multiplier (it only ever passes ones, :455); `self.perceptual_loss_fn` is a
+        speech2lip_amd.LPIPS (set it as the reference's constructor does, :76)."""
+        from .autograd import lpips_distance
+        if mask is not None:
+            m = mask.permute(0, 2, 3, 1)
+            prediction, target = m * prediction, m * target
+        d = lpips_distance(self.perceptual_loss_fn, prediction, target, from01=True)
+        loss_perceptual = d.mean() * weights
+        loss["loss"] = loss["loss"] + loss_perceptual
+        loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + loss_perceptual.detach().cpu()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 class MlpState:
     """What one forward of the MLP leaves behind for its backward: fp32 mode x [N,128] + hsave [8,N,256]; bf16 mode the

@@ -216,6 +216,33 @@ def make_syncnet_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+LPIPS_ALEX_CONVS = (("net.slice1.0", 3, 64, 11), ("net.slice2.3", 64, 192, 5), ("net.slice3.6", 192, 384, 3),
+                    ("net.slice4.8", 384, 256, 3), ("net.slice5.10", 256, 256, 3))
+
+
+def make_lpips_state_dict(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Seeded weights with the state-dict keys of lpips.LPIPS(net='alex', version='0.1') (lpips==0.1.4, requirement.txt:11).
+    The real ones -- torchvision's AlexNet features and the package's alex.pth linear heads -- are not in the reference
+    repository, so parity of this net is structural: same generator on both sides.  He-uniform convolutions, small biases,
+    non-negative linear heads (the package clamps them at >= 0 in training), the package's fixed shift / scale."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def u(name, n, lo, hi):
+        return (lo + (hi - lo) * uniform01(n, _stream_id("lpips." + name, seed))).astype(np.float32)
+
+    out["scaling_layer.shift"] = np.array([-.030, -.088, -.188], np.float32).reshape(1, 3, 1, 1)
+    out["scaling_layer.scale"] = np.array([.458, .448, .450], np.float32).reshape(1, 3, 1, 1)
+    for name, cin, cout, k in LPIPS_ALEX_CONVS:
+        b = np.sqrt(6.0 / (cin * k * k))
+        out[name + ".weight"] = u(name + ".w", cout * cin * k * k, -b, b).reshape(cout, cin, k, k)
+        out[name + ".bias"] = u(name + ".b", cout, -0.05, 0.1)
+    for i, (_, _, cout, _) in enumerate(LPIPS_ALEX_CONVS):
+        w = u(f"lin{i}", cout, 0.0, 2.0 / cout).reshape(1, cout, 1, 1)
+        out[f"lin{i}.model.1.weight"] = w
+        out[f"lins.{i}.model.1.weight"] = w
+    return out
+
+
 def synthetic_sync_batch(batch: int, seed: int = 0, frames_t: int = 5, height: int = 96, width: int = 96):
     """(mel [B,1,80,16], rgb_window_pos [B,3,T,H,W], rgb_window_neg [B,3,T,H,W]) in the layouts of
     someones_lip_dataset.py:331 / training.py:548-553.  Smooth images plus noise, so that the two windows are

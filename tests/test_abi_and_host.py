@@ -204,3 +204,30 @@ def test_render_body_generator_is_deterministic_and_complete(tmp_path):
     assert text.count("v_mfma_f32_16x16x4_f32") == 16 * 192 + 192 + 4 * 12
     assert text.count("s_barrier") == 1 + 16 + 2 + 2 + 1          # prime, slabs, q0/p0, q5/p5, output layer
     assert text.count("global_load_lds_dwordx4") >= 9 * 4
+
+
+def test_lpips_module_has_the_package_state_dict_and_oracle_properties():
+    """speech2lip_amd.LPIPS carries the state-dict keys of lpips.LPIPS(net='alex') (lpips==0.1.4), frozen; the oracle's
+    restatement is zero on identical images, symmetric, and positive otherwise."""
+    import speech2lip_amd as s2l
+    from oracle import s2l_oracle as O
+    from speech2lip_amd import weights as W
+    m = s2l.LPIPS(net="alex", version="0.1")
+    want = {"scaling_layer.shift", "scaling_layer.scale"}
+    for name in ("net.slice1.0", "net.slice2.3", "net.slice3.6", "net.slice4.8", "net.slice5.10"):
+        want |= {name + ".weight", name + ".bias"}
+    for i in range(5):
+        want |= {f"lin{i}.model.1.weight", f"lins.{i}.model.1.weight"}
+    assert set(m.state_dict().keys()) == want
+    assert tuple(m.state_dict()["lin2.model.1.weight"].shape) == (1, 384, 1, 1)
+    assert tuple(m.state_dict()["net.slice1.0.weight"].shape) == (64, 3, 11, 11)
+    assert not any(p.requires_grad for p in m.parameters()) and not m.training
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()}, strict=True)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+    sd = O.to_sd(W.make_lpips_state_dict(0))
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.rand(2, 3, 64, 80, generator=g) * 2 - 1, torch.rand(2, 3, 64, 80, generator=g) * 2 - 1
+    dab, dba = O.lpips_alex(sd, a, b), O.lpips_alex(sd, b, a)
+    assert tuple(dab.shape) == (2, 1, 1, 1) and float(dab.min()) > 0
+    assert torch.allclose(dab, dba, rtol=1e-6) and float(O.lpips_alex(sd, a, a).abs().max()) == 0.0

@@ -1,0 +1,113 @@
+"""GPU parity of the perceptual term: LPIPS(net='alex', version='0.1') forward and the gradient with respect
+to the generated image, against oracle/s2l_oracle.py's restatement of the lpips==0.1.4 package on the same seeded weights
+(structural parity: the package and its weights are not available -- see the oracle's header), through the C-ABI
+(s2l_lpips_*), the module with the package's signature, the autograd wrapper and Trainer.add_perceptual_loss."""
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from oracle import s2l_oracle as O
+from speech2lip_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lp(dev):
+    m = s2l.LPIPS(net="alex", version="0.1").to(dev)
+    m.load_state_dict({k: T(v) for k, v in W.make_lpips_state_dict(0).items()}, strict=True)
+    return m
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return O.to_sd(W.make_lpips_state_dict(0), torch.float64)
+
+
+def images(n, h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    base = 0.5 + 0.3 * np.sin(7 * xx + 2 * yy)[None, :, :, None]
+    a = np.clip(base + 0.5 * (rng.random((n, h, w, 3)) - 0.5), 0, 1).astype(np.float32)
+    b = np.clip(base + 0.5 * (rng.random((n, h, w, 3)) - 0.5), 0, 1).astype(np.float32)
+    return T(a), T(b)
+
+
+def relerr(a, b):
+    b = torch.as_tensor(b).detach()
+    return float((a.detach().cpu().double() - b.double()).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 96, 96), (3, 64, 83), (2, 31, 31), (1, 500, 500)])
+def test_lpips_forward_and_gradient_vs_oracle(lp, sd, dev, n, h, w):
+    """distance [N] and d distance / d in0 against fp64 autograd through the oracle: the lip size (96x96, training.py:420-421),
+    a ragged batch, the smallest image AlexNet's poolings admit, and the fused face (500x500, :453-456)."""
+    a, b = images(n, h, w, 5 + h)
+    x0 = (a.double() * 2 - 1).permute(0, 3, 1, 2).requires_grad_(True)
+    x1 = (b.double() * 2 - 1).permute(0, 3, 1, 2)
+    ref = O.lpips_alex(sd, x0, x1).flatten()
+    wgt = torch.linspace(0.5, 1.5, n, dtype=torch.float64)
+    (ref * wgt).sum().backward()
+    out, state = lp.distance_nhwc((a * 2 - 1).to(dev), (b * 2 - 1).to(dev), keep=True)
+    assert float(ref.detach().min()) > 1e-3
+    assert relerr(out, ref) <= 2e-5, relerr(out, ref)
+    g = lp.backward_nhwc(state, wgt.float().to(dev))
+    gref = x0.grad.permute(0, 2, 3, 1)
+    assert float(gref.abs().max()) > 0
+    assert relerr(g, gref) <= 2e-4, relerr(g, gref)
+    # [0,1] inputs with the reference's (x - 0.5) * 2 folded in: same distance, gradient times the chain factor; accumulation
+    out01, st01 = lp.distance_nhwc(a.to(dev), b.to(dev), from01=True, keep=True)
+    assert relerr(out01, ref) <= 2e-5
+    base = (torch.rand(n, h, w, 3, device=dev) - 0.5) * float(gref.abs().max())
+    acc = base.clone()
+    lp.backward_nhwc(st01, wgt.float().to(dev), out=acc)
+    assert relerr(acc - base, 2 * gref) <= 4e-4
+
+
+def test_lpips_module_signature_autograd_and_trainer(lp, sd, dev):
+    """The package's call -- LPIPS(in0, in1) on NCHW images in [-1,1] -> [N,1,1,1], differentiable -- and
+    Trainer.add_perceptual_loss (training.py:655-674) driven like the reference drives it, against the oracle."""
+    a, b = images(2, 96, 96, 3)
+    pred = a.to(dev).requires_grad_(True)
+    d = lp((pred.permute(0, 3, 1, 2) - 0.5) * 2, (b.to(dev).permute(0, 3, 1, 2) - 0.5) * 2)
+    assert tuple(d.shape) == (2, 1, 1, 1)
+    d.mean().backward()
+    po = a.double().requires_grad_(True)
+    ref = O.perceptual_loss(sd, po, b.double(), 1.0)
+    ref.backward()
+    assert relerr(d.mean(), ref) <= 2e-5
+    assert relerr(pred.grad, po.grad) <= 2e-4
+    # identical images: distance exactly 0
+    assert float(lp(pred.detach().permute(0, 3, 1, 2), pred.detach().permute(0, 3, 1, 2)).abs().max()) == 0.0
+    # the Trainer method, two terms pending at once (lip and face), as in one iteration of train_stage1
+    tr = s2l.Trainer.__new__(s2l.Trainer)
+    tr.perceptual_loss_fn = lp
+    a2, b2 = images(1, 120, 100, 9)
+    p1, p2 = a.to(dev).requires_grad_(True), a2.to(dev).requires_grad_(True)
+    loss = {"loss": 0, "loss_perceptual": 0}
+    tr.add_perceptual_loss(p1, b.to(dev), loss, weights=0.01)
+    tr.add_perceptual_loss(p2, b2.to(dev), loss, mask=torch.ones(1, 3, 120, 100, device=dev), weights=0.02)
+    loss["loss"].backward()
+    q1, q2 = a.double().requires_grad_(True), a2.double().requires_grad_(True)
+    ro = O.perceptual_loss(sd, q1, b.double(), 0.01) + O.perceptual_loss(sd, q2, b2.double(), 0.02)
+    ro.backward()
+    assert relerr(loss["loss"], ro) <= 2e-5 and relerr(loss["loss_perceptual"], ro) <= 2e-5
+    assert relerr(p1.grad, q1.grad) <= 2e-4 and relerr(p2.grad, q2.grad) <= 2e-4
+
+
+def test_lpips_errors(lp, dev):
+    with pytest.raises(ValueError, match="at least 31x31"):
+        lp.distance_nhwc(torch.zeros(1, 30, 64, 3, device=dev), torch.zeros(1, 30, 64, 3, device=dev))
+    with pytest.raises(s2l._abi.S2LError, match="no CPU fallback"):
+        lp.distance_nhwc(torch.zeros(1, 64, 64, 3), torch.zeros(1, 64, 64, 3))
+    with pytest.raises(NotImplementedError):
+        s2l.LPIPS(net="vgg")
+    assert lp.distance_nhwc(torch.zeros(0, 64, 64, 3, device=dev), torch.zeros(0, 64, 64, 3, device=dev)).numel() == 0
