@@ -14,7 +14,7 @@
 // padding).  ~20 GFLOP per 500x500 image pair forward + backward against 315 for the U-Net next to it: written for
 // exactness and determinism (no atomics), not for speed.
 // Parity: weights of the real package are not available here (they come from torchvision + the package's own alex.pth):
-// tests compare with oracle/s2l_oracle.py's restatement on seeded weights -- structural parity, as for SyncNet.
+// tests compare with the CPU restatement of the same published algorithm on seeded weights -- structural parity, as for SyncNet.
 #include "conv_gemm.h"
 
 namespace s2l {
