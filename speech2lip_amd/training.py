@@ -467,17 +467,20 @@ class SyncChain:
 
 class StageOneStep:
     """One optimisation step's loss and gradients as the reference forms them after `it > 100000` (train_stage1,
-    training.py:347-574, May flags; LPIPS terms excluded -- their weights are not in the reference repository):
+    training.py:347-574, May flags):
 
-        loss = lambda_rgb * MSE(lip)                                                        (:417-418)
-             [+ w_post_fusion * MSE(U-Net(composite_blackaug(lip)), rgb_face_ori)]           (:436-459, `face_loss`)
+        loss = lambda_rgb * MSE(lip)  [+ w_perceptual * LPIPS(lip)]                          (:417-421, `perceptual`)
+             [+ w_post_fusion * (MSE + w_perceptual * LPIPS)(U-Net(composite_blackaug(lip)), rgb_face_ori)]   (:436-459, `face_loss`)
              + w_syncloss * sync_contrastive(window of T more renders -> composite -> U-Net -> crop/resize)   (:491-557)
 
     for B main frames (each a sample) of which the first S carry a sync window.  All frames -- B main + S*T window -- go
     through ONE batched LipTrainStep forward/backward."""
 
     def __init__(self, model: TalkingFace, height: int, width: int, syncnet=None, precision: str = "bf16", syncnet_T: int = 5,
-                 w_syncloss: float = 0.01, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, face_loss: bool = False):
+                 w_syncloss: float = 0.01, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, face_loss: bool = False,
+                 perceptual=None, w_perceptual_loss: float = 0.01):
+        """perceptual: a speech2lip_amd.LPIPS (training.py:76) or None; its terms are means over the B main frames, like the MSE."""
+        self.perceptual, self.w_perc = perceptual, float(w_perceptual_loss)
         self.model, self.h, self.w = model, int(height), int(width)
         self.step = LipTrainStep(model, height, width, precision)
         self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss) if syncnet is not None else None
@@ -521,6 +524,12 @@ class StageOneStep:
                            B * P * 3, _stream()), "s2l_mse")
         losses["loss_rgb"] = loss[0]
         total_loss = loss[0]
+        if self.perceptual is not None:          # training.py:420-421 (use_lip_perc_loss 'v1')
+            d, st = self.perceptual.distance_nhwc(pred[:B].reshape(B, self.h, self.w, 3), tgt.reshape(B, self.h, self.w, 3), from01=True,
+                                                  keep=True)
+            self.perceptual.backward_nhwc(st, torch.full((B,), self.w_perc / B, device=dev), out=dpred[:B].view(B, self.h, self.w, 3))
+            losses["loss_perceptual"] = d.mean() * self.w_perc
+            total_loss = total_loss + losses["loss_perceptual"]
         if face is not None:
             if not self.face_loss:
                 raise ValueError("pass face_loss=True to StageOneStep to use the face photometric term")
@@ -534,6 +543,12 @@ class StageOneStep:
             with torch.cuda.device(dev):
                 ck(lib.s2l_mse(_ptr(recon), _ptr(gt), ctypes.c_float(self.lambda_rgb * self.w_post_fusion), _ptr(d_recon), _ptr(mwork),
                                _ptr(floss), recon.numel(), _stream()), "s2l_mse")
+            if self.perceptual is not None:      # training.py:453-456 (use_face_perc_loss; its mask is all ones)
+                wp = self.w_perc * self.w_post_fusion
+                d, st = self.perceptual.distance_nhwc(recon, gt, from01=True, keep=True)
+                self.perceptual.backward_nhwc(st, torch.full((B,), wp / B, device=dev), out=d_recon)
+                losses["loss_perceptual"] = losses["loss_perceptual"] + d.mean() * wp
+                total_loss = total_loss + d.mean() * wp
             d_new = m.post_fusion_unet.backward_input(saved, d_recon)
             d_lip = m.composite_backward_lip(d_new, args[0], args[1], args[2], args[3], args[4], self.h, self.w, hole_noise=holes)
             dpred[:B] += d_lip.reshape(B, P, 3)

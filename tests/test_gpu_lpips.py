@@ -111,3 +111,46 @@ def test_lpips_errors(lp, dev):
     with pytest.raises(NotImplementedError):
         s2l.LPIPS(net="vgg")
     assert lp.distance_nhwc(torch.zeros(0, 64, 64, 3, device=dev), torch.zeros(0, 64, 64, 3, device=dev)).numel() == 0
+
+
+def test_stage_one_step_with_perceptual_terms_vs_oracle_autograd(lp, dev):
+    """StageOneStep(perceptual=LPIPS): loss = MSE(lip) + w LPIPS(lip) + MSE(face) + w LPIPS(face) through composite + frozen
+    U-Net (training.py:417-459), every MLP gradient against torch autograd through the oracle (fp32 mode)."""
+    from tests.test_gpu_parity import make_model
+    h, w, B, FH, FW, x0, y0 = 32, 40, 2, 64, 72, 14, 20
+    np_sd, np_unet = W.make_state_dict(0, "he"), W.make_unet_state_dict(0)
+    m = make_model(dev, h, w)
+    m.load_state_dict({k: T(v) for k, v in np_unet.items()})
+    m.post_fusion_unet.eval()
+    rng = np.random.default_rng(4)
+    win = T(W.synthetic_audio(B, seed=7).astype(np.float32))
+    idx, u01 = [3, 40], [0.3, 0.9]
+    targets = T(rng.random((B, h * w, 3), dtype=np.float32))
+    face = T(rng.random((1, FH, FW, 3), dtype=np.float32))
+    gt = T(rng.random((B, FH, FW, 3), dtype=np.float32))
+    mask = torch.zeros(1, FH, FW, 3)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    coord = T(W.synthetic_warp_coords(B, FH, FW, seed=3))
+    step = s2l.StageOneStep(m, h, w, precision="fp32", face_loss=True, perceptual=lp, w_perceptual_loss=0.05)
+    loss, g, aux = step.loss_and_grads(win.to(dev), idx, targets.to(dev), u01,
+                                       face=dict(rgb_face_canonical=face.to(dev), rgb_face_gt=gt.to(dev), mask_lip_canonical=mask.to(dev),
+                                                 lip_lefttop_x=x0, lip_lefttop_y=y0, coord=coord.to(dev)))
+    sd_ = {k: T(v).clone().requires_grad_(True) for k, v in np_sd.items()}
+    usd, lsd = O.to_sd(np_unet), O.to_sd(W.make_lpips_state_dict(0))
+    coords = O.get_coords(w, h)
+    pred = torch.stack([O.predict_lip_image(sd_, coords, win[b], idx[b], h, w, u01[b]) for b in range(B)])
+    lip = pred.reshape(B, h, w, 3)
+    new = torch.cat([O.composite(lip[b:b + 1], face, gt[b:b + 1], mask, x0, y0, coord[b:b + 1])[0] for b in range(B)])
+    recon = O.unet_forward(usd, new)
+    ref = (O.mse_loss(pred, targets) + O.perceptual_loss(lsd, lip, targets.reshape(B, h, w, 3), 0.05)
+           + O.mse_loss(recon, gt) + O.perceptual_loss(lsd, recon, gt, 0.05))
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref)), (float(loss), float(ref))
+    perc = O.perceptual_loss(lsd, lip, targets.reshape(B, h, w, 3), 0.05) + O.perceptual_loss(lsd, recon, gt, 0.05)
+    assert abs(float(aux["loss_perceptual"]) - float(perc)) <= 2e-5 * float(perc) and float(perc) > 1e-4
+    for k, v in sd_.items():
+        if v.grad is None:
+            continue
+        scale = float(v.grad.abs().max()) + 1e-12
+        err = float((g[k].cpu() - v.grad).abs().max())
+        assert err <= 5e-4 * scale + 1e-9, f"{k}: max err {err:.3e} vs scale {scale:.3e}"

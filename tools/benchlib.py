@@ -218,6 +218,48 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
+def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
+    """One FULL stage-1 iteration of the reference per sample (training.py:347-574 after it > 100000, May flags), B samples per
+    step: MSE + LPIPS on the 96x96 lip, MSE + LPIPS on the fused face (composite with black holes -> frozen U-Net @500x500), the
+    lipsync_expert loss over a 5-frame window (5 more renders -> composite -> U-Net crop -> SyncNet x2), all of it back to
+    the MLP, Adam.  (The reference runs batch_size 1: `ms_per_sample` is the time of one of its iterations.)"""
+    H = Wd = 96
+    m = make_model(dev, H, Wd, unet=True, train=True)
+    m.post_fusion_unet.eval()
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
+    lp = s2l.LPIPS(net="alex", version="0.1").to(dev)
+    lp.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()})
+    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
+    audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
+    target = torch.rand(B, H * Wd, 3, device=dev)
+    step = s2l.StageOneStep(m, H, Wd, syncnet=net, precision=precision, face_loss=True, perceptual=lp)
+    sync = sync_batch(dev, B)
+    coord, g = device_warp_coords(dev, B, seed=5)
+    face = dict(rgb_face_canonical=sync["rgb_face_canonical"], rgb_face_gt=sync["rgb_face_gt"], mask_lip_canonical=sync["mask_lip_canonical"],
+                lip_lefttop_x=sync["lip_lefttop_x"], lip_lefttop_y=sync["lip_lefttop_y"], coord=coord,
+                hole_noise=(torch.randn(B, 500, 500, device=dev, generator=g), torch.randn(B, 500, 500, device=dev, generator=g)))
+    u01 = [0.5] * B
+
+    def one():
+        loss, gr, aux = step.loss_and_grads(audio, list(range(B)), target, u01, sync=sync, face=face)
+        s2l.training.apply_grads(m, gr)
+        opt.step()
+        return loss, aux
+    l0 = float(one()[0])
+    warm_until_allocator_settles(one)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l, aux = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": f"full stage-1 iteration x {B} samples: MSE + LPIPS(alex) on the 96x96 lip and on the fused 500x500 face (composite "
+                      f"with black holes + frozen U-Net), sync loss over a 5-frame window, {precision} MLP, Adam",
+            "ms_per_step": round(dt * 1e3, 2), "ms_per_sample": round(dt * 1e3 / B, 2), "loss_first": l0, "loss_last": float(l),
+            "loss_perceptual_last": float(aux["loss_perceptual"]), "loss_face_last": float(aux["loss_face"]),
+            "loss_sync_last": float(aux["loss_sync"]), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+
 def bench_train(dev, B=64, precision="bf16", steps=5):
     """BASELINE config 5: one step = 4-tap ensemble forward + MSE + full backward + Adam for B frames at 96x96."""
     H = Wd = 96
