@@ -191,7 +191,26 @@ struct ConvArgs {
   const float* gate;  // or null: [F,H,W,cout]; the output is zeroed where gate <= 0 (ReLU mask of the backward pass)
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
   int relu;           // 1: ReLU in the epilogue (forward); 0: linear (input-gradient convolutions)
+#ifdef S2L_EXP_TRACE
+  long long* trace;   // experiment builds (tools/trace_conv.py): [workgroup][24] timestamps of this launch
+#endif
 };
+
+#ifdef S2L_EXP_TRACE
+static long long* g_conv_trace = nullptr;     // [launch][8192 workgroups][24]
+static int g_conv_launch = 0;
+extern "C" int s2l_debug_set_conv_trace(void* p) { g_conv_trace = static_cast<long long*>(p); g_conv_launch = 0; return 0; }
+#define CONV_TRACE(slot)                                                                                              \
+  do {                                                                                                                \
+    if (a.trace && threadIdx.x == 0)                                                                                  \
+      a.trace[(blockIdx.x + gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z)) * 24 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define CONV_TRACE_ARGS(a, grid)                                                                              \
+  (a).trace = (g_conv_trace && (int64_t)(grid).x * (grid).y * (grid).z <= 8192) ? g_conv_trace + (int64_t)(g_conv_launch++) * 8192 * 24 : nullptr
+#else
+#define CONV_TRACE(slot) do { } while (0)
+#define CONV_TRACE_ARGS(a, grid) do { } while (0)
+#endif
 
 __device__ __forceinline__ f4 mfma16u(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -210,6 +229,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   const float* inA = a.inA + frame * (int64_t)a.H * a.W * a.CA;
   const float* inB = a.inB ? a.inB + frame * (int64_t)a.H * a.W * a.CB : nullptr;
 
+  CONV_TRACE(0);
+#ifdef S2L_EXP_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    long long* t = a.trace + (blockIdx.x + gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z)) * 24;
+    t[22] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+    t[23] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+  }
+#endif
   f4 acc[4][4];   // [M-block][pixel group = tile row 4*wave + g]
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
@@ -254,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   fetch(0);
   commit();
   __syncthreads();
+  CONV_TRACE(1);
   for (int cc = 0; cc < nchunks; ++cc) {
     if (cc + 1 < nchunks) fetch(cc + 1);
 #pragma unroll
@@ -272,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[mb][g] = mfma16u(A4[mb][ks], B4[g][ks], acc[mb][g]);
     }
+    CONV_TRACE(2 + cc);
     __syncthreads();            // everyone is done reading chunk cc
     if (cc + 1 < nchunks) {
       commit();
@@ -353,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
       }
     }
   }
+  CONV_TRACE(20);
 }
 
 // ---- upsampling (MaxPool2d(2) lives in the conv epilogue) ------------------------------------------------------------------------------
@@ -416,6 +446,7 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   const int64_t gz = F * a.n_ct;
   if (gz > 65535) return S2L_E_SIZE;
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
+  CONV_TRACE_ARGS(a, grid);
   if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
@@ -440,7 +471,9 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
   a.n_ct = a.cout / 64;
   const int64_t gz = F * a.n_ct;
   if (gz > 65535) return S2L_E_SIZE;
-  hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)gz), dim3(256), 0, st, a);
+  const dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
+  CONV_TRACE_ARGS(a, grid);
+  hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
