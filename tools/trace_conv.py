@@ -29,26 +29,9 @@ t = t[t[:, 0] > 0]
 n = len(t)
 nch = int((t[0, 2:18] > 0).sum())
 print(f"launch {which}: {n} workgroups, {nch} chunks each")
-t0 = t[:, 0].min()
 life = t[:, 20] - t[:, 0]
 pro = t[:, 1] - t[:, 0]
 chunks = np.diff(t[:, 1:2 + nch], axis=1)
 epi = t[:, 20] - t[:, 1 + nch]
-print(f"kernel span {t[:, 20].max() - t0} ticks; workgroup lifetime median {np.median(life):.0f} (p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f})")
+print(f"workgroup lifetime median {np.median(life):.0f} (p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f})")
 print(f"  prologue (first fetch + commit + barrier) median {np.median(pro):.0f}; per chunk median {np.median(chunks):.0f} (p10 {np.percentile(chunks, 10):.0f}, p90 {np.percentile(chunks, 90):.0f}; ideal alone 18432, sharing a SIMD 36864); epilogue {np.median(epi):.0f}")
-hw, xcc = t[:, 22], t[:, 23] & 0xf
-cu_key = (xcc << 16) | ((hw >> 8) & 0xff) << 0 | ((hw >> 13) & 0x7) << 8      # cu_id + sh, se
-# co-residency: for each CU, sweep the intervals
-ev = {}
-for k, a, b in zip(cu_key, t[:, 0], t[:, 20]):
-    ev.setdefault(int(k), []).append((a, 1)); ev[int(k)].append((b, -1))
-tot = {0: 0, 1: 0, 2: 0, 3: 0}
-for k, e in ev.items():
-    e.sort()
-    cur, last = 0, t0
-    for tm, d in e:
-        tot[min(cur, 3)] += tm - last
-        cur += d; last = tm
-    tot[0] += t[:, 20].max() - last
-s = sum(tot.values())
-print(f"  {len(ev)} distinct CU keys; time share with 0/1/2/3+ workgroups resident on a CU: " + ", ".join(f"{k}: {v / s:.3f}" for k, v in tot.items()))
