@@ -74,6 +74,18 @@ class Trainer:
         if self.use_syncloss and self.syncnet is None:
             from .syncnet import SyncNet_color
             self.syncnet = SyncNet_color().to(self.device)
+        # the other loss switches of training.py:21-100 (May values unless overridden)
+        tc = self.cfg["training"]
+        self.use_post_fusion = bool(kwargs.get("use_post_fusion", self.cfg["model"].get("use_post_fusion", True)))
+        self.fusion_lip_only = self.use_fusion_face = True
+        self.w_photometric_loss = float(kwargs.get("w_photometric_loss", tc.get("lambda_rgb", 1.0)))
+        self.w_post_fusion = float(kwargs.get("w_post_fusion", tc.get("w_post_fusion", 1.0)))
+        self.use_perceptual_loss = bool(kwargs.get("use_perceptual_loss", tc.get("use_perceptual_loss", False)))
+        self.w_perceptual_loss = float(kwargs.get("w_perceptual_loss", tc.get("w_perceptual_loss", 0.01)))
+        self.perceptual_loss_fn = kwargs.get("perceptual_loss_fn")
+        if self.use_perceptual_loss and self.perceptual_loss_fn is None:      # training.py:75-76
+            from .lpips import LPIPS
+            self.perceptual_loss_fn = LPIPS(net="alex", version="0.1", model_path="models/lpips_weights_v0.1/alex.pth").to(self.device)
 
     def load_checkpoint_syncnet(self, path, model=None):
         """training.py:130-138: `lipsync_expert.pth` holds {'state_dict': ...}, keys possibly prefixed by 'module.'."""
@@ -157,6 +169,78 @@ class Trainer:
         loss_perceptual = d.mean() * weights
         loss["loss"] = loss["loss"] + loss_perceptual
         loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + loss_perceptual.detach().cpu()
+
+
+    def train_stage1(self, data, eval_model=False, it=None, seed=None):
+        """One optimisation step as the reference performs it (training.py:347-574) under the May flags, through the drop-in's
+        methods and their hand-written backward kernels:  zero_grad -> lip render -> MSE [+ LPIPS] on the lip -> composite with
+        black holes + post-fusion U-Net -> [LPIPS +] MSE on the face -> canonical-depth photo loss (v2) -> after it > 100000 the
+        sync loss over the 5-frame window -> backward -> NaN check -> optimizer.step().  Returns (loss_rgb, loss dict) like the
+        reference.  One frame per call (batch_size 1, batch_rays = H*W: the only case the reference's own crop code supports,
+        :536-537)."""
+        tc, m = self.cfg["training"], self.model
+        b, self.height, self.width = int(data["rgb"].shape[0]), int(data["rgb"].shape[1]), int(data["rgb"].shape[2])
+        if b != 1 or self.batch_rays != self.height * self.width:
+            raise NotImplementedError("train_stage1: one frame per step with batch_rays = H*W (the May configuration)")
+        depth_v2 = bool(tc.get("use_canonical_depth_loss_photo_v2", False))
+        loss = {"loss_rgb": 0}
+        if self.use_perceptual_loss:
+            loss["loss_perceptual"] = 0
+        if self.use_syncloss:
+            loss["loss_sync"] = 0
+        if depth_v2:
+            loss["loss_canonical_depth_photo"] = 0
+        dev = self.device
+        on = lambda t: t.to(dev) if isinstance(t, torch.Tensor) else t
+        H, W = self.height, self.width
+        coords = self.prepare_coords(data.get("coord"), b)
+        rgb = on(data["rgb"]).reshape(-1, 3)
+        self.optimizer.zero_grad()
+        loss["loss"] = 0
+        first = int(data["index"].reshape(-1)[0]) if isinstance(data["index"], torch.Tensor) else int(data["index"])
+        rgb_map = self.predict_lip_image(0, coords, on(data["audio"]), None, {"index": torch.tensor([first])}, None, None, seed=seed)
+        if tc.get("use_lip_photo_loss", "v1") == "v1":
+            self.add_photometric_loss(rgb_map, rgb, loss, weights=self.w_photometric_loss)
+        if self.use_perceptual_loss and tc.get("use_lip_perc_loss", "v1") == "v1":
+            self.add_perceptual_loss(rgb_map.reshape(1, H, W, 3), rgb.reshape(1, H, W, 3), loss, weights=self.w_perceptual_loss)
+        x0, y0 = data["lip_lefttop_x"], data["lip_lefttop_y"]
+        if self.use_post_fusion:
+            face_gt, face_can = on(data["rgb_face_ori"]), on(data["rgb_face_zero"])
+            recon, _, _ = m.post_fusion2_onlylip(rgb_map.reshape(1, H, W, 3), face_can, face_gt, on(data["mask_lip_canonical"]), x0, y0,
+                                                 on(data["coord"]), mask_head_observed=None, use_post_fusion_blackaug=True)
+            if self.use_perceptual_loss and tc.get("use_face_perc_loss", True) is True:
+                self.add_perceptual_loss(recon, face_gt, loss, mask=torch.ones_like(recon).permute(0, 3, 1, 2),
+                                         weights=self.w_perceptual_loss * self.w_post_fusion)
+            if tc.get("use_face_photo_loss", True) is True:
+                self.add_photometric_loss(recon, face_gt, loss, weights=self.w_photometric_loss * self.w_post_fusion)
+            if depth_v2:      # :461-477: warp the observed frame into the canonical view with the learned depth
+                rel_pose = self.compute_rel_pose_inverse(on(data["canonical_euler"]), on(data["canonical_trans"]), on(data["euler"]),
+                                                         on(data["trans"]), device=dev)
+                mask = on(data["mask_head_3DMM_canonical"]) * (1 - on(data["mask_face_3DMM_canonical"]))
+                self.canonical_depth_photo_loss(m.canonical_depth_head, rel_pose, face_gt, face_can, loss, mask=mask)
+        if self.use_syncloss and it is not None and it > 100000 and tc.get("stage", "stage1") == "stage1":
+            from .autograd import crop_resize
+            total = int(data["total_frame"].reshape(-1)[0]) if isinstance(data["total_frame"], torch.Tensor) else int(data["total_frame"])
+            window = []
+            for t in range(int(data["audio_window"].shape[1])):
+                cur = {"index": torch.tensor([min(first + t, total - 1)]), "total_frame": data["total_frame"]}
+                lip = self.predict_lip_image(0, self.prepare_coords(None, b), on(data["audio_window"])[:, t], None, cur, None, None,
+                                             seed=seed).reshape(1, H, W, 3)
+                merged, _, _ = m.post_fusion2_onlylip(lip, on(data["rgb_face_zero"]), on(data["rgb_face_ori"]), on(data["mask_lip_canonical"]),
+                                                      x0, y0, on(data["coord_window"])[:, t], use_canonical_space=False)
+                bbox = data["canonical_face_bbox"][0] if isinstance(data["canonical_face_bbox"], torch.Tensor) else data["canonical_face_bbox"]
+                window.append(crop_resize(merged, [float(v) for v in bbox], (96, 96)).unsqueeze(0))
+            rgb_window = torch.cat(window, 0).permute(1, 4, 0, 2, 3)       # T,B,H,W,C -> B,C,T,H,W (:547-548)
+            loss_sync = self.get_sync_contrastive_loss(on(data["mel"]), rgb_window, on(data["rgb_window_neg"])) * self.w_syncloss
+            loss["loss_sync"] = loss["loss_sync"] + loss_sync
+            loss["loss"] = loss["loss"] + loss_sync
+        loss["loss"].backward()
+        for k, v in m.state_dict().items():          # check_weights (src/common.py:56-64)
+            if v.dtype.is_floating_point and torch.isnan(v).any():
+                import logging
+                logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
+        self.optimizer.step()
+        return loss["loss_rgb"], loss
 
 
 # ----------------------------------------------------------------------------------------------------------------------

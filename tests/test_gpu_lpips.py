@@ -154,3 +154,47 @@ def test_stage_one_step_with_perceptual_terms_vs_oracle_autograd(lp, dev):
         scale = float(v.grad.abs().max()) + 1e-12
         err = float((g[k].cpu() - v.grad).abs().max())
         assert err <= 5e-4 * scale + 1e-9, f"{k}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_trainer_train_stage1_with_perceptual_terms_equals_the_fused_step(lp, dev):
+    """Trainer.train_stage1 (training.py:347-574) with use_perceptual_loss on -- LPIPS on the lip (:420-421) and on the fused face
+    (:453-456) next to the two MSE terms -- leaves the gradients of the fused StageOneStep(perceptual=...) in .grad."""
+    import random
+    from tests.test_gpu_parity import make_model
+    h, w, FH, FW, x0, y0 = 32, 40, 64, 72, 14, 20
+    m = make_model(dev, h, w).train()
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    m.post_fusion_unet.eval()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    rng = np.random.default_rng(11)
+    data = {"audio": T(W.synthetic_audio(1, seed=5).astype(np.float32)), "rgb": T(rng.random((1, h, w, 3), dtype=np.float32)),
+            "index": torch.tensor([17]), "total_frame": torch.tensor([599]), "coord": T(W.synthetic_warp_coords(1, FH, FW, seed=2)),
+            "rgb_face_zero": T(rng.random((1, FH, FW, 3), dtype=np.float32)), "rgb_face_ori": T(rng.random((1, FH, FW, 3), dtype=np.float32)),
+            "lip_lefttop_x": x0, "lip_lefttop_y": y0}
+    mask = torch.zeros(1, FH, FW, 3)
+    mask[:, y0:y0 + h, x0:x0 + w] = 1
+    data["mask_lip_canonical"] = mask
+    holes = (T(rng.standard_normal((1, FH, FW)).astype(np.float32)), T(rng.standard_normal((1, FH, FW)).astype(np.float32)))
+    cfg = {**m.cfg, "training": {**m.cfg["training"], "use_canonical_depth_loss_photo_v2": False, "batch_rays": h * w}}
+    tr = s2l.Trainer(m, optimizer=torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=cfg,
+                     use_syncloss=False, use_perceptual_loss=True, w_perceptual_loss=0.05, perceptual_loss_fn=lp)
+    saved = (torch.rand, torch.randn, random.random)
+    fq = [holes[0][:, None].repeat(1, 3, 1, 1), holes[1][:, None].repeat(1, 3, 1, 1)]
+    torch.rand = lambda *a, **k: torch.full((1,), 0.42, device=dev)
+    torch.randn = lambda *a, **k: fq.pop(0)
+    random.random = lambda: 0.9
+    try:
+        _, loss = tr.train_stage1(data, it=10, seed=0)
+    finally:
+        torch.rand, torch.randn, random.random = saved
+    step = s2l.StageOneStep(m, h, w, precision="fp32", face_loss=True, perceptual=lp, w_perceptual_loss=0.05)
+    ref_loss, ref_g, aux = step.loss_and_grads(data["audio"].to(dev), [17], data["rgb"].reshape(1, -1, 3).to(dev), [0.42],
+                                               face=dict(rgb_face_canonical=data["rgb_face_zero"].to(dev), rgb_face_gt=data["rgb_face_ori"].to(dev),
+                                                         mask_lip_canonical=mask.to(dev), lip_lefttop_x=x0, lip_lefttop_y=y0,
+                                                         coord=data["coord"].to(dev), hole_noise=(holes[0].to(dev), holes[1].to(dev))))
+    assert abs(float(loss["loss"].detach()) - float(ref_loss)) <= 2e-6 * max(1.0, float(ref_loss))
+    assert abs(float(loss["loss_perceptual"]) - float(aux["loss_perceptual"])) <= 1e-6 and float(aux["loss_perceptual"]) > 1e-4
+    params = dict(m.named_parameters())
+    for k, gk in ref_g.items():
+        assert relerr(params[k].grad.reshape(gk.shape), gk.cpu()) <= 2e-4, (k, relerr(params[k].grad.reshape(gk.shape), gk.cpu()))

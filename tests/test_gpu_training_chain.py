@@ -552,3 +552,69 @@ def test_sync_chain_unet_window_is_bit_identical_to_full_frames(golden, syncnet,
         assert float(l_w) == float(l_f)
         assert float(d_f.abs().max()) > 0
         assert relerr(d_w, d_f.cpu()) <= 1e-5, (bbox, relerr(d_w, d_f.cpu()))      # float atomics in the composite's scatter
+
+
+def _patched_draws(eps, holes, dev):
+    """torch.rand / torch.randn / random.random as tools/make_goldens.py patched them around the reference's train_stage1."""
+    import random
+    eq = [float(v) for v in eps]
+    fq = [holes[0].cpu()[:, None].repeat(1, 3, 1, 1), holes[1].cpu()[:, None].repeat(1, 3, 1, 1)]
+    saved = (torch.rand, torch.randn, random.random)
+    torch.rand = lambda *a, **k: torch.full((1,), eq.pop(0), device=dev)
+    torch.randn = lambda *a, **k: fq.pop(0)
+    random.random = lambda: 0.9
+
+    def restore():
+        import random as r
+        torch.rand, torch.randn, r.random = saved
+        return eq, fq
+    return restore
+
+
+def test_trainer_train_stage1_reproduces_the_reference_step(golden, syncnet, dev):
+    """Trainer.train_stage1 -- the reference's own method name, arguments and return value (training.py:347-574) -- on the data
+    dict the goldens were generated from: after it > 100000 (frozen U-Net, sync window; G11) and before (U-Net trained; G14).
+    Loss dictionary and the gradients left in .grad against what the REFERENCE's train_stage1 produced on the same inputs."""
+    g, data, eps, _, face = _g11_device(golden, dev)
+    cfgm = lambda m: {**m.cfg, "training": {**m.cfg["training"], "use_canonical_depth_loss_photo_v2": False, "use_perceptual_loss": False,
+                                            "use_sync_contrastive_loss": True, "stage": "stage1", "batch_rays": 16 * 24}}
+    # ---- G11: it = 100001
+    m = full_model(dev, 16, 24).train()
+    m.post_fusion_unet.eval()                                              # train.py:188-197
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
+    tr = s2l.Trainer(m, optimizer=opt, cfg=cfgm(m), syncnet=syncnet, use_syncloss=True)
+    restore = _patched_draws(eps, face["hole_noise"], dev)
+    try:
+        loss_rgb, loss = tr.train_stage1(data, it=100001, seed=0)
+    finally:
+        eq, fq = restore()
+    assert not eq and not fq                                               # six eps draws and two noise fields, as the reference
+    assert abs(float(loss["loss"]) - float(g["loss"])) <= 3e-6 and abs(float(loss["loss_sync"]) - float(g["loss_sync"])) <= 2e-6
+    assert abs(float(loss_rgb) - float(g["loss_rgb"])) <= 2e-6 and set(loss) == {"loss", "loss_rgb", "loss_sync"}
+    params = dict(m.named_parameters())
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            assert relerr(params[key[2:]].grad, g[key]) <= 5e-4, (key, relerr(params[key[2:]].grad, g[key]))
+    assert relerr(params["pts_linears.5.weight"].grad[:, 250:262], g["g_pts5_cols"]) <= 5e-4
+    # ---- G14: it = 50000, the U-Net in train mode and trained with the MLP
+    e = golden("g14_stage1_early.npz")
+    m = full_model(dev, 16, 24).train()
+    tr = s2l.Trainer(m, optimizer=torch.optim.SGD(m.parameters(), lr=0.0), cfg=cfgm(m), syncnet=syncnet, use_syncloss=True)
+    restore = _patched_draws(e["eps"], face["hole_noise"], dev)
+    try:
+        _, loss = tr.train_stage1(data, it=50000, seed=0)
+    finally:
+        eq, fq = restore()
+    assert not eq and not fq and float(loss["loss_sync"]) == 0.0
+    assert abs(float(loss["loss"]) - float(e["loss"])) <= 5e-6
+    params = dict(m.named_parameters())
+    for key in e:
+        if key.startswith("g_"):
+            got, ref = params[key[2:]].grad.cpu(), T(e[key])
+            err = (got - ref).abs() / float(ref.abs().max())
+            if key[2:].startswith("post_fusion_unet"):
+                assert float(err.max()) <= 5e-2 and float((err > 5e-3).float().mean()) <= 0.05, (key, float(err.max()))
+            else:
+                assert float(err.max()) <= 1e-3, (key, float(err.max()))
