@@ -4,15 +4,19 @@ text (build.py runs this before hipcc; the kernel `#include`s the result inside 
 Why assembly: the renderer runs one wave per SIMD (512 registers), and on CDNA4 a wave's VALU instructions do NOT overlap its
 own MFMAs -- every VALU instruction between two MFMAs costs its 4 cycles plus a ~9-cycle pipe switch
 (tools/ubench/gen_mfma_shadow.py), while LDS reads, LDS-DMA issues and SALU are free.  So the layer body must contain nothing
-but MFMAs, ds_reads and scalar code, with the few unavoidable VALU instructions (ReLU = accvgpr_read + v_max per value, one
-ring-address add per slab) bunched.  hipcc's version of the same loop spends 106.9 k cycles per layer; this schedule spends
-101 k (tools/ubench/gen_layer_asm.py), the MFMAs alone 98.3 k.  The arithmetic -- operands, accumulation order, roundings -- is
-that of the C++ kernel it replaces: frames are bit-identical.
+but MFMAs, ds_reads and scalar code, with the few unavoidable VALU instructions (ReLU = accvgpr_read + v_max per value, the
+17 ring addresses of a layer) bunched between two layers.  hipcc's version of the same loop spent 106.9 k cycles per layer; this
+schedule spends 100.6 k (tools/trace_tiles.py; tools/ubench/gen_layer_asm.py is the same loop as a stand-alone benchmark), the
+MFMAs alone 98.3 k.  The arithmetic -- operands, accumulation order, roundings -- is that of the C++ kernel it replaced: frames
+are bit-identical (tools/ab_render.py).
 
 Structure (see render.hip for the tile / ring / table description): 117 ring steps per tile; a layer = 16 slabs of
 16 k-quads x 4 k-steps x 3 sample groups = 3072 MFMAs; A quads come from the ring two quads ahead into four rotating
-register sets; the slab's bias is read straight into AGPRs and enters as srcC of the first three MFMAs; at k-quad 14 the
-slab's buffer is retired (lgkmcnt / vmcnt / s_barrier) and refilled by four LDS-DMA loads tucked behind MFMAs.
+register sets; the slab's bias is read straight into AGPRs and enters as srcC of the first three MFMAs; the scalar half of
+the ring protocol runs behind the MFMAs of k-quad 13, then lgkmcnt / vmcnt / s_barrier retire the slab's buffer and four
+LDS-DMA loads refill it from behind the MFMAs of k-quad 14.  The four table refills per tile and the q5/p5 step of
+pts_linears[5] are out of line, behind scalar branches on the layer counter.  The generator tracks every LDS operation in
+flight and derives each s_waitcnt lgkmcnt(n) from that list; it asserts that all paths into the layer loop carry the same list.
 
 Register map (per wave):  v0-191 B operands in[g][k] | v192-207 four A-quad sets | v208.. addresses and temporaries
                           a0-191 accumulators acc[g][mb][r] | a192-195 bias / srcC | a196-207 output-layer accumulators
