@@ -4,9 +4,10 @@ text (build.py runs this before hipcc; the kernel `#include`s the result inside 
 Why assembly: the renderer runs one wave per SIMD (512 registers), and on CDNA4 a wave's VALU instructions do NOT overlap its
 own MFMAs -- every VALU instruction between two MFMAs costs its 4 cycles plus a ~9-cycle pipe switch
 (tools/ubench/gen_mfma_shadow.py), while LDS reads, LDS-DMA issues and SALU are free.  So the layer body must contain nothing
-but MFMAs, ds_reads and scalar code, with the few unavoidable VALU instructions (ReLU = accvgpr_read + v_max per value, the
-17 ring addresses of a layer) bunched between two layers.  hipcc's version of the same loop spent 106.9 k cycles per layer; this
-schedule spends 100.6 k (tools/trace_tiles.py; tools/ubench/gen_layer_asm.py is the same loop as a stand-alone benchmark), the
+but MFMAs, ds_reads and scalar code, with the few unavoidable VALU instructions (the v_max of the ReLU, the 17 ring addresses of a
+layer) bunched between two layers; even the accumulator -> B-register move of the ReLU goes through LDS (ds_write from AGPRs,
+ds_read into VGPRs) because that is free and v_accvgpr_read is not.  hipcc's version of the same loop spent 106.9 k cycles per layer; this
+schedule spends 99.95 k (tools/trace_tiles.py; tools/ubench/gen_layer_asm.py is the same loop as a stand-alone benchmark), the
 MFMAs alone 98.3 k.  The arithmetic -- operands, accumulation order, roundings -- is that of the C++ kernel it replaced: frames
 are bit-identical (tools/ab_render.py).
 
@@ -30,7 +31,7 @@ KRING, SLAB, NSLABS, NLAYERS = 9, 16384, 113, 7
 # ---- vector registers
 V_IN, V_W = 0, 192
 V_LANE16, V_RING, V_DMAOFF, V_BIAS, V_QADDR, V_TMP, V_BOUT, V_PIXOFF = 208, 209, 210, 211, 212, 213, 214, 215
-V_T0, V_BIAS0, V_PIX = 216, 220, 221          # V_T0..V_T0+3: one f4 of temporaries
+V_T0, V_BIAS0, V_PIX, V_SCR = 216, 220, 221, 222   # V_T0..V_T0+3: one f4 of temporaries; V_SCR: this wave's 1 KiB LDS scratch
 V_RA = 224                                      # 17 ring addresses of a layer: slabs 0..15 and the slab after
 V_LAST = 240
 A_ACC, A_BIAS, A_RGB = 0, 192, 196
@@ -193,7 +194,10 @@ class Body:
                 c = first_c if (first_c and j == 0 and jj == 0) else dst(g)
                 self.e(f"v_mfma_f32_16x16x4_f32 {dst(g)}, v{w + jj}, v{self.inreg(g, j * 4 + jj)}, {c}")
                 for t in sprinkle.pop(jj * G + g, []):
-                    self.e(t)
+                    if isinstance(t, tuple):
+                        self.lds_op(t[1], t[2])
+                    else:
+                        self.e(t)
         assert not sprinkle
 
     def a_read(self, slab_tag, tq, areg):
@@ -233,6 +237,15 @@ class Body:
                        f"s_add_u32 {s('IS')}, {s('IS')}, 1", f"s_cmp_eq_u32 {s('IS')}, {NSLABS}",
                        f"s_cselect_b64 {s2('WPTR')}, {s2('WBASE')}, {s2('WPTR')}", f"s_cselect_b32 {s('IS')}, 0, {s('IS')}"]
                 sprinkle = {0: [dma[0]], 3: [dma[1]], 6: [dma[2]], 9: [dma[3], *ptr]}
+            if mb == 15 and j >= 1:
+                # The layer's last slab: once k-quad j-1 has been issued, block j-1 of the B registers is dead and block j-1
+                # of the accumulators has been final since slab j-1 -- move it across through this wave's LDS scratch
+                # (ds_write from AGPRs, ds_read into VGPRs: free next to MFMAs; LDS executes a wave's operations in order),
+                # so that only v_max is left for the VALU block between the layers.
+                for g in range(G):
+                    b0, a0 = self.inreg(g, (j - 1) * 4), A_ACC + (g * 16 + j - 1) * 4
+                    sprinkle.setdefault(1 + 4 * g, []).append(("lds", f"ds_write_b128 v{V_SCR}, a[{a0}:{a0 + 3}]", ("W", g, j - 1)))
+                    sprinkle.setdefault(2 + 4 * g, []).append(("lds", f"ds_read_b128 v[{b0}:{b0 + 3}], v{V_SCR}", ("R", g, j - 1)))
             self.quad_mfmas(mb, j, dst, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]", sprinkle=sprinkle)
             if j == 14:
                 e(f"{join}:")
@@ -249,18 +262,25 @@ class Body:
                 e(f"s_sub_u32 {s('T6')}, {s('T6')}, {s('T7')}")
             e(f"v_add_u32 v{V_RA + i}, {s('T6')}, v{V_LANE16}")
 
-    def relu_all(self):
+    def last_block_to_b_registers(self):
+        """after the layer's last slab: blocks 0..14 of the accumulators already sit in the B registers (slab 15 moved them
+        through LDS); block 15, which that slab produced, follows by v_accvgpr_read"""
         e = self.e
+        self.wait_all_lds()
         e("s_nop 7")
         e("s_nop 3")
+        for g in range(G):
+            b = A_ACC + (g * 16 + 15) * 4
+            for r in range(4):
+                e(f"v_accvgpr_read_b32 v{self.inreg(g, 60 + r)}, a{b + r}")
+
+    def relu_all(self):
+        self.last_block_to_b_registers()
         for mb in range(16):
             for g in range(G):
-                b = A_ACC + (g * 16 + mb) * 4
-                for r in range(4):
-                    e(f"v_accvgpr_read_b32 v{self.inreg(g, mb * 4 + r)}, a{b + r}")
                 for r in range(4):
                     v = self.inreg(g, mb * 4 + r)
-                    e(f"v_max_f32 v{v}, 0, v{v}")
+                    self.e(f"v_max_f32 v{v}, 0, v{v}")
 
     # ---- table steps
     def q_step(self, with_acc):
@@ -274,8 +294,7 @@ class Body:
                     self.lds_op(f"ds_read_b128 v[{b}:{b + 3}], v{V_TMP} offset:{g * 1024 + mb * 64}", ("Q", g, mb))
             self.wait_all_lds()
             return
-        e("s_nop 7")
-        e("s_nop 3")
+        self.last_block_to_b_registers()      # in = acc
         items = [(g, mb) for g in range(G) for mb in range(16)]
         for n in range(3):
             g, mb = items[n]
@@ -286,9 +305,7 @@ class Body:
                 g2, mb2 = items[n + 3]
                 t2 = V_W + 4 * ((n + 3) % 4)
                 self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_TMP} offset:{g2 * 1024 + mb2 * 64}", ("Q", g2, mb2))
-            b, a0, t = self.inreg(g, mb * 4), A_ACC + (g * 16 + mb) * 4, V_W + 4 * (n % 4)
-            for r in range(4):
-                e(f"v_accvgpr_read_b32 v{b + r}, a{a0 + r}")
+            b, t = self.inreg(g, mb * 4), V_W + 4 * (n % 4)
             self.wait_lds(("Q", g, mb))
             e(f"v_pk_add_f32 v[{b}:{b + 1}], v[{b}:{b + 1}], v[{t}:{t + 1}]")
             e(f"v_pk_add_f32 v[{b + 2}:{b + 3}], v[{b + 2}:{b + 3}], v[{t + 2}:{t + 3}]")
@@ -340,7 +357,7 @@ def generate():
     e(f"s_mov_b32 {s('IS')}, 0")
     e(f"s_mov_b32 {s('CUR')}, 0")
     e(f"s_mov_b32 {s('CURB')}, 0")
-    for dst, src in ((V_LANE16, "lane16"), (V_DMAOFF, "dmaoff"), (V_BIAS0, "biasaddr"), (V_QADDR, "qaddr"), (V_BOUT, "boutaddr"), (V_PIX, "px")):
+    for dst, src in ((V_LANE16, "lane16"), (V_DMAOFF, "dmaoff"), (V_BIAS0, "biasaddr"), (V_QADDR, "qaddr"), (V_BOUT, "boutaddr"), (V_PIX, "px"), (V_SCR, "scraddr")):
         e(f"v_mov_b32 v{dst}, %[{src}]")
     # prime the ring: q0 and p0 of the first tile, weight slabs 0..5 (steps 0..7 -> buffers 0..7)
     e(f"s_mov_b32 {s('T')}, {s('LDSBASE')}")
@@ -399,14 +416,14 @@ def generate():
     p0n = lambda: b.p_refill("P0", "PGN")
     for mb in range(16):
         b.slab(mb, {7: [(4, q5)], 8: [(4, p5), (6, q0n)], 9: [(6, p0n)]}.get(mb))
-    end_state = [(t[0], t[1] - 16) + t[2:] for t in b.lds]
-    assert end_state == loop_state, (end_state, loop_state)
+    slab_end = list(b.lds)         # the first quads of the next slab + the tail of the accumulator moves: both continuations
+    assert [t for t in slab_end if t[0] == "A"] == [("A", 16, 0), ("A", 16, 1)]      # below wait for all of it first
     e(f"s_cmp_eq_u32 {s('LAYER')}, 4")
     e("s_cbranch_scc1 S2L_SKIP")
     b.relu_all()
     b.ring_table()
+    b.lds = list(loop_state)       # (complete, which is stronger than "in flight")
     if TRACE:
-        b.lds = list(loop_state)
         b.trace("layer")
         e("s_nop 0")      # (the first quads are waited for as "in flight": already complete, which is stronger)
         b.lds = list(loop_state)
@@ -471,8 +488,7 @@ def generate():
 
     # ================= out of line: pts_linears[5] on cat([skip, h4]): + q5[frame] + p5[pixel], ReLU
     e("S2L_SKIP:")
-    b.lds = list(loop_state)   # (quads read from the q5 step: discarded)
-    b.wait_all_lds()
+    b.lds = list(slab_end)     # (the two quads read from the q5 step are discarded)
     b.q_step(True)
     b.advance()
     b.weight_refill()
@@ -499,7 +515,7 @@ OPERANDS = """      :
       : [ldsbase] "s"(ldsbase), [npg] "s"(a.npg), [gdiv] "s"(gdiv), [gmod] "s"(gmod), [tile0] "s"(tile0), [ntiles] "s"(a.ntiles),
         [grid] "s"(grid), [nframes] "s"(a.nframes), [hw] "s"(a.hw), [fg0] "s"(fg0), [pg0] "s"(pg0), [fgl] "s"(fgl), [pgl] "s"(pgl),
         [wave] "s"(wave), [wsrc] "s"(wsrc), [q0] "s"(a.q0), [q5] "s"(a.q5), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [out] "s"(a.out),
-        [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px)TRACE_OPERAND
+        [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px), [scraddr] "v"(scraddr)TRACE_OPERAND
 """
 
 

@@ -23,8 +23,8 @@
 // The kernel BODY is one fixed-register assembly text, written at build time by csrc/gen_render_body.py (which also says
 // why: with one wave per SIMD, VALU instructions never overlap the wave's own MFMAs, so the schedule has to be owned, not
 // suggested).  The C++ below only unpacks the arguments.  The C++ version of the same loop, kept until commit 62292d8,
-// produced the same bits at 0.905-0.915 of the fp32-MFMA peak; this one runs at 0.93-0.94 (the rest is mostly clock: at full
-// load the part settles at 2.29-2.33 GHz, 0.969 of the cycles are MFMA cycles).
+// produced the same bits at 0.905-0.915 of the fp32-MFMA peak; this one runs at 0.94-0.95 (the rest is mostly clock: at full
+// load the part settles at 2.29-2.33 GHz, 0.975 of the cycles are MFMA cycles).
 #include "s2l_common.h"
 
 namespace s2l {
@@ -44,8 +44,10 @@ constexpr int kRing = 9;                       // 16 KiB steps resident in LDS (
 constexpr int kSlabBytes = kSlab * 4;          // 16384
 constexpr int kTileFrames = 12, kTilePixels = 16;
 constexpr int kBiasFloats = kHidden * kW + 4;  // OFF_BIAS .. OFF_BOUT+4 are contiguous in the blob
-// ring + bias block + 64 B: the body prefetches "the next slab's bias" once past the block's end (unused values)
-constexpr int kLdsBytes = kRing * kSlabBytes + kBiasFloats * 4 + 64;
+// ring + bias block + 76 B (the body prefetches "the next slab's bias" once past the block's end: unused values; the scratch
+// below is 16-byte aligned) + 1 KiB of scratch per wave (accumulators -> B registers between two layers)
+constexpr int kScratchOff = kRing * kSlabBytes + (kBiasFloats * 4 + 64 + 15) / 16 * 16;
+constexpr int kLdsBytes = kScratchOff + 4 * 1024;
 static_assert(OFF_WOUT == OFF_WMLP + int64_t(kHidden) * 16 * kSlab, "weight slabs must be contiguous");
 static_assert(OFF_BOUT == OFF_BIAS + kHidden * kW, "bias block must be contiguous");
 static_assert(kHidden == 7 && kSlabBytes == 16384, "gen_render_body.py is written for 7 MFMA layers of 16 KiB slabs");
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   const uint32_t biasaddr = lds0 + kRing * kSlabBytes + 16 * q;              // bias of features 16 mb + 4 q .. + 3
   const uint32_t boutaddr = lds0 + kRing * kSlabBytes + kHidden * kW * 4;    // output-layer bias (rows >= 3 are zero)
   const uint32_t qaddr = lds0 + wave * 3072 + q * 16;                        // q rows of this wave's three frames
+  const uint32_t scraddr = lds0 + kScratchOff + wave * 1024 + lane * 16;     // this wave's scratch
 #include "render_body.inc"
 }
 
