@@ -25,7 +25,8 @@ ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16" \
             "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
-            "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8"; do
+            "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
+            "stage1_full:tools/bench_train.py 8 bf16 --full"; do
   name=${spec%%:*}; cmd=${spec#*:}
   python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1

@@ -55,7 +55,8 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
                     ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
                     ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
                     ("config3_nounet", "BASELINE config 3: lip 128x128 + composite, 5000 frames: python tools/bench_config3.py 5000 500"),
-                    ("stage1_sync", "BASELINE config 5 with the sync loss: python tools/bench_train.py 64 bf16 --sync=8")):
+                    ("stage1_sync", "BASELINE config 5 with the sync loss: python tools/bench_train.py 64 bf16 --sync=8"),
+                    ("stage1_full", "full stage-1 iteration (MSE + LPIPS on lip and face, U-Net, sync window): python tools/bench_train.py 8 bf16 --full")):
     rows = stats("x_" + name)
     if not rows:
         continue
