@@ -38,7 +38,7 @@ A_ACC, A_BIAS, A_RGB = 0, 192, 196
 A_LAST = 207
 # ---- scalar registers (all owned by the body; the compiler's operands live elsewhere)
 S = {n: 36 + i for i, n in enumerate(
-    "CUR T LDSBASE CURB WPTR WPTR1 WBASE WBASE1 IS LAYER FG PG NPG GDIV GMOD TILE NTILES GRID NFM1 HW FGN PGN FGL PGL "
+    "CUR T LDSBASE CURB WPTR WPTR1 WBASE WBASE1 IS LAYER FG PG NFG PADA PADB TILE TEND PADC NFM1 HW FGN PGN PADD PADE "
     "Q0 Q01 Q5 Q51 P0 P01 P5 P51 OUT OUT1 WAVE PAD T4 T5 T6 T7 T8 T9 EX EX1 NFRAMES PAD2 TRACE TRACE1".split())}
 TRACE = os.environ.get("S2L_RENDER_TRACE") == "1"      # experiment builds only (tools/trace_tiles.py): per-tile phase timestamps
 # pairs must be even-aligned
@@ -346,9 +346,8 @@ def generate():
     b.outofline = []
     e = b.e
     # ================= prologue: operands -> owned registers
-    for dst, src in (("LDSBASE", "ldsbase"), ("NPG", "npg"), ("GDIV", "gdiv"), ("GMOD", "gmod"), ("TILE", "tile0"), ("NTILES", "ntiles"),
-                     ("GRID", "grid"), ("NFRAMES", "nframes"), ("HW", "hw"), ("FG", "fg0"), ("PG", "pg0"), ("FGL", "fgl"), ("PGL", "pgl"),
-                     ("WAVE", "wave")):
+    for dst, src in (("LDSBASE", "ldsbase"), ("NFG", "nfg"), ("TILE", "tile0"), ("TEND", "tile_end"), ("NFRAMES", "nframes"), ("HW", "hw"),
+                     ("FG", "fg0"), ("PG", "pg0"), ("WAVE", "wave")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
     for dst, src in (("WBASE", "wsrc"), ("Q0", "q0"), ("Q5", "q5"), ("P0", "p0"), ("P5", "p5"), ("OUT", "out")) + ((("TRACE", "trace"),) if TRACE else ()):
         e(f"s_mov_b64 {s2(dst)}, %[{src}]")
@@ -382,18 +381,19 @@ def generate():
 
     # ================= tile loop
     e("S2L_TILE:")
-    # coordinates of the tile whose tables are prefetched during layer 6: this workgroup's next tile, or the last tile
-    e(f"s_add_u32 {s('PGN')}, {s('PG')}, {s('GMOD')}")
-    e(f"s_add_u32 {s('FGN')}, {s('FG')}, {s('GDIV')}")
-    e(f"s_cmp_ge_u32 {s('PGN')}, {s('NPG')}")
-    e(f"s_cselect_b32 {s('T6')}, {s('NPG')}, 0")
-    e(f"s_cselect_b32 {s('T7')}, 1, 0")
-    e(f"s_sub_u32 {s('PGN')}, {s('PGN')}, {s('T6')}")
-    e(f"s_add_u32 {s('FGN')}, {s('FGN')}, {s('T7')}")
-    e(f"s_add_u32 {s('T7')}, {s('TILE')}, {s('GRID')}")
-    e(f"s_cmp_lt_u32 {s('T7')}, {s('NTILES')}")
-    e(f"s_cselect_b32 {s('FGN')}, {s('FGN')}, {s('FGL')}")
-    e(f"s_cselect_b32 {s('PGN')}, {s('PGN')}, {s('PGL')}")
+    # A workgroup owns a contiguous range of tiles in pixel-group-major order (tile t = pixel group t / nfg, frame group
+    # t % nfg): for ~84 tiles in a row the p0 / p5 rows it streams are the ones it streamed for the previous tile, i.e. L2
+    # hits instead of HBM reads.  (FGN, PGN): the tile whose tables are prefetched during layer 6 -- the next one, or, on
+    # the range's last tile, the same one again (valid addresses, unused data).
+    e(f"s_add_u32 {s('FGN')}, {s('FG')}, 1")
+    e(f"s_cmp_eq_u32 {s('FGN')}, {s('NFG')}")
+    e(f"s_cselect_b32 {s('FGN')}, 0, {s('FGN')}")
+    e(f"s_cselect_b32 {s('T6')}, 1, 0")
+    e(f"s_add_u32 {s('PGN')}, {s('PG')}, {s('T6')}")
+    e(f"s_add_u32 {s('T7')}, {s('TILE')}, 1")
+    e(f"s_cmp_lt_u32 {s('T7')}, {s('TEND')}")
+    e(f"s_cselect_b32 {s('FGN')}, {s('FGN')}, {s('FG')}")
+    e(f"s_cselect_b32 {s('PGN')}, {s('PGN')}, {s('PG')}")
     # ---- h0 = relu(p0[pixel] + q0[frame])
     b.trace(0)
     b.q_step(False)
@@ -478,10 +478,10 @@ def generate():
     e(f"s_mov_b64 exec, {s2('EX')}")
     b.trace(9)
     # ---- next tile of this workgroup
-    e(f"s_add_u32 {s('TILE')}, {s('TILE')}, {s('GRID')}")
+    e(f"s_add_u32 {s('TILE')}, {s('TILE')}, 1")
     e(f"s_mov_b32 {s('FG')}, {s('FGN')}")
     e(f"s_mov_b32 {s('PG')}, {s('PGN')}")
-    e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
+    e(f"s_cmp_lt_u32 {s('TILE')}, {s('TEND')}")
     e("s_cbranch_scc1 S2L_TILE")
     e("s_waitcnt vmcnt(0)")     # run-ahead DMAs must land before the workgroup's LDS is released
     e("s_branch S2L_END")
@@ -512,8 +512,8 @@ def generate():
 
 
 OPERANDS = """      :
-      : [ldsbase] "s"(ldsbase), [npg] "s"(a.npg), [gdiv] "s"(gdiv), [gmod] "s"(gmod), [tile0] "s"(tile0), [ntiles] "s"(a.ntiles),
-        [grid] "s"(grid), [nframes] "s"(a.nframes), [hw] "s"(a.hw), [fg0] "s"(fg0), [pg0] "s"(pg0), [fgl] "s"(fgl), [pgl] "s"(pgl),
+      : [ldsbase] "s"(ldsbase), [nfg] "s"(nfg), [tile0] "s"(tile0), [tile_end] "s"(tile_end), [nframes] "s"(a.nframes), [hw] "s"(a.hw),
+        [fg0] "s"(fg0), [pg0] "s"(pg0),
         [wave] "s"(wave), [wsrc] "s"(wsrc), [q0] "s"(a.q0), [q5] "s"(a.q5), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [out] "s"(a.out),
         [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px), [scraddr] "v"(scraddr)TRACE_OPERAND
 """

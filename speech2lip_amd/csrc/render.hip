@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   const int q = lane >> 4, px = lane & 15;      // k-subgroup and sample of this lane in every 16x16x4 MFMA
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ldsbase = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);   // this wave's quarter of ring buffer 0
-  // tile t = frame group t / npg, pixel group t % npg; the body steps (fg, pg) by (gdiv, gmod) instead of dividing
-  const int grid = (int)gridDim.x, tile0 = (int)blockIdx.x;
-  const int gdiv = __builtin_amdgcn_readfirstlane(grid / a.npg), gmod = __builtin_amdgcn_readfirstlane(grid % a.npg);
-  const int fg0 = __builtin_amdgcn_readfirstlane(tile0 / a.npg), pg0 = __builtin_amdgcn_readfirstlane(tile0 % a.npg);
-  const int fgl = __builtin_amdgcn_readfirstlane((a.ntiles - 1) / a.npg), pgl = __builtin_amdgcn_readfirstlane((a.ntiles - 1) % a.npg);
+  // this workgroup's tiles: a contiguous range in pixel-group-major order, tile t = (pixel group t / nfg, frame group t % nfg)
+  const int nfg = __builtin_amdgcn_readfirstlane(a.ntiles / a.npg);
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * blockIdx.x / gridDim.x));
+  const int tile_end = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * (blockIdx.x + 1) / gridDim.x));
+  const int fg0 = __builtin_amdgcn_readfirstlane(tile0 % nfg), pg0 = __builtin_amdgcn_readfirstlane(tile0 / nfg);
   const float* wsrc = a.packed + OFF_WMLP;
   const uint32_t lane16 = lds0 + lane * 16;                                  // A quads and p rows are lane-linear
   const uint32_t dmaoff = wave * 4096 + lane * 16;                           // this lane's 16 B of a 16 KiB step

@@ -283,3 +283,17 @@ def test_parity_on_weights_moved_by_training(dev):
     for k in ref_g:
         sc = float(ref_g[k].abs().max()) + 1e-12
         assert float((g[k].cpu() - ref_g[k]).abs().max()) <= 3e-4 * sc, k
+
+
+def test_render_clip_bits_are_pinned(dev):
+    """The renderer has been rewritten three times (C++ with compiler-scheduled loads, C++ on the LDS-DMA ring, generated
+    assembly) with the arithmetic -- operands, accumulation order, roundings -- unchanged: the sha256 of the 1000-frame 96x96 clip
+    of tools/ab_render.py is the same for all of them.  A schedule change must keep it; an arithmetic change must say so here."""
+    import hashlib
+    from tools.benchlib import make_model as bench_model
+    m = bench_model(dev, 96, 96)
+    for frames, digest in ((24, "cac76c6f37cf20de"), (1000, "4eb292b93e4ac3c7")):
+        audio = T(W.synthetic_audio(frames, 1).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            clip = m.render_clip(audio, torch.arange(frames, device=dev), 96, 96)
+        assert hashlib.sha256(clip.cpu().numpy().tobytes()).hexdigest()[:16] == digest, frames
