@@ -93,9 +93,10 @@ class SimpleUnetLight(nn.Module):
         if out is None:
             out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        # frames go through in groups that keep the activation workspace around 2 GiB
+        # frames go through in groups that keep the activation workspace around 16 GiB of the 288: every convolution is one
+        # launch per group, and a launch needs many waves of workgroups (512 fit at a time) to amortise its ramp and tail
         per_frame = int(lib.s2l_unet_work_floats(H, W, 1))
-        group = max(1, min(F_, (1 << 29) // max(per_frame, 1)))
+        group = max(1, min(F_, (1 << 32) // max(per_frame, 1)))
         work = torch.empty(per_frame * group, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             for s in range(0, F_, group):
