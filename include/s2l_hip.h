@@ -286,11 +286,18 @@ int s2l_unet_backward(const float* packed, const float* saved, const float* d_ou
  * that the align_corners=True up-samplings take their source positions from the FULL frame's geometry: every output and gradient
  * whose dependency cone (radius <= 32 pixels) stays inside the crop equals the full-frame value bit for bit; values nearer than
  * that to a crop edge that is not a frame edge must not be used. */
-int s2l_unet_forward_saved_window(const float* packed, const float* x, float* saved, float* out, int height, int width,
-                                  int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames, s2l_stream_t stream);
-int s2l_unet_backward_window(const float* packed, const float* saved, const float* d_out, float* work, float* d_x, int height,
-                             int width, int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames,
-                             s2l_stream_t stream);
+int s2l_unet_forward_saved_window(const float* packed, const uint16_t* packed16, const float* x, float* saved, float* out,
+                                  int height, int width, int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames,
+                                  s2l_stream_t stream);
+int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, const float* saved, const float* d_out, float* work,
+                             float* d_x, int height, int width, int full_h, int full_w, int origin_y, int origin_x,
+                             int64_t n_frames, s2l_stream_t stream);
+/* packed16 (or NULL): the nine 3x3 layers in bf16 operand form, s2l_unet_packed16_halves() uint16 written by s2l_unet_pack16
+ * (same tensor table and BatchNorm fold as s2l_unet_pack).  With it those convolutions and their input-gradient twins run on
+ * v_mfma_f32_32x32x16_bf16 -- bf16 weights and staged inputs, fp32 accumulation, fp32 tensors in HBM -- the precision BASELINE
+ * config 5 names for the training step; NULL = exact fp32 everywhere.  The first 3->64 and the last (fused 1x1) layers stay fp32. */
+int64_t s2l_unet_packed16_halves(void);
+int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, uint16_t* packed16, s2l_stream_t stream);
 
 /* TRAIN mode of the same network, as the reference runs it until `it > 100000` (train.py:188-197): every BatchNorm2d normalises
  * with the statistics of the batch (biased variance) and updates its running statistics in place (momentum, unbiased variance:

@@ -65,10 +65,12 @@ EXPORTS = {
                                        c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_train_backward": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int64, c_void_p]),
-    "s2l_unet_forward_saved_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
-                                              c_void_p]),
-    "s2l_unet_backward_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                         c_int64, c_void_p]),
+    "s2l_unet_forward_saved_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                              c_int64, c_void_p]),
+    "s2l_unet_backward_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int64, c_void_p]),
+    "s2l_unet_packed16_halves": (c_int64, []),
+    "s2l_unet_pack16": (c_int, [c_void_p, ctypes.c_float, c_void_p, c_void_p]),
     "s2l_crop_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_crop_resize_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64,
                                          c_void_p]),

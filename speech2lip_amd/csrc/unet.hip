@@ -116,6 +116,43 @@ __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float 
   for (int i = tid; i < 4; i += nt) packed[kUnetOutB + i] = i < 3 ? t.outb[i] : 0.f;
 }
 
+// ---- bf16 operand form of the 3x3 layers 1..9 (training chain in the precision BASELINE config 5 names) -------------------
+// conv3x3_bf16_kernel runs the same implicit GEMM on v_mfma_f32_32x32x16_bf16: weights and the staged input tile are bf16,
+// accumulation, bias / ReLU / gate and every tensor in HBM stay fp32.  A chunk = (64 output channels, 32 input channels):
+// 9 taps x 2 k-steps x 2 M-blocks x 64 lanes x 8 bf16; lane l of an A quad holds W[row 32 mb + (l & 31)][k 16 s + 8 (l >> 5) + j].
+constexpr int kChunk16Halves = 9 * 2 * 2 * 64 * 8;
+__host__ __device__ constexpr int64_t unet_w16_off(int layer) {
+  int64_t off = 0;
+  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 32) * kChunk16Halves;
+  return off;
+}
+__host__ __device__ constexpr int64_t unet_wT16_off(int layer) {
+  int64_t off = unet_w16_off(10);
+  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cin / 64) * (kUnetConvs[l].cout / 32) * kChunk16Halves;
+  return off;
+}
+constexpr int64_t kUnetPacked16Halves = unet_wT16_off(10);
+
+__device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // round to nearest even
+
+// one thread per packed bf16 element; transposed = the input-gradient form (rows = forward input channels, taps mirrored)
+__global__ void unet_pack_conv16(UnetTensors t, int layer, uint16_t* __restrict__ packed16, float eps, int transposed) {
+  const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
+  const int rows = transposed ? cin : cout, kdim = transposed ? cout : cin;
+  const int64_t n = (int64_t)(rows / 64) * (kdim / 32) * kChunk16Halves;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int j = e & 7, lane = (e >> 3) & 63, mb = (e >> 9) & 1, ks = (e >> 10) & 1;
+  const int tap = (int)((e >> 11) % 9);
+  const int64_t chunk = e / kChunk16Halves;
+  const int cc = (int)(chunk % (kdim / 32)), ct = (int)(chunk / (kdim / 32));
+  const int row = ct * 64 + mb * 32 + (lane & 31), k = cc * 32 + ks * 16 + 8 * (lane >> 5) + j;
+  const int co = transposed ? k : row, ci = transposed ? row : k;
+  const float scale = eps < 0.f ? 1.f : t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  packed16[(transposed ? unet_wT16_off(layer) : unet_w16_off(layer)) + e] =
+      to_bf16(t.w[layer][((int64_t)co * cin + ci) * 9 + (transposed ? 8 - tap : tap)] * scale);
+}
+
 // ---- first conv: 3 -> 64 on MFMA (0.5 % of the FLOPs, but 64 MB of output per frame: write-bound) -----------------------
 // D[co][pixel] = sum_k W[co][k] in[k][pixel], k = c*9 + tap (27, zero-padded to 28 = 7 k-steps of v_mfma_f32_16x16x4_f32): the
 // same fma chain, in the same order, as a scalar loop over k.  A wave owns 16 consecutive pixels per iteration: lane
@@ -191,6 +228,7 @@ struct ConvArgs {
   const float* gate;  // or null: [F,H,W,cout]; the output is zeroed where gate <= 0 (ReLU mask of the backward pass)
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
   int relu;           // 1: ReLU in the epilogue (forward); 0: linear (input-gradient convolutions)
+  const uint16_t* w16;   // conv3x3_bf16_kernel: packed bf16 chunks [cout/64][cin/32][kChunk16Halves]
 #ifdef S2L_EXP_TRACE
   long long* trace;   // experiment builds (tools/trace_conv.py): [workgroup][24] timestamps of this launch
 #endif
@@ -431,9 +469,163 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 static UpWin no_window(int h, int w, int Ho, int Wo) { return UpWin{h, w, Ho, Wo, 0, 0, 0, 0}; }
 
+// ---- the same convolution with bf16 operands (ConvArgs::w16) ---------------------------------------------------------------
+// Tile, grid, inputs and epilogue as conv3x3_kernel (no fused 1x1 output convolution).  Input channels go through LDS 32 at a
+// time: the 18x18 halo tile as bf16 [pixel][32 channels] with an 80-byte pixel stride (conflict-free ds_read_b128 of the 32
+// pixels of an N-block), converted from the fp32 activations on the way in, and the chunk's weights in A-operand order
+// (36.9 KB).  Per tap and k-step a wave issues 2 + 2 ds_read_b128 for 4 MFMAs of 32x32x16; wave w owns tile rows 4w..4w+3 as
+// two N-blocks of 2 rows x 16 pixels.  16x fewer matrix-pipe cycles than the fp32 form: the kernel is bound by staging and HBM.
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef short bf8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+constexpr int kPix16 = 40;   // halves per halo pixel: 32 channels + 8 of padding
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf2v v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f16v mfma32_bf16(u4v a, u4v b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds_in[18 * 18 * kPix16];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_w[kChunk16Halves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hh = lane >> 5;
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  const int ct = blockIdx.z % a.n_ct;
+  const int64_t frame = blockIdx.z / a.n_ct;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int cin = a.CA + a.CB;
+  const int nchunks = cin / 32;
+  const float* inA = a.inA + frame * (int64_t)a.H * a.W * a.CA;
+  const float* inB = a.inB ? a.inB + frame * (int64_t)a.H * a.W * a.CB : nullptr;
+
+  f16v acc[2][2];   // [M-block of 32 channels][N-block: tile rows 4 wave + 2 nb, + 1]
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = a.bias ? a.bias[ct * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+
+  constexpr int kInQuads = 18 * 18 * 8;                 // f4 (4 fp32 channels) elements of the halo tile
+  constexpr int kInPer = (kInQuads + 255) / 256;        // 11 (the last pass is partial)
+  constexpr int kWPer = kChunk16Halves / 8 / 256;       // 9
+  f4 pin[kInPer];
+  u4v pw[kWPer];
+  auto fetch = [&](int cc) {
+    const bool fromA = cc * 32 < a.CA;
+    const float* src = fromA ? inA : inB;
+    const int C = fromA ? a.CA : a.CB;
+    const int coff = fromA ? cc * 32 : cc * 32 - a.CA;
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int pi = i >> 3, c4 = i & 7;
+      const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
+      pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+        pin[k] = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * c4);
+    }
+    const u4v* wsrc = reinterpret_cast<const u4v*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
+#pragma unroll
+    for (int k = 0; k < kWPer; ++k) pw[k] = wsrc[threadIdx.x + k * 256];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < kInQuads) {
+        uint2 h;
+        h.x = pack_bf16x2(pin[k][0], pin[k][1]);
+        h.y = pack_bf16x2(pin[k][2], pin[k][3]);
+        *reinterpret_cast<uint2*>(lds_in + (i >> 3) * kPix16 + 4 * (i & 7)) = h;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kWPer; ++k) reinterpret_cast<u4v*>(lds_w)[threadIdx.x + k * 256] = pw[k];
+  };
+  // halo pixel of this lane's column in N-block nb, before the tap offset
+  const int pbase = (4 * wave + (n >> 4)) * 18 + (n & 15);
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (cc + 1 < nchunks) fetch(cc + 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t % 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u4v A[2], B[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) A[mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + ks) * 2 + mb) * 64 + lane];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          B[nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * ks + 8 * hh);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[mb], B[nb], acc[mb][nb]);
+      }
+    }
+    __syncthreads();            // everyone is done reading chunk cc
+    if (cc + 1 < nchunks) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel (row 4 wave + 2 nb + (n >> 4), col n & 15)
+  const int gx = x0 + (n & 15);
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int gy = y0 + 4 * wave + 2 * nb + (n >> 4);
+    const bool ok = gy < a.H && gx < a.W;
+    const int64_t pix = frame * (int64_t)a.H * a.W + (int64_t)gy * a.W + gx;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        f4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = a.relu ? fmaxf(acc[mb][nb][4 * rr + r], 0.f) : acc[mb][nb][4 * rr + r];
+        if (ok) {
+          float* dst = a.out + pix * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh;
+          if (a.gate) {
+            const f4 gt = *reinterpret_cast<const f4*>(a.gate + (dst - a.out));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = gt[r] > 0.f ? h[r] : 0.f;
+          }
+          *reinterpret_cast<f4*>(dst) = h;
+        }
+        if (a.pool) {   // MaxPool2d(2): the N-block's two rows are lanes n and n ^ 16, the column pair n and n ^ 1
+          const int H2 = a.H / 2, W2 = a.W / 2;
+          const int py2 = (y0 + 4 * wave + 2 * nb) / 2, px2 = gx / 2;
+          f4 m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = fmaxf(acc[mb][nb][4 * rr + r], 0.f);
+            v = fmaxf(v, __shfl_xor(v, 16));
+            m[r] = fmaxf(v, __shfl_xor(v, 1));
+          }
+          if (!(n & 17) && py2 < H2 && px2 < W2)
+            *reinterpret_cast<f4*>(a.pool + ((frame * H2 + py2) * (int64_t)W2 + px2) * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = m;
+        }
+      }
+  }
+}
+
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
-                       float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr) {
+                       float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr,
+                       const uint16_t* packed16 = nullptr) {
   ConvArgs a;
+  a.w16 = packed16 ? packed16 + unet_w16_off(layer) : nullptr;
   a.inA = inA; a.inB = inB; a.CA = CA; a.CB = CB;
   a.cout = kUnetConvs[layer].cout;
   a.w = packed + unet_w_off(layer);
@@ -448,6 +640,7 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
   if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
+  else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
@@ -458,8 +651,9 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
 // dz -> dx of a 3x3 convolution is the same implicit GEMM with the transposed, tap-mirrored chunks (unet_pack_conv_T), no
 // bias, no ReLU, and the ReLU mask of the activation that FED the layer applied in the epilogue (`gate`).
 static int launch_conv_dgrad(const float* dz, const float* packed, int layer, float* dx, const float* gate, int H, int W,
-                             int64_t F, hipStream_t st) {
+                             int64_t F, hipStream_t st, const uint16_t* packed16 = nullptr) {
   ConvArgs a;
+  a.w16 = packed16 ? packed16 + unet_wT16_off(layer) : nullptr;
   a.inA = dz; a.inB = nullptr; a.CA = kUnetConvs[layer].cout; a.CB = 0;
   a.cout = kUnetConvs[layer].cin;
   a.w = packed + unet_wT_off(layer);
@@ -473,7 +667,8 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
   if (gz > 65535) return S2L_E_SIZE;
   const dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
-  hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
+  if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
@@ -1133,9 +1328,9 @@ static int unet_window(int height, int width, int full_h, int full_w, int oy, in
   return 0;
 }
 
-extern "C" int s2l_unet_forward_saved_window(const float* packed, const float* x, float* saved, float* out, int height, int width,
-                                             int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames,
-                                             s2l_stream_t stream) {
+extern "C" int s2l_unet_forward_saved_window(const float* packed, const uint16_t* packed16, const float* x, float* saved, float* out,
+                                             int height, int width, int full_h, int full_w, int origin_y, int origin_x,
+                                             int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
   { const int rcw = unet_window(height, width, full_h, full_w, origin_y, origin_x); if (rcw) return rcw; }
   if (n_frames == 0) return S2L_OK;
@@ -1149,33 +1344,33 @@ extern "C" int s2l_unet_forward_saved_window(const float* packed, const float* x
   int rc;
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), s.a0, H, W);
-  if ((rc = launch_conv(s.a0, 64, nullptr, 0, packed, 1, s.x1, nullptr, H, W, F, st, s.p1))) return rc;
-  if ((rc = launch_conv(s.p1, 64, nullptr, 0, packed, 2, s.a2, nullptr, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv(s.a2, 128, nullptr, 0, packed, 3, s.x2, nullptr, H2, W2, F, st, s.p2))) return rc;
-  if ((rc = launch_conv(s.p2, 128, nullptr, 0, packed, 4, s.a4, nullptr, H4, W4, F, st))) return rc;
-  if ((rc = launch_conv(s.a4, 128, nullptr, 0, packed, 5, s.x3, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv(s.a0, 64, nullptr, 0, packed, 1, s.x1, nullptr, H, W, F, st, s.p1, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(s.p1, 64, nullptr, 0, packed, 2, s.a2, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(s.a2, 128, nullptr, 0, packed, 3, s.x2, nullptr, H2, W2, F, st, s.p2, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(s.p2, 128, nullptr, 0, packed, 4, s.a4, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(s.a4, 128, nullptr, 0, packed, 5, s.x3, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
   const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
   const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, s.x3, s.u3, H4, W4, 128, H2, W2,
                      p2 * 32, w21);
-  if ((rc = launch_conv(s.x2, 128, s.u3, 128, packed, 6, s.a6, nullptr, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv(s.a6, 128, nullptr, 0, packed, 7, s.u1, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(s.x2, 128, s.u3, 128, packed, 6, s.a6, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(s.a6, 128, nullptr, 0, packed, 7, s.u1, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
                      p1 * 16, w10);
-  if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st))) return rc;
+  if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st, nullptr, nullptr, packed16))) return rc;
   if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9))) return rc;
   return (int)hipGetLastError();
 }
 
 extern "C" int s2l_unet_forward_saved(const float* packed, const float* x, float* saved, float* out, int height, int width,
                                       int64_t n_frames, s2l_stream_t stream) {
-  return s2l_unet_forward_saved_window(packed, x, saved, out, height, width, height, width, 0, 0, n_frames, stream);
+  return s2l_unet_forward_saved_window(packed, nullptr, x, saved, out, height, width, height, width, 0, 0, n_frames, stream);
 }
 
 // d_out [F,H,W,3] -> d_x [F,H,W,3], from the activations s2l_unet_forward_saved kept; work: s2l_unet_backward_work_floats.
-extern "C" int s2l_unet_backward_window(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
-                                        int height, int width, int full_h, int full_w, int origin_y, int origin_x,
-                                        int64_t n_frames, s2l_stream_t stream) {
+extern "C" int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, const float* saved, const float* d_out,
+                                        float* work, float* d_x, int height, int width, int full_h, int full_w, int origin_y,
+                                        int origin_x, int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
   { const int rcw = unet_window(height, width, full_h, full_w, origin_y, origin_x); if (rcw) return rcw; }
   if (n_frames == 0) return S2L_OK;
@@ -1193,22 +1388,22 @@ extern "C" int s2l_unet_backward_window(const float* packed, const float* saved,
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
   int rc;
   hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, packed + kUnetOutW, s.y9, zA, p1 * 16);   // z9
-  if ((rc = launch_conv_dgrad(zA, packed, 9, zB, s.a8, H, W, F, st))) return rc;                                          // z8
-  if ((rc = launch_conv_dgrad(zB, packed, 8, gcat8, nullptr, H, W, F, st))) return rc;                                    // [g_x1 | g_uu]
+  if ((rc = launch_conv_dgrad(zA, packed, 9, zB, s.a8, H, W, F, st, packed16))) return rc;                                          // z8
+  if ((rc = launch_conv_dgrad(zB, packed, 8, gcat8, nullptr, H, W, F, st, packed16))) return rc;                                    // [g_x1 | g_uu]
   const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
   const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
   hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64, H, W, p2 * 16, w10);
-  if ((rc = launch_conv_dgrad(z7, packed, 7, z6, s.a6, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv_dgrad(z6, packed, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                                  // [g_x2 | g_u3]
+  if ((rc = launch_conv_dgrad(z7, packed, 7, z6, s.a6, H2, W2, F, st, packed16))) return rc;
+  if ((rc = launch_conv_dgrad(z6, packed, 6, gcat6, nullptr, H2, W2, F, st, packed16))) return rc;                                  // [g_x2 | g_u3]
   hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, s.x3, z5, H4, W4, 128, H2, W2,
                      p4 * 32, w21);
-  if ((rc = launch_conv_dgrad(z5, packed, 5, z4, s.a4, H4, W4, F, st))) return rc;
-  if ((rc = launch_conv_dgrad(z4, packed, 4, gp2, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z5, packed, 5, z4, s.a4, H4, W4, F, st, packed16))) return rc;
+  if ((rc = launch_conv_dgrad(z4, packed, 4, gp2, nullptr, H4, W4, F, st, packed16))) return rc;
   hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, s.x2, s.p2, z3, H2, W2, 128, p2 * 32);
-  if ((rc = launch_conv_dgrad(z3, packed, 3, z2, s.a2, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv_dgrad(z2, packed, 2, gp1, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z3, packed, 3, z2, s.a2, H2, W2, F, st, packed16))) return rc;
+  if ((rc = launch_conv_dgrad(z2, packed, 2, gp1, nullptr, H2, W2, F, st, packed16))) return rc;
   hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p1 * 16), dim3(256), 0, st, gcat8, 128, gp1, s.x1, s.p1, zA, H, W, 64, p1 * 16);   // z1
-  if ((rc = launch_conv_dgrad(zA, packed, 1, zB, s.a0, H, W, F, st))) return rc;                                          // z0
+  if ((rc = launch_conv_dgrad(zA, packed, 1, zB, s.a0, H, W, F, st, packed16))) return rc;                                          // z0
   hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
                      packed + unet_w_off(0), d_x, H, W);
   return (int)hipGetLastError();
@@ -1216,7 +1411,7 @@ extern "C" int s2l_unet_backward_window(const float* packed, const float* saved,
 
 extern "C" int s2l_unet_backward(const float* packed, const float* saved, const float* d_out, float* work, float* d_x,
                                  int height, int width, int64_t n_frames, s2l_stream_t stream) {
-  return s2l_unet_backward_window(packed, saved, d_out, work, d_x, height, width, height, width, 0, 0, n_frames, stream);
+  return s2l_unet_backward_window(packed, nullptr, saved, d_out, work, d_x, height, width, height, width, 0, 0, n_frames, stream);
 }
 
 // ---- TRAIN mode entry points ------------------------------------------------------------------------------------------------
@@ -1231,6 +1426,26 @@ static int unet_table(const float* const* th, UnetTensors& t) {
   t.outw = th[50]; t.outb = th[51];
   return 0;
 }
+
+extern "C" int64_t s2l_unet_packed16_halves(void) { return kUnetPacked16Halves; }
+
+// bf16 operand blob of the nine 3x3 layers (forward and input-gradient form) for the `packed16` argument of the window entry
+// points; same tensor table and BatchNorm fold as s2l_unet_pack
+extern "C" int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, uint16_t* packed16, s2l_stream_t stream) {
+  if (!packed16) return S2L_E_NULL;
+  if (misaligned16(packed16)) return S2L_E_ALIGN;
+  UnetTensors t;
+  const int rc = unet_table(tensors_host, t);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 1; l < 10; ++l) {
+    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 32) * kChunk16Halves;     // same count both ways
+    hipLaunchKernelGGL(unet_pack_conv16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16, bn_eps, 0);
+    hipLaunchKernelGGL(unet_pack_conv16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16, bn_eps, 1);
+  }
+  return (int)hipGetLastError();
+}
+
 
 // RAW (un-folded) weights in the chunk layout, forward and transposed: what the train-mode network multiplies with.  Same table
 // and blob size as s2l_unet_pack; re-run after every optimizer step.
@@ -1298,6 +1513,7 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
                          packed_raw + unet_w_off(0), (const float*)nullptr, b.z[0], H, W);
     } else {
       ConvArgs a;
+      a.w16 = nullptr;
       a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
       a.w = packed_raw + unet_w_off(l); a.bias = nullptr; a.out = b.z[l]; a.out3 = nullptr; a.pool = nullptr; a.gate = nullptr; a.relu = 0;
       a.outw = a.outb = nullptr; a.H = hh[lv]; a.W = ww[lv];

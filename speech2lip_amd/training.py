@@ -469,7 +469,7 @@ class SyncChain:
     UNET_RADIUS = 40   # pixels: >= the U-Net's dependency radius (32: 2 + 4 + 8 down, 4 + 4 + 2 + 2 up, pooling alignment) + slack
 
     def __init__(self, model: TalkingFace, syncnet, syncnet_T: int = 5, w_syncloss: float = 0.01, out_hw=(96, 96),
-                 max_frames_per_group: int = 40, window: bool = True):
+                 max_frames_per_group: int = 40, window: bool = True, unet_precision: str = "fp32"):
         from .syncnet import SyncLoss
         if getattr(model, "post_fusion_unet", None) is None:
             raise ValueError("SyncChain needs model.use_post_fusion (the window is the U-Net's output)")
@@ -481,6 +481,7 @@ class SyncChain:
         # sync loss reads nothing else of its output (training.py:541-544) and every value it reads, and every gradient that
         # comes back, is bit-identical to the full-frame evaluation (s2l_unet_forward_saved_window)
         self.window = bool(window)
+        self.unet_precision = unet_precision      # "bf16": the frozen U-Net's 3x3 convolutions on the bf16 MFMA (fp32 accumulation)
 
     def unet_window(self, bbox, FH: int, FW: int):
         """(x0, y0, x1, y1) of the crop the U-Net runs on: the box dilated by UNET_RADIUS, on the 4-pixel grid of the two pooling
@@ -526,7 +527,7 @@ class SyncChain:
             new, _ = m.composite_clip(lips[fr], rgb_face_canonical, gt_f, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_f)
             crop = new[:, wy0:wy1, wx0:wx1].contiguous() if self.window else new
             ch, cw_ = crop.shape[1], crop.shape[2]
-            recon, saved = unet.forward_saved_nhwc(crop, window=win)
+            recon, saved = unet.forward_saved_nhwc(crop, window=win, precision=self.unet_precision)
             wnd = window[s0:s1]
             with torch.cuda.device(dev):
                 ck(lib.s2l_crop_resize(_ptr(recon), ch, cw_, x - wx0, y - wy0, x2 - wx0, y2 - wy0, _ptr(wnd), oh, ow, T, n * T, _stream()),
@@ -567,7 +568,9 @@ class StageOneStep:
         self.perceptual, self.w_perc = perceptual, float(w_perceptual_loss)
         self.model, self.h, self.w = model, int(height), int(width)
         self.step = LipTrainStep(model, height, width, precision)
-        self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss) if syncnet is not None else None
+        # precision "bf16" (BASELINE config 5): bf16 operands in the MLP kernels AND in the frozen U-Net's 3x3 convolutions
+        self.unet_precision = "bf16" if precision == "bf16" else "fp32"
+        self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss, unet_precision=self.unet_precision) if syncnet is not None else None
         self.T, self.lambda_rgb, self.w_post_fusion, self.face_loss = int(syncnet_T), float(lambda_rgb), float(w_post_fusion), face_loss
 
     def loss_and_grads(self, audio, frame_idx, targets, u01, sync=None, face=None):
@@ -622,7 +625,7 @@ class StageOneStep:
             gt = _dev_f32(face["rgb_face_gt"], dev, "rgb_face_gt")
             args = (face["rgb_face_canonical"], face["mask_lip_canonical"], face["lip_lefttop_x"], face["lip_lefttop_y"], face["coord"])
             new, _ = m.composite_clip(lip, args[0], gt, args[1], args[2], args[3], args[4], hole_noise=holes)
-            recon, saved = m.post_fusion_unet.forward_saved_nhwc(new)
+            recon, saved = m.post_fusion_unet.forward_saved_nhwc(new, precision=self.unet_precision)
             d_recon, floss = torch.empty_like(recon), _f(dev, 1)
             with torch.cuda.device(dev):
                 ck(lib.s2l_mse(_ptr(recon), _ptr(gt), ctypes.c_float(self.lambda_rgb * self.w_post_fusion), _ptr(d_recon), _ptr(mwork),

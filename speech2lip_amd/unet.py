@@ -77,6 +77,25 @@ class SimpleUnetLight(nn.Module):
             self._packed, self._packed_key = packed, key
         return self._packed
 
+    def packed_weights_bf16(self) -> torch.Tensor:
+        """The nine 3x3 layers in bf16 operand form (forward and input-gradient), for forward_saved_nhwc(precision="bf16")."""
+        lib = _abi.load()
+        tensors = self._tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if getattr(self, "_packed16", None) is None or key != self._packed16_key:
+            dev = tensors[0].device
+            if dev.type != "cuda":
+                raise _abi.S2LError(f"U-Net parameters are on {dev}; the HIP path needs a GPU (no CPU fallback)")
+            hold = [t.detach().to(torch.float32).contiguous() for t in tensors]
+            table = (ctypes.c_void_p * len(hold))(*[h.data_ptr() for h in hold])
+            packed16 = torch.empty(int(lib.s2l_unet_packed16_halves()), dtype=torch.int16, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_unet_pack16(table, ctypes.c_float(float(self.inc.double_conv[1].eps)), ctypes.c_void_p(packed16.data_ptr()),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_pack16")
+                torch.cuda.current_stream().synchronize()      # `hold` may be temporaries
+            self._packed16, self._packed16_key = packed16, key
+        return self._packed16
+
     def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """x [F,H,W,3] -> [F,H,W,3] (the layout the composite produces and the caller wants)."""
         lib = _abi.load()
@@ -182,13 +201,18 @@ class SimpleUnetLight(nn.Module):
             off += n
         return dx, grads
 
-    def forward_saved_nhwc(self, x: torch.Tensor, window=None):
+    def forward_saved_nhwc(self, x: torch.Tensor, window=None, precision: str = "fp32"):
         """Training-time forward of the frozen eval-mode network: x [F,H,W,3] -> (out [F,H,W,3], saved), where `saved` holds
         every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F.
         window = (full_h, full_w, origin_y, origin_x): x is a crop of a full frame (s2l_unet_forward_saved_window); values
-        within 32 pixels of a crop edge that is not a frame edge are not the full-frame values."""
+        within 32 pixels of a crop edge that is not a frame edge are not the full-frame values.
+        precision "bf16": the 3x3 convolutions (and their input gradients in backward_input) take bf16 operands on the
+        32x32x16 MFMA -- fp32 accumulation, fp32 tensors in memory -- the precision BASELINE config 5 names for training."""
         lib = _abi.load()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         packed = self.packed_weights()
+        packed16 = self.packed_weights_bf16() if precision == "bf16" else None
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         if self.training:
@@ -200,18 +224,19 @@ class SimpleUnetLight(nn.Module):
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
         saved = torch.empty(int(lib.s2l_unet_saved_floats(H, W, F_)), dtype=torch.float32, device=x.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
+        p16 = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(x.device):
             fh, fw, oy, ox = (H, W, 0, 0) if window is None else (int(v) for v in window)
-            _abi.check(lib.s2l_unet_forward_saved_window(p(packed), p(x), p(saved), p(out), H, W, fh, fw, oy, ox, F_,
+            _abi.check(lib.s2l_unet_forward_saved_window(p(packed), p16(packed16), p(x), p(saved), p(out), H, W, fh, fw, oy, ox, F_,
                                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                        "s2l_unet_forward_saved_window")
-        return out, (saved, packed, (F_, H, W), (fh, fw, oy, ox))
+        return out, (saved, packed, (F_, H, W), (fh, fw, oy, ox), packed16)
 
     def backward_input(self, saved_ctx, d_out: torch.Tensor) -> torch.Tensor:
         """d loss / d x [F,H,W,3] from d loss / d out, through the frozen network (what autograd propagates once the
         post-fusion net is fixed, train.py:188-197)."""
         lib = _abi.load()
-        saved, packed, (F_, H, W), (fh, fw, oy, ox) = saved_ctx
+        saved, packed, (F_, H, W), (fh, fw, oy, ox), packed16 = saved_ctx
         d = d_out.detach().to(torch.float32).contiguous()
         if d.shape != (F_, H, W, 3) or d.device != saved.device:
             raise ValueError(f"d_out must be [{F_},{H},{W},3] on {saved.device}")
@@ -219,7 +244,8 @@ class SimpleUnetLight(nn.Module):
         work = torch.empty(int(lib.s2l_unet_backward_work_floats(H, W, F_)), dtype=torch.float32, device=d.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(d.device):
-            _abi.check(lib.s2l_unet_backward_window(p(packed), p(saved), p(d), p(work), p(dx), H, W, fh, fw, oy, ox, F_,
+            _abi.check(lib.s2l_unet_backward_window(p(packed), ctypes.c_void_p(0 if packed16 is None else packed16.data_ptr()), p(saved), p(d),
+                                                    p(work), p(dx), H, W, fh, fw, oy, ox, F_,
                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward_window")
         return dx
 

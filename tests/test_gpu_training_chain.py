@@ -618,3 +618,39 @@ def test_trainer_train_stage1_reproduces_the_reference_step(golden, syncnet, dev
                 assert float(err.max()) <= 5e-2 and float((err > 5e-3).float().mean()) <= 0.05, (key, float(err.max()))
             else:
                 assert float(err.max()) <= 1e-3, (key, float(err.max()))
+
+
+@pytest.mark.parametrize("fh,fw,F", [(64, 80, 2), (500, 500, 1)])
+def test_unet_bf16_convolutions_vs_fp32(dev, fh, fw, F):
+    """precision="bf16" of the frozen U-Net (training chain, BASELINE config 5's precision): bf16 weights and staged inputs on the
+    32x32x16 MFMA, fp32 accumulation and fp32 tensors in memory.  Against the exact fp32 path: the output and the input-gradient
+    convolutions agree like bf16 operands allow (relative L2 error < 1e-2), pooled maps and ReLU gates included."""
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    x = T(W.synthetic_image((F, fh, fw, 3), 5, "x")).to(dev)
+    rng = np.random.default_rng(2)
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    o32, c32 = u.forward_saved_nhwc(x)
+    g32 = u.backward_input(c32, d)
+    o16, c16 = u.forward_saved_nhwc(x, precision="bf16")
+    g16 = u.backward_input(c16, d)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+
+    def cos(a, b):
+        return float((a.flatten() @ b.flatten()) / (a.norm() * b.norm()))
+    assert rel(o16, o32) <= 1e-2 and cos(o16, o32) >= 0.9999, (rel(o16, o32), cos(o16, o32))
+    assert not torch.equal(o16, o32)
+    # the input-gradient convolutions alone: fp32 forward state (identical ReLU / pooling decisions), bf16 operands in the backward
+    gm = u.backward_input((*c32[:4], c16[4]), d)
+    assert rel(gm, g32) <= 1.5e-2, rel(gm, g32)
+    # end to end the gradient is that of the bf16 forward: activations within bf16 rounding of zero resolve their ReLU the
+    # other way, which moves the gradient by far more than the operand rounding does (white-noise d: the worst case)
+    assert cos(g16, g32) >= 0.98 and rel(g16, g32) <= 0.25, (rel(g16, g32), cos(g16, g32))
+    # same result for a crop evaluated as a window of the full frame (the sync chain's use)
+    if fh == 500:
+        win = (fh, fw, 48, 68)
+        crop = x[:, 48:460, 68:432].contiguous()
+        ow, _ = u.forward_saved_nhwc(crop, window=win, precision="bf16")
+        assert torch.equal(ow[:, 40:-40, 40:-40], o16[:, 88:420, 108:392])
