@@ -295,7 +295,7 @@ int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, cons
 /* packed16 (or NULL): the nine 3x3 layers in bf16 operand form, s2l_unet_packed16_halves() uint16 written by s2l_unet_pack16
  * (same tensor table and BatchNorm fold as s2l_unet_pack).  With it those convolutions and their input-gradient twins run on
  * v_mfma_f32_32x32x16_bf16 -- bf16 weights and staged inputs, fp32 accumulation, fp32 tensors in HBM -- the precision BASELINE
- * config 5 names for the training step; NULL = exact fp32 everywhere.  The first 3->64 and the last (fused 1x1) layers stay fp32. */
+ * config 5 names for the training step; NULL = exact fp32 everywhere.  (The 3->64 first layer, 0.5 % of the work, stays fp32.) */
 int64_t s2l_unet_packed16_halves(void);
 int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, uint16_t* packed16, s2l_stream_t stream);
 

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 static UpWin no_window(int h, int w, int Ho, int Wo) { return UpWin{h, w, Ho, Wo, 0, 0, 0, 0}; }
 
 // ---- the same convolution with bf16 operands (ConvArgs::w16) ---------------------------------------------------------------
-// Tile, grid, inputs and epilogue as conv3x3_kernel (no fused 1x1 output convolution).  Input channels go through LDS 32 at a
+// Tile, grid, inputs and epilogue as conv3x3_kernel.  Input channels go through LDS 32 at a
 // time: the 18x18 halo tile as bf16 [pixel][32 channels] with an 80-byte pixel stride (conflict-free ds_read_b128 of the 32
 // pixels of an N-block), converted from the fp32 activations on the way in, and the chunk's weights in A-operand order
 // (36.9 KB).  Per tap and k-step a wave issues 2 + 2 ds_read_b128 for 4 MFMAs of 32x32x16; wave w owns tile rows 4w..4w+3 as
@@ -491,6 +491,7 @@ __device__ __forceinline__ f16v mfma32_bf16(u4v a, u4v b, f16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
+template <bool FUSE_OUT>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t lds_in[18 * 18 * kPix16];
   __shared__ __attribute__((aligned(16))) uint16_t lds_w[kChunk16Halves];
@@ -588,14 +589,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
     const int gy = y0 + 4 * wave + 2 * nb + (n >> 4);
     const bool ok = gy < a.H && gx < a.W;
     const int64_t pix = frame * (int64_t)a.H * a.W + (int64_t)gy * a.W + gx;
+    if (FUSE_OUT) {
+      // outc (conv1x1 64 -> 3) on the 64 channels of this pixel: lane partial over its 32, the other half sits in lane ^ 32
+      float p3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float h = fmaxf(acc[mb][nb][r], 0.f);
+          const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+          for (int o = 0; o < 3; ++o) p3[o] = fmaf(a.outw[o * 64 + c], h, p3[o]);
+        }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) p3[o] += __shfl_xor(p3[o], 32);
+      if (hh == 0 && ok) {
+        float* o3 = a.out3 + pix * 3;
+        o3[0] = p3[0] + a.outb[0];
+        o3[1] = p3[1] + a.outb[1];
+        o3[2] = p3[2] + a.outb[2];
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         f4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = a.relu ? fmaxf(acc[mb][nb][4 * rr + r], 0.f) : acc[mb][nb][4 * rr + r];
-        if (ok) {
+        for (int r = 0; r < 4; ++r) h[r] = (a.relu || FUSE_OUT) ? fmaxf(acc[mb][nb][4 * rr + r], 0.f) : acc[mb][nb][4 * rr + r];
+        if (ok && a.out) {     // (FUSE_OUT: the last hidden activation, kept only for the backward pass)
           float* dst = a.out + pix * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh;
           if (a.gate) {
             const f4 gt = *reinterpret_cast<const f4*>(a.gate + (dst - a.out));
@@ -604,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
           }
           *reinterpret_cast<f4*>(dst) = h;
         }
-        if (a.pool) {   // MaxPool2d(2): the N-block's two rows are lanes n and n ^ 16, the column pair n and n ^ 1
+        if (!FUSE_OUT && a.pool) {   // MaxPool2d(2): the N-block's two rows are lanes n and n ^ 16, the column pair n and n ^ 1
           const int H2 = a.H / 2, W2 = a.W / 2;
           const int py2 = (y0 + 4 * wave + 2 * nb) / 2, px2 = gx / 2;
           f4 m;
@@ -639,8 +661,9 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   if (gz > 65535) return S2L_E_SIZE;
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
-  if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
-  else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel, grid, dim3(256), 0, st, a);
+  if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+  else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
+  else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
@@ -667,7 +690,7 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
   if (gz > 65535) return S2L_E_SIZE;
   const dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
-  if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel, grid, dim3(256), 0, st, a);
+  if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
@@ -1358,7 +1381,7 @@ extern "C" int s2l_unet_forward_saved_window(const float* packed, const uint16_t
   hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
                      p1 * 16, w10);
   if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st, nullptr, nullptr, packed16))) return rc;
-  if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9))) return rc;
+  if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9, packed16))) return rc;
   return (int)hipGetLastError();
 }
 
