@@ -429,21 +429,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 // output tensors; the bilinear source position is computed in FULL-frame coordinates (align_corners=True makes the scale depend on
 // the full size) and then shifted into the crop, so every value that does not depend on data outside the crop equals the
 // full-frame value bit for bit.  Without a window: hf = h, wf = w, Hof = Ho, Wof = Wo, origins 0.
+// Elementwise kernels over [F, rows, cols, C] tensors take a (ceil(cols * C/4 / 256), rows, F) grid: a thread finds its channel
+// quad and column with one 32-bit division, its row and frame in blockIdx (a linear index would cost three 64-bit divisions).
+__device__ __forceinline__ bool quad_of_thread(int cols, int cq, int rows, int& c4, int& x, int& y, int64_t& f, int64_t& i) {
+  const unsigned ix = blockIdx.x * 256u + threadIdx.x;
+  if (ix >= (unsigned)cols * (unsigned)cq) return false;
+  x = (int)(ix / (unsigned)cq);
+  c4 = (int)(ix - (unsigned)x * (unsigned)cq);
+  y = (int)blockIdx.y;
+  f = blockIdx.z;
+  i = ((f * rows + y) * (int64_t)cols + x) * cq + c4;
+  return true;
+}
+static dim3 quad_grid(int cols, int C, int rows, int64_t F) {
+  return dim3((unsigned)(((int64_t)cols * (C / 4) + 255) / 256), (unsigned)rows, (unsigned)F);
+}
+
 struct UpWin {
   int hf, wf, Hof, Wof;     // full low-resolution size, full output size
   int oyi, oxi, oyo, oxo;   // origin of the input crop / output crop inside the full tensors
 };
 __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int C,
-                                                       int Ho, int Wo, int64_t n_out, UpWin win) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_out) return;
-  const int cq = C / 4;
-  const int c4 = (int)(i % cq);
-  int64_t p = i / cq;
-  const int xo = (int)(p % Wo);
-  p /= Wo;
-  const int yo = (int)(p % Ho);
-  const int64_t f = p / Ho;
+                                                       int Ho, int Wo, UpWin win) {
+  int c4, xo, yo;
+  int64_t f, i;
+  if (!quad_of_thread(Wo, C / 4, Ho, c4, xo, yo, f, i)) return;
   const int padT = (win.Hof - 2 * win.hf) / 2, padL = (win.Wof - 2 * win.wf) / 2;
   const int yu = yo + win.oyo - padT, xu = xo + win.oxo - padL;
   f4 o = (f4){0.f, 0.f, 0.f, 0.f};
@@ -755,16 +765,10 @@ __global__ __launch_bounds__(256) void conv_first_bwd_kernel(const float* __rest
 // [coff, coff + C) of it; act, z: [F,h,w,C].
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ g, int ldg, int coff,
                                                            const float* __restrict__ act, float* __restrict__ z, int h, int w, int C,
-                                                           int Ho, int Wo, int64_t n_in, UpWin win) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_in) return;
-  const int cq = C / 4;
-  const int c4 = (int)(i % cq);
-  int64_t p = i / cq;
-  const int xi = (int)(p % w);
-  p /= w;
-  const int yi = (int)(p % h);
-  const int64_t f = p / h;
+                                                           int Ho, int Wo, UpWin win) {
+  int c4, xi, yi;
+  int64_t f, i;
+  if (!quad_of_thread(w, C / 4, h, c4, xi, yi, f, i)) return;
   const int yif = yi + win.oyi, xif = xi + win.oxi;          // position in the full low-resolution tensor
   const int padT = (win.Hof - 2 * win.hf) / 2, padL = (win.Wof - 2 * win.wf) / 2;
   const float sy = 2 * win.hf > 1 ? (float)(win.hf - 1) / (float)(2 * win.hf - 1) : 0.f;
@@ -801,16 +805,11 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
 // order (ATen's max_pool2d backward), x / pooled = the forward's activation and its pooled copy.
 __global__ __launch_bounds__(256) void pool_bwd_add_kernel(const float* __restrict__ gcat, int ldg, const float* __restrict__ gpool,
                                                           const float* __restrict__ x, const float* __restrict__ pooled,
-                                                          float* __restrict__ z, int H, int W, int C, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int cq = C / 4;
-  const int c4 = (int)(i % cq) * 4;
-  int64_t p = i / cq;
-  const int xx = (int)(p % W);
-  p /= W;
-  const int yy = (int)(p % H);
-  const int64_t f = p / H;
+                                                          float* __restrict__ z, int H, int W, int C) {
+  int cq4, xx, yy;
+  int64_t f, i;
+  if (!quad_of_thread(W, C / 4, H, cq4, xx, yy, f, i)) return;
+  const int c4 = cq4 * 4;
   const int H2 = H / 2, W2 = W / 2;
   const int64_t pix = (f * H + yy) * (int64_t)W + xx;
   const f4 xv = *reinterpret_cast<const f4*>(x + pix * C + c4);
@@ -1314,12 +1313,12 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2))) return rc;   // + MaxPool2d(2)
   if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st))) return rc;
   if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st))) return rc;
-  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2,
-                     W2, p2 * 32, no_window(H4, W4, H2, W2));
+  hipLaunchKernelGGL(upsample2_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2, W2,
+                     no_window(H4, W4, H2, W2));
   if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st))) return rc;
   if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st))) return rc;
-  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
-                     p1 * 16, no_window(H2, W2, H, W));   // t64a is free again: it becomes up(u1)
+  hipLaunchKernelGGL(upsample2_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
+                     no_window(H2, W2, H, W));   // t64a is free again: it becomes up(u1)
   if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st))) return rc;
   if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st))) return rc;
   return (int)hipGetLastError();
@@ -1374,12 +1373,12 @@ extern "C" int s2l_unet_forward_saved_window(const float* packed, const uint16_t
   if ((rc = launch_conv(s.a4, 128, nullptr, 0, packed, 5, s.x3, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
   const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
   const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
-  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p2 * 32 + 255) / 256)), dim3(256), 0, st, s.x3, s.u3, H4, W4, 128, H2, W2,
-                     p2 * 32, w21);
+  hipLaunchKernelGGL(upsample2_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, s.x3, s.u3, H4, W4, 128, H2, W2,
+                     w21);
   if ((rc = launch_conv(s.x2, 128, s.u3, 128, packed, 6, s.a6, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
   if ((rc = launch_conv(s.a6, 128, nullptr, 0, packed, 7, s.u1, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
-  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)((p1 * 16 + 255) / 256)), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
-                     p1 * 16, w10);
+  hipLaunchKernelGGL(upsample2_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, s.u1, s.uu, H2, W2, 64, H, W,
+                     w10);
   if ((rc = launch_conv(s.x1, 64, s.uu, 64, packed, 8, s.a8, nullptr, H, W, F, st, nullptr, nullptr, packed16))) return rc;
   if ((rc = launch_conv(s.a8, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, s.y9, packed16))) return rc;
   return (int)hipGetLastError();
@@ -1415,17 +1414,20 @@ extern "C" int s2l_unet_backward_window(const float* packed, const uint16_t* pac
   if ((rc = launch_conv_dgrad(zB, packed, 8, gcat8, nullptr, H, W, F, st, packed16))) return rc;                                    // [g_x1 | g_uu]
   const UpWin w21 = UpWin{(full_h / 2) / 2, (full_w / 2) / 2, full_h / 2, full_w / 2, origin_y / 4, origin_x / 4, origin_y / 2, origin_x / 2};
   const UpWin w10 = UpWin{full_h / 2, full_w / 2, full_h, full_w, origin_y / 2, origin_x / 2, origin_y, origin_x};
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64, H, W, p2 * 16, w10);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W2, 64, H2, F), dim3(256), 0, st, gcat8, 128, 64, s.u1, z7, H2, W2, 64,
+                     H, W, w10);
   if ((rc = launch_conv_dgrad(z7, packed, 7, z6, s.a6, H2, W2, F, st, packed16))) return rc;
   if ((rc = launch_conv_dgrad(z6, packed, 6, gcat6, nullptr, H2, W2, F, st, packed16))) return rc;                                  // [g_x2 | g_u3]
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, s.x3, z5, H4, W4, 128, H2, W2,
-                     p4 * 32, w21);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W4, 128, H4, F), dim3(256), 0, st, gcat6, 256, 128, s.x3, z5, H4, W4, 128,
+                     H2, W2, w21);
   if ((rc = launch_conv_dgrad(z5, packed, 5, z4, s.a4, H4, W4, F, st, packed16))) return rc;
   if ((rc = launch_conv_dgrad(z4, packed, 4, gp2, nullptr, H4, W4, F, st, packed16))) return rc;
-  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, s.x2, s.p2, z3, H2, W2, 128, p2 * 32);
+  hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, gcat6, 256, gp2, s.x2, s.p2, z3,
+                     H2, W2, 128);
   if ((rc = launch_conv_dgrad(z3, packed, 3, z2, s.a2, H2, W2, F, st, packed16))) return rc;
   if ((rc = launch_conv_dgrad(z2, packed, 2, gp1, nullptr, H2, W2, F, st, packed16))) return rc;
-  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p1 * 16), dim3(256), 0, st, gcat8, 128, gp1, s.x1, s.p1, zA, H, W, 64, p1 * 16);   // z1
+  hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, gcat8, 128, gp1, s.x1, s.p1, zA,
+                     H, W, 64);   // z1
   if ((rc = launch_conv_dgrad(zA, packed, 1, zB, s.a0, H, W, F, st, packed16))) return rc;                                          // z0
   hipLaunchKernelGGL(conv_first_bwd_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, zB,
                      packed + unet_w_off(0), d_x, H, W);
@@ -1553,11 +1555,11 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
     if (l == 1) hipLaunchKernelGGL(maxpool2_kernel, blocks(p2 * 16), dim3(256), 0, st, b.act[1], b.p1, H, W, 64, p2 * 16);
     if (l == 3) hipLaunchKernelGGL(maxpool2_kernel, blocks(p4 * 32), dim3(256), 0, st, b.act[3], b.p2, H2, W2, 128, p4 * 32);
     if (l == 5)
-      hipLaunchKernelGGL(upsample2_kernel, blocks(p2 * 32), dim3(256), 0, st, b.act[5], b.u3, H4, W4, 128, H2, W2, p2 * 32,
-                         no_window(H4, W4, H2, W2));
+      hipLaunchKernelGGL(upsample2_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, b.act[5], b.u3, H4, W4, 128, H2, W2,
+                     no_window(H4, W4, H2, W2));
     if (l == 7)
-      hipLaunchKernelGGL(upsample2_kernel, blocks(p1 * 16), dim3(256), 0, st, b.act[7], b.uu, H2, W2, 64, H, W, p1 * 16,
-                         no_window(H2, W2, H, W));
+      hipLaunchKernelGGL(upsample2_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, b.act[7], b.uu, H2, W2, 64, H, W,
+                     no_window(H2, W2, H, W));
   }
   hipLaunchKernelGGL(outc_kernel, blocks(p1), dim3(256), 0, st, b.act[9], t.outw, t.outb, out, p1);
   return (int)hipGetLastError();
@@ -1637,24 +1639,26 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
   if ((rc = launch_conv_dgrad(zA, packed_raw, 9, zB, b.act[8], H, W, F, st))) return rc;
   layer_grads(8, zB);
   if ((rc = launch_conv_dgrad(zB, packed_raw, 8, gcat8, nullptr, H, W, F, st))) return rc;                                // [g_x1 | g_uu]
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p2 * 16), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64, H, W, p2 * 16,
-                     no_window(H2, W2, H, W));
+  hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W2, 64, H2, F), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64,
+                     H, W, no_window(H2, W2, H, W));
   layer_grads(7, z7);
   if ((rc = launch_conv_dgrad(z7, packed_raw, 7, z6, b.act[6], H2, W2, F, st))) return rc;
   layer_grads(6, z6);
   if ((rc = launch_conv_dgrad(z6, packed_raw, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                              // [g_x2 | g_u3]
-  hipLaunchKernelGGL(upsample2_bwd_kernel, blocks(p4 * 32), dim3(256), 0, st, gcat6, 256, 128, b.act[5], z5, H4, W4, 128, H2, W2,
-                     p4 * 32, no_window(H4, W4, H2, W2));
+  hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W4, 128, H4, F), dim3(256), 0, st, gcat6, 256, 128, b.act[5], z5, H4, W4, 128,
+                     H2, W2, no_window(H4, W4, H2, W2));
   layer_grads(5, z5);
   if ((rc = launch_conv_dgrad(z5, packed_raw, 5, z4, b.act[4], H4, W4, F, st))) return rc;
   layer_grads(4, z4);
   if ((rc = launch_conv_dgrad(z4, packed_raw, 4, gp2, nullptr, H4, W4, F, st))) return rc;
-  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p2 * 32), dim3(256), 0, st, gcat6, 256, gp2, b.act[3], b.p2, z3, H2, W2, 128, p2 * 32);
+  hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, gcat6, 256, gp2, b.act[3], b.p2, z3,
+                     H2, W2, 128);
   layer_grads(3, z3);
   if ((rc = launch_conv_dgrad(z3, packed_raw, 3, z2, b.act[2], H2, W2, F, st))) return rc;
   layer_grads(2, z2);
   if ((rc = launch_conv_dgrad(z2, packed_raw, 2, gp1, nullptr, H2, W2, F, st))) return rc;
-  hipLaunchKernelGGL(pool_bwd_add_kernel, blocks(p1 * 16), dim3(256), 0, st, gcat8, 128, gp1, b.act[1], b.p1, zA, H, W, 64, p1 * 16);
+  hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, gcat8, 128, gp1, b.act[1], b.p1, zA,
+                     H, W, 64);
   layer_grads(1, zA);
   if ((rc = launch_conv_dgrad(zA, packed_raw, 1, zB, b.act[0], H, W, F, st))) return rc;
   layer_grads(0, zB);
