@@ -265,8 +265,8 @@ int s2l_composite_tables(const float* face_canon, const float* mask, float* bgm,
 int64_t s2l_unet_packed_floats(void);
 int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames);
 int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
-int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height,
-                     int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_forward(const float* packed, const uint16_t* packed16, const float* x, float* work, float* out, int height,
+                     int width, int64_t n_frames, s2l_stream_t stream);   /* packed16: NULL = exact fp32 (see s2l_unet_pack16 below) */
 
 /* Training: the same network keeping every activation (saved: s2l_unet_saved_floats(H, W, F) floats), and
  * its INPUT gradient d_out [F,H,W,3] -> d_x [F,H,W,3] (work: s2l_unet_backward_work_floats(H, W, F) floats of scratch) -- what

@@ -98,7 +98,7 @@ EXPORTS = {
     "s2l_unet_packed_floats": (c_int64, []),
     "s2l_unet_work_floats": (c_int64, [c_int, c_int, c_int64]),
     "s2l_unet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),
-    "s2l_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_composite_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "s2l_rel_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "s2l_warp_grid": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_int, c_int64,

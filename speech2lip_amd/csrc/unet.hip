@@ -1291,8 +1291,8 @@ extern "C" int s2l_unet_pack(const float* const* tensors_host, float bn_eps, flo
 }
 
 // x [F,H,W,3] NHWC -> out [F,H,W,3].  H, W >= 4.  work: s2l_unet_work_floats(H, W, F) floats.
-extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work, float* out, int height, int width,
-                                int64_t n_frames, s2l_stream_t stream) {
+extern "C" int s2l_unet_forward(const float* packed, const uint16_t* packed16, const float* x, float* work, float* out, int height,
+                                int width, int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
   if (n_frames == 0) return S2L_OK;
   if (!packed || !x || !work || !out) return S2L_E_NULL;
@@ -1308,19 +1308,19 @@ extern "C" int s2l_unet_forward(const float* packed, const float* x, float* work
   if (F > 65535) return S2L_E_SIZE;
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
-  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1))) return rc;   // + MaxPool2d(2)
-  if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2))) return rc;   // + MaxPool2d(2)
-  if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st))) return rc;
-  if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1, nullptr, packed16))) return rc;   // + MaxPool2d(2)
+  if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2, nullptr, packed16))) return rc;   // + MaxPool2d(2)
+  if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2, W2,
                      no_window(H4, W4, H2, W2));
-  if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st))) return rc;
-  if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
                      no_window(H2, W2, H, W));   // t64a is free again: it becomes up(u1)
-  if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st))) return rc;
-  if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st))) return rc;
+  if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, nullptr, packed16))) return rc;
   return (int)hipGetLastError();
 }
 

@@ -96,10 +96,15 @@ class SimpleUnetLight(nn.Module):
             self._packed16, self._packed16_key = packed16, key
         return self._packed16
 
-    def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        """x [F,H,W,3] -> [F,H,W,3] (the layout the composite produces and the caller wants)."""
+    def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None, precision: str = "fp32") -> torch.Tensor:
+        """x [F,H,W,3] -> [F,H,W,3] (the layout the composite produces and the caller wants).  precision "bf16" is an opt-in
+        speed mode: bf16 operands in the 3x3 convolutions (fp32 accumulation and tensors), ~5e-3 relative error against the
+        default exact-fp32 evaluation."""
         lib = _abi.load()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         packed = self.packed_weights()
+        packed16 = self.packed_weights_bf16() if precision == "bf16" else None
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         if self.training:
@@ -120,7 +125,8 @@ class SimpleUnetLight(nn.Module):
         with torch.cuda.device(x.device):
             for s in range(0, F_, group):
                 n = min(group, F_ - s)
-                _abi.check(lib.s2l_unet_forward(ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(x[s:].data_ptr()),
+                _abi.check(lib.s2l_unet_forward(ctypes.c_void_p(packed.data_ptr()),
+                                                ctypes.c_void_p(0 if packed16 is None else packed16.data_ptr()), ctypes.c_void_p(x[s:].data_ptr()),
                                                 ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(out[s:].data_ptr()),
                                                 H, W, n, st), "s2l_unet_forward")
         return out
