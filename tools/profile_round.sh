@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-form
 rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
 ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
-for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16" \
+for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \
             "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
             "stage1_full:tools/bench_train.py 8 bf16 --full"; do

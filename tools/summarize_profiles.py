@@ -50,7 +50,7 @@ if "FETCH_SIZE" in cv and "WRITE_SIZE" in cv:
                % (cv["FETCH_SIZE"] * 1024 * 2 + cv["WRITE_SIZE"] * 1024))
 for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench_train.py 64 bf16"),
                     ("train_fp32", "training step, fp32 parity mode: python tools/bench_train.py 64 fp32"),
-                    ("unet", "post-fusion U-Net: python tools/bench_unet.py 16"),
+                    ("unet", "post-fusion U-Net, fp32 and the opt-in bf16 operand mode: python tools/bench_unet.py 16 --bf16"),
                     ("syncnet", "sync loss (T3): python tools/bench_syncnet.py 16"),
                     ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
                     ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
