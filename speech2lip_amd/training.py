@@ -179,6 +179,8 @@ class Trainer:
         reference.  One frame per call (batch_size 1, batch_rays = H*W: the only case the reference's own crop code supports,
         :536-537)."""
         tc, m = self.cfg["training"], self.model
+        if self.optimizer is None:
+            raise ValueError("train_stage1 steps an optimizer: construct Trainer(model, optimizer=...)")
         b, self.height, self.width = int(data["rgb"].shape[0]), int(data["rgb"].shape[1]), int(data["rgb"].shape[2])
         if b != 1 or self.batch_rays != self.height * self.width:
             raise NotImplementedError("train_stage1: one frame per step with batch_rays = H*W (the May configuration)")
