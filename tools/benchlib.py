@@ -144,15 +144,22 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
     return res
 
 
-def warm_until_allocator_settles(fn, max_steps=5):
-    """Run `fn` until torch's caching allocator makes no new device allocation during a step (a step that still calls
-    hipMalloc for tens of GB is 5-10x slower and would be timing the allocator, not the kernels).  Returns fn's last result."""
-    r = None
-    for _ in range(max_steps):
+def warm_until_allocator_settles(fn, max_steps=8, min_steps=4, tol=1.25):
+    """Run `fn` until a step is in steady state: at least `min_steps` steps, no new device allocation by torch's caching
+    allocator during the step (a step that still calls hipMalloc for tens of GB is 5-10x slower), and a wall time within `tol`
+    of the previous step's (the first few steps of a process also pay one-off costs -- lazily loaded code objects of the
+    optimiser's kernels, clock ramp -- of ~70 ms in total, which a 5-step timed window would otherwise report as 2x).
+    Returns fn's last result."""
+    r, last = None, None
+    for i in range(max_steps):
         before = torch.cuda.memory_stats().get("num_device_alloc", 0)
+        t = time.perf_counter()
         r = fn()
         torch.cuda.synchronize()
-        if torch.cuda.memory_stats().get("num_device_alloc", 0) == before:
+        dt = time.perf_counter() - t
+        settled = torch.cuda.memory_stats().get("num_device_alloc", 0) == before and last is not None and dt <= tol * last
+        last = dt
+        if settled and i + 1 >= min_steps:
             break
     return r
 
