@@ -37,13 +37,24 @@ V_LAST = 240
 A_ACC, A_BIAS, A_RGB = 0, 192, 196
 A_LAST = 207
 # ---- scalar registers (all owned by the body; the compiler's operands live elsewhere)
-S = {n: 36 + i for i, n in enumerate(
-    "CUR T LDSBASE CURB WPTR WPTR1 WBASE WBASE1 IS LAYER FG PG NFG PADA PADB TILE TEND PADC NFM1 HW FGN PGN PADD PADE "
-    "Q0 Q01 Q5 Q51 P0 P01 P5 P51 OUT OUT1 WAVE PAD T4 T5 T6 T7 T8 T9 EX EX1 NFRAMES PAD2 TRACE TRACE1".split())}
+def _scalar_map(first, singles, pairs):
+    """names -> SGPR numbers from `first` on; a pair NAME / NAME1 starts on an even register"""
+    m, r = {}, first
+    for n in pairs:
+        r += r & 1
+        m[n], m[n + "1"] = r, r + 1
+        r += 2
+    for n in singles:
+        m[n] = r
+        r += 1
+    return m
+
+
+S = _scalar_map(36,
+                singles="CUR T LDSBASE CURB IS LAYER FG PG NFG TILE TEND NFM1 HW FGN PGN WAVE NFRAMES".split(),
+                pairs=("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX", "TRACE"))
+S.update(T5=S["T41"], T7=S["T61"], T9=S["T81"])          # the halves of the temporary pairs by their own names
 TRACE = os.environ.get("S2L_RENDER_TRACE") == "1"      # experiment builds only (tools/trace_tiles.py): per-tile phase timestamps
-# pairs must be even-aligned
-for pair in ("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX", "TRACE"):
-    assert S[pair] % 2 == 0, pair
 S_LAST = max(S.values())
 
 
