@@ -231,3 +231,24 @@ def test_lpips_module_has_the_package_state_dict_and_oracle_properties():
     dab, dba = O.lpips_alex(sd, a, b), O.lpips_alex(sd, b, a)
     assert tuple(dab.shape) == (2, 1, 1, 1) and float(dab.min()) > 0
     assert torch.allclose(dab, dba, rtol=1e-6) and float(O.lpips_alex(sd, a, a).abs().max()) == 0.0
+
+
+def test_sync_chain_unet_window_geometry():
+    """SyncChain.unet_window: the canonical-face box dilated by the U-Net's dependency radius, origins on the 4-pixel grid of the
+    two pooling levels, sizes multiples of 4 unless the crop ends at the frame edge (what s2l_unet_forward_saved_window accepts)."""
+    import speech2lip_amd as s2l
+    ch = s2l.SyncChain.__new__(s2l.SyncChain)
+    ch.window = True
+    r = s2l.SyncChain.UNET_RADIUS
+    assert r >= 32
+    for bbox, (FH, FW) in (([110, 90, 390, 420, 1.0], (500, 500)), ([0, 0, 500, 500, 1.0], (500, 500)), ([3, 5, 97, 121, 0.9], (130, 101)),
+                           ([200, 260, 500, 500, 1.0], (500, 500)), ([37, 41, 77, 83, 1.0], (501, 503))):
+        x0, y0, x1, y1 = ch.unet_window(bbox, FH, FW)
+        assert 0 <= x0 <= max(0, bbox[0] - r) and 0 <= y0 <= max(0, bbox[1] - r)
+        assert min(FW, bbox[2] + r) <= x1 <= FW and min(FH, bbox[3] + r) <= y1 <= FH
+        assert x0 % 4 == 0 and y0 % 4 == 0
+        assert (x1 - x0) % 4 == 0 or x1 == FW
+        assert (y1 - y0) % 4 == 0 or y1 == FH
+        assert x0 >= bbox[0] - r - 3 and y0 >= bbox[1] - r - 3          # no larger than needed
+    ch.window = False
+    assert ch.unet_window([110, 90, 390, 420, 1.0], 500, 500) == (0, 0, 500, 500)
