@@ -42,6 +42,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     try:
         import gen_render_body
         gen_render_body.main(os.path.join(objdir, "render_body.inc"))
+        import gen_conv_body               # ... and so are the U-Net's fp32 3x3 convolutions (unet.hip)
+        gen_conv_body.main(objdir)
     finally:
         sys.path.pop(0)
     procs = []

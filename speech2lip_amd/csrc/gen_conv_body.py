@@ -1,0 +1,498 @@
+"""Generates conv_body_<variant>.inc: the body of s2l::conv3x3_asm_kernel<variant> (csrc/unet.hip) as ONE fixed-register gfx950
+assembly text, like gen_render_body.py does for the renderer and for the same reason: with one wave per SIMD a wave's VALU
+instructions never overlap its own MFMAs, so the chunk loop must be nothing but MFMAs, LDS reads, LDS-DMA issues and scalar code.
+
+The convolution is the implicit GEMM of conv3x3_kernel (same tile, same packed weights, same LDS layouts, same accumulation
+order per output: chunk, tap, k-step -- results are bit-identical):
+  * tile = 16x16 pixels x 64 output channels; wave w owns tile rows 4w..4w+3 (g = 0..3), lane (q = lane >> 4, px = lane & 15);
+    D[channel 16 mb + 4 q + r][pixel px of row g] in acc[mb][g][r] (64 VGPRs, C/D in VGPRs);
+  * input channels go through LDS 16 at a time: halo tile [18*18][16] fp32 (20 736 B) + the chunk's weights in A-operand order
+    [9 taps][4 mb][64 lanes][4] (36 864 B); TWO such buffers, filled by LDS-DMA (global_load_lds_dwordx4: 6 + 9 instructions per
+    wave and chunk, tucked behind the MFMAs of the chunk before) -- one s_barrier per chunk;
+  * out-of-image halo pixels: the DMA lanes are masked off (exec) and the buffer's halo region is zero-filled by ds_write first
+    (border tiles only);
+  * a workgroup is persistent (one per CU) and walks a contiguous range of tiles (frame, channel tile, y, x; x fastest); the
+    first chunk of the next tile is fetched during the last chunk of the current one;
+  * epilogue per tile: ReLU, optional 2x2 max-pool, stores (the bias is the accumulators' initial value).
+
+Variants: "fwd" (bias, ReLU), "fwd_pool" (+ the pooled copy).  Inputs A | B (virtual concat) with CA % 16 == 0 and CB in (0, CA)."""
+import os
+import sys
+
+HALO_BYTES, W_BYTES = 18 * 18 * 64, 9 * 4 * 64 * 16
+BUF = HALO_BYTES + W_BYTES           # 57 600
+
+# ---- vector registers
+V_ACC = 0                      # 64: acc[(mb*4+g)*4 + r]
+V_OPS = (64, 96)               # two operand sets: A quads of mb 0..3 (16 regs), then B quads of g 0..3 (16 regs)
+V_BIAS = 128                   # 16: bias quad per mb
+V_LANE16, V_PART16, V_PX, V_Q16 = 144, 145, 146, 147
+V_ABASE = (148, 149)           # A-read base of buffer 0 / 1
+V_BBASE = (150, 151)           # B-read base of buffer 0 / 1
+V_HOFF = 152                   # 6: halo voffset per DMA instruction (per tile)
+V_ZBASE = (158, 159)           # zero-fill LDS address of buffer 0 / 1 (this wave's six KiB of the halo region)
+V_WOFF = 160                   # 3: weight DMA voffsets
+V_PROW, V_PCOL = 163, 169      # 6 + 6: halo pixel row / column of this lane for DMA instruction i
+V_ZERO = 176                   # 4 zeros (aligned)
+V_SOFF = 180                   # 4: store offsets per g
+V_T = 184                      # temporaries 184..199
+V_LAST = 199
+
+
+def _scalar_map(first, singles, pairs, skip=(32, 33)):
+    m, r = {}, first
+    for n in pairs:
+        while (r & 1) or r in skip or (r + 1) in skip:
+            r += 1
+        m[n], m[n + "1"] = r, r + 1
+        r += 2
+    for n in singles:
+        while r in skip:
+            r += 1
+        m[n] = r
+        r += 1
+    return m
+
+
+S = _scalar_map(8,
+                singles="LDSB CA CB COUT H W TILESX TILESY NCT TILE TEND NCH CC WAVE TX TY CT FRAME NTX NTY NCTN NFR X0 Y0 BORDER "
+                        "C CHB HASNEXT T0 T1 T2 T3 H2 W2".split(),
+                pairs=("KARG", "INA", "INB", "WB", "BIAS", "OUT", "POOL", "M0_", "M1_", "M2_", "M3_", "M4_", "M5_", "VALID2",
+                       "COLOK", "SRC", "WCH", "P0", "P2", "OUTF", "POOLF"))
+S_LAST = max(S.values())
+assert S_LAST <= 101, S_LAST
+
+
+def s(n):
+    return f"s{S[n]}"
+
+
+def s2(n):
+    return f"s[{S[n]}:{S[n] + 1}]"
+
+
+class Body:
+    def __init__(self, variant):
+        self.variant, self.pool = variant, variant == "fwd_pool"
+        self.L, self.lds, self.nlabel = [], [], 0
+
+    def e(self, t):
+        self.L.append(t)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"S2LC_{self.variant}_{stem}_{self.nlabel}"
+
+    def lds_op(self, text, tag):
+        self.e(text)
+        self.lds.append(tag)
+
+    def wait_lds(self, tag):
+        if tag not in self.lds:
+            return
+        newer = len(self.lds) - 1 - self.lds.index(tag)
+        assert newer <= 15
+        self.e(f"s_waitcnt lgkmcnt({newer})")
+        self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    @staticmethod
+    def acc(mb, g):
+        b = V_ACC + (mb * 4 + g) * 4
+        return f"v[{b}:{b + 3}]"
+
+    # ------------------------------------------------------------------ set-up of the tile whose chunks are fetched next
+    def fetch_setup(self, tx, ty, ct, frame):
+        """masks M_i, BORDER, halo offsets HOFF_i (for the A input), SRC = first chunk's source, WCH = first weight chunk,
+        C = channels of the source tensor, CHB = chunk index at which the source switches to input B"""
+        e = self.e
+        e(f"s_lshl_b32 {s('X0')}, {s(tx)}, 4")
+        e(f"s_lshl_b32 {s('Y0')}, {s(ty)}, 4")
+        e(f"s_sub_u32 {s('T2')}, {s('Y0')}, 1")
+        e(f"s_sub_u32 {s('T3')}, {s('X0')}, 1")
+        e(f"s_mov_b32 {s('BORDER')}, 0")
+        e(f"s_mov_b32 {s('C')}, {s('CA')}")
+        for i in range(6):
+            gy, gx, t = V_T, V_T + 1, V_T + 2
+            e(f"v_add_u32 v{gy}, {s('T2')}, v{V_PROW + i}")
+            e(f"v_add_u32 v{gx}, {s('T3')}, v{V_PCOL + i}")
+            e(f"v_cmp_gt_u32 vcc, {s('H')}, v{gy}")              # unsigned compare: also rejects -1
+            e(f"s_mov_b64 {s2('P0')}, vcc")
+            e(f"v_cmp_gt_u32 vcc, {s('W')}, v{gx}")
+            e(f"s_and_b64 {s2('P0')}, {s2('P0')}, vcc")
+            e(f"v_cmp_gt_u32 vcc, 18, v{V_PROW + i}")             # the pixel exists: p < 324  <=>  prow < 18
+            e(f"s_and_b64 {s2(f'M{i}_')}, {s2('P0')}, vcc")
+            e(f"s_andn2_b64 {s2('P0')}, vcc, {s2(f'M{i}_')}")      # an existing pixel outside the image -> border tile
+            e(f"s_cmp_lg_u64 {s2('P0')}, 0")
+            e(f"s_cselect_b32 {s('BORDER')}, 1, {s('BORDER')}")
+            e(f"v_mul_lo_u32 v{t}, v{gy}, {s('W')}")
+            e(f"v_add_u32 v{t}, v{t}, v{gx}")
+            e(f"v_mul_lo_u32 v{t}, v{t}, {s('C')}")
+            e(f"v_lshl_add_u32 v{V_HOFF + i}, v{t}, 2, v{V_PART16}")
+        # SRC = inA + frame * H*W*CA*4
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('CA')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s(frame)}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s(frame)}")
+        e(f"s_add_u32 {s('SRC')}, {s('INA')}, {s('T0')}")
+        e(f"s_addc_u32 {s('SRC1')}, {s('INA1')}, {s('T1')}")
+        # WCH = w + ct * NCH * 36864
+        e(f"s_mul_i32 {s('T0')}, {s(ct)}, {s('NCH')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
+        # the tile's bias quads (waited for with the chunk's DMA; copied into the accumulators when the tile starts)
+        e(f"s_lshl_b32 {s('T0')}, {s(ct)}, 8")
+        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_Q16}")
+        for mb in range(4):
+            e(f"global_load_dwordx4 v[{V_BIAS + 4 * mb}:{V_BIAS + 4 * mb + 3}], v{V_T}, {s2('BIAS')} offset:{64 * mb}")
+
+    def switch_to_b(self, frame):
+        """SRC = inB + frame * H*W*CB*4 (CB == CA: the halo offsets stay valid)"""
+        e = self.e
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('CB')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s(frame)}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s(frame)}")
+        e(f"s_add_u32 {s('SRC')}, {s('INB')}, {s('T0')}")
+        e(f"s_addc_u32 {s('SRC1')}, {s('INB1')}, {s('T1')}")
+
+    # ------------------------------------------------------------------ DMA of one chunk into buffer b
+    def dma_groups(self, b):
+        """the 15 LDS-DMA instructions of a chunk as self-contained groups (each sets m0 / exec itself)"""
+        groups = []
+        for i in range(6):      # halo: KiB (wave*6 + i) of the buffer's halo region; waves 0..2 six each, wave 3 only i < 3
+            g = [f"s_mul_i32 {s('T0')}, {s('WAVE')}, {6 * 1024}",
+                 f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF + i * 1024}",
+                 f"s_add_u32 m0, {s('T0')}, {s('LDSB')}",
+                 f"s_mov_b64 exec, {s2(f'M{i}_')}",
+                 f"global_load_lds_dwordx4 v{V_HOFF + i}, {s2('SRC')}",
+                 "s_mov_b64 exec, -1"]
+            groups.append(g)
+        for gi in range(3):     # weights: this wave's 9 KiB = 4 + 4 + 1
+            g = [f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216",
+                 f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF + HALO_BYTES + gi * 4096}",
+                 f"s_add_u32 m0, {s('T0')}, {s('LDSB')}",
+                 "s_nop 0"]
+            for k in range(4 if gi < 2 else 1):
+                g.append(f"global_load_lds_dwordx4 v{V_WOFF + gi}, {s2('WCH')} offset:{1024 * k}")
+            groups.append(g)
+        return groups
+
+    def zero_fill(self, b):
+        """border tiles: zero this wave's part of buffer b's halo region (before the masked DMA lands on it)"""
+        e = self.e
+        skip = self.label("interior")
+        e(f"s_cmp_eq_u32 {s('BORDER')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        for i in range(6):
+            if i == 2:
+                e(f"s_mov_b64 exec, {s2('VALID2')}")
+            if i == 3:
+                e("s_mov_b64 exec, -1")
+                e(f"s_cmp_eq_u32 {s('WAVE')}, 3")          # wave 3 has only 21 - 18 = 3 KiB of the 20.25
+                e(f"s_cbranch_scc1 {skip}_w3")
+            e(f"ds_write_b128 v{V_ZBASE[b]}, v[{V_ZERO}:{V_ZERO + 3}] offset:{1024 * i}")
+        e(f"{skip}_w3:")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"{skip}:")
+
+    # ------------------------------------------------------------------ one chunk's MFMAs
+    def tap_reads(self, b, t, oset, tag):
+        dy, dx = t // 3, t % 3
+        base = V_OPS[oset]
+        for mb in range(4):
+            self.lds_op(f"ds_read_b128 v[{base + 4 * mb}:{base + 4 * mb + 3}], v{V_ABASE[b]} offset:{(t * 4 + mb) * 1024}", (tag, t, "A", mb))
+        for g in range(4):
+            self.lds_op(f"ds_read_b128 v[{base + 16 + 4 * g}:{base + 19 + 4 * g}], v{V_BBASE[b]} offset:{((g + dy) * 18 + dx) * 64}",
+                        (tag, t, "B", g))
+
+    def chunk(self, b, sprinkle, tag):
+        """576 MFMAs on buffer b (tap 0's operand reads were issued by the caller under `tag`); `sprinkle`: list of
+        instruction groups tucked behind MFMAs of the first taps"""
+        self.lds = [(tag, 0, "A", mb) for mb in range(4)] + [(tag, 0, "B", g) for g in range(4)]
+        pending = list(sprinkle)
+        for t in range(9):
+            if t + 1 < 9:
+                self.tap_reads(b, t + 1, (t + 1) % 2, tag)
+            self.wait_lds((tag, t, "B", 3))
+            base = V_OPS[t % 2]
+            n = 0
+            for ks in range(4):
+                for mb in range(4):
+                    for g in range(4):
+                        self.e(f"v_mfma_f32_16x16x4_f32 {self.acc(mb, g)}, v{base + 4 * mb + ks}, v{base + 16 + 4 * g + ks}, {self.acc(mb, g)}")
+                        n += 1
+                        if pending and n % 4 == 0:
+                            for x in pending.pop(0):
+                                self.e(x)
+        assert not pending, len(pending)
+        assert not self.lds
+
+    # ------------------------------------------------------------------ epilogue of a tile
+    def epilogue(self):
+        e = self.e
+        e("s_nop 7")
+        e("s_nop 7")
+        # OUTF = out + frame * H*W*cout*4
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_add_u32 {s('OUTF')}, {s('OUT')}, {s('T0')}")
+        e(f"s_addc_u32 {s('OUTF1')}, {s('OUT1')}, {s('T1')}")
+        # lane's column and row 0 of this wave; store offset of row g: ((gy W + gx) cout + 64 ct) * 4 + 16 q  (+ 64 mb as immediate)
+        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
+        e(f"s_lshl_b32 {s('Y0')}, {s('TY')}, 4")
+        e(f"s_lshl_b32 {s('T2')}, {s('WAVE')}, 2")
+        e(f"s_add_u32 {s('T2')}, {s('T2')}, {s('Y0')}")           # gy of g = 0
+        e(f"v_add_u32 v{V_T}, {s('X0')}, v{V_PX}")                # gx
+        e(f"v_cmp_gt_u32 vcc, {s('W')}, v{V_T}")
+        e(f"s_mov_b64 {s2('COLOK')}, vcc")
+        e(f"s_lshl_b32 {s('T3')}, {s('CT')}, 8")                   # 64 ct * 4
+        for g in range(4):
+            e(f"s_add_u32 {s('T0')}, {s('T2')}, {g}")
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('W')}")
+            e(f"v_add_u32 v{V_T + 1}, {s('T0')}, v{V_T}")
+            e(f"v_mul_lo_u32 v{V_T + 1}, v{V_T + 1}, {s('COUT')}")
+            e(f"v_lshl_add_u32 v{V_T + 1}, v{V_T + 1}, 2, v{V_Q16}")
+            e(f"v_add_u32 v{V_SOFF + g}, {s('T3')}, v{V_T + 1}")
+        for mb in range(4):
+            for g in range(4):
+                b0 = V_ACC + (mb * 4 + g) * 4
+                for r in range(4):
+                    e(f"v_max_f32 v{b0 + r}, 0, v{b0 + r}")
+        for g in range(4):
+            skip = self.label("norow")
+            e(f"s_add_u32 {s('T0')}, {s('T2')}, {g}")
+            e(f"s_cmp_ge_u32 {s('T0')}, {s('H')}")
+            e(f"s_cbranch_scc1 {skip}")
+            e(f"s_mov_b64 exec, {s2('COLOK')}")
+            for mb in range(4):
+                b0 = V_ACC + (mb * 4 + g) * 4
+                e(f"global_store_dwordx4 v{V_SOFF + g}, v[{b0}:{b0 + 3}], {s2('OUTF')} offset:{64 * mb}")
+            e("s_mov_b64 exec, -1")
+            e(f"{skip}:")
+        if self.pool:
+            # MaxPool2d(2): rows (g, g+1) pair up in registers, columns px ^ 1 across lanes (DPP); even px lanes store
+            e(f"s_lshr_b32 {s('H2')}, {s('H')}, 1")
+            e(f"s_lshr_b32 {s('W2')}, {s('W')}, 1")
+            e(f"s_mul_i32 {s('T0')}, {s('H2')}, {s('W2')}")
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
+            e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+            e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('FRAME')}")
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FRAME')}")
+            e(f"s_add_u32 {s('POOLF')}, {s('POOL')}, {s('T0')}")
+            e(f"s_addc_u32 {s('POOLF1')}, {s('POOL1')}, {s('T1')}")
+            e(f"v_lshrrev_b32 v{V_T + 2}, 1, v{V_T}")              # px2 = gx / 2
+            e(f"v_cmp_gt_u32 vcc, {s('W2')}, v{V_T + 2}")
+            e(f"s_mov_b64 {s2('P0')}, vcc")
+            e(f"v_and_b32 v{V_T + 3}, 1, v{V_T}")
+            e(f"v_cmp_eq_u32 vcc, 0, v{V_T + 3}")
+            e(f"s_and_b64 {s2('P0')}, {s2('P0')}, vcc")
+            for gp in range(2):
+                skip = self.label("nopool")
+                e(f"s_add_u32 {s('T0')}, {s('T2')}, {2 * gp}")
+                e(f"s_lshr_b32 {s('T0')}, {s('T0')}, 1")             # py2
+                e(f"s_cmp_ge_u32 {s('T0')}, {s('H2')}")
+                e(f"s_cbranch_scc1 {skip}")
+                e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('W2')}")
+                e(f"v_add_u32 v{V_T + 4}, {s('T0')}, v{V_T + 2}")
+                e(f"v_mul_lo_u32 v{V_T + 4}, v{V_T + 4}, {s('COUT')}")
+                e(f"v_lshl_add_u32 v{V_T + 4}, v{V_T + 4}, 2, v{V_Q16}")
+                e(f"v_add_u32 v{V_T + 4}, {s('T3')}, v{V_T + 4}")
+                for mb in range(4):
+                    a0, a1 = V_ACC + (mb * 4 + 2 * gp) * 4, V_ACC + (mb * 4 + 2 * gp + 1) * 4
+                    for r in range(4):
+                        e(f"v_max_f32 v{V_T + 8 + r}, v{a0 + r}, v{a1 + r}")
+                    e("s_nop 1")        # (five wait states between a write of exec and a DPP instruction)
+                    for r in range(4):
+                        e(f"v_mov_b32_dpp v{V_T + 12 + r}, v{V_T + 8 + r} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                    for r in range(4):
+                        e(f"v_max_f32 v{V_T + 8 + r}, v{V_T + 8 + r}, v{V_T + 12 + r}")
+                    e(f"s_mov_b64 exec, {s2('P0')}")
+                    e(f"global_store_dwordx4 v{V_T + 4}, v[{V_T + 8}:{V_T + 11}], {s2('POOLF')} offset:{64 * mb}")
+                    e("s_mov_b64 exec, -1")
+                e(f"{skip}:")
+
+    # ------------------------------------------------------------------ the whole body
+    def emit(self):
+        e = self.e
+        # ---- operands and kernel arguments
+        for dst, src in (("LDSB", "ldsbase"), ("TILE", "tile0"), ("TEND", "tile_end"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"),
+                         ("FRAME", "frame0"), ("WAVE", "wave")):
+            e(f"s_mov_b32 {s(dst)}, %[{src}]")
+        e(f"s_mov_b64 {s2('KARG')}, %[karg]")
+        for dst, off in (("INA", "oinA"), ("INB", "oinB"), ("WB", "ow"), ("BIAS", "obias"), ("OUT", "oout"), ("POOL", "opool")):
+            e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, %[{off}]")
+        for dst, off in (("CA", "oCA"), ("CB", "oCB"), ("COUT", "ocout"), ("H", "oH"), ("W", "oW"), ("TILESX", "otx"), ("TILESY", "oty"),
+                         ("NCT", "onct")):
+            e(f"s_load_dword {s(dst)}, {s2('KARG')}, %[{off}]")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
+        e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 4")
+        e(f"s_lshr_b32 {s('CHB')}, {s('CA')}, 4")
+        # ---- lane constants
+        e(f"v_mov_b32 v{V_T}, %[lane]")
+        e(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_T}")
+        e(f"v_and_b32 v{V_T + 1}, 3, v{V_T}")
+        e(f"v_lshlrev_b32 v{V_PART16}, 4, v{V_T + 1}")
+        e(f"v_and_b32 v{V_PX}, 15, v{V_T}")
+        e(f"v_lshrrev_b32 v{V_T + 1}, 4, v{V_T}")
+        e(f"v_lshlrev_b32 v{V_Q16}, 4, v{V_T + 1}")
+        for b in range(2):
+            e(f"s_add_u32 {s('T0')}, {s('LDSB')}, {b * BUF + HALO_BYTES}")
+            e(f"v_add_u32 v{V_ABASE[b]}, {s('T0')}, v{V_LANE16}")
+            # B base: ((4 wave) * 18 + px) * 64 + 16 q
+            e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {4 * 18 * 64}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDSB')}")
+            e(f"v_lshl_add_u32 v{V_T + 2}, v{V_PX}, 6, v{V_Q16}")
+            e(f"v_add_u32 v{V_BBASE[b]}, {s('T0')}, v{V_T + 2}")
+            e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {6 * 1024}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDSB')}")
+            e(f"v_add_u32 v{V_ZBASE[b]}, {s('T0')}, v{V_LANE16}")
+        for gi in range(3):
+            e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {gi * 4096}")
+            e(f"v_add_u32 v{V_WOFF + gi}, {s('T0')}, v{V_LANE16}")
+        e(f"v_lshrrev_b32 v{V_T + 1}, 2, v{V_T}")                  # lane / 4
+        for i in range(6):
+            e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {6 * 16}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {16 * i}")
+            e(f"v_add_u32 v{V_T + 2}, {s('T0')}, v{V_T + 1}")       # p
+            e(f"v_mul_u32_u24 v{V_T + 3}, 3641, v{V_T + 2}")
+            e(f"v_lshrrev_b32 v{V_PROW + i}, 16, v{V_T + 3}")       # p / 18 (exact for p < 400)
+            e(f"v_mul_u32_u24 v{V_T + 3}, 18, v{V_PROW + i}")
+            e(f"v_sub_u32 v{V_PCOL + i}, v{V_T + 2}, v{V_T + 3}")
+        for r in range(4):
+            e(f"v_mov_b32 v{V_ZERO + r}, 0")
+        # the only partially valid DMA instruction: wave 3, i = 2 (pixels 320..335 -> lanes < 16 exist)
+        e(f"s_mov_b64 {s2('VALID2')}, -1")
+        e(f"s_cmp_eq_u32 {s('WAVE')}, 3")
+        e(f"s_cselect_b64 {s2('VALID2')}, 0xffff, {s2('VALID2')}")
+        # ---- first tile: set up, fetch chunk 0 into buffer 0
+        self.fetch_setup("TX", "TY", "CT", "FRAME")
+        self.zero_fill(0)
+        for g in self.dma_groups(0):
+            for x in g:
+                e(x)
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+
+        e("S2LC_TILE:")
+        # accumulators = bias of this channel tile (the C++ kernel's initial value; loaded when the tile's fetch was set up)
+        for mb in range(4):
+            for g in range(4):
+                for r in range(4):
+                    e(f"v_mov_b32 v{V_ACC + (mb * 4 + g) * 4 + r}, v{V_BIAS + 4 * mb + r}")
+        e(f"s_mov_b32 {s('CC')}, 0")
+        e("S2LC_PAIR:")
+        for b in range(2):
+            ctag = self.label("chunk")
+            self.lds = []
+            self.tap_reads(b, 0, 0, ctag)          # in flight while the scalar code below decides what to fetch
+            self.lds = []
+            # ---- what is fetched while chunk CC (in buffer b) computes: chunk CC + 1 of this tile, or chunk 0 of the next tile
+            have = self.label("fetch")
+            none = self.label("nofetch")
+            nexttile = self.label("nexttile")
+            e(f"s_add_u32 {s('T0')}, {s('CC')}, 1")
+            e(f"s_cmp_lt_u32 {s('T0')}, {s('NCH')}")
+            e(f"s_cbranch_scc0 {nexttile}")
+            # same tile: next 16 channels (64 bytes further), or the first 16 of input B; next weight chunk
+            e(f"s_add_u32 {s('SRC')}, {s('SRC')}, 64")
+            e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
+            tob = self.label("tob")
+            e(f"s_cmp_lg_u32 {s('T0')}, {s('CHB')}")
+            e(f"s_cbranch_scc1 {tob}")
+            self.switch_to_b("FRAME")
+            e(f"{tob}:")
+            e(f"s_add_u32 {s('WCH')}, {s('WCH')}, {W_BYTES}")
+            e(f"s_addc_u32 {s('WCH1')}, {s('WCH1')}, 0")
+            e(f"s_branch {have}")
+            e(f"{nexttile}:")
+            e(f"s_add_u32 {s('T0')}, {s('TILE')}, 1")
+            e(f"s_cmp_lt_u32 {s('T0')}, {s('TEND')}")
+            e(f"s_cselect_b32 {s('HASNEXT')}, 1, 0")
+            e(f"s_cbranch_scc0 {none}")
+            # coordinates of the next tile (x fastest, then y, channel tile, frame) and its set-up
+            e(f"s_add_u32 {s('NTX')}, {s('TX')}, 1")
+            e(f"s_mov_b32 {s('NTY')}, {s('TY')}")
+            e(f"s_mov_b32 {s('NCTN')}, {s('CT')}")
+            e(f"s_mov_b32 {s('NFR')}, {s('FRAME')}")
+            e(f"s_cmp_lt_u32 {s('NTX')}, {s('TILESX')}")
+            e(f"s_cbranch_scc1 {nexttile}_ok")
+            e(f"s_mov_b32 {s('NTX')}, 0")
+            e(f"s_add_u32 {s('NTY')}, {s('NTY')}, 1")
+            e(f"s_cmp_lt_u32 {s('NTY')}, {s('TILESY')}")
+            e(f"s_cbranch_scc1 {nexttile}_ok")
+            e(f"s_mov_b32 {s('NTY')}, 0")
+            e(f"s_add_u32 {s('NCTN')}, {s('NCTN')}, 1")
+            e(f"s_cmp_lt_u32 {s('NCTN')}, {s('NCT')}")
+            e(f"s_cbranch_scc1 {nexttile}_ok")
+            e(f"s_mov_b32 {s('NCTN')}, 0")
+            e(f"s_add_u32 {s('NFR')}, {s('NFR')}, 1")
+            e(f"{nexttile}_ok:")
+            self.fetch_setup("NTX", "NTY", "NCTN", "NFR")
+            e(f"{have}:")
+            self.zero_fill(1 - b)
+            # the chunk's MFMAs with the DMA groups behind them; without a fetch, the same MFMAs without
+            groups = self.dma_groups(1 - b)
+            join = self.label("join")
+            self.chunk(b, groups, ctag)
+            e(f"s_branch {join}")
+            e(f"{none}:")
+            self.chunk(b, [], ctag)
+            e(f"{join}:")
+            e("s_waitcnt vmcnt(0)")
+            e("s_barrier")
+            e(f"s_add_u32 {s('CC')}, {s('CC')}, 1")
+        e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
+        e("s_cbranch_scc1 S2LC_PAIR")
+        self.epilogue()
+        e(f"s_add_u32 {s('TILE')}, {s('TILE')}, 1")
+        e(f"s_mov_b32 {s('TX')}, {s('NTX')}")
+        e(f"s_mov_b32 {s('TY')}, {s('NTY')}")
+        e(f"s_mov_b32 {s('CT')}, {s('NCTN')}")
+        e(f"s_mov_b32 {s('FRAME')}, {s('NFR')}")
+        e(f"s_cmp_lt_u32 {s('TILE')}, {s('TEND')}")
+        e("s_cbranch_scc1 S2LC_TILE")
+        e("s_waitcnt vmcnt(0)")
+        return [x for x in self.L if x is not None]
+
+
+OPERANDS = """      :
+      : [karg] "s"(karg), [ldsbase] "s"(ldsbase), [tile0] "s"(tile0), [tile_end] "s"(tile_end), [tx0] "s"(tx0), [ty0] "s"(ty0),
+        [ct0] "s"(ct0), [frame0] "s"(frame0), [wave] "s"(wave), [lane] "v"(lane),
+        [oinA] "n"(offsetof(ConvArgs, inA)), [oinB] "n"(offsetof(ConvArgs, inB)), [ow] "n"(offsetof(ConvArgs, w)),
+        [obias] "n"(offsetof(ConvArgs, bias)), [oout] "n"(offsetof(ConvArgs, out)), [opool] "n"(offsetof(ConvArgs, pool)),
+        [oCA] "n"(offsetof(ConvArgs, CA)), [oCB] "n"(offsetof(ConvArgs, CB)), [ocout] "n"(offsetof(ConvArgs, cout)),
+        [oH] "n"(offsetof(ConvArgs, H)), [oW] "n"(offsetof(ConvArgs, W)), [otx] "n"(offsetof(ConvArgs, tiles_x)),
+        [oty] "n"(offsetof(ConvArgs, tiles_y)), [onct] "n"(offsetof(ConvArgs, n_ct))
+"""
+
+
+def main(outdir):
+    total = 0
+    for variant in ("fwd", "fwd_pool"):
+        lines = Body(variant).emit()
+        # labels are per variant, except the two loop heads
+        lines = [x.replace("S2LC_TILE", f"S2LC_{variant}_TILE").replace("S2LC_PAIR", f"S2LC_{variant}_PAIR") for x in lines]
+        clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"s{r}" for r in range(8, S_LAST + 1) if r not in (32, 33)] + ["vcc", "scc", "memory"]
+        out = ["// GENERATED by csrc/gen_conv_body.py -- do not edit; the generator is the source.", "asm volatile("]
+        out += [f'    "{x}\\n\\t"' for x in lines]
+        out.append(OPERANDS.rstrip("\n"))
+        out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+        with open(os.path.join(outdir, f"conv_body_{variant}.inc"), "w") as f:
+            f.write("\n".join(out) + "\n")
+        total += len(lines)
+    return total
+
+
+if __name__ == "__main__":
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build")
+    print(f"conv_body_*.inc: {main(d)} instructions")

@@ -229,6 +229,7 @@ struct ConvArgs {
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
   int relu;           // 1: ReLU in the epilogue (forward); 0: linear (input-gradient convolutions)
   const uint16_t* w16;   // conv3x3_bf16_kernel: packed bf16 chunks [cout/64][cin/32][kChunk16Halves]
+  int n_frames_asm;      // conv3x3_asm_kernel: frames of this launch (its grid is the CU count, not the tile count)
 #ifdef S2L_EXP_TRACE
   long long* trace;   // experiment builds (tools/trace_conv.py): [workgroup][24] timestamps of this launch
 #endif
@@ -248,6 +249,10 @@ extern "C" int s2l_debug_set_conv_trace(void* p) { g_conv_trace = static_cast<lo
 #else
 #define CONV_TRACE(slot) do { } while (0)
 #define CONV_TRACE_ARGS(a, grid) do { } while (0)
+#endif
+
+#ifndef S2L_CONV_ASM
+#define S2L_CONV_ASM 1
 #endif
 
 __device__ __forceinline__ f4 mfma16u(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -653,6 +658,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
   }
 }
 
+// ---- the forward convolution with its body as one fixed-register assembly text (csrc/gen_conv_body.py: persistent, one wave
+// per SIMD, both operands by LDS-DMA into two buffers, the chunk loop nothing but MFMAs, LDS reads and scalar code).  Same tile,
+// packed weights, LDS layouts and accumulation order as conv3x3_kernel: bit-identical outputs.  POOL: also the 2x2-pooled copy.
+constexpr int kConvAsmLds = 2 * (18 * 18 * 16 * 4 + kChunkFloats * 4);
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char conv_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ldsbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)conv_smem);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();   // the body loads ConvArgs fields itself (s_load)
+#else
+  const void* karg = nullptr;   // (host pass of the compiler: never executed)
+#endif
+  // this workgroup's tiles: a contiguous range of (frame, channel tile, y, x), x fastest
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames_asm;
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)(total * blockIdx.x / gridDim.x));
+  const int tile_end = __builtin_amdgcn_readfirstlane((int)(total * (blockIdx.x + 1) / gridDim.x));
+  int t = tile0;
+  const int tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
+  t /= a.tiles_x;
+  const int ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
+  t /= a.tiles_y;
+  const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct), frame0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
+  if (POOL) {
+#include "conv_body_fwd_pool.inc"
+  } else {
+#include "conv_body_fwd.inc"
+  }
+}
+
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
                        float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr,
                        const uint16_t* packed16 = nullptr) {
@@ -671,6 +708,20 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   if (gz > 65535) return S2L_E_SIZE;
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
+  if (S2L_CONV_ASM && !out3 && !a.w16 && a.bias && (CB == 0 || CB == CA) && CA % 16 == 0 && (int64_t)a.tiles_x * a.tiles_y * gz < 0x7fffffff) {
+    a.n_frames_asm = (int)F;
+    int dev = 0, n_cu = 0;
+    int rc = current_device_cus(&dev, &n_cu);
+    if (rc) return rc;
+    static LdsOptIn flags_plain, flags_pool;
+    const void* kern = pool ? reinterpret_cast<const void*>(&conv3x3_asm_kernel<true>) : reinterpret_cast<const void*>(&conv3x3_asm_kernel<false>);
+    if ((rc = ensure_dynamic_lds(kern, kConvAsmLds, pool ? flags_pool : flags_plain, dev))) return rc;
+    const int64_t total = (int64_t)a.tiles_x * a.tiles_y * gz;
+    const unsigned g1 = (unsigned)(total < n_cu ? total : n_cu);
+    if (pool) hipLaunchKernelGGL(conv3x3_asm_kernel<true>, dim3(g1), dim3(256), kConvAsmLds, st, a);
+    else hipLaunchKernelGGL(conv3x3_asm_kernel<false>, dim3(g1), dim3(256), kConvAsmLds, st, a);
+    return (int)hipGetLastError();
+  }
   if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);

@@ -206,6 +206,28 @@ def test_render_body_generator_is_deterministic_and_complete(tmp_path):
     assert text.count("global_load_lds_dwordx4") >= 9 * 4
 
 
+def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
+    """csrc/gen_conv_body.py writes the U-Net 3x3 convolution's assembly bodies.  Two runs give the same text; each variant holds
+    the chunk's 9 taps x 64 MFMAs four times (two LDS buffers x with / without a fetch behind them), 15 LDS-DMA instructions per
+    fetching copy plus the prime, and only the pooling variant stores a second tensor."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_conv_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_conv_body.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    gen.main(str(a))
+    gen.main(str(b))
+    for variant in ("fwd", "fwd_pool"):
+        text = open(a / f"conv_body_{variant}.inc").read()
+        assert text == open(b / f"conv_body_{variant}.inc").read()
+        assert text.count("v_mfma_f32_16x16x4_f32") == 4 * 9 * 64
+        assert text.count("global_load_lds_dwordx4") == 3 * (6 + 9)
+        assert text.count("s_barrier") == 3
+        assert (text.count("global_store_dwordx4") == 16 + 8) == (variant == "fwd_pool")
+        assert "s32" not in text.split("asm volatile")[1].split(": [karg]")[0].replace("s32x", "")   # s32/s33 stay the compiler's
+
+
 def test_lpips_module_has_the_package_state_dict_and_oracle_properties():
     """speech2lip_amd.LPIPS carries the state-dict keys of lpips.LPIPS(net='alex') (lpips==0.1.4), frozen; the oracle's
     restatement is zero on identical images, symmetric, and positive otherwise."""
