@@ -19,6 +19,9 @@ Variants: "fwd" (bias, ReLU), "fwd_pool" (+ the pooled copy).  Inputs A | B (vir
 import os
 import sys
 
+EVERY = int(os.environ.get("S2L_CONV_EVERY", "12"))      # one group of memory instructions behind every EVERY-th MFMA of a chunk
+EXP = os.environ.get("S2L_CONV_EXP", "").split(",")      # timing experiments (results are wrong with some of them)
+TRACE = os.environ.get("S2L_CONV_TRACE") == "1"      # experiment builds only (tools/trace_conv_asm.py): per-tile timestamps
 HALO_BYTES, W_BYTES = 18 * 18 * 64, 9 * 4 * 64 * 16
 BUF = HALO_BYTES + W_BYTES           # 57 600
 
@@ -58,7 +61,7 @@ S = _scalar_map(8,
                 singles="LDSB CA CB COUT H W TILESX TILESY NCT TILE TEND NCH CC WAVE TX TY CT FRAME NTX NTY NCTN NFR X0 Y0 BORDER "
                         "C CHB HASNEXT T0 T1 T2 T3 H2 W2".split(),
                 pairs=("KARG", "INA", "INB", "WB", "BIAS", "OUT", "POOL", "M0_", "M1_", "M2_", "M3_", "M4_", "M5_", "VALID2",
-                       "COLOK", "SRC", "WCH", "P0", "P2", "OUTF", "POOLF"))
+                       "COLOK", "SRC", "WCH", "P0", "P2", "OUTF", "POOLF") + (("TRACE", "TS", "TA") if TRACE else ()))
 S_LAST = max(S.values())
 assert S_LAST <= 101, S_LAST
 
@@ -94,6 +97,29 @@ class Body:
         assert newer <= 15
         self.e(f"s_waitcnt lgkmcnt({newer})")
         self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    def trace(self, slot, plus_cc=False):
+        """experiment builds: wave 0 stores s_memtime to trace[TILE][slot (+ CC)] (24 slots of 8 bytes per tile)"""
+        if not TRACE:
+            return
+        e = self.e
+        skip = self.label("notrace")
+        e(f"s_memtime {s2('TS')}")
+        e(f"s_cmp_eq_u64 {s2('TRACE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u32 {s('WAVE')}, 0")
+        e(f"s_cbranch_scc0 {skip}")
+        e(f"s_mul_i32 {s('TA')}, {s('TILE')}, 192")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {8 * slot}")
+        if plus_cc:
+            e(f"s_lshl_b32 {s('TA1')}, {s('CC')}, 3")
+            e(f"s_add_u32 {s('TA')}, {s('TA')}, {s('TA1')}")
+        e(f"s_add_u32 {s('TA')}, {s('TRACE')}, {s('TA')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('TRACE1')}, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_store_dwordx2 {s2('TS')}, {s2('TA')}, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"{skip}:")
 
     @staticmethod
     def acc(mb, g):
@@ -160,7 +186,7 @@ class Body:
 
     # ------------------------------------------------------------------ DMA of one chunk into buffer b
     def dma_groups(self, b):
-        """the 15 LDS-DMA instructions of a chunk as self-contained groups (each sets m0 / exec itself)"""
+        """the 15 LDS-DMA instructions of a chunk, each a self-contained group (sets m0 / exec itself)"""
         groups = []
         for i in range(6):      # halo: KiB (wave*6 + i) of the buffer's halo region; waves 0..2 six each, wave 3 only i < 3
             g = [f"s_mul_i32 {s('T0')}, {s('WAVE')}, {6 * 1024}",
@@ -171,13 +197,12 @@ class Body:
                  "s_mov_b64 exec, -1"]
             groups.append(g)
         for gi in range(3):     # weights: this wave's 9 KiB = 4 + 4 + 1
-            g = [f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216",
-                 f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF + HALO_BYTES + gi * 4096}",
-                 f"s_add_u32 m0, {s('T0')}, {s('LDSB')}",
-                 "s_nop 0"]
             for k in range(4 if gi < 2 else 1):
-                g.append(f"global_load_lds_dwordx4 v{V_WOFF + gi}, {s2('WCH')} offset:{1024 * k}")
-            groups.append(g)
+                groups.append([f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216",
+                               f"s_add_u32 {s('T0')}, {s('T0')}, {b * BUF + HALO_BYTES + gi * 4096}",
+                               f"s_add_u32 m0, {s('T0')}, {s('LDSB')}",
+                               "s_nop 0",
+                               f"global_load_lds_dwordx4 v{V_WOFF + gi}, {s2('WCH')} offset:{1024 * k}"])
         return groups
 
     def zero_fill(self, b):
@@ -213,6 +238,7 @@ class Body:
         instruction groups tucked behind MFMAs of the first taps"""
         self.lds = [(tag, 0, "A", mb) for mb in range(4)] + [(tag, 0, "B", g) for g in range(4)]
         pending = list(sprinkle)
+        nmf = 0
         for t in range(9):
             if t + 1 < 9:
                 self.tap_reads(b, t + 1, (t + 1) % 2, tag)
@@ -224,7 +250,8 @@ class Body:
                     for g in range(4):
                         self.e(f"v_mfma_f32_16x16x4_f32 {self.acc(mb, g)}, v{base + 4 * mb + ks}, v{base + 16 + 4 * g + ks}, {self.acc(mb, g)}")
                         n += 1
-                        if pending and n % 4 == 0:
+                        nmf += 1
+                        if pending and nmf % EVERY == 0:
                             for x in pending.pop(0):
                                 self.e(x)
         assert not pending, len(pending)
@@ -263,7 +290,8 @@ class Body:
             for g in range(4):
                 b0 = V_ACC + (mb * 4 + g) * 4
                 for r in range(4):
-                    e(f"v_max_f32 v{b0 + r}, 0, v{b0 + r}")
+                    if "nomax" not in EXP:
+                        e(f"v_max_f32 v{b0 + r}, 0, v{b0 + r}")
         for g in range(4):
             skip = self.label("norow")
             e(f"s_add_u32 {s('T0')}, {s('T2')}, {g}")
@@ -272,7 +300,8 @@ class Body:
             e(f"s_mov_b64 exec, {s2('COLOK')}")
             for mb in range(4):
                 b0 = V_ACC + (mb * 4 + g) * 4
-                e(f"global_store_dwordx4 v{V_SOFF + g}, v[{b0}:{b0 + 3}], {s2('OUTF')} offset:{64 * mb}")
+                if "nostore" not in EXP:
+                    e(f"global_store_dwordx4 v{V_SOFF + g}, v[{b0}:{b0 + 3}], {s2('OUTF')} offset:{64 * mb}")
             e("s_mov_b64 exec, -1")
             e(f"{skip}:")
         if self.pool:
@@ -330,6 +359,8 @@ class Body:
         for dst, off in (("CA", "oCA"), ("CB", "oCB"), ("COUT", "ocout"), ("H", "oH"), ("W", "oW"), ("TILESX", "otx"), ("TILESY", "oty"),
                          ("NCT", "onct")):
             e(f"s_load_dword {s(dst)}, {s2('KARG')}, %[{off}]")
+        if TRACE:
+            e(f"s_load_dwordx2 {s2('TRACE')}, {s2('KARG')}, %[otrace]")
         e("s_waitcnt lgkmcnt(0)")
         e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
         e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 4")
@@ -384,12 +415,14 @@ class Body:
         e("s_barrier")
 
         e("S2LC_TILE:")
+        self.trace(0)
         # accumulators = bias of this channel tile (the C++ kernel's initial value; loaded when the tile's fetch was set up)
         for mb in range(4):
             for g in range(4):
                 for r in range(4):
                     e(f"v_mov_b32 v{V_ACC + (mb * 4 + g) * 4 + r}, v{V_BIAS + 4 * mb + r}")
         e(f"s_mov_b32 {s('CC')}, 0")
+        self.trace(1)
         e("S2LC_PAIR:")
         for b in range(2):
             ctag = self.label("chunk")
@@ -450,10 +483,12 @@ class Body:
             e(f"{join}:")
             e("s_waitcnt vmcnt(0)")
             e("s_barrier")
+            self.trace(2, plus_cc=True)
             e(f"s_add_u32 {s('CC')}, {s('CC')}, 1")
         e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
         e("s_cbranch_scc1 S2LC_PAIR")
         self.epilogue()
+        self.trace(20)
         e(f"s_add_u32 {s('TILE')}, {s('TILE')}, 1")
         e(f"s_mov_b32 {s('TX')}, {s('NTX')}")
         e(f"s_mov_b32 {s('TY')}, {s('NTY')}")
@@ -462,6 +497,8 @@ class Body:
         e(f"s_cmp_lt_u32 {s('TILE')}, {s('TEND')}")
         e("s_cbranch_scc1 S2LC_TILE")
         e("s_waitcnt vmcnt(0)")
+        if TRACE:
+            e("s_dcache_wb")
         return [x for x in self.L if x is not None]
 
 
@@ -485,7 +522,7 @@ def main(outdir):
         clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"s{r}" for r in range(8, S_LAST + 1) if r not in (32, 33)] + ["vcc", "scc", "memory"]
         out = ["// GENERATED by csrc/gen_conv_body.py -- do not edit; the generator is the source.", "asm volatile("]
         out += [f'    "{x}\\n\\t"' for x in lines]
-        out.append(OPERANDS.rstrip("\n"))
+        out.append(OPERANDS.rstrip("\n") + (',\n        [otrace] "n"(offsetof(ConvArgs, trace))' if TRACE else ""))
         out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
         with open(os.path.join(outdir, f"conv_body_{variant}.inc"), "w") as f:
             f.write("\n".join(out) + "\n")
