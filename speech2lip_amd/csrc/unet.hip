@@ -708,7 +708,9 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   if (gz > 65535) return S2L_E_SIZE;
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
-  if (S2L_CONV_ASM && !out3 && !a.w16 && a.bias && (CB == 0 || CB == CA) && CA % 16 == 0 && (int64_t)a.tiles_x * a.tiles_y * gz < 0x7fffffff) {
+  // the assembly kernel: A | B of equal width, an even number of 16-channel chunks, and per-frame byte offsets that fit 31 bits
+  if (S2L_CONV_ASM && !out3 && !a.w16 && a.bias && (CB == 0 || CB == CA) && (CA + CB) % 32 == 0 &&
+      (int64_t)(H + 2) * (W + 2) * std::max(CA, a.cout) * 4 < 0x7fffffff && (int64_t)a.tiles_x * a.tiles_y * gz < 0x7fffffff) {
     a.n_frames_asm = (int)F;
     int dev = 0, n_cu = 0;
     int rc = current_device_cus(&dev, &n_cu);

@@ -8,7 +8,7 @@ F, H, W = 16, 500, 500
 LAYERS = [  # (name, cin, cout, scale)
     ("inc.2  64->64  +pool", 64, 64, 1), ("down1.1 64->128", 64, 128, 2), ("down1.2 128->128 +pool", 128, 128, 2),
     ("down2.1 128->128", 128, 128, 4), ("down2.2 128->128", 128, 128, 4), ("up1.1  256->128", 256, 128, 2),
-    ("up1.2  128->128", 128, 128, 2), ("up2.1  128->64", 128, 64, 1), ("up2.2  64->64 +outc", 64, 64, 1)]
+    ("up1.2  128->64", 128, 64, 2), ("up2.1  128->64", 128, 64, 1), ("up2.2  64->64 +outc", 64, 64, 1)]
 
 
 def main(path, ghz=2.3, n_cu=256):
