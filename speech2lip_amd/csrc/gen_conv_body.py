@@ -21,7 +21,9 @@ order per output: chunk, tap, k-step -- results are bit-identical):
   * end of a tile: ReLU writes the accumulators into 64 staging registers; the 16 (+ 8 pooled) stores are issued behind MFMAs of
     the NEXT tile's first chunk (16 bytes per lane and cycle is all the store path takes: 4 k cycles per tile if exposed).
 
-Variants: "fwd" (bias, ReLU), "fwd_pool" (+ the 2x2 max-pooled copy).  Inputs A | B (virtual concat) with CA % 16 == 0, CB in
+Variants: "fwd" (bias, ReLU), "fwd_pool" (+ the 2x2 max-pooled copy), "fwd_out" (+ the network's 1x1 output convolution
+64 -> 3 on the ReLU'd tile, conv3x3_kernel<true>'s arithmetic in its order; the 64-channel activation itself is stored only
+when the caller keeps it for a backward pass).  Inputs A | B (virtual concat) with CA % 16 == 0, CB in
 (0, CA) and an even number of chunks, so that a tile starts on buffer 0 and ends on buffer 1."""
 import os
 import sys
@@ -47,6 +49,7 @@ V_ZERO = 160                   # 4 zeros
 V_SOFF = 164                   # 4: store offsets per g of the tile that just ended
 V_POFF = 168                   # 2: pooled store offsets per row pair
 V_T = 172                      # temporaries 172..187
+V_OWB, V_X16, V_X32 = 188, 189, 190      # fwd_out: LDS address of this lane's output-weight quads; 4 * (lane ^ 16), 4 * (lane ^ 32)
 V_STAGE = 192                  # 64: ReLU(acc) of the tile that just ended, until its stores are issued
 V_LAST = 255
 A_BIAS = 0                     # AGPRs 0..15: bias quad per mb of the tile being fetched / started
@@ -69,10 +72,11 @@ def _scalar_map(first, singles, pairs, skip=(32, 33)):
 
 S = _scalar_map(8,
                 singles="LDSB CA CB COUT H W TILESX TILESY NCT TILE TEND NCH CC WAVE TX TY CT FRAME NTX NTY NCTN NFR X0 Y0 BORDER "
-                        "CHB T0 T1 T2 T3 FO".split(),
+                        "CHB T0 T1 T2 T3 FO OB1 OB2".split(),
                 pairs=("P0", "INA", "INB", "WB", "BIAS", "OUT", "POOL", "M0_", "M1_", "M2_", "M3_", "M4_", "M5_", "VALID2", "VALID3",
                        "COLOK", "SRC", "WCH", "OUTF", "POOLF", "TOFF", "SM0", "SM1", "SM2", "SM3", "PM0", "PM1")
                       + (("TRACE",) if TRACE else ()))
+S["OB0"] = S["CB"]                                  # (fwd_out: the output bias; CB is dead once NCH is known)
 S["KARG"], S["KARG1"] = S["P0"], S["P01"]          # the kernel-argument pointer is dead once the arguments are loaded
 S["TS"], S["TS1"], S["TA"], S["TA1"] = S["COLOK"], S["COLOK1"], S["P0"], S["P01"]   # (trace builds: both are dead at the trace points)
 S_LAST = max(S.values())
@@ -89,7 +93,7 @@ def s2(n):
 
 class Body:
     def __init__(self, variant):
-        self.variant, self.pool = variant, variant == "fwd_pool"
+        self.variant, self.pool, self.fuse = variant, variant == "fwd_pool", variant == "fwd_out"
         self.L, self.lds, self.nlabel = [], [], 0
 
     def e(self, t):
@@ -372,6 +376,8 @@ class Body:
             for g in range(4):
                 for r in range(4):
                     e(f"v_max_f32 v{self.stage(mb, g) + r}, 0, v{V_ACC + (mb * 4 + g) * 4 + r}")
+        if self.fuse:
+            self.output_conv()
         if self.pool:
             e(f"s_lshr_b32 {s('Y0')}, {s('H')}, 1")                # H2
             e(f"s_lshr_b32 {s('X0')}, {s('W')}, 1")                # W2
@@ -399,6 +405,61 @@ class Body:
                 e(f"v_lshl_add_u32 v{V_T + 4}, v{V_T + 4}, 2, v{V_Q16}")
                 e(f"v_add_u32 v{V_POFF + gp}, {s('T3')}, v{V_T + 4}")
 
+    def output_conv(self):
+        """fwd_out: out3[pixel][o] = outb[o] + sum_c outw[o][c] h[c] -- per lane an fma chain over its 16 channels (mb, r in
+        order, from 0), then + the lanes 16 and 32 further (q), as conv3x3_kernel<true>; lanes q == 0 store 12 bytes.
+        Registers: the operand set the tile's last tap used (V_OPS[1]) and the temporaries; T2 = row of g = 0, SM_g = row masks."""
+        e = self.e
+        P, X, WB = V_OPS[1], V_OPS[1] + 16, (V_T, V_OPS[1] + 16)     # p[g][o] at P + 4 g + o; shuffle temporaries; weight quads of o
+        def read_w(o):
+            for mb in range(4):
+                e(f"ds_read_b128 v[{WB[o % 2] + 4 * mb}:{WB[o % 2] + 4 * mb + 3}], v{V_OWB} offset:{256 * o + 64 * mb}")
+        e("s_waitcnt lgkmcnt(0)")          # (the next tile's first operands: the counter is only exact without them)
+        read_w(0)
+        read_w(1)
+        # OUT3F = out3 + frame * H*W*12 (POOL / POOLF hold out3 in this variant)
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, 12")
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_add_u32 {s('POOLF')}, {s('POOL')}, {s('T0')}")
+        e(f"s_addc_u32 {s('POOLF1')}, {s('POOL1')}, {s('T1')}")
+        for o in range(3):
+            e("s_waitcnt lgkmcnt(4)" if o < 2 else "s_waitcnt lgkmcnt(0)")
+            for g in range(4):
+                for mb in range(4):
+                    for r in range(4):
+                        c = "0" if (mb, r) == (0, 0) else f"v{P + 4 * g + o}"
+                        e(f"v_fma_f32 v{P + 4 * g + o}, v{WB[o % 2] + 4 * mb + r}, v{self.stage(mb, g) + r}, {c}")
+            if o == 0:
+                read_w(2)
+        for dist in (V_X16, V_X32):
+            for g in range(4):
+                for o in range(3):
+                    e(f"ds_bpermute_b32 v{X + 4 * g + o}, v{dist}, v{P + 4 * g + o}")
+            e("s_waitcnt lgkmcnt(0)")
+            for g in range(4):
+                for o in range(3):
+                    e(f"v_add_f32 v{P + 4 * g + o}, v{P + 4 * g + o}, v{X + 4 * g + o}")
+        for g in range(4):
+            for o in range(3):
+                e(f"v_add_f32 v{P + 4 * g + o}, {s(f'OB{o}')}, v{P + 4 * g + o}")
+        for g in range(4):
+            e(f"s_add_u32 {s('T0')}, {s('T2')}, {g}")
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('W')}")
+            e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_GX}")
+            e(f"v_mul_lo_u32 v{V_T}, v{V_T}, 12")
+            e(f"s_and_b64 exec, {s2(f'SM{g}')}, 0xffff")
+            e(f"global_store_dwordx3 v{V_T}, v[{P + 4 * g}:{P + 4 * g + 2}], {s2('POOLF')}")
+            e("s_mov_b64 exec, -1")
+        # the activation itself is stored only if the caller keeps it
+        keep = self.label("keep")
+        e(f"s_cmp_lg_u64 {s2('OUT')}, 0")
+        e(f"s_cbranch_scc1 {keep}")
+        for g in range(4):
+            e(f"s_mov_b64 {s2(f'SM{g}')}, 0")
+        e(f"{keep}:")
+
     # ------------------------------------------------------------------ the whole body
     def emit(self):
         e = self.e
@@ -407,16 +468,24 @@ class Body:
                          ("FRAME", "frame0"), ("WAVE", "wave")):
             e(f"s_mov_b32 {s(dst)}, %[{src}]")
         e(f"s_mov_b64 {s2('KARG')}, %[karg]")
-        for dst, off in (("INA", "oinA"), ("INB", "oinB"), ("WB", "ow"), ("BIAS", "obias"), ("OUT", "oout"), ("POOL", "opool")):
+        for dst, off in (("INA", "oinA"), ("INB", "oinB"), ("WB", "ow"), ("BIAS", "obias"), ("OUT", "oout")) + (() if self.fuse else (("POOL", "opool"),)):
             e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, %[{off}]")
         for dst, off in (("CA", "oCA"), ("CB", "oCB"), ("COUT", "ocout"), ("H", "oH"), ("W", "oW"), ("TILESX", "otx"), ("TILESY", "oty"),
                          ("NCT", "onct")):
             e(f"s_load_dword {s(dst)}, {s2('KARG')}, %[{off}]")
         if TRACE:
             e(f"s_load_dwordx2 {s2('TRACE')}, {s2('KARG')}, %[otrace]")
+        if self.fuse:      # POOL <- out3; output weights and bias through PM0 / PM1 (zeroed below)
+            e(f"s_load_dwordx2 {s2('POOL')}, {s2('KARG')}, %[oout3]")
+            e(f"s_load_dwordx2 {s2('PM0')}, {s2('KARG')}, %[ooutw]")
+            e(f"s_load_dwordx2 {s2('PM1')}, {s2('KARG')}, %[ooutb]")
         e("s_waitcnt lgkmcnt(0)")
         e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
         e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 4")
+        if self.fuse:
+            e(f"s_load_dword {s('OB0')}, {s2('PM1')}, 0")
+            e(f"s_load_dword {s('OB1')}, {s2('PM1')}, 4")
+            e(f"s_load_dword {s('OB2')}, {s2('PM1')}, 8")
         e(f"s_lshr_b32 {s('CHB')}, {s('CA')}, 4")
         e(f"s_mul_i32 {s('FO')}, {s('H')}, {s('W')}")              # bytes of one input frame (the launcher checks < 2^31)
         e(f"s_mul_i32 {s('FO')}, {s('FO')}, {s('CA')}")
@@ -463,6 +532,23 @@ class Body:
             e(f"v_lshl_add_u32 v{V_HOFF + i}, v{V_T + 3}, 2, v{V_PART16}")
         for r in range(4):
             e(f"v_mov_b32 v{V_ZERO + r}, 0")
+        if self.fuse:
+            # the 768 bytes of output weights -> LDS behind the two buffers (wave 0, 48 lanes); the wait and barrier of the prime
+            e(f"s_add_u32 {s('T0')}, {s('LDSB')}, {2 * BUF}")
+            e(f"v_add_u32 v{V_OWB}, {s('T0')}, v{V_Q16}")
+            e(f"v_xor_b32 v{V_X16}, 16, v{V_T}")
+            e(f"v_lshlrev_b32 v{V_X16}, 2, v{V_X16}")
+            e(f"v_xor_b32 v{V_X32}, 32, v{V_T}")
+            e(f"v_lshlrev_b32 v{V_X32}, 2, v{V_X32}")
+            now = self.label("noweights")
+            e(f"s_cmp_lg_u32 {s('WAVE')}, 0")
+            e(f"s_cbranch_scc1 {now}")
+            e(f"s_mov_b32 m0, {s('T0')}")
+            e("s_mov_b32 exec_hi, 0xffff")
+            e(f"global_load_lds_dwordx4 v{V_LANE16}, {s2('PM0')}")
+            e("s_mov_b64 exec, -1")
+            e(f"{now}:")
+            e("s_waitcnt lgkmcnt(0)")          # the output bias
         # which DMA lanes carry an existing halo pixel: all but wave 3's i = 2 (pixels 320..335 -> lanes < 16) and i >= 3 (none)
         e(f"s_mov_b64 {s2('VALID2')}, -1")
         e(f"s_mov_b64 {s2('VALID3')}, -1")
@@ -580,13 +666,14 @@ OPERANDS = """      :
         [obias] "n"(offsetof(ConvArgs, bias)), [oout] "n"(offsetof(ConvArgs, out)), [opool] "n"(offsetof(ConvArgs, pool)),
         [oCA] "n"(offsetof(ConvArgs, CA)), [oCB] "n"(offsetof(ConvArgs, CB)), [ocout] "n"(offsetof(ConvArgs, cout)),
         [oH] "n"(offsetof(ConvArgs, H)), [oW] "n"(offsetof(ConvArgs, W)), [otx] "n"(offsetof(ConvArgs, tiles_x)),
-        [oty] "n"(offsetof(ConvArgs, tiles_y)), [onct] "n"(offsetof(ConvArgs, n_ct))
+        [oty] "n"(offsetof(ConvArgs, tiles_y)), [onct] "n"(offsetof(ConvArgs, n_ct)), [oout3] "n"(offsetof(ConvArgs, out3)),
+        [ooutw] "n"(offsetof(ConvArgs, outw)), [ooutb] "n"(offsetof(ConvArgs, outb))
 """
 
 
 def main(outdir):
     total = 0
-    for variant in ("fwd", "fwd_pool"):
+    for variant in ("fwd", "fwd_pool", "fwd_out"):
         lines = Body(variant).emit()
         # labels are per variant
         lines = [x.replace("S2LC_TILE", f"S2LC_{variant}_TILE").replace("S2LC_EVEN", f"S2LC_{variant}_EVEN").replace("S2LC_ODD", f"S2LC_{variant}_ODD")

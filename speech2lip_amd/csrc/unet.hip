@@ -660,12 +660,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
 
 // ---- the forward convolution with its body as one fixed-register assembly text (csrc/gen_conv_body.py: persistent, one wave
 // per SIMD, both operands by LDS-DMA into two buffers, the chunk loop nothing but MFMAs, LDS reads and scalar code).  Same tile,
-// packed weights, LDS layouts and accumulation order as conv3x3_kernel: bit-identical outputs.  POOL: also the 2x2-pooled copy.
-constexpr int kConvAsmLds = 2 * (18 * 18 * 16 * 4 + kChunkFloats * 4);
-template <bool POOL>
+// packed weights, LDS layouts and accumulation order as conv3x3_kernel: bit-identical outputs.  VARIANT 1: also the 2x2-pooled copy; 2: also the network's 1x1 output
+// convolution (conv3x3_kernel<true>'s epilogue), the activation itself stored only if a.out is set.
+constexpr int kConvAsmLds = 2 * (18 * 18 * 16 * 4 + kChunkFloats * 4) + 768;      // two buffers + variant 2's output weights
+template <int VARIANT>
 __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char conv_smem[];
-  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t ldsbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)conv_smem);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -683,8 +683,10 @@ __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
   const int ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
   t /= a.tiles_y;
   const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct), frame0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
-  if (POOL) {
+  if (VARIANT == 1) {
 #include "conv_body_fwd_pool.inc"
+  } else if (VARIANT == 2) {
+#include "conv_body_fwd_out.inc"
   } else {
 #include "conv_body_fwd.inc"
   }
@@ -709,19 +711,19 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
   // the assembly kernel: A | B of equal width, an even number of 16-channel chunks, and per-frame byte offsets that fit 31 bits
-  if (S2L_CONV_ASM && !out3 && !a.w16 && a.bias && (CB == 0 || CB == CA) && (CA + CB) % 32 == 0 &&
+  if (S2L_CONV_ASM && !(out3 && pool) && !a.w16 && a.bias && (CB == 0 || CB == CA) && (CA + CB) % 32 == 0 && (!out3 || a.cout == 64) &&
       (int64_t)(H + 2) * (W + 2) * std::max(CA, a.cout) * 4 < 0x7fffffff && (int64_t)a.tiles_x * a.tiles_y * gz < 0x7fffffff) {
     a.n_frames_asm = (int)F;
     int dev = 0, n_cu = 0;
     int rc = current_device_cus(&dev, &n_cu);
     if (rc) return rc;
-    static LdsOptIn flags_plain, flags_pool;
-    const void* kern = pool ? reinterpret_cast<const void*>(&conv3x3_asm_kernel<true>) : reinterpret_cast<const void*>(&conv3x3_asm_kernel<false>);
-    if ((rc = ensure_dynamic_lds(kern, kConvAsmLds, pool ? flags_pool : flags_plain, dev))) return rc;
+    static LdsOptIn flags[3];
+    const int variant = out3 ? 2 : pool ? 1 : 0;
+    void (*const kern[3])(ConvArgs) = {conv3x3_asm_kernel<0>, conv3x3_asm_kernel<1>, conv3x3_asm_kernel<2>};
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[variant]), kConvAsmLds, flags[variant], dev))) return rc;
     const int64_t total = (int64_t)a.tiles_x * a.tiles_y * gz;
     const unsigned g1 = (unsigned)(total < n_cu ? total : n_cu);
-    if (pool) hipLaunchKernelGGL(conv3x3_asm_kernel<true>, dim3(g1), dim3(256), kConvAsmLds, st, a);
-    else hipLaunchKernelGGL(conv3x3_asm_kernel<false>, dim3(g1), dim3(256), kConvAsmLds, st, a);
+    hipLaunchKernelGGL(kern[variant], dim3(g1), dim3(256), kConvAsmLds, st, a);
     return (int)hipGetLastError();
   }
   if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);

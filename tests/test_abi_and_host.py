@@ -219,13 +219,15 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
     a.mkdir(), b.mkdir()
     gen.main(str(a))
     gen.main(str(b))
-    for variant in ("fwd", "fwd_pool"):
+    for variant in ("fwd", "fwd_pool", "fwd_out"):
         text = open(a / f"conv_body_{variant}.inc").read()
         assert text == open(b / f"conv_body_{variant}.inc").read()
         assert text.count("v_mfma_f32_16x16x4_f32") == 4 * 9 * 64
-        assert text.count("global_load_lds_dwordx4") == 4 * (6 + 9)
+        assert text.count("global_load_lds_dwordx4") == 4 * (6 + 9) + (variant == "fwd_out")      # + the output weights
         assert text.count("s_barrier") == 1 + 4
         assert text.count("global_store_dwordx4") == 2 * (16 + (8 if variant == "fwd_pool" else 0))
+        assert text.count("global_store_dwordx3") == (4 if variant == "fwd_out" else 0)              # 12-byte output pixels, per tile row
+        assert text.count("v_fma_f32") == (3 * 4 * 16 if variant == "fwd_out" else 0)                 # 64 -> 3 on 4 rows, 16 channels per lane
         body = text.split("asm volatile")[1].split(": [karg]")[0]
         assert "s32" not in body and "s33" not in body           # s32 / s33 stay the compiler's
         assert '"v"(' not in text                                # every VGPR is the body's: no vector operand
