@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for a round on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r01'
-# Kernel-trace stats and each PMC group are separate runs (PMC is never combined with sys/hip traces).
+# Kernel-trace stats and each PMC group are separate runs (PMC is never combined with sys/hip traces); every run under `timeout`
+# (a profiler run that hangs would otherwise hold the box until gpurun's own limit).
 set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,17 +11,17 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 C="python $R/tools/bench_composite.py 256"
-$B > $O/bench_line.json 2> $O/bench.err
-$C > $O/composite_line.json 2> $O/composite.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $B > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma -o s -- $B > $O/pmc_mfma.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o s -- $B > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o s -- $B > $O/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/pmc_sq -o s -- $B > $O/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o s -- $C > $O/cstats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_fetch -o s -- $C > $O/cpmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/cpmc_write -o s -- $C > $O/cpmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
+timeout 300 $B > $O/bench_line.json 2> $O/bench.err
+timeout 300 $C > $O/composite_line.json 2> $O/composite.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $B > $O/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_mfma -o s -- $B > $O/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o s -- $B > $O/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o s -- $B > $O/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/pmc_sq -o s -- $B > $O/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o s -- $C > $O/cstats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_fetch -o s -- $C > $O/cpmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/cpmc_write -o s -- $C > $O/cpmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
 ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \
@@ -28,7 +29,7 @@ for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_tr
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
             "stage1_full:tools/bench_train.py 8 bf16 --full"; do
   name=${spec%%:*}; cmd=${spec#*:}
-  python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1
+  timeout 300 python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1
 done
 ls $O
