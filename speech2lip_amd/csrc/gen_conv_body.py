@@ -23,7 +23,9 @@ order per output: chunk, tap, k-step -- results are bit-identical):
 
 Variants: "fwd" (bias, ReLU), "fwd_pool" (+ the 2x2 max-pooled copy), "fwd_out" (+ the network's 1x1 output convolution
 64 -> 3 on the ReLU'd tile, conv3x3_kernel<true>'s arithmetic in its order; the 64-channel activation itself is stored only
-when the caller keeps it for a backward pass).  Inputs A | B (virtual concat) with CA % 16 == 0, CB in
+when the caller keeps it for a backward pass), "lin" (no bias, no ReLU; an optional gate tensor of the output's shape zeroes the
+result where it is <= 0: the input-gradient convolutions of the backward passes -- fed with the transposed, tap-mirrored chunks --
+and the raw convolutions of the train-mode forward).  Inputs A | B (virtual concat) with CA % 16 == 0, CB in
 (0, CA) and an even number of chunks, so that a tile starts on buffer 0 and ends on buffer 1."""
 import os
 import sys
@@ -76,6 +78,7 @@ S = _scalar_map(8,
                 pairs=("P0", "INA", "INB", "WB", "BIAS", "OUT", "POOL", "M0_", "M1_", "M2_", "M3_", "M4_", "M5_", "VALID2", "VALID3",
                        "COLOK", "SRC", "WCH", "OUTF", "POOLF", "TOFF", "SM0", "SM1", "SM2", "SM3", "PM0", "PM1")
                       + (("TRACE",) if TRACE else ()))
+S["GATE"], S["GATE1"], S["GATEF"], S["GATEF1"], S["LASTF"], S["LASTF1"] = S["POOL"], S["POOL1"], S["POOLF"], S["POOLF1"], S["PM0"], S["PM01"]   # (lin)
 S["OB0"] = S["CB"]                                  # (fwd_out: the output bias; CB is dead once NCH is known)
 S["KARG"], S["KARG1"] = S["P0"], S["P01"]          # the kernel-argument pointer is dead once the arguments are loaded
 S["TS"], S["TS1"], S["TA"], S["TA1"] = S["COLOK"], S["COLOK1"], S["P0"], S["P01"]   # (trace builds: both are dead at the trace points)
@@ -93,7 +96,7 @@ def s2(n):
 
 class Body:
     def __init__(self, variant):
-        self.variant, self.pool, self.fuse = variant, variant == "fwd_pool", variant == "fwd_out"
+        self.variant, self.pool, self.fuse, self.lin = variant, variant == "fwd_pool", variant == "fwd_out", variant == "lin"
         self.L, self.lds, self.nlabel = [], [], 0
 
     def e(self, t):
@@ -173,11 +176,11 @@ class Body:
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
         e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
         e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
-        # the tile's bias quads
-        e(f"s_lshl_b32 {s('T0')}, {s(ct)}, 8")
-        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_Q16}")
-        for mb in range(4):
-            e(f"global_load_dwordx4 a[{A_BIAS + 4 * mb}:{A_BIAS + 4 * mb + 3}], v{V_T}, {s2('BIAS')} offset:{64 * mb}")
+        if not self.lin:      # the tile's bias quads
+            e(f"s_lshl_b32 {s('T0')}, {s(ct)}, 8")
+            e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_Q16}")
+            for mb in range(4):
+                e(f"global_load_dwordx4 a[{A_BIAS + 4 * mb}:{A_BIAS + 4 * mb + 3}], v{V_T}, {s2('BIAS')} offset:{64 * mb}")
         # interior tile (the whole 18x18 halo lies in the image): every existing halo pixel is fetched
         border, done = self.label("border"), self.label("masks")
         e(f"s_cmp_eq_u32 {s(tx)}, 0")
@@ -341,11 +344,50 @@ class Body:
         assert len(self.lds) == (8 if read_next else 0)
 
     # ------------------------------------------------------------------ end of a tile
+    def gate_groups(self):
+        """lin: the gate quads of this tile -> staging registers, from the tile's last chunk (LASTF: all ones there if there is
+        a gate, else zero); SOFF / SM of the tile are set up just before that chunk"""
+        groups = []
+        for g in range(4):
+            for mb in range(4):
+                st = self.stage(mb, g)
+                groups.append([f"s_and_b64 exec, {s2(f'SM{g}')}, {s2('LASTF')}",
+                               f"global_load_dwordx4 v[{st}:{st + 3}], v{V_SOFF + g}, {s2('GATEF')} offset:{64 * mb}",
+                               "s_mov_b64 exec, -1"])
+        return groups
+
     def tile_end(self):
         """ReLU(acc) -> staging registers; store offsets and masks of this tile (its stores are issued later)"""
         e = self.e
         e("s_nop 7")
         e("s_nop 7")
+        if self.lin:
+            # (addresses: store_setup ran before the tile's last chunk)  stage = acc, or acc where the gate is positive
+            plain, done = self.label("nogate"), self.label("staged")
+            e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+            e(f"s_cbranch_scc1 {plain}")
+            for i in range(64):
+                e(f"v_cmp_lt_f32 vcc, 0, v{V_STAGE + i}")
+                e(f"v_cndmask_b32 v{V_STAGE + i}, 0, v{V_ACC + i}, vcc")
+            e(f"s_branch {done}")
+            e(f"{plain}:")
+            for i in range(64):
+                e(f"v_mov_b32 v{V_STAGE + i}, v{V_ACC + i}")
+            e(f"{done}:")
+            return
+        self.store_setup()
+        for mb in range(4):
+            for g in range(4):
+                for r in range(4):
+                    e(f"v_max_f32 v{self.stage(mb, g) + r}, 0, v{V_ACC + (mb * 4 + g) * 4 + r}")
+        if self.fuse:
+            self.output_conv()
+        if self.pool:
+            self.pool_setup()
+
+    def store_setup(self):
+        """OUTF, SOFF_g, SM_g (and T2 = image row of g = 0, T3 = 256 ct, V_GX) of tile (TX, TY, CT, FRAME)"""
+        e = self.e
         # OUTF = out + frame * H*W*cout*4
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
@@ -372,13 +414,16 @@ class Body:
             e(f"v_mul_lo_u32 v{V_T + 1}, v{V_T + 1}, {s('COUT')}")
             e(f"v_lshl_add_u32 v{V_T + 1}, v{V_T + 1}, 2, v{V_Q16}")
             e(f"v_add_u32 v{V_SOFF + g}, {s('T3')}, v{V_T + 1}")
-        for mb in range(4):
-            for g in range(4):
-                for r in range(4):
-                    e(f"v_max_f32 v{self.stage(mb, g) + r}, 0, v{V_ACC + (mb * 4 + g) * 4 + r}")
-        if self.fuse:
-            self.output_conv()
-        if self.pool:
+        if self.lin:          # the gate has the output's shape: same offsets from its own frame base
+            e(f"s_sub_u32 {s('T0')}, {s('OUTF')}, {s('OUT')}")
+            e(f"s_subb_u32 {s('T1')}, {s('OUTF1')}, {s('OUT1')}")
+            e(f"s_add_u32 {s('GATEF')}, {s('GATE')}, {s('T0')}")
+            e(f"s_addc_u32 {s('GATEF1')}, {s('GATE1')}, {s('T1')}")
+
+    def pool_setup(self):
+        """POOLF, POFF_gp, PM_gp of the tile (after store_setup: T2, T3, V_GX)"""
+        e = self.e
+        if True:
             e(f"s_lshr_b32 {s('Y0')}, {s('H')}, 1")                # H2
             e(f"s_lshr_b32 {s('X0')}, {s('W')}, 1")                # W2
             e(f"s_mul_i32 {s('T0')}, {s('Y0')}, {s('X0')}")
@@ -468,13 +513,15 @@ class Body:
                          ("FRAME", "frame0"), ("WAVE", "wave")):
             e(f"s_mov_b32 {s(dst)}, %[{src}]")
         e(f"s_mov_b64 {s2('KARG')}, %[karg]")
-        for dst, off in (("INA", "oinA"), ("INB", "oinB"), ("WB", "ow"), ("BIAS", "obias"), ("OUT", "oout")) + (() if self.fuse else (("POOL", "opool"),)):
+        for dst, off in (("INA", "oinA"), ("INB", "oinB"), ("WB", "ow"), ("BIAS", "obias"), ("OUT", "oout")) + (() if self.fuse or self.lin else (("POOL", "opool"),)):
             e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, %[{off}]")
         for dst, off in (("CA", "oCA"), ("CB", "oCB"), ("COUT", "ocout"), ("H", "oH"), ("W", "oW"), ("TILESX", "otx"), ("TILESY", "oty"),
                          ("NCT", "onct")):
             e(f"s_load_dword {s(dst)}, {s2('KARG')}, %[{off}]")
         if TRACE:
             e(f"s_load_dwordx2 {s2('TRACE')}, {s2('KARG')}, %[otrace]")
+        if self.lin:
+            e(f"s_load_dwordx2 {s2('GATE')}, {s2('KARG')}, %[ogate]")
         if self.fuse:      # POOL <- out3; output weights and bias through PM0 / PM1 (zeroed below)
             e(f"s_load_dwordx2 {s2('POOL')}, {s2('KARG')}, %[oout3]")
             e(f"s_load_dwordx2 {s2('PM0')}, {s2('KARG')}, %[ooutw]")
@@ -575,7 +622,10 @@ class Body:
         for mb in range(4):
             for g in range(4):
                 for r in range(4):
-                    e(f"v_accvgpr_read_b32 v{V_ACC + (mb * 4 + g) * 4 + r}, a{A_BIAS + 4 * mb + r}")
+                    if self.lin:
+                        e(f"v_mov_b32 v{V_ACC + (mb * 4 + g) * 4 + r}, 0")
+                    else:
+                        e(f"v_accvgpr_read_b32 v{V_ACC + (mb * 4 + g) * 4 + r}, a{A_BIAS + 4 * mb + r}")
         e(f"s_mov_b32 {s('CC')}, 0")
         self.trace(1)
         # ---- chunk 0 (buffer 0): fetches chunk 1 of the same tile, and issues the stores of the tile before
@@ -604,8 +654,14 @@ class Body:
         e(f"s_cmp_lt_u32 {s('T0')}, {s('NCH')}")
         e(f"s_cbranch_scc0 {nexttile}")
         self.advance_in_tile()
+        if self.lin:
+            e(f"s_mov_b64 {s2('LASTF')}, 0")
         e(f"s_branch {fetch}")
         e(f"{nexttile}:")
+        if self.lin:      # the tile's last chunk: its stores' addresses (the stores of the tile before are all issued), its gate
+            self.store_setup()
+            e(f"s_cmp_lg_u64 {s2('GATE')}, 0")
+            e(f"s_cselect_b64 {s2('LASTF')}, -1, 0")
         e(f"s_add_u32 {s('T0')}, {s('TILE')}, 1")
         e(f"s_cmp_lt_u32 {s('T0')}, {s('TEND')}")
         e(f"s_cbranch_scc0 {nofetch}")
@@ -631,10 +687,17 @@ class Body:
         self.fetch_setup("NTX", "NTY", "NCTN", "NFR")
         e(f"{fetch}:")
         self.zero_fill(0)
-        self.chunk(1, self.dma_groups(0))
+        dma, gates = self.dma_groups(0), (self.gate_groups() if self.lin else [])
+        mixed = []
+        while dma or gates:
+            if dma:
+                mixed.append(dma.pop(0))
+            if gates:
+                mixed.append(gates.pop(0))
+        self.chunk(1, mixed)
         e(f"s_branch {after}")
         e(f"{nofetch}:")
-        self.chunk(1, [], read_next=False)
+        self.chunk(1, self.gate_groups() if self.lin else [], read_next=False)
         e(f"{after}:")
         e(f"s_add_u32 {s('CC')}, {s('CC')}, 1")
         e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
@@ -667,13 +730,13 @@ OPERANDS = """      :
         [oCA] "n"(offsetof(ConvArgs, CA)), [oCB] "n"(offsetof(ConvArgs, CB)), [ocout] "n"(offsetof(ConvArgs, cout)),
         [oH] "n"(offsetof(ConvArgs, H)), [oW] "n"(offsetof(ConvArgs, W)), [otx] "n"(offsetof(ConvArgs, tiles_x)),
         [oty] "n"(offsetof(ConvArgs, tiles_y)), [onct] "n"(offsetof(ConvArgs, n_ct)), [oout3] "n"(offsetof(ConvArgs, out3)),
-        [ooutw] "n"(offsetof(ConvArgs, outw)), [ooutb] "n"(offsetof(ConvArgs, outb))
+        [ooutw] "n"(offsetof(ConvArgs, outw)), [ooutb] "n"(offsetof(ConvArgs, outb)), [ogate] "n"(offsetof(ConvArgs, gate))
 """
 
 
 def main(outdir):
     total = 0
-    for variant in ("fwd", "fwd_pool", "fwd_out"):
+    for variant in ("fwd", "fwd_pool", "fwd_out", "lin"):
         lines = Body(variant).emit()
         # labels are per variant
         lines = [x.replace("S2LC_TILE", f"S2LC_{variant}_TILE").replace("S2LC_EVEN", f"S2LC_{variant}_EVEN").replace("S2LC_ODD", f"S2LC_{variant}_ODD")

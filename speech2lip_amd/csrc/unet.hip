@@ -661,7 +661,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
 // ---- the forward convolution with its body as one fixed-register assembly text (csrc/gen_conv_body.py: persistent, one wave
 // per SIMD, both operands by LDS-DMA into two buffers, the chunk loop nothing but MFMAs, LDS reads and scalar code).  Same tile,
 // packed weights, LDS layouts and accumulation order as conv3x3_kernel: bit-identical outputs.  VARIANT 1: also the 2x2-pooled copy; 2: also the network's 1x1 output
-// convolution (conv3x3_kernel<true>'s epilogue), the activation itself stored only if a.out is set.
+// convolution (conv3x3_kernel<true>'s epilogue), the activation itself stored only if a.out is set; 3: no bias, no ReLU, optional
+// gate (the input-gradient convolutions and the raw convolutions of the train-mode forward).
 constexpr int kConvAsmLds = 2 * (18 * 18 * 16 * 4 + kChunkFloats * 4) + 768;      // two buffers + variant 2's output weights
 template <int VARIANT>
 __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
@@ -687,9 +688,34 @@ __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
 #include "conv_body_fwd_pool.inc"
   } else if (VARIANT == 2) {
 #include "conv_body_fwd_out.inc"
+  } else if (VARIANT == 3) {
+#include "conv_body_lin.inc"
   } else {
 #include "conv_body_fwd.inc"
   }
+}
+
+// The assembly kernel takes the launch if it has the epilogue: A | B of equal width, an even number of 16-channel chunks,
+// per-frame byte offsets that fit 31 bits, and (bias + ReLU [+ pooling | + fused output]) or (no bias, no ReLU [+ gate]).
+static int launch_conv_asm(ConvArgs& a, int64_t F, hipStream_t st, bool* launched) {
+  *launched = false;
+  const bool fwd = a.bias && a.relu && !a.gate && !(a.out3 && a.pool) && (!a.out3 || a.cout == 64);
+  const bool lin = !a.bias && !a.relu && !a.out3 && !a.pool && a.out;
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * F;
+  if (!S2L_CONV_ASM || a.w16 || !(fwd || lin) || !(a.CB == 0 || a.CB == a.CA) || (a.CA + a.CB) % 32 != 0 || a.cout % 64 != 0 ||
+      (int64_t)(a.H + 2) * (a.W + 2) * std::max(a.CA, a.cout) * 4 >= 0x7fffffff || total >= 0x7fffffff)
+    return S2L_OK;
+  a.n_frames_asm = (int)F;
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  static LdsOptIn flags[4];
+  const int variant = lin ? 3 : a.out3 ? 2 : a.pool ? 1 : 0;
+  void (*const kern[4])(ConvArgs) = {conv3x3_asm_kernel<0>, conv3x3_asm_kernel<1>, conv3x3_asm_kernel<2>, conv3x3_asm_kernel<3>};
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[variant]), kConvAsmLds, flags[variant], dev))) return rc;
+  hipLaunchKernelGGL(kern[variant], dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kConvAsmLds, st, a);
+  *launched = true;
+  return (int)hipGetLastError();
 }
 
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
@@ -710,22 +736,9 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   if (gz > 65535) return S2L_E_SIZE;
   dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
-  // the assembly kernel: A | B of equal width, an even number of 16-channel chunks, and per-frame byte offsets that fit 31 bits
-  if (S2L_CONV_ASM && !(out3 && pool) && !a.w16 && a.bias && (CB == 0 || CB == CA) && (CA + CB) % 32 == 0 && (!out3 || a.cout == 64) &&
-      (int64_t)(H + 2) * (W + 2) * std::max(CA, a.cout) * 4 < 0x7fffffff && (int64_t)a.tiles_x * a.tiles_y * gz < 0x7fffffff) {
-    a.n_frames_asm = (int)F;
-    int dev = 0, n_cu = 0;
-    int rc = current_device_cus(&dev, &n_cu);
-    if (rc) return rc;
-    static LdsOptIn flags[3];
-    const int variant = out3 ? 2 : pool ? 1 : 0;
-    void (*const kern[3])(ConvArgs) = {conv3x3_asm_kernel<0>, conv3x3_asm_kernel<1>, conv3x3_asm_kernel<2>};
-    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[variant]), kConvAsmLds, flags[variant], dev))) return rc;
-    const int64_t total = (int64_t)a.tiles_x * a.tiles_y * gz;
-    const unsigned g1 = (unsigned)(total < n_cu ? total : n_cu);
-    hipLaunchKernelGGL(kern[variant], dim3(g1), dim3(256), kConvAsmLds, st, a);
-    return (int)hipGetLastError();
-  }
+  bool done = false;
+  const int rc_asm = launch_conv_asm(a, F, st, &done);
+  if (done) return rc_asm;
   if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
@@ -755,6 +768,9 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
   if (gz > 65535) return S2L_E_SIZE;
   const dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
   CONV_TRACE_ARGS(a, grid);
+  bool done = false;
+  const int rc_asm = launch_conv_asm(a, F, st, &done);
+  if (done) return rc_asm;
   if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
@@ -1598,7 +1614,9 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
       a.w = packed_raw + unet_w_off(l); a.bias = nullptr; a.out = b.z[l]; a.out3 = nullptr; a.pool = nullptr; a.gate = nullptr; a.relu = 0;
       a.outw = a.outb = nullptr; a.H = hh[lv]; a.W = ww[lv];
       a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16; a.n_ct = C / 64;
-      hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)(F * a.n_ct)), dim3(256), 0, st, a);
+      bool done = false;
+      if ((rc = launch_conv_asm(a, F, st, &done))) return rc;
+      if (!done) hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)(F * a.n_ct)), dim3(256), 0, st, a);
     }
     int nb = 0;
     run_stats(b.z[l], C, pl[lv], scratch, st, &nb);

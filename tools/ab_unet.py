@@ -13,6 +13,18 @@ for (F, H, Wd) in ((2, 64, 80), (1, 37, 53), (3, 500, 500), (1, 412, 364)):
     out = u.forward_nhwc(x)
     torch.cuda.synchronize()
     res[f"{F}x{H}x{Wd}"] = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]
+# the backward passes (input-gradient convolutions with / without gate; raw convolutions of the train-mode forward)
+h = lambda a: hashlib.sha256(a.detach().cpu().numpy().tobytes()).hexdigest()[:12]
+for (F, H, Wd) in ((2, 64, 80), (1, 101, 77)):
+    x = torch.from_numpy(W.synthetic_image((F, H, Wd, 3), 7, "x")).to(dev)
+    g = torch.from_numpy(W.synthetic_image((F, H, Wd, 3), 8, "x")).to(dev) - 0.5
+    out, ctx = u.forward_saved_nhwc(x)
+    res[f"bwd_{F}x{H}x{Wd}"] = h(out) + "/" + h(u.backward_input(ctx, g))
+    u.train()
+    out, ctx = u.forward_train_nhwc(x, update_running=False)
+    dx, grads = u.backward_train(ctx, g)
+    res[f"train_{F}x{H}x{Wd}"] = h(out) + "/" + h(dx) + "/" + h(torch.cat([grads[k].reshape(-1) for k in sorted(grads)]))
+    u.eval()
 x = torch.rand(16, 500, 500, 3, device=dev)
 out = torch.empty_like(x)
 ms = _median_ms(lambda: u.forward_nhwc(x, out=out), reps=5, inner=1)
