@@ -423,32 +423,31 @@ class Body:
     def pool_setup(self):
         """POOLF, POFF_gp, PM_gp of the tile (after store_setup: T2, T3, V_GX)"""
         e = self.e
-        if True:
-            e(f"s_lshr_b32 {s('Y0')}, {s('H')}, 1")                # H2
-            e(f"s_lshr_b32 {s('X0')}, {s('W')}, 1")                # W2
-            e(f"s_mul_i32 {s('T0')}, {s('Y0')}, {s('X0')}")
-            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
-            e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
-            e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('FRAME')}")
-            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FRAME')}")
-            e(f"s_add_u32 {s('POOLF')}, {s('POOL')}, {s('T0')}")
-            e(f"s_addc_u32 {s('POOLF1')}, {s('POOL1')}, {s('T1')}")
-            e(f"v_lshrrev_b32 v{V_T + 2}, 1, v{V_GX}")             # px2 = gx / 2
-            e(f"v_cmp_gt_u32 vcc, {s('X0')}, v{V_T + 2}")
-            e(f"s_mov_b64 {s2('P0')}, vcc")
-            e(f"v_and_b32 v{V_T + 3}, 1, v{V_GX}")
-            e(f"v_cmp_eq_u32 vcc, 0, v{V_T + 3}")
-            e(f"s_and_b64 {s2('P0')}, {s2('P0')}, vcc")
-            for gp in range(2):
-                e(f"s_add_u32 {s('T0')}, {s('T2')}, {2 * gp}")
-                e(f"s_lshr_b32 {s('T0')}, {s('T0')}, 1")             # py2
-                e(f"s_cmp_lt_u32 {s('T0')}, {s('Y0')}")
-                e(f"s_cselect_b64 {s2(f'PM{gp}')}, {s2('P0')}, 0")
-                e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('X0')}")
-                e(f"v_add_u32 v{V_T + 4}, {s('T0')}, v{V_T + 2}")
-                e(f"v_mul_lo_u32 v{V_T + 4}, v{V_T + 4}, {s('COUT')}")
-                e(f"v_lshl_add_u32 v{V_T + 4}, v{V_T + 4}, 2, v{V_Q16}")
-                e(f"v_add_u32 v{V_POFF + gp}, {s('T3')}, v{V_T + 4}")
+        e(f"s_lshr_b32 {s('Y0')}, {s('H')}, 1")                # H2
+        e(f"s_lshr_b32 {s('X0')}, {s('W')}, 1")                # W2
+        e(f"s_mul_i32 {s('T0')}, {s('Y0')}, {s('X0')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FRAME')}")
+        e(f"s_add_u32 {s('POOLF')}, {s('POOL')}, {s('T0')}")
+        e(f"s_addc_u32 {s('POOLF1')}, {s('POOL1')}, {s('T1')}")
+        e(f"v_lshrrev_b32 v{V_T + 2}, 1, v{V_GX}")             # px2 = gx / 2
+        e(f"v_cmp_gt_u32 vcc, {s('X0')}, v{V_T + 2}")
+        e(f"s_mov_b64 {s2('P0')}, vcc")
+        e(f"v_and_b32 v{V_T + 3}, 1, v{V_GX}")
+        e(f"v_cmp_eq_u32 vcc, 0, v{V_T + 3}")
+        e(f"s_and_b64 {s2('P0')}, {s2('P0')}, vcc")
+        for gp in range(2):
+            e(f"s_add_u32 {s('T0')}, {s('T2')}, {2 * gp}")
+            e(f"s_lshr_b32 {s('T0')}, {s('T0')}, 1")             # py2
+            e(f"s_cmp_lt_u32 {s('T0')}, {s('Y0')}")
+            e(f"s_cselect_b64 {s2(f'PM{gp}')}, {s2('P0')}, 0")
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('X0')}")
+            e(f"v_add_u32 v{V_T + 4}, {s('T0')}, v{V_T + 2}")
+            e(f"v_mul_lo_u32 v{V_T + 4}, v{V_T + 4}, {s('COUT')}")
+            e(f"v_lshl_add_u32 v{V_T + 4}, v{V_T + 4}, 2, v{V_Q16}")
+            e(f"v_add_u32 v{V_POFF + gp}, {s('T3')}, v{V_T + 4}")
 
     def output_conv(self):
         """fwd_out: out3[pixel][o] = outb[o] + sum_c outw[o][c] h[c] -- per lane an fma chain over its 16 channels (mb, r in

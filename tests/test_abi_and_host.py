@@ -210,7 +210,8 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
     """csrc/gen_conv_body.py writes the U-Net 3x3 convolution's assembly bodies.  Two runs give the same text; each variant holds
     the chunk's 9 taps x 64 MFMAs four times (first chunk of a tile, later even chunks, odd chunks with / without a fetch), 15
     LDS-DMA instructions per fetching copy plus the prime, one barrier per chunk copy plus the prime, and the tile's 16 (+ 8
-    pooled) stores twice: behind the next tile's first chunk, and after the loop for the last tile."""
+    pooled) stores twice: behind the next tile's first chunk, and after the loop for the last tile.  The variants differ in
+    their tile ends only: pooled copy, fused 1x1 output convolution, or no bias / ReLU with an optional gate."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_conv_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_conv_body.py"))
     gen = importlib.util.module_from_spec(spec)
@@ -219,7 +220,7 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
     a.mkdir(), b.mkdir()
     gen.main(str(a))
     gen.main(str(b))
-    for variant in ("fwd", "fwd_pool", "fwd_out"):
+    for variant in ("fwd", "fwd_pool", "fwd_out", "lin"):
         text = open(a / f"conv_body_{variant}.inc").read()
         assert text == open(b / f"conv_body_{variant}.inc").read()
         assert text.count("v_mfma_f32_16x16x4_f32") == 4 * 9 * 64
@@ -228,6 +229,8 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
         assert text.count("global_store_dwordx4") == 2 * (16 + (8 if variant == "fwd_pool" else 0))
         assert text.count("global_store_dwordx3") == (4 if variant == "fwd_out" else 0)              # 12-byte output pixels, per tile row
         assert text.count("v_fma_f32") == (3 * 4 * 16 if variant == "fwd_out" else 0)                 # 64 -> 3 on 4 rows, 16 channels per lane
+        assert text.count("global_load_dwordx4 v[") == (2 * 16 if variant == "lin" else 0)           # gate quads, behind both last-chunk copies
+        assert text.count("global_load_dwordx4 a[") == (0 if variant == "lin" else 2 * 4)            # bias quads (prime + per tile)
         body = text.split("asm volatile")[1].split(": [karg]")[0]
         assert "s32" not in body and "s33" not in body           # s32 / s33 stay the compiler's
         assert '"v"(' not in text                                # every VGPR is the body's: no vector operand
