@@ -267,6 +267,11 @@ int64_t s2l_unet_work_floats(int height, int width, int64_t n_frames);
 int s2l_unet_pack(const float* const* tensors_host, float bn_eps, float* packed, s2l_stream_t stream);
 int s2l_unet_forward(const float* packed, const uint16_t* packed16, const float* x, float* work, float* out, int height,
                      int width, int64_t n_frames, s2l_stream_t stream);   /* packed16: NULL = exact fp32 (see s2l_unet_pack16 below) */
+/* The fp32 3x3 convolutions exist twice: as generated gfx950 assembly (csrc/gen_conv_body.py; the default wherever a launch has
+ * the shape it takes) and as the C++ kernel it replaced.  Both perform the same arithmetic in the same order: outputs, input
+ * gradients and weight gradients are bit-identical, which tests/test_gpu_unet_kernels.py checks over frame shapes by switching
+ * here.  kind: 0 = assembly where available, 1 = the C++ kernel everywhere.  Process-wide (an atomic), a validation aid. */
+int s2l_set_unet_conv_kernel(int kind);
 
 /* Training: the same network keeping every activation (saved: s2l_unet_saved_floats(H, W, F) floats), and
  * its INPUT gradient d_out [F,H,W,3] -> d_x [F,H,W,3] (work: s2l_unet_backward_work_floats(H, W, F) floats of scratch) -- what

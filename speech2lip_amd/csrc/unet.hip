@@ -697,8 +697,16 @@ __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
 
 // The assembly kernel takes the launch if it has the epilogue: A | B of equal width, an even number of 16-channel chunks,
 // per-frame byte offsets that fit 31 bits, and (bias + ReLU [+ pooling | + fused output]) or (no bias, no ReLU [+ gate]).
+static std::atomic<int> g_conv_kernel_kind{0};
+extern "C" int s2l_set_unet_conv_kernel(int kind) {
+  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+  g_conv_kernel_kind.store(kind, std::memory_order_relaxed);
+  return S2L_OK;
+}
+
 static int launch_conv_asm(ConvArgs& a, int64_t F, hipStream_t st, bool* launched) {
   *launched = false;
+  if (g_conv_kernel_kind.load(std::memory_order_relaxed) == 1) return S2L_OK;
   const bool fwd = a.bias && a.relu && !a.gate && !(a.out3 && a.pool) && (!a.out3 || a.cout == 64);
   const bool lin = !a.bias && !a.relu && !a.out3 && !a.pool && a.out;
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * F;

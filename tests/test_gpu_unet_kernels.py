@@ -1,0 +1,65 @@
+"""The U-Net's fp32 3x3 convolutions exist as generated gfx950 assembly (csrc/gen_conv_body.py: four tile-end variants) and as
+the C++ kernel it replaced (csrc/unet.hip conv3x3_kernel).  Parity with the reference network is tested on whichever runs
+(tests/test_gpu_parity.py, test_gpu_training_chain.py: goldens G7 / G13 and the oracle); here: both forms perform the same
+arithmetic in the same order, so every output, input gradient and weight gradient is the same bit pattern -- over frame shapes
+that hit the tile borders, single-tile frames, exact multiples of 16, fewer tiles than CUs and more, ragged pooled sizes."""
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from speech2lip_amd import _abi, weights as W
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 4, 4), (1, 5, 7), (2, 8, 8), (1, 15, 15), (1, 16, 16), (1, 17, 17), (3, 16, 48), (1, 31, 33), (1, 32, 32), (2, 33, 31),
+          (1, 47, 65), (1, 65, 63), (5, 20, 36), (2, 128, 130), (1, 257, 63), (1, 4, 200), (1, 200, 4), (7, 44, 52), (24, 40, 40),
+          (1, 500, 500)]
+
+
+@pytest.fixture(scope="module")
+def unet():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    dev = torch.device("cuda:0")
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
+    yield u
+    assert _abi.load().s2l_set_unet_conv_kernel(0) == 0
+
+
+def all_outputs(u, x, g):
+    res = {"eval": u.forward_nhwc(x)}
+    out, ctx = u.forward_saved_nhwc(x)
+    res["saved"], res["d_x"] = out, u.backward_input(ctx, g)
+    u.train()
+    try:
+        out, ctx = u.forward_train_nhwc(x, update_running=False)
+        dx, grads = u.backward_train(ctx, g)
+    finally:
+        u.eval()
+    res["train"], res["train_d_x"] = out, dx
+    res.update({"grad " + k: v for k, v in grads.items()})
+    return {k: v.clone() for k, v in res.items()}
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_assembly_and_cpp_convolutions_agree_bit_for_bit(unet, shape):
+    lib = _abi.load()
+    dev = next(unet.parameters()).device
+    x = torch.from_numpy(W.synthetic_image(shape + (3,), 11, "x")).to(dev)
+    g = torch.from_numpy(W.synthetic_image(shape + (3,), 12, "x")).to(dev) - 0.5
+    assert lib.s2l_set_unet_conv_kernel(0) == 0
+    a = all_outputs(unet, x, g)
+    assert lib.s2l_set_unet_conv_kernel(1) == 0
+    try:
+        b = all_outputs(unet, x, g)
+    finally:
+        assert lib.s2l_set_unet_conv_kernel(0) == 0
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["eval"].abs().max()) > 0 and float(a["d_x"].abs().max()) > 0
+
+
+def test_conv_kernel_switch_rejects_other_kinds():
+    assert _abi.load().s2l_set_unet_conv_kernel(2) == -2 and _abi.load().s2l_set_unet_conv_kernel(-1) == -2
