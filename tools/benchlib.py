@@ -144,6 +144,33 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
     return res
 
 
+def bench_unet(dev, F=16, H=500, Wd=500):
+    """Post-fusion U-Net at the reference's face frame: eval forward (what inference runs), and saved forward + input gradient
+    (the frozen net inside loss.backward()); 2 * 78.8 GMAC per frame and pass."""
+    import speech2lip_amd as s2l
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
+    x = torch.rand(F, H, Wd, 3, device=dev)
+    d = torch.randn(F, H, Wd, 3, device=dev)
+    out = torch.empty_like(x)
+    macs = 64 * 3 * H * Wd
+    for (name, cin, cout), s in zip(W.UNET_CONVS, (1, 1, 2, 2, 4, 4, 2, 2, 1, 1)):
+        macs += cin * cout * 9 * (H // s) * (Wd // s)
+
+    def fb():
+        o, ctx = u.forward_saved_nhwc(x)
+        u.backward_input(ctx, d)
+    res = {"config": f"SimpleUnetLight {H}x{Wd}, fp32 MFMA, {F} frames per call", "gflop_per_frame": round(2 * macs / 1e9, 2)}
+    for key, fn, passes in (("forward", lambda: u.forward_nhwc(x, out=out), 1), ("forward_plus_input_gradient", fb, 2)):
+        for _ in range(2):
+            fn()
+        ms = _median_ms(fn, reps=5, inner=1)
+        tf = passes * 2 * macs * F / (ms * 1e-3) / 1e12
+        res[key] = {"ms_per_frame": round(ms / F, 4), "frames_per_s": round(F / ms * 1e3, 1), "tflops": round(tf, 1),
+                    "frac_of_mfma_peak": round(tf / 157.3, 4)}
+    return res
+
+
 def warm_until_allocator_settles(fn, max_steps=8, min_steps=4, tol=1.25):
     """Run `fn` until a step is in steady state: at least `min_steps` steps, no new device allocation by torch's caching
     allocator during the step (a step that still calls hipMalloc for tens of GB is 5-10x slower), and a wall time within `tol`
