@@ -1728,8 +1728,12 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
       a.n_chunks = F * a.H * a.chunks_x;
       a.partial = wpart;
       const int tiles = (C / 64) * (cin / 16);
+      // split K so that ~2048 workgroups exist (8 per CU), as far as the partial buffer reaches: it holds 32 partials of the
+      // largest layer (256 x 128), i.e. 256 of a 64 x 64 one -- with a flat cap of 32 the two 64 -> 64 layers at full
+      // resolution ran on 128 workgroups (0.30 of the MFMA peak; 0.6 with this)
       int S = (int)((2048 + tiles - 1) / tiles);
-      if (S > 32) S = 32;
+      const int cap = (int)(32 * (int64_t)256 * 128 / ((int64_t)C * cin));
+      if (S > cap) S = cap;
       if (S > a.n_chunks) S = (int)a.n_chunks;
       hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
       const int64_t ne = (int64_t)C * cin * 9;
