@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 // channels, 16 input channels, all 9 taps), wave w owns output channels 16 w .. 16 w + 15 (9 accumulators of 4 registers).
 // K runs over chunks of 64 consecutive pixels of one image row; a chunk stages dz [64 px][64 co] and the 3 x 66-pixel halo of
 // the input [3][66][16 ci] in LDS.  The chunks are dealt round-robin to gridDim.z workgroups (split K); their partial results
-// are summed in a fixed order by wgrad_reduce3_kernel.
+// are summed in a fixed order by wgrad_reduce_wide_kernel.
 struct WgradArgs {
   const float* dz;     // [F,H,W,cout]
   const float* inA;    // [F,H,W,CA]
@@ -1252,20 +1252,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[((int64_t)(ct * 64 + 16 * wave + 4 * q + r) * cin + cc * 16 + i16) * 9 + t] = acc[t][r];
 }
-__global__ __launch_bounds__(256) void wgrad_reduce3_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
-                                                           int64_t n) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+// sum of the split-K partials in a fixed order: 64 elements per workgroup, four threads per element take every fourth partial
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
+                                                               int64_t n) {
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
   float s = 0.f;
-  for (int b = 0; b < n_parts; ++b) s += partial[(int64_t)b * n + e];
-  out[e] = s;
+  if (e < n)
+    for (int b = pl; b < n_parts; b += 4) s += partial[(int64_t)b * n + e];
+  red[pl][el] = s;
+  __syncthreads();
+  if (pl == 0 && e < n) out[e] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
 }
 // first convolution (3 input channels): partial[blk][co][c*9 + t]; thread = (co, pixel lane of 4)
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                               float* __restrict__ partial, int H, int W, int64_t n_pix,
                                                               int64_t per_block) {
   __shared__ float red[4][64 * 27];
-  const int co = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  // a wave = one pixel at a time, lane = output channel: the pixel index is wave-uniform (readfirstlane), so the 27 input values
+  // of its 3x3 neighbourhood are scalar loads and reach the FMAs as scalar operands (as 27 vector loads of one address each
+  // this kernel took 1.8 ms per 8 frames, 12x the time of its HBM traffic)
+  const int co = threadIdx.x & 63, pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
@@ -1720,7 +1728,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
       const int64_t perw = (p1 + 1023) / 1024;
       const int nbw = (int)((p1 + perw - 1) / perw);
       hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(nbw), dim3(256), 0, st, gy, x, wpart, H, W, p1, perw);
-      hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(64 * 27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
     } else {
       WgradArgs a;
       a.dz = gy; a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
@@ -1737,7 +1745,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
       if (S > a.n_chunks) S = (int)a.n_chunks;
       hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
       const int64_t ne = (int64_t)C * cin * 9;
-      hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(ne), dim3(256), 0, st, wpart, g, S, ne);
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, st, wpart, g, S, ne);
     }
   };
 
@@ -1746,7 +1754,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
     const int64_t perw = (p1 + 2047) / 2048;
     const int nbw = (int)((p1 + perw - 1) / perw);
     hipLaunchKernelGGL(outc_wgrad_kernel, dim3(nbw), dim3(256), 0, st, d_out, b.act[9], wpart, p1, perw);
-    hipLaunchKernelGGL(wgrad_reduce3_kernel, blocks(195), dim3(256), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(4), dim3(256), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);
   }
   hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, t.outw, b.act[9], zA, p1 * 16);
   layer_grads(9, zA);
