@@ -668,11 +668,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
 }
 
 // out[i] = sum over the parts in a fixed order: 64 float4 columns per block, the parts split over the block's 4 waves
-// (each sums its quarter in part order), then the four partial sums are added in wave order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts) {
+// (each sums its quarter in part order), then the four partial sums are added in wave order.  A second, small tensor (the bias
+// gradient's partials) rides in the same launch: the blocks behind the first tensor's take it.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts,
+                                                          const float* __restrict__ part2, float* __restrict__ out2, int n2) {
   __shared__ f4 red[4][64];
   const int col = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = (blockIdx.x * 64 + col) * 4;
+  const int nb1 = (n / 4 + 63) / 64;
+  int blk = blockIdx.x;
+  if (blk >= nb1) {     // (block-uniform)
+    blk -= nb1;
+    part = part2; out = out2; n = n2;
+  }
+  const int i = (blk * 64 + col) * 4;
   f4 s = f4{0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     const int per = (parts + 3) / 4;
@@ -889,8 +897,8 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
   else
     hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(parts), dim3(256), WgCfg<128>::kLds, st, dzT, inT, work, bpart, n_tiles);
   const int n = 256 * k_in;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, st, work, dw, n, parts);
-  if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, st, bpart, db, 256, parts);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 63) / 64 + (db ? 1 : 0)), dim3(256), 0, st, work, dw, n, parts,
+                     (const float*)bpart, db, 256);
   return (int)hipGetLastError();
 }
 
@@ -916,7 +924,8 @@ extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* 
   hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_groups, n_rows);
   // parts x [772] -> [768] + [4]: reduce into a scratch row behind the partials, then split
   float* sum = work + (int64_t)kWgParts * 772;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts, (const float*)nullptr,
+                     (float*)nullptr, 0);
   (void)hipMemcpyAsync(dwout, sum, 768 * sizeof(float), hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(dbout, sum + 768, 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   return (int)hipGetLastError();
