@@ -52,8 +52,8 @@ constexpr int kWgRows = 256;       // rows per workgroup tile of the forward / b
 __host__ __device__ constexpr int64_t image_off(int64_t group, int n_blocks, int R, int lane) {   // in halves
   return ((group * n_blocks + R) * 64 + lane) * 16;
 }
-// ReLU masks: uint64 [layer 8][64-row tile][R 8][32]: entry 16*g + r = ballot of (h > 0) over the lanes of the wave that owns
-// rows 32g..32g+31 of the tile, for accumulator register r
+// ReLU masks: uint32 [layer 8][group of 32 rows][stage q 4][lane n + 32 hh]: the lane's 32 values of the stage (blocks 2q, 2q + 1)
+// are 16 bf16 pairs d = 8 which + 2 a + p; bit 15 - d = (low half of pair d is non-zero), bit 31 - d = (high half is)
 
 }  // namespace b16
 }  // namespace s2l

@@ -4,13 +4,14 @@
 // activations and saved gradients are bf16, which makes every one of these kernels HBM-bound instead of MFMA-bound
 // (9.7 GB of saved state per direction for 64 frames at 96x96 instead of 38 GB).
 //
-// Layouts: s2l_bf16.h.  A workgroup (4 waves, one per SIMD) owns 256 rows of the batch; a wave owns 64 (two groups of 32
-// = two B operands per A read).  A layer's weights pass through LDS in four 2-block stages; the next stage's global loads
-// are in flight in registers while the current one computes (one barrier per stage).  Activations stay in registers
-// between layers (kfeat16 trick); per 32-feature block the epilogue adds bias, applies ReLU, records the ReLU bit masks
-// (64-bit ballots, 32 B per row per layer) and converts to bf16; the eight dwords a lane then holds ARE its next-layer B
-// operands, and they are stored as they are (two 16-byte stores per lane, 2 KiB contiguous per wave and block): the
-// weight-gradient GEMM reads these row-major images back with the LDS transpose read (ds_read_b64_tr_b16).
+// Layouts: s2l_bf16.h.  A workgroup (8 waves, two per SIMD: one wave's epilogue runs next to the other's MFMAs) owns 256 rows
+// of the batch, a wave 32.  A layer's weights pass through LDS in four 2-block stages; the next stage's global loads are in
+// flight in registers while the current one computes (one barrier per stage).  Activations stay in registers between layers
+// (kfeat16 trick); per 32-feature block the epilogue (bias = the accumulators' initial value) converts to bf16, applies ReLU
+// and extracts its mask on the packed pairs (relu_pk / nz01_pk below: one mask dword per lane and stage, 32 B per row and
+// layer); the eight dwords a lane then holds ARE its next-layer B operands, and they are stored as they are (two 16-byte
+// stores per lane, 2 KiB contiguous per wave and block): the weight-gradient GEMM reads these row-major images back with the
+// LDS transpose read (ds_read_b64_tr_b16).
 #include "s2l_common.h"
 #include "s2l_bf16.h"
 
@@ -42,6 +43,31 @@ __device__ __forceinline__ uint16_t bf1(float x) { return __builtin_bit_cast(uin
 __device__ __forceinline__ f16v mfma32(u4 a, u4 b, f16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
+
+// ReLU and its mask on PACKED bf16 pairs -- no compare / ballot / lane broadcast, i.e. no VALU -> SGPR -> VALU round trip (the
+// v_cmp + two v_writelane per value of the first version cost ~60 cycles per value, 2 000 per stage):
+//   relu_pk:  max as signed 16-bit integers with 0 (a negative bf16, -0 included, is a negative int16): bf16(relu(x)) exactly,
+//             since rounding keeps the sign;
+//   nz01_pk:  min as unsigned 16-bit integers with 1: 1 where the half is non-zero (= the ReLU passed), else 0;
+//   mul01_pk: halves times 0 / 1 as unsigned 16-bit integers: keeps or clears a bf16 bit pattern.
+// A lane's 32 values of a stage (two 32-feature blocks) are 16 dwords d = 8 which + 2 a + p (halves c = 2p, 2p + 1); their mask
+// is ONE dword per lane: bit 15 - d for the low half of dword d, bit 31 - d for the high half (built by 16 x "shift left, or").
+__device__ __forceinline__ uint32_t relu_pk(uint32_t x) {
+  uint32_t o;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(o) : "v"(x));
+  return o;
+}
+__device__ __forceinline__ uint32_t nz01_pk(uint32_t x) {
+  uint32_t o;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(o) : "v"(x), "s"(0x00010001u));
+  return o;
+}
+__device__ __forceinline__ uint32_t mul01_pk(uint32_t x, uint32_t m01) {
+  uint32_t o;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(x), "v"(m01));
+  return o;
+}
+__device__ __forceinline__ uint32_t mask01_of(uint32_t mword, int d) { return (mword >> (15 - d)) & 0x00010001u; }
 
 // K loop of TWO 32-row output blocks (independent accumulators) against one B operand set: the A quads are read from LDS
 // S2L_KDEPTH - 1 k-steps ahead into rotating registers; the sched_barrier pins that order.
@@ -256,38 +282,28 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
           kloop2<16>(reinterpret_cast<const u4*>(wl + 2 * kSlabX) + lane, reinterpret_cast<const u4*>(wl + 2 * kSlabX + kSlabH) + lane,
                      bcur, acc[0], acc[1]);
         T16(1);
-        // epilogue: ReLU, masks, bf16.  The 32 ballots of the two blocks (64 dwords) are collected one dword per lane with
-        // v_writelane: lane 32 which + 2 r + half holds that half of ballot r of block `which`.
-        int mword = 0;
+        // epilogue: bf16, ReLU and the mask dword on packed pairs (relu_pk / nz01_pk above)
+        uint32_t mword = 0;
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
           const int R = 2 * q + which;
           uint32_t vals[4][2];
 #pragma unroll
           for (int a4 = 0; a4 < 4; ++a4) {
-            float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              v[c] = fmaxf(acc[which][4 * a4 + c], 0.f);
-              if (!(S2L_EXP & 2)) {
-                const uint64_t b = __ballot(v[c] > 0.f);
-                const int r = 4 * a4 + c;
-                // s_nop: gfx940+ needs 2 wait states between a VALU write of an SGPR (the compare) and a VALU read of it;
-                // the compiler's hazard recogniser does not look inside inline asm
-                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(mword) : "s"((uint32_t)b), "n"(32 * which + 2 * r));
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(mword) : "s"((uint32_t)(b >> 32)), "n"(32 * which + 2 * r + 1));
-              }
+            for (int p2 = 0; p2 < 2; ++p2) {
+              const uint32_t v = relu_pk(pk2(acc[which][4 * a4 + 2 * p2], acc[which][4 * a4 + 2 * p2 + 1]));
+              if (!(S2L_EXP & 2)) mword = (mword << 1) | nz01_pk(v);
+              vals[a4][p2] = v;
             }
-            vals[a4][0] = pk2(v[0], v[1]);
-            vals[a4][1] = pk2(v[2], v[3]);
           }
           bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
           bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
           if (!(S2L_EXP & 1))
             image_store(vals, a.hT + L * a.layer_stride + image_off(group, 8, R, 0), lane);
         }
-        if (!(S2L_EXP & 2))   // uint64 index R*32 + 16g + r  ->  dword index 2*(...) + half
-          reinterpret_cast<int*>(a.masks + L * a.mask_layer_stride + tile64 * 256 + (2 * q + (lane >> 5)) * 32 + 16 * g)[lane & 31] = mword;
+        if (!(S2L_EXP & 2))   // dword (layer, 32-row group, stage, lane)
+          reinterpret_cast<uint32_t*>(a.masks + L * a.mask_layer_stride)[group * 256 + q * 64 + lane] = mword;
         if (s == 31) {  // output layer on h7 (= bnext), weights in the X part of this stage; rows 0..2 of block 0
           f16v ao;
 #pragma unroll
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
 // ---- backward dz chain ------------------------------------------------------------------------------------------------------
 // g_7 = (Wout^T drgb) . m_7;  g_{l-1} = (W_l^T g_l) . m_{l-1} for l = 7..1 (l = 5: the h_4 half of pts_linears[5]);
 // d audio = G5[:, audio]^T g_5 + G0[:, audio]^T g_0.  Every g_l is stored as a [feature][64 rows] bf16 tile (dzT) for the
-// weight-gradient GEMMs; the masks are the forward's ballots, read back as wave-uniform SGPR pairs (one v_cndmask per value).
+// weight-gradient GEMMs; the masks are the forward's per-lane mask dwords, applied to the packed bf16 pairs (mul01_pk).
 constexpr int kLdsBwdW = 2 * kStageB * 2;
 constexpr int kLdsBwd = kLdsBwdW + 8 * kSlabU0 * 2;
 
@@ -329,32 +345,13 @@ struct BwdArgs {
   int n_tiles;
 };
 
-__device__ __forceinline__ float mask_sel(float v, uint64_t m) {
-  float o;
-  // s_nop: the mask reaches its SGPR pair through v_readlane (a VALU write); gfx940+ wants two wait states before a VALU
-  // reads it, and the hazard recogniser does not look inside inline asm
-  asm("s_nop 1\n\tv_cndmask_b32 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
-  return o;
-}
-
-// masked gradient block -> bf16 pairs; mrow = the 16 ballots of this (layer, 64-row tile, R, wave of the pair): one load,
-// then each word is broadcast into an SGPR pair with v_readlane
-__device__ __forceinline__ void mask_block(const f16v& acc, const uint64_t* __restrict__ mrow, int lane, uint32_t (&vals)[4][2]) {
-  const uint64_t mv = mrow[lane & 15];
-  const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
+// masked gradient block -> bf16 pairs; mword = this lane's mask dword of the stage the block belongs to (block `which` of it)
+__device__ __forceinline__ void mask_block(const f16v& acc, uint32_t mword, int which, uint32_t (&vals)[4][2]) {
 #pragma unroll
-  for (int a4 = 0; a4 < 4; ++a4) {
-    float v[4];
+  for (int a4 = 0; a4 < 4; ++a4)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int idx = 4 * a4 + c;
-      const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mlo, idx) |
-                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, idx) << 32);
-      v[c] = mask_sel(acc[4 * a4 + c], m);
-    }
-    vals[a4][0] = pk2(v[0], v[1]);
-    vals[a4][1] = pk2(v[2], v[3]);
-  }
+    for (int p2 = 0; p2 < 2; ++p2)
+      vals[a4][p2] = mul01_pk(pk2(acc[4 * a4 + 2 * p2], acc[4 * a4 + 2 * p2 + 1]), mask01_of(mword, 8 * which + 2 * a4 + p2));
 }
 
 __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
@@ -393,6 +390,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
       b0 = u4{pk2(d0, d1), pk2(d2, 0.f), 0u, 0u};
     }
     // U0: g_7
+    uint32_t m7 = 0;
 #pragma unroll
     for (int R = 0; R < 8; ++R) {
       f16v acc;
@@ -400,7 +398,8 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       acc = mfma32(u0[R * 64 + lane], b0, acc);
       uint32_t vals[4][2];
-      mask_block(acc, a.masks + 7 * a.mask_layer_stride + tile64 * 256 + R * 32 + 16 * g, lane, vals);
+      if (!(R & 1)) m7 = reinterpret_cast<const uint32_t*>(a.masks + 7 * a.mask_layer_stride)[group * 256 + (R >> 1) * 64 + lane];
+      mask_block(acc, m7, R & 1, vals);
       bcur[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
       bcur[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
       image_store(vals, a.dzT + 7 * a.layer_stride + image_off(group, 8, R, 0), lane);
@@ -441,18 +440,13 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
     // stage's k-loops and the last stage's epilogue of a layer run alone (the next layer needs all 256 outputs).
     for (int l = 7; l >= 1; --l) {   // W_l^T g_l -> g_{l-1}
       f16v accs[2][2];
-      const uint64_t* mbase = a.masks + (l - 1) * a.mask_layer_stride + tile64 * 256 + 16 * g;
+      const uint32_t* mbase = reinterpret_cast<const uint32_t*>(a.masks + (l - 1) * a.mask_layer_stride) + group * 256 + lane;
       uint16_t* dbase = a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, 0, 0);
       uint32_t pv[2][4][2];          // bf16 pairs of the stage whose epilogue is in flight
-      uint32_t pmlo[2], pmhi[2];     // its two mask rows (lane r holds ballot r)
-      float hold[2];
-      // one value (register r of block `which`) of the pending epilogue
-      auto slice_of = [&](const f16v (&accp)[2], int which, int r) {
-        const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(pmlo[which], r) |
-                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(pmhi[which], r) << 32);
-        const float v = mask_sel(accp[which][r], m);
-        if (r & 1) pv[which][r >> 2][(r >> 1) & 1] = pk2(hold[which], v);
-        else hold[which] = v;
+      uint32_t pm = 0;               // this lane's mask dword of that stage
+      // one pair (registers 2 j, 2 j + 1 of block `which`) of the pending epilogue
+      auto slice_of = [&](const f16v (&accp)[2], int which, int j) {
+        pv[which][j >> 1][j & 1] = mul01_pk(pk2(accp[which][2 * j], accp[which][2 * j + 1]), mask01_of(pm, 8 * which + j));
       };
       auto finish = [&](int qp) {    // bnext entries and image stores of stage qp
 #pragma unroll
@@ -463,13 +457,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
           image_store(pv[which], dbase + image_off(0, 8, R, 0), lane);
         }
       };
-      auto load_masks = [&](int qp) {
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-          const uint64_t mv = mbase[(2 * qp + which) * 32 + (lane & 15)];
-          pmlo[which] = (uint32_t)mv, pmhi[which] = (uint32_t)(mv >> 32);
-        }
-      };
+      auto load_masks = [&](int qp) { pm = mbase[qp * 64]; };
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nxt = next_of(u);
@@ -483,19 +471,16 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
           for (int r = 0; r < 16; ++r) acc[w2][r] = 0.f;
         if (q > 0) load_masks(q - 1);
         kloop2e<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc[0], acc[1],
-                    [&](int t) {
-                      if (q > 0) {
-                        slice_of(accp, 0, t);
-                        slice_of(accp, 1, t);
-                      }
+                    [&](int t) {      // 16 pairs over the 16 k-steps
+                      if (q > 0) slice_of(accp, t >> 3, t & 7);
                     });
         if (q > 0) finish(q - 1);
         if (q == 3) {                // this layer's last stage: its own epilogue now
           load_masks(3);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            slice_of(acc, 0, r);
-            slice_of(acc, 1, r);
+          for (int j = 0; j < 8; ++j) {
+            slice_of(acc, 0, j);
+            slice_of(acc, 1, j);
           }
           finish(3);
         }

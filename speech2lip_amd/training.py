@@ -248,7 +248,7 @@ class Trainer:
 # ----------------------------------------------------------------------------------------------------------------------
 class MlpState:
     """What one forward of the MLP leaves behind for its backward: fp32 mode x [N,128] + hsave [8,N,256]; bf16 mode the
-    operand image xT, the activation images hT and the ReLU ballots."""
+    operand image xT, the activation images hT and the ReLU mask words."""
 
     def __init__(self, precision, N, dev, lib):
         self.precision, self.N = precision, N

@@ -18,16 +18,20 @@ def tiles_to_rows(img_i16: torch.Tensor, n_layers: int, np_rows: int, feats: int
 
 
 def masks_to_rows(masks_i64: torch.Tensor, np_rows: int) -> torch.Tensor:
-    """uint64 ballots [8][np/64][R 8][g*16 + r] -> bool [8][np][256] (bit lane = 32*hh + n)."""
-    m = masks_i64.cpu().numpy().view(np.uint64).reshape(8, np_rows // 64, 8, 2, 16)
-    bits = ((m[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool)     # [8,T,R,g,r,lane]
-    out = np.zeros((8, np_rows // 64, 64, 256), dtype=bool)
-    for R in range(8):
-        for r in range(16):
-            for hh in range(2):
-                f = 32 * R + 8 * (r >> 2) + 4 * hh + (r & 3)
-                for g in range(2):
-                    out[:, :, 32 * g:32 * g + 32, f] = bits[:, :, R, g, r, 32 * hh:32 * hh + 32]
+    """ReLU mask dwords [8 layers][np/32 groups][4 stages][64 lanes = n + 32 hh] (csrc/train_bf16.hip: bit 15 - d = low half of
+    the lane's dword d of the stage, bit 31 - d = its high half, d = 8 which + 2 a + p, halves c = 2p, 2p + 1) -> bool
+    [8][np][256], feature 32 (2 q + which) + 8 a + 4 hh + c of row 32 group + n."""
+    m = masks_i64.cpu().numpy().view(np.uint32).reshape(8, np_rows // 32, 4, 2, 32)            # L, G, q, hh, n
+    out = np.zeros((8, np_rows // 32, 32, 256), dtype=bool)
+    for q in range(4):
+        for which in range(2):
+            for a in range(4):
+                for p in range(2):
+                    d = 8 * which + 2 * a + p
+                    for half in range(2):
+                        bit = ((m[:, :, q] >> np.uint32((31 if half else 15) - d)) & np.uint32(1)).astype(bool)   # L, G, hh, n
+                        for hh in range(2):
+                            out[:, :, :, 32 * (2 * q + which) + 8 * a + 4 * hh + 2 * p + half] = bit[:, :, hh, :]
     return torch.from_numpy(out.reshape(8, np_rows, 256))
 
 
