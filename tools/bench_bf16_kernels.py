@@ -8,13 +8,15 @@ import speech2lip_amd as s2l
 from speech2lip_amd import _abi, weights as W
 from speech2lip_amd.talking_face import _ptr, _stream
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+_args = [x for x in sys.argv[1:] if not x.startswith("--")]
+B = int(_args[0]) if _args else 64
 dev = torch.device("cuda:0")
 m = s2l.TalkingFace(dev, s2l.may_config(96, 96)).eval()
 m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
 lib = _abi.load()
 N = 4 * 96 * 96 * B
 Np = int(lib.s2l_bf16_rows_padded(N)); lay = Np * 256
+torch.manual_seed(0)
 x = torch.randn(N, 128, device=dev) * 0.5
 xT = torch.empty(Np * 128, dtype=torch.int16, device=dev)
 lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, _stream())
@@ -37,6 +39,11 @@ def timed(fn, it=5):
 tf = timed(lambda: lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()))
 tb = timed(lambda: lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()))
 tw = timed(lambda: lib.s2l_wgrad_bf16(_ptr(dzT[3 * lay:]), _ptr(hT[2 * lay:]), 256, _ptr(work), _ptr(dw), _ptr(db), N, _stream()))
+if "--digest" in sys.argv:      # A/B aid: two builds with the same arithmetic print the same digests
+    import hashlib
+    torch.cuda.synchronize()
+    hsh = lambda x: hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()[:12]
+    print("digests: hT", hsh(hT), "masks", hsh(masks), "rgb", hsh(rgb), "dzT", hsh(dzT), "dxa", hsh(dxa), "dw", hsh(dw), "db", hsh(db))
 gb = 8 * lay * 2 / 1e9
 print(f"{os.environ.get('S2L_LIB', 'default'):28s} rows {N}: forward {tf:.3f} ms ({gb / tf * 1e3:.0f} GB/s of tiles written), "
       f"backward {tb:.3f} ms, one wgrad {tw:.3f} ms ({2 * lay * 2 / 1e9 / tw * 1e3:.0f} GB/s read)")
