@@ -44,6 +44,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         gen_render_body.main(os.path.join(objdir, "render_body.inc"))
         import gen_conv_body               # ... and so are the U-Net's fp32 3x3 convolutions (unet.hip)
         gen_conv_body.main(objdir)
+        import gen_fwd16_body              # ... and the bf16 training forward (train_bf16.hip)
+        gen_fwd16_body.main(objdir)
     finally:
         sys.path.pop(0)
     procs = []

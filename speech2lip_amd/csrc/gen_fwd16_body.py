@@ -1,0 +1,529 @@
+"""Generates fwd16_body.inc: the body of s2l::b16::fwd_asm_bf16_kernel (csrc/train_bf16.hip) as ONE fixed-register gfx950 assembly
+text -- the bf16 training forward with 64 rows per wave, one wave per SIMD.
+
+Why assembly: inside one wave nothing overlaps (MFMAs, the VALU epilogue, a burst of stores, the stage DMA simply
+add up), so the schedule has to be owned: every memory instruction rides behind an MFMA, the k-steps carry nothing but two LDS
+reads and four MFMAs, and the two activation sets are pinned to the two register halves.  Same arithmetic in the same order as
+fwd_bf16_kernel: activation images, mask dwords and rgb are bit-identical.
+
+  * workgroup = 4 waves = 256 rows; wave w owns row groups g0 = 8 tile + 2 w and g0 + 1 (32 rows each, nb = 0, 1): an A quad
+    (weights) read from LDS feeds TWO MFMAs -- half the LDS traffic per MFMA of the 32-row kernel;
+  * stage = a quarter layer (output blocks R = 2q, 2q + 1): [X slab R0][X slab R1][H slab R0][H slab R1] (s2l_bf16.h), 48 KiB, by
+    LDS-DMA into one of two buffers, the next stage's twelve 1-KiB instructions one behind every third MFMA;
+  * accumulators acc[which][nb] in VGPRs, their first MFMA takes the bias quads (read from LDS during the stage before) as C;
+  * activation sets: P in VGPRs 0..127, Q in AGPRs 0..127 ([nb][k-step 16][4]); a layer reads one and writes the other
+    (layer 0 writes P; odd layers write Q through v_accvgpr_write); the embedded rows bx live in AGPRs 128..191 and are
+    prefetched for the next tile during layer 6;
+  * epilogue per pair: v_cvt_pk_bf16_f32, v_pk_max_i16 (ReLU), v_pk_min_u16 + v_lshl_or_b32 (mask bit): 4 VALU per two values;
+  * the images of a stage are stored behind the MFMAs of the NEXT stage (16 B per lane and clock is all the store path takes).
+
+Layer bodies: A (layer 0: x only, -> P), B (h from P -> Q: layers 1, 3, 7), C (h from Q -> P: 2, 4, 6), D (layer 5: x + h from P ->
+Q); four stages each, sequenced by a scalar layer counter."""
+import os
+import sys
+
+EXP = int(os.environ.get("S2L_FWD_EXP", "0"))      # timing experiments (results wrong): 1 no image stores, 2 no epilogue VALU, 4 no MFMAs, 8 no stage DMA, 16 no barrier
+SLAB_H, SLAB_X = 16384, 8192            # bytes
+STAGE = 2 * SLAB_X + 2 * SLAB_H         # 49152
+LDS_W = 2 * STAGE                       # bias block behind the two stage buffers: [8][256] floats + bout[4]
+EVERY = 3
+
+# ---- vector registers
+V_P = 0                        # 128: activation set P [nb][t][4]
+V_ACC = 128                    # 64: acc[(which * 2 + nb) * 16 + r]
+V_BIAS = 192                   # 32: bias regs [which][16] of the stage being computed (srcC of its first MFMAs)
+V_LANE16, V_LANE32, V_LANE32B, V_LANE4, V_DMAOFF = 224, 225, 226, 227, 228
+V_AX = (229, 230)              # LDS address of this lane's A quads, X part of buffer 0 / 1
+V_AH = (231, 232)              # ... H part
+V_BIAS0 = 233                  # LDS address of the bias block + 16 hh
+V_BN = 234                     # ... + 1024 * layer of the stage whose bias is read next
+V_RGBOFF = (235, 236)          # byte offset of this lane's row (nb) in rgb, relative to the tile's first row
+V_M = (237, 238)               # mask dwords being built
+V_T = 240                      # temporaries 240..251 (quads at 240, 244, 248)
+V_LAST = 251
+# ---- accumulation registers
+A_Q = 0                        # 128: activation set Q
+A_BX = 128                     # 64: embedded rows [nb][t 8][4]
+NSLOT = int(os.environ.get("S2L_FWD_NSLOT", "5"))   # A-quad slots: reads run NSLOT - 1 k-steps ahead of their MFMAs
+A_A = 192                      # 8 NSLOT: A quads [slot][which 2][4]
+A_LAST = A_A + 8 * NSLOT - 1
+assert A_LAST <= 255
+
+
+def _scalar_map(first, singles, pairs, skip=(32, 33)):
+    m, r = {}, first
+    for n in pairs:
+        while (r & 1) or r in skip or (r + 1) in skip:
+            r += 1
+        m[n], m[n + "1"] = r, r + 1
+        r += 2
+    for n in singles:
+        while r in skip:
+            r += 1
+        m[n] = r
+        r += 1
+    return m
+
+
+S = _scalar_map(8,
+                singles="LDSB WAVE TILE NTILES GRID L ST T0 T1 T2 T3 NX NH ONE PENDOK BXF MDST G0 NROWS".split(),
+                pairs=("KARG", "WB", "XT", "HT", "MASKS", "RGB", "LSTR", "MSTR", "WP", "HTL", "MKL", "PEND", "XTN", "XTA", "EX"))
+S_LAST = max(S.values())
+assert S_LAST <= 95, S_LAST
+
+
+def s(n):
+    return f"s{S[n]}"
+
+
+def s2(n):
+    return f"s[{S[n]}:{S[n] + 1}]"
+
+
+def vq(b):
+    return f"v[{b}:{b + 3}]"
+
+
+def aq(b):
+    return f"a[{b}:{b + 3}]"
+
+
+class Body:
+    def __init__(self):
+        self.L, self.lds, self.nlabel = [], [], 0
+
+    def e(self, t):
+        self.L.append(t)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"S2LF_{stem}_{self.nlabel}"
+
+    def lds_op(self, text, tag):
+        self.e(text)
+        self.lds.append(tag)
+
+    def wait_lds(self, tag):
+        if tag not in self.lds:
+            return
+        newer = min(15, len(self.lds) - 1 - self.lds.index(tag))      # (the counter has four bits: waiting for fewer is stricter)
+        self.e(f"s_waitcnt lgkmcnt({newer})")
+        self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    def wait_all_lds(self):
+        if self.lds:
+            self.e("s_waitcnt lgkmcnt(0)")
+            self.lds = []
+
+    # ------------------------------------------------------------------ registers
+    @staticmethod
+    def acc(which, nb):
+        b = V_ACC + (which * 2 + nb) * 16
+        return f"v[{b}:{b + 15}]"
+
+    @staticmethod
+    def setreg(setname, nb, t):
+        """B operand quad of k-step t of row group nb in set P (VGPR) / Q (AGPR) / X (bx, AGPR)"""
+        if setname == "P":
+            return vq(V_P + nb * 64 + t * 4)
+        if setname == "Q":
+            return aq(A_Q + nb * 64 + t * 4)
+        return aq(A_BX + nb * 32 + t * 4)
+
+    # ------------------------------------------------------------------ per-stage scalar set-up
+    def stage_setup(self, q):
+        """next stage: WP = its global address, MDST = LDS address of this wave's part of the other buffer, NX / NH"""
+        e = self.e
+        e(f"s_add_u32 {s('T0')}, {s('ST')}, 1")
+        e(f"s_and_b32 {s('T0')}, {s('T0')}, 31")
+        e(f"s_mul_i32 {s('T1')}, {s('T0')}, {STAGE}")
+        e(f"s_add_u32 {s('WP')}, {s('WB')}, {s('T1')}")
+        e(f"s_addc_u32 {s('WP1')}, {s('WB1')}, 0")
+        e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10")
+        e(f"s_add_u32 {s('T1')}, {s('T1')}, {((q + 1) & 1) * STAGE}")
+        e(f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}")
+        e(f"s_lshr_b32 {s('T1')}, {s('T0')}, 2")                   # layer of the next stage
+        e(f"s_cmp_lg_u32 {s('T1')}, 0")
+        e(f"s_cselect_b32 {s('NH')}, 1, 0")
+        e(f"s_cmp_eq_u32 {s('T1')}, 0")
+        e(f"s_cselect_b32 {s('NX')}, 1, 0")
+        e(f"s_cmp_eq_u32 {s('T1')}, 5")
+        e(f"s_cselect_b32 {s('NX')}, 1, {s('NX')}")
+        e(f"s_cmp_eq_u32 {s('T0')}, 31")
+        e(f"s_cselect_b32 {s('NX')}, 1, {s('NX')}")
+        # bias of the next stage: layer T1, blocks 2 (q + 1) & 7 ...
+        e(f"s_lshl_b32 {s('T1')}, {s('T1')}, 10")
+        e(f"v_add_u32 v{V_BN}, {s('T1')}, v{V_BIAS0}")
+
+    def dma_items(self):
+        items = []
+        for k in range(12):
+            flag = "NX" if k < 4 else "NH"
+            skip = self.label("nodma")
+            items.append([f"s_mov_b32 m0, {s('MDST')}",
+                          f"s_cmp_eq_u32 {s(flag)}, 0",
+                          f"s_cbranch_scc1 {skip}",
+                          None if EXP & 8 else f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}",
+                          f"{skip}:",
+                          f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096",
+                          f"s_add_u32 {s('WP')}, {s('WP')}, 4096",
+                          f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"])
+        return items
+
+    def store_items(self, setname, qprev, guarded):
+        """the eight image stores of the stage before (blocks 2 qprev, 2 qprev + 1 of `setname`) at PEND"""
+        items = []
+        for nb in range(2):
+            for which in range(2):
+                for half in range(2):
+                    t = 2 * (2 * qprev + which) + half
+                    src = self.setreg(setname, nb, t)
+                    it = []
+                    skip = self.label("nostore")
+                    if guarded:
+                        it += [f"s_cmp_eq_u32 {s('PENDOK')}, 0", f"s_cbranch_scc1 {skip}"]
+                    if not EXP & 1:
+                        it.append(f"global_store_dwordx4 v{V_LANE32B if nb else V_LANE32}, {src}, {s2('PEND')} offset:{which * 2048 + half * 16}")
+                    if guarded:
+                        it.append(f"{skip}:")
+                    items.append(it)
+        return items
+
+    def bx_items(self, half):
+        """embedded rows of the NEXT tile -> bx (AGPRs), eight loads per call; only in layer 6 and if there is a next tile (BXF)"""
+        items = []
+        for k in range(8 * half, 8 * half + 8):
+            nb, t = k >> 3, k & 7
+            skip = self.label("nobx")
+            items.append([f"s_cmp_eq_u32 {s('BXF')}, 0", f"s_cbranch_scc1 {skip}",
+                          f"s_add_u32 {s('XTA')}, {s('XTN')}, {nb * 8192 + (t >> 1) * 2048}",
+                          f"s_addc_u32 {s('XTA1')}, {s('XTN1')}, 0",
+                          f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE32}, {s2('XTA')} offset:{(t & 1) * 16}",
+                          f"{skip}:"])
+        return items
+
+    # ------------------------------------------------------------------ k-loop of a stage
+    def kloop(self, buf, parts, items, every=EVERY, lds_after=None):
+        """parts: list of (part 'x' | 'h', set name of the B operands); A quads through three AGPR slots two k-steps ahead;
+        the first MFMA of each accumulator takes the bias registers as C.  `items`: instruction groups, one behind every
+        `every`-th MFMA; lds_after = (n, [(text, tag)]): LDS operations issued behind MFMA n (through the tracker)."""
+        e = self.e
+        steps = []
+        for part, setname in parts:
+            for t in range(8 if part == "x" else 16):
+                steps.append((part, setname, t))
+
+        def read(i):
+            part, _, t = steps[i]
+            base = (V_AX if part == "x" else V_AH)[buf]
+            slab = SLAB_X if part == "x" else SLAB_H
+            for which in range(2):
+                dst = A_A + ((i % NSLOT) * 2 + which) * 4
+                self.lds_op(f"ds_read_b128 {aq(dst)}, v{base} offset:{which * slab + t * 1024}", ("A", i, which))
+        for i in range(min(NSLOT - 1, len(steps))):
+            read(i)
+        pending = list(items)
+        nmf = 0
+        for i, (part, setname, t) in enumerate(steps):
+            if i + NSLOT - 1 < len(steps):
+                read(i + NSLOT - 1)
+            self.wait_lds(("A", i, 1))
+            for which in range(2):
+                a = aq(A_A + ((i % NSLOT) * 2 + which) * 4)
+                for nb in range(2):
+                    c = self.acc(which, nb)
+                    srcc = f"v[{V_BIAS + which * 16}:{V_BIAS + which * 16 + 15}]" if i == 0 else c
+                    bsrc = self.setreg("X" if part == "x" else setname, nb, t)
+                    if not EXP & 4:
+                        e(f"v_mfma_f32_32x32x16_bf16 {c}, {a}, {bsrc}, {srcc}")
+                    nmf += 1
+                    if lds_after and nmf == lds_after[0]:
+                        for text, tag in lds_after[1]:
+                            self.lds_op(text, tag)
+                    if pending and nmf % every == 0:
+                        for x in pending.pop(0):
+                            if x is not None:
+                                e(x)
+        while pending:
+            for x in pending.pop(0):
+                if x is not None:
+                    e(x)
+
+    def bias_reads(self, qnext):
+        """bias quads of the NEXT stage (blocks 2 qnext, 2 qnext + 1 of the layer V_BN points at) -> V_BIAS, as (text, tag)"""
+        out = []
+        for which in range(2):
+            for a4 in range(4):
+                out.append((f"ds_read_b128 {vq(V_BIAS + which * 16 + a4 * 4)}, v{V_BN} offset:{(2 * qnext + which) * 128 + a4 * 32}",
+                            ("bias", which, a4)))
+        return out
+
+    # ------------------------------------------------------------------ epilogue of a stage
+    def epilogue(self, q, outset):
+        e = self.e
+        e("s_nop 7")
+        e("s_nop 7")
+        e("s_nop 7")
+        for nb in range(2):
+            e(f"v_mov_b32 v{V_M[nb]}, 0")
+        for nb in range(2):
+            for which in range(2):
+                R = 2 * q + which
+                for d8 in range(0 if EXP & 2 else 8):
+                    src = V_ACC + (which * 2 + nb) * 16 + 2 * d8
+                    dst = nb * 64 + (2 * R + (d8 >> 2)) * 4 + (d8 & 3)
+                    d = f"v{V_P + dst}" if outset == "P" else f"v{V_T + (d8 & 3)}"
+                    e(f"v_cvt_pk_bf16_f32 {d}, v{src}, v{src + 1}")
+                    e(f"v_pk_max_i16 {d}, {d}, 0")
+                    e(f"v_pk_min_u16 v{V_T + 4 + (d8 & 3)}, {d}, {s('ONE')}")
+                    e(f"v_lshl_or_b32 v{V_M[nb]}, v{V_M[nb]}, 1, v{V_T + 4 + (d8 & 3)}")
+                    if outset == "Q":
+                        e(f"v_accvgpr_write_b32 a{A_Q + dst}, {d}")
+        for nb in range(2):
+            e(f"global_store_dword v{V_LANE4}, v{V_M[nb]}, {s2('MKL')} offset:{nb * 1024 + q * 256}")
+        # the images of this stage are stored behind the next stage's MFMAs
+        e(f"s_add_u32 {s('PEND')}, {s('HTL')}, {q * 4096}")
+        e(f"s_addc_u32 {s('PEND1')}, {s('HTL1')}, 0")
+        e(f"s_mov_b32 {s('PENDOK')}, 1")
+
+    # ------------------------------------------------------------------ a layer body: four stages
+    def layer_setup(self):
+        """HTL = hT + L * LSTR + 16384 g0, MKL = masks + L * MSTR + 1024 g0"""
+        e = self.e
+        for dst, base, stride, shift in (("HTL", "HT", "LSTR", 14), ("MKL", "MASKS", "MSTR", 10)):
+            e(f"s_mul_hi_u32 {s('T1')}, {s(stride)}, {s('L')}")
+            e(f"s_mul_i32 {s('T0')}, {s(stride)}, {s('L')}")
+            e(f"s_mul_i32 {s('T2')}, {s(stride + '1')}, {s('L')}")
+            e(f"s_add_u32 {s('T1')}, {s('T1')}, {s('T2')}")
+            e(f"s_add_u32 {s(dst)}, {s(base)}, {s('T0')}")
+            e(f"s_addc_u32 {s(dst + '1')}, {s(base + '1')}, {s('T1')}")
+            e(f"s_lshr_b32 {s('T1')}, {s('G0')}, {32 - shift}")
+            e(f"s_lshl_b32 {s('T0')}, {s('G0')}, {shift}")
+            e(f"s_add_u32 {s(dst)}, {s(dst)}, {s('T0')}")
+            e(f"s_addc_u32 {s(dst + '1')}, {s(dst + '1')}, {s('T1')}")
+
+    def layer_body(self, kind):
+        e = self.e
+        inset = {"A": "Q", "B": "P", "C": "Q", "D": "P"}[kind]        # (A: only the stores of the tile before read it)
+        outset = {"A": "P", "B": "Q", "C": "P", "D": "Q"}[kind]
+        parts = {"A": [("x", None)], "B": [("h", "P")], "C": [("h", "Q")], "D": [("x", None), ("h", "P")]}[kind]
+        self.layer_setup()
+        if kind == "C":       # layer 6: the next tile's embedded rows may be fetched (bx is dead after layer 5)
+            e(f"s_add_u32 {s('T0')}, {s('TILE')}, {s('GRID')}")
+            e(f"s_cmp_lt_u32 {s('T0')}, {s('NTILES')}")
+            e(f"s_cselect_b32 {s('BXF')}, 1, 0")
+            e(f"s_cmp_eq_u32 {s('L')}, 6")
+            e(f"s_cselect_b32 {s('BXF')}, {s('BXF')}, 0")
+            e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 3")                # first row group of this wave in the next tile
+            e(f"s_lshl_b32 {s('T3')}, {s('WAVE')}, 1")
+            e(f"s_add_u32 {s('T2')}, {s('T2')}, {s('T3')}")
+            self.xt_pointer("T2")
+        for q in range(4):
+            self.stage_setup(q)
+            items = self.dma_items()
+            st = self.store_items(inset, 3, guarded=(kind == "A")) if q == 0 else self.store_items(outset, q - 1, guarded=False)
+            order = os.environ.get("S2L_FWD_ORDER", "stores_first")
+            if order == "stores_first":      # the stores' acknowledgements are what the stage-end vmcnt(0) waits for longest
+                mixed = st + items
+            elif order == "dma_first":
+                mixed = items + st
+            else:
+                mixed = []
+                while items or st:
+                    if items:
+                        mixed.append(items.pop(0))
+                    if st:
+                        mixed.append(st.pop(0))
+            if kind == "C" and q < 2:
+                mixed += self.bx_items(q)
+            # the next stage's bias quads are read once this stage's first MFMAs (which take V_BIAS as C) have been issued
+            self.lds = []
+            nmf_total = sum(8 if p == "x" else 16 for p, _ in parts) * 4
+            every = EVERY if len(mixed) * EVERY <= nmf_total - 4 else max(1, (nmf_total - 4) // len(mixed))
+            self.kloop(q & 1, parts, mixed, every, lds_after=(8, self.bias_reads((q + 1) & 3)))
+            self.epilogue(q, outset)
+            e(f"s_add_u32 {s('ST')}, {s('ST')}, 1")
+            e(f"s_and_b32 {s('ST')}, {s('ST')}, 31")
+            if kind == "B" and q == 3:
+                self.output_layer()
+            e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+            if not EXP & 16:
+                e("s_barrier")
+
+    # ------------------------------------------------------------------ output layer (after stage 31's epilogue)
+    def output_layer(self):
+        """rgb[row][c] = bout[c] + sum_k Wout[c][k] h7[k][row]: weights = the X part of stage 31 (buffer 1) read as 16 k-steps,
+        h7 = set Q; once per tile, not scheduled tightly"""
+        e = self.e
+        skip = self.label("notlast")
+        e(f"s_cmp_lg_u32 {s('L')}, 7")
+        e(f"s_cbranch_scc1 {skip}")
+        e("s_waitcnt lgkmcnt(0)")
+        for nb in range(2):
+            for r in range(16):
+                e(f"v_mov_b32 v{V_ACC + nb * 16 + r}, 0")
+        for t0 in range(0, 16, 6):
+            ts = list(range(t0, min(16, t0 + 6)))
+            for t in ts:
+                e(f"ds_read_b128 {aq(A_A + (t - t0) * 4)}, v{V_AX[1]} offset:{t * 1024}")
+            e("s_waitcnt lgkmcnt(0)")
+            for t in ts:
+                for nb in range(2):
+                    c = f"v[{V_ACC + nb * 16}:{V_ACC + nb * 16 + 15}]"
+                    e(f"v_mfma_f32_32x32x16_bf16 {c}, {aq(A_A + (t - t0) * 4)}, {self.setreg('Q', nb, t)}, {c}")
+        e(f"ds_read_b128 {vq(V_T)}, v{V_T + 8}")          # bout (V_T + 8 = its LDS address)
+        e("s_nop 7")
+        e("s_nop 7")
+        e("s_nop 7")
+        e("s_waitcnt lgkmcnt(0)")
+        for nb in range(2):
+            for c in range(3):
+                e(f"v_add_f32 v{V_ACC + nb * 16 + c}, v{V_ACC + nb * 16 + c}, v{V_T + c}")
+        for nb in range(2):      # lanes hh == 0 whose row exists store 12 bytes
+            e(f"s_lshl_b32 {s('T0')}, {s('TILE')}, 8")
+            e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 6")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {32 * nb}")                   # first row of this group
+            e(f"v_add_u32 v{V_T + 4}, {s('T0')}, v{V_T + 9}")                 # row = first + n
+            e(f"v_cmp_gt_u32 vcc, {s('NROWS')}, v{V_T + 4}")
+            e(f"s_and_b64 {s2('EX')}, vcc, 0xffffffff")                         # hh == 0: lanes 0..31
+            e(f"v_mul_lo_u32 v{V_T + 5}, v{V_T + 4}, 12")
+            e(f"s_mov_b64 exec, {s2('EX')}")
+            e(f"global_store_dwordx3 v{V_T + 5}, v[{V_ACC + nb * 16}:{V_ACC + nb * 16 + 2}], {s2('RGB')}")
+            e("s_mov_b64 exec, -1")
+        e(f"{skip}:")
+
+    # ------------------------------------------------------------------ the whole body
+    def emit(self):
+        e = self.e
+        for dst, src in (("LDSB", "ldsbase"), ("WAVE", "wave"), ("TILE", "tile0"), ("GRID", "grid")):
+            e(f"s_mov_b32 {s(dst)}, %[{src}]")
+        e(f"s_mov_b64 {s2('KARG')}, %[karg]")
+        for dst, off in (("WB", "owb"), ("XT", "oxt"), ("HT", "oht"), ("MASKS", "omasks"), ("RGB", "orgb"), ("LSTR", "olstr"),
+                         ("MSTR", "omstr")):
+            e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, %[{off}]")
+        e(f"s_load_dword {s('NTILES')}, {s2('KARG')}, %[ontiles]")
+        e(f"s_load_dword {s('NROWS')}, {s2('KARG')}, %[onrows]")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_lshl_b64 {s2('LSTR')}, {s2('LSTR')}, 1")            # halves -> bytes
+        e(f"s_lshl_b64 {s2('MSTR')}, {s2('MSTR')}, 3")            # uint64 -> bytes
+        e(f"s_mov_b32 {s('ONE')}, 0x00010001")
+        e(f"s_mov_b32 {s('PENDOK')}, 0")
+        e(f"s_mov_b32 {s('ST')}, 0")
+        # ---- lane constants
+        e(f"v_mbcnt_lo_u32_b32 v{V_T}, -1, 0")
+        e(f"v_mbcnt_hi_u32_b32 v{V_T}, -1, v{V_T}")
+        e(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_T}")
+        e(f"v_lshlrev_b32 v{V_LANE32}, 5, v{V_T}")
+        e(f"v_add_u32 v{V_LANE32B}, 16384, v{V_LANE32}")
+        e(f"v_lshlrev_b32 v{V_LANE4}, 2, v{V_T}")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 10")
+        e(f"v_add_u32 v{V_DMAOFF}, {s('T0')}, v{V_LANE16}")
+        for b in range(2):
+            e(f"s_add_u32 {s('T0')}, {s('LDSB')}, {b * STAGE}")
+            e(f"v_add_u32 v{V_AX[b]}, {s('T0')}, v{V_LANE16}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {2 * SLAB_X}")
+            e(f"v_add_u32 v{V_AH[b]}, {s('T0')}, v{V_LANE16}")
+        e(f"v_lshrrev_b32 v{V_T + 1}, 5, v{V_T}")                  # hh
+        e(f"v_lshlrev_b32 v{V_T + 1}, 4, v{V_T + 1}")
+        e(f"s_add_u32 {s('T0')}, {s('LDSB')}, {LDS_W}")
+        e(f"v_add_u32 v{V_BIAS0}, {s('T0')}, v{V_T + 1}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, 8192")
+        e(f"v_mov_b32 v{V_T + 8}, {s('T0')}")                      # LDS address of bout
+        e(f"v_and_b32 v{V_T + 9}, 31, v{V_T}")                     # n
+        # ---- first tile: stage 0 (x part) -> buffer 0, embedded rows -> bx, bias of stage 0
+        done = "S2LF_DONE"
+        e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
+        e(f"s_cbranch_scc0 {done}")
+        e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10")
+        e(f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}")
+        e(f"s_mov_b64 {s2('WP')}, {s2('WB')}")
+        for k in range(4):
+            e(f"s_mov_b32 m0, {s('MDST')}")
+            e("s_nop 0")
+            e(f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}")
+            e(f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096")
+            e(f"s_add_u32 {s('WP')}, {s('WP')}, 4096")
+            e(f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0")
+        e(f"s_lshl_b32 {s('G0')}, {s('TILE')}, 3")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 1")
+        e(f"s_add_u32 {s('G0')}, {s('G0')}, {s('T0')}")
+        self.xt_pointer("G0")
+        for k in range(16):
+            nb, t = k >> 3, k & 7
+            e(f"s_add_u32 {s('XTA')}, {s('XTN')}, {nb * 8192 + (t >> 1) * 2048}")
+            e(f"s_addc_u32 {s('XTA1')}, {s('XTN1')}, 0")
+            e(f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE32}, {s2('XTA')} offset:{(t & 1) * 16}")
+        e(f"v_mov_b32 v{V_BN}, v{V_BIAS0}")
+        for text, _ in self.bias_reads(0):
+            e(text)
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        self.lds = []
+        e("s_barrier")
+
+        e("S2LF_TILE:")
+        e(f"s_mov_b32 {s('L')}, 0")
+        self.layer_body("A")
+        e(f"s_mov_b32 {s('L')}, 1")
+        e("S2LF_B:")
+        self.layer_body("B")
+        e(f"s_cmp_eq_u32 {s('L')}, 7")
+        e("s_cbranch_scc1 S2LF_TILE_END")
+        e(f"s_add_u32 {s('L')}, {s('L')}, 1")
+        e("S2LF_C:")
+        self.layer_body("C")
+        e(f"s_add_u32 {s('L')}, {s('L')}, 1")
+        e(f"s_cmp_eq_u32 {s('L')}, 5")
+        e("s_cbranch_scc0 S2LF_B")
+        self.layer_body("D")
+        e(f"s_mov_b32 {s('L')}, 6")
+        e("s_branch S2LF_C")
+        e("S2LF_TILE_END:")
+        e(f"s_add_u32 {s('TILE')}, {s('TILE')}, {s('GRID')}")
+        e(f"s_lshl_b32 {s('G0')}, {s('TILE')}, 3")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 1")
+        e(f"s_add_u32 {s('G0')}, {s('G0')}, {s('T0')}")
+        e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
+        e("s_cbranch_scc1 S2LF_TILE")
+        # ---- the last stage's images (blocks 6, 7 of layer 7: set Q)
+        for it in self.store_items("Q", 3, guarded=False):
+            for x in it:
+                e(x)
+        e("s_waitcnt vmcnt(0)")
+        e(f"{done}:")
+        return [x for x in self.L if x is not None]
+
+    def xt_pointer(self, g):
+        """XTN = xT + 8192 * group g (bytes; 4 blocks of 2 KiB per 32-row group)"""
+        e = self.e
+        e(f"s_lshr_b32 {s('T1')}, {s(g)}, 19")
+        e(f"s_lshl_b32 {s('T0')}, {s(g)}, 13")
+        e(f"s_add_u32 {s('XTN')}, {s('XT')}, {s('T0')}")
+        e(f"s_addc_u32 {s('XTN1')}, {s('XT1')}, {s('T1')}")
+
+
+OPERANDS = """      :
+      : [karg] "s"(karg), [ldsbase] "s"(ldsbase), [wave] "s"(wave), [tile0] "s"(tile0), [grid] "s"(grid),
+        [owb] "n"(offsetof(FwdArgs, wb)), [oxt] "n"(offsetof(FwdArgs, xT)), [oht] "n"(offsetof(FwdArgs, hT)),
+        [omasks] "n"(offsetof(FwdArgs, masks)), [orgb] "n"(offsetof(FwdArgs, rgb)), [olstr] "n"(offsetof(FwdArgs, layer_stride)),
+        [omstr] "n"(offsetof(FwdArgs, mask_layer_stride)), [ontiles] "n"(offsetof(FwdArgs, n_tiles)),
+        [onrows] "n"(offsetof(FwdArgs, n_rows))
+"""
+
+
+def main(outdir):
+    lines = Body().emit()
+    clob = ([f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)]
+            + [f"s{r}" for r in range(8, S_LAST + 1) if r not in (32, 33)] + ["vcc", "scc", "memory"])
+    out = ["// GENERATED by csrc/gen_fwd16_body.py -- do not edit; the generator is the source.", "asm volatile("]
+    out += [f'    "{x}\\n\\t"' for x in lines]
+    out.append(OPERANDS.rstrip("\n"))
+    out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+    with open(os.path.join(outdir, "fwd16_body.inc"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    return len(lines)
+
+
+if __name__ == "__main__":
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build")
+    print(f"fwd16_body.inc: {main(d)} instructions")

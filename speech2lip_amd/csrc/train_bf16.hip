@@ -328,6 +328,37 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
   }
 }
 
+// ---- the forward kernel with its body as one fixed-register assembly text (csrc/gen_fwd16_body.py): 64 rows per wave, one wave
+// per SIMD, stages by LDS-DMA, every memory instruction behind an MFMA.  Same arithmetic in the same order as fwd_bf16_kernel:
+// images, mask dwords and rgb are bit-identical (tests/test_gpu_parity.py switches between the two with
+// s2l_set_bf16_forward_kernel).  NOT the default: it runs at the same 3.3 ms as the C++ kernel.  Its ablation builds
+// (S2L_FWD_EXP in the generator) say why: a stage's 80 KB of texture-path traffic (32 KB of image stores at 16 B/clk/CU + 48 KB
+// of stage DMA) take ~2 850 cycles, its MFMAs + epilogue + fixed costs ~3 900, and within one wave the two do not overlap
+// yet (a wave that finds the texture queue full stalls, and the stage-end vmcnt(0) cannot tell DMA from stores).  It is kept,
+// selectable and tested, as the base for that work.
+#ifndef S2L_FWD_ASM
+#define S2L_FWD_ASM 1
+#endif
+__global__ __launch_bounds__(256, 1) void fwd_asm_bf16_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias = reinterpret_cast<float*>(smem + kLdsW);
+  for (int i = threadIdx.x; i < 8 * 256; i += 256) {
+    const int L = i >> 8, f = i & 255;
+    bias[i] = L == 0 ? a.pf[OFF_BG0 + f] : L == 5 ? a.pf[OFF_BG5 + f] : a.pf[OFF_BIAS + (L - 1) * 256 + f];
+  }
+  if (threadIdx.x < 4) bias[2048 + threadIdx.x] = a.pf[OFF_BOUT + threadIdx.x];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ldsbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x), grid = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();   // the body loads FwdArgs fields itself (s_load)
+#else
+  const void* karg = nullptr;   // (host pass of the compiler: never executed)
+#endif
+#include "fwd16_body.inc"
+}
+
 // ---- backward dz chain ------------------------------------------------------------------------------------------------------
 // g_7 = (Wout^T drgb) . m_7;  g_{l-1} = (W_l^T g_l) . m_{l-1} for l = 7..1 (l = 5: the h_4 half of pts_linears[5]);
 // d audio = G5[:, audio]^T g_5 + G0[:, audio]^T g_0.  Every g_l is stored as a [feature][64 rows] bf16 tile (dzT) for the
@@ -821,6 +852,14 @@ static int persistent_grid(const void* kernel, int lds_bytes, LdsOptIn& flags, i
   return 0;
 }
 
+// 0 = the C++ forward kernel (default), 1 = the assembly kernel (64 rows per wave): same bits
+static std::atomic<int> g_fwd_kernel_kind{0};
+extern "C" int s2l_set_bf16_forward_kernel(int kind) {
+  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+  g_fwd_kernel_kind.store(kind, std::memory_order_relaxed);
+  return S2L_OK;
+}
+
 extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const uint16_t* xT, uint16_t* hT,
                                       uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream) {
   if (n_rows < 0) return S2L_E_SIZE;
@@ -834,6 +873,13 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   a.n_tiles = (int)(np / kWgRows);
   static LdsOptIn flags;
   int grid = 0;
+  if (S2L_FWD_ASM && g_fwd_kernel_kind.load(std::memory_order_relaxed) == 1 && n_rows < 0x7fffffff) {
+    static LdsOptIn flags_asm;
+    const int rc = persistent_grid(reinterpret_cast<const void*>(fwd_asm_bf16_kernel), kLdsFwd, flags_asm, a.n_tiles, &grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fwd_asm_bf16_kernel, dim3(grid), dim3(256), kLdsFwd, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+  }
   const int rc = persistent_grid(reinterpret_cast<const void*>(fwd_bf16_kernel), kLdsFwd, flags, a.n_tiles, &grid);
   if (rc) return rc;
   hipLaunchKernelGGL(fwd_bf16_kernel, dim3(grid), dim3(512), kLdsFwd, static_cast<hipStream_t>(stream), a);

@@ -236,6 +236,27 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
         assert '"v"(' not in text                                # every VGPR is the body's: no vector operand
 
 
+def test_fwd16_body_generator_is_deterministic_and_complete(tmp_path):
+    """csrc/gen_fwd16_body.py writes the assembly form of the bf16 training forward (64 rows per wave).  Two runs give the same
+    text; it holds the MFMAs of its four layer bodies -- layer 0: 4 stages x 32, layers of kind B / C: 4 x 64 each, layer 5:
+    4 x 96 -- plus the output layer's 32, one barrier per stage and the prime, twelve stage-DMA instructions per stage."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_fwd16_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_fwd16_body.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    gen.main(str(a))
+    gen.main(str(b))
+    text = open(a / "fwd16_body.inc").read()
+    assert text == open(b / "fwd16_body.inc").read()
+    assert text.count("v_mfma_f32_32x32x16_bf16") == 4 * 32 + 2 * 4 * 64 + 4 * 96 + 32
+    assert text.count("s_barrier") == 16 + 1
+    assert text.count("global_load_lds_dwordx4") == 16 * 12 + 4
+    assert text.count("global_store_dwordx4") == 16 * 8 + 8            # a stage's images behind the next stage's MFMAs, + the last
+    assert '"v"(' not in text
+
+
 def test_lpips_module_has_the_package_state_dict_and_oracle_properties():
     """speech2lip_amd.LPIPS carries the state-dict keys of lpips.LPIPS(net='alex') (lpips==0.1.4), frozen; the oracle's
     restatement is zero on identical images, symmetric, and positive otherwise."""

@@ -638,6 +638,34 @@ def test_bf16_forward_matches_emulation(dev, h, w, B):
     assert O.rmse(rgb.cpu(), ref32.cpu()) <= 2e-2
 
 
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3), (96, 96, 6)])
+def test_bf16_forward_assembly_kernel_is_bit_identical(dev, h, w, B):
+    """The generated-assembly forward (csrc/gen_fwd16_body.py, 64 rows per wave; s2l_set_bf16_forward_kernel(1)) performs the
+    C++ kernel's arithmetic in its order: activation images, mask dwords and rgb are the same bits -- one tile per workgroup,
+    a partial last tile, and (96x96x6 = 864 tiles) several tiles per persistent workgroup."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    m, lib, x, N = _bf16_inputs(dev, h, w, B)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    outs = []
+    try:
+        for kind in (1, 0):
+            assert lib.s2l_set_bf16_forward_kernel(kind) == 0
+            hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+            masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+            rgb = torch.zeros(N, 3, device=dev)
+            _abi.check(lib.s2l_train_forward_bf16(_ptr(m.packed_weights_bf16()), _ptr(m.packed_weights()), _ptr(_bf16_inputs.last[0]), _ptr(hT),
+                                                  _ptr(masks), _ptr(rgb), N, _stream()), "s2l_train_forward_bf16")
+            torch.cuda.synchronize()
+            outs.append((hT, masks, rgb))
+    finally:
+        assert lib.s2l_set_bf16_forward_kernel(0) == 0
+    for a, b, name in zip(outs[0], outs[1], ("images", "masks", "rgb")):
+        assert torch.equal(a, b), name
+    assert float(outs[0][2].abs().max()) > 0
+    assert lib.s2l_set_bf16_forward_kernel(2) == -2
+
+
 @pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
 def test_bf16_backward_matches_emulation(dev, h, w, B):
     """bf16 dz chain: every saved gradient tile and the audio-feature gradient against the step-wise CPU emulation."""
