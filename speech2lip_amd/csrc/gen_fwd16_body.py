@@ -9,13 +9,19 @@ fwd_bf16_kernel: activation images, mask dwords and rgb are bit-identical.
   * workgroup = 4 waves = 256 rows; wave w owns row groups g0 = 8 tile + 2 w and g0 + 1 (32 rows each, nb = 0, 1): an A quad
     (weights) read from LDS feeds TWO MFMAs -- half the LDS traffic per MFMA of the 32-row kernel;
   * stage = a quarter layer (output blocks R = 2q, 2q + 1): [X slab R0][X slab R1][H slab R0][H slab R1] (s2l_bf16.h), 48 KiB, by
-    LDS-DMA into one of two buffers, the next stage's twelve 1-KiB instructions one behind every third MFMA;
+    LDS-DMA into one of two buffers: the next stage's twelve 1-KiB instructions ride behind MFMAs of this stage's k-loop, the wait
+    for them and the stage's one barrier sit right behind the k-loop;
   * accumulators acc[which][nb] in VGPRs, their first MFMA takes the bias quads (read from LDS during the stage before) as C;
   * activation sets: P in VGPRs 0..127, Q in AGPRs 0..127 ([nb][k-step 16][4]); a layer reads one and writes the other
     (layer 0 writes P; odd layers write Q through v_accvgpr_write); the embedded rows bx live in AGPRs 128..191 and are
     prefetched for the next tile during layer 6;
   * epilogue per pair: v_cvt_pk_bf16_f32, v_pk_max_i16 (ReLU), v_pk_min_u16 + v_lshl_or_b32 (mask bit): 4 VALU per two values;
-  * the images of a stage are stored behind the MFMAs of the NEXT stage (16 B per lane and clock is all the store path takes).
+  * the images of a stage are stored during the NEXT stage: four stores behind MFMAs of its k-loop, four between the pairs of its
+    epilogue (16 B per lane and clock is all the store path takes).
+
+State: bit-identical, and as fast as the C++ kernel, not faster -- 3.3 ms, of which the MFMAs are 1.0; PMC: the
+texture path is 59 % busy, the waves spend 30 % of their cycles in s_waitcnt.  S2L_FWD_EXP builds ablate stores / epilogue /
+MFMAs / DMA / barrier for the next attempt.
 
 Layer bodies: A (layer 0: x only, -> P), B (h from P -> Q: layers 1, 3, 7), C (h from Q -> P: 2, 4, 6), D (layer 5: x + h from P ->
 Q); four stages each, sequenced by a scalar layer counter."""
@@ -240,12 +246,14 @@ class Body:
                     if lds_after and nmf == lds_after[0]:
                         for text, tag in lds_after[1]:
                             self.lds_op(text, tag)
-                    if pending and nmf % every == 0:
-                        for x in pending.pop(0):
+                    if pending and (nmf >= pending[0][0] if isinstance(pending[0], tuple) else nmf % every == 0):
+                        grp = pending.pop(0)
+                        for x in (grp[1] if isinstance(grp, tuple) else grp):
                             if x is not None:
                                 e(x)
         while pending:
-            for x in pending.pop(0):
+            grp = pending.pop(0)
+            for x in (grp[1] if isinstance(grp, tuple) else grp):
                 if x is not None:
                     e(x)
 
@@ -259,8 +267,12 @@ class Body:
         return out
 
     # ------------------------------------------------------------------ epilogue of a stage
-    def epilogue(self, q, outset):
+    def epilogue(self, q, outset, items=()):
+        """items: instruction groups spread evenly between the pairs"""
         e = self.e
+        items = list(items)
+        gap = 32 // (len(items) + 1) if items else 0
+        npair = 0
         e("s_nop 7")
         e("s_nop 7")
         e("s_nop 7")
@@ -279,6 +291,15 @@ class Body:
                     e(f"v_lshl_or_b32 v{V_M[nb]}, v{V_M[nb]}, 1, v{V_T + 4 + (d8 & 3)}")
                     if outset == "Q":
                         e(f"v_accvgpr_write_b32 a{A_Q + dst}, {d}")
+                    npair += 1
+                    if items and npair % gap == 0:
+                        for x in items.pop(0):
+                            if x is not None:
+                                e(x)
+        for grp in items:
+            for x in grp:
+                if x is not None:
+                    e(x)
         for nb in range(2):
             e(f"global_store_dword v{V_LANE4}, v{V_M[nb]}, {s2('MKL')} offset:{nb * 1024 + q * 256}")
         # the images of this stage are stored behind the next stage's MFMAs
@@ -322,33 +343,28 @@ class Body:
             self.stage_setup(q)
             items = self.dma_items()
             st = self.store_items(inset, 3, guarded=(kind == "A")) if q == 0 else self.store_items(outset, q - 1, guarded=False)
-            order = os.environ.get("S2L_FWD_ORDER", "stores_first")
-            if order == "stores_first":      # the stores' acknowledgements are what the stage-end vmcnt(0) waits for longest
-                mixed = st + items
-            elif order == "dma_first":
-                mixed = items + st
-            else:
-                mixed = []
-                while items or st:
-                    if items:
-                        mixed.append(items.pop(0))
-                    if st:
-                        mixed.append(st.pop(0))
+            # The texture path serves one 1-KiB store per 64 cycles and CU (256 per wave) and a DMA instruction in ~20: four of
+            # the eight stores go first, one behind every eighth MFMA, the twelve DMA instructions behind them; the wait + barrier
+            # sit right behind the k-loop (the DMA is old by then), the other four stores ride in the epilogue and have a whole
+            # stage until the next wait.
+            nmf_total = sum(8 if p == "x" else 16 for p, _ in parts) * 4
+            sgap = 8 if nmf_total >= 64 else 2
+            dgap = max(1, (nmf_total - 4 * sgap - 2) // 12)
+            mixed = [(2 + sgap * k, st[k]) for k in range(4)] + [(2 + 4 * sgap + dgap * k, items[k]) for k in range(12)]
+            late = st[4:]
             if kind == "C" and q < 2:
-                mixed += self.bx_items(q)
+                late = late + self.bx_items(q)
             # the next stage's bias quads are read once this stage's first MFMAs (which take V_BIAS as C) have been issued
             self.lds = []
-            nmf_total = sum(8 if p == "x" else 16 for p, _ in parts) * 4
-            every = EVERY if len(mixed) * EVERY <= nmf_total - 4 else max(1, (nmf_total - 4) // len(mixed))
-            self.kloop(q & 1, parts, mixed, every, lds_after=(8, self.bias_reads((q + 1) & 3)))
-            self.epilogue(q, outset)
+            self.kloop(q & 1, parts, mixed, 1, lds_after=(8, self.bias_reads((q + 1) & 3)))
+            e("s_waitcnt vmcnt(0) lgkmcnt(0)")      # the next stage has landed (this wave's part); nobody reads this buffer any more
+            if not EXP & 16:
+                e("s_barrier")
+            self.epilogue(q, outset, late)
             e(f"s_add_u32 {s('ST')}, {s('ST')}, 1")
             e(f"s_and_b32 {s('ST')}, {s('ST')}, 31")
             if kind == "B" and q == 3:
                 self.output_layer()
-            e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-            if not EXP & 16:
-                e("s_barrier")
 
     # ------------------------------------------------------------------ output layer (after stage 31's epilogue)
     def output_layer(self):
@@ -391,6 +407,7 @@ class Body:
             e(f"s_mov_b64 exec, {s2('EX')}")
             e(f"global_store_dwordx3 v{V_T + 5}, v[{V_ACC + nb * 16}:{V_ACC + nb * 16 + 2}], {s2('RGB')}")
             e("s_mov_b64 exec, -1")
+        e("s_barrier")      # the weights just read sit in buffer 1, which the next stage's DMA (for stage 1) overwrites
         e(f"{skip}:")
 
     # ------------------------------------------------------------------ the whole body

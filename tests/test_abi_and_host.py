@@ -239,7 +239,8 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
 def test_fwd16_body_generator_is_deterministic_and_complete(tmp_path):
     """csrc/gen_fwd16_body.py writes the assembly form of the bf16 training forward (64 rows per wave).  Two runs give the same
     text; it holds the MFMAs of its four layer bodies -- layer 0: 4 stages x 32, layers of kind B / C: 4 x 64 each, layer 5:
-    4 x 96 -- plus the output layer's 32, one barrier per stage and the prime, twelve stage-DMA instructions per stage."""
+    4 x 96 -- plus the output layer's 32, one barrier per stage (+ the prime, + one behind the output layer), twelve stage-DMA
+    instructions per stage."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_fwd16_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_fwd16_body.py"))
     gen = importlib.util.module_from_spec(spec)
@@ -251,7 +252,7 @@ def test_fwd16_body_generator_is_deterministic_and_complete(tmp_path):
     text = open(a / "fwd16_body.inc").read()
     assert text == open(b / "fwd16_body.inc").read()
     assert text.count("v_mfma_f32_32x32x16_bf16") == 4 * 32 + 2 * 4 * 64 + 4 * 96 + 32
-    assert text.count("s_barrier") == 16 + 1
+    assert text.count("s_barrier") == 16 + 1 + 1                      # per stage, the prime, after the output layer
     assert text.count("global_load_lds_dwordx4") == 16 * 12 + 4
     assert text.count("global_store_dwordx4") == 16 * 8 + 8            # a stage's images behind the next stage's MFMAs, + the last
     assert '"v"(' not in text
