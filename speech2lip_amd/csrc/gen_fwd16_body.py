@@ -189,7 +189,7 @@ class Body:
                     if guarded:
                         it += [f"s_cmp_eq_u32 {s('PENDOK')}, 0", f"s_cbranch_scc1 {skip}"]
                     if not EXP & 1:
-                        it.append(f"global_store_dwordx4 v{V_LANE32B if nb else V_LANE32}, {src}, {s2('PEND')} offset:{which * 2048 + half * 16}")
+                        it.append(f"global_store_dwordx4 v{V_LANE32B if nb else V_LANE32}, {src}, {s2('PEND')} offset:{which * 2048 + half * 16}" + os.environ.get("S2L_FWD_STORE_MOD", ""))
                     if guarded:
                         it.append(f"{skip}:")
                     items.append(it)
