@@ -424,9 +424,10 @@ int s2l_lpips_backward(const float* packed, float* work, const float* d_out, int
  * (src/face_simple/training.py:158-251, 605-619) through TalkingFace.rgb_forward (tf_nerf.py:225-285).
  * s2l_pack_bf16: bf16 operand images from the state-dict tensors (table as s2l_pack_weights) and the fp32 blob of
  * s2l_pack_weights (folded first/skip matrices, biases); packed_bf16: s2l_bf16_packed_halves() uint16.
- * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/32][8][64][16]
- * ([layer][group of 32 rows][32-feature block][lane n + 32 hh][4a + c] = feature 32R + 8a + 4hh + c of row n); masks: Np * 32 bytes per layer ([8][Np/64][256] uint64 of storage) holding one ReLU mask dword per lane and stage (layout: csrc/s2l_bf16.h), written by the forward and read by the backward only; xT: the embedded
- * rows in the same image layout with 4 blocks, bf16 [Np/32][4][64][16] (s2l_ensemble_rows_bf16 for a whole batch of frames:
+ * Rows are processed in tiles of 256: Np = s2l_bf16_rows_padded(N).  hT, dzT: bf16 [8][Np/32][8][2][64][8]
+ * ([layer][group of 32 rows][32-feature block][half][lane n + 32 hh][4 (a & 1) + c] = feature 32R + 8a + 4hh + c of row n, half = a >> 1:
+ * each of a block's two store instructions writes 1 KiB of contiguous memory, csrc/s2l_bf16.h); masks: Np * 32 bytes per layer ([8][Np/64][256] uint64 of storage) holding one ReLU mask dword per lane and stage (layout: csrc/s2l_bf16.h), written by the forward and read by the backward only; xT: the embedded
+ * rows in the same image layout with 4 blocks, bf16 [Np/32][4][2][64][8] (s2l_ensemble_rows_bf16 for a whole batch of frames:
  * feat [F,64], time_index int64 [F] and u01 fp32 [F] on the device, areas fp32 [4*HW*F]; or s2l_rows_to_tiles_bf16 from
  * fp32 rows); rgb, drgb: fp32 [N,3]; dxa: fp32 [N,64]. */
 int64_t s2l_bf16_packed_halves(void);

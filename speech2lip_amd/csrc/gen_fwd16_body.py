@@ -38,7 +38,7 @@ EVERY = 3
 V_P = 0                        # 128: activation set P [nb][t][4]
 V_ACC = 128                    # 64: acc[(which * 2 + nb) * 16 + r]
 V_BIAS = 192                   # 32: bias regs [which][16] of the stage being computed (srcC of its first MFMAs)
-V_LANE16, V_LANE32, V_LANE32B, V_LANE4, V_DMAOFF = 224, 225, 226, 227, 228
+V_LANE16, V_LANE32, V_LANE16B, V_LANE4, V_DMAOFF = 224, 225, 226, 227, 228      # (V_LANE32: unused since the image planes)
 V_AX = (229, 230)              # LDS address of this lane's A quads, X part of buffer 0 / 1
 V_AH = (231, 232)              # ... H part
 V_BIAS0 = 233                  # LDS address of the bias block + 16 hh
@@ -189,7 +189,7 @@ class Body:
                     if guarded:
                         it += [f"s_cmp_eq_u32 {s('PENDOK')}, 0", f"s_cbranch_scc1 {skip}"]
                     if not EXP & 1:
-                        it.append(f"global_store_dwordx4 v{V_LANE32B if nb else V_LANE32}, {src}, {s2('PEND')} offset:{which * 2048 + half * 16}" + os.environ.get("S2L_FWD_STORE_MOD", ""))
+                        it.append(f"global_store_dwordx4 v{V_LANE16B if nb else V_LANE16}, {src}, {s2('PEND')} offset:{which * 2048 + half * 1024}" + os.environ.get("S2L_FWD_STORE_MOD", ""))
                     if guarded:
                         it.append(f"{skip}:")
                     items.append(it)
@@ -204,7 +204,7 @@ class Body:
             items.append([f"s_cmp_eq_u32 {s('BXF')}, 0", f"s_cbranch_scc1 {skip}",
                           f"s_add_u32 {s('XTA')}, {s('XTN')}, {nb * 8192 + (t >> 1) * 2048}",
                           f"s_addc_u32 {s('XTA1')}, {s('XTN1')}, 0",
-                          f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE32}, {s2('XTA')} offset:{(t & 1) * 16}",
+                          f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE16}, {s2('XTA')} offset:{(t & 1) * 1024}",
                           f"{skip}:"])
         return items
 
@@ -432,7 +432,7 @@ class Body:
         e(f"v_mbcnt_hi_u32_b32 v{V_T}, -1, v{V_T}")
         e(f"v_lshlrev_b32 v{V_LANE16}, 4, v{V_T}")
         e(f"v_lshlrev_b32 v{V_LANE32}, 5, v{V_T}")
-        e(f"v_add_u32 v{V_LANE32B}, 16384, v{V_LANE32}")
+        e(f"v_add_u32 v{V_LANE16B}, 16384, v{V_LANE16}")
         e(f"v_lshlrev_b32 v{V_LANE4}, 2, v{V_T}")
         e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 10")
         e(f"v_add_u32 v{V_DMAOFF}, {s('T0')}, v{V_LANE16}")
@@ -470,7 +470,7 @@ class Body:
             nb, t = k >> 3, k & 7
             e(f"s_add_u32 {s('XTA')}, {s('XTN')}, {nb * 8192 + (t >> 1) * 2048}")
             e(f"s_addc_u32 {s('XTA1')}, {s('XTN1')}, 0")
-            e(f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE32}, {s2('XTA')} offset:{(t & 1) * 16}")
+            e(f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE16}, {s2('XTA')} offset:{(t & 1) * 1024}")
         e(f"v_mov_b32 v{V_BN}, v{V_BIAS0}")
         for text, _ in self.bias_reads(0):
             e(text)

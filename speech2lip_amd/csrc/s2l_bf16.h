@@ -43,15 +43,22 @@ __host__ __device__ constexpr int bwd_stage_quarter(int u) { return u < 8 ? (u &
 
 // Saved activations / gradients ("images"): exactly what a lane holds after a 32-feature block's epilogue, so the forward
 // and backward kernels store them with two 16-byte stores per lane and no transposition:
-//     image[row group of 32][block R = F/32][lane = n + 32 hh][16 bf16],  element 4a + c  =  feature 32R + 8a + 4hh + c
-// of row n.  For a fixed hh this is a row-major [32 rows][16 features] bf16 matrix with 32-byte rows whose 8-byte groups
-// are 4 consecutive features -- the shape ds_read_b64_tr_b16 turns into "8 consecutive rows of one feature per lane",
-// which is what BOTH operands of the weight-gradient GEMM dW = dz^T h need (the reduction runs over rows).
+//     image[row group of 32][block R = F/32][half 2][lane = n + 32 hh][8 bf16],  element 4 (a & 1) + c of half a >> 1  =
+// feature 32R + 8a + 4hh + c of row n.  The two 16-byte pieces of a lane sit 1 KiB apart, so that each of the two store
+// instructions of a block writes 1 KiB of CONTIGUOUS memory: 16 full 64-byte sectors.  (Until late in round 2 a lane's 32 bytes
+// were adjacent; every store instruction then touched 32 half-filled sectors, and tools/ubench/gen_mfma_shadow.py's
+// gstore_*_pitch32 / pitch16 show that the texture path takes twice as long for that: 82 against 40 cycles per instruction
+// and CU.)  For a fixed hh and both halves this is a row-major [32 rows][16 features] bf16 matrix whose 8-byte groups are 4
+// consecutive features -- rebuilt with 32-byte rows in LDS by the weight-gradient kernel's copy, it is the shape
+// ds_read_b64_tr_b16 turns into "8 consecutive rows of one feature per lane", which is what BOTH operands of the
+// weight-gradient GEMM dW = dz^T h need (the reduction runs over rows).
 constexpr int kGroupRows = 32;
 constexpr int kWgRows = 256;       // rows per workgroup tile of the forward / backward kernels
-__host__ __device__ constexpr int64_t image_off(int64_t group, int n_blocks, int R, int lane) {   // in halves
-  return ((group * n_blocks + R) * 64 + lane) * 16;
-}
+// offset (in halves) of block R of a row group (2 KiB = 1024 halves per block); of the 16-byte piece `half` of a lane in it;
+// of the 8-byte group a (features 8a + 4hh ..) of a lane in it
+__host__ __device__ constexpr int64_t image_off(int64_t group, int n_blocks, int R) { return (group * n_blocks + R) * 1024; }
+__host__ __device__ constexpr int image_piece(int half, int lane) { return (half * 64 + lane) * 8; }
+__host__ __device__ constexpr int image_quad(int a, int lane) { return image_piece(a >> 1, lane) + 4 * (a & 1); }
 // ReLU masks: uint32 [layer 8][group of 32 rows][stage q 4][lane n + 32 hh]: the lane's 32 values of the stage (blocks 2q, 2q + 1)
 // are 16 bf16 pairs d = 8 which + 2 a + p; bit 15 - d = (low half of pair d is non-zero), bit 31 - d = (high half is)
 

@@ -195,9 +195,9 @@ __device__ __forceinline__ void stage_lstore(const Stage& st, uint16_t* dst, int
 
 // Store one finished 32-feature block of this wave's 32 rows: the lane's eight bf16 pairs, as held (s2l_bf16.h image).
 __device__ __forceinline__ void image_store(const uint32_t (&vals)[4][2], uint16_t* gdst, int lane) {
-  u4* g = reinterpret_cast<u4*>(gdst) + 2 * lane;
+  u4* g = reinterpret_cast<u4*>(gdst) + lane;      // two contiguous 1-KiB planes per block (s2l_bf16.h)
   g[0] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
-  g[1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
+  g[64] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
 }
 
 #ifdef S2L_TRACE16   // experiment build: per-stage phase timestamps of waves 0 and 4 of workgroup 0 (s_memtime)
@@ -248,11 +248,11 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
     const int64_t row = (int64_t)tile * kWgRows + 32 * wave + n;
     const int64_t tile64 = (int64_t)tile * 4 + (wave >> 1), group = (int64_t)tile * 8 + wave;
     {   // B operands of the embedded rows: the image's two 16-byte halves of block R are k-steps 2R and 2R + 1
-      const u4* xi = reinterpret_cast<const u4*>(a.xT + image_off(group, 4, 0, lane));
+      const u4* xi = reinterpret_cast<const u4*>(a.xT + image_off(group, 4, 0)) + lane;
 #pragma unroll
       for (int R = 0; R < 4; ++R) {
         bx[2 * R] = xi[R * 128];
-        bx[2 * R + 1] = xi[R * 128 + 1];
+        bx[2 * R + 1] = xi[R * 128 + 64];
       }
     }
     for (int L = 0; L < 8; ++L) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
           bnext[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
           bnext[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
           if (!(S2L_EXP & 1))
-            image_store(vals, a.hT + L * a.layer_stride + image_off(group, 8, R, 0), lane);
+            image_store(vals, a.hT + L * a.layer_stride + image_off(group, 8, R), lane);
         }
         if (!(S2L_EXP & 2))   // dword (layer, 32-row group, stage, lane)
           reinterpret_cast<uint32_t*>(a.masks + L * a.mask_layer_stride)[group * 256 + q * 64 + lane] = mword;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
       mask_block(acc, m7, R & 1, vals);
       bcur[2 * R] = u4{vals[0][0], vals[0][1], vals[1][0], vals[1][1]};
       bcur[2 * R + 1] = u4{vals[2][0], vals[2][1], vals[3][0], vals[3][1]};
-      image_store(vals, a.dzT + 7 * a.layer_stride + image_off(group, 8, R, 0), lane);
+      image_store(vals, a.dzT + 7 * a.layer_stride + image_off(group, 8, R), lane);
     }
 
     int u = 0;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
     for (int l = 7; l >= 1; --l) {   // W_l^T g_l -> g_{l-1}
       f16v accs[2][2];
       const uint32_t* mbase = reinterpret_cast<const uint32_t*>(a.masks + (l - 1) * a.mask_layer_stride) + group * 256 + lane;
-      uint16_t* dbase = a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, 0, 0);
+      uint16_t* dbase = a.dzT + (l - 1) * a.layer_stride + image_off(group, 8, 0);
       uint32_t pv[2][4][2];          // bf16 pairs of the stage whose epilogue is in flight
       uint32_t pm = 0;               // this lane's mask dword of that stage
       // one pair (registers 2 j, 2 j + 1 of block `which`) of the pending epilogue
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
           const int R = 2 * qp + which;
           bnext[2 * R] = u4{pv[which][0][0], pv[which][0][1], pv[which][1][0], pv[which][1][1]};
           bnext[2 * R + 1] = u4{pv[which][2][0], pv[which][2][1], pv[which][3][0], pv[which][3][1]};
-          image_store(pv[which], dbase + image_off(0, 8, R, 0), lane);
+          image_store(pv[which], dbase + image_off(0, 8, R), lane);
         }
       };
       auto load_masks = [&](int qp) { pm = mbase[qp * 64]; };
@@ -587,18 +587,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1, n = lane & 31, hh = lane >> 5;
   u4 sa[8], sb[C::kBPieces];
-  // a 64-row chunk of an image with NBLK blocks: piece p = ((rg * NBLK + R) * 64 + L) * 2 + h16 (linear in memory)
+  // a 64-row chunk of an image with NBLK blocks: thread-piece p = ((rg * NBLK + R) * 64 + L) * 2 + h16 is the 16-byte piece h16
+  // of lane L of block rR; in memory that piece sits at index mem_of(p) (the two pieces of a lane are 1 KiB apart, s2l_bf16.h),
+  // in LDS the two are adjacent again (32-byte rows) -- consecutive threads write consecutive 16 bytes of LDS and read two
+  // 512-byte runs of memory per wave instruction
+  auto mem_of = [](int p) { return (p & ~127) | ((p & 1) << 6) | ((p >> 1) & 63); };
   auto lds_of = [](int p, int nblk, int base_half) {
     const int h16 = p & 1, L = (p >> 1) & 63, rR = p >> 7;   // rR = rg * nblk + R
     return (base_half + rR * 2 + (L >> 5)) * kHalfBytes + (L & 31) * 32 + h16 * 16;
   };
   auto gload = [&](int tile) {
-    const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 64 * 256) + tid;
-    const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * 64 * KB) + tid;
+    const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 64 * 256);
+    const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * 64 * KB);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sa[k] = pa[256 * k];
+    for (int k = 0; k < 8; ++k) sa[k] = pa[mem_of(tid + 256 * k)];
 #pragma unroll
-    for (int k = 0; k < C::kBPieces; ++k) sb[k] = pb[256 * k];
+    for (int k = 0; k < C::kBPieces; ++k) sb[k] = pb[mem_of(tid + 256 * k)];
   };
   auto lstore = [&](int buf) {
     char* base = smem + buf * C::kBufBytes;
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void rows_to_image_kernel(const float* __restr
   f4 v = f4{0.f, 0.f, 0.f, 0.f};
   if (row < n_rows) v = *reinterpret_cast<const f4*>(x + row * K + f);
   const int R = f >> 5, a4 = (f & 31) >> 3, hh = (f >> 2) & 1;
-  uint16_t* dst = xT + image_off(row >> 5, K / 32, R, (int)(row & 31) + 32 * hh) + 4 * a4;
+  uint16_t* dst = xT + image_off(row >> 5, K / 32, R) + image_quad(a4, (int)(row & 31) + 32 * hh);
   *reinterpret_cast<u2*>(dst) = u2{pk2(v[0], v[1]), pk2(v[2], v[3])};
 }
 
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(256) void ensemble_rows_bf16_kernel(const float* __
     if (k0 == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;
   }
   const int R = k0 >> 5, a4 = (k0 & 31) >> 3, hh = (k0 >> 2) & 1;
-  *reinterpret_cast<u2*>(xT + image_off(row >> 5, 4, R, (int)(row & 31) + 32 * hh) + 4 * a4) = u2{pk2(val[0], val[1]), pk2(val[2], val[3])};
+  *reinterpret_cast<u2*>(xT + image_off(row >> 5, 4, R) + image_quad(a4, (int)(row & 31) + 32 * hh)) = u2{pk2(val[0], val[1]), pk2(val[2], val[3])};
 }
 
 // output layer: dWout[c][f] = sum_rows drgb[row][c] h7[row][f], dbout[c] = sum_rows drgb[row][c].  thread = (4-feature group,
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(256) void out_grad_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = 8 * rs + r;
-      const u2 w = *reinterpret_cast<const u2*>(h7T + image_off(grp, 8, R, row + 32 * hh) + 4 * a4);
+      const u2 w = *reinterpret_cast<const u2*>(h7T + image_off(grp, 8, R) + image_quad(a4, row + 32 * hh));
       const float h[4] = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
 #pragma unroll
       for (int e = 0; e < 4; ++e)

@@ -9,11 +9,11 @@ def bf(x: torch.Tensor) -> torch.Tensor:
 
 
 def tiles_to_rows(img_i16: torch.Tensor, n_layers: int, np_rows: int, feats: int = 256) -> torch.Tensor:
-    """int16 view of the bf16 image [L][np/32][feats/32][lane = n + 32 hh][4a + c] (feature 32R + 8a + 4hh + c of row n,
-    csrc/s2l_bf16.h) -> fp32 [L][np][feats]."""
+    """int16 view of the bf16 image [L][np/32][feats/32][half 2][lane = n + 32 hh][4 (a & 1) + c] (feature 32R + 8a + 4hh + c of
+    row n, a = 2 half + (a & 1); csrc/s2l_bf16.h) -> fp32 [L][np][feats]."""
     nb = feats // 32
-    t = img_i16.cpu().view(torch.bfloat16).to(torch.float32).reshape(n_layers, np_rows // 32, nb, 2, 32, 4, 4)   # L,G,R,hh,n,a,c
-    t = t.permute(0, 1, 4, 2, 5, 3, 6)                                                                           # L,G,n,R,a,hh,c
+    t = img_i16.cpu().view(torch.bfloat16).to(torch.float32).reshape(n_layers, np_rows // 32, nb, 2, 2, 32, 2, 4)   # L,G,R,half,hh,n,a1,c
+    t = t.permute(0, 1, 5, 2, 3, 6, 4, 7)                                                                          # L,G,n,R,half,a1,hh,c
     return t.reshape(n_layers, np_rows, feats)
 
 

@@ -31,6 +31,12 @@ VARIANTS = {
     "gstore_12": lambda i: [f"global_store_dwordx4 %5, v[40:43], %4 offset:{64 * ((i // 12) % 4)}"] if i % 12 == 0 else [],
     "gstore_4": lambda i: [f"global_store_dwordx4 %5, v[40:43], %4 offset:{64 * ((i // 4) % 4)}"] if i % 4 == 0 else [],
     "gstore_burst16": lambda i: [f"global_store_dwordx4 %5, v[40:43], %4 offset:{64 * (k % 4)}" for k in range(16)] if i == 0 else [],
+    # the same store rate with other address patterns: 16 B per lane at a 32-byte pitch (the bf16 images' two half-stores:
+    # 32 half-filled 64-byte sectors per instruction) and at a 16-byte pitch (1 KiB contiguous: 16 full sectors)
+    "gstore_4_pitch32": lambda i: [f"global_store_dwordx4 %6, v[40:43], %4 offset:{16 * ((i // 4) % 2)}"] if i % 4 == 0 else [],
+    "gstore_4_pitch16": lambda i: [f"global_store_dwordx4 %7, v[40:43], %4 offset:{1024 * ((i // 4) % 2)}"] if i % 4 == 0 else [],
+    "gstore_8_pitch32": lambda i: [f"global_store_dwordx4 %6, v[40:43], %4 offset:{16 * ((i // 8) % 2)}"] if i % 8 == 0 else [],
+    "gstore_8_pitch16": lambda i: [f"global_store_dwordx4 %7, v[40:43], %4 offset:{1024 * ((i // 8) % 2)}"] if i % 8 == 0 else [],
     "accwrite": lambda i: [f"v_accvgpr_write_b32 a{16 + i % 12}, v{40 + i % 12}"],
 }
 NMF = 144
@@ -74,7 +80,8 @@ for n, (name, fn) in enumerate(VARIANTS.items()):
   asm volatile(
 {body(fn, name)}
       : "=v"(r) : "s"(iters), "v"(threadIdx.x & 63), "v"(threadIdx.x + 1024), "s"(sink),
-        "v"((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4096 + (threadIdx.x & 15) * 256 + ((threadIdx.x >> 4) & 3) * 16)
+        "v"((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4096 + (threadIdx.x & 15) * 256 + ((threadIdx.x >> 4) & 3) * 16),
+        "v"((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4096 + (threadIdx.x & 63) * 32), "v"((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4096 + (threadIdx.x & 63) * 16)
       : {", ".join('"%s"' % c for c in clob)});
   long long t1 = __builtin_readcyclecounter();
   out[blockIdx.x * 256 + threadIdx.x] = r + lds[threadIdx.x ^ 1];
