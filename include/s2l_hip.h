@@ -439,10 +439,10 @@ int s2l_ensemble_rows_bf16(const float* packed, const float* coords, const float
                            int64_t n_frames, s2l_stream_t stream);
 int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32, const uint16_t* xT, uint16_t* hT,
                            uint64_t* masks, float* rgb, int64_t n_rows, s2l_stream_t stream);
-/* The bf16 forward exists twice: the C++ kernel (32 rows per wave, two waves per SIMD; the default) and a generated gfx950
- * assembly kernel (csrc/gen_fwd16_body.py: 64 rows per wave, one wave per SIMD) that performs the same arithmetic in the same
- * order -- images, masks and rgb are bit-identical -- and currently runs at the same speed (see train_bf16.hip).
- * kind: 0 = C++ (default), 1 = assembly.  Process-wide (an atomic). */
+/* The bf16 forward exists twice: a generated gfx950 assembly kernel (csrc/gen_fwd16_body.py: 64 rows per wave, one wave per
+ * SIMD; the default) and the C++ kernel it replaced (32 rows per wave, two waves per SIMD), which performs the same arithmetic
+ * in the same order -- images, masks and rgb are bit-identical (tests switch between the two).
+ * kind: 0 = assembly (default), 1 = C++.  Process-wide (an atomic). */
 int s2l_set_bf16_forward_kernel(int kind);
 int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
                             float* dxa, int64_t n_rows, s2l_stream_t stream);

@@ -19,15 +19,15 @@ fwd_bf16_kernel: activation images, mask dwords and rgb are bit-identical.
   * the images of a stage are stored during the NEXT stage: four stores behind MFMAs of its k-loop, four between the pairs of its
     epilogue (16 B per lane and clock is all the store path takes).
 
-State: bit-identical, and as fast as the C++ kernel, not faster -- 3.3 ms, of which the MFMAs are 1.0; PMC: the
-texture path is 59 % busy, the waves spend 30 % of their cycles in s_waitcnt.  S2L_FWD_EXP builds ablate stores / epilogue /
-MFMAs / DMA / barrier for the next attempt.
+State: bit-identical; 3.04 ms against the C++ kernel's 3.3-3.4 ms.  S2L_FWD_EXP builds ablate stores / epilogue /
+MFMAs / DMA / barrier, S2L_FWD_TRACE=1 builds time the phases of every stage (tools/trace_fwd16.py).
 
 Layer bodies: A (layer 0: x only, -> P), B (h from P -> Q: layers 1, 3, 7), C (h from Q -> P: 2, 4, 6), D (layer 5: x + h from P ->
 Q); four stages each, sequenced by a scalar layer counter."""
 import os
 import sys
 
+TRACE = os.environ.get("S2L_FWD_TRACE") == "1"      # experiment builds (tools/trace_fwd16.py): per-stage phase timestamps of wave 0
 EXP = int(os.environ.get("S2L_FWD_EXP", "0"))      # timing experiments (results wrong): 1 no image stores, 2 no epilogue VALU, 4 no MFMAs, 8 no stage DMA, 16 no barrier
 SLAB_H, SLAB_X = 16384, 8192            # bytes
 STAGE = 2 * SLAB_X + 2 * SLAB_H         # 49152
@@ -73,9 +73,9 @@ def _scalar_map(first, singles, pairs, skip=(32, 33)):
 
 S = _scalar_map(8,
                 singles="LDSB WAVE TILE NTILES GRID L ST T0 T1 T2 T3 NX NH ONE PENDOK BXF MDST G0 NROWS".split(),
-                pairs=("KARG", "WB", "XT", "HT", "MASKS", "RGB", "LSTR", "MSTR", "WP", "HTL", "MKL", "PEND", "XTN", "XTA", "EX"))
+                pairs=("KARG", "WB", "XT", "HT", "MASKS", "RGB", "LSTR", "MSTR", "WP", "HTL", "MKL", "PEND", "XTN", "XTA", "EX") + (("TRACE", "TS", "TA") if TRACE else ()))
 S_LAST = max(S.values())
-assert S_LAST <= 95, S_LAST
+assert S_LAST <= 101, S_LAST
 
 
 def s(n):
@@ -121,6 +121,28 @@ class Body:
             self.e("s_waitcnt lgkmcnt(0)")
             self.lds = []
 
+    def trace(self, slot):
+        """experiment builds: wave 0 stores s_memtime to trace[(TILE * 32 + ST) * 8 + slot]"""
+        if not TRACE:
+            return
+        e = self.e
+        skip = self.label("notrace")
+        e(f"s_memtime {s2('TS')}")
+        e(f"s_cmp_eq_u64 {s2('TRACE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u32 {s('WAVE')}, 0")
+        e(f"s_cbranch_scc0 {skip}")
+        e(f"s_lshl_b32 {s('TA')}, {s('TILE')}, 5")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {s('ST')}")
+        e(f"s_lshl_b32 {s('TA')}, {s('TA')}, 6")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {8 * slot}")
+        e(f"s_add_u32 {s('TA')}, {s('TRACE')}, {s('TA')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('TRACE1')}, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_store_dwordx2 {s2('TS')}, {s2('TA')}, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"{skip}:")
+
     # ------------------------------------------------------------------ registers
     @staticmethod
     def acc(which, nb):
@@ -137,44 +159,42 @@ class Body:
         return aq(A_BX + nb * 32 + t * 4)
 
     # ------------------------------------------------------------------ per-stage scalar set-up
-    def stage_setup(self, q):
-        """next stage: WP = its global address, MDST = LDS address of this wave's part of the other buffer, NX / NH"""
-        e = self.e
-        e(f"s_add_u32 {s('T0')}, {s('ST')}, 1")
-        e(f"s_and_b32 {s('T0')}, {s('T0')}, 31")
-        e(f"s_mul_i32 {s('T1')}, {s('T0')}, {STAGE}")
-        e(f"s_add_u32 {s('WP')}, {s('WB')}, {s('T1')}")
-        e(f"s_addc_u32 {s('WP1')}, {s('WB1')}, 0")
-        e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10")
-        e(f"s_add_u32 {s('T1')}, {s('T1')}, {((q + 1) & 1) * STAGE}")
-        e(f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}")
-        e(f"s_lshr_b32 {s('T1')}, {s('T0')}, 2")                   # layer of the next stage
-        e(f"s_cmp_lg_u32 {s('T1')}, 0")
-        e(f"s_cselect_b32 {s('NH')}, 1, 0")
-        e(f"s_cmp_eq_u32 {s('T1')}, 0")
-        e(f"s_cselect_b32 {s('NX')}, 1, 0")
-        e(f"s_cmp_eq_u32 {s('T1')}, 5")
-        e(f"s_cselect_b32 {s('NX')}, 1, {s('NX')}")
-        e(f"s_cmp_eq_u32 {s('T0')}, 31")
-        e(f"s_cselect_b32 {s('NX')}, 1, {s('NX')}")
-        # bias of the next stage: layer T1, blocks 2 (q + 1) & 7 ...
-        e(f"s_lshl_b32 {s('T1')}, {s('T1')}, 10")
-        e(f"v_add_u32 v{V_BN}, {s('T1')}, v{V_BIAS0}")
-
-    def dma_items(self):
-        items = []
-        for k in range(12):
-            flag = "NX" if k < 4 else "NH"
-            skip = self.label("nodma")
-            items.append([f"s_mov_b32 m0, {s('MDST')}",
-                          f"s_cmp_eq_u32 {s(flag)}, 0",
-                          f"s_cbranch_scc1 {skip}",
-                          None if EXP & 8 else f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}",
-                          f"{skip}:",
-                          f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096",
-                          f"s_add_u32 {s('WP')}, {s('WP')}, 4096",
-                          f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"])
-        return items
+    def stage_program(self, kind, q):
+        """the next stage's set-up (WP = its global address, MDST = LDS address of this wave's part of the other buffer, V_BN = bias
+        base of its layer) and its LDS-DMA, as groups of at most four instructions, one group per MFMA slot.  Which parts the
+        next stage needs is static except at three layer ends, where the instruction is skipped inside its own group."""
+        st = lambda *xs: list(xs)
+        # (x part, h part) of the next stage: True / False / (runtime: scalar L equals value -> present) / ("ne", value)
+        if kind == "A":
+            need = (True, False) if q < 3 else (False, True)
+        elif kind == "D":
+            need = (True, True) if q < 3 else (False, True)
+        elif kind == "C":
+            need = (False, True) if q < 3 else (("eq", 4), True)
+        else:
+            need = (False, True) if q < 2 else ((("eq", 7), True) if q == 2 else (("eq", 7), ("ne", 7)))
+        groups = [st(f"s_add_u32 {s('T0')}, {s('ST')}, 1", f"s_and_b32 {s('T0')}, {s('T0')}, 31", f"s_mul_i32 {s('T1')}, {s('T0')}, {STAGE}"),
+                  st(f"s_add_u32 {s('WP')}, {s('WB')}, {s('T1')}", f"s_addc_u32 {s('WP1')}, {s('WB1')}, 0", f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10"),
+                  st(f"s_add_u32 {s('T1')}, {s('T1')}, {((q + 1) & 1) * STAGE}", f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}",
+                     f"s_lshr_b32 {s('T1')}, {s('T0')}, 2"),
+                  st(f"s_lshl_b32 {s('T1')}, {s('T1')}, 10", f"v_add_u32 v{V_BN}, {s('T1')}, v{V_BIAS0}")]
+        for part, n_instr, present in (("x", 4, need[0]), ("h", 8, need[1])):
+            if present is False:
+                groups.append(st(f"s_add_u32 {s('MDST')}, {s('MDST')}, {4096 * n_instr}", f"s_add_u32 {s('WP')}, {s('WP')}, {4096 * n_instr}",
+                                 f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"))
+                continue
+            for k in range(n_instr):
+                g = [f"s_mov_b32 m0, {s('MDST')}"]
+                load = None if EXP & 8 else f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}"
+                if present is True:
+                    g += ["s_nop 0", load]
+                else:
+                    skip = self.label("nodma")
+                    g += [f"s_cmp_{'lg' if present[0] == 'eq' else 'eq'}_u32 {s('L')}, {present[1]}", f"s_cbranch_scc1 {skip}", load, f"{skip}:"]
+                groups.append(g)
+                groups.append(st(f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096", f"s_add_u32 {s('WP')}, {s('WP')}, 4096",
+                                 f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"))
+        return groups
 
     def store_items(self, setname, qprev, guarded):
         """the eight image stores of the stage before (blocks 2 qprev, 2 qprev + 1 of `setname`) at PEND"""
@@ -268,31 +288,42 @@ class Body:
 
     # ------------------------------------------------------------------ epilogue of a stage
     def epilogue(self, q, outset, items=()):
-        """items: instruction groups spread evenly between the pairs"""
+        """bf16, ReLU, mask bits: batches of four pairs (independent instructions back to back; one update of the mask dword per
+        batch, in the order of fwd_bf16_kernel: which, pair); items: instruction groups, one behind each batch"""
         e = self.e
         items = list(items)
-        gap = 32 // (len(items) + 1) if items else 0
-        npair = 0
         e("s_nop 7")
         e("s_nop 7")
         e("s_nop 7")
         for nb in range(2):
             e(f"v_mov_b32 v{V_M[nb]}, 0")
-        for nb in range(2):
-            for which in range(2):
-                R = 2 * q + which
-                for d8 in range(0 if EXP & 2 else 8):
-                    src = V_ACC + (which * 2 + nb) * 16 + 2 * d8
-                    dst = nb * 64 + (2 * R + (d8 >> 2)) * 4 + (d8 & 3)
-                    d = f"v{V_P + dst}" if outset == "P" else f"v{V_T + (d8 & 3)}"
-                    e(f"v_cvt_pk_bf16_f32 {d}, v{src}, v{src + 1}")
-                    e(f"v_pk_max_i16 {d}, {d}, 0")
-                    e(f"v_pk_min_u16 v{V_T + 4 + (d8 & 3)}, {d}, {s('ONE')}")
-                    e(f"v_lshl_or_b32 v{V_M[nb]}, v{V_M[nb]}, 1, v{V_T + 4 + (d8 & 3)}")
+        for which in range(2):
+            R = 2 * q + which
+            for g4 in range(2):
+                for nb in range(2):
+                    if EXP & 2:
+                        continue
+                    ds, ts = [], []
+                    for k in range(4):
+                        d8 = 4 * g4 + k
+                        src = V_ACC + (which * 2 + nb) * 16 + 2 * d8
+                        dst = nb * 64 + (2 * R + g4) * 4 + k
+                        d = f"v{V_P + dst}" if outset == "P" else f"v{V_T + k}"
+                        ds.append((d, dst))
+                        ts.append(f"v{V_T + 4 + k}")
+                        e(f"v_cvt_pk_bf16_f32 {d}, v{src}, v{src + 1}")
+                    for d, _ in ds:
+                        e(f"v_pk_max_i16 {d}, {d}, 0")
+                    for (d, _), tt in zip(ds, ts):
+                        e(f"v_pk_min_u16 {tt}, {d}, {s('ONE')}")
                     if outset == "Q":
-                        e(f"v_accvgpr_write_b32 a{A_Q + dst}, {d}")
-                    npair += 1
-                    if items and npair % gap == 0:
+                        for d, dst in ds:
+                            e(f"v_accvgpr_write_b32 a{A_Q + dst}, {d}")
+                    e(f"v_lshl_or_b32 {ts[0]}, {ts[0]}, 1, {ts[1]}")          # t0 t1
+                    e(f"v_lshl_or_b32 {ts[2]}, {ts[2]}, 1, {ts[3]}")          # t2 t3
+                    e(f"v_lshl_or_b32 {ts[0]}, {ts[0]}, 2, {ts[2]}")          # t0 t1 t2 t3
+                    e(f"v_lshl_or_b32 v{V_M[nb]}, v{V_M[nb]}, 4, {ts[0]}")
+                    if items:
                         for x in items.pop(0):
                             if x is not None:
                                 e(x)
@@ -302,7 +333,7 @@ class Body:
                     e(x)
         for nb in range(2):
             e(f"global_store_dword v{V_LANE4}, v{V_M[nb]}, {s2('MKL')} offset:{nb * 1024 + q * 256}")
-        # the images of this stage are stored behind the next stage's MFMAs
+        # the images of this stage are stored during the next stage
         e(f"s_add_u32 {s('PEND')}, {s('HTL')}, {q * 4096}")
         e(f"s_addc_u32 {s('PEND1')}, {s('HTL1')}, 0")
         e(f"s_mov_b32 {s('PENDOK')}, 1")
@@ -340,27 +371,32 @@ class Body:
             e(f"s_add_u32 {s('T2')}, {s('T2')}, {s('T3')}")
             self.xt_pointer("T2")
         for q in range(4):
-            self.stage_setup(q)
-            items = self.dma_items()
             st = self.store_items(inset, 3, guarded=(kind == "A")) if q == 0 else self.store_items(outset, q - 1, guarded=False)
-            # The texture path serves one 1-KiB store per 64 cycles and CU (256 per wave) and a DMA instruction in ~20: four of
-            # the eight stores go first, one behind every eighth MFMA, the twelve DMA instructions behind them; the wait + barrier
-            # sit right behind the k-loop (the DMA is old by then), the other four stores ride in the epilogue and have a whole
-            # stage until the next wait.
+            # tools/trace_fwd16.py: the next stage's set-up and DMA ride behind the first MFMAs, at most four scalar / memory
+            # instructions per MFMA (a longer run lets the matrix pipe drain), so that the DMA is old when the wait right behind the
+            # k-loop asks for it; the eight stores ride between the batches of the epilogue (behind the wait: they have a whole
+            # stage until the next one; the texture path takes 40 cycles per contiguous 1-KiB store)
+            prog = self.stage_program(kind, q)
+            mixed = [(1 + k, g) for k, g in enumerate(prog)]
             nmf_total = sum(8 if p == "x" else 16 for p, _ in parts) * 4
-            sgap = 8 if nmf_total >= 64 else 2
-            dgap = max(1, (nmf_total - 4 * sgap - 2) // 12)
-            mixed = [(2 + sgap * k, st[k]) for k in range(4)] + [(2 + 4 * sgap + dgap * k, items[k]) for k in range(12)]
-            late = st[4:]
+            nk = int(os.environ.get("S2L_FWD_KSTORES", "0")) if nmf_total >= 64 else 0      # stores that ride in the k-loop's tail
+            first = max(len(prog) + 2, nmf_total - 30)
+            mixed += [(first + 10 * k, st[k]) for k in range(nk)]
+            late = st[nk:]
             if kind == "C" and q < 2:
                 late = late + self.bx_items(q)
             # the next stage's bias quads are read once this stage's first MFMAs (which take V_BIAS as C) have been issued
             self.lds = []
+            self.trace(0)
             self.kloop(q & 1, parts, mixed, 1, lds_after=(8, self.bias_reads((q + 1) & 3)))
+            self.trace(1)
             e("s_waitcnt vmcnt(0) lgkmcnt(0)")      # the next stage has landed (this wave's part); nobody reads this buffer any more
+            self.trace(2)
             if not EXP & 16:
                 e("s_barrier")
+            self.trace(3)
             self.epilogue(q, outset, late)
+            self.trace(4)
             e(f"s_add_u32 {s('ST')}, {s('ST')}, 1")
             e(f"s_and_b32 {s('ST')}, {s('ST')}, 31")
             if kind == "B" and q == 3:
@@ -415,6 +451,8 @@ class Body:
         e = self.e
         for dst, src in (("LDSB", "ldsbase"), ("WAVE", "wave"), ("TILE", "tile0"), ("GRID", "grid")):
             e(f"s_mov_b32 {s(dst)}, %[{src}]")
+        if TRACE:
+            e(f"s_mov_b64 {s2('TRACE')}, %[trace]")
         e(f"s_mov_b64 {s2('KARG')}, %[karg]")
         for dst, off in (("WB", "owb"), ("XT", "oxt"), ("HT", "oht"), ("MASKS", "omasks"), ("RGB", "orgb"), ("LSTR", "olstr"),
                          ("MSTR", "omstr")):
@@ -507,6 +545,8 @@ class Body:
             for x in it:
                 e(x)
         e("s_waitcnt vmcnt(0)")
+        if TRACE:
+            e("s_dcache_wb")
         e(f"{done}:")
         return [x for x in self.L if x is not None]
 
@@ -534,7 +574,7 @@ def main(outdir):
             + [f"s{r}" for r in range(8, S_LAST + 1) if r not in (32, 33)] + ["vcc", "scc", "memory"])
     out = ["// GENERATED by csrc/gen_fwd16_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]
-    out.append(OPERANDS.rstrip("\n"))
+    out.append(OPERANDS.rstrip("\n") + (', [trace] "s"(g_ftrace)' if TRACE else ""))
     out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
     with open(os.path.join(outdir, "fwd16_body.inc"), "w") as f:
         f.write("\n".join(out) + "\n")

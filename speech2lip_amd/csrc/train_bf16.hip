@@ -331,13 +331,15 @@ __global__ __launch_bounds__(512, 1) void fwd_bf16_kernel(FwdArgs a) {
 // ---- the forward kernel with its body as one fixed-register assembly text (csrc/gen_fwd16_body.py): 64 rows per wave, one wave
 // per SIMD, stages by LDS-DMA, every memory instruction behind an MFMA.  Same arithmetic in the same order as fwd_bf16_kernel:
 // images, mask dwords and rgb are bit-identical (tests/test_gpu_parity.py switches between the two with
-// s2l_set_bf16_forward_kernel).  NOT the default: it runs at the same 3.3 ms as the C++ kernel.  Its ablation builds
-// (S2L_FWD_EXP in the generator) say why: a stage's 80 KB of texture-path traffic (32 KB of image stores at 16 B/clk/CU + 48 KB
-// of stage DMA) take ~2 850 cycles, its MFMAs + epilogue + fixed costs ~3 900, and within one wave the two do not overlap
-// yet (a wave that finds the texture queue full stalls, and the stage-end vmcnt(0) cannot tell DMA from stores).  It is kept,
-// selectable and tested, as the base for that work.
+// s2l_set_bf16_forward_kernel).  3.04 ms against the C++ kernel's 3.3-3.4 ms for 64 frames of 96x96 (tools/bench_bf16_kernels.py);
+// tools/trace_fwd16.py (experiment build) gives the phases of a stage: k-loop 2 250 cycles (64 MFMAs = 2 048), wait 110, barrier
+// 120, epilogue 1 180 (its eight image stores keep the texture path busy for 1 280), 110 to the next k-loop.
 #ifndef S2L_FWD_ASM
 #define S2L_FWD_ASM 1
+#endif
+#ifdef S2L_EXP_TRACE   // experiment builds (generator run with S2L_FWD_TRACE=1, tools/trace_fwd16.py): per-stage timestamps
+__device__ unsigned long long* g_ftrace = nullptr;
+extern "C" int s2l_debug_set_fwd_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ftrace), &p, sizeof(p)); }
 #endif
 __global__ __launch_bounds__(256, 1) void fwd_asm_bf16_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -856,7 +858,7 @@ static int persistent_grid(const void* kernel, int lds_bytes, LdsOptIn& flags, i
   return 0;
 }
 
-// 0 = the C++ forward kernel (default), 1 = the assembly kernel (64 rows per wave): same bits
+// 0 = the assembly forward kernel (64 rows per wave; default), 1 = the C++ kernel: same bits
 static std::atomic<int> g_fwd_kernel_kind{0};
 extern "C" int s2l_set_bf16_forward_kernel(int kind) {
   if (kind != 0 && kind != 1) return S2L_E_SIZE;
@@ -877,7 +879,7 @@ extern "C" int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* 
   a.n_tiles = (int)(np / kWgRows);
   static LdsOptIn flags;
   int grid = 0;
-  if (S2L_FWD_ASM && g_fwd_kernel_kind.load(std::memory_order_relaxed) == 1 && n_rows < 0x7fffffff) {
+  if (S2L_FWD_ASM && g_fwd_kernel_kind.load(std::memory_order_relaxed) == 0 && n_rows < 0x7fffffff) {
     static LdsOptIn flags_asm;
     const int rc = persistent_grid(reinterpret_cast<const void*>(fwd_asm_bf16_kernel), kLdsFwd, flags_asm, a.n_tiles, &grid);
     if (rc) return rc;

@@ -239,8 +239,7 @@ def test_conv_body_generator_is_deterministic_and_complete(tmp_path):
 def test_fwd16_body_generator_is_deterministic_and_complete(tmp_path):
     """csrc/gen_fwd16_body.py writes the assembly form of the bf16 training forward (64 rows per wave).  Two runs give the same
     text; it holds the MFMAs of its four layer bodies -- layer 0: 4 stages x 32, layers of kind B / C: 4 x 64 each, layer 5:
-    4 x 96 -- plus the output layer's 32, one barrier per stage (+ the prime, + one behind the output layer), twelve stage-DMA
-    instructions per stage."""
+    4 x 96 -- plus the output layer's 32, one barrier per stage (+ the prime, + one behind the output layer), the stage DMA of the parts the next stage needs."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_fwd16_body", os.path.join(ROOT, "speech2lip_amd", "csrc", "gen_fwd16_body.py"))
     gen = importlib.util.module_from_spec(spec)
@@ -253,7 +252,9 @@ def test_fwd16_body_generator_is_deterministic_and_complete(tmp_path):
     assert text == open(b / "fwd16_body.inc").read()
     assert text.count("v_mfma_f32_32x32x16_bf16") == 4 * 32 + 2 * 4 * 64 + 4 * 96 + 32
     assert text.count("s_barrier") == 16 + 1 + 1                      # per stage, the prime, after the output layer
-    assert text.count("global_load_lds_dwordx4") == 16 * 12 + 4
+    # stage DMA: only the parts the next stage needs (x: 4 instructions, h: 8) -- layer 0: 3 x 4 + 8, layer 5: 3 x 12 + 8,
+    # kind C: 3 x 8 + (4 + 8), kind B: 2 x 8 + (4 + 8) + (4 + 8); + the prime's 4
+    assert text.count("global_load_lds_dwordx4") == 20 + 44 + 36 + 40 + 4
     assert text.count("global_store_dwordx4") == 16 * 8 + 8            # a stage's images behind the next stage's MFMAs, + the last
     assert '"v"(' not in text
 

@@ -640,8 +640,8 @@ def test_bf16_forward_matches_emulation(dev, h, w, B):
 
 @pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3), (96, 96, 6)])
 def test_bf16_forward_assembly_kernel_is_bit_identical(dev, h, w, B):
-    """The generated-assembly forward (csrc/gen_fwd16_body.py, 64 rows per wave; s2l_set_bf16_forward_kernel(1)) performs the
-    C++ kernel's arithmetic in its order: activation images, mask dwords and rgb are the same bits -- one tile per workgroup,
+    """The generated-assembly forward (csrc/gen_fwd16_body.py, 64 rows per wave; the default) performs the arithmetic of the
+    C++ kernel (s2l_set_bf16_forward_kernel(1)) in its order: activation images, mask dwords and rgb are the same bits -- one tile per workgroup,
     a partial last tile, and (96x96x6 = 864 tiles) several tiles per persistent workgroup."""
     from speech2lip_amd import _abi
     from speech2lip_amd.talking_face import _ptr, _stream
@@ -649,7 +649,7 @@ def test_bf16_forward_assembly_kernel_is_bit_identical(dev, h, w, B):
     Np = int(lib.s2l_bf16_rows_padded(N))
     outs = []
     try:
-        for kind in (1, 0):
+        for kind in (0, 1):
             assert lib.s2l_set_bf16_forward_kernel(kind) == 0
             hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
             masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)

@@ -27,7 +27,7 @@ work = torch.empty(int(lib.s2l_wgrad_bf16_work_floats()), device=dev)
 dw, db = torch.empty(256, 256, device=dev), torch.empty(256, device=dev)
 pb, pf = m.packed_weights_bf16(), m.packed_weights()
 
-if os.environ.get("S2L_FWD_KIND"):      # 1 = the assembly forward kernel
+if os.environ.get("S2L_FWD_KIND"):      # 1 = the C++ forward kernel instead of the assembly one
     assert lib.s2l_set_bf16_forward_kernel(int(os.environ["S2L_FWD_KIND"])) == 0
 
 def timed(fn, it=5):

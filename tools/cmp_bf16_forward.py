@@ -1,4 +1,4 @@
-"""A/B: the assembly bf16 forward (kind 1) against the C++ kernel (kind 0) on the same inputs (s2l_set_bf16_forward_kernel), per layer.
+"""A/B: the assembly bf16 forward (kind 0, the default) against the C++ kernel (kind 1) on the same inputs (s2l_set_bf16_forward_kernel), per layer.
     python tools/cmp_bf16_forward.py [rows=200000]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ xT = torch.zeros(Np * 128, dtype=torch.int16, device=dev)
 lib.s2l_rows_to_tiles_bf16(_ptr(x), 128, _ptr(xT), N, _stream())
 pb, pf = m.packed_weights_bf16(), m.packed_weights()
 outs = []
-for kind in (1, 0):
+for kind in (0, 1):
     assert lib.s2l_set_bf16_forward_kernel(kind) == 0
     hT = torch.zeros(8 * lay, dtype=torch.int16, device=dev)
     masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
