@@ -28,6 +28,8 @@ import os
 import sys
 
 TRACE = os.environ.get("S2L_FWD_TRACE") == "1"      # experiment builds (tools/trace_fwd16.py): per-stage phase timestamps of wave 0
+BX_MODE = os.environ.get("S2L_FWD_BX", "kloop")      # embedded rows of the next tile: "start" = loaded at its start (exposed), "epilogue" / "kloop" = prefetched in layer 6
+BX_AT_TILE_START = BX_MODE == "start"   # embedded rows of a tile: loaded at its start (exposed) or prefetched in layer 6
 EXP = int(os.environ.get("S2L_FWD_EXP", "0"))      # timing experiments (results wrong): 1 no image stores, 2 no epilogue VALU, 4 no MFMAs, 8 no stage DMA, 16 no barrier
 SLAB_H, SLAB_X = 16384, 8192            # bytes
 STAGE = 2 * SLAB_X + 2 * SLAB_H         # 49152
@@ -379,12 +381,17 @@ class Body:
             prog = self.stage_program(kind, q)
             mixed = [(1 + k, g) for k, g in enumerate(prog)]
             nmf_total = sum(8 if p == "x" else 16 for p, _ in parts) * 4
-            nk = int(os.environ.get("S2L_FWD_KSTORES", "0")) if nmf_total >= 64 else 0      # stores that ride in the k-loop's tail
-            first = max(len(prog) + 2, nmf_total - 30)
-            mixed += [(first + 10 * k, st[k]) for k in range(nk)]
+            nk = int(os.environ.get("S2L_FWD_KSTORES", "0")) if nmf_total >= 64 else 0      # stores that ride in the k-loop
+            if os.environ.get("S2L_FWD_KWHERE", "head") == "head":      # ahead of the set-up / DMA groups
+                mixed = [(1 + k, st[k]) for k in range(nk)] + [(1 + nk + k, g) for k, g in enumerate(prog)]
+            else:
+                first = max(len(prog) + 2, nmf_total - 30)
+                mixed += [(first + 10 * k, st[k]) for k in range(nk)]
             late = st[nk:]
-            if kind == "C" and q < 2:
+            if kind == "C" and q < 2 and BX_MODE == "epilogue":
                 late = late + self.bx_items(q)
+            if kind == "C" and q < 2 and BX_MODE == "kloop":      # behind the DMA groups: nothing else asks for the texture path for a while
+                mixed = mixed + [(len(mixed) + 2 + 2 * k, g) for k, g in enumerate(self.bx_items(q))]
             # the next stage's bias quads are read once this stage's first MFMAs (which take V_BIAS as C) have been issued
             self.lds = []
             self.trace(0)
@@ -539,7 +546,19 @@ class Body:
         e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 1")
         e(f"s_add_u32 {s('G0')}, {s('G0')}, {s('T0')}")
         e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
-        e("s_cbranch_scc1 S2LF_TILE")
+        if BX_AT_TILE_START:
+            e("s_cbranch_scc0 S2LF_LAST")
+            self.xt_pointer("G0")
+            for k in range(16):
+                nb, t = k >> 3, k & 7
+                e(f"s_add_u32 {s('XTA')}, {s('XTN')}, {nb * 8192 + (t >> 1) * 2048}")
+                e(f"s_addc_u32 {s('XTA1')}, {s('XTN1')}, 0")
+                e(f"global_load_dwordx4 {self.setreg('X', nb, t)}, v{V_LANE16}, {s2('XTA')} offset:{(t & 1) * 1024}")
+            e("s_waitcnt vmcnt(0)")
+            e("s_branch S2LF_TILE")
+            e("S2LF_LAST:")
+        else:
+            e("s_cbranch_scc1 S2LF_TILE")
         # ---- the last stage's images (blocks 6, 7 of layer 7: set Q)
         for it in self.store_items("Q", 3, guarded=False):
             for x in it:

@@ -54,3 +54,8 @@ for kind, stages in (("layer 0 (x only: 32 MFMAs)", range(0, 4)), ("layer 5 (x +
     print(f"   {names[4]:24s} median {np.median(v):7.0f}  p10 {np.percentile(v, 10):7.0f}  p90 {np.percentile(v, 90):7.0f}")
 tot = t[:, 31, 4] - t[:, 0, 0]
 print(f"tile (32 stages) median {np.median(tot):.0f} cycles = {np.median(tot) / 32:.0f} per stage")
+if os.environ.get("S2L_TRACE_DETAIL"):
+    print("per stage: median k-loop / wait / epilogue, and p90 of the k-loop")
+    for s_ in range(32):
+        print(f"  stage {s_:2d} (layer {s_ >> 2} q {s_ & 3}): {np.median(d[:, s_, 0]):6.0f} {np.median(d[:, s_, 1]):6.0f} {np.median(d[:, s_, 3]):6.0f}   p90 {np.percentile(d[:, s_, 0], 90):6.0f}"
+              f"   tile-order effect: first tile of a workgroup {np.median(d[:256, s_, 0]):6.0f}, later {np.median(d[256:, s_, 0]):6.0f}")
