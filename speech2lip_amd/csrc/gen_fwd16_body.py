@@ -75,7 +75,7 @@ def _scalar_map(first, singles, pairs, skip=(32, 33)):
 
 S = _scalar_map(8,
                 singles="LDSB WAVE TILE NTILES GRID L ST T0 T1 T2 T3 NX NH ONE PENDOK BXF MDST G0 NROWS".split(),
-                pairs=("KARG", "WB", "XT", "HT", "MASKS", "RGB", "LSTR", "MSTR", "WP", "HTL", "MKL", "PEND", "XTN", "XTA", "EX") + (("TRACE", "TS", "TA") if TRACE else ()))
+                pairs=("KARG", "WB", "XT", "HT", "MASKS", "RGB", "LSTR", "MSTR", "WP", "HTL", "MKL", "PEND", "XTN", "XTA", "EX", "WQ") + (("TRACE", "TS", "TA") if TRACE else ()))
 S_LAST = max(S.values())
 assert S_LAST <= 101, S_LAST
 
@@ -162,11 +162,12 @@ class Body:
 
     # ------------------------------------------------------------------ per-stage scalar set-up
     def stage_program(self, kind, q):
-        """the next stage's set-up (WP = its global address, MDST = LDS address of this wave's part of the other buffer, V_BN = bias
-        base of its layer) and its LDS-DMA, as groups of at most four instructions, one group per MFMA slot.  Which parts the
-        next stage needs is static except at three layer ends, where the instruction is skipped inside its own group."""
-        st = lambda *xs: list(xs)
-        # (x part, h part) of the next stage: True / False / (runtime: scalar L equals value -> present) / ("ne", value)
+        """the next stage's set-up (its global address, the other LDS buffer, V_BN = bias base of its layer) and its LDS-DMA, as
+        groups of at most five instructions, one group per MFMA slot.  A wave copies CONTIGUOUS pieces -- 4 KiB of the X part,
+        8 KiB of the H part -- so that four DMA instructions share one base and one M0 (the instruction offset moves both the
+        global and the LDS address): 12 loads and ~22 scalar instructions per stage.  Which parts the next stage needs is
+        static except at three layer ends, where the loads are skipped inside their own group."""
+        # (x part, h part) of the next stage: True / False / ("eq" | "ne", value of the scalar L for which it is present)
         if kind == "A":
             need = (True, False) if q < 3 else (False, True)
         elif kind == "D":
@@ -175,27 +176,37 @@ class Body:
             need = (False, True) if q < 3 else (("eq", 4), True)
         else:
             need = (False, True) if q < 2 else ((("eq", 7), True) if q == 2 else (("eq", 7), ("ne", 7)))
-        groups = [st(f"s_add_u32 {s('T0')}, {s('ST')}, 1", f"s_and_b32 {s('T0')}, {s('T0')}, 31", f"s_mul_i32 {s('T1')}, {s('T0')}, {STAGE}"),
-                  st(f"s_add_u32 {s('WP')}, {s('WB')}, {s('T1')}", f"s_addc_u32 {s('WP1')}, {s('WB1')}, 0", f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10"),
-                  st(f"s_add_u32 {s('T1')}, {s('T1')}, {((q + 1) & 1) * STAGE}", f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}",
-                     f"s_lshr_b32 {s('T1')}, {s('T0')}, 2"),
-                  st(f"s_lshl_b32 {s('T1')}, {s('T1')}, 10", f"v_add_u32 v{V_BN}, {s('T1')}, v{V_BIAS0}")]
-        for part, n_instr, present in (("x", 4, need[0]), ("h", 8, need[1])):
-            if present is False:
-                groups.append(st(f"s_add_u32 {s('MDST')}, {s('MDST')}, {4096 * n_instr}", f"s_add_u32 {s('WP')}, {s('WP')}, {4096 * n_instr}",
-                                 f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"))
-                continue
-            for k in range(n_instr):
-                g = [f"s_mov_b32 m0, {s('MDST')}"]
-                load = None if EXP & 8 else f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}"
-                if present is True:
-                    g += ["s_nop 0", load]
-                else:
-                    skip = self.label("nodma")
-                    g += [f"s_cmp_{'lg' if present[0] == 'eq' else 'eq'}_u32 {s('L')}, {present[1]}", f"s_cbranch_scc1 {skip}", load, f"{skip}:"]
-                groups.append(g)
-                groups.append(st(f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096", f"s_add_u32 {s('WP')}, {s('WP')}, 4096",
-                                 f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0"))
+        groups = [[f"s_add_u32 {s('T0')}, {s('ST')}, 1", f"s_and_b32 {s('T0')}, {s('T0')}, 31", f"s_mul_i32 {s('T1')}, {s('T0')}, {STAGE}"],
+                  [f"s_add_u32 {s('WP')}, {s('WB')}, {s('T1')}", f"s_addc_u32 {s('WP1')}, {s('WB1')}, 0",
+                   f"s_add_u32 {s('T3')}, {s('LDSB')}, {((q + 1) & 1) * STAGE}"],
+                  [f"s_lshr_b32 {s('T1')}, {s('T0')}, 2", f"s_lshl_b32 {s('T1')}, {s('T1')}, 10", f"v_add_u32 v{V_BN}, {s('T1')}, v{V_BIAS0}"]]
+
+        def loads(present, offs):
+            out = []
+            skip = self.label("nodma")
+            if present is not True:
+                out += [f"s_cmp_{'lg' if present[0] == 'eq' else 'eq'}_u32 {s('L')}, {present[1]}", f"s_cbranch_scc1 {skip}"]
+            for o in offs:
+                if not EXP & 8:
+                    out.append(f"global_load_lds_dwordx4 v{V_LANE16}, {s2('WQ')} offset:{o}")
+            if present is not True:
+                out.append(f"{skip}:")
+            return out
+        if need[0] is not False:      # X part: bytes [4096 wave, + 4096) of the stage
+            groups.append([f"s_lshl_b32 {s('T2')}, {s('WAVE')}, 12", f"s_add_u32 {s('WQ')}, {s('WP')}, {s('T2')}", f"s_addc_u32 {s('WQ1')}, {s('WP1')}, 0",
+                           f"s_add_u32 {s('MDST')}, {s('T3')}, {s('T2')}", f"s_mov_b32 m0, {s('MDST')}"])
+            groups.append(loads(need[0], (0, 1024)))
+            groups.append(loads(need[0], (2048, 3072)))
+        if need[1] is not False:      # H part: bytes [16384 + 8192 wave, + 8192)
+            groups.append([f"s_lshl_b32 {s('T2')}, {s('WAVE')}, 13", f"s_add_u32 {s('T2')}, {s('T2')}, 16384", f"s_add_u32 {s('WQ')}, {s('WP')}, {s('T2')}",
+                           f"s_addc_u32 {s('WQ1')}, {s('WP1')}, 0"])
+            groups.append([f"s_add_u32 {s('MDST')}, {s('T3')}, {s('T2')}", f"s_mov_b32 m0, {s('MDST')}"])
+            groups.append(loads(need[1], (0, 1024)))
+            groups.append(loads(need[1], (2048, 3072)))
+            groups.append([f"s_add_u32 {s('WQ')}, {s('WQ')}, 4096", f"s_addc_u32 {s('WQ1')}, {s('WQ1')}, 0", f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096",
+                           f"s_mov_b32 m0, {s('MDST')}"])
+            groups.append(loads(need[1], (0, 1024)))
+            groups.append(loads(need[1], (2048, 3072)))
         return groups
 
     def store_items(self, setname, qprev, guarded):
@@ -497,16 +508,14 @@ class Body:
         done = "S2LF_DONE"
         e(f"s_cmp_lt_u32 {s('TILE')}, {s('NTILES')}")
         e(f"s_cbranch_scc0 {done}")
-        e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 10")
-        e(f"s_add_u32 {s('MDST')}, {s('T1')}, {s('LDSB')}")
-        e(f"s_mov_b64 {s2('WP')}, {s2('WB')}")
-        for k in range(4):
-            e(f"s_mov_b32 m0, {s('MDST')}")
-            e("s_nop 0")
-            e(f"global_load_lds_dwordx4 v{V_DMAOFF}, {s2('WP')}")
-            e(f"s_add_u32 {s('MDST')}, {s('MDST')}, 4096")
-            e(f"s_add_u32 {s('WP')}, {s('WP')}, 4096")
-            e(f"s_addc_u32 {s('WP1')}, {s('WP1')}, 0")
+        e(f"s_lshl_b32 {s('T2')}, {s('WAVE')}, 12")
+        e(f"s_add_u32 {s('WQ')}, {s('WB')}, {s('T2')}")
+        e(f"s_addc_u32 {s('WQ1')}, {s('WB1')}, 0")
+        e(f"s_add_u32 {s('MDST')}, {s('LDSB')}, {s('T2')}")
+        e(f"s_mov_b32 m0, {s('MDST')}")
+        e("s_nop 0")
+        for o in (0, 1024, 2048, 3072):
+            e(f"global_load_lds_dwordx4 v{V_LANE16}, {s2('WQ')} offset:{o}")
         e(f"s_lshl_b32 {s('G0')}, {s('TILE')}, 3")
         e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 1")
         e(f"s_add_u32 {s('G0')}, {s('G0')}, {s('T0')}")
