@@ -746,23 +746,27 @@ __global__ __launch_bounds__(256) void ensemble_rows_bf16_kernel(const float* __
                                                                 const float* __restrict__ u01, EnsBatch sh, uint16_t* __restrict__ xT,
                                                                 float* __restrict__ areas, int64_t n_pix, int64_t n_rows,
                                                                 int64_t n_padded) {
+  // thread = one 16-byte piece of the image: (row group, block R, half, lane = row + 32 hh) holds features
+  // 32 R + 16 half + 4 hh + {0..3} and the same + 8; consecutive threads write consecutive 16 bytes
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t row = t >> 5;
+  const int64_t grp = t >> 9;
+  const int p = (int)(t & 511), R = p >> 7, half = (p >> 6) & 1, lane = p & 63, hh = lane >> 5;
+  const int64_t row = grp * kGroupRows + (lane & 31);
   if (row >= n_padded) return;
-  const int k0 = (int)(t & 31) * 4;
-  f4 val = f4{0.f, 0.f, 0.f, 0.f};
+  const int k0 = 32 * R + 16 * half + 4 * hh;
+  float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (row < n_rows) {
-    const int64_t bt = row / n_pix, p = row - bt * n_pix;
+    const int64_t bt = row / n_pix, px = row - bt * n_pix;
     const int tap = (int)(bt & 3);
     const int64_t b = bt >> 2;
     const float eps = sh.ry * u01[b] / 2.0f;
-    const float u0 = coords[2 * p], v0 = coords[2 * p + 1];
+    const float u0 = coords[2 * px], v0 = coords[2 * px + 1];
     const float cu = fminf(fmaxf(u0 + (sh.dx[tap >> 1] + eps), 0.f), 1.f);
     const float cv = fminf(fmaxf(v0 + (sh.dy[tap & 1] + eps), 0.f), 1.f);
     const float time_pos = (float)tidx[b];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + j;
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + (j & 3) + 8 * (j >> 2);
       float v;
       if (k < kEmb) v = embed16(cu, cv, k);
       else if (k < kEmb + kAud) v = feat[b * kAud + (k - kEmb)];
@@ -775,8 +779,8 @@ __global__ __launch_bounds__(256) void ensemble_rows_bf16_kernel(const float* __
     }
     if (k0 == 0) areas[row] = fabsf((cu - u0) * (cv - v0)) + 1e-9f;
   }
-  const int R = k0 >> 5, a4 = (k0 & 31) >> 3, hh = (k0 >> 2) & 1;
-  *reinterpret_cast<u2*>(xT + image_off(row >> 5, 4, R) + image_quad(a4, (int)(row & 31) + 32 * hh)) = u2{pk2(val[0], val[1]), pk2(val[2], val[3])};
+  *reinterpret_cast<u4*>(xT + image_off(grp, 4, R) + image_piece(half, lane)) =
+      u4{pk2(val[0], val[1]), pk2(val[2], val[3]), pk2(val[4], val[5]), pk2(val[6], val[7])};
 }
 
 // output layer: dWout[c][f] = sum_rows drgb[row][c] h7[row][f], dbout[c] = sum_rows drgb[row][c].  A row group's h7 image is
@@ -1003,7 +1007,7 @@ extern "C" int s2l_ensemble_rows_bf16(const float* packed, const float* coords, 
   EnsBatch sh;
   sh.dx[0] = (float)(-rx), sh.dx[1] = (float)rx, sh.dy[0] = (float)(-ry), sh.dy[1] = (float)ry, sh.ry = (float)ry;
   const int64_t n_rows = 4 * n_pixels * n_frames, np = s2l_bf16_rows_padded(n_rows);
-  hipLaunchKernelGGL(ensemble_rows_bf16_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(ensemble_rows_bf16_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      packed, coords, feat, time_index, u01, sh, xT, areas, n_pixels, n_rows, np);
   return (int)hipGetLastError();
 }
