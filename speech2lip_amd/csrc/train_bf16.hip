@@ -22,7 +22,7 @@
 #define S2L_ALWAYS_X 0   // experiment: 1 copies both parts of every stage unconditionally (straight-line code, exact vmcnt scoreboard): measured neutral
 #endif
 #ifndef S2L_EXP
-#define S2L_EXP 0   // tools/ubench experiments only: 1 no tile store, 2 no masks, 4 no MFMA k-loops (results wrong)
+#define S2L_EXP 0   // tools/ubench experiments only: 1 no tile store, 2 no masks, 4 no MFMA k-loops, 16 no dxa stores in the backward (results wrong)
 #endif
 
 namespace s2l {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_a[R][r] = 0.f;
       kloop2<16>(reinterpret_cast<const u4*>(wl) + lane, reinterpret_cast<const u4*>(wl + kSlabH) + lane, bcur, acc_a[0], acc_a[1]);
-      if (row < a.n_rows) {
+      if (row < a.n_rows && !(S2L_EXP & 16)) {
 #pragma unroll
         for (int R = 0; R < 2; ++R)
 #pragma unroll
