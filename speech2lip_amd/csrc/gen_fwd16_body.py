@@ -259,8 +259,8 @@ class Body:
             for which in range(2):
                 dst = A_A + ((i % NSLOT) * 2 + which) * 4
                 self.lds_op(f"ds_read_b128 {aq(dst)}, v{base} offset:{which * slab + t * 1024}", ("A", i, which))
-        for i in range(min(NSLOT - 1, len(steps))):
-            read(i)
+        # the first NSLOT - 1 k-steps' A quads were read by the stage before (first_reads: behind its barrier, during its epilogue)
+        self.lds = [("A", i, which) for i in range(min(NSLOT - 1, len(steps))) for which in range(2)]
         pending = list(items)
         nmf = 0
         for i, (part, setname, t) in enumerate(steps):
@@ -289,6 +289,14 @@ class Body:
             for x in (grp[1] if isinstance(grp, tuple) else grp):
                 if x is not None:
                     e(x)
+
+    def first_reads(self, buf, part):
+        """A quads of the first NSLOT - 1 k-steps of the stage that computes next from buffer `buf`, whose first part is `part`"""
+        base = (V_AX if part == "x" else V_AH)[buf]
+        slab = SLAB_X if part == "x" else SLAB_H
+        for i in range(min(NSLOT - 1, 8 if part == "x" else 16)):
+            for which in range(2):
+                self.e(f"ds_read_b128 {aq(A_A + ((i % NSLOT) * 2 + which) * 4)}, v{base} offset:{which * slab + i * 1024}")
 
     def bias_reads(self, qnext):
         """bias quads of the NEXT stage (blocks 2 qnext, 2 qnext + 1 of the layer V_BN points at) -> V_BIAS, as (text, tag)"""
@@ -404,7 +412,6 @@ class Body:
             if kind == "C" and q < 2 and BX_MODE == "kloop":      # behind the DMA groups: nothing else asks for the texture path for a while
                 mixed = mixed + [(len(mixed) + 2 + 2 * k, g) for k, g in enumerate(self.bx_items(q))]
             # the next stage's bias quads are read once this stage's first MFMAs (which take V_BIAS as C) have been issued
-            self.lds = []
             self.trace(0)
             self.kloop(q & 1, parts, mixed, 1, lds_after=(8, self.bias_reads((q + 1) & 3)))
             self.trace(1)
@@ -413,12 +420,26 @@ class Body:
             if not EXP & 16:
                 e("s_barrier")
             self.trace(3)
+            if q < 3:      # the next stage is the next quarter of this layer: its first A quads fly during the epilogue
+                self.first_reads((q + 1) & 1, parts[0][0])
             self.epilogue(q, outset, late)
             self.trace(4)
             e(f"s_add_u32 {s('ST')}, {s('ST')}, 1")
             e(f"s_and_b32 {s('ST')}, {s('ST')}, 31")
             if kind == "B" and q == 3:
                 self.output_layer()
+            if q == 3:     # the next stage opens another layer (buffer 0): which one is a run-time question for two kinds
+                if kind in ("A", "D"):
+                    self.first_reads(0, "h")
+                else:
+                    alt, join = self.label("nextx"), self.label("nextjoin")
+                    e(f"s_cmp_eq_u32 {s('L')}, {4 if kind == 'C' else 7}")        # C: layer 5 follows layer 4; B: layer 0 (of the next tile) follows layer 7
+                    e(f"s_cbranch_scc1 {alt}")
+                    self.first_reads(0, "h")
+                    e(f"s_branch {join}")
+                    e(f"{alt}:")
+                    self.first_reads(0, "x")
+                    e(f"{join}:")
 
     # ------------------------------------------------------------------ output layer (after stage 31's epilogue)
     def output_layer(self):
@@ -531,6 +552,7 @@ class Body:
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         self.lds = []
         e("s_barrier")
+        self.first_reads(0, "x")
 
         e("S2LF_TILE:")
         e(f"s_mov_b32 {s('L')}, 0")
