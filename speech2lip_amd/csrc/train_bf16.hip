@@ -689,29 +689,32 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   }
 }
 
-// out[i] = sum over the parts in a fixed order: 64 float4 columns per block, the parts split over the block's 4 waves
-// (each sums its quarter in part order), then the four partial sums are added in wave order.  A second, small tensor (the bias
-// gradient's partials) rides in the same launch: the blocks behind the first tensor's take it.
+// out[i] = sum over the parts in a fixed order: 16 float4 columns per block, the parts dealt round-robin to 16 threads per column
+// (thread p takes parts p, p + 16, ...), whose sums are then added in thread order.  A second, small tensor (the bias gradient's
+// partials) rides in the same launch: the blocks behind the first tensor's take it.  (With 64 columns x 4 part-quarters per
+// block a thread summed 64 parts one after the other: 19 us per GEMM, ten times per step.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int parts,
                                                           const float* __restrict__ part2, float* __restrict__ out2, int n2) {
-  __shared__ f4 red[4][64];
-  const int col = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nb1 = (n / 4 + 63) / 64;
+  __shared__ f4 red[16][17];
+  const int col = threadIdx.x & 15, w = threadIdx.x >> 4;
+  const int nb1 = (n / 4 + 15) / 16;
   int blk = blockIdx.x;
   if (blk >= nb1) {     // (block-uniform)
     blk -= nb1;
     part = part2; out = out2; n = n2;
   }
-  const int i = (blk * 64 + col) * 4;
+  const int i = (blk * 16 + col) * 4;
   f4 s = f4{0.f, 0.f, 0.f, 0.f};
-  if (i < n) {
-    const int per = (parts + 3) / 4;
-    const int p1 = min(parts, (w + 1) * per);
-    for (int p = w * per; p < p1; ++p) s += *reinterpret_cast<const f4*>(part + (int64_t)p * n + i);
-  }
+  if (i < n)
+    for (int p = w; p < parts; p += 16) s += *reinterpret_cast<const f4*>(part + (int64_t)p * n + i);
   red[w][col] = s;
   __syncthreads();
-  if (w == 0 && i < n) *reinterpret_cast<f4*>(out + i) = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+  if (w == 0 && i < n) {
+    f4 acc = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) acc += red[k][col];
+    *reinterpret_cast<f4*>(out + i) = acc;
+  }
 }
 
 // x fp32 [N,K] -> bf16 image (K/32 blocks; K = 128: the embedded rows, for dG0 / dG5).  thread = (row, 4 features).
@@ -961,7 +964,7 @@ extern "C" int s2l_wgrad_bf16(const uint16_t* dzT, const uint16_t* inT, int k_in
   else
     hipLaunchKernelGGL(wgrad_bf16_kernel<128>, dim3(parts), dim3(256), WgCfg<128>::kLds, st, dzT, inT, work, bpart, n_tiles);
   const int n = 256 * k_in;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 63) / 64 + (db ? 1 : 0)), dim3(256), 0, st, work, dw, n, parts,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n / 4 + 15) / 16 + (db ? 4 : 0)), dim3(256), 0, st, work, dw, n, parts,
                      (const float*)bpart, db, 256);
   return (int)hipGetLastError();
 }
@@ -990,7 +993,7 @@ extern "C" int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* 
   hipLaunchKernelGGL(out_grad_kernel, dim3(parts), dim3(256), 0, st, drgb, h7T, work, n_groups, n_rows);
   // parts x [772] -> [768] + [4]: reduce into a scratch row behind the partials, then split
   float* sum = work + (int64_t)kOutParts * 772;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 63) / 64), dim3(256), 0, st, work, sum, 772, parts, (const float*)nullptr,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((772 / 4 + 15) / 16), dim3(256), 0, st, work, sum, 772, parts, (const float*)nullptr,
                      (float*)nullptr, 0);
   (void)hipMemcpyAsync(dwout, sum, 768 * sizeof(float), hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(dbout, sum + 768, 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
