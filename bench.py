@@ -38,7 +38,7 @@ H = W_ = 96
 HW = H * W_
 FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
 FP32_MFMA_PEAK = 157.3e12
-TRAFFIC_BYTES_PER_FRAME = 2.08e8 / 1000   # measured with PMC counters (2*FETCH_SIZE + WRITE_SIZE), see profiles/r02l_rocprofv3_summary.txt
+TRAFFIC_BYTES_PER_FRAME = 2.08e8 / 1000   # measured with PMC counters (2*FETCH_SIZE + WRITE_SIZE), see profiles/r02m_rocprofv3_summary.txt
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
