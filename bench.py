@@ -38,7 +38,18 @@ H = W_ = 96
 HW = H * W_
 FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.md §8d (official, factored)
 FP32_MFMA_PEAK = 157.3e12
-TRAFFIC_BYTES_PER_FRAME = 2.08e8 / 1000   # measured with PMC counters (2*FETCH_SIZE + WRITE_SIZE), see profiles/r02m_rocprofv3_summary.txt
+
+
+def measured_traffic():
+    """HBM bytes per 1000-frame dispatch of the render kernel from the latest PMC passes (2*FETCH_SIZE + WRITE_SIZE,
+    separate rocprofv3 runs): tools/summarize_profiles.py writes profiles/render_traffic.json next to the profile summary
+    it was computed from, so the number in the line is the number in the profile it names."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "render_traffic.json")) as f:
+            t = json.load(f)
+        return t["hbm_bytes_per_dispatch"] / t["frames_per_dispatch"], t["profile"]
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -293,6 +304,7 @@ def main():
         with torch.no_grad():
             ref = O.render_clip(O.to_sd(W.make_state_dict(0, "he")), audio[:1].cpu(), [int(gids[0])], H, W_)[0]
         got = local[0].cpu()
+        traffic_per_frame, traffic_src = measured_traffic()
         line = {
             "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -306,7 +318,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), see profiles/
-                         "traffic": round(TRAFFIC_BYTES_PER_FRAME * frames_per_launch),
+                         "traffic": round(traffic_per_frame * frames_per_launch) if traffic_per_frame else None,
+                         "traffic_source": traffic_src,
                          "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
             "parity": {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1)},

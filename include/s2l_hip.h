@@ -331,7 +331,8 @@ int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors
  * F.interpolate(mode='bilinear', align_corners=False), no antialiasing).  src [F,src_h,src_w,3]; box = data['canonical_face_bbox'];
  * dst [F,out_h,out_w,3] when window_t == 0, or the rgb_window layout [F/T,3,T,out_h,out_w] (:547-548) with frame f = s*T + t
  * when window_t == T > 0.  s2l_crop_resize_backward: d_dst (same layout) -> d_src [F,src_h,src_w,3], zero outside the box
- * (deterministic gather, no atomics). */
+ * (deterministic gather, no atomics).  x2 / y2 beyond the frame are clipped to it, as the python slice clips them (the scale is
+ * that of the clipped crop); x < 0, y < 0 or an empty box return S2L_E_GEOMETRY. */
 int s2l_crop_resize(const float* src, int src_h, int src_w, int x, int y, int x2, int y2, float* dst, int out_h, int out_w,
                     int window_t, int64_t n_frames, s2l_stream_t stream);
 int s2l_crop_resize_backward(const float* d_dst, int src_h, int src_w, int x, int y, int x2, int y2, float* d_src, int out_h,

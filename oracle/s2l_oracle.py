@@ -269,11 +269,13 @@ def unet_forward(sd: SD, x_nhwc: torch.Tensor, prefix: str = "post_fusion_unet."
         if training:
             mean = y.mean(dim=(0, 2, 3))
             var = y.var(dim=(0, 2, 3), unbiased=False)
-            if new_stats is not None:
+            if new_stats is not None:      # a dict that already holds statistics (an earlier call's) is continued from
                 n = y.numel() // y.shape[1]
-                new_stats[bn + ".running_mean"] = ((1 - momentum) * sd[bn + ".running_mean"] + momentum * mean).detach()
-                new_stats[bn + ".running_var"] = ((1 - momentum) * sd[bn + ".running_var"] + momentum * var * n / max(n - 1, 1)).detach()
-                new_stats[bn + ".num_batches_tracked"] = sd[bn + ".num_batches_tracked"] + 1 if bn + ".num_batches_tracked" in sd else None
+                old = lambda k: new_stats[k] if new_stats.get(k) is not None else sd.get(k)
+                nbt = old(bn + ".num_batches_tracked")
+                new_stats[bn + ".running_mean"] = ((1 - momentum) * old(bn + ".running_mean") + momentum * mean).detach()
+                new_stats[bn + ".running_var"] = ((1 - momentum) * old(bn + ".running_var") + momentum * var * n / max(n - 1, 1)).detach()
+                new_stats[bn + ".num_batches_tracked"] = nbt + 1 if nbt is not None else None
             y = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * sd[bn + ".weight"].view(1, -1, 1, 1) \
                 + sd[bn + ".bias"].view(1, -1, 1, 1)
             return F.relu(y)
@@ -475,12 +477,17 @@ def crop_resize(img_nhwc: torch.Tensor, bbox, size=(96, 96)) -> torch.Tensor:
 
 def sync_chain_window(sd: SD, unet_sd: SD, coords, audio_window, index: int, total_frame: int, eps_u01, face_canon, rgb_gt,
                       mask, x0: int, y0: int, coord_window, bbox, height: int, width: int, pad_mode: int = PAD_MODE_MAY,
-                      pad_div: int = 5) -> torch.Tensor:
+                      pad_div: int = 5, unet_training: bool = False, new_stats: Optional[dict] = None) -> torch.Tensor:
     """The generated 5-frame window of the sync loss for ONE sample (training.py:491-548): for t in 0..T-1 the 4-tap
     ensemble render of audio_window[t] at frame index min(index + t, total_frame - 1) (:515-518), pasted and warped with
-    coord_window[t] against the MAIN frame's observed image (:527-536), through the eval-mode U-Net (the first return
-    value of post_fusion2_onlylip is rgb_recon, tf_nerf.py:387-389; the U-Net is frozen and in eval mode once the sync
-    loss is active, train.py:188-197), cropped to the canonical face box and resized to 96x96 (:541-544).
+    coord_window[t] against the MAIN frame's observed image (:527-536), through the frozen U-Net (the first return
+    value of post_fusion2_onlylip is rgb_recon, tf_nerf.py:387-389), cropped to the canonical face box and resized to
+    96x96 (:541-544).  BatchNorm mode of the frozen net: train.py:188-197 calls post_fusion_unet.eval() ONCE when the
+    sync loss becomes active, but Trainer.train_step (training.py:150) calls self.model.train() on every step, which puts
+    the sub-module back into train mode -- so a reference run that goes through train_step normalises each one-frame call
+    with that frame's batch statistics (and keeps updating the running statistics) although the parameters are frozen:
+    `unet_training=True` (`new_stats` collects the running statistics, call after call).  `unet_training=False` is
+    train_stage1 called with the sub-module left in eval mode (golden G11).
     audio_window [T,16,29]; eps_u01: one U(0,1) draw per frame (each predict_lip_image call draws its own, :200);
     face_canon/rgb_gt/mask [1,FH,FW,3]; coord_window [T,FH,FW,2] -> rgb_window [1,3,T,96,96] (:547-548)."""
     frames = []
@@ -488,7 +495,7 @@ def sync_chain_window(sd: SD, unet_sd: SD, coords, audio_window, index: int, tot
         idx = index + t if index + t < total_frame else total_frame - 1
         lip = predict_lip_image(sd, coords, audio_window[t], idx, height, width, eps_u01[t]).reshape(1, height, width, 3)
         new, _ = composite(lip, face_canon, rgb_gt, mask, x0, y0, coord_window[t:t + 1], pad_mode=pad_mode, pad_div=pad_div)
-        recon = unet_forward(unet_sd, new)
+        recon = unet_forward(unet_sd, new, training=unet_training, new_stats=new_stats)
         frames.append(crop_resize(recon, bbox))
     win = torch.stack(frames, 0)                       # T,B,H,W,C
     return win.permute(1, 4, 0, 2, 3)                  # B,C,T,H,W
@@ -496,7 +503,8 @@ def sync_chain_window(sd: SD, unet_sd: SD, coords, audio_window, index: int, tot
 
 def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio, data: dict, eps_u01, hole_noise, height: int,
                      width: int, lambda_rgb: float = 1.0, w_post_fusion: float = 1.0, w_syncloss: float = 0.01,
-                     pad_mode: int = PAD_MODE_MAY, pad_div: int = 5, unet_training: bool = False, with_sync: bool = True) -> dict:
+                     pad_mode: int = PAD_MODE_MAY, pad_div: int = 5, unet_training: bool = False, with_sync: bool = True,
+                     new_stats: Optional[dict] = None) -> dict:
     """The loss of ONE reference optimisation step after `it > 100000` (Trainer.train_stage1, training.py:347-574) under the
     May flags with the LPIPS and canonical-depth terms switched off:
         loss = lambda_rgb * MSE(predict_lip_image, rgb)                                              (:414-418)
@@ -509,6 +517,9 @@ def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio
     hole_noise: None when the coin of tf_nerf.py:371 came up tails, else the two randn fields [1,FH,FW].
     unet_training / with_sync=False: the step BEFORE `it > 100000` -- the post-fusion net in train mode (BatchNorm batch
     statistics, its parameters trained too) and no sync term (:491 is false).
+    unet_training / with_sync=True: the step after `it > 100000` as Trainer.train_step runs it (self.model.train() at
+    training.py:150 undoes train.py's post_fusion_unet.eval()): every one-frame U-Net call -- the main frame first, then
+    the T window frames -- uses its own batch statistics; `new_stats` receives the running statistics after all 1 + T calls.
     Differentiable w.r.t. `sd` and `unet_sd` (build them with requires_grad tensors)."""
     coords = get_coords(width, height)
     idx = int(data["index"])
@@ -518,13 +529,14 @@ def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio
     lip = pred.reshape(1, height, width, 3)
     new, _ = composite(lip, data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0, data["coord"],
                        pad_mode=pad_mode, pad_div=pad_div, blackaug=hole_noise)
-    recon = unet_forward(unet_sd, new, training=unet_training)
+    recon = unet_forward(unet_sd, new, training=unet_training, new_stats=new_stats)
     loss_face = mse_loss(recon, data["rgb_face_ori"], lambda_rgb * w_post_fusion)
     if not with_sync:
         return {"loss": loss_rgb + loss_face, "loss_rgb": loss_rgb, "loss_face": loss_face, "pred": pred, "rgb_face_recon": recon}
     window = sync_chain_window(sd, unet_sd, coords, data["audio_window"][0], idx, int(data["total_frame"]), eps_u01[1:],
                                data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], x0, y0,
-                               data["coord_window"][0], data["canonical_face_bbox"][0], height, width, pad_mode, pad_div)
+                               data["coord_window"][0], data["canonical_face_bbox"][0], height, width, pad_mode, pad_div,
+                               unet_training=unet_training, new_stats=new_stats)
     loss_sync = sync_contrastive_loss(sync_sd, data["mel"], window, data["rgb_window_neg"], blocks_face, blocks_audio,
                                       window.shape[2]) * w_syncloss
     return {"loss": loss_rgb + loss_face + loss_sync, "loss_rgb": loss_rgb, "loss_face": loss_face, "loss_sync": loss_sync,

@@ -54,17 +54,32 @@ _MAY = {
         "use_post_fusion": True, "use_post_fusion_wface": False, "use_post_fusion_blackaug": True,
         "use_light_unet": True, "use_resnet": False, "post_fusion_channel": 3, "expand_lip_mask": True,
         "use_canonical_depth": False, "canonical_depth_height": 500, "canonical_depth_width": 500,
+        "lambda_rgb": 1.0,          # read from cfg['model'] by the reference (src/face_simple/config.py:41; may.yaml:11)
     },
     "training": {"out_dir": "log/face_simple/may", "batch_rays": 96 * 96, "n_sample_points": 16,
                  "use_coords_mapping": False, "fusion_lip_only": True, "use_local_ensemble": True,
-                 "multi_gpu": True, "add_noise_audio": False, "add_noise_uv": False},
+                 "multi_gpu": True, "add_noise_audio": False, "add_noise_uv": False,
+                 # loss switches of may.yaml:43-54.  `may_config(train_flags=False)` (the default) switches the three that need
+                 # assets outside the reference repository off: LPIPS / AlexNet weights, lipsync_expert.pth, the 3DMM depth init
+                 "stage": "stage1", "w_post_fusion": 1.0, "use_perceptual_loss": True, "w_perceptual_loss": 0.01,
+                 "use_syncloss": True, "w_syncloss": 0.01, "use_canonical_depth_loss_photo": False,
+                 "use_canonical_depth_loss_photo_v2": True, "use_canonical_depth_loss_geo": False,
+                 "use_lip_photo_loss": "v1", "use_lip_perc_loss": "v1", "use_face_photo_loss": True, "use_face_perc_loss": True},
 }
 
 
-def may_config(height: int = 96, width: int = 96, data_path: str = "dataset/may_face_crop_lip") -> dict:
+def may_config(height: int = 96, width: int = 96, data_path: str = "dataset/may_face_crop_lip", train_flags: bool = False) -> dict:
     """The May flag set (configs/face_simple_configs/may/may.yaml over its defaults) restricted
-    to the keys the hot path reads, for a `height` x `width` lip crop."""
+    to the keys the hot path reads, for a `height` x `width` lip crop.
+    train_flags=True keeps may.yaml's loss switches as they are (use_perceptual_loss, use_syncloss,
+    use_canonical_depth + its photo loss v2: a `Trainer` built on it forms the whole May loss and needs the LPIPS / SyncNet
+    weights and, for the depth head, `model.canonical_depth_init_path` or the N(0,1) init); the default switches those three
+    off, which is what inference and the weight-free benchmarks want."""
     cfg = copy.deepcopy(_MAY)
     cfg["data"].update(height=int(height), width=int(width), path=data_path)
     cfg["training"]["batch_rays"] = int(height) * int(width)
+    if train_flags:
+        cfg["model"]["use_canonical_depth"] = True
+    else:
+        cfg["training"].update(use_perceptual_loss=False, use_syncloss=False, use_canonical_depth_loss_photo_v2=False)
     return cfg

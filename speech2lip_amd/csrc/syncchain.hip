@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256) void crop_resize_bwd_kernel(ResizeArgs a, cons
 static int resize_args(ResizeArgs& a, int src_h, int src_w, int x, int y, int x2, int y2, int out_h, int out_w, int t,
                        int64_t n_frames) {
   if (src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0 || t < 0 || n_frames < 0) return S2L_E_SIZE;
-  if (x < 0 || y < 0 || x2 > src_w || y2 > src_h || x2 <= x || y2 <= y) return S2L_E_GEOMETRY;   // python slicing would clip
+  // rgb_merged[:, y:y2, x:x2, :] (training.py:541-543): python slicing silently clips an end beyond the frame (face-detector boxes
+  // on face-cropped clips often do), and the resize scale follows the CLIPPED crop.  A negative start would wrap around in
+  // python; that and an empty box are errors here.
+  x2 = x2 < src_w ? x2 : src_w;
+  y2 = y2 < src_h ? y2 : src_h;
+  if (x < 0 || y < 0 || x2 <= x || y2 <= y) return S2L_E_GEOMETRY;
   if (t > 0 && n_frames % t != 0) return S2L_E_SIZE;
   a.src_h = src_h; a.src_w = src_w; a.x = x; a.y = y; a.cw = x2 - x; a.ch = y2 - y;
   a.out_h = out_h; a.out_w = out_w; a.T = t;

@@ -64,7 +64,7 @@ class alexnet(nn.Module):
 
 class LPIPS(nn.Module):
     def __init__(self, pretrained=True, net="alex", version="0.1", lpips=True, spatial=False, pnet_rand=False, pnet_tune=False,
-                 use_dropout=True, model_path=None, eval_mode=True, verbose=False):
+                 use_dropout=True, model_path=None, eval_mode=True, verbose=False, trunk_path=None):
         super().__init__()
         if net not in ("alex", "alexnet") or version != "0.1" or not lpips or spatial or pnet_tune:
             raise NotImplementedError("the HIP path implements LPIPS(net='alex', version='0.1', lpips=True, spatial=False) with a "
@@ -77,13 +77,79 @@ class LPIPS(nn.Module):
         self.lins = nn.ModuleList([getattr(self, f"lin{i}") for i in range(5)])
         for p in self.parameters():
             p.requires_grad = False
-        if pretrained and model_path is not None and os.path.exists(model_path):     # the package's alex.pth holds the linear heads
-            self.load_state_dict(torch.load(model_path, map_location="cpu"), strict=False)
+        # What `lpips.LPIPS(pretrained=True, net='alex')` loads: (i) the AlexNet trunk = torchvision's ImageNet weights
+        # (`tv.alexnet(pretrained=True).features`, lpips/pretrained_networks.py), (ii) the linear heads from `model_path` (the
+        # package's weights/v0.1/alex.pth when None).  Neither file is in the reference repository or this image, and there is no
+        # network: `trunk_path` (or $S2L_ALEXNET_WEIGHTS) names a torchvision AlexNet state dict (`features.N.weight/bias`), and a
+        # perceptual loss on random features is never silent -- `weights_loaded` records what arrived, and a pretrained=True module
+        # that is missing either part warns loudly here and raises at its first use unless `allow_random_weights` is set.
+        self.weights_loaded = {"trunk": False, "lins": False}
+        self.allow_random_weights = not pretrained
+        if pretrained:
+            trunk_path = trunk_path or os.environ.get("S2L_ALEXNET_WEIGHTS")
+            if trunk_path is not None:
+                self.load_trunk(torch.load(trunk_path, map_location="cpu"))
+            if model_path is not None and os.path.exists(model_path):
+                self.load_lins(torch.load(model_path, map_location="cpu"))
+            missing = [k for k, v in self.weights_loaded.items() if not v]
+            if missing:
+                import warnings
+                warnings.warn(f"LPIPS(pretrained=True): no weights loaded for {missing} (model_path={model_path!r}, trunk_path="
+                              f"{trunk_path!r}); the module holds RANDOM values there and will refuse to run until load_trunk / "
+                              "load_lins / load_state_dict supplies them or allow_random_weights is set", RuntimeWarning, stacklevel=2)
         self._packed = self._packed_key = self._work = None
         self.eval()
 
     def train(self, mode: bool = True):
         return super().train(False)       # frozen expert: dropout never active, as eval_mode=True in the package
+
+    def load_trunk(self, state):
+        """torchvision AlexNet weights -> net.slice*: accepts `alexnet().state_dict()` (`features.0.weight` ...), its `.features`
+        (`0.weight` ...), or this module's own `net.slice1.0.weight` names.  Every one of the five convolutions must be present."""
+        state = state.get("state_dict", state) if isinstance(state, dict) else state
+        own = {}
+        for name, idx, *_ in ALEX_CONVS:
+            for kind in ("weight", "bias"):
+                for cand in (f"net.{name}.{idx}.{kind}", f"features.{idx}.{kind}", f"{idx}.{kind}"):
+                    if cand in state:
+                        own[f"net.{name}.{idx}.{kind}"] = state[cand]
+                        break
+                else:
+                    raise KeyError(f"AlexNet trunk weights: no entry for features.{idx}.{kind}")
+        res = self.load_state_dict(own, strict=False)
+        assert not res.unexpected_keys
+        self.weights_loaded["trunk"] = True
+        return self
+
+    def load_lins(self, state):
+        """The package's weights/v0.1/alex.pth: `lin{i}.model.1.weight` for i = 0..4 (strict: all five, nothing else but their
+        `lins.{i}` aliases)."""
+        want = {f"lin{i}.model.1.weight" for i in range(5)}
+        keys = {k for k in state if not k.startswith("lins.")}
+        if keys != want:
+            raise KeyError(f"LPIPS linear heads: expected exactly {sorted(want)}, got {sorted(keys)}")
+        use_dropout = isinstance(self.lin0.model[0], nn.Dropout)
+        own = {(k if use_dropout else k.replace("model.1", "model.0")): v for k, v in state.items() if k in want}
+        res = self.load_state_dict(own, strict=False)
+        assert not res.unexpected_keys
+        self.weights_loaded["lins"] = True
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        if any(k.startswith("net.") for k in state_dict):
+            self.weights_loaded["trunk"] = all(f"net.{n}.{i}.weight" in state_dict for n, i, *_ in ALEX_CONVS)
+        if any(k.startswith("lin") for k in state_dict):
+            self.weights_loaded["lins"] = self.weights_loaded["lins"] or all(
+                any(k.startswith(f"lin{i}.") or k.startswith(f"lins.{i}.") for k in state_dict) for i in range(5))
+        return res
+
+    def _require_weights(self):
+        if not self.allow_random_weights and not all(self.weights_loaded.values()):
+            missing = [k for k, v in self.weights_loaded.items() if not v]
+            raise _abi.S2LError(f"LPIPS(pretrained=True) has no weights for {missing}: a perceptual loss on random features would train "
+                                "silently against noise.  Supply them (load_trunk / load_lins / load_state_dict, trunk_path= or "
+                                "$S2L_ALEXNET_WEIGHTS) or set allow_random_weights = True for structural tests.")
 
     def _tensors(self):
         t = []
@@ -117,6 +183,7 @@ class LPIPS(nn.Module):
         so that several calls can be pending, as the lip and the face term of one step are); otherwise the module's
         scratch workspace is reused."""
         lib = _abi.load()
+        self._require_weights()
         packed = self.packed_weights()
         dev = packed.device
         if in0.device != dev or in1.device != dev:

@@ -6,9 +6,11 @@
   * `LipTrainStep` is the batched engine underneath: `forward` renders the 4-tap local ensemble of a batch of frames with
     saved activations, `backward` turns d loss / d pred into the gradients of all 42 hot-path tensors -- fp32 exact-parity
     mode or the bf16 mode BASELINE config 5 names.
-  * `SyncChain` carries the lip-sync expert's loss back to the rendered lips through the crop/resize, the frozen eval-mode
-    post-fusion U-Net and the paste + head-pose-warp composite (training.py:491-557), and `StageOneStep` adds it (and the
-    optional face photometric term, :458-459) to the MSE step.
+  * `SyncChain` carries the lip-sync expert's loss back to the rendered lips through the crop/resize, the frozen
+    post-fusion U-Net -- in whichever BatchNorm mode the sub-module is in: eval (running statistics; crop-window and bf16
+    operand forms) or train (batch statistics per one-frame call: what the reference's loop actually runs, because
+    Trainer.train_step calls self.model.train() on every step, training.py:150; golden G16) -- and the paste + head-pose-warp
+    composite (training.py:491-557), and `StageOneStep` adds it (and the optional face photometric term, :458-459) to the MSE step.
 Every arithmetic step is a hand-written HIP kernel behind the C-ABI; torch is device memory, streams and views.
 """
 from __future__ import annotations
@@ -78,7 +80,9 @@ class Trainer:
         tc = self.cfg["training"]
         self.use_post_fusion = bool(kwargs.get("use_post_fusion", self.cfg["model"].get("use_post_fusion", True)))
         self.fusion_lip_only = self.use_fusion_face = True
-        self.w_photometric_loss = float(kwargs.get("w_photometric_loss", tc.get("lambda_rgb", 1.0)))
+        # lambda_rgb lives under cfg['model'] in the reference (src/face_simple/config.py:41, may.yaml:11); cfg['training'] is a fallback
+        self.w_photometric_loss = float(kwargs.get("w_photometric_loss",
+                                                   self.cfg["model"].get("lambda_rgb", tc.get("lambda_rgb", 1.0))))
         self.w_post_fusion = float(kwargs.get("w_post_fusion", tc.get("w_post_fusion", 1.0)))
         self.use_perceptual_loss = bool(kwargs.get("use_perceptual_loss", tc.get("use_perceptual_loss", False)))
         self.w_perceptual_loss = float(kwargs.get("w_perceptual_loss", tc.get("w_perceptual_loss", 0.01)))
@@ -170,6 +174,19 @@ class Trainer:
         loss["loss"] = loss["loss"] + loss_perceptual
         loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + loss_perceptual.detach().cpu()
 
+
+    def train_step(self, data, data_zero=None, it=None, seed=None):
+        """training.py:140-155, statement for statement: `self.model.train()`, then `train_stage1`; returns
+        (loss_rgb.item(), loss dict).  NB `self.model.train()` puts EVERY sub-module into train mode, including a post-fusion
+        U-Net that train.py:188-197 froze and switched to eval() when `it` passed 100000: from then on the reference's loop runs
+        that U-Net with frozen parameters but BatchNorm batch statistics (and moving running statistics).  The drop-in does the
+        same, because `post_fusion2_onlylip` follows the sub-module's own mode (golden G16)."""
+        self.model.train()
+        if self.cfg["training"].get("stage", "stage1") == "stage1":
+            loss, loss_all = self.train_stage1(data, it=it, seed=seed)
+        else:
+            raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
+        return float(loss), loss_all
 
     def train_stage1(self, data, eval_model=False, it=None, seed=None):
         """One optimisation step as the reference performs it (training.py:347-574) under the May flags, through the drop-in's
@@ -483,6 +500,7 @@ class SyncChain:
         # sync loss reads nothing else of its output (training.py:541-544) and every value it reads, and every gradient that
         # comes back, is bit-identical to the full-frame evaluation (s2l_unet_forward_saved_window)
         self.window = bool(window)
+        self.unet_param_grads = None      # a dict: train-mode U-Net parameter gradients are accumulated into it (StageOneStep sets it)
         self.unet_precision = unet_precision      # "bf16": the frozen U-Net's 3x3 convolutions on the bf16 MFMA (fp32 accumulation)
 
     def unet_window(self, bbox, FH: int, FW: int):
@@ -512,12 +530,16 @@ class SyncChain:
         if gt.shape[0] != S or cw.shape != (S, T, FH, FW, 2):
             raise ValueError("rgb_face_gt must be [S,FH,FW,3] and coord_window [S,T,FH,FW,2]")
         x, y, x2, y2 = (int(v) for v in list(canonical_face_bbox)[:4])
+        x2, y2 = min(x2, FW), min(y2, FH)          # rgb_merged[:, y:y2, x:x2] clips a box that leaves the frame (training.py:541-543)
         oh, ow = self.out_hw
-        wx0, wy0, wx1, wy1 = self.unet_window((x, y, x2, y2), FH, FW)
-        win = (FH, FW, wy0, wx0)
+        unet = m.post_fusion_unet
+        # the sub-module's own mode decides, as in post_fusion2_onlylip: a net left in train mode (the reference's loop: train_step's
+        # self.model.train(), training.py:150) normalises every frame with its own statistics -- whole frames, exact fp32
+        use_window = self.window and not unet.training
+        wx0, wy0, wx1, wy1 = self.unet_window((x, y, x2, y2), FH, FW) if use_window else (0, 0, FW, FH)
+        win = (FH, FW, wy0, wx0) if not unet.training else None
         mel = _dev_f32(mel, dev, "mel")
         neg = _dev_f32(rgb_window_neg, dev, "rgb_window_neg")
-        unet = m.post_fusion_unet
         d_lips = torch.empty_like(lips)
         window = _f(dev, S, 3, T, oh, ow)
         total = torch.zeros((), dtype=torch.float32, device=dev)
@@ -527,9 +549,9 @@ class SyncChain:
             gt_f = gt[s0:s1].repeat_interleave(T, dim=0)                      # each window frame sees its sample's main frame
             coord_f = cw[s0:s1].reshape(n * T, FH, FW, 2)
             new, _ = m.composite_clip(lips[fr], rgb_face_canonical, gt_f, mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_f)
-            crop = new[:, wy0:wy1, wx0:wx1].contiguous() if self.window else new
+            crop = new[:, wy0:wy1, wx0:wx1].contiguous() if use_window else new
             ch, cw_ = crop.shape[1], crop.shape[2]
-            recon, saved = unet.forward_saved_nhwc(crop, window=win, precision=self.unet_precision)
+            recon, saved = unet.forward_for_backward(crop, window=win, precision=self.unet_precision)
             wnd = window[s0:s1]
             with torch.cuda.device(dev):
                 ck(lib.s2l_crop_resize(_ptr(recon), ch, cw_, x - wx0, y - wy0, x2 - wx0, y2 - wy0, _ptr(wnd), oh, ow, T, n * T, _stream()),
@@ -541,9 +563,9 @@ class SyncChain:
             with torch.cuda.device(dev):
                 ck(lib.s2l_crop_resize_backward(_ptr(d_win), ch, cw_, x - wx0, y - wy0, x2 - wx0, y2 - wy0, _ptr(d_recon), oh, ow, T, n * T,
                                                 _stream()), "s2l_crop_resize_backward")
-            d_new = unet.backward_input(saved, d_recon)
+            d_new = unet.backward_to_input(saved, d_recon, self.unet_param_grads)
             del saved, recon, d_recon
-            if self.window:   # the gradient is exactly zero outside the crop (its support is the box dilated by <= 32 pixels)
+            if use_window:   # the gradient is exactly zero outside the crop (its support is the box dilated by <= 32 pixels)
                 full = torch.zeros(n * T, FH, FW, 3, dtype=torch.float32, device=dev)
                 full[:, wy0:wy1, wx0:wx1] = d_new
                 d_new = full
@@ -606,6 +628,13 @@ class StageOneStep:
         pred = self.step.forward(a, idx, u)                                   # [B + S*T, P, 3]
         dpred = torch.zeros_like(pred)
         losses = {}
+        # a post-fusion U-Net that is in train mode AND still trains (the reference until it > 100000) gets its parameter gradients
+        # too, under `post_fusion_unet.<name>`; a frozen one in train mode (the reference's loop afterwards, see SyncChain) only
+        # passes the input gradient on
+        unet = getattr(m, "post_fusion_unet", None)
+        unet_grads = {} if (unet is not None and unet.training and any(p.requires_grad for p in unet.parameters())) else None
+        if self.chain is not None:
+            self.chain.unet_param_grads = unet_grads
         tgt = _dev_f32(targets, dev, "targets").reshape(B, P, 3)
         loss, mwork = _f(dev, 1), _f(dev, 1024)
         with torch.cuda.device(dev):
@@ -627,7 +656,7 @@ class StageOneStep:
             gt = _dev_f32(face["rgb_face_gt"], dev, "rgb_face_gt")
             args = (face["rgb_face_canonical"], face["mask_lip_canonical"], face["lip_lefttop_x"], face["lip_lefttop_y"], face["coord"])
             new, _ = m.composite_clip(lip, args[0], gt, args[1], args[2], args[3], args[4], hole_noise=holes)
-            recon, saved = m.post_fusion_unet.forward_saved_nhwc(new, precision=self.unet_precision)
+            recon, saved = m.post_fusion_unet.forward_for_backward(new, precision=self.unet_precision)
             d_recon, floss = torch.empty_like(recon), _f(dev, 1)
             with torch.cuda.device(dev):
                 ck(lib.s2l_mse(_ptr(recon), _ptr(gt), ctypes.c_float(self.lambda_rgb * self.w_post_fusion), _ptr(d_recon), _ptr(mwork),
@@ -638,7 +667,7 @@ class StageOneStep:
                 self.perceptual.backward_nhwc(st, torch.full((B,), wp / B, device=dev), out=d_recon)
                 losses["loss_perceptual"] = losses["loss_perceptual"] + d.mean() * wp
                 total_loss = total_loss + d.mean() * wp
-            d_new = m.post_fusion_unet.backward_input(saved, d_recon)
+            d_new = m.post_fusion_unet.backward_to_input(saved, d_recon, unet_grads)
             d_lip = m.composite_backward_lip(d_new, args[0], args[1], args[2], args[3], args[4], self.h, self.w, hole_noise=holes)
             dpred[:B] += d_lip.reshape(B, P, 3)
             losses["loss_face"] = floss[0]
@@ -653,6 +682,8 @@ class StageOneStep:
             losses["rgb_window"] = window
             total_loss = total_loss + sl
         g, aux = self.step.backward(dpred)
+        if unet_grads:
+            g.update({"post_fusion_unet." + k: v for k, v in unet_grads.items()})
         aux.update(losses)
         aux["pred"] = pred
         return total_loss, g, aux

@@ -117,10 +117,14 @@ class SimpleUnetLight(nn.Module):
         if out is None:
             out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        # frames go through in groups that keep the activation workspace around 16 GiB of the 288: every convolution is one
-        # launch per group, and a launch needs many waves of workgroups (512 fit at a time) to amortise its ramp and tail
+        # frames go through in groups: every convolution is one launch per group, and a launch needs many waves of workgroups
+        # (512 fit at a time) to amortise its ramp and tail.  The activation workspace of a group is capped at 16 GiB and at
+        # half of the memory that is free right now (training state or a smaller device may have claimed the rest)
         per_frame = int(lib.s2l_unet_work_floats(H, W, 1))
-        group = max(1, min(F_, (1 << 32) // max(per_frame, 1)))
+        free_bytes, _ = torch.cuda.mem_get_info(x.device)
+        free_bytes += torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device)     # torch's own cached blocks
+        budget_floats = max(per_frame, min(1 << 32, free_bytes // 8))
+        group = max(1, min(F_, budget_floats // max(per_frame, 1)))
         work = torch.empty(per_frame * group, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             for s in range(0, F_, group):
@@ -178,7 +182,10 @@ class SimpleUnetLight(nn.Module):
             for mod in self.modules():
                 if isinstance(mod, nn.BatchNorm2d):
                     mod.num_batches_tracked += 1
-            self._packed = None        # the folded eval-mode blob is stale now (the kernel rewrote the running statistics)
+            # the folded eval-mode blobs are stale now: the kernel rewrote the running statistics in place, which does not bump
+            # the tensors' version counters (the cache keys), and BOTH the fp32 and the bf16 blob fold them
+            self._packed = self._packed_key = None
+            self._packed16 = self._packed16_key = None
         return out, (raw, x, saved, (F_, H, W))
 
     def backward_train(self, ctx, d_out: torch.Tensor, want_input_grad: bool = True):
@@ -254,6 +261,41 @@ class SimpleUnetLight(nn.Module):
                                                     p(work), p(dx), H, W, fh, fw, oy, ox, F_,
                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward_window")
         return dx
+
+    # ------------------------------------------------------------------ mode-following pair for the fused training steps
+    def forward_for_backward(self, x: torch.Tensor, window=None, precision: str = "fp32"):
+        """What `post_fusion_unet(x)` computes in the module's CURRENT mode, with the state its backward needs:
+        eval mode -> forward_saved_nhwc (running statistics; `window` / bf16 operands allowed);
+        train mode -> BatchNorm batch statistics, ONE FRAME PER CALL in frame order -- the reference only ever hands the net one
+        frame at a time (tf_nerf.py:387 inside train_stage1's batch-1 calls), so each frame is normalised with its own
+        statistics and the running statistics move once per frame, in that order.  This is also the mode of a FROZEN net inside
+        the reference's loop after it > 100000: Trainer.train_step's self.model.train() (training.py:150) undoes the .eval() of
+        train.py:195.  A crop is not equivalent then (statistics are over the whole frame) and exact fp32 is used."""
+        if not self.training:
+            return self.forward_saved_nhwc(x, window=window, precision=precision)
+        if window is not None:
+            raise ValueError("train-mode BatchNorm needs whole frames: statistics are taken over the full image")
+        outs, ctxs = [], []
+        for f in range(x.shape[0]):
+            o, c = self.forward_train_nhwc(x[f:f + 1], update_running=True)
+            outs.append(o)
+            ctxs.append(c)
+        return torch.cat(outs, 0), ("train", ctxs)
+
+    def backward_to_input(self, ctx, d_out: torch.Tensor, param_grads: dict = None) -> torch.Tensor:
+        """d loss / d x for a `forward_for_backward` state.  Train mode: the BatchNorm backward carries the batch-statistics terms
+        whether or not the parameters are frozen; when `param_grads` is a dict the parameter gradients are ACCUMULATED into it
+        under their state-dict names (the net while it still trains, it <= 100000)."""
+        if not (isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train"):
+            return self.backward_input(ctx, d_out)
+        dxs = []
+        for f, c in enumerate(ctx[1]):
+            dx, grads = self.backward_train(c, d_out[f:f + 1], want_input_grad=True)
+            dxs.append(dx)
+            if param_grads is not None:
+                for k, v in grads.items():
+                    param_grads[k] = v.clone() if k not in param_grads else param_grads[k] + v
+        return torch.cat(dxs, 0)
 
     def forward(self, x, x_level1=None, x_level2=None):
         """NCHW in, NCHW out, as the reference's forward (SimpleUnetLight.py:99-111).  With autograd recording and an input

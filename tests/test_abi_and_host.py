@@ -286,6 +286,66 @@ def test_lpips_module_has_the_package_state_dict_and_oracle_properties():
     assert torch.allclose(dab, dba, rtol=1e-6) and float(O.lpips_alex(sd, a, a).abs().max()) == 0.0
 
 
+def test_lpips_pretrained_never_runs_on_random_weights(tmp_path):
+    """LPIPS(pretrained=True) (training.py:76) must not train silently against random features: the package would load
+    torchvision's AlexNet + its own linear heads; here a missing part warns at construction, records it in weights_loaded and
+    refuses to run, and load_trunk / load_lins accept the torchvision / package key layouts with strict key checks."""
+    import warnings
+    import speech2lip_amd as s2l
+    from speech2lip_amd import _abi, weights as W
+    with pytest.warns(RuntimeWarning, match="RANDOM"):
+        m = s2l.LPIPS(net="alex", version="0.1", model_path="models/lpips_weights_v0.1/alex.pth")      # the reference's call
+    assert m.weights_loaded == {"trunk": False, "lins": False}
+    with pytest.raises(_abi.S2LError, match="random features"):
+        m._require_weights()
+    sd = {k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()}
+    tv = {f"features.{k.split('.')[2]}.{k.split('.')[3]}": v for k, v in sd.items() if k.startswith("net.")}      # torchvision names
+    assert set(tv) == {f"features.{i}.{p}" for i in (0, 3, 6, 8, 10) for p in ("weight", "bias")}
+    heads = {k: v for k, v in sd.items() if k.startswith("lin") and not k.startswith("lins.")}
+    torch.save(tv, tmp_path / "alexnet.pth")
+    torch.save(heads, tmp_path / "alex.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m2 = s2l.LPIPS(net="alex", version="0.1", model_path=str(tmp_path / "alex.pth"), trunk_path=str(tmp_path / "alexnet.pth"))
+    assert m2.weights_loaded == {"trunk": True, "lins": True}
+    m2._require_weights()
+    for k, v in sd.items():
+        assert torch.equal(m2.state_dict()[k], v), k
+    with pytest.raises(KeyError):
+        m.load_trunk({k: v for k, v in tv.items() if not k.startswith("features.8")})
+    with pytest.raises(KeyError):
+        m.load_lins({**heads, "lin5.model.1.weight": heads["lin0.model.1.weight"]})
+    m.load_trunk(tv)
+    assert m.weights_loaded == {"trunk": True, "lins": False}
+    m.load_lins(heads)
+    m._require_weights()
+    s2l.LPIPS(pretrained=False)._require_weights()            # explicit random init (pnet_rand-style structural use) is allowed
+
+
+def test_config_and_trainer_read_the_reference_keys():
+    """lambda_rgb lives under cfg['model'] (src/face_simple/config.py:41, may.yaml:11); may_config(train_flags=True) carries
+    may.yaml's loss switches (:43-54)."""
+    import speech2lip_amd as s2l
+    cfg = s2l.may_config(96, 96, train_flags=True)
+    assert cfg["model"]["lambda_rgb"] == 1.0 and cfg["model"]["use_canonical_depth"] is True
+    t = cfg["training"]
+    assert t["use_perceptual_loss"] and t["use_syncloss"] and t["use_canonical_depth_loss_photo_v2"] and t["stage"] == "stage1"
+    assert (t["w_post_fusion"], t["w_perceptual_loss"], t["w_syncloss"]) == (1.0, 0.01, 0.01)
+    cfg0 = s2l.may_config(96, 96)
+    assert not cfg0["training"]["use_perceptual_loss"] and not cfg0["training"]["use_syncloss"]
+    from speech2lip_amd.training import Trainer
+
+    class _M:      # Trainer only reads these from the model at construction
+        audio_dims, device = 64, "cpu"
+    cfg0["model"]["lambda_rgb"] = 0.25
+    cfg0["training"]["lambda_rgb"] = 9.0
+    _M.cfg = cfg0
+    assert Trainer(_M()).w_photometric_loss == 0.25
+    del cfg0["model"]["lambda_rgb"]
+    assert Trainer(_M()).w_photometric_loss == 9.0
+    assert hasattr(Trainer, "train_step")
+
+
 def test_sync_chain_unet_window_geometry():
     """SyncChain.unet_window: the canonical-face box dilated by the U-Net's dependency radius, origins on the 4-pixel grid of the
     two pooling levels, sizes multiples of 4 unless the crop ends at the frame edge (what s2l_unet_forward_saved_window accepts)."""

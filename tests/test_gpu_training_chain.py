@@ -106,7 +106,9 @@ def test_composite_lip_gradient_vs_oracle_autograd(dev, expand, holes, F):
 
 # ------------------------------------------------------------------------------------------------ crop + resize
 @pytest.mark.parametrize("bbox,size,Tw", [((5, 7, 45, 47), (96, 96), 0), ((0, 0, 60, 50), (17, 23), 0), ((10, 3, 14, 9), (96, 96), 0),
-                                          ((8, 6, 56, 58), (96, 96), 5), ((120, 80, 380, 400), (96, 96), 5)])
+                                          ((8, 6, 56, 58), (96, 96), 5), ((120, 80, 380, 400), (96, 96), 5),
+                                          ((40, 30, 70, 60), (96, 96), 0),      # box leaves the 50x60 frame: python slicing clips it
+                                          ((30, 20, 60, 90), (96, 96), 5)])     # ... and in the window layout (64x64 frames: y2 = 90 is clipped to 64)
 def test_crop_resize_and_adjoint_vs_oracle(dev, bbox, size, Tw):
     from speech2lip_amd import autograd as A
     rng = np.random.default_rng(sum(bbox))
@@ -414,8 +416,10 @@ def _check_unet_train_grads(grads, g):
             sub = got if got.numel() <= 4096 else got.reshape(-1)[::13]
             scale = float(np.abs(g[key]).max())
             e = (sub.reshape(g[key].shape) - T(g[key])).abs() / scale
-            assert float(e.max()) <= 5e-3 and float((e > 5e-4).float().mean()) <= 0.02, (key, float(e.max()), float((e > 5e-4).float().mean()))
-            assert abs(float(got.abs().double().sum()) - float(g["n_" + key[2:]])) <= 2e-3 * float(g["n_" + key[2:]]), key
+            # the fixture's input keeps every ReLU / max-pool decision of the reference run >= 1e-5 from its boundary
+            # (tools/make_goldens.py, DecisionMargins): no tie can resolve differently here, so the bound is a rounding bound
+            assert float(e.max()) <= 1e-3, (key, float(e.max()))
+            assert abs(float(got.abs().double().sum()) - float(g["n_" + key[2:]])) <= 5e-4 * float(g["n_" + key[2:]]), key
 
 
 def test_unet_train_mode_golden(golden, dev):
@@ -428,7 +432,8 @@ def test_unet_train_mode_golden(golden, dev):
     out, ctx = u.forward_train_nhwc(T(g["x"]).to(dev))
     close(out, g["y"], 5e-6, 5e-5)
     dx, grads = u.backward_train(ctx, T(g["d_out"]).to(dev))
-    assert relerr(dx, g["d_x"]) <= 2e-3
+    assert float(g["margin"]) >= 1e-5
+    assert relerr(dx, g["d_x"]) <= 1e-3
     _check_unet_train_grads(grads, g)
     sd = u.state_dict()
     for key in g:
@@ -454,7 +459,7 @@ def test_unet_train_mode_through_the_module_and_autograd(golden, dev):
     y = u(x)
     (y.permute(0, 2, 3, 1) * T(g["d_out"]).to(dev)).sum().backward()
     close(y.permute(0, 2, 3, 1), g["y"], 5e-6, 5e-5)
-    assert relerr(x.grad.permute(0, 2, 3, 1), g["d_x"]) <= 2e-3
+    assert relerr(x.grad.permute(0, 2, 3, 1), g["d_x"]) <= 1e-3
     _check_unet_train_grads({k: p.grad for k, p in u.named_parameters()}, g)
 
 
@@ -495,6 +500,7 @@ def test_stage_one_step_before_the_unet_is_fixed_autograd(golden, dev):
     import random
     g, data, _, _, face = _g11_device(golden, dev)
     e = golden("g14_stage1_early.npz")
+    face = dict(face, rgb_face_gt=T(e["rgb_face_ori"]).to(dev))           # the searched observed frame of G14 (no decision ties)
     m = full_model(dev, 16, 24).train()
     assert m.post_fusion_unet.training
     tr = s2l.Trainer(m)
@@ -523,10 +529,7 @@ def test_stage_one_step_before_the_unet_is_fixed_autograd(golden, dev):
             name = key[2:]
             got, ref = params[name].grad.cpu(), T(e[key])
             err = (got - ref).abs() / float(ref.abs().max())
-            if name.startswith("post_fusion_unet"):    # ReLU ties of the fp32 network: bulk tight, outliers loose
-                assert float(err.max()) <= 5e-2 and float((err > 5e-3).float().mean()) <= 0.05, (name, float(err.max()))
-            else:
-                assert float(err.max()) <= 1e-3, (name, float(err.max()))
+            assert float(err.max()) <= 1e-3, (name, float(err.max()))     # U-Net tensors too: the fixture has no decision ties
     assert int(m.post_fusion_unet.inc.double_conv[1].num_batches_tracked) == 101      # 100 in the seeded state dict + this step
 
 
@@ -604,7 +607,7 @@ def test_trainer_train_stage1_reproduces_the_reference_step(golden, syncnet, dev
     tr = s2l.Trainer(m, optimizer=torch.optim.SGD(m.parameters(), lr=0.0), cfg=cfgm(m), syncnet=syncnet, use_syncloss=True)
     restore = _patched_draws(e["eps"], face["hole_noise"], dev)
     try:
-        _, loss = tr.train_stage1(data, it=50000, seed=0)
+        _, loss = tr.train_stage1(dict(data, rgb_face_ori=T(e["rgb_face_ori"])), it=50000, seed=0)
     finally:
         eq, fq = restore()
     assert not eq and not fq and float(loss["loss_sync"]) == 0.0
@@ -614,10 +617,76 @@ def test_trainer_train_stage1_reproduces_the_reference_step(golden, syncnet, dev
         if key.startswith("g_"):
             got, ref = params[key[2:]].grad.cpu(), T(e[key])
             err = (got - ref).abs() / float(ref.abs().max())
-            if key[2:].startswith("post_fusion_unet"):
-                assert float(err.max()) <= 5e-2 and float((err > 5e-3).float().mean()) <= 0.05, (key, float(err.max()))
-            else:
-                assert float(err.max()) <= 1e-3, (key, float(err.max()))
+            assert float(err.max()) <= 1e-3, (key, float(err.max()))          # U-Net tensors included (tie-free fixture)
+
+
+def _check_g16(g, loss, loss_sync, grads, unet, dev):
+    assert abs(float(loss) - float(g["loss"])) <= 3e-6 and abs(float(loss_sync) - float(g["loss_sync"])) <= 2e-6
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            assert relerr(grads[key[2:]], g[key]) <= 5e-4, (key, relerr(grads[key[2:]], g[key]))
+        if key.startswith("s_"):
+            close(unet.state_dict()[key[2:]], g[key], 2e-6, 2e-5)
+    assert relerr(grads["pts_linears.5.weight"][:, 250:262], g["g_pts5_cols"]) <= 5e-4
+    assert int(unet.inc.double_conv[1].num_batches_tracked) == int(g["tracked"])       # 1 main + 5 window one-frame calls
+
+
+def test_trainer_train_step_is_the_reference_loop_step(golden, syncnet, dev):
+    """Trainer.train_step (training.py:140-155): self.model.train() then train_stage1.  After it > 100000 that .train() undoes the
+    post_fusion_unet.eval() of train.py:195, so the FROZEN U-Net runs with BatchNorm batch statistics on each one-frame call and
+    keeps moving its running statistics.  Against the reference's own train_step on the same batch (G16): loss dict, return
+    value, MLP gradients, running statistics, num_batches_tracked."""
+    g11, data, eps, _, face = _g11_device(golden, dev)
+    g = golden("g16_stage1_trainbn.npz")
+    m = full_model(dev, 16, 24).train()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    m.post_fusion_unet.eval()                                              # train.py:188-197 ... and train_step undoes it
+    cfg = {**m.cfg, "training": {**m.cfg["training"], "use_canonical_depth_loss_photo_v2": False, "use_perceptual_loss": False,
+                                 "stage": "stage1", "batch_rays": 16 * 24}}
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
+    tr = s2l.Trainer(m, optimizer=opt, cfg=cfg, syncnet=syncnet, use_syncloss=True)
+    restore = _patched_draws(eps, face["hole_noise"], dev)
+    try:
+        item, loss = tr.train_step(data, it=100001, seed=0)
+    finally:
+        eq, fq = restore()
+    assert not eq and not fq and m.post_fusion_unet.training
+    assert isinstance(item, float) and abs(item - float(g["loss_item"])) <= 2e-6
+    assert abs(float(g["loss"]) - float(g11["loss"])) > 0.1                # a different step than the eval-mode G11
+    _check_g16(g, loss["loss"], loss["loss_sync"], {k: p.grad for k, p in m.named_parameters() if p.grad is not None},
+               m.post_fusion_unet, dev)
+    assert not any(p.grad is not None for p in m.post_fusion_unet.parameters())
+
+
+def test_stage_one_step_follows_the_unet_mode(golden, syncnet, dev):
+    """The fused StageOneStep / SyncChain follow the post-fusion U-Net's own mode like post_fusion2_onlylip does: train mode and
+    frozen = the reference's loop after it > 100000 (G16: one-frame batch statistics, whole frames, running statistics moved in
+    call order: main frame, then the window); train mode and trainable, no sync = the step before (G14: the U-Net's parameter
+    gradients come back under post_fusion_unet.*); eval mode = G11 (test_stage_one_step_golden_fp32)."""
+    _, data, eps, sync, face = _g11_device(golden, dev)
+    g = golden("g16_stage1_trainbn.npz")
+    m = full_model(dev, 16, 24).train()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    step = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="fp32", face_loss=True)
+    a, idx, tgt = data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev)
+    loss, grads, aux = step.loss_and_grads(a, idx, tgt, [eps[0]], sync=sync, face=face)
+    assert not any(k.startswith("post_fusion_unet") for k in grads)
+    _check_g16(g, loss, aux["loss_sync"], grads, m.post_fusion_unet, dev)
+    close(aux["rgb_window"], g["rgb_window"], 2e-6, 3e-5)
+    # before it > 100000: the net trains with the MLP
+    e = golden("g14_stage1_early.npz")
+    m = full_model(dev, 16, 24).train()
+    step = s2l.StageOneStep(m, 16, 24, syncnet=None, precision="fp32", face_loss=True)
+    face14 = dict(face, rgb_face_gt=T(e["rgb_face_ori"]).to(dev))
+    loss, grads, _ = step.loss_and_grads(a, idx, tgt, [float(e["eps"][0])], face=face14)
+    assert abs(float(loss) - float(e["loss"])) <= 5e-6
+    for key in e:
+        if key.startswith("g_"):
+            assert relerr(grads[key[2:]], e[key]) <= 1e-3, (key, relerr(grads[key[2:]], e[key]))
+    assert sum(float(v.abs().double().sum()) for k, v in grads.items() if k.startswith("post_fusion_unet")) == \
+        pytest.approx(float(e["n_unet"]), rel=5e-4)
 
 
 @pytest.mark.parametrize("fh,fw,F", [(64, 80, 2), (500, 500, 1)])

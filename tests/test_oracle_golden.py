@@ -277,14 +277,15 @@ def test_g13_unet_train_mode(golden):
     y = O.unet_forward(usd, x, training=True, new_stats=stats)
     (y * T(g["d_out"])).sum().backward()
     assert _maxerr(y.detach(), g["y"]) <= 3e-5
-    assert _maxerr(x.grad, g["d_x"]) <= 1e-3 * float(np.abs(g["d_x"]).max())
+    assert float(g["margin"]) >= 1e-5          # the fixture's input keeps every ReLU / max-pool decision clear of rounding
+    assert _maxerr(x.grad, g["d_x"]) <= 1e-4 * float(np.abs(g["d_x"]).max())
     pre = "post_fusion_unet."
     for key in g:
         if key.startswith("g_"):
             got = usd[pre + key[2:]].grad
             got = got if got.numel() <= 4096 else got.reshape(-1)[::13]
-            assert _maxerr(got.reshape(g[key].shape), g[key]) <= 1e-3 * float(np.abs(g[key]).max()), key
-            assert abs(float(usd[pre + key[2:]].grad.abs().double().sum()) - float(g["n_" + key[2:]])) <= 1e-3 * float(g["n_" + key[2:]])
+            assert _maxerr(got.reshape(g[key].shape), g[key]) <= 1e-4 * float(np.abs(g[key]).max()), key
+            assert abs(float(usd[pre + key[2:]].grad.abs().double().sum()) - float(g["n_" + key[2:]])) <= 1e-4 * float(g["n_" + key[2:]])
         if key.startswith("s_"):
             assert _maxerr(stats[pre + key[2:]], g[key]) <= 1e-5, key
     assert int(g["tracked"]) == int(usd[pre + "inc.double_conv.1.num_batches_tracked"]) + 1
@@ -292,10 +293,11 @@ def test_g13_unet_train_mode(golden):
 
 def test_g14_stage_one_step_before_the_unet_is_fixed(golden):
     """The reference's train_stage1 at it = 50000: post-fusion U-Net in train mode and trained with the MLP, no sync term.
-    MLP gradients to 2e-5; the U-Net encoder gradients carry one ReLU tie of the fp32 evaluation (tools/make_goldens.py, G14),
-    so they are held to 3 % of their maxima."""
+    The observed frame of this fixture was searched so that no ReLU / max-pool decision of the reference's run sits within fp32
+    rounding of its boundary (tools/make_goldens.py, G14): MLP gradients to 2e-5, U-Net gradients to 1e-4 of their maxima."""
     g, data, _, holes = g11_inputs(golden)
     e = golden("g14_stage1_early.npz")
+    data = dict(data, rgb_face_ori=T(e["rgb_face_ori"]))
     sd = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
     usd = {k: T(v).clone() for k, v in W.make_unet_state_dict(0).items()}
     for v in usd.values():
@@ -308,5 +310,28 @@ def test_g14_stage_one_step_before_the_unet_is_fixed(golden):
         if key.startswith("g_"):
             name = key[2:]
             got = (usd if name.startswith("post_fusion_unet") else sd)[name].grad
-            tol = 3e-2 if name.startswith("post_fusion_unet") else 2e-5
+            tol = 1e-4 if name.startswith("post_fusion_unet") else 2e-5
             assert _maxerr(got, e[key]) <= tol * float(np.abs(e[key]).max()), key
+
+
+def test_g16_stage_one_step_through_train_step(golden):
+    """The step after it > 100000 as the reference's loop reaches it -- Trainer.train_step (training.py:140-155), whose
+    self.model.train() puts the frozen post-fusion U-Net back into train mode: every one-frame U-Net call (main frame, then the
+    five window frames) normalises with its own batch statistics and moves the running statistics (tools/make_goldens.py G16)."""
+    g11, data, eps, holes = g11_inputs(golden)
+    g = golden("g16_stage1_trainbn.npz")
+    sd = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    stats = {}
+    res = O.stage_one_losses(sd, O.to_sd(W.make_unet_state_dict(0)), O.to_sd(W.make_syncnet_state_dict(0)), W.SYNCNET_FACE,
+                             W.SYNCNET_AUDIO, data, eps, holes, 16, 24, unet_training=True, with_sync=True, new_stats=stats)
+    res["loss"].backward()
+    assert abs(float(res["loss"]) - float(g["loss"])) <= 1e-6 and abs(float(res["loss_sync"]) - float(g["loss_sync"])) <= 1e-7
+    assert abs(float(g["loss"]) - float(g11["loss"])) > 0.1        # not the eval-mode step: the face term differs by far
+    assert float(g["loss_item"]) == float(g["loss_rgb"])           # train_step returns loss_rgb.item()
+    assert _maxerr(res["rgb_window"].detach(), g["rgb_window"]) <= 1e-6
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            assert _maxerr(sd[key[2:]].grad, g[key]) <= 1e-4 * float(np.abs(g[key]).max()), key
+        if key.startswith("s_"):
+            assert _maxerr(stats["post_fusion_unet." + key[2:]], g[key]) <= 1e-5, key
+    assert _maxerr(sd["pts_linears.5.weight"].grad[:, 250:262], g["g_pts5_cols"]) <= 1e-4 * float(np.abs(g["g_pts5_cols"]).max())

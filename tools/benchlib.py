@@ -262,7 +262,7 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
     m.post_fusion_unet.eval()
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
-    lp = s2l.LPIPS(net="alex", version="0.1").to(dev)
+    lp = s2l.LPIPS(pretrained=False, net="alex", version="0.1").to(dev)      # seeded weights are loaded below
     lp.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()})
     opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
     audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)

@@ -61,6 +61,39 @@ def ref_model(ref_config, TalkingFace, height, width, data_path=None, use_post_f
     return model, cfg
 
 
+
+class DecisionMargins:
+    """Forward hooks on a reference SimpleUnetLight: the smallest |BatchNorm output| (= ReLU pre-activation) and the smallest gap
+    between the two largest values of a 2x2 max-pool window whose maximum is positive, over everything the hooked module
+    evaluates.  A value inside fp32 rounding of such a decision boundary resolves differently in another evaluation order and
+    moves every gradient upstream of it; gradient fixtures are generated from inputs that keep clear of them."""
+
+    def __init__(self, unet):
+        self.relu, self.pool, self.handles = float("inf"), float("inf"), []
+        for mod in unet.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                self.handles.append(mod.register_forward_hook(self._bn))
+            elif isinstance(mod, torch.nn.MaxPool2d):
+                self.handles.append(mod.register_forward_pre_hook(self._mp))
+
+    def _bn(self, mod, inp, out):
+        self.relu = min(self.relu, float(out.detach().abs().min()))
+
+    def _mp(self, mod, inp):
+        x = inp[0].detach()
+        b, c, h, w = x.shape
+        win = x[:, :, :h // 2 * 2, :w // 2 * 2].reshape(b, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, h // 2, w // 2, 4)
+        top = win.topk(2, dim=-1).values
+        gap = (top[..., 0] - top[..., 1])[top[..., 0] > 0]
+        if gap.numel():
+            self.pool = min(self.pool, float(gap.min()))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        return min(self.relu, self.pool)
+
+
 def maxerr(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
 
@@ -423,20 +456,42 @@ def main():
 
     # ---- G14: the same reference train_stage1 BEFORE it > 100000: the post-fusion U-Net in train mode and trained with the MLP
     # (train.py:188-197 not yet applied), no sync term: MSE(lip) + MSE(face recon through composite-with-black-holes + U-Net)
+    # The observed frame of this step is searched (seeds 14000, 14001, ...) until the reference's own run keeps every ReLU
+    # pre-activation and every positive max-pool decision of the train-mode U-Net at least MARGIN14 away from its boundary: then
+    # the gradients are a smooth function of the rounding and can be held to 1e-3 (a tie moves them by percents).
+    import copy
+    MARGIN14 = 4e-6
+
+    def early_step(mdl, d14, probe):
+        tr.model = mdl
+        tr.optimizer = torch.optim.SGD(mdl.parameters(), lr=0.0)
+        eq, fq = [0.81], [f_.clone() for f_ in fields]
+        torch.rand = lambda *a, **k: torch.full((1,), eq.pop(0))
+        torch.randn = lambda *a, **k: fq.pop(0)
+        _random.random = lambda: 0.9
+        dm = DecisionMargins(mdl.post_fusion_unet) if probe else None
+        try:
+            _, la = tr.train_stage1(d14, it=50000, seed=0)
+        finally:
+            torch.rand, torch.randn, _random.random = real_rand, real_randn, real_random
+        return la, (dm.close() if probe else None)
+
     model, cfg = ref_model(ref_config, TalkingFace, h_, w_)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()}, strict=False)
     model.train()
     cfg["training"].update(use_canonical_depth_loss_photo_v2=False, use_perceptual_loss=False)
-    tr.model, tr.cfg = model, cfg
-    tr.optimizer = torch.optim.SGD(model.parameters(), lr=0.0)
-    eq, fq = [0.81], [f_.clone() for f_ in fields]
-    torch.rand = lambda *a, **k: torch.full((1,), eq.pop(0))
-    torch.randn = lambda *a, **k: fq.pop(0)
-    _random.random = lambda: 0.9
-    try:
-        _, loss_all = tr.train_stage1(data, it=50000, seed=0)
-    finally:
-        torch.rand, torch.randn, _random.random = real_rand, real_randn, real_random
+    tr.cfg = cfg
+    for s14 in range(14000, 16000):
+        gt14 = torch.from_numpy(np.random.default_rng(s14).random((1, FH, FW, 3), dtype=np.float32))
+        data14 = dict(data, rgb_face_ori=gt14)
+        _, margin14 = early_step(copy.deepcopy(model), data14, True)
+        if margin14 >= MARGIN14:
+            break
+    else:
+        raise AssertionError("G14: no observed frame with clear decision margins found")
+    print(f"  [info] G14: observed-frame seed {s14}, smallest decision margin of the reference run {margin14:.2e}")
+    data_g11, data = data, data14
+    loss_all, _ = early_step(model, data, False)
     ref_g = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
     sd_g = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
     usd_g = {k: torch.from_numpy(v).clone() for k, v in W.make_unet_state_dict(0).items()}
@@ -456,17 +511,73 @@ def main():
             if dev_ > 1e-4:
                 print(f"  [info] {k}: rel dev {dev_:.2e}, |grad|max {float(ref_g[k].abs().max()):.3e}")
             worst = max(worst, dev_)
-    # The MLP and decoder gradients agree to ~1e-5; the encoder layers deviate by 0.2-1.5 % of their maxima: the reference's fused
-    # BatchNorm and the oracle's mean/var composition round differently, one ReLU of the deepest layer whose pre-activation is within
-    # that rounding of zero resolves differently, and every gradient upstream of it (and that layer's BatchNorm bias gradient most
-    # of all) moves with it.  Inherent to fp32 evaluation of this network; the limit for this check is set accordingly.
+    # (With the g4 observed frame this check used to sit at 1.5 %: one ReLU of the deepest layer had its pre-activation within fp32
+    # rounding of zero and resolved differently in the reference's fused BatchNorm and the oracle's mean/var composition.  The
+    # searched frame has no such decision, and the limit is 1e-3.)
     report["stage1_early_grads_rel"] = worst
     ukeep = ["post_fusion_unet.inc.double_conv.0.weight", "post_fusion_unet.up2.conv.double_conv.4.weight", "post_fusion_unet.outc.conv.weight",
              "post_fusion_unet.down1.maxpool_conv.1.double_conv.1.bias"]
+    data = data_g11
     np.savez_compressed(os.path.join(GOLD, "g14_stage1_early.npz"), eps=np.array([0.81], np.float32), loss=np.array(float(loss_all["loss"])),
+                        rgb_face_ori=gt14.numpy(), gt_seed=np.array(s14), margin=np.array(margin14),
                         **{"g_" + k: ref_g[k].numpy() for k in ("output_linear.weight", "pts_linears.3.bias", "fc_uv.weight", "encoder_fc1.0.weight")},
                         **{"g_" + k: ref_g[k].numpy() for k in ukeep},
                         n_unet=np.array(sum(float(ref_g[k].abs().double().sum()) for k in ref_g if k.startswith("post_fusion_unet"))))
+
+    # ---- G16: the step after it > 100000 AS THE REFERENCE'S LOOP RUNS IT: train.py:188-197 freezes the post-fusion U-Net and calls
+    # .eval() on it once, but every iteration then goes through Trainer.train_step (training.py:140-155), whose first statement is
+    # self.model.train() -- which puts the frozen sub-module back into train mode.  The U-Net of the face term and of the five window
+    # frames therefore normalises each ONE-frame call with that frame's batch statistics and keeps moving its running statistics,
+    # with its parameters fixed.  (G11 above is train_stage1 entered directly with the sub-module left in eval mode.)
+    model, cfg = ref_model(ref_config, TalkingFace, h_, w_)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()}, strict=False)
+    model.train()
+    for p_ in model.post_fusion_unet.parameters():
+        p_.requires_grad = False
+    model.post_fusion_unet.eval()                                     # train.py:195
+    cfg["training"].update(use_canonical_depth_loss_photo_v2=False, use_perceptual_loss=False, stage="stage1")
+    tr.model, tr.cfg = model, cfg
+    tr.optimizer = torch.optim.SGD([p_ for p_ in model.parameters() if p_.requires_grad], lr=0.0)
+    eq, fq = list(eps_list), [f_.clone() for f_ in fields]
+    torch.rand = lambda *a, **k: torch.full((1,), eq.pop(0))
+    torch.randn = lambda *a, **k: fq.pop(0)
+    _random.random = lambda: 0.9
+    try:
+        loss_item, loss_all = tr.train_step(data, it=100001, seed=0)
+    finally:
+        torch.rand, torch.randn, _random.random = real_rand, real_randn, real_random
+    assert not eq and not fq and model.post_fusion_unet.training      # train_step undid the .eval()
+    ref_g = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    assert not [k for k in ref_g if k.startswith("post_fusion_unet")]
+    ref_b = {k: v.clone() for k, v in model.named_buffers() if k.startswith("post_fusion_unet")}
+    sd_g = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    stats16 = {}
+    res = O.stage_one_losses(sd_g, O.to_sd(W.make_unet_state_dict(0)), osd, W.SYNCNET_FACE, W.SYNCNET_AUDIO, data, eps_list,
+                             (fields[0][:, 0], fields[1][:, 0]), h_, w_, unet_training=True, with_sync=True, new_stats=stats16)
+    res["loss"].backward()
+    report["stage1_trainbn_loss"] = maxerr(loss_all["loss"].detach(), res["loss"].detach())
+    report["stage1_trainbn_loss_sync"] = maxerr(loss_all["loss_sync"].detach(), res["loss_sync"].detach())
+    worst = 0.0
+    for k in sd_g:
+        worst = max(worst, maxerr(ref_g[k], sd_g[k].grad) / (float(ref_g[k].abs().max()) + 1e-12))
+    report["stage1_trainbn_grads_rel"] = worst
+    report["stage1_trainbn_running_stats"] = max(maxerr(ref_b[k], stats16[k]) for k in ref_b if "num_batches" not in k)
+    nb0 = int(W.make_unet_state_dict(0).get("post_fusion_unet.inc.double_conv.1.num_batches_tracked", 0))
+    assert all(int(ref_b[k]) == nb0 + 6 for k in ref_b if "num_batches" in k)                             # 1 main + 5 window calls
+    assert all(stats16[k] is None or int(stats16[k]) == nb0 + 6 for k in ref_b if "num_batches" in k)
+    g11 = dict(np.load(os.path.join(GOLD, "g11_stage1.npz")))
+    print(f"  [info] train-mode-BN step: loss {float(loss_all['loss']):.6f} (eval-mode G11: {float(g11['loss']):.6f}), sync "
+          f"{float(loss_all['loss_sync']):.6f} (G11: {float(g11['loss_sync']):.6f}); worst relative gradient deviation {worst:.2e}")
+    skeep = ["inc.double_conv.1.running_mean", "inc.double_conv.1.running_var", "down2.maxpool_conv.1.double_conv.4.running_var",
+             "up2.conv.double_conv.4.running_mean", "up2.conv.double_conv.4.running_var"]
+    np.savez_compressed(
+        os.path.join(GOLD, "g16_stage1_trainbn.npz"), loss=np.array(float(loss_all["loss"])), loss_rgb=np.array(float(loss_all["loss_rgb"])),
+        loss_sync=np.array(float(loss_all["loss_sync"])), loss_item=np.array(float(loss_item)),
+        rgb_window=res["rgb_window"].detach().numpy(), tracked=np.array(nb0 + 6),
+        **{"g_" + k: ref_g[k].numpy() for k in ("output_linear.weight", "pts_linears.7.bias", "pts_linears.0.weight", "fc_time.bias",
+                                                "fc_audio_skip.weight", "encoder_conv.0.weight", "encoder_fc1.2.bias")},
+        g_pts5_cols=ref_g["pts_linears.5.weight"][:, 250:262].numpy(),
+        **{"s_" + k: ref_b["post_fusion_unet." + k].numpy() for k in skeep})
 
     # ---- G12: canonical-depth photometric loss (training.py:462-477): the reference's own Trainer.inverse_warping +
     # add_loss_canonical_depth_photo and the gradient loss.backward() leaves in canonical_depth_head.grad
@@ -503,8 +614,22 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in usd.items()}, strict=False)
     unet = model.post_fusion_unet
     unet.train()
-    xin = torch.from_numpy(rng2.random((2, 20, 24, 3), dtype=np.float32)).requires_grad_(True)
-    dout = torch.from_numpy(rng2.standard_normal((2, 20, 24, 3)).astype(np.float32))
+    MARGIN13 = 1e-5
+    for s13 in range(13000, 15000):      # input searched like G14's observed frame: no ReLU / max-pool decision within MARGIN13
+        rng13 = np.random.default_rng(s13)
+        xin = torch.from_numpy(rng13.random((2, 20, 24, 3), dtype=np.float32))
+        probe, dm = copy.deepcopy(unet), None
+        dm = DecisionMargins(probe)
+        with torch.no_grad():
+            probe(xin.permute(0, 3, 1, 2))
+        margin13 = dm.close()
+        if margin13 >= MARGIN13:
+            break
+    else:
+        raise AssertionError("G13: no input with clear decision margins found")
+    print(f"  [info] G13: input seed {s13}, smallest decision margin of the reference run {margin13:.2e}")
+    xin.requires_grad_(True)
+    dout = torch.from_numpy(rng13.standard_normal((2, 20, 24, 3)).astype(np.float32))
     y_ref = unet(xin.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     (y_ref * dout).sum().backward()
     usd_t = {k: torch.from_numpy(v).clone() for k, v in usd.items()}
@@ -535,14 +660,14 @@ def main():
                         **{"n_" + k: np.array(float(refp[k].grad.abs().double().sum())) for k in keep},
                         **{"s_" + k: refb[k].numpy() for k in ("inc.double_conv.1.running_mean", "inc.double_conv.1.running_var",
                                                                "up1.conv.double_conv.4.running_mean", "up1.conv.double_conv.4.running_var")},
-                        tracked=refb["inc.double_conv.1.num_batches_tracked"].numpy())
+                        tracked=refb["inc.double_conv.1.num_batches_tracked"].numpy(), x_seed=np.array(s13), margin=np.array(margin13))
 
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
     # sits ~4e-6 from the fp64 evaluation of the same formula), and inverse_warping multiplies that by the image gradient.
-    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3, "stage1_early_grads_rel": 3e-2, "unet_train_forward": 3e-5, "unet_train_dx_rel": 1e-3,
-              "unet_train_grads_rel": 1e-3, "unet_train_running_stats": 1e-5}
+    limits = {"inverse_warping": 1e-4, "stage1_grads_rel": 2e-5, "depth_photo_grad_rel": 1e-3, "stage1_early_grads_rel": 1e-3, "stage1_trainbn_grads_rel": 1e-3, "stage1_trainbn_running_stats": 1e-5, "unet_train_forward": 3e-5, "unet_train_dx_rel": 1e-4,
+              "unet_train_grads_rel": 1e-4, "unet_train_running_stats": 1e-5}
     limits.update({k: 1e-5 for k in report if k.startswith("warp_grid")})
     bad = []
     for k, v in report.items():

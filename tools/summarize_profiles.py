@@ -36,6 +36,12 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
     out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes\n" % traffic)
+    # the figure bench.py's roofline.traffic carries: tracked next to the profile it comes from, read by bench.py
+    json.dump({"profile": f"profiles/{tag}_rocprofv3_summary.txt", "kernel": "s2l::render_tiles_kernel",
+               "frames_per_dispatch": 1000, "height": 96, "width": 96,
+               "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+               "hbm_bytes_per_dispatch": round(traffic), "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024"},
+              open("profiles/render_traffic.json", "w"), indent=1)
 out.append("\n## composite: rocprofv3 --kernel-trace --stats -- python tools/bench_composite.py 256\n")
 for r in stats("cstats"):
     out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
