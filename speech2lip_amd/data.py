@@ -16,8 +16,16 @@ modes ('val' / 'test'), but once per CLIP: every per-frame array is stacked and 
 one go (pinned staging, non-blocking copies), because the renderer consumes whole clips.  JPEG
 decoding uses PIL (the reference uses imageio -- PIL underneath -- and cv2; decoders agree to
 within 1/255 on the same libjpeg family, which is why parity of this row is pinned on synthetic
-folders written by the tests rather than on golden pixels).  Training-only fields (mel windows,
-SyncNet crops, head masks) are not read.
+folders written by the tests rather than on golden pixels).
+
+`SomeonesLipClip.load_one_frame(index)` is the per-frame mirror of the reference's `load_one_frame`
+(:242-399): the same dictionary, key for key, including the training fields the sync loss consumes
+(`mel`, `coord_window`, `audio_window`, `canonical_face_bbox`, `rgb_window_neg`, `total_frame`) and the
+6-DoF pose / canonical masks of the depth loss.  It is checked field by field against what the
+REFERENCE's own reader yields for the committed fixture folder (golden G15, tools/make_goldens.py;
+pinned except JPEG decoding, cv2.resize's interpolation and cv2.boundingRect's rounding -- those three
+libraries are absent from the image).  The mel front-end (src/data/audio.py, librosa) is out of scope:
+the spectrogram is read precomputed from `audio/mel.npy` ([80, T_mel], what `melspectrogram` returns).
 """
 from __future__ import annotations
 
@@ -40,6 +48,41 @@ def _read_rgb(path: str) -> np.ndarray:
 def _read_bgr01(path: str) -> np.ndarray:
     """cv2.imread(path) / 255 (someones_lip_dataset.py:72): channels in BGR order, float64 -> float32."""
     return _read_rgb(path)[:, :, ::-1].copy()
+
+
+def _resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv2.resize(img, (out_w, out_h)) for uint8 images, default INTER_LINEAR: half-pixel centres
+    (src = (dst + 0.5) * scale - 0.5, taps clamped to the image), separable, OpenCV's fixed-point form (11-bit
+    coefficients, the two passes rounded once at the end).  UNPINNED: cv2 is not in the image to check against."""
+    h, w = img.shape[:2]
+    if (h, w) == (out_h, out_w):
+        return img.copy()
+
+    def taps(n_in, n_out):
+        src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+        i0 = np.floor(src).astype(np.int64)
+        f = src - i0
+        f = np.where(i0 < 0, 0.0, f)
+        i0c = np.clip(i0, 0, n_in - 1)
+        i1c = np.clip(i0 + 1, 0, n_in - 1)
+        f = np.where(i0 >= n_in - 1, 0.0, f)
+        c1 = np.rint(f * 2048).astype(np.int64)
+        return i0c, i1c, 2048 - c1, c1
+    y0, y1, wy0, wy1 = taps(h, out_h)
+    x0, x1, wx0, wx1 = taps(w, out_w)
+    a = img.astype(np.int64)
+    rows = a[:, x0] * wx0[None, :, None] + a[:, x1] * wx1[None, :, None]            # [h, out_w, C] * 2^11
+    out = rows[y0] * wy0[:, None, None] + rows[y1] * wy1[:, None, None]             # * 2^22
+    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+
+
+def crop_audio_window(spec: np.ndarray, start_frame: int, fps: int = 25, syncnet_mel_step_size: int = 16) -> np.ndarray:
+    """someones_lip_dataset.py:401-414: 16 mel frames from int(80 * start_frame / fps), or the last 16."""
+    start = int(80.0 * (start_frame / float(fps)))
+    end = start + syncnet_mel_step_size
+    if end > spec.shape[0]:
+        start, end = spec.shape[0] - 16, spec.shape[0]
+    return spec[start:end, :]
 
 
 def list_dir(folder: str, ext: str):
@@ -109,6 +152,12 @@ class SomeonesLipClip:
         if mode not in ("val", "test", "train"):
             raise ValueError(f"unknown mode {mode!r}")
         self.dataset_folder, self.mode, self.cfg, self.img_ext = dataset_folder, mode, cfg, img_ext
+        tc, mc = ((cfg or {}).get("training", {}), (cfg or {}).get("model", {}))
+        self.use_syncloss = bool(tc.get("use_syncloss", False))                            # :34
+        self.use_sync_contrastive_loss = bool(tc.get("use_sync_contrastive_loss", False))
+        self.use_canonical_depth = bool(mc.get("use_canonical_depth", False))
+        self.use_post_fusion = bool(mc.get("use_post_fusion", True))
+        self.fmin = 95 if "may" in dataset_folder else 55                                  # :104-109 (mel front-end parameter)
         self.canonical_idx = 12 if "obama2" in dataset_folder else 0                      # :37-41
         j = lambda *p: os.path.join(dataset_folder, *p)
         canon = "{:05d}.jpg".format(self.canonical_idx + 1)
@@ -116,24 +165,102 @@ class SomeonesLipClip:
         self.face_h, self.face_w = self.rgb_face_zero.shape[:2]
         rgb_zero = _read_rgb(j("images", canon))                                           # :69
         self.lip_h, self.lip_w = rgb_zero.shape[:2]
+        self.rgb_zero = rgb_zero
         self.mask_lip_canonical = _read_bgr01(j("canonical_lip_mask.jpg"))                 # :72
+        if self.use_canonical_depth:                                                       # :75-93
+            if os.path.exists(j("track_params.pt")):
+                params = torch.load(j("track_params.pt"))
+                self.pose_features_euler, self.pose_features_trans = params["euler"], params["trans"]
+                self.canonical_euler = self.pose_features_euler[self.canonical_idx]
+                self.canonical_trans = self.pose_features_trans[self.canonical_idx]
+            self.mask_head_canonical = _read_bgr01(j("canonical_head_mask.jpg"))[:, :, :1].copy()     # channel 0 of BGR
+            self.mask_face_canonical = _read_bgr01(j("canonical_face_mask.jpg"))
         lms = np.loadtxt(j("landmarks", "{:05d}.lms".format(self.canonical_idx + 1)), dtype=np.float32)
         ratio = float((cfg or {}).get("data", {}).get("center_point_y_ratio", 1.0)) if cfg else 1.0
         self.lefttop_x, self.lefttop_y, _, _ = compute_mouth_bbox(lms, self.lip_w, self.lip_h, dataset_folder, ratio)
         self.image_files = list_dir(j("images"), img_ext)
         self.coord_files = list_dir(j("coords"), ".npy") if os.path.isdir(j("coords")) else None
-        aud = np.load(j("audio", "audio.npy"))                                             # :104
+        aud = np.load(j("audio", "audio.npy"))                                             # :102
+        if self.use_syncloss and mode == "train":                                          # :113-120
+            # orig_mel = melspectrogram(load_wav(audio/audio.wav), fmin).T -- the mel front-end is out of scope:
+            # the spectrogram is taken precomputed, in melspectrogram's own [80, T_mel] orientation
+            self.orig_mel = np.load(j("audio", "mel.npy")).T
+            self.face_bbox_dict = np.load(j("face_bbox_dict.npy"), allow_pickle=True).item()
         if mode == "test":                                                                 # :156-161
             self.aud_features = np.load(j("audio_test", "audio.npy"))
         else:
             sl = split_slice(aud.shape[0], mode, dataset_folder)
             self.aud_features = aud[sl]
             self.image_files = self.image_files[sl]
+            if mode == "train":
+                # :131 runs BEFORE the pose grids are sliced (:134-135) and while the 6-DoF pose still spans the whole clip
+                self.data_zero = self.load_one_frame(self.canonical_idx)
+                self.data_zero["rgb"] = self.data_zero["rgb"].unsqueeze(0)
+                self.data_zero["audio"] = self.data_zero["audio"].unsqueeze(0)
             if self.coord_files is not None:
                 self.coord_files = self.coord_files[sl]
+            if self.use_canonical_depth and hasattr(self, "pose_features_euler"):          # :136-138, :153-155
+                self.pose_features_euler = self.pose_features_euler[sl]
+                self.pose_features_trans = self.pose_features_trans[sl]
 
     def __len__(self):
         return int(self.aud_features.shape[0]) if self.mode == "test" else len(self.image_files)
+
+    def load_one_frame(self, index: int) -> dict:
+        """The dictionary `SomeonesLipDataset.load_one_frame(index)` returns (someones_lip_dataset.py:242-399), key for key and
+        type for type (host tensors / ints; the DataLoader's collate adds the batch axis).  Train mode with use_syncloss adds
+        the sync-loss inputs (:328-385)."""
+        j = lambda *p: os.path.join(self.dataset_folder, *p)
+        n = len(self)
+        inputs = {"audio": torch.from_numpy(np.asarray(self.aud_features[index]).astype(np.float32)),     # torch.Tensor(float64) casts
+                  "index": index, "total_frame": n}
+        if self.coord_files is not None:                                                   # :251-262
+            inputs["coord"] = torch.from_numpy(np.load(j("coords", self.coord_files[index])).astype(np.float32))
+        inputs["rgb_face_zero"] = torch.from_numpy(self.rgb_face_zero)
+        inputs["mask_lip_canonical"] = torch.from_numpy(self.mask_lip_canonical)
+        inputs["lip_lefttop_x"], inputs["lip_lefttop_y"] = self.lefttop_x, self.lefttop_y
+        if self.use_post_fusion or self.mode in ("val", "test"):                           # :272-275
+            inputs["rgb_face_ori"] = torch.from_numpy(_read_rgb(j("ori_images_face", self.image_files[index])))
+        if self.use_canonical_depth:                                                       # :295-297
+            inputs["mask_head_3DMM_canonical"] = torch.from_numpy(self.mask_head_canonical)
+            inputs["mask_face_3DMM_canonical"] = torch.from_numpy(self.mask_face_canonical)
+
+        def pose():                                                                        # :304-309 / :387-392
+            if self.use_canonical_depth:
+                inputs["canonical_euler"], inputs["canonical_trans"] = self.canonical_euler, self.canonical_trans
+                inputs["euler"], inputs["trans"] = self.pose_features_euler[index], self.pose_features_trans[index]
+        if self.mode == "test":                                                            # :299-314
+            inputs["rgb_zero"] = torch.from_numpy(self.rgb_zero)
+            pose()
+            return inputs
+        rgb = _read_rgb(j("images", self.image_files[index]))                              # :316-326
+        inputs["rgb"] = torch.from_numpy(rgb)
+        inputs["rgb_zero"] = torch.from_numpy(self.rgb_zero)
+        inputs["height"], inputs["width"] = rgb.shape[0], rgb.shape[1]
+        inputs["face_h"], inputs["face_w"] = self.face_h, self.face_w
+        if self.use_syncloss and self.mode == "train":                                     # :328-385
+            mel = crop_audio_window(self.orig_mel.copy(), index + 2)
+            inputs["mel"] = torch.from_numpy(np.ascontiguousarray(mel.T).astype(np.float32)).unsqueeze(0)      # [1,80,16]
+            # five consecutive frames; past the end of the split the last one that existed is repeated (:333-362)
+            last = lambda k, m: min(index + k, m - 1)
+            inputs["coord_window"] = torch.from_numpy(np.stack(
+                [np.load(j("coords", self.coord_files[last(k, len(self.coord_files))])).astype(np.float32) for k in range(5)]))
+            inputs["audio_window"] = torch.from_numpy(np.stack(
+                [np.asarray(self.aud_features[last(k, len(self.aud_features))]) for k in range(5)]).astype(np.float32))
+            inputs["canonical_face_bbox"] = self.face_bbox_dict["{:05d}.jpg".format(self.canonical_idx + 1)]   # :363
+            if self.use_sync_contrastive_loss:                                             # :365-385
+                # a window 5 frames later, or 10 frames earlier near the end; `index - 10` can be negative, which python's
+                # list indexing wraps to the end of the split -- reproduced, because that is what the reference trains on
+                start = index + 5 if index + 5 + 5 < len(self.image_files) else index - 10
+                frames = []
+                for k in range(5):
+                    from PIL import Image
+                    with Image.open(j("ori_images_face", self.image_files[start + k])) as im:
+                        u8 = np.asarray(im.convert("RGB"))
+                    frames.append((_resize_bilinear_u8(u8, 96, 96) / 255.0).astype(np.float32))
+                inputs["rgb_window_neg"] = torch.from_numpy(np.ascontiguousarray(np.transpose(np.asarray(frames), (3, 0, 1, 2))))
+        pose()
+        return inputs
 
     def load(self, device, first: int = 0, count: Optional[int] = None) -> ClipTensors:
         """Frames [first, first+count) of the split as device tensors (one H2D batch)."""
@@ -161,6 +288,21 @@ class SomeonesLipClip:
                            rgb_face_zero=up(self.rgb_face_zero[None]), mask_lip_canonical=up(self.mask_lip_canonical[None]),
                            lip_lefttop_x=self.lefttop_x, lip_lefttop_y=self.lefttop_y, height=self.lip_h, width=self.lip_w,
                            names=["{:05d}".format(int(i) + 1) for i in idx])
+
+
+def collate_batch(items):
+    """torch's default_collate for a list of `load_one_frame` dictionaries (what the reference's DataLoader hands to
+    Trainer.train_step, someones_lip_dataset.py:422-431): tensors and numpy arrays are stacked, ints become int64 tensors."""
+    out = {}
+    for k in items[0]:
+        vals = [it[k] for it in items]
+        if isinstance(vals[0], torch.Tensor):
+            out[k] = torch.stack(vals, 0)
+        elif isinstance(vals[0], np.ndarray):
+            out[k] = torch.stack([torch.from_numpy(np.ascontiguousarray(v)) for v in vals], 0)
+        else:
+            out[k] = torch.tensor(vals)
+    return out
 
 
 def render_clip_frames(model, clip: ClipTensors, use_post_fusion: bool = True):

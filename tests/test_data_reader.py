@@ -1,7 +1,12 @@
-"""CPU: the dataset wire-format reader on a synthetic folder written here in the
-reference's on-disk layout (src/data/someones_lip_dataset.py).  Parity of this row is pinned on the
-reference's documented conventions, not on golden pixels: its reader needs cv2/imageio, which this
-image does not have."""
+"""CPU: the dataset wire-format reader.
+
+Pinned by execution: golden G15 holds what the REFERENCE's own `SomeonesLipDataset` (src/data/someones_lip_dataset.py) yields for
+the committed fixture folder -- train / val / test, with and without the canonical-depth inputs, including the sync-loss
+training fields -- and `SomeonesLipClip.load_one_frame` must reproduce it key for key, dtype for dtype, value for value
+(test_reader_equals_the_reference_reader_g15).  The reference reader needs cv2 / imageio / librosa, which this image lacks; the
+golden script supplied functional stand-ins for the four calls it makes into them, so JPEG decoding, cv2.resize's interpolation
+and cv2.boundingRect's rounding remain UNPINNED (the fixture's frames are flat colours).  The other tests exercise the same
+conventions on synthetic folders written here."""
 import os
 
 import numpy as np
@@ -82,8 +87,9 @@ def test_write_frames_roundtrip(tmp_path):
 
 def test_committed_fixture_hand_traced():
     """tests/golden/dataset_fixture/may_face_crop_lip (tools/make_dataset_fixture.py) read by SomeonesLipClip, against what
-    the reference reader yields for it WHEN ITS CODE IS TRACED BY HAND (someones_lip_dataset.py line numbers in the comments).
-    Unpinned: the decoded JPEG pixels (the reference decodes with cv2 / imageio, absent here) -- flat images make them exact."""
+    the reference reader yields for it when its code is traced by hand (someones_lip_dataset.py line numbers in the comments) --
+    kept as the readable companion of test_reader_equals_the_reference_reader_g15, which checks the same folder against the
+    reference reader's actual output."""
     folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
     # :173-193 compute_mouth_bbox on landmarks 48..67: cv2.boundingRect of float points = (floor(5.5), floor(4.75),
     #   floor(12.25) - 5 + 1, floor(8.5) - 4 + 1) = (5, 4, 8, 5); centre x = 5 + 8/2 = 9.0; 'may' is neither 'adnerf' nor
@@ -117,3 +123,84 @@ def test_committed_fixture_hand_traced():
     assert te.audio[:, 0, 0].tolist() == [100.0, 101.0, 102.0, 103.0, 104.0] and te.coord is None
     # a folder that is not a named speaker uses the 90/10 split for val (:144-145 falls through with length = 18 -> [18:])
     assert D.split_slice(20, "val", "dataset/someone_face_crop_lip") == slice(18, None)
+
+
+G15_CASES = (("train", [0, 7, 8, 13, 16, 17]), ("val", [0, 19]), ("test", [0, 4]))
+
+
+def _fixture_reader(mode, depth):
+    from speech2lip_amd import config as C
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    cfg = C.may_config(6, 8, train_flags=True)                   # may.yaml's switches: use_syncloss, use_post_fusion, ...
+    cfg["model"]["use_canonical_depth"] = bool(depth)
+    cfg["training"]["use_sync_contrastive_loss"] = True          # may.yaml:47
+    return D.SomeonesLipClip(folder, mode, cfg=cfg)
+
+
+def _same(got, want, what):
+    got = got.numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    assert got.shape == want.shape and got.dtype == want.dtype, (what, got.shape, want.shape, got.dtype, want.dtype)
+    assert np.array_equal(got, want), (what, float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()))
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_reader_equals_the_reference_reader_g15(golden, depth):
+    """Field by field against the reference reader's own output on the fixture folder (tools/make_goldens.py, G15):
+    constructor state (:43-164), compute_mouth_bbox (:173-193), load_one_frame (:242-399) in every mode."""
+    g = golden("g15_dataset_reader.npz")
+    for mode, indices in G15_CASES:
+        tag = f"{mode}_depth{depth}"
+        ds = _fixture_reader(mode, depth)
+        assert len(ds) == int(g[tag + "/len"])
+        assert (ds.lefttop_x, ds.lefttop_y, ds.face_h, ds.face_w, ds.lip_h, ds.lip_w, ds.canonical_idx, ds.fmin) == tuple(
+            int(g[f"{tag}/{k}"]) for k in ("lefttop_x", "lefttop_y", "face_h", "face_w", "dst_mouth_h", "dst_mouth_w", "canonical_idx", "fmin"))
+        if mode != "test":
+            assert list(ds.image_files) == [str(v) for v in g[tag + "/files"]]
+            assert list(ds.coord_files) == [str(v) for v in g[tag + "/coord_files"]]
+        for i in indices:
+            want = {k.split("/")[-1]: v for k, v in g.items() if k.startswith(f"{tag}/{i}/")}
+            got = ds.load_one_frame(i)
+            assert set(got) == set(want), (tag, i, set(got) ^ set(want))
+            for k, v in want.items():
+                _same(got[k], v, (tag, i, k))
+        if mode == "train":      # :131-133: the canonical frame's dictionary, read before the pose grids are sliced
+            want = {k.split("/")[-1]: v for k, v in g.items() if k.startswith(f"{tag}/data_zero/")}
+            assert set(ds.data_zero) == set(want)
+            for k, v in want.items():
+                _same(ds.data_zero[k], v, (tag, "data_zero", k))
+
+
+def test_g15_training_fields_are_the_traced_ones(golden):
+    """The golden itself says what the reference does at the edges (so a reader of this file does not have to run it):"""
+    g = golden("g15_dataset_reader.npz")
+    t = "train_depth0"
+    assert int(g[t + "/len"]) == 18 and int(g[t + "/17/total_frame"]) == 18
+    # coord_window / audio_window repeat the last frame of the split past its end (:333-362)
+    assert [round(float(v), 2) for v in g[t + "/16/coord_window"][:, 0, 0, 0]] == [0.17, 0.18, 0.18, 0.18, 0.18]
+    assert g[t + "/16/audio_window"][:, 0, 0].tolist() == [16.0, 17.0, 17.0, 17.0, 17.0]
+    # mel: 16 frames from int(80 * (index + 2) / 25), or the last 16 of the 64 (:401-414)
+    assert g[t + "/0/mel"].shape == (1, 80, 16) and g[t + "/0/mel"][0, 0].tolist() == [float(v) for v in range(6, 22)]
+    assert g[t + "/17/mel"][0, 0].tolist() == [float(v) for v in range(48, 64)]
+    # the negative window: frames index+5 .. index+9 while index + 10 < 18, else index-10 .. index-6 -- and for index 8 that
+    # start is -2, which python wraps to the END of the split: frames 17, 18, then 1, 2, 3 (grey levels 10 (k+1) / 255)
+    lv = lambda a: [int(round(float(v) * 255 / 10)) for v in a[0, :, 0, 0]]
+    assert lv(g[t + "/7/rgb_window_neg"]) == [13, 14, 15, 16, 17]
+    assert lv(g[t + "/8/rgb_window_neg"]) == [17, 18, 1, 2, 3]
+    assert lv(g[t + "/16/rgb_window_neg"]) == [7, 8, 9, 10, 11]
+    assert g[t + "/7/rgb_window_neg"].shape == (3, 5, 96, 96)
+    assert g[t + "/7/canonical_face_bbox"].tolist() == pytest.approx([2.0, 1.0, 14.0, 11.0, 0.9])
+
+
+def test_resize_bilinear_u8_properties():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (12, 16, 3), dtype=np.uint8)
+    assert np.array_equal(D._resize_bilinear_u8(img, 12, 16), img)
+    flat = np.full((12, 16, 3), 77, np.uint8)
+    assert np.array_equal(D._resize_bilinear_u8(flat, 96, 96), np.full((96, 96, 3), 77, np.uint8))
+    up = D._resize_bilinear_u8(img, 24, 32)
+    assert up.shape == (24, 32, 3) and up.dtype == np.uint8
+    # half-pixel centres: a 2x up-sampling weighs its two nearest source pixels 3:1
+    a, b = int(img[3, 4, 0]), int(img[3, 5, 0])
+    c, d = int(img[4, 4, 0]), int(img[4, 5, 0])
+    want = (0.75 * (0.75 * a + 0.25 * b) + 0.25 * (0.75 * c + 0.25 * d))
+    assert abs(int(up[7, 9, 0]) - want) <= 1.0

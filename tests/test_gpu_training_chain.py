@@ -723,3 +723,44 @@ def test_unet_bf16_convolutions_vs_fp32(dev, fh, fw, F):
         crop = x[:, 48:460, 68:432].contiguous()
         ow, _ = u.forward_saved_nhwc(crop, window=win, precision="bf16")
         assert torch.equal(ow[:, 40:-40, 40:-40], o16[:, 88:420, 108:392])
+
+
+def test_train_step_from_a_dataset_folder(syncnet, dev):
+    """Dataset folder -> SomeonesLipClip.load_one_frame (golden G15: equal to the reference reader's dictionary) -> collate ->
+    Trainer.train_step, i.e. the reference's loop body fed from disk instead of from a golden: the it > 100000 step (sync window
+    assembled by the reader: mel, audio_window, coord_window, rgb_window_neg, canonical_face_bbox, total_frame) against the
+    oracle's stage_one_losses on the same dictionary."""
+    import os
+    from speech2lip_amd import config as C, data as D
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    cfg = C.may_config(6, 8, data_path=folder, train_flags=True)
+    cfg["model"]["use_canonical_depth"] = False
+    cfg["training"].update(use_sync_contrastive_loss=True, use_perceptual_loss=False, use_canonical_depth_loss_photo_v2=False)
+    ds = D.SomeonesLipClip(folder, "train", cfg=cfg)
+    batch = D.collate_batch([ds.load_one_frame(16)])            # index + t runs past the 18-frame split: the reader repeats frames
+    assert batch["audio_window"].shape == (1, 5, 16, 29) and batch["mel"].shape == (1, 1, 80, 16) and int(batch["total_frame"]) == 18
+    m = full_model(dev, 6, 8, path=folder).train()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    m.post_fusion_unet.eval()
+    tr = s2l.Trainer(m, optimizer=torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=cfg, syncnet=syncnet)
+    eps = [0.3, 0.6, 0.1, 0.8, 0.45, 0.7]
+    holes = (torch.randn(1, 12, 16, generator=torch.Generator().manual_seed(5)), torch.randn(1, 12, 16, generator=torch.Generator().manual_seed(6)))
+    restore = _patched_draws(eps, (holes[0].to(dev), holes[1].to(dev)), dev)
+    try:
+        item, loss = tr.train_step({k: v.to(dev) for k, v in batch.items()}, it=100001, seed=0)
+    finally:
+        eq, fq = restore()
+    assert not eq and not fq
+    sd = {k: T(v).clone().requires_grad_(True) for k, v in W.make_state_dict(0, "he").items()}
+    data = {k: (v if v.dim() else int(v)) for k, v in batch.items()}
+    data.update(index=16, total_frame=18, lip_lefttop_x=int(batch["lip_lefttop_x"]), lip_lefttop_y=int(batch["lip_lefttop_y"]))
+    res = O.stage_one_losses(sd, O.to_sd(W.make_unet_state_dict(0)), O.to_sd(W.make_syncnet_state_dict(0)), W.SYNCNET_FACE, W.SYNCNET_AUDIO,
+                             data, eps, holes, 6, 8, unet_training=True, with_sync=True)
+    res["loss"].backward()
+    assert abs(float(loss["loss"]) - float(res["loss"])) <= 1e-5 * max(1.0, abs(float(res["loss"])))
+    assert abs(float(loss["loss_sync"]) - float(res["loss_sync"])) <= 2e-6
+    assert abs(item - float(res["loss_rgb"] + res["loss_face"])) <= 1e-5
+    params = dict(m.named_parameters())
+    for name in ("output_linear.weight", "pts_linears.3.weight", "fc_audio.weight", "encoder_conv.0.weight"):
+        assert relerr(params[name].grad, sd[name].grad) <= 2e-3, (name, relerr(params[name].grad, sd[name].grad))

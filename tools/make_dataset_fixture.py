@@ -10,6 +10,12 @@ TRACED BY HAND (tests/test_data_reader.py::test_committed_fixture_hand_traced ho
   images/%05d.jpg           6x8 flat grey 200                        (defines the lip crop size 6 x 8)
   canonical_lip_mask.jpg    12x16, white box rows 4..9, cols 5..12
   landmarks/00001.lms       68 points; mouth points (48..67) span x in [5.5, 12.25], y in [4.75, 8.5]
+Training-side inputs (someones_lip_dataset.py:75-93, 113-120, 328-392):
+  audio/mel.npy          float32 [80,64], mel[c,t] = t + c/100: what `melspectrogram(load_wav(audio.wav))` would return -- the mel
+                         front-end (src/data/audio.py, librosa) is out of scope, so the reader takes the spectrogram precomputed
+  face_bbox_dict.npy     pickled dict {"%05d.jpg": float32 [x, y, x2, y2, conf]} (preprocess/detect_landmarks.py:33-63)
+  track_params.pt        {'euler': [20,3], 'trans': [20,3]} float32, euler[k] = (k, k+0.25, k+0.5)/100, trans[k] = (k, -k, 10+k)/10
+  canonical_head_mask.jpg / canonical_face_mask.jpg   12x16 white boxes rows 1..10 x cols 2..13 / rows 3..8 x cols 4..11
 
 The decoded PIXELS are whatever PIL's libjpeg yields; the reference decodes with cv2.imread / imageio (not installed in this
 image), so pixel-level agreement with the reference reader is NOT pinned -- only the conventions are (split slices, index and file
@@ -36,4 +42,16 @@ lms = np.full((68, 2), 1.0, np.float32)
 lms[48:, 0] = np.linspace(5.5, 12.25, 20)
 lms[48:, 1] = np.linspace(4.75, 8.5, 20)
 np.savetxt(os.path.join(ROOT, "landmarks", "00001.lms"), lms)
+import torch  # noqa: E402
+
+np.save(os.path.join(ROOT, "audio", "mel.npy"), (np.arange(64, dtype=np.float32)[None, :] + np.arange(80, dtype=np.float32)[:, None] / 100))
+np.save(os.path.join(ROOT, "face_bbox_dict.npy"),
+        {"%05d.jpg" % (k + 1): np.array([2 + k % 2, 1, 14, 11 - k % 3, 0.9 + k / 1000], np.float32) for k in range(N)})
+kk = torch.arange(N, dtype=torch.float32)[:, None]
+torch.save({"euler": (kk + torch.tensor([[0.0, 0.25, 0.5]])) / 100, "trans": torch.cat([kk, -kk, 10 + kk], 1) / 10},
+           os.path.join(ROOT, "track_params.pt"))
+for name, (r0, r1, c0, c1) in (("canonical_head_mask.jpg", (1, 11, 2, 14)), ("canonical_face_mask.jpg", (3, 9, 4, 12))):
+    mk = np.zeros((FH, FW, 3), np.uint8)
+    mk[r0:r1, c0:c1] = 255
+    Image.fromarray(mk).save(os.path.join(ROOT, name), quality=100)
 print("wrote", ROOT)

@@ -662,6 +662,68 @@ def main():
                                                                "up1.conv.double_conv.4.running_mean", "up1.conv.double_conv.4.running_var")},
                         tracked=refb["inc.double_conv.1.num_batches_tracked"].numpy(), x_seed=np.array(s13), margin=np.array(margin13))
 
+    # ---- G15: the reference's OWN dataset reader (src/data/someones_lip_dataset.py) run on the committed fixture folder
+    # tests/golden/dataset_fixture/may_face_crop_lip (tools/make_dataset_fixture.py).  cv2 / imageio / librosa are not installed:
+    # the four calls the reader makes into them get FUNCTIONAL stand-ins here, in the golden script only --
+    #   imageio.imread(path)            PIL decode, RGB uint8
+    #   cv2.imread(path)                PIL decode, channels reversed to BGR
+    #   cv2.boundingRect(float points)  (floor(min x), floor(min y), floor(max x) - floor(min x) + 1, floor(max y) - floor(min y) + 1)
+    #   cv2.resize(img, (w, h))         PIL bilinear
+    #   audio.load_wav / melspectrogram the spectrogram precomputed in audio/mel.npy (the mel front-end is out of scope)
+    # -- so DECODED PIXELS, the resize interpolation and boundingRect's rounding REMAIN UNPINNED (the fixture's frames are flat
+    # colours, which every decoder / interpolator reproduces).  What IS pinned by execution instead of by a hand trace is
+    # everything else the reader does: split slices, index / file-name mapping, compute_mouth_bbox incl. the x1.02 rule,
+    # float64 -> float32 audio, mask channel order, the canonical frame, and the training fields of load_one_frame (:328-392):
+    # mel window (crop_audio_window at index + 2, clamped at the end), coord_window / audio_window with their repeat-last
+    # fallback past the split's end, the negative window's start rule (index + 5, or index - 10 -- which python's negative
+    # indexing wraps around), canonical_face_bbox, total_frame, the 6-DoF pose slices and the two canonical masks.
+    from PIL import Image as _Image
+    cv2s, iios = sys.modules["cv2"], sys.modules["imageio"]
+    cv2s.imread = lambda path: np.asarray(_Image.open(path).convert("RGB"))[:, :, ::-1].copy()
+    iios.imread = lambda path: np.asarray(_Image.open(path).convert("RGB"))
+    cv2s.resize = lambda img, size: np.asarray(_Image.fromarray(np.asarray(img)).resize((int(size[0]), int(size[1])), _Image.BILINEAR))
+
+    def _bounding_rect(pts):
+        pts = np.asarray(pts, dtype=np.float64)
+        x, y = int(np.floor(pts[:, 0].min())), int(np.floor(pts[:, 1].min()))
+        return x, y, int(np.floor(pts[:, 0].max())) - x + 1, int(np.floor(pts[:, 1].max())) - y + 1
+    cv2s.boundingRect = _bounding_rect
+    import src.data.audio as ref_audio
+    ref_audio.load_wav = lambda path, sr: path
+    ref_audio.melspectrogram = lambda wav, fmin: np.load(os.path.join(os.path.dirname(wav), "mel.npy"))
+    from src.data.someones_lip_dataset import SomeonesLipDataset
+    folder = os.path.join(GOLD, "dataset_fixture", "may_face_crop_lip")
+    g15 = {}
+
+    def put(tag, d):
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                v = v.numpy()
+            g15[f"{tag}/{k}"] = np.asarray(v)
+
+    for depth in (False, True):
+        cfg_d = ref_config.load_config("configs/face_simple_configs/may/may.yaml", "configs/default.yaml", abs_path=REF)
+        cfg_d["model"]["use_canonical_depth"] = depth
+        assert cfg_d["training"]["use_syncloss"] and cfg_d["training"]["use_sync_contrastive_loss"] and cfg_d["model"]["use_post_fusion"]
+        for mode, indices in (("train", [0, 7, 8, 13, 16, 17]), ("val", [0, 19]), ("test", [0, 4])):
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):          # the reader prints the paths it loads
+                ds = SomeonesLipDataset(folder, mode, cfg=cfg_d, img_ext=".jpg")
+            tag = f"{mode}_depth{int(depth)}"
+            put(tag, {"len": len(ds), "lefttop_x": ds.lefttop_x, "lefttop_y": ds.lefttop_y, "face_h": ds.face_h, "face_w": ds.face_w,
+                      "dst_mouth_h": ds.dst_mouth_h, "dst_mouth_w": ds.dst_mouth_w, "canonical_idx": ds.canonical_idx, "fmin": ds.fmin,
+                      "files": np.array(ds.input_file_list), "coord_files": np.array(ds.coords_file_list)})
+            if mode == "train":
+                put(tag + "/data_zero", ds.data_zero)
+            for i in indices:
+                inputs, idx = ds[i]
+                assert idx == i
+                put(f"{tag}/{i}", inputs)
+    np.savez_compressed(os.path.join(GOLD, "g15_dataset_reader.npz"), **g15)
+    print(f"  [info] G15: {len(g15)} arrays from the reference's SomeonesLipDataset on the fixture folder "
+          f"(train/val/test x use_canonical_depth off/on); fields of one train item: "
+          f"{sorted(k.split('/')[-1] for k in g15 if k.startswith('train_depth1/7/'))}")
+
     np.savez_compressed(os.path.join(GOLD, "g0_weight_checksums.npz"), **w_sum)
     print("oracle vs reference, max |err| per check:")
     # The warp grid is ill-conditioned in fp32 (K.T cancels two ~9.5-unit translations; the reference's own fp32 result
