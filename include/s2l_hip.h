@@ -303,6 +303,16 @@ int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, cons
  * config 5 names for the training step; NULL = exact fp32 everywhere.  (The 3->64 first layer, 0.5 % of the work, stays fp32.) */
 int64_t s2l_unet_packed16_halves(void);
 int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, uint16_t* packed16, s2l_stream_t stream);
+/* Split-bf16 ("bf16x3") operand form of the nine 3x3 layers for INFERENCE (SimpleUnetLight.py:16-111 as called at tf_nerf.py:387):
+ * every fp32 operand is carried as hi = bf16(x), lo = bf16(x - hi) and a product is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
+ * on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- ~2^-16 relative operand error (plain bf16: 2^-8), three MFMAs at 16x the
+ * fp32-MFMA rate.  The result stays inside the north-star tolerance (PSNR >= 50 dB / RMSE <= 1e-4 against the exact fp32 network) by
+ * orders of magnitude; the exact fp32 kernels remain the default.  s2l_unet_pack16x3 writes s2l_unet_packed16x3_halves() uint16
+ * (same tensor table and BatchNorm fold as s2l_unet_pack); s2l_unet_forward_split = s2l_unet_forward with those layers in this form. */
+int64_t s2l_unet_packed16x3_halves(void);
+int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps, uint16_t* packed16x3, s2l_stream_t stream);
+int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, const float* x, float* work, float* out, int height,
+                           int width, int64_t n_frames, s2l_stream_t stream);
 
 /* TRAIN mode of the same network, as the reference runs it until `it > 100000` (train.py:188-197): every BatchNorm2d normalises
  * with the statistics of the batch (biased variance) and updates its running statistics in place (momentum, unbiased variance:

@@ -73,6 +73,9 @@ EXPORTS = {
     "s2l_set_bf16_forward_kernel": (c_int, [c_int]),
     "s2l_unet_packed16_halves": (c_int64, []),
     "s2l_unet_pack16": (c_int, [c_void_p, ctypes.c_float, c_void_p, c_void_p]),
+    "s2l_unet_packed16x3_halves": (c_int64, []),
+    "s2l_unet_pack16x3": (c_int, [c_void_p, ctypes.c_float, c_void_p, c_void_p]),
+    "s2l_unet_forward_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_crop_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_crop_resize_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int64,
                                          c_void_p]),

@@ -132,6 +132,17 @@ __host__ __device__ constexpr int64_t unet_wT16_off(int layer) {
   return off;
 }
 constexpr int64_t kUnetPacked16Halves = unet_wT16_off(10);
+// Split-bf16 ("bf16x3") operand form of the forward 3x3 layers: every fp32 operand x is carried as hi = bf16(x) and
+// lo = bf16(x - hi) (x - hi - lo is <= 2^-17 |x|), and a product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16 relative operand error instead of bf16's 2^-8, three MFMAs at 16x the
+// fp32-MFMA rate.  A chunk = (64 output channels, 16 input channels) in the SAME LDS shape as the plain bf16 chunk:
+// [tap 9][part: hi, lo][M-block 2][lane 64][8 bf16], lane l of an A quad holds W[row 32 mb + (l & 31)][k 8 (l >> 5) + j].
+__host__ __device__ constexpr int64_t unet_w16x3_off(int layer) {
+  int64_t off = 0;
+  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunk16Halves;
+  return off;
+}
+constexpr int64_t kUnetPacked16x3Halves = unet_w16x3_off(10);
 
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // round to nearest even
 
@@ -151,6 +162,23 @@ __global__ void unet_pack_conv16(UnetTensors t, int layer, uint16_t* __restrict_
   const float scale = eps < 0.f ? 1.f : t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   packed16[(transposed ? unet_wT16_off(layer) : unet_w16_off(layer)) + e] =
       to_bf16(t.w[layer][((int64_t)co * cin + ci) * 9 + (transposed ? 8 - tap : tap)] * scale);
+}
+
+// split form (forward only): one thread per packed element, hi and lo parts of the BatchNorm-folded fp32 weight
+__global__ void unet_pack_conv16x3(UnetTensors t, int layer, uint16_t* __restrict__ packed, float eps) {
+  const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
+  const int64_t n = (int64_t)(cout / 64) * (cin / 16) * kChunk16Halves;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int j = e & 7, lane = (e >> 3) & 63, mb = (e >> 9) & 1, part = (e >> 10) & 1;
+  const int tap = (int)((e >> 11) % 9);
+  const int64_t chunk = e / kChunk16Halves;
+  const int cc = (int)(chunk % (cin / 16)), ct = (int)(chunk / (cin / 16));
+  const int co = ct * 64 + mb * 32 + (lane & 31), ci = cc * 16 + 8 * (lane >> 5) + j;
+  const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
+  const float w = t.w[layer][((int64_t)co * cin + ci) * 9 + tap] * scale;      // the fp32 kernel's folded weight, bit for bit
+  const uint16_t hi = to_bf16(w);
+  packed[unet_w16x3_off(layer) + e] = part == 0 ? hi : to_bf16(w - __uint_as_float((uint32_t)hi << 16));
 }
 
 // ---- first conv: 3 -> 64 on MFMA (0.5 % of the FLOPs, but 64 MB of output per frame: write-bound) -----------------------
@@ -228,7 +256,8 @@ struct ConvArgs {
   const float* gate;  // or null: [F,H,W,cout]; the output is zeroed where gate <= 0 (ReLU mask of the backward pass)
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;
   int relu;           // 1: ReLU in the epilogue (forward); 0: linear (input-gradient convolutions)
-  const uint16_t* w16;   // conv3x3_bf16_kernel: packed bf16 chunks [cout/64][cin/32][kChunk16Halves]
+  const uint16_t* w16;   // conv3x3_bf16_kernel: packed bf16 chunks [cout/64][cin/32][kChunk16Halves]; split form: [cout/64][cin/16][...]
+  int split;             // 1: w16 is the split-bf16 (hi, lo) form
   int n_frames_asm;      // conv3x3_asm_kernel: frames of this launch (its grid is the CU count, not the tile count)
 #ifdef S2L_EXP_TRACE
   long long* trace;   // experiment builds (tools/trace_conv.py): [workgroup][24] timestamps of this launch
@@ -506,7 +535,10 @@ __device__ __forceinline__ f16v mfma32_bf16(u4v a, u4v b, f16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
-template <bool FUSE_OUT>
+// SPLIT: the split-bf16 form (unet_w16x3_off): 16 input channels per chunk, a halo pixel's 80 bytes hold [hi 16 ch | lo 16 ch | pad],
+// the chunk's weights [tap][hi, lo][mb][lane][8] -- the same LDS shapes and the same eight ds_read_b128 per tap, but twelve MFMAs:
+// acc += A_hi B_hi + A_hi B_lo + A_lo B_hi (the lo x lo term is below 2^-17 of the product and is dropped).
+template <bool FUSE_OUT, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t lds_in[18 * 18 * kPix16];
   __shared__ __attribute__((aligned(16))) uint16_t lds_w[kChunk16Halves];
@@ -517,7 +549,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
   const int64_t frame = blockIdx.z / a.n_ct;
   const int x0 = tx * 16, y0 = ty * 16;
   const int cin = a.CA + a.CB;
-  const int nchunks = cin / 32;
+  constexpr int kCC = SPLIT ? 16 : 32;                  // input channels per chunk
+  const int nchunks = cin / kCC;
   const float* inA = a.inA + frame * (int64_t)a.H * a.W * a.CA;
   const float* inB = a.inB ? a.inB + frame * (int64_t)a.H * a.W * a.CB : nullptr;
 
@@ -529,20 +562,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = a.bias ? a.bias[ct * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
 
-  constexpr int kInQuads = 18 * 18 * 8;                 // f4 (4 fp32 channels) elements of the halo tile
-  constexpr int kInPer = (kInQuads + 255) / 256;        // 11 (the last pass is partial)
+  constexpr int kQ = kCC / 4;                           // f4 (4 fp32 channels) elements per halo pixel
+  constexpr int kInQuads = 18 * 18 * kQ;
+  constexpr int kInPer = (kInQuads + 255) / 256;        // 11 (SPLIT: 6; the last pass is partial)
   constexpr int kWPer = kChunk16Halves / 8 / 256;       // 9
   f4 pin[kInPer];
   u4v pw[kWPer];
   auto fetch = [&](int cc) {
-    const bool fromA = cc * 32 < a.CA;
+    const bool fromA = cc * kCC < a.CA;
     const float* src = fromA ? inA : inB;
     const int C = fromA ? a.CA : a.CB;
-    const int coff = fromA ? cc * 32 : cc * 32 - a.CA;
+    const int coff = fromA ? cc * kCC : cc * kCC - a.CA;
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) {
       const int i = threadIdx.x + k * 256;
-      const int pi = i >> 3, c4 = i & 7;
+      const int pi = i / kQ, c4 = i % kQ;
       const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
       pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
       if (i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
@@ -560,7 +594,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
         uint2 h;
         h.x = pack_bf16x2(pin[k][0], pin[k][1]);
         h.y = pack_bf16x2(pin[k][2], pin[k][3]);
-        *reinterpret_cast<uint2*>(lds_in + (i >> 3) * kPix16 + 4 * (i & 7)) = h;
+        *reinterpret_cast<uint2*>(lds_in + (i / kQ) * kPix16 + 4 * (i % kQ)) = h;
+        if (SPLIT) {      // lo = bf16(x - hi): the second 16 "channels" of the pixel
+          uint2 l;
+          l.x = pack_bf16x2(pin[k][0] - __uint_as_float(h.x << 16), pin[k][1] - __uint_as_float(h.x & 0xffff0000u));
+          l.y = pack_bf16x2(pin[k][2] - __uint_as_float(h.y << 16), pin[k][3] - __uint_as_float(h.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(lds_in + (i / kQ) * kPix16 + 16 + 4 * (i % kQ)) = l;
+        }
       }
     }
 #pragma unroll
@@ -576,18 +616,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3, dx = t % 3;
+      if (SPLIT) {
+        u4v A[2][2], B[2][2];   // [part: hi, lo][block]
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        u4v A[2], B[2];
+        for (int pt = 0; pt < 2; ++pt) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) A[mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + ks) * 2 + mb) * 64 + lane];
+          for (int mb = 0; mb < 2; ++mb) A[pt][mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + pt) * 2 + mb) * 64 + lane];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          B[nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * ks + 8 * hh);
+          for (int nb = 0; nb < 2; ++nb)
+            B[pt][nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * pt + 8 * hh);
+        }
+        // smallest terms first: the two cross terms, then hi x hi
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[mb], B[nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[1][mb], B[0][nb], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[0][mb], B[1][nb], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[0][mb], B[0][nb], acc[mb][nb]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u4v A[2], B[2];
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) A[mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + ks) * 2 + mb) * 64 + lane];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            B[nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * ks + 8 * hh);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[mb], B[nb], acc[mb][nb]);
+        }
       }
     }
     __syncthreads();            // everyone is done reading chunk cc
@@ -728,9 +793,10 @@ static int launch_conv_asm(ConvArgs& a, int64_t F, hipStream_t st, bool* launche
 
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
                        float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr,
-                       const uint16_t* packed16 = nullptr) {
+                       const uint16_t* packed16 = nullptr, int split = 0) {
   ConvArgs a;
-  a.w16 = packed16 ? packed16 + unet_w16_off(layer) : nullptr;
+  a.w16 = packed16 ? packed16 + (split ? unet_w16x3_off(layer) : unet_w16_off(layer)) : nullptr;
+  a.split = split;
   a.inA = inA; a.inB = inB; a.CA = CA; a.CB = CB;
   a.cout = kUnetConvs[layer].cout;
   a.w = packed + unet_w_off(layer);
@@ -747,7 +813,9 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
-  if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+  if (out3 && a.w16 && split) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, true>), grid, dim3(256), 0, st, a);
+  else if (a.w16 && split) hipLaunchKernelGGL((conv3x3_bf16_kernel<false, true>), grid, dim3(256), 0, st, a);
+  else if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
@@ -763,6 +831,7 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
                              int64_t F, hipStream_t st, const uint16_t* packed16 = nullptr) {
   ConvArgs a;
   a.w16 = packed16 ? packed16 + unet_wT16_off(layer) : nullptr;
+  a.split = 0;
   a.inA = dz; a.inB = nullptr; a.CA = kUnetConvs[layer].cout; a.CB = 0;
   a.cout = kUnetConvs[layer].cin;
   a.w = packed + unet_wT_off(layer);
@@ -1408,8 +1477,8 @@ extern "C" int s2l_unet_pack(const float* const* tensors_host, float bn_eps, flo
 }
 
 // x [F,H,W,3] NHWC -> out [F,H,W,3].  H, W >= 4.  work: s2l_unet_work_floats(H, W, F) floats.
-extern "C" int s2l_unet_forward(const float* packed, const uint16_t* packed16, const float* x, float* work, float* out, int height,
-                                int width, int64_t n_frames, s2l_stream_t stream) {
+static int unet_forward_impl(const float* packed, const uint16_t* packed16, int split, const float* x, float* work, float* out,
+                             int height, int width, int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames < 0) return S2L_E_SIZE;
   if (n_frames == 0) return S2L_OK;
   if (!packed || !x || !work || !out) return S2L_E_NULL;
@@ -1425,20 +1494,33 @@ extern "C" int s2l_unet_forward(const float* packed, const uint16_t* packed16, c
   if (F > 65535) return S2L_E_SIZE;
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(((int64_t)H * W + 255) / 256), (unsigned)F), dim3(256), 0, st, x,
                      packed + unet_w_off(0), packed + unet_b_off(0), t64a, H, W);
-  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1, nullptr, packed16))) return rc;   // + MaxPool2d(2)
-  if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
-  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2, nullptr, packed16))) return rc;   // + MaxPool2d(2)
-  if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
-  if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(t64a, 64, nullptr, 0, packed, 1, x1, nullptr, H, W, F, st, pool1, nullptr, packed16, split))) return rc;   // + MaxPool2d(2)
+  if ((rc = launch_conv(pool1, 64, nullptr, 0, packed, 2, t128a, nullptr, H2, W2, F, st, nullptr, nullptr, packed16, split))) return rc;
+  if ((rc = launch_conv(t128a, 128, nullptr, 0, packed, 3, x2, nullptr, H2, W2, F, st, pool2, nullptr, packed16, split))) return rc;   // + MaxPool2d(2)
+  if ((rc = launch_conv(pool2, 128, nullptr, 0, packed, 4, t128c, nullptr, H4, W4, F, st, nullptr, nullptr, packed16, split))) return rc;
+  if ((rc = launch_conv(t128c, 128, nullptr, 0, packed, 5, x3, nullptr, H4, W4, F, st, nullptr, nullptr, packed16, split))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, x3, up1in, H4, W4, 128, H2, W2,
                      no_window(H4, W4, H2, W2));
-  if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
-  if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(x2, 128, up1in, 128, packed, 6, t128b, nullptr, H2, W2, F, st, nullptr, nullptr, packed16, split))) return rc;
+  if ((rc = launch_conv(t128b, 128, nullptr, 0, packed, 7, u1, nullptr, H2, W2, F, st, nullptr, nullptr, packed16, split))) return rc;
   hipLaunchKernelGGL(upsample2_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, u1, t64a, H2, W2, 64, H, W,
                      no_window(H2, W2, H, W));   // t64a is free again: it becomes up(u1)
-  if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st, nullptr, nullptr, packed16))) return rc;
-  if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, nullptr, packed16))) return rc;
+  if ((rc = launch_conv(x1, 64, t64a, 64, packed, 8, t64b, nullptr, H, W, F, st, nullptr, nullptr, packed16, split))) return rc;
+  if ((rc = launch_conv(t64b, 64, nullptr, 0, packed, 9, nullptr, out, H, W, F, st, nullptr, nullptr, packed16, split))) return rc;
   return (int)hipGetLastError();
+}
+
+extern "C" int s2l_unet_forward(const float* packed, const uint16_t* packed16, const float* x, float* work, float* out, int height,
+                                int width, int64_t n_frames, s2l_stream_t stream) {
+  return unet_forward_impl(packed, packed16, 0, x, work, out, height, width, n_frames, stream);
+}
+// The same network with the nine 3x3 layers in the split-bf16 operand form (s2l_unet_pack16x3): fp32-grade results (~1e-6 of the
+// output scale) at a multiple of the fp32-MFMA rate.
+extern "C" int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, const float* x, float* work, float* out,
+                                      int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (!packed16x3) return S2L_E_NULL;
+  if (misaligned16(packed16x3)) return S2L_E_ALIGN;
+  return unet_forward_impl(packed, packed16x3, 1, x, work, out, height, width, n_frames, stream);
 }
 
 // ---- training: forward that keeps every activation, and the input gradient ----------------------------------------------
@@ -1587,6 +1669,21 @@ extern "C" int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, u
   return (int)hipGetLastError();
 }
 
+
+extern "C" int64_t s2l_unet_packed16x3_halves(void) { return kUnetPacked16x3Halves; }
+extern "C" int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps, uint16_t* packed16x3, s2l_stream_t stream) {
+  if (!packed16x3) return S2L_E_NULL;
+  if (misaligned16(packed16x3)) return S2L_E_ALIGN;
+  UnetTensors t;
+  const int rc = unet_table(tensors_host, t);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int l = 1; l < 10; ++l) {
+    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunk16Halves;
+    hipLaunchKernelGGL(unet_pack_conv16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16x3, bn_eps);
+  }
+  return (int)hipGetLastError();
+}
 
 // RAW (un-folded) weights in the chunk layout, forward and transposed: what the train-mode network multiplies with.  Same table
 // and blob size as s2l_unet_pack; re-run after every optimizer step.

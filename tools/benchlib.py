@@ -92,8 +92,9 @@ def bench_composite(dev, frames=256, check=True):
     return res
 
 
-def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
-    """BASELINE config 3 end to end: 128x128 lip render for n frames + composite into 500x500 (+ optionally the U-Net)."""
+def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision="fp32"):
+    """BASELINE config 3 end to end: 128x128 lip render for n frames + composite into 500x500 (+ optionally the U-Net;
+    unet_precision "fp32" = the exact parity kernels, "split" = split-bf16 operands, SimpleUnetLight.forward_nhwc)."""
     h = w = 128
     FH = FW = 500
     x0, y0 = 186, 300
@@ -114,7 +115,7 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
             m.render_clip(audio[s:s + k], torch.arange(s, s + k, device=dev), h, w, out=lip[:k])
             m.composite_clip(lip[:k], face, gt[:k], mask, x0, y0, coord[:k], out=out[:k])
             if unet:
-                m.post_fusion_unet.forward_nhwc(out[:k], out=recon[:k])
+                m.post_fusion_unet.forward_nhwc(out[:k], out=recon[:k], precision=unet_precision)
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -122,7 +123,8 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fl = lip_flops_per_frame(h * w)
-    res = {"config": f"config 3: {n} frames, 128x128 lip + composite into 500x500" + (" + post-fusion U-Net" if unet else "")
+    res = {"config": f"config 3: {n} frames, 128x128 lip + composite into 500x500"
+           + (f" + post-fusion U-Net ({'exact fp32 MFMA' if unet_precision == 'fp32' else 'split-bf16 operands hi+lo, fp32 accumulation' if unet_precision == 'split' else unet_precision})" if unet else "")
            + f", batches of {batch}", "seconds": round(dt, 3), "frames_per_s": round(n / dt, 1),
            "lip_gflop_per_frame": round(fl / 1e9, 3), "lip_tflops": round(fl * n / dt / 1e12, 1)}
     if check:
@@ -168,6 +170,16 @@ def bench_unet(dev, F=16, H=500, Wd=500):
         tf = passes * 2 * macs * F / (ms * 1e-3) / 1e12
         res[key] = {"ms_per_frame": round(ms / F, 4), "frames_per_s": round(F / ms * 1e3, 1), "tflops": round(tf, 1),
                     "frac_of_mfma_peak": round(tf / 157.3, 4)}
+    # the inference speed mode: split-bf16 operands (three bf16 MFMAs per product), against the exact fp32 output above
+    ref = u.forward_nhwc(x).clone()
+    for _ in range(2):
+        u.forward_nhwc(x, out=out, precision="split")
+    ms = _median_ms(lambda: u.forward_nhwc(x, out=out, precision="split"), reps=5, inner=1)
+    mse = float(((out.double() - ref.double()) ** 2).mean())
+    res["forward_split_bf16"] = {"ms_per_frame": round(ms / F, 4), "frames_per_s": round(F / ms * 1e3, 1),
+                                 "speedup_vs_fp32": round(res["forward"]["ms_per_frame"] / (ms / F), 2),
+                                 "psnr_db_vs_fp32": round(10 * np.log10(1.0 / max(mse, 1e-30)), 1), "rmse_vs_fp32": float(f"{np.sqrt(mse):.3e}"),
+                                 "operands": "hi + lo bf16 parts of every fp32 operand; a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation"}
     return res
 
 
