@@ -138,6 +138,7 @@ def extra_measurements(dev):
     from tools import benchlib
     out = {}
     for name, fn in (("composite", lambda: benchlib.bench_composite(dev, 256)),
+                     ("small_clips", lambda: benchlib.bench_small_clips(dev)),
                      ("config3", lambda: benchlib.bench_config3(dev, 5000, 500)),
                      ("config3_with_unet", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True)),
                      ("config3_with_unet_split_bf16", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True, unet_precision="split")),

@@ -101,6 +101,12 @@ int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float*
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
+/* The renderer has three tile shapes (4 waves x G groups of 16 samples): 16 pixels x 12 frames (clips), 192 pixels x 1 frame
+ * (clip lengths that are not multiples of 12) and 64 pixels x 1 frame (one frame per call, the reference's own mode,
+ * inference.py:129,140-159: the whole chip works on the one frame).  s2l_render_lip picks the one with the smallest estimated time;
+ * frames are bit-identical whichever shape rendered them.  s2l_set_render_shape: 0 = choose per call (default), 1 / 2 / 3 = always
+ * the 12-frame / 192-pixel / 64-pixel shape (tests and A/B measurements; process-wide). */
+int s2l_set_render_shape(int mode);
 /* Cap on the persistent renderer's workgroups ON THE CURRENT DEVICE (hipGetDevice of the calling thread; 0 = one per CU, the
  * default).  A multi-GPU host that overlaps RCCL with rendering passes CUs - k so that k CUs stay free for RCCL's kernels;
  * results do not depend on it.  Per-device state held in atomics: safe with one host thread per GPU.  All other one-time

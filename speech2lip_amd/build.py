@@ -41,7 +41,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     sys.path.insert(0, CSRC)
     try:
         import gen_render_body
-        gen_render_body.main(os.path.join(objdir, "render_body.inc"))
+        gen_render_body.main_all(objdir)       # render_body.inc (long shape), render_body_wide.inc, render_body_single.inc
         import gen_conv_body               # ... and so are the U-Net's fp32 3x3 convolutions (unet.hip)
         gen_conv_body.main(objdir)
         import gen_fwd16_body              # ... and the bf16 training forward (train_bf16.hip)

@@ -21,12 +21,30 @@ flight and derives each s_waitcnt lgkmcnt(n) from that list; it asserts that all
 
 Register map (per wave):  v0-191 B operands in[g][k] | v192-207 four A-quad sets | v208.. addresses and temporaries
                           a0-191 accumulators acc[g][mb][r] | a192-195 bias / srcC | a196-207 output-layer accumulators
-                          s36.. scalar state (ring position, weight-slab pointer, tile coordinates, table pointers)."""
+                          s36.. scalar state (ring position, weight-slab pointer, tile coordinates, table pointers).
+
+Tile shapes (VARIANTS below).  A tile is 4 waves x G groups of 16 samples, arranged as PGT pixel groups x FT frames:
+  long   G = 3, 1 x 12:   wave w, group g = frame 3 w + g of ONE pixel group: one p0 / p5 ring step per tile.  The shape for clips;
+                          its generated text is pinned (frames of a clip of F = 12 k frames are rendered by exactly this code).
+  wide   G = 3, 12 x 1:   group = pixel group 3 w + g of ONE frame: no frame slot is ever wasted, at the price of 12 p0 + 12 p5 ring
+                          steps per tile (+19 % ring traffic, +3 % cycles).  Short clips whose length is not a multiple of 12.
+  single G = 1, 4 x 1:    64 samples per tile: a 96x96 frame is 144 tiles instead of 48, i.e. the chip's 256 CUs can all work on
+                          ONE frame -- the reference's own operating mode (one frame per call, inference.py:129,140).
+Every sample column sees the same MFMA sequence in every shape, so frames are bit-identical whichever shape rendered them.
+A ring step j+9 is requested by the `advance` that retires step j; `Body.refill_at` maps a position in the tile's step sequence
+(q0, PGT x p0, 80 slabs, q5, PGT x p5, 33 slabs) to what that request must be."""
 import os
 import sys
 
-G = 3
+G, PGT, FT = 3, 1, 12          # set_variant() below
 KRING, SLAB, NSLABS, NLAYERS = 9, 16384, 113, 7
+VARIANTS = {"long": (3, 1, 12), "wide": (3, 12, 1), "single": (1, 4, 1)}
+
+
+def set_variant(name):
+    global G, PGT, FT
+    G, PGT, FT = VARIANTS[name]
+    assert 4 * G == PGT * FT and (FT == 1 or PGT == 1)
 
 # ---- vector registers
 V_IN, V_W = 0, 192
@@ -51,7 +69,7 @@ def _scalar_map(first, singles, pairs):
 
 
 S = _scalar_map(36,
-                singles="CUR T LDSBASE CURB IS LAYER FG PG NFG TILE TEND NFM1 HW FGN PGN WAVE NFRAMES".split(),
+                singles="CUR T LDSBASE CURB IS LAYER FG PG NFG TILE TEND NFM1 HW FGN PGN WAVE NFRAMES NPGM1".split(),
                 pairs=("WPTR", "WBASE", "Q0", "Q5", "P0", "P5", "OUT", "T4", "T6", "T8", "EX", "TRACE"))
 S.update(T5=S["T41"], T7=S["T61"], T9=S["T81"])          # the halves of the temporary pairs by their own names
 TRACE = os.environ.get("S2L_RENDER_TRACE") == "1"      # experiment builds only (tools/trace_tiles.py): per-tile phase timestamps
@@ -166,11 +184,17 @@ class Body:
         for t in self.dma4():
             self.e(t)
 
-    def p_refill(self, ptab, pg):
-        """issue_p: 16 KiB of the pixel table of pixel group `pg` (same shape as a weight slab)."""
+    def p_refill(self, ptab, pg, k=0):
+        """issue_p: 16 KiB of the pixel table of pixel group `pg` * PGT + k (clamped to the last group: a tile block may reach past
+        the image; those samples are never stored) -- same shape as a weight slab."""
         e = self.e
         e(f"s_mov_b32 m0, {s('T')}")
-        e(f"s_mov_b32 {s('T8')}, {s(pg)}")
+        if PGT == 1:
+            e(f"s_mov_b32 {s('T8')}, {s(pg)}")
+        else:
+            e(f"s_mul_i32 {s('T8')}, {s(pg)}, {PGT}")
+            e(f"s_add_u32 {s('T8')}, {s('T8')}, {k}")
+            e(f"s_min_u32 {s('T8')}, {s('T8')}, {s('NPGM1')}")
         e(f"s_mov_b32 {s('T9')}, 0")
         e(f"s_lshl_b64 {s2('T8')}, {s2('T8')}, 14")
         e(f"s_add_u32 {s('T4')}, {s(ptab)}, {s('T8')}")
@@ -179,9 +203,10 @@ class Body:
             e(t)
 
     def q_refill(self, qtab, fg):
-        """issue_q: rows of the frame table for frames fg*12 + wave*4 + i, clamped to the last frame; 1 KiB each."""
+        """issue_q: rows of the frame table for frames fg*FT + wave*4 + i, clamped to the last frame; 1 KiB each (row r of the
+        step = frame fg*FT + r; rows past the tile's FT frames are loaded all the same: every step is 16 DMA instructions)."""
         e = self.e
-        e(f"s_mul_i32 {s('T6')}, {s(fg)}, 12")
+        e(f"s_mul_i32 {s('T6')}, {s(fg)}, {FT}")
         e(f"s_lshl_b32 {s('T7')}, {s('WAVE')}, 2")
         e(f"s_add_u32 {s('T6')}, {s('T6')}, {s('T7')}")
         for i in range(4):
@@ -198,6 +223,11 @@ class Body:
     # ---- one slab
     def quad_mfmas(self, mb, j, dst, first_c=None, sprinkle=None):
         """12 MFMAs of k-quad j; sprinkle[n]: instructions tucked behind MFMA n (scalar, LDS and DMA issue is free there)."""
+        if G != 3 and sprinkle:      # positions are written for the 12 MFMAs of a G = 3 quad: compress them onto 4 G slots
+            packed = {}
+            for pos in sorted(sprinkle):
+                packed.setdefault(pos * G // 3, []).extend(sprinkle[pos])
+            sprinkle = packed
         sprinkle = dict(sprinkle or {})
         w = V_W + 4 * (j % 4)
         for jj in range(4):
@@ -221,6 +251,17 @@ class Body:
         dst = lambda g: self.acc(g, mb)
         for j in range(16):
             sprinkle = {}
+            moves = {}
+            if mb == 15 and j >= 1:
+                # The layer's last slab: once k-quad j-1 has been issued, block j-1 of the B registers is dead and block j-1
+                # of the accumulators has been final since slab j-1 -- move it across through this wave's LDS scratch
+                # (ds_write from AGPRs, ds_read into VGPRs: free next to MFMAs; LDS executes a wave's operations in order),
+                # so that only v_max is left for the VALU block between the layers.  (`moves` also goes to the out-of-line
+                # copies of k-quad 14 that the table requests of the one-frame shapes put on this slab.)
+                for g in range(G):
+                    b0, a0 = self.inreg(g, (j - 1) * 4), A_ACC + (g * 16 + j - 1) * 4
+                    moves.setdefault(1 + 4 * g, []).append(("lds", f"ds_write_b128 v{V_SCR}, a[{a0}:{a0 + 3}]", ("W", g, j - 1)))
+                    moves.setdefault(2 + 4 * g, []).append(("lds", f"ds_read_b128 v[{b0}:{b0 + 3}], v{V_SCR}", ("R", g, j - 1)))
             if j == 13:     # the scalar side of `advance`, ahead of the barrier and behind MFMAs
                 pre = [f"s_add_u32 {s('T')}, {s('CURB')}, {s('LDSBASE')}", f"s_add_u32 {s('CUR')}, {s('CUR')}, 1",
                        f"s_cmp_eq_u32 {s('CUR')}, {KRING}", f"s_cselect_b32 {s('CUR')}, 0, {s('CUR')}",
@@ -242,21 +283,14 @@ class Body:
                     ol = self.label("table")
                     e(f"s_cmp_eq_u32 {s('LAYER')}, {layer}")
                     e(f"s_cbranch_scc1 {ol}")
-                    self.outofline.append((ol, join, emit, mb, j))
+                    self.outofline.append((ol, join, emit, mb, j, {k: list(v) for k, v in moves.items()}))
                 dma = self.dma4()
                 ptr = [f"s_add_u32 {s('WPTR')}, {s('WPTR')}, {SLAB}", f"s_addc_u32 {s('WPTR1')}, {s('WPTR1')}, 0",
                        f"s_add_u32 {s('IS')}, {s('IS')}, 1", f"s_cmp_eq_u32 {s('IS')}, {NSLABS}",
                        f"s_cselect_b64 {s2('WPTR')}, {s2('WBASE')}, {s2('WPTR')}", f"s_cselect_b32 {s('IS')}, 0, {s('IS')}"]
                 sprinkle = {0: [dma[0]], 3: [dma[1]], 6: [dma[2]], 9: [dma[3], *ptr]}
-            if mb == 15 and j >= 1:
-                # The layer's last slab: once k-quad j-1 has been issued, block j-1 of the B registers is dead and block j-1
-                # of the accumulators has been final since slab j-1 -- move it across through this wave's LDS scratch
-                # (ds_write from AGPRs, ds_read into VGPRs: free next to MFMAs; LDS executes a wave's operations in order),
-                # so that only v_max is left for the VALU block between the layers.
-                for g in range(G):
-                    b0, a0 = self.inreg(g, (j - 1) * 4), A_ACC + (g * 16 + j - 1) * 4
-                    sprinkle.setdefault(1 + 4 * g, []).append(("lds", f"ds_write_b128 v{V_SCR}, a[{a0}:{a0 + 3}]", ("W", g, j - 1)))
-                    sprinkle.setdefault(2 + 4 * g, []).append(("lds", f"ds_read_b128 v[{b0}:{b0 + 3}], v{V_SCR}", ("R", g, j - 1)))
+            for pos, items in moves.items():
+                sprinkle.setdefault(pos, []).extend(items)
             self.quad_mfmas(mb, j, dst, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]", sprinkle=sprinkle)
             if j == 14:
                 e(f"{join}:")
@@ -295,14 +329,16 @@ class Body:
 
     # ---- table steps
     def q_step(self, with_acc):
-        """in[g][k] = (acc[g][k] +) q[frame of g][k].  q step: 16 rows of 1 KiB; this wave's frames are rows wave*3 + g."""
+        """in[g][k] = (acc[g][k] +) q[frame of g][k].  q step: 16 rows of 1 KiB; row of (wave, g): 3 wave + g in the long shape
+        (the wave part sits in V_QADDR), row 0 -- the tile's one frame -- in the others."""
         e = self.e
+        QG = 1024 if FT > 1 else 0
         e(f"v_add_u32 v{V_TMP}, {s('CURB')}, v{V_QADDR}")
         if not with_acc:
             for g in range(G):
                 for mb in range(16):
                     b = self.inreg(g, mb * 4)
-                    self.lds_op(f"ds_read_b128 v[{b}:{b + 3}], v{V_TMP} offset:{g * 1024 + mb * 64}", ("Q", g, mb))
+                    self.lds_op(f"ds_read_b128 v[{b}:{b + 3}], v{V_TMP} offset:{g * QG + mb * 64}", ("Q", g, mb))
             self.wait_all_lds()
             return
         self.last_block_to_b_registers()      # in = acc
@@ -310,21 +346,30 @@ class Body:
         for n in range(3):
             g, mb = items[n]
             t = V_W + 4 * (n % 4)
-            self.lds_op(f"ds_read_b128 v[{t}:{t + 3}], v{V_TMP} offset:{g * 1024 + mb * 64}", ("Q", g, mb))
+            self.lds_op(f"ds_read_b128 v[{t}:{t + 3}], v{V_TMP} offset:{g * QG + mb * 64}", ("Q", g, mb))
         for n, (g, mb) in enumerate(items):
             if n + 3 < len(items):
                 g2, mb2 = items[n + 3]
                 t2 = V_W + 4 * ((n + 3) % 4)
-                self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_TMP} offset:{g2 * 1024 + mb2 * 64}", ("Q", g2, mb2))
+                self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_TMP} offset:{g2 * QG + mb2 * 64}", ("Q", g2, mb2))
             b, t = self.inreg(g, mb * 4), V_W + 4 * (n % 4)
             self.wait_lds(("Q", g, mb))
             e(f"v_pk_add_f32 v[{b}:{b + 1}], v[{b}:{b + 1}], v[{t}:{t + 1}]")
             e(f"v_pk_add_f32 v[{b + 2}:{b + 3}], v[{b + 2}:{b + 3}], v[{t + 2}:{t + 3}]")
         self.wait_all_lds()
 
-    def p_step(self):
-        """in[g][k] = relu(in[g][k] + p[pixel][k]); p step: [mb][lane] f4, i.e. lane-linear like an A quad."""
+    def p_step(self, k=0):
+        """in[g][k] = relu(in[g][k] + p[pixel][k]); p step: [mb][lane] f4, i.e. lane-linear like an A quad.  Long shape: every
+        group of every wave has the tile's one pixel group.  Other shapes: step k holds pixel group k of the tile's block, which is
+        group k % G of wave k // G -- that wave adds it, the others only pass the step."""
         e = self.e
+        groups = range(G)
+        skip = None
+        if PGT > 1:
+            groups = [k % G]
+            skip = self.label("pskip")
+            e(f"s_cmp_eq_u32 {s('WAVE')}, {k // G}")
+            e(f"s_cbranch_scc0 {skip}")
         e(f"v_add_u32 v{V_RING}, {s('CURB')}, v{V_LANE16}")
         for mb in range(3):
             t = V_W + 4 * (mb % 4)
@@ -335,13 +380,46 @@ class Body:
                 self.lds_op(f"ds_read_b128 v[{t2}:{t2 + 3}], v{V_RING} offset:{(mb + 3) * 1024}", ("P", mb + 3))
             self.wait_lds(("P", mb))
             t = V_W + 4 * (mb % 4)
-            for g in range(G):
+            for g in groups:
                 b = self.inreg(g, mb * 4)
                 e(f"v_pk_add_f32 v[{b}:{b + 1}], v[{b}:{b + 1}], v[{t}:{t + 1}]")
                 e(f"v_pk_add_f32 v[{b + 2}:{b + 3}], v[{b + 2}:{b + 3}], v[{t + 2}:{t + 3}]")
                 for r in range(4):
                     e(f"v_max_f32 v{b + r}, 0, v{b + r}")
         self.wait_all_lds()
+        if skip:
+            e(f"{skip}:")
+
+    # ---- what the advance that retires position `pos` of the tile's step sequence has to request: step pos + KRING
+    @staticmethod
+    def tile_steps():
+        return ["Q0"] + [("P0", k) for k in range(PGT)] + ["W"] * 80 + ["Q5"] + [("P5", k) for k in range(PGT)] + ["W"] * 33
+
+    def refill_at(self, pos):
+        """emitter (or None = the next weight slab) for the step KRING after position pos; steps past the tile's end are the NEXT
+        tile's (FGN, PGN)"""
+        steps = self.tile_steps()
+        tgt, nxt = pos + KRING, False
+        if tgt >= len(steps):
+            tgt, nxt = tgt - len(steps), True
+        kind = steps[tgt]
+        fg, pg = ("FGN", "PGN") if nxt else ("FG", "PG")
+        if kind == "W":
+            return None
+        if kind == "Q0":
+            return lambda: self.q_refill("Q0", fg)
+        if kind == "Q5":
+            return lambda: self.q_refill("Q5", fg)
+        tab, k = kind
+        return lambda: self.p_refill(tab, pg, k)
+
+    def advance_and_refill(self, pos):
+        self.advance()
+        emit = self.refill_at(pos)
+        if emit is None:
+            self.weight_refill()
+        else:
+            emit()
 
     def prefetch_first_quads(self, with_bias):
         self.ring_table()
@@ -358,7 +436,7 @@ def generate():
     e = b.e
     # ================= prologue: operands -> owned registers
     for dst, src in (("LDSBASE", "ldsbase"), ("NFG", "nfg"), ("TILE", "tile0"), ("TEND", "tile_end"), ("NFRAMES", "nframes"), ("HW", "hw"),
-                     ("FG", "fg0"), ("PG", "pg0"), ("WAVE", "wave")):
+                     ("FG", "fg0"), ("PG", "pg0"), ("WAVE", "wave")) + ((("NPGM1", "npgm1"),) if PGT > 1 else ()):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
     for dst, src in (("WBASE", "wsrc"), ("Q0", "q0"), ("Q5", "q5"), ("P0", "p0"), ("P5", "p5"), ("OUT", "out")) + ((("TRACE", "trace"),) if TRACE else ()):
         e(f"s_mov_b64 {s2(dst)}, %[{src}]")
@@ -369,26 +447,27 @@ def generate():
     e(f"s_mov_b32 {s('CURB')}, 0")
     for dst, src in ((V_LANE16, "lane16"), (V_DMAOFF, "dmaoff"), (V_BIAS0, "biasaddr"), (V_QADDR, "qaddr"), (V_BOUT, "boutaddr"), (V_PIX, "px"), (V_SCR, "scraddr")):
         e(f"v_mov_b32 v{dst}, %[{src}]")
-    # prime the ring: q0 and p0 of the first tile, weight slabs 0..5 (steps 0..7 -> buffers 0..7)
-    e(f"s_mov_b32 {s('T')}, {s('LDSBASE')}")
-    b.q_refill("Q0", "FG")
-    e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB}")
-    b.p_refill("P0", "PG")
-    for st in range(2, KRING - 1):
-        e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB * st}")
-        b.weight_refill_setup()
-        e("s_nop 0")
-        for t in b.dma4():
-            e(t)
+    # prime the ring with the first tile's steps 0..7 (buffers 0..7): q0, its p0 steps, weight slabs
+    def prime(st):
+        if st == 0:
+            e(f"s_mov_b32 {s('T')}, {s('LDSBASE')}")
+        else:
+            e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB * st}")
+        emit = b.refill_at(st - KRING)       # (the request for step st)
+        if emit is not None:
+            emit()
+        else:
+            b.weight_refill_setup()
+            e("s_nop 0")
+            for t in b.dma4():
+                e(t)
+    for st in range(KRING - 1):
+        prime(st)
     # step 0 landed and published (with the bias block the C++ prologue wrote); top the ring up
     e("s_waitcnt lgkmcnt(0)")
     e("s_waitcnt vmcnt(28)")
     e("s_barrier")
-    e(f"s_add_u32 {s('T')}, {s('LDSBASE')}, {SLAB * (KRING - 1)}")
-    b.weight_refill_setup()
-    e("s_nop 0")
-    for t in b.dma4():
-        e(t)
+    prime(KRING - 1)
 
     # ================= tile loop
     e("S2L_TILE:")
@@ -408,11 +487,10 @@ def generate():
     # ---- h0 = relu(p0[pixel] + q0[frame])
     b.trace(0)
     b.q_step(False)
-    b.advance()
-    b.weight_refill()
-    b.p_step()
-    b.advance()
-    b.weight_refill()
+    b.advance_and_refill(0)
+    for k in range(PGT):
+        b.p_step(k)
+        b.advance_and_refill(1 + k)
     e(f"v_mov_b32 v{V_BIAS}, v{V_BIAS0}")
     e(f"s_mov_b32 {s('LAYER')}, 0")
     b.trace(1)
@@ -421,12 +499,20 @@ def generate():
 
     # ---- the layer loop
     e("S2L_LAYER:")
-    q5 = lambda: b.q_refill("Q5", "FG")
-    p5 = lambda: b.p_refill("P5", "PG")
-    q0n = lambda: b.q_refill("Q0", "FGN")
-    p0n = lambda: b.p_refill("P0", "PGN")
+    # the table requests issued from inside the layer loop, keyed by (slab, runtime layer): slab mb of layer L is position
+    # base1 + 16 L + mb of the tile for L < 5 and base2 + 16 (L - 5) + mb behind the q5 / p5 steps
+    base1 = 1 + PGT
+    base2 = base1 + 81 + PGT
+    special = {}
+    for L in range(NLAYERS):
+        for mb in range(16):
+            emit = b.refill_at((base1 + 16 * L if L < 5 else base2 + 16 * (L - 5)) + mb)
+            if emit is not None:
+                special.setdefault(mb, []).append((L, emit))
+    if (G, PGT, FT) == (3, 1, 12):
+        assert {mb: [L for L, _ in v] for mb, v in special.items()} == {7: [4], 8: [4, 6], 9: [6]}
     for mb in range(16):
-        b.slab(mb, {7: [(4, q5)], 8: [(4, p5), (6, q0n)], 9: [(6, p0n)]}.get(mb))
+        b.slab(mb, special.get(mb))
     slab_end = list(b.lds)         # the first quads of the next slab + the tail of the accumulator moves: both continuations
     assert [t for t in slab_end if t[0] == "A"] == [("A", 16, 0), ("A", 16, 1)]      # below wait for all of it first
     e(f"s_cmp_eq_u32 {s('LAYER')}, 4")
@@ -455,24 +541,41 @@ def generate():
             b.wait_lds(("B", 0))
         b.quad_mfmas(0, j, rgb, first_c=f"a[{A_BIAS}:{A_BIAS + 3}]")
     b.wait_all_lds()
-    b.advance()               # publishes the next tile's q0 step
-    b.weight_refill()
-    # ---- store: lanes 0..15 (k-subgroup 0) hold rgb of pixel pg*16 + lane for the wave's three frames
-    e(f"s_lshl_b32 {s('T6')}, {s('PG')}, 4")
-    e(f"v_add_u32 v{V_TMP}, {s('T6')}, v{V_PIX}")
-    e(f"v_cmp_gt_u32 vcc, {s('HW')}, v{V_TMP}")
-    e(f"v_mul_u32_u24 v{V_PIXOFF}, 12, v{V_TMP}")
-    e(f"s_mov_b64 {s2('EX')}, exec")
-    e("s_nop 3")
-    e("s_and_b64 exec, vcc, 0xffff")
-    e(f"s_mul_i32 {s('T6')}, {s('FG')}, 12")
-    e(f"s_mul_i32 {s('T7')}, {s('WAVE')}, {G}")
-    e(f"s_add_u32 {s('T6')}, {s('T6')}, {s('T7')}")      # frame0
-    e("s_nop 7")
-    e("s_nop 7")
+    b.advance_and_refill(len(b.tile_steps()) - 1)      # (long shape: the next weight slab; publishes the next tile's q0 step)
+    if PGT == 1:
+        # ---- store: lanes 0..15 (k-subgroup 0) hold rgb of pixel pg*16 + lane for the wave's three frames
+        e(f"s_lshl_b32 {s('T6')}, {s('PG')}, 4")
+        e(f"v_add_u32 v{V_TMP}, {s('T6')}, v{V_PIX}")
+        e(f"v_cmp_gt_u32 vcc, {s('HW')}, v{V_TMP}")
+        e(f"v_mul_u32_u24 v{V_PIXOFF}, 12, v{V_TMP}")
+        e(f"s_mov_b64 {s2('EX')}, exec")
+        e("s_nop 3")
+        e("s_and_b64 exec, vcc, 0xffff")
+        e(f"s_mul_i32 {s('T6')}, {s('FG')}, 12")
+        e(f"s_mul_i32 {s('T7')}, {s('WAVE')}, {G}")
+        e(f"s_add_u32 {s('T6')}, {s('T6')}, {s('T7')}")      # frame0
+        e("s_nop 7")
+        e("s_nop 7")
+    else:
+        e(f"s_mov_b64 {s2('EX')}, exec")
+        e(f"s_mov_b32 {s('T6')}, {s('FG')}")                  # the tile's one frame (always < NFRAMES)
     for g in range(G):
         skip = b.label("nostore")
-        e(f"s_add_u32 {s('T7')}, {s('T6')}, {g}")
+        if PGT > 1:
+            # group g of this wave = pixel group PG * PGT + WAVE * G + g: lanes 0..15 hold rgb of its pixels
+            e(f"s_mul_i32 {s('T8')}, {s('PG')}, {PGT}")
+            e(f"s_mul_i32 {s('T9')}, {s('WAVE')}, {G}")
+            e(f"s_add_u32 {s('T8')}, {s('T8')}, {s('T9')}")
+            e(f"s_add_u32 {s('T8')}, {s('T8')}, {g}")
+            e(f"s_lshl_b32 {s('T8')}, {s('T8')}, 4")
+            e(f"v_add_u32 v{V_TMP}, {s('T8')}, v{V_PIX}")
+            e(f"v_cmp_gt_u32 vcc, {s('HW')}, v{V_TMP}")
+            e(f"v_mul_u32_u24 v{V_PIXOFF}, 12, v{V_TMP}")
+            e("s_nop 3")
+            e(f"s_and_b64 exec, vcc, 0xffff")
+            e("s_nop 7")
+            e("s_nop 7")
+        e(f"s_add_u32 {s('T7')}, {s('T6')}, {g if PGT == 1 else 0}")
         e(f"s_cmp_ge_u32 {s('T7')}, {s('NFRAMES')}")
         e(f"s_cbranch_scc1 {skip}")
         # byte offset of the frame = frame * hw * 12 (64-bit)
@@ -486,6 +589,8 @@ def generate():
         e(f"s_addc_u32 {s('T5')}, {s('OUT1')}, {s('T9')}")
         e(f"global_store_dwordx3 v{V_PIXOFF}, a[{A_RGB + 4 * g}:{A_RGB + 4 * g + 2}], {s2('T4')}")
         e(f"{skip}:")
+        if PGT > 1:
+            e(f"s_mov_b64 exec, {s2('EX')}")
     e(f"s_mov_b64 exec, {s2('EX')}")
     b.trace(9)
     # ---- next tile of this workgroup
@@ -501,11 +606,10 @@ def generate():
     e("S2L_SKIP:")
     b.lds = list(slab_end)     # (the two quads read from the q5 step are discarded)
     b.q_step(True)
-    b.advance()
-    b.weight_refill()
-    b.p_step()
-    b.advance()
-    b.weight_refill()
+    b.advance_and_refill(base1 + 80)
+    for k in range(PGT):
+        b.p_step(k)
+        b.advance_and_refill(base1 + 81 + k)
     b.trace("layer")
     e(f"s_mov_b32 {s('LAYER')}, 5")
     e(f"v_add_u32 v{V_BIAS}, 1024, v{V_BIAS}")
@@ -513,10 +617,10 @@ def generate():
     assert b.lds == loop_state
     e("s_branch S2L_LAYER")
     # ================= out of line: the four table refills per tile (the slab's k-quad 14 is repeated here without DMA tucks)
-    for ol, join, emit, mb, j in b.outofline:
+    for ol, join, emit, mb, j, moves in b.outofline:
         e(f"{ol}:")
         emit()
-        b.quad_mfmas(mb, j, lambda g: b.acc(g, mb))
+        b.quad_mfmas(mb, j, lambda g: b.acc(g, mb), sprinkle=moves)       # (same LDS operations, in the same order, as the in-line copy)
         e(f"s_branch {join}")
     e("S2L_END:")
     return [x for x in b.L if x is not None]
@@ -524,25 +628,40 @@ def generate():
 
 OPERANDS = """      :
       : [ldsbase] "s"(ldsbase), [nfg] "s"(nfg), [tile0] "s"(tile0), [tile_end] "s"(tile_end), [nframes] "s"(a.nframes), [hw] "s"(a.hw),
-        [fg0] "s"(fg0), [pg0] "s"(pg0),
+        [fg0] "s"(fg0), [pg0] "s"(pg0),NPGM1_OPERAND
         [wave] "s"(wave), [wsrc] "s"(wsrc), [q0] "s"(a.q0), [q5] "s"(a.q5), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [out] "s"(a.out),
         [lane16] "v"(lane16), [dmaoff] "v"(dmaoff), [biasaddr] "v"(biasaddr), [qaddr] "v"(qaddr), [boutaddr] "v"(boutaddr), [px] "v"(px), [scraddr] "v"(scraddr)TRACE_OPERAND
 """
 
 
-def main(path):
+def main(path, variant="long"):
+    set_variant(variant)
     lines = generate()
-    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(36, S_LAST + 1)]
+    if variant != "long":      # the variants share a translation unit: their labels must differ (the long shape keeps its text)
+        lines = [x.replace("S2L_", f"S2L{variant[0].upper()}_") for x in lines]
+    assert S["NPGM1"] == S_LAST       # the long shape does not use it: its text (clobber list included) stays what it was
+    s_last = S_LAST - (1 if PGT == 1 else 0)
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(36, s_last + 1)]
     clob += ["vcc", "scc", "memory"]   # (m0 and exec: nothing follows the body; exec is restored)
     out = ["// GENERATED by csrc/gen_render_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]
-    out.append(OPERANDS.rstrip("\n").replace("TRACE_OPERAND", ', [trace] "s"(g_trace)' if TRACE else ""))
+    out.append(OPERANDS.rstrip("\n").replace("TRACE_OPERAND", ', [trace] "s"(g_trace)' if TRACE else "")
+               .replace("NPGM1_OPERAND", ' [npgm1] "s"(npgm1),' if PGT > 1 else ""))
     out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     return len(lines)
 
 
+def main_all(objdir):
+    """render_body.inc (the long shape, its text pinned) + render_body_wide.inc + render_body_single.inc"""
+    n = {}
+    for variant in VARIANTS:
+        n[variant] = main(os.path.join(objdir, "render_body.inc" if variant == "long" else f"render_body_{variant}.inc"), variant)
+    return n
+
+
 if __name__ == "__main__":
-    n = main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "render_body.inc"))
-    print(f"render_body.inc: {n} instructions")
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build")
+    for k, v in main_all(d).items():
+        print(f"render body, {k}: {v} instructions")

@@ -37,12 +37,24 @@ struct RenderArgs {
   const float* q5;
   float* out;         // [F][HW][3]
   int hw, nframes;
-  int npg, ntiles;    // pixel groups of 16, tiles = npg * ceil(F/12)
+  int npg, ntiles;    // pixel groups of 16 in the image; tiles = ceil(npg / PGT) * nfg
+  int nfg;            // frame groups = ceil(F / FT)
 };
+
+// Tile shapes (csrc/gen_render_body.py, VARIANTS): 4 waves x G groups of 16 samples = PGT pixel groups x FT frames.
+//   kLong   3 groups, 1 x 12: the shape for clips (its generated text is pinned);
+//   kWide   3 groups, 12 x 1: one frame per tile -- no wasted frame slots when F is not a multiple of 12;
+//   kSingle 1 group,   4 x 1: 64 samples per tile, so that ONE frame spreads over the whole chip (the reference's per-frame mode).
+// Frames are bit-identical whichever shape rendered them (every sample column sees the same MFMA sequence).
+enum RenderShape { kLong = 0, kWide = 1, kSingle = 2 };
+struct ShapeDims { int g, pgt, ft; };
+__host__ __device__ constexpr ShapeDims shape_dims(int shape) {
+  return shape == kLong ? ShapeDims{3, 1, 12} : shape == kWide ? ShapeDims{3, 12, 1} : ShapeDims{1, 4, 1};
+}
 
 constexpr int kRing = 9;                       // 16 KiB steps resident in LDS (gen_render_body.py: KRING)
 constexpr int kSlabBytes = kSlab * 4;          // 16384
-constexpr int kTileFrames = 12, kTilePixels = 16;
+constexpr int kTilePixels = 16;
 constexpr int kBiasFloats = kHidden * kW + 4;  // OFF_BIAS .. OFF_BOUT+4 are contiguous in the blob
 // ring + bias block + 76 B (the body prefetches "the next slab's bias" once past the block's end: unused values; the scratch
 // below is 16-byte aligned) + 1 KiB of scratch per wave (accumulators -> B registers between two layers)
@@ -58,6 +70,7 @@ __device__ long long* g_trace = nullptr;
 extern "C" int s2l_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
 #endif
 
+template <int SHAPE>
 __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // biases -> LDS (ordinary stores; the body waits for them before its first barrier)
@@ -68,8 +81,10 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   const int q = lane >> 4, px = lane & 15;      // k-subgroup and sample of this lane in every 16x16x4 MFMA
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ldsbase = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);   // this wave's quarter of ring buffer 0
-  // this workgroup's tiles: a contiguous range in pixel-group-major order, tile t = (pixel group t / nfg, frame group t % nfg)
-  const int nfg = __builtin_amdgcn_readfirstlane(a.ntiles / a.npg);
+  // this workgroup's tiles: a contiguous range in pixel-group-major order, tile t = (pixel-group block t / nfg, frame group t % nfg)
+  const int nfg = __builtin_amdgcn_readfirstlane(a.nfg);
+  const int npgm1 = __builtin_amdgcn_readfirstlane(a.npg - 1);      // (the wide shapes clamp their table rows to the last group)
+  (void)npgm1;
   const int tile0 = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * blockIdx.x / gridDim.x));
   const int tile_end = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * (blockIdx.x + 1) / gridDim.x));
   const int fg0 = __builtin_amdgcn_readfirstlane(tile0 % nfg), pg0 = __builtin_amdgcn_readfirstlane(tile0 / nfg);
@@ -78,9 +93,16 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   const uint32_t dmaoff = wave * 4096 + lane * 16;                           // this lane's 16 B of a 16 KiB step
   const uint32_t biasaddr = lds0 + kRing * kSlabBytes + 16 * q;              // bias of features 16 mb + 4 q .. + 3
   const uint32_t boutaddr = lds0 + kRing * kSlabBytes + kHidden * kW * 4;    // output-layer bias (rows >= 3 are zero)
-  const uint32_t qaddr = lds0 + wave * 3072 + q * 16;                        // q rows of this wave's three frames
+  // q rows: the long shape's wave owns frames (rows) 3 wave + g; the one-frame shapes read row 0
+  const uint32_t qaddr = lds0 + (SHAPE == kLong ? wave * 3072 : 0) + q * 16;
   const uint32_t scraddr = lds0 + kScratchOff + wave * 1024 + lane * 16;     // this wave's scratch
+  if constexpr (SHAPE == kLong) {
 #include "render_body.inc"
+  } else if constexpr (SHAPE == kWide) {
+#include "render_body_wide.inc"
+  } else {
+#include "render_body_single.inc"
+  }
 }
 
 }  // namespace s2l
@@ -99,6 +121,32 @@ extern "C" int s2l_set_render_cus(int n_workgroups) {
   return S2L_OK;
 }
 
+// 0 = choose per call (below), 1 + shape = always that shape (tests, A/B runs)
+static std::atomic<int> g_render_shape{0};
+extern "C" int s2l_set_render_shape(int mode) {
+  if (mode < 0 || mode > 3) return S2L_E_SIZE;
+  g_render_shape.store(mode, std::memory_order_relaxed);
+  return S2L_OK;
+}
+
+// The shape with the smallest estimated time on n_cu CUs: rounds of tiles over the persistent grid x the cost of a tile (a G = 1
+// tile streams the same 113 weight slabs for a third of the MFMAs: ~0.36 of a G = 3 tile; the wide shape's 22 extra table steps
+// cost ~3 %).  Ties go to the long shape (pinned text, least table traffic).
+static int pick_render_shape(int64_t npg, int64_t n_frames, int n_cu) {
+  double best = 0;
+  int pick = s2l::kLong;
+  const double cost[3] = {1.0, 1.03, 0.36};
+  for (int shp = 0; shp < 3; ++shp) {
+    const s2l::ShapeDims d = s2l::shape_dims(shp);
+    const int64_t tiles = ((npg + d.pgt - 1) / d.pgt) * ((n_frames + d.ft - 1) / d.ft);
+    // a persistent workgroup owns a contiguous range of ceil / floor(tiles / grid) tiles: the longest range sets the time
+    const int64_t grid = tiles < n_cu ? tiles : n_cu;
+    const double t = (double)((tiles + grid - 1) / grid) * cost[shp];
+    if (shp == 0 || t < best * 0.97) best = t, pick = shp;
+  }
+  return pick;
+}
+
 extern "C" int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0, const float* q5,
                               float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream) {
   using namespace s2l;
@@ -111,20 +159,25 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   a.packed = packed; a.p0t = p0; a.p5t = p5; a.q0 = q0; a.q5 = q5; a.out = out;
   a.hw = (int)hw; a.nframes = (int)n_frames;
   a.npg = (int)((hw + kTilePixels - 1) / kTilePixels);
-  const int64_t ntiles = (int64_t)a.npg * ((n_frames + kTileFrames - 1) / kTileFrames);
-  if (ntiles > 0x7fffffff) return S2L_E_SIZE;
-  a.ntiles = (int)ntiles;
 
   // per-device one-time setup (CU count, >64 KiB dynamic-LDS opt-in), thread-safe: s2l_common.h
-  static LdsOptIn lds_flags;
+  static LdsOptIn lds_flags[3];
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
-  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&render_tiles_kernel), kLdsBytes, lds_flags, dev))) return rc;
   const int limit = g_render_cu_limit[dev].load(std::memory_order_relaxed);
   if (limit > 0 && limit < n_cu) n_cu = limit;
+  const int forced = g_render_shape.load(std::memory_order_relaxed);
+  const int shape = forced ? forced - 1 : pick_render_shape(a.npg, n_frames, n_cu);
+  const ShapeDims d = shape_dims(shape);
+  a.nfg = (int)((n_frames + d.ft - 1) / d.ft);
+  const int64_t ntiles = (int64_t)((a.npg + d.pgt - 1) / d.pgt) * a.nfg;
+  if (ntiles > 0x7fffffff) return S2L_E_SIZE;
+  a.ntiles = (int)ntiles;
+  void (*const kern[3])(RenderArgs) = {render_tiles_kernel<kLong>, render_tiles_kernel<kWide>, render_tiles_kernel<kSingle>};
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[shape]), kLdsBytes, lds_flags[shape], dev))) return rc;
   // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
-  hipLaunchKernelGGL(render_tiles_kernel, dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(kern[shape], dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }

@@ -61,6 +61,60 @@ def _median_ms(fn, reps=6, inner=10):
     return float(np.median([a.elapsed_time(b) for a, b in evs])) / inner
 
 
+def bench_small_clips(dev):
+    """The reference's own operating point: ONE frame per call (inference.py:129 DataLoader batch 1, :140-159), and BASELINE
+    config 1's 16-frame clip.  Per size: `render_clip` at F = 1 and F = 16 (per-call latency through the host wrapper as a caller
+    sees it, and stream time per call from HIP events around back-to-back calls), the long-clip per-frame cost for comparison,
+    and the drop-in per-frame sequence audio_merge_forward(H*W tiled windows) + rgb_forward(H*W rows) (inference.py:144-159)."""
+    res = {}
+    for h in (64, 96):
+        w, hw = h, h * h
+        m = make_model(dev, h, w)
+        long_f = 480
+        audio = torch.from_numpy(W.synthetic_audio(long_f, 1).astype(np.float32)).to(dev)
+        idx = torch.arange(long_f, device=dev)
+        out_long = torch.empty(long_f, h, w, 3, device=dev)
+        m.render_clip(audio, idx, h, w, out=out_long)
+        ms_long = _median_ms(lambda: m.render_clip(audio, idx, h, w, out=out_long), reps=5, inner=2)
+        entry = {"long_clip_us_per_frame": round(ms_long / long_f * 1e3, 2)}
+        for F in (1, 16):
+            a, i, o = audio[:F].contiguous(), idx[:F].contiguous(), torch.empty(F, h, w, 3, device=dev)
+            call = lambda: m.render_clip(a, i, h, w, out=o)
+            for _ in range(5):
+                call()
+            torch.cuda.synchronize()
+            ms_stream = _median_ms(call, reps=7, inner=20)
+            lat = []
+            for _ in range(30):               # latency of ONE call seen by a synchronous caller
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            assert torch.equal(o, out_long[:F])          # any tile shape: the same bits as the long clip's frames
+            entry[f"render_clip_F{F}"] = {"stream_us_per_call": round(ms_stream * 1e3, 1), "frames_per_s": round(F / ms_stream * 1e3, 1),
+                                          "sync_latency_us_per_call": round(float(np.median(lat)) * 1e6, 1),
+                                          "per_frame_cost_over_long_clip": round(ms_stream / F / (ms_long / long_f), 2)}
+        # the drop-in per-frame sequence, as inference.py drives the module
+        from speech2lip_amd import get_coords
+        coords = get_coords(w, h, dev)
+        win = audio[:1]
+
+        def dropin():
+            feat = m.audio_merge_forward(win.tile(hw, 1, 1))                         # inference.py:144, 151
+            rows = torch.cat([coords[:, None, :], feat[:, None, :]], -1).view(-1, 66)   # :152
+            return m.rgb_forward(rows, time_pts=torch.tensor([7]))[:, :3]           # :158-159
+        with torch.no_grad():
+            for _ in range(3):
+                r = dropin()
+            torch.cuda.synchronize()
+            ms_drop = _median_ms(dropin, reps=5, inner=10)
+        entry["dropin_per_frame_sequence"] = {"us_per_frame": round(ms_drop * 1e3, 1), "frames_per_s": round(1e3 / ms_drop, 1),
+                                              "max_abs_diff_vs_render_clip": float((r.reshape(h, w, 3) - m.render_clip(win, [7], h, w)[0]).abs().max())}
+        res[f"{h}x{w}"] = entry
+    return res
+
+
 def bench_composite(dev, frames=256, check=True):
     """A7 alone at BASELINE config 3 geometry: 128x128 lip in a 500x500 face.  HBM-bound: 8,000,000 + 12 h w B/frame."""
     h = w = 128
