@@ -463,6 +463,13 @@ int s2l_train_forward_bf16(const uint16_t* packed_bf16, const float* packed_f32,
 int s2l_set_bf16_forward_kernel(int kind);
 int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
                             float* dxa, int64_t n_rows, s2l_stream_t stream);
+/* The backward exists twice as well: the C++ kernel above and a generated gfx950 assembly kernel (csrc/gen_bwd16_body.py: 64 rows
+ * per wave, one wave per SIMD) whose dz images are bit-identical.  The assembly kernel returns the gradient of the audio columns
+ * summed over each 256-row tile -- dxa_tiles [ceil(n_rows / 256)][64], tile t = rows [256 t, 256 t + 256) -- instead of per row
+ * (the per-row form costs 2.4 GB of traffic per 64-frame step only to be column-summed per frame, training.py:171's adjoint): use
+ * it when a frame's 4 H W rows are a whole number of tiles, then s2l_segment_colsums over the tiles of each frame. */
+int s2l_train_backward_bf16_tiles(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
+                                  float* dxa_tiles, int64_t n_rows, s2l_stream_t stream);
 /* Weight gradients from the tiles: dw [256,k_in] = dzT_layer^T . inT (k_in = 256: inT = the hT layer below; k_in = 128:
  * inT = the embedded rows in the same image layout, s2l_rows_to_tiles_bf16), db NULL or [256] = column sums of dz; work:
  * s2l_wgrad_bf16_work_floats() floats (per-workgroup partial sums, reduced in a fixed order).  s2l_out_grad_bf16:

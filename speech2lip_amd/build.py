@@ -46,6 +46,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         gen_conv_body.main(objdir)
         import gen_fwd16_body              # ... and the bf16 training forward (train_bf16.hip)
         gen_fwd16_body.main(objdir)
+        import gen_bwd16_body              # ... and its backward
+        gen_bwd16_body.main(objdir)
     finally:
         sys.path.pop(0)
     procs = []

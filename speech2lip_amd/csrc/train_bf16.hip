@@ -529,6 +529,24 @@ __global__ __launch_bounds__(512, 1) void bwd_bf16_kernel(BwdArgs a) {
   }
 }
 
+// ---- the backward kernel with its body as one fixed-register assembly text (csrc/gen_bwd16_body.py): 64 rows per wave, one wave
+// per SIMD, stages by LDS-DMA, every memory instruction behind an MFMA -- the twin of fwd_asm_bf16_kernel.  The dz images are
+// bit-identical to bwd_bf16_kernel's.  The audio gradient leaves this kernel as the column sums of each 256-row tile
+// (BwdArgs::dxa = dxa_tiles [n_tiles][64]) instead of per row: the caller uses it when a tile never straddles two frames.
+constexpr int kLdsBwdAsm = 2 * kStageB * 2 + 8 * kSlabU0 * 2 + 1024;      // two stage buffers, Wout^T, the four waves' column sums
+__global__ __launch_bounds__(256, 1) void bwd_asm_bf16_kernel(BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ldsbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x), grid = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();   // the body loads BwdArgs fields itself (s_load)
+#else
+  const void* karg = nullptr;   // (host pass of the compiler: never executed)
+#endif
+#include "bwd16_body.inc"
+}
+
 // ---- weight gradients ---------------------------------------------------------------------------------------------------------
 // dW[m][k] = sum_rows dz[row][m] in[row][k]: both MFMA operands want "8 consecutive rows of one feature" per lane.  The images
 // are row-major per (block, hh): [32 rows][16 features], 32-byte rows; ds_read_b64_tr_b16 reads a [4 rows][16 features] block
@@ -938,6 +956,27 @@ extern "C" int s2l_train_backward_bf16(const uint16_t* packed_bf16, const float*
   const int rc = persistent_grid(reinterpret_cast<const void*>(bwd_bf16_kernel), kLdsBwd, flags, a.n_tiles, &grid);
   if (rc) return rc;
   hipLaunchKernelGGL(bwd_bf16_kernel, dim3(grid), dim3(512), kLdsBwd, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+// The assembly backward: dzT as s2l_train_backward_bf16 (bit-identical); the audio gradient as per-TILE column sums
+// dxa_tiles [n_rows_padded / 256][64] (tile t = rows [256 t, 256 t + 256)) instead of per row.
+extern "C" int s2l_train_backward_bf16_tiles(const uint16_t* packed_bf16, const float* drgb, const uint64_t* masks, uint16_t* dzT,
+                                             float* dxa_tiles, int64_t n_rows, s2l_stream_t stream) {
+  if (n_rows < 0 || n_rows >= (int64_t(1) << 24) * 16) return S2L_E_SIZE;      // 12 * row must fit 32 bits
+  if (n_rows == 0) return S2L_OK;
+  if (!packed_bf16 || !drgb || !masks || !dzT || !dxa_tiles) return S2L_E_NULL;
+  if (misaligned16(packed_bf16) || misaligned16(dzT) || misaligned16(dxa_tiles) || misaligned16(masks)) return S2L_E_ALIGN;
+  BwdArgs a;
+  const int64_t np = s2l_bf16_rows_padded(n_rows);
+  a.wb = packed_bf16, a.drgb = drgb, a.masks = masks, a.dzT = dzT, a.dxa = dxa_tiles;
+  a.n_rows = n_rows, a.layer_stride = np * 256, a.mask_layer_stride = np / 64 * 256;
+  a.n_tiles = (int)(np / kWgRows);
+  static LdsOptIn flags;
+  int grid = 0;
+  const int rc = persistent_grid(reinterpret_cast<const void*>(bwd_asm_bf16_kernel), kLdsBwdAsm, flags, a.n_tiles, &grid);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_asm_bf16_kernel, dim3(grid), dim3(256), kLdsBwdAsm, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
 

@@ -289,20 +289,27 @@ def mlp_forward(model: TalkingFace, st: MlpState, rgb: torch.Tensor, stream) -> 
         ck(lib.s2l_train_forward(_ptr(packed), _ptr(st.x), _ptr(st.hsave), _ptr(rgb), st.N, stream), "s2l_train_forward")
 
 
-def mlp_backward(model: TalkingFace, st: MlpState, drgb: torch.Tensor, stream):
+def mlp_backward(model: TalkingFace, st: MlpState, drgb: torch.Tensor, stream, tile_sums: bool = False):
     """d loss / d rgb [N,3] -> ({state-dict name: gradient} for the 30 MLP tensors, dxa [N,64] = gradient of the audio columns).
-    dz chain, weight-gradient GEMMs, and the un-fold of the pack-time folds (s2l_unfold_first_layer) -- all HIP."""
+    dz chain, weight-gradient GEMMs, and the un-fold of the pack-time folds (s2l_unfold_first_layer) -- all HIP.
+    tile_sums (bf16 mode): the generated-assembly backward kernel, whose audio gradient comes back summed over each 256-row tile
+    ([ceil(N / 256), 64]) -- for callers whose frames are whole numbers of tiles."""
     lib, ck = _abi.load(), _abi.check
     packed = model.packed_weights()
     dev, N = packed.device, st.N
-    dxa = _f(dev, N, 64)
     bf16 = st.precision == "bf16"
     if bf16:
         pb = model.packed_weights_bf16()
         lay = st.Np * 256
         dzT = torch.empty(8 * lay, dtype=torch.int16, device=dev)
-        ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(st.masks), _ptr(dzT), _ptr(dxa), N, stream),
-           "s2l_train_backward_bf16")
+        if tile_sums:
+            dxa = _f(dev, st.Np // 256, 64)
+            ck(lib.s2l_train_backward_bf16_tiles(_ptr(pb), _ptr(drgb), _ptr(st.masks), _ptr(dzT), _ptr(dxa), N, stream),
+               "s2l_train_backward_bf16_tiles")
+        else:
+            dxa = _f(dev, N, 64)
+            ck(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(st.masks), _ptr(dzT), _ptr(dxa), N, stream),
+               "s2l_train_backward_bf16")
         work = _f(dev, int(lib.s2l_wgrad_bf16_work_floats()))
 
         def wgrad(k, inp, k_in, want_bias=True):          # dz of layer k against hT[inp] or the x tiles
@@ -311,6 +318,7 @@ def mlp_backward(model: TalkingFace, st: MlpState, drgb: torch.Tensor, stream):
             ck(lib.s2l_wgrad_bf16(_ptr(dzT[k * lay:]), _ptr(src), k_in, _ptr(work), _ptr(out), _ptr(db), N, stream), "s2l_wgrad_bf16")
             return out, db
     else:
+        dxa = _f(dev, N, 64)
         dzsave = _f(dev, 8, N, 256)
         ck(lib.s2l_train_backward(_ptr(packed), _ptr(drgb), _ptr(st.hsave), _ptr(dzsave), _ptr(dxa), N, stream), "s2l_train_backward")
         work = _f(dev, int(lib.s2l_split_work_floats(256 * 256)))
@@ -397,6 +405,7 @@ class LipTrainStep:
         self.model, self.h, self.w = model, int(height), int(width)
         self.lib = _abi.load()
         self.coords = get_coords(width, height, model.packed_weights().device)
+        self.bf16_backward_kernel = "asm"      # "cpp": always the C++ kernel (per-row audio gradient); same dz images bit for bit
         self._ctx = None
 
     def forward(self, audio, frame_idx, u01) -> torch.Tensor:
@@ -442,10 +451,13 @@ class LipTrainStep:
         with torch.cuda.device(dev):
             s = _stream()
             ck(lib.s2l_ensemble_backward_batch(_ptr(dp), _ptr(areas), _ptr(drgb), P, B, s), "s2l_ensemble_backward_batch")
-            g, dxa = mlp_backward(m, st, drgb, s)
+            # bf16 mode, frames that are whole numbers of 256-row tiles (96x96, 64x64, 128x128 ...): the assembly backward kernel,
+            # which sums the audio gradient per tile itself; otherwise the per-row form
+            tiles = self.precision == "bf16" and (4 * P) % 256 == 0 and self.bf16_backward_kernel == "asm"
+            g, dxa = mlp_backward(m, st, drgb, s, tile_sums=tiles)
             # per-frame gradient of the audio feature (rows of frame b are contiguous), then the encoder backward
             da, swork = _f(dev, B, 64), _f(dev, B * 32 * 64)
-            ck(lib.s2l_segment_colsums(_ptr(dxa), 64, 64, 4 * P, B, _ptr(swork), _ptr(da), s), "s2l_segment_colsums")
+            ck(lib.s2l_segment_colsums(_ptr(dxa), 64, 64, (4 * P) // 256 if tiles else 4 * P, B, _ptr(swork), _ptr(da), s), "s2l_segment_colsums")
             g.update(audio_backward(m, a32, da, s))
         self._ctx = None
         return g, {"d_audio_feat": da}

@@ -41,6 +41,8 @@ def timed(fn, it=5):
 
 tf = timed(lambda: lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()))
 tb = timed(lambda: lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(dxa), N, _stream()))
+tiles = torch.empty(Np // 256, 64, device=dev)
+tba = timed(lambda: lib.s2l_train_backward_bf16_tiles(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dzT), _ptr(tiles), N, _stream()))
 tw = timed(lambda: lib.s2l_wgrad_bf16(_ptr(dzT[3 * lay:]), _ptr(hT[2 * lay:]), 256, _ptr(work), _ptr(dw), _ptr(db), N, _stream()))
 if "--digest" in sys.argv:      # A/B aid: two builds with the same arithmetic print the same digests
     import hashlib
@@ -49,4 +51,4 @@ if "--digest" in sys.argv:      # A/B aid: two builds with the same arithmetic p
     print("digests: hT", hsh(hT), "masks", hsh(masks), "rgb", hsh(rgb), "dzT", hsh(dzT), "dxa", hsh(dxa), "dw", hsh(dw), "db", hsh(db))
 gb = 8 * lay * 2 / 1e9
 print(f"{os.environ.get('S2L_LIB', 'default'):28s} rows {N}: forward {tf:.3f} ms ({gb / tf * 1e3:.0f} GB/s of tiles written), "
-      f"backward {tb:.3f} ms, one wgrad {tw:.3f} ms ({2 * lay * 2 / 1e9 / tw * 1e3:.0f} GB/s read)")
+      f"backward {tb:.3f} ms (C++) / {tba:.3f} ms (assembly), one wgrad {tw:.3f} ms ({2 * lay * 2 / 1e9 / tw * 1e3:.0f} GB/s read)")
