@@ -325,3 +325,65 @@ def test_render_clip_bits_are_pinned(dev):
         with torch.no_grad():
             clip = m.render_clip(audio, torch.arange(frames, device=dev), 96, 96)
         assert hashlib.sha256(clip.cpu().numpy().tobytes()).hexdigest()[:16] == digest, frames
+
+
+# ------------------------------------------------------------------------------------------------ composite geometry (property)
+def test_composite_random_geometry_property(dev):
+    """SURVEY.md §4's property test for the paste + warp composite: random frame sizes, lip sizes, lip offsets (incl. boxes that
+    touch the frame border on every side), both pad modes, expand_lip_mask on / off, per-frame and per-clip constants, F = 1..3,
+    coordinates that leave [-1, 1] -- every valid geometry must equal the oracle (tf_nerf.py:320-386) and every geometry the
+    reference's F.pad / slicing cannot express must raise S2L_E_GEOMETRY instead of rendering something."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from speech2lip_amd import _abi
+
+    @st.composite
+    def cases(draw):
+        FH, FW = draw(st.integers(8, 70)), draw(st.integers(8, 90))
+        lh, lw = draw(st.integers(1, min(24, FH))), draw(st.integers(1, min(30, FW)))
+        edge = draw(st.sampled_from(["free", "left", "top", "right", "bottom", "corner"]))
+        x0 = {"left": 0, "right": FW - lw, "corner": FW - lw}.get(edge, draw(st.integers(-2, FW - lw + 2)))
+        y0 = {"top": 0, "bottom": FH - lh, "corner": FH - lh}.get(edge, draw(st.integers(-2, FH - lh + 2)))
+        return dict(FH=FH, FW=FW, lh=lh, lw=lw, x0=x0, y0=y0, may=draw(st.booleans()), expand=draw(st.booleans()),
+                    F=draw(st.integers(1, 3)), per_clip=draw(st.booleans()), seed=draw(st.integers(0, 2 ** 16)))
+
+    seen = {"ok": 0, "geometry": 0}
+
+    @settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(cases())
+    def run(c):
+        rng = np.random.default_rng(c["seed"])
+        FH, FW, lh, lw, x0, y0, F = c["FH"], c["FW"], c["lh"], c["lw"], c["x0"], c["y0"], c["F"]
+        path = "dataset/may_face_crop_lip" if c["may"] else "dataset/someone_else"
+        m = make_model(dev, lh, lw, path=path)
+        m.expand_lip_mask = c["expand"]
+        nc = 1 if c["per_clip"] else F
+        lip = T(rng.random((F, lh, lw, 3), dtype=np.float32))
+        face = T(rng.random((nc, FH, FW, 3), dtype=np.float32))
+        gt = T(rng.random((F, FH, FW, 3), dtype=np.float32))
+        mask = T(rng.random((nc, FH, FW, 3), dtype=np.float32))
+        coord = T((rng.random((F, FH, FW, 2), dtype=np.float32) * 2.6 - 1.3))
+        ox, oy = (x0, y0) if c["may"] else (x0 - 1, y0 - 1)
+        p = lw // 5
+        valid = ox >= 0 and oy >= 0 and ox + lw <= FW and oy + lh <= FH and (not c["expand"] or (x0 - p >= 0 and y0 - p >= 0))
+        args = (lip.to(dev), face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev))
+        if not valid:
+            with pytest.raises(_abi.S2LError, match="geometry|GEOMETRY"):
+                m.composite_clip(*args)
+            seen["geometry"] += 1
+            return
+        new, can = m.composite_clip(*args, want_canonical=True)
+        with torch.no_grad():
+            ref = [O.composite(lip[f:f + 1], face[min(f, nc - 1)][None], gt[f:f + 1], mask[min(f, nc - 1)][None], x0, y0, coord[f:f + 1],
+                               pad_mode=O.PAD_MODE_MAY if c["may"] else O.PAD_MODE_DEFAULT, expand_lip_mask=c["expand"]) for f in range(F)]
+        ref_new, ref_can = torch.cat([r[0] for r in ref]), torch.cat([r[1] for r in ref])
+        assert torch.equal(can.cpu(), ref_can), c                                   # merged_canonical is bit-exact
+        d = (new.cpu() - ref_new).abs().amax(-1)
+        # a coordinate within rounding of a pixel boundary of the expanded rectangle may fall on the other side: whole pixels, rarely
+        assert int((d > 1e-5).sum()) <= max(2, d.numel() // 2000), (c, int((d > 1e-5).sum()), float(d.max()))
+        if F >= 2 and c["per_clip"]:      # the clip fast path (span kernel) gives the one-pixel kernel's bits
+            one, _ = m.composite_clip(args[0][:1], args[1], args[2][:1], args[3], x0, y0, args[6][:1])
+            assert torch.equal(one[0], new[0]), c
+        seen["ok"] += 1
+
+    run()
+    assert seen["ok"] >= 25 and seen["geometry"] >= 3, seen

@@ -698,6 +698,53 @@ def test_bf16_forward_assembly_kernel_is_bit_identical(dev, h, w, B):
     assert lib.s2l_set_bf16_forward_kernel(2) == -2
 
 
+@pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3), (96, 96, 6)])
+def test_bf16_backward_assembly_kernel_is_bit_identical(dev, h, w, B):
+    """The generated-assembly backward (csrc/gen_bwd16_body.py, 64 rows per wave; s2l_train_backward_bf16_tiles) performs the dz
+    chain of the C++ kernel in its order: every dz image is the same bits -- one tile per workgroup, a partial last tile (12x20x3 =
+    2880 rows), several tiles per persistent workgroup (96x96x6 = 864 tiles).  Its audio gradient is the C++ kernel's per-row dxa
+    summed over each 256-row tile (one accumulator chain for both audio products, fixed-order tile sums: equal to rounding)."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    m, lib, x, N = _bf16_inputs(dev, h, w, B)
+    Np = int(lib.s2l_bf16_rows_padded(N))
+    hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+    rgb = torch.empty(N, 3, device=dev)
+    pb, pf = m.packed_weights_bf16(), m.packed_weights()
+    _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(_bf16_inputs.last[0]), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd")
+    drgb = (torch.randn(N, 3, generator=torch.Generator(device="cpu").manual_seed(5)) * 1e-3).to(dev)
+    dz_c = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+    dz_a = torch.full((8 * Np * 256,), 0x7fc0, dtype=torch.int16, device=dev)
+    dxa = torch.zeros(Np, 64, device=dev)
+    tiles = torch.full((Np // 256, 64), float("nan"), device=dev)
+    _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dz_c), _ptr(dxa), N, _stream()), "bwd")
+    _abi.check(lib.s2l_train_backward_bf16_tiles(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dz_a), _ptr(tiles), N, _stream()), "bwd asm")
+    torch.cuda.synchronize()
+    assert torch.equal(dz_c, dz_a)
+    assert float(dz_a.view(8, -1).float().abs().max()) > 0
+    ref = dxa.view(Np // 256, 256, 64).double().sum(1)
+    assert float((tiles.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the step picks the assembly kernel when a frame is a whole number of tiles: same gradients either way
+    if (4 * h * w) % 256 == 0:
+        step = s2l.LipTrainStep(m, h, w, precision="bf16")
+        win = T(W.synthetic_audio(B, seed=2).astype(np.float32)).to(dev)
+        tgt = torch.rand(B, h * w, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        res = {}
+        for kind in ("asm", "cpp"):
+            step.bf16_backward_kernel = kind
+            loss, g, aux = step.loss_and_grads(win, list(range(B)), tgt, [0.4] * B)
+            res[kind] = (float(loss), g, aux["d_audio_feat"])
+        assert res["asm"][0] == res["cpp"][0]
+        for k in res["asm"][1]:
+            a, b = res["asm"][1][k], res["cpp"][1][k]
+            if k.startswith("encoder_"):      # downstream of the audio gradient: equal to the rounding of a different summation order
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, k
+            else:
+                assert torch.equal(a, b), k
+        assert float((res["asm"][2] - res["cpp"][2]).abs().max()) <= 1e-5 * float(res["cpp"][2].abs().max())
+
+
 @pytest.mark.parametrize("h,w,B", [(16, 16, 1), (12, 20, 3)])
 def test_bf16_backward_matches_emulation(dev, h, w, B):
     """bf16 dz chain: every saved gradient tile and the audio-feature gradient against the step-wise CPU emulation."""

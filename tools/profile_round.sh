@@ -8,6 +8,8 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
+# never profile a stale library: rebuild if any source is newer than the .so (hipcc is on the box; ~10 s when it has to)
+(cd $R && python -c "from speech2lip_amd.build import build_library; build_library()" > $O/build.log 2>&1)
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 C="python $R/tools/bench_composite.py 256"
@@ -22,9 +24,12 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cstats -o
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cpmc_fetch -o s -- $C > $O/cpmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/cpmc_write -o s -- $C > $O/cpmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tpmc_fetch -o s -- python $R/tools/bench_train.py 64 bf16 > $O/tpmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tpmc_write -o s -- python $R/tools/bench_train.py 64 bf16 > $O/tpmc_write.log 2>&1
 ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \
+            "small_clips:tools/bench_small_clips.py" "config3_split:tools/bench_config3.py 1000 100 --split" \
             "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
             "stage1_full:tools/bench_train.py 8 bf16 --full"; do

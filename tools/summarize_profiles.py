@@ -56,7 +56,9 @@ if "FETCH_SIZE" in cv and "WRITE_SIZE" in cv:
                % (cv["FETCH_SIZE"] * 1024 * 2 + cv["WRITE_SIZE"] * 1024))
 for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench_train.py 64 bf16"),
                     ("train_fp32", "training step, fp32 parity mode: python tools/bench_train.py 64 fp32"),
-                    ("unet", "post-fusion U-Net, fp32 and the opt-in bf16 operand mode: python tools/bench_unet.py 16 --bf16"),
+                    ("unet", "post-fusion U-Net: exact fp32, split-bf16 (the inference speed mode) and plain bf16 operands: python tools/bench_unet.py 16 --bf16"),
+                    ("small_clips", "one frame per call / 16-frame clips (tile shapes of the renderer): python tools/bench_small_clips.py"),
+                    ("config3_split", "lip 128x128 + composite + U-Net in split-bf16 mode: python tools/bench_config3.py 1000 100 --split"),
                     ("syncnet", "sync loss (T3): python tools/bench_syncnet.py 16"),
                     ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
                     ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
@@ -72,6 +74,28 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
         out.append(open(p).read().strip() + "\n")
     for r in rows[:12]:
         out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
+# HBM traffic of the bf16 training step, per kernel (PMC passes of tools/bench_train.py 64 bf16; bytes per dispatch)
+tf, tw = {}, {}
+for d, dst in (("tpmc_fetch", tf), ("tpmc_write", tw)):
+    path = f"{src}/{d}/s_counter_collection.csv"
+    if os.path.exists(path):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                agg[r["Kernel_Name"].split("(")[0]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, dd in agg.items():
+            dst[k] = (sum(dd.values()) / len(dd) * 1024, len(dd))
+if tf or tw:
+    out.append("\n## bf16 training step: HBM bytes per dispatch (2*FETCH_SIZE | WRITE_SIZE; separate PMC passes of tools/bench_train.py 64 bf16)\n")
+    steps = max(1, min((n for _, n in tf.values()), default=1))
+    total = 0.0
+    for k in sorted(set(tf) | set(tw), key=lambda k: -(2 * tf.get(k, (0, 0))[0] + tw.get(k, (0, 0))[0]) * max(tf.get(k, (0, 1))[1], 1)):
+        fb, n = tf.get(k, (0.0, 0))
+        wb, n2 = tw.get(k, (0.0, 0))
+        n = max(n, n2)
+        if 2 * fb + wb < 1e6:
+            continue
+        out.append("%-70s dispatches %4d  read %9.3f GB  written %9.3f GB\n" % (k[:70], n, 2 * fb / 1e9, wb / 1e9))
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
 print("".join(out))
