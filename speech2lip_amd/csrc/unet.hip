@@ -519,6 +519,9 @@ static UpWin no_window(int h, int w, int Ho, int Wo) { return UpWin{h, w, Ho, Wo
 // pixels of an N-block), converted from the fp32 activations on the way in, and the chunk's weights in A-operand order
 // (36.9 KB).  Per tap and k-step a wave issues 2 + 2 ds_read_b128 for 4 MFMAs of 32x32x16; wave w owns tile rows 4w..4w+3 as
 // two N-blocks of 2 rows x 16 pixels.  16x fewer matrix-pipe cycles than the fp32 form: the kernel is bound by staging and HBM.
+#ifndef S2L_UEXP
+#define S2L_UEXP 0   // tools/ubench experiments on conv3x3_bf16_kernel only (results wrong): 1 no MFMAs, 2 no activation loads, 4 no weight loads, 8 no LDS commits, 16 no epilogue stores
+#endif
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef short bf8v __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -532,22 +535,46 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ f16v mfma32_bf16(u4v a, u4v b, f16v c) {
+#if S2L_UEXP & 1
+  c[0] += __uint_as_float(a[0] ^ b[0]);      // keeps the operand reads alive
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+#endif
 }
 
 // SPLIT: the split-bf16 form (unet_w16x3_off): 16 input channels per chunk, a halo pixel's 80 bytes hold [hi 16 ch | lo 16 ch | pad],
 // the chunk's weights [tap][hi, lo][mb][lane][8] -- the same LDS shapes and the same eight ds_read_b128 per tap, but twelve MFMAs:
 // acc += A_hi B_hi + A_hi B_lo + A_lo B_hi (the lo x lo term is below 2^-17 of the product and is dropped).
-template <bool FUSE_OUT, bool SPLIT = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds_in[18 * 18 * kPix16];
-  __shared__ __attribute__((aligned(16))) uint16_t lds_w[kChunk16Halves];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// WAVES = 8 (the split form's default): ONE workgroup of 512 threads per CU owns a 32 x 16-pixel tile (wave w: rows 4 w .. 4 w + 3,
+// as before); the chunk's weights go from global memory straight to LDS (LDS-DMA, no registers, no ds_write pass) into one of TWO
+// buffers, a whole chunk ahead of their use, and are staged once per eight waves instead of once per four.  (Ablations of the
+// 4-wave form, tools/ubench notes in DESIGN 4.6: loads + commits were 2.4 of the 7.0 ms of convolution time in a 16-frame forward
+// -- two workgroups per CU do not hide each other's ~2 us of load latency.)
+constexpr int kBf16WideLds = 34 * 18 * kPix16 * 2 + 2 * kChunk16Halves * 2;      // 48 960 + 73 728 bytes
+template <bool FUSE_OUT, bool SPLIT = false, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_kernel(ConvArgs a) {
+  constexpr int kThreads = 64 * WAVES, kTileH = 4 * WAVES, kHaloH = kTileH + 2;
+  constexpr bool kDma = WAVES == 8;
+  static_assert(WAVES == 4 || (WAVES == 8 && SPLIT), "the 8-wave form exists for the split operands");
+  uint16_t* lds_in;
+  uint16_t* lds_w;        // (kDma: buffer 0; buffer 1 follows it)
+  if constexpr (kDma) {
+    extern __shared__ __attribute__((aligned(16))) char conv16_smem[];
+    lds_in = reinterpret_cast<uint16_t*>(conv16_smem);
+    lds_w = lds_in + kHaloH * 18 * kPix16;
+  } else {
+    __shared__ __attribute__((aligned(16))) uint16_t s_in[18 * 18 * kPix16];
+    __shared__ __attribute__((aligned(16))) uint16_t s_w[kChunk16Halves];
+    lds_in = s_in;
+    lds_w = s_w;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, hh = lane >> 5;
   const int tx = blockIdx.x, ty = blockIdx.y;
   const int ct = blockIdx.z % a.n_ct;
   const int64_t frame = blockIdx.z / a.n_ct;
-  const int x0 = tx * 16, y0 = ty * 16;
+  const int x0 = tx * 16, y0 = ty * kTileH;
   const int cin = a.CA + a.CB;
   constexpr int kCC = SPLIT ? 16 : 32;                  // input channels per chunk
   const int nchunks = cin / kCC;
@@ -563,11 +590,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = a.bias ? a.bias[ct * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
 
   constexpr int kQ = kCC / 4;                           // f4 (4 fp32 channels) elements per halo pixel
-  constexpr int kInQuads = 18 * 18 * kQ;
-  constexpr int kInPer = (kInQuads + 255) / 256;        // 11 (SPLIT: 6; the last pass is partial)
-  constexpr int kWPer = kChunk16Halves / 8 / 256;       // 9
+  constexpr int kInQuads = kHaloH * 18 * kQ;
+  constexpr int kInPer = (kInQuads + kThreads - 1) / kThreads;      // 11 (SPLIT: 6, 8 waves: 5; the last pass is partial)
+  constexpr int kWPer = kDma ? 1 : kChunk16Halves / 8 / 256;         // 9
   f4 pin[kInPer];
   u4v pw[kWPer];
+  // 8-wave form: the chunk's 36 KiB of weights as 36 LDS-DMA instructions of 1 KiB (lane l moves bytes [16 l, 16 l + 16)), wave w
+  // issues pieces w, w + 8, ...; they land while the current chunk computes and are waited for (vmcnt) before the publishing barrier
+  auto dma_weights = [&](int cc) {
+    if constexpr (kDma) {
+      const char* wsrc = reinterpret_cast<const char*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
+      char* wdst = reinterpret_cast<char*>(lds_w + (cc & 1) * kChunk16Halves);
+      for (int p = wave; p < kChunk16Halves * 2 / 1024; p += WAVES)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(wsrc + p * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) uint32_t*)(wdst + p * 1024), 16, 0, 0);
+    }
+  };
   auto fetch = [&](int cc) {
     const bool fromA = cc * kCC < a.CA;
     const float* src = fromA ? inA : inB;
@@ -575,21 +613,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
     const int coff = fromA ? cc * kCC : cc * kCC - a.CA;
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) {
-      const int i = threadIdx.x + k * 256;
+      const int i = threadIdx.x + k * kThreads;
       const int pi = i / kQ, c4 = i % kQ;
       const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
       pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
-      if (i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+      if (!(S2L_UEXP & 2) && i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
         pin[k] = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * c4);
     }
-    const u4v* wsrc = reinterpret_cast<const u4v*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
+    if constexpr (kDma) {
+      dma_weights(cc);
+    } else {
+      const u4v* wsrc = reinterpret_cast<const u4v*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
 #pragma unroll
-    for (int k = 0; k < kWPer; ++k) pw[k] = wsrc[threadIdx.x + k * 256];
+      for (int k = 0; k < kWPer; ++k) pw[k] = (S2L_UEXP & 4) ? u4v{(uint32_t)cc, 0u, 0u, 0u} : wsrc[threadIdx.x + k * 256];
+    }
   };
   auto commit = [&]() {
+    if (S2L_UEXP & 8) return;
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) {
-      const int i = threadIdx.x + k * 256;
+      const int i = threadIdx.x + k * kThreads;
       if (i < kInQuads) {
         uint2 h;
         h.x = pack_bf16x2(pin[k][0], pin[k][1]);
@@ -603,43 +646,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
         }
       }
     }
+    if constexpr (kDma) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's weight pieces of the next chunk have landed in the other buffer
+    } else {
 #pragma unroll
-    for (int k = 0; k < kWPer; ++k) reinterpret_cast<u4v*>(lds_w)[threadIdx.x + k * 256] = pw[k];
+      for (int k = 0; k < kWPer; ++k) reinterpret_cast<u4v*>(lds_w)[threadIdx.x + k * 256] = pw[k];
+    }
   };
   // halo pixel of this lane's column in N-block nb, before the tap offset
   const int pbase = (4 * wave + (n >> 4)) * 18 + (n & 15);
+#ifdef S2L_EXP_TRACE
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define PH(k) do { const long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define PH(k) do { } while (0)
+#endif
+  CONV_TRACE(0);
   fetch(0);
   commit();
   __syncthreads();
+  PH(0);
   for (int cc = 0; cc < nchunks; ++cc) {
-    if (cc + 1 < nchunks) fetch(cc + 1);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3, dx = t % 3;
-      if (SPLIT) {
-        u4v A[2][2], B[2][2];   // [part: hi, lo][block]
+    // 8-wave form: the two waves of a SIMD are released by the same barrier; if both issued the next chunk's loads first (~1.5 k
+    // cycles of address arithmetic and texture-path issue, tools/trace_conv16.py) the matrix pipe would idle that long.  Waves
+    // 0..3 fetch before their MFMAs, waves 4..7 after their fifth tap: one of the two always has matrix work.
+    if (cc + 1 < nchunks && (!kDma || wave < 4)) fetch(cc + 1);
+    PH(1);
+    const uint16_t* wcur = kDma ? lds_w + (cc & 1) * kChunk16Halves : lds_w;
+    if constexpr (SPLIT) {
+      // the operands of tap t + 1 are read while the twelve MFMAs of tap t issue (two register sets): the LDS latency, which
+      // the compiler's own schedule exposed 22 times per chunk (reads, lgkmcnt(0), a few MFMAs), hides behind matrix work
+      u4v A[2][2][2], B[2][2][2];   // [set][part: hi, lo][block]
+      auto load_tap = [&](int t, int set) {
+        const int dy = t / 3, dx = t % 3;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb) A[pt][mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + pt) * 2 + mb) * 64 + lane];
+          for (int mb = 0; mb < 2; ++mb) A[set][pt][mb] = reinterpret_cast<const u4v*>(wcur)[((t * 2 + pt) * 2 + mb) * 64 + lane];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            B[pt][nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * pt + 8 * hh);
+            B[set][pt][nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * pt + 8 * hh);
         }
+      };
+      load_tap(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < 9) load_tap(t + 1, cur ^ 1);
+        if (kDma && t == 5 && wave >= 4 && cc + 1 < nchunks) fetch(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
         // smallest terms first: the two cross terms, then hi x hi
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[1][mb], B[0][nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][1][mb], B[cur][0][nb], acc[mb][nb]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[0][mb], B[1][nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][0][mb], B[cur][1][nb], acc[mb][nb]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[0][mb], B[0][nb], acc[mb][nb]);
-      } else {
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][0][mb], B[cur][0][nb], acc[mb][nb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t % 3;
+      {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u4v A[2], B[2];
@@ -655,12 +730,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
         }
       }
     }
+    }
+    PH(2);
     __syncthreads();            // everyone is done reading chunk cc
+    PH(3);
     if (cc + 1 < nchunks) {
       commit();
+      PH(4);
       __syncthreads();
+      PH(5);
     }
   }
+#ifdef S2L_EXP_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    long long* tt = a.trace + (blockIdx.x + gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z)) * 24;
+    for (int k = 0; k < 6; ++k) tt[2 + k] = tph[k];
+    tt[1] = nchunks;
+  }
+#endif
 
   // epilogue: D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel (row 4 wave + 2 nb + (n >> 4), col n & 15)
   const int gx = x0 + (n & 15);
@@ -721,6 +808,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvArgs a) {
         }
       }
   }
+  CONV_TRACE(20);
 }
 
 // ---- the forward convolution with its body as one fixed-register assembly text (csrc/gen_conv_body.py: persistent, one wave
@@ -813,8 +901,16 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
-  if (out3 && a.w16 && split) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, true>), grid, dim3(256), 0, st, a);
-  else if (a.w16 && split) hipLaunchKernelGGL((conv3x3_bf16_kernel<false, true>), grid, dim3(256), 0, st, a);
+  if (a.w16 && split) {      // the 8-wave form: 32 x 16-pixel tiles, > 64 KiB of dynamic LDS (opt-in per device)
+    const dim3 wgrid(a.tiles_x, (H + 31) / 32, (unsigned)gz);
+    static LdsOptIn wflags[2];
+    int dev = 0, n_cu = 0;
+    int rc = current_device_cus(&dev, &n_cu);
+    if (rc) return rc;
+    void (*const kern)(ConvArgs) = out3 ? conv3x3_bf16_kernel<true, true, 8> : conv3x3_bf16_kernel<false, true, 8>;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kBf16WideLds, wflags[out3 ? 1 : 0], dev))) return rc;
+    hipLaunchKernelGGL(kern, wgrid, dim3(512), kBf16WideLds, st, a);
+  }
   else if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
