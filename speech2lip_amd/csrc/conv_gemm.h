@@ -28,7 +28,7 @@ inline Shape out_shape(const LayerSpec& s, Shape in) {
 }
 
 
-constexpr int64_t kPartialFloats = 1 << 21;   // split-K scratch a caller provides per launch
+constexpr int64_t kPartialFloats = 1 << 23;   // split-K scratch a caller provides per launch (32 MiB)
 
 // ---- packing: fold BatchNorm (eval; gamma == nullptr: a plain convolution), lay out for the implicit GEMM ----------------------------------------------------
 // forward:  dst[(tap*cinp + ci)*RP + co] = w[co][ci][ky][kx] * g[co]/sqrt(var[co]+eps)
@@ -73,10 +73,14 @@ constexpr int kLd = 80;  // LDS row stride in floats: 80 % 32 == 16 keeps the fo
 
 __device__ static __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// K advances in GROUPS of up to four 16-wide chunks per barrier pair (round 3): with one chunk per pair a wave issued 16 MFMAs
+// (512 cycles) between two barriers and a global-load wait, and the kernel sat at 0.20 of the fp32-MFMA peak on the lip-sync
+// expert; the accumulation order (chunk by chunk, k ascending) is unchanged, so the results are the same bits.
+constexpr int kGroup = 4;
 template <bool DGRAD>
 __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
-  __shared__ float As[16 * kLd];
-  __shared__ float Bs[16 * kLd];
+  __shared__ float As[16 * kGroup * kLd];
+  __shared__ float Bs[16 * kGroup * kLd];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
   const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
@@ -101,7 +105,7 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  auto fetch = [&](int chunk, f4& av, f4& bv) {
+  auto fetch1 = [&](int chunk, f4& av, f4& bv) {
     av = *reinterpret_cast<const f4*>(a.w + ((int64_t)chunk * 16 + ak) * a.RP + row0 + ar4 * 4);
     const int kidx0 = chunk * 16;
     const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp + 4 * cq;
@@ -129,27 +133,53 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       }
     }
   };
+  f4 av[kGroup], bv[kGroup];
+  auto fetch = [&](int chunk) {      // chunks chunk .. chunk + kGroup - 1 that exist (the MFMA loop stops at the last one)
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g)
+      if (chunk + g < chunk_hi) fetch1(chunk + g, av[g], bv[g]);
+  };
 
-  f4 av, bv;
-  if (chunk_lo < chunk_hi) fetch(chunk_lo, av, bv);
-  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-    __syncthreads();  // the previous chunk's operand reads are done
-    *reinterpret_cast<f4*>(&As[ak * kLd + ar4 * 4]) = av;
+  if (chunk_lo < chunk_hi) fetch(chunk_lo);
+  for (int chunk = chunk_lo; chunk < chunk_hi; chunk += kGroup) {
+    const int ng = min(kGroup, chunk_hi - chunk);      // (uniform over the workgroup)
+    __syncthreads();  // the previous group's operand reads are done
 #pragma unroll
-    for (int j = 0; j < 4; ++j) Bs[(4 * cq + j) * kLd + pl] = bv[j];
+    for (int g = 0; g < kGroup; ++g) {
+      if (g < ng) {
+        *reinterpret_cast<f4*>(&As[(16 * g + ak) * kLd + ar4 * 4]) = av[g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[(16 * g + 4 * cq + j) * kLd + pl] = bv[g][j];
+      }
+    }
     __syncthreads();
-    if (chunk + 1 < chunk_hi) fetch(chunk + 1, av, bv);
+    if (chunk + kGroup < chunk_hi) fetch(chunk + kGroup);
+    // the 16 operand values of chunk g + 1 are read from LDS while the 16 MFMAs of chunk g issue (two register sets): with
+    // "4 reads, wait, 4 MFMAs" per k-step a chunk took ~1 400 cycles for 512 cycles of matrix work (one wave per SIMD per workgroup)
+    float fa[2][4][2], fb[2][4][2];
+    auto lds_operands = [&](int g, int set) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float fa[2], fb[2];
+      for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = As[(4 * kk + q) * kLd + 32 * wm + 16 * i + l16];
+        for (int i = 0; i < 2; ++i) fa[set][kk][i] = As[(16 * g + 4 * kk + q) * kLd + 32 * wm + 16 * i + l16];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = Bs[(4 * kk + q) * kLd + 32 * wn + 16 * j + l16];
+        for (int j = 0; j < 2; ++j) fb[set][kk][j] = Bs[(16 * g + 4 * kk + q) * kLd + 32 * wn + 16 * j + l16];
+      }
+    };
+    lds_operands(0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < kGroup; ++g) {
+      if (g < ng) {
+        if (g + 1 < ng) lds_operands(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[g & 1][kk][i], fb[g & 1][kk][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -224,9 +254,16 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   a.kcp = ceil_to(a.kc, 16);
   a.nchunks = a.kh * a.kw * a.kcp / 16;
   const int tiles = ((a.ncols + 63) / 64) * (a.RP / 64);
+  // One 64 x 64 tile walks its K range alone, one workgroup of four waves: a CU that holds a single such workgroup streams its
+  // operands at ~12 GB/s (dependent fetch -> commit -> MFMA rounds), so a launch of ~150-300 tiles ran at a quarter of the MFMA
+  // rate however its inner loop was scheduled (round 3 measurements: grouping chunks, pipelining the LDS reads: +-0).  What it lacks
+  // is workgroups in flight: K is split until ~4 workgroups per CU exist (the LDS and register budget of 4), each with >= 8 chunks.
   int splits = 1;
-  if (tiles < 128 && a.nchunks >= 16) {
-    splits = min(min(256 / tiles, a.nchunks / 8), 64);
+  if (tiles < 1024 && a.nchunks >= 16) {
+    // few tiles (deep layers, small batches): fill the chip once, >= 8 chunks each; 128..1023 tiles: towards 4 per CU, but only
+    // while a workgroup keeps >= 32 chunks (below that the partial-sum pass costs more than the parallelism returns)
+    splits = tiles < 128 ? min(min(256 / tiles, a.nchunks / 8), 64) : min((1024 + tiles - 1) / tiles, a.nchunks / 32);
+    splits = max(splits, 1);
     while (splits > 1 && (int64_t)splits * a.ncols * a.RP > kPartialFloats) --splits;
   }
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
