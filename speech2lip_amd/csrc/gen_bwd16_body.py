@@ -161,7 +161,7 @@ class Body:
                     skip = self.label("nostore")
                     if guarded:
                         it += [f"s_cmp_eq_u32 {s('PENDOK')}, 0", f"s_cbranch_scc1 {skip}"]
-                    it.append(f"global_store_dwordx4 v{V_LANE16B if nb else V_LANE16}, {src}, {s2('PEND')} offset:{which * 2048 + half * 1024}")
+                    it.append(f"global_store_dwordx4 v{V_LANE16B if nb else V_LANE16}, {src}, {s2('PEND')} offset:{which * 2048 + half * 1024}" + os.environ.get("S2L_BWD_STORE_MOD", " nt"))
                     if guarded:
                         it.append(f"{skip}:")
                     items.append(it)

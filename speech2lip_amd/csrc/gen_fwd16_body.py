@@ -17,7 +17,10 @@ fwd_bf16_kernel: activation images, mask dwords and rgb are bit-identical.
     prefetched for the next tile during layer 6;
   * epilogue per pair: v_cvt_pk_bf16_f32, v_pk_max_i16 (ReLU), v_pk_min_u16 + v_lshl_or_b32 (mask bit): 4 VALU per two values;
   * the images of a stage are stored during the NEXT stage: four stores behind MFMAs of its k-loop, four between the pairs of its
-    epilogue (16 B per lane and clock is all the store path takes).
+    epilogue (16 B per lane and clock is all the store path takes).  The stores are non-temporal (`nt`) since round 3: every store
+    instruction writes 1 KiB of contiguous memory that nothing reads before the weight-gradient kernels stream it, 9.7 GB later
+    (forward 3.06 -> 2.98 ms, backward 2.59 -> 2.48 ms; with round 2's first image layout -- a lane's two 16-byte halves in
+    different instructions, meeting only in L2 -- the same modifier had cost a factor of two).
 
 State: bit-identical; 3.04 ms against the C++ kernel's 3.3-3.4 ms.  S2L_FWD_EXP builds ablate stores / epilogue /
 MFMAs / DMA / barrier, S2L_FWD_TRACE=1 builds time the phases of every stage (tools/trace_fwd16.py).
@@ -222,7 +225,7 @@ class Body:
                     if guarded:
                         it += [f"s_cmp_eq_u32 {s('PENDOK')}, 0", f"s_cbranch_scc1 {skip}"]
                     if not EXP & 1:
-                        it.append(f"global_store_dwordx4 v{V_LANE16B if nb else V_LANE16}, {src}, {s2('PEND')} offset:{which * 2048 + half * 1024}" + os.environ.get("S2L_FWD_STORE_MOD", ""))
+                        it.append(f"global_store_dwordx4 v{V_LANE16B if nb else V_LANE16}, {src}, {s2('PEND')} offset:{which * 2048 + half * 1024}" + os.environ.get("S2L_FWD_STORE_MOD", " nt"))
                     if guarded:
                         it.append(f"{skip}:")
                     items.append(it)

@@ -619,10 +619,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const uint16_t* __re
   auto gload = [&](int tile) {
     const u4* pa = reinterpret_cast<const u4*>(dzT + (int64_t)tile * 64 * 256);
     const u4* pb = reinterpret_cast<const u4*>(inT + (int64_t)tile * 64 * KB);
+    // both images are streamed exactly once per launch: non-temporal loads keep them out of the caches' retention policy
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sa[k] = pa[mem_of(tid + 256 * k)];
+    for (int k = 0; k < 8; ++k) sa[k] = __builtin_nontemporal_load(pa + mem_of(tid + 256 * k));
 #pragma unroll
-    for (int k = 0; k < C::kBPieces; ++k) sb[k] = pb[mem_of(tid + 256 * k)];
+    for (int k = 0; k < C::kBPieces; ++k) sb[k] = __builtin_nontemporal_load(pb + mem_of(tid + 256 * k));
   };
   auto lstore = [&](int buf) {
     char* base = smem + buf * C::kBufBytes;
