@@ -378,8 +378,8 @@ static int rows_grid(int ntiles, const void* kernel, LdsOptIn& flags, int* grid)
   return 0;
 }
 
-int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st) {
-  constexpr int G = 2;   // x operands (32 registers per group) live beside both 64-register arrays
+template <int G>
+static int launch_rows_fwd_g(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st) {
   const int64_t ntiles = (n_rows + G * 64 - 1) / (G * 64);
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   RowsFwdArgs a{packed, x, out, hsave, n_rows, (int)ntiles};
@@ -389,6 +389,17 @@ int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsav
   if (rc) return rc;
   hipLaunchKernelGGL((rows_fwd_kernel<G>), dim3(grid), dim3(256), kLdsBytes, st, a);
   return (int)hipGetLastError();
+}
+
+int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st) {
+  // G = 2: 128-row tiles (x operands, 32 registers per group, live beside both 64-register arrays).  One frame of the reference's
+  // per-frame call (inference.py:158: 9 216 rows at 96x96) is only 72 such tiles for 256 CUs: when the 128-row tiles do not fill
+  // the chip, 64-row tiles (G = 1: half the MFMAs per weight slab, twice the workgroups) finish sooner.  Same per-row arithmetic.
+  int dev = 0, n_cu = 0;
+  const int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  if ((n_rows + 127) / 128 < n_cu) return launch_rows_fwd_g<1>(packed, x, out, hsave, n_rows, st);
+  return launch_rows_fwd_g<2>(packed, x, out, hsave, n_rows, st);
 }
 
 int launch_rows_bwd(const float* packed, const float* drgb, const float* hsave, float* dzsave, float* dxa, int64_t n_rows,
