@@ -330,7 +330,9 @@ int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, cons
  * s2l_unet_train_backward: d_out [F,H,W,3] -> d_x [F,H,W,3] (or NULL) and grads [s2l_unet_grad_floats()]: for each of the ten 3x3
  *   layers in execution order conv.weight [cout,cin,3,3], bn.weight [cout], bn.bias [cout]; then outc.conv.weight [3,64],
  *   outc.conv.bias [3].  work: s2l_unet_train_work_floats(H, W, F) floats.  Weight gradients are split-K MFMA GEMMs over the
- *   pixels, reduced in a fixed order. */
+ *   pixels, reduced in a fixed order.  grads == NULL (with d_x != NULL): a FROZEN net that still runs train-mode BatchNorm (the
+ *   reference after it > 100000, where Trainer.train_step's model.train() undoes train.py:195's .eval()): only d_x, the weight-
+ *   gradient kernels are not launched. */
 int64_t s2l_unet_train_saved_floats(int height, int width, int64_t n_frames);
 int64_t s2l_unet_train_work_floats(int height, int width, int64_t n_frames);
 int64_t s2l_unet_grad_floats(void);

@@ -1882,7 +1882,8 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
                                        const float* d_out, float* work, float* d_x, float* grads, int height, int width,
                                        int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
-  if (!packed_raw || !x || !saved || !d_out || !work || !grads) return S2L_E_NULL;
+  if (!packed_raw || !x || !saved || !d_out || !work) return S2L_E_NULL;
+  if (!grads && !d_x) return S2L_E_NULL;      // nothing to compute
   if (misaligned16(packed_raw) || misaligned16(saved) || misaligned16(work)) return S2L_E_ALIGN;
   UnetTensors t;
   int rc = unet_table(tensors_host, t);
@@ -1891,6 +1892,10 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
   const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
   const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
   const int64_t pl[3] = {p1, p2, p4};
+  // grads == NULL: a FROZEN net in train-mode BatchNorm (the reference's loop after it > 100000: Trainer.train_step's model.train()
+  // undoes the .eval() of train.py:195): only the input gradient is wanted -- the weight-gradient GEMMs (a third of the pass) are
+  // skipped; the BatchNorm backward still needs its two per-channel sums, which land in scratch behind the reduction partials
+  const bool want_params = grads != nullptr;
   const int hh[3] = {H, H2, H4}, ww[3] = {W, W2, W4};
   const TrainBufs b = train_bufs(const_cast<float*>(saved), p1, p2, p4);
   float* zA = work;              float* zB = zA + p1 * 64;      float* gcat8 = zB + p1 * 64;                      // @H
@@ -1912,11 +1917,12 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
     const int64_t per = (n + kStatBlocks - 1) / kStatBlocks;
     const int nb = (int)((n + per - 1) / per);
     const float* stl = b.st + l * 512;
-    float* g = grads + grad_off(l);
-    float* dgamma = g + (int64_t)C * cin * 9;
+    float* g = want_params ? grads + grad_off(l) : nullptr;
+    float* dgamma = want_params ? g + (int64_t)C * cin * 9 : sums + 512;      // (sums: 2 x 128 means; + 512: 2 x 128 floats of scratch)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(n * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, n * C / 4);
+    if (!want_params) return;
     if (l == 0) {
       const int64_t perw = (p1 + 1023) / 1024;
       const int nbw = (int)((p1 + perw - 1) / perw);
@@ -1943,7 +1949,7 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
   };
 
   // output convolution: gy9 = outc^T d_out * (a9 > 0); d outc.weight / bias
-  {
+  if (want_params) {
     const int64_t perw = (p1 + 2047) / 2048;
     const int nbw = (int)((p1 + perw - 1) / perw);
     hipLaunchKernelGGL(outc_wgrad_kernel, dim3(nbw), dim3(256), 0, st, d_out, b.act[9], wpart, p1, perw);

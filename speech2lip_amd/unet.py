@@ -212,9 +212,12 @@ class SimpleUnetLight(nn.Module):
             self._packed16x3 = self._packed16x3_key = None
         return out, (raw, x, saved, (F_, H, W))
 
-    def backward_train(self, ctx, d_out: torch.Tensor, want_input_grad: bool = True):
+    def backward_train(self, ctx, d_out: torch.Tensor, want_input_grad: bool = True, want_param_grads: bool = True):
         """d loss / d out [F,H,W,3] -> (d loss / d x or None, {state-dict name: gradient}) for every conv / BatchNorm / outc
-        parameter (what loss.backward() leaves in .grad while the post-fusion net trains)."""
+        parameter (what loss.backward() leaves in .grad while the post-fusion net trains).  want_param_grads=False (a frozen
+        net in train-mode BatchNorm): the weight-gradient kernels are not launched and the dict is empty."""
+        if not (want_input_grad or want_param_grads):
+            raise ValueError("backward_train: nothing to compute")
         lib = _abi.load()
         raw, x, saved, (F_, H, W) = ctx
         dev = x.device
@@ -224,12 +227,14 @@ class SimpleUnetLight(nn.Module):
         tensors = self._tensors()
         table = self._table(tensors)
         dx = torch.empty_like(d) if want_input_grad else None
-        flat = torch.empty(int(lib.s2l_unet_grad_floats()), dtype=torch.float32, device=dev)
+        flat = torch.empty(int(lib.s2l_unet_grad_floats()), dtype=torch.float32, device=dev) if want_param_grads else None
         work = torch.empty(int(lib.s2l_unet_train_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(dev):
             _abi.check(lib.s2l_unet_train_backward(p(raw), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_,
                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_train_backward")
+        if not want_param_grads:
+            return dx, {}
         params = dict(self.named_parameters())
         grads, off = {}, 0
         for name in self.grad_names():
@@ -314,7 +319,7 @@ class SimpleUnetLight(nn.Module):
             return self.backward_input(ctx, d_out)
         dxs = []
         for f, c in enumerate(ctx[1]):
-            dx, grads = self.backward_train(c, d_out[f:f + 1], want_input_grad=True)
+            dx, grads = self.backward_train(c, d_out[f:f + 1], want_input_grad=True, want_param_grads=param_grads is not None)
             dxs.append(dx)
             if param_grads is not None:
                 for k, v in grads.items():

@@ -387,3 +387,43 @@ def test_composite_random_geometry_property(dev):
 
     run()
     assert seen["ok"] >= 25 and seen["geometry"] >= 3, seen
+
+
+def test_render_and_crop_resize_random_sizes_property(sd, dev):
+    """SURVEY.md §4's property tests, the remaining two axes: (H, W, F) of the lip crop -- any size, any clip length, any tile
+    shape the renderer picks -- against the oracle on sampled frames, and random crop boxes (incl. boxes that leave the frame, which
+    python slicing clips, training.py:541-543) of crop + Resize([96,96]) and its adjoint against autograd through the oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from speech2lip_amd import autograd as A
+
+    @settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(1, 40), st.integers(1, 40), st.integers(1, 30), st.integers(0, 2 ** 16))
+    def render(h, w, F, seed):
+        m = make_model(dev, h, w)
+        win = T(W.synthetic_audio(F, seed=seed % 97).astype(np.float32))
+        idx = [seed % 1000 + 3 * k for k in range(F)]
+        out = m.render_clip(win.to(dev), idx, h, w)
+        assert out.shape == (F, h, w, 3)
+        with torch.no_grad():
+            for k in sorted({0, F // 2, F - 1}):
+                close(out[k], O.render_clip(sd, win[k:k + 1], [idx[k]], h, w)[0])
+
+    @settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(4, 70), st.integers(4, 70), st.integers(0, 2 ** 16), st.sampled_from([(96, 96), (17, 23), (5, 4)]))
+    def resize(H, Wd, seed, size):
+        rng = np.random.default_rng(seed)
+        x0, y0 = int(rng.integers(0, Wd - 1)), int(rng.integers(0, H - 1))
+        x2, y2 = int(rng.integers(x0 + 1, Wd + 12)), int(rng.integers(y0 + 1, H + 12))        # may leave the frame: clipped
+        x = T(rng.random((2, H, Wd, 3), dtype=np.float32))
+        x_o = x.clone().requires_grad_(True)
+        ref = O.crop_resize(x_o, (x0, y0, x2, y2), size)
+        d = T(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        (ref * d).sum().backward()
+        x_d = x.to(dev).requires_grad_(True)
+        got = A.crop_resize(x_d, (x0, y0, x2, y2), size, 0)
+        close(got, ref.detach(), 2e-7, 1e-6)
+        (got * d.to(dev)).sum().backward()
+        assert float((x_d.grad.cpu() - x_o.grad).abs().max()) <= 3e-6 * max(1.0, float(x_o.grad.abs().max()))
+
+    render()
+    resize()

@@ -490,6 +490,11 @@ def test_unet_train_mode_vs_oracle_sizes(dev, F, fh, fw):
         a, b = gk.cpu().double().flatten(), ref.double().flatten()
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         assert rel <= 5e-3, (name, rel)
+    # a frozen net in train-mode BatchNorm: the input gradient alone (grads == NULL in the C ABI), the same bits, no dict
+    dx_only, none = u.backward_train(ctx, d.to(dev), want_param_grads=False)
+    assert none == {} and torch.equal(dx_only, dx)
+    with pytest.raises(ValueError):
+        u.backward_train(ctx, d.to(dev), want_input_grad=False, want_param_grads=False)
 
 
 def test_stage_one_step_before_the_unet_is_fixed_autograd(golden, dev):

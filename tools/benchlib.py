@@ -277,7 +277,7 @@ def sync_batch(dev, S, T=5, FH=500, FW=500, h=96, w=96, x0=202, y0=316, seed=11)
                 canonical_face_bbox=[110, 90, 390, 420, 1.0], mel=mel, rgb_window_neg=neg)
 
 
-def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
+def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=False):
     """BASELINE config 5 as named -- MLP forward + backward WITH the lipsync_expert loss: B main frames (MSE) of which the
     first S carry a 5-frame sync window (5 S more renders -> composite -> frozen U-Net @500x500 -> crop/resize -> SyncNet x2 ->
     BCE, and all of it back to the MLP), bf16 MLP kernels, Adam.  FLOPs counted: the MLP's as-written 3 x 4 x 2 x 644,864 per
@@ -286,7 +286,13 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
     reported separately."""
     H = Wd = 96
     m = make_model(dev, H, Wd, unet=True, train=True)
-    m.post_fusion_unet.eval()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    # eval: running statistics (train.py:195), crop window + bf16 operands; train: the mode the reference's loop really leaves the
+    # frozen net in (Trainer.train_step's model.train(), training.py:150; golden G16): batch statistics per one-frame call,
+    # whole 500x500 frames, exact fp32
+    if not unet_train_mode:
+        m.post_fusion_unet.eval()
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
@@ -311,8 +317,12 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3):
     mlp = train_flops(B + 5 * S, H * Wd)
     wx0, wy0, wx1, wy1 = step.chain.unet_window(sync["canonical_face_bbox"], 500, 500) if S else (0, 0, 500, 500)
     unet = 2 * 157.6e9 * 5 * S * ((wx1 - wx0) * (wy1 - wy0) / 250000.0)     # the U-Net runs on the face box + its dependency radius
+    if unet_train_mode:
+        wx0, wy0, wx1, wy1 = 0, 0, 500, 500
+        unet = 2 * 157.6e9 * 5 * S
     return {"config": f"stage-1 step, {B} main frames 96x96 + sync loss on {S} samples ({5 * S} window frames through composite + U-Net "
-                      f"@500x500 + SyncNet), {precision} MLP, Adam", "ms_per_step": round(dt * 1e3, 2),
+                      f"@500x500 + SyncNet), {precision} MLP, Adam" + (", frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16)" if unet_train_mode
+                                                                       else ", frozen U-Net in eval-mode BatchNorm"), "ms_per_step": round(dt * 1e3, 2),
             "unet_window": [wx0, wy0, wx1, wy1], "mlp_frames_per_step": B + 5 * S, "mlp_tflop_per_step": round(mlp / 1e12, 3), "unet_tflop_per_step": round(unet / 1e12, 3),
             "tflops": round((mlp + unet) / dt / 1e12, 1), "loss_first": l0, "loss_last": float(l),
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
@@ -325,7 +335,13 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
     the MLP, Adam.  (The reference runs batch_size 1: `ms_per_sample` is the time of one of its iterations.)"""
     H = Wd = 96
     m = make_model(dev, H, Wd, unet=True, train=True)
-    m.post_fusion_unet.eval()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    # eval: running statistics (train.py:195), crop window + bf16 operands; train: the mode the reference's loop really leaves the
+    # frozen net in (Trainer.train_step's model.train(), training.py:150; golden G16): batch statistics per one-frame call,
+    # whole 500x500 frames, exact fp32
+    if not unet_train_mode:
+        m.post_fusion_unet.eval()
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     lp = s2l.LPIPS(pretrained=False, net="alex", version="0.1").to(dev)      # seeded weights are loaded below
