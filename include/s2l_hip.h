@@ -304,7 +304,8 @@ int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, cons
                              float* d_x, int height, int width, int full_h, int full_w, int origin_y, int origin_x,
                              int64_t n_frames, s2l_stream_t stream);
 /* packed16 (or NULL): the nine 3x3 layers in bf16 operand form, s2l_unet_packed16_halves() uint16 written by s2l_unet_pack16
- * (same tensor table and BatchNorm fold as s2l_unet_pack).  With it those convolutions and their input-gradient twins run on
+ * (same tensor table and BatchNorm fold as s2l_unet_pack; bn_eps < 0: NO fold, the raw weights -- the bf16 twin of s2l_unet_pack_raw,
+ * for s2l_unet_train_*_bf16).  With it those convolutions and their input-gradient twins run on
  * v_mfma_f32_32x32x16_bf16 -- bf16 weights and staged inputs, fp32 accumulation, fp32 tensors in HBM -- the precision BASELINE
  * config 5 names for the training step; NULL = exact fp32 everywhere.  (The 3->64 first layer, 0.5 % of the work, stays fp32.) */
 int64_t s2l_unet_packed16_halves(void);
@@ -343,6 +344,16 @@ int s2l_unet_train_forward(const float* packed_raw, const float* const* tensors_
 int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors_host, const float* x, const float* saved,
                             const float* d_out, float* work, float* d_x, float* grads, int height, int width, int64_t n_frames,
                             s2l_stream_t stream);
+/* The same two passes with the 3x3 layers 1..9 (forward convolutions; their input-gradient twins) on bf16 operands, for the bf16
+ * training step of BASELINE config 5 when the frozen net runs train-mode BatchNorm (the reference's loop, training.py:150):
+ * packed16_raw = s2l_unet_pack16 called with bn_eps < 0 (no fold: the raw weights, forward and transposed halves).  Accumulation,
+ * tensors, batch statistics, the BatchNorm backward, the weight gradients and the 3->64 first layer stay fp32. */
+int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
+                                float momentum, int update_running, const float* x, float* saved, float* scratch, float* out,
+                                int height, int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_train_backward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                 const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
+                                 int height, int width, int64_t n_frames, s2l_stream_t stream);
 
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
  * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with

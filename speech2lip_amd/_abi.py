@@ -65,6 +65,10 @@ EXPORTS = {
                                        c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_train_backward": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_forward_bf16": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_backward_bf16": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_forward_saved_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                               c_int64, c_void_p]),
     "s2l_unet_backward_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -1820,12 +1820,14 @@ static void run_stats(const float* z, int C, int64_t n_pix, float* partial, hipS
 // x [F,H,W,3] -> out [F,H,W,3] with batch statistics; running_mean / running_var of the ten BatchNorm layers (entries 3 and 4 of
 // each layer's five pointers in `tensors_host`, the s2l_unet_pack table) are UPDATED IN PLACE when update_running != 0.
 // saved: s2l_unet_train_saved_floats floats (kept for s2l_unet_train_backward); scratch: at least 256*2*128 floats.
-extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* const* tensors_host, float bn_eps, float momentum,
-                                      int update_running, const float* x, float* saved, float* scratch, float* out, int height,
-                                      int width, int64_t n_frames, s2l_stream_t stream) {
+// packed16_raw != NULL: the 3x3 layers 1..9 take bf16 operands (s2l_unet_pack16 with bn_eps < 0: the raw weights) on
+// v_mfma_f32_32x32x16_bf16 -- fp32 accumulation, fp32 tensors, fp32 statistics -- as the eval-mode chain does in the bf16 step
+static int unet_train_forward_impl(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                   float bn_eps, float momentum, int update_running, const float* x, float* saved, float* scratch,
+                                   float* out, int height, int width, int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
   if (!packed_raw || !x || !saved || !scratch || !out) return S2L_E_NULL;
-  if (misaligned16(packed_raw) || misaligned16(saved)) return S2L_E_ALIGN;
+  if (misaligned16(packed_raw) || misaligned16(saved) || misaligned16(packed16_raw)) return S2L_E_ALIGN;
   UnetTensors t;
   int rc = unet_table(tensors_host, t);
   if (rc) return rc;
@@ -1847,14 +1849,19 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
                          packed_raw + unet_w_off(0), (const float*)nullptr, b.z[0], H, W);
     } else {
       ConvArgs a;
-      a.w16 = nullptr;
+      a.w16 = packed16_raw ? packed16_raw + unet_w16_off(l) : nullptr;
+      a.split = 0;
       a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
       a.w = packed_raw + unet_w_off(l); a.bias = nullptr; a.out = b.z[l]; a.out3 = nullptr; a.pool = nullptr; a.gate = nullptr; a.relu = 0;
       a.outw = a.outb = nullptr; a.H = hh[lv]; a.W = ww[lv];
       a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16; a.n_ct = C / 64;
+      if (F * a.n_ct > 65535) return S2L_E_SIZE;
+      const dim3 grid(a.tiles_x, a.tiles_y, (unsigned)(F * a.n_ct));
       bool done = false;
-      if ((rc = launch_conv_asm(a, F, st, &done))) return rc;
-      if (!done) hipLaunchKernelGGL(conv3x3_kernel<false>, dim3(a.tiles_x, a.tiles_y, (unsigned)(F * a.n_ct)), dim3(256), 0, st, a);
+      if ((rc = launch_conv_asm(a, F, st, &done))) return rc;       // (declines bf16 operands)
+      if (done) {}
+      else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
     }
     int nb = 0;
     run_stats(b.z[l], C, pl[lv], scratch, st, &nb);
@@ -1875,13 +1882,27 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
   hipLaunchKernelGGL(outc_kernel, blocks(p1), dim3(256), 0, st, b.act[9], t.outw, t.outb, out, p1);
   return (int)hipGetLastError();
 }
+extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* const* tensors_host, float bn_eps, float momentum,
+                                      int update_running, const float* x, float* saved, float* scratch, float* out, int height,
+                                      int width, int64_t n_frames, s2l_stream_t stream) {
+  return unet_train_forward_impl(packed_raw, nullptr, tensors_host, bn_eps, momentum, update_running, x, saved, scratch, out, height,
+                                 width, n_frames, stream);
+}
+extern "C" int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                           float bn_eps, float momentum, int update_running, const float* x, float* saved,
+                                           float* scratch, float* out, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (!packed16_raw) return S2L_E_NULL;
+  return unet_train_forward_impl(packed_raw, packed16_raw, tensors_host, bn_eps, momentum, update_running, x, saved, scratch, out,
+                                 height, width, n_frames, stream);
+}
 
 // d_out [F,H,W,3] -> d_x [F,H,W,3] (may be NULL) and grads (s2l_unet_grad_floats floats: per layer conv.weight [cout,cin,3,3],
 // bn.weight [cout], bn.bias [cout] in execution order, then outc.conv.weight [3,64], outc.conv.bias [3]).
-extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors_host, const float* x, const float* saved,
-                                       const float* d_out, float* work, float* d_x, float* grads, int height, int width,
-                                       int64_t n_frames, s2l_stream_t stream) {
+static int unet_train_backward_impl(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                    const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
+                                    int height, int width, int64_t n_frames, s2l_stream_t stream) {
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
+  if (misaligned16(packed16_raw)) return S2L_E_ALIGN;
   if (!packed_raw || !x || !saved || !d_out || !work) return S2L_E_NULL;
   if (!grads && !d_x) return S2L_E_NULL;      // nothing to compute
   if (misaligned16(packed_raw) || misaligned16(saved) || misaligned16(work)) return S2L_E_ALIGN;
@@ -1957,32 +1978,46 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
   }
   hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, t.outw, b.act[9], zA, p1 * 16);
   layer_grads(9, zA);
-  if ((rc = launch_conv_dgrad(zA, packed_raw, 9, zB, b.act[8], H, W, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(zA, packed_raw, 9, zB, b.act[8], H, W, F, st, packed16_raw))) return rc;
   layer_grads(8, zB);
-  if ((rc = launch_conv_dgrad(zB, packed_raw, 8, gcat8, nullptr, H, W, F, st))) return rc;                                // [g_x1 | g_uu]
+  if ((rc = launch_conv_dgrad(zB, packed_raw, 8, gcat8, nullptr, H, W, F, st, packed16_raw))) return rc;                                // [g_x1 | g_uu]
   hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W2, 64, H2, F), dim3(256), 0, st, gcat8, 128, 64, b.act[7], z7, H2, W2, 64,
                      H, W, no_window(H2, W2, H, W));
   layer_grads(7, z7);
-  if ((rc = launch_conv_dgrad(z7, packed_raw, 7, z6, b.act[6], H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z7, packed_raw, 7, z6, b.act[6], H2, W2, F, st, packed16_raw))) return rc;
   layer_grads(6, z6);
-  if ((rc = launch_conv_dgrad(z6, packed_raw, 6, gcat6, nullptr, H2, W2, F, st))) return rc;                              // [g_x2 | g_u3]
+  if ((rc = launch_conv_dgrad(z6, packed_raw, 6, gcat6, nullptr, H2, W2, F, st, packed16_raw))) return rc;                              // [g_x2 | g_u3]
   hipLaunchKernelGGL(upsample2_bwd_kernel, quad_grid(W4, 128, H4, F), dim3(256), 0, st, gcat6, 256, 128, b.act[5], z5, H4, W4, 128,
                      H2, W2, no_window(H4, W4, H2, W2));
   layer_grads(5, z5);
-  if ((rc = launch_conv_dgrad(z5, packed_raw, 5, z4, b.act[4], H4, W4, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z5, packed_raw, 5, z4, b.act[4], H4, W4, F, st, packed16_raw))) return rc;
   layer_grads(4, z4);
-  if ((rc = launch_conv_dgrad(z4, packed_raw, 4, gp2, nullptr, H4, W4, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z4, packed_raw, 4, gp2, nullptr, H4, W4, F, st, packed16_raw))) return rc;
   hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W2, 128, H2, F), dim3(256), 0, st, gcat6, 256, gp2, b.act[3], b.p2, z3,
                      H2, W2, 128);
   layer_grads(3, z3);
-  if ((rc = launch_conv_dgrad(z3, packed_raw, 3, z2, b.act[2], H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z3, packed_raw, 3, z2, b.act[2], H2, W2, F, st, packed16_raw))) return rc;
   layer_grads(2, z2);
-  if ((rc = launch_conv_dgrad(z2, packed_raw, 2, gp1, nullptr, H2, W2, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(z2, packed_raw, 2, gp1, nullptr, H2, W2, F, st, packed16_raw))) return rc;
   hipLaunchKernelGGL(pool_bwd_add_kernel, quad_grid(W, 64, H, F), dim3(256), 0, st, gcat8, 128, gp1, b.act[1], b.p1, zA,
                      H, W, 64);
   layer_grads(1, zA);
-  if ((rc = launch_conv_dgrad(zA, packed_raw, 1, zB, b.act[0], H, W, F, st))) return rc;
+  if ((rc = launch_conv_dgrad(zA, packed_raw, 1, zB, b.act[0], H, W, F, st, packed16_raw))) return rc;
   layer_grads(0, zB);
   if (d_x) launch_conv_first_bwd(zB, packed_raw + unet_w_off(0), gcat8, d_x, H, W, F, st);      // (gcat8 is dead by now)
   return (int)hipGetLastError();
+}
+extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* const* tensors_host, const float* x, const float* saved,
+                                       const float* d_out, float* work, float* d_x, float* grads, int height, int width,
+                                       int64_t n_frames, s2l_stream_t stream) {
+  return unet_train_backward_impl(packed_raw, nullptr, tensors_host, x, saved, d_out, work, d_x, grads, height, width, n_frames, stream);
+}
+// the input gradients of layers 1..9 with bf16 operands (the transposed half of the same s2l_unet_pack16(bn_eps < 0) blob);
+// BatchNorm backward, weight gradients and the first layer stay fp32
+extern "C" int s2l_unet_train_backward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                            const float* x, const float* saved, const float* d_out, float* work, float* d_x,
+                                            float* grads, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (!packed16_raw) return S2L_E_NULL;
+  return unet_train_backward_impl(packed_raw, packed16_raw, tensors_host, x, saved, d_out, work, d_x, grads, height, width, n_frames,
+                                  stream);
 }

@@ -171,11 +171,38 @@ class SimpleUnetLight(nn.Module):
             names += [f"{name}.weight", f"{bn}.weight", f"{bn}.bias"]
         return names + ["outc.conv.weight", "outc.conv.bias"]
 
-    def forward_train_nhwc(self, x: torch.Tensor, update_running: bool = True):
+    def _raw_blobs(self, tensors, table, want16: bool):
+        """The un-folded weights in the kernels' layouts (fp32: s2l_unet_pack_raw; bf16: s2l_unet_pack16 with bn_eps < 0), cached on
+        the versions of the WEIGHT tensors alone: the running statistics the train-mode forward rewrites are not in these blobs,
+        so a frozen net packs once and a training net once per optimizer step."""
+        lib = _abi.load()
+        dev = tensors[0].device
+        key = tuple((t.data_ptr(), t._version) for i, t in enumerate(tensors) if i % 5 == 0 or i >= 50)
+        if getattr(self, "_raw_key", None) != key:
+            self._raw = self._raw16 = None
+            self._raw_key = key
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if self._raw is None:
+                raw = torch.empty(int(lib.s2l_unet_packed_floats()), dtype=torch.float32, device=dev)
+                _abi.check(lib.s2l_unet_pack_raw(table, p(raw), st), "s2l_unet_pack_raw")
+                self._raw = raw
+            if want16 and self._raw16 is None:
+                raw16 = torch.empty(int(lib.s2l_unet_packed16_halves()), dtype=torch.int16, device=dev)
+                _abi.check(lib.s2l_unet_pack16(table, ctypes.c_float(-1.0), p(raw16), st), "s2l_unet_pack16")
+                self._raw16 = raw16
+        return self._raw, (self._raw16 if want16 else None)
+
+    def forward_train_nhwc(self, x: torch.Tensor, update_running: bool = True, precision: str = "fp32"):
         """The network in TRAIN mode (the reference until it > 100000, train.py:188-197): x [F,H,W,3] -> (out, ctx).  BatchNorm
         uses the statistics of the batch; with update_running the running_mean / running_var buffers are updated in place
-        and num_batches_tracked is incremented, as nn.BatchNorm2d does.  ctx feeds backward_train."""
+        and num_batches_tracked is incremented, as nn.BatchNorm2d does.  ctx feeds backward_train.
+        precision "bf16": the 3x3 convolutions here and their input gradients in backward_train take bf16 operands (fp32
+        accumulation, statistics and tensors), as forward_saved_nhwc(precision="bf16") does for the eval-mode net."""
         lib = _abi.load()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         tensors = self._tensors()
@@ -188,7 +215,7 @@ class SimpleUnetLight(nn.Module):
         if C != 3 or H < 4 or W < 4:
             raise ValueError(f"U-Net input must be [F,H>=4,W>=4,3], got {tuple(x.shape)}")
         table = self._table(tensors)
-        raw = torch.empty(int(lib.s2l_unet_packed_floats()), dtype=torch.float32, device=dev)
+        raw, raw16 = self._raw_blobs(tensors, table, precision == "bf16")
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
         saved = torch.empty(int(lib.s2l_unet_train_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
         scratch = torch.empty(262144, dtype=torch.float32, device=dev)
@@ -197,10 +224,14 @@ class SimpleUnetLight(nn.Module):
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _abi.check(lib.s2l_unet_pack_raw(table, p(raw), st), "s2l_unet_pack_raw")
-            _abi.check(lib.s2l_unet_train_forward(p(raw), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
-                                                  1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
-                       "s2l_unet_train_forward")
+            if raw16 is None:
+                _abi.check(lib.s2l_unet_train_forward(p(raw), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                                      1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                           "s2l_unet_train_forward")
+            else:
+                _abi.check(lib.s2l_unet_train_forward_bf16(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)),
+                                                           ctypes.c_float(momentum), 1 if update_running else 0, p(x), p(saved),
+                                                           p(scratch), p(out), H, W, F_, st), "s2l_unet_train_forward_bf16")
         if update_running:
             for mod in self.modules():
                 if isinstance(mod, nn.BatchNorm2d):
@@ -210,7 +241,7 @@ class SimpleUnetLight(nn.Module):
             self._packed = self._packed_key = None
             self._packed16 = self._packed16_key = None
             self._packed16x3 = self._packed16x3_key = None
-        return out, (raw, x, saved, (F_, H, W))
+        return out, (raw, x, saved, (F_, H, W), raw16)
 
     def backward_train(self, ctx, d_out: torch.Tensor, want_input_grad: bool = True, want_param_grads: bool = True):
         """d loss / d out [F,H,W,3] -> (d loss / d x or None, {state-dict name: gradient}) for every conv / BatchNorm / outc
@@ -219,7 +250,7 @@ class SimpleUnetLight(nn.Module):
         if not (want_input_grad or want_param_grads):
             raise ValueError("backward_train: nothing to compute")
         lib = _abi.load()
-        raw, x, saved, (F_, H, W) = ctx
+        raw, x, saved, (F_, H, W), raw16 = ctx
         dev = x.device
         d = d_out.detach().to(torch.float32).contiguous()
         if d.shape != (F_, H, W, 3) or d.device != dev:
@@ -231,8 +262,13 @@ class SimpleUnetLight(nn.Module):
         work = torch.empty(int(lib.s2l_unet_train_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_unet_train_backward(p(raw), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_,
-                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_train_backward")
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if raw16 is None:
+                _abi.check(lib.s2l_unet_train_backward(p(raw), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_, st),
+                           "s2l_unet_train_backward")
+            else:
+                _abi.check(lib.s2l_unet_train_backward_bf16(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), p(flat),
+                                                            H, W, F_, st), "s2l_unet_train_backward_bf16")
         if not want_param_grads:
             return dx, {}
         params = dict(self.named_parameters())
@@ -299,14 +335,14 @@ class SimpleUnetLight(nn.Module):
         frame at a time (tf_nerf.py:387 inside train_stage1's batch-1 calls), so each frame is normalised with its own
         statistics and the running statistics move once per frame, in that order.  This is also the mode of a FROZEN net inside
         the reference's loop after it > 100000: Trainer.train_step's self.model.train() (training.py:150) undoes the .eval() of
-        train.py:195.  A crop is not equivalent then (statistics are over the whole frame) and exact fp32 is used."""
+        train.py:195.  A crop is not equivalent then (statistics are over the whole frame); `precision` as in eval mode."""
         if not self.training:
             return self.forward_saved_nhwc(x, window=window, precision=precision)
         if window is not None:
             raise ValueError("train-mode BatchNorm needs whole frames: statistics are taken over the full image")
         outs, ctxs = [], []
         for f in range(x.shape[0]):
-            o, c = self.forward_train_nhwc(x[f:f + 1], update_running=True)
+            o, c = self.forward_train_nhwc(x[f:f + 1], update_running=True, precision=precision)
             outs.append(o)
             ctxs.append(c)
         return torch.cat(outs, 0), ("train", ctxs)

@@ -730,6 +730,58 @@ def test_unet_bf16_convolutions_vs_fp32(dev, fh, fw, F):
         assert torch.equal(ow[:, 40:-40, 40:-40], o16[:, 88:420, 108:392])
 
 
+@pytest.mark.parametrize("fh,fw", [(64, 80), (500, 500)])
+def test_unet_train_mode_bf16_convolutions_vs_fp32(dev, fh, fw):
+    """The same operand mode for the net in TRAIN-mode BatchNorm (the reference's loop runs the frozen net that way, G16):
+    s2l_unet_train_forward_bf16 / s2l_unet_train_backward_bf16 against the exact fp32 train-mode pair.  Batch statistics, running
+    statistics and the BatchNorm backward stay fp32; only the 3x3 convolutions' operands are rounded."""
+    def net():
+        u = s2l.SimpleUnetLight().to(dev).train()
+        u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
+        return u
+    u32, u16 = net(), net()
+    x = T(W.synthetic_image((1, fh, fw, 3), 5, "x")).to(dev)
+    d = T(np.random.default_rng(2).standard_normal((1, fh, fw, 3)).astype(np.float32)).to(dev)
+    o32, c32 = u32.forward_train_nhwc(x)
+    o16, c16 = u16.forward_train_nhwc(x, precision="bf16")
+    g32, p32 = u32.backward_train(c32, d)
+    g16, p16 = u16.backward_train(c16, d)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+
+    def cos(a, b):
+        return float((a.flatten() @ b.flatten()) / (a.norm() * b.norm()))
+    # (eval mode holds 1e-2; batch normalisation rescales every layer to unit variance, so ten layers of 2^-9 operand rounding add up
+    # un-attenuated: 1.3e-2 measured at 64x80)
+    assert rel(o16, o32) <= 2e-2 and cos(o16, o32) >= 0.9998 and not torch.equal(o16, o32), (rel(o16, o32), cos(o16, o32))
+    # the input-gradient convolutions alone: the fp32 forward's state (identical ReLU / pooling decisions and statistics), bf16
+    # operands in the backward
+    gm, _ = u32.backward_train((*c32[:4], c16[4]), d, want_param_grads=False)
+    assert rel(gm, g32) <= 2.5e-2, rel(gm, g32)
+    # end to end it is the gradient of the bf16 forward: ReLUs within bf16 rounding of zero resolve the other way (white-noise d)
+    assert cos(g16, g32) >= 0.97 and rel(g16, g32) <= 0.3, (rel(g16, g32), cos(g16, g32))
+    for k in p32:      # weight gradients: fp32 GEMMs over the bf16 forward's activations and the bf16 input-gradient chain
+        assert cos(p16[k], p32[k]) >= 0.97, (k, cos(p16[k], p32[k]))
+    sd32, sd16 = u32.state_dict(), u16.state_dict()
+    for k in sd32:     # running statistics moved once, to nearly the same place; counters equal
+        if k.endswith("num_batches_tracked"):
+            assert int(sd32[k]) == int(sd16[k]) == 101      # (the synthetic state dict starts the counters at 100)
+        elif "running" in k:
+            assert rel(sd16[k], sd32[k]) <= 2e-2, (k, rel(sd16[k], sd32[k]))
+    # the frozen form (input gradient alone) is the same chain
+    g16b, none = u16.backward_train(c16, d, want_param_grads=False)
+    assert none == {} and torch.equal(g16b, g16)
+    # the raw blobs are cached on the weights' versions: a second forward re-uses them, an in-place weight update re-packs
+    raw_a = u16._raw16
+    u16.forward_train_nhwc(x, precision="bf16")
+    assert u16._raw16 is raw_a
+    with torch.no_grad():
+        u16.inc.double_conv[3].weight.mul_(1.5)
+    o_b, _ = u16.forward_train_nhwc(x, precision="bf16")
+    assert u16._raw16 is not raw_a
+
+
 def test_train_step_from_a_dataset_folder(syncnet, dev):
     """Dataset folder -> SomeonesLipClip.load_one_frame (golden G15: equal to the reference reader's dictionary) -> collate ->
     Trainer.train_step, i.e. the reference's loop body fed from disk instead of from a golden: the it > 100000 step (sync window
