@@ -423,6 +423,14 @@ int s2l_sync_loss(const float* audio_emb, const float* face_emb, const float* y,
                   float* loss, int accumulate, float* d_face_emb, int64_t batch, s2l_stream_t stream);
 int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
                               float* d_face, int64_t batch, s2l_stream_t stream);
+/* The contrastive loss embeds the generated AND the negative windows of the same audio (training.py:592-601).  s2l_syncnet_forward_pair:
+ * face [face_batch,48,96,15] (generated windows first), mel [audio_batch,80,16], audio_batch <= face_batch: one pass per encoder --
+ * twice the columns per weight read in the face encoder, the audio encoder once; work: s2l_syncnet_work_floats(face_batch).
+ * s2l_syncnet_face_backward_prefix: d_face [batch,48,96,15] for the FIRST `batch` windows of a forward over work_batch windows. */
+int s2l_syncnet_forward_pair(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                             float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream);
+int s2l_syncnet_face_backward_prefix(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                     float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream);
 int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,
                     s2l_stream_t stream);
 int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width,

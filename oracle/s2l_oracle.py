@@ -419,21 +419,29 @@ def depth_photo_loss(depth: torch.Tensor, T: torch.Tensor, src_nhwc: torch.Tenso
 
 
 # --------------------------------------------------------------------------- T3: lip-sync expert loss
-def syncnet_encoder(sd: SD, x: torch.Tensor, prefix: str, blocks, eps: float = 1e-5) -> torch.Tensor:
+def syncnet_encoder(sd: SD, x: torch.Tensor, prefix: str, blocks, eps: float = 1e-5, margins: Optional[list] = None) -> torch.Tensor:
     """One encoder of SyncNet_color (syncnet.py:11-54) in eval mode: per block conv -> BatchNorm(running stats) ->
-    (+ x if residual) -> ReLU (conv.py:5-19).  `blocks` = speech2lip_amd.weights.SYNCNET_FACE / SYNCNET_AUDIO."""
+    (+ x if residual) -> ReLU (conv.py:5-19).  `blocks` = speech2lip_amd.weights.SYNCNET_FACE / SYNCNET_AUDIO.
+    margins (a list, test aid): per block the [B] tensor min |pre-ReLU value| / rms of that sample's pre-ReLU map -- how far the
+    sample's closest ReLU decision is from a tie (another fp32 evaluation order may resolve a tie the other way, which changes
+    the GRADIENT inside that unit's receptive field by O(1), not by rounding)."""
     for i, (cin, cout, k, stride, pad, res) in enumerate(blocks):
         p = f"{prefix}.{i}.conv_block."
         y = F.conv2d(x, sd[p + "0.weight"], sd[p + "0.bias"], stride=stride, padding=pad)
         y = F.batch_norm(y, sd[p + "1.running_mean"], sd[p + "1.running_var"], sd[p + "1.weight"], sd[p + "1.bias"],
                          training=False, eps=eps)
-        x = F.relu(y + x if res else y)
+        z = y + x if res else y
+        if margins is not None:
+            zd = z.detach().reshape(z.shape[0], -1)
+            margins.append(zd.abs().min(dim=1).values / zd.pow(2).mean(dim=1).sqrt().clamp_min(1e-30))
+        x = F.relu(z)
     return x
 
 
-def syncnet_forward(sd: SD, audio_sequences: torch.Tensor, face_sequences: torch.Tensor, blocks_face, blocks_audio):
+def syncnet_forward(sd: SD, audio_sequences: torch.Tensor, face_sequences: torch.Tensor, blocks_face, blocks_audio,
+                    face_margins: Optional[list] = None):
     """SyncNet_color.forward (syncnet.py:57-67): ([B,1,80,16], [B,15,48,96]) -> L2-normalised ([B,512], [B,512])."""
-    f = syncnet_encoder(sd, face_sequences, "face_encoder", blocks_face)
+    f = syncnet_encoder(sd, face_sequences, "face_encoder", blocks_face, margins=face_margins)
     a = syncnet_encoder(sd, audio_sequences, "audio_encoder", blocks_audio)
     a, f = a.reshape(a.shape[0], -1), f.reshape(f.shape[0], -1)
     return F.normalize(a, p=2, dim=1), F.normalize(f, p=2, dim=1)
@@ -452,11 +460,12 @@ def cosine_loss(a: torch.Tensor, v: torch.Tensor, y: torch.Tensor) -> torch.Tens
     return F.binary_cross_entropy(d.unsqueeze(1), y)
 
 
-def sync_contrastive_loss(sd: SD, mel, g_rgb_pos, g_rgb_neg, blocks_face, blocks_audio, syncnet_T: int = 5):
+def sync_contrastive_loss(sd: SD, mel, g_rgb_pos, g_rgb_neg, blocks_face, blocks_audio, syncnet_T: int = 5,
+                          pos_margins: Optional[list] = None):
     """Trainer.get_sync_contrastive_loss (training.py:581-603): BCE(cos, 1) on the generated window + BCE(cos, 0) on the
-    negative window."""
+    negative window.  pos_margins: see syncnet_encoder (the face encoder on the generated window, the pass gradients flow through)."""
     B = mel.shape[0]
-    a, v = syncnet_forward(sd, mel, sync_window(g_rgb_pos, syncnet_T), blocks_face, blocks_audio)
+    a, v = syncnet_forward(sd, mel, sync_window(g_rgb_pos, syncnet_T), blocks_face, blocks_audio, face_margins=pos_margins)
     pos = cosine_loss(a, v, torch.ones(B, 1, dtype=mel.dtype))
     a, v = syncnet_forward(sd, mel, sync_window(g_rgb_neg, syncnet_T), blocks_face, blocks_audio)
     neg = cosine_loss(a, v, torch.zeros(B, 1, dtype=mel.dtype))

@@ -130,6 +130,8 @@ EXPORTS = {
     "s2l_syncnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_sync_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "s2l_syncnet_face_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_syncnet_forward_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_syncnet_face_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_sync_window": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_sync_window_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_bf16_packed_halves": (c_int64, []),

@@ -5,8 +5,8 @@
 //   forward : rows = output channels, cols = output pixels (b,oy,ox), k = (ky,kx,ci), B gathered from the NHWC input
 //   dgrad   : rows = input channels,  cols = input pixels  (b,iy,ix), k = (ky,kx,co), B gathered from the masked output
 //             gradient at oy = (iy + pad - ky) / stride where that division is exact
-// A workgroup (4 waves, 2x2) owns a 64x64 tile; K advances in chunks of 16 through LDS with the next chunk's global loads
-// in flight during the MFMAs.  Deep layers have few pixels and K up to 4608, so K is also split across gridDim.z into partial
+// A workgroup (4 waves) owns a 64x64 tile (32x128 / 16x256 for layers of <= 32 / <= 16 rows); K advances in chunks of 16 through
+// LDS with the next chunk's global loads in flight during the MFMAs.  Deep layers have few pixels and K up to 4608, so K is also split across gridDim.z into partial
 // tiles that a second kernel reduces in a fixed order (deterministic) before the epilogue.
 #pragma once
 #include "s2l_common.h"
@@ -69,115 +69,145 @@ struct ConvArgs {
   int rows, RP, kc, kcp, ncols, nchunks, chunks_per_split;
 };
 
-constexpr int kLd = 80;  // LDS row stride in floats: 80 % 32 == 16 keeps the four k-rows of an operand read on distinct banks
-
 __device__ static __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // K advances in GROUPS of up to four 16-wide chunks per barrier pair (round 3): with one chunk per pair a wave issued 16 MFMAs
 // (512 cycles) between two barriers and a global-load wait, and the kernel sat at 0.20 of the fp32-MFMA peak on the lip-sync
 // expert; the accumulation order (chunk by chunk, k ascending) is unchanged, so the results are the same bits.
 constexpr int kGroup = 4;
-template <bool DGRAD>
+
+// Tile shapes.  TM rows x TN columns per workgroup of four waves, TM * TN = 4096 accumulators in every shape:
+//   TM = 64: waves 2 x 2, each 32 x 32 (2 x 2 MFMA sub-tiles)            -- the general case
+//   TM = 32: waves 1 x 4, each 32 x 32 (2 x 2)         tile 32 x 128    -- <= 32 rows: the 15 -> 32 first layer of the face
+//   TM = 16: waves 1 x 4, each 16 x 64 (1 x 4)         tile 16 x 256       encoder, the data gradients of its first two layers
+//                                                                          (32 and 15 rows), AlexNet's 3-row input gradient
+// A 64-row tile on those layers spent 1/2 .. 3/4 of its MFMAs on zero rows (the two largest launches of the sync-loss gradient).
+// The accumulation order per output element does not depend on the shape.
+template <int TM> struct TileShape {
+  static constexpr int TN = 4096 / TM;
+  static constexpr int WGM = TM == 64 ? 2 : 1, WGN = 4 / WGM;
+  static constexpr int SM = TM / (16 * WGM), SN = TN / (16 * WGN);
+  static constexpr int NB = TN / 64;                       // B pixels fetched per thread and chunk
+  static constexpr int LdA = TM == 64 ? 80 : TM == 32 ? 48 : 16;      // LDS row strides in floats, stride % 32 == 16: the four
+  static constexpr int LdB = TN + 16;                                 //   k-rows of an operand read land on distinct banks
+  static constexpr int G = TM == 16 ? 2 : kGroup;          // chunks per barrier pair (LDS: 40 / 48 / 37 KiB)
+};
+
+template <bool DGRAD, int TM>
 __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
-  __shared__ float As[16 * kGroup * kLd];
-  __shared__ float Bs[16 * kGroup * kLd];
+  using S = TileShape<TM>;
+  constexpr int TN = S::TN, SM = S::SM, SN = S::SN, NB = S::NB, LdA = S::LdA, LdB = S::LdB, G = S::G;
+  __shared__ float As[16 * G * LdA];
+  __shared__ float Bs[16 * G * LdB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
-  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+  const int wm = wave % S::WGM, wn = wave / S::WGM, q = lane >> 4, l16 = lane & 15;
+  const int col0 = blockIdx.x * TN, row0 = blockIdx.y * TM;
   const int chunk_lo = blockIdx.z * a.chunks_per_split;
   const int chunk_hi = min(a.nchunks, chunk_lo + a.chunks_per_split);
 
-  // B-load role: pixel pl of the tile, channel quad cq of the chunk
+  // B-load role: pixels pl + 64 j of the tile, channel quad cq of the chunk
   const int pl = t >> 2, cq = t & 3;
-  const int col = col0 + pl;
-  const bool col_ok = col < a.ncols;
   const int cw = DGRAD ? a.win : a.wout, chw = DGRAD ? a.hin * a.win : a.hout * a.wout;
-  const int cc = col_ok ? col : 0;
-  const int n = cc / chw, rem = cc - n * chw;
-  const int cy = rem / cw, cx = rem - cy * cw;
-  // A-load role
-  const int ak = t >> 4, ar4 = t & 15;
+  bool col_ok[NB];
+  int pn[NB], cy[NB], cx[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = col0 + pl + 64 * j;
+    col_ok[j] = col < a.ncols;
+    const int cc = col_ok[j] ? col : 0;
+    pn[j] = cc / chw;
+    const int rem = cc - pn[j] * chw;
+    cy[j] = rem / cw, cx[j] = rem - cy[j] * cw;
+  }
+  // A-load role: 16 k-rows x TM / 4 row quads
+  const bool a_ok = t < 4 * TM;
+  const int ak = t / (TM / 4), ar4 = t % (TM / 4);
   const bool vec = (a.kc & 3) == 0;
 
-  f4 acc[2][2];
+  f4 acc[SM][SN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < SM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < SN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  auto fetch1 = [&](int chunk, f4& av, f4& bv) {
-    av = *reinterpret_cast<const f4*>(a.w + ((int64_t)chunk * 16 + ak) * a.RP + row0 + ar4 * 4);
+  auto fetch1 = [&](int chunk, f4& av, f4 (&bv)[NB]) {
+    if (a_ok) av = *reinterpret_cast<const f4*>(a.w + ((int64_t)chunk * 16 + ak) * a.RP + row0 + ar4 * 4);
     const int kidx0 = chunk * 16;
     const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp + 4 * cq;
     const int ky = tap / a.kw, kx = tap - ky * a.kw;
-    bool ok = col_ok && c0 < a.kc;
-    const float* src;
-    if (!DGRAD) {
-      const int iy = cy * a.sy - a.py + ky, ix = cx * a.sx - a.px + kx;
-      ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-      src = a.in + (((int64_t)n * a.hin + iy) * a.win + ix) * a.cin + c0;
-    } else {
-      const int ty = cy + a.py - ky, tx = cx + a.px - kx;
-      const int oy = ty / a.sy, ox = tx / a.sx;
-      ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
-      src = a.in + (((int64_t)n * a.hout + oy) * a.wout + ox) * a.cout + c0;
-    }
-    bv = f4{0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      if (vec) {
-        bv = *reinterpret_cast<const f4*>(src);
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < a.kc) bv[j] = src[j];
+    for (int j = 0; j < NB; ++j) {
+      bool ok = col_ok[j] && c0 < a.kc;
+      const float* src;
+      if (!DGRAD) {
+        const int iy = cy[j] * a.sy - a.py + ky, ix = cx[j] * a.sx - a.px + kx;
+        ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+        src = a.in + (((int64_t)pn[j] * a.hin + iy) * a.win + ix) * a.cin + c0;
+      } else {
+        const int ty = cy[j] + a.py - ky, tx = cx[j] + a.px - kx;
+        const int oy = ty / a.sy, ox = tx / a.sx;
+        ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
+        src = a.in + (((int64_t)pn[j] * a.hout + oy) * a.wout + ox) * a.cout + c0;
+      }
+      bv[j] = f4{0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        if (vec) {
+          bv[j] = *reinterpret_cast<const f4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < a.kc) bv[j][e] = src[e];
+        }
       }
     }
   };
-  f4 av[kGroup], bv[kGroup];
-  auto fetch = [&](int chunk) {      // chunks chunk .. chunk + kGroup - 1 that exist (the MFMA loop stops at the last one)
+  f4 av[G], bv[G][NB];
+  auto fetch = [&](int chunk) {      // chunks chunk .. chunk + G - 1 that exist (the MFMA loop stops at the last one)
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g)
+    for (int g = 0; g < G; ++g)
       if (chunk + g < chunk_hi) fetch1(chunk + g, av[g], bv[g]);
   };
 
   if (chunk_lo < chunk_hi) fetch(chunk_lo);
-  for (int chunk = chunk_lo; chunk < chunk_hi; chunk += kGroup) {
-    const int ng = min(kGroup, chunk_hi - chunk);      // (uniform over the workgroup)
+  for (int chunk = chunk_lo; chunk < chunk_hi; chunk += G) {
+    const int ng = min(G, chunk_hi - chunk);      // (uniform over the workgroup)
     __syncthreads();  // the previous group's operand reads are done
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g) {
+    for (int g = 0; g < G; ++g) {
       if (g < ng) {
-        *reinterpret_cast<f4*>(&As[(16 * g + ak) * kLd + ar4 * 4]) = av[g];
+        if (a_ok) *reinterpret_cast<f4*>(&As[(16 * g + ak) * LdA + ar4 * 4]) = av[g];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[(16 * g + 4 * cq + j) * kLd + pl] = bv[g][j];
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Bs[(16 * g + 4 * cq + e) * LdB + pl + 64 * j] = bv[g][j][e];
       }
     }
     __syncthreads();
-    if (chunk + kGroup < chunk_hi) fetch(chunk + kGroup);
-    // the 16 operand values of chunk g + 1 are read from LDS while the 16 MFMAs of chunk g issue (two register sets): with
-    // "4 reads, wait, 4 MFMAs" per k-step a chunk took ~1 400 cycles for 512 cycles of matrix work (one wave per SIMD per workgroup)
-    float fa[2][4][2], fb[2][4][2];
+    if (chunk + G < chunk_hi) fetch(chunk + G);
+    // the operand values of chunk g + 1 are read from LDS while the MFMAs of chunk g issue (two register sets): with
+    // "reads, wait, MFMAs" per k-step a chunk took ~1 400 cycles for 512 cycles of matrix work (one wave per SIMD per workgroup)
+    float fa[2][4][SM], fb[2][4][SN];
     auto lds_operands = [&](int g, int set) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[set][kk][i] = As[(16 * g + 4 * kk + q) * kLd + 32 * wm + 16 * i + l16];
+        for (int i = 0; i < SM; ++i) fa[set][kk][i] = As[(16 * g + 4 * kk + q) * LdA + 16 * SM * wm + 16 * i + l16];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[set][kk][j] = Bs[(16 * g + 4 * kk + q) * kLd + 32 * wn + 16 * j + l16];
+        for (int j = 0; j < SN; ++j) fb[set][kk][j] = Bs[(16 * g + 4 * kk + q) * LdB + 16 * SN * wn + 16 * j + l16];
       }
     };
     lds_operands(0, 0);
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g) {
+    for (int g = 0; g < G; ++g) {
       if (g < ng) {
         if (g + 1 < ng) lds_operands(g + 1, (g + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < SM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[g & 1][kk][i], fb[g & 1][kk][j], acc[i][j]);
+            for (int j = 0; j < SN; ++j) acc[i][j] = mfma16(fa[g & 1][kk][i], fb[g & 1][kk][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -185,12 +215,12 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
   // D[row = 4q + r][col = l16] of sub-tile (i, j)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = col0 + 32 * wn + 16 * j + l16;
+  for (int j = 0; j < SN; ++j) {
+    const int c = col0 + 16 * SN * wn + 16 * j + l16;
     if (c >= a.ncols) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r0 = row0 + 32 * wm + 16 * i + 4 * q;
+    for (int i = 0; i < SM; ++i) {
+      const int r0 = row0 + 16 * SM * wm + 16 * i + 4 * q;
       if (a.partial) {
         *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.RP + r0) = acc[i][j];
         continue;
@@ -245,6 +275,12 @@ __global__ static __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int
   }
 }
 
+template <bool DGRAD, int TM>
+static void launch_conv_shape(const ConvArgs& a, int splits, hipStream_t st) {
+  constexpr int TN = TileShape<TM>::TN;
+  hipLaunchKernelGGL((conv_gemm_kernel<DGRAD, TM>), dim3((a.ncols + TN - 1) / TN, (a.rows + TM - 1) / TM, splits), dim3(256), 0, st, a);
+}
+
 template <bool DGRAD>
 static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   a.ncols = (int)(B * (DGRAD ? a.hin * a.win : a.hout * a.wout));
@@ -253,8 +289,9 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   a.kc = DGRAD ? a.cout : a.cin;
   a.kcp = ceil_to(a.kc, 16);
   a.nchunks = a.kh * a.kw * a.kcp / 16;
-  const int tiles = ((a.ncols + 63) / 64) * (a.RP / 64);
-  // One 64 x 64 tile walks its K range alone, one workgroup of four waves: a CU that holds a single such workgroup streams its
+  const int TM = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : 64, TN = 4096 / TM;
+  const int tiles = ((a.ncols + TN - 1) / TN) * ((a.rows + TM - 1) / TM);
+  // One tile walks its K range alone, one workgroup of four waves: a CU that holds a single such workgroup streams its
   // operands at ~12 GB/s (dependent fetch -> commit -> MFMA rounds), so a launch of ~150-300 tiles ran at a quarter of the MFMA
   // rate however its inner loop was scheduled (round 3 measurements: grouping chunks, pipelining the LDS reads: +-0).  What it lacks
   // is workgroups in flight: K is split until ~4 workgroups per CU exist (the LDS and register budget of 4), each with >= 8 chunks.
@@ -270,7 +307,9 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
   float* partial = a.partial;
   a.partial = splits > 1 ? partial : nullptr;
-  hipLaunchKernelGGL(conv_gemm_kernel<DGRAD>, dim3((a.ncols + 63) / 64, a.RP / 64, splits), dim3(256), 0, st, a);
+  if (TM == 16) launch_conv_shape<DGRAD, 16>(a, splits, st);
+  else if (TM == 32) launch_conv_shape<DGRAD, 32>(a, splits, st);
+  else launch_conv_shape<DGRAD, 64>(a, splits, st);
   if (splits > 1) {
     const int64_t n = (int64_t)a.ncols * (a.RP / 4);
     hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);

@@ -230,16 +230,21 @@ extern "C" int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, 
   return (int)hipGetLastError();
 }
 
-extern "C" int s2l_syncnet_forward(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
-                                   float* face_emb, int64_t batch, s2l_stream_t stream) {
-  if (batch < 0 || batch > 4096) return S2L_E_SIZE;
-  if (batch == 0) return S2L_OK;
-  if (!packed || !mel || !face || !work || !audio_emb || !face_emb) return S2L_E_NULL;
+// audio_batch mel windows and face_batch >= audio_batch face windows in ONE pass per encoder (the contrastive loss embeds the generated
+// and the negative windows of the same audio, training.py:592-601: twice the columns per weight read for the face encoder, the
+// audio encoder once instead of twice).  The activations are laid out for face_batch.
+static int syncnet_forward_impl(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream) {
+  if (face_batch < 0 || face_batch > 4096 || audio_batch < 0 || audio_batch > face_batch) return S2L_E_SIZE;
+  if (face_batch == 0) return S2L_OK;
+  if (!packed || !face || !work || !face_emb || (audio_batch && (!mel || !audio_emb))) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(work) || misaligned16(face) || misaligned16(mel)) return S2L_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const PackedLayout pl = packed_layout();
-  const WorkLayout wl = work_layout(batch);
+  const WorkLayout wl = work_layout(face_batch);
   for (int l = 0; l < kNumLayers; ++l) {
+    const int64_t batch = l < kNumFace ? face_batch : audio_batch;
+    if (batch == 0) continue;
     const LayerSpec& s = spec_of(l);
     ConvArgs a = base_args(s, wl.in_shape[l], wl.out_shape_[l]);
     a.in = l == 0 ? face : l == kNumFace ? mel : work + wl.act[l - 1];
@@ -252,9 +257,20 @@ extern "C" int s2l_syncnet_forward(const float* packed, const float* mel, const 
     if (rc) return rc;
   }
   // both encoders end 1x1x512 (syncnet.py:59-60 flattens them): normalise
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumFace - 1], face_emb, kSyncEmb);
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumLayers - 1], audio_emb, kSyncEmb);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)face_batch), dim3(64), 0, st, work + wl.act[kNumFace - 1], face_emb, kSyncEmb);
+  if (audio_batch)
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)audio_batch), dim3(64), 0, st, work + wl.act[kNumLayers - 1], audio_emb,
+                       kSyncEmb);
   return (int)hipGetLastError();
+}
+extern "C" int s2l_syncnet_forward(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                   float* face_emb, int64_t batch, s2l_stream_t stream) {
+  if (batch > 0 && (!mel || !audio_emb)) return S2L_E_NULL;
+  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, batch, batch, stream);
+}
+extern "C" int s2l_syncnet_forward_pair(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                        float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream) {
+  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, audio_batch, face_batch, stream);
 }
 
 extern "C" int s2l_sync_loss(const float* audio_emb, const float* face_emb, const float* y, float weight, float* scratch,
@@ -269,15 +285,17 @@ extern "C" int s2l_sync_loss(const float* audio_emb, const float* face_emb, cons
   return (int)hipGetLastError();
 }
 
-extern "C" int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
-                                         float* d_face, int64_t batch, s2l_stream_t stream) {
-  if (batch < 0 || batch > 4096) return S2L_E_SIZE;
+// the data gradient for the FIRST `batch` windows of a forward over work_batch windows (NHWC, batch outermost: a prefix of every
+// activation)
+static int syncnet_face_backward_impl(const float* packed, const float* face, float* work, const float* d_face_emb, float* d_face,
+                                      int64_t batch, int64_t work_batch, s2l_stream_t stream) {
+  if (batch < 0 || work_batch > 4096 || batch > work_batch) return S2L_E_SIZE;
   if (batch == 0) return S2L_OK;
   if (!packed || !face || !work || !d_face_emb || !d_face) return S2L_E_NULL;
   if (misaligned16(packed) || misaligned16(work)) return S2L_E_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const PackedLayout pl = packed_layout();
-  const WorkLayout wl = work_layout(batch);
+  const WorkLayout wl = work_layout(work_batch);
   float* g_cur = work + wl.grad[0];
   float* g_nxt = work + wl.grad[1];
   hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)batch), dim3(64), 0, st, work + wl.act[kNumFace - 1], d_face_emb, g_cur,
@@ -298,6 +316,14 @@ extern "C" int s2l_syncnet_face_backward(const float* packed, const float* face,
     g_nxt = tmp;
   }
   return (int)hipGetLastError();
+}
+extern "C" int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                         float* d_face, int64_t batch, s2l_stream_t stream) {
+  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, batch, stream);
+}
+extern "C" int s2l_syncnet_face_backward_prefix(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                                float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream) {
+  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, work_batch, stream);
 }
 
 extern "C" int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,

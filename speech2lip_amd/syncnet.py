@@ -110,15 +110,40 @@ class SyncNet_color(nn.Module):
         self._last = (face, B)
         return a, v
 
-    def face_backward(self, d_face_emb: torch.Tensor) -> torch.Tensor:
-        """d loss / d face [B,48,96,15] from d loss / d face_emb [B,512], for the window of the last embed_nhwc call."""
+    def embed_pair_nhwc(self, mel: torch.Tensor, face_nhwc: torch.Tensor):
+        """mel [B,...]; face [n B,48,96,15], n >= 1 (the generated windows first, then e.g. the negative ones of the same audio,
+        training.py:592-601) -> (audio_emb [B,512], face_emb [n B,512]): each encoder runs ONCE (s2l_syncnet_forward_pair)."""
         lib = _abi.load()
-        face, B = self._last
+        packed = self.packed_weights()
+        dev = packed.device
+        if mel.device != dev or face_nhwc.device != dev:
+            raise _abi.S2LError("SyncNet inputs must be on the GPU that holds its weights (no CPU fallback)")
+        mel = mel.detach().to(torch.float32).contiguous()
+        face = face_nhwc.detach().to(torch.float32).contiguous()
+        FB, B = face.shape[0], mel.numel() // (80 * 16)
+        if tuple(face.shape[1:]) != (48, 96, 15) or mel.numel() != B * 80 * 16 or B < 1 or FB < B or FB % B:
+            raise ValueError(f"SyncNet expects face [n B,48,96,15] and mel [B,1,80,16]; got {tuple(face.shape)}, {tuple(mel.shape)}")
+        a = torch.empty(B, 512, dtype=torch.float32, device=dev)
+        v = torch.empty(FB, 512, dtype=torch.float32, device=dev)
+        work = self._workspace(FB, dev)
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_syncnet_forward_pair(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, FB, _st()),
+                       "s2l_syncnet_forward_pair")
+        self._last = (face, FB)
+        return a, v
+
+    def face_backward(self, d_face_emb: torch.Tensor) -> torch.Tensor:
+        """d loss / d face [B,48,96,15] from d loss / d face_emb [B,512], for the FIRST B windows of the last embed call."""
+        lib = _abi.load()
+        face, FB = self._last
         d = d_face_emb.detach().to(torch.float32).contiguous()
-        out = torch.empty_like(face)
+        B = d.shape[0]
+        if B > FB or d.shape[1:] != (512,):
+            raise ValueError(f"d_face_emb must be [B <= {FB},512], got {tuple(d.shape)}")
+        out = torch.empty(B, *face.shape[1:], dtype=torch.float32, device=face.device)
         with torch.cuda.device(face.device):
-            _abi.check(lib.s2l_syncnet_face_backward(_p(self._packed), _p(face), _p(self._work), _p(d), _p(out), B, _st()),
-                       "s2l_syncnet_face_backward")
+            _abi.check(lib.s2l_syncnet_face_backward_prefix(_p(self._packed), _p(face), _p(self._work), _p(d), _p(out), B, FB, _st()),
+                       "s2l_syncnet_face_backward_prefix")
         return out
 
     def forward(self, audio_sequences, face_sequences):
@@ -126,15 +151,22 @@ class SyncNet_color(nn.Module):
         return self.embed_nhwc(audio_sequences, face_sequences.permute(0, 2, 3, 1))
 
 
-def sync_window(g_rgb: torch.Tensor, syncnet_T: int = 5) -> torch.Tensor:
-    """[B,3,T,H,W] RGB window -> face [B,H-H//2,W,3T] NHWC (BGR, lower half rows, frames on channels; training.py:588-590)."""
+def sync_window(g_rgb: torch.Tensor, syncnet_T: int = 5, out: torch.Tensor = None) -> torch.Tensor:
+    """[B,3,T,H,W] RGB window -> face [B,H-H//2,W,3T] NHWC (BGR, lower half rows, frames on channels; training.py:588-590).
+    out: a contiguous [B,H-H//2,W,3T] fp32 view to write into (e.g. one half of a pair batch)."""
     g = g_rgb.detach().to(torch.float32).contiguous()
     if g.device.type != "cuda":
         raise _abi.S2LError("sync_window: input must be on the GPU (no CPU fallback)")
     B, C, T, H, W = g.shape
     if C != 3 or T != syncnet_T:
         raise ValueError(f"rgb window must be [B,3,{syncnet_T},H,W], got {tuple(g.shape)}")
-    face = torch.empty(B, H - H // 2, W, 3 * T, dtype=torch.float32, device=g.device)
+    shape = (B, H - H // 2, W, 3 * T)
+    if out is None:
+        face = torch.empty(shape, dtype=torch.float32, device=g.device)
+    else:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != g.device:
+            raise ValueError(f"sync_window: out must be a contiguous fp32 {shape} tensor on {g.device}")
+        face = out
     with torch.cuda.device(g.device):
         _abi.check(_abi.load().s2l_sync_window(_p(g), _p(face), T, H, W, B, _st()), "s2l_sync_window")
     return face
@@ -177,13 +209,20 @@ class SyncLoss:
         dev = g_rgb_pos.device
         B, _, _, H, W = g_rgb_pos.shape
         ones = torch.ones(B, dtype=torch.float32, device=dev)
-        a, v = self.syncnet.embed_nhwc(mel, sync_window(g_rgb_pos, T))
+        if tuple(g_rgb_neg.shape) != tuple(g_rgb_pos.shape):
+            raise ValueError(f"positive and negative windows differ in shape: {tuple(g_rgb_pos.shape)}, {tuple(g_rgb_neg.shape)}")
+        # the reference embeds (mel, pos) and (mel, neg) in two SyncNet calls; the net is frozen and in eval mode, every window's
+        # embedding is a function of that window alone, so both face batches go through the encoder as one batch of 2B and the
+        # audio encoder runs once
+        face = torch.empty(2 * B, H - H // 2, W, 3 * T, dtype=torch.float32, device=dev)
+        sync_window(g_rgb_pos, T, out=face[:B])
+        sync_window(g_rgb_neg, T, out=face[B:])
+        a, v = self.syncnet.embed_pair_nhwc(mel, face)
         if want_grad:
-            pos, dv = self.cosine_loss(a, v, ones, weight, True)
+            pos, dv = self.cosine_loss(a, v[:B], ones, weight, True)
             d_pos = sync_window_backward(self.syncnet.face_backward(dv), T, H, W)
         else:
-            pos = self.cosine_loss(a, v, ones, weight)
-        a, v = self.syncnet.embed_nhwc(mel, sync_window(g_rgb_neg, T))
-        neg = self.cosine_loss(a, v, torch.zeros_like(ones), weight)
+            pos = self.cosine_loss(a, v[:B], ones, weight)
+        neg = self.cosine_loss(a, v[B:], torch.zeros_like(ones), weight)
         loss = pos + neg
         return (loss, d_pos) if want_grad else loss

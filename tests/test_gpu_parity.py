@@ -548,20 +548,40 @@ def test_syncnet_golden_embeddings_loss_and_gradient(golden, syncnet, dev):
     assert abs(float(tr.get_sync_contrastive_loss(mel, pos, neg)) - float(g["loss"])) <= 2e-6
 
 
+def _window_grad_close_or_tie(got, ref, margins, scale=None):
+    """d loss / d window per SAMPLE.  A sample is `tight` (max error <= 1e-4 of the gradient's max) unless one of its ReLU decisions
+    sits within fp32 rounding of a tie -- the oracle reports the sample's smallest |pre-activation| / rms over the face encoder
+    (`margins`, oracle.syncnet_encoder): with ~3e6 units per window that minimum is ~1e-7..1e-6 for EVERY input, the size of the
+    rounding difference between two summation orders, so no seed is tie-free.  A flipped unit changes the gradient inside its
+    receptive field by O(1) of its own contribution and nothing else: such a sample must still agree in the bulk (<= 30 % of the
+    entries beyond 2e-4, rmse <= 5e-3), needs a margin < 1e-6 to be excused, and at most B // 2 samples may be excused."""
+    B = got.shape[0]
+    scale = scale or float(ref.abs().max())
+    mm = torch.stack(margins).min(dim=0).values
+    excused = 0
+    for b in range(B):
+        err = (got[b] - ref[b]).abs() / scale
+        if float(err.max()) <= 1e-4:
+            continue
+        frac, rm = float((err > 2e-4).float().mean()), O.rmse(got[b], ref[b]) / scale
+        assert float(mm[b]) < 1e-6 and frac <= 0.3 and rm <= 5e-3, (b, float(mm[b]), frac, rm, float(err.max()))
+        excused += 1
+    assert excused <= B // 2, excused
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_sync_loss_vs_oracle_autograd(syncnet, dev, B):
     """Other batch sizes / seeds against the CPU oracle and its autograd; cosine_loss alone with mixed labels."""
     sd_ = O.to_sd(W.make_syncnet_state_dict(0))
     mel, pos, neg = (T(x) for x in W.synthetic_sync_batch(B, seed=10 + B))
     pos_o = pos.clone().requires_grad_(True)
-    loss_o = O.sync_contrastive_loss(sd_, mel, pos_o, neg, W.SYNCNET_FACE, W.SYNCNET_AUDIO)
+    margins = []
+    loss_o = O.sync_contrastive_loss(sd_, mel, pos_o, neg, W.SYNCNET_FACE, W.SYNCNET_AUDIO, pos_margins=margins)
     loss_o.backward()
     sl = s2l.SyncLoss(syncnet)
     loss, dpos = sl.get_sync_contrastive_loss(mel.to(dev), pos.to(dev), neg.to(dev), want_grad=True, weight=0.01)
     assert abs(float(loss) - 0.01 * float(loss_o)) <= 1e-7
-    scale = 0.01 * float(pos_o.grad.abs().max())
-    err = (dpos.cpu() - 0.01 * pos_o.grad).abs() / scale
-    assert float((err > 2e-4).float().mean()) <= 0.01 and float(err.max()) <= 2e-2
+    _window_grad_close_or_tie(dpos.cpu(), 0.01 * pos_o.grad, margins)
     rng = np.random.default_rng(B)
     a = torch.nn.functional.normalize(T(rng.random((5, 512), dtype=np.float32)), dim=1)
     v = torch.nn.functional.normalize(T(rng.random((5, 512), dtype=np.float32)), dim=1).requires_grad_(True)
@@ -571,6 +591,38 @@ def test_sync_loss_vs_oracle_autograd(syncnet, dev, B):
     got, dv = sl.cosine_loss(a.to(dev), v.detach().to(dev), y.to(dev), want_grad=True)
     assert abs(float(got) - float(ref)) <= 1e-6
     close(dv, v.grad, 1e-7, 1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_syncnet_pair_pass_equals_two_passes(syncnet, dev, B):
+    """s2l_syncnet_forward_pair / s2l_syncnet_face_backward_prefix (generated + negative windows as one batch of 2B, audio once)
+    against the two separate passes the reference makes.  Not the same bits: the split-K factor of the deep layers follows the
+    column count, so partial sums associate differently -- fp32 rounding only."""
+    from speech2lip_amd.syncnet import sync_window
+    mel, pos, neg = (T(x).to(dev) for x in W.synthetic_sync_batch(B, seed=40 + B))
+    fp, fn = sync_window(pos), sync_window(neg)
+    a1, vp = syncnet.embed_nhwc(mel, fn)
+    a1, vp = syncnet.embed_nhwc(mel, fp)
+    d = torch.nn.functional.normalize(T(np.random.default_rng(B).standard_normal((B, 512)).astype(np.float32)), dim=1).to(dev)
+    g1 = syncnet.face_backward(d)
+    _, vn = syncnet.embed_nhwc(mel, fn)
+    face = torch.empty(2 * B, *fp.shape[1:], device=dev)
+    assert sync_window(pos, out=face[:B]).data_ptr() == face.data_ptr()
+    sync_window(neg, out=face[B:])
+    assert torch.equal(face[:B], fp) and torch.equal(face[B:], fn)
+    a2, v2 = syncnet.embed_pair_nhwc(mel, face)
+    close(a2, a1.cpu(), 2e-7, 2e-6)
+    close(v2[:B], vp.cpu(), 2e-7, 2e-6)
+    close(v2[B:], vn.cpu(), 2e-7, 2e-6)
+    g2 = syncnet.face_backward(d)          # the first B windows of the pair pass
+    assert g2.shape == g1.shape
+    margins = []
+    O.syncnet_encoder(O.to_sd(W.make_syncnet_state_dict(0)), fp.cpu().permute(0, 3, 1, 2), "face_encoder", W.SYNCNET_FACE, margins=margins)
+    _window_grad_close_or_tie(g2.cpu(), g1.cpu(), margins)
+    with pytest.raises(ValueError):
+        syncnet.face_backward(torch.zeros(2 * B + 1, 512, device=dev))
+    with pytest.raises(ValueError):
+        syncnet.embed_pair_nhwc(mel, face[:2 * B - 1] if B > 1 else face[:0])
 
 
 def test_sync_window_layout_and_adjoint(dev):
