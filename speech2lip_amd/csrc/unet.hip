@@ -597,29 +597,45 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
   u4v pw[kWPer];
   // 8-wave form: the chunk's 36 KiB of weights as 36 LDS-DMA instructions of 1 KiB (lane l moves bytes [16 l, 16 l + 16)), wave w
   // issues pieces w, w + 8, ...; they land while the current chunk computes and are waited for (vmcnt) before the publishing barrier
-  auto dma_weights = [&](int cc) {
+  constexpr int kDmaPieces = kChunk16Halves * 2 / 1024, kDmaPer = (kDmaPieces + WAVES - 1) / WAVES;      // 36; 5 per wave (the last partial)
+  auto dma_piece = [&](int cc, int j) {      // piece wave + WAVES j of chunk cc's weights
     if constexpr (kDma) {
-      const char* wsrc = reinterpret_cast<const char*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
-      char* wdst = reinterpret_cast<char*>(lds_w + (cc & 1) * kChunk16Halves);
-      for (int p = wave; p < kChunk16Halves * 2 / 1024; p += WAVES)
+      const int p = wave + WAVES * j;
+      if (p < kDmaPieces) {
+        const char* wsrc = reinterpret_cast<const char*>(a.w16 + ((int64_t)ct * nchunks + cc) * kChunk16Halves);
+        char* wdst = reinterpret_cast<char*>(lds_w + (cc & 1) * kChunk16Halves);
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(wsrc + p * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) uint32_t*)(wdst + p * 1024), 16, 0, 0);
+      }
     }
   };
-  auto fetch = [&](int cc) {
-    const bool fromA = cc * kCC < a.CA;
-    const float* src = fromA ? inA : inB;
-    const int C = fromA ? a.CA : a.CB;
-    const int coff = fromA ? cc * kCC : cc * kCC - a.CA;
+  auto dma_weights = [&](int cc) {
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) {
-      const int i = threadIdx.x + k * kThreads;
-      const int pi = i / kQ, c4 = i % kQ;
-      const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
-      pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
-      if (!(S2L_UEXP & 2) && i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-        pin[k] = *reinterpret_cast<const f4*>(src + ((int64_t)gy * a.W + gx) * C + coff + 4 * c4);
-    }
+    for (int j = 0; j < kDmaPer; ++j) dma_piece(cc, j);
+  };
+  // the halo pixel each of this thread's loads reads is the same for every chunk of the tile: its index (or -1: outside the frame /
+  // past the halo) is formed once -- re-deriving it per chunk (two divisions, bounds, a 64-bit product per load) was 2.4 k cycles of
+  // issue per chunk and wave, next to 4.4 k of matrix work (tools/trace_conv16.py)
+  static_assert(kThreads % kQ == 0, "a thread keeps its channel quad across passes");
+  int pixoff[kInPer];
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) {
+    const int i = threadIdx.x + k * kThreads;
+    const int pi = i / kQ;
+    const int gy = y0 - 1 + pi / 18, gx = x0 - 1 + pi % 18;
+    pixoff[k] = (i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? gy * a.W + gx : -1;
+  }
+  const int c4x4 = 4 * (threadIdx.x % kQ);
+  auto fetch_one = [&](int cc, int k) {      // load k of chunk cc's halo tile into its staging register
+    const bool fromA = cc * kCC < a.CA;
+    const float* src = (fromA ? inA : inB) + (fromA ? cc * kCC : cc * kCC - a.CA) + c4x4;
+    const int C = fromA ? a.CA : a.CB;
+    pin[k] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (!(S2L_UEXP & 2) && pixoff[k] >= 0) pin[k] = *reinterpret_cast<const f4*>(src + (int64_t)pixoff[k] * C);
+  };
+  auto fetch = [&](int cc) {
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) fetch_one(cc, k);
     if constexpr (kDma) {
       dma_weights(cc);
     } else {
@@ -654,7 +670,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
     }
   };
   // halo pixel of this lane's column in N-block nb, before the tap offset
-  const int pbase = (4 * wave + (n >> 4)) * 18 + (n & 15);
+  // N-block nb of wave w: lanes 0..15 -> tile row 4 w + nb, lanes 16..31 -> row 4 w + 2 + nb (columns n & 15): the two rows of a
+  // 2x2 pooling window are the SAME lane's two N-blocks, its two columns are lanes n and n ^ 1 (one DPP quad permute) -- with rows
+  // (2 nb, 2 nb + 1) per block the pooled copy cost two ds_bpermute per value, 5 k cycles per tile (tools/trace_conv16.py)
+  const int pbase = (4 * wave + 2 * (n >> 4)) * 18 + (n & 15);
 #ifdef S2L_EXP_TRACE
   long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #define PH(k) do { const long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
@@ -667,10 +686,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
   __syncthreads();
   PH(0);
   for (int cc = 0; cc < nchunks; ++cc) {
-    // 8-wave form: the two waves of a SIMD are released by the same barrier; if both issued the next chunk's loads first (~1.5 k
-    // cycles of address arithmetic and texture-path issue, tools/trace_conv16.py) the matrix pipe would idle that long.  Waves
-    // 0..3 fetch before their MFMAs, waves 4..7 after their fifth tap: one of the two always has matrix work.
-    if (cc + 1 < nchunks && (!kDma || wave < 4)) fetch(cc + 1);
+    // 8-wave form: a wave issues in order, and every 1-KiB memory instruction waits its turn at the CU's one texture-address path
+    // (76 KiB per chunk = 1.2 k cycles of it): issued as a block -- before the MFMAs, or mid-way by half of the waves -- the next
+    // chunk's ten memory instructions were 2.4 k cycles in which that wave fed nothing to the matrix pipe (tools/trace_conv16.py).
+    // They are issued ONE PER TAP behind the tap's twelve MFMAs instead (taps 0..4), which are queued in the pipe while the
+    // address path digests the instruction; the last four taps give the loads time to land before the barrier.
+    if (cc + 1 < nchunks && !kDma) fetch(cc + 1);
     PH(1);
     const uint16_t* wcur = kDma ? lds_w + (cc & 1) * kChunk16Halves : lds_w;
     if constexpr (SPLIT) {
@@ -685,7 +706,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
           for (int mb = 0; mb < 2; ++mb) A[set][pt][mb] = reinterpret_cast<const u4v*>(wcur)[((t * 2 + pt) * 2 + mb) * 64 + lane];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            B[set][pt][nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * pt + 8 * hh);
+            B[set][pt][nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (nb + dy) * 18 + dx) * kPix16 + 16 * pt + 8 * hh);
         }
       };
       load_tap(0, 0);
@@ -693,7 +714,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
       for (int t = 0; t < 9; ++t) {
         const int cur = t & 1;
         if (t + 1 < 9) load_tap(t + 1, cur ^ 1);
-        if (kDma && t == 5 && wave >= 4 && cc + 1 < nchunks) fetch(cc + 1);
         __builtin_amdgcn_sched_barrier(0);
         // smallest terms first: the two cross terms, then hi x hi
 #pragma unroll
@@ -709,6 +729,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][0][mb], B[cur][0][nb], acc[mb][nb]);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kDma) {
+          if (cc + 1 < nchunks) {
+            if (t < kInPer) fetch_one(cc + 1, t);
+            if (t < kDmaPer) dma_piece(cc + 1, t);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     } else {
 #pragma unroll
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
           for (int mb = 0; mb < 2; ++mb) A[mb] = reinterpret_cast<const u4v*>(lds_w)[((t * 2 + ks) * 2 + mb) * 64 + lane];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            B[nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (2 * nb + dy) * 18 + dx) * kPix16 + 16 * ks + 8 * hh);
+            B[nb] = *reinterpret_cast<const u4v*>(lds_in + (pbase + (nb + dy) * 18 + dx) * kPix16 + 16 * ks + 8 * hh);
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -749,11 +776,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
   }
 #endif
 
-  // epilogue: D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel (row 4 wave + 2 nb + (n >> 4), col n & 15)
+  // epilogue: D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel (row 4 wave + 2 (n >> 4) + nb, col n & 15)
   const int gx = x0 + (n & 15);
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    const int gy = y0 + 4 * wave + 2 * nb + (n >> 4);
+    const int gy = y0 + 4 * wave + 2 * (n >> 4) + nb;
     const bool ok = gy < a.H && gx < a.W;
     const int64_t pix = frame * (int64_t)a.H * a.W + (int64_t)gy * a.W + gx;
     if (FUSE_OUT) {
@@ -793,22 +820,374 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
           }
           *reinterpret_cast<f4*>(dst) = h;
         }
-        if (!FUSE_OUT && a.pool) {   // MaxPool2d(2): the N-block's two rows are lanes n and n ^ 16, the column pair n and n ^ 1
-          const int H2 = a.H / 2, W2 = a.W / 2;
-          const int py2 = (y0 + 4 * wave + 2 * nb) / 2, px2 = gx / 2;
-          f4 m;
+      }
+  }
+  if (!FUSE_OUT && a.pool) {   // MaxPool2d(2): rows = the lane's two N-blocks, columns = lanes n and n ^ 1
+    const int H2 = a.H / 2, W2 = a.W / 2;
+    const int py2 = (y0 + 4 * wave + 2 * (n >> 4)) / 2, px2 = gx / 2;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(acc[mb][nb][4 * rr + r], 0.f);
-            v = fmaxf(v, __shfl_xor(v, 16));
-            m[r] = fmaxf(v, __shfl_xor(v, 1));
-          }
-          if (!(n & 17) && py2 < H2 && px2 < W2)
-            *reinterpret_cast<f4*>(a.pool + ((frame * H2 + py2) * (int64_t)W2 + px2) * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = m;
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        f4 m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaxf(fmaxf(acc[mb][0][4 * rr + r], acc[mb][1][4 * rr + r]), 0.f);
+          const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+          m[r] = fmaxf(v, o);
         }
+        if (!(n & 1) && py2 < H2 && px2 < W2)
+          *reinterpret_cast<f4*>(a.pool + ((frame * H2 + py2) * (int64_t)W2 + px2) * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = m;
       }
   }
   CONV_TRACE(20);
+}
+
+// ---- the split-bf16 convolution as a PERSISTENT kernel with ONE barrier per chunk (round 3) ------------------------------------
+// Same arithmetic, tile (32 x 16 pixels, 64 output channels, eight waves) and accumulation order as
+// conv3x3_bf16_kernel<.., SPLIT = true, 8>: the outputs are the same bits (tools/cmp_split_kernels.py, test_unet_split_*).  What
+// changed is when memory is touched.  tools/trace_conv16.py on the one-tile-per-workgroup form: of 55-98 k cycles per tile 10 k were
+// the exposed loads of the first chunk; every chunk paid barrier -> commit (hi / lo conversion + LDS writes) -> barrier with the
+// matrix pipe idle, and ~2.4 k cycles at the first barrier for the NEXT chunk's loads, because __syncthreads drains vmcnt; and with
+// all eight waves in step, operand reads issued as a block of eight kept the LDS busy for ~500 cycles per tap in which nobody had
+// operands.  Here:
+//  * a workgroup walks a contiguous range of (frame, channel tile, y, x) tiles; the chunks of all its tiles form ONE stream;
+//  * TWO halo buffers (64 bytes per pixel, no padding: the 16-byte segment index is XORed with (column >> 2) & 3, rows are 20 pixels
+//    = 5 x 256 bytes apart, so the sixteen pixels of an operand read cover all 64 banks) and two weight buffers: during chunk g the
+//    weights of g + 1 arrive by LDS-DMA, the halo values of g + 1 (requested during g - 1, held in registers) are converted and
+//    written behind the MFMAs of taps 5..8, and the values of g + 2 are requested -- one barrier per chunk, no commit phase;
+//  * the requests are assembly text (the compiler would drain vmcnt before every LDS access that may alias an outstanding LDS-DMA)
+//    and the waits are counted: loads return in order, so "at most n outstanding" retires everything older than the n newest
+//    (a tile's epilogue stores in between only make a wait stricter);
+//  * the eight operand reads of tap t + 1 are issued one behind each of the first eight MFMAs of tap t.
+constexpr int kSwzRow = 20 * 64;                                // bytes between halo rows
+constexpr int kSwzIn = 34 * kSwzRow;                            // 43 520 bytes per halo buffer
+constexpr int kSplitLds = 2 * kSwzIn + 2 * kChunk16Halves * 2;  // 87 040 + 73 728 = 160 768 bytes
+template <int N> struct IntC { static constexpr int value = N; };
+
+template <bool FUSE_OUT>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
+  constexpr int kThreads = 512, kQ = 4, kInQuads = 34 * 18 * kQ, kInPer = 5;
+  constexpr int kDmaPieces = kChunk16Halves * 2 / 1024, kDmaPer = 5;        // 36 pieces of 1 KiB: waves 0..3 move five, 4..7 four
+  static_assert(kInPer * kThreads >= kInQuads && kDmaPer * 8 >= kDmaPieces, "coverage");
+  extern __shared__ __attribute__((aligned(16))) char split_smem[];
+  char* const lds_in = split_smem;                              // two halo buffers
+  const uint16_t* const lds_w = reinterpret_cast<const uint16_t*>(split_smem + 2 * kSwzIn);      // two weight buffers
+  const uint32_t lds_w_addr = (uint32_t)(uintptr_t)(split_smem + 2 * kSwzIn);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, hh = lane >> 5;
+  const int nchunks = (a.CA + a.CB) / 16;                       // even for every layer of the net (checked by the launcher)
+  const int tiles_y = (a.H + 31) / 32;
+  const int64_t total = (int64_t)a.tiles_x * tiles_y * a.n_ct * a.n_frames_asm;
+  const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
+  if (tile0 >= tile_end) return;
+#ifdef S2L_EXP_TRACE
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 24] = tlast;
+#define PHS(k) do { const long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } while (0)
+#else
+#define PHS(k) do { } while (0)
+#endif
+  const int n_dma = wave < 4 ? 5 : 4;                           // this wave's weight pieces per chunk
+
+  struct TilePos { int x0, y0, ct; int64_t frame; };
+  auto decode = [&](int t) {
+    TilePos p;
+    p.x0 = (t % a.tiles_x) * 16;
+    t /= a.tiles_x;
+    p.y0 = (t % tiles_y) * 32;
+    t /= tiles_y;
+    p.ct = t % a.n_ct;
+    p.frame = t / a.n_ct;
+    return p;
+  };
+
+  // ---- per-thread LDS offsets (independent of the tile) ----
+  // commit: quad i = tid + 512 k of the halo tile = pixel i / 4 (row-major 34 x 18), channels 4 (i % 4) .. + 3: 8 bytes of hi at
+  // segment (c4 >> 1), 8 bytes of lo at segment 2 + (c4 >> 1) = the hi address ^ 32
+  int coff[kInPer];
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) {
+    const int i = threadIdx.x + k * kThreads, pi = i / kQ, c4 = i % kQ;
+    const int row = pi / 18, col = pi % 18;
+    coff[k] = row * kSwzRow + col * 64 + ((((c4 >> 1) ^ ((col >> 2) & 3))) << 4) + (c4 & 1) * 8;
+  }
+  // operand reads: lane (n, hh) of N-block blk, tap (dy, dx), part pt: pixel (row 4 wave + 2 (n >> 4) + blk + dy, col (n & 15) + dx),
+  // segment 2 pt + hh; (blk + dy) * kSwzRow is an immediate offset
+  int zb[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int col = (n & 15) + dx;
+      zb[dx][pt] = (4 * wave + 2 * (n >> 4)) * kSwzRow + col * 64 + (((2 * pt + hh) ^ ((col >> 2) & 3)) << 4);
+    }
+
+  // ---- input stream: the next chunk whose halo values are requested ----
+  int f_tile = tile0, f_cc = 0;
+  int pixoff[kInPer], f_vbits = 0;
+  const float *f_inA = nullptr, *f_inB = nullptr;
+  const int c4x4 = 4 * (threadIdx.x % kQ);
+  auto f_setup = [&]() {
+    const TilePos p = decode(f_tile);
+    f_vbits = 0;
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) {
+      const int i = threadIdx.x + k * kThreads;
+      const int pi = i / kQ;
+      const int gy = p.y0 - 1 + pi / 18, gx = p.x0 - 1 + pi % 18;
+      const bool ok = i < kInQuads && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      pixoff[k] = ok ? gy * a.W + gx : 0;                       // (clamped: the load is always issued, the value dropped at commit)
+      f_vbits |= (ok ? 1 : 0) << k;
+    }
+    f_inA = a.inA + p.frame * (int64_t)a.H * a.W * a.CA;
+    f_inB = a.inB ? a.inB + p.frame * (int64_t)a.H * a.W * a.CB : nullptr;
+  };
+  f4 pin[2][kInPer];
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) pin[0][k] = pin[1][k] = (f4){0.f, 0.f, 0.f, 0.f};
+  int pvalid[2] = {0, 0};
+  auto fetch_one = [&](int k, auto SET) {
+    const bool fromA = f_cc * 16 < a.CA;
+    const float* src = (fromA ? f_inA : f_inB) + (fromA ? f_cc * 16 : f_cc * 16 - a.CA) + c4x4;
+    const int C = fromA ? a.CA : a.CB;
+    // ("+v": the staging register is one physical register from request to commit, which only happens behind a counted wait;
+    // every request of a register is the SAME instruction in straight-line code -- a second site would make the compiler copy it)
+    f4& dstreg = pin[decltype(SET)::value][k];
+    const float* addr = src + (int64_t)pixoff[k] * C;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dstreg) : "v"(addr) : "memory");
+  };
+  auto f_advance = [&](auto SET) {
+    pvalid[decltype(SET)::value] = f_vbits;
+    if (++f_cc == nchunks) {
+      f_cc = 0;
+      if (++f_tile < tile_end) f_setup();
+    }
+  };
+  // ---- weight stream: the next chunk whose weights are moved ----
+  int w_tile = tile0, w_cc = 0;
+  const uint16_t* w_ptr = a.w16 + (int64_t)decode(tile0).ct * nchunks * kChunk16Halves;      // chunk (w_tile, w_cc)
+  auto dma_piece = [&](int j, int buf) {
+    const int p = wave + 8 * j;
+    if (p < kDmaPieces) {
+      const char* wsrc = reinterpret_cast<const char*>(w_ptr) + p * 1024 + lane * 16;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_w_addr + (uint32_t)(buf * kChunk16Halves * 2 + p * 1024));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(wsrc) : "memory");
+    }
+  };
+  auto w_advance = [&]() {
+    w_ptr += kChunk16Halves;
+    if (++w_cc == nchunks) {
+      w_cc = 0;
+      if (++w_tile < tile_end) w_ptr = a.w16 + (int64_t)decode(w_tile).ct * nchunks * kChunk16Halves;
+    }
+  };
+  auto commit_one = [&](int k, auto SET, int buf) {
+    constexpr int set = decltype(SET)::value;
+    const int i = threadIdx.x + k * kThreads;
+    if (i < kInQuads) {
+      f4 v = pin[set][k];
+      if (!((pvalid[set] >> k) & 1)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      uint2 h, l;
+      h.x = pack_bf16x2(v[0], v[1]);
+      h.y = pack_bf16x2(v[2], v[3]);
+      l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
+      l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+      char* dst = lds_in + buf * kSwzIn;
+      *reinterpret_cast<uint2*>(dst + coff[k]) = h;
+      *reinterpret_cast<uint2*>(dst + (coff[k] ^ 32)) = l;
+    }
+  };
+  auto wait_loads = [&](int newer) {      // every vector-memory LOAD except the `newer` most recent ones has landed
+    switch (newer) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+  };
+  // the wait that retires the staged VALUES of a set names them as in-out operands: what commit_one reads are this statement's
+  // outputs, so no pass can move the conversion arithmetic (pure functions of the registers, as far as the compiler knows) above it
+  auto wait_values = [&](int newer, auto SET) {
+    constexpr int set = decltype(SET)::value;
+#define S2L_WAIT_VALUES(N)                                                                                                       \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pin[set][0]), "+v"(pin[set][1]), "+v"(pin[set][2]), "+v"(pin[set][3]), "+v"(pin[set][4]) : : "memory")
+    switch (newer) {
+      case 0: S2L_WAIT_VALUES(0); break;
+      case 4: S2L_WAIT_VALUES(4); break;
+      case 5: S2L_WAIT_VALUES(5); break;
+      case 9: S2L_WAIT_VALUES(9); break;
+      default: S2L_WAIT_VALUES(10); break;
+    }
+#undef S2L_WAIT_VALUES
+  };
+  auto barrier_lgkm = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // ---- prologue: chunk 0 (values + weights) and the values of chunk 1 ----
+  const int64_t chunks_total = (int64_t)(tile_end - tile0) * nchunks;      // >= 2
+  f_setup();
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+  f_advance(IntC<0>{});
+#pragma unroll
+  for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
+  w_advance();
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+  f_advance(IntC<1>{});
+  wait_values(5, IntC<0>{});
+#pragma unroll
+  for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
+  barrier_lgkm();
+  PHS(0);
+
+  int64_t seq = 0;
+  f16v acc[2][2];
+
+  auto step = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;                   // chunk parity = its halo / weight buffer = the staging set of chunk g + 2
+    const bool next1 = seq + 1 < chunks_total;                  // chunk g + 1 exists: its weights move, its values are committed
+    const bool next2 = seq + 2 < chunks_total;                  // chunk g + 2 exists: its values are requested into pin[set]
+    const int issued = (next1 ? n_dma : 0) + (next2 ? kInPer : 0);
+    const uint16_t* wcur = lds_w + set * kChunk16Halves;
+    const char* icur = lds_in + set * kSwzIn;
+    u4v A[2][2][2], B[2][2][2];   // [register set][part: hi, lo][block]
+    // operand read i (0..7) of tap t into register set os, in the order the tap's MFMAs need them: lo weights, hi pixels (first
+    // cross term), lo pixels (second), hi weights (third)
+    auto read_one = [&](int t, int os, int i) {
+      const int dy = t / 3, dx = t % 3;
+      const int kind = i >> 1, blk = i & 1;      // 0: A lo, 1: B hi, 2: B lo, 3: A hi
+      if (kind == 0 || kind == 3) {
+        const int pt = kind == 0 ? 1 : 0;
+        A[os][pt][blk] = reinterpret_cast<const u4v*>(wcur)[((t * 2 + pt) * 2 + blk) * 64 + lane];
+      } else {
+        const int pt = kind == 1 ? 0 : 1;
+        B[os][pt][blk] = *reinterpret_cast<const u4v*>(icur + zb[dx][pt] + (blk + dy) * kSwzRow);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_one(0, 0, i);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int cur = t & 1;
+      if (t == 5 && next1) wait_values(issued, IntC<set ^ 1>{});      // the values of chunk g + 1 (requested during g - 1) have landed
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {      // smallest terms first: lo x hi, hi x lo, hi x hi
+        const int g = m >> 2, mb = (m >> 1) & 1, nb = m & 1;
+        const int pa = g == 0 ? 1 : 0, pb = g == 1 ? 1 : 0;
+        acc[mb][nb] = mfma32_bf16(A[cur][pa][mb], B[cur][pb][nb], acc[mb][nb]);
+        if (m < 8 && t + 1 < 9) read_one(t + 1, cur ^ 1, m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // behind tap 0..4: two requests each, weights first (they are needed at the end of THIS chunk): D0 D1 | D2 D3 | D4 L0 | L1 L2 | L3 L4
+      if (t < 5 && !(S2L_UEXP & 32)) {
+        const int r0 = 2 * t, r1 = 2 * t + 1;
+        if (r0 < 5) { if (next1) dma_piece(r0, set ^ 1); } else if (next2) fetch_one(r0 - 5, SET);
+        if (r1 < 5) { if (next1) dma_piece(r1, set ^ 1); } else if (next2) fetch_one(r1 - 5, SET);
+      }
+      // behind tap 5..8: the values of chunk g + 1 -> the other halo buffer (2 + 1 + 1 + 1 quads)
+      if (t >= 5 && next1) {
+        if (t == 5) commit_one(0, IntC<set ^ 1>{}, set ^ 1);
+        commit_one(t - 4, IntC<set ^ 1>{}, set ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PHS(1);
+    if (next1) w_advance();
+    if (next2) f_advance(SET);
+    ++seq;
+    PHS(5);
+    wait_loads(next2 ? kInPer : 0);                             // the weights of chunk g + 1 have landed (the values of g + 2 may fly)
+    PHS(3);
+    barrier_lgkm();
+    PHS(2);
+  };
+
+  for (int tile = tile0; tile < tile_end; ++tile) {
+    const TilePos tp = decode(tile);
+    const int x0 = tp.x0, y0 = tp.y0, ct = tp.ct;
+    const int64_t frame = tp.frame;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = a.bias ? a.bias[ct * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
+    // (the compiler waits for the bias loads HERE, not at the first MFMA inside the chunk loop, where its vmcnt(0) would also
+    // drain the pipeline's requests on every pass)
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+    for (int cc = 0; cc < nchunks; cc += 2) {
+      step(IntC<0>{});
+      step(IntC<1>{});
+    }
+
+    // epilogue (as conv3x3_bf16_kernel): D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel
+    // (row 4 wave + 2 (n >> 4) + nb, col n & 15)
+    const int gx = x0 + (n & 15);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int gy = y0 + 4 * wave + 2 * (n >> 4) + nb;
+      const bool ok = gy < a.H && gx < a.W;
+      const int64_t pix = frame * (int64_t)a.H * a.W + (int64_t)gy * a.W + gx;
+      if (FUSE_OUT) {
+        float p3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float h = fmaxf(acc[mb][nb][r], 0.f);
+            const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) p3[o] = fmaf(a.outw[o * 64 + c], h, p3[o]);
+          }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) p3[o] += __shfl_xor(p3[o], 32);
+        if (hh == 0 && ok) {
+          float* o3 = a.out3 + pix * 3;
+          o3[0] = p3[0] + a.outb[0];
+          o3[1] = p3[1] + a.outb[1];
+          o3[2] = p3[2] + a.outb[2];
+        }
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          f4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (a.relu || FUSE_OUT) ? fmaxf(acc[mb][nb][4 * rr + r], 0.f) : acc[mb][nb][4 * rr + r];
+          if (ok && a.out) *reinterpret_cast<f4*>(a.out + pix * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = h;
+        }
+    }
+    if (!FUSE_OUT && a.pool) {   // MaxPool2d(2): rows = the lane's two N-blocks, columns = lanes n and n ^ 1
+      const int H2 = a.H / 2, W2 = a.W / 2;
+      const int py2 = (y0 + 4 * wave + 2 * (n >> 4)) / 2, px2 = gx / 2;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          f4 m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(fmaxf(acc[mb][0][4 * rr + r], acc[mb][1][4 * rr + r]), 0.f);
+            const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+            m[r] = fmaxf(v, o);
+          }
+          if (!(n & 1) && py2 < H2 && px2 < W2)
+            *reinterpret_cast<f4*>(a.pool + ((frame * H2 + py2) * (int64_t)W2 + px2) * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = m;
+        }
+    }
+    PHS(0);       // (epilogue + next tile's bias: counted with the prologue)
+  }
+#ifdef S2L_EXP_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    long long* tt = a.trace + blockIdx.x * 24;
+    for (int k = 0; k < 6; ++k) tt[2 + k] = tph[k];
+    tt[1] = chunks_total;
+    tt[20] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // ---- the forward convolution with its body as one fixed-register assembly text (csrc/gen_conv_body.py: persistent, one wave
@@ -851,6 +1230,12 @@ __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
 // The assembly kernel takes the launch if it has the epilogue: A | B of equal width, an even number of 16-channel chunks,
 // per-frame byte offsets that fit 31 bits, and (bias + ReLU [+ pooling | + fused output]) or (no bias, no ReLU [+ gate]).
 static std::atomic<int> g_conv_kernel_kind{0};
+static std::atomic<int> g_split_kernel_kind{0};      // 0: conv3x3_split_kernel (persistent), 1: conv3x3_bf16_kernel<.., true, 8> (one tile per workgroup)
+extern "C" int s2l_set_unet_split_kernel(int kind) {
+  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+  g_split_kernel_kind.store(kind, std::memory_order_relaxed);
+  return S2L_OK;
+}
 extern "C" int s2l_set_unet_conv_kernel(int kind) {
   if (kind != 0 && kind != 1) return S2L_E_SIZE;
   g_conv_kernel_kind.store(kind, std::memory_order_relaxed);
@@ -901,15 +1286,24 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
-  if (a.w16 && split) {      // the 8-wave form: 32 x 16-pixel tiles, > 64 KiB of dynamic LDS (opt-in per device)
-    const dim3 wgrid(a.tiles_x, (H + 31) / 32, (unsigned)gz);
-    static LdsOptIn wflags[2];
+  if (a.w16 && split) {      // the 8-wave forms: 32 x 16-pixel tiles, > 64 KiB of dynamic LDS (opt-in per device)
     int dev = 0, n_cu = 0;
     int rc = current_device_cus(&dev, &n_cu);
     if (rc) return rc;
-    void (*const kern)(ConvArgs) = out3 ? conv3x3_bf16_kernel<true, true, 8> : conv3x3_bf16_kernel<false, true, 8>;
-    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kBf16WideLds, wflags[out3 ? 1 : 0], dev))) return rc;
-    hipLaunchKernelGGL(kern, wgrid, dim3(512), kBf16WideLds, st, a);
+    const int64_t total = (int64_t)a.tiles_x * ((H + 31) / 32) * gz;
+    if (g_split_kernel_kind.load(std::memory_order_relaxed) == 0 && ((CA + CB) / 16) % 2 == 0 && total < 0x7fffffff) {
+      static LdsOptIn pflags[2];        // persistent, two chunks ahead
+      void (*const kern)(ConvArgs) = out3 ? conv3x3_split_kernel<true> : conv3x3_split_kernel<false>;
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kSplitLds, pflags[out3 ? 1 : 0], dev))) return rc;
+      a.n_frames_asm = (int)F;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kSplitLds, st, a);
+    } else {
+      const dim3 wgrid(a.tiles_x, (H + 31) / 32, (unsigned)gz);
+      static LdsOptIn wflags[2];
+      void (*const kern)(ConvArgs) = out3 ? conv3x3_bf16_kernel<true, true, 8> : conv3x3_bf16_kernel<false, true, 8>;
+      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kBf16WideLds, wflags[out3 ? 1 : 0], dev))) return rc;
+      hipLaunchKernelGGL(kern, wgrid, dim3(512), kBf16WideLds, st, a);
+    }
   }
   else if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
