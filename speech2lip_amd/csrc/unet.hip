@@ -862,7 +862,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
 //  * the eight operand reads of tap t + 1 are issued one behind each of the first eight MFMAs of tap t.
 constexpr int kSwzRow = 20 * 64;                                // bytes between halo rows
 constexpr int kSwzIn = 34 * kSwzRow;                            // 43 520 bytes per halo buffer
-constexpr int kSplitLds = 2 * kSwzIn + 2 * kChunk16Halves * 2;  // 87 040 + 73 728 = 160 768 bytes
+constexpr int kSplitBias = 2 * kSwzIn + 2 * kChunk16Halves * 2;  // 87 040 + 73 728 = 160 768 bytes, then the layer's biases (<= 128)
+constexpr int kSplitLds = kSplitBias + 512;
 template <int N> struct IntC { static constexpr int value = N; };
 
 template <bool FUSE_OUT>
@@ -1024,6 +1025,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
   };
   auto barrier_lgkm = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+  // the layer's biases wait in LDS: read from global memory at every tile start, their ~2 k cycles of latency were exposed
+  float* const lds_bias = reinterpret_cast<float*>(split_smem + kSplitBias);
+  if (threadIdx.x < 128) lds_bias[threadIdx.x] = (a.bias && (int)threadIdx.x < a.n_ct * 64) ? a.bias[threadIdx.x] : 0.f;
+
   // ---- prologue: chunk 0 (values + weights) and the values of chunk 1 ----
   const int64_t chunks_total = (int64_t)(tile_end - tile0) * nchunks;      // >= 2
   f_setup();
@@ -1113,10 +1118,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = a.bias ? a.bias[ct * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] : 0.f;
-    // (the compiler waits for the bias loads HERE, not at the first MFMA inside the chunk loop, where its vmcnt(0) would also
-    // drain the pipeline's requests on every pass)
-    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        for (int rr = 0; rr < 4; ++rr) {
+          const f4 b = *reinterpret_cast<const f4*>(lds_bias + ct * 64 + mb * 32 + 8 * rr + 4 * hh);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mb][nb][4 * rr + r] = b[r];
+        }
     for (int cc = 0; cc < nchunks; cc += 2) {
       step(IntC<0>{});
       step(IntC<1>{});
@@ -1150,16 +1156,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
           o3[2] = p3[2] + a.outb[2];
         }
       }
+      if (!a.out) continue;       // (FUSE_OUT: the last hidden activation is kept only for a backward pass)
+      // The activation leaves through LDS: as the MFMA leaves it, a store instruction would write 16 bytes to each of 64 different
+      // 128-byte lines (lane = pixel); transposed, lane l writes channel quad l & 7 of pixel l >> 3: eight whole lines per
+      // instruction.  Staging = the four 1-KiB pieces of weight buffer 1 that THIS wave's LDS-DMA writes (wave + 8 j): the buffer
+      // was last read in the chunk that just ended, and the only later writer of these pieces is this wave, after its epilogue.
+      // [32 pixels][32 channels] fp32, 128 bytes per pixel, the 16-byte quad index XORed with (pixel >> 1) & 7 (conflict-free both ways).
+      char* const stage = split_smem + 2 * kSwzIn + kChunk16Halves * 2 + wave * 1024;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           f4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (a.relu || FUSE_OUT) ? fmaxf(acc[mb][nb][4 * rr + r], 0.f) : acc[mb][nb][4 * rr + r];
-          if (ok && a.out) *reinterpret_cast<f4*>(a.out + pix * a.cout + ct * 64 + mb * 32 + 8 * rr + 4 * hh) = h;
+          *reinterpret_cast<f4*>(stage + (n >> 3) * 8192 + (n & 7) * 128 + (((2 * rr + hh) ^ ((n >> 1) & 7)) << 4)) = h;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int px = 8 * q + (lane >> 3), chq = lane & 7;
+          const f4 h = *reinterpret_cast<const f4*>(stage + q * 8192 + (px & 7) * 128 + ((chq ^ ((px >> 1) & 7)) << 4));
+          const int sy = y0 + 4 * wave + 2 * (px >> 4) + nb, sx = x0 + (px & 15);
+          if (sy < a.H && sx < a.W)
+            *reinterpret_cast<f4*>(a.out + (frame * (int64_t)a.H * a.W + (int64_t)sy * a.W + sx) * a.cout + ct * 64 + mb * 32 + 4 * chq) = h;
+        }
+      }
     }
+    PHS(4);
     if (!FUSE_OUT && a.pool) {   // MaxPool2d(2): rows = the lane's two N-blocks, columns = lanes n and n ^ 1
       const int H2 = a.H / 2, W2 = a.W / 2;
       const int py2 = (y0 + 4 * wave + 2 * (n >> 4)) / 2, px2 = gx / 2;

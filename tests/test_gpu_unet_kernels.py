@@ -63,3 +63,27 @@ def test_assembly_and_cpp_convolutions_agree_bit_for_bit(unet, shape):
 
 def test_conv_kernel_switch_rejects_other_kinds():
     assert _abi.load().s2l_set_unet_conv_kernel(2) == -2 and _abi.load().s2l_set_unet_conv_kernel(-1) == -2
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4), (1, 33, 17), (3, 37, 501), (2, 64, 48), (1, 500, 500), (7, 200, 333), (40, 96, 96)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_split_persistent_kernel_equals_the_one_tile_form(unet, shape):
+    """The split-bf16 layers run in a persistent kernel (tiles as one chunk stream per workgroup, two swizzled halo buffers, LDS-DMA
+    weights, counted vmcnt waits, one barrier per chunk, the activation leaving through LDS): the same products in the same
+    order as conv3x3_bf16_kernel<.., SPLIT, 8>, so the SAME BITS -- over single-tile frames, partial tiles, fewer tiles than
+    workgroups and several tiles per workgroup (the streams' tile crossings), repeated (a counted wait that is one short shows
+    as run-to-run differences)."""
+    F, H, Wd = shape
+    dev = next(unet.parameters()).device
+    x = torch.from_numpy(np.random.default_rng(H * 1000 + Wd).random((F, H, Wd, 3), dtype=np.float32)).to(dev)
+    lib = _abi.load()
+    try:
+        assert lib.s2l_set_unet_split_kernel(1) == 0
+        ref = unet.forward_nhwc(x, precision="split").clone()
+        assert lib.s2l_set_unet_split_kernel(0) == 0
+        for _ in range(3):
+            assert torch.equal(unet.forward_nhwc(x, precision="split"), ref)
+    finally:
+        lib.s2l_set_unet_split_kernel(0)
+    assert float(ref.abs().max()) > 0
+    assert lib.s2l_set_unet_split_kernel(2) == -2

@@ -34,7 +34,7 @@ for launch in range(9):
     ph = tl[:, 2:8] / np.maximum(nch[:, None], 1)
     names = ["prologue/chunk", "issue", "mfma", "barrier1", "commit", "barrier2"]
     if len(tl) <= 256:      # the persistent kernel: one record per workgroup, phases summed over all its chunks
-        names = ["prologue+epilogues/chunk", "mfma+requests+commit", "barrier", "weights wait", "(unused)", "advance"]
+        names = ["prologue+epilogues/chunk", "mfma+requests+commit", "barrier", "weights wait", "epilogue stores", "advance"]
     inloop = tl[:, 2:8].sum(axis=1)
     span = tl[:, 20].max() - tl[:, 0].min()
     print(f"layer {launch + 1}: {len(tl)} workgroups x {int(np.median(nch))} chunks, lifetime {np.median(life):.0f} cycles = {np.median(life / np.maximum(nch, 1)):.0f} per chunk; "
