@@ -233,9 +233,8 @@ class SimpleUnetLight(nn.Module):
                                                            ctypes.c_float(momentum), 1 if update_running else 0, p(x), p(saved),
                                                            p(scratch), p(out), H, W, F_, st), "s2l_unet_train_forward_bf16")
         if update_running:
-            for mod in self.modules():
-                if isinstance(mod, nn.BatchNorm2d):
-                    mod.num_batches_tracked += 1
+            # (one fused launch for the ten counters: as ten `+= 1` they were 400 launches per sync step in train-mode BatchNorm)
+            torch._foreach_add_([mod.num_batches_tracked for mod in self.modules() if isinstance(mod, nn.BatchNorm2d)], 1)
             # the folded eval-mode blobs are stale now: the kernel rewrote the running statistics in place, which does not bump
             # the tensors' version counters (the cache keys), and BOTH the fp32 and the bf16 blob fold them
             self._packed = self._packed_key = None
