@@ -290,7 +290,7 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
         p.requires_grad = False
     # eval: running statistics (train.py:195), crop window + bf16 operands; train: the mode the reference's loop really leaves the
     # frozen net in (Trainer.train_step's model.train(), training.py:150; golden G16): batch statistics per one-frame call,
-    # whole 500x500 frames, exact fp32
+    # whole 500x500 frames (bf16 operands too when the step's precision is bf16)
     if not unet_train_mode:
         m.post_fusion_unet.eval()
     net = s2l.SyncNet_color().to(dev)
@@ -337,11 +337,7 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
     m = make_model(dev, H, Wd, unet=True, train=True)
     for p in m.post_fusion_unet.parameters():
         p.requires_grad = False
-    # eval: running statistics (train.py:195), crop window + bf16 operands; train: the mode the reference's loop really leaves the
-    # frozen net in (Trainer.train_step's model.train(), training.py:150; golden G16): batch statistics per one-frame call,
-    # whole 500x500 frames, exact fp32
-    if not unet_train_mode:
-        m.post_fusion_unet.eval()
+    m.post_fusion_unet.eval()      # (eval-mode BatchNorm: running statistics, crop window; see bench_train_sync for the train-mode form)
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     lp = s2l.LPIPS(pretrained=False, net="alex", version="0.1").to(dev)      # seeded weights are loaded below

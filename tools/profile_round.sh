@@ -26,13 +26,17 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -
 timeout 300 rocprofv3 --kernel-trace --pmc TA_BUSY_avr SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/cpmc_sq -o s -- $C > $O/cpmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/tpmc_fetch -o s -- python $R/tools/bench_train.py 64 bf16 > $O/tpmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/tpmc_write -o s -- python $R/tools/bench_train.py 64 bf16 > $O/tpmc_write.log 2>&1
+# the split-bf16 U-Net convolution: matrix-pipe busy and HBM bytes per launch
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/upmc_mfma -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/upmc_fetch -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/upmc_write -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_write.log 2>&1
 ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \
             "small_clips:tools/bench_small_clips.py" "config3_split:tools/bench_config3.py 1000 100 --split" \
             "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
-            "stage1_full:tools/bench_train.py 8 bf16 --full"; do
+            "stage1_full:tools/bench_train.py 8 bf16 --full" "stage1_sync_trainbn:tools/bench_train.py 64 bf16 --sync=8 --trainbn"; do
   name=${spec%%:*}; cmd=${spec#*:}
   timeout 300 python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1

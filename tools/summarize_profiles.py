@@ -64,7 +64,8 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
                     ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
                     ("config3_nounet", "BASELINE config 3: lip 128x128 + composite, 5000 frames: python tools/bench_config3.py 5000 500"),
                     ("stage1_sync", "BASELINE config 5 with the sync loss: python tools/bench_train.py 64 bf16 --sync=8"),
-                    ("stage1_full", "full stage-1 iteration (MSE + LPIPS on lip and face, U-Net, sync window): python tools/bench_train.py 8 bf16 --full")):
+                    ("stage1_full", "full stage-1 iteration (MSE + LPIPS on lip and face, U-Net, sync window): python tools/bench_train.py 8 bf16 --full"),
+                    ("stage1_sync_trainbn", "config 5 with the sync loss, frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16): python tools/bench_train.py 64 bf16 --sync=8 --trainbn")):
     rows = stats("x_" + name)
     if not rows:
         continue
@@ -96,6 +97,19 @@ if tf or tw:
         if 2 * fb + wb < 1e6:
             continue
         out.append("%-70s dispatches %4d  read %9.3f GB  written %9.3f GB\n" % (k[:70], n, 2 * fb / 1e9, wb / 1e9))
+# the split-bf16 U-Net convolution kernel (tools/bench_unet.py 16: ten launches per forward, 16 frames 500x500)
+uv = {}
+for d in ("upmc_mfma", "upmc_fetch", "upmc_write"):
+    uv.update(pmc(d, "conv3x3_split_kernel"))
+if uv:
+    out.append("\n## U-Net split-bf16 convolution kernel (conv3x3_split_kernel), PMC averages per dispatch: python tools/bench_unet.py 16\n")
+    for k, v in uv.items():
+        out.append("%-34s %.6g\n" % (k, v))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in uv and "GRBM_GUI_ACTIVE" in uv:
+        out.append("MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.4f of the kernel's cycles\n"
+                   % (uv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (uv["GRBM_GUI_ACTIVE"] / 8)))
+    if "FETCH_SIZE" in uv and "WRITE_SIZE" in uv:
+        out.append("HBM traffic per dispatch = 2*FETCH_SIZE + WRITE_SIZE = %.4g bytes\n" % (uv["FETCH_SIZE"] * 2048 + uv["WRITE_SIZE"] * 1024))
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
 print("".join(out))
