@@ -67,6 +67,7 @@ struct ConvArgs {
   float* partial;     // split-K: [splits][ncols][RP] partial sums, else null
   int hin, win, cin, hout, wout, cout, kh, kw, sy, sx, py, px;
   int rows, RP, kc, kcp, ncols, nchunks, chunks_per_split;
+  int PR;             // row stride of the split-K partial tiles: rows rounded up to the tile height (16 / 32 / 64), <= RP
 };
 
 __device__ static __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -222,7 +223,7 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     for (int i = 0; i < SM; ++i) {
       const int r0 = row0 + 16 * SM * wm + 16 * i + 4 * q;
       if (a.partial) {
-        *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.RP + r0) = acc[i][j];
+        *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.PR + r0) = acc[i][j];
         continue;
       }
 #pragma unroll
@@ -249,12 +250,12 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 template <bool DGRAD>
 __global__ static __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int splits) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int rq = a.RP / 4;
+  const int rq = a.PR / 4;
   if (i >= (int64_t)a.ncols * rq) return;
   const int c = (int)(i / rq), r0 = (int)(i % rq) * 4;
-  f4 s = *reinterpret_cast<const f4*>(a.partial + (int64_t)c * a.RP + r0);
+  f4 s = *reinterpret_cast<const f4*>(a.partial + (int64_t)c * a.PR + r0);
   for (int k = 1; k < splits; ++k) {
-    const f4 p = *reinterpret_cast<const f4*>(a.partial + ((int64_t)k * a.ncols + c) * a.RP + r0);
+    const f4 p = *reinterpret_cast<const f4*>(a.partial + ((int64_t)k * a.ncols + c) * a.PR + r0);
     s += p;
   }
 #pragma unroll
@@ -290,6 +291,7 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   a.kcp = ceil_to(a.kc, 16);
   a.nchunks = a.kh * a.kw * a.kcp / 16;
   const int TM = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : 64, TN = 4096 / TM;
+  a.PR = ceil_to(a.rows, TM);      // (narrow layers: a quarter / half of the 64-row padding, so their split-K fits the scratch)
   const int tiles = ((a.ncols + TN - 1) / TN) * ((a.rows + TM - 1) / TM);
   // One tile walks its K range alone, one workgroup of four waves: a CU that holds a single such workgroup streams its
   // operands at ~12 GB/s (dependent fetch -> commit -> MFMA rounds), so a launch of ~150-300 tiles ran at a quarter of the MFMA
@@ -301,7 +303,7 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
     // while a workgroup keeps >= 32 chunks (below that the partial-sum pass costs more than the parallelism returns)
     splits = tiles < 128 ? min(min(256 / tiles, a.nchunks / 8), 64) : min((1024 + tiles - 1) / tiles, a.nchunks / 32);
     splits = max(splits, 1);
-    while (splits > 1 && (int64_t)splits * a.ncols * a.RP > kPartialFloats) --splits;
+    while (splits > 1 && (int64_t)splits * a.ncols * a.PR > kPartialFloats) --splits;
   }
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
@@ -311,7 +313,7 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   else if (TM == 32) launch_conv_shape<DGRAD, 32>(a, splits, st);
   else launch_conv_shape<DGRAD, 64>(a, splits, st);
   if (splits > 1) {
-    const int64_t n = (int64_t)a.ncols * (a.RP / 4);
+    const int64_t n = (int64_t)a.ncols * (a.PR / 4);
     hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
   }
   return (int)hipGetLastError();
