@@ -862,11 +862,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
 //  * the eight operand reads of tap t + 1 are issued one behind each of the first eight MFMAs of tap t.
 constexpr int kSwzRow = 20 * 64;                                // bytes between halo rows
 constexpr int kSwzIn = 34 * kSwzRow;                            // 43 520 bytes per halo buffer
-constexpr int kSplitBias = 2 * kSwzIn + 2 * kChunk16Halves * 2;  // 87 040 + 73 728 = 160 768 bytes, then the layer's biases (<= 128)
-constexpr int kSplitLds = kSplitBias + 512;
+constexpr int kSplitBias = 2 * kSwzIn + 2 * kChunk16Halves * 2;  // 87 040 + 73 728 = 160 768 bytes, then the layer's biases (<= 256)
+constexpr int kSplitLds = kSplitBias + 1024;
 template <int N> struct IntC { static constexpr int value = N; };
 
-template <bool FUSE_OUT>
+// SPLIT = false: the same kernel for PLAIN bf16 operands (the training chain: forward with saved activations, the input-gradient
+// twins with their ReLU gate, the raw convolutions of train-mode BatchNorm).  A chunk is then 32 input channels = the same 64 bytes
+// per halo pixel and the same 36 KiB of weights ([tap][k-step][M-block] where the split form has [tap][part][M-block]): identical
+// LDS shapes and operand reads, eight MFMAs per tap instead of twelve.  The halo values travel in HALVES of 16 channels, one per
+// staging set (so the register budget is the split form's): during chunk g set 0 (channels 0..15 of g + 1, requested during
+// g - 1) is committed behind taps 0..1 and re-requested for g + 2 behind taps 2..4, set 1 behind taps 5..6 and 7..8.
+template <bool FUSE_OUT, bool SPLIT = true>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
   constexpr int kThreads = 512, kQ = 4, kInQuads = 34 * 18 * kQ, kInPer = 5;
   constexpr int kDmaPieces = kChunk16Halves * 2 / 1024, kDmaPer = 5;        // 36 pieces of 1 KiB: waves 0..3 move five, 4..7 four
@@ -877,7 +883,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
   const uint32_t lds_w_addr = (uint32_t)(uintptr_t)(split_smem + 2 * kSwzIn);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 31, hh = lane >> 5;
-  const int nchunks = (a.CA + a.CB) / 16;                       // even for every layer of the net (checked by the launcher)
+  constexpr int kCC = SPLIT ? 16 : 32;                          // input channels per chunk
+  const int nchunks = (a.CA + a.CB) / kCC;                      // even for every layer of the net (checked by the launcher)
+  const int nunits = SPLIT ? nchunks : 2 * nchunks;             // 16-channel staging units per tile
   const int tiles_y = (a.H + 31) / 32;
   const int64_t total = (int64_t)a.tiles_x * tiles_y * a.n_ct * a.n_frames_asm;
   const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
   };
   auto f_advance = [&](auto SET) {
     pvalid[decltype(SET)::value] = f_vbits;
-    if (++f_cc == nchunks) {
+    if (++f_cc == nunits) {       // (f_cc counts 16-channel units)
       f_cc = 0;
       if (++f_tile < tile_end) f_setup();
     }
@@ -983,20 +991,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       if (++w_tile < tile_end) w_ptr = a.w16 + (int64_t)decode(w_tile).ct * nchunks * kChunk16Halves;
     }
   };
-  auto commit_one = [&](int k, auto SET, int buf) {
+  auto commit_one = [&](int k, auto SET, int buf) {       // (plain form: set = the chunk's half, channels 16 set .. + 15 = segments 2 set, 2 set + 1)
     constexpr int set = decltype(SET)::value;
     const int i = threadIdx.x + k * kThreads;
     if (i < kInQuads) {
       f4 v = pin[set][k];
       if (!((pvalid[set] >> k) & 1)) v = (f4){0.f, 0.f, 0.f, 0.f};
-      uint2 h, l;
+      uint2 h;
       h.x = pack_bf16x2(v[0], v[1]);
       h.y = pack_bf16x2(v[2], v[3]);
-      l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
-      l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
       char* dst = lds_in + buf * kSwzIn;
-      *reinterpret_cast<uint2*>(dst + coff[k]) = h;
-      *reinterpret_cast<uint2*>(dst + (coff[k] ^ 32)) = l;
+      if constexpr (SPLIT) {
+        uint2 l;
+        l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
+        l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+        *reinterpret_cast<uint2*>(dst + coff[k]) = h;
+        *reinterpret_cast<uint2*>(dst + (coff[k] ^ 32)) = l;
+      } else {
+        *reinterpret_cast<uint2*>(dst + (coff[k] ^ (set * 32))) = h;
+      }
     }
   };
   auto wait_loads = [&](int newer) {      // every vector-memory LOAD except the `newer` most recent ones has landed
@@ -1027,23 +1040,48 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
 
   // the layer's biases wait in LDS: read from global memory at every tile start, their ~2 k cycles of latency were exposed
   float* const lds_bias = reinterpret_cast<float*>(split_smem + kSplitBias);
-  if (threadIdx.x < 128) lds_bias[threadIdx.x] = (a.bias && (int)threadIdx.x < a.n_ct * 64) ? a.bias[threadIdx.x] : 0.f;
+  if (threadIdx.x < 256) lds_bias[threadIdx.x] = (a.bias && (int)threadIdx.x < a.n_ct * 64) ? a.bias[threadIdx.x] : 0.f;
 
   // ---- prologue: chunk 0 (values + weights) and the values of chunk 1 ----
   const int64_t chunks_total = (int64_t)(tile_end - tile0) * nchunks;      // >= 2
   f_setup();
+  if constexpr (SPLIT) {
 #pragma unroll
-  for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
-  f_advance(IntC<0>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    f_advance(IntC<0>{});
 #pragma unroll
-  for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
-  w_advance();
+    for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
+    w_advance();
 #pragma unroll
-  for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
-  f_advance(IntC<1>{});
-  wait_values(5, IntC<0>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    f_advance(IntC<1>{});
+    wait_values(5, IntC<0>{});
 #pragma unroll
-  for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
+    for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
+  } else {
+    // both halves of chunk 0, committed at once (the one exposed latency of the workgroup); then both halves of chunk 1
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    f_advance(IntC<0>{});
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    f_advance(IntC<1>{});
+#pragma unroll
+    for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
+    w_advance();
+    wait_values(0, IntC<0>{});
+    wait_values(0, IntC<1>{});
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<1>{}, 0);
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    f_advance(IntC<0>{});
+#pragma unroll
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    f_advance(IntC<1>{});
+  }
   barrier_lgkm();
   PHS(0);
 
@@ -1109,6 +1147,64 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
     PHS(2);
   };
 
+  // plain bf16: one step per 32-channel chunk; both staging sets turn over inside it
+  auto step_plain = [&]() {
+    const int buf = (int)(seq & 1);
+    const bool next1 = seq + 1 < chunks_total;                  // chunk g + 1 exists: weights move, both halves are committed
+    const bool next2 = seq + 2 < chunks_total;                  // chunk g + 2 exists: both halves are requested
+    const uint16_t* wcur = lds_w + buf * kChunk16Halves;
+    const char* icur = lds_in + buf * kSwzIn;
+    u4v A[2][2][2], B[2][2][2];   // [register set][k-step][block]
+    auto read_one = [&](int t, int os, int i) {      // read i (0..7): A k-step 0 (2 blocks), B k-step 0, A k-step 1, B k-step 1
+      const int dy = t / 3, dx = t % 3;
+      const int ks = i >> 2, isB = (i >> 1) & 1, blk = i & 1;
+      if (!isB) A[os][ks][blk] = reinterpret_cast<const u4v*>(wcur)[((t * 2 + ks) * 2 + blk) * 64 + lane];
+      else B[os][ks][blk] = *reinterpret_cast<const u4v*>(icur + zb[dx][ks] + (blk + dy) * kSwzRow);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_one(0, 0, i);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int cur = t & 1;
+      // set 0 = channels 0..15 of chunk g + 1 (requested during g - 1, before that chunk's set-1 requests: 5 newer loads);
+      // set 1 = channels 16..31 (newer: this chunk's weight pieces and set-0 requests)
+      if (t == 0 && next1) wait_values(kInPer, IntC<0>{});
+      if (t == 5 && next1) wait_values(n_dma + (next2 ? kInPer : 0), IntC<1>{});
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int ks = m >> 2, mb = (m >> 1) & 1, nb = m & 1;
+        acc[mb][nb] = mfma32_bf16(A[cur][ks][mb], B[cur][ks][nb], acc[mb][nb]);
+        if (t + 1 < 9) read_one(t + 1, cur ^ 1, m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (next1) {      // commits: set 0 behind taps 0, 1 (3 + 2 quads), set 1 behind taps 5, 6
+        if (t == 0) { commit_one(0, IntC<0>{}, buf ^ 1); commit_one(1, IntC<0>{}, buf ^ 1); commit_one(2, IntC<0>{}, buf ^ 1); }
+        if (t == 1) { commit_one(3, IntC<0>{}, buf ^ 1); commit_one(4, IntC<0>{}, buf ^ 1); }
+        if (t == 5) { commit_one(0, IntC<1>{}, buf ^ 1); commit_one(1, IntC<1>{}, buf ^ 1); commit_one(2, IntC<1>{}, buf ^ 1); }
+        if (t == 6) { commit_one(3, IntC<1>{}, buf ^ 1); commit_one(4, IntC<1>{}, buf ^ 1); }
+      }
+      // requests: D0 D1 | D2 D3 | D4 L0 | L1 L2 | L3 L4 behind taps 0..4 (set 0 <- g + 2), L0' L1' L2' | L3' L4' behind taps 7, 8 (set 1)
+      if (t < 5) {
+        const int r0 = 2 * t, r1 = 2 * t + 1;
+        if (r0 < 5) { if (next1) dma_piece(r0, buf ^ 1); } else if (next2) fetch_one(r0 - 5, IntC<0>{});
+        if (r1 < 5) { if (next1) dma_piece(r1, buf ^ 1); } else if (next2) fetch_one(r1 - 5, IntC<0>{});
+      }
+      if (t == 4 && next2) f_advance(IntC<0>{});
+      if (t == 7 && next2) { fetch_one(0, IntC<1>{}); fetch_one(1, IntC<1>{}); fetch_one(2, IntC<1>{}); }
+      if (t == 8 && next2) { fetch_one(3, IntC<1>{}); fetch_one(4, IntC<1>{}); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PHS(1);
+    if (next1) w_advance();
+    if (next2) f_advance(IntC<1>{});
+    ++seq;
+    PHS(5);
+    wait_loads(next2 ? 2 * kInPer : 0);                         // the weights of chunk g + 1 have landed (the values of g + 2 may fly)
+    PHS(3);
+    barrier_lgkm();
+    PHS(2);
+  };
+
   for (int tile = tile0; tile < tile_end; ++tile) {
     const TilePos tp = decode(tile);
     const int x0 = tp.x0, y0 = tp.y0, ct = tp.ct;
@@ -1124,8 +1220,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
           for (int r = 0; r < 4; ++r) acc[mb][nb][4 * rr + r] = b[r];
         }
     for (int cc = 0; cc < nchunks; cc += 2) {
-      step(IntC<0>{});
-      step(IntC<1>{});
+      if constexpr (SPLIT) {
+        step(IntC<0>{});
+        step(IntC<1>{});
+      } else {
+        step_plain();
+        step_plain();
+      }
     }
 
     // epilogue (as conv3x3_bf16_kernel): D reg r of lane (n, hh) = channel 32 mb + (r & 3) + 8 (r >> 2) + 4 hh of pixel
@@ -1175,10 +1276,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int px = 8 * q + (lane >> 3), chq = lane & 7;
-          const f4 h = *reinterpret_cast<const f4*>(stage + q * 8192 + (px & 7) * 128 + ((chq ^ ((px >> 1) & 7)) << 4));
+          f4 h = *reinterpret_cast<const f4*>(stage + q * 8192 + (px & 7) * 128 + ((chq ^ ((px >> 1) & 7)) << 4));
           const int sy = y0 + 4 * wave + 2 * (px >> 4) + nb, sx = x0 + (px & 15);
-          if (sy < a.H && sx < a.W)
-            *reinterpret_cast<f4*>(a.out + (frame * (int64_t)a.H * a.W + (int64_t)sy * a.W + sx) * a.cout + ct * 64 + mb * 32 + 4 * chq) = h;
+          if (sy < a.H && sx < a.W) {
+            const int64_t o = (frame * (int64_t)a.H * a.W + (int64_t)sy * a.W + sx) * a.cout + ct * 64 + mb * 32 + 4 * chq;
+            if (a.gate) {      // input-gradient twins: the ReLU mask of the activation that fed the layer
+              const f4 gt = *reinterpret_cast<const f4*>(a.gate + o);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = gt[r] > 0.f ? h[r] : 0.f;
+            }
+            *reinterpret_cast<f4*>(a.out + o) = h;
+          }
         }
       }
     }
@@ -1287,6 +1395,32 @@ static int launch_conv_asm(ConvArgs& a, int64_t F, hipStream_t st, bool* launche
   return (int)hipGetLastError();
 }
 
+// The persistent kernel takes a bf16-operand launch (split or plain) when its chunk count is even and selector 0 is set:
+// 32 x 16-pixel tiles, a contiguous tile range per workgroup, one workgroup per CU.
+static int launch_conv_persistent(ConvArgs& a, int64_t F, bool fuse_out, bool split, hipStream_t st, bool* launched) {
+  *launched = false;
+  const int64_t total = (int64_t)a.tiles_x * ((a.H + 31) / 32) * a.n_ct * F;
+  const int nchunks = (a.CA + a.CB) / (split ? 16 : 32);
+  if (g_split_kernel_kind.load(std::memory_order_relaxed) != 0 || (a.CA + a.CB) % (split ? 16 : 32) != 0 || nchunks % 2 != 0 ||
+      (a.CB != 0 && a.CA % 16 != 0) || a.n_ct > 4 || a.pool && fuse_out || total >= 0x7fffffff || total == 0)
+    return S2L_OK;
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  // plain bf16: a chunk is a third of the split form's matrix work, so the one exposed first-chunk latency of a workgroup only
+  // pays off over a few tiles (one 500x500 frame per call = 2 tiles per workgroup measured 1 % slower than one tile per workgroup)
+  if (!split && total < 4 * (int64_t)n_cu) return S2L_OK;
+  static LdsOptIn pflags[4];
+  void (*const kern[4])(ConvArgs) = {conv3x3_split_kernel<false, false>, conv3x3_split_kernel<true, false>,
+                                     conv3x3_split_kernel<false, true>, conv3x3_split_kernel<true, true>};
+  const int v = (split ? 2 : 0) + (fuse_out ? 1 : 0);
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[v]), kSplitLds, pflags[v], dev))) return rc;
+  a.n_frames_asm = (int)F;
+  hipLaunchKernelGGL(kern[v], dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kSplitLds, st, a);
+  *launched = true;
+  return (int)hipGetLastError();
+}
+
 static int launch_conv(const float* inA, int CA, const float* inB, int CB, const float* packed, int layer, float* out,
                        float* out3, int H, int W, int64_t F, hipStream_t st, float* pool = nullptr, float* keep = nullptr,
                        const uint16_t* packed16 = nullptr, int split = 0) {
@@ -1309,26 +1443,25 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
-  if (a.w16 && split) {      // the 8-wave forms: 32 x 16-pixel tiles, > 64 KiB of dynamic LDS (opt-in per device)
+  if (a.w16 && (split || g_split_kernel_kind.load(std::memory_order_relaxed) == 0)) {
+    bool launched = false;
+    const int rc = launch_conv_persistent(a, F, out3 != nullptr, split != 0, st, &launched);
+    if (rc || launched) return rc;
+    // the split form without the persistent kernel: one 32 x 16-pixel tile per 512-thread workgroup
+    const dim3 wgrid(a.tiles_x, (H + 31) / 32, (unsigned)gz);
+    static LdsOptIn wflags[2];
     int dev = 0, n_cu = 0;
-    int rc = current_device_cus(&dev, &n_cu);
-    if (rc) return rc;
-    const int64_t total = (int64_t)a.tiles_x * ((H + 31) / 32) * gz;
-    if (g_split_kernel_kind.load(std::memory_order_relaxed) == 0 && ((CA + CB) / 16) % 2 == 0 && total < 0x7fffffff) {
-      static LdsOptIn pflags[2];        // persistent, two chunks ahead
-      void (*const kern)(ConvArgs) = out3 ? conv3x3_split_kernel<true> : conv3x3_split_kernel<false>;
-      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kSplitLds, pflags[out3 ? 1 : 0], dev))) return rc;
-      a.n_frames_asm = (int)F;
-      hipLaunchKernelGGL(kern, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kSplitLds, st, a);
-    } else {
-      const dim3 wgrid(a.tiles_x, (H + 31) / 32, (unsigned)gz);
-      static LdsOptIn wflags[2];
-      void (*const kern)(ConvArgs) = out3 ? conv3x3_bf16_kernel<true, true, 8> : conv3x3_bf16_kernel<false, true, 8>;
-      if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kBf16WideLds, wflags[out3 ? 1 : 0], dev))) return rc;
+    int rc2 = current_device_cus(&dev, &n_cu);
+    if (rc2) return rc2;
+    void (*const kern)(ConvArgs) = out3 ? conv3x3_bf16_kernel<true, true, 8> : conv3x3_bf16_kernel<false, true, 8>;
+    if (split) {
+      if ((rc2 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kBf16WideLds, wflags[out3 ? 1 : 0], dev))) return rc2;
       hipLaunchKernelGGL(kern, wgrid, dim3(512), kBf16WideLds, st, a);
+      return (int)hipGetLastError();
     }
   }
-  else if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+  if (a.w16 && split) return S2L_E_SIZE;      // (not reached)
+  if (out3 && a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<true>, grid, dim3(256), 0, st, a);
   else if (out3) hipLaunchKernelGGL(conv3x3_kernel<true>, grid, dim3(256), 0, st, a);
   else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
@@ -1361,7 +1494,12 @@ static int launch_conv_dgrad(const float* dz, const float* packed, int layer, fl
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
-  if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+  if (a.w16) {
+    bool launched = false;
+    const int rc = launch_conv_persistent(a, F, false, false, st, &launched);
+    if (rc || launched) return rc;
+    hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+  }
   else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
@@ -2277,7 +2415,11 @@ static int unet_train_forward_impl(const float* packed_raw, const uint16_t* pack
       bool done = false;
       if ((rc = launch_conv_asm(a, F, st, &done))) return rc;       // (declines bf16 operands)
       if (done) {}
-      else if (a.w16) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+      else if (a.w16) {
+        bool pl = false;
+        if ((rc = launch_conv_persistent(a, F, false, false, st, &pl))) return rc;
+        if (!pl) hipLaunchKernelGGL(conv3x3_bf16_kernel<false>, grid, dim3(256), 0, st, a);
+      }
       else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
     }
     int nb = 0;

@@ -65,8 +65,8 @@ def test_conv_kernel_switch_rejects_other_kinds():
     assert _abi.load().s2l_set_unet_conv_kernel(2) == -2 and _abi.load().s2l_set_unet_conv_kernel(-1) == -2
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 4), (1, 33, 17), (3, 37, 501), (2, 64, 48), (1, 500, 500), (7, 200, 333), (40, 96, 96)],
-                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(1, 4, 4), (1, 33, 17), (3, 37, 501), (2, 64, 48), (1, 500, 500), (7, 200, 333), (40, 96, 96),
+                                   (16, 160, 256)], ids=lambda s: "x".join(map(str, s)))
 def test_split_persistent_kernel_equals_the_one_tile_form(unet, shape):
     """The split-bf16 layers run in a persistent kernel (tiles as one chunk stream per workgroup, two swizzled halo buffers, LDS-DMA
     weights, counted vmcnt waits, one barrier per chunk, the activation leaving through LDS): the same products in the same
@@ -76,14 +76,23 @@ def test_split_persistent_kernel_equals_the_one_tile_form(unet, shape):
     F, H, Wd = shape
     dev = next(unet.parameters()).device
     x = torch.from_numpy(np.random.default_rng(H * 1000 + Wd).random((F, H, Wd, 3), dtype=np.float32)).to(dev)
+    g = torch.from_numpy(np.random.default_rng(7).standard_normal((F, H, Wd, 3)).astype(np.float32)).to(dev)
     lib = _abi.load()
+
+    def chain():      # the plain-bf16 training chain through the same kernel (launches of >= 4 tiles per workgroup): forward with
+        out, ctx = unet.forward_saved_nhwc(x, precision="bf16")      # saved state (pooled copies, fused output layer), gated input gradients
+        return out.clone(), unet.backward_input(ctx, g).clone()
     try:
         assert lib.s2l_set_unet_split_kernel(1) == 0
         ref = unet.forward_nhwc(x, precision="split").clone()
+        ref_out, ref_dx = chain()
         assert lib.s2l_set_unet_split_kernel(0) == 0
         for _ in range(3):
             assert torch.equal(unet.forward_nhwc(x, precision="split"), ref)
+        for _ in range(2):
+            out, dx = chain()
+            assert torch.equal(out, ref_out) and torch.equal(dx, ref_dx)
     finally:
         lib.s2l_set_unet_split_kernel(0)
-    assert float(ref.abs().max()) > 0
+    assert float(ref.abs().max()) > 0 and float(ref_dx.abs().max()) > 0
     assert lib.s2l_set_unet_split_kernel(2) == -2

@@ -11,17 +11,18 @@ import speech2lip_amd as s2l
 from speech2lip_amd import weights as W, _abi
 dev = torch.device("cuda:0")
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+PREC = sys.argv[3] if len(sys.argv) > 3 else "split"      # "bf16": the plain-bf16 form of the same kernels
 u = s2l.SimpleUnetLight().to(dev).eval()
 u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
 x = torch.rand(F, 500, 500, 3, device=dev)
 for _ in range(2):
-    u.forward_nhwc(x, precision="split")
+    u.forward_nhwc(x, precision=PREC)
 torch.cuda.synchronize()
 trace = torch.zeros(12 * 8192 * 24, dtype=torch.int64, device=dev)
 lib = _abi.load()
 lib.s2l_debug_set_conv_trace.argtypes = [ctypes.c_void_p]
 lib.s2l_debug_set_conv_trace(trace.data_ptr())
-u.forward_nhwc(x, precision="split")
+u.forward_nhwc(x, precision=PREC)
 torch.cuda.synchronize()
 t = trace.cpu().numpy().reshape(12, 8192, 24)
 for launch in range(9):
