@@ -96,3 +96,30 @@ def test_split_persistent_kernel_equals_the_one_tile_form(unet, shape):
         lib.s2l_set_unet_split_kernel(0)
     assert float(ref.abs().max()) > 0 and float(ref_dx.abs().max()) > 0
     assert lib.s2l_set_unet_split_kernel(2) == -2
+
+
+def test_persistent_kernel_random_shapes_race_screen(unet):
+    """tools/soak_conv_kernels.py in small: 36 random frame shapes (a third of them few large frames, the rest many small ones, so that
+    workgroups own one tile, several tiles, and tile ranges that cross channel tiles and frames), split forward + plain-bf16 saved
+    forward + gated input gradient, persistent kernel twice against the one-tile kernels: every output the same bits."""
+    dev = next(unet.parameters()).device
+    lib = _abi.load()
+    rng = np.random.default_rng(123)
+    try:
+        for it in range(36):
+            big = it % 3 == 0
+            F = int(rng.integers(1, 4)) if big else int(rng.integers(1, 48))
+            H = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
+            Wd = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
+            x = torch.rand(F, H, Wd, 3, device=dev)
+            d = torch.randn(F, H, Wd, 3, device=dev)
+            res = []
+            for kind in (1, 0, 0):
+                assert lib.s2l_set_unet_split_kernel(kind) == 0
+                a = unet.forward_nhwc(x, precision="split").clone()
+                o, ctx = unet.forward_saved_nhwc(x, precision="bf16")
+                res.append((a, o.clone(), unet.backward_input(ctx, d).clone()))
+            for j in range(3):
+                assert torch.equal(res[0][j], res[1][j]) and torch.equal(res[0][j], res[2][j]), (F, H, Wd, j)
+    finally:
+        lib.s2l_set_unet_split_kernel(0)
