@@ -520,7 +520,7 @@ static UpWin no_window(int h, int w, int Ho, int Wo) { return UpWin{h, w, Ho, Wo
 // (36.9 KB).  Per tap and k-step a wave issues 2 + 2 ds_read_b128 for 4 MFMAs of 32x32x16; wave w owns tile rows 4w..4w+3 as
 // two N-blocks of 2 rows x 16 pixels.  16x fewer matrix-pipe cycles than the fp32 form: the kernel is bound by staging and HBM.
 #ifndef S2L_UEXP
-#define S2L_UEXP 0   // tools/ubench experiments on conv3x3_bf16_kernel only (results wrong): 1 no MFMAs, 2 no activation loads, 4 no weight loads, 8 no LDS commits, 16 no epilogue stores
+#define S2L_UEXP 0   // tools/ubench experiments on the bf16-operand convolution kernels only (results wrong): 1 no MFMAs, 2 no activation loads, 4 no weight loads, 8 no LDS commits, 16 no epilogue stores, 32 no requests inside the persistent kernel's chunk loop
 #endif
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef short bf8v __attribute__((ext_vector_type(8)));
