@@ -1,7 +1,9 @@
 """Build libs2l_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
 from __future__ import annotations
 
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -9,10 +11,30 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libs2l_hip.so")
+RESOURCES = os.path.join(PKG, "kernel_resources.json")      # per-kernel registers / spills / scratch / LDS of the last build
 SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip"]
 # -ffp-contract=off: parity needs the reference's separate roundings (x*y then +z); FMAs are explicit fmaf()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
+_REMARK = re.compile(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]|"
+                     r"Occupancy \[waves/SIMD\]):\s*(\S+)")
+
+
+def _parse_resources(text: str) -> dict:
+    """{kernel symbol: {vgprs, agprs, scratch, sgpr_spill, vgpr_spill, lds, occupancy}} from -Rpass-analysis=kernel-resource-usage.
+    Several kernels wait with COUNTED vmcnt on requests the compiler does not know as memory operations (render, bf16 forward /
+    backward bodies, conv3x3_split_kernel): a register spill to scratch would be an uncounted vector-memory operation inside their
+    loops, so tests/test_abi_and_host.py checks this table for zero scratch."""
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "SGPRs Spill": "sgpr_spill",
+            "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy"}
+    for m in _REMARK.finditer(text):
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None:
+            cur[keys[k]] = int(v)
+    return out
 
 
 def _hipcc() -> str:
@@ -32,7 +54,7 @@ def needs_build() -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every .hip translation unit and link the shared library next to this file."""
-    if not force and not needs_build():
+    if not force and not needs_build() and os.path.exists(RESOURCES):
         return LIB
     hipcc = _hipcc()
     objdir = os.path.join(PKG, "build")
@@ -57,19 +79,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    objs = []
+    objs, resources = [], {}
     for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out)
+        resources.update(_parse_resources(out))
+        rest = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
+        if verbose and rest.strip():
+            print(rest)
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(LIB + ".tmp", LIB)
+    with open(RESOURCES, "w") as f:
+        json.dump(resources, f, indent=0, sort_keys=True)
     return LIB
 
 

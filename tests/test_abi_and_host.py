@@ -365,3 +365,23 @@ def test_sync_chain_unet_window_geometry():
         assert x0 >= bbox[0] - r - 3 and y0 >= bbox[1] - r - 3          # no larger than needed
     ch.window = False
     assert ch.unet_window([110, 90, 390, 420, 1.0], 500, 500) == (0, 0, 500, 500)
+
+
+def test_no_kernel_spills_to_scratch():
+    """Several kernels wait with COUNTED vmcnt on requests issued as assembly text (the renderer, the bf16 forward / backward bodies,
+    conv3x3_split_kernel): a VGPR spilled to scratch would be a vector-memory operation the count does not know, inside their loops.
+    The build records hipcc's per-kernel resource table; no kernel of the library may use scratch or spill a VGPR."""
+    import json
+    from speech2lip_amd import build
+    build.build_library()
+    if not os.path.exists(build.RESOURCES):
+        build.build_library(force=True)
+    table = json.load(open(build.RESOURCES))
+    assert len(table) >= 100
+    bad = {k: v for k, v in table.items() if v.get("scratch", 0) != 0 or v.get("vgpr_spill", 0) != 0}
+    assert not bad, bad
+    counted = [k for k in table if any(s in k for s in ("conv3x3_split_kernel", "render_tiles_kernel", "fwd_asm_bf16_kernel",
+                                                        "bwd_asm_bf16_kernel", "conv3x3_asm_kernel"))]
+    assert len(counted) >= 4 + 3 + 1 + 1 + 4, counted
+    for k in counted:
+        assert table[k]["vgprs"] + table[k].get("agprs", 0) <= 512
