@@ -15,11 +15,11 @@ __device__ inline float lrelu(float x) { return x > 0.f ? x : 0.02f * x; }
 
 // Conv1d(k=3, stride=2, pad=1) + LeakyReLU(0.02) over kFB frames held in LDS.
 // xin [kFB][CIN][TIN], yout [kFB][COUT][TIN/2], wT [CIN][3][COUT].
-template <int CIN, int COUT, int TIN>
+template <int CIN, int COUT, int TIN, int FB = kFB>
 __device__ inline void conv_stage(const float* __restrict__ wT, const float* __restrict__ b, const float* xin,
                                   float* yout) {
   constexpr int TOUT = TIN / 2;
-  for (int item = threadIdx.x; item < kFB * COUT * TOUT; item += blockDim.x) {
+  for (int item = threadIdx.x; item < FB * COUT * TOUT; item += blockDim.x) {
     const int o = item % COUT;
     const int tau = (item / COUT) % TOUT;
     const int fb = item / (COUT * TOUT);
@@ -37,37 +37,46 @@ __device__ inline void conv_stage(const float* __restrict__ wT, const float* __r
   __syncthreads();
 }
 
+// FB frames per block: 4 for clips; 1 when a call has fewer than 4 frames (the reference's one-frame-per-call mode: a block of 4 with
+// one valid frame spent 3/4 of its dependent load + fma chains on copies of it -- 40 us of a 180-us single-frame render).  The
+// arithmetic per output is the same chain in both.
+template <int FB>
 __global__ __launch_bounds__(256) void audio_encode_kernel(const float* __restrict__ packed,
                                                           const float* __restrict__ windows,
                                                           float* __restrict__ feat, int64_t n) {
-  __shared__ float x0[kFB * 29 * 16];
-  __shared__ float y1[kFB * 32 * 8];
-  __shared__ float y2[kFB * 32 * 4];
-  __shared__ float y3[kFB * 64 * 2];
-  __shared__ float y4[kFB * 64];
-  __shared__ float f1[kFB * 64];
-  const int64_t f0 = (int64_t)blockIdx.x * kFB;
+  __shared__ float x0[FB * 29 * 16];
+  __shared__ float y1[FB * 32 * 8];
+  __shared__ float y2[FB * 32 * 4];
+  __shared__ float y3[FB * 64 * 2];
+  __shared__ float y4[FB * 64];
+  __shared__ float f1[FB * 64];
+  const int64_t f0 = (int64_t)blockIdx.x * FB;
   // windows [f][t 16][c 29] -> x0 [fb][c][t]   (the permute of tf_nerf.py:207)
-  for (int i = threadIdx.x; i < kFB * 16 * 29; i += blockDim.x) {
+  for (int i = threadIdx.x; i < FB * 16 * 29; i += blockDim.x) {
     const int fb = i / (16 * 29), r = i - fb * 16 * 29;
     const int t = r / 29, c = r - t * 29;
     const int64_t f = f0 + fb < n ? f0 + fb : n - 1;
     x0[(fb * 29 + c) * 16 + t] = windows[f * 16 * 29 + r];
   }
   __syncthreads();
-  conv_stage<29, 32, 16>(packed + OFF_C0W, packed + OFF_C0B, x0, y1);
-  conv_stage<32, 32, 8>(packed + OFF_C2W, packed + OFF_C2B, y1, y2);
-  conv_stage<32, 64, 4>(packed + OFF_C4W, packed + OFF_C4B, y2, y3);
-  conv_stage<64, 64, 2>(packed + OFF_C6W, packed + OFF_C6B, y3, y4);
+  conv_stage<29, 32, 16, FB>(packed + OFF_C0W, packed + OFF_C0B, x0, y1);
+  conv_stage<32, 32, 8, FB>(packed + OFF_C2W, packed + OFF_C2B, y1, y2);
+  conv_stage<32, 64, 4, FB>(packed + OFF_C4W, packed + OFF_C4B, y2, y3);
+  conv_stage<64, 64, 2, FB>(packed + OFF_C6W, packed + OFF_C6B, y3, y4);
   {  // Linear(64,64) + LeakyReLU, Linear(64,64): thread = (frame, output)
     const int fb = threadIdx.x >> 6, o = threadIdx.x & 63;
+    const bool mine = fb < FB;      // (FB = 1: one wave works, the others only keep the barrier)
     float acc = packed[OFF_F0B + o];
-    for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + k * 64 + o], y4[fb * 64 + k], acc);
-    f1[fb * 64 + o] = lrelu(acc);
+    if (mine) {
+      for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + k * 64 + o], y4[fb * 64 + k], acc);
+      f1[fb * 64 + o] = lrelu(acc);
+    }
     __syncthreads();
     acc = packed[OFF_F2B + o];
-    for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F2W + k * 64 + o], f1[fb * 64 + k], acc);
-    if (f0 + fb < n) feat[(f0 + fb) * 64 + o] = acc;
+    if (mine) {
+      for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F2W + k * 64 + o], f1[fb * 64 + k], acc);
+      if (f0 + fb < n) feat[(f0 + fb) * 64 + o] = acc;
+    }
   }
 }
 
@@ -239,6 +248,8 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
     acc0[fb] = packed[OFF_BSUM0 + tid];
     acc5[fb] = packed[OFF_BSUM5 + tid];
   }
+  // (x8: eight pairs of weight loads in flight per thread; the fma chains keep their order.  One frame per call: 28 -> 21 us)
+#pragma unroll 8
   for (int k = 0; k < 64; ++k) {
     const float w0 = packed[OFF_WAT + k * 256 + tid], w5 = packed[OFF_WAST + k * 256 + tid];
 #pragma unroll
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
     acc5[fb] = packed[OFF_B5 + tid];
   }
   __syncthreads();
+#pragma unroll 8
   for (int k = 0; k < 256; ++k) {
     const float w0 = packed[OFF_W0T + k * 256 + tid], w5 = packed[OFF_W5AT + k * 256 + tid];
 #pragma unroll
@@ -368,9 +380,14 @@ extern "C" int s2l_audio_encode(const float* packed, const float* windows, float
   if (n < 0) return S2L_E_SIZE;
   if (n == 0) return S2L_OK;
   if (!packed || !windows || !feat) return S2L_E_NULL;
-  const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
-  hipLaunchKernelGGL(s2l::audio_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     packed, windows, feat, n);
+  if (n < s2l::kFB) {
+    hipLaunchKernelGGL(s2l::audio_encode_kernel<1>, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), packed, windows,
+                       feat, n);
+  } else {
+    const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
+    hipLaunchKernelGGL(s2l::audio_encode_kernel<s2l::kFB>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       packed, windows, feat, n);
+  }
   return (int)hipGetLastError();
 }
 

@@ -78,6 +78,16 @@ def test_audio_encoder_ragged_batches(model, sd, dev, n):
     close(model.audio_merge_forward(win.to(dev)), ref, AUDIO_RMSE, AUDIO_MAX)
 
 
+def test_audio_encoder_is_the_same_function_for_any_batch(model, dev):
+    """A frame's feature is a pure function of its window: calls with fewer than four frames run one frame per block, clips four
+    -- the same fma chains, so the SAME BITS (the N-GPU clip equals the 1-GPU clip bit for bit also when a rank's block is short)."""
+    win = T(W.synthetic_audio(64, seed=9).astype(np.float32)).to(dev)
+    full = model.audio_merge_forward(win)
+    for n in (1, 2, 3, 4, 5, 7):
+        for start in (0, 11, 64 - n):
+            assert torch.equal(model.audio_merge_forward(win[start:start + n]), full[start:start + n]), (n, start)
+
+
 def test_rgb_forward_golden_rows(model, golden, sd, dev):
     g = golden("g3_rgb.npz")
     close(model.rgb_forward(T(g["gen_rows"]).to(dev), time_pts=torch.tensor([12345], device=dev)), g["gen_out"])
