@@ -59,6 +59,19 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 50, 30, 0, 4, 1, null) == -4
     assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 2, 30, 0, 4, 1, null) == -4
     assert lib.s2l_composite(one, one, 7, one, 0, one, one, one, null, null, 16, 24, 64, 64, 20, 30, 0, 4, 1, null) == -2
+    # round-3 entry points: the pair pass of the lip-sync expert, the frozen / bf16 train-mode U-Net, the kernel selectors
+    assert lib.s2l_syncnet_forward_pair(one, one, one, one, one, one, 5, 4, null) == -2          # more mel windows than face windows
+    assert lib.s2l_syncnet_forward_pair(one, one, one, one, one, one, 0, 0, null) == 0
+    assert lib.s2l_syncnet_forward_pair(one, null, one, one, null, one, 2, 4, null) == -1        # mel / audio_emb needed when audio_batch > 0
+    assert lib.s2l_syncnet_face_backward_prefix(one, one, one, one, one, 5, 4, null) == -2       # more gradients than forwarded windows
+    assert lib.s2l_syncnet_face_backward_prefix(one, one, one, one, one, 0, 4, null) == 0
+    tbl = (ctypes.c_void_p * 52)(*([16] * 52))
+    assert lib.s2l_unet_train_backward(one, tbl, one, one, one, one, null, null, 8, 8, 1, null) == -1       # neither d_x nor grads
+    assert lib.s2l_unet_train_backward_bf16(one, null, tbl, one, one, one, one, one, one, 8, 8, 1, null) == -1   # no bf16 blob
+    assert lib.s2l_unet_train_forward_bf16(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -1
+    assert lib.s2l_unet_train_forward_bf16(one, odd, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -3
+    assert lib.s2l_unet_train_forward(one, tbl, 1e-5, 0.1, 0, one, one, one, one, 3, 8, 1, null) == -2             # H < 4
+    assert lib.s2l_set_unet_split_kernel(2) == -2 and lib.s2l_set_unet_split_kernel(0) == 0
 
 
 def test_config_inherit_and_merge(tmp_path):
