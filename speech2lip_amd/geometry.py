@@ -9,7 +9,7 @@ batch is a whole clip instead of one frame, and there is no CPU fallback.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -16,8 +16,6 @@ Every arithmetic step is a hand-written HIP kernel behind the C-ABI; torch is de
 from __future__ import annotations
 
 import ctypes
-import random
-from typing import Optional
 
 import torch
 
