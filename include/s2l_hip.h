@@ -357,6 +357,22 @@ int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16_t* packed1
 int s2l_unet_train_backward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                  const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
                                  int height, int width, int64_t n_frames, s2l_stream_t stream);
+/* F successive ONE-FRAME train-mode calls in one set of launches -- how the reference's loop runs the (frozen) net: tf_nerf.py:387
+ * inside train_stage1's batch-1 calls, main frame then the five window frames of every sample (training.py:436-459, 504-548), with
+ * Trainer.train_step's model.train() in force (training.py:150).  Every frame is its own statistics group: normalised with its own
+ * batch statistics; the running statistics move once per frame, in frame order; the BatchNorm backward carries each frame's own
+ * terms.  Per frame the arithmetic is that of a call with n_frames = 1: the same bits (tests: test_unet_train_frames_*).
+ * packed16_raw: NULL = fp32 convolutions, else the s2l_unet_pack16(bn_eps < 0) blob.  The backward returns the input gradient
+ * only (a frozen net).  Sizes: s2l_unet_train_frames_{saved,scratch,work}_floats. */
+int64_t s2l_unet_train_frames_saved_floats(int height, int width, int64_t n_frames);
+int64_t s2l_unet_train_frames_scratch_floats(int64_t n_frames);
+int64_t s2l_unet_train_frames_work_floats(int height, int width, int64_t n_frames);
+int s2l_unet_train_forward_frames(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
+                                  float momentum, int update_running, const float* x, float* saved, float* scratch, float* out,
+                                  int height, int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_train_backward_frames(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                   const float* x, const float* saved, const float* d_out, float* work, float* d_x, int height,
+                                   int width, int64_t n_frames, s2l_stream_t stream);
 
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
  * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with

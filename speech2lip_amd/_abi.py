@@ -69,6 +69,13 @@ EXPORTS = {
                                             c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_train_backward_bf16": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_frames_saved_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_frames_scratch_floats": (c_int64, [c_int64]),
+    "s2l_unet_train_frames_work_floats": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_forward_frames": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_backward_frames": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_forward_saved_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                               c_int64, c_void_p]),
     "s2l_unet_backward_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -1693,6 +1693,10 @@ constexpr int kStatBlocks = 1024;   // row blocks of the per-channel reductions 
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ z, int C, int64_t n_pix, int64_t per_block,
                                                            float* __restrict__ partial) {
   __shared__ float red[2][256];
+  // blockIdx.y = statistics group (1 group: the whole batch, nn.BatchNorm2d; F groups: one per frame -- the reference hands the
+  // net one frame per call, so a batch of its calls is F independent normalisations); n_pix = pixels of ONE group
+  z += (int64_t)blockIdx.y * n_pix * C;
+  partial += (int64_t)blockIdx.y * gridDim.x * 2 * C;
   const int lanes = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
   const int64_t p0 = (int64_t)blockIdx.x * per_block;
   int64_t p1 = p0 + per_block;
@@ -1745,31 +1749,36 @@ __device__ __forceinline__ void channel_totals(const float* __restrict__ partial
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n, float eps,
                                                         float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                        float* __restrict__ st) {
+                                                        float* __restrict__ st, int groups) {
   const int c = blockIdx.x;
-  double s, ss;
-  channel_totals(partial, n_blocks, C, c, &s, &ss);
-  if (threadIdx.x != 0) return;
-  const double mean = s / n;
-  double var = ss / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float scale = gamma[c] * invstd;
-  st[c] = scale;
-  st[C + c] = beta[c] - (float)mean * scale;
-  st[2 * C + c] = (float)mean;
-  st[3 * C + c] = invstd;
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+  // groups in order: the running statistics move once per group, as they do over the reference's successive one-frame calls
+  for (int g = 0; g < groups; ++g) {
+    double s, ss;
+    channel_totals(partial + (int64_t)g * n_blocks * 2 * C, n_blocks, C, c, &s, &ss);
+    if (threadIdx.x != 0) continue;
+    float* stg = st + g * 512;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[c] * invstd;
+    stg[c] = scale;
+    stg[C + c] = beta[c] - (float)mean * scale;
+    stg[2 * C + c] = (float)mean;
+    stg[3 * C + c] = invstd;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+    }
   }
 }
 
 // a = relu(z * scale + shift); pool != NULL: also MaxPool2d(2) of a ([F,H/2,W/2,C]), one thread per (pixel, channel quad)
 __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ z, const float* __restrict__ st, float* __restrict__ a,
-                                                     int C, int64_t n_quads) {
+                                                     int C, int64_t n_quads, int64_t group_quads) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_quads) return;
+  st += (i / group_quads) * 512;
   const int c4 = (int)(i % (C / 4)) * 4;
   const f4 v = *reinterpret_cast<const f4*>(z + i * 4);
   const f4 sc = *reinterpret_cast<const f4*>(st + c4), sh = *reinterpret_cast<const f4*>(st + C + c4);
@@ -1823,6 +1832,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                            const float* __restrict__ st, int C, int64_t n_pix, int64_t per_block,
                                                            float* __restrict__ partial) {
   __shared__ float red[2][256];
+  gy += (int64_t)blockIdx.y * n_pix * C;       // (blockIdx.y = statistics group, as in channel_stats_kernel)
+  z += (int64_t)blockIdx.y * n_pix * C;
+  st += blockIdx.y * 512;
+  partial += (int64_t)blockIdx.y * gridDim.x * 2 * C;
   const int lanes = 256 / C, c = threadIdx.x % C, pl = threadIdx.x / C;
   const float mean = st[2 * C + c], invstd = st[3 * C + c];
   const int64_t p0 = (int64_t)blockIdx.x * per_block;
@@ -1858,20 +1871,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ sums) {
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, g = blockIdx.y;      // (per group: its own sums; dgamma / dbeta are per-group scratch then)
   double s1, s2;
-  channel_totals(partial, n_blocks, C, c, &s1, &s2);
+  channel_totals(partial + (int64_t)g * n_blocks * 2 * C, n_blocks, C, c, &s1, &s2);
   if (threadIdx.x != 0) return;
-  dgamma[c] = (float)s2;
-  dbeta[c] = (float)s1;
-  sums[c] = (float)(s1 / n);
-  sums[C + c] = (float)(s2 / n);
+  dgamma[g * 256 + c] = (float)s2;
+  dbeta[g * 256 + c] = (float)s1;
+  sums[g * 256 + c] = (float)(s1 / n);
+  sums[g * 256 + C + c] = (float)(s2 / n);
 }
 // stage 3 (in place): dz = scale * (gy - s1/n - zhat * s2/n)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ gy, const float* __restrict__ z, const float* __restrict__ st,
-                                                          const float* __restrict__ sums, int C, int64_t n_quads) {
+                                                          const float* __restrict__ sums, int C, int64_t n_quads, int64_t group_quads) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_quads) return;
+  st += (i / group_quads) * 512;
+  sums += (i / group_quads) * 256;
   const int c4 = (int)(i % (C / 4)) * 4;
   f4 g = *reinterpret_cast<const f4*>(gy + i * 4);
   const f4 v = *reinterpret_cast<const f4*>(z + i * 4);
@@ -2070,11 +2085,11 @@ static TrainBufs train_bufs(float* w, int64_t p1, int64_t p2, int64_t p4) {
   b.st = w;
   return b;
 }
-static int64_t train_saved_floats(int64_t p1, int64_t p2, int64_t p4) {
+static int64_t train_saved_floats(int64_t p1, int64_t p2, int64_t p4, int64_t groups = 1) {
   const int64_t pl[3] = {p1, p2, p4};
   int64_t n = 0;
   for (int l = 0; l < 10; ++l) n += 2 * pl[kLvl[l]] * kUnetConvs[l].cout;
-  return n + p2 * 64 + p4 * 128 + p2 * 128 + p1 * 64 + 10 * 512;
+  return n + p2 * 64 + p4 * 128 + p2 * 128 + p1 * 64 + 10 * 512 * groups;      // st: [10][groups][4][128]
 }
 // offsets of the gradients in the flat output of s2l_unet_train_backward: per layer conv.weight, bn.weight, bn.bias; then
 // outc.conv.weight [3,64], outc.conv.bias [3]
@@ -2365,11 +2380,22 @@ extern "C" int64_t s2l_unet_train_work_floats(int height, int width, int64_t n_f
   return n_frames * (p1 * 256 + p2 * 768 + p4 * 384) + 32 * (int64_t)256 * 128 * 9 + kStatBlocks * 2 * 128 + 4096;
 }
 extern "C" int64_t s2l_unet_grad_floats(void) { return grad_off(10) + 192 + 3; }
+// the per-frame-statistics pair (s2l_unet_train_forward_frames / _backward_frames)
+extern "C" int64_t s2l_unet_train_frames_saved_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 1) return 0;
+  return train_saved_floats((int64_t)height * width * n_frames, (int64_t)(height / 2) * (width / 2) * n_frames,
+                            (int64_t)(height / 4) * (width / 4) * n_frames, n_frames);
+}
+extern "C" int64_t s2l_unet_train_frames_scratch_floats(int64_t n_frames) { return n_frames < 1 ? 0 : n_frames * kStatBlocks * 2 * 128; }
+extern "C" int64_t s2l_unet_train_frames_work_floats(int height, int width, int64_t n_frames) {
+  if (height < 4 || width < 4 || n_frames < 1) return 0;
+  return s2l_unet_train_work_floats(height, width, n_frames) + (n_frames - 1) * ((int64_t)kStatBlocks * 2 * 128 + 512);
+}
 
-static void run_stats(const float* z, int C, int64_t n_pix, float* partial, hipStream_t st, int* n_blocks) {
-  const int64_t per = (n_pix + kStatBlocks - 1) / kStatBlocks;
+static void run_stats(const float* z, int C, int64_t n_pix, float* partial, hipStream_t st, int* n_blocks, int groups = 1) {
+  const int64_t per = (n_pix + kStatBlocks - 1) / kStatBlocks;      // n_pix: pixels of one group
   *n_blocks = (int)((n_pix + per - 1) / per);
-  hipLaunchKernelGGL(channel_stats_kernel, dim3(*n_blocks), dim3(256), 0, st, z, C, n_pix, per, partial);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(*n_blocks, groups), dim3(256), 0, st, z, C, n_pix, per, partial);
 }
 
 // x [F,H,W,3] -> out [F,H,W,3] with batch statistics; running_mean / running_var of the ten BatchNorm layers (entries 3 and 4 of
@@ -2377,9 +2403,12 @@ static void run_stats(const float* z, int C, int64_t n_pix, float* partial, hipS
 // saved: s2l_unet_train_saved_floats floats (kept for s2l_unet_train_backward); scratch: at least 256*2*128 floats.
 // packed16_raw != NULL: the 3x3 layers 1..9 take bf16 operands (s2l_unet_pack16 with bn_eps < 0: the raw weights) on
 // v_mfma_f32_32x32x16_bf16 -- fp32 accumulation, fp32 tensors, fp32 statistics -- as the eval-mode chain does in the bf16 step
+// frames_are_groups: every frame is its own statistics group (F successive one-frame calls of the reference in one set of launches:
+// scratch F x 262144 floats, saved with F statistics blocks per layer); else the batch is one group (nn.BatchNorm2d on [F,C,H,W]).
 static int unet_train_forward_impl(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                    float bn_eps, float momentum, int update_running, const float* x, float* saved, float* scratch,
-                                   float* out, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+                                   float* out, int height, int width, int64_t n_frames, s2l_stream_t stream,
+                                   bool frames_are_groups = false) {
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
   if (!packed_raw || !x || !saved || !scratch || !out) return S2L_E_NULL;
   if (misaligned16(packed_raw) || misaligned16(saved) || misaligned16(packed16_raw)) return S2L_E_ALIGN;
@@ -2390,6 +2419,7 @@ static int unet_train_forward_impl(const float* packed_raw, const uint16_t* pack
   const int H = height, W = width, H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
   const int64_t F = n_frames, p1 = (int64_t)H * W * F, p2 = (int64_t)H2 * W2 * F, p4 = (int64_t)H4 * W4 * F;
   const int64_t pl[3] = {p1, p2, p4};
+  const int groups = frames_are_groups ? (int)F : 1;
   const int hh[3] = {H, H2, H4}, ww[3] = {W, W2, W4};
   const TrainBufs b = train_bufs(saved, p1, p2, p4);
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
@@ -2423,12 +2453,14 @@ static int unet_train_forward_impl(const float* packed_raw, const uint16_t* pack
       else hipLaunchKernelGGL(conv3x3_kernel<false>, grid, dim3(256), 0, st, a);
     }
     int nb = 0;
-    run_stats(b.z[l], C, pl[lv], scratch, st, &nb);
-    float* stl = b.st + l * 512;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (double)pl[lv], bn_eps, momentum, t.gamma[l],
+    const int64_t gpix = pl[lv] / groups;      // pixels per statistics group
+    run_stats(b.z[l], C, gpix, scratch, st, &nb, groups);
+    float* stl = b.st + (int64_t)l * 512 * groups;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (double)gpix, bn_eps, momentum, t.gamma[l],
                        t.beta[l], update_running ? const_cast<float*>(t.mean[l]) : nullptr,
-                       update_running ? const_cast<float*>(t.var[l]) : nullptr, stl);
-    hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4);
+                       update_running ? const_cast<float*>(t.var[l]) : nullptr, stl, groups);
+    hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4,
+                       gpix * C / 4);
     if (l == 1) hipLaunchKernelGGL(maxpool2_kernel, blocks(p2 * 16), dim3(256), 0, st, b.act[1], b.p1, H, W, 64, p2 * 16);
     if (l == 3) hipLaunchKernelGGL(maxpool2_kernel, blocks(p4 * 32), dim3(256), 0, st, b.act[3], b.p2, H2, W2, 128, p4 * 32);
     if (l == 5)
@@ -2447,6 +2479,15 @@ extern "C" int s2l_unet_train_forward(const float* packed_raw, const float* cons
   return unet_train_forward_impl(packed_raw, nullptr, tensors_host, bn_eps, momentum, update_running, x, saved, scratch, out, height,
                                  width, n_frames, stream);
 }
+// F frames = F successive one-frame train-mode calls of the reference (tf_nerf.py:387 inside train_stage1's batch-1 calls) in one set
+// of launches: every frame is normalised with its own statistics, the running statistics move once per frame IN FRAME ORDER.  Same
+// arithmetic per frame as F calls with n_frames = 1: the same bits.  packed16_raw: NULL = exact fp32 convolutions.
+extern "C" int s2l_unet_train_forward_frames(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                             float bn_eps, float momentum, int update_running, const float* x, float* saved,
+                                             float* scratch, float* out, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  return unet_train_forward_impl(packed_raw, packed16_raw, tensors_host, bn_eps, momentum, update_running, x, saved, scratch, out,
+                                 height, width, n_frames, stream, true);
+}
 extern "C" int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                            float bn_eps, float momentum, int update_running, const float* x, float* saved,
                                            float* scratch, float* out, int height, int width, int64_t n_frames, s2l_stream_t stream) {
@@ -2459,7 +2500,8 @@ extern "C" int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16
 // bn.weight [cout], bn.bias [cout] in execution order, then outc.conv.weight [3,64], outc.conv.bias [3]).
 static int unet_train_backward_impl(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                     const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
-                                    int height, int width, int64_t n_frames, s2l_stream_t stream) {
+                                    int height, int width, int64_t n_frames, s2l_stream_t stream, bool frames_are_groups = false) {
+  if (frames_are_groups && grads) return S2L_E_SIZE;      // (per-frame groups exist for the frozen net: input gradient only)
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
   if (misaligned16(packed16_raw)) return S2L_E_ALIGN;
   if (!packed_raw || !x || !saved || !d_out || !work) return S2L_E_NULL;
@@ -2483,8 +2525,9 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
   float* z3 = gcat6 + p2 * 256;  float* z2 = z3 + p2 * 128;     float* gp1 = z2 + p2 * 128;
   float* z5 = gp1 + p2 * 64;     float* z4 = z5 + p4 * 128;     float* gp2 = z4 + p4 * 128;                       // @H/4
   float* wpart = gp2 + p4 * 128;                                 // split-K partials of the weight gradients
-  float* rpart = wpart + 32 * (int64_t)256 * 128 * 9;            // reduction partials + per-channel means
-  float* sums = rpart + kStatBlocks * 2 * 128;
+  const int groups = frames_are_groups ? (int)F : 1;
+  float* rpart = wpart + 32 * (int64_t)256 * 128 * 9;            // reduction partials + per-channel means, per statistics group
+  float* sums = rpart + (int64_t)kStatBlocks * 2 * 128 * groups;
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
   const float* inA[10] = {x, b.act[0], b.p1, b.act[2], b.p2, b.act[4], b.act[3], b.act[6], b.act[1], b.act[8]};
   const float* inB[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, b.u3, nullptr, b.uu, nullptr};
@@ -2493,15 +2536,18 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
   // BatchNorm backward (in place: gy -> dz) + the layer's weight gradient
   auto layer_grads = [&](int l, float* gy) {
     const int lv = kLvl[l], C = kUnetConvs[l].cout, cin = kUnetConvs[l].cin;
-    const int64_t n = pl[lv];
+    const int64_t n = pl[lv] / groups;      // pixels per statistics group
     const int64_t per = (n + kStatBlocks - 1) / kStatBlocks;
     const int nb = (int)((n + per - 1) / per);
-    const float* stl = b.st + l * 512;
+    const float* stl = b.st + (int64_t)l * 512 * groups;
     float* g = want_params ? grads + grad_off(l) : nullptr;
-    float* dgamma = want_params ? g + (int64_t)C * cin * 9 : sums + 512;      // (sums: 2 x 128 means; + 512: 2 x 128 floats of scratch)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dgamma + C, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(n * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, n * C / 4);
+    // (sums: per group 2 x 128 means; frozen net: dgamma / dbeta go to 256 floats of scratch per group behind them)
+    float* dgamma = want_params ? g + (int64_t)C * cin * 9 : sums + 256 * groups;
+    float* dbeta = want_params ? dgamma + C : dgamma + 128;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, pl[lv] * C / 4,
+                       n * C / 4);
     if (!want_params) return;
     if (l == 0) {
       const int64_t perw = (p1 + 1023) / 1024;
@@ -2573,6 +2619,14 @@ extern "C" int s2l_unet_train_backward(const float* packed_raw, const float* con
 }
 // the input gradients of layers 1..9 with bf16 operands (the transposed half of the same s2l_unet_pack16(bn_eps < 0) blob);
 // BatchNorm backward, weight gradients and the first layer stay fp32
+// input gradient of s2l_unet_train_forward_frames (a frozen net: no parameter gradients), per-frame statistics terms
+extern "C" int s2l_unet_train_backward_frames(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                              const float* x, const float* saved, const float* d_out, float* work, float* d_x,
+                                              int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (!d_x) return S2L_E_NULL;
+  return unet_train_backward_impl(packed_raw, packed16_raw, tensors_host, x, saved, d_out, work, d_x, nullptr, height, width, n_frames,
+                                  stream, true);
+}
 extern "C" int s2l_unet_train_backward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                             const float* x, const float* saved, const float* d_out, float* work, float* d_x,
                                             float* grads, int height, int width, int64_t n_frames, s2l_stream_t stream) {

@@ -278,6 +278,64 @@ class SimpleUnetLight(nn.Module):
             off += n
         return dx, grads
 
+    def forward_train_frames_nhwc(self, x: torch.Tensor, update_running: bool = True, precision: str = "fp32"):
+        """x [F,H,W,3] -> (out, ctx): F successive ONE-FRAME train-mode calls in one set of launches (s2l_unet_train_forward_frames):
+        each frame normalised with its own batch statistics, the running statistics moved once per frame in frame order,
+        num_batches_tracked += F -- what the reference's loop does to the (frozen) net, bit for bit what F calls of
+        forward_train_nhwc(x[f:f+1]) compute.  ctx feeds backward_train_frames (input gradient only)."""
+        lib = _abi.load()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if x.device.type != "cuda":
+            raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
+        tensors = self._tensors()
+        dev = tensors[0].device
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise _abi.S2LError("U-Net parameters and buffers must be contiguous fp32 tensors on one GPU")
+        x = x.detach().to(torch.float32).contiguous()
+        F_, H, W, C = x.shape
+        if C != 3 or H < 4 or W < 4 or F_ < 1:
+            raise ValueError(f"U-Net input must be [F>=1,H>=4,W>=4,3], got {tuple(x.shape)}")
+        table = self._table(tensors)
+        raw, raw16 = self._raw_blobs(tensors, table, precision == "bf16")
+        out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
+        saved = torch.empty(int(lib.s2l_unet_train_frames_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.s2l_unet_train_frames_scratch_floats(F_)), dtype=torch.float32, device=dev)
+        bn = self.inc.double_conv[1]
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _abi.check(lib.s2l_unet_train_forward_frames(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                                         1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                       "s2l_unet_train_forward_frames")
+        if update_running:
+            torch._foreach_add_([mod.num_batches_tracked for mod in self.modules() if isinstance(mod, nn.BatchNorm2d)], F_)
+            self._packed = self._packed_key = None
+            self._packed16 = self._packed16_key = None
+            self._packed16x3 = self._packed16x3_key = None
+        return out, (raw, x, saved, (F_, H, W), raw16)
+
+    def backward_train_frames(self, ctx, d_out: torch.Tensor) -> torch.Tensor:
+        """d loss / d x [F,H,W,3] for a forward_train_frames_nhwc state (the net's parameters receive nothing: frozen)."""
+        lib = _abi.load()
+        raw, x, saved, (F_, H, W), raw16 = ctx
+        dev = x.device
+        d = d_out.detach().to(torch.float32).contiguous()
+        if d.shape != (F_, H, W, 3) or d.device != dev:
+            raise ValueError(f"d_out must be [{F_},{H},{W},3] on {dev}")
+        tensors = self._tensors()
+        table = self._table(tensors)
+        dx = torch.empty_like(d)
+        work = torch.empty(int(lib.s2l_unet_train_frames_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
+        p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        with torch.cuda.device(dev):
+            _abi.check(lib.s2l_unet_train_backward_frames(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), H, W, F_,
+                                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "s2l_unet_train_backward_frames")
+        return dx
+
     def forward_saved_nhwc(self, x: torch.Tensor, window=None, precision: str = "fp32"):
         """Training-time forward of the frozen eval-mode network: x [F,H,W,3] -> (out [F,H,W,3], saved), where `saved` holds
         every activation `backward_input` needs (504 MB per 500x500 frame).  The caller bounds F.
@@ -339,6 +397,18 @@ class SimpleUnetLight(nn.Module):
             return self.forward_saved_nhwc(x, window=window, precision=precision)
         if window is not None:
             raise ValueError("train-mode BatchNorm needs whole frames: statistics are taken over the full image")
+        if not any(p.requires_grad for p in self.parameters()):
+            # the frozen net of the loop after it > 100000: the frames go through in groups of whole frames, every frame still its own
+            # statistics group (s2l_unet_train_forward_frames: the same bits as one call per frame, ~1/F of the launches)
+            F_, H, W = x.shape[0], x.shape[1], x.shape[2]
+            per_frame = 4 * (int(_abi.load().s2l_unet_train_frames_saved_floats(H, W, 1)) + int(_abi.load().s2l_unet_train_frames_work_floats(H, W, 1)))
+            group = max(1, min(F_, (16 << 30) // max(per_frame, 1)))
+            outs, ctxs = [], []
+            for s0 in range(0, F_, group):
+                o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)
+                outs.append(o)
+                ctxs.append((s0, min(F_, s0 + group), c))
+            return torch.cat(outs, 0), ("train_frames", ctxs)
         outs, ctxs = [], []
         for f in range(x.shape[0]):
             o, c = self.forward_train_nhwc(x[f:f + 1], update_running=True, precision=precision)
@@ -350,6 +420,8 @@ class SimpleUnetLight(nn.Module):
         """d loss / d x for a `forward_for_backward` state.  Train mode: the BatchNorm backward carries the batch-statistics terms
         whether or not the parameters are frozen; when `param_grads` is a dict the parameter gradients are ACCUMULATED into it
         under their state-dict names (the net while it still trains, it <= 100000)."""
+        if isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train_frames":
+            return torch.cat([self.backward_train_frames(c, d_out[s0:s1]) for s0, s1, c in ctx[1]], 0)
         if not (isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train"):
             return self.backward_input(ctx, d_out)
         dxs = []

@@ -782,6 +782,52 @@ def test_unet_train_mode_bf16_convolutions_vs_fp32(dev, fh, fw):
     assert u16._raw16 is not raw_a
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("F,fh,fw", [(5, 36, 44), (3, 500, 500)])
+def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
+    """s2l_unet_train_forward_frames / _backward_frames: F frames, each its own statistics group, in one set of launches == F
+    successive one-frame train-mode calls (what the reference's loop makes): outputs, input gradients, the running statistics
+    after the F sequential momentum updates and the batch counters -- the same bits.  And forward_for_backward takes this route for a
+    frozen net, the per-frame route for a net that trains."""
+    def net():
+        u = s2l.SimpleUnetLight().to(dev).train()
+        u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
+        return u
+    ua, ub = net(), net()
+    rng = np.random.default_rng(F * fh)
+    x = T(rng.random((F, fh, fw, 3), dtype=np.float32)).to(dev)
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    outs, dxs = [], []
+    for f in range(F):
+        o, c = ua.forward_train_nhwc(x[f:f + 1], precision=precision)
+        outs.append(o)
+        dxs.append(ua.backward_train(c, d[f:f + 1], want_param_grads=False)[0])
+    o_b, c_b = ub.forward_train_frames_nhwc(x, precision=precision)
+    dx_b = ub.backward_train_frames(c_b, d)
+    assert torch.equal(o_b, torch.cat(outs, 0)) and torch.equal(dx_b, torch.cat(dxs, 0))
+    sa, sb = ua.state_dict(), ub.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sb["inc.double_conv.1.num_batches_tracked"]) == 100 + F
+    # the mode-following pair: frozen -> frames route, same numbers again; trainable -> one call per frame with parameter gradients
+    for p_ in ub.parameters():
+        p_.requires_grad_(False)
+    o2, ctx = ub.forward_for_backward(x, precision=precision)
+    assert ctx[0] == "train_frames" and o2.shape == o_b.shape
+    dx2 = ub.backward_to_input(ctx, d)
+    uc = net()
+    for f in range(F):      # bring a third net to ub's state before that call, then compare
+        uc.forward_train_nhwc(x[f:f + 1], precision=precision)
+    oc, dc = [], []
+    for f in range(F):
+        o, c = uc.forward_train_nhwc(x[f:f + 1], precision=precision)
+        oc.append(o)
+        dc.append(uc.backward_train(c, d[f:f + 1], want_param_grads=False)[0])
+    assert torch.equal(o2, torch.cat(oc, 0)) and torch.equal(dx2, torch.cat(dc, 0))
+    _, ctx_t = ua.forward_for_backward(x[:2], precision=precision)
+    assert ctx_t[0] == "train"
+
+
 def test_train_step_from_a_dataset_folder(syncnet, dev):
     """Dataset folder -> SomeonesLipClip.load_one_frame (golden G15: equal to the reference reader's dictionary) -> collate ->
     Trainer.train_step, i.e. the reference's loop body fed from disk instead of from a golden: the it > 100000 step (sync window
