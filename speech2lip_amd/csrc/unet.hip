@@ -1773,6 +1773,46 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   }
 }
 
+// the same per group with the groups in PARALLEL (grid C x groups), the running statistics left to bn_running_kernel: with forty
+// frames per launch the in-order loop above was 80 us of sequential 1024-term reductions per layer.  Each block leaves the two
+// numbers its group contributes to the running statistics in its own slots of the partial buffer (row 0 of its group; nobody else
+// reads this channel's column).
+__global__ __launch_bounds__(64) void bn_finalize_groups_kernel(float* __restrict__ partial, int n_blocks, int C, double n, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ st) {
+  const int c = blockIdx.x, g = blockIdx.y;
+  float* pg = partial + (int64_t)g * n_blocks * 2 * C;
+  double s, ss;
+  channel_totals(pg, n_blocks, C, c, &s, &ss);
+  if (threadIdx.x != 0) return;
+  float* stg = st + g * 512;
+  const double mean = s / n;
+  double var = ss / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float scale = gamma[c] * invstd;
+  stg[c] = scale;
+  stg[C + c] = beta[c] - (float)mean * scale;
+  stg[2 * C + c] = (float)mean;
+  stg[3 * C + c] = invstd;
+  pg[c] = (float)mean;
+  pg[C + c] = (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+}
+// running statistics: one momentum update per group, in group (= frame) order; thread = channel
+__global__ __launch_bounds__(128) void bn_running_kernel(const float* __restrict__ partial, int n_blocks, int C, int groups, float momentum,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float rm = running_mean[c], rv = running_var[c];
+  for (int g = 0; g < groups; ++g) {
+    const float* pg = partial + (int64_t)g * n_blocks * 2 * C;
+    rm = (1.f - momentum) * rm + momentum * pg[c];
+    rv = (1.f - momentum) * rv + momentum * pg[C + c];
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
+}
+
 // a = relu(z * scale + shift); pool != NULL: also MaxPool2d(2) of a ([F,H/2,W/2,C]), one thread per (pixel, channel quad)
 __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ z, const float* __restrict__ st, float* __restrict__ a,
                                                      int C, int64_t n_quads, int64_t group_quads) {
@@ -2456,9 +2496,17 @@ static int unet_train_forward_impl(const float* packed_raw, const uint16_t* pack
     const int64_t gpix = pl[lv] / groups;      // pixels per statistics group
     run_stats(b.z[l], C, gpix, scratch, st, &nb, groups);
     float* stl = b.st + (int64_t)l * 512 * groups;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (double)gpix, bn_eps, momentum, t.gamma[l],
-                       t.beta[l], update_running ? const_cast<float*>(t.mean[l]) : nullptr,
-                       update_running ? const_cast<float*>(t.var[l]) : nullptr, stl, groups);
+    if (groups == 1) {
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (double)gpix, bn_eps, momentum, t.gamma[l],
+                         t.beta[l], update_running ? const_cast<float*>(t.mean[l]) : nullptr,
+                         update_running ? const_cast<float*>(t.var[l]) : nullptr, stl, groups);
+    } else {
+      hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(C, groups), dim3(64), 0, st, scratch, nb, C, (double)gpix, bn_eps, t.gamma[l],
+                         t.beta[l], stl);
+      if (update_running)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(128), 0, st, scratch, nb, C, groups, momentum,
+                           const_cast<float*>(t.mean[l]), const_cast<float*>(t.var[l]));
+    }
     hipLaunchKernelGGL(bn_relu_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, b.z[l], stl, b.act[l], C, pl[lv] * C / 4,
                        gpix * C / 4);
     if (l == 1) hipLaunchKernelGGL(maxpool2_kernel, blocks(p2 * 16), dim3(256), 0, st, b.act[1], b.p1, H, W, 64, p2 * 16);
