@@ -186,6 +186,41 @@ class Trainer:
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
         return float(loss), loss_all
 
+    def visualize(self, visualize, logger, it):
+        """training.py:676-740 under the May flags: eval mode, the 4-tap ensemble render of the validation frame (`seed=0`, one
+        chunk = the whole lip image), PSNR = -10 log10(mean((pred - rgb)^2)) against `visualize['rgb']`; without a logger the PSNR is
+        returned (what `evaluate` uses), with one the reference's four records are written; then train mode again."""
+        import numpy as np
+        from .rendering import get_coords
+        self.model.eval()
+        try:
+            with torch.no_grad():
+                image = visualize["rgb"].squeeze()
+                rgb_zero = visualize["rgb_zero"].reshape(-1, 3) if "rgb_zero" in visualize else None
+                H, W = int(visualize["height"]), int(visualize["width"])
+                if (H, W) != (self.height, self.width) or self.batch_rays != H * W:
+                    raise NotImplementedError("visualize renders the configured lip crop in one chunk (batch_rays = H*W)")
+                audio = visualize["audio"].to(self.device)
+                coords = get_coords(W, H, self.device)
+                on = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in visualize.items()}
+                rgb_map = self.predict_lip_image(0, coords, audio, None, on, rgb_zero, None, seed=0).reshape(H, W, 3)
+                mse = torch.mean((rgb_map.cpu() - image.cpu()) ** 2)
+                psnr = -10.0 * torch.log(mse) / torch.log(torch.Tensor([10.0]))
+                if logger is None:
+                    return psnr
+                to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)      # utils.py:6
+                logger.add_image("rgb_prediction", to8b(rgb_map.cpu().numpy()).transpose([2, 0, 1]), it)
+                logger.add_image("rgb_gt", image.cpu().numpy().transpose([2, 0, 1]), it)
+                logger.add_scalar("val_mini/loss", mse, it)
+                logger.add_scalar("val_mini/psnr", psnr, it)
+        finally:
+            self.model.train()
+
+    def evaluate(self, val_loader, focal_length=None, batch_size=None, it=None):
+        """training.py:742-751: mean PSNR of `visualize` over the validation loader."""
+        psnr = torch.stack([self.visualize(inputs, None, it=it) for inputs in val_loader], 0).mean()
+        return {"psnr": psnr}
+
     def train_stage1(self, data, eval_model=False, it=None, seed=None):
         """One optimisation step as the reference performs it (training.py:347-574) under the May flags, through the drop-in's
         methods and their hand-written backward kernels:  zero_grad -> lip render -> MSE [+ LPIPS] on the lip -> composite with

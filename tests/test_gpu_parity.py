@@ -291,6 +291,45 @@ def test_predict_lip_image_golden(golden, dev):
     assert abs(loss - float(g["loss"])) <= 1e-6
 
 
+def test_trainer_visualize_and_evaluate(sd, dev):
+    """Trainer.visualize / evaluate (training.py:676-751, the validation callers of predict_lip_image): eval mode, the ensemble
+    render with time index + seed 0, PSNR against the frame; with a logger the reference's four records; train mode afterwards."""
+    h, w = 12, 20
+    m = make_model(dev, h, w)
+    tr = s2l.Trainer(m)
+    assert tr.height == h and tr.width == w
+    win = T(W.synthetic_audio(4, seed=21).astype(np.float32))
+    rng = np.random.default_rng(5)
+    frames = [{"rgb": T(rng.random((1, h, w, 3), dtype=np.float32)), "rgb_zero": torch.zeros(1, h, w, 3), "audio": win[i:i + 1],
+               "index": torch.tensor([40 + i]), "height": torch.tensor(h), "width": torch.tensor(w)} for i in range(3)]
+    u = 0.25
+    real = torch.rand
+    torch.rand = lambda *a, **k: torch.full((1,), u, device=dev)
+    try:
+        m.train()
+        got = tr.evaluate(frames, None, 1, it=7)
+        assert m.training                                     # the reference leaves the model in train mode
+        records = []
+
+        class Logger:
+            def add_image(self, name, img, it):
+                records.append((name, img.shape, img.dtype, it))
+
+            def add_scalar(self, name, v, it):
+                records.append((name, float(v), it))
+        assert tr.visualize(frames[0], Logger(), 7) is None
+    finally:
+        torch.rand = real
+    want = []
+    with torch.no_grad():
+        for i, fr in enumerate(frames):
+            pred = O.predict_lip_image(sd, O.get_coords(w, h), win[i], 40 + i, h, w, u)[:, :3].reshape(h, w, 3)
+            want.append(-10.0 * torch.log10(torch.mean((pred - fr["rgb"][0]) ** 2)))
+    assert abs(float(got["psnr"]) - float(torch.stack(want).mean())) <= 1e-4
+    assert [r[0] for r in records] == ["rgb_prediction", "rgb_gt", "val_mini/loss", "val_mini/psnr"]
+    assert records[0][1] == (3, h, w) and records[0][2] == np.uint8 and abs(records[3][1] - float(want[0])) <= 1e-4
+
+
 @pytest.mark.parametrize("h,w,u", [(12, 20, 0.0), (5, 7, 0.999), (96, 96, 0.5)])
 def test_predict_lip_image_vs_oracle(sd, dev, h, w, u):
     m = make_model(dev, h, w)
