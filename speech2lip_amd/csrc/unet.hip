@@ -856,9 +856,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
 //    = 5 x 256 bytes apart, so the sixteen pixels of an operand read cover all 64 banks) and two weight buffers: during chunk g the
 //    weights of g + 1 arrive by LDS-DMA, the halo values of g + 1 (requested during g - 1, held in registers) are converted and
 //    written behind the MFMAs of taps 5..8, and the values of g + 2 are requested -- one barrier per chunk, no commit phase;
-//  * the requests are assembly text (the compiler would drain vmcnt before every LDS access that may alias an outstanding LDS-DMA)
-//    and the waits are counted: loads return in order, so "at most n outstanding" retires everything older than the n newest
-//    (a tile's epilogue stores in between only make a wait stricter);
+//  * the weight requests are assembly text (the compiler would drain vmcnt before every LDS access that may alias an LDS-DMA it
+//    knows about) waited for with a counted vmcnt: loads return in order, so "at most n outstanding" retires everything older
+//    than the n newest (a tile's epilogue stores in between only make a wait stricter); so are the requests of the halo values
+//    inside the chunk loop (see fetch_one for the three rules that keep their registers from being copied in flight);
 //  * the eight operand reads of tap t + 1 are issued one behind each of the first eight MFMAs of tap t.
 constexpr int kSwzRow = 20 * 64;                                // bytes between halo rows
 constexpr int kSwzIn = 34 * kSwzRow;                            // 43 520 bytes per halo buffer
@@ -956,15 +957,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
   for (int k = 0; k < kInPer; ++k) pin[0][k] = pin[1][k] = (f4){0.f, 0.f, 0.f, 0.f};
   int pvalid[2] = {0, 0};
-  auto fetch_one = [&](int k, auto SET) {
+  auto fetch_one = [&](int k, auto SET, auto PLAIN) {
     const bool fromA = f_cc * 16 < a.CA;
     const float* src = (fromA ? f_inA : f_inB) + (fromA ? f_cc * 16 : f_cc * 16 - a.CA) + c4x4;
     const int C = fromA ? a.CA : a.CB;
-    // ("+v": the staging register is one physical register from request to commit, which only happens behind a counted wait;
-    // every request of a register is the SAME instruction in straight-line code -- a second site would make the compiler copy it)
-    f4& dstreg = pin[decltype(SET)::value][k];
+    // Inside the chunk loop the request is assembly text with a TIED operand: the staging variable is defined in place, so it
+    // never leaves its physical register, and nothing reads it until `values_landed` below.  Three rules keep the register
+    // allocator from copying a register whose load is still in flight (a copy taken before the data lands and written back later
+    // -- ~1 % of random shapes showed wrong pixels in tools/soak_conv_kernels.py while any of them was broken):
+    //  (1) every in-loop definition of a staging register is a tied asm (no second register can hold the value);
+    //  (2) the prologue's requests are ORDINARY loads (`plain`), so the copies the allocator makes at the loop entry, where
+    //      prologue and loop disagree about registers, are behind the compiler's own wait;
+    //  (3) the counted wait is an asm WITHOUT register operands, followed by one tied no-op per staging set (a switch over tied
+    //      asm statements made the allocator copy the set into temporaries before the wait and back after it).
+    // tests/test_abi_and_host.py checks the built code object: no v_mov / v_accvgpr reads a register that an asm load writes.
     const float* addr = src + (int64_t)pixoff[k] * C;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dstreg) : "v"(addr) : "memory");
+    if constexpr (decltype(PLAIN)::value) {
+      pin[decltype(SET)::value][k] = *reinterpret_cast<const f4*>(addr);
+    } else {
+      f4& dstreg = pin[decltype(SET)::value][k];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dstreg) : "v"(addr) : "memory");
+    }
   };
   auto f_advance = [&](auto SET) {
     pvalid[decltype(SET)::value] = f_vbits;
@@ -1021,20 +1034,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     }
   };
-  // the wait that retires the staged VALUES of a set names them as in-out operands: what commit_one reads are this statement's
-  // outputs, so no pass can move the conversion arithmetic (pure functions of the registers, as far as the compiler knows) above it
-  auto wait_values = [&](int newer, auto SET) {
+  // the counted wait for a staging set + the tied no-op that makes the set's registers depend on it (rule 3)
+  auto values_landed = [&](int newer, auto SET) {
     constexpr int set = decltype(SET)::value;
-#define S2L_WAIT_VALUES(N)                                                                                                       \
-  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pin[set][0]), "+v"(pin[set][1]), "+v"(pin[set][2]), "+v"(pin[set][3]), "+v"(pin[set][4]) : : "memory")
-    switch (newer) {
-      case 0: S2L_WAIT_VALUES(0); break;
-      case 4: S2L_WAIT_VALUES(4); break;
-      case 5: S2L_WAIT_VALUES(5); break;
-      case 9: S2L_WAIT_VALUES(9); break;
-      default: S2L_WAIT_VALUES(10); break;
-    }
-#undef S2L_WAIT_VALUES
+    wait_loads(newer);
+    f4 &p0 = pin[set][0], &p1 = pin[set][1], &p2 = pin[set][2], &p3 = pin[set][3], &p4 = pin[set][4];
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4) : : "memory");
   };
   auto barrier_lgkm = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -1047,41 +1052,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
   f_setup();
   if constexpr (SPLIT) {
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{}, IntC<1>{});
     f_advance(IntC<0>{});
 #pragma unroll
     for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
     w_advance();
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{}, IntC<1>{});
     f_advance(IntC<1>{});
-    wait_values(5, IntC<0>{});
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
+    wait_loads(kInPer);                                         // chunk 0's weight pieces (older than chunk 1's five value loads)
   } else {
     // both halves of chunk 0, committed at once (the one exposed latency of the workgroup); then both halves of chunk 1
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{}, IntC<1>{});
     f_advance(IntC<0>{});
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{}, IntC<1>{});
     f_advance(IntC<1>{});
 #pragma unroll
     for (int j = 0; j < kDmaPer; ++j) dma_piece(j, 0);
     w_advance();
-    wait_values(0, IntC<0>{});
-    wait_values(0, IntC<1>{});
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<0>{}, 0);
 #pragma unroll
     for (int k = 0; k < kInPer; ++k) commit_one(k, IntC<1>{}, 0);
+    wait_loads(0);                                              // chunk 0's weight pieces
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<0>{}, IntC<1>{});
     f_advance(IntC<0>{});
 #pragma unroll
-    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{});
+    for (int k = 0; k < kInPer; ++k) fetch_one(k, IntC<1>{}, IntC<1>{});
     f_advance(IntC<1>{});
   }
+  // the compiler waits for the prologue's (ordinary) loads HERE: a load it still counts as pending at the loop entry would make it
+  // drain vmcnt at the first use inside the loop, on every pass
+  asm volatile("" : "+v"(pin[0][0]), "+v"(pin[0][1]), "+v"(pin[0][2]), "+v"(pin[0][3]), "+v"(pin[0][4]));
+  asm volatile("" : "+v"(pin[1][0]), "+v"(pin[1][1]), "+v"(pin[1][2]), "+v"(pin[1][3]), "+v"(pin[1][4]));
   barrier_lgkm();
   PHS(0);
 
@@ -1092,7 +1100,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int set = decltype(SET)::value;                   // chunk parity = its halo / weight buffer = the staging set of chunk g + 2
     const bool next1 = seq + 1 < chunks_total;                  // chunk g + 1 exists: its weights move, its values are committed
     const bool next2 = seq + 2 < chunks_total;                  // chunk g + 2 exists: its values are requested into pin[set]
-    const int issued = (next1 ? n_dma : 0) + (next2 ? kInPer : 0);
     const uint16_t* wcur = lds_w + set * kChunk16Halves;
     const char* icur = lds_in + set * kSwzIn;
     u4v A[2][2][2], B[2][2][2];   // [register set][part: hi, lo][block]
@@ -1114,7 +1121,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int cur = t & 1;
-      if (t == 5 && next1) wait_values(issued, IntC<set ^ 1>{});      // the values of chunk g + 1 (requested during g - 1) have landed
+      if (t == 5 && next1) values_landed((next1 ? n_dma : 0) + (next2 ? kInPer : 0), IntC<set ^ 1>{});      // chunk g + 1's values (requested during g - 1)
 #pragma unroll
       for (int m = 0; m < 12; ++m) {      // smallest terms first: lo x hi, hi x lo, hi x hi
         const int g = m >> 2, mb = (m >> 1) & 1, nb = m & 1;
@@ -1126,8 +1133,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       // behind tap 0..4: two requests each, weights first (they are needed at the end of THIS chunk): D0 D1 | D2 D3 | D4 L0 | L1 L2 | L3 L4
       if (t < 5 && !(S2L_UEXP & 32)) {
         const int r0 = 2 * t, r1 = 2 * t + 1;
-        if (r0 < 5) { if (next1) dma_piece(r0, set ^ 1); } else if (next2) fetch_one(r0 - 5, SET);
-        if (r1 < 5) { if (next1) dma_piece(r1, set ^ 1); } else if (next2) fetch_one(r1 - 5, SET);
+        if (r0 < 5) { if (next1) dma_piece(r0, set ^ 1); } else if (next2) fetch_one(r0 - 5, SET, IntC<0>{});
+        if (r1 < 5) { if (next1) dma_piece(r1, set ^ 1); } else if (next2) fetch_one(r1 - 5, SET, IntC<0>{});
       }
       // behind tap 5..8: the values of chunk g + 1 -> the other halo buffer (2 + 1 + 1 + 1 quads)
       if (t >= 5 && next1) {
@@ -1168,8 +1175,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       const int cur = t & 1;
       // set 0 = channels 0..15 of chunk g + 1 (requested during g - 1, before that chunk's set-1 requests: 5 newer loads);
       // set 1 = channels 16..31 (newer: this chunk's weight pieces and set-0 requests)
-      if (t == 0 && next1) wait_values(kInPer, IntC<0>{});
-      if (t == 5 && next1) wait_values(n_dma + (next2 ? kInPer : 0), IntC<1>{});
+      if (t == 0 && next1) values_landed(kInPer, IntC<0>{});
+      if (t == 5 && next1) values_landed(n_dma + (next2 ? kInPer : 0), IntC<1>{});
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int ks = m >> 2, mb = (m >> 1) & 1, nb = m & 1;
@@ -1186,12 +1193,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       // requests: D0 D1 | D2 D3 | D4 L0 | L1 L2 | L3 L4 behind taps 0..4 (set 0 <- g + 2), L0' L1' L2' | L3' L4' behind taps 7, 8 (set 1)
       if (t < 5) {
         const int r0 = 2 * t, r1 = 2 * t + 1;
-        if (r0 < 5) { if (next1) dma_piece(r0, buf ^ 1); } else if (next2) fetch_one(r0 - 5, IntC<0>{});
-        if (r1 < 5) { if (next1) dma_piece(r1, buf ^ 1); } else if (next2) fetch_one(r1 - 5, IntC<0>{});
+        if (r0 < 5) { if (next1) dma_piece(r0, buf ^ 1); } else if (next2) fetch_one(r0 - 5, IntC<0>{}, IntC<0>{});
+        if (r1 < 5) { if (next1) dma_piece(r1, buf ^ 1); } else if (next2) fetch_one(r1 - 5, IntC<0>{}, IntC<0>{});
       }
       if (t == 4 && next2) f_advance(IntC<0>{});
-      if (t == 7 && next2) { fetch_one(0, IntC<1>{}); fetch_one(1, IntC<1>{}); fetch_one(2, IntC<1>{}); }
-      if (t == 8 && next2) { fetch_one(3, IntC<1>{}); fetch_one(4, IntC<1>{}); }
+      if (t == 7 && next2) { fetch_one(0, IntC<1>{}, IntC<0>{}); fetch_one(1, IntC<1>{}, IntC<0>{}); fetch_one(2, IntC<1>{}, IntC<0>{}); }
+      if (t == 8 && next2) { fetch_one(3, IntC<1>{}, IntC<0>{}); fetch_one(4, IntC<1>{}, IntC<0>{}); }
       __builtin_amdgcn_sched_barrier(0);
     }
     PHS(1);
@@ -1402,7 +1409,7 @@ static int launch_conv_persistent(ConvArgs& a, int64_t F, bool fuse_out, bool sp
   const int64_t total = (int64_t)a.tiles_x * ((a.H + 31) / 32) * a.n_ct * F;
   const int nchunks = (a.CA + a.CB) / (split ? 16 : 32);
   if (g_split_kernel_kind.load(std::memory_order_relaxed) != 0 || (a.CA + a.CB) % (split ? 16 : 32) != 0 || nchunks % 2 != 0 ||
-      (a.CB != 0 && a.CA % 16 != 0) || a.n_ct > 4 || a.pool && fuse_out || total >= 0x7fffffff || total == 0)
+      (a.CB != 0 && a.CA % 16 != 0) || a.n_ct > 4 || (a.pool && fuse_out) || total >= 0x7fffffff || total == 0)
     return S2L_OK;
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);

@@ -404,3 +404,52 @@ def test_no_kernel_spills_to_scratch():
     assert len(counted) >= 4 + 3 + 1 + 1 + 4, counted
     for k in counted:
         assert table[k]["vgprs"] + table[k].get("agprs", 0) <= 512
+
+
+def test_staging_registers_of_the_persistent_conv_kernel_are_never_copied(tmp_path):
+    """conv3x3_split_kernel requests halo values with assembly-text loads into tied operands and retires them with a hand-counted
+    vmcnt (csrc/unet.hip, fetch_one: three rules).  If the register allocator ever copies one of those registers (v_mov /
+    v_accvgpr) the copy may be taken before the data has landed -- a rare, timing-dependent corruption that an earlier form of the
+    kernel had (tools/soak_conv_kernels.py found it).  Check the compiler's own assembly: in every instantiation, no move reads a
+    register that an assembly-text load writes, and all instantiations stage in registers only (no scratch)."""
+    import shutil
+    import subprocess
+    from speech2lip_amd import build
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    build.build_library()                                      # (generates the .inc files unet.hip includes)
+    out = tmp_path / "unet.s"
+    flags = [f for f in build.FLAGS if not f.startswith("-Rpass")]
+    subprocess.run([hipcc, *flags, "-I", os.path.join(build.PKG, "build"), "-S", "--cuda-device-only",
+                    os.path.join(build.CSRC, "unet.hip"), "-o", str(out)], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    txt = out.read_text().split("\n")
+    starts = [i for i, l in enumerate(txt) if re.match(r"^_ZN3s2l20conv3x3_split_kernel\w+:", l)]
+    assert len(starts) == 4
+    for st in starts:
+        end = next(i for i in range(st, len(txt)) if "s_endpgm" in txt[i])
+        body = txt[st:end]
+        regs, inasm = set(), False
+        for l in body:
+            if "ASMSTART" in l:
+                inasm = True
+            elif "ASMEND" in l:
+                inasm = False
+            elif inasm:
+                m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+                if m:
+                    regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        assert len(regs) == 40, (txt[st], sorted(regs))       # two staging sets of five 16-byte registers, the same ones at every site
+        for l in body:
+            l2 = l.strip()
+            ops = l2.split(None, 1)
+            if len(ops) < 2 or not ops[0].startswith(("v_mov", "v_accvgpr", "v_swap")):
+                continue
+            used = set()
+            for src in ops[1].split(",")[1:]:
+                for m in re.finditer(r"v\[(\d+):(\d+)\]", src):
+                    used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                for m in re.finditer(r"\bv(\d+)\b", src):
+                    used.add(int(m.group(1)))
+            assert not (used & regs), (txt[st], l2)
+        assert not any("scratch_" in l for l in body)
