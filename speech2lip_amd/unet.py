@@ -402,7 +402,7 @@ class SimpleUnetLight(nn.Module):
             # statistics group (s2l_unet_train_forward_frames: the same bits as one call per frame, ~1/F of the launches)
             F_, H, W = x.shape[0], x.shape[1], x.shape[2]
             per_frame = 4 * (int(_abi.load().s2l_unet_train_frames_saved_floats(H, W, 1)) + int(_abi.load().s2l_unet_train_frames_work_floats(H, W, 1)))
-            group = max(1, min(F_, (16 << 30) // max(per_frame, 1)))
+            group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
             outs, ctxs = [], []
             for s0 in range(0, F_, group):
                 o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)

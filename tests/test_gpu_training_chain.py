@@ -826,6 +826,19 @@ def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
     assert torch.equal(o2, torch.cat(oc, 0)) and torch.equal(dx2, torch.cat(dc, 0))
     _, ctx_t = ua.forward_for_backward(x[:2], precision=precision)
     assert ctx_t[0] == "train"
+    # several groups of frames (a small memory budget): same numbers, the running statistics still in frame order
+    ud, ue = net(), net()
+    for u_ in (ud, ue):
+        for p_ in u_.parameters():
+            p_.requires_grad_(False)
+    per_frame = 4 * (int(s2l._abi.load().s2l_unet_train_frames_saved_floats(fh, fw, 1)) + int(s2l._abi.load().s2l_unet_train_frames_work_floats(fh, fw, 1)))
+    ue.train_frames_budget_bytes = 2 * per_frame
+    o_d, c_d = ud.forward_for_backward(x, precision=precision)
+    o_e, c_e = ue.forward_for_backward(x, precision=precision)
+    assert len(c_d[1]) == 1 and len(c_e[1]) == (F + 1) // 2
+    assert torch.equal(o_d, o_e) and torch.equal(ud.backward_to_input(c_d, d), ue.backward_to_input(c_e, d))
+    for k, v in ud.state_dict().items():
+        assert torch.equal(v, ue.state_dict()[k]), k
 
 
 def test_train_step_from_a_dataset_folder(syncnet, dev):
