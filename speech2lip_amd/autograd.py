@@ -171,13 +171,15 @@ class _UnetTrain(torch.autograd.Function):
     def forward(ctx, unet, x, *params):
         out, saved = unet.forward_train_nhwc(x, update_running=True)
         ctx.unet, ctx.saved, ctx.need_dx = unet, saved, x.requires_grad
+        ctx.need_params = any(p_.requires_grad for p_ in params)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx)
+        # a frozen net in train-mode BatchNorm (the reference's loop after it > 100000) needs no weight-gradient kernels
+        dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx, want_param_grads=ctx.need_params)
         ctx.saved = None
-        return (None, dx, *[grads[n] for n in ctx.unet.grad_names()])
+        return (None, dx, *[grads.get(n) if ctx.need_params else None for n in ctx.unet.grad_names()])
 
 
 def unet_train(unet, x_nhwc):

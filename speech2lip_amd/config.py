@@ -62,7 +62,8 @@ _MAY = {
                  # loss switches of may.yaml:43-54.  `may_config(train_flags=False)` (the default) switches the three that need
                  # assets outside the reference repository off: LPIPS / AlexNet weights, lipsync_expert.pth, the 3DMM depth init
                  "stage": "stage1", "w_post_fusion": 1.0, "use_perceptual_loss": True, "w_perceptual_loss": 0.01,
-                 "use_syncloss": True, "w_syncloss": 0.01, "use_canonical_depth_loss_photo": False,
+                 "use_syncloss": True, "use_sync_contrastive_loss": True, "w_syncloss": 0.01, "use_fusion_face": True,
+                 "fix_post_net": False, "use_canonical_depth_loss_photo": False,
                  "use_canonical_depth_loss_photo_v2": True, "use_canonical_depth_loss_geo": False,
                  "use_lip_photo_loss": "v1", "use_lip_perc_loss": "v1", "use_face_photo_loss": True, "use_face_perc_loss": True},
 }
@@ -81,5 +82,63 @@ def may_config(height: int = 96, width: int = 96, data_path: str = "dataset/may_
     if train_flags:
         cfg["model"]["use_canonical_depth"] = True
     else:
-        cfg["training"].update(use_perceptual_loss=False, use_syncloss=False, use_canonical_depth_loss_photo_v2=False)
+        cfg["training"].update(use_perceptual_loss=False, use_syncloss=False, use_sync_contrastive_loss=False,
+                               use_canonical_depth_loss_photo_v2=False)
     return cfg
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's plugin factory for this path: src/config.py:8-11 (`method_dict`), :67-95 (`get_model`, `get_trainer`),
+# dispatching to src/face_simple/config.py:13-94.  Same names, same argument order, same cfg keys.
+def _fs_get_model(cfg, device=None, dataset=None, **kwargs):
+    """src/face_simple/config.py:13-23: `TalkingFace(device=device, cfg=cfg)`; `len_dataset` / `config` / `dataset` are accepted
+    and ignored exactly as there."""
+    from .talking_face import TalkingFace
+    return TalkingFace(device=device, cfg=cfg)
+
+
+def _fs_get_trainer(model, optimizer, cfg, device, **kwargs):
+    """src/face_simple/config.py:25-94: reads the same cfg keys and passes them to `Trainer` under the reference's keyword names.
+    The reference indexes every key with [] because its default.yaml supplies them all; here a key that is absent falls back to
+    that default.yaml's value (configs/face_simple_configs/default.yaml), so both a full reference config and `may_config()` work."""
+    from .training import Trainer
+    tc, mc, test = cfg.get("training", {}), cfg.get("model", {}), cfg.get("test", {})
+    return Trainer(
+        model, optimizer, device=device, out_dir=tc.get("out_dir"), cfg=cfg,
+        threshold=test.get("threshold", 0.5), raw_noise_std=tc.get("raw_noise_std", 1),
+        n_sample_points=tc.get("n_sample_points", 64), n_sample_points_fine=tc.get("n_sample_points_fine", 64),
+        lindisp=tc.get("lindisp", False), perturb=tc.get("perturb", True), lambda_rgb=mc.get("lambda_rgb", 1.0),
+        multi_gpu=tc.get("multi_gpu", True), local_rank=tc.get("local_rank", 0), batch_rays=tc.get("batch_rays"),
+        use_audio_net=mc.get("audio_net", False), use_coords2audio=mc.get("use_coords2audio", False),
+        use_delta_uv=mc.get("use_delta_uv", False), use_canonical_loss=tc.get("use_canonical_loss", False),
+        use_temp_consist=tc.get("use_temp_consist", False), use_head_pose=mc.get("use_head_pose", False),
+        use_head_pose_net=mc.get("use_head_pose_net", False), use_audio=mc.get("use_audio", True),
+        use_loss_bg=tc.get("use_loss_bg", False), use_loss_face=tc.get("use_loss_face", False),
+        use_loss_facewoaudio=tc.get("use_loss_facewoaudio", False), use_loss_lip=tc.get("use_loss_lip", False),
+        use_coords_mapping=tc.get("use_coords_mapping", False), add_noise_uv=tc.get("add_noise_uv", False),
+        add_noise_audio=tc.get("add_noise_audio", False), use_time=mc.get("use_time", False),
+        use_post_fusion=mc.get("use_post_fusion", False), w_post_fusion=tc.get("w_post_fusion", 1.0),
+        use_perceptual_loss=tc.get("use_perceptual_loss", False), w_perceptual_loss=tc.get("w_perceptual_loss", 1.0),
+        use_syncloss=tc.get("use_syncloss", False), w_syncloss=tc.get("w_syncloss", 1.0),
+        use_fusion_face=tc.get("use_fusion_face", True), use_c_lip=tc.get("use_c_lip", False),
+        fusion_lip_only=tc.get("fusion_lip_only", False), **kwargs)
+
+
+class _Namespace:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# `method_dict[cfg['method']].config.get_model(...)` as in src/config.py:76-78
+face_simple = _Namespace(config=_Namespace(get_model=_fs_get_model, get_trainer=_fs_get_trainer))
+method_dict = {"face_simple": face_simple}
+
+
+def get_model(cfg, device=None, len_dataset=None, config=None):
+    """src/config.py:67-78."""
+    return method_dict[cfg["method"]].config.get_model(cfg, device=device, len_dataset=len_dataset, config=config)
+
+
+def get_trainer(model, optimizer, cfg, device):
+    """src/config.py:82-95."""
+    return method_dict[cfg["method"]].config.get_trainer(model, optimizer, cfg, device)

@@ -23,7 +23,7 @@ folders written by the tests rather than on golden pixels).
 (`mel`, `coord_window`, `audio_window`, `canonical_face_bbox`, `rgb_window_neg`, `total_frame`) and the
 6-DoF pose / canonical masks of the depth loss.  It is checked field by field against what the
 REFERENCE's own reader yields for the committed fixture folder (golden G15, tools/make_goldens.py;
-pinned except JPEG decoding, cv2.resize's interpolation and cv2.boundingRect's rounding -- those three
+pinned except JPEG decoding, cv2.resize's interpolation (restated from OpenCV's published code) and cv2.boundingRect's rounding -- those three
 libraries are absent from the image).  The mel front-end (src/data/audio.py, librosa) is out of scope:
 the spectrogram is read precomputed from `audio/mel.npy` ([80, T_mel], what `melspectrogram` returns).
 """
@@ -51,29 +51,55 @@ def _read_bgr01(path: str) -> np.ndarray:
 
 
 def _resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """cv2.resize(img, (out_w, out_h)) for uint8 images, default INTER_LINEAR: half-pixel centres
-    (src = (dst + 0.5) * scale - 0.5, taps clamped to the image), separable, OpenCV's fixed-point form (11-bit
-    coefficients, the two passes rounded once at the end).  UNPINNED: cv2 is not in the image to check against."""
+    """cv2.resize(img, (out_w, out_h)) for uint8 images with the default INTER_LINEAR, restating the published algorithm of
+    OpenCV 4.4 (`opencv-python==4.4.0.40`, requirement.txt:17; modules/imgproc/src/resize.cpp), pass by pass:
+      * scale = 1 / (dst / src) in double; source position fx = float((dx + 0.5) * scale - 0.5), sx = floor(fx), fx -= sx;
+        horizontally a tap left of the image gives (sx, fx) = (0, 0) and a tap pair that would leave it on the right gives
+        (width - 1, 0) [resizeGeneric set-up]; vertically the two ROW indices are clamped instead and the fraction is kept;
+      * coefficients are shorts: round-half-even(float(1 - f) * 2048) and round-half-even(f * 2048) (saturate_cast<short>);
+      * horizontal pass (HResizeLinear, uchar -> int): D = S[sx] * a0 + S[sx + 1] * a1   (scale 2^11, exact);
+      * vertical pass (VResizeLinear<uchar, int, short, FixedPtCast<.., 22>>): the TRUNCATING form
+            dst = ( ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 ) >> 2
+        -- not one rounding of the 22-bit product: the shifts drop bits between the passes, which moves the result by one
+        level on some pixels;
+      * an exact 2x reduction of both axes is switched to INTER_AREA by cv::resize (`is_area_fast && iscale == 2`):
+        (a + b + c + d + 2) >> 2 over the 2x2 block.
+    cv2 itself is not in the image, so this stays a restatement of published code; tests/test_data_reader.py pins it with a
+    scalar re-derivation and hand-computed pixels on a non-flat image."""
     h, w = img.shape[:2]
     if (h, w) == (out_h, out_w):
         return img.copy()
+    if h == 2 * out_h and w == 2 * out_w:
+        a = img.astype(np.int32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
-    def taps(n_in, n_out):
-        src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
-        i0 = np.floor(src).astype(np.int64)
-        f = src - i0
-        f = np.where(i0 < 0, 0.0, f)
-        i0c = np.clip(i0, 0, n_in - 1)
-        i1c = np.clip(i0 + 1, 0, n_in - 1)
-        f = np.where(i0 >= n_in - 1, 0.0, f)
-        c1 = np.rint(f * 2048).astype(np.int64)
-        return i0c, i1c, 2048 - c1, c1
-    y0, y1, wy0, wy1 = taps(h, out_h)
-    x0, x1, wx0, wx1 = taps(w, out_w)
+    def positions(n_in, n_out):
+        scale = 1.0 / (float(n_out) / float(n_in))
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        return i0, (f - i0.astype(np.float32)).astype(np.float32)
+
+    def coefs(f):                       # saturate_cast<short>(float * 2048): cvRound = round half to even
+        c0 = np.rint((np.float32(1.0) - f).astype(np.float32) * np.float32(2048.0)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+        return c0, c1
+
+    sx, fx = positions(w, out_w)
+    fx = np.where(sx < 0, np.float32(0), fx)
+    sx = np.where(sx < 0, 0, sx)
+    fx = np.where(sx >= w - 1, np.float32(0), fx).astype(np.float32)
+    sx = np.where(sx >= w - 1, w - 1, sx)
+    a0, a1 = coefs(fx)
+    sx1 = np.minimum(sx + 1, w - 1)                                                    # its coefficient is 0 there
+    sy, fy = positions(h, out_h)
+    b0, b1 = coefs(fy)
+    y0, y1 = np.clip(sy, 0, h - 1), np.clip(sy + 1, 0, h - 1)
     a = img.astype(np.int64)
-    rows = a[:, x0] * wx0[None, :, None] + a[:, x1] * wx1[None, :, None]            # [h, out_w, C] * 2^11
-    out = rows[y0] * wy0[:, None, None] + rows[y1] * wy1[:, None, None]             # * 2^22
-    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    cshape = (1, -1) + (1,) * (a.ndim - 2)
+    rows = a[:, sx] * a0.reshape(cshape) + a[:, sx1] * a1.reshape(cshape)                # [h, out_w(, C)] * 2^11
+    rshape = (-1, 1) + (1,) * (a.ndim - 2)
+    out = (((b0.reshape(rshape) * (rows[y0] >> 4)) >> 16) + ((b1.reshape(rshape) * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 def crop_audio_window(spec: np.ndarray, start_frame: int, fps: int = 25, syncnet_mel_step_size: int = 16) -> np.ndarray:
@@ -184,6 +210,12 @@ class SomeonesLipClip:
         if self.use_syncloss and mode == "train":                                          # :113-120
             # orig_mel = melspectrogram(load_wav(audio/audio.wav), fmin).T -- the mel front-end is out of scope:
             # the spectrogram is taken precomputed, in melspectrogram's own [80, T_mel] orientation
+            if not os.path.exists(j("audio", "mel.npy")):
+                raise FileNotFoundError(
+                    f"{j('audio', 'mel.npy')} not found: with training.use_syncloss the reader needs the mel spectrogram of "
+                    f"audio/audio.wav precomputed as a float [80, T_mel] array -- what the reference computes on the fly with "
+                    f"src/data/audio.py melspectrogram(load_wav(audio.wav, 16000), fmin={self.fmin}) (someones_lip_dataset.py:113-118; "
+                    f"librosa is not part of this path).  Save that array with np.save.")
             self.orig_mel = np.load(j("audio", "mel.npy")).T
             self.face_bbox_dict = np.load(j("face_bbox_dict.npy"), allow_pickle=True).item()
         if mode == "test":                                                                 # :156-161

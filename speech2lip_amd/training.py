@@ -55,39 +55,88 @@ def predict_lip_image(model: TalkingFace, coords, audio, index, height: int, wid
 class Trainer:
     """The slice of the reference `Trainer` (training.py:21-156) that sits on the hot path."""
 
-    def __init__(self, model, optimizer=None, cfg=None, device=None, **kwargs):
+    # keyword names of the reference constructor (training.py:21-37) whose May value is the only one the hot path implements:
+    # passing anything else is an error, not a silently different model
+    _MAY_ONLY = {"use_audio_net": True, "use_head_pose_net": False, "use_coords2audio": False, "use_delta_uv": False,
+                 "use_canonical_loss": False, "use_temp_consist": False, "use_head_pose": False, "use_audio": True,
+                 "use_loss_bg": False, "use_loss_face": False, "use_loss_facewoaudio": False, "use_loss_lip": False,
+                 "use_coords_mapping": False, "add_noise_uv": False, "add_noise_audio": False, "use_time": True,
+                 "use_merge_loss": False, "update_pose": False, "use_c_lip": False, "use_fusion_face": True,
+                 "fusion_lip_only": True}
+    # accepted and stored, no effect on this path (NeRF-era sampling knobs the face_simple trainer never reads back)
+    _STORED = ("threshold", "n_sample_points", "n_sample_points_fine", "lindisp", "raw_noise_std", "perturb", "local_rank")
+
+    def __init__(self, model, optimizer=None, device=None, out_dir=None, cfg=None, batch_rays=None, **kwargs):
+        """Positional order and keyword names of the reference constructor (training.py:21-37):
+        `Trainer(model, optimizer, device, out_dir, cfg=cfg, batch_rays=..., lambda_rgb=..., use_syncloss=..., ...)`, so
+        `get_trainer` (src/face_simple/config.py:25-94) and positional callers bind as they do there.  Flags of the May set
+        are accepted with their May value and refused with any other; `multi_gpu=True` does not wrap the model in DDP (the
+        hand-written backward does not run through DDP's hooks): with an initialised process group `train_stage1` averages the
+        gradients over the ranks in one bucket (`sharded.allreduce_grads`) before the optimizer step -- the same result.
+        Extras of this build: `syncnet=`, `perceptual_loss_fn=` (pre-built frozen nets), `w_photometric_loss=` (alias of
+        the reference's `lambda_rgb`)."""
+        if isinstance(device, dict) or isinstance(out_dir, dict):
+            raise TypeError("Trainer(model, optimizer, device, out_dir, cfg=...): cfg is the FIFTH argument, as in the reference")
         self.model = model
         self.optimizer = optimizer
         self.cfg = cfg if cfg is not None else model.cfg
-        self.device = device if device is not None else model.device
+        self.device = torch.device(device) if device is not None else model.device
+        self.out_dir = out_dir if out_dir is not None else self.cfg.get("training", {}).get("out_dir")
+        for name, may in self._MAY_ONLY.items():
+            if name in kwargs and bool(kwargs.pop(name)) != may:
+                raise NotImplementedError(f"Trainer({name}={not may}) is outside the May flag set this path implements (SURVEY.md §8a)")
+        for name in self._STORED:
+            if name in kwargs:
+                setattr(self, name, kwargs.pop(name))
+        tc = self.cfg["training"]
         self.height = int(self.cfg["data"]["height"])
         self.width = int(self.cfg["data"]["width"])
-        self.batch_rays = int(self.cfg["training"].get("batch_rays", self.height * self.width))
-        self.multi_gpu = False
+        self.batch_rays = int(batch_rays if batch_rays is not None else tc.get("batch_rays", self.height * self.width))
+        self.multi_gpu = bool(kwargs.pop("multi_gpu", False))
         self.use_audio = self.use_audio_net = self.use_time = True
-        self.use_delta_uv = self.add_noise_audio = False
+        self.use_delta_uv = self.add_noise_audio = self.add_noise_uv = False
+        self.use_head_pose = self.use_head_pose_net = self.use_coords2audio = self.use_coords_mapping = False
         self.audio_dims = model.audio_dims
         # T3 (training.py:83-91): the frozen lip-sync expert, only when the config asks for the sync loss
-        self.use_syncloss = bool(kwargs.get("use_syncloss", self.cfg["training"].get("use_syncloss", False)))
-        self.w_syncloss = float(kwargs.get("w_syncloss", self.cfg["training"].get("w_syncloss", 0.01)))
-        self.syncnet = kwargs.get("syncnet")
+        self.use_syncloss = bool(kwargs.pop("use_syncloss", tc.get("use_syncloss", False)))
+        self.w_syncloss = float(kwargs.pop("w_syncloss", tc.get("w_syncloss", 0.01)))
+        self.syncnet = kwargs.pop("syncnet", None)
+        ckpt = kwargs.pop("syncnet_checkpoint_path", "models/lipsync_expert.pth")      # training.py:88
         if self.use_syncloss and self.syncnet is None:
+            import os
             from .syncnet import SyncNet_color
             self.syncnet = SyncNet_color().to(self.device)
+            for p_ in self.syncnet.parameters():
+                p_.requires_grad = False
+            if os.path.exists(ckpt):
+                self.load_checkpoint_syncnet(ckpt, self.syncnet)
+            else:      # the expert's weights are not part of the reference repository either (README: a separate download)
+                import logging
+                logging.getLogger(__name__).warning("%s not found: the sync loss runs on a randomly initialised SyncNet", ckpt)
+        if self.use_syncloss:
+            self.use_low_resolution = bool(tc.get("use_low_resolution", False))
+            if self.use_low_resolution:
+                raise NotImplementedError("training.use_low_resolution is outside the May flag set")
         # the other loss switches of training.py:21-100 (May values unless overridden)
-        tc = self.cfg["training"]
-        self.use_post_fusion = bool(kwargs.get("use_post_fusion", self.cfg["model"].get("use_post_fusion", True)))
+        self.use_post_fusion = bool(kwargs.pop("use_post_fusion", self.cfg["model"].get("use_post_fusion", True)))
+        self.use_post_fusion_wface = bool(self.cfg["model"].get("use_post_fusion_wface", False))
         self.fusion_lip_only = self.use_fusion_face = True
         # lambda_rgb lives under cfg['model'] in the reference (src/face_simple/config.py:41, may.yaml:11); cfg['training'] is a fallback
-        self.w_photometric_loss = float(kwargs.get("w_photometric_loss",
-                                                   self.cfg["model"].get("lambda_rgb", tc.get("lambda_rgb", 1.0))))
-        self.w_post_fusion = float(kwargs.get("w_post_fusion", tc.get("w_post_fusion", 1.0)))
-        self.use_perceptual_loss = bool(kwargs.get("use_perceptual_loss", tc.get("use_perceptual_loss", False)))
-        self.w_perceptual_loss = float(kwargs.get("w_perceptual_loss", tc.get("w_perceptual_loss", 0.01)))
-        self.perceptual_loss_fn = kwargs.get("perceptual_loss_fn")
+        lam = kwargs.pop("lambda_rgb", self.cfg["model"].get("lambda_rgb", tc.get("lambda_rgb", 1.0)))
+        self.w_photometric_loss = float(kwargs.pop("w_photometric_loss", lam))
+        self.w_post_fusion = float(kwargs.pop("w_post_fusion", tc.get("w_post_fusion", 1.0)))
+        self.use_perceptual_loss = bool(kwargs.pop("use_perceptual_loss", tc.get("use_perceptual_loss", False)))
+        self.w_perceptual_loss = float(kwargs.pop("w_perceptual_loss", tc.get("w_perceptual_loss", 0.01)))
+        self.perceptual_loss_fn = kwargs.pop("perceptual_loss_fn", None)
         if self.use_perceptual_loss and self.perceptual_loss_fn is None:      # training.py:75-76
             from .lpips import LPIPS
             self.perceptual_loss_fn = LPIPS(net="alex", version="0.1", model_path="models/lpips_weights_v0.1/alex.pth").to(self.device)
+        if tc.get("fix_post_net", False) is True and getattr(model, "post_fusion_unet", None) is not None:      # training.py:121-129
+            for p_ in model.post_fusion_unet.parameters():
+                p_.requires_grad = False
+            model.post_fusion_unet.eval()
+        if kwargs:
+            raise TypeError(f"Trainer got unexpected keyword arguments {sorted(kwargs)} (reference: training.py:21-37)")
 
     def load_checkpoint_syncnet(self, path, model=None):
         """training.py:130-138: `lipsync_expert.pth` holds {'state_dict': ...}, keys possibly prefixed by 'module.'."""
@@ -221,6 +270,19 @@ class Trainer:
         psnr = torch.stack([self.visualize(inputs, None, it=it) for inputs in val_loader], 0).mean()
         return {"psnr": psnr}
 
+    def _average_gradients_over_ranks(self):
+        """What DistributedDataParallel (training.py:41) does for the reference: every rank ends the backward with the MEAN of the
+        ranks' gradients.  One flattened bucket, one all-reduce (sharded.allreduce_grads); no-op without `multi_gpu`, without a
+        process group, or with one rank."""
+        import torch.distributed as dist
+        if not (self.multi_gpu and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from .sharded import allreduce_grads
+        named = {n: p for n, p in self.model.named_parameters() if p.grad is not None}
+        avg = allreduce_grads({n: p.grad for n, p in named.items()})
+        for n, p in named.items():
+            p.grad.copy_(avg[n])
+
     def train_stage1(self, data, eval_model=False, it=None, seed=None):
         """One optimisation step as the reference performs it (training.py:347-574) under the May flags, through the drop-in's
         methods and their hand-written backward kernels:  zero_grad -> lip render -> MSE [+ LPIPS] on the lip -> composite with
@@ -287,6 +349,7 @@ class Trainer:
             loss["loss_sync"] = loss["loss_sync"] + loss_sync
             loss["loss"] = loss["loss"] + loss_sync
         loss["loss"].backward()
+        self._average_gradients_over_ranks()
         for k, v in m.state_dict().items():          # check_weights (src/common.py:56-64)
             if v.dtype.is_floating_point and torch.isnan(v).any():
                 import logging

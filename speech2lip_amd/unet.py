@@ -424,6 +424,9 @@ class SimpleUnetLight(nn.Module):
             return torch.cat([self.backward_train_frames(c, d_out[s0:s1]) for s0, s1, c in ctx[1]], 0)
         if not (isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train"):
             return self.backward_input(ctx, d_out)
+        if param_grads is None and any(p_.requires_grad for p_ in self.parameters()):
+            raise ValueError("backward_to_input: this train-mode U-Net still has trainable parameters; pass param_grads={} to "
+                             "receive their gradients (or freeze the net as train.py:188-197 does)")
         dxs = []
         for f, c in enumerate(ctx[1]):
             dx, grads = self.backward_train(c, d_out[f:f + 1], want_input_grad=True, want_param_grads=param_grads is not None)

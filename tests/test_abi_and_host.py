@@ -453,3 +453,74 @@ def test_staging_registers_of_the_persistent_conv_kernel_are_never_copied(tmp_pa
                     used.add(int(m.group(1)))
             assert not (used & regs), (txt[st], l2)
         assert not any("scratch_" in l for l in body)
+
+
+def _reference_style_config(h=80, w=120):
+    """A config dictionary with every key the reference's factory indexes (src/face_simple/config.py:33-73) -- the merged form
+    of its default.yaml + face_simple default.yaml + may.yaml, typed here key by key (values: may.yaml where it sets them, the
+    defaults otherwise)."""
+    import speech2lip_amd as s2l
+    cfg = s2l.may_config(h, w, train_flags=True)
+    cfg["model"].update(use_canonical_depth=False, post_fusion_warping="backward")
+    cfg["training"].update(
+        lindisp=False, perturb=True, raw_noise_std=1, n_sample_points_fine=64, local_rank=0, use_canonical_loss=False,
+        use_temp_consist=False, use_loss_bg=False, use_loss_face=False, use_loss_facewoaudio=False, use_loss_lip=False,
+        use_c_lip=False, use_perceptual_loss_mask=False, use_low_resolution=False, use_perceptual_loss=False, use_syncloss=False,
+        out_dir="log/face_simple/may")
+    cfg["test"] = {"threshold": 0.5}
+    return cfg
+
+
+def test_factories_build_model_and_trainer_like_the_reference():
+    """src/config.py:67-95 + src/face_simple/config.py:13-94: `get_model(cfg, device, len_dataset, config)` and
+    `get_trainer(model, optimizer, cfg, device)` through `method_dict['face_simple'].config`, and the reference's POSITIONAL
+    constructor order `Trainer(model, optimizer, device, out_dir, cfg=...)` (training.py:21-23)."""
+    import speech2lip_amd as s2l
+    from speech2lip_amd import config as C
+    cfg = _reference_style_config()
+    assert cfg["training"]["use_sync_contrastive_loss"] is True            # may.yaml:47 (ADVICE round 3)
+    assert s2l.may_config(96, 96)["training"]["use_sync_contrastive_loss"] is False
+    model = s2l.get_model(cfg, device="cpu", len_dataset=123, config=None)
+    assert isinstance(model, s2l.TalkingFace) and model.audio_dims == 64 and hasattr(model, "post_fusion_unet")
+    assert C.method_dict["face_simple"].config.get_model is not None and set(C.method_dict) == {"face_simple"}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    tr = s2l.get_trainer(model, opt, cfg, torch.device("cpu"))
+    assert isinstance(tr, s2l.Trainer) and tr.optimizer is opt and tr.model is model and tr.cfg is cfg
+    assert tr.out_dir == "log/face_simple/may" and tr.device == torch.device("cpu")
+    assert tr.batch_rays == 80 * 120 and (tr.height, tr.width) == (80, 120)
+    assert tr.multi_gpu is True and tr.w_photometric_loss == 1.0 and tr.w_post_fusion == 1.0
+    assert tr.use_post_fusion and tr.fusion_lip_only and not tr.use_syncloss and not tr.use_perceptual_loss
+    assert (tr.threshold, tr.n_sample_points, tr.n_sample_points_fine, tr.raw_noise_std) == (0.5, 16, 64, 1)
+    # positional binding as in the reference: (model, optimizer, device, out_dir, cfg=...)
+    tr2 = s2l.Trainer(model, opt, torch.device("cpu"), "some/dir", cfg=cfg, batch_rays=9600, lambda_rgb=0.5, use_time=True)
+    assert tr2.device == torch.device("cpu") and tr2.out_dir == "some/dir" and tr2.cfg is cfg and tr2.w_photometric_loss == 0.5
+    with pytest.raises(TypeError):
+        s2l.Trainer(model, opt, cfg)                       # round 3's order (cfg third) must not bind silently
+    with pytest.raises(NotImplementedError):
+        s2l.Trainer(model, opt, "cpu", "d", cfg=cfg, use_head_pose=True)
+    with pytest.raises(TypeError):
+        s2l.Trainer(model, opt, "cpu", "d", cfg=cfg, no_such_flag=1)
+    # fix_post_net (training.py:121-129): parameters frozen, sub-module in eval mode
+    cfg2 = _reference_style_config()
+    cfg2["training"]["fix_post_net"] = True
+    m2 = s2l.get_model(cfg2, device="cpu")
+    s2l.get_trainer(m2, None, cfg2, "cpu")
+    assert not any(p.requires_grad for p in m2.post_fusion_unet.parameters()) and not m2.post_fusion_unet.training
+    with pytest.raises(KeyError):
+        s2l.get_model({**cfg, "method": "nerf"}, device="cpu")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs/face_simple_configs/may/may.yaml"),
+                    reason="the reference checkout only exists in the build container")
+def test_factories_accept_the_reference_may_yaml():
+    """The reference's own may.yaml over its defaults, loaded by our load_config, goes through get_model / get_trainer unchanged
+    (except the two switches that need files outside the repository: the 3DMM depth init and the expert / LPIPS weights)."""
+    import speech2lip_amd as s2l
+    cfg = s2l.load_config("configs/face_simple_configs/may/may.yaml", "configs/default.yaml", abs_path="/root/reference")
+    assert cfg["method"] == "face_simple" and cfg["training"]["use_sync_contrastive_loss"] is True
+    cfg["model"]["use_canonical_depth"] = False
+    cfg["training"].update(use_perceptual_loss=False, use_syncloss=False)
+    model = s2l.get_model(cfg, device="cpu", len_dataset=None, config=None)
+    tr = s2l.get_trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), cfg, "cpu")
+    assert (tr.height, tr.width, tr.batch_rays) == (80, 120, 9600) and tr.multi_gpu is True
+    assert tr.w_perceptual_loss == 0.01 and tr.w_syncloss == 0.01 and tr.use_post_fusion
