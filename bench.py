@@ -40,16 +40,35 @@ FLOPS_PER_FRAME = 2 * 459_520 * HW + 2 * (67_328 + 43_008 + 131_072)   # SURVEY.
 FP32_MFMA_PEAK = 157.3e12
 
 
-def measured_traffic():
-    """HBM bytes per 1000-frame dispatch of the render kernel from the latest PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-    separate rocprofv3 runs): tools/summarize_profiles.py writes profiles/render_traffic.json next to the profile summary
-    it was computed from, so the number in the line is the number in the profile it names."""
+def render_kernel_digest():
+    """sha256 (first 16 hex digits) of the generated assembly text of the long-shape render kernel of THIS build
+    (speech2lip_amd/build/render_body.inc): the identity of the kernel a PMC figure belongs to."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "speech2lip_amd", "build", "render_body.inc"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def measured_traffic(frames_per_launch):
+    """HBM bytes per frame of the render kernel from the latest PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+    runs): tools/summarize_profiles.py writes profiles/render_traffic.json next to the profile summary it was computed from,
+    with the digest of the kernel text and the launch size it was measured on.  The PMC figure is NOT collected in this run
+    (counters need rocprofv3 around the process); it is reported only when it describes this build's kernel at this launch
+    size -- otherwise traffic is null and `traffic_source` says why."""
     try:
         with open(os.path.join(ROOT, "profiles", "render_traffic.json")) as f:
             t = json.load(f)
-        return t["hbm_bytes_per_dispatch"] / t["frames_per_dispatch"], t["profile"]
+        per_frame = t["hbm_bytes_per_dispatch"] / t["frames_per_dispatch"]
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, "no profiles/render_traffic.json"
+    now = render_kernel_digest()
+    if t.get("kernel_text_sha256_16") not in (None, now):
+        return None, f"stale: {t['profile']} was taken on kernel text {t.get('kernel_text_sha256_16')}, this build is {now}"
+    if int(t["frames_per_dispatch"]) != int(round(frames_per_launch)):
+        return None, f"stale: {t['profile']} measured {t['frames_per_dispatch']} frames per launch, this run launches {frames_per_launch:g}"
+    return per_frame, t["profile"]
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -87,10 +106,22 @@ def cpu_baseline(frames_budget_s: float = 12.0):
             O.render_clip(sd, win, list(range(nb, nb + 8)), H, W_)
             nb += 8
         dtb = time.perf_counter() - tb0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": ncpu,
+            "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{n} frames 96x96, as-shipped per-frame path (oracle.render_frame_as_shipped), fp32, {dt:.1f} s",
             "batched_value": round(nb / dtb, 3),
             "batched_sample": f"{nb} frames 96x96 in clips of 8 (oracle.render_clip: encoder once per frame), {dtb:.1f} s"}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def _flush_c_stdout():
@@ -165,17 +196,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=None,
                     help="frames per GPU per step; default 1000 at N = 1 (BASELINE config 2), 5000 at N > 1 (config 4: 40k / 8)")
-    ap.add_argument("--chunks", type=int, default=1,
-                    help="all-gather chunks per step (N > 1).  1 = render the clip in one persistent launch, then one "
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="all-gather chunks per step (N > 1).  Default: AUTO -- during warm-up one step of each implemented schedule "
+                         "({1 chunk, no CUs reserved} and {4 chunks, 8 CUs left to RCCL}) is timed (max over ranks) and the timed steps "
+                         "run the faster one; both times are printed in multi_gpu.schedules.  1 = render the clip in one persistent launch, then one "
                          "all-gather: the renderer fills every CU (151 KiB LDS + all registers per workgroup), so an "
                          "RCCL kernel overlapped with it can only start on CUs a finished workgroup has released and "
                          "then delays the statically-striped workgroups of the next launch; >1 enables the overlap")
     ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
                     help="dtype of the reassembled clip (N > 1): f32 = bit-identical to a 1-GPU render (default); u8 = the 8-bit "
                          "frames the reference writes (cv2.imwrite semantics), quantised per rank, 4x less all-gather traffic")
-    ap.add_argument("--reserve-cus", type=int, default=0,
+    ap.add_argument("--reserve-cus", type=int, default=None,
                     help="leave this many CUs to RCCL (use with --chunks > 1): the renderer launches CUs - k persistent workgroups, "
-                         "so the all-gather of one chunk can run while the next chunk renders.  Default 0 = no overlap attempted")
+                         "so the all-gather of one chunk can run while the next chunk renders.  Default: 0 with an explicit --chunks, AUTO otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-5 `extra` measurements (N = 1)")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
@@ -213,30 +246,37 @@ def main():
     from speech2lip_amd import sharded, weights as W
 
     F = args.frames if args.frames is not None else (1000 if world == 1 else 5000)
-    if args.reserve_cus > 0:
-        from speech2lip_amd import _abi
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        _abi.check(_abi.load().s2l_set_render_cus(max(1, n_cu - args.reserve_cus)), "s2l_set_render_cus")
+    from speech2lip_amd import _abi
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     model = s2l.TalkingFace(dev, s2l.may_config(H, W_), mode="eval").eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
     QUANTUM = 48   # frames: keeps each chunk launch a whole number of 256-tile waves at 96x96
-    n_chunks = args.chunks if (world > 1 or args.force_chunks) else 1
-
-    def rank_inputs(r):      # audio windows and global frame ids of rank r (any rank can rebuild any other rank's)
-        ids = sharded.global_frame_ids(F, r, world, n_chunks, QUANTUM).to(dev)
-        return torch.from_numpy(W.synthetic_audio(F, seed=1 + r).astype(np.float32)).to(dev), ids
-
-    audio, gids = rank_inputs(rank)                                                               # resident in HBM
+    chunked = world > 1 or args.force_chunks
     quant = s2l.to8b if args.gather == "u8" else None
     clip = torch.empty((F * world, H, W_, 3), dtype=torch.uint8 if quant else torch.float32, device=dev) if use_dist else None
     kernel_events = []
 
-    def render(off, cnt, out):
-        model.render_clip(audio[off:off + cnt], gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
+    class Schedule:
+        """One way of running a step: how many chunks (= launches + all-gathers) and how many CUs the renderer leaves to RCCL."""
 
-    def step(gather=True):
-        return sharded.render_sharded(render, F, (H, W_, 3), dev, n_chunks=n_chunks, clip=clip, gather=gather,
-                                      quantum=QUANTUM, force_collective=args.force_dist, quantize=quant if use_dist else None)
+        def __init__(self, n_chunks, reserve):
+            self.n_chunks, self.reserve = (n_chunks if chunked else 1), reserve
+            self.audio, self.gids = self.rank_inputs(rank)                                      # resident in HBM
+            self.name = f"{self.n_chunks}-chunk" + (f"+{reserve}cu-reserved" if reserve else "")
+
+        def rank_inputs(self, r):      # audio windows and global frame ids of rank r (any rank can rebuild any other rank's)
+            ids = sharded.global_frame_ids(F, r, world, self.n_chunks, QUANTUM).to(dev)
+            return torch.from_numpy(W.synthetic_audio(F, seed=1 + r).astype(np.float32)).to(dev), ids
+
+        def activate(self):            # s2l_set_render_cus is process-global: set it for the steps that follow
+            _abi.check(_abi.load().s2l_set_render_cus(max(1, n_cu - self.reserve) if self.reserve else 0), "s2l_set_render_cus")
+
+        def render(self, off, cnt, out):
+            model.render_clip(self.audio[off:off + cnt], self.gids[off:off + cnt], H, W_, out=out, _events=kernel_events)
+
+        def step(self, gather=True):
+            return sharded.render_sharded(self.render, F, (H, W_, 3), dev, n_chunks=self.n_chunks, clip=clip, gather=gather,
+                                          quantum=QUANTUM, force_collective=args.force_dist, quantize=quant if use_dist else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -256,6 +296,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, r
+
+    # ---- schedule: explicit flags, or (N > 1) the faster of the implemented ones, measured here during warm-up -------------
+    auto = world > 1 and args.chunks is None and args.reserve_cus is None
+    schedule_times = None
+    if auto:
+        candidates = [Schedule(1, 0), Schedule(4, 8)]
+        schedule_times = {}
+        for c in candidates:
+            c.activate()
+            c.step()                                  # first launch of this form (allocations, RCCL channel set-up): untimed
+            dt_c, _ = timed(1, c.step)                # MAX over ranks, so every rank picks the same schedule
+            schedule_times[c.name] = round(dt_c * 1e3, 3)
+        sched = min(candidates, key=lambda c: schedule_times[c.name])
+        del candidates
+    else:
+        sched = Schedule(args.chunks or 1, args.reserve_cus or 0)
+    sched.activate()
+    n_chunks, audio, gids, step = sched.n_chunks, sched.audio, sched.gids, sched.step
 
     for _ in range(args.warmup):
         step()
@@ -283,22 +341,34 @@ def main():
             dist.all_gather_into_tensor(clip, src)
         dt_gather, _ = timed(n_aux, gather_only)
         # cross-rank verification: rank 0 re-renders the LAST rank's block itself and compares with what the gather delivered
+        step()
+        torch.cuda.synchronize()
         verified = None
-        if n_chunks == 1:
-            step()
-            torch.cuda.synchronize()
-            if rank == 0:
-                r = world - 1
-                a_r, ids_r = rank_inputs(r)
-                mine = model.render_clip(a_r, ids_r, H, W_)
-                theirs = clip[r * F:(r + 1) * F]
-                verified = bool(torch.equal(quant(mine) if quant else mine, theirs))
-                if not verified:
-                    raise SystemExit(f"bench.py: gathered frames of rank {r} differ from a local re-render of the same frame ids")
+        if rank == 0:
+            r = world - 1
+            a_r, ids_r = sched.rank_inputs(r)
+            mine = model.render_clip(a_r, ids_r, H, W_)
+            theirs = clip[ids_r]                      # rank r's frames sit at their global frame ids, whatever the chunking
+            verified = bool(torch.equal(quant(mine) if quant else mine, theirs))
+            if not verified:
+                raise SystemExit(f"bench.py: gathered frames of rank {r} differ from a local re-render of the same frame ids")
+        # the product entry on a RAGGED clip (N % G != 0): sharded.render_clip_sharded pads the short blocks, gathers, trims;
+        # rank 0 compares the whole clip with its own one-GPU render (bit for bit)
+        n_rag = max(1, 48 * world - 5)
+        a_rag = torch.from_numpy(W.synthetic_audio(n_rag, seed=99).astype(np.float32)).to(dev)
+        i_rag = torch.arange(39_000, 39_000 + n_rag, device=dev)
+        got_rag = sharded.render_clip_sharded(model, a_rag, i_rag, H, W_, force_collective=args.force_dist)
+        torch.cuda.synchronize()
+        ragged_ok = bool(torch.equal(got_rag, model.render_clip(a_rag, i_rag, H, W_))) if rank == 0 else None
+        if rank == 0 and not ragged_ok:
+            raise SystemExit("bench.py: render_clip_sharded on a ragged clip differs from the one-GPU render")
         multi = {"render_only_ms": round(dt_render / n_aux * 1e3, 3), "gather_only_ms": round(dt_gather / n_aux * 1e3, 3),
                  "gather_bytes_per_rank": int(src.numel() * src.element_size()),
                  "per_gpu_rate_with_gather_over_without": round((dt_render / n_aux) / (dt / args.steps), 4),
                  "remote_block_bit_identical_to_local_render": verified,
+                 "ragged_clip": {"frames": n_rag, "bit_identical_to_one_gpu_render": ragged_ok},
+                 "schedule": sched.name, "schedule_selection": "auto (timed during warm-up, max over ranks)" if auto else "flags",
+                 "schedules_ms_per_step": schedule_times,
                  "note": "weak-scaling efficiency = value_N / (N * value_1) is computed by the driver from its own runs"}
 
     if rank == 0:
@@ -307,7 +377,7 @@ def main():
         with torch.no_grad():
             ref = O.render_clip(O.to_sd(W.make_state_dict(0, "he")), audio[:1].cpu(), [int(gids[0])], H, W_)[0]
         got = local[0].cpu()
-        traffic_per_frame, traffic_src = measured_traffic()
+        traffic_per_frame, traffic_src = measured_traffic(frames_per_launch)
         line = {
             "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -317,7 +387,7 @@ def main():
                        + (f" (BASELINE config 4 workload: {F * world} frames over {world} GPUs)" if world > 1 else ""),
                        "frames_per_gpu": F, "height": H, "width": W_, "parallelism": f"frame-shard x{world}" +
                        (f" + {n_chunks}-chunk {args.gather} all-gather" if world > 1 else "") +
-                       (f", {args.reserve_cus} CUs left to RCCL" if args.reserve_cus else "")},
+                       (f", {sched.reserve} CUs left to RCCL" if sched.reserve else "")},
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": FP32_MFMA_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), see profiles/

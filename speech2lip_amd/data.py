@@ -371,6 +371,6 @@ def write_frames(frames: torch.Tensor, names, out_dir: str, ext: str = ".jpg") -
     because cv2.imwrite expects it: the files hold the same RGB picture).  cv2.imwrite rounds and saturates."""
     from PIL import Image
     os.makedirs(out_dir, exist_ok=True)
-    arr = to8b(frames).cpu().numpy()
+    arr = (frames if frames.dtype == torch.uint8 else to8b(frames)).cpu().numpy()      # already-quantised frames pass through
     for a, name in zip(arr, names):
         Image.fromarray(a, "RGB").save(os.path.join(out_dir, name + ext), quality=95)

@@ -1,0 +1,176 @@
+"""The C-ABI's own concurrency contract (include/s2l_hip.h:9-15): "calls are asynchronous on that stream and re-entrant
+across streams; the library never allocates, frees or synchronises" -- and the process-global switches are atomics that
+a second host thread may flip while the first renders.
+
+The reference side is a single Python thread on the default stream under `torch.no_grad()` (inference.py:149), so there
+is nothing of its own to mirror; what the tests pin is that the claim, which goes beyond the reference, holds:
+  (a) the renderer, the composite and the U-Net running CONCURRENTLY on two non-default streams give the bits of a serial
+      default-stream run;
+  (b) `render_clip` (one frame and sixteen) + composite captured into a HIP graph (`torch.cuda.CUDAGraph`) replay to the
+      eager output -- on the captured inputs and on new ones copied into the static buffers: no host-side work is
+      needed per replay, which is the launch-overhead-free per-frame mode;
+  (c) `s2l_set_render_shape` flipped from a second thread while the first renders leaves every frame bit-identical
+      (all tile shapes perform the same arithmetic per sample; the switch is an atomic read once per call);
+  (d) a 100-shape slice of the race soak of the counted-`vmcnt` assembly kernels (tools/soak_conv_kernels.py).
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from speech2lip_amd import _abi, weights as W
+from tests.test_gpu_configs import _config3_inputs
+from tests.test_gpu_parity import make_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene(dev):
+    """One model (128x128 lip, U-Net loaded) and two independent sets of clip inputs."""
+    F = 6
+    h, w, FH, FW, x0, y0, face, gt, mask, coord = _config3_inputs(dev, F)
+    m = make_model(dev, h, w)
+    m.load_state_dict({k: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    sets = []
+    for s in (0, 1):
+        _, _, _, _, _, _, _, gt_s, _, coord_s = _config3_inputs(dev, F, seed=s)
+        sets.append(dict(audio=T(W.synthetic_audio(F, seed=20 + s).astype(np.float32)).to(dev),
+                         idx=torch.arange(500 * s, 500 * s + F, device=dev), gt=gt_s.to(dev), coord=coord_s.to(dev)))
+    const = dict(face=face.to(dev), mask=mask.to(dev), x0=x0, y0=y0, h=h, w=w)
+    # warm every cache the calls below touch (packed weights, pixel tables, U-Net pack, LDS opt-ins)
+    chain(m, sets[0], const)
+    torch.cuda.synchronize()
+    return m, sets, const
+
+
+def chain(m, s, c):
+    lip = m.render_clip(s["audio"], s["idx"], c["h"], c["w"])
+    new, _ = m.composite_clip(lip, c["face"], s["gt"], c["mask"], c["x0"], c["y0"], s["coord"])
+    rec = m.post_fusion_unet.forward_nhwc(new)
+    return lip, new, rec
+
+
+def test_two_streams_concurrently_equal_serial_default_stream(scene, dev):
+    m, sets, const = scene
+    serial = [chain(m, s, const) for s in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    results = [[], []]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    # interleave the launches of the two streams, several rounds, so that kernels of both are in flight together:
+    # stream 0 renders + composites + runs the U-Net on set 0 while stream 1 does the same on set 1 (persistent render
+    # workgroups of one stream next to U-Net convolutions of the other)
+    for rnd in range(4):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                results[k].append(chain(m, sets[k], const))
+    for st in streams:
+        st.synchronize()
+    for k in (0, 1):
+        for got in results[k]:
+            for a, b, name in zip(got, serial[k], ("lip", "composite", "unet")):
+                assert torch.equal(a, b), (k, name)
+    # and the SAME kernel on both streams at once, at a size that fills the chip for longer than a launch takes
+    big = [T(W.synthetic_audio(300, seed=40 + k).astype(np.float32)).to(dev) for k in (0, 1)]
+    idx = torch.arange(300, device=dev)
+    ref = [m.render_clip(a, idx, 96, 96) for a in big]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for k, st in enumerate(streams):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            outs[k] = m.render_clip(big[k], idx, 96, 96)
+    for st in streams:
+        st.synchronize()
+    assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+
+
+@pytest.mark.parametrize("F", [1, 16])
+def test_hip_graph_of_render_and_composite_replays_to_the_eager_output(dev, F):
+    h, w, FH, FW, x0, y0, face, gt, mask, coord = _config3_inputs(dev, F)
+    m = make_model(dev, h, w)
+    face, mask = face.to(dev), mask.to(dev)
+    audio = [T(W.synthetic_audio(F, seed=60 + k).astype(np.float32)).to(dev) for k in (0, 1)]
+    idx = [torch.arange(7, 7 + F, device=dev), torch.arange(900, 900 + F, device=dev)]
+    gts = [gt.to(dev), torch.flip(gt, dims=[2]).contiguous().to(dev)]
+    coords = [coord.to(dev), T(W.synthetic_warp_coords(F, FH, FW, seed=77)).to(dev)]
+
+    def eager(k):
+        lip = m.render_clip(audio[k], idx[k], h, w)
+        return lip, m.composite_clip(lip, face, gts[k], mask, x0, y0, coords[k])[0]
+
+    want = [eager(0), eager(1)]
+    torch.cuda.synchronize()
+    s_audio, s_idx, s_gt, s_coord = audio[0].clone(), idx[0].clone(), gts[0].clone(), coords[0].clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        lip = m.render_clip(s_audio, s_idx, h, w)
+        new = m.composite_clip(lip, face, s_gt, mask, x0, y0, s_coord)[0]
+    for rep in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(lip, want[0][0]) and torch.equal(new, want[0][1])
+    for dst, src in ((s_audio, audio[1]), (s_idx, idx[1]), (s_gt, gts[1]), (s_coord, coords[1])):
+        dst.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lip, want[1][0]) and torch.equal(new, want[1][1])
+    assert not torch.equal(want[0][0], want[1][0])
+
+
+def test_render_shape_switch_from_another_thread_keeps_the_bits(dev):
+    lib = _abi.load()
+    h = w = 64
+    m = make_model(dev, h, w)
+    audio = T(W.synthetic_audio(40, seed=3).astype(np.float32)).to(dev)
+    idx = torch.arange(40, device=dev)
+    ref = m.render_clip(audio, idx, h, w).clone()
+    one = m.render_clip(audio[:1], idx[:1], h, w).clone()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    flips = [0]
+
+    def flipper():
+        k = 0
+        while not stop.is_set():
+            assert lib.s2l_set_render_shape(k % 4) == 0
+            k += 1
+        flips[0] = k
+
+    th = threading.Thread(target=flipper)
+    th.start()
+    try:
+        outs = []
+        for it in range(200):
+            outs.append(m.render_clip(audio, idx, h, w) if it % 2 == 0 else m.render_clip(audio[:1], idx[:1], h, w))
+        torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join()
+        assert lib.s2l_set_render_shape(0) == 0
+    assert flips[0] > 100                                  # the other thread really ran
+    for it, o in enumerate(outs):
+        assert torch.equal(o, ref if it % 2 == 0 else one), it
+
+
+def test_soak_slice_of_the_counted_wait_assembly_kernels(dev):
+    """100 random shapes: render_tiles_kernel<long|wide|single> against each other, fwd/bwd_asm_bf16 against the C++ kernels,
+    conv3x3_split_kernel against the one-tile form -- bit for bit, each run twice."""
+    from tools import soak_conv_kernels as soak
+    notes = []
+    bad = soak.soak_render(dev, 60, seed=4, log=lambda *a: notes.append(a))
+    bad += soak.soak_bf16(dev, 25, seed=4, log=lambda *a: notes.append(a))
+    bad += soak.soak_conv(dev, 15, seed=4, log=lambda *a: notes.append(a))
+    torch.cuda.synchronize()
+    assert not bad, notes

@@ -60,11 +60,11 @@ def test_bench_force_dist_single_rank(flags):
     assert mg["gather_only_ms"] > 0 and mg["render_only_ms"] > 0
     bytes_per_frame = H * W_ * 3 * (1 if "u8" in flags else 4)
     assert mg["gather_bytes_per_rank"] == 96 * bytes_per_frame
+    assert mg["remote_block_bit_identical_to_local_render"] is True           # any chunking: frames sit at their global ids
+    assert mg["ragged_clip"]["bit_identical_to_one_gpu_render"] is True and mg["ragged_clip"]["frames"] == 43
+    assert mg["schedule_selection"] == "flags" and mg["schedule"] == ("2-chunk" if "--chunks" in flags else "1-chunk")
     if "--chunks" in flags:
-        assert mg["remote_block_bit_identical_to_local_render"] is None       # the cross-check is defined for one chunk
         assert "2-chunk" not in line["config"]["parallelism"]                 # world 1: the label only names real gathers
-    else:
-        assert mg["remote_block_bit_identical_to_local_render"] is True
     assert line["parity"]["psnr_db_vs_cpu"] >= 90.0
     assert line["roofline"]["frames_per_launch"] == (48 if "--chunks" in flags else 96)
 
@@ -125,6 +125,27 @@ def test_render_sharded_collective_equals_direct_render(single_rank_group, frame
     assert clip8.dtype == torch.uint8 and torch.equal(clip8, s2l.to8b(direct))
 
 
+@pytest.mark.parametrize("n,n_chunks,gather", [(37, 1, "f32"), (50, 3, "f32"), (37, 1, "u8"), (1, 1, "f32")])
+def test_render_clip_sharded_product_entry_on_rccl(single_rank_group, n, n_chunks, gather):
+    """The product entry (sharded.render_clip_sharded: whole-clip inputs in, whole clip out, blocks of ceil(N / G)) through the
+    RCCL all-gather with one rank == model.render_clip; host-side inputs are accepted (audio.npy comes from disk)."""
+    import speech2lip_amd as s2l
+    from speech2lip_amd import sharded, weights as W
+    from tests.test_gpu_parity import make_model
+    dev = single_rank_group
+    m = make_model(dev, H, W_)
+    audio = torch.from_numpy(W.synthetic_audio(n, seed=5).astype(np.float32))          # on the HOST
+    idx = torch.arange(39_990, 39_990 + n)
+    direct = m.render_clip(audio.to(dev), idx.to(dev), H, W_)
+    clip, (first, count) = sharded.render_clip_sharded(m, audio, idx, H, W_, gather=gather, n_chunks=n_chunks,
+                                                       force_collective=True, return_local=True)
+    torch.cuda.synchronize()
+    assert (first, count) == (0, n) and clip.shape == (n, H, W_, 3)
+    assert torch.equal(clip, s2l.to8b(direct) if gather == "u8" else direct)
+    whole = sharded.gather_clip(s2l.to8b(direct), n)                                     # the final-frames form (tools/infer_clip.py --gather)
+    assert torch.equal(whole, s2l.to8b(direct))
+
+
 def test_allreduce_grads_on_rccl(single_rank_group):
     """The data-parallel gradient bucket of config 5 on the RCCL backend (world 1: identity, but through the same calls)."""
     from speech2lip_amd import sharded
@@ -145,6 +166,9 @@ def test_bench_n_ranks_bit_check(gather):
     assert line["config"]["frames_per_gpu"] == 480
     mg = line["multi_gpu"]
     assert mg["remote_block_bit_identical_to_local_render"] is True
+    assert mg["ragged_clip"]["bit_identical_to_one_gpu_render"] is True and mg["ragged_clip"]["frames"] == 48 * n - 5     # N % G != 0
+    assert mg["schedule_selection"].startswith("auto") and set(mg["schedules_ms_per_step"]) == {"1-chunk", "4-chunk+8cu-reserved"}
+    assert mg["schedule"] in mg["schedules_ms_per_step"]
     assert mg["gather_bytes_per_rank"] == 480 * H * W_ * 3 * (4 if gather == "f32" else 1)
     # whole-job frames: every rank's 480 frames per step
     assert abs(line["value"] - 480 * n * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) <= 0.01 * line["value"]

@@ -99,3 +99,107 @@ def test_two_rank_gradient_bucket_allreduce():
     assert ret[0] and ret[1]
     g = {"x": torch.ones(2)}
     assert sharded.allreduce_grads(g) is g            # no process group: untouched
+
+
+# ---- the product entry: render_clip_sharded (ragged N, trimmed clip, global frame order) ---------------------------------
+def test_shard_range_is_ceil_blocks():
+    """contiguous blocks of ceil(N / G) frames; the tail ranks may be short or empty."""
+    assert [sharded.shard_range(10, r, 3) for r in range(3)] == [(0, 4, 4), (4, 4, 4), (8, 2, 4)]
+    assert [sharded.shard_range(5, r, 4) for r in range(4)] == [(0, 2, 2), (2, 2, 2), (4, 1, 2), (5, 0, 2)]
+    assert [sharded.shard_range(2, r, 3) for r in range(3)] == [(0, 1, 1), (1, 1, 1), (2, 0, 1)]
+    assert sharded.shard_range(0, 1, 2) == (0, 0, 0) and sharded.shard_range(40000, 7, 8) == (35000, 5000, 5000)
+    for n in (0, 1, 7, 16, 1000, 1001):
+        for g in (1, 2, 3, 8):
+            blocks = [sharded.shard_range(n, r, g) for r in range(g)]
+            assert sum(c for _, c, _ in blocks) == n
+            assert all(b[0] == sum(c for _, c, _ in blocks[:r]) for r, b in enumerate(blocks))
+
+
+def _stub_frame(audio_block, idx_block, out):
+    """CPU stand-in for the renderer: like the real one, every frame is a pure function of (its audio window, its frame index)."""
+    v = audio_block.double().sum(dim=(1, 2)) * 0.001 + idx_block.double() * 0.37
+    out.copy_(v.float().view(-1, 1, 1, 1).expand_as(out))
+
+
+def _clip_inputs(n):
+    g = torch.Generator().manual_seed(n)
+    return torch.randn(n, 16, 29, generator=g), torch.arange(100, 100 + n)
+
+
+def _clip_worker(rank, world, port, cases, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from speech2lip_amd.data import to8b
+        ok = True
+        for n, nc in cases:
+            audio, idx = _clip_inputs(n)
+            want = torch.empty(n, 2, 3, 3)
+            if n:
+                _stub_frame(audio, idx, want)
+            calls = []
+
+            def render(a, i, out):
+                calls.append(int(a.shape[0]))
+                _stub_frame(a, i, out)
+
+            clip, (first, count) = sharded.render_clip_sharded(None, audio, idx, 2, 3, n_chunks=nc, render_fn=render,
+                                                               return_local=True)
+            ok = ok and clip.shape == (n, 2, 3, 3) and torch.equal(clip, want)
+            ok = ok and (first, count) == sharded.shard_range(n, rank, world)[:2] and sum(calls) == count     # only its own frames
+            clip8 = sharded.render_clip_sharded(None, audio, idx, 2, 3, n_chunks=nc, gather="u8",
+                                                render_fn=lambda a, i, o: (_stub_frame(a, i, o), o.div_(64.0))[0])
+            ok = ok and clip8.dtype == torch.uint8 and torch.equal(clip8, to8b((want / 64.0).contiguous()))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_clip_on_two_and_three_ranks_equals_one_process():
+    """N % G != 0 (and N < G): padded blocks through the all-gather, trimmed to N, global frame order; fp32 and uint8;
+    one chunk and several."""
+    cases = [(10, 1), (7, 1), (7, 3), (11, 2), (2, 1), (1, 1), (0, 1), (12, 4)]
+    for world in (2, 3):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_clip_worker, args=(world, _free_port(), cases, ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world)), (world, dict(ret))
+
+
+def test_render_clip_sharded_without_a_process_group_is_a_plain_render():
+    audio, idx = _clip_inputs(5)
+    want = torch.empty(5, 2, 3, 3)
+    _stub_frame(audio, idx, want)
+    got = sharded.render_clip_sharded(None, audio, idx, 2, 3, render_fn=_stub_frame)
+    assert torch.equal(got, want)
+
+
+def _gather_clip_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for n in (7, 9, 2, 0):
+            whole = (torch.arange(n * 4, dtype=torch.int32).reshape(n, 2, 2) % 251).to(torch.uint8)
+            first, count, _ = sharded.shard_range(n, rank, world)
+            got = sharded.gather_clip(whole[first:first + count].clone(), n)
+            ok = ok and got.dtype == torch.uint8 and torch.equal(got, whole)
+        # the DDP-equivalent gradient averaging of Trainer(multi_gpu=True) (reference: training.py:41)
+        from speech2lip_amd.training import Trainer
+        tr = Trainer.__new__(Trainer)
+        tr.multi_gpu, tr.model = True, torch.nn.Linear(3, 2)
+        for p_ in tr.model.parameters():
+            p_.grad = torch.full_like(p_, float(rank + 1))
+        tr._average_gradients_over_ranks()
+        mean = sum(range(1, world + 1)) / world
+        ok = ok and all(torch.allclose(p_.grad, torch.full_like(p_, mean)) for p_ in tr.model.parameters())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_clip_and_gradient_averaging_three_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_clip_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    assert all(ret[r] for r in range(3))

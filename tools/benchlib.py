@@ -135,7 +135,7 @@ def bench_composite(dev, frames=256, check=True):
     ms = _median_ms(run)
     bpf = 8_000_000 + 12 * h * w
     gbs = bpf * frames / (ms * 1e-3) / 1e9
-    res = {"kernel": "s2l::composite_kernel", "frames": frames, "ms": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1),
+    res = {"kernel": "s2l::span_kernel + s2l::lip_merge_kernel (clip path; per-clip s2l::composite_tables_kernel)", "frames": frames, "ms": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1),
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                         "frac": round(gbs * 1e9 / HBM_PEAK, 4), "algorithmic_bytes_per_frame": bpf}}
     if check:

@@ -6,15 +6,25 @@ batch of frames instead of >100 launches per frame.
     python tools/infer_clip.py --config configs/face_simple_configs/may/may.yaml --default configs/default.yaml \
         --checkpoint out/may/model.pt [--mode val|test] [--batch 100] [--out DIR]
 
-Not a CLI product: a 40-line example of the drop-in calls."""
+Multi-GPU (BASELINE config 4): launch it under torchrun and the frames are sharded across the ranks in contiguous blocks of
+ceil(N / G) (speech2lip_amd.sharded.shard_range); every rank renders + composites + runs the U-Net on its own
+block and writes its own files -- the data path needs no collective.  With --gather the 8-bit clip is also reassembled on every
+rank by one RCCL all-gather (sharded.gather_clip; N need not divide by G) and rank 0 writes all files; with --lip-only the lip
+frames alone are rendered through sharded.render_clip_sharded (fp32, bit-identical to one GPU).
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/infer_clip.py --config ... [--gather]
+
+Not a CLI product: a short example of the drop-in calls."""
 import argparse
 import os
 import sys
 
 import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech2lip_amd as s2l
+from speech2lip_amd import sharded
 
 
 def main():
@@ -25,8 +35,16 @@ def main():
     ap.add_argument("--mode", default="val", choices=["val", "test"])        # test = --use_new_audio (audio_test/audio.npy)
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--out")
+    ap.add_argument("--gather", action="store_true", help="multi-GPU: all-gather the 8-bit clip, rank 0 writes every file")
+    ap.add_argument("--lip-only", action="store_true", help="render only the lip crops (sharded.render_clip_sharded)")
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL on this driver)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     cfg = s2l.load_config(args.config, args.default)
     ds = s2l.SomeonesLipClip(cfg["data"]["path"], args.mode, cfg)
     cfg["data"]["height"], cfg["data"]["width"] = ds.lip_h, ds.lip_w
@@ -35,12 +53,32 @@ def main():
         model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"], strict=False)
     out_dir = args.out or os.path.join(cfg["training"]["out_dir"], "test_post" if args.mode == "val" else "test_new_audio")
     n = len(ds)
-    for first in range(0, n, args.batch):
-        clip = ds.load(dev, first, args.batch)
-        lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=bool(cfg["model"].get("use_post_fusion", True)))
-        frames = recon if recon is not None else (merged if merged is not None else lip)
-        s2l.write_frames(frames, clip.names, out_dir)
-        print(f"frames {first + 1}..{first + len(clip.names)} of {n} -> {out_dir}", flush=True)
+    names = ["%05d" % (i + 1) for i in range(n)]                              # inference.py:177
+    if args.lip_only:
+        audio = torch.from_numpy(ds.aud_features.astype("float32"))
+        lips = sharded.render_clip_sharded(model, audio, torch.arange(n), ds.lip_h, ds.lip_w, gather="u8")
+        if rank == 0:
+            s2l.write_frames(lips, names, out_dir)
+    else:
+        first0, count, _ = sharded.shard_range(n, rank, world)               # this rank's contiguous block of the clip
+        blocks = []
+        for first in range(first0, first0 + count, args.batch):
+            clip = ds.load(dev, first, min(args.batch, first0 + count - first))
+            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=bool(cfg["model"].get("use_post_fusion", True)))
+            frames = recon if recon is not None else (merged if merged is not None else lip)
+            if args.gather and world > 1:
+                blocks.append(s2l.to8b(frames))
+            else:
+                s2l.write_frames(frames, clip.names, out_dir)
+            print(f"[rank {rank}] frames {first + 1}..{first + len(clip.names)} of {n} -> {out_dir}", flush=True)
+        if args.gather and world > 1:
+            mine = torch.cat(blocks, 0) if blocks else torch.empty((0, ds.face_h, ds.face_w, 3), dtype=torch.uint8, device=dev)
+            whole = sharded.gather_clip(mine, n)
+            if rank == 0:
+                s2l.write_frames(whole, names, out_dir)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,33 +1,154 @@
-"""Race screen for the persistent bf16-operand convolution kernel: random frame shapes, split-bf16 forward and the plain-bf16 training
-chain, persistent form vs the one-tile-per-workgroup kernels, bit for bit, repeated.   python tools/soak_conv_kernels.py [rounds=150]"""
-import os, sys
+"""Race screens for the kernels that wait with hand-counted `s_waitcnt vmcnt(n)` on requests issued as assembly text
+(DESIGN.md §4.1, §4.5, §4.6): random shapes, every result compared BIT FOR BIT with an independent kernel that performs the same
+arithmetic, and with a second run of itself.
+
+  conv    conv3x3_split_kernel (persistent, bf16 operands): split-bf16 forward and the plain-bf16 training chain,
+          persistent form vs the one-tile-per-workgroup kernels (the soak that found round 3's ~1 %-of-shapes copy race);
+  render  render_tiles_kernel<long | wide | single>: random (H, W, F), the three tile shapes against each other and the
+          auto-picked one, each twice (every sample column sees the same MFMA sequence in every shape);
+  bf16    fwd_asm_bf16_kernel / bwd_asm_bf16_kernel: random (h, w, B) rows, assembly vs the C++ kernels (activation images,
+          ReLU mask words, rgb, dz images), each twice.
+
+    python tools/soak_conv_kernels.py [rounds=150] [conv|render|bf16|all]
+
+`tests/test_gpu_concurrency.py` runs a 100-shape slice of the three under `-m gpu`."""
+import ctypes
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+import torch
+
 import speech2lip_amd as s2l
-from speech2lip_amd import weights as W, _abi
-dev = torch.device("cuda:0")
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-u = s2l.SimpleUnetLight().to(dev).eval()
-u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
-lib = _abi.load()
-rng = np.random.default_rng(0)
-bad = 0
-for it in range(rounds):
-    big = it % 3 == 0      # a third: few large frames; the rest: many small ones (both reach >= 4 tiles per workgroup, the plain form's threshold)
-    F = int(rng.integers(1, 4)) if big else int(rng.integers(1, 64))
-    H = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
-    Wd = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
-    x = torch.rand(F, H, Wd, 3, device=dev)
-    d = torch.randn(F, H, Wd, 3, device=dev)
-    res = []
-    for kind in (1, 0, 0):
-        _abi.check(lib.s2l_set_unet_split_kernel(kind), "kind")
-        a = u.forward_nhwc(x, precision="split").clone()
-        o, ctx = u.forward_saved_nhwc(x, precision="bf16")
-        res.append((a, o.clone(), u.backward_input(ctx, d).clone()))
-    ok = all(torch.equal(res[0][j], res[k][j]) for j in range(3) for k in (1, 2))
-    if not ok:
-        bad += 1
-        print("MISMATCH", F, H, Wd, [[torch.equal(res[0][j], res[k][j]) for j in range(3)] for k in (1, 2)])
-lib.s2l_set_unet_split_kernel(0)
-print(f"{rounds} shapes, {bad} mismatches")
+from speech2lip_amd import _abi, weights as W
+from speech2lip_amd.talking_face import _ptr, _stream
+
+
+def soak_conv(dev, rounds, seed=0, log=print):
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
+    lib = _abi.load()
+    rng = np.random.default_rng(seed)
+    bad = []
+    try:
+        for it in range(rounds):
+            big = it % 3 == 0      # a third: few large frames; the rest: many small ones (both reach >= 4 tiles per workgroup, the plain form's threshold)
+            F = int(rng.integers(1, 4)) if big else int(rng.integers(1, 64))
+            H = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
+            Wd = int(rng.integers(200, 520)) if big else int(rng.integers(4, 140))
+            x = torch.rand(F, H, Wd, 3, device=dev)
+            d = torch.randn(F, H, Wd, 3, device=dev)
+            res = []
+            for kind in (1, 0, 0):
+                _abi.check(lib.s2l_set_unet_split_kernel(kind), "kind")
+                a = u.forward_nhwc(x, precision="split").clone()
+                o, ctx = u.forward_saved_nhwc(x, precision="bf16")
+                res.append((a, o.clone(), u.backward_input(ctx, d).clone()))
+            ok = all(torch.equal(res[0][j], res[k][j]) for j in range(3) for k in (1, 2))
+            if not ok:
+                bad.append(("conv", F, H, Wd))
+                log("MISMATCH conv", F, H, Wd, [[torch.equal(res[0][j], res[k][j]) for j in range(3)] for k in (1, 2)])
+    finally:
+        lib.s2l_set_unet_split_kernel(0)
+    return bad
+
+
+def soak_render(dev, rounds, seed=0, log=print):
+    lib = _abi.load()
+    rng = np.random.default_rng(seed + 1)
+    models = {}
+    bad = []
+    try:
+        for it in range(rounds):
+            kind = it % 4
+            if kind == 0:        # the clip regime: many frames, mid-size crops (several tiles per persistent workgroup)
+                H, Wd, F = int(rng.integers(24, 100)), int(rng.integers(24, 100)), int(rng.integers(40, 400))
+            elif kind == 1:      # the per-frame regime
+                H, Wd, F = int(rng.integers(1, 132)), int(rng.integers(1, 132)), int(rng.integers(1, 4))
+            else:                # ragged everything
+                H, Wd, F = int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.integers(1, 60))
+            m = models.get("m")
+            if m is None:
+                m = models["m"] = s2l.TalkingFace(dev, s2l.may_config(16, 16), mode="eval").eval()
+                m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
+            audio = torch.from_numpy(W.synthetic_audio(F, seed=int(rng.integers(1 << 20))).astype(np.float32)).to(dev)
+            idx = torch.from_numpy(rng.integers(0, 40000, F)).to(dev)
+            outs = []
+            for shape in (0, 1, 2, 3, 0, 1, 2, 3):          # 0 = auto; 1 + shape forces long / wide / single
+                _abi.check(lib.s2l_set_render_shape(shape), "s2l_set_render_shape")
+                outs.append(m.render_clip(audio, idx, H, Wd).clone())
+            if not all(torch.equal(outs[0], o) for o in outs[1:]):
+                bad.append(("render", H, Wd, F))
+                log("MISMATCH render", H, Wd, F, [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+            m._tables = {}       # the pixel tables of this crop size are not needed again
+    finally:
+        lib.s2l_set_render_shape(0)
+    return bad
+
+
+def soak_bf16(dev, rounds, seed=0, log=print):
+    lib = _abi.load()
+    rng = np.random.default_rng(seed + 2)
+    m = s2l.TalkingFace(dev, s2l.may_config(16, 16), mode="eval").eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
+    pb, pf = m.packed_weights_bf16(), m.packed_weights()
+    bad = []
+    try:
+        for it in range(rounds):
+            if it % 3 == 0:      # several tiles per persistent workgroup (> 256 tiles of 256 rows)
+                h, w, B = int(rng.integers(40, 100)), int(rng.integers(40, 100)), int(rng.integers(3, 9))
+            else:
+                h, w, B = int(rng.integers(1, 48)), int(rng.integers(1, 48)), int(rng.integers(1, 6))
+            P = h * w
+            N = 4 * P * B
+            Np = int(lib.s2l_bf16_rows_padded(N))
+            feat = m.audio_merge_forward(torch.from_numpy(W.synthetic_audio(B, seed=int(rng.integers(1 << 20))).astype(np.float32)).to(dev))
+            coords = s2l.get_coords(w, h, dev)
+            xT = torch.zeros(Np * 128, dtype=torch.int16, device=dev)
+            areas = torch.empty(N, device=dev)
+            t_idx = torch.from_numpy(rng.integers(0, 40000, B)).to(dev)
+            t_u = torch.from_numpy(rng.random(B, dtype=np.float32)).to(dev)
+            _abi.check(lib.s2l_ensemble_rows_bf16(_ptr(pf), _ptr(coords), _ptr(feat), _ptr(t_idx), _ptr(t_u), w, h, _ptr(xT), _ptr(areas),
+                                                  P, B, _stream()), "s2l_ensemble_rows_bf16")
+            drgb = (torch.randn(N, 3, device=dev) * 1e-3)
+            fwd = []
+            for kind in (1, 0, 0):                           # 1 = the C++ forward, 0 = the generated assembly (default)
+                _abi.check(lib.s2l_set_bf16_forward_kernel(kind), "s2l_set_bf16_forward_kernel")
+                hT = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+                masks = torch.zeros(8 * (Np // 64) * 256, dtype=torch.int64, device=dev)
+                rgb = torch.zeros(N, 3, device=dev)
+                _abi.check(lib.s2l_train_forward_bf16(_ptr(pb), _ptr(pf), _ptr(xT), _ptr(hT), _ptr(masks), _ptr(rgb), N, _stream()), "fwd16")
+                fwd.append((hT, masks, rgb))
+            ok = all(torch.equal(fwd[0][j], fwd[k][j]) for j in range(3) for k in (1, 2))
+            masks = fwd[0][1]
+            dz_c = torch.zeros(8 * Np * 256, dtype=torch.int16, device=dev)
+            dxa = torch.zeros(Np, 64, device=dev)
+            _abi.check(lib.s2l_train_backward_bf16(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dz_c), _ptr(dxa), N, _stream()), "bwd16")
+            tiles0 = None
+            for rep in range(2):
+                dz_a = torch.full((8 * Np * 256,), 0x7fc0, dtype=torch.int16, device=dev)
+                tiles = torch.full((Np // 256, 64), float("nan"), device=dev)
+                _abi.check(lib.s2l_train_backward_bf16_tiles(_ptr(pb), _ptr(drgb), _ptr(masks), _ptr(dz_a), _ptr(tiles), N, _stream()), "bwd16 asm")
+                ok = ok and torch.equal(dz_c, dz_a) and (tiles0 is None or torch.equal(tiles0, tiles))
+                tiles0 = tiles
+            if not ok:
+                bad.append(("bf16", h, w, B))
+                log("MISMATCH bf16", h, w, B)
+    finally:
+        lib.s2l_set_bf16_forward_kernel(0)
+    return bad
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    which = sys.argv[2] if len(sys.argv) > 2 else "conv"
+    bad = []
+    for name, fn in (("conv", soak_conv), ("render", soak_render), ("bf16", soak_bf16)):
+        if which in (name, "all"):
+            b = fn(dev, rounds)
+            torch.cuda.synchronize()
+            print(f"{name}: {rounds} shapes, {len(b)} mismatches", flush=True)
+            bad += b
+    sys.exit(1 if bad else 0)

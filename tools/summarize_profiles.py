@@ -38,7 +38,8 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes\n" % traffic)
     # the figure bench.py's roofline.traffic carries: tracked next to the profile it comes from, read by bench.py
     json.dump({"profile": f"profiles/{tag}_rocprofv3_summary.txt", "kernel": "s2l::render_tiles_kernel",
-               "frames_per_dispatch": 1000, "height": 96, "width": 96,
+               "frames_per_dispatch": 1000, "height": 96, "width": 96, "render_shape": "long (3 x (1 x 12)), auto-picked for 1000 frames",
+               "kernel_text_sha256_16": __import__("hashlib").sha256(open("speech2lip_amd/build/render_body.inc", "rb").read()).hexdigest()[:16],
                "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                "hbm_bytes_per_dispatch": round(traffic), "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024"},
               open("profiles/render_traffic.json", "w"), indent=1)
