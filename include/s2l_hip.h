@@ -29,7 +29,7 @@ enum {
   S2L_E_NULL = -1,     /* a required pointer is NULL            */
   S2L_E_SIZE = -2,     /* a size / count argument is invalid    */
   S2L_E_ALIGN = -3,    /* a pointer is not 16-byte aligned      */
-  S2L_E_GEOMETRY = -4  /* composite: lip box / mask rectangle leaves the face frame */
+  S2L_E_GEOMETRY = -4  /* a box the reference cannot evaluate either: composite lip box ENTIRELY outside the face frame (F.pad raises; a partly-outside box is cropped as F.pad crops), crop/U-Net windows, LPIPS minimum size */
 };
 
 /* Index of each state-dict tensor in the pointer table handed to s2l_pack_weights.  Names are
@@ -218,7 +218,11 @@ int s2l_mse(const float* pred, const float* target, float weight, float* dpred, 
  * out_new [F,FH,FW,3]; out_canonical [F,FH,FW,3] or NULL (rgb_merged_canonical, :352).
  * bgm: NULL, or the per-clip table of s2l_composite_tables for these face_canon/mask (used only
  * when both strides are 0): halves the gather traffic, results are bit-identical.
- * expand_pad = p (lip_w/5, or lip_w/12 for obama2, :357-360); pad_mode S2L_PAD_*. */
+ * expand_pad = p (lip_w/5, or lip_w/12 for obama2, :357-360); pad_mode S2L_PAD_*.
+ * Edge geometry follows the reference statement for statement (golden G17): a lip box that leaves the face frame is pasted
+ * CROPPED (F.pad with negative amounts, :343-350); the rectangle is a python slice (:362) -- a negative bound wraps once, both
+ * bounds are clamped, start >= stop is empty (then out = rgb_gt everywhere); a box that would need a crop larger than the lip
+ * (beyond the frame by more than touching it) makes F.pad raise there and returns S2L_E_GEOMETRY here. */
 int s2l_composite(const float* lip, const float* face_canon, int64_t face_stride, const float* mask,
                   int64_t mask_stride, const float* rgb_gt, const float* coord, float* out_new,
                   float* out_canonical, const float* bgm, int lip_h, int lip_w, int face_h, int face_w,

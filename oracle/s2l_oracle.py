@@ -184,12 +184,15 @@ def composite(lip: torch.Tensor, face_canon: torch.Tensor, rgb_gt: torch.Tensor,
     B, h, w, _ = lip.shape
     FH, FW = face_canon.shape[1:3]
     ox, oy = (x0, y0) if pad_mode == PAD_MODE_MAY else (x0 - 1, y0 - 1)
-    lip_pad = torch.zeros_like(face_canon)
-    lip_pad[:, oy:oy + h, ox:ox + w, :] = lip
+    # F.pad as the reference calls it (:343-350): a NEGATIVE amount crops, so a lip box that leaves the face frame is pasted
+    # with its outside part cut off (and a box entirely outside raises, as there)
+    lip_pad = F.pad(lip.permute(0, 3, 1, 2), (ox, FW - ox - w, oy, FH - oy - h), mode="constant", value=0).permute(0, 2, 3, 1)
     merged_c = mask * lip_pad + (1 - mask) * face_canon
     if expand_lip_mask:
         p = w // pad_div
         m = torch.zeros_like(mask)
+        # python slicing as in :362 -- a negative start (x0 < p) WRAPS to the far side, which usually leaves an empty slice:
+        # the rectangle vanishes and the output is the observed frame everywhere.  Reproduced, not repaired.
         m[:, y0 - p:y0 + h + 2 * p, x0 - p:x0 + w + p, :] = 1
     else:
         m = mask.clone()

@@ -32,7 +32,7 @@ TENSOR_ORDER = [
 assert len(TENSOR_ORDER) == S2L_NUM_TENSORS
 
 _ERRORS = {-1: "S2L_E_NULL (null pointer)", -2: "S2L_E_SIZE (bad size)", -3: "S2L_E_ALIGN (pointer not 16-byte aligned)",
-           -4: "S2L_E_GEOMETRY (lip box / mask rectangle leaves the face frame)"}
+           -4: "S2L_E_GEOMETRY (geometry the reference cannot evaluate either, e.g. a lip box entirely outside the face frame)"}
 
 EXPORTS = {
     "s2l_version": (c_char_p, []),

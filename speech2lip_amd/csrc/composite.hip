@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void lip_merge_kernel(SpanArgs sa) {
   const int64_t f = blockIdx.y;
   if (p >= n) return;
   const int ly = p / a.w, lx = p - ly * a.w;
+  // a lip pixel the (possibly cropped) paste puts outside the frame is never looked up: taps are clamped to the frame first
+  if ((unsigned)(a.oy + ly) >= (unsigned)a.FH || (unsigned)(a.ox + lx) >= (unsigned)a.FW) return;
   const int o = (a.oy + ly) * a.FW + a.ox + lx;
   const Px m = load_px(a.mask + o * 3);
   const Px l = load_px(a.lip + (f * n + p) * 3);
@@ -503,14 +505,19 @@ static int composite_args(s2l::CompArgs& a, const float* face_canon, int64_t fac
   a.h = lip_h; a.w = lip_w; a.FH = face_h; a.FW = face_w;
   a.ox = pad_mode == S2L_PAD_MAY ? x0 : x0 - 1;
   a.oy = pad_mode == S2L_PAD_MAY ? y0 : y0 - 1;
-  // F.pad with a negative amount would crop: the reference assumes the lip box lies inside the face frame
-  if (a.ox < 0 || a.oy < 0 || a.ox + lip_w > face_w || a.oy + lip_h > face_h) return S2L_E_GEOMETRY;
+  // F.pad with a negative amount CROPS (tf_nerf.py:343-350): a lip box that leaves the face frame is pasted with its outside
+  // part cut off -- every kernel tests taps against the box AND the frame, so any origin works (a box that only touches the
+  // frame from outside is cropped to nothing: the lip contributes zeros).  A box BEYOND that would need a crop larger than the
+  // lip: F.pad raises in the reference ("narrow(): length must be non-negative"): S2L_E_GEOMETRY here (golden G17).
+  if (a.ox + lip_w < 0 || a.oy + lip_h < 0 || a.ox > face_w || a.oy > face_h) return S2L_E_GEOMETRY;
+  if ((int64_t)a.ox + lip_w > 0x3fffffff || (int64_t)a.oy + lip_h > 0x3fffffff || a.ox < -0x3fffffff || a.oy < -0x3fffffff) return S2L_E_SIZE;
   if (expand_pad >= 0) {
-    a.ry0 = y0 - expand_pad; a.rx0 = x0 - expand_pad;
-    if (a.ry0 < 0 || a.rx0 < 0) return S2L_E_GEOMETRY;  // python slicing would wrap around
-    a.ry1 = y0 + lip_h + 2 * expand_pad; a.rx1 = x0 + lip_w + expand_pad;
-    if (a.ry1 > face_h) a.ry1 = face_h;
-    if (a.rx1 > face_w) a.rx1 = face_w;
+    // the rectangle is a PYTHON SLICE (tf_nerf.py:362): a negative bound has the axis length added once, then both bounds are
+    // clamped to [0, length]; start >= stop is an empty slice (no warped pixel shows) -- e.g. x0 < padding wraps the start to the
+    // far side.  Reproduced as the reference behaves, not repaired.
+    const auto bound = [](int64_t v, int len) { if (v < 0) v += len; return (int)(v < 0 ? 0 : v > len ? len : v); };
+    a.ry0 = bound((int64_t)y0 - expand_pad, face_h); a.ry1 = bound((int64_t)y0 + lip_h + 2 * (int64_t)expand_pad, face_h);
+    a.rx0 = bound((int64_t)x0 - expand_pad, face_w); a.rx1 = bound((int64_t)x0 + lip_w + expand_pad, face_w);
   } else {
     a.ry0 = a.ry1 = a.rx0 = a.rx1 = -1;
   }

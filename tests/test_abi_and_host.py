@@ -55,9 +55,13 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_render_lip(one, one, one, one, one, one, 16, 0, null) == 0
     odd = ctypes.c_void_p(20)
     assert lib.s2l_render_lip(one, odd, one, one, one, one, 16, 1, null) == -3   # S2L_E_ALIGN
-    # composite geometry: lip box outside the face frame / negative rectangle start
-    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 50, 30, 0, 4, 1, null) == -4
-    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 2, 30, 0, 4, 1, null) == -4
+    # composite geometry: a lip box ENTIRELY outside the face frame is an error, as in the reference (F.pad raises; a box that
+    # only leaves the frame partly is cropped, golden G17 -- those calls go on to launch and need a GPU)
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 70, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, -25, 30, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 20, 65, 0, 4, 1, null) == -4
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 20, 64, 0, 4, 1, null) != -4    # touching from outside: cropped to nothing
+    assert lib.s2l_composite(one, one, 0, one, 0, one, one, one, null, null, 16, 24, 64, 64, 0, 0, 1, 4, 1, null) != -4     # default mode: origin (-1, -1), cropped
     assert lib.s2l_composite(one, one, 7, one, 0, one, one, one, null, null, 16, 24, 64, 64, 20, 30, 0, 4, 1, null) == -2
     # round-3 entry points: the pair pass of the lip-sync expert, the frozen / bf16 train-mode U-Net, the kernel selectors
     assert lib.s2l_syncnet_forward_pair(one, one, one, one, one, one, 5, 4, null) == -2          # more mel windows than face windows

@@ -331,8 +331,10 @@ def test_render_clip_bits_are_pinned(dev):
 def test_composite_random_geometry_property(dev):
     """SURVEY.md §4's property test for the paste + warp composite: random frame sizes, lip sizes, lip offsets (incl. boxes that
     touch the frame border on every side), both pad modes, expand_lip_mask on / off, per-frame and per-clip constants, F = 1..3,
-    coordinates that leave [-1, 1] -- every valid geometry must equal the oracle (tf_nerf.py:320-386) and every geometry the
-    reference's F.pad / slicing cannot express must raise S2L_E_GEOMETRY instead of rendering something."""
+    coordinates that leave [-1, 1] -- every geometry the reference evaluates must equal the oracle (tf_nerf.py:320-386), INCLUDING
+    lip boxes that leave the face frame (F.pad's negative amounts crop the lip, :343-350) and rectangles whose python slice wraps
+    (:362; golden G17 pins both against the reference itself); a box entirely outside the frame makes the reference's F.pad
+    raise, and must raise S2L_E_GEOMETRY here instead of rendering something."""
     from hypothesis import given, settings, strategies as st, HealthCheck
     from speech2lip_amd import _abi
 
@@ -340,15 +342,17 @@ def test_composite_random_geometry_property(dev):
     def cases(draw):
         FH, FW = draw(st.integers(8, 70)), draw(st.integers(8, 90))
         lh, lw = draw(st.integers(1, min(24, FH))), draw(st.integers(1, min(30, FW)))
-        edge = draw(st.sampled_from(["free", "left", "top", "right", "bottom", "corner"]))
-        x0 = {"left": 0, "right": FW - lw, "corner": FW - lw}.get(edge, draw(st.integers(-2, FW - lw + 2)))
-        y0 = {"top": 0, "bottom": FH - lh, "corner": FH - lh}.get(edge, draw(st.integers(-2, FH - lh + 2)))
+        edge = draw(st.sampled_from(["free", "free", "left", "top", "right", "bottom", "corner", "over", "outside"]))
+        x0 = {"left": 0, "right": FW - lw, "corner": FW - lw, "outside": draw(st.sampled_from([-lw - 2, FW + 2, -lw, FW]))}.get(
+            edge, draw(st.integers(-lw + 1, FW) if edge == "over" else st.integers(-2, FW - lw + 2)))
+        y0 = {"top": 0, "bottom": FH - lh, "corner": FH - lh}.get(
+            edge, draw(st.integers(-lh + 1, FH) if edge == "over" else st.integers(-2, FH - lh + 2)))
         return dict(FH=FH, FW=FW, lh=lh, lw=lw, x0=x0, y0=y0, may=draw(st.booleans()), expand=draw(st.booleans()),
                     F=draw(st.integers(1, 3)), per_clip=draw(st.booleans()), seed=draw(st.integers(0, 2 ** 16)))
 
-    seen = {"ok": 0, "geometry": 0}
+    seen = {"ok": 0, "geometry": 0, "cropped": 0}
 
-    @settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
     @given(cases())
     def run(c):
         rng = np.random.default_rng(c["seed"])
@@ -363,14 +367,17 @@ def test_composite_random_geometry_property(dev):
         mask = T(rng.random((nc, FH, FW, 3), dtype=np.float32))
         coord = T((rng.random((F, FH, FW, 2), dtype=np.float32) * 2.6 - 1.3))
         ox, oy = (x0, y0) if c["may"] else (x0 - 1, y0 - 1)
-        p = lw // 5
-        valid = ox >= 0 and oy >= 0 and ox + lw <= FW and oy + lh <= FH and (not c["expand"] or (x0 - p >= 0 and y0 - p >= 0))
+        outside = ox + lw < 0 or oy + lh < 0 or ox > FW or oy > FH              # F.pad would have to crop more than the lip has
         args = (lip.to(dev), face.to(dev), gt.to(dev), mask.to(dev), x0, y0, coord.to(dev))
-        if not valid:
+        if outside:
             with pytest.raises(_abi.S2LError, match="geometry|GEOMETRY"):
                 m.composite_clip(*args)
+            with pytest.raises(RuntimeError):                                    # ... as the reference's F.pad does (oracle = the same call)
+                O.composite(lip[:1], face[:1], gt[:1], mask[:1], x0, y0, coord[:1], pad_mode=O.PAD_MODE_MAY if c["may"] else O.PAD_MODE_DEFAULT)
             seen["geometry"] += 1
             return
+        if ox < 0 or oy < 0 or ox + lw > FW or oy + lh > FH:
+            seen["cropped"] += 1
         new, can = m.composite_clip(*args, want_canonical=True)
         with torch.no_grad():
             ref = [O.composite(lip[f:f + 1], face[min(f, nc - 1)][None], gt[f:f + 1], mask[min(f, nc - 1)][None], x0, y0, coord[f:f + 1],
@@ -386,7 +393,37 @@ def test_composite_random_geometry_property(dev):
         seen["ok"] += 1
 
     run()
-    assert seen["ok"] >= 25 and seen["geometry"] >= 3, seen
+    assert seen["ok"] >= 40 and seen["geometry"] >= 3 and seen["cropped"] >= 8, seen
+
+
+def test_composite_edge_geometry_golden_g17(golden, dev):
+    """The reference's own outputs for lip boxes that leave the face frame (F.pad crops, tf_nerf.py:343-350) and rectangles whose
+    python slice wraps or is clipped (:362) -- tools/make_golden_edges.py; both pad modes and the obama2 rule; the one-pixel
+    kernel (one frame) and the clip fast path (the same frame twice with per-clip constants)."""
+    g = golden("g17_composite_edges.npz")
+    face, gt, mask, coord = (T(g[k]).to(dev) for k in ("face", "gt", "mask", "coord"))
+    shown = {}
+    for name in [str(n) for n in g["names"]]:
+        lip = T(g[f"{name}/lip"]).to(dev)
+        x0, y0, path = int(g[f"{name}/x0"]), int(g[f"{name}/y0"]), str(g[f"{name}/path"])
+        m = make_model(dev, lip.shape[1], lip.shape[2], path=path)
+        new, can = m.composite_clip(lip, face, gt, mask, x0, y0, coord, want_canonical=True)
+        assert torch.equal(can.cpu(), T(g[f"{name}/merged_canonical"])), name          # elementwise: bit-exact
+        close(new, g[f"{name}/merged_new"], 1e-6, 2e-6)
+        two, _ = m.composite_clip(lip.expand(2, -1, -1, -1).contiguous(), face, gt.expand(2, -1, -1, -1).contiguous(), mask, x0, y0,
+                                  coord.expand(2, -1, -1, -1).contiguous())
+        assert torch.equal(two[0], new[0]) and torch.equal(two[1], new[0]), name         # span kernel + merged-box table
+        shown[name] = float((new != gt).any(-1).float().mean())
+        assert abs(shown[name] - float(g[f"{name}/shown"])) <= 2e-3, (name, shown[name])
+        # the lip gradient follows the same geometry: finite, zero wherever the forward shows no warped pixel
+        d_lip = m.composite_backward_lip(torch.ones_like(new), face, mask, x0, y0, coord, lip.shape[1], lip.shape[2])
+        assert torch.isfinite(d_lip).all() and (shown[name] > 0 or float(d_lip.abs().max()) == 0.0)
+    assert shown["default_rect_wraps"] == 0.0 and shown["obama2_rect_inside"] > 0.1      # the wrapped slice is EMPTY, as in the reference
+    assert bool(g["outside_raises"])
+    from speech2lip_amd import _abi
+    m = make_model(dev, 16, 24)
+    with pytest.raises(_abi.S2LError, match="geometry|GEOMETRY"):
+        m.composite_clip(torch.zeros(1, 16, 24, 3, device=dev), face, gt, mask, 70, 10, coord)
 
 
 def test_render_and_crop_resize_random_sizes_property(sd, dev):

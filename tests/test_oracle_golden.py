@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/s2l_oracle.py) against the golden vectors that
 tools/make_goldens.py captured from the reference itself."""
+import pytest
 import numpy as np
 import torch
 
@@ -335,3 +336,20 @@ def test_g16_stage_one_step_through_train_step(golden):
         if key.startswith("s_"):
             assert _maxerr(stats["post_fusion_unet." + key[2:]], g[key]) <= 1e-5, key
     assert _maxerr(sd["pts_linears.5.weight"].grad[:, 250:262], g["g_pts5_cols"]) <= 1e-4 * float(np.abs(g["g_pts5_cols"]).max())
+
+
+
+def test_g17_composite_edges_oracle(golden):
+    """Lip boxes that leave the face frame and wrapping rectangle slices: the oracle equals the reference's own outputs
+    (tools/make_golden_edges.py) bit for bit."""
+    g = golden("g17_composite_edges.npz")
+    T = torch.from_numpy
+    face, gt, mask, coord = (T(g[k]) for k in ("face", "gt", "mask", "coord"))
+    for name in [str(n) for n in g["names"]]:
+        path = str(g[f"{name}/path"])
+        mode = O.PAD_MODE_MAY if ("may" in path or "obama2" in path) else O.PAD_MODE_DEFAULT
+        new, can = O.composite(T(g[f"{name}/lip"]), face, gt, mask, int(g[f"{name}/x0"]), int(g[f"{name}/y0"]), coord, pad_mode=mode,
+                               pad_div=12 if "obama2" in path else 5)
+        assert torch.equal(new, T(g[f"{name}/merged_new"])) and torch.equal(can, T(g[f"{name}/merged_canonical"])), name
+    with pytest.raises(RuntimeError):
+        O.composite(torch.zeros(1, 16, 24, 3), face, gt, mask, 70, 10, coord)
