@@ -169,6 +169,7 @@ def extra_measurements(dev):
     from tools import benchlib
     out = {}
     for name, fn in (("composite", lambda: benchlib.bench_composite(dev, 256)),
+                     ("render_split", lambda: benchlib.bench_render_split(dev)),
                      ("small_clips", lambda: benchlib.bench_small_clips(dev)),
                      ("config3", lambda: benchlib.bench_config3(dev, 5000, 500)),
                      ("config3_with_unet", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True)),

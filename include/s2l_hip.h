@@ -101,6 +101,18 @@ int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float*
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
+/* OPT-IN split-bf16 speed mode of s2l_render_lip (same arguments + packed16; same tile shapes, ring and tables; csrc/render16.hip):
+ * the seven 256x256 layers and the output layer on v_mfma_f32_16x16x32_bf16 with every fp32 operand x carried as
+ * hi = bf16(x), lo = bf16(x - hi) and a product evaluated as W_lo a_hi + W_hi a_lo + W_hi a_hi, fp32 accumulation; the first
+ * layer and the skip terms stay exact fp32 table sums.  ~1e-6 of the output scale from the exact kernel (north-star bar: RMSE
+ * <= 1e-4), several times its frame rate.  The exact fp32 kernel is the default everywhere; this one runs only when a caller
+ * asks for it (TalkingFace.render_clip(precision="split")).  Replaces the same reference lines as s2l_render_lip
+ * (inference.py:140-159, tf_nerf.py:225-285).
+ * s2l_pack_render16: the bf16 (hi | lo) A-operand slabs, s2l_render16_packed_halves() uint16 values, from the fp32 blob. */
+int64_t s2l_render16_packed_halves(void);
+int s2l_pack_render16(const float* packed, void* packed16, s2l_stream_t stream);
+int s2l_render_lip_split(const float* packed, const void* packed16, const float* p0, const float* p5, const float* q0,
+                         const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
 /* The renderer has three tile shapes (4 waves x G groups of 16 samples): 16 pixels x 12 frames (clips), 192 pixels x 1 frame
  * (clip lengths that are not multiples of 12) and 64 pixels x 1 frame (one frame per call, the reference's own mode,
  * inference.py:129,140-159: the whole chip works on the one frame).  s2l_render_lip picks the one with the smallest estimated time;

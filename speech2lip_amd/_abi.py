@@ -42,6 +42,9 @@ EXPORTS = {
     "s2l_frame_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_pixel_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_render_lip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_render16_packed_halves": (c_int64, []),
+    "s2l_pack_render16": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "s2l_render_lip_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_set_render_cus": (c_int, [c_int]),
     "s2l_rgb_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_embed_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),

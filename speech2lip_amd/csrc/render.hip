@@ -129,6 +129,10 @@ extern "C" int s2l_set_render_shape(int mode) {
   return S2L_OK;
 }
 
+// (shared with the split-half renderer of render16.hip)
+extern "C" int s2l_render_shape_mode(void) { return g_render_shape.load(std::memory_order_relaxed); }
+extern "C" int s2l_render_cu_limit(int dev) { return (dev >= 0 && dev < s2l::kMaxDevices) ? g_render_cu_limit[dev].load(std::memory_order_relaxed) : 0; }
+
 // The shape with the smallest estimated time on n_cu CUs: rounds of tiles over the persistent grid x the cost of a tile (a G = 1
 // tile streams the same 113 weight slabs for a third of the MFMAs: ~0.36 of a G = 3 tile; the wide shape's 22 extra table steps
 // cost ~3 %).  Ties go to the long shape (pinned text, least table traffic).

@@ -449,8 +449,24 @@ class TalkingFace(nn.Module):
             self._tables[key] = (p0, p5)
         return self._tables[key]
 
-    def render_clip(self, audio, frame_idx, height: int, width: int, out: Optional[torch.Tensor] = None, _events=None):
+    def packed_weights_split(self) -> torch.Tensor:
+        """bf16 (hi | lo) A-operand slabs of the MLP for render_clip(precision="split") (csrc/render16.hip), rebuilt with the
+        fp32 blob."""
+        lib = _abi.load()
+        packed = self.packed_weights()
+        if getattr(self, "_packed_split", None) is None or self._packed_split_of is not packed:
+            blob = torch.empty(int(lib.s2l_render16_packed_halves()), dtype=torch.int16, device=packed.device)
+            with torch.cuda.device(packed.device):
+                _abi.check(lib.s2l_pack_render16(_ptr(packed), _ptr(blob), _stream()), "s2l_pack_render16")
+            self._packed_split, self._packed_split_of = blob, packed
+        return self._packed_split
+
+    def render_clip(self, audio, frame_idx, height: int, width: int, out: Optional[torch.Tensor] = None, _events=None,
+                    precision: str = "fp32"):
         """audio [F,16,29] + frame indices [F] -> lip frames [F,H,W,3].
+        precision: "fp32" (default) the exact fp32-MFMA kernel -- the parity mode and the headline; "split" the opt-in speed
+        mode: every operand of the 256x256 layers as hi + lo bf16 parts, three bf16 MFMAs per product, fp32 accumulation
+        (~1e-6 of the output scale from the exact frames, far inside the north-star's RMSE <= 1e-4).
 
         Same function of its inputs as running the reference's per-frame loop
         (inference.py:140-159) F times, without its redundancy: the encoder runs once per frame
@@ -466,6 +482,9 @@ class TalkingFace(nn.Module):
         idx = torch.as_tensor(frame_idx, device=dev).to(torch.int64).reshape(-1).contiguous()
         if idx.numel() != F:
             raise ValueError("frame_idx must have one entry per audio window")
+        if precision not in ("fp32", "split"):
+            raise ValueError("precision must be 'fp32' or 'split'")
+        split = self.packed_weights_split() if precision == "split" else None
         hw = int(height) * int(width)
         p0, p5 = self.pixel_tables(height, width)
         if out is None:
@@ -484,8 +503,12 @@ class TalkingFace(nn.Module):
             if _events is not None:   # bench: HIP events on the launch stream around the dominant kernel
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            _abi.check(lib.s2l_render_lip(_ptr(packed), _ptr(p0), _ptr(p5), _ptr(q0), _ptr(q5), _ptr(out), hw, F, st),
-                       "s2l_render_lip")
+            if precision == "split":
+                _abi.check(lib.s2l_render_lip_split(_ptr(packed), _ptr(split), _ptr(p0), _ptr(p5), _ptr(q0), _ptr(q5), _ptr(out), hw, F, st),
+                           "s2l_render_lip_split")
+            else:
+                _abi.check(lib.s2l_render_lip(_ptr(packed), _ptr(p0), _ptr(p5), _ptr(q0), _ptr(q5), _ptr(out), hw, F, st),
+                           "s2l_render_lip")
             if _events is not None:
                 ev1.record()
                 _events.append((ev0, ev1))

@@ -61,6 +61,42 @@ def _median_ms(fn, reps=6, inner=10):
     return float(np.median([a.elapsed_time(b) for a, b in evs])) / inner
 
 
+def bench_render_split(dev, frames=1000, h=96, w=96):
+    """The opt-in split-half speed mode of the renderer (csrc/render16.hip) on BASELINE config 2's workload, next to the exact
+    fp32 kernel on the same inputs: frames/s of both (HIP events around whole render_clip calls: encoder + frame vectors +
+    render), the ratio, and the accuracy of BOTH against the CPU oracle on sampled frames.  Reported in `extra` only: the
+    headline value and dtype stay the exact kernel's."""
+    from oracle import s2l_oracle as O
+    m = make_model(dev, h, w)
+    win = torch.from_numpy(W.synthetic_audio(frames, seed=1).astype(np.float32)).to(dev)
+    idx = torch.arange(frames, device=dev)
+    out = torch.empty(frames, h, w, 3, device=dev)
+    res = {"workload": f"{h}x{w} lip crop, {frames} frames per launch (BASELINE config 2's)", "kernel": "s2l::render16_tiles_kernel (s2l_render_lip_split)",
+           "arithmetic": "operands as hi + lo IEEE halves, W_lo a_hi + W_hi a_lo + W_hi a_hi on v_mfma_f32_16x16x32_f16, fp32 accumulation"}
+    ms = {}
+    for prec in ("fp32", "split"):
+        m.render_clip(win, idx, h, w, out=out, precision=prec)
+        torch.cuda.synchronize()
+        ms[prec] = _median_ms(lambda: m.render_clip(win, idx, h, w, out=out, precision=prec), reps=5, inner=4)
+    sd = O.to_sd(W.make_state_dict(0, "he"))
+    ks = [0, frames // 2, frames - 1]
+    with torch.no_grad():
+        ref = torch.stack([O.render_clip(sd, win[k:k + 1].cpu(), [k], h, w)[0] for k in ks])
+    acc = {}
+    for prec in ("fp32", "split"):
+        got = m.render_clip(win, idx, h, w, precision=prec)[ks].cpu()
+        acc[prec] = {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1),
+                     "max_abs_err": float(f"{float((got - ref).abs().max()):.3e}")}
+    flop = lip_flops_per_frame(h * w) * frames
+    res.update(ms_per_clip=round(ms["split"], 3), frames_per_s=round(frames / ms["split"] * 1e3, 1),
+               exact_kernel_ms_per_clip=round(ms["fp32"], 3), exact_kernel_frames_per_s=round(frames / ms["fp32"] * 1e3, 1),
+               speedup_vs_exact=round(ms["fp32"] / ms["split"], 3),
+               algorithmic_tflops=round(flop / (ms["split"] * 1e-3) / 1e12, 1),
+               frac_of_f16_mfma_peak_at_3_mfma_per_product=round(3 * flop / (ms["split"] * 1e-3) / BF16_MFMA_PEAK, 4),
+               parity=acc["split"], exact_kernel_parity=acc["fp32"], frames_checked=ks)
+    return res
+
+
 def bench_small_clips(dev):
     """The reference's own operating point: ONE frame per call (inference.py:129 DataLoader batch 1, :140-159), and BASELINE
     config 1's 16-frame clip.  Per size: `render_clip` at F = 1 and F = 16 (per-call latency through the host wrapper as a caller

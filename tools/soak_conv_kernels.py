@@ -4,7 +4,7 @@ arithmetic, and with a second run of itself.
 
   conv    conv3x3_split_kernel (persistent, bf16 operands): split-bf16 forward and the plain-bf16 training chain,
           persistent form vs the one-tile-per-workgroup kernels (the soak that found round 3's ~1 %-of-shapes copy race);
-  render  render_tiles_kernel<long | wide | single>: random (H, W, F), the three tile shapes against each other and the
+  render  render_tiles_kernel / render16_tiles_kernel<long | wide | single>: random (H, W, F), the three tile shapes against each other and the
           auto-picked one, each twice (every sample column sees the same MFMA sequence in every shape);
   bf16    fwd_asm_bf16_kernel / bwd_asm_bf16_kernel: random (h, w, B) rows, assembly vs the C++ kernels (activation images,
           ReLU mask words, rgb, dz images), each twice.
@@ -74,13 +74,14 @@ def soak_render(dev, rounds, seed=0, log=print):
                 m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
             audio = torch.from_numpy(W.synthetic_audio(F, seed=int(rng.integers(1 << 20))).astype(np.float32)).to(dev)
             idx = torch.from_numpy(rng.integers(0, 40000, F)).to(dev)
-            outs = []
-            for shape in (0, 1, 2, 3, 0, 1, 2, 3):          # 0 = auto; 1 + shape forces long / wide / single
-                _abi.check(lib.s2l_set_render_shape(shape), "s2l_set_render_shape")
-                outs.append(m.render_clip(audio, idx, H, Wd).clone())
-            if not all(torch.equal(outs[0], o) for o in outs[1:]):
-                bad.append(("render", H, Wd, F))
-                log("MISMATCH render", H, Wd, F, [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+            for precision in ("fp32", "split"):             # the exact kernel and the split-half speed mode (render16.hip)
+                outs = []
+                for shape in (0, 1, 2, 3, 0, 1, 2, 3):      # 0 = auto; 1 + shape forces long / wide / single
+                    _abi.check(lib.s2l_set_render_shape(shape), "s2l_set_render_shape")
+                    outs.append(m.render_clip(audio, idx, H, Wd, precision=precision).clone())
+                if not all(torch.equal(outs[0], o) for o in outs[1:]):
+                    bad.append(("render", precision, H, Wd, F))
+                    log("MISMATCH render", precision, H, Wd, F, [bool(torch.equal(outs[0], o)) for o in outs[1:]])
             m._tables = {}       # the pixel tables of this crop size are not needed again
     finally:
         lib.s2l_set_render_shape(0)
