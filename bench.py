@@ -174,6 +174,8 @@ def extra_measurements(dev):
                      ("config3", lambda: benchlib.bench_config3(dev, 5000, 500)),
                      ("config3_with_unet", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True)),
                      ("config3_with_unet_split_bf16", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True, unet_precision="split")),
+                     ("config3_all_split", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True, unet_precision="split", lip_precision="split")),
+                     ("config3_lip_split", lambda: benchlib.bench_config3(dev, 5000, 500, lip_precision="split")),
                      ("unet_fp32", lambda: benchlib.bench_unet(dev, 16)),
                      ("train_bf16", lambda: benchlib.bench_train(dev, 64, "bf16")),
                      ("train_bf16_with_sync_loss", lambda: benchlib.bench_train_sync(dev, 64, 8, "bf16")),

@@ -337,17 +337,21 @@ def collate_batch(items):
     return out
 
 
-def render_clip_frames(model, clip: ClipTensors, use_post_fusion: bool = True):
+def render_clip_frames(model, clip: ClipTensors, use_post_fusion: bool = True, precision: str = "fp32"):
     """The body of `inference.py:140-172` for a whole clip: lip frames [F,h,w,3] and, when the clip has
-    pose grids and observed frames, (rgb_face_recon, rgb_merged_new) [F,FH,FW,3]."""
-    lip = model.render_clip(clip.audio, clip.index, clip.height, clip.width)
+    pose grids and observed frames, (rgb_face_recon, rgb_merged_new) [F,FH,FW,3].
+    precision: "fp32" (default) the exact kernels; "split" the opt-in speed modes of the lip renderer (hi + lo halves) and of
+    the U-Net's convolutions (hi + lo bf16): fp32-grade output (>= 99 dB against the exact path) at a multiple of its rate."""
+    if precision not in ("fp32", "split"):
+        raise ValueError("precision must be 'fp32' or 'split'")
+    lip = model.render_clip(clip.audio, clip.index, clip.height, clip.width, precision=precision)
     if not (use_post_fusion and clip.coord is not None and clip.rgb_face_ori is not None):
         return lip, None, None
     new, _ = model.composite_clip(lip, clip.rgb_face_zero, clip.rgb_face_ori, clip.mask_lip_canonical, clip.lip_lefttop_x,
                                   clip.lip_lefttop_y, clip.coord)
     recon = None
     if getattr(model, "post_fusion_unet", None) is not None and not model.training:
-        recon = model.post_fusion_unet.forward_nhwc(new)
+        recon = model.post_fusion_unet.forward_nhwc(new, precision=precision)
     return lip, recon, new
 
 

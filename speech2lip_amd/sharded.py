@@ -124,7 +124,7 @@ def gather_clip(local: torch.Tensor, n_frames: int, group=None) -> torch.Tensor:
 
 def render_clip_sharded(model, audio, frame_idx, height: int, width: int, group=None, gather: str = "f32", n_chunks: int = 1,
                         quantum: int = 1, render_fn: Callable = None, device=None, force_collective: bool = False,
-                        return_local: bool = False):
+                        return_local: bool = False, precision: str = "fp32"):
     """The multi-GPU product entry for BASELINE config 4: every rank calls this with the WHOLE clip's inputs
     (audio [N,16,29] -- 1.9 KB per frame -- and the N frame indices, host or device tensors) and gets the whole rendered clip
     [N,H,W,3] back in global frame order; each rank renders only its own contiguous block of ceil(N / G) frames
@@ -139,6 +139,7 @@ def render_clip_sharded(model, audio, frame_idx, height: int, width: int, group=
     n_chunks > 1 cuts every rank's block into chunks whose gathers run (async, on the process group's stream) while the next
             chunk renders; the clip is then assembled chunk by chunk (each chunk lands as G contiguous pieces), still in global
             frame order because chunk c of rank r covers frames [r * per + off_c, r * per + off_c + cnt_c).
+    precision: "fp32" (default, the exact kernel) or "split" (the opt-in speed mode of TalkingFace.render_clip).
     render_fn(audio_block, idx_block, out_block) replaces `model.render_clip` (tests run a CPU stand-in over gloo).
     Without a process group (or world 1) it is a plain `render_clip` of the whole clip.
     Returns the clip (and this rank's (first, count) with return_local=True)."""
@@ -157,7 +158,7 @@ def render_clip_sharded(model, audio, frame_idx, height: int, width: int, group=
         raise ValueError("frame_idx must have one entry per audio window")
     if render_fn is None:
         def render_fn(a, i, out):
-            model.render_clip(a.to(device), i.to(device), H, W, out=out)
+            model.render_clip(a.to(device), i.to(device), H, W, out=out, precision=precision)
     if gather == "u8":
         from .data import to8b as quantize
     else:

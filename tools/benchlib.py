@@ -182,7 +182,7 @@ def bench_composite(dev, frames=256, check=True):
     return res
 
 
-def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision="fp32"):
+def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision="fp32", lip_precision="fp32"):
     """BASELINE config 3 end to end: 128x128 lip render for n frames + composite into 500x500 (+ optionally the U-Net;
     unet_precision "fp32" = the exact parity kernels, "split" = split-bf16 operands, SimpleUnetLight.forward_nhwc)."""
     h = w = 128
@@ -202,7 +202,7 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision
     def run():
         for s in range(0, n, batch):
             k = min(batch, n - s)
-            m.render_clip(audio[s:s + k], torch.arange(s, s + k, device=dev), h, w, out=lip[:k])
+            m.render_clip(audio[s:s + k], torch.arange(s, s + k, device=dev), h, w, out=lip[:k], precision=lip_precision)
             m.composite_clip(lip[:k], face, gt[:k], mask, x0, y0, coord[:k], out=out[:k])
             if unet:
                 m.post_fusion_unet.forward_nhwc(out[:k], out=recon[:k], precision=unet_precision)
@@ -215,6 +215,7 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision
     fl = lip_flops_per_frame(h * w)
     res = {"config": f"config 3: {n} frames, 128x128 lip + composite into 500x500"
            + (f" + post-fusion U-Net ({'exact fp32 MFMA' if unet_precision == 'fp32' else 'split-bf16 operands hi+lo, fp32 accumulation' if unet_precision == 'split' else unet_precision})" if unet else "")
+           + (", lip renderer in its split-half speed mode" if lip_precision == "split" else "")
            + f", batches of {batch}", "seconds": round(dt, 3), "frames_per_s": round(n / dt, 1),
            "lip_gflop_per_frame": round(fl / 1e9, 3), "lip_tflops": round(fl * n / dt / 1e12, 1)}
     if check:

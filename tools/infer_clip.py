@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--out")
     ap.add_argument("--gather", action="store_true", help="multi-GPU: all-gather the 8-bit clip, rank 0 writes every file")
+    ap.add_argument("--fast", action="store_true", help="the opt-in split speed modes of the lip renderer and the U-Net (fp32-grade output)")
     ap.add_argument("--lip-only", action="store_true", help="render only the lip crops (sharded.render_clip_sharded)")
     args = ap.parse_args()
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -64,7 +65,8 @@ def main():
         blocks = []
         for first in range(first0, first0 + count, args.batch):
             clip = ds.load(dev, first, min(args.batch, first0 + count - first))
-            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=bool(cfg["model"].get("use_post_fusion", True)))
+            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=bool(cfg["model"].get("use_post_fusion", True)),
+                                                            precision="split" if args.fast else "fp32")
             frames = recon if recon is not None else (merged if merged is not None else lip)
             if args.gather and world > 1:
                 blocks.append(s2l.to8b(frames))

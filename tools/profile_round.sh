@@ -30,6 +30,14 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/upmc_mfma -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_mfma.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/upmc_fetch -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/upmc_write -o s -- python $R/tools/bench_unet.py 16 > $O/upmc_write.log 2>&1
+# the split-half speed mode of the renderer (render16_tiles_kernel): kernel stats, matrix-pipe busy, HBM bytes per launch
+S="python $R/tools/bench_render_split.py 1000"
+timeout 300 $S > $O/render_split_line.json 2> $O/render_split.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sstats -o s -- $S > $O/sstats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/spmc_mfma -o s -- $S > $O/spmc_mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/spmc_fetch -o s -- $S > $O/spmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/spmc_write -o s -- $S > $O/spmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $O/spmc_sq -o s -- $S > $O/spmc_sq.log 2>&1
 ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \

@@ -43,6 +43,24 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
                "hbm_bytes_per_dispatch": round(traffic), "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024"},
               open("profiles/render_traffic.json", "w"), indent=1)
+p = f"{src}/render_split_line.json"
+if os.path.exists(p):
+    out.append(f"\n## split-half speed mode of the renderer (opt-in; csrc/render16.hip): python tools/bench_render_split.py 1000\n{open(p).read().strip()}\n")
+    for r in stats("sstats"):
+        if "render" in r["Name"]:
+            out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
+    sv = {}
+    for d in ("spmc_mfma", "spmc_fetch", "spmc_write", "spmc_sq"):
+        sv.update(pmc(d, "render16_tiles_kernel"))
+    out.append("render16_tiles_kernel PMC, per dispatch (1000 frames 96x96):\n")
+    for k, v in sv.items():
+        out.append("%-34s %.6g\n" % (k, v))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sv and "GRBM_GUI_ACTIVE" in sv:
+        out.append("MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.4f of the kernel's cycles\n"
+                   % (sv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (sv["GRBM_GUI_ACTIVE"] / 8)))
+    if "FETCH_SIZE" in sv and "WRITE_SIZE" in sv:
+        out.append("HBM traffic per dispatch = 2*FETCH_SIZE + WRITE_SIZE = %.4g bytes (algorithmic: 1000 x 112,448 = 1.124e8)\n"
+                   % (sv["FETCH_SIZE"] * 1024 * 2 + sv["WRITE_SIZE"] * 1024))
 out.append("\n## composite: rocprofv3 --kernel-trace --stats -- python tools/bench_composite.py 256\n")
 for r in stats("cstats"):
     out.append("%-92s calls %4s avg_ns %16s pct %7s\n" % (r["Name"][:92], r["Calls"], r["AverageNs"], r["Percentage"]))
