@@ -2,7 +2,7 @@
 from .config import get_model, get_trainer, load_config, may_config, method_dict
 from .data import ClipTensors, SomeonesLipClip, render_clip_frames, to8b, write_frames
 from .rendering import get_coords
-from .talking_face import Embedder, PositionalEncodingTime, TalkingFace
+from .talking_face import Embedder, FrameGraph, PositionalEncodingTime, TalkingFace
 from . import training
 from .training import LipTrainStep, StageOneStep, SyncChain, Trainer, predict_lip_image
 from . import autograd
@@ -11,6 +11,6 @@ from .syncnet import SyncLoss, SyncNet_color
 from .lpips import LPIPS
 from . import geometry
 
-__all__ = ["TalkingFace", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "get_model", "get_trainer", "method_dict", "Trainer",
+__all__ = ["TalkingFace", "FrameGraph", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "get_model", "get_trainer", "method_dict", "Trainer",
            "predict_lip_image", "LipTrainStep", "StageOneStep", "SyncChain", "training", "autograd",
            "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "SyncNet_color", "SyncLoss", "LPIPS", "geometry"]

@@ -26,6 +26,13 @@ wave converts its 192 accumulators: per pair of values  2 v_accvgpr_read, 2 v_ma
 2 v_cvt_f32_f16 (hi back to fp32), 2 v_sub (exact), v_cvt_pkrtz_f16_f32 (lo) -- 960 VALU instructions per layer and wave next
 to 1152 MFMAs of 16 cycles.  Measured (MI355X, 96x96 x 1000 frames): 16.1 ms = 62 k frames/s, 3.5 x the exact kernel.
 
+Can the conversions hide behind the MFMAs?  Measured with `S2L_RENDER16_FILLER=n` (n dummy VALU instructions behind every MFMA;
+16.2 ms without): n = 1: 17.8 ms, 2: 18.9, 3: 20.5 -- a filler costs ~2.2 cycles there against ~4.5 in the block between two
+layers, i.e. hiding halves its price, it does not remove it; with the B registers live until a layer's last slab the only
+hideable form (pack the accumulators in place in AGPRs behind the following slabs, move 192 registers at the layer's end) adds
+384 moves per layer and comes out ~15 % of the conversion time ahead: not built.  PMC (profiles/r04a): matrix pipe busy 0.70,
+2.16 GHz under this load; the MFMAs issue back to back at 16 cycles inside the slabs.
+
 Register map (per wave):  v0-191 B operands: group g, k-step s: hi v[64 g + 8 s .. + 3], lo v[64 g + 8 s + 4 .. + 7]
                           (the same 192 registers hold fp32 values, one feature each, while a table step is being added)
                           v192-207 temporaries | v208-223 addresses | v224-240 ring addresses of a layer
@@ -45,6 +52,8 @@ V_LAST = R.V_LAST
 KSTEPS = 8                # k-steps of 32 per slab (K = 256)
 HALF = os.environ.get("S2L_RENDER16_HALF", "f16")       # "f16" (default) or "bf16" (A/B builds: compile render16.hip with -DS2L_RENDER16_BF16)
 MFMA = f"v_mfma_f32_16x16x32_{HALF}"
+FILLER = int(os.environ.get("S2L_RENDER16_FILLER", "0"))
+FILLER_KIND = os.environ.get("S2L_RENDER16_FILLER_KIND", "max")
 
 
 class Body16(R.Body):
@@ -80,6 +89,9 @@ class Body16(R.Body):
                 b = breg(g, ks)
                 c = first_c if (first_c and ks == 0 and part == 0) else dst(g)
                 self.e(f"{MFMA} {dst(g)}, {w}, v[{b}:{b + 3}], {c}")
+                for _ in range(FILLER):      # experiment: dummy VALU instructions behind every MFMA (what does a filler cost?)
+                    self.e(f"v_cvt_pkrtz_f16_f32 v{V_W + 15}, v{V_W + 14}, v{V_W + 13}" if FILLER_KIND == "cvt" else
+                           f"v_accvgpr_read_b32 v{V_W + 15}, a{A_BIAS}" if FILLER_KIND == "acc" else f"v_max_f32 v{V_W + 15}, 0, v{V_W + 14}")
                 for t in sprinkle.pop(n, []):
                     if isinstance(t, tuple):
                         self.lds_op(t[1], t[2])

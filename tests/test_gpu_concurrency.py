@@ -174,3 +174,24 @@ def test_soak_slice_of_the_counted_wait_assembly_kernels(dev):
     bad += soak.soak_conv(dev, 15, seed=4, log=lambda *a: notes.append(a))
     torch.cuda.synchronize()
     assert not bad, notes
+
+
+def test_frame_graph_is_the_eager_pipeline(scene, dev):
+    """speech2lip_amd.FrameGraph: render + composite + U-Net of ONE frame captured once, replayed per frame with new inputs ==
+    the eager calls, bit for bit (the reference's per-frame mode, inference.py:128-172, without per-frame launch overhead)."""
+    m, sets, const = scene
+    s0, s1 = sets
+    fg = s2l.FrameGraph(m, 1, const["h"], const["w"], face=(const["face"], const["mask"], const["x0"], const["y0"], 500, 500), unet=True)
+    for s in (s0, s1, s0):
+        for k in (0, 3):
+            one = {key: s[key][k:k + 1] for key in ("audio", "idx", "gt", "coord")}
+            want = chain(m, one, const)
+            lip, new, rec = fg(one["audio"], one["idx"], rgb_gt=one["gt"], coord=one["coord"])
+            torch.cuda.synchronize()
+            assert torch.equal(lip, want[0]) and torch.equal(new, want[1]) and torch.equal(rec, want[2])
+    lips = s2l.FrameGraph(m, 4, const["h"], const["w"], precision="split")
+    got = lips(s0["audio"][:4], s0["idx"][:4])
+    torch.cuda.synchronize()
+    assert torch.equal(got, m.render_clip(s0["audio"][:4], s0["idx"][:4], const["h"], const["w"], precision="split"))
+    with pytest.raises(ValueError):
+        s2l.FrameGraph(m, 1, const["h"], const["w"], unet=True)

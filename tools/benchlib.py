@@ -131,6 +131,26 @@ def bench_small_clips(dev):
             entry[f"render_clip_F{F}"] = {"stream_us_per_call": round(ms_stream * 1e3, 1), "frames_per_s": round(F / ms_stream * 1e3, 1),
                                           "sync_latency_us_per_call": round(float(np.median(lat)) * 1e6, 1),
                                           "per_frame_cost_over_long_clip": round(ms_stream / F / (ms_long / long_f), 2)}
+        # ONE frame per call through a captured HIP graph (speech2lip_amd.FrameGraph): input copies + one replay, as a synchronous
+        # per-frame caller (the reference's batch_size-1 loop) would see it
+        fg = s2l.FrameGraph(m, 1, h, w)
+        a1, i1 = audio[:1].contiguous(), idx[:1].contiguous()
+        gcall = lambda: fg(a1, i1)
+        for _ in range(5):
+            gcall()
+        torch.cuda.synchronize()
+        ms_g = _median_ms(gcall, reps=7, inner=20)
+        lat = []
+        for _ in range(30):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gcall()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        assert torch.equal(fg(a1, i1), out_long[:1])
+        entry["frame_graph_F1"] = {"stream_us_per_call": round(ms_g * 1e3, 1), "frames_per_s": round(1e3 / ms_g, 1),
+                                   "sync_latency_us_per_call": round(float(np.median(lat)) * 1e6, 1)}
+        del fg
         # the drop-in per-frame sequence, as inference.py drives the module
         from speech2lip_amd import get_coords
         coords = get_coords(w, h, dev)
