@@ -140,7 +140,7 @@ def spawn_ranks(args) -> int:
     import socket
     import subprocess
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and not args.debug_one_device:
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-3 / config-5 `extra` measurements (N = 1)")
     ap.add_argument("--force-chunks", action="store_true", help="debug: chunked launches at N=1 (measures chunking overhead)")
+    ap.add_argument("--debug-one-device", action="store_true",
+                    help="debug / tests: every rank uses cuda:0 and the process group runs on gloo (host-staged collectives): the whole "
+                         "N > 1 control flow -- schedule selection, gathers, barriers, remote-block and ragged-clip checks -- on a "
+                         "ONE-GPU box.  Timings of such a run mean nothing and the line says so")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the RCCL path (process group, all-gather, barriers) even with one rank")
     args = ap.parse_args()
@@ -229,13 +233,18 @@ def main():
     if world != args.gpus:      # the line's n_gpus must be what --gpus asked for
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.debug_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.debug_one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         # RCCL sets up its rings lazily on the first collective of each kind: do that here, outside any step, so that a
         # run with --warmup 0 does not time communicator setup
         t = torch.zeros(1, device=dev)
@@ -385,6 +394,7 @@ def main():
             "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"INVALID_debug_one_device": "all ranks shared cuda:0 over gloo: control-flow test, not a measurement"} if args.debug_one_device else {}),
             "config": {"workload": f"May face_simple 96x96 lip crop, 8-layer x256 v2 MLP, {F} synthetic audio frames per GPU per step"
                        + (" (BASELINE config 2)" if world == 1 and F == 1000 else "")
                        + (f" (BASELINE config 4 workload: {F * world} frames over {world} GPUs)" if world > 1 else ""),

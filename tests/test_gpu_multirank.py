@@ -172,3 +172,23 @@ def test_bench_n_ranks_bit_check(gather):
     assert mg["gather_bytes_per_rank"] == 480 * H * W_ * 3 * (4 if gather == "f32" else 1)
     # whole-job frames: every rank's 480 frames per step
     assert abs(line["value"] - 480 * n * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) <= 0.01 * line["value"]
+
+
+@pytest.mark.parametrize("n,extra", [(2, ()), (3, ("--gather", "u8")), (2, ("--chunks", "3", "--reserve-cus", "8"))], ids=["2-auto", "3-u8-auto", "2-flags"])
+def test_bench_multi_rank_control_flow_on_one_gpu(n, extra):
+    """The WHOLE N > 1 path of bench.py with N real ranks -- schedule selection timed during warm-up (max over ranks), per-chunk
+    gathers, barriers, rank 0's re-render of the last rank's block, the ragged clip through sharded.render_clip_sharded (N % G != 0)
+    -- on the one GPU this box has: `--debug-one-device` puts every rank on cuda:0 and the process group on gloo.  The first
+    multi-GPU node then only adds RCCL itself, which the one-rank legs above already exercise."""
+    line = _run_bench("--gpus", str(n), "--frames", "96", *COMMON, "--debug-one-device", *extra, timeout=1800)
+    assert line["n_gpus"] == n and "INVALID_debug_one_device" in line
+    mg = line["multi_gpu"]
+    assert mg["remote_block_bit_identical_to_local_render"] is True
+    assert mg["ragged_clip"] == {"frames": 48 * n - 5, "bit_identical_to_one_gpu_render": True}
+    if "--chunks" in extra:
+        assert mg["schedule_selection"] == "flags" and mg["schedule"] == "3-chunk+8cu-reserved"
+    else:
+        assert mg["schedule_selection"].startswith("auto") and set(mg["schedules_ms_per_step"]) == {"1-chunk", "4-chunk+8cu-reserved"}
+        assert mg["schedule"] == min(mg["schedules_ms_per_step"], key=mg["schedules_ms_per_step"].get)
+    assert mg["gather_bytes_per_rank"] == 96 * H * W_ * 3 * (1 if "u8" in extra else 4)
+    assert line["config"]["frames_per_gpu"] == 96 and line["parity"]["psnr_db_vs_cpu"] >= 90.0
