@@ -19,6 +19,7 @@
 // workgroups per CU overlap one another's staging.  The concat is virtual (two input pointers), the
 // final 1x1 convolution is fused into the last conv's epilogue.
 #include "s2l_common.h"
+#include "conv16.h"
 
 namespace s2l {
 
@@ -1369,8 +1370,8 @@ __global__ __launch_bounds__(256) void conv3x3_asm_kernel(ConvArgs a) {
 // per-frame byte offsets that fit 31 bits, and (bias + ReLU [+ pooling | + fused output]) or (no bias, no ReLU [+ gate]).
 static std::atomic<int> g_conv_kernel_kind{0};
 static std::atomic<int> g_split_kernel_kind{0};      // 0: conv3x3_split_kernel (persistent), 1: conv3x3_bf16_kernel<.., true, 8> (one tile per workgroup)
-extern "C" int s2l_set_unet_split_kernel(int kind) {
-  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+extern "C" int s2l_set_unet_split_kernel(int kind) {      // 2: conv16_asm_kernel (csrc/conv16.hip) where it applies, else kind 0
+  if (kind != 0 && kind != 1 && kind != 2) return S2L_E_SIZE;
   g_split_kernel_kind.store(kind, std::memory_order_relaxed);
   return S2L_OK;
 }
@@ -1408,7 +1409,7 @@ static int launch_conv_persistent(ConvArgs& a, int64_t F, bool fuse_out, bool sp
   *launched = false;
   const int64_t total = (int64_t)a.tiles_x * ((a.H + 31) / 32) * a.n_ct * F;
   const int nchunks = (a.CA + a.CB) / (split ? 16 : 32);
-  if (g_split_kernel_kind.load(std::memory_order_relaxed) != 0 || (a.CA + a.CB) % (split ? 16 : 32) != 0 || nchunks % 2 != 0 ||
+  if (g_split_kernel_kind.load(std::memory_order_relaxed) == 1 || (a.CA + a.CB) % (split ? 16 : 32) != 0 || nchunks % 2 != 0 ||
       (a.CB != 0 && a.CA % 16 != 0) || a.n_ct > 4 || (a.pool && fuse_out) || total >= 0x7fffffff || total == 0)
     return S2L_OK;
   int dev = 0, n_cu = 0;
@@ -1450,6 +1451,15 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
+  if (a.w16 && split && !out3 && g_split_kernel_kind.load(std::memory_order_relaxed) == 2) {
+    // the generated-assembly split convolution (bias + ReLU; a pooled copy comes from maxpool2_kernel: max of the same fp32 values)
+    Conv16Args c;
+    c.inA = a.inA; c.inB = a.inB; c.w16 = a.w16; c.bias = a.bias; c.out = a.out; c.CA = a.CA; c.CB = a.CB; c.cout = a.cout;
+    c.H = H; c.W = W; c.tiles_x = a.tiles_x; c.tiles_y = a.tiles_y; c.n_ct = a.n_ct; c.relu = 1; c.n_frames = (int)F; c.pool = pool;
+    bool launched = false;
+    const int rc = launch_conv16_asm(c, st, &launched);
+    if (rc || launched) return rc;
+  }
   if (a.w16 && (split || g_split_kernel_kind.load(std::memory_order_relaxed) == 0)) {
     bool launched = false;
     const int rc = launch_conv_persistent(a, F, out3 != nullptr, split != 0, st, &launched);
