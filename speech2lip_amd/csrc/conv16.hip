@@ -15,7 +15,7 @@ static_assert(offsetof(Conv16Args, inA) == 0 && offsetof(Conv16Args, inB) == 8 &
               "gen_conv16_body.py (ARG) loads these fields from the kernarg segment by offset");
 
 constexpr int kC16Halo = 18 * 18 * 64, kC16W = 9 * 2 * 2 * 64 * 16, kC16Buf = kC16Halo + kC16W;
-constexpr int kC16Lds = 2 * kC16Buf + 1024;
+constexpr int kC16Lds = 2 * kC16Buf + 1024 + 4 * 4096;      // two buffers, the bias table, the store staging (gen_conv16_body.py)
 static_assert(kC16Lds <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
@@ -59,6 +59,19 @@ __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
         const int col = (n & 15) + dx, row = 4 * wave + (n >> 4);
         cst[(12 + dx * 2 + pt) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * pt + hh) ^ ((col >> 2) & 3)) << 4));
       }
+  }
+  // store staging (this wave's 4 KiB: [32 pixels][32 channels] fp32, 16-byte quad index ^ ((pixel >> 1) & 7)): write address of the
+  // lane's register quad rq (pixel n = lane & 31, channels 8 rq + 4 hh ..), read address of store j (pixel 8 j + (lane >> 3), quad lane & 7)
+  {
+    const uint32_t stg = lds0 + 2 * kC16Buf + 1024 + wave * 4096;
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) cst[(18 + rq) * 256 + tid] = stg + (uint32_t)(n * 128 + (((2 * rq + hh) ^ ((n >> 1) & 7)) << 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = 8 * j + (lane >> 3);
+      cst[(22 + j) * 256 + tid] = stg + (uint32_t)(px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4));
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the constants are in LDS (each lane reads back only its own words)
 #include "conv16_body.inc"

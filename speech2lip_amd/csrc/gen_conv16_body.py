@@ -3,57 +3,64 @@ inference speed mode as ONE fixed-register gfx950 assembly text (the renderer's 
 SIMD, the chunk loop owned instruction by instruction).
 
 Arithmetic = conv3x3_split_kernel's (csrc/unet.hip), operation for operation and in its order, so the outputs are THE SAME BITS
-(tests/test_gpu_unet_kernels.py): fp32 activations split on the way into LDS as hi = bf16(x), lo = bf16(x - hi); the
-BatchNorm-folded weights pre-split by s2l_unet_pack16x3 ([cout/64][cin/16][tap 9][part 2][block 2][lane 64][8]); per 16-channel
-chunk and tap three products on v_mfma_f32_32x32x16_bf16, smallest first: W_lo x_hi, W_hi x_lo, W_hi x_hi; accumulators start at
-the bias; ReLU; fp32 NHWC out.
+(tests/test_gpu_unet_kernels.py, tools/cmp_conv16.py): fp32 activations split on the way into LDS as hi = bf16(x),
+lo = bf16(x - hi); the BatchNorm-folded weights pre-split by s2l_unet_pack16x3 ([cout/64][cin/16][tap 9][part 2][block 2]
+[lane 64][8]); per 16-channel chunk and tap three products on v_mfma_f32_32x32x16_bf16, smallest first: W_lo x_hi, W_hi x_lo,
+W_hi x_hi; accumulators start at the bias; ReLU; fp32 NHWC out.
 
-What differs from the C++ kernel is the shape of the work (it was bound by LDS reads: eight waves each reading all of a chunk's
-weights, 0.67 operand reads per MFMA, matrix pipe busy 0.66):
+Shape of the work:
   * tile = 16 x 16 pixels x 64 output channels, FOUR waves (one per SIMD); wave w owns rows 4 w .. 4 w + 3 as two N-blocks of
-    2 rows x 16 pixels, and both 32-channel M-blocks: 4 accumulator blocks of 16 registers; per tap 4 + 4 ds_read_b128 feed 12
-    MFMAs of 32 cycles: 21 B/clk per wave, 85 of the LDS's 128 B/clk per CU;
-  * TWO buffers of (halo 18 x 18 pixels x 64 B [hi 16 ch | lo 16 ch], the 16-byte segment index XORed with (column >> 2) & 3:
+    2 rows x 16 pixels, and both 32-channel M-blocks: 4 accumulator blocks of 16 AGPRs; per tap 4 + 4 ds_read_b128 feed 12 MFMAs
+    of 32 cycles (the C++ kernel: eight waves each reading all of a chunk's weights, 0.67 operand reads per MFMA, LDS-bound);
+  * TWO LDS buffers of (halo 18 x 18 pixels x 64 B [hi 16 ch | lo 16 ch], the 16-byte segment index XORed with (column >> 2) & 3:
     the sixteen pixels of an operand read cover all 64 banks) + (weights 36 KiB, by LDS-DMA: nine 1-KiB pieces per wave);
-  * during chunk c: the weights of c + 1 are requested behind the first MFMAs, the halo values of c + 1 (fp32, six 16-byte loads per
-    lane) too; behind taps 5..8 they are split and written to the other buffer (16 VALU + 2 ds_write per quad, two per MFMA slot:
-    a filler beside a bf16 MFMA costs about half of what it costs alone); ONE barrier per chunk;
-  * the next TILE's first chunk is staged during the current tile's last chunk (the geometry registers are free by then), so only a
-    workgroup's very first chunk is exposed;
-  * a tile's end: ReLU, the accumulators leave through 16 global_store_dwordx4 per lane (32 bytes per pixel and instruction);
-    the next tile's bias comes from a table in LDS.
+  * a workgroup's chunks form ONE stream across its tiles.  During chunk g: the weights of g + 1 arrive by LDS-DMA; the halo values
+    of g + 2 (fp32, six 16-byte loads per lane) are REQUESTED into one of two register sets; the values of g + 1 (requested a whole
+    chunk ago: HBM latency is ~2 k cycles, a chunk 3.5 k) are split and written to the other buffer behind taps 5..8 (16 VALU +
+    2 ds_write per quad; a filler beside a bf16 MFMA costs about half of what it costs alone); ONE barrier per chunk.  v1 of
+    this kernel requested one chunk ahead and issued a tile's stores in a burst: ablation builds priced that at 1.4 ms + 1.1 ms of
+    a 7.6-ms 16-frame forward;
+  * two accumulator sets (AGPRs), alternating per tile: a tile's 16 stores per lane (ReLU on the way: v_accvgpr_read, v_max) are
+    issued behind the MFMAs of the NEXT tile's first chunk, which accumulates into the other set; the bias enters from a table in
+    LDS straight into the AGPRs.
 
-Register map (per wave): v0-63 acc[mb][nb][16] | v64-95, v96-127 two operand sets (A[part][mb], B[part][nb]: 8 x 4) |
-v128-151 staged halo quads of the next chunk | v152.. per-lane constants and temporaries (names below).
-Scalars: s8.. (names below); kernel arguments are loaded from the kernarg segment (struct Conv16Args, csrc/conv16.hip)."""
+Register map (per wave): a0-63 / a64-127 accumulator sets acc[mb][nb][16] | v0-31, v32-63 two operand sets (A[part][mb],
+B[part][nb]: 8 x 4) | v64-87, v88-111 two sets of staged halo quads | v112.. per-lane constants and temporaries (names below).
+Scalars: s16.. (names below); kernel arguments are loaded from the kernarg segment (struct Conv16Args, csrc/conv16.h)."""
 import os
 import sys
 
 HALO_BYTES, W_BYTES = 18 * 18 * 64, 9 * 2 * 2 * 64 * 16        # 20 736 + 36 864
 BUF = HALO_BYTES + W_BYTES                                      # 57 600
 BIAS_OFF = 2 * BUF                                              # 256 floats
-LDS_BYTES = BIAS_OFF + 1024
 NQ = 6                                                          # halo quads per lane: 18 * 18 * 4 = 1296 = 5 * 256 + 16
 EXP = int(os.environ.get("S2L_C16_EXP", "0"))                  # ablation builds (results wrong): 1 no stores, 2 no halo loads, 4 no weight DMA, 8 no commit
 
-# ---- vector registers
-V_ACC = 0
-V_OPS = (64, 96)                # operand set: A[pt][mb] at + (pt * 2 + mb) * 4, B[pt][nb] at + 16 + (pt * 2 + nb) * 4
-V_PIN = 128                     # 6 quads x 4
-# LDS addresses, one set per buffer (DS immediates are 16 bits: buffer 1 starts at 57 600)
-V_WHI = (152, 171)              # 6: write address of the quads' hi halves
-V_WLO = (158, 177)              # 6: ... lo halves (= hi ^ 32)
-V_BOFS = (164, 183)             # 6: B-read addresses [dx][pt]
-V_AOFS = (170, 189)             # A-read address (LDS base + halo + lane * 16 folded into the immediate: base + lane * 16)
-V_HRC = 190                     # 6: halo (row << 8 | col) of the quads
-V_PIX = 196                     # 6: pixel index inside the frame of the quads (0 where invalid)
-V_MSK = 202                     # 6: all ones / zero
-V_VOFF = 208                    # 6: byte offset of the quads from the chunk's source pointer
-V_LANE, V_COL, V_ROW2, V_HH16, V_C4X16, V_DMA, V_TID = 214, 215, 216, 217, 218, 219, 220
-V_T = 222                       # temporaries 222..241 (even: 64-bit tuples must be aligned)
-V_SOFF = 242                    # 2: store byte offsets per N-block
+# ---- registers
+A_ACC = (0, 64)                 # two accumulator sets
+V_OPS = (0, 32)                 # operand set: A[pt][mb] at + (pt * 2 + mb) * 4, B[pt][nb] at + 16 + (pt * 2 + nb) * 4
+V_PIN = (64, 88)                # staged halo quads, 6 x 4 per set
+V_SMSK = (112, 118)             # 6 per set: the validity masks the set's quads were requested under
+V_WHI = (124, 143)              # LDS addresses, one set per buffer (DS immediates are 16 bits: buffer 1 starts at 57 600)
+V_WLO = (130, 149)
+V_BOFS = (136, 155)
+V_AOFS = (142, 161)
+V_HRC = 162                     # 6: halo (row << 8 | col) of the quads
+V_PIX = 168                     # 6: pixel index inside the frame of the quads of the REQUEST stream's tile (0 where invalid)
+V_MSK = 174                     # 6: all ones / zero, same tile
+V_VOFF = 180                    # 6: byte offset of the quads from the chunk's source pointer
+V_LANE, V_COL, V_ROW2, V_HH16, V_C4X16, V_DMA, V_TID, V_BIASA = 186, 187, 188, 189, 190, 191, 192, 193
+V_T = 194                       # temporaries 194..225 (even: 64-bit tuples must be aligned); the store path uses all 32
+V_SOFF = 226                    # 8: store byte offsets [nb][j] of the tile whose stores are pending (-1: no store for this lane)
+V_SWA = 234                     # 4: staging write addresses per register quad rq (this wave's 4 KiB of the store staging area)
+V_SRA = 238                     # 4: staging read addresses per store j
+V_L3, V_L7X16 = 242, 243        # lane >> 3, (lane & 7) * 16
 V_LAST = 243
-CONST_WORDS = 18                # per lane, written to LDS by the C++ prologue: whi[6] (absolute, buffer 0), hrc[6], bofs[6] (absolute, buffer 0)
+A_LAST = 127
+STG_OFF = BIAS_OFF + 1024       # store staging: 4 waves x [32 pixels][32 channels] fp32, the 16-byte quad index XORed with (pixel >> 1) & 7
+LDS_BYTES = STG_OFF + 4 * 4096
+CONST_WORDS = 26                # per lane, from the C++ prologue: whi[6], hrc[6], bofs[6], swa[4], sra[4] (absolute LDS addresses)
+
 
 def _scalars(first, singles, pairs):
     m, r = {}, first
@@ -67,8 +74,11 @@ def _scalars(first, singles, pairs):
     return m
 
 
-S = _scalars(16, singles="CA CB COUT H W TILESX TILESY NCT NTL NCH CHA WAVE LDS0 TX TY CT FR X0 Y0 SX0 SY0 CC RELU T0 T1 T2 T3 CBYTES NTX NTY NCTN NFR LDSW TGT".split(),
-             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "EX", "M5", "TA", "TB"))
+# three streams walk the workgroup's tiles: compute ("" prefix), halo requests two chunks ahead (R), weight DMA one ahead (W)
+S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA WAVE LDS0 RELU CBYTES LDSW T0 T1 T2 T3 "
+                          "TX TY CT FR X0 Y0 CC NTL LEFT RTX RTY RCT RFR RC RLEFT SX0 SY0 WTX WTY WCT WFR WC WLEFT").split(),
+             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "EX", "M5",
+                    "TA", "SM0"))
 S_LAST = max(S.values())
 assert S_LAST <= 100, S_LAST
 
@@ -112,23 +122,30 @@ class Body:
         self.e("s_waitcnt lgkmcnt(0)")
         self.lds = []
 
+    def emit_group(self, g):
+        for it in g:
+            if isinstance(it, tuple) and it[0] == "wait":
+                self.wait_lds(it[1])
+            elif isinstance(it, tuple):
+                self.lds_op(it[0], it[1])
+            else:
+                self.e(it)
+
     # ---- registers
     @staticmethod
-    def acc(mb, nb):
-        b = V_ACC + (mb * 2 + nb) * 16
-        return f"v[{b}:{b + 15}]"
+    def acc(aset, mb, nb):
+        b = A_ACC[aset] + (mb * 2 + nb) * 16
+        return f"a[{b}:{b + 15}]"
 
     @staticmethod
     def opa(os_, pt, mb):
-        b = V_OPS[os_] + (pt * 2 + mb) * 4
-        return b
+        return V_OPS[os_] + (pt * 2 + mb) * 4
 
     @staticmethod
     def opb(os_, pt, nb):
-        b = V_OPS[os_] + 16 + (pt * 2 + nb) * 4
-        return b
+        return V_OPS[os_] + 16 + (pt * 2 + nb) * 4
 
-    # ---- operand reads of tap t from buffer `buf` into operand set os_: list of 8 (text, tag), in the order the MFMAs need them:
+    # ---- operand reads of tap t from buffer `buf` into operand set os_: 8 (text, tag), in the order the MFMAs need them:
     # A lo, B hi (first product), B lo (second), A hi (third)
     def tap_reads(self, t, buf, os_):
         dy, dx = t // 3, t % 3
@@ -147,108 +164,40 @@ class Body:
                     out.append((f"ds_read_b128 v[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + pt} offset:{off}", ("R", t, kind, blk)))
         return out
 
-    def tap_mfmas(self, os_, sprinkle):
-        """12 MFMAs of one tap on operand set os_; sprinkle: list of 12 lists of items tucked behind MFMA m (item: text or (text, tag))"""
+    def tap_mfmas(self, aset, os_, sprinkle):
+        """12 MFMAs of one tap on operand set os_; sprinkle: 12 lists of items tucked behind MFMA m"""
         for m in range(12):
             g, mb, nb = m >> 2, (m >> 1) & 1, m & 1
             pa, pb = (1 if g == 0 else 0), (1 if g == 1 else 0)
             a, b = self.opa(os_, pa, mb), self.opb(os_, pb, nb)
-            self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(mb, nb)}, v[{a}:{a + 3}], v[{b}:{b + 3}], {self.acc(mb, nb)}")
-            for it in sprinkle[m]:
-                if isinstance(it, tuple):
-                    self.lds_op(it[0], it[1])
-                else:
-                    self.e(it)
+            self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(aset, mb, nb)}, v[{a}:{a + 3}], v[{b}:{b + 3}], {self.acc(aset, mb, nb)}")
+            self.emit_group(sprinkle[m])
 
-    # ---- staging of one chunk: requests (global loads + weight DMA) and the split + LDS commit
-    def chunk_source(self):
-        """scalar set-up for the chunk S[TGT] (0 .. NCH-1) of the tile whose frame bases are FRA / FRB and whose channel tile is the
-        one WB was set for: SRC = pointer to channel 0 of the chunk at pixel 0 of the frame, CBYTES = bytes per pixel of that tensor,
-        WCH / WCH1_ / WCH2_ = the chunk's weights (+ 4 KiB, + 8 KiB)."""
+    # ---- streams
+    def next_coords(self, p):
+        """the stream with prefix p moves to its next tile (x fastest, then y, channel tile, frame) -- or stays on its last one"""
         e = self.e
-        e(f"s_cmp_lt_u32 {s('TGT')}, {s('CHA')}")                      # chunk from A?
-        e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
-        e(f"s_cselect_b32 {s('CBYTES')}, {s('CA')}, {s('CB')}")
-        e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
-        e(f"s_sub_u32 {s('T0')}, {s('TGT')}, {s('T0')}")               # chunk index inside its tensor
-        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 6")                        # * 16 channels * 4 bytes
-        e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
-        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
-        e(f"s_lshl_b32 {s('CBYTES')}, {s('CBYTES')}, 2")
-        e(f"s_mul_i32 {s('T0')}, {s('TGT')}, {W_BYTES}")
-        e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
-        e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
-        e(f"s_add_u32 {s('WCH1_')}, {s('WCH')}, 4096")
-        e(f"s_addc_u32 {s('WCH1_1')}, {s('WCH1')}, 0")
-        e(f"s_add_u32 {s('WCH2_')}, {s('WCH')}, 8192")
-        e(f"s_addc_u32 {s('WCH2_1')}, {s('WCH1')}, 0")
-
-    def request_items(self, buf):
-        """the chunk's requests as a list of instruction groups (each group goes behind one MFMA): 6 x (offset, load) and 9 DMA pieces"""
-        items = []
-        for i in range(NQ):
-            g = [f"v_mul_lo_u32 v{V_VOFF + i}, v{V_PIX + i}, {s('CBYTES')}", f"v_add_u32 v{V_VOFF + i}, v{V_VOFF + i}, v{V_C4X16}"]
-            if i == NQ - 1:
-                g += [f"s_mov_b64 exec, {s2('M5')}"]
-            if not EXP & 2:
-                g += [f"global_load_dwordx4 v[{V_PIN + 4 * i}:{V_PIN + 4 * i + 3}], v{V_VOFF + i}, {s2('SRC')}"]
-            if i == NQ - 1:
-                g += ["s_mov_b64 exec, -1"]
-            items.append(g)
-        for grp in range(3):
-            base = ("WCH", "WCH1_", "WCH2_")[grp]
-            for j in range(4 if grp < 2 else 1):
-                g = []
-                if j == 0:
-                    g += [f"s_add_u32 m0, {s('LDSW')}, {buf * BUF + grp * 4096}", "s_nop 0"]
-                if not EXP & 4:
-                    g += [f"global_load_lds_dwordx4 v{V_DMA}, {s2(base)} offset:{1024 * j}"]
-                items.append(g)
-        return items
-
-    def commit_items(self, buf):
-        """split + LDS write of the six staged quads into buffer `buf`: a list of small instruction groups"""
-        items = []
-        for i in range(NQ):
-            p = V_PIN + 4 * i
-            h, l, t = V_T, V_T + 2, V_T + 4
-            if i % 2:
-                h, l, t = V_T + 8, V_T + 10, V_T + 12
-            g1 = [f"v_and_b32 v{p + j}, v{p + j}, v{V_MSK + i}" for j in range(4)]
-            g2 = [f"v_cvt_pk_bf16_f32 v{h}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{h + 1}, v{p + 2}, v{p + 3}",
-                  f"v_lshlrev_b32 v{t}, 16, v{h}", f"v_and_b32 v{t + 1}, 0xffff0000, v{h}"]
-            g3 = [f"v_lshlrev_b32 v{t + 2}, 16, v{h + 1}", f"v_and_b32 v{t + 3}, 0xffff0000, v{h + 1}",
-                  f"v_sub_f32 v{p}, v{p}, v{t}", f"v_sub_f32 v{p + 1}, v{p + 1}, v{t + 1}"]
-            g4 = [f"v_sub_f32 v{p + 2}, v{p + 2}, v{t + 2}", f"v_sub_f32 v{p + 3}, v{p + 3}, v{t + 3}",
-                  f"v_cvt_pk_bf16_f32 v{l}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{l + 1}, v{p + 2}, v{p + 3}"]
-            wr = []
-            if i == NQ - 1:
-                wr += [f"s_mov_b64 exec, {s2('M5')}"]
-            wr += [(f"ds_write_b64 v{V_WHI[buf] + i}, v[{h}:{h + 1}]", ("W", i, 0)),
-                   (f"ds_write_b64 v{V_WLO[buf] + i}, v[{l}:{l + 1}]", ("W", i, 1))]
-            if i == NQ - 1:
-                wr += ["s_mov_b64 exec, -1"]
-            items += [g1, g2, g3, g4, wr] if not EXP & 8 else []
-        return items
-
-    def emit_group(self, g):
-        for it in g:
-            if isinstance(it, tuple):
-                self.lds_op(it[0], it[1])
-            else:
-                self.e(it)
-
-    def stage_now(self, buf):
-        """prologue form: request, wait, commit -- everything exposed (a workgroup's first chunk only)"""
-        self.chunk_source()
-        for g in self.request_items(buf):
-            self.emit_group(g)
-        self.e("s_waitcnt vmcnt(0)")
-        for g in self.commit_items(buf):
-            self.emit_group(g)
+        stay = self.label("stay")
+        e(f"s_cmp_lt_u32 {s(p + 'LEFT')}, 2")
+        e(f"s_cbranch_scc1 {stay}")
+        e(f"s_sub_u32 {s(p + 'LEFT')}, {s(p + 'LEFT')}, 1")
+        e(f"s_add_u32 {s(p + 'TX')}, {s(p + 'TX')}, 1")
+        e(f"s_cmp_eq_u32 {s(p + 'TX')}, {s('TILESX')}")
+        e(f"s_cselect_b32 {s(p + 'TX')}, 0, {s(p + 'TX')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'TY')}, {s(p + 'TY')}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(p + 'TY')}, {s('TILESY')}")
+        e(f"s_cselect_b32 {s(p + 'TY')}, 0, {s(p + 'TY')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'CT')}, {s(p + 'CT')}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(p + 'CT')}, {s('NCT')}")
+        e(f"s_cselect_b32 {s(p + 'CT')}, 0, {s(p + 'CT')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'FR')}, {s(p + 'FR')}, {s('T0')}")
+        e(f"{stay}:")
 
     def geometry(self):
-        """per-lane staging geometry of the tile at (SX0, SY0): pixel index and validity mask of the six quads"""
+        """per-lane geometry of the request stream's tile at (SX0, SY0): pixel index and validity mask of the six quads"""
         e = self.e
         for i in range(NQ):
             r, c, t = V_T, V_T + 1, V_T + 2
@@ -268,11 +217,14 @@ class Body:
             e(f"v_cndmask_b32 v{V_PIX + i}, 0, v{t}, vcc")
             e(f"v_cndmask_b32 v{V_MSK + i}, 0, -1, vcc")
 
-    def frame_bases(self, fr_name):
-        """FRA / FRB = inA / inB + frame * H * W * C * 4 of the tile being STAGED"""
+    def request_tile_setup(self):
+        """FRA / FRB (frame bases of inA / inB) and the geometry registers for the request stream's tile (RTX, RTY, RFR)"""
         e = self.e
+        e(f"s_lshl_b32 {s('SX0')}, {s('RTX')}, 4")
+        e(f"s_lshl_b32 {s('SY0')}, {s('RTY')}, 4")
+        self.geometry()
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
-        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s(fr_name)}")                # pixels before this frame (< 2^31: the launcher checks)
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('RFR')}")               # pixels before this frame (< 2^31: the launcher checks)
         for fr, src, c in (("FRA", "INA", "CA"), ("FRB", "INB", "CB")):
             e(f"s_mul_i32 {s('T1')}, {s(c)}, 4")
             e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
@@ -280,89 +232,209 @@ class Body:
             e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
 
-    def tile_weights(self, ct_name):
-        """WB = w16 + channel tile * NCH * W_BYTES of the tile being STAGED"""
+    def weight_tile_setup(self):
+        """WB = w16 + WCT * NCH * W_BYTES"""
         e = self.e
-        e(f"s_mul_i32 {s('T0')}, {s(ct_name)}, {s('NCH')}")
+        e(f"s_mul_i32 {s('T0')}, {s('WCT')}, {s('NCH')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
         e(f"s_add_u32 {s('WB')}, {s('W16')}, {s('T0')}")
         e(f"s_addc_u32 {s('WB1')}, {s('W161')}, 0")
 
-    def next_tile_coords(self):
-        """(NTX, NTY, NCTN, NFR) = the tile after (TX, TY, CT, FR): x fastest, then y, channel tile, frame"""
+    def request_source(self):
+        """SRC = pointer to channel 0 of chunk RC at pixel 0 of the request tile's frame; CBYTES = bytes per pixel of that tensor"""
         e = self.e
-        e(f"s_add_u32 {s('NTX')}, {s('TX')}, 1")
-        e(f"s_cmp_eq_u32 {s('NTX')}, {s('TILESX')}")
-        e(f"s_cselect_b32 {s('NTX')}, 0, {s('NTX')}")
-        e(f"s_cselect_b32 {s('T0')}, 1, 0")
-        e(f"s_add_u32 {s('NTY')}, {s('TY')}, {s('T0')}")
-        e(f"s_cmp_eq_u32 {s('NTY')}, {s('TILESY')}")
-        e(f"s_cselect_b32 {s('NTY')}, 0, {s('NTY')}")
-        e(f"s_cselect_b32 {s('T0')}, 1, 0")
-        e(f"s_add_u32 {s('NCTN')}, {s('CT')}, {s('T0')}")
-        e(f"s_cmp_eq_u32 {s('NCTN')}, {s('NCT')}")
-        e(f"s_cselect_b32 {s('NCTN')}, 0, {s('NCTN')}")
-        e(f"s_cselect_b32 {s('T0')}, 1, 0")
-        e(f"s_add_u32 {s('NFR')}, {s('FR')}, {s('T0')}")
+        e(f"s_cmp_lt_u32 {s('RC')}, {s('CHA')}")                       # chunk from A?
+        e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
+        e(f"s_cselect_b32 {s('CBYTES')}, {s('CA')}, {s('CB')}")
+        e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
+        e(f"s_sub_u32 {s('T0')}, {s('RC')}, {s('T0')}")                # chunk index inside its tensor
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 6")                        # * 16 channels * 4 bytes
+        e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
+        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
+        e(f"s_lshl_b32 {s('CBYTES')}, {s('CBYTES')}, 2")
 
-    # ---- one chunk: reads buffer `buf`; stage: None, or "next" = request + commit the chunk S[TGT] into the other buffer
-    def chunk(self, buf, stage):
+    def weight_source(self):
+        """WCH / WCH1_ / WCH2_ = chunk WC of the weight stream's channel tile (+ 4 KiB, + 8 KiB)"""
         e = self.e
-        if stage:
-            self.chunk_source()                          # (scalar; for the chunk S[TGT] of the staging tile)
-        req = self.request_items(buf ^ 1) if stage else []
-        com = self.commit_items(buf ^ 1) if stage else []
-        # operands of tap 0 (exposed after the barrier; 8 reads)
-        for text, tag in self.tap_reads(0, buf, 0):
+        e(f"s_mul_i32 {s('T0')}, {s('WC')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
+        e(f"s_add_u32 {s('WCH1_')}, {s('WCH')}, 4096")
+        e(f"s_addc_u32 {s('WCH1_1')}, {s('WCH1')}, 0")
+        e(f"s_add_u32 {s('WCH2_')}, {s('WCH')}, 8192")
+        e(f"s_addc_u32 {s('WCH2_1')}, {s('WCH1')}, 0")
+
+    def advance_request(self):
+        e = self.e
+        same = self.label("rsame")
+        e(f"s_add_u32 {s('RC')}, {s('RC')}, 1")
+        e(f"s_cmp_lt_u32 {s('RC')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {same}")
+        e(f"s_mov_b32 {s('RC')}, 0")
+        self.next_coords("R")
+        self.request_tile_setup()
+        e(f"{same}:")
+
+    def advance_weights(self):
+        e = self.e
+        same = self.label("wsame")
+        e(f"s_add_u32 {s('WC')}, {s('WC')}, 1")
+        e(f"s_cmp_lt_u32 {s('WC')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {same}")
+        e(f"s_mov_b32 {s('WC')}, 0")
+        self.next_coords("W")
+        self.weight_tile_setup()
+        e(f"{same}:")
+
+    # ---- instruction groups
+    def dma_items(self, wbuf):
+        """nine 1-KiB pieces of the weight stream's chunk -> weight area of buffer wbuf"""
+        items = []
+        for grp in range(3):
+            base = ("WCH", "WCH1_", "WCH2_")[grp]
+            for j in range(4 if grp < 2 else 1):
+                g = []
+                if j == 0:
+                    g += [f"s_add_u32 m0, {s('LDSW')}, {wbuf * BUF + grp * 4096}", "s_nop 0"]
+                if not EXP & 4:
+                    g += [f"global_load_lds_dwordx4 v{V_DMA}, {s2(base)} offset:{1024 * j}"]
+                items.append(g)
+        return items
+
+    def halo_items(self, pset):
+        """six 16-byte loads of the request stream's chunk into staging set pset (+ the masks they were requested under)"""
+        items = []
+        for i in range(NQ):
+            g = [f"v_mul_lo_u32 v{V_VOFF + i}, v{V_PIX + i}, {s('CBYTES')}", f"v_add_u32 v{V_VOFF + i}, v{V_VOFF + i}, v{V_C4X16}",
+                 f"v_mov_b32 v{V_SMSK[pset] + i}, v{V_MSK + i}"]
+            if EXP & 16:      # ablation: the same bytes as six fully coalesced 1-KiB instructions per wave (wrong data)
+                g += [f"v_lshlrev_b32 v{V_VOFF + i}, 4, v{V_TID}", f"v_add_u32 v{V_VOFF + i}, {4096 * i}, v{V_VOFF + i}"]
+            if i == NQ - 1:
+                g += [f"s_mov_b64 exec, {s2('M5')}"]
+            if not EXP & 2:
+                g += [f"global_load_dwordx4 v[{V_PIN[pset] + 4 * i}:{V_PIN[pset] + 4 * i + 3}], v{V_VOFF + i}, {s2('SRC')}"]
+            if i == NQ - 1:
+                g += ["s_mov_b64 exec, -1"]
+            items.append(g)
+        return items
+
+    def commit_items(self, pset, buf):
+        """split + LDS write of staging set pset into the halo area of buffer buf"""
+        items = []
+        for i in range(NQ):
+            p = V_PIN[pset] + 4 * i
+            h, l, t = V_T, V_T + 2, V_T + 4
+            if i % 2:
+                h, l, t = V_T + 8, V_T + 10, V_T + 12
+            g1 = [f"v_and_b32 v{p + j}, v{p + j}, v{V_SMSK[pset] + i}" for j in range(4)]
+            g2 = [f"v_cvt_pk_bf16_f32 v{h}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{h + 1}, v{p + 2}, v{p + 3}",
+                  f"v_lshlrev_b32 v{t}, 16, v{h}", f"v_and_b32 v{t + 1}, 0xffff0000, v{h}"]
+            g3 = [f"v_lshlrev_b32 v{t + 2}, 16, v{h + 1}", f"v_and_b32 v{t + 3}, 0xffff0000, v{h + 1}",
+                  f"v_sub_f32 v{p}, v{p}, v{t}", f"v_sub_f32 v{p + 1}, v{p + 1}, v{t + 1}"]
+            g4 = [f"v_sub_f32 v{p + 2}, v{p + 2}, v{t + 2}", f"v_sub_f32 v{p + 3}, v{p + 3}, v{t + 3}",
+                  f"v_cvt_pk_bf16_f32 v{l}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{l + 1}, v{p + 2}, v{p + 3}"]
+            wr = []
+            if i == NQ - 1:
+                wr += [f"s_mov_b64 exec, {s2('M5')}"]
+            wr += [(f"ds_write_b64 v{V_WHI[buf] + i}, v[{h}:{h + 1}]", ("W", i, 0)),
+                   (f"ds_write_b64 v{V_WLO[buf] + i}, v[{l}:{l + 1}]", ("W", i, 1))]
+            if i == NQ - 1:
+                wr += ["s_mov_b64 exec, -1"]
+            items += [g1, g2, g3, g4, wr] if not EXP & 8 else []
+        return items
+
+    def store_items(self, aset):
+        """the stores of the tile that accumulated in set `aset` (offsets V_SOFF, base OUTF: set by tile_end), ReLU on the way.
+        A block (mb, nb) = 32 channels x 32 pixels leaves through this wave's 4 KiB of LDS staging: as the MFMA leaves it, a store
+        instruction would write 16 bytes to each of 64 different 128-byte lines (measured: the 16 such stores per lane cost as much
+        as having no stores at all saves, 1.1 of 7.6 ms); transposed, lane l writes channel quad l & 7 of pixel 8 j + (l >> 3):
+        eight whole lines per instruction.  Per block: 16 v_accvgpr_read, 16 v_max, 4 ds_write_b128, 4 ds_read_b128, 4 stores."""
+        items = []
+        ta, tb = V_T, V_T + 16
+        for nb in range(2):
+            for mb in range(2):
+                blk = nb * 2 + mb
+                a0 = A_ACC[aset] + (mb * 2 + nb) * 16
+                for rq in range(4):
+                    items.append([f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}" for j in range(4)])
+                    items.append([f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}" for j in range(4)]
+                                 + [(f"ds_write_b128 v{V_SWA + rq}, v[{ta + 4 * rq}:{ta + 4 * rq + 3}]", ("SW", blk, rq))])
+                for j in range(4):
+                    items.append([(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", blk, j))])
+                for j in range(4):
+                    g = [("wait", ("SR", blk, j)), f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + nb * 4 + j}", "s_nop 0", "s_and_b64 exec, vcc, exec"]
+                    if EXP & 32:
+                        g += [f"v_lshlrev_b32 v{V_VOFF}, 4, v{V_LANE}", f"global_store_dwordx4 v{V_VOFF}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')} offset:{mb * 128}"]
+                    elif not EXP & 1:
+                        g += [f"global_store_dwordx4 v{V_SOFF + nb * 4 + j}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')} offset:{mb * 128}"]
+                    g += ["s_mov_b64 exec, -1"]
+                    items.append(g)
+        return items
+
+    # ---- one chunk of the compute stream: reads buffer p; aset = accumulator set of its tile
+    def chunk(self, p, aset, stores=False):
+        """stores: this is the first chunk of a tile that has a predecessor -- the predecessor's stores ride behind taps 0..3"""
+        e = self.e
+        self.weight_source()
+        self.request_source()
+        dma = self.dma_items(p ^ 1)                      # weights of chunk g + 1
+        req = self.halo_items(p)                         # halo values of chunk g + 2 -> staging set p
+        com = self.commit_items(p ^ 1, p ^ 1)            # halo values of chunk g + 1 (set p ^ 1) -> buffer p ^ 1
+        sto = self.store_items(aset ^ 1) if stores else []
+        assert len(sto) in (0, 64)
+        for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
             self.lds_op(text, tag)
         for t in range(9):
             os_ = t & 1
-            nxt = self.tap_reads(t + 1, buf, os_ ^ 1) if t + 1 < 9 else []
+            nxt = self.tap_reads(t + 1, p, os_ ^ 1) if t + 1 < 9 else []
             sprinkle = [[] for _ in range(12)]
             for m, rd in enumerate(nxt):
                 sprinkle[m].append(rd)
-            if t == 0 and req:                           # the 15 request groups: 8 behind tap 0, 7 behind tap 1
-                for k, g in enumerate(req[:8]):
-                    sprinkle[k + 2].extend(g)
-            if t == 1 and req:
-                for k, g in enumerate(req[8:]):
-                    sprinkle[k + 2].extend(g)
+            # order of the vector-memory operations of a chunk: [the previous tile's stores][9 DMA pieces][6 requests] -- the counted
+            # wait behind tap 4 then never waits for a request of THIS chunk, whether or not stores take part in the count
+            if sto and t < 4:                            # one block (16 groups) per tap
+                for k, g in enumerate(sto[16 * t:16 * (t + 1)]):
+                    sprinkle[min(11, 1 + (k * 11) // 16)].extend(g)
+            t_dma, t_req = (4, 4) if sto else (2, 3)
+            if t == t_dma:                               # 9 DMA groups
+                for k, g in enumerate(dma):
+                    sprinkle[k].extend(g)
+            if t == t_req:                               # 6 request groups -- AFTER the tap's DMA pieces when they share a tap: the
+                for k, g in enumerate(req):              # chunk's closing vmcnt(6) counts on the requests being the six newest operations
+                    sprinkle[9 + k // 2 if sto else 2 * k].extend(g)
             if t >= 5 and com:                           # the 30 commit groups behind taps 5..8: 8 + 8 + 7 + 7
                 per = [8, 8, 7, 7][t - 5]
                 start = [0, 8, 16, 23][t - 5]
                 for k, g in enumerate(com[start:start + per]):
                     sprinkle[k + 2].extend(g)
-            if t == 5 and com:
-                e("s_waitcnt vmcnt(0)")                  # the staged values (requested ~ 2 k cycles ago) and the weight pieces have landed
-            # this tap's operands: the newest 8 reads (issued behind the previous tap) -- wait for all of them
+            if t == 5:
+                # staging set p ^ 1 was requested during the previous chunk; newer vector-memory operations: this chunk's 9 DMA
+                # pieces and 6 requests
+                e("s_waitcnt vmcnt(15)")
             self.wait_lds(("R", t, 3, 1))
-            self.tap_mfmas(os_, sprinkle)
+            self.tap_mfmas(aset, os_, sprinkle)
         self.wait_all_lds()
-        e("s_waitcnt vmcnt(0)")
+        e("s_waitcnt vmcnt(6)")                          # the weight pieces of chunk g + 1 have landed (the six new requests may fly)
         e("s_barrier")
+        self.advance_weights()
+        self.advance_request()
 
-    def bias_init(self):
-        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh): 8 reads for nb = 0, copied to nb = 1"""
+    def bias_init(self, aset):
+        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of both N-blocks"""
         e = self.e
         e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")                        # CT * 64 floats
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {BIAS_OFF}")
-        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_HH16}")
+        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_BIASA}")
         for mb in range(2):
-            for rq in range(4):
-                b = V_ACC + (mb * 2) * 16 + 4 * rq
-                self.lds_op(f"ds_read_b128 v[{b}:{b + 3}], v{V_T} offset:{mb * 128 + rq * 32}", ("BI", mb, rq))
-        self.wait_all_lds()
-        for mb in range(2):
-            for r in range(16):
-                e(f"v_mov_b32 v{V_ACC + (mb * 2 + 1) * 16 + r}, v{V_ACC + (mb * 2) * 16 + r}")
+            for nb in range(2):
+                for rq in range(4):
+                    b = A_ACC[aset] + (mb * 2 + nb) * 16 + 4 * rq
+                    self.lds_op(f"ds_read_b128 a[{b}:{b + 3}], v{V_T} offset:{mb * 128 + rq * 32}", ("BI", mb, nb, rq))
+            self.wait_all_lds()
 
-    def epilogue(self):
-        """ReLU (RELU = 0.0 or -inf as the lower bound) and the stores of the tile at (TX, TY, CT, FR)"""
+    def tile_end(self):
+        """the finished tile's store state: OUTF and, per N-block and store j, this lane's byte offset (pixel 8 j + (lane >> 3) of
+        the block, channel quad lane & 7) or -1 outside the image; then the compute stream moves on"""
         e = self.e
-        for r in range(64):
-            e(f"v_max_f32 v{V_ACC + r}, {s('RELU')}, v{V_ACC + r}")
-        # OUTF = out + ((FR * H * W) * COUT + CT * 64) * 4
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
         e(f"s_lshl_b32 {s('T1')}, {s('COUT')}, 2")
@@ -373,30 +445,29 @@ class Body:
         e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")
         e(f"s_add_u32 {s('OUTF')}, {s('OUTF')}, {s('T0')}")
         e(f"s_addc_u32 {s('OUTF1')}, {s('OUTF1')}, 0")
+        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
+        e(f"s_lshl_b32 {s('Y0')}, {s('TY')}, 4")
         e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 2")
         e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('Y0')}")                # first row of this wave
-        e(f"v_add_u32 v{V_T + 1}, {s('X0')}, v{V_COL}")                # gx
-        e(f"v_cmp_gt_u32 {s2('TB')}, {s('W')}, v{V_T + 1}")
-        e(f"s_mov_b64 {s2('EX')}, exec")
+        for half in range(2):                                           # columns 8 half + (lane >> 3)
+            e(f"v_add_u32 v{V_T + half}, {s('X0')}, v{V_L3}")
+            if half:
+                e(f"v_add_u32 v{V_T + half}, 8, v{V_T + half}")
         for nb in range(2):
-            e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_ROW2}")               # gy of N-block 0: row0 + (n >> 4)
-            if nb:
-                e(f"v_add_u32 v{V_T}, 2, v{V_T}")
-            e(f"v_cmp_gt_u32 vcc, {s('H')}, v{V_T}")
-            e(f"s_and_b64 vcc, vcc, {s2('TB')}")
-            e(f"v_mul_lo_u32 v{V_T + 2}, v{V_T}, {s('W')}")
-            e(f"v_add_u32 v{V_T + 2}, v{V_T + 2}, v{V_T + 1}")          # pixel index
-            e(f"v_mul_lo_u32 v{V_SOFF + nb}, v{V_T + 2}, {s('T1')}")    # * COUT * 4
-            e(f"v_add_u32 v{V_SOFF + nb}, v{V_SOFF + nb}, v{V_HH16}")
-            e("s_nop 1")
-            e("s_and_b64 exec, exec, vcc")
-            for mb in range(2):
-                for rq in range(4):
-                    b = V_ACC + (mb * 2 + nb) * 16 + 4 * rq
-                    if not EXP & 1:
-                        e(f"global_store_dwordx4 v{V_SOFF + nb}, v[{b}:{b + 3}], {s2('OUTF')} offset:{mb * 128 + rq * 32}")
-            e(f"s_mov_b64 exec, {s2('EX')}")
-        e("s_nop 2")
+            for j in range(4):
+                row, half = 2 * nb + (j >> 1), j & 1
+                d = V_SOFF + nb * 4 + j
+                e(f"s_add_u32 {s('T2')}, {s('T0')}, {row}")             # gy (wave-uniform)
+                e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
+                e(f"s_cselect_b64 {s2('TA')}, -1, 0")
+                e(f"v_cmp_gt_u32 vcc, {s('W')}, v{V_T + half}")
+                e(f"s_and_b64 vcc, vcc, {s2('TA')}")
+                e(f"s_mul_i32 {s('T3')}, {s('T2')}, {s('W')}")
+                e(f"v_add_u32 v{V_T + 2}, {s('T3')}, v{V_T + half}")    # pixel index
+                e(f"v_mul_lo_u32 v{V_T + 2}, v{V_T + 2}, {s('T1')}")    # * COUT * 4
+                e(f"v_add_u32 v{V_T + 2}, v{V_T + 2}, v{V_L7X16}")
+                e(f"v_cndmask_b32 v{d}, -1, v{V_T + 2}, vcc")
+        self.next_coords("")
 
 
 def generate():
@@ -413,13 +484,16 @@ def generate():
         e(f"s_load_dword {s(dst)}, {s2('KARG')}, {ARG[field]}")
     e(f"v_mov_b32 v{V_TID}, %[tid]")
     e(f"v_and_b32 v{V_LANE}, 63, v{V_TID}")
-    # per-lane constants: the C++ prologue left CONST_WORDS words per lane at the start of LDS ([word][256 threads])
+    # per-lane constants: the C++ prologue left 18 words per lane at the start of LDS ([word][256 threads])
     e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
     e(f"v_add_u32 v{V_T}, {s('LDS0')}, v{V_T}")
     for i in range(NQ):
         e(f"ds_read_b32 v{V_WHI[0] + i}, v{V_T} offset:{1024 * i}")
         e(f"ds_read_b32 v{V_HRC + i}, v{V_T} offset:{1024 * (6 + i)}")
         e(f"ds_read_b32 v{V_BOFS[0] + i}, v{V_T} offset:{1024 * (12 + i)}")
+    for i in range(4):
+        e(f"ds_read_b32 v{V_SWA + i}, v{V_T} offset:{1024 * (18 + i)}")
+        e(f"ds_read_b32 v{V_SRA + i}, v{V_T} offset:{1024 * (22 + i)}")
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")                                                    # (everybody has read its constants: the buffers may be written)
     for i in range(NQ):
@@ -432,6 +506,9 @@ def generate():
     e(f"v_bfe_u32 v{V_ROW2}, v{V_LANE}, 4, 1")                         # (n >> 4) & 1
     e(f"v_lshrrev_b32 v{V_HH16}, 5, v{V_LANE}")
     e(f"v_lshlrev_b32 v{V_HH16}, 4, v{V_HH16}")                        # hh * 16 bytes
+    e(f"v_lshrrev_b32 v{V_L3}, 3, v{V_LANE}")
+    e(f"v_and_b32 v{V_L7X16}, 7, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_L7X16}, 4, v{V_L7X16}")
     e(f"v_and_b32 v{V_C4X16}, 3, v{V_TID}")
     e(f"v_lshlrev_b32 v{V_C4X16}, 4, v{V_C4X16}")                      # (tid & 3) * 16 bytes
     e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216")
@@ -440,6 +517,8 @@ def generate():
     e(f"v_add_u32 v{V_AOFS[1]}, {BUF}, v{V_AOFS[0]}")
     e(f"s_add_u32 {s('LDSW')}, {s('LDS0')}, {HALO_BYTES}")
     e(f"s_add_u32 {s('LDSW')}, {s('LDSW')}, {s('T0')}")                 # LDS address of this wave's weight pieces in buffer 0
+    e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
+    e(f"v_add_u32 v{V_BIASA}, {s('T0')}, v{V_HH16}")                    # bias table + hh * 16
     e(f"s_cmp_eq_u32 {s('WAVE')}, 0")                                  # quad 5 exists for lanes 0..15 of wave 0 only
     e(f"s_cselect_b64 {s2('M5')}, 0xffff, 0")
     e("s_waitcnt lgkmcnt(0)")
@@ -447,7 +526,7 @@ def generate():
     e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 4")
     e(f"s_lshr_b32 {s('CHA')}, {s('CA')}, 4")
     e(f"s_cmp_eq_u32 {s('T3')}, 0")
-    e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the epilogue's v_max: -inf (linear) or 0
+    e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the stores' v_max: -inf (linear) or 0
     # the bias table -> LDS: thread t (< 64 * NCT) copies bias[t]
     e(f"s_lshl_b32 {s('T0')}, {s('NCT')}, 6")
     e(f"v_cmp_gt_u32 vcc, {s('T0')}, v{V_TID}")
@@ -461,61 +540,73 @@ def generate():
     e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
     e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
     e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
-    # first tile: geometry, pointers, chunk 0 staged synchronously
-    e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
-    e(f"s_lshl_b32 {s('Y0')}, {s('TY')}, 4")
-    e(f"s_mov_b32 {s('SX0')}, {s('X0')}")
-    e(f"s_mov_b32 {s('SY0')}, {s('Y0')}")
-    b.geometry()
-    b.frame_bases("FR")
-    b.tile_weights("CT")
-    e(f"s_mov_b32 {s('TGT')}, 0")
-    b.stage_now(0)
+    # the streams start on the workgroup's first tile
+    e(f"s_mov_b32 {s('LEFT')}, {s('NTL')}")
+    for p in ("R", "W"):
+        for c in ("TX", "TY", "CT", "FR"):
+            e(f"s_mov_b32 {s(p + c)}, {s(c)}")
+        e(f"s_mov_b32 {s(p + 'LEFT')}, {s('NTL')}")
+    e(f"s_mov_b32 {s('RC')}, 0")
+    e(f"s_mov_b32 {s('WC')}, 0")
+    b.request_tile_setup()
+    b.weight_tile_setup()
+    # chunk 0: weights -> buffer 0, halo -> set 0 -> buffer 0 (all exposed: once per workgroup); chunk 1's halo requested into set 1
+    b.weight_source()
+    b.request_source()
+    for g in b.dma_items(0):
+        b.emit_group(g)
+    for g in b.halo_items(0):
+        b.emit_group(g)
+    b.advance_weights()
+    b.advance_request()
+    e("s_waitcnt vmcnt(0)")
+    for g in b.commit_items(0, 0):
+        b.emit_group(g)
+    b.request_source()
+    for g in b.halo_items(1):
+        b.emit_group(g)
+    b.advance_request()
     b.wait_all_lds()
+    e("s_waitcnt vmcnt(6)")
     e("s_barrier")
 
-    # ================= tile loop
-    e("S2LK_TILE:")
-    b.bias_init()
-    e(f"s_mov_b32 {s('CC')}, 0")
-    e("S2LK_PAIR:")
-    # chunk CC (even) reads buffer 0 and stages CC + 1 of this tile into buffer 1
-    e(f"s_add_u32 {s('TGT')}, {s('CC')}, 1")
-    b.chunk(0, "next")
-    # chunk CC + 1 reads buffer 1; it stages CC + 2 -- or, at the tile's end, chunk 0 of the NEXT tile -- into buffer 0
-    last = b.label("lastpair")
-    join = b.label("staged")
-    e(f"s_add_u32 {s('TGT')}, {s('CC')}, 2")
-    e(f"s_cmp_lt_u32 {s('TGT')}, {s('NCH')}")
-    e(f"s_cbranch_scc1 {join}")
-    # the tile ends with this chunk: the staging state (geometry registers, FRA / FRB / WB) moves on to the next tile -- or stays on
-    # this one when it is the workgroup's last (valid addresses, unused data)
-    b.next_tile_coords()
-    e(f"s_cmp_gt_u32 {s('NTL')}, 1")
-    for n_, c_ in (("NTX", "TX"), ("NTY", "TY"), ("NCTN", "CT"), ("NFR", "FR")):
-        e(f"s_cselect_b32 {s(n_)}, {s(n_)}, {s(c_)}")
-    e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
-    e(f"s_lshl_b32 {s('SY0')}, {s('NTY')}, 4")
-    b.geometry()
-    b.frame_bases("NFR")
-    b.tile_weights("NCTN")
-    e(f"s_mov_b32 {s('TGT')}, 0")
-    e(f"{join}:")
-    b.chunk(1, "next")
-    e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
-    e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
-    e("s_cbranch_scc1 S2LK_PAIR")
-    b.epilogue()
-    # next tile
-    e(f"s_mov_b32 {s('TX')}, {s('NTX')}")
-    e(f"s_mov_b32 {s('TY')}, {s('NTY')}")
-    e(f"s_mov_b32 {s('CT')}, {s('NCTN')}")
-    e(f"s_mov_b32 {s('FR')}, {s('NFR')}")
-    e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
-    e(f"s_lshl_b32 {s('Y0')}, {s('TY')}, 4")
-    e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
-    e(f"s_cmp_gt_u32 {s('NTL')}, 0")
-    e("s_cbranch_scc1 S2LK_TILE")
+    # ================= tile loop, unrolled over the two accumulator sets; a tile's first chunk exists with and without the
+    # previous tile's stores riding on it (the workgroup's first tile has no predecessor)
+    e(f"s_mov_b32 {s('SM0')}, 0")                                     # SM0: 1 once a tile has finished (its stores are pending)
+    for aset in (0, 1):
+        e(f"S2LK_TILE{aset}:")
+        b.bias_init(aset)
+        e(f"s_mov_b32 {s('CC')}, 0")
+        e(f"s_cmp_eq_u32 {s('SM0')}, 0")
+        e(f"s_cbranch_scc1 S2LK_FIRST{aset}")
+        saved = list(b.lds)
+        b.chunk(0, aset, stores=True)
+        e(f"s_branch S2LK_ODD{aset}")
+        e(f"S2LK_PAIR{aset}:")
+        e(f"S2LK_FIRST{aset}:")
+        b.lds = list(saved)
+        b.chunk(0, aset)
+        e(f"S2LK_ODD{aset}:")
+        b.chunk(1, aset)
+        e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
+        e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 S2LK_PAIR{aset}")
+        b.tile_end()
+        e(f"s_mov_b32 {s('SM0')}, 1")
+        e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
+        e(f"s_cmp_eq_u32 {s('NTL')}, 0")
+        e(f"s_cbranch_scc1 S2LK_FLUSH{aset}")
+    e("s_branch S2LK_TILE0")
+    # ================= the last tile's stores
+    for aset in (0, 1):
+        e(f"S2LK_FLUSH{aset}:")
+        e("s_nop 7")
+        e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
+        for g in b.store_items(aset):
+            b.emit_group(g)
+        b.wait_all_lds()
+        e("s_branch S2LK_END")
+    e("S2LK_END:")
     e("s_waitcnt vmcnt(0)")
     return b.L
 
@@ -528,7 +619,8 @@ OPERANDS = """      :
 
 def main(objdir):
     lines = generate()
-    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1)] + ["vcc", "scc", "memory"]
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1)]
+    clob += ["vcc", "scc", "memory"]
     out = ["// GENERATED by csrc/gen_conv16_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]
     out.append(OPERANDS.rstrip("\n"))
