@@ -14,8 +14,9 @@ static_assert(offsetof(Conv16Args, inA) == 0 && offsetof(Conv16Args, inB) == 8 &
               offsetof(Conv16Args, n_ct) == 68 && offsetof(Conv16Args, relu) == 72,
               "gen_conv16_body.py (ARG) loads these fields from the kernarg segment by offset");
 
-constexpr int kC16Halo = 18 * 18 * 64, kC16W = 9 * 2 * 2 * 64 * 16, kC16Buf = kC16Halo + kC16W;
-constexpr int kC16Lds = 2 * kC16Buf + 1024 + 4 * 4096;      // two buffers, the bias table, the store staging (gen_conv16_body.py)
+constexpr int kC16TileH = 32;      // tile = 32 rows x 16 columns (gen_conv16_body.py: TILE_H)
+constexpr int kC16Halo = (kC16TileH + 2) * 18 * 64, kC16W = 9 * 2 * 2 * 64 * 16, kC16Buf = kC16Halo + kC16W;
+constexpr int kC16Lds = 2 * kC16Buf + 1024;      // two buffers + the bias table (the store staging aliases buffer 1's halo area)
 static_assert(kC16Lds <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
@@ -37,18 +38,19 @@ __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
   const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
   const int fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
   const int ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
-  // per-lane constants.  Staging: quad qi = tid + 256 i of the 18 x 18 x 4 halo quads = pixel qi / 4 (row-major), channels
+  // per-lane constants.  Staging: quad qi = tid + 256 i of the 34 x 18 x 4 halo quads = pixel qi / 4 (row-major), channels
   // 4 (qi % 4) .. + 3 of the chunk: 8 bytes of hi at 16-byte segment (c4 >> 1) ^ swizzle, 8 bytes of lo at that address ^ 32.
-  // They reach the assembly body through LDS ([word 18][thread 256] at the start of buffer 0; the body reads them first).
+  // They reach the assembly body through LDS ([word 34][thread 256] at the start of buffer 0; the body reads them first).
   uint32_t* cst = reinterpret_cast<uint32_t*>(c16_smem);
+  constexpr int kQuads = (kC16TileH + 2) * 18 * 4;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int qi = tid + 256 * i, pi = (qi < 1296 ? qi : 0) / 4, c4 = qi & 3;
+  for (int i = 0; i < 10; ++i) {
+    const int qi = tid + 256 * i, pi = (qi < kQuads ? qi : 0) / 4, c4 = qi & 3;
     const int row = pi / 18, col = pi % 18;
     cst[i * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + ((((c4 >> 1) ^ ((col >> 2) & 3))) << 4) + (c4 & 1) * 8);
-    cst[(6 + i) * 256 + tid] = (uint32_t)((row << 8) | col);
+    cst[(10 + i) * 256 + tid] = (uint32_t)((row << 8) | col);
   }
-  // operand reads: lane (n = lane & 31, hh = lane >> 5): pixel (row 4 wave + (n >> 4) [+ 2 blk + dy as an immediate], col (n & 15) + dx),
+  // operand reads: lane (n = lane & 31, hh = lane >> 5): pixel (row 8 wave + (n >> 4) [+ 2 blk + dy as an immediate], col (n & 15) + dx),
   // 16-byte segment (2 part + hh) ^ swizzle
   {
     const int n = lane & 31, hh = lane >> 5;
@@ -56,21 +58,22 @@ __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        const int col = (n & 15) + dx, row = 4 * wave + (n >> 4);
-        cst[(12 + dx * 2 + pt) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * pt + hh) ^ ((col >> 2) & 3)) << 4));
+        const int col = (n & 15) + dx, row = 8 * wave + (n >> 4);
+        cst[(20 + dx * 2 + pt) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * pt + hh) ^ ((col >> 2) & 3)) << 4));
       }
   }
-  // store staging (this wave's 4 KiB: [32 pixels][32 channels] fp32, 16-byte quad index ^ ((pixel >> 1) & 7)): write address of the
-  // lane's register quad rq (pixel n = lane & 31, channels 8 rq + 4 hh ..), read address of store j (pixel 8 j + (lane >> 3), quad lane & 7)
+  // store staging (this wave's 4 KiB at the start of buffer 1: [32 pixels][32 channels] fp32, 16-byte quad index ^ ((pixel >> 1) & 7)):
+  // write address of the lane's register quad rq (pixel n = lane & 31, channels 8 rq + 4 hh ..), read address of store j
+  // (pixel 8 j + (lane >> 3), quad lane & 7)
   {
-    const uint32_t stg = lds0 + 2 * kC16Buf + 1024 + wave * 4096;
+    const uint32_t stg = lds0 + kC16Buf + wave * 4096;
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) cst[(18 + rq) * 256 + tid] = stg + (uint32_t)(n * 128 + (((2 * rq + hh) ^ ((n >> 1) & 7)) << 4));
+    for (int rq = 0; rq < 4; ++rq) cst[(26 + rq) * 256 + tid] = stg + (uint32_t)(n * 128 + (((2 * rq + hh) ^ ((n >> 1) & 7)) << 4));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int px = 8 * j + (lane >> 3);
-      cst[(22 + j) * 256 + tid] = stg + (uint32_t)(px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4));
+      cst[(30 + j) * 256 + tid] = stg + (uint32_t)(px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4));
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the constants are in LDS (each lane reads back only its own words)
@@ -106,6 +109,8 @@ namespace s2l {
 int launch_conv16_asm(const Conv16Args& a0, hipStream_t st, bool* launched) {
   *launched = false;
   Conv16Args a = a0;
+  a.tiles_x = (a.W + 15) / 16;
+  a.tiles_y = (a.H + kC16TileH - 1) / kC16TileH;
   const int nch = (a.CA + a.CB) / 16;
   if ((a.CA + a.CB) % 16 != 0 || nch % 2 != 0 || a.CA % 16 != 0 || a.cout % 64 != 0 || a.n_ct != a.cout / 64 || a.n_ct > 4 ||
       (int64_t)a.H * a.W * 128 * 4 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames >= 0x7fffffffLL || a.n_frames <= 0)

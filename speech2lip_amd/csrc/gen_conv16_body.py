@@ -8,77 +8,84 @@ lo = bf16(x - hi); the BatchNorm-folded weights pre-split by s2l_unet_pack16x3 (
 [lane 64][8]); per 16-channel chunk and tap three products on v_mfma_f32_32x32x16_bf16, smallest first: W_lo x_hi, W_hi x_lo,
 W_hi x_hi; accumulators start at the bias; ReLU; fp32 NHWC out.
 
-Shape of the work:
-  * tile = 16 x 16 pixels x 64 output channels, FOUR waves (one per SIMD); wave w owns rows 4 w .. 4 w + 3 as two N-blocks of
-    2 rows x 16 pixels, and both 32-channel M-blocks: 4 accumulator blocks of 16 AGPRs; per tap 4 + 4 ds_read_b128 feed 12 MFMAs
-    of 32 cycles (the C++ kernel: eight waves each reading all of a chunk's weights, 0.67 operand reads per MFMA, LDS-bound);
-  * TWO LDS buffers of (halo 18 x 18 pixels x 64 B [hi 16 ch | lo 16 ch], the 16-byte segment index XORed with (column >> 2) & 3:
+Shape of the work (v4):
+  * tile = 32 rows x 16 columns x 64 output channels, FOUR waves (one per SIMD); wave w owns rows 8 w .. 8 w + 7 as four N-blocks
+    of 2 rows x 16 pixels, and both 32-channel M-blocks: 8 accumulator blocks of 16 AGPRs; per tap 4 + 8 ds_read_b128 (into AGPRs:
+    both operand sets live there) feed 24 MFMAs of 32 cycles: 0.5 operand reads per MFMA (the C++ kernel: eight waves each reading
+    all of a chunk's weights, 0.67);
+  * why 32 x 16: three earlier forms of this kernel used 16 x 16 tiles and were bound by the TEXTURE PATH -- per chunk and CU
+    36 KiB of weight DMA + 20 KiB of halo loads (+ 64 KiB of stores per tile) at ~16 B/clk is as long as the chunk's 3 456 MFMA
+    cycles; ablation builds (S2L_C16_EXP) without any ONE of the three ran 15 % faster, without all three 25 %.  The taller tile
+    halves the weight bytes per MFMA and trims the halo overlap (1.27 -> 1.20): -30 % texture-path work per MFMA;
+  * TWO LDS buffers of (halo 34 x 18 pixels x 64 B [hi 16 ch | lo 16 ch], the 16-byte segment index XORed with (column >> 2) & 3:
     the sixteen pixels of an operand read cover all 64 banks) + (weights 36 KiB, by LDS-DMA: nine 1-KiB pieces per wave);
-  * a workgroup's chunks form ONE stream across its tiles.  During chunk g: the weights of g + 1 arrive by LDS-DMA; the halo values
-    of g + 2 (fp32, six 16-byte loads per lane) are REQUESTED into one of two register sets; the values of g + 1 (requested a whole
-    chunk ago: HBM latency is ~2 k cycles, a chunk 3.5 k) are split and written to the other buffer behind taps 5..8 (16 VALU +
-    2 ds_write per quad; a filler beside a bf16 MFMA costs about half of what it costs alone); ONE barrier per chunk.  v1 of
-    this kernel requested one chunk ahead and issued a tile's stores in a burst: ablation builds priced that at 1.4 ms + 1.1 ms of
-    a 7.6-ms 16-frame forward;
-  * two accumulator sets (AGPRs), alternating per tile: a tile's 16 stores per lane (ReLU on the way: v_accvgpr_read, v_max) are
-    issued behind the MFMAs of the NEXT tile's first chunk, which accumulates into the other set; the bias enters from a table in
-    LDS straight into the AGPRs.
+  * a workgroup's chunks form ONE stream across its tiles, staged one chunk ahead: during chunk g the weights of g + 1 arrive by
+    LDS-DMA, its halo values (fp32, ten 16-byte loads per lane) are requested behind taps 0..2 and split + written to the other
+    buffer behind taps 6..8 (16 VALU + 2 ds_write per quad; a filler beside a bf16 MFMA costs about half of what it costs alone);
+    ONE barrier per chunk.  (Requesting two chunks ahead, v2 / v3, bought nothing: the loads' cost is issue, not latency.)
+  * a tile's end: the accumulators leave through this wave's 4 KiB of LDS (buffer 1's halo area is idle then) so that a store
+    instruction writes eight whole 128-byte lines (as the MFMA leaves them, 16 bytes to each of 64 lines: measured 6 x the cost);
+    ReLU on the way; the next tile's bias comes from a table in LDS straight into the AGPRs.
 
-Register map (per wave): a0-63 / a64-127 accumulator sets acc[mb][nb][16] | v0-31, v32-63 two operand sets (A[part][mb],
-B[part][nb]: 8 x 4) | v64-87, v88-111 two sets of staged halo quads | v112.. per-lane constants and temporaries (names below).
+Register map (per wave): a0-127 acc[mb][nb][16] | a128-175, a176-223 two operand sets (A[part][mb] 4 x 4, B[part][nb] 8 x 4) |
+v0-39 staged halo quads | v40.. per-lane constants and temporaries (names below).
 Scalars: s16.. (names below); kernel arguments are loaded from the kernarg segment (struct Conv16Args, csrc/conv16.h)."""
 import os
 import sys
 
-HALO_BYTES, W_BYTES = 18 * 18 * 64, 9 * 2 * 2 * 64 * 16        # 20 736 + 36 864
-BUF = HALO_BYTES + W_BYTES                                      # 57 600
+TILE_H = 32
+HALO_ROWS = TILE_H + 2
+HALO_BYTES, W_BYTES = HALO_ROWS * 18 * 64, 9 * 2 * 2 * 64 * 16  # 39 168 + 36 864
+BUF = HALO_BYTES + W_BYTES                                      # 76 032
 BIAS_OFF = 2 * BUF                                              # 256 floats
-NQ = 6                                                          # halo quads per lane: 18 * 18 * 4 = 1296 = 5 * 256 + 16
+LDS_BYTES = BIAS_OFF + 1024
+STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 4 waves x 4 KiB
+NQ = 10                                                         # halo quads per lane: 34 * 18 * 4 = 2448 = 9 * 256 + 144
+CONST_WORDS = 34                                                # per lane, from the C++ prologue: whi[10], hrc[10], bofs[6], swa[4], sra[4]
+STORE_MOD = os.environ.get("S2L_C16_STORE_MOD", "")
 EXP = int(os.environ.get("S2L_C16_EXP", "0"))                  # ablation builds (results wrong): 1 no stores, 2 no halo loads, 4 no weight DMA, 8 no commit
 
 # ---- registers
-A_ACC = (0, 64)                 # two accumulator sets
-V_OPS = (0, 32)                 # operand set: A[pt][mb] at + (pt * 2 + mb) * 4, B[pt][nb] at + 16 + (pt * 2 + nb) * 4
-V_PIN = (64, 88)                # staged halo quads, 6 x 4 per set
-V_SMSK = (112, 118)             # 6 per set: the validity masks the set's quads were requested under
-V_WHI = (124, 143)              # LDS addresses, one set per buffer (DS immediates are 16 bits: buffer 1 starts at 57 600)
-V_WLO = (130, 149)
-V_BOFS = (136, 155)
-V_AOFS = (142, 161)
-V_HRC = 162                     # 6: halo (row << 8 | col) of the quads
-V_PIX = 168                     # 6: pixel index inside the frame of the quads of the REQUEST stream's tile (0 where invalid)
-V_MSK = 174                     # 6: all ones / zero, same tile
-V_VOFF = 180                    # 6: byte offset of the quads from the chunk's source pointer
-V_LANE, V_COL, V_ROW2, V_HH16, V_C4X16, V_DMA, V_TID, V_BIASA = 186, 187, 188, 189, 190, 191, 192, 193
-V_T = 194                       # temporaries 194..225 (even: 64-bit tuples must be aligned); the store path uses all 32
-V_SOFF = 226                    # 8: store byte offsets [nb][j] of the tile whose stores are pending (-1: no store for this lane)
-V_SWA = 234                     # 4: staging write addresses per register quad rq (this wave's 4 KiB of the store staging area)
-V_SRA = 238                     # 4: staging read addresses per store j
-V_L3, V_L7X16 = 242, 243        # lane >> 3, (lane & 7) * 16
-V_LAST = 243
-A_LAST = 127
-STG_OFF = BIAS_OFF + 1024       # store staging: 4 waves x [32 pixels][32 channels] fp32, the 16-byte quad index XORed with (pixel >> 1) & 7
-LDS_BYTES = STG_OFF + 4 * 4096
-CONST_WORDS = 26                # per lane, from the C++ prologue: whi[6], hrc[6], bofs[6], swa[4], sra[4] (absolute LDS addresses)
+A_ACC = 0
+A_OPS = (128, 176)              # operand set: A[pt][mb] at + (pt * 2 + mb) * 4, B[pt][nb] at + 16 + (pt * 4 + nb) * 4
+A_LAST = 223
+V_PIN = 0                       # 10 quads x 4
+V_WHI = (40, 50)                # LDS addresses, one set per buffer (DS immediates are 16 bits)
+V_WLO = (60, 70)
+V_BOFS = (80, 86)
+V_AOFS = (92, 93)
+V_HRC = 94                      # 10: halo (row << 8 | col) of the quads
+V_PIX = 104                     # 10: pixel index inside the frame of the quads of the STAGING stream's tile (0 where invalid)
+V_MSK = 114                     # 10: all ones / zero, same tile
+V_VOFF = 124                    # 10: byte offset of the quads from the chunk's source pointer
+V_LANE, V_TID, V_HH16, V_C4X16, V_DMA, V_BIASA, V_L3, V_L7X16 = 134, 135, 136, 137, 138, 139, 140, 141
+V_T = 144                       # temporaries 144..175
+V_SOFF = 176                    # 16: store byte offsets [nb][j] of the tile that just ended (-1: no store for this lane)
+V_SWA = 192                     # 4: staging write addresses per register quad rq
+V_SRA = 196                     # 4: staging read addresses per store j
+V_LAST = 199
 
 
-def _scalars(first, singles, pairs):
+def _scalars(first, singles, pairs, skip=(32, 33)):
+    """names -> SGPR numbers (s32 / s33 are reserved by the compiler on this target: never on the clobber list)"""
     m, r = {}, first
     for n in pairs:
-        r += r & 1
+        while (r & 1) or r in skip or (r + 1) in skip:
+            r += 1
         m[n], m[n + "1"] = r, r + 1
         r += 2
     for n in singles:
+        while r in skip:
+            r += 1
         m[n] = r
         r += 1
     return m
 
 
-# three streams walk the workgroup's tiles: compute ("" prefix), halo requests two chunks ahead (R), weight DMA one ahead (W)
+# two streams walk the workgroup's tiles: compute ("" prefix) and staging, one chunk ahead (N)
 S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA WAVE LDS0 RELU CBYTES LDSW T0 T1 T2 T3 "
-                          "TX TY CT FR X0 Y0 CC NTL LEFT RTX RTY RCT RFR RC RLEFT SX0 SY0 WTX WTY WCT WFR WC WLEFT").split(),
-             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "EX", "M5",
-                    "TA", "SM0"))
+                          "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0").split(),
+             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "EX", "M9", "TA"))
 S_LAST = max(S.values())
 assert S_LAST <= 100, S_LAST
 
@@ -133,48 +140,51 @@ class Body:
 
     # ---- registers
     @staticmethod
-    def acc(aset, mb, nb):
-        b = A_ACC[aset] + (mb * 2 + nb) * 16
+    def acc(mb, nb):
+        b = A_ACC + (mb * 4 + nb) * 16
         return f"a[{b}:{b + 15}]"
 
     @staticmethod
     def opa(os_, pt, mb):
-        return V_OPS[os_] + (pt * 2 + mb) * 4
+        return A_OPS[os_] + (pt * 2 + mb) * 4
 
     @staticmethod
     def opb(os_, pt, nb):
-        return V_OPS[os_] + 16 + (pt * 2 + nb) * 4
+        return A_OPS[os_] + 16 + (pt * 4 + nb) * 4
 
-    # ---- operand reads of tap t from buffer `buf` into operand set os_: 8 (text, tag), in the order the MFMAs need them:
-    # A lo, B hi (first product), B lo (second), A hi (third)
+    # ---- operand reads of tap t from buffer `buf` into operand set os_: 12 (text, tag), in the order the MFMAs need them:
+    # A lo (2), B hi (4) [first product], B lo (4) [second], A hi (2) [third]
     def tap_reads(self, t, buf, os_):
         dy, dx = t // 3, t % 3
         out = []
         for kind in range(4):
-            for blk in range(2):
+            for blk in range(2 if kind in (0, 3) else 4):
                 if kind in (0, 3):
                     pt = 1 if kind == 0 else 0
                     r = self.opa(os_, pt, blk)
-                    off = HALO_BYTES + ((t * 2 + pt) * 2 + blk) * 1024
-                    out.append((f"ds_read_b128 v[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, kind, blk)))
+                    off = ((t * 2 + pt) * 2 + blk) * 1024      # (V_AOFS points at the buffer's weight area)
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, kind, blk)))
                 else:
                     pt = 0 if kind == 1 else 1
                     r = self.opb(os_, pt, blk)
                     off = (2 * blk + dy) * 18 * 64
-                    out.append((f"ds_read_b128 v[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + pt} offset:{off}", ("R", t, kind, blk)))
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + pt} offset:{off}", ("R", t, kind, blk)))
         return out
 
-    def tap_mfmas(self, aset, os_, sprinkle):
-        """12 MFMAs of one tap on operand set os_; sprinkle: 12 lists of items tucked behind MFMA m"""
-        for m in range(12):
-            g, mb, nb = m >> 2, (m >> 1) & 1, m & 1
+    def tap_mfmas(self, os_, sprinkle):
+        """24 MFMAs of one tap on operand set os_; sprinkle: 24 lists of items tucked behind MFMA m"""
+        m = 0
+        for g in range(3):
             pa, pb = (1 if g == 0 else 0), (1 if g == 1 else 0)
-            a, b = self.opa(os_, pa, mb), self.opb(os_, pb, nb)
-            self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(aset, mb, nb)}, v[{a}:{a + 3}], v[{b}:{b + 3}], {self.acc(aset, mb, nb)}")
-            self.emit_group(sprinkle[m])
+            for mb in range(2):
+                for nb in range(4):
+                    a, b = self.opa(os_, pa, mb), self.opb(os_, pb, nb)
+                    self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(mb, nb)}, a[{a}:{a + 3}], a[{b}:{b + 3}], {self.acc(mb, nb)}")
+                    self.emit_group(sprinkle[m])
+                    m += 1
 
     # ---- streams
-    def next_coords(self, p):
+    def next_coords(self, p, ct_name):
         """the stream with prefix p moves to its next tile (x fastest, then y, channel tile, frame) -- or stays on its last one"""
         e = self.e
         stay = self.label("stay")
@@ -189,15 +199,15 @@ class Body:
         e(f"s_cmp_eq_u32 {s(p + 'TY')}, {s('TILESY')}")
         e(f"s_cselect_b32 {s(p + 'TY')}, 0, {s(p + 'TY')}")
         e(f"s_cselect_b32 {s('T0')}, 1, 0")
-        e(f"s_add_u32 {s(p + 'CT')}, {s(p + 'CT')}, {s('T0')}")
-        e(f"s_cmp_eq_u32 {s(p + 'CT')}, {s('NCT')}")
-        e(f"s_cselect_b32 {s(p + 'CT')}, 0, {s(p + 'CT')}")
+        e(f"s_add_u32 {s(ct_name)}, {s(ct_name)}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(ct_name)}, {s('NCT')}")
+        e(f"s_cselect_b32 {s(ct_name)}, 0, {s(ct_name)}")
         e(f"s_cselect_b32 {s('T0')}, 1, 0")
         e(f"s_add_u32 {s(p + 'FR')}, {s(p + 'FR')}, {s('T0')}")
         e(f"{stay}:")
 
     def geometry(self):
-        """per-lane geometry of the request stream's tile at (SX0, SY0): pixel index and validity mask of the six quads"""
+        """per-lane geometry of the staging stream's tile at (SX0, SY0): pixel index and validity mask of the ten quads"""
         e = self.e
         for i in range(NQ):
             r, c, t = V_T, V_T + 1, V_T + 2
@@ -211,52 +221,45 @@ class Body:
             e(f"v_cmp_gt_u32 {s2('TA')}, {s('W')}, v{c}")
             e(f"s_and_b64 vcc, vcc, {s2('TA')}")
             if i == NQ - 1:
-                e(f"s_and_b64 vcc, vcc, {s2('M5')}")
+                e(f"s_and_b64 vcc, vcc, {s2('M9')}")
             e(f"v_mul_lo_u32 v{t}, v{r}, {s('W')}")
             e(f"v_add_u32 v{t}, v{t}, v{c}")
             e(f"v_cndmask_b32 v{V_PIX + i}, 0, v{t}, vcc")
             e(f"v_cndmask_b32 v{V_MSK + i}, 0, -1, vcc")
 
-    def request_tile_setup(self):
-        """FRA / FRB (frame bases of inA / inB) and the geometry registers for the request stream's tile (RTX, RTY, RFR)"""
+    def staging_tile_setup(self):
+        """geometry registers, frame bases FRA / FRB and the weight base WB for the staging stream's tile (NTX, NTY, NCT_, NFR)"""
         e = self.e
-        e(f"s_lshl_b32 {s('SX0')}, {s('RTX')}, 4")
-        e(f"s_lshl_b32 {s('SY0')}, {s('RTY')}, 4")
+        e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
+        e(f"s_mul_i32 {s('SY0')}, {s('NTY')}, {TILE_H}")
         self.geometry()
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
-        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('RFR')}")               # pixels before this frame (< 2^31: the launcher checks)
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('NFR')}")               # pixels before this frame (< 2^31: the launcher checks)
         for fr, src, c in (("FRA", "INA", "CA"), ("FRB", "INB", "CB")):
             e(f"s_mul_i32 {s('T1')}, {s(c)}, 4")
             e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
             e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
             e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
-
-    def weight_tile_setup(self):
-        """WB = w16 + WCT * NCH * W_BYTES"""
-        e = self.e
-        e(f"s_mul_i32 {s('T0')}, {s('WCT')}, {s('NCH')}")
+        e(f"s_mul_i32 {s('T0')}, {s('NCT_')}, {s('NCH')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
         e(f"s_add_u32 {s('WB')}, {s('W16')}, {s('T0')}")
         e(f"s_addc_u32 {s('WB1')}, {s('W161')}, 0")
 
-    def request_source(self):
-        """SRC = pointer to channel 0 of chunk RC at pixel 0 of the request tile's frame; CBYTES = bytes per pixel of that tensor"""
+    def staging_source(self):
+        """for chunk NC of the staging tile: SRC (channel 0 of the chunk at pixel 0 of the frame), CBYTES (bytes per pixel of that
+        tensor), WCH / WCH1_ / WCH2_ (the chunk's weights, + 4 KiB, + 8 KiB)"""
         e = self.e
-        e(f"s_cmp_lt_u32 {s('RC')}, {s('CHA')}")                       # chunk from A?
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('CHA')}")                       # chunk from A?
         e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
         e(f"s_cselect_b32 {s('CBYTES')}, {s('CA')}, {s('CB')}")
         e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
-        e(f"s_sub_u32 {s('T0')}, {s('RC')}, {s('T0')}")                # chunk index inside its tensor
+        e(f"s_sub_u32 {s('T0')}, {s('NC')}, {s('T0')}")                # chunk index inside its tensor
         e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 6")                        # * 16 channels * 4 bytes
         e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
         e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
         e(f"s_lshl_b32 {s('CBYTES')}, {s('CBYTES')}, 2")
-
-    def weight_source(self):
-        """WCH / WCH1_ / WCH2_ = chunk WC of the weight stream's channel tile (+ 4 KiB, + 8 KiB)"""
-        e = self.e
-        e(f"s_mul_i32 {s('T0')}, {s('WC')}, {W_BYTES}")
+        e(f"s_mul_i32 {s('T0')}, {s('NC')}, {W_BYTES}")
         e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
         e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
         e(f"s_add_u32 {s('WCH1_')}, {s('WCH')}, 4096")
@@ -264,31 +267,20 @@ class Body:
         e(f"s_add_u32 {s('WCH2_')}, {s('WCH')}, 8192")
         e(f"s_addc_u32 {s('WCH2_1')}, {s('WCH1')}, 0")
 
-    def advance_request(self):
+    def advance_staging(self):
         e = self.e
-        same = self.label("rsame")
-        e(f"s_add_u32 {s('RC')}, {s('RC')}, 1")
-        e(f"s_cmp_lt_u32 {s('RC')}, {s('NCH')}")
+        same = self.label("nsame")
+        e(f"s_add_u32 {s('NC')}, {s('NC')}, 1")
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('NCH')}")
         e(f"s_cbranch_scc1 {same}")
-        e(f"s_mov_b32 {s('RC')}, 0")
-        self.next_coords("R")
-        self.request_tile_setup()
-        e(f"{same}:")
-
-    def advance_weights(self):
-        e = self.e
-        same = self.label("wsame")
-        e(f"s_add_u32 {s('WC')}, {s('WC')}, 1")
-        e(f"s_cmp_lt_u32 {s('WC')}, {s('NCH')}")
-        e(f"s_cbranch_scc1 {same}")
-        e(f"s_mov_b32 {s('WC')}, 0")
-        self.next_coords("W")
-        self.weight_tile_setup()
+        e(f"s_mov_b32 {s('NC')}, 0")
+        self.next_coords("N", "NCT_")
+        self.staging_tile_setup()
         e(f"{same}:")
 
     # ---- instruction groups
     def dma_items(self, wbuf):
-        """nine 1-KiB pieces of the weight stream's chunk -> weight area of buffer wbuf"""
+        """nine 1-KiB pieces of the staging chunk's weights -> weight area of buffer wbuf"""
         items = []
         for grp in range(3):
             base = ("WCH", "WCH1_", "WCH2_")[grp]
@@ -301,32 +293,29 @@ class Body:
                 items.append(g)
         return items
 
-    def halo_items(self, pset):
-        """six 16-byte loads of the request stream's chunk into staging set pset (+ the masks they were requested under)"""
+    def halo_items(self):
+        """ten 16-byte loads of the staging chunk's halo values"""
         items = []
         for i in range(NQ):
-            g = [f"v_mul_lo_u32 v{V_VOFF + i}, v{V_PIX + i}, {s('CBYTES')}", f"v_add_u32 v{V_VOFF + i}, v{V_VOFF + i}, v{V_C4X16}",
-                 f"v_mov_b32 v{V_SMSK[pset] + i}, v{V_MSK + i}"]
-            if EXP & 16:      # ablation: the same bytes as six fully coalesced 1-KiB instructions per wave (wrong data)
-                g += [f"v_lshlrev_b32 v{V_VOFF + i}, 4, v{V_TID}", f"v_add_u32 v{V_VOFF + i}, {4096 * i}, v{V_VOFF + i}"]
+            g = [f"v_mul_lo_u32 v{V_VOFF + i}, v{V_PIX + i}, {s('CBYTES')}", f"v_add_u32 v{V_VOFF + i}, v{V_VOFF + i}, v{V_C4X16}"]
             if i == NQ - 1:
-                g += [f"s_mov_b64 exec, {s2('M5')}"]
+                g += [f"s_mov_b64 exec, {s2('M9')}"]
             if not EXP & 2:
-                g += [f"global_load_dwordx4 v[{V_PIN[pset] + 4 * i}:{V_PIN[pset] + 4 * i + 3}], v{V_VOFF + i}, {s2('SRC')}"]
+                g += [f"global_load_dwordx4 v[{V_PIN + 4 * i}:{V_PIN + 4 * i + 3}], v{V_VOFF + i}, {s2('SRC')}"]
             if i == NQ - 1:
                 g += ["s_mov_b64 exec, -1"]
             items.append(g)
         return items
 
-    def commit_items(self, pset, buf):
-        """split + LDS write of staging set pset into the halo area of buffer buf"""
+    def commit_items(self, buf):
+        """split + LDS write of the staged quads into the halo area of buffer buf"""
         items = []
         for i in range(NQ):
-            p = V_PIN[pset] + 4 * i
+            p = V_PIN + 4 * i
             h, l, t = V_T, V_T + 2, V_T + 4
             if i % 2:
                 h, l, t = V_T + 8, V_T + 10, V_T + 12
-            g1 = [f"v_and_b32 v{p + j}, v{p + j}, v{V_SMSK[pset] + i}" for j in range(4)]
+            g1 = [f"v_and_b32 v{p + j}, v{p + j}, v{V_MSK + i}" for j in range(4)]
             g2 = [f"v_cvt_pk_bf16_f32 v{h}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{h + 1}, v{p + 2}, v{p + 3}",
                   f"v_lshlrev_b32 v{t}, 16, v{h}", f"v_and_b32 v{t + 1}, 0xffff0000, v{h}"]
             g3 = [f"v_lshlrev_b32 v{t + 2}, 16, v{h + 1}", f"v_and_b32 v{t + 3}, 0xffff0000, v{h + 1}",
@@ -335,7 +324,7 @@ class Body:
                   f"v_cvt_pk_bf16_f32 v{l}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{l + 1}, v{p + 2}, v{p + 3}"]
             wr = []
             if i == NQ - 1:
-                wr += [f"s_mov_b64 exec, {s2('M5')}"]
+                wr += [f"s_mov_b64 exec, {s2('M9')}"]
             wr += [(f"ds_write_b64 v{V_WHI[buf] + i}, v[{h}:{h + 1}]", ("W", i, 0)),
                    (f"ds_write_b64 v{V_WLO[buf] + i}, v[{l}:{l + 1}]", ("W", i, 1))]
             if i == NQ - 1:
@@ -343,97 +332,87 @@ class Body:
             items += [g1, g2, g3, g4, wr] if not EXP & 8 else []
         return items
 
-    def store_items(self, aset):
-        """the stores of the tile that accumulated in set `aset` (offsets V_SOFF, base OUTF: set by tile_end), ReLU on the way.
-        A block (mb, nb) = 32 channels x 32 pixels leaves through this wave's 4 KiB of LDS staging: as the MFMA leaves it, a store
-        instruction would write 16 bytes to each of 64 different 128-byte lines (measured: the 16 such stores per lane cost as much
-        as having no stores at all saves, 1.1 of 7.6 ms); transposed, lane l writes channel quad l & 7 of pixel 8 j + (l >> 3):
-        eight whole lines per instruction.  Per block: 16 v_accvgpr_read, 16 v_max, 4 ds_write_b128, 4 ds_read_b128, 4 stores."""
-        items = []
+    def store_tile(self):
+        """the stores of the tile that just ended (offsets V_SOFF, base OUTF: set by tile_end), ReLU on the way.  A block
+        (mb, nb) = 32 channels x 32 pixels leaves through this wave's 4 KiB of LDS staging: transposed, lane l writes channel quad
+        l & 7 of pixel 8 j + (l >> 3): eight whole 128-byte lines per store instruction."""
+        e = self.e
         ta, tb = V_T, V_T + 16
-        for nb in range(2):
+        for nb in range(4):
             for mb in range(2):
                 blk = nb * 2 + mb
-                a0 = A_ACC[aset] + (mb * 2 + nb) * 16
+                a0 = A_ACC + (mb * 4 + nb) * 16
                 for rq in range(4):
-                    items.append([f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}" for j in range(4)])
-                    items.append([f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}" for j in range(4)]
-                                 + [(f"ds_write_b128 v{V_SWA + rq}, v[{ta + 4 * rq}:{ta + 4 * rq + 3}]", ("SW", blk, rq))])
+                    for j in range(4):
+                        e(f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}")
+                    for j in range(4):
+                        e(f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}")
+                    self.lds_op(f"ds_write_b128 v{V_SWA + rq}, v[{ta + 4 * rq}:{ta + 4 * rq + 3}]", ("SW", blk, rq))
                 for j in range(4):
-                    items.append([(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", blk, j))])
+                    self.lds_op(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", blk, j))
                 for j in range(4):
-                    g = [("wait", ("SR", blk, j)), f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + nb * 4 + j}", "s_nop 0", "s_and_b64 exec, vcc, exec"]
-                    if EXP & 32:
-                        g += [f"v_lshlrev_b32 v{V_VOFF}, 4, v{V_LANE}", f"global_store_dwordx4 v{V_VOFF}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')} offset:{mb * 128}"]
-                    elif not EXP & 1:
-                        g += [f"global_store_dwordx4 v{V_SOFF + nb * 4 + j}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')} offset:{mb * 128}"]
-                    g += ["s_mov_b64 exec, -1"]
-                    items.append(g)
-        return items
+                    self.wait_lds(("SR", blk, j))
+                    e(f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + nb * 4 + j}")
+                    e("s_nop 0")
+                    e("s_and_b64 exec, vcc, exec")
+                    if not EXP & 1:
+                        e(f"global_store_dwordx4 v{V_SOFF + nb * 4 + j}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')} offset:{mb * 128}" + STORE_MOD)
+                    e("s_mov_b64 exec, -1")
+        self.wait_all_lds()
 
-    # ---- one chunk of the compute stream: reads buffer p; aset = accumulator set of its tile
-    def chunk(self, p, aset, stores=False):
-        """stores: this is the first chunk of a tile that has a predecessor -- the predecessor's stores ride behind taps 0..3"""
+    # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
+    def chunk(self, p):
         e = self.e
-        self.weight_source()
-        self.request_source()
-        dma = self.dma_items(p ^ 1)                      # weights of chunk g + 1
-        req = self.halo_items(p)                         # halo values of chunk g + 2 -> staging set p
-        com = self.commit_items(p ^ 1, p ^ 1)            # halo values of chunk g + 1 (set p ^ 1) -> buffer p ^ 1
-        sto = self.store_items(aset ^ 1) if stores else []
-        assert len(sto) in (0, 64)
+        self.staging_source()
+        dma = self.dma_items(p ^ 1)
+        req = self.halo_items()
+        com = self.commit_items(p ^ 1)
         for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
             self.lds_op(text, tag)
         for t in range(9):
             os_ = t & 1
             nxt = self.tap_reads(t + 1, p, os_ ^ 1) if t + 1 < 9 else []
-            sprinkle = [[] for _ in range(12)]
+            sprinkle = [[] for _ in range(24)]
             for m, rd in enumerate(nxt):
                 sprinkle[m].append(rd)
-            # order of the vector-memory operations of a chunk: [the previous tile's stores][9 DMA pieces][6 requests] -- the counted
-            # wait behind tap 4 then never waits for a request of THIS chunk, whether or not stores take part in the count
-            if sto and t < 4:                            # one block (16 groups) per tap
-                for k, g in enumerate(sto[16 * t:16 * (t + 1)]):
-                    sprinkle[min(11, 1 + (k * 11) // 16)].extend(g)
-            t_dma, t_req = (4, 4) if sto else (2, 3)
-            if t == t_dma:                               # 9 DMA groups
+            # the chunk's vector-memory instructions: 9 DMA pieces behind the second half of tap 0, the 10 halo requests behind taps
+            # 1 and 2.  Measured alternatives (16 frames 500 x 500, whole forward): everything one per MFMA from tap 0 on 7.53 ms; one
+            # every 4 / 6 / 8 / 10 MFMAs over taps 0..4 7.24 - 7.32 ms; this placement 7.05 - 7.09 ms.
+            if t == 0:
                 for k, g in enumerate(dma):
-                    sprinkle[k].extend(g)
-            if t == t_req:                               # 6 request groups -- AFTER the tap's DMA pieces when they share a tap: the
-                for k, g in enumerate(req):              # chunk's closing vmcnt(6) counts on the requests being the six newest operations
-                    sprinkle[9 + k // 2 if sto else 2 * k].extend(g)
-            if t >= 5 and com:                           # the 30 commit groups behind taps 5..8: 8 + 8 + 7 + 7
-                per = [8, 8, 7, 7][t - 5]
-                start = [0, 8, 16, 23][t - 5]
-                for k, g in enumerate(com[start:start + per]):
-                    sprinkle[k + 2].extend(g)
-            if t == 5:
-                # staging set p ^ 1 was requested during the previous chunk; newer vector-memory operations: this chunk's 9 DMA
-                # pieces and 6 requests
-                e("s_waitcnt vmcnt(15)")
+                    sprinkle[12 + k].extend(g)
+            if t in (1, 2):
+                for k, g in enumerate(req[(t - 1) * 5:t * 5]):
+                    sprinkle[12 + 2 * k].extend(g)
+            if t >= 6 and com:                           # the 50 commit groups behind taps 6..8: 17 + 17 + 16
+                start = [0, 17, 34][t - 6]
+                for k, g in enumerate(com[start:start + (17 if t < 8 else 16)]):
+                    sprinkle[6 + k].extend(g)
+            if t == 6:
+                e("s_waitcnt vmcnt(0)")                  # the staged values (requested four taps ago) and the weight pieces have landed
             self.wait_lds(("R", t, 3, 1))
-            self.tap_mfmas(aset, os_, sprinkle)
+            self.tap_mfmas(os_, sprinkle)
         self.wait_all_lds()
-        e("s_waitcnt vmcnt(6)")                          # the weight pieces of chunk g + 1 have landed (the six new requests may fly)
+        e("s_waitcnt vmcnt(0)")
         e("s_barrier")
-        self.advance_weights()
-        self.advance_request()
+        self.advance_staging()
 
-    def bias_init(self, aset):
-        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of both N-blocks"""
+    def bias_init(self):
+        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of the four N-blocks"""
         e = self.e
         e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")                        # CT * 64 floats
         e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_BIASA}")
         for mb in range(2):
-            for nb in range(2):
+            for nb in range(4):
                 for rq in range(4):
-                    b = A_ACC[aset] + (mb * 2 + nb) * 16 + 4 * rq
+                    b = A_ACC + (mb * 4 + nb) * 16 + 4 * rq
                     self.lds_op(f"ds_read_b128 a[{b}:{b + 3}], v{V_T} offset:{mb * 128 + rq * 32}", ("BI", mb, nb, rq))
-            self.wait_all_lds()
+                if nb % 2:
+                    self.wait_all_lds()
 
     def tile_end(self):
         """the finished tile's store state: OUTF and, per N-block and store j, this lane's byte offset (pixel 8 j + (lane >> 3) of
-        the block, channel quad lane & 7) or -1 outside the image; then the compute stream moves on"""
+        the block, channel quad lane & 7) or -1 outside the image; the stores; then the compute stream moves on"""
         e = self.e
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
@@ -446,14 +425,14 @@ class Body:
         e(f"s_add_u32 {s('OUTF')}, {s('OUTF')}, {s('T0')}")
         e(f"s_addc_u32 {s('OUTF1')}, {s('OUTF1')}, 0")
         e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
-        e(f"s_lshl_b32 {s('Y0')}, {s('TY')}, 4")
-        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 2")
+        e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 3")
         e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('Y0')}")                # first row of this wave
         for half in range(2):                                           # columns 8 half + (lane >> 3)
             e(f"v_add_u32 v{V_T + half}, {s('X0')}, v{V_L3}")
             if half:
                 e(f"v_add_u32 v{V_T + half}, 8, v{V_T + half}")
-        for nb in range(2):
+        for nb in range(4):
             for j in range(4):
                 row, half = 2 * nb + (j >> 1), j & 1
                 d = V_SOFF + nb * 4 + j
@@ -467,7 +446,11 @@ class Body:
                 e(f"v_mul_lo_u32 v{V_T + 2}, v{V_T + 2}, {s('T1')}")    # * COUT * 4
                 e(f"v_add_u32 v{V_T + 2}, v{V_T + 2}, v{V_L7X16}")
                 e(f"v_cndmask_b32 v{d}, -1, v{V_T + 2}, vcc")
-        self.next_coords("")
+        e("s_nop 7")
+        e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
+        self.store_tile()
+        e("s_barrier")                                                # (the staging area is buffer 1's halo region: nobody may commit the next
+        self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
 
 
 def generate():
@@ -484,26 +467,29 @@ def generate():
         e(f"s_load_dword {s(dst)}, {s2('KARG')}, {ARG[field]}")
     e(f"v_mov_b32 v{V_TID}, %[tid]")
     e(f"v_and_b32 v{V_LANE}, 63, v{V_TID}")
-    # per-lane constants: the C++ prologue left 18 words per lane at the start of LDS ([word][256 threads])
+    # per-lane constants: the C++ prologue left CONST_WORDS words per lane at the start of LDS ([word][256 threads])
     e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
     e(f"v_add_u32 v{V_T}, {s('LDS0')}, v{V_T}")
     for i in range(NQ):
         e(f"ds_read_b32 v{V_WHI[0] + i}, v{V_T} offset:{1024 * i}")
-        e(f"ds_read_b32 v{V_HRC + i}, v{V_T} offset:{1024 * (6 + i)}")
-        e(f"ds_read_b32 v{V_BOFS[0] + i}, v{V_T} offset:{1024 * (12 + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(NQ):
+        e(f"ds_read_b32 v{V_HRC + i}, v{V_T} offset:{1024 * (10 + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(6):
+        e(f"ds_read_b32 v{V_BOFS[0] + i}, v{V_T} offset:{1024 * (20 + i)}")
     for i in range(4):
-        e(f"ds_read_b32 v{V_SWA + i}, v{V_T} offset:{1024 * (18 + i)}")
-        e(f"ds_read_b32 v{V_SRA + i}, v{V_T} offset:{1024 * (22 + i)}")
+        e(f"ds_read_b32 v{V_SWA + i}, v{V_T} offset:{1024 * (26 + i)}")
+        e(f"ds_read_b32 v{V_SRA + i}, v{V_T} offset:{1024 * (30 + i)}")
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")                                                    # (everybody has read its constants: the buffers may be written)
     for i in range(NQ):
         e(f"v_xor_b32 v{V_WLO[0] + i}, 32, v{V_WHI[0] + i}")
         e(f"v_add_u32 v{V_WHI[1] + i}, {BUF}, v{V_WHI[0] + i}")
         e(f"v_add_u32 v{V_WLO[1] + i}, {BUF}, v{V_WLO[0] + i}")
+    for i in range(6):
         e(f"v_add_u32 v{V_BOFS[1] + i}, {BUF}, v{V_BOFS[0] + i}")
     e(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE}")                           # lane * 16
-    e(f"v_and_b32 v{V_COL}, 15, v{V_LANE}")
-    e(f"v_bfe_u32 v{V_ROW2}, v{V_LANE}, 4, 1")                         # (n >> 4) & 1
     e(f"v_lshrrev_b32 v{V_HH16}, 5, v{V_LANE}")
     e(f"v_lshlrev_b32 v{V_HH16}, 4, v{V_HH16}")                        # hh * 16 bytes
     e(f"v_lshrrev_b32 v{V_L3}, 3, v{V_LANE}")
@@ -513,14 +499,19 @@ def generate():
     e(f"v_lshlrev_b32 v{V_C4X16}, 4, v{V_C4X16}")                      # (tid & 3) * 16 bytes
     e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216")
     e(f"v_add_u32 v{V_DMA}, {s('T0')}, v{V_T}")                         # this lane's 16 B of the wave's nine 1-KiB pieces (global offset)
-    e(f"v_add_u32 v{V_AOFS[0]}, {s('LDS0')}, v{V_T}")                   # A reads: LDS base + lane * 16 (+ the halo region as an immediate)
+    e(f"s_add_u32 {s('T1')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"v_add_u32 v{V_AOFS[0]}, {s('T1')}, v{V_T}")                      # A reads: the buffer's weight area + lane * 16
     e(f"v_add_u32 v{V_AOFS[1]}, {BUF}, v{V_AOFS[0]}")
     e(f"s_add_u32 {s('LDSW')}, {s('LDS0')}, {HALO_BYTES}")
     e(f"s_add_u32 {s('LDSW')}, {s('LDSW')}, {s('T0')}")                 # LDS address of this wave's weight pieces in buffer 0
     e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
     e(f"v_add_u32 v{V_BIASA}, {s('T0')}, v{V_HH16}")                    # bias table + hh * 16
-    e(f"s_cmp_eq_u32 {s('WAVE')}, 0")                                  # quad 5 exists for lanes 0..15 of wave 0 only
-    e(f"s_cselect_b64 {s2('M5')}, 0xffff, 0")
+    # quad 9 exists for threads 0..143: waves 0 and 1, lanes 0..15 of wave 2
+    e(f"s_cmp_lt_u32 {s('WAVE')}, 2")
+    e(f"s_cselect_b64 {s2('M9')}, -1, 0")
+    e(f"s_cmp_eq_u32 {s('WAVE')}, 2")
+    e(f"s_cselect_b64 {s2('TA')}, 0xffff, 0")
+    e(f"s_or_b64 {s2('M9')}, {s2('M9')}, {s2('TA')}")
     e("s_waitcnt lgkmcnt(0)")
     e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
     e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 4")
@@ -540,73 +531,40 @@ def generate():
     e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
     e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
     e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
-    # the streams start on the workgroup's first tile
+    # the staging stream starts on the workgroup's first tile
     e(f"s_mov_b32 {s('LEFT')}, {s('NTL')}")
-    for p in ("R", "W"):
-        for c in ("TX", "TY", "CT", "FR"):
-            e(f"s_mov_b32 {s(p + c)}, {s(c)}")
-        e(f"s_mov_b32 {s(p + 'LEFT')}, {s('NTL')}")
-    e(f"s_mov_b32 {s('RC')}, 0")
-    e(f"s_mov_b32 {s('WC')}, 0")
-    b.request_tile_setup()
-    b.weight_tile_setup()
-    # chunk 0: weights -> buffer 0, halo -> set 0 -> buffer 0 (all exposed: once per workgroup); chunk 1's halo requested into set 1
-    b.weight_source()
-    b.request_source()
+    e(f"s_mov_b32 {s('NLEFT')}, {s('NTL')}")
+    for n_, c_ in (("NTX", "TX"), ("NTY", "TY"), ("NCT_", "CT"), ("NFR", "FR")):
+        e(f"s_mov_b32 {s(n_)}, {s(c_)}")
+    e(f"s_mov_b32 {s('NC')}, 0")
+    b.staging_tile_setup()
+    # chunk 0 -> buffer 0, all exposed (once per workgroup)
+    b.staging_source()
     for g in b.dma_items(0):
         b.emit_group(g)
-    for g in b.halo_items(0):
+    for g in b.halo_items():
         b.emit_group(g)
-    b.advance_weights()
-    b.advance_request()
     e("s_waitcnt vmcnt(0)")
-    for g in b.commit_items(0, 0):
+    for g in b.commit_items(0):
         b.emit_group(g)
-    b.request_source()
-    for g in b.halo_items(1):
-        b.emit_group(g)
-    b.advance_request()
+    b.advance_staging()
     b.wait_all_lds()
-    e("s_waitcnt vmcnt(6)")
     e("s_barrier")
 
-    # ================= tile loop, unrolled over the two accumulator sets; a tile's first chunk exists with and without the
-    # previous tile's stores riding on it (the workgroup's first tile has no predecessor)
-    e(f"s_mov_b32 {s('SM0')}, 0")                                     # SM0: 1 once a tile has finished (its stores are pending)
-    for aset in (0, 1):
-        e(f"S2LK_TILE{aset}:")
-        b.bias_init(aset)
-        e(f"s_mov_b32 {s('CC')}, 0")
-        e(f"s_cmp_eq_u32 {s('SM0')}, 0")
-        e(f"s_cbranch_scc1 S2LK_FIRST{aset}")
-        saved = list(b.lds)
-        b.chunk(0, aset, stores=True)
-        e(f"s_branch S2LK_ODD{aset}")
-        e(f"S2LK_PAIR{aset}:")
-        e(f"S2LK_FIRST{aset}:")
-        b.lds = list(saved)
-        b.chunk(0, aset)
-        e(f"S2LK_ODD{aset}:")
-        b.chunk(1, aset)
-        e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
-        e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
-        e(f"s_cbranch_scc1 S2LK_PAIR{aset}")
-        b.tile_end()
-        e(f"s_mov_b32 {s('SM0')}, 1")
-        e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
-        e(f"s_cmp_eq_u32 {s('NTL')}, 0")
-        e(f"s_cbranch_scc1 S2LK_FLUSH{aset}")
-    e("s_branch S2LK_TILE0")
-    # ================= the last tile's stores
-    for aset in (0, 1):
-        e(f"S2LK_FLUSH{aset}:")
-        e("s_nop 7")
-        e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
-        for g in b.store_items(aset):
-            b.emit_group(g)
-        b.wait_all_lds()
-        e("s_branch S2LK_END")
-    e("S2LK_END:")
+    # ================= tile loop
+    e("S2LK_TILE:")
+    b.bias_init()
+    e(f"s_mov_b32 {s('CC')}, 0")
+    e("S2LK_PAIR:")
+    b.chunk(0)
+    b.chunk(1)
+    e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
+    e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
+    e("s_cbranch_scc1 S2LK_PAIR")
+    b.tile_end()
+    e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
+    e(f"s_cmp_gt_u32 {s('NTL')}, 0")
+    e("s_cbranch_scc1 S2LK_TILE")
     e("s_waitcnt vmcnt(0)")
     return b.L
 
@@ -619,7 +577,7 @@ OPERANDS = """      :
 
 def main(objdir):
     lines = generate()
-    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1)]
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
     clob += ["vcc", "scc", "memory"]
     out = ["// GENERATED by csrc/gen_conv16_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]

@@ -95,7 +95,7 @@ def test_split_persistent_kernel_equals_the_one_tile_form(unet, shape):
     finally:
         lib.s2l_set_unet_split_kernel(0)
     assert float(ref.abs().max()) > 0 and float(ref_dx.abs().max()) > 0
-    assert lib.s2l_set_unet_split_kernel(2) == -2
+    assert lib.s2l_set_unet_split_kernel(3) == -2
 
 
 def test_persistent_kernel_random_shapes_race_screen(unet):
@@ -123,3 +123,26 @@ def test_persistent_kernel_random_shapes_race_screen(unet):
                 assert torch.equal(res[0][j], res[1][j]) and torch.equal(res[0][j], res[2][j]), (F, H, Wd, j)
     finally:
         lib.s2l_set_unet_split_kernel(0)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4), (1, 16, 16), (1, 33, 17), (2, 20, 36), (3, 64, 64), (1, 131, 77), (3, 37, 501), (2, 500, 500),
+                                   (40, 96, 96), (7, 200, 333)], ids=lambda s: "x".join(map(str, s)))
+def test_generated_assembly_split_convolution_equals_the_cpp_kernel(unet, shape):
+    """conv16_asm_kernel (csrc/gen_conv16_body.py: 32 x 16 tiles, four waves, operands and accumulators in AGPRs, one chunk stream
+    per workgroup, stores through an LDS transpose; selector 2) performs conv3x3_split_kernel's arithmetic in its order: the
+    split-mode forward is THE SAME BITS -- single-tile frames, partial tiles on every border, one tile per workgroup and many
+    (the streams' tile crossings and the store staging that aliases a halo buffer), virtual-concat layers, both pooled layers --
+    and it is repeatable (a counted wait that is one short shows as run-to-run differences)."""
+    F, H, Wd = shape
+    dev = next(unet.parameters()).device
+    x = torch.from_numpy(np.random.default_rng(H * 977 + Wd).random((F, H, Wd, 3), dtype=np.float32)).to(dev)
+    lib = _abi.load()
+    try:
+        assert lib.s2l_set_unet_split_kernel(0) == 0
+        ref = unet.forward_nhwc(x, precision="split").clone()
+        assert lib.s2l_set_unet_split_kernel(2) == 0
+        for _ in range(3):
+            assert torch.equal(unet.forward_nhwc(x, precision="split"), ref)
+    finally:
+        lib.s2l_set_unet_split_kernel(0)
+    assert float(ref.abs().max()) > 0

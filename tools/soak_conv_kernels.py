@@ -2,8 +2,8 @@
 (DESIGN.md §4.1, §4.5, §4.6): random shapes, every result compared BIT FOR BIT with an independent kernel that performs the same
 arithmetic, and with a second run of itself.
 
-  conv    conv3x3_split_kernel (persistent, bf16 operands): split-bf16 forward and the plain-bf16 training chain,
-          persistent form vs the one-tile-per-workgroup kernels (the soak that found round 3's ~1 %-of-shapes copy race);
+  conv    conv3x3_split_kernel (persistent, bf16 operands) and conv16_asm_kernel (generated assembly): split-bf16 forward and the
+          plain-bf16 training chain, against the one-tile-per-workgroup kernels (the soak that found round 3's ~1 %-of-shapes copy race);
   render  render_tiles_kernel / render16_tiles_kernel<long | wide | single>: random (H, W, F), the three tile shapes against each other and the
           auto-picked one, each twice (every sample column sees the same MFMA sequence in every shape);
   bf16    fwd_asm_bf16_kernel / bwd_asm_bf16_kernel: random (h, w, B) rows, assembly vs the C++ kernels (activation images,
@@ -40,15 +40,15 @@ def soak_conv(dev, rounds, seed=0, log=print):
             x = torch.rand(F, H, Wd, 3, device=dev)
             d = torch.randn(F, H, Wd, 3, device=dev)
             res = []
-            for kind in (1, 0, 0):
+            for kind in (1, 0, 0, 2, 2):      # one tile per workgroup; the persistent C++ kernel twice; the generated-assembly kernel twice
                 _abi.check(lib.s2l_set_unet_split_kernel(kind), "kind")
                 a = u.forward_nhwc(x, precision="split").clone()
                 o, ctx = u.forward_saved_nhwc(x, precision="bf16")
                 res.append((a, o.clone(), u.backward_input(ctx, d).clone()))
-            ok = all(torch.equal(res[0][j], res[k][j]) for j in range(3) for k in (1, 2))
+            ok = all(torch.equal(res[0][j], res[k][j]) for j in range(3) for k in (1, 2, 3, 4))
             if not ok:
                 bad.append(("conv", F, H, Wd))
-                log("MISMATCH conv", F, H, Wd, [[torch.equal(res[0][j], res[k][j]) for j in range(3)] for k in (1, 2)])
+                log("MISMATCH conv", F, H, Wd, [[torch.equal(res[0][j], res[k][j]) for j in range(3)] for k in (1, 2, 3, 4)])
     finally:
         lib.s2l_set_unet_split_kernel(0)
     return bad
