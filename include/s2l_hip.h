@@ -337,7 +337,8 @@ int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps, uint16_t* 
 int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, const float* x, float* work, float* out, int height,
                            int width, int64_t n_frames, s2l_stream_t stream);
 /* Which kernel runs the split-bf16 layers: 0 (default) the persistent form with a two-chunk-deep operand pipeline, 1 the
- * one-tile-per-workgroup form it replaced.  Same arithmetic in the same order: the outputs are the same bits (a test aid). */
+ * one-tile-per-workgroup form it replaced, 2 the generated-assembly form (csrc/conv16.hip; layers it does not cover run as 0).
+ * Same arithmetic in the same order: the outputs are the same bits (a test aid).  Any other value: S2L_E_SIZE. */
 int s2l_set_unet_split_kernel(int kind);
 
 /* TRAIN mode of the same network, as the reference runs it until `it > 100000` (train.py:188-197): every BatchNorm2d normalises

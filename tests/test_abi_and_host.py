@@ -75,7 +75,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_unet_train_forward_bf16(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -1
     assert lib.s2l_unet_train_forward_bf16(one, odd, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -3
     assert lib.s2l_unet_train_forward(one, tbl, 1e-5, 0.1, 0, one, one, one, one, 3, 8, 1, null) == -2             # H < 4
-    assert lib.s2l_set_unet_split_kernel(2) == -2 and lib.s2l_set_unet_split_kernel(0) == 0
+    assert lib.s2l_set_unet_split_kernel(3) == -2 and lib.s2l_set_unet_split_kernel(0) == 0
     # F one-frame calls in one set of launches (every frame its own statistics group)
     assert lib.s2l_unet_train_backward_frames(one, null, tbl, one, one, one, one, null, 8, 8, 2, null) == -1     # input gradient is the output
     assert lib.s2l_unet_train_forward_frames(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 0, null) == -2
