@@ -391,6 +391,32 @@ int s2l_unet_train_backward_frames(const float* packed_raw, const uint16_t* pack
                                    const float* x, const float* saved, const float* d_out, float* work, float* d_x, int height,
                                    int width, int64_t n_frames, s2l_stream_t stream);
 
+/* The same pair on HALF-WIDTH TENSORS (csrc/unet_half.inc, csrc/convh.hip): every tensor between the kernels -- pre-BatchNorm outputs,
+ * activations, pooled / up-sampled copies, gradients -- is bf16 NHWC; bf16 operands, fp32 accumulation, fp32 per-frame statistics (of
+ * the bf16-rounded pre-BatchNorm tensor), results rounded to nearest even on store; x, out, d_out, d_x stay fp32.  Replaces the same
+ * reference lines as s2l_unet_train_forward_frames / _backward_frames (the frozen net of training.py:436-459 left in .train() by
+ * Trainer.train_step: tf_nerf.py:387 -> SimpleUnetLight.py:99-111 with batch statistics per one-frame call) at about half their HBM and
+ * texture-path traffic.  packed16_raw: s2l_unet_pack16 with bn_eps < 0 (required).  saved: ..._h_saved_halves halves; scratch:
+ * ..._h_scratch_floats floats; work: ..._h_work_halves halves.  A geometry the convolution kernel does not take: S2L_E_SIZE. */
+int64_t s2l_unet_train_frames_h_saved_halves(int height, int width, int64_t n_frames);
+int64_t s2l_unet_train_frames_h_scratch_floats(int64_t n_frames);
+int64_t s2l_unet_train_frames_h_work_halves(int height, int width, int64_t n_frames);
+int s2l_unet_train_forward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
+                                    float momentum, int update_running, const float* x, uint16_t* saved, float* scratch, float* out,
+                                    int height, int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_train_backward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                     const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x, int height, int width,
+                                     int64_t n_frames, s2l_stream_t stream);
+/* One 3x3 layer (1..9) of that chain on its own: out [F,H,W,cout] bf16 = conv(concat(inA, inB) bf16, the layer's raw bf16 weights);
+ * transposed != 0: the layer's input gradient (inA = the gradient of its output; gate, or NULL: [F,H,W,cin] bf16, out = 0 where
+ * gate <= 0).  s2l_debug_conv_layer_f32: the fp32-tensor kernel it replaces (same operands, same accumulation order: on
+ * bf16-representable inputs s2l_convh_layer's output is the round-to-nearest-even bf16 of its output -- the tests' comparator). */
+int s2l_convh_layer(const uint16_t* packed16_raw, int layer, int transposed, const uint16_t* inA, int CA, const uint16_t* inB, int CB,
+                    const uint16_t* gate, uint16_t* out, int height, int width, int64_t n_frames, s2l_stream_t stream);
+int s2l_debug_conv_layer_f32(const float* packed_raw, const uint16_t* packed16_raw, int layer, int transposed, const float* inA, int CA,
+                             const float* inB, int CB, const float* gate, float* out, int height, int width, int64_t n_frames,
+                             s2l_stream_t stream);
+
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
  * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with
  * F.interpolate(mode='bilinear', align_corners=False), no antialiasing).  src [F,src_h,src_w,3]; box = data['canonical_face_bbox'];

@@ -83,6 +83,16 @@ EXPORTS = {
                                               c_int64, c_void_p]),
     "s2l_unet_backward_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int64, c_void_p]),
+    "s2l_unet_train_frames_h_saved_halves": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_frames_h_scratch_floats": (c_int64, [c_int64]),
+    "s2l_unet_train_frames_h_work_halves": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_forward_frames_h": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_backward_frames_h": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                 c_int64, c_void_p]),
+    "s2l_convh_layer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_debug_conv_layer_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                         c_int64, c_void_p]),
     "s2l_set_unet_conv_kernel": (c_int, [c_int]),
     "s2l_set_unet_split_kernel": (c_int, [c_int]),
     "s2l_set_render_shape": (c_int, [c_int]),

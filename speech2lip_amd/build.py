@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libs2l_hip.so")
 RESOURCES = os.path.join(PKG, "kernel_resources.json")      # per-kernel registers / spills / scratch / LDS of the last build
-SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip", "render16.hip", "conv16.hip"]
+SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip", "render16.hip", "conv16.hip", "convh.hip"]
 # -ffp-contract=off: parity needs the reference's separate roundings (x*y then +z); FMAs are explicit fmaf()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
@@ -68,6 +68,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         gen_render16_body.main_all(objdir)     # render16_body_{long,wide,single}.inc: the split-bf16 speed mode (render16.hip)
         import gen_conv16_body
         gen_conv16_body.main(objdir)           # conv16_body.inc: the split-bf16 3x3 convolution of the U-Net's speed mode (conv16.hip)
+        import gen_convh_body
+        gen_convh_body.main(objdir)            # convh_body.inc: the 3x3 convolution on bf16 tensors of the half-width training chain (convh.hip)
         import gen_conv_body               # ... and so are the U-Net's fp32 3x3 convolutions (unet.hip)
         gen_conv_body.main(objdir)
         import gen_fwd16_body              # ... and the bf16 training forward (train_bf16.hip)

@@ -1,0 +1,24 @@
+// Arguments of s2l::convh_asm_kernel (csrc/convh.hip): the generated-assembly 3x3 convolution on half-width (bf16) tensors.  The
+// assembly body loads the fields from the kernarg segment by offset (gen_convh_body.py: ARG) -- keep the order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace s2l {
+
+struct ConvHArgs {
+  const uint16_t* inA;     // [F,H,W,CA] bf16
+  const uint16_t* inB;     // [F,H,W,CB] or null (virtual concat: channels of A first; CB == CA)
+  const uint16_t* w16;     // s2l_unet_pack16 chunks of this layer: [rows/64][k/32][tap 9][k-step 2][block 2][lane 64][8]
+  const float* bias;       // [cout] or null
+  uint16_t* out;           // [F,H,W,cout] bf16
+  const uint16_t* gate;    // or null: [F,H,W,cout] bf16; out = gate > 0 ? value : 0
+  int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;      // tiles of 32 rows x 16 columns
+  int relu;                // 1: max(0, .) before the conversion
+  int n_frames;
+};
+
+// 0 if the launch was taken (*launched) or does not fit the kernel (!*launched)
+int launch_convh(const ConvHArgs& a, hipStream_t st, bool* launched);
+
+}  // namespace s2l

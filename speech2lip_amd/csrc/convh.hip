@@ -1,0 +1,108 @@
+// The 3x3 convolution of the U-Net's training chain on HALF-WIDTH tensors (bf16 NHWC activations and gradients in HBM) as a
+// generated-assembly kernel: csrc/gen_convh_body.py has the design, the register map and the schedule.  Replaces, inside
+// `SimpleUnetLight.forward` / its autograd backward in TRAIN mode (SimpleUnetLight.py:16-111 applied at tf_nerf.py:387 by the frozen
+// net of training.py:436-459 after `it > 100000`), one `nn.Conv2d(3x3, padding=1, bias=False)` or its input gradient.
+#include "s2l_common.h"
+#include "convh.h"
+
+namespace s2l {
+
+static_assert(offsetof(ConvHArgs, inA) == 0 && offsetof(ConvHArgs, inB) == 8 && offsetof(ConvHArgs, w16) == 16 &&
+              offsetof(ConvHArgs, bias) == 24 && offsetof(ConvHArgs, out) == 32 && offsetof(ConvHArgs, gate) == 40 &&
+              offsetof(ConvHArgs, CA) == 48 && offsetof(ConvHArgs, CB) == 52 && offsetof(ConvHArgs, cout) == 56 &&
+              offsetof(ConvHArgs, H) == 60 && offsetof(ConvHArgs, W) == 64 && offsetof(ConvHArgs, tiles_x) == 68 &&
+              offsetof(ConvHArgs, tiles_y) == 72 && offsetof(ConvHArgs, n_ct) == 76 && offsetof(ConvHArgs, relu) == 80,
+              "gen_convh_body.py (ARG) loads these fields from the kernarg segment by offset");
+
+constexpr int kCHTileH = 32;      // tile = 32 rows x 16 columns (gen_convh_body.py: TILE_H)
+constexpr int kCHHalo = (kCHTileH + 2) * 18 * 64, kCHW = 9 * 2 * 2 * 64 * 16, kCHBuf = kCHHalo + kCHW;
+constexpr int kCHLds = 2 * kCHBuf + 1024;      // two buffers + the bias table (the store staging aliases buffer 1's halo area)
+static_assert(kCHLds <= 160 * 1024, "LDS budget");
+
+__global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();   // the body loads the ConvHArgs fields itself (s_load)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ch_smem);
+  // this workgroup's tiles: a contiguous range, tile t = ((frame * n_ct + ct) * tiles_y + ty) * tiles_x + tx
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
+  const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
+  if (tile0 >= tile_end) return;
+  int t = tile0;
+  const int tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
+  t /= a.tiles_x;
+  const int ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
+  t /= a.tiles_y;
+  const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
+  const int fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
+  const int ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
+  // per-lane constants; they reach the assembly body through LDS ([word 28][thread 256] at the start of buffer 0; the body reads them
+  // first).  Halo DMA instruction i of wave w fills slots (10 w + i) * 64 + lane: slot s = 16 bytes at s * 16 of the halo area = pixel
+  // s >> 2 (row-major, 18 columns), physical segment s & 3 = logical segment (channels 8 seg .. + 7 of the chunk) ^ ((col >> 2) & 3).
+  uint32_t* cst = reinterpret_cast<uint32_t*>(ch_smem);
+  constexpr int kSlots = kCHHalo / 16;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int sl = (wave * 10 + i) * 64 + lane;
+    const int pi = sl >> 2, row = pi / 18, col = pi % 18, seg = (sl & 3) ^ ((col >> 2) & 3);
+    cst[i * 256 + tid] = sl < kSlots ? (uint32_t)(col | (row << 8) | (seg << 16)) : 0x80000000u;
+  }
+  // operand reads: lane (n = lane & 31, hh = lane >> 5): pixel (row 8 wave + (n >> 4) [+ 2 blk + dy as an immediate], col (n & 15) + dx),
+  // 16-byte segment (2 ks + hh) ^ swizzle
+  {
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int col = (n & 15) + dx, row = 8 * wave + (n >> 4);
+        cst[(10 + dx * 2 + ks) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * ks + hh) ^ ((col >> 2) & 3)) << 4));
+      }
+  }
+  // store staging (this wave's 4 KiB at the start of buffer 1: [32 pixels][64 channels] bf16, 16-byte piece index ^ ((pixel >> 1) & 7)):
+  // write address of piece pc = 4 mb + rq (pixel n = lane & 31, channels 8 pc + 4 hh ..: 8 bytes), read address of store j (pixel
+  // 8 j + (lane >> 3), piece lane & 7)
+  {
+    const uint32_t stg = lds0 + kCHBuf + wave * 4096;
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) cst[(16 + pc) * 256 + tid] = stg + (uint32_t)(n * 128 + ((pc ^ ((n >> 1) & 7)) << 4) + hh * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = 8 * j + (lane >> 3);
+      cst[(24 + j) * 256 + tid] = stg + (uint32_t)(px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the constants are in LDS (each lane reads back only its own words)
+#include "convh_body.inc"
+}
+
+// 0 if the launch was taken.  Conditions: an even number of 32-channel chunks, a concatenation of two equally wide tensors, cout a
+// multiple of 64 (<= 256), frames small enough for 32-bit in-frame byte offsets.
+int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
+  *launched = false;
+  ConvHArgs a = a0;
+  a.tiles_x = (a.W + 15) / 16;
+  a.tiles_y = (a.H + kCHTileH - 1) / kCHTileH;
+  a.n_ct = a.cout / 64;
+  const int nch = (a.CA + a.CB) / 32;
+  const int cmax = a.CA > a.cout ? a.CA : a.cout;
+  if ((a.CA + a.CB) % 32 != 0 || nch % 2 != 0 || a.CA % 32 != 0 || !(a.CB == 0 || (a.CB == a.CA && a.inB)) || a.cout % 64 != 0 ||
+      a.n_ct > 4 || a.n_ct < 1 || (int64_t)a.H * a.W * cmax * 2 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames >= 0x7fffffffLL ||
+      a.n_frames <= 0 || a.H > 255 * 32 || a.W > 255 * 16)
+    return S2L_OK;
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
+  if (total >= 0x7fffffff) return S2L_OK;
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  static LdsOptIn flag;
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag, dev))) return rc;
+  hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
+  *launched = true;
+  return (int)hipGetLastError();
+}
+
+}  // namespace s2l

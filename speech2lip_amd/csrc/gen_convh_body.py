@@ -1,0 +1,591 @@
+"""Generates convh_body.inc: the body of s2l::convh_asm_kernel (csrc/convh.hip) -- the 3x3 convolution of the U-Net's training chain on
+HALF-WIDTH TENSORS: bf16 NHWC activations / gradients in HBM, bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation, bf16 out.
+
+Why: the bf16-operand convolutions over fp32 tensors (conv3x3_split_kernel<.., false>, csrc/unet.hip) are bound by the CU's texture path,
+not by the matrix pipe (~16 B/clk/CU; a 32-channel chunk moves 78 KiB of fp32 halo + 36 KiB of weights next to 4.6 k MFMA
+cycles, and a 64 -> 64 layer's tile stores 128 KiB per 9.2 k cycles).  With bf16 tensors every byte count but the weights' halves, and the
+halo tile needs no registers and no VALU: its 16-byte pieces go from global memory straight to their (swizzled) LDS slots by LDS-DMA --
+the lane -> address map is free, so the swizzle is a permutation of which lane fetches which piece.
+
+Arithmetic: per 32-channel chunk and tap two k-steps (channels 16 ks + 8 hh + j of the chunk), acc += A[ks] B[ks], taps 0..8 in order --
+conv3x3_bf16_kernel's order (csrc/unet.hip), so on bf16-representable inputs the fp32 accumulators are THE SAME BITS and the output is
+their round-to-nearest-even bf16 (tests/test_gpu_unet_half.py).  Weights: s2l_unet_pack16's blob ([cout/64][cin/32][tap 9][k-step 2]
+[block 2][lane 64][8]; its transposed half for the input gradients).  Epilogue: acc (+ bias) -> max(lower bound) -> bf16 -> zero where
+gate <= 0 (the ReLU mask of the activation that fed the layer: input-gradient launches) -> NHWC.
+
+Shape of the work = gen_conv16_body.py v4 (32 x 16-pixel tiles x 64 output channels, four waves, accumulators and both operand sets in
+AGPRs, two LDS buffers of halo 34 x 18 pixels x 64 B + weights 36 KiB, the workgroup's chunks as ONE stream staged a chunk ahead, one
+barrier per chunk, stores through an LDS transpose: a pixel's 64 channels = one 128-byte line).  What differs:
+  * halo: ten LDS-DMA instructions per wave and chunk (slot s = 16 bytes at s * 16 of the halo area = pixel s >> 2, physical segment
+    s & 3 = logical segment ^ ((column >> 2) & 3)); pixels outside the image: the lane is masked off and a ds_write zeroes its slot;
+  * 16 MFMAs per tap (2 k-steps x 2 M-blocks x 4 N-blocks);
+  * the gate's sixteen 16-byte pieces per lane are requested during the tile's last chunk.
+
+Register map (per wave): a0-127 acc[mb][nb][16] | a128-175, a176-223 two operand sets (A[ks][mb] 4 x 4, B[ks][nb] 8 x 4) | VGPRs: names below."""
+import os
+import sys
+
+TILE_H = 32
+HALO_ROWS = TILE_H + 2
+HALO_BYTES, W_BYTES = HALO_ROWS * 18 * 64, 9 * 2 * 2 * 64 * 16  # 39 168 + 36 864
+N_SLOTS = HALO_BYTES // 16                                      # 2 448
+BUF = HALO_BYTES + W_BYTES                                      # 76 032
+BIAS_OFF = 2 * BUF                                              # 256 floats
+LDS_BYTES = BIAS_OFF + 1024
+STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 4 waves x 4 KiB
+NI = 10                                                         # halo DMA instructions per wave (wave w: slots 640 w ..)
+CONST_WORDS = 28                                                # per lane, from the C++ prologue: hrc[10], bofs[6], swa[8], sra[4]
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads
+
+# ---- registers
+A_ACC = 0
+A_OPS = (128, 176)              # operand set: A[ks][mb] at + (ks * 2 + mb) * 4, B[ks][nb] at + 16 + (ks * 4 + nb) * 4
+A_LAST = 223
+V_VOFF = 0                      # 10: byte offset of this lane's piece of DMA instruction i from the chunk's source pointer (staging tile)
+V_HRC = 10                      # 10: col | row << 8 | logical segment << 16, or negative: no such slot
+V_VALID, V_ZMASK = 20, 21       # bit i: the piece is inside the image / is a halo slot outside it (zeroed)
+V_SLOT = (22, 23)               # LDS address of slot (640 wave + lane) per buffer
+V_Z = 24                        # 4 zeros
+V_BOFS = (28, 34)
+V_AOFS = (40, 41)
+V_LANE, V_TID, V_HH16, V_DMA, V_BIASA, V_L3, V_L7X16, V_ONES, V_FFFF = 42, 43, 44, 45, 46, 47, 48, 49, 50
+V_SWA = 52                      # 8: staging write addresses per piece mb * 4 + rq
+V_SRA = 60                      # 4: staging read addresses per store j
+V_T = 64                        # temporaries 64..127
+V_SOFF = 128                    # 16: store byte offsets [nb][j] of the compute tile (-1: no store for this lane)
+V_G = 144                       # 64: gate pieces [nb][j][4]
+V_LAST = 207
+
+
+def _scalars(first, singles, pairs, skip=(32, 33)):
+    m, r = {}, first
+    for n in pairs:
+        while (r & 1) or r in skip or (r + 1) in skip:
+            r += 1
+        m[n], m[n + "1"] = r, r + 1
+        r += 2
+    for n in singles:
+        while r in skip:
+            r += 1
+        m[n] = r
+        r += 1
+    return m
+
+
+S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA WAVE LDS0 RELU CA2 LDSW LDSH T0 T1 T2 T3 "
+                          "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0").split(),
+             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "GATEF",
+                    "EX", "TA", "TB"))
+S_LAST = max(S.values())
+assert S_LAST <= 100, S_LAST
+
+# byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
+ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
+       "tiles_y": 72, "n_ct": 76, "relu": 80}
+
+
+def s(n):
+    return f"s{S[n]}"
+
+
+def s2(n):
+    return f"s[{S[n]}:{S[n] + 1}]"
+
+
+class Body:
+    def __init__(self):
+        self.L, self.lds, self.nlabel = [], [], 0
+
+    def e(self, t):
+        self.L.append(t)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"S2LH_{stem}_{self.nlabel}"
+
+    def lds_op(self, text, tag):
+        self.e(text)
+        self.lds.append(tag)
+
+    def wait_lds(self, tag):
+        if tag not in self.lds:
+            return
+        newer = len(self.lds) - 1 - self.lds.index(tag)
+        assert newer <= 15, newer
+        self.e(f"s_waitcnt lgkmcnt({newer})")
+        self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    def wait_all_lds(self):
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.lds = []
+
+    def emit_group(self, g):
+        for it in g:
+            if isinstance(it, tuple) and it[0] == "wait":
+                self.wait_lds(it[1])
+            elif isinstance(it, tuple):
+                self.lds_op(it[0], it[1])
+            else:
+                self.e(it)
+
+    # ---- registers
+    @staticmethod
+    def acc(mb, nb):
+        b = A_ACC + (mb * 4 + nb) * 16
+        return f"a[{b}:{b + 15}]"
+
+    @staticmethod
+    def opa(os_, ks, mb):
+        return A_OPS[os_] + (ks * 2 + mb) * 4
+
+    @staticmethod
+    def opb(os_, ks, nb):
+        return A_OPS[os_] + 16 + (ks * 4 + nb) * 4
+
+    # ---- operand reads of tap t from buffer `buf` into operand set os_: 12 (text, tag) in the order the MFMAs use them
+    def tap_reads(self, t, buf, os_):
+        dy, dx = t // 3, t % 3
+        out = []
+        for ks in range(2):
+            for mb in range(2):
+                r = self.opa(os_, ks, mb)
+                off = ((t * 2 + ks) * 2 + mb) * 1024      # (V_AOFS points at the buffer's weight area)
+                out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, ks, 0, mb)))
+            for nb in range(4):
+                r = self.opb(os_, ks, nb)
+                off = (2 * nb + dy) * 18 * 64
+                out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + ks} offset:{off}", ("R", t, ks, 1, nb)))
+        return out
+
+    def tap_mfmas(self, os_, sprinkle):
+        """16 MFMAs of one tap on operand set os_; sprinkle: 16 lists of items tucked behind MFMA m"""
+        m = 0
+        for ks in range(2):
+            for mb in range(2):
+                for nb in range(4):
+                    a, b = self.opa(os_, ks, mb), self.opb(os_, ks, nb)
+                    self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(mb, nb)}, a[{a}:{a + 3}], a[{b}:{b + 3}], {self.acc(mb, nb)}")
+                    self.emit_group(sprinkle[m])
+                    m += 1
+
+    # ---- streams
+    def next_coords(self, p, ct_name):
+        """the stream with prefix p moves to its next tile (x fastest, then y, channel tile, frame) -- or stays on its last one"""
+        e = self.e
+        stay = self.label("stay")
+        e(f"s_cmp_lt_u32 {s(p + 'LEFT')}, 2")
+        e(f"s_cbranch_scc1 {stay}")
+        e(f"s_sub_u32 {s(p + 'LEFT')}, {s(p + 'LEFT')}, 1")
+        e(f"s_add_u32 {s(p + 'TX')}, {s(p + 'TX')}, 1")
+        e(f"s_cmp_eq_u32 {s(p + 'TX')}, {s('TILESX')}")
+        e(f"s_cselect_b32 {s(p + 'TX')}, 0, {s(p + 'TX')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'TY')}, {s(p + 'TY')}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(p + 'TY')}, {s('TILESY')}")
+        e(f"s_cselect_b32 {s(p + 'TY')}, 0, {s(p + 'TY')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(ct_name)}, {s(ct_name)}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(ct_name)}, {s('NCT')}")
+        e(f"s_cselect_b32 {s(ct_name)}, 0, {s(ct_name)}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'FR')}, {s(p + 'FR')}, {s('T0')}")
+        e(f"{stay}:")
+
+    def geometry(self):
+        """per-lane geometry of the staging stream's tile at (SX0, SY0): byte offset of the ten pieces from the chunk's source pointer,
+        which of them are inside the image (V_VALID) and which are halo slots outside it (V_ZMASK)"""
+        e = self.e
+        r, c, t, t2, t3 = V_T, V_T + 1, V_T + 2, V_T + 3, V_T + 4
+        e(f"v_mov_b32 v{V_VALID}, 0")
+        e(f"v_mov_b32 v{V_ZMASK}, 0")
+        for i in range(NI):
+            e(f"v_bfe_u32 v{r}, v{V_HRC + i}, 8, 8")
+            e(f"v_and_b32 v{c}, 0xff, v{V_HRC + i}")
+            e(f"v_add_u32 v{r}, {s('SY0')}, v{r}")                     # gy + 1
+            e(f"v_add_u32 v{c}, {s('SX0')}, v{c}")                     # gx + 1
+            e(f"v_subrev_u32 v{r}, 1, v{r}")                            # gy (wraps below 0: fails the unsigned test)
+            e(f"v_subrev_u32 v{c}, 1, v{c}")
+            e(f"v_cmp_gt_u32 vcc, {s('H')}, v{r}")
+            e(f"v_cmp_gt_u32 {s2('TA')}, {s('W')}, v{c}")
+            e(f"v_cmp_le_i32 {s2('TB')}, 0, v{V_HRC + i}")             # the slot exists
+            e(f"s_and_b64 vcc, vcc, {s2('TA')}")
+            e(f"s_and_b64 vcc, vcc, {s2('TB')}")
+            e(f"v_mul_lo_u32 v{t}, v{r}, {s('W')}")
+            e(f"v_add_u32 v{t}, v{t}, v{c}")
+            e(f"v_mul_lo_u32 v{t}, v{t}, {s('CA2')}")
+            e(f"v_bfe_u32 v{t2}, v{V_HRC + i}, 16, 2")
+            e(f"v_lshlrev_b32 v{t2}, 4, v{t2}")
+            e(f"v_add_u32 v{t}, v{t}, v{t2}")
+            e(f"v_cndmask_b32 v{V_VOFF + i}, 0, v{t}, vcc")
+            e(f"v_mov_b32 v{t2}, {1 << i}")
+            e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
+            e(f"v_or_b32 v{V_VALID}, v{V_VALID}, v{t3}")
+            e(f"s_andn2_b64 vcc, {s2('TB')}, vcc")
+            e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
+            e(f"v_or_b32 v{V_ZMASK}, v{V_ZMASK}, v{t3}")
+
+    def staging_tile_setup(self):
+        """geometry registers, frame bases FRA / FRB and the weight base WB for the staging stream's tile (NTX, NTY, NCT_, NFR)"""
+        e = self.e
+        e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
+        e(f"s_mul_i32 {s('SY0')}, {s('NTY')}, {TILE_H}")
+        self.geometry()
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('NFR')}")               # pixels before this frame (< 2^31: the launcher checks)
+        for fr, src, c in (("FRA", "INA", "CA"), ("FRB", "INB", "CB")):
+            e(f"s_lshl_b32 {s('T1')}, {s(c)}, 1")
+            e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
+            e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
+            e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
+            e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
+        e(f"s_mul_i32 {s('T0')}, {s('NCT_')}, {s('NCH')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WB')}, {s('W16')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WB1')}, {s('W161')}, 0")
+
+    def staging_source(self):
+        """for chunk NC of the staging tile: SRC (channel 0 of the chunk at pixel 0 of the frame; both tensors of a concatenation have
+        CA channels: the launcher checks) and WCH / WCH1_ / WCH2_ (the chunk's weights, + 4 KiB, + 8 KiB)"""
+        e = self.e
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('CHA')}")                       # chunk from A?
+        e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
+        e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
+        e(f"s_sub_u32 {s('T0')}, {s('NC')}, {s('T0')}")                # chunk index inside its tensor
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 6")                        # * 32 channels * 2 bytes
+        e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
+        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
+        e(f"s_mul_i32 {s('T0')}, {s('NC')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
+        e(f"s_add_u32 {s('WCH1_')}, {s('WCH')}, 4096")
+        e(f"s_addc_u32 {s('WCH1_1')}, {s('WCH1')}, 0")
+        e(f"s_add_u32 {s('WCH2_')}, {s('WCH')}, 8192")
+        e(f"s_addc_u32 {s('WCH2_1')}, {s('WCH1')}, 0")
+
+    def advance_staging(self):
+        e = self.e
+        same = self.label("nsame")
+        e(f"s_add_u32 {s('NC')}, {s('NC')}, 1")
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {same}")
+        e(f"s_mov_b32 {s('NC')}, 0")
+        self.next_coords("N", "NCT_")
+        self.staging_tile_setup()
+        e(f"{same}:")
+
+    # ---- instruction groups
+    def dma_items(self, wbuf):
+        """nine 1-KiB pieces of the staging chunk's weights -> weight area of buffer wbuf"""
+        items = []
+        for grp in range(3):
+            base = ("WCH", "WCH1_", "WCH2_")[grp]
+            for j in range(4 if grp < 2 else 1):
+                g = []
+                if j == 0:
+                    g += [f"s_add_u32 m0, {s('LDSW')}, {wbuf * BUF + grp * 4096}", "s_nop 0"]
+                if not EXP & 4:
+                    g += [f"global_load_lds_dwordx4 v{V_DMA}, {s2(base)} offset:{1024 * j}"]
+                items.append(g)
+        return items
+
+    def halo_items(self, buf):
+        """ten LDS-DMA instructions of the staging chunk's halo tile -> halo area of buffer buf, and the zeroes of its slots outside the image"""
+        items = []
+        t = V_T + 8
+        for i in range(NI):
+            g = [f"s_add_u32 m0, {s('LDSH')}, {buf * BUF + 1024 * i}",
+                 f"v_bfe_u32 v{t}, v{V_VALID}, {i}, 1", f"v_cmp_eq_u32 vcc, 1, v{t}", "s_nop 0", "s_mov_b64 exec, vcc"]
+            if not EXP & 2:
+                g += [f"global_load_lds_dwordx4 v{V_VOFF + i}, {s2('SRC')}"]
+            g += ["s_mov_b64 exec, -1", f"v_bfe_u32 v{t}, v{V_ZMASK}, {i}, 1", f"v_cmp_eq_u32 vcc, 1, v{t}", "s_nop 0", "s_mov_b64 exec, vcc",
+                  (f"ds_write_b128 v{V_SLOT[buf]}, v[{V_Z}:{V_Z + 3}] offset:{1024 * i}", ("Z", i)), "s_mov_b64 exec, -1"]
+            items.append(g)
+        return items
+
+    def gate_loads(self):
+        """the gate's sixteen pieces of this lane (the compute tile's store positions), if the launch has a gate and this is the tile's
+        last pair of chunks"""
+        e = self.e
+        skip = self.label("nogate")
+        e(f"s_add_u32 {s('T0')}, {s('CC')}, 2")
+        e(f"s_cmp_lt_u32 {s('T0')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        for k in range(16):
+            e(f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + k}")          # (with every lane active: a compare leaves 0 for inactive lanes)
+            e("s_nop 0")
+            e("s_mov_b64 exec, vcc")
+            if not EXP & 16:
+                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_SOFF + k}, {s2('GATEF')}")
+            e("s_mov_b64 exec, -1")
+        e(f"{skip}:")
+
+    def store_tile(self):
+        """the stores of the tile that just ended (offsets V_SOFF, bases OUTF / GATEF: set by tile_begin).  An N-block's 64 channels x
+        32 pixels leave through this wave's 4 KiB of LDS staging as bf16: lane (n, hh) writes the 8 bytes of channels 8 pc + 4 hh .. + 3
+        of pixel n for the eight pieces pc = 4 mb + rq; lane l reads piece l & 7 of pixel 8 j + (l >> 3): a store instruction writes
+        eight whole 128-byte lines.  Lower bound (ReLU or none) in fp32 before the conversion; gate (<= 0 -> 0) on the packed halves."""
+        e = self.e
+        ta, tc, tb, tm = V_T, V_T + 16, V_T + 32, V_T + 48
+        for nb in range(4):
+            for mb in range(2):
+                a0 = A_ACC + (mb * 4 + nb) * 16
+                for rq in range(4):
+                    for j in range(4):
+                        e(f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}")
+                    for j in range(4):
+                        e(f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}")
+                    e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq}, v{ta + 4 * rq}, v{ta + 4 * rq + 1}")
+                    e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq + 1}, v{ta + 4 * rq + 2}, v{ta + 4 * rq + 3}")
+                    self.lds_op(f"ds_write_b64 v{V_SWA + mb * 4 + rq}, v[{tc + 2 * rq}:{tc + 2 * rq + 1}]", ("SW", nb, mb, rq))
+            for j in range(4):
+                self.lds_op(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", nb, j))
+            nogate = self.label("ng")
+            e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+            e(f"s_cbranch_scc1 {nogate}")
+            self.wait_lds(("SR", nb, 3))
+            for j in range(4):
+                for d in range(4):
+                    g, m, x = V_G + 16 * nb + 4 * j + d, tm + d, tb + 4 * j + d
+                    e(f"v_pk_max_i16 v{m}, v{g}, v{V_Z}")
+                    e(f"v_pk_min_u16 v{m}, v{m}, v{V_ONES}")
+                    e(f"v_pk_mul_lo_u16 v{m}, v{m}, v{V_FFFF}")
+                    e(f"v_and_b32 v{x}, v{x}, v{m}")
+            e(f"{nogate}:")
+            self.wait_all_lds()                               # (either path: the read-backs have arrived)
+            for j in range(4):
+                e(f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + nb * 4 + j}")
+                e("s_nop 0")
+                e("s_mov_b64 exec, vcc")
+                if not EXP & 1:
+                    e(f"global_store_dwordx4 v{V_SOFF + nb * 4 + j}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')}")
+                e("s_mov_b64 exec, -1")
+
+    # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
+    def chunk(self, p):
+        e = self.e
+        self.staging_source()
+        dma = self.dma_items(p ^ 1)
+        hal = self.halo_items(p ^ 1)
+        for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
+            self.lds_op(text, tag)
+        for t in range(9):
+            os_ = t & 1
+            nxt = self.tap_reads(t + 1, p, os_ ^ 1) if t + 1 < 9 else []
+            sprinkle = [[] for _ in range(16)]
+            for m, rd in enumerate(nxt):
+                sprinkle[m].append(rd)
+            if t == 0:                                   # (m0 belongs to one group at a time: weights behind tap 0, halo behind taps 1..2)
+                for k, g in enumerate(dma):
+                    sprinkle[6 + k].extend(g)
+            if t in (1, 2):
+                for k, g in enumerate(hal[(t - 1) * 5:t * 5]):
+                    sprinkle[3 + 3 * k].extend(g)
+            if t == 4 and p == 1:
+                self.gate_loads()
+            self.wait_lds(("R", t, 1, 1, 3))
+            self.tap_mfmas(os_, sprinkle)
+        self.wait_all_lds()
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+        self.advance_staging()
+
+    def bias_init(self):
+        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of the four N-blocks"""
+        e = self.e
+        e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")                        # CT * 64 floats
+        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_BIASA}")
+        for mb in range(2):
+            for nb in range(4):
+                for rq in range(4):
+                    b = A_ACC + (mb * 4 + nb) * 16 + 4 * rq
+                    self.lds_op(f"ds_read_b128 a[{b}:{b + 3}], v{V_T} offset:{mb * 128 + rq * 32}", ("BI", mb, nb, rq))
+                if nb % 2:
+                    self.wait_all_lds()
+
+    def tile_begin(self):
+        """the compute tile's store state: OUTF / GATEF and, per N-block and store j, this lane's byte offset (pixel 8 j + (lane >> 3) of
+        the block, piece lane & 7) or -1 outside the image"""
+        e = self.e
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
+        e(f"s_lshl_b32 {s('T1')}, {s('COUT')}, 1")
+        e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
+        e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 7")
+        e(f"s_add_u32 {s('T2')}, {s('T2')}, {s('T0')}")
+        e(f"s_addc_u32 {s('T3')}, {s('T3')}, 0")
+        for dst, src in (("OUTF", "OUT"), ("GATEF", "GATE")):
+            e(f"s_add_u32 {s(dst)}, {s(src)}, {s('T2')}")
+            e(f"s_addc_u32 {s(dst + '1')}, {s(src + '1')}, {s('T3')}")
+        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
+        e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 3")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('Y0')}")                # first row of this wave
+        for half in range(2):                                           # columns 8 half + (lane >> 3)
+            e(f"v_add_u32 v{V_T + half}, {s('X0')}, v{V_L3}")
+            if half:
+                e(f"v_add_u32 v{V_T + half}, 8, v{V_T + half}")
+        for nb in range(4):
+            for j in range(4):
+                row, half = 2 * nb + (j >> 1), j & 1
+                d = V_SOFF + nb * 4 + j
+                e(f"s_add_u32 {s('T2')}, {s('T0')}, {row}")             # gy (wave-uniform)
+                e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
+                e(f"s_cselect_b64 {s2('TA')}, -1, 0")
+                e(f"v_cmp_gt_u32 vcc, {s('W')}, v{V_T + half}")
+                e(f"s_and_b64 vcc, vcc, {s2('TA')}")
+                e(f"s_mul_i32 {s('T3')}, {s('T2')}, {s('W')}")
+                e(f"v_add_u32 v{V_T + 2}, {s('T3')}, v{V_T + half}")    # pixel index
+                e(f"v_mul_lo_u32 v{V_T + 2}, v{V_T + 2}, {s('T1')}")    # * COUT * 2
+                e(f"v_add_u32 v{V_T + 2}, v{V_T + 2}, v{V_L7X16}")
+                e(f"v_cndmask_b32 v{d}, -1, v{V_T + 2}, vcc")
+
+    def tile_end(self):
+        e = self.e
+        e("s_nop 7")
+        e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
+        self.store_tile()
+        e("s_barrier")                                                # (the staging area is buffer 1's halo region: nobody may stage the next
+        self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
+
+
+def generate():
+    b = Body()
+    e = b.e
+    # ================= prologue
+    e(f"s_mov_b64 {s2('KARG')}, %[karg]")
+    for dst, src in (("WAVE", "wave"), ("LDS0", "lds0"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"), ("FR", "fr0"), ("NTL", "ntl")):
+        e(f"s_mov_b32 {s(dst)}, %[{src}]")
+    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"), ("GATE", "gate")):
+        e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, {ARG[field]}")
+    for dst, field in (("CA", "CA"), ("CB", "CB"), ("COUT", "cout"), ("H", "H"), ("W", "W"), ("TILESX", "tiles_x"), ("TILESY", "tiles_y"),
+                       ("NCT", "n_ct"), ("T3", "relu")):
+        e(f"s_load_dword {s(dst)}, {s2('KARG')}, {ARG[field]}")
+    e(f"v_mov_b32 v{V_TID}, %[tid]")
+    e(f"v_and_b32 v{V_LANE}, 63, v{V_TID}")
+    # per-lane constants: the C++ prologue left CONST_WORDS words per lane at the start of LDS ([word][256 threads])
+    e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
+    e(f"v_add_u32 v{V_T}, {s('LDS0')}, v{V_T}")
+    for i in range(NI):
+        e(f"ds_read_b32 v{V_HRC + i}, v{V_T} offset:{1024 * i}")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(6):
+        e(f"ds_read_b32 v{V_BOFS[0] + i}, v{V_T} offset:{1024 * (10 + i)}")
+    for i in range(8):
+        e(f"ds_read_b32 v{V_SWA + i}, v{V_T} offset:{1024 * (16 + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(4):
+        e(f"ds_read_b32 v{V_SRA + i}, v{V_T} offset:{1024 * (24 + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")                                                    # (everybody has read its constants: the buffers may be written)
+    for i in range(6):
+        e(f"v_add_u32 v{V_BOFS[1] + i}, {BUF}, v{V_BOFS[0] + i}")
+    e(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE}")                           # lane * 16
+    e(f"v_lshrrev_b32 v{V_HH16}, 5, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_HH16}, 4, v{V_HH16}")                        # hh * 16 bytes
+    e(f"v_lshrrev_b32 v{V_L3}, 3, v{V_LANE}")
+    e(f"v_and_b32 v{V_L7X16}, 7, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_L7X16}, 4, v{V_L7X16}")
+    e(f"v_mov_b32 v{V_ONES}, 0x00010001")
+    e(f"v_mov_b32 v{V_FFFF}, -1")
+    for k in range(4):
+        e(f"v_mov_b32 v{V_Z + k}, 0")
+    for k in range(64):
+        e(f"v_mov_b32 v{V_G + k}, 0x3f803f80")                          # no gate: every half passes
+    e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, 9216")
+    e(f"v_add_u32 v{V_DMA}, {s('T0')}, v{V_T}")                         # this lane's 16 B of the wave's nine 1-KiB weight pieces (global offset)
+    e(f"s_add_u32 {s('T1')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"v_add_u32 v{V_AOFS[0]}, {s('T1')}, v{V_T}")                      # A reads: the buffer's weight area + lane * 16
+    e(f"v_add_u32 v{V_AOFS[1]}, {BUF}, v{V_AOFS[0]}")
+    e(f"s_add_u32 {s('LDSW')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"s_add_u32 {s('LDSW')}, {s('LDSW')}, {s('T0')}")                 # LDS address of this wave's weight pieces in buffer 0
+    e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {NI * 1024}")
+    e(f"s_add_u32 {s('LDSH')}, {s('LDS0')}, {s('T0')}")                 # LDS address of this wave's halo slots in buffer 0
+    e(f"v_add_u32 v{V_SLOT[0]}, {s('LDSH')}, v{V_T}")
+    e(f"v_add_u32 v{V_SLOT[1]}, {BUF}, v{V_SLOT[0]}")
+    e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
+    e(f"v_add_u32 v{V_BIASA}, {s('T0')}, v{V_HH16}")                    # bias table + hh * 16
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
+    e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 5")
+    e(f"s_lshr_b32 {s('CHA')}, {s('CA')}, 5")
+    e(f"s_lshl_b32 {s('CA2')}, {s('CA')}, 1")
+    e(f"s_cmp_eq_u32 {s('T3')}, 0")
+    e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the epilogue's v_max: -inf (linear) or 0
+    # the bias table -> LDS: thread t (< 64 * NCT) copies bias[t] (no bias: zeros)
+    e(f"s_lshl_b32 {s('T0')}, {s('NCT')}, 6")
+    e(f"v_cmp_gt_u32 vcc, {s('T0')}, v{V_TID}")
+    e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
+    e(f"v_mov_b32 v{V_T + 1}, 0")
+    e(f"s_mov_b64 {s2('EX')}, exec")
+    e(f"s_cmp_eq_u64 {s2('BIAS')}, 0")
+    e("s_cbranch_scc1 S2LH_NOBIAS")
+    e("s_and_b64 exec, exec, vcc")
+    e(f"global_load_dword v{V_T + 1}, v{V_T}, {s2('BIAS')}")
+    e(f"s_mov_b64 exec, {s2('EX')}")
+    e("s_waitcnt vmcnt(0)")
+    e("S2LH_NOBIAS:")
+    e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
+    e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
+    e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
+    # the staging stream starts on the workgroup's first tile
+    e(f"s_mov_b32 {s('LEFT')}, {s('NTL')}")
+    e(f"s_mov_b32 {s('NLEFT')}, {s('NTL')}")
+    for n_, c_ in (("NTX", "TX"), ("NTY", "TY"), ("NCT_", "CT"), ("NFR", "FR")):
+        e(f"s_mov_b32 {s(n_)}, {s(c_)}")
+    e(f"s_mov_b32 {s('NC')}, 0")
+    b.staging_tile_setup()
+    # chunk 0 -> buffer 0, all exposed (once per workgroup)
+    b.staging_source()
+    for g in b.dma_items(0):
+        b.emit_group(g)
+    for g in b.halo_items(0):
+        b.emit_group(g)
+    b.advance_staging()
+    b.wait_all_lds()
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+
+    # ================= tile loop
+    e("S2LH_TILE:")
+    b.tile_begin()
+    b.bias_init()
+    e(f"s_mov_b32 {s('CC')}, 0")
+    e("S2LH_PAIR:")
+    b.chunk(0)
+    b.chunk(1)
+    e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
+    e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
+    e("s_cbranch_scc1 S2LH_PAIR")
+    b.tile_end()
+    e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
+    e(f"s_cmp_gt_u32 {s('NTL')}, 0")
+    e("s_cbranch_scc1 S2LH_TILE")
+    e("s_waitcnt vmcnt(0)")
+    return b.L
+
+
+OPERANDS = """      :
+      : [karg] "s"(karg), [wave] "s"(wave), [lds0] "s"(lds0), [tx0] "s"(tx0), [ty0] "s"(ty0), [ct0] "s"(ct0), [fr0] "s"(fr0), [ntl] "s"(ntl),
+        [tid] "v"(tid)
+"""
+
+
+def main(objdir):
+    lines = generate()
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
+    clob += ["vcc", "scc", "memory"]
+    out = ["// GENERATED by csrc/gen_convh_body.py -- do not edit; the generator is the source.", "asm volatile("]
+    out += [f'    "{x}\\n\\t"' for x in lines]
+    out.append(OPERANDS.rstrip("\n"))
+    out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+    with open(os.path.join(objdir, "convh_body.inc"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    return len(lines)
+
+
+if __name__ == "__main__":
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build")
+    print(f"convh body: {main(d)} instructions")

@@ -20,40 +20,10 @@
 // final 1x1 convolution is fused into the last conv's epilogue.
 #include "s2l_common.h"
 #include "conv16.h"
+#include "convh.h"
+#include "unet_layout.h"
 
 namespace s2l {
-
-// ---- packed layout ---------------------------------------------------------------------------------
-struct ConvSpec {
-  int cin, cout;
-};
-constexpr ConvSpec kUnetConvs[10] = {{3, 64},    {64, 64},   {64, 128}, {128, 128}, {128, 128},
-                                     {128, 128}, {256, 128}, {128, 64}, {128, 64},  {64, 64}};
-constexpr int kChunkFloats = 9 * 4 * 64 * 4;   // one (cout tile of 64, cin chunk of 16): 9 taps x 4 M-blocks x 64 lanes x 4
-
-__host__ __device__ constexpr int64_t unet_w_off(int layer) {
-  int64_t off = 0;
-  for (int l = 0; l < layer; ++l)
-    off += l == 0 ? 64 * 27 : (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
-  return off;
-}
-constexpr int64_t kUnetBiasOff = unet_w_off(10);                   // folded biases, layer by layer
-__host__ __device__ constexpr int64_t unet_b_off(int layer) {
-  int64_t off = kUnetBiasOff;
-  for (int l = 0; l < layer; ++l) off += kUnetConvs[l].cout;
-  return off;
-}
-constexpr int64_t kUnetOutW = unet_b_off(10);                      // outc weight [3][64]
-constexpr int64_t kUnetOutB = kUnetOutW + 192;                     // outc bias [4]
-// transposed chunks of layers 1..9 for the input-gradient convolutions (s2l_unet_backward): the same chunk format with the
-// roles of cin / cout swapped and the taps mirrored, dx = conv3x3(dz, W^T flipped)
-constexpr int64_t kUnetWT = kUnetOutB + 4;
-__host__ __device__ constexpr int64_t unet_wT_off(int layer) {
-  int64_t off = kUnetWT;
-  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cin / 64) * (kUnetConvs[l].cout / 16) * kChunkFloats;
-  return off;
-}
-constexpr int64_t kUnetPackedFloats = unet_wT_off(10);
 
 struct UnetTensors {
   const float* w[10];
@@ -121,18 +91,6 @@ __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float 
 // conv3x3_bf16_kernel runs the same implicit GEMM on v_mfma_f32_32x32x16_bf16: weights and the staged input tile are bf16,
 // accumulation, bias / ReLU / gate and every tensor in HBM stay fp32.  A chunk = (64 output channels, 32 input channels):
 // 9 taps x 2 k-steps x 2 M-blocks x 64 lanes x 8 bf16; lane l of an A quad holds W[row 32 mb + (l & 31)][k 16 s + 8 (l >> 5) + j].
-constexpr int kChunk16Halves = 9 * 2 * 2 * 64 * 8;
-__host__ __device__ constexpr int64_t unet_w16_off(int layer) {
-  int64_t off = 0;
-  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 32) * kChunk16Halves;
-  return off;
-}
-__host__ __device__ constexpr int64_t unet_wT16_off(int layer) {
-  int64_t off = unet_w16_off(10);
-  for (int l = 1; l < layer; ++l) off += (int64_t)(kUnetConvs[l].cin / 64) * (kUnetConvs[l].cout / 32) * kChunk16Halves;
-  return off;
-}
-constexpr int64_t kUnetPacked16Halves = unet_wT16_off(10);
 // Split-bf16 ("bf16x3") operand form of the forward 3x3 layers: every fp32 operand x is carried as hi = bf16(x) and
 // lo = bf16(x - hi) (x - hi - lo is <= 2^-17 |x|), and a product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16 relative operand error instead of bf16's 2^-8, three MFMAs at 16x the
@@ -2125,7 +2083,6 @@ struct TrainBufs {
   float *p1, *p2, *u3, *uu;   // pooled / up-sampled inputs
   float* st;                  // [10][4][128]: scale, shift, mean, invstd
 };
-static const int kLvl[10] = {0, 0, 1, 1, 2, 2, 1, 1, 0, 0};   // resolution level of each convolution's output
 static TrainBufs train_bufs(float* w, int64_t p1, int64_t p2, int64_t p4) {
   const int64_t pl[3] = {p1, p2, p4};
   TrainBufs b;
@@ -2699,3 +2656,5 @@ extern "C" int s2l_unet_train_backward_bf16(const float* packed_raw, const uint1
   return unet_train_backward_impl(packed_raw, packed16_raw, tensors_host, x, saved, d_out, work, d_x, grads, height, width, n_frames,
                                   stream);
 }
+
+#include "unet_half.inc"

@@ -282,10 +282,12 @@ class SimpleUnetLight(nn.Module):
         """x [F,H,W,3] -> (out, ctx): F successive ONE-FRAME train-mode calls in one set of launches (s2l_unet_train_forward_frames):
         each frame normalised with its own batch statistics, the running statistics moved once per frame in frame order,
         num_batches_tracked += F -- what the reference's loop does to the (frozen) net, bit for bit what F calls of
-        forward_train_nhwc(x[f:f+1]) compute.  ctx feeds backward_train_frames (input gradient only)."""
+        forward_train_nhwc(x[f:f+1]) compute.  ctx feeds backward_train_frames (input gradient only).
+        precision "bf16h": bf16 operands AND bf16 tensors between the kernels (s2l_unet_train_forward_frames_h: half the memory
+        traffic of "bf16"; fp32 accumulation and statistics; x / out / gradients at the boundary stay fp32)."""
         lib = _abi.load()
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16", "bf16h"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16h'")
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         tensors = self._tensors()
@@ -298,18 +300,28 @@ class SimpleUnetLight(nn.Module):
         if C != 3 or H < 4 or W < 4 or F_ < 1:
             raise ValueError(f"U-Net input must be [F>=1,H>=4,W>=4,3], got {tuple(x.shape)}")
         table = self._table(tensors)
-        raw, raw16 = self._raw_blobs(tensors, table, precision == "bf16")
+        half = precision == "bf16h"
+        raw, raw16 = self._raw_blobs(tensors, table, precision != "fp32")
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
-        saved = torch.empty(int(lib.s2l_unet_train_frames_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.s2l_unet_train_frames_scratch_floats(F_)), dtype=torch.float32, device=dev)
+        if half:
+            saved = torch.empty(int(lib.s2l_unet_train_frames_h_saved_halves(H, W, F_)), dtype=torch.int16, device=dev)
+            scratch = torch.empty(int(lib.s2l_unet_train_frames_h_scratch_floats(F_)), dtype=torch.float32, device=dev)
+        else:
+            saved = torch.empty(int(lib.s2l_unet_train_frames_saved_floats(H, W, F_)), dtype=torch.float32, device=dev)
+            scratch = torch.empty(int(lib.s2l_unet_train_frames_scratch_floats(F_)), dtype=torch.float32, device=dev)
         bn = self.inc.double_conv[1]
         momentum = 0.1 if bn.momentum is None else float(bn.momentum)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _abi.check(lib.s2l_unet_train_forward_frames(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
-                                                         1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
-                       "s2l_unet_train_forward_frames")
+            if half:
+                _abi.check(lib.s2l_unet_train_forward_frames_h(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                                               1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                           "s2l_unet_train_forward_frames_h")
+            else:
+                _abi.check(lib.s2l_unet_train_forward_frames(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                                             1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                           "s2l_unet_train_forward_frames")
         if update_running:
             torch._foreach_add_([mod.num_batches_tracked for mod in self.modules() if isinstance(mod, nn.BatchNorm2d)], F_)
             self._packed = self._packed_key = None
@@ -328,8 +340,15 @@ class SimpleUnetLight(nn.Module):
         tensors = self._tensors()
         table = self._table(tensors)
         dx = torch.empty_like(d)
-        work = torch.empty(int(lib.s2l_unet_train_frames_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        if saved.dtype == torch.int16:      # the half-width chain (precision "bf16h")
+            work = torch.empty(int(lib.s2l_unet_train_frames_h_work_halves(H, W, F_)), dtype=torch.int16, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_unet_train_backward_frames_h(p(raw), p(raw16), table, p(saved), p(d), p(work), p(dx), H, W, F_,
+                                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                           "s2l_unet_train_backward_frames_h")
+            return dx
+        work = torch.empty(int(lib.s2l_unet_train_frames_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _abi.check(lib.s2l_unet_train_backward_frames(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), H, W, F_,
                                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
