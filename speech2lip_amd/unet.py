@@ -419,8 +419,15 @@ class SimpleUnetLight(nn.Module):
         if not any(p.requires_grad for p in self.parameters()):
             # the frozen net of the loop after it > 100000: the frames go through in groups of whole frames, every frame still its own
             # statistics group (s2l_unet_train_forward_frames: the same bits as one call per frame, ~1/F of the launches)
+            # precision "bf16" here also means bf16 TENSORS between the kernels (the half-width chain, csrc/unet_half.inc: the same
+            # operands, half the memory traffic) unless `half_width_tensors` is set to False on the module
             F_, H, W = x.shape[0], x.shape[1], x.shape[2]
-            per_frame = 4 * (int(_abi.load().s2l_unet_train_frames_saved_floats(H, W, 1)) + int(_abi.load().s2l_unet_train_frames_work_floats(H, W, 1)))
+            lib = _abi.load()
+            if precision == "bf16" and getattr(self, "half_width_tensors", True) and H <= 255 * 32 and W <= 255 * 16:
+                precision = "bf16h"
+                per_frame = 2 * (int(lib.s2l_unet_train_frames_h_saved_halves(H, W, 1)) + int(lib.s2l_unet_train_frames_h_work_halves(H, W, 1)))
+            else:
+                per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
             group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
             outs, ctxs = [], []
             for s0 in range(0, F_, group):

@@ -794,6 +794,7 @@ def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
         u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
         return u
     ua, ub = net(), net()
+    ub.half_width_tensors = False      # (this test pins the fp32-TENSOR frames route; the half-width one: tests/test_gpu_unet_half.py)
     rng = np.random.default_rng(F * fh)
     x = T(rng.random((F, fh, fw, 3), dtype=np.float32)).to(dev)
     d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
@@ -829,6 +830,7 @@ def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
     # several groups of frames (a small memory budget): same numbers, the running statistics still in frame order
     ud, ue = net(), net()
     for u_ in (ud, ue):
+        u_.half_width_tensors = False
         for p_ in u_.parameters():
             p_.requires_grad_(False)
     per_frame = 4 * (int(s2l._abi.load().s2l_unet_train_frames_saved_floats(fh, fw, 1)) + int(s2l._abi.load().s2l_unet_train_frames_work_floats(fh, fw, 1)))
