@@ -91,7 +91,7 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   const int cmax = a.CA > a.cout ? a.CA : a.cout;
   if ((a.CA + a.CB) % 32 != 0 || nch % 2 != 0 || a.CA % 32 != 0 || !(a.CB == 0 || (a.CB == a.CA && a.inB)) || a.cout % 64 != 0 ||
       a.n_ct > 4 || a.n_ct < 1 || (int64_t)a.H * a.W * cmax * 2 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames >= 0x7fffffffLL ||
-      a.n_frames <= 0 || a.H > 255 * 32 || a.W > 255 * 16)
+      a.n_frames <= 0 || a.H > 255 * 32 || a.W > 255 * 16 || a.relu != 0)      // (the body is generated without the ReLU: WITH_RELU)
     return S2L_OK;
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
   if (total >= 0x7fffffff) return S2L_OK;

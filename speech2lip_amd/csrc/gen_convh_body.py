@@ -35,26 +35,28 @@ LDS_BYTES = BIAS_OFF + 1024
 STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 4 waves x 4 KiB
 NI = 10                                                         # halo DMA instructions per wave (wave w: slots 640 w ..)
 CONST_WORDS = 28                                                # per lane, from the C++ prologue: hrc[10], bofs[6], swa[8], sra[4]
+WITH_RELU = False                                               # (the training chain is linear up to the gate; csrc/convh.hip refuses relu)
 EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads
 
 # ---- registers
 A_ACC = 0
 A_OPS = (128, 176)              # operand set: A[ks][mb] at + (ks * 2 + mb) * 4, B[ks][nb] at + 16 + (ks * 4 + nb) * 4
 A_LAST = 223
-V_VOFF = 0                      # 10: byte offset of this lane's piece of DMA instruction i from the chunk's source pointer (staging tile)
+V_VOFF = 0                      # 10: byte offset of this lane's piece of DMA instruction i from the TILE's source pointer: a per-lane
+                                #     constant ((row * W + col) * 2 CA + 16 segment); the tile's origin is in the scalar base
 V_HRC = 10                      # 10: col | row << 8 | logical segment << 16, or negative: no such slot
-V_VALID, V_ZMASK = 20, 21       # bit i: the piece is inside the image / is a halo slot outside it (zeroed)
+V_VALID, V_ZMASK = 20, 21       # bit i: the piece is inside the image / is a halo slot outside it (zeroed); staging tile
 V_SLOT = (22, 23)               # LDS address of slot (640 wave + lane) per buffer
 V_Z = 24                        # 4 zeros
 V_BOFS = (28, 34)
 V_AOFS = (40, 41)
-V_LANE, V_TID, V_HH16, V_DMA, V_BIASA, V_L3, V_L7X16, V_ONES, V_FFFF = 42, 43, 44, 45, 46, 47, 48, 49, 50
+V_LANE, V_TID, V_HH16, V_DMA, V_BIASA, V_L3, V_L7X16, V_ONES, V_FFFF, V_INR = 42, 43, 44, 45, 46, 47, 48, 49, 50, 51
 V_SWA = 52                      # 8: staging write addresses per piece mb * 4 + rq
 V_SRA = 60                      # 4: staging read addresses per store j
 V_T = 64                        # temporaries 64..127
-V_SOFF = 128                    # 16: store byte offsets [nb][j] of the compute tile (-1: no store for this lane)
-V_G = 144                       # 64: gate pieces [nb][j][4]
-V_LAST = 207
+V_VS = 128                      # 2: byte offset of this lane's 16 bytes in a store of column half h from the row's pointer
+V_G = 132                       # 64: gate pieces [nb][j][4]
+V_LAST = 195
 
 
 def _scalars(first, singles, pairs, skip=(32, 33)):
@@ -73,11 +75,11 @@ def _scalars(first, singles, pairs, skip=(32, 33)):
 
 
 S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA WAVE LDS0 RELU CA2 LDSW LDSH T0 T1 T2 T3 "
-                          "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0").split(),
+                          "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0 RS GY0").split(),
              pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "GATEF",
-                    "EX", "TA", "TB"))
+                    "EX", "TA", "TB", "XM0", "XM1_", "ROWB"))
 S_LAST = max(S.values())
-assert S_LAST <= 100, S_LAST
+assert S_LAST <= 101, S_LAST
 
 # byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
 ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
@@ -192,10 +194,25 @@ class Body:
         e(f"{stay}:")
 
     def geometry(self):
-        """per-lane geometry of the staging stream's tile at (SX0, SY0): byte offset of the ten pieces from the chunk's source pointer,
-        which of them are inside the image (V_VALID) and which are halo slots outside it (V_ZMASK)"""
+        """which of this lane's ten pieces of the staging stream's tile at (SX0, SY0) are inside the image (V_VALID) and which are halo
+        slots outside it (V_ZMASK).  A tile whose halo lies inside the image (most): every slot is valid."""
         e = self.e
-        r, c, t, t2, t3 = V_T, V_T + 1, V_T + 2, V_T + 3, V_T + 4
+        r, c, t2, t3 = V_T, V_T + 1, V_T + 3, V_T + 4
+        slow, done = self.label("border"), self.label("geo")
+        e(f"s_cmp_eq_u32 {s('SX0')}, 0")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_cmp_eq_u32 {s('SY0')}, 0")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_add_u32 {s('T0')}, {s('SX0')}, 16")
+        e(f"s_cmp_ge_u32 {s('T0')}, {s('W')}")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_add_u32 {s('T0')}, {s('SY0')}, {TILE_H}")
+        e(f"s_cmp_ge_u32 {s('T0')}, {s('H')}")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"v_mov_b32 v{V_VALID}, v{V_INR}")
+        e(f"v_mov_b32 v{V_ZMASK}, 0")
+        e(f"s_branch {done}")
+        e(f"{slow}:")
         e(f"v_mov_b32 v{V_VALID}, 0")
         e(f"v_mov_b32 v{V_ZMASK}, 0")
         for i in range(NI):
@@ -210,32 +227,31 @@ class Body:
             e(f"v_cmp_le_i32 {s2('TB')}, 0, v{V_HRC + i}")             # the slot exists
             e(f"s_and_b64 vcc, vcc, {s2('TA')}")
             e(f"s_and_b64 vcc, vcc, {s2('TB')}")
-            e(f"v_mul_lo_u32 v{t}, v{r}, {s('W')}")
-            e(f"v_add_u32 v{t}, v{t}, v{c}")
-            e(f"v_mul_lo_u32 v{t}, v{t}, {s('CA2')}")
-            e(f"v_bfe_u32 v{t2}, v{V_HRC + i}, 16, 2")
-            e(f"v_lshlrev_b32 v{t2}, 4, v{t2}")
-            e(f"v_add_u32 v{t}, v{t}, v{t2}")
-            e(f"v_cndmask_b32 v{V_VOFF + i}, 0, v{t}, vcc")
             e(f"v_mov_b32 v{t2}, {1 << i}")
             e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
             e(f"v_or_b32 v{V_VALID}, v{V_VALID}, v{t3}")
             e(f"s_andn2_b64 vcc, {s2('TB')}, vcc")
             e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
             e(f"v_or_b32 v{V_ZMASK}, v{V_ZMASK}, v{t3}")
+        e(f"{done}:")
 
     def staging_tile_setup(self):
-        """geometry registers, frame bases FRA / FRB and the weight base WB for the staging stream's tile (NTX, NTY, NCT_, NFR)"""
+        """validity masks, the tensors' bases FRA / FRB at the TILE's origin (halo pixel (0, 0): may lie before the frame) and the weight
+        base WB for the staging stream's tile (NTX, NTY, NCT_, NFR)"""
         e = self.e
         e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
         e(f"s_mul_i32 {s('SY0')}, {s('NTY')}, {TILE_H}")
         self.geometry()
         e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
         e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('NFR')}")               # pixels before this frame (< 2^31: the launcher checks)
-        for fr, src, c in (("FRA", "INA", "CA"), ("FRB", "INB", "CB")):
-            e(f"s_lshl_b32 {s('T1')}, {s(c)}, 1")
-            e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
-            e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
+        e(f"s_sub_u32 {s('T1')}, {s('SY0')}, 1")
+        e(f"s_mul_i32 {s('T1')}, {s('T1')}, {s('W')}")
+        e(f"s_add_u32 {s('T1')}, {s('T1')}, {s('SX0')}")
+        e(f"s_sub_u32 {s('T1')}, {s('T1')}, 1")                         # (SY0 - 1) W + SX0 - 1 >= -(W + 1)
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")                 # pixel index of the halo origin, as a signed number
+        e(f"s_mul_hi_i32 {s('T3')}, {s('T0')}, {s('CA2')}")             # (both tensors of a concatenation have CA channels)
+        e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('CA2')}")
+        for fr, src in (("FRA", "INA"), ("FRB", "INB")):
             e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
         e(f"s_mul_i32 {s('T0')}, {s('NCT_')}, {s('NCH')}")
@@ -302,6 +318,18 @@ class Body:
             items.append(g)
         return items
 
+    def row_exec(self, row, half, base, first):
+        """exec = the lanes of store (row, half) inside the image; ROWB = base + row * RS"""
+        e = self.e
+        if first:
+            e(f"s_mov_b64 {s2('ROWB')}, {s2(base)}")
+        elif half == 0:
+            e(f"s_add_u32 {s('ROWB')}, {s('ROWB')}, {s('RS')}")
+            e(f"s_addc_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
+        e(f"s_add_u32 {s('T2')}, {s('GY0')}, {row}")
+        e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
+        e(f"s_cselect_b64 exec, {s2('XM0' if half == 0 else 'XM1_')}, 0")
+
     def gate_loads(self):
         """the gate's sixteen pieces of this lane (the compute tile's store positions), if the launch has a gate and this is the tile's
         last pair of chunks"""
@@ -313,19 +341,18 @@ class Body:
         e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
         e(f"s_cbranch_scc1 {skip}")
         for k in range(16):
-            e(f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + k}")          # (with every lane active: a compare leaves 0 for inactive lanes)
-            e("s_nop 0")
-            e("s_mov_b64 exec, vcc")
+            nb, j = k >> 2, k & 3
+            self.row_exec(2 * nb + (j >> 1), j & 1, "GATEF", k == 0)
             if not EXP & 16:
-                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_SOFF + k}, {s2('GATEF')}")
-            e("s_mov_b64 exec, -1")
+                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_VS + (j & 1)}, {s2('ROWB')}")
+        e("s_mov_b64 exec, -1")
         e(f"{skip}:")
 
     def store_tile(self):
-        """the stores of the tile that just ended (offsets V_SOFF, bases OUTF / GATEF: set by tile_begin).  An N-block's 64 channels x
-        32 pixels leave through this wave's 4 KiB of LDS staging as bf16: lane (n, hh) writes the 8 bytes of channels 8 pc + 4 hh .. + 3
-        of pixel n for the eight pieces pc = 4 mb + rq; lane l reads piece l & 7 of pixel 8 j + (l >> 3): a store instruction writes
-        eight whole 128-byte lines.  Lower bound (ReLU or none) in fp32 before the conversion; gate (<= 0 -> 0) on the packed halves."""
+        """the stores of the tile that just ended (bases OUTF / GATEF, masks XM0 / XM1_, GY0: set by tile_begin).  An N-block's 64
+        channels x 32 pixels leave through this wave's 4 KiB of LDS staging as bf16: lane (n, hh) writes the 8 bytes of channels
+        8 pc + 4 hh .. + 3 of pixel n for the eight pieces pc = 4 mb + rq; lane l reads piece l & 7 of pixel 8 j + (l >> 3): a store
+        instruction writes eight whole 128-byte lines.  Gate (<= 0 -> 0) on the packed halves."""
         e = self.e
         ta, tc, tb, tm = V_T, V_T + 16, V_T + 32, V_T + 48
         for nb in range(4):
@@ -334,8 +361,9 @@ class Body:
                 for rq in range(4):
                     for j in range(4):
                         e(f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}")
-                    for j in range(4):
-                        e(f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}")
+                    if WITH_RELU:
+                        for j in range(4):
+                            e(f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}")
                     e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq}, v{ta + 4 * rq}, v{ta + 4 * rq + 1}")
                     e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq + 1}, v{ta + 4 * rq + 2}, v{ta + 4 * rq + 3}")
                     self.lds_op(f"ds_write_b64 v{V_SWA + mb * 4 + rq}, v[{tc + 2 * rq}:{tc + 2 * rq + 1}]", ("SW", nb, mb, rq))
@@ -355,12 +383,10 @@ class Body:
             e(f"{nogate}:")
             self.wait_all_lds()                               # (either path: the read-backs have arrived)
             for j in range(4):
-                e(f"v_cmp_ne_u32 vcc, -1, v{V_SOFF + nb * 4 + j}")
-                e("s_nop 0")
-                e("s_mov_b64 exec, vcc")
+                self.row_exec(2 * nb + (j >> 1), j & 1, "OUTF", nb == 0 and j == 0)
                 if not EXP & 1:
-                    e(f"global_store_dwordx4 v{V_SOFF + nb * 4 + j}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('OUTF')}")
-                e("s_mov_b64 exec, -1")
+                    e(f"global_store_dwordx4 v{V_VS + (j & 1)}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
+            e("s_mov_b64 exec, -1")
 
     # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
     def chunk(self, p):
@@ -405,11 +431,17 @@ class Body:
                     self.wait_all_lds()
 
     def tile_begin(self):
-        """the compute tile's store state: OUTF / GATEF and, per N-block and store j, this lane's byte offset (pixel 8 j + (lane >> 3) of
-        the block, piece lane & 7) or -1 outside the image"""
+        """the compute tile's store state: OUTF / GATEF = the address of (first row of this wave, column X0, channel tile CT), GY0 = that
+        row, XM0 / XM1_ = the lanes whose column (X0 + 8 half + (lane >> 3)) is inside the image"""
         e = self.e
-        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
-        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
+        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
+        e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
+        e(f"s_lshl_b32 {s('GY0')}, {s('WAVE')}, 3")
+        e(f"s_add_u32 {s('GY0')}, {s('GY0')}, {s('Y0')}")
+        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('FR')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('GY0')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('W')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('X0')}")                 # pixel index (< 2^31: the launcher checks F H W)
         e(f"s_lshl_b32 {s('T1')}, {s('COUT')}, 1")
         e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
         e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
@@ -419,28 +451,10 @@ class Body:
         for dst, src in (("OUTF", "OUT"), ("GATEF", "GATE")):
             e(f"s_add_u32 {s(dst)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(dst + '1')}, {s(src + '1')}, {s('T3')}")
-        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
-        e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
-        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 3")
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('Y0')}")                # first row of this wave
-        for half in range(2):                                           # columns 8 half + (lane >> 3)
-            e(f"v_add_u32 v{V_T + half}, {s('X0')}, v{V_L3}")
-            if half:
-                e(f"v_add_u32 v{V_T + half}, 8, v{V_T + half}")
-        for nb in range(4):
-            for j in range(4):
-                row, half = 2 * nb + (j >> 1), j & 1
-                d = V_SOFF + nb * 4 + j
-                e(f"s_add_u32 {s('T2')}, {s('T0')}, {row}")             # gy (wave-uniform)
-                e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
-                e(f"s_cselect_b64 {s2('TA')}, -1, 0")
-                e(f"v_cmp_gt_u32 vcc, {s('W')}, v{V_T + half}")
-                e(f"s_and_b64 vcc, vcc, {s2('TA')}")
-                e(f"s_mul_i32 {s('T3')}, {s('T2')}, {s('W')}")
-                e(f"v_add_u32 v{V_T + 2}, {s('T3')}, v{V_T + half}")    # pixel index
-                e(f"v_mul_lo_u32 v{V_T + 2}, v{V_T + 2}, {s('T1')}")    # * COUT * 2
-                e(f"v_add_u32 v{V_T + 2}, v{V_T + 2}, v{V_L7X16}")
-                e(f"v_cndmask_b32 v{d}, -1, v{V_T + 2}, vcc")
+        e(f"v_add_u32 v{V_T}, {s('X0')}, v{V_L3}")
+        e(f"v_cmp_gt_u32 {s2('XM0')}, {s('W')}, v{V_T}")
+        e(f"v_add_u32 v{V_T}, 8, v{V_T}")
+        e(f"v_cmp_gt_u32 {s2('XM1_')}, {s('W')}, v{V_T}")
 
     def tile_end(self):
         e = self.e
@@ -512,6 +526,29 @@ def generate():
     e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 5")
     e(f"s_lshr_b32 {s('CHA')}, {s('CA')}, 5")
     e(f"s_lshl_b32 {s('CA2')}, {s('CA')}, 1")
+    # the pieces' constant byte offsets from the tile's origin, and which of the ten exist
+    e(f"v_mov_b32 v{V_INR}, 0")
+    for i in range(NI):
+        r, c, t = V_T, V_T + 1, V_T + 2
+        e(f"v_bfe_u32 v{r}, v{V_HRC + i}, 8, 8")
+        e(f"v_and_b32 v{c}, 0xff, v{V_HRC + i}")
+        e(f"v_mul_lo_u32 v{r}, v{r}, {s('W')}")
+        e(f"v_add_u32 v{r}, v{r}, v{c}")
+        e(f"v_mul_lo_u32 v{r}, v{r}, {s('CA2')}")
+        e(f"v_bfe_u32 v{c}, v{V_HRC + i}, 16, 2")
+        e(f"v_lshlrev_b32 v{c}, 4, v{c}")
+        e(f"v_add_u32 v{r}, v{r}, v{c}")
+        e(f"v_cmp_le_i32 vcc, 0, v{V_HRC + i}")
+        e(f"v_cndmask_b32 v{V_VOFF + i}, 0, v{r}, vcc")
+        e(f"v_mov_b32 v{t}, {1 << i}")
+        e(f"v_cndmask_b32 v{t}, 0, v{t}, vcc")
+        e(f"v_or_b32 v{V_INR}, v{V_INR}, v{t}")
+    e(f"s_lshl_b32 {s('T0')}, {s('COUT')}, 1")
+    e(f"s_mul_i32 {s('RS')}, {s('W')}, {s('T0')}")                      # bytes between output rows
+    e(f"v_mul_lo_u32 v{V_VS}, v{V_L3}, {s('T0')}")
+    e(f"v_add_u32 v{V_VS}, v{V_VS}, v{V_L7X16}")                        # column (lane >> 3), piece lane & 7
+    e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 3")
+    e(f"v_add_u32 v{V_VS + 1}, {s('T0')}, v{V_VS}")                      # column 8 + (lane >> 3)
     e(f"s_cmp_eq_u32 {s('T3')}, 0")
     e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the epilogue's v_max: -inf (linear) or 0
     # the bias table -> LDS: thread t (< 64 * NCT) copies bias[t] (no bias: zeros)
