@@ -7,12 +7,12 @@
 namespace s2l {
 
 struct ConvHArgs {
-  const uint16_t* inA;     // [F,H,W,CA] bf16
-  const uint16_t* inB;     // [F,H,W,CB] or null (virtual concat: channels of A first; CB == CA)
+  const uint16_t* inA;     // [F][CA/32][H][W][32] bf16: 32-channel planes ("C32", csrc/unet_half.inc)
+  const uint16_t* inB;     // [F][CB/32][H][W][32] or null (virtual concat: planes of A first)
   const uint16_t* w16;     // s2l_unet_pack16 chunks of this layer: [rows/64][k/32][tap 9][k-step 2][block 2][lane 64][8]
   const float* bias;       // [cout] or null
-  uint16_t* out;           // [F,H,W,cout] bf16
-  const uint16_t* gate;    // or null: [F,H,W,cout] bf16; out = gate > 0 ? value : 0
+  uint16_t* out;           // [F][cout/32][H][W][32] bf16
+  const uint16_t* gate;    // or null: out's shape; out = gate > 0 ? value : 0
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;      // tiles of 32 rows x 16 columns
   int relu;                // 1: max(0, .) before the conversion
   int n_frames;

@@ -61,26 +61,27 @@ __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
         cst[(10 + dx * 2 + ks) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * ks + hh) ^ ((col >> 2) & 3)) << 4));
       }
   }
-  // store staging (this wave's 4 KiB at the start of buffer 1: [32 pixels][64 channels] bf16, 16-byte piece index ^ ((pixel >> 1) & 7)):
-  // write address of piece pc = 4 mb + rq (pixel n = lane & 31, channels 8 pc + 4 hh ..: 8 bytes), read address of store j (pixel
-  // 8 j + (lane >> 3), piece lane & 7)
+  // store staging (this wave's 4 KiB at the start of buffer 1: [M-block 2][32 pixels][32 channels] bf16, a pixel's 16-byte piece index
+  // ^ ((pixel >> 2) & 3)): write address of piece pc = 4 mb + rq (pixel n = lane & 31, channels 8 rq + 4 hh .. of M-block mb: 8 bytes),
+  // read address of store j = (row j >> 1 of the N-block, M-block j & 1): pixel 16 (j >> 1) + (lane >> 2), piece lane & 3
   {
     const uint32_t stg = lds0 + kCHBuf + wave * 4096;
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) cst[(16 + pc) * 256 + tid] = stg + (uint32_t)(n * 128 + ((pc ^ ((n >> 1) & 7)) << 4) + hh * 8);
+    for (int pc = 0; pc < 8; ++pc)
+      cst[(16 + pc) * 256 + tid] = stg + (uint32_t)((pc >> 2) * 2048 + n * 64 + (((pc & 3) ^ ((n >> 2) & 3)) << 4) + hh * 8);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int px = 8 * j + (lane >> 3);
-      cst[(24 + j) * 256 + tid] = stg + (uint32_t)(px * 128 + (((lane & 7) ^ ((px >> 1) & 7)) << 4));
+      const int px = 16 * (j >> 1) + (lane >> 2);
+      cst[(24 + j) * 256 + tid] = stg + (uint32_t)((j & 1) * 2048 + px * 64 + (((lane & 3) ^ ((px >> 2) & 3)) << 4));
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the constants are in LDS (each lane reads back only its own words)
 #include "convh_body.inc"
 }
 
-// 0 if the launch was taken.  Conditions: an even number of 32-channel chunks, a concatenation of two equally wide tensors, cout a
-// multiple of 64 (<= 256), frames small enough for 32-bit in-frame byte offsets.
+// 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
+// (<= 256), tensors small enough for 31-bit pixel indices over all their planes.
 int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   *launched = false;
   ConvHArgs a = a0;
@@ -88,10 +89,10 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   a.tiles_y = (a.H + kCHTileH - 1) / kCHTileH;
   a.n_ct = a.cout / 64;
   const int nch = (a.CA + a.CB) / 32;
-  const int cmax = a.CA > a.cout ? a.CA : a.cout;
-  if ((a.CA + a.CB) % 32 != 0 || nch % 2 != 0 || a.CA % 32 != 0 || !(a.CB == 0 || (a.CB == a.CA && a.inB)) || a.cout % 64 != 0 ||
-      a.n_ct > 4 || a.n_ct < 1 || (int64_t)a.H * a.W * cmax * 2 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames >= 0x7fffffffLL ||
-      a.n_frames <= 0 || a.H > 255 * 32 || a.W > 255 * 16 || a.relu != 0)      // (the body is generated without the ReLU: WITH_RELU)
+  const int cmax = std::max(a.CA, std::max(a.CB, a.cout));
+  if (a.CA % 32 != 0 || a.CB % 32 != 0 || a.CA < 32 || nch % 2 != 0 || (a.CB != 0 && !a.inB) || a.cout % 64 != 0 || a.n_ct > 4 || a.n_ct < 1 ||
+      a.n_frames <= 0 || (int64_t)a.H * a.W * 64 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames * (cmax / 32) >= 0x7fffffffLL / 2 ||
+      a.H > 255 * 32 || a.W > 255 * 16 || a.relu != 0)      // (the body is generated without the ReLU: WITH_RELU)
     return S2L_OK;
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
   if (total >= 0x7fffffff) return S2L_OK;

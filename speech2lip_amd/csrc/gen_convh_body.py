@@ -54,7 +54,7 @@ V_LANE, V_TID, V_HH16, V_DMA, V_BIASA, V_L3, V_L7X16, V_ONES, V_FFFF, V_INR = 42
 V_SWA = 52                      # 8: staging write addresses per piece mb * 4 + rq
 V_SRA = 60                      # 4: staging read addresses per store j
 V_T = 64                        # temporaries 64..127
-V_VS = 128                      # 2: byte offset of this lane's 16 bytes in a store of column half h from the row's pointer
+V_VS = 128                      # byte offset of this lane's 16 bytes in a store from the row's pointer (lane * 16)
 V_G = 132                       # 64: gate pieces [nb][j][4]
 V_LAST = 195
 
@@ -74,10 +74,10 @@ def _scalars(first, singles, pairs, skip=(32, 33)):
     return m
 
 
-S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA WAVE LDS0 RELU CA2 LDSW LDSH T0 T1 T2 T3 "
+S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA CHB WAVE LDS0 RELU HW64 HW LDSW LDSH T0 T1 T2 T3 "
                           "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0 RS GY0").split(),
              pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "WCH1_", "WCH2_", "FRA", "FRB", "OUTF", "GATEF",
-                    "EX", "TA", "TB", "XM0", "XM1_", "ROWB"))
+                    "EX", "TA", "TB", "XM0", "ROWB"))
 S_LAST = max(S.values())
 assert S_LAST <= 101, S_LAST
 
@@ -242,16 +242,16 @@ class Body:
         e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
         e(f"s_mul_i32 {s('SY0')}, {s('NTY')}, {TILE_H}")
         self.geometry()
-        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('W')}")
-        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('NFR')}")               # pixels before this frame (< 2^31: the launcher checks)
         e(f"s_sub_u32 {s('T1')}, {s('SY0')}, 1")
         e(f"s_mul_i32 {s('T1')}, {s('T1')}, {s('W')}")
         e(f"s_add_u32 {s('T1')}, {s('T1')}, {s('SX0')}")
-        e(f"s_sub_u32 {s('T1')}, {s('T1')}, 1")                         # (SY0 - 1) W + SX0 - 1 >= -(W + 1)
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")                 # pixel index of the halo origin, as a signed number
-        e(f"s_mul_hi_i32 {s('T3')}, {s('T0')}, {s('CA2')}")             # (both tensors of a concatenation have CA channels)
-        e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('CA2')}")
-        for fr, src in (("FRA", "INA"), ("FRB", "INB")):
+        e(f"s_sub_u32 {s('T1')}, {s('T1')}, 1")                         # (SY0 - 1) W + SX0 - 1 >= -(W + 1): the halo origin inside a plane
+        for fr, src, ch in (("FRA", "INA", "CHA"), ("FRB", "INB", "CHB")):
+            e(f"s_mul_i32 {s('T0')}, {s('NFR')}, {s(ch)}")              # planes of this tensor before the frame
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW')}")             # pixels (< 2^31: the launcher checks)
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")             # signed
+            e(f"s_ashr_i32 {s('T3')}, {s('T0')}, 26")                   # * 64 bytes as a signed 64-bit number
+            e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 6")
             e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
         e(f"s_mul_i32 {s('T0')}, {s('NCT_')}, {s('NCH')}")
@@ -260,16 +260,17 @@ class Body:
         e(f"s_addc_u32 {s('WB1')}, {s('W161')}, 0")
 
     def staging_source(self):
-        """for chunk NC of the staging tile: SRC (channel 0 of the chunk at pixel 0 of the frame; both tensors of a concatenation have
-        CA channels: the launcher checks) and WCH / WCH1_ / WCH2_ (the chunk's weights, + 4 KiB, + 8 KiB)"""
+        """for chunk NC of the staging tile: SRC (the chunk's 32-channel plane at the tile's halo origin) and WCH / WCH1_ / WCH2_ (the
+        chunk's weights, + 4 KiB, + 8 KiB)"""
         e = self.e
         e(f"s_cmp_lt_u32 {s('NC')}, {s('CHA')}")                       # chunk from A?
         e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
         e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
-        e(f"s_sub_u32 {s('T0')}, {s('NC')}, {s('T0')}")                # chunk index inside its tensor
-        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 6")                        # * 32 channels * 2 bytes
+        e(f"s_sub_u32 {s('T0')}, {s('NC')}, {s('T0')}")                # plane index inside its tensor
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('HW64')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW64')}")
         e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
-        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, 0")
+        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, {s('T1')}")
         e(f"s_mul_i32 {s('T0')}, {s('NC')}, {W_BYTES}")
         e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
         e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
@@ -318,17 +319,22 @@ class Body:
             items.append(g)
         return items
 
-    def row_exec(self, row, half, base, first):
-        """exec = the lanes of store (row, half) inside the image; ROWB = base + row * RS"""
+    def row_exec(self, row, mb, base, first):
+        """exec = the lanes of the store of (row, M-block) inside the image; ROWB = base + row * RS + mb * HW64"""
         e = self.e
         if first:
             e(f"s_mov_b64 {s2('ROWB')}, {s2(base)}")
-        elif half == 0:
+        elif mb == 0:
+            e(f"s_sub_u32 {s('ROWB')}, {s('ROWB')}, {s('HW64')}")        # back to M-block 0, one row down
+            e(f"s_subb_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
             e(f"s_add_u32 {s('ROWB')}, {s('ROWB')}, {s('RS')}")
+            e(f"s_addc_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
+        else:
+            e(f"s_add_u32 {s('ROWB')}, {s('ROWB')}, {s('HW64')}")
             e(f"s_addc_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
         e(f"s_add_u32 {s('T2')}, {s('GY0')}, {row}")
         e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
-        e(f"s_cselect_b64 exec, {s2('XM0' if half == 0 else 'XM1_')}, 0")
+        e(f"s_cselect_b64 exec, {s2('XM0')}, 0")
 
     def gate_loads(self):
         """the gate's sixteen pieces of this lane (the compute tile's store positions), if the launch has a gate and this is the tile's
@@ -344,15 +350,15 @@ class Body:
             nb, j = k >> 2, k & 3
             self.row_exec(2 * nb + (j >> 1), j & 1, "GATEF", k == 0)
             if not EXP & 16:
-                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_VS + (j & 1)}, {s2('ROWB')}")
+                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_VS}, {s2('ROWB')}")
         e("s_mov_b64 exec, -1")
         e(f"{skip}:")
 
     def store_tile(self):
-        """the stores of the tile that just ended (bases OUTF / GATEF, masks XM0 / XM1_, GY0: set by tile_begin).  An N-block's 64
-        channels x 32 pixels leave through this wave's 4 KiB of LDS staging as bf16: lane (n, hh) writes the 8 bytes of channels
-        8 pc + 4 hh .. + 3 of pixel n for the eight pieces pc = 4 mb + rq; lane l reads piece l & 7 of pixel 8 j + (l >> 3): a store
-        instruction writes eight whole 128-byte lines.  Gate (<= 0 -> 0) on the packed halves."""
+        """the stores of the tile that just ended (bases OUTF / GATEF, mask XM0, GY0: set by tile_begin).  An N-block's 64 channels x
+        32 pixels leave through this wave's 4 KiB of LDS staging as bf16 ([M-block][pixel][32 channels]): lane (n, hh) writes the 8
+        bytes of channels 8 rq + 4 hh .. + 3 of pixel n of M-block mb; lane l reads piece l & 3 of pixel 16 r + (l >> 2): a store
+        instruction writes one row of the tile in one 32-channel plane, 1 KiB contiguous.  Gate (<= 0 -> 0) on the packed halves."""
         e = self.e
         ta, tc, tb, tm = V_T, V_T + 16, V_T + 32, V_T + 48
         for nb in range(4):
@@ -385,7 +391,7 @@ class Body:
             for j in range(4):
                 self.row_exec(2 * nb + (j >> 1), j & 1, "OUTF", nb == 0 and j == 0)
                 if not EXP & 1:
-                    e(f"global_store_dwordx4 v{V_VS + (j & 1)}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
+                    e(f"global_store_dwordx4 v{V_VS}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
             e("s_mov_b64 exec, -1")
 
     # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
@@ -402,12 +408,22 @@ class Body:
             sprinkle = [[] for _ in range(16)]
             for m, rd in enumerate(nxt):
                 sprinkle[m].append(rd)
-            if t == 0:                                   # (m0 belongs to one group at a time: weights behind tap 0, halo behind taps 1..2)
-                for k, g in enumerate(dma):
-                    sprinkle[6 + k].extend(g)
-            if t in (1, 2):
-                for k, g in enumerate(hal[(t - 1) * 5:t * 5]):
-                    sprinkle[3 + 3 * k].extend(g)
+            # m0 belongs to one group at a time: the weight pieces behind tap 0, the halo requests behind taps 1..2
+            order = os.environ.get("S2L_CH_ORDER", "weights_first")      # (halo first measured 4 % slower: 7.25 vs 6.98 ms per 20 frames)
+            if order == "halo_first":
+                if t == 0:
+                    for k, g in enumerate(hal):
+                        sprinkle[1 + k + k // 2].extend(g)
+                if t in (1, 2):
+                    for k, g in enumerate(dma[:4] if t == 1 else dma[4:]):
+                        sprinkle[4 + 2 * k].extend(g)
+            else:
+                if t == 0:
+                    for k, g in enumerate(dma):
+                        sprinkle[6 + k].extend(g)
+                if t in (1, 2):
+                    for k, g in enumerate(hal[(t - 1) * 5:t * 5]):
+                        sprinkle[3 + 3 * k].extend(g)
             if t == 4 and p == 1:
                 self.gate_loads()
             self.wait_lds(("R", t, 1, 1, 3))
@@ -431,30 +447,29 @@ class Body:
                     self.wait_all_lds()
 
     def tile_begin(self):
-        """the compute tile's store state: OUTF / GATEF = the address of (first row of this wave, column X0, channel tile CT), GY0 = that
-        row, XM0 / XM1_ = the lanes whose column (X0 + 8 half + (lane >> 3)) is inside the image"""
+        """the compute tile's store state: OUTF / GATEF = the address of (plane 2 CT of frame FR, first row of this wave, column X0),
+        GY0 = that row, XM0 = the lanes whose column (X0 + (lane >> 2)) is inside the image"""
         e = self.e
         e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
         e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
         e(f"s_lshl_b32 {s('GY0')}, {s('WAVE')}, 3")
         e(f"s_add_u32 {s('GY0')}, {s('GY0')}, {s('Y0')}")
-        e(f"s_mul_i32 {s('T0')}, {s('H')}, {s('FR')}")
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('GY0')}")
-        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('W')}")
-        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('X0')}")                 # pixel index (< 2^31: the launcher checks F H W)
-        e(f"s_lshl_b32 {s('T1')}, {s('COUT')}, 1")
-        e(f"s_mul_hi_u32 {s('T3')}, {s('T0')}, {s('T1')}")
-        e(f"s_mul_i32 {s('T2')}, {s('T0')}, {s('T1')}")
-        e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 7")
-        e(f"s_add_u32 {s('T2')}, {s('T2')}, {s('T0')}")
-        e(f"s_addc_u32 {s('T3')}, {s('T3')}, 0")
+        e(f"s_lshr_b32 {s('T0')}, {s('COUT')}, 5")                      # planes per frame
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
+        e(f"s_lshl_b32 {s('T1')}, {s('CT')}, 1")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")                 # plane index of (FR, CT, M-block 0)
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW')}")
+        e(f"s_mul_i32 {s('T1')}, {s('GY0')}, {s('W')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('X0')}")                 # pixel index (< 2^31: the launcher checks)
+        e(f"s_lshr_b32 {s('T3')}, {s('T0')}, 26")
+        e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 6")
         for dst, src in (("OUTF", "OUT"), ("GATEF", "GATE")):
             e(f"s_add_u32 {s(dst)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(dst + '1')}, {s(src + '1')}, {s('T3')}")
-        e(f"v_add_u32 v{V_T}, {s('X0')}, v{V_L3}")
+        e(f"v_lshrrev_b32 v{V_T}, 2, v{V_LANE}")
+        e(f"v_add_u32 v{V_T}, {s('X0')}, v{V_T}")
         e(f"v_cmp_gt_u32 {s2('XM0')}, {s('W')}, v{V_T}")
-        e(f"v_add_u32 v{V_T}, 8, v{V_T}")
-        e(f"v_cmp_gt_u32 {s2('XM1_')}, {s('W')}, v{V_T}")
 
     def tile_end(self):
         e = self.e
@@ -525,8 +540,8 @@ def generate():
     e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
     e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 5")
     e(f"s_lshr_b32 {s('CHA')}, {s('CA')}, 5")
-    e(f"s_lshl_b32 {s('CA2')}, {s('CA')}, 1")
-    # the pieces' constant byte offsets from the tile's origin, and which of the ten exist
+    e(f"s_lshr_b32 {s('CHB')}, {s('CB')}, 5")
+    # the pieces' constant byte offsets from the tile's origin inside a 32-channel plane, and which of the ten exist
     e(f"v_mov_b32 v{V_INR}, 0")
     for i in range(NI):
         r, c, t = V_T, V_T + 1, V_T + 2
@@ -534,7 +549,7 @@ def generate():
         e(f"v_and_b32 v{c}, 0xff, v{V_HRC + i}")
         e(f"v_mul_lo_u32 v{r}, v{r}, {s('W')}")
         e(f"v_add_u32 v{r}, v{r}, v{c}")
-        e(f"v_mul_lo_u32 v{r}, v{r}, {s('CA2')}")
+        e(f"v_lshlrev_b32 v{r}, 6, v{r}")
         e(f"v_bfe_u32 v{c}, v{V_HRC + i}, 16, 2")
         e(f"v_lshlrev_b32 v{c}, 4, v{c}")
         e(f"v_add_u32 v{r}, v{r}, v{c}")
@@ -543,12 +558,10 @@ def generate():
         e(f"v_mov_b32 v{t}, {1 << i}")
         e(f"v_cndmask_b32 v{t}, 0, v{t}, vcc")
         e(f"v_or_b32 v{V_INR}, v{V_INR}, v{t}")
-    e(f"s_lshl_b32 {s('T0')}, {s('COUT')}, 1")
-    e(f"s_mul_i32 {s('RS')}, {s('W')}, {s('T0')}")                      # bytes between output rows
-    e(f"v_mul_lo_u32 v{V_VS}, v{V_L3}, {s('T0')}")
-    e(f"v_add_u32 v{V_VS}, v{V_VS}, v{V_L7X16}")                        # column (lane >> 3), piece lane & 7
-    e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 3")
-    e(f"v_add_u32 v{V_VS + 1}, {s('T0')}, v{V_VS}")                      # column 8 + (lane >> 3)
+    e(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
+    e(f"s_lshl_b32 {s('HW64')}, {s('HW')}, 6")                          # bytes of one 32-channel plane (< 2^31: the launcher checks)
+    e(f"s_lshl_b32 {s('RS')}, {s('W')}, 6")                             # bytes between rows of a plane
+    e(f"v_lshlrev_b32 v{V_VS}, 4, v{V_LANE}")                           # a store's lane offset: column lane >> 2, piece lane & 3
     e(f"s_cmp_eq_u32 {s('T3')}, 0")
     e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the epilogue's v_max: -inf (linear) or 0
     # the bias table -> LDS: thread t (< 64 * NCT) copies bias[t] (no bias: zeros)

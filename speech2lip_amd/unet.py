@@ -17,6 +17,18 @@ from . import _abi
 from .weights import UNET_CONVS
 
 
+def nhwc_to_c32(x: torch.Tensor) -> torch.Tensor:
+    """[F,H,W,C] -> the half-width chain's layout [F,C/32,H,W,32] (32-channel planes; csrc/unet_half.inc).  A test / tool helper:
+    the chain itself never converts."""
+    F_, H, W, C = x.shape
+    return x.reshape(F_, H, W, C // 32, 32).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def c32_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    F_, P, H, W, _ = x.shape
+    return x.permute(0, 2, 3, 1, 4).reshape(F_, H, W, P * 32).contiguous()
+
+
 def _double_conv(cin, cout, mid=None):
     mid = mid or cout
     seq = nn.Sequential(nn.Conv2d(cin, mid, 3, padding=1, bias=False), nn.BatchNorm2d(mid), nn.ReLU(inplace=True),

@@ -18,6 +18,7 @@ import torch
 
 import speech2lip_amd as s2l
 from speech2lip_amd import _abi, weights as W
+from speech2lip_amd.unet import c32_to_nhwc, nhwc_to_c32
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -70,10 +71,11 @@ def test_convolution_is_the_rounded_fp32_tensor_kernel(blobs, dev, layer, transp
     _abi.check(lib.s2l_debug_conv_layer_f32(p(raw), p(raw16), layer, transposed, p(a32), CA, p(b32), CB, p(g32), p(ref), H, Wd, F, st),
                "s2l_debug_conv_layer_f32")
     want = ref.to(torch.bfloat16).view(torch.int16)
+    ah, bh, gh = nhwc_to_c32(a), (nhwc_to_c32(b) if cat else None), (nhwc_to_c32(gt) if gate else None)      # the chain's plane layout
     for rep in range(2):
-        out = torch.full((F, H, Wd, cout), -1, dtype=torch.int16, device=dev)
-        _abi.check(lib.s2l_convh_layer(p(raw16), layer, transposed, p(a), CA, p(b), CB, p(gt), p(out), H, Wd, F, st), "s2l_convh_layer")
-        assert torch.equal(out, want), rep
+        out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+        _abi.check(lib.s2l_convh_layer(p(raw16), layer, transposed, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "s2l_convh_layer")
+        assert torch.equal(c32_to_nhwc(out), want), rep
     assert float(ref.abs().max()) > 0 and bool(torch.isfinite(ref).all())
     if gate:
         assert float((ref == 0).float().mean()) > 0.3      # the gate really closed
@@ -82,8 +84,8 @@ def test_convolution_is_the_rounded_fp32_tensor_kernel(blobs, dev, layer, transp
 def test_convolution_argument_errors(blobs, dev):
     _, raw, raw16 = blobs
     lib = _abi.load()
-    a = torch.zeros(1, 8, 8, 64, dtype=torch.int16, device=dev)
-    o = torch.zeros(1, 8, 8, 64, dtype=torch.int16, device=dev)
+    a = torch.zeros(1, 2, 8, 8, 32, dtype=torch.int16, device=dev)
+    o = torch.zeros(1, 2, 8, 8, 32, dtype=torch.int16, device=dev)
     assert lib.s2l_convh_layer(p(raw16), 0, 0, p(a), 64, None, 0, None, p(o), 8, 8, 1, None) == -2       # layer 0 is the fp32-input convolution
     assert lib.s2l_convh_layer(p(raw16), 1, 0, p(a), 32, None, 0, None, p(o), 8, 8, 1, None) == -2       # channel count of the layer
     assert lib.s2l_convh_layer(None, 1, 0, p(a), 64, None, 0, None, p(o), 8, 8, 1, None) == -1

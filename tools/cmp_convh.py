@@ -14,6 +14,7 @@ import torch
 
 import speech2lip_amd as s2l
 from speech2lip_amd import _abi, weights as W
+from speech2lip_amd.unet import c32_to_nhwc, nhwc_to_c32
 from speech2lip_amd.unet import UNET_CONVS
 
 CONVS = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128), (256, 128), (128, 64), (128, 64), (64, 64)]
@@ -39,10 +40,11 @@ def layer_case(lib, u, raw, raw16, dev, layer, transposed, F, H, Wd, gate, seed)
     a32, b32, g32 = a.float(), (b.float() if b is not None else None), (gt.float() if gt is not None else None)
     _abi.check(lib.s2l_debug_conv_layer_f32(p(raw), p(raw16), layer, int(transposed), p(a32), CA, p(b32), CB, p(g32), p(ref), H, Wd, F, st), "ref")
     outs = []
+    ah, bh, gh = nhwc_to_c32(a), (nhwc_to_c32(b) if b is not None else None), (nhwc_to_c32(gt) if gt is not None else None)
     for rep in range(2):
-        out = torch.full((F, H, Wd, cout), -1, dtype=torch.int16, device=dev)
-        _abi.check(lib.s2l_convh_layer(p(raw16), layer, int(transposed), p(a), CA, p(b), CB, p(gt), p(out), H, Wd, F, st), "convh")
-        outs.append(out)
+        out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+        _abi.check(lib.s2l_convh_layer(p(raw16), layer, int(transposed), p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "convh")
+        outs.append(c32_to_nhwc(out))
     torch.cuda.synchronize()
     want = bf16_bits(ref)
     eq = bool(torch.equal(outs[0], want))
