@@ -406,8 +406,9 @@ class Body:
             os_ = t & 1
             nxt = self.tap_reads(t + 1, p, os_ ^ 1) if t + 1 < 9 else []
             sprinkle = [[] for _ in range(16)]
+            rpm = int(os.environ.get("S2L_CH_RPM", "1"))      # operand reads of the next tap per MFMA slot
             for m, rd in enumerate(nxt):
-                sprinkle[m].append(rd)
+                sprinkle[m // rpm].append(rd)
             # m0 belongs to one group at a time: the weight pieces behind tap 0, the halo requests behind taps 1..2
             order = os.environ.get("S2L_CH_ORDER", "weights_first")      # (halo first measured 4 % slower: 7.25 vs 6.98 ms per 20 frames)
             if order == "halo_first":

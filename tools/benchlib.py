@@ -334,7 +334,7 @@ def sync_batch(dev, S, T=5, FH=500, FW=500, h=96, w=96, x0=202, y0=316, seed=11)
                 canonical_face_bbox=[110, 90, 390, 420, 1.0], mel=mel, rgb_window_neg=neg)
 
 
-def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=False):
+def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=False, half_width_tensors=True):
     """BASELINE config 5 as named -- MLP forward + backward WITH the lipsync_expert loss: B main frames (MSE) of which the
     first S carry a 5-frame sync window (5 S more renders -> composite -> frozen U-Net @500x500 -> crop/resize -> SyncNet x2 ->
     BCE, and all of it back to the MLP), bf16 MLP kernels, Adam.  FLOPs counted: the MLP's as-written 3 x 4 x 2 x 644,864 per
@@ -350,6 +350,7 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
     # whole 500x500 frames (bf16 operands too when the step's precision is bf16)
     if not unet_train_mode:
         m.post_fusion_unet.eval()
+    m.post_fusion_unet.half_width_tensors = half_width_tensors      # (train mode + bf16 only: bf16 tensors between the U-Net's kernels)
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
@@ -378,8 +379,9 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
         wx0, wy0, wx1, wy1 = 0, 0, 500, 500
         unet = 2 * 157.6e9 * 5 * S
     return {"config": f"stage-1 step, {B} main frames 96x96 + sync loss on {S} samples ({5 * S} window frames through composite + U-Net "
-                      f"@500x500 + SyncNet), {precision} MLP, Adam" + (", frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16)" if unet_train_mode
-                                                                       else ", frozen U-Net in eval-mode BatchNorm"), "ms_per_step": round(dt * 1e3, 2),
+                      f"@500x500 + SyncNet), {precision} MLP, Adam" + (", frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16)" +
+                                                                        (", bf16 tensors between its kernels (csrc/unet_half.inc)" if half_width_tensors and precision == "bf16" else ", fp32 tensors between its kernels")
+                                                                        if unet_train_mode else ", frozen U-Net in eval-mode BatchNorm"), "ms_per_step": round(dt * 1e3, 2),
             "unet_window": [wx0, wy0, wx1, wy1], "mlp_frames_per_step": B + 5 * S, "mlp_tflop_per_step": round(mlp / 1e12, 3), "unet_tflop_per_step": round(unet / 1e12, 3),
             "tflops": round((mlp + unet) / dt / 1e12, 1), "loss_first": l0, "loss_last": float(l),
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
