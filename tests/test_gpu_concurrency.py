@@ -172,6 +172,7 @@ def test_soak_slice_of_the_counted_wait_assembly_kernels(dev):
     bad = soak.soak_render(dev, 60, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_bf16(dev, 25, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_conv(dev, 15, seed=4, log=lambda *a: notes.append(a))
+    bad += soak.soak_convh(dev, 40, seed=4, log=lambda *a: notes.append(a))
     torch.cuda.synchronize()
     assert not bad, notes
 

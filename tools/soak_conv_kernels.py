@@ -6,10 +6,11 @@ arithmetic, and with a second run of itself.
           plain-bf16 training chain, against the one-tile-per-workgroup kernels (the soak that found round 3's ~1 %-of-shapes copy race);
   render  render_tiles_kernel / render16_tiles_kernel<long | wide | single>: random (H, W, F), the three tile shapes against each other and the
           auto-picked one, each twice (every sample column sees the same MFMA sequence in every shape);
+  convh   convh_asm_kernel (bf16 planes): random layer / direction / gate / size against the fp32-tensor kernel's rounded output;
   bf16    fwd_asm_bf16_kernel / bwd_asm_bf16_kernel: random (h, w, B) rows, assembly vs the C++ kernels (activation images,
           ReLU mask words, rgb, dz images), each twice.
 
-    python tools/soak_conv_kernels.py [rounds=150] [conv|render|bf16|all]
+    python tools/soak_conv_kernels.py [rounds=150] [conv|render|bf16|convh|all]
 
 `tests/test_gpu_concurrency.py` runs a 100-shape slice of the three under `-m gpu`."""
 import ctypes
@@ -141,12 +142,56 @@ def soak_bf16(dev, rounds, seed=0, log=print):
     return bad
 
 
+def soak_convh(dev, rounds, seed=0, log=print):
+    """convh_asm_kernel (bf16 planes, csrc/convh.hip): random layer / direction / size / gate against the fp32-tensor kernel of the same
+    arithmetic (its output rounded to bf16), each twice."""
+    from speech2lip_amd.unet import c32_to_nhwc, nhwc_to_c32
+    convs = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128), (256, 128), (128, 64), (128, 64), (64, 64)]
+    u = s2l.SimpleUnetLight().to(dev).train()
+    u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
+    tensors = u._tensors()
+    raw, raw16 = u._raw_blobs(tensors, u._table(tensors), True)
+    lib = _abi.load()
+    rng = np.random.default_rng(seed + 3)
+    p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+    bad = []
+    for it in range(rounds):
+        layer, tr, gate = int(rng.integers(1, 10)), int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        big = it % 4 == 0
+        F = int(rng.integers(1, 3)) if big else int(rng.integers(1, 24))
+        H = int(rng.integers(150, 420)) if big else int(rng.integers(1, 90))
+        Wd = int(rng.integers(150, 420)) if big else int(rng.integers(1, 90))
+        cin, cout = convs[layer]
+        if tr:
+            cin, cout = cout, cin
+        cat = layer in (6, 8) and not tr
+        CA, CB = (cin // 2, cin // 2) if cat else (cin, 0)
+        a = torch.randn(F, H, Wd, CA, device=dev).to(torch.bfloat16)
+        b = torch.randn(F, H, Wd, CB, device=dev).to(torch.bfloat16) if CB else None
+        gt = torch.randn(F, H, Wd, cout, device=dev).clamp_min(0).to(torch.bfloat16) if (gate and tr) else None
+        a32, b32, g32 = a.float(), (b.float() if cat else None), (gt.float() if gt is not None else None)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ref = torch.zeros(F, H, Wd, cout, device=dev)
+        _abi.check(lib.s2l_debug_conv_layer_f32(p(raw), p(raw16), layer, tr, p(a32), CA, p(b32), CB, p(g32), p(ref), H, Wd, F, st), "ref")
+        want = ref.to(torch.bfloat16).view(torch.int16)
+        ah, bh, gh = nhwc_to_c32(a), (nhwc_to_c32(b) if cat else None), (nhwc_to_c32(gt) if gt is not None else None)
+        ok = True
+        for rep in range(2):
+            out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+            _abi.check(lib.s2l_convh_layer(p(raw16), layer, tr, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "convh")
+            ok = ok and torch.equal(c32_to_nhwc(out), want)
+        if not ok:
+            bad.append(("convh", layer, tr, F, H, Wd, gate))
+            log("MISMATCH convh", layer, tr, F, H, Wd, gate)
+    return bad
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     which = sys.argv[2] if len(sys.argv) > 2 else "conv"
     bad = []
-    for name, fn in (("conv", soak_conv), ("render", soak_render), ("bf16", soak_bf16)):
+    for name, fn in (("conv", soak_conv), ("render", soak_render), ("bf16", soak_bf16), ("convh", soak_convh)):
         if which in (name, "all"):
             b = fn(dev, rounds)
             torch.cuda.synchronize()
