@@ -36,7 +36,7 @@ STG_OFF = BUF                                                   # store staging 
 NI = 10                                                         # halo DMA instructions per wave (wave w: slots 640 w ..)
 CONST_WORDS = 28                                                # per lane, from the C++ prologue: hrc[10], bofs[6], swa[8], sra[4]
 WITH_RELU = False                                               # (the training chain is linear up to the gate; csrc/convh.hip refuses relu)
-EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads
 
 # ---- registers
 A_ACC = 0
@@ -152,11 +152,13 @@ class Body:
             for mb in range(2):
                 r = self.opa(os_, ks, mb)
                 off = ((t * 2 + ks) * 2 + mb) * 1024      # (V_AOFS points at the buffer's weight area)
-                out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, ks, 0, mb)))
+                if not (EXP & 64 and t > 0):
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, ks, 0, mb)))
             for nb in range(4):
                 r = self.opb(os_, ks, nb)
                 off = (2 * nb + dy) * 18 * 64
-                out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + ks} offset:{off}", ("R", t, ks, 1, nb)))
+                if not (EXP & 32 and (t > 0 or nb < 3 or ks < 1)):
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + ks} offset:{off}", ("R", t, ks, 1, nb)))
         return out
 
     def tap_mfmas(self, os_, sprinkle):
@@ -427,7 +429,10 @@ class Body:
                         sprinkle[3 + 3 * k].extend(g)
             if t == 4 and p == 1:
                 self.gate_loads()
-            self.wait_lds(("R", t, 1, 1, 3))
+            if EXP & 96:
+                self.wait_all_lds()
+            else:
+                self.wait_lds(("R", t, 1, 1, 3))
             self.tap_mfmas(os_, sprinkle)
         self.wait_all_lds()
         e("s_waitcnt vmcnt(0)")
