@@ -129,6 +129,22 @@ if uv:
                    % (uv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (uv["GRBM_GUI_ACTIVE"] / 8)))
     if "FETCH_SIZE" in uv and "WRITE_SIZE" in uv:
         out.append("HBM traffic per dispatch = 2*FETCH_SIZE + WRITE_SIZE = %.4g bytes\n" % (uv["FETCH_SIZE"] * 2048 + uv["WRITE_SIZE"] * 1024))
+# the half-width convolution kernel (tools/bench_convh.py 20: the 18 convolutions of forward + input gradient, 20 frames 500x500)
+hv = {}
+for d in ("hpmc_mfma", "hpmc_fetch", "hpmc_write", "hpmc_sq"):
+    hv.update(pmc(d, "convh_asm_kernel"))
+if hv:
+    out.append("\n## half-width convolution kernel (convh_asm_kernel), PMC averages per dispatch: python tools/bench_convh.py 20\n")
+    p_ = f"{src}/convh_line.txt"
+    if os.path.exists(p_):
+        out.append(open(p_).read())
+    for k, v in hv.items():
+        out.append("%-34s %.6g\n" % (k, v))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in hv and "GRBM_GUI_ACTIVE" in hv:
+        out.append("MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.4f of the kernel's cycles\n"
+                   % (hv["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (hv["GRBM_GUI_ACTIVE"] / 8)))
+    if "FETCH_SIZE" in hv and "WRITE_SIZE" in hv:
+        out.append("HBM traffic per dispatch = 2*FETCH_SIZE + WRITE_SIZE = %.4g bytes\n" % (hv["FETCH_SIZE"] * 2048 + hv["WRITE_SIZE"] * 1024))
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{tag}_rocprofv3_summary.txt", "w").writelines(out)
 print("".join(out))
