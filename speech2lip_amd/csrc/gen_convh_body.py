@@ -442,6 +442,12 @@ class Body:
     def bias_init(self):
         """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of the four N-blocks"""
         e = self.e
+        if EXP & 128:
+            return
+        if EXP & 256:                                                   # zeros by register writes instead of the LDS table
+            for r in range(128):
+                e(f"v_accvgpr_write_b32 a{A_ACC + r}, 0")
+            return
         e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")                        # CT * 64 floats
         e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_BIASA}")
         for mb in range(2):
