@@ -52,13 +52,19 @@ __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
   }
   // operand reads: lane (n = lane & 31, hh = lane >> 5): pixel (row 8 wave + (n >> 4) [+ 2 blk + dy as an immediate], col (n & 15) + dx),
   // 16-byte segment (2 part + hh) ^ swizzle
+  // (which pixel of its N-block lane n stands for follows ds_read_b128's NON-contiguous lane groups {0-3, 12-15, 20-27} / {4-11, 16-19,
+  // 28-31}: the sixteen lanes of a group read one row -- csrc/convh.hip has the measurement)
+  const int n_ = lane & 31;
+  const int in_g0 = (n_ < 4) || (n_ >= 12 && n_ < 16) || (n_ >= 20 && n_ < 28);
+  const int prow = in_g0 ? 0 : 1;
+  const int pcol = in_g0 ? (n_ < 4 ? n_ : n_ < 16 ? n_ - 8 : n_ - 12) : (n_ < 12 ? n_ - 4 : n_ < 20 ? n_ - 8 : n_ - 16);
   {
-    const int n = lane & 31, hh = lane >> 5;
+    const int hh = lane >> 5;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
-        const int col = (n & 15) + dx, row = 8 * wave + (n >> 4);
+        const int col = pcol + dx, row = 8 * wave + prow;
         cst[(20 + dx * 2 + pt) * 256 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * pt + hh) ^ ((col >> 2) & 3)) << 4));
       }
   }
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void conv16_asm_kernel(Conv16Args a) {
   // (pixel 8 j + (lane >> 3), quad lane & 7)
   {
     const uint32_t stg = lds0 + kC16Buf + wave * 4096;
-    const int n = lane & 31, hh = lane >> 5;
+    const int n = 16 * prow + pcol, hh = lane >> 5;      // the lane's pixel of the block
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) cst[(26 + rq) * 256 + tid] = stg + (uint32_t)(n * 128 + (((2 * rq + hh) ^ ((n >> 1) & 7)) << 4));
 #pragma unroll
