@@ -417,6 +417,13 @@ int s2l_debug_conv_layer_f32(const float* packed_raw, const uint16_t* packed16_r
                              const float* inB, int CB, const float* gate, float* out, int height, int width, int64_t n_frames,
                              s2l_stream_t stream);
 
+/* Measurement aid (tools/ubench_mfma.py): `waves` (4 or 8) waves per CU each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 on
+ * registers and nothing else -- the rate the chip sustains under that load (the clock drops below its 2.4 GHz peak). */
+int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream);
+/* Which form of the half-width convolution runs: 0 (default) eight waves per workgroup (two per SIMD), 1 four waves (one per SIMD).
+ * Same arithmetic in the same order: the outputs are the same bits (a test aid).  Any other value: S2L_E_SIZE. */
+int s2l_set_unet_half_kernel(int kind);
+
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:
  * rgb_merged[:, y:y2, x:x2, :] then transforms.Resize([96,96]); torchvision 0.9.0 resizes tensors with
  * F.interpolate(mode='bilinear', align_corners=False), no antialiasing).  src [F,src_h,src_w,3]; box = data['canonical_face_bbox'];

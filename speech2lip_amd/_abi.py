@@ -93,6 +93,8 @@ EXPORTS = {
     "s2l_convh_layer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_debug_conv_layer_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                          c_int64, c_void_p]),
+    "s2l_set_unet_half_kernel": (c_int, [c_int]),
+    "s2l_debug_bf16_mfma_rate": (c_int, [c_int64, c_int, c_void_p, c_void_p]),
     "s2l_set_unet_conv_kernel": (c_int, [c_int]),
     "s2l_set_unet_split_kernel": (c_int, [c_int]),
     "s2l_set_render_shape": (c_int, [c_int]),

@@ -4,6 +4,7 @@
 // net of training.py:436-459 after `it > 100000`), one `nn.Conv2d(3x3, padding=1, bias=False)` or its input gradient.
 #include "s2l_common.h"
 #include "convh.h"
+#include <atomic>
 
 namespace s2l {
 
@@ -88,6 +89,63 @@ __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
 #include "convh_body.inc"
 }
 
+// The eight-wave form (gen_convh8_body.py): two waves per SIMD, wave w owns rows 4 w .. 4 w + 3 of the tile.  Same arithmetic, same bits.
+__global__ __launch_bounds__(512) void convh8_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ch_smem);
+  const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
+  const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
+  if (tile0 >= tile_end) return;
+  int t = tile0;
+  const int tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
+  t /= a.tiles_x;
+  const int ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
+  t /= a.tiles_y;
+  const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
+  const int fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
+  const int ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
+  // per-lane constants ([word 23][thread 512] at the start of buffer 0): halo DMA instruction i of wave w fills slots (5 w + i) * 64 + lane
+  uint32_t* cst = reinterpret_cast<uint32_t*>(ch_smem);
+  constexpr int kSlots = kCHHalo / 16;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int sl = (wave * 5 + i) * 64 + lane;
+    const int pi = sl >> 2, row = pi / 18, col = pi % 18, seg = (sl & 3) ^ ((col >> 2) & 3);
+    cst[i * 512 + tid] = sl < kSlots ? (uint32_t)(col | (row << 8) | (seg << 16)) : 0x80000000u;
+  }
+  const int n_ = lane & 31, hh_ = lane >> 5;      // (lane -> pixel of the N-block by ds_read_b128's lane groups: see convh_asm_kernel)
+  const int in_g0 = (n_ < 4) || (n_ >= 12 && n_ < 16) || (n_ >= 20 && n_ < 28);
+  const int prow = in_g0 ? 0 : 1;
+  const int pcol = in_g0 ? (n_ < 4 ? n_ : n_ < 16 ? n_ - 8 : n_ - 12) : (n_ < 12 ? n_ - 4 : n_ < 20 ? n_ - 8 : n_ - 16);
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = pcol + dx, row = 4 * wave + prow;
+      cst[(5 + dx * 2 + ks) * 512 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * ks + hh_) ^ ((col >> 2) & 3)) << 4));
+    }
+  {
+    const uint32_t stg = lds0 + kCHBuf + wave * 4096;      // 8 x 4 KiB of buffer 1's halo area
+    const int pix = 16 * prow + pcol;
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc)
+      cst[(11 + pc) * 512 + tid] = stg + (uint32_t)((pc >> 2) * 2048 + pix * 64 + (((pc & 3) ^ ((pix >> 1) & 3)) << 4) + hh_ * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = 16 * (j >> 1) + (lane >> 2);
+      cst[(19 + j) * 512 + tid] = stg + (uint32_t)((j & 1) * 2048 + px * 64 + (((lane & 3) ^ ((px >> 1) & 3)) << 4));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#include "convh8_body.inc"
+}
+
+static std::atomic<int> g_convh_kind{0};      // 0: eight waves, 1: four waves (s2l_set_unet_half_kernel)
+
 // 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
 // (<= 256), tensors small enough for 31-bit pixel indices over all their planes.
 int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
@@ -107,11 +165,61 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
-  static LdsOptIn flag;
-  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag, dev))) return rc;
-  hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
+  static LdsOptIn flag4, flag8;
+  if (g_convh_kind.load(std::memory_order_relaxed) == 1) {
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag4, dev))) return rc;
+    hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
+  } else {
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh8_asm_kernel), kCHLds, flag8, dev))) return rc;
+    hipLaunchKernelGGL(convh8_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
+  }
   *launched = true;
   return (int)hipGetLastError();
 }
 
 }  // namespace s2l
+
+// A measurement aid: what does the chip SUSTAIN on v_mfma_f32_32x32x16_bf16 with nothing else in the way?  `waves` waves per CU (4 or 8),
+// each issuing `iters` x 8 independent MFMAs on registers; the caller times the launch (tools/ubench_mfma.py).  The dense-MFMA figure of
+// MI355X_MICROARCH.md is at the 2.4 GHz peak clock; under this load the clock is lower (power).
+namespace s2l {
+typedef short bf8v_ __attribute__((ext_vector_type(8)));
+typedef float f16v_ __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512) void mfma_rate_kernel(int64_t iters, float* __restrict__ sink) {
+  bf8v_ a, b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = (short)(0x3f80 + ((threadIdx.x + k) & 7));
+    b[k] = (short)(0x3c00 + ((threadIdx.x * 3 + k) & 15));
+  }
+  f16v_ acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int64_t i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t += acc[j][0];
+  if (t == 123.456f) sink[0] = t;      // (keeps the chain alive)
+}
+}  // namespace s2l
+extern "C" int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream) {
+  if (iters < 1 || (waves != 4 && waves != 8) || !sink) return S2L_E_SIZE;
+  int dev = 0, n_cu = 0;
+  const int rc = s2l::current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  hipLaunchKernelGGL(s2l::mfma_rate_kernel, dim3(n_cu), dim3(64 * waves), 0, static_cast<hipStream_t>(stream), iters, sink);
+  return (int)hipGetLastError();
+}
+
+// Which form runs the half-width convolutions: 0 (default) eight waves per workgroup, 1 four.  Same arithmetic in the same order: the same
+// bits (a test aid).
+extern "C" int s2l_set_unet_half_kernel(int kind) {
+  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+  s2l::g_convh_kind.store(kind, std::memory_order_relaxed);
+  return S2L_OK;
+}

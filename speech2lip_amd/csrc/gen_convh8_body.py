@@ -1,0 +1,632 @@
+"""Generates convh8_body.inc: the EIGHT-wave form of the half-width convolution (gen_convh_body.py has the design and the arithmetic, which
+are unchanged: the outputs are the same bits).  Same 32 x 16-pixel tile x 64 output channels, same LDS shapes and requests; what differs
+is the wave shape: 8 waves = TWO per SIMD, wave w owns rows 4 w .. 4 w + 3 as two N-blocks (accumulators 2 x 2 x 16 = 64 AGPRs, two operand
+sets of 32: 128 AGPRs + <= 128 VGPRs), 8 MFMAs per tap behind 4 + 4 operand reads.  Why: with one wave per SIMD every stall of that wave --
+the barrier, the first tap after it, the tile's epilogue -- idles the matrix pipe (busy 0.53 of the cycles, profiles/r04b); a second wave
+on the SIMD issues its MFMAs meanwhile.  Price: a third more operand bytes from LDS (which has the headroom: 0.39 of the cycles).
+
+Register map (per wave): a0-63 acc[mb][nb][16] | a64-95, a96-127 two operand sets (A[ks][mb] 4 x 4, B[ks][nb] 4 x 4) | VGPRs: names below."""
+import os
+import sys
+
+TILE_H = 32
+HALO_ROWS = TILE_H + 2
+HALO_BYTES, W_BYTES = HALO_ROWS * 18 * 64, 9 * 2 * 2 * 64 * 16  # 39 168 + 36 864
+N_SLOTS = HALO_BYTES // 16                                      # 2 448
+BUF = HALO_BYTES + W_BYTES                                      # 76 032
+BIAS_OFF = 2 * BUF                                              # 256 floats
+LDS_BYTES = BIAS_OFF + 1024
+STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 8 waves x 4 KiB
+NW, NB = 8, 2                                                   # waves, N-blocks (2 rows x 16 pixels) per wave
+NI = 5                                                          # halo DMA instructions per wave (wave w: slots 320 w ..)
+CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
+WITH_RELU = False                                               # (the training chain is linear up to the gate; csrc/convh.hip refuses relu)
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads
+
+# ---- registers
+A_ACC = 0
+A_OPS = (64, 96)                # operand set: A[ks][mb] at + (ks * 2 + mb) * 4, B[ks][nb] at + 16 + (ks * 2 + nb) * 4
+A_LAST = 127
+V_VOFF = 0                      # 5: byte offset of this lane's piece of DMA instruction i from the TILE's source pointer (a constant)
+V_HRC = 5                       # 5: col | row << 8 | logical segment << 16, or negative: no such slot
+V_VALID, V_ZMASK = 10, 11       # bit i: the piece is inside the image / is a halo slot outside it (zeroed); staging tile
+V_SLOT = (12, 13)               # LDS address of slot (320 wave + lane) per buffer
+V_DMA2 = 14                     # the wave's extra weight piece (waves 0..3)
+V_Z = 16                        # 4 zeros
+V_BOFS = (20, 26)
+V_AOFS = (32, 33)
+V_LANE, V_TID, V_HH16, V_DMA, V_BIASA, V_L3, V_L7X16, V_ONES, V_FFFF, V_INR = 34, 35, 36, 37, 38, 39, 40, 41, 42, 43
+V_VS = 44                       # byte offset of this lane's 16 bytes in a store from the row's pointer (lane * 16)
+V_SWA = 46                      # 8: staging write addresses per piece mb * 4 + rq
+V_SRA = 54                      # 4: staging read addresses per store j
+V_T = 60                        # temporaries 60..87 (the store read-backs share the accumulator temporaries)
+V_G = 88                        # 32: gate pieces [nb][j][4]
+V_LAST = 119
+
+
+def _scalars(first, singles, pairs, skip=(32, 33)):
+    m, r = {}, first
+    for n in pairs:
+        while (r & 1) or r in skip or (r + 1) in skip:
+            r += 1
+        m[n], m[n + "1"] = r, r + 1
+        r += 2
+    for n in singles:
+        while r in skip:
+            r += 1
+        m[n] = r
+        r += 1
+    return m
+
+
+S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA CHB WAVE LDS0 RELU HW64 HW LDSW LDSH T0 T1 T2 T3 "
+                          "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0 RS GY0 LDSW2").split(),
+             pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "FRA", "FRB", "OUTF", "GATEF",
+                    "EX", "TA", "TB", "XM0", "ROWB"))
+S_LAST = max(S.values())
+assert S_LAST <= 101, S_LAST
+
+# byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
+ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
+       "tiles_y": 72, "n_ct": 76, "relu": 80}
+
+
+def s(n):
+    return f"s{S[n]}"
+
+
+def s2(n):
+    return f"s[{S[n]}:{S[n] + 1}]"
+
+
+class Body:
+    def __init__(self):
+        self.L, self.lds, self.nlabel = [], [], 0
+
+    def e(self, t):
+        self.L.append(t)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return f"S2L8_{stem}_{self.nlabel}"
+
+    def lds_op(self, text, tag):
+        self.e(text)
+        self.lds.append(tag)
+
+    def wait_lds(self, tag):
+        if tag not in self.lds:
+            return
+        newer = len(self.lds) - 1 - self.lds.index(tag)
+        assert newer <= 15, newer
+        self.e(f"s_waitcnt lgkmcnt({newer})")
+        self.lds = self.lds[len(self.lds) - newer:] if newer else []
+
+    def wait_all_lds(self):
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.lds = []
+
+    def emit_group(self, g):
+        for it in g:
+            if isinstance(it, tuple) and it[0] == "wait":
+                self.wait_lds(it[1])
+            elif isinstance(it, tuple):
+                self.lds_op(it[0], it[1])
+            else:
+                self.e(it)
+
+    # ---- registers
+    @staticmethod
+    def acc(mb, nb):
+        b = A_ACC + (mb * NB + nb) * 16
+        return f"a[{b}:{b + 15}]"
+
+    @staticmethod
+    def opa(os_, ks, mb):
+        return A_OPS[os_] + (ks * 2 + mb) * 4
+
+    @staticmethod
+    def opb(os_, ks, nb):
+        return A_OPS[os_] + 16 + (ks * NB + nb) * 4
+
+    # ---- operand reads of tap t from buffer `buf` into operand set os_: 12 (text, tag) in the order the MFMAs use them
+    def tap_reads(self, t, buf, os_):
+        dy, dx = t // 3, t % 3
+        out = []
+        for ks in range(2):
+            for mb in range(2):
+                r = self.opa(os_, ks, mb)
+                off = ((t * 2 + ks) * 2 + mb) * 1024      # (V_AOFS points at the buffer's weight area)
+                if not (EXP & 64 and t > 0):
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_AOFS[buf]} offset:{off}", ("R", t, ks, 0, mb)))
+            for nb in range(NB):
+                r = self.opb(os_, ks, nb)
+                off = (2 * nb + dy) * 18 * 64
+                if not (EXP & 32 and (t > 0 or nb < NB - 1 or ks < 1)):
+                    out.append((f"ds_read_b128 a[{r}:{r + 3}], v{V_BOFS[buf] + dx * 2 + ks} offset:{off}", ("R", t, ks, 1, nb)))
+        return out
+
+    def tap_mfmas(self, os_, sprinkle):
+        """8 MFMAs of one tap on operand set os_; sprinkle: 8 lists of items tucked behind MFMA m"""
+        m = 0
+        for ks in range(2):
+            for mb in range(2):
+                for nb in range(NB):
+                    a, b = self.opa(os_, ks, mb), self.opb(os_, ks, nb)
+                    self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(mb, nb)}, a[{a}:{a + 3}], a[{b}:{b + 3}], {self.acc(mb, nb)}")
+                    self.emit_group(sprinkle[m])
+                    m += 1
+
+    # ---- streams
+    def next_coords(self, p, ct_name):
+        """the stream with prefix p moves to its next tile (x fastest, then y, channel tile, frame) -- or stays on its last one"""
+        e = self.e
+        stay = self.label("stay")
+        e(f"s_cmp_lt_u32 {s(p + 'LEFT')}, 2")
+        e(f"s_cbranch_scc1 {stay}")
+        e(f"s_sub_u32 {s(p + 'LEFT')}, {s(p + 'LEFT')}, 1")
+        e(f"s_add_u32 {s(p + 'TX')}, {s(p + 'TX')}, 1")
+        e(f"s_cmp_eq_u32 {s(p + 'TX')}, {s('TILESX')}")
+        e(f"s_cselect_b32 {s(p + 'TX')}, 0, {s(p + 'TX')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'TY')}, {s(p + 'TY')}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(p + 'TY')}, {s('TILESY')}")
+        e(f"s_cselect_b32 {s(p + 'TY')}, 0, {s(p + 'TY')}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(ct_name)}, {s(ct_name)}, {s('T0')}")
+        e(f"s_cmp_eq_u32 {s(ct_name)}, {s('NCT')}")
+        e(f"s_cselect_b32 {s(ct_name)}, 0, {s(ct_name)}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'FR')}, {s(p + 'FR')}, {s('T0')}")
+        e(f"{stay}:")
+
+    def geometry(self):
+        """which of this lane's ten pieces of the staging stream's tile at (SX0, SY0) are inside the image (V_VALID) and which are halo
+        slots outside it (V_ZMASK).  A tile whose halo lies inside the image (most): every slot is valid."""
+        e = self.e
+        r, c, t2, t3 = V_T, V_T + 1, V_T + 3, V_T + 4
+        slow, done = self.label("border"), self.label("geo")
+        e(f"s_cmp_eq_u32 {s('SX0')}, 0")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_cmp_eq_u32 {s('SY0')}, 0")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_add_u32 {s('T0')}, {s('SX0')}, 16")
+        e(f"s_cmp_ge_u32 {s('T0')}, {s('W')}")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"s_add_u32 {s('T0')}, {s('SY0')}, {TILE_H}")
+        e(f"s_cmp_ge_u32 {s('T0')}, {s('H')}")
+        e(f"s_cbranch_scc1 {slow}")
+        e(f"v_mov_b32 v{V_VALID}, v{V_INR}")
+        e(f"v_mov_b32 v{V_ZMASK}, 0")
+        e(f"s_branch {done}")
+        e(f"{slow}:")
+        e(f"v_mov_b32 v{V_VALID}, 0")
+        e(f"v_mov_b32 v{V_ZMASK}, 0")
+        for i in range(NI):
+            e(f"v_bfe_u32 v{r}, v{V_HRC + i}, 8, 8")
+            e(f"v_and_b32 v{c}, 0xff, v{V_HRC + i}")
+            e(f"v_add_u32 v{r}, {s('SY0')}, v{r}")                     # gy + 1
+            e(f"v_add_u32 v{c}, {s('SX0')}, v{c}")                     # gx + 1
+            e(f"v_subrev_u32 v{r}, 1, v{r}")                            # gy (wraps below 0: fails the unsigned test)
+            e(f"v_subrev_u32 v{c}, 1, v{c}")
+            e(f"v_cmp_gt_u32 vcc, {s('H')}, v{r}")
+            e(f"v_cmp_gt_u32 {s2('TA')}, {s('W')}, v{c}")
+            e(f"v_cmp_le_i32 {s2('TB')}, 0, v{V_HRC + i}")             # the slot exists
+            e(f"s_and_b64 vcc, vcc, {s2('TA')}")
+            e(f"s_and_b64 vcc, vcc, {s2('TB')}")
+            e(f"v_mov_b32 v{t2}, {1 << i}")
+            e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
+            e(f"v_or_b32 v{V_VALID}, v{V_VALID}, v{t3}")
+            e(f"s_andn2_b64 vcc, {s2('TB')}, vcc")
+            e(f"v_cndmask_b32 v{t3}, 0, v{t2}, vcc")
+            e(f"v_or_b32 v{V_ZMASK}, v{V_ZMASK}, v{t3}")
+        e(f"{done}:")
+
+    def staging_tile_setup(self):
+        """validity masks, the tensors' bases FRA / FRB at the TILE's origin (halo pixel (0, 0): may lie before the frame) and the weight
+        base WB for the staging stream's tile (NTX, NTY, NCT_, NFR)"""
+        e = self.e
+        e(f"s_lshl_b32 {s('SX0')}, {s('NTX')}, 4")
+        e(f"s_mul_i32 {s('SY0')}, {s('NTY')}, {TILE_H}")
+        self.geometry()
+        e(f"s_sub_u32 {s('T1')}, {s('SY0')}, 1")
+        e(f"s_mul_i32 {s('T1')}, {s('T1')}, {s('W')}")
+        e(f"s_add_u32 {s('T1')}, {s('T1')}, {s('SX0')}")
+        e(f"s_sub_u32 {s('T1')}, {s('T1')}, 1")                         # (SY0 - 1) W + SX0 - 1 >= -(W + 1): the halo origin inside a plane
+        for fr, src, ch in (("FRA", "INA", "CHA"), ("FRB", "INB", "CHB")):
+            e(f"s_mul_i32 {s('T0')}, {s('NFR')}, {s(ch)}")              # planes of this tensor before the frame
+            e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW')}")             # pixels (< 2^31: the launcher checks)
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")             # signed
+            e(f"s_ashr_i32 {s('T3')}, {s('T0')}, 26")                   # * 64 bytes as a signed 64-bit number
+            e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 6")
+            e(f"s_add_u32 {s(fr)}, {s(src)}, {s('T2')}")
+            e(f"s_addc_u32 {s(fr + '1')}, {s(src + '1')}, {s('T3')}")
+        e(f"s_mul_i32 {s('T0')}, {s('NCT_')}, {s('NCH')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WB')}, {s('W16')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WB1')}, {s('W161')}, 0")
+
+    def staging_source(self):
+        """for chunk NC of the staging tile: SRC (the chunk's 32-channel plane at the tile's halo origin) and WCH (the chunk's weights)"""
+        e = self.e
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('CHA')}")                       # chunk from A?
+        e(f"s_cselect_b64 {s2('SRC')}, {s2('FRA')}, {s2('FRB')}")
+        e(f"s_cselect_b32 {s('T0')}, 0, {s('CHA')}")
+        e(f"s_sub_u32 {s('T0')}, {s('NC')}, {s('T0')}")                # plane index inside its tensor
+        e(f"s_mul_hi_u32 {s('T1')}, {s('T0')}, {s('HW64')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW64')}")
+        e(f"s_add_u32 {s('SRC')}, {s('SRC')}, {s('T0')}")
+        e(f"s_addc_u32 {s('SRC1')}, {s('SRC1')}, {s('T1')}")
+        e(f"s_mul_i32 {s('T0')}, {s('NC')}, {W_BYTES}")
+        e(f"s_add_u32 {s('WCH')}, {s('WB')}, {s('T0')}")
+        e(f"s_addc_u32 {s('WCH1')}, {s('WB1')}, 0")
+
+    def advance_staging(self):
+        e = self.e
+        same = self.label("nsame")
+        e(f"s_add_u32 {s('NC')}, {s('NC')}, 1")
+        e(f"s_cmp_lt_u32 {s('NC')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {same}")
+        e(f"s_mov_b32 {s('NC')}, 0")
+        self.next_coords("N", "NCT_")
+        self.staging_tile_setup()
+        e(f"{same}:")
+
+    # ---- instruction groups
+    def dma_items(self, wbuf):
+        """this wave's 1-KiB pieces of the staging chunk's 36 KiB of weights -> weight area of buffer wbuf: pieces 4 w .. 4 w + 3 and, for
+        waves 0..3, piece 32 + w"""
+        items = []
+        for j in range(4):
+            g = []
+            if j == 0:
+                g += [f"s_add_u32 m0, {s('LDSW')}, {wbuf * BUF}", "s_nop 0"]
+            if not EXP & 4:
+                g += [f"global_load_lds_dwordx4 v{V_DMA}, {s2('WCH')} offset:{1024 * j}"]
+            items.append(g)
+        skip = self.label("nox")
+        g = [f"s_cmp_gt_u32 {s('WAVE')}, 3", f"s_cbranch_scc1 {skip}", f"s_add_u32 m0, {s('LDSW2')}, {wbuf * BUF}", "s_nop 0"]
+        if not EXP & 4:
+            g += [f"global_load_lds_dwordx4 v{V_DMA2}, {s2('WCH')}"]
+        g += [f"{skip}:"]
+        items.append(g)
+        return items
+
+    def halo_items(self, buf):
+        """five LDS-DMA instructions of the staging chunk's halo tile -> halo area of buffer buf, and the zeroes of its slots outside the image"""
+        items = []
+        t = V_T + 8
+        for i in range(NI):
+            g = [f"s_add_u32 m0, {s('LDSH')}, {buf * BUF + 1024 * i}",
+                 f"v_bfe_u32 v{t}, v{V_VALID}, {i}, 1", f"v_cmp_eq_u32 vcc, 1, v{t}", "s_nop 0", "s_mov_b64 exec, vcc"]
+            if not EXP & 2:
+                g += [f"global_load_lds_dwordx4 v{V_VOFF + i}, {s2('SRC')}"]
+            g += ["s_mov_b64 exec, -1", f"v_bfe_u32 v{t}, v{V_ZMASK}, {i}, 1", f"v_cmp_eq_u32 vcc, 1, v{t}", "s_nop 0", "s_mov_b64 exec, vcc",
+                  (f"ds_write_b128 v{V_SLOT[buf]}, v[{V_Z}:{V_Z + 3}] offset:{1024 * i}", ("Z", i)), "s_mov_b64 exec, -1"]
+            items.append(g)
+        return items
+
+    def row_exec(self, row, mb, base, first):
+        """exec = the lanes of the store of (row, M-block) inside the image; ROWB = base + row * RS + mb * HW64"""
+        e = self.e
+        if first:
+            e(f"s_mov_b64 {s2('ROWB')}, {s2(base)}")
+        elif mb == 0:
+            e(f"s_sub_u32 {s('ROWB')}, {s('ROWB')}, {s('HW64')}")        # back to M-block 0, one row down
+            e(f"s_subb_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
+            e(f"s_add_u32 {s('ROWB')}, {s('ROWB')}, {s('RS')}")
+            e(f"s_addc_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
+        else:
+            e(f"s_add_u32 {s('ROWB')}, {s('ROWB')}, {s('HW64')}")
+            e(f"s_addc_u32 {s('ROWB1')}, {s('ROWB1')}, 0")
+        e(f"s_add_u32 {s('T2')}, {s('GY0')}, {row}")
+        e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
+        e(f"s_cselect_b64 exec, {s2('XM0')}, 0")
+
+    def gate_loads(self):
+        """the gate's eight pieces of this lane (the compute tile's store positions), if the launch has a gate and this is the tile's
+        last pair of chunks"""
+        e = self.e
+        skip = self.label("nogate")
+        e(f"s_add_u32 {s('T0')}, {s('CC')}, 2")
+        e(f"s_cmp_lt_u32 {s('T0')}, {s('NCH')}")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        for k in range(4 * NB):
+            nb, j = k >> 2, k & 3
+            self.row_exec(2 * nb + (j >> 1), j & 1, "GATEF", k == 0)
+            if not EXP & 16:
+                e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_VS}, {s2('ROWB')}")
+        e("s_mov_b64 exec, -1")
+        e(f"{skip}:")
+
+    def store_tile(self):
+        """the stores of the tile that just ended (bases OUTF / GATEF, mask XM0, GY0: set by tile_begin).  An N-block's 64 channels x
+        32 pixels leave through this wave's 4 KiB of LDS staging as bf16 ([M-block][pixel][32 channels]): lane (n, hh) writes the 8
+        bytes of channels 8 rq + 4 hh .. + 3 of pixel n of M-block mb; lane l reads piece l & 3 of pixel 16 r + (l >> 2): a store
+        instruction writes one row of the tile in one 32-channel plane, 1 KiB contiguous.  Gate (<= 0 -> 0) on the packed halves."""
+        e = self.e
+        ta, tc, tb, tm = V_T, V_T + 16, V_T, V_T + 24      # (the read-backs land in the accumulator temporaries, which are spent by then)
+        for nb in range(NB):
+            for mb in range(2):
+                a0 = A_ACC + (mb * NB + nb) * 16
+                for rq in range(4):
+                    for j in range(4):
+                        e(f"v_accvgpr_read_b32 v{ta + 4 * rq + j}, a{a0 + 4 * rq + j}")
+                    if WITH_RELU:
+                        for j in range(4):
+                            e(f"v_max_f32 v{ta + 4 * rq + j}, {s('RELU')}, v{ta + 4 * rq + j}")
+                    e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq}, v{ta + 4 * rq}, v{ta + 4 * rq + 1}")
+                    e(f"v_cvt_pk_bf16_f32 v{tc + 2 * rq + 1}, v{ta + 4 * rq + 2}, v{ta + 4 * rq + 3}")
+                    self.lds_op(f"ds_write_b64 v{V_SWA + mb * 4 + rq}, v[{tc + 2 * rq}:{tc + 2 * rq + 1}]", ("SW", nb, mb, rq))
+            for j in range(4):
+                self.lds_op(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", nb, j))
+            nogate = self.label("ng")
+            e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+            e(f"s_cbranch_scc1 {nogate}")
+            self.wait_lds(("SR", nb, 3))
+            for j in range(4):
+                for d in range(4):
+                    g, m, x = V_G + 16 * nb + 4 * j + d, tm + d, tb + 4 * j + d
+                    e(f"v_pk_max_i16 v{m}, v{g}, v{V_Z}")
+                    e(f"v_pk_min_u16 v{m}, v{m}, v{V_ONES}")
+                    e(f"v_pk_mul_lo_u16 v{m}, v{m}, v{V_FFFF}")
+                    e(f"v_and_b32 v{x}, v{x}, v{m}")
+            e(f"{nogate}:")
+            self.wait_all_lds()                               # (either path: the read-backs have arrived)
+            for j in range(4):
+                self.row_exec(2 * nb + (j >> 1), j & 1, "OUTF", nb == 0 and j == 0)
+                if not EXP & 1:
+                    e(f"global_store_dwordx4 v{V_VS}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
+            e("s_mov_b64 exec, -1")
+
+    # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
+    def chunk(self, p):
+        e = self.e
+        self.staging_source()
+        dma = self.dma_items(p ^ 1)
+        hal = self.halo_items(p ^ 1)
+        for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
+            self.lds_op(text, tag)
+        for t in range(9):
+            os_ = t & 1
+            nxt = self.tap_reads(t + 1, p, os_ ^ 1) if t + 1 < 9 else []
+            sprinkle = [[] for _ in range(8)]
+            for m, rd in enumerate(nxt):
+                sprinkle[m].append(rd)
+            # m0 belongs to one group at a time: the weight pieces behind tap 0, the halo requests behind taps 1..2
+            if t == 0:
+                for k, g in enumerate(dma):
+                    sprinkle[3 + k].extend(g)
+            if t in (1, 2):
+                for k, g in enumerate(hal[:3] if t == 1 else hal[3:]):
+                    sprinkle[2 + 2 * k].extend(g)
+            if t == 4 and p == 1:
+                self.gate_loads()
+            if EXP & 96:
+                self.wait_all_lds()
+            else:
+                self.wait_lds(("R", t, 1, 1, NB - 1))
+            self.tap_mfmas(os_, sprinkle)
+        self.wait_all_lds()
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+        self.advance_staging()
+
+    def bias_init(self):
+        """acc = bias of (CT, mb, channels (r & 3) + 8 (r >> 2) + 4 hh), straight into the AGPRs of the four N-blocks"""
+        e = self.e
+        if EXP & 128:
+            return
+        if EXP & 256:                                                   # zeros by register writes instead of the LDS table
+            for r in range(32 * NB):
+                e(f"v_accvgpr_write_b32 a{A_ACC + r}, 0")
+            return
+        e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")                        # CT * 64 floats
+        e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_BIASA}")
+        for mb in range(2):
+            for nb in range(NB):
+                for rq in range(4):
+                    b = A_ACC + (mb * NB + nb) * 16 + 4 * rq
+                    self.lds_op(f"ds_read_b128 a[{b}:{b + 3}], v{V_T} offset:{mb * 128 + rq * 32}", ("BI", mb, nb, rq))
+                if nb % 2:
+                    self.wait_all_lds()
+
+    def tile_begin(self):
+        """the compute tile's store state: OUTF / GATEF = the address of (plane 2 CT of frame FR, first row of this wave, column X0),
+        GY0 = that row, XM0 = the lanes whose column (X0 + (lane >> 2)) is inside the image"""
+        e = self.e
+        e(f"s_lshl_b32 {s('X0')}, {s('TX')}, 4")
+        e(f"s_mul_i32 {s('Y0')}, {s('TY')}, {TILE_H}")
+        e(f"s_lshl_b32 {s('GY0')}, {s('WAVE')}, 2")                     # 4 rows per wave
+        e(f"s_add_u32 {s('GY0')}, {s('GY0')}, {s('Y0')}")
+        e(f"s_lshr_b32 {s('T0')}, {s('COUT')}, 5")                      # planes per frame
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('FR')}")
+        e(f"s_lshl_b32 {s('T1')}, {s('CT')}, 1")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")                 # plane index of (FR, CT, M-block 0)
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('HW')}")
+        e(f"s_mul_i32 {s('T1')}, {s('GY0')}, {s('W')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('X0')}")                 # pixel index (< 2^31: the launcher checks)
+        e(f"s_lshr_b32 {s('T3')}, {s('T0')}, 26")
+        e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 6")
+        for dst, src in (("OUTF", "OUT"), ("GATEF", "GATE")):
+            e(f"s_add_u32 {s(dst)}, {s(src)}, {s('T2')}")
+            e(f"s_addc_u32 {s(dst + '1')}, {s(src + '1')}, {s('T3')}")
+        e(f"v_lshrrev_b32 v{V_T}, 2, v{V_LANE}")
+        e(f"v_add_u32 v{V_T}, {s('X0')}, v{V_T}")
+        e(f"v_cmp_gt_u32 {s2('XM0')}, {s('W')}, v{V_T}")
+
+    def tile_end(self):
+        e = self.e
+        e("s_nop 7")
+        e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
+        self.store_tile()
+        e("s_barrier")                                                # (the staging area is buffer 1's halo region: nobody may stage the next
+        self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
+
+
+def generate():
+    b = Body()
+    e = b.e
+    # ================= prologue
+    e(f"s_mov_b64 {s2('KARG')}, %[karg]")
+    for dst, src in (("WAVE", "wave"), ("LDS0", "lds0"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"), ("FR", "fr0"), ("NTL", "ntl")):
+        e(f"s_mov_b32 {s(dst)}, %[{src}]")
+    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"), ("GATE", "gate")):
+        e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, {ARG[field]}")
+    for dst, field in (("CA", "CA"), ("CB", "CB"), ("COUT", "cout"), ("H", "H"), ("W", "W"), ("TILESX", "tiles_x"), ("TILESY", "tiles_y"),
+                       ("NCT", "n_ct"), ("T3", "relu")):
+        e(f"s_load_dword {s(dst)}, {s2('KARG')}, {ARG[field]}")
+    e(f"v_mov_b32 v{V_TID}, %[tid]")
+    e(f"v_and_b32 v{V_LANE}, 63, v{V_TID}")
+    # per-lane constants: the C++ prologue left CONST_WORDS words per lane at the start of LDS ([word][512 threads])
+    e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
+    e(f"v_add_u32 v{V_T}, {s('LDS0')}, v{V_T}")
+    for i in range(NI):
+        e(f"ds_read_b32 v{V_HRC + i}, v{V_T} offset:{2048 * i}")
+    for i in range(6):
+        e(f"ds_read_b32 v{V_BOFS[0] + i}, v{V_T} offset:{2048 * (NI + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(8):
+        e(f"ds_read_b32 v{V_SWA + i}, v{V_T} offset:{2048 * (NI + 6 + i)}")
+    for i in range(4):
+        e(f"ds_read_b32 v{V_SRA + i}, v{V_T} offset:{2048 * (NI + 14 + i)}")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")                                                    # (everybody has read its constants: the buffers may be written)
+    for i in range(6):
+        e(f"v_add_u32 v{V_BOFS[1] + i}, {BUF}, v{V_BOFS[0] + i}")
+    e(f"v_lshlrev_b32 v{V_T}, 4, v{V_LANE}")                           # lane * 16
+    e(f"v_lshrrev_b32 v{V_HH16}, 5, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_HH16}, 4, v{V_HH16}")                        # hh * 16 bytes
+    e(f"v_lshrrev_b32 v{V_L3}, 3, v{V_LANE}")
+    e(f"v_and_b32 v{V_L7X16}, 7, v{V_LANE}")
+    e(f"v_lshlrev_b32 v{V_L7X16}, 4, v{V_L7X16}")
+    e(f"v_mov_b32 v{V_ONES}, 0x00010001")
+    e(f"v_mov_b32 v{V_FFFF}, -1")
+    for k in range(4):
+        e(f"v_mov_b32 v{V_Z + k}, 0")
+    for k in range(16 * NB):
+        e(f"v_mov_b32 v{V_G + k}, 0x3f803f80")                          # no gate: every half passes
+    e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 12")
+    e(f"v_add_u32 v{V_DMA}, {s('T0')}, v{V_T}")                         # this lane's 16 B of the wave's four 1-KiB weight pieces 4 w .. (global offset)
+    e(f"s_lshl_b32 {s('T2')}, {s('WAVE')}, 10")
+    e(f"s_add_u32 {s('T2')}, {s('T2')}, 32768")
+    e(f"v_add_u32 v{V_DMA2}, {s('T2')}, v{V_T}")                        # ... and of piece 32 + w (waves 0..3)
+    e(f"s_add_u32 {s('LDSW2')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"s_add_u32 {s('LDSW2')}, {s('LDSW2')}, {s('T2')}")
+    e(f"s_add_u32 {s('T1')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"v_add_u32 v{V_AOFS[0]}, {s('T1')}, v{V_T}")                      # A reads: the buffer's weight area + lane * 16
+    e(f"v_add_u32 v{V_AOFS[1]}, {BUF}, v{V_AOFS[0]}")
+    e(f"s_add_u32 {s('LDSW')}, {s('LDS0')}, {HALO_BYTES}")
+    e(f"s_add_u32 {s('LDSW')}, {s('LDSW')}, {s('T0')}")                 # LDS address of this wave's weight pieces in buffer 0
+    e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {NI * 1024}")
+    e(f"s_add_u32 {s('LDSH')}, {s('LDS0')}, {s('T0')}")                 # LDS address of this wave's halo slots in buffer 0
+    e(f"v_add_u32 v{V_SLOT[0]}, {s('LDSH')}, v{V_T}")
+    e(f"v_add_u32 v{V_SLOT[1]}, {BUF}, v{V_SLOT[0]}")
+    e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
+    e(f"v_add_u32 v{V_BIASA}, {s('T0')}, v{V_HH16}")                    # bias table + hh * 16
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_add_u32 {s('NCH')}, {s('CA')}, {s('CB')}")
+    e(f"s_lshr_b32 {s('NCH')}, {s('NCH')}, 5")
+    e(f"s_lshr_b32 {s('CHA')}, {s('CA')}, 5")
+    e(f"s_lshr_b32 {s('CHB')}, {s('CB')}, 5")
+    # the pieces' constant byte offsets from the tile's origin inside a 32-channel plane, and which of the ten exist
+    e(f"v_mov_b32 v{V_INR}, 0")
+    for i in range(NI):
+        r, c, t = V_T, V_T + 1, V_T + 2
+        e(f"v_bfe_u32 v{r}, v{V_HRC + i}, 8, 8")
+        e(f"v_and_b32 v{c}, 0xff, v{V_HRC + i}")
+        e(f"v_mul_lo_u32 v{r}, v{r}, {s('W')}")
+        e(f"v_add_u32 v{r}, v{r}, v{c}")
+        e(f"v_lshlrev_b32 v{r}, 6, v{r}")
+        e(f"v_bfe_u32 v{c}, v{V_HRC + i}, 16, 2")
+        e(f"v_lshlrev_b32 v{c}, 4, v{c}")
+        e(f"v_add_u32 v{r}, v{r}, v{c}")
+        e(f"v_cmp_le_i32 vcc, 0, v{V_HRC + i}")
+        e(f"v_cndmask_b32 v{V_VOFF + i}, 0, v{r}, vcc")
+        e(f"v_mov_b32 v{t}, {1 << i}")
+        e(f"v_cndmask_b32 v{t}, 0, v{t}, vcc")
+        e(f"v_or_b32 v{V_INR}, v{V_INR}, v{t}")
+    e(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
+    e(f"s_lshl_b32 {s('HW64')}, {s('HW')}, 6")                          # bytes of one 32-channel plane (< 2^31: the launcher checks)
+    e(f"s_lshl_b32 {s('RS')}, {s('W')}, 6")                             # bytes between rows of a plane
+    e(f"v_lshlrev_b32 v{V_VS}, 4, v{V_LANE}")                           # a store's lane offset: column lane >> 2, piece lane & 3
+    e(f"s_cmp_eq_u32 {s('T3')}, 0")
+    e(f"s_cselect_b32 {s('RELU')}, 0xff800000, 0")                    # lower bound of the epilogue's v_max: -inf (linear) or 0
+    # the bias table -> LDS: thread t (< 64 * NCT) copies bias[t] (no bias: zeros)
+    e(f"s_lshl_b32 {s('T0')}, {s('NCT')}, 6")
+    e(f"v_cmp_gt_u32 vcc, {s('T0')}, v{V_TID}")
+    e(f"v_lshlrev_b32 v{V_T}, 2, v{V_TID}")
+    e(f"v_mov_b32 v{V_T + 1}, 0")
+    e(f"s_mov_b64 {s2('EX')}, exec")
+    e(f"s_cmp_eq_u64 {s2('BIAS')}, 0")
+    e("s_cbranch_scc1 S2L8_NOBIAS")
+    e("s_and_b64 exec, exec, vcc")
+    e(f"global_load_dword v{V_T + 1}, v{V_T}, {s2('BIAS')}")
+    e(f"s_mov_b64 exec, {s2('EX')}")
+    e("s_waitcnt vmcnt(0)")
+    e("S2L8_NOBIAS:")
+    e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
+    e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
+    e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
+    # the staging stream starts on the workgroup's first tile
+    e(f"s_mov_b32 {s('LEFT')}, {s('NTL')}")
+    e(f"s_mov_b32 {s('NLEFT')}, {s('NTL')}")
+    for n_, c_ in (("NTX", "TX"), ("NTY", "TY"), ("NCT_", "CT"), ("NFR", "FR")):
+        e(f"s_mov_b32 {s(n_)}, {s(c_)}")
+    e(f"s_mov_b32 {s('NC')}, 0")
+    b.staging_tile_setup()
+    # chunk 0 -> buffer 0, all exposed (once per workgroup)
+    b.staging_source()
+    for g in b.dma_items(0):
+        b.emit_group(g)
+    for g in b.halo_items(0):
+        b.emit_group(g)
+    b.advance_staging()
+    b.wait_all_lds()
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+
+    # ================= tile loop
+    e("S2L8_TILE:")
+    b.tile_begin()
+    b.bias_init()
+    e(f"s_mov_b32 {s('CC')}, 0")
+    e("S2L8_PAIR:")
+    b.chunk(0)
+    b.chunk(1)
+    e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
+    e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
+    e("s_cbranch_scc1 S2L8_PAIR")
+    b.tile_end()
+    e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
+    e(f"s_cmp_gt_u32 {s('NTL')}, 0")
+    e("s_cbranch_scc1 S2L8_TILE")
+    e("s_waitcnt vmcnt(0)")
+    return b.L
+
+
+OPERANDS = """      :
+      : [karg] "s"(karg), [wave] "s"(wave), [lds0] "s"(lds0), [tx0] "s"(tx0), [ty0] "s"(ty0), [ct0] "s"(ct0), [fr0] "s"(fr0), [ntl] "s"(ntl),
+        [tid] "v"(tid)
+"""
+
+
+def main(objdir):
+    lines = generate()
+    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
+    clob += ["vcc", "scc", "memory"]
+    out = ["// GENERATED by csrc/gen_convh8_body.py -- do not edit; the generator is the source.", "asm volatile("]
+    out += [f'    "{x}\\n\\t"' for x in lines]
+    out.append(OPERANDS.rstrip("\n"))
+    out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+    with open(os.path.join(objdir, "convh8_body.inc"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    return len(lines)
+
+
+if __name__ == "__main__":
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build")
+    print(f"convh8 body: {main(d)} instructions")

@@ -81,6 +81,36 @@ def test_convolution_is_the_rounded_fp32_tensor_kernel(blobs, dev, layer, transp
         assert float((ref == 0).float().mean()) > 0.3      # the gate really closed
 
 
+@pytest.mark.parametrize("layer,transposed,F,H,Wd,gate", [(1, 0, 2, 40, 40, False), (9, 1, 1, 33, 17, True), (6, 0, 2, 37, 53, False), (3, 1, 1, 125, 125, True),
+                                                          (8, 0, 2, 500, 500, False)])
+def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, transposed, F, H, Wd, gate):
+    """s2l_set_unet_half_kernel: 0 = eight waves per workgroup (default), 1 = four; same arithmetic in the same order."""
+    _, raw, raw16 = blobs
+    lib = _abi.load()
+    g = torch.Generator(device="cpu").manual_seed(7 * layer + H)
+    cin, cout = CONVS[layer]
+    if transposed:
+        cin, cout = cout, cin
+    cat = layer in (6, 8) and not transposed
+    CA, CB = (cin // 2, cin // 2) if cat else (cin, 0)
+    ah = nhwc_to_c32(torch.randn(F, H, Wd, CA, generator=g).to(torch.bfloat16).to(dev))
+    bh = nhwc_to_c32(torch.randn(F, H, Wd, CB, generator=g).to(torch.bfloat16).to(dev)) if CB else None
+    gh = nhwc_to_c32(torch.randn(F, H, Wd, cout, generator=g).clamp_min(0).to(torch.bfloat16).to(dev)) if gate else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    try:
+        for kind in (0, 1, 0):
+            assert lib.s2l_set_unet_half_kernel(kind) == 0
+            out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+            _abi.check(lib.s2l_convh_layer(p(raw16), layer, transposed, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "s2l_convh_layer")
+            outs.append(out)
+        torch.cuda.synchronize()
+    finally:
+        lib.s2l_set_unet_half_kernel(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert lib.s2l_set_unet_half_kernel(2) == -2
+
+
 def test_convolution_argument_errors(blobs, dev):
     _, raw, raw16 = blobs
     lib = _abi.load()

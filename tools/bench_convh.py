@@ -1,5 +1,5 @@
 """Per-layer time of the half-width convolution kernel (csrc/convh.hip) at the training chain's shapes.
-    python tools/bench_convh.py [frames=20] [size=500]"""
+    python tools/bench_convh.py [frames=20] [size=500] [kernel: 0 eight waves | 1 four]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,8 @@ dev = torch.device("cuda:0")
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 lib = _abi.load()
+if len(sys.argv) > 3:
+    _abi.check(lib.s2l_set_unet_half_kernel(int(sys.argv[3])), "s2l_set_unet_half_kernel")      # 0: eight waves, 1: four
 u = s2l.SimpleUnetLight().to(dev).train()
 u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
 tensors = u._tensors()

@@ -176,10 +176,12 @@ def soak_convh(dev, rounds, seed=0, log=print):
         want = ref.to(torch.bfloat16).view(torch.int16)
         ah, bh, gh = nhwc_to_c32(a), (nhwc_to_c32(b) if cat else None), (nhwc_to_c32(gt) if gt is not None else None)
         ok = True
-        for rep in range(2):
+        for kind in (0, 0, 1):      # the eight-wave form twice, the four-wave form
+            _abi.check(lib.s2l_set_unet_half_kernel(kind), "s2l_set_unet_half_kernel")
             out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
             _abi.check(lib.s2l_convh_layer(p(raw16), layer, tr, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "convh")
             ok = ok and torch.equal(c32_to_nhwc(out), want)
+        lib.s2l_set_unet_half_kernel(0)
         if not ok:
             bad.append(("convh", layer, tr, F, H, Wd, gate))
             log("MISMATCH convh", layer, tr, F, H, Wd, gate)
