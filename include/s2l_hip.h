@@ -407,6 +407,16 @@ int s2l_unet_train_forward_frames_h(const float* packed_raw, const uint16_t* pac
 int s2l_unet_train_backward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                      const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x, int height, int width,
                                      int64_t n_frames, s2l_stream_t stream);
+/* The EVAL-mode pair (s2l_unet_forward_saved_window / s2l_unet_backward_window with bf16 operands) on half-width tensors: BatchNorm
+ * folded into the weights (packed16: s2l_unet_pack16 with the real eps; packed: s2l_unet_pack's blob for the first layer, the biases and
+ * the output layer), bias + ReLU in the convolution's epilogue, every tensor between the kernels bf16 in 32-channel planes; window
+ * semantics and geometry errors as the fp32-tensor pair.  saved: s2l_unet_saved_h_halves halves; work: s2l_unet_backward_h_work_halves. */
+int64_t s2l_unet_saved_h_halves(int height, int width, int64_t n_frames);
+int64_t s2l_unet_backward_h_work_halves(int height, int width, int64_t n_frames);
+int s2l_unet_forward_saved_h(const float* packed, const uint16_t* packed16, const float* x, uint16_t* saved, float* out, int height, int width,
+                             int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames, s2l_stream_t stream);
+int s2l_unet_backward_h(const float* packed, const uint16_t* packed16, const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x,
+                        int height, int width, int full_h, int full_w, int origin_y, int origin_x, int64_t n_frames, s2l_stream_t stream);
 /* One 3x3 layer (1..9) of that chain on its own: out [F,H,W,cout] bf16 = conv(concat(inA, inB) bf16, the layer's raw bf16 weights);
  * transposed != 0: the layer's input gradient (inA = the gradient of its output; gate, or NULL: [F,H,W,cin] bf16, out = 0 where
  * gate <= 0).  s2l_debug_conv_layer_f32: the fp32-tensor kernel it replaces (same operands, same accumulation order: on

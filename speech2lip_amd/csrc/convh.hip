@@ -90,26 +90,31 @@ __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
 }
 
 // The eight-wave form (gen_convh8_body.py): two waves per SIMD, wave w owns rows 4 w .. 4 w + 3 of the tile.  Same arithmetic, same bits.
-__global__ __launch_bounds__(512) void convh8_asm_kernel(ConvHArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
-  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+// Two bodies: linear (the train-mode chain) and max(0, .) before the conversion (the eval-mode chain's folded BatchNorm + ReLU).
+struct ConvH8Ctx {
+  int tx0, ty0, ct0, fr0, ntl, wave;
+  uint32_t lds0;
+};
+__device__ __forceinline__ bool convh8_prologue(const ConvHArgs& a, char* smem, ConvH8Ctx& c) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ch_smem);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
   const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
-  if (tile0 >= tile_end) return;
+  if (tile0 >= tile_end) return false;
   int t = tile0;
-  const int tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
+  c.tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
   t /= a.tiles_x;
-  const int ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
+  c.ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
   t /= a.tiles_y;
-  const int ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
-  const int fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
-  const int ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
+  c.ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
+  c.fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
+  c.ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
+  c.wave = wave;
+  c.lds0 = lds0;
   // per-lane constants ([word 23][thread 512] at the start of buffer 0): halo DMA instruction i of wave w fills slots (5 w + i) * 64 + lane
-  uint32_t* cst = reinterpret_cast<uint32_t*>(ch_smem);
+  uint32_t* cst = reinterpret_cast<uint32_t*>(smem);
   constexpr int kSlots = kCHHalo / 16;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -128,20 +133,36 @@ __global__ __launch_bounds__(512) void convh8_asm_kernel(ConvHArgs a) {
       const int col = pcol + dx, row = 4 * wave + prow;
       cst[(5 + dx * 2 + ks) * 512 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * ks + hh_) ^ ((col >> 2) & 3)) << 4));
     }
-  {
-    const uint32_t stg = lds0 + kCHBuf + wave * 4096;      // 8 x 4 KiB of buffer 1's halo area
-    const int pix = 16 * prow + pcol;
+  const uint32_t stg = lds0 + kCHBuf + wave * 4096;      // 8 x 4 KiB of buffer 1's halo area
+  const int pix = 16 * prow + pcol;
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc)
-      cst[(11 + pc) * 512 + tid] = stg + (uint32_t)((pc >> 2) * 2048 + pix * 64 + (((pc & 3) ^ ((pix >> 1) & 3)) << 4) + hh_ * 8);
+  for (int pc = 0; pc < 8; ++pc)
+    cst[(11 + pc) * 512 + tid] = stg + (uint32_t)((pc >> 2) * 2048 + pix * 64 + (((pc & 3) ^ ((pix >> 1) & 3)) << 4) + hh_ * 8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int px = 16 * (j >> 1) + (lane >> 2);
-      cst[(19 + j) * 512 + tid] = stg + (uint32_t)((j & 1) * 2048 + px * 64 + (((lane & 3) ^ ((px >> 1) & 3)) << 4));
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int px = 16 * (j >> 1) + (lane >> 2);
+    cst[(19 + j) * 512 + tid] = stg + (uint32_t)((j & 1) * 2048 + px * 64 + (((lane & 3) ^ ((px >> 1) & 3)) << 4));
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
+  return true;
+}
+__global__ __launch_bounds__(512) void convh8_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  ConvH8Ctx c;
+  if (!convh8_prologue(a, ch_smem, c)) return;
+  const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
+  const uint32_t lds0 = c.lds0;
 #include "convh8_body.inc"
+}
+__global__ __launch_bounds__(512) void convh8_relu_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  ConvH8Ctx c;
+  if (!convh8_prologue(a, ch_smem, c)) return;
+  const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
+  const uint32_t lds0 = c.lds0;
+#include "convh8r_body.inc"
 }
 
 static std::atomic<int> g_convh_kind{0};      // 0: eight waves, 1: four waves (s2l_set_unet_half_kernel)
@@ -158,17 +179,21 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   const int cmax = std::max(a.CA, std::max(a.CB, a.cout));
   if (a.CA % 32 != 0 || a.CB % 32 != 0 || a.CA < 32 || nch % 2 != 0 || (a.CB != 0 && !a.inB) || a.cout % 64 != 0 || a.n_ct > 4 || a.n_ct < 1 ||
       a.n_frames <= 0 || (int64_t)a.H * a.W * 64 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames * (cmax / 32) >= 0x7fffffffLL / 2 ||
-      a.H > 255 * 32 || a.W > 255 * 16 || a.relu != 0)      // (the body is generated without the ReLU: WITH_RELU)
+      a.H > 255 * 32 || a.W > 255 * 16)
     return S2L_OK;
+  const bool four = g_convh_kind.load(std::memory_order_relaxed) == 1 && a.relu == 0;      // (the four-wave body exists in the linear form only)
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
   if (total >= 0x7fffffff) return S2L_OK;
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
-  static LdsOptIn flag4, flag8;
-  if (g_convh_kind.load(std::memory_order_relaxed) == 1) {
+  static LdsOptIn flag4, flag8, flag8r;
+  if (four) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag4, dev))) return rc;
     hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
+  } else if (a.relu) {
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh8_relu_asm_kernel), kCHLds, flag8r, dev))) return rc;
+    hipLaunchKernelGGL(convh8_relu_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
   } else {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh8_asm_kernel), kCHLds, flag8, dev))) return rc;
     hipLaunchKernelGGL(convh8_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);

@@ -20,7 +20,8 @@ STG_OFF = BUF                                                   # store staging 
 NW, NB = 8, 2                                                   # waves, N-blocks (2 rows x 16 pixels) per wave
 NI = 5                                                          # halo DMA instructions per wave (wave w: slots 320 w ..)
 CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
-WITH_RELU = False                                               # (the training chain is linear up to the gate; csrc/convh.hip refuses relu)
+WITH_RELU = False                                               # main() generates both: convh8_body.inc (linear) and convh8r_body.inc (max(0, .))
+PFX = "S2L8"                                                    # label prefix (two bodies in one translation unit)
 EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads
 
 # ---- registers
@@ -88,7 +89,7 @@ class Body:
 
     def label(self, stem):
         self.nlabel += 1
-        return f"S2L8_{stem}_{self.nlabel}"
+        return f"{PFX}_{stem}_{self.nlabel}"
 
     def lds_op(self, text, tag):
         self.e(text)
@@ -562,12 +563,12 @@ def generate():
     e(f"v_mov_b32 v{V_T + 1}, 0")
     e(f"s_mov_b64 {s2('EX')}, exec")
     e(f"s_cmp_eq_u64 {s2('BIAS')}, 0")
-    e("s_cbranch_scc1 S2L8_NOBIAS")
+    e(f"s_cbranch_scc1 {PFX}_NOBIAS")
     e("s_and_b64 exec, exec, vcc")
     e(f"global_load_dword v{V_T + 1}, v{V_T}, {s2('BIAS')}")
     e(f"s_mov_b64 exec, {s2('EX')}")
     e("s_waitcnt vmcnt(0)")
-    e("S2L8_NOBIAS:")
+    e(f"{PFX}_NOBIAS:")
     e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
     e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
     e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
@@ -590,20 +591,20 @@ def generate():
     e("s_barrier")
 
     # ================= tile loop
-    e("S2L8_TILE:")
+    e(f"{PFX}_TILE:")
     b.tile_begin()
     b.bias_init()
     e(f"s_mov_b32 {s('CC')}, 0")
-    e("S2L8_PAIR:")
+    e(f"{PFX}_PAIR:")
     b.chunk(0)
     b.chunk(1)
     e(f"s_add_u32 {s('CC')}, {s('CC')}, 2")
     e(f"s_cmp_lt_u32 {s('CC')}, {s('NCH')}")
-    e("s_cbranch_scc1 S2L8_PAIR")
+    e(f"s_cbranch_scc1 {PFX}_PAIR")
     b.tile_end()
     e(f"s_sub_u32 {s('NTL')}, {s('NTL')}, 1")
     e(f"s_cmp_gt_u32 {s('NTL')}, 0")
-    e("s_cbranch_scc1 S2L8_TILE")
+    e(f"s_cbranch_scc1 {PFX}_TILE")
     e("s_waitcnt vmcnt(0)")
     return b.L
 
@@ -615,16 +616,22 @@ OPERANDS = """      :
 
 
 def main(objdir):
-    lines = generate()
-    clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
-    clob += ["vcc", "scc", "memory"]
-    out = ["// GENERATED by csrc/gen_convh8_body.py -- do not edit; the generator is the source.", "asm volatile("]
-    out += [f'    "{x}\\n\\t"' for x in lines]
-    out.append(OPERANDS.rstrip("\n"))
-    out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
-    with open(os.path.join(objdir, "convh8_body.inc"), "w") as f:
-        f.write("\n".join(out) + "\n")
-    return len(lines)
+    global WITH_RELU, PFX
+    n = 0
+    for relu, pfx, name in ((False, "S2L8", "convh8_body.inc"), (True, "S2L9", "convh8r_body.inc")):
+        WITH_RELU, PFX = relu, pfx
+        lines = generate()
+        clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
+        clob += ["vcc", "scc", "memory"]
+        out = ["// GENERATED by csrc/gen_convh8_body.py -- do not edit; the generator is the source.", "asm volatile("]
+        out += [f'    "{x}\\n\\t"' for x in lines]
+        out.append(OPERANDS.rstrip("\n"))
+        out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
+        with open(os.path.join(objdir, name), "w") as f:
+            f.write("\n".join(out) + "\n")
+        n = len(lines)
+    WITH_RELU, PFX = False, "S2L8"
+    return n
 
 
 if __name__ == "__main__":

@@ -373,12 +373,14 @@ class SimpleUnetLight(nn.Module):
         window = (full_h, full_w, origin_y, origin_x): x is a crop of a full frame (s2l_unet_forward_saved_window); values
         within 32 pixels of a crop edge that is not a frame edge are not the full-frame values.
         precision "bf16": the 3x3 convolutions (and their input gradients in backward_input) take bf16 operands on the
-        32x32x16 MFMA -- fp32 accumulation, fp32 tensors in memory -- the precision BASELINE config 5 names for training."""
+        32x32x16 MFMA -- fp32 accumulation, fp32 tensors in memory -- the precision BASELINE config 5 names for training.
+        precision "bf16h": the same operands AND bf16 tensors between the kernels (s2l_unet_forward_saved_h: 32-channel planes,
+        half the memory traffic; x / out / the gradients at the boundary stay fp32)."""
         lib = _abi.load()
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ("fp32", "bf16", "bf16h"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16h'")
         packed = self.packed_weights()
-        packed16 = self.packed_weights_bf16() if precision == "bf16" else None
+        packed16 = self.packed_weights_bf16() if precision != "fp32" else None
         if x.device.type != "cuda":
             raise _abi.S2LError("U-Net input must be on the GPU (no CPU fallback)")
         if self.training:
@@ -388,11 +390,17 @@ class SimpleUnetLight(nn.Module):
         if C != 3 or H < 4 or W < 4:
             raise ValueError(f"U-Net input must be [F,H>=4,W>=4,3], got {tuple(x.shape)}")
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=x.device)
-        saved = torch.empty(int(lib.s2l_unet_saved_floats(H, W, F_)), dtype=torch.float32, device=x.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         p16 = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        fh, fw, oy, ox = (H, W, 0, 0) if window is None else (int(v) for v in window)
+        if precision == "bf16h":
+            saved = torch.empty(int(lib.s2l_unet_saved_h_halves(H, W, F_)), dtype=torch.int16, device=x.device)
+            with torch.cuda.device(x.device):
+                _abi.check(lib.s2l_unet_forward_saved_h(p(packed), p(packed16), p(x), p(saved), p(out), H, W, fh, fw, oy, ox, F_,
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_forward_saved_h")
+            return out, (saved, packed, (F_, H, W), (fh, fw, oy, ox), packed16)
+        saved = torch.empty(int(lib.s2l_unet_saved_floats(H, W, F_)), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            fh, fw, oy, ox = (H, W, 0, 0) if window is None else (int(v) for v in window)
             _abi.check(lib.s2l_unet_forward_saved_window(p(packed), p16(packed16), p(x), p(saved), p(out), H, W, fh, fw, oy, ox, F_,
                                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                        "s2l_unet_forward_saved_window")
@@ -407,8 +415,14 @@ class SimpleUnetLight(nn.Module):
         if d.shape != (F_, H, W, 3) or d.device != saved.device:
             raise ValueError(f"d_out must be [{F_},{H},{W},3] on {saved.device}")
         dx = torch.empty_like(d)
-        work = torch.empty(int(lib.s2l_unet_backward_work_floats(H, W, F_)), dtype=torch.float32, device=d.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
+        if saved.dtype == torch.int16:      # the half-width chain (precision "bf16h")
+            work = torch.empty(int(lib.s2l_unet_backward_h_work_halves(H, W, F_)), dtype=torch.int16, device=d.device)
+            with torch.cuda.device(d.device):
+                _abi.check(lib.s2l_unet_backward_h(p(packed), p(packed16), p(saved), p(d), p(work), p(dx), H, W, fh, fw, oy, ox, F_,
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_backward_h")
+            return dx
+        work = torch.empty(int(lib.s2l_unet_backward_work_floats(H, W, F_)), dtype=torch.float32, device=d.device)
         with torch.cuda.device(d.device):
             _abi.check(lib.s2l_unet_backward_window(p(packed), ctypes.c_void_p(0 if packed16 is None else packed16.data_ptr()), p(saved), p(d),
                                                     p(work), p(dx), H, W, fh, fw, oy, ox, F_,
@@ -425,6 +439,8 @@ class SimpleUnetLight(nn.Module):
         the reference's loop after it > 100000: Trainer.train_step's self.model.train() (training.py:150) undoes the .eval() of
         train.py:195.  A crop is not equivalent then (statistics are over the whole frame); `precision` as in eval mode."""
         if not self.training:
+            if precision == "bf16" and getattr(self, "half_width_tensors", True) and x.shape[1] <= 255 * 32 and x.shape[2] <= 255 * 16:
+                precision = "bf16h"      # (bf16 tensors between the kernels too: the half-width chain, csrc/unet_half.inc)
             return self.forward_saved_nhwc(x, window=window, precision=precision)
         if window is not None:
             raise ValueError("train-mode BatchNorm needs whole frames: statistics are taken over the full image")
@@ -441,6 +457,8 @@ class SimpleUnetLight(nn.Module):
             else:
                 per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
             group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
+            if getattr(self, "train_frames_per_group", None):
+                group = max(1, min(F_, int(self.train_frames_per_group)))
             outs, ctxs = [], []
             for s0 in range(0, F_, group):
                 o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)

@@ -203,3 +203,42 @@ def test_frozen_train_mode_net_takes_the_half_width_route(dev):
     w.train_frames_budget_bytes = 2 * 2 * (int(lib.s2l_unet_train_frames_h_saved_halves(40, 56, 1)) + int(lib.s2l_unet_train_frames_h_work_halves(40, 56, 1)))
     o_w, c_w = w.forward_for_backward(x, precision="bf16")
     assert len(c_w[1]) == 2 and torch.equal(o_w, o_u) and torch.equal(w.backward_to_input(c_w, d), g_u)
+
+
+@pytest.mark.parametrize("fh,fw,F", [(64, 80, 2), (500, 500, 1)])
+def test_eval_mode_chain_against_the_fp32_tensor_chain(dev, fh, fw, F):
+    """precision "bf16h" of the frozen EVAL-mode net (s2l_unet_forward_saved_h / s2l_unet_backward_h): the same bf16 operands as
+    precision "bf16", bf16 tensors between the kernels.  Against the exact fp32 pair at the bounds of tests/test_gpu_training_chain.py's
+    bf16 test (relaxed by the extra storage rounding), against the fp32-tensor bf16 pair, deterministic, and equal on a crop window."""
+    u = s2l.SimpleUnetLight().to(dev).eval()
+    u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
+    x = T(W.synthetic_image((F, fh, fw, 3), 5, "x")).to(dev)
+    d = T(np.random.default_rng(2).standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    o32, c32 = u.forward_saved_nhwc(x)
+    g32 = u.backward_input(c32, d)
+    o16, c16 = u.forward_saved_nhwc(x, precision="bf16")
+    g16 = u.backward_input(c16, d)
+    oh, ch = u.forward_saved_nhwc(x, precision="bf16h")
+    gh = u.backward_input(ch, d)
+    assert ch[0].dtype == torch.int16 and c16[0].dtype == torch.float32
+    assert rel(oh, o32) <= 1.5e-2 and cos(oh, o32) >= 0.9998, (rel(oh, o32), cos(oh, o32), rel(o16, o32))
+    assert rel(oh, o16) <= 1e-2 and not torch.equal(oh, o16)
+    assert cos(gh, g32) >= 0.97 and rel(gh, g32) <= 0.3, (rel(gh, g32), cos(gh, g32), rel(g16, g32), cos(g16, g32))
+    oh2, ch2 = u.forward_saved_nhwc(x, precision="bf16h")
+    assert torch.equal(oh2, oh) and torch.equal(u.backward_input(ch2, d), gh)
+    if fh == 500:      # a crop evaluated as a window of the full frame (the sync chain's use): interior values are the full frame's bits
+        win = (fh, fw, 48, 68)
+        crop = x[:, 48:460, 68:432].contiguous()
+        ow, cw = u.forward_saved_nhwc(crop, window=win, precision="bf16h")
+        assert torch.equal(ow[:, 40:-40, 40:-40], oh[:, 88:420, 108:392])
+        dw = torch.zeros_like(d)
+        dw[:, 120:380, 140:360] = d[:, 120:380, 140:360]      # a gradient whose cone stays inside the crop
+        g_full = u.backward_input(ch, dw)
+        g_win = u.backward_input(cw, dw[:, 48:460, 68:432].contiguous())
+        assert torch.equal(g_win[:, 40:-40, 40:-40], g_full[:, 88:420, 108:392])
+    # the mode-following pair takes this route for an eval-mode net in bf16 precision (and not when switched off)
+    _, ctx = u.forward_for_backward(x, precision="bf16")
+    assert ctx[0].dtype == torch.int16
+    u.half_width_tensors = False
+    _, ctx = u.forward_for_backward(x, precision="bf16")
+    assert ctx[0].dtype == torch.float32

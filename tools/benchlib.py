@@ -334,7 +334,7 @@ def sync_batch(dev, S, T=5, FH=500, FW=500, h=96, w=96, x0=202, y0=316, seed=11)
                 canonical_face_bbox=[110, 90, 390, 420, 1.0], mel=mel, rgb_window_neg=neg)
 
 
-def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=False, half_width_tensors=True):
+def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=False, half_width_tensors=True, frames_per_group=None):
     """BASELINE config 5 as named -- MLP forward + backward WITH the lipsync_expert loss: B main frames (MSE) of which the
     first S carry a 5-frame sync window (5 S more renders -> composite -> frozen U-Net @500x500 -> crop/resize -> SyncNet x2 ->
     BCE, and all of it back to the MLP), bf16 MLP kernels, Adam.  FLOPs counted: the MLP's as-written 3 x 4 x 2 x 644,864 per
@@ -351,6 +351,8 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
     if not unet_train_mode:
         m.post_fusion_unet.eval()
     m.post_fusion_unet.half_width_tensors = half_width_tensors      # (train mode + bf16 only: bf16 tensors between the U-Net's kernels)
+    if frames_per_group:
+        m.post_fusion_unet.train_frames_per_group = frames_per_group
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
