@@ -183,6 +183,8 @@ def extra_measurements(dev):
                      ("train_bf16_with_sync_loss_trainmode_bn_fp32_tensors",
                       lambda: benchlib.bench_train_sync(dev, 64, 8, "bf16", unet_train_mode=True, half_width_tensors=False)),
                      ("stage1_full_iteration_bf16", lambda: benchlib.bench_stage1_full(dev, 8, "bf16")),
+                     ("stage1_full_iteration_bf16_trainmode_bn", lambda: benchlib.bench_stage1_full(dev, 8, "bf16", unet_train_mode=True)),
+                     ("stage1_early_iteration_bf16", lambda: benchlib.bench_stage1_full(dev, 8, "bf16", early=True)),
                      ("train_fp32", lambda: benchlib.bench_train(dev, 64, "fp32", steps=3))):
         try:
             r = fn()

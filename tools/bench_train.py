@@ -1,7 +1,7 @@
 """BASELINE config 5 timing: one training step = 4-tap ensemble forward + MSE + full backward for a
 batch of frames at 96x96 (fp32 exact-parity mode).  FLOPs per step (as-written
 model, fwd + dgrad + wgrad, 4 taps): 3 * 4 * 2 * 644,864 * HW * frames.
-    python tools/bench_train.py [frames=64] [fp32|bf16] [--profile] [--sync=S] [--full]
+    python tools/bench_train.py [frames=64] [fp32|bf16] [--profile] [--sync=S [--trainbn]] [--full [--trainbn | --early]]
 bf16 = the precision BASELINE config 5 names (bf16 MFMA operands and saved state, fp32 accumulation and master weights)."""
 import json, os, sys, time
 import torch
@@ -11,7 +11,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if args else 64
 PREC = args[1] if len(args) > 1 else "fp32"
 if "--full" in sys.argv:      # every term of the reference's stage-1 iteration (LPIPS, face, sync) on each of the B samples
-    print(json.dumps(benchlib.bench_stage1_full(torch.device("cuda:0"), B, PREC)))
+    print(json.dumps(benchlib.bench_stage1_full(torch.device("cuda:0"), B, PREC, unet_train_mode="--trainbn" in sys.argv, early="--early" in sys.argv)))
     sys.exit(0)
 sync = [a for a in sys.argv[1:] if a.startswith("--sync")]
 if sync:      # --sync=S: the step with the lipsync_expert loss attached to S of the B samples

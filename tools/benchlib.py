@@ -389,24 +389,30 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
-def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
+def bench_stage1_full(dev, B=8, precision="bf16", steps=3, unet_train_mode=False, early=False):
     """One FULL stage-1 iteration of the reference per sample (training.py:347-574 after it > 100000, May flags), B samples per
     step: MSE + LPIPS on the 96x96 lip, MSE + LPIPS on the fused face (composite with black holes -> frozen U-Net @500x500), the
     lipsync_expert loss over a 5-frame window (5 more renders -> composite -> U-Net crop -> SyncNet x2), all of it back to
     the MLP, Adam.  (The reference runs batch_size 1: `ms_per_sample` is the time of one of its iterations.)"""
     H = Wd = 96
     m = make_model(dev, H, Wd, unet=True, train=True)
-    for p in m.post_fusion_unet.parameters():
-        p.requires_grad = False
-    m.post_fusion_unet.eval()      # (eval-mode BatchNorm: running statistics, crop window; see bench_train_sync for the train-mode form)
+    # early = the iterations before `it > 100000` (train.py:188-197 not reached yet): the post-fusion net TRAINS with the MLP (train-mode
+    # BatchNorm, parameter gradients, golden G14), no sync loss.  Otherwise the net is frozen: eval-mode BatchNorm as train.py:195 words
+    # it, or (unet_train_mode) train-mode BatchNorm as the loop really runs it (Trainer.train_step's model.train(), golden G16)
+    if not early:
+        for p in m.post_fusion_unet.parameters():
+            p.requires_grad = False
+        if not unet_train_mode:
+            m.post_fusion_unet.eval()
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     lp = s2l.LPIPS(pretrained=False, net="alex", version="0.1").to(dev)      # seeded weights are loaded below
     lp.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()})
-    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith(("coord_linears", "post_fusion_unet"))], lr=1e-4)
+    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith("coord_linears") and
+                            (early or not n_.startswith("post_fusion_unet"))], lr=1e-4)
     audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
     target = torch.rand(B, H * Wd, 3, device=dev)
-    step = s2l.StageOneStep(m, H, Wd, syncnet=net, precision=precision, face_loss=True, perceptual=lp)
+    step = s2l.StageOneStep(m, H, Wd, syncnet=None if early else net, precision=precision, face_loss=True, perceptual=lp)
     sync = sync_batch(dev, B)
     coord, g = device_warp_coords(dev, B, seed=5)
     face = dict(rgb_face_canonical=sync["rgb_face_canonical"], rgb_face_gt=sync["rgb_face_gt"], mask_lip_canonical=sync["mask_lip_canonical"],
@@ -415,7 +421,7 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
     u01 = [0.5] * B
 
     def one():
-        loss, gr, aux = step.loss_and_grads(audio, list(range(B)), target, u01, sync=sync, face=face)
+        loss, gr, aux = step.loss_and_grads(audio, list(range(B)), target, u01, sync=None if early else sync, face=face)
         s2l.training.apply_grads(m, gr)
         opt.step()
         return loss, aux
@@ -426,11 +432,14 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3):
         l, aux = one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    mode = ("U-Net TRAINING with the MLP (it <= 100000: train-mode BatchNorm, parameter gradients), no sync loss" if early else
+            "frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16), sync loss over a 5-frame window" if unet_train_mode else
+            "frozen U-Net in eval-mode BatchNorm, sync loss over a 5-frame window")
     return {"config": f"full stage-1 iteration x {B} samples: MSE + LPIPS(alex) on the 96x96 lip and on the fused 500x500 face (composite "
-                      f"with black holes + frozen U-Net), sync loss over a 5-frame window, {precision} MLP, Adam",
+                      f"with black holes + post-fusion U-Net), {mode}, {precision} MLP, Adam",
             "ms_per_step": round(dt * 1e3, 2), "ms_per_sample": round(dt * 1e3 / B, 2), "loss_first": l0, "loss_last": float(l),
             "loss_perceptual_last": float(aux["loss_perceptual"]), "loss_face_last": float(aux["loss_face"]),
-            "loss_sync_last": float(aux["loss_sync"]), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+            "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
 def bench_train(dev, B=64, precision="bf16", steps=5):
