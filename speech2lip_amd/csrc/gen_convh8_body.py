@@ -22,7 +22,7 @@ NI = 5                                                          # halo DMA instr
 CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
 WITH_RELU = False                                               # main() generates both: convh8_body.inc (linear) and convh8r_body.inc (max(0, .))
 PFX = "S2L8"                                                    # label prefix (two bodies in one translation unit)
-EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier
 
 # ---- registers
 A_ACC = 0
@@ -412,7 +412,8 @@ class Body:
             self.tap_mfmas(os_, sprinkle)
         self.wait_all_lds()
         e("s_waitcnt vmcnt(0)")
-        e("s_barrier")
+        if not EXP & 1024:
+            e("s_barrier")
         self.advance_staging()
 
     def bias_init(self):
@@ -463,7 +464,8 @@ class Body:
         e = self.e
         e("s_nop 7")
         e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
-        self.store_tile()
+        if not EXP & 512:
+            self.store_tile()
         e("s_barrier")                                                # (the staging area is buffer 1's halo region: nobody may stage the next
         self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
 
