@@ -104,12 +104,13 @@ __device__ __forceinline__ bool convh8_prologue(const ConvHArgs& a, char* smem, 
   const int tile0 = (int)(total * blockIdx.x / gridDim.x), tile_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
   if (tile0 >= tile_end) return false;
   int t = tile0;
+  // (tile t = ((frame * tiles_y + ty) * tiles_x + tx) * n_ct + ct: the channel tiles of one position are consecutive)
+  c.ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
+  t /= a.n_ct;
   c.tx0 = __builtin_amdgcn_readfirstlane(t % a.tiles_x);
   t /= a.tiles_x;
   c.ty0 = __builtin_amdgcn_readfirstlane(t % a.tiles_y);
-  t /= a.tiles_y;
-  c.ct0 = __builtin_amdgcn_readfirstlane(t % a.n_ct);
-  c.fr0 = __builtin_amdgcn_readfirstlane(t / a.n_ct);
+  c.fr0 = __builtin_amdgcn_readfirstlane(t / a.tiles_y);
   c.ntl = __builtin_amdgcn_readfirstlane(tile_end - tile0);
   c.wave = wave;
   c.lds0 = lds0;

@@ -160,23 +160,24 @@ class Body:
 
     # ---- streams
     def next_coords(self, p, ct_name):
-        """the stream with prefix p moves to its next tile (x fastest, then y, channel tile, frame) -- or stays on its last one"""
+        """the stream with prefix p moves to its next tile (channel tile fastest, then x, y, frame: the channel tiles of one position
+        read the same halo planes back to back, the second time from L2) -- or stays on its last one"""
         e = self.e
         stay = self.label("stay")
         e(f"s_cmp_lt_u32 {s(p + 'LEFT')}, 2")
         e(f"s_cbranch_scc1 {stay}")
         e(f"s_sub_u32 {s(p + 'LEFT')}, {s(p + 'LEFT')}, 1")
-        e(f"s_add_u32 {s(p + 'TX')}, {s(p + 'TX')}, 1")
+        e(f"s_add_u32 {s(ct_name)}, {s(ct_name)}, 1")
+        e(f"s_cmp_eq_u32 {s(ct_name)}, {s('NCT')}")
+        e(f"s_cselect_b32 {s(ct_name)}, 0, {s(ct_name)}")
+        e(f"s_cselect_b32 {s('T0')}, 1, 0")
+        e(f"s_add_u32 {s(p + 'TX')}, {s(p + 'TX')}, {s('T0')}")
         e(f"s_cmp_eq_u32 {s(p + 'TX')}, {s('TILESX')}")
         e(f"s_cselect_b32 {s(p + 'TX')}, 0, {s(p + 'TX')}")
         e(f"s_cselect_b32 {s('T0')}, 1, 0")
         e(f"s_add_u32 {s(p + 'TY')}, {s(p + 'TY')}, {s('T0')}")
         e(f"s_cmp_eq_u32 {s(p + 'TY')}, {s('TILESY')}")
         e(f"s_cselect_b32 {s(p + 'TY')}, 0, {s(p + 'TY')}")
-        e(f"s_cselect_b32 {s('T0')}, 1, 0")
-        e(f"s_add_u32 {s(ct_name)}, {s(ct_name)}, {s('T0')}")
-        e(f"s_cmp_eq_u32 {s(ct_name)}, {s('NCT')}")
-        e(f"s_cselect_b32 {s(ct_name)}, 0, {s(ct_name)}")
         e(f"s_cselect_b32 {s('T0')}, 1, 0")
         e(f"s_add_u32 {s(p + 'FR')}, {s(p + 'FR')}, {s('T0')}")
         e(f"{stay}:")
