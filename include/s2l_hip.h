@@ -391,6 +391,12 @@ int s2l_unet_train_backward_frames(const float* packed_raw, const uint16_t* pack
                                    const float* x, const float* saved, const float* d_out, float* work, float* d_x, int height,
                                    int width, int64_t n_frames, s2l_stream_t stream);
 
+/* s2l_unet_train_backward_frames for a net that still TRAINS (before `it > 100000`, train.py:188-197 not reached): also the parameter
+ * gradients of the F one-frame calls, summed over the frames (layout and meaning of `grads` as s2l_unet_train_backward; d_x may be NULL). */
+int s2l_unet_train_backward_frames_grads(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                         const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
+                                         int height, int width, int64_t n_frames, s2l_stream_t stream);
+
 /* The same pair on HALF-WIDTH TENSORS (csrc/unet_half.inc, csrc/convh.hip): every tensor between the kernels -- pre-BatchNorm outputs,
  * activations, pooled / up-sampled copies, gradients -- is bf16 NHWC; bf16 operands, fp32 accumulation, fp32 per-frame statistics (of
  * the bf16-rounded pre-BatchNorm tensor), results rounded to nearest even on store; x, out, d_out, d_x stay fp32.  Replaces the same

@@ -100,6 +100,8 @@ EXPORTS = {
     "s2l_unet_forward_saved_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_backward_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
                                     c_void_p]),
+    "s2l_unet_train_backward_frames_grads": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_set_unet_conv_kernel": (c_int, [c_int]),
     "s2l_set_unet_split_kernel": (c_int, [c_int]),
     "s2l_set_render_shape": (c_int, [c_int]),

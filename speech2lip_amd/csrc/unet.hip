@@ -1895,6 +1895,20 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
   sums[g * 256 + c] = (float)(s1 / n);
   sums[g * 256 + C + c] = (float)(s2 / n);
 }
+// per-group dgamma / dbeta ([group][256]: 128 + 128) -> their sums over the groups, in group order (a TRAINING net whose frames are
+// separate statistics groups: the batch's parameter gradient is the sum of the per-call gradients)
+__global__ __launch_bounds__(128) void sum_groups_kernel(const float* __restrict__ per_group, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        int C, int groups) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    a += per_group[g * 256 + c];
+    b += per_group[g * 256 + 128 + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
 // stage 3 (in place): dz = scale * (gy - s1/n - zhat * s2/n)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ gy, const float* __restrict__ z, const float* __restrict__ st,
                                                           const float* __restrict__ sums, int C, int64_t n_quads, int64_t group_quads) {
@@ -2523,7 +2537,6 @@ extern "C" int s2l_unet_train_forward_bf16(const float* packed_raw, const uint16
 static int unet_train_backward_impl(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                     const float* x, const float* saved, const float* d_out, float* work, float* d_x, float* grads,
                                     int height, int width, int64_t n_frames, s2l_stream_t stream, bool frames_are_groups = false) {
-  if (frames_are_groups && grads) return S2L_E_SIZE;      // (per-frame groups exist for the frozen net: input gradient only)
   if (height < 4 || width < 4 || n_frames <= 0 || n_frames > 65535) return S2L_E_SIZE;
   if (misaligned16(packed16_raw)) return S2L_E_ALIGN;
   if (!packed_raw || !x || !saved || !d_out || !work) return S2L_E_NULL;
@@ -2564,13 +2577,17 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
     const float* stl = b.st + (int64_t)l * 512 * groups;
     float* g = want_params ? grads + grad_off(l) : nullptr;
     // (sums: per group 2 x 128 means; frozen net: dgamma / dbeta go to 256 floats of scratch per group behind them)
-    float* dgamma = want_params ? g + (int64_t)C * cin * 9 : sums + 256 * groups;
-    float* dbeta = want_params ? dgamma + C : dgamma + 128;
+    // per-frame groups: every group leaves its own dgamma / dbeta in scratch; a training net's are their sums over the groups
+    const bool via_scratch = !want_params || groups > 1;
+    float* dgamma = via_scratch ? sums + 256 * groups : g + (int64_t)C * cin * 9;
+    float* dbeta = via_scratch ? dgamma + 128 : dgamma + C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, pl[lv] * C / 4,
                        n * C / 4);
     if (!want_params) return;
+    if (groups > 1)
+      hipLaunchKernelGGL(sum_groups_kernel, dim3(1), dim3(128), 0, st, dgamma, g + (int64_t)C * cin * 9, g + (int64_t)C * cin * 9 + C, C, groups);
     if (l == 0) {
       const int64_t perw = (p1 + 1023) / 1024;
       const int nbw = (int)((p1 + perw - 1) / perw);
@@ -2648,6 +2665,15 @@ extern "C" int s2l_unet_train_backward_frames(const float* packed_raw, const uin
   if (!d_x) return S2L_E_NULL;
   return unet_train_backward_impl(packed_raw, packed16_raw, tensors_host, x, saved, d_out, work, d_x, nullptr, height, width, n_frames,
                                   stream, true);
+}
+// the same for a net that still TRAINS (it <= 100000): also the parameter gradients of the F one-frame calls, summed (grads as
+// s2l_unet_train_backward; d_x may be NULL)
+extern "C" int s2l_unet_train_backward_frames_grads(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                                    const float* x, const float* saved, const float* d_out, float* work, float* d_x,
+                                                    float* grads, int height, int width, int64_t n_frames, s2l_stream_t stream) {
+  if (!grads) return S2L_E_NULL;
+  return unet_train_backward_impl(packed_raw, packed16_raw, tensors_host, x, saved, d_out, work, d_x, grads, height, width, n_frames, stream,
+                                  true);
 }
 extern "C" int s2l_unet_train_backward_bf16(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                             const float* x, const float* saved, const float* d_out, float* work, float* d_x,

@@ -341,8 +341,9 @@ class SimpleUnetLight(nn.Module):
             self._packed16x3 = self._packed16x3_key = None
         return out, (raw, x, saved, (F_, H, W), raw16)
 
-    def backward_train_frames(self, ctx, d_out: torch.Tensor) -> torch.Tensor:
-        """d loss / d x [F,H,W,3] for a forward_train_frames_nhwc state (the net's parameters receive nothing: frozen)."""
+    def backward_train_frames(self, ctx, d_out: torch.Tensor, want_param_grads: bool = False):
+        """d loss / d x [F,H,W,3] for a forward_train_frames_nhwc state.  want_param_grads (a net that still trains; fp32 tensors only):
+        returns (d_x, {state-dict name: gradient}) -- the parameter gradients of the F one-frame calls, summed."""
         lib = _abi.load()
         raw, x, saved, (F_, H, W), raw16 = ctx
         dev = x.device
@@ -361,6 +362,19 @@ class SimpleUnetLight(nn.Module):
                            "s2l_unet_train_backward_frames_h")
             return dx
         work = torch.empty(int(lib.s2l_unet_train_frames_work_floats(H, W, F_)), dtype=torch.float32, device=dev)
+        if want_param_grads:
+            flat = torch.empty(int(lib.s2l_unet_grad_floats()), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _abi.check(lib.s2l_unet_train_backward_frames_grads(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_,
+                                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                           "s2l_unet_train_backward_frames_grads")
+            params = dict(self.named_parameters())
+            grads, off = {}, 0
+            for name in self.grad_names():
+                n = params[name].numel()
+                grads[name] = flat[off:off + n].reshape(params[name].shape)
+                off += n
+            return dx, grads
         with torch.cuda.device(dev):
             _abi.check(lib.s2l_unet_train_backward_frames(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), H, W, F_,
                                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -465,6 +479,20 @@ class SimpleUnetLight(nn.Module):
                 outs.append(o)
                 ctxs.append((s0, min(F_, s0 + group), c))
             return torch.cat(outs, 0), ("train_frames", ctxs)
+        # a net that still trains (it <= 100000): the same frames route with fp32 tensors (every frame its own statistics group,
+        # running statistics in frame order), its backward also returns the parameter gradients summed over the frames
+        # (`batch_train_frames = False` on the module: one forward_train_nhwc / backward_train call per frame instead)
+        if getattr(self, "batch_train_frames", True):
+            F_, H, W = x.shape[0], x.shape[1], x.shape[2]
+            lib = _abi.load()
+            per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
+            group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
+            outs, ctxs = [], []
+            for s0 in range(0, F_, group):
+                o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)
+                outs.append(o)
+                ctxs.append((s0, min(F_, s0 + group), c))
+            return (outs[0] if len(outs) == 1 else torch.cat(outs, 0)), ("train_frames_grads", ctxs)
         outs, ctxs = [], []
         for f in range(x.shape[0]):
             o, c = self.forward_train_nhwc(x[f:f + 1], update_running=True, precision=precision)
@@ -478,6 +506,20 @@ class SimpleUnetLight(nn.Module):
         under their state-dict names (the net while it still trains, it <= 100000)."""
         if isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train_frames":
             return torch.cat([self.backward_train_frames(c, d_out[s0:s1]) for s0, s1, c in ctx[1]], 0)
+        if isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train_frames_grads":
+            if param_grads is None and any(p_.requires_grad for p_ in self.parameters()):
+                raise ValueError("backward_to_input: this train-mode U-Net still has trainable parameters; pass param_grads={} to "
+                                 "receive their gradients (or freeze the net as train.py:188-197 does)")
+            dxs = []
+            for s0, s1, c in ctx[1]:
+                if param_grads is None:
+                    dxs.append(self.backward_train_frames(c, d_out[s0:s1]))
+                    continue
+                dx, grads = self.backward_train_frames(c, d_out[s0:s1], want_param_grads=True)
+                dxs.append(dx)
+                for k, v in grads.items():
+                    param_grads[k] = v.clone() if k not in param_grads else param_grads[k] + v
+            return dxs[0] if len(dxs) == 1 else torch.cat(dxs, 0)
         if not (isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train"):
             return self.backward_input(ctx, d_out)
         if param_grads is None and any(p_.requires_grad for p_ in self.parameters()):

@@ -826,6 +826,9 @@ def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
         dc.append(uc.backward_train(c, d[f:f + 1], want_param_grads=False)[0])
     assert torch.equal(o2, torch.cat(oc, 0)) and torch.equal(dx2, torch.cat(dc, 0))
     _, ctx_t = ua.forward_for_backward(x[:2], precision=precision)
+    assert ctx_t[0] == "train_frames_grads"      # a net that trains: the frames route with parameter gradients (test below)
+    ua.batch_train_frames = False
+    _, ctx_t = ua.forward_for_backward(x[:2], precision=precision)
     assert ctx_t[0] == "train"
     # several groups of frames (a small memory budget): same numbers, the running statistics still in frame order
     ud, ue = net(), net()
@@ -841,6 +844,36 @@ def test_unet_train_frames_equal_one_call_per_frame(dev, precision, F, fh, fw):
     assert torch.equal(o_d, o_e) and torch.equal(ud.backward_to_input(c_d, d), ue.backward_to_input(c_e, d))
     for k, v in ud.state_dict().items():
         assert torch.equal(v, ue.state_dict()[k]), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_unet_frames_in_one_call_equal_one_call_per_frame(dev, precision):
+    """A net that still trains (it <= 100000): forward_for_backward batches its one-frame calls too (s2l_unet_train_backward_frames_grads):
+    outputs, input gradients and running statistics are the bits of one call per frame; the parameter gradients are the per-frame
+    gradients summed (here: against their sum in frame order, to fp32 summation-order accuracy)."""
+    def net():
+        u = s2l.SimpleUnetLight().to(dev).train()
+        u.load_state_dict({k[len("post_fusion_unet."):]: T(v) for k, v in W.make_unet_state_dict(0).items()})
+        return u
+    ua, ub = net(), net()
+    ua.batch_train_frames = False
+    F, fh, fw = 4, 44, 60
+    rng = np.random.default_rng(11)
+    x = T(rng.random((F, fh, fw, 3), dtype=np.float32)).to(dev)
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    oa, ca = ua.forward_for_backward(x, precision=precision)
+    ob, cb = ub.forward_for_backward(x, precision=precision)
+    assert ca[0] == "train" and cb[0] == "train_frames_grads" and torch.equal(oa, ob)
+    ga, gb = {}, {}
+    dxa, dxb = ua.backward_to_input(ca, d, param_grads=ga), ub.backward_to_input(cb, d, param_grads=gb)
+    assert torch.equal(dxa, dxb) and set(ga) == set(gb) and len(gb) == 32
+    for k in ga:
+        assert relerr(gb[k], ga[k].cpu()) <= 2e-5, (k, relerr(gb[k], ga[k].cpu()))
+    sa, sb = ua.state_dict(), ub.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    with pytest.raises(ValueError):
+        ub.backward_to_input(cb, d)      # trainable parameters and nowhere to put their gradients
 
 
 def test_train_step_from_a_dataset_folder(syncnet, dev):
