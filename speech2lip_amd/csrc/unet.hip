@@ -2016,6 +2016,118 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[((int64_t)(ct * 64 + 16 * wave + 4 * q + r) * cin + cc * 16 + i16) * 9 + t] = acc[t][r];
 }
+// The same weight gradient with bf16 OPERANDS (the precision of the training chain's other convolutions; fp32 accumulation, fp32
+// tensors in memory): dW[co][ci][t] on v_mfma_f32_16x16x32_bf16, K = 32 pixels per instruction.  Workgroup = (64 output channels, 32
+// input channels, 9 taps), wave w owns output channels 16 w .. + 15 (9 x 2 accumulators of 4 registers).  A 16-bit MFMA operand is 8
+// CONSECUTIVE k per lane, i.e. 8 consecutive pixels of one channel -- NHWC has them C floats apart -- so the transposition happens in
+// registers on the way into LDS: a thread fetches 8 (dz) or 10 (input, with the two neighbours the tap shifts need) consecutive pixels
+// of one channel quad, converts, and writes 16-byte pixel octets: dzT [co 64][px 64], aT [dy 3][dx 3][ci 32][px 64] -- one copy of the
+// input rows PER dx, so that every tap's operand is an aligned ds_read_b128 (a one-pixel shift of a packed octet would not be).
+// K chunks, split K and the partial layout as conv_wgrad_kernel (wgrad_reduce_wide_kernel sums them).  16 x the matrix rate of the
+// fp32 form: the kernel is bound by reading dz (cin / 32 times) and the input (cout / 64 times).
+constexpr int kWgPitch = 72;      // halves per LDS row: 64 pixels + 8 of padding (144 bytes: rows stay 16-byte aligned)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds_dz[64 * kWgPitch];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_a[9 * 32 * kWgPitch];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kg = lane >> 4, i16 = lane & 15;
+  const int ct = blockIdx.x, cc = blockIdx.y;      // cc: 32-channel block of the (virtually concatenated) input
+  const int cin = a.CA + a.CB;
+  const bool fromA = cc * 32 < a.CA;
+  const float* in = fromA ? a.inA : a.inB;
+  const int Cin = fromA ? a.CA : a.CB;
+  const int coff = fromA ? cc * 32 : cc * 32 - a.CA;
+  f4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  // fetch tasks.  dz: thread < 128 = (pixel octet pg = tid >> 4, channel quad cq = tid & 15): 8 pixels x 4 channels.
+  // input: thread < 192 = (row dy = tid / 64, pixel octet pg = (tid >> 3) & 7, channel quad cq = tid & 7): 10 pixels x 4 channels.
+  f4 pd[8], pa[10];
+  const bool has_dz = threadIdx.x < 128, has_a = threadIdx.x < 192;
+  const int dpg = threadIdx.x >> 4, dcq = threadIdx.x & 15;
+  const int ady = threadIdx.x >> 6, apg = (threadIdx.x >> 3) & 7, acq = threadIdx.x & 7;
+  auto fetch = [&](int64_t ch) {
+    const int cx = (int)(ch % a.chunks_x);
+    const int64_t row = ch / a.chunks_x;                  // f * H + y
+    const int y = (int)(row % a.H);
+    const int64_t f = row / a.H;
+    const int x0 = cx * 64;
+    if (has_dz) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int x = x0 + 8 * dpg + k;
+        pd[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (x < a.W) pd[k] = *reinterpret_cast<const f4*>(a.dz + (row * a.W + x) * a.cout + ct * 64 + 4 * dcq);
+      }
+    }
+    if (has_a) {
+      const int gy = y + ady - 1;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int gx = x0 + 8 * apg + k - 1;
+        pa[k] = (f4){0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+          pa[k] = *reinterpret_cast<const f4*>(in + ((f * a.H + gy) * (int64_t)a.W + gx) * Cin + coff + 4 * acq);
+      }
+    }
+  };
+  auto commit = [&]() {
+    if (has_dz) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u4v o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(pd[2 * k][c], pd[2 * k + 1][c]);
+        *reinterpret_cast<u4v*>(lds_dz + (4 * dcq + c) * kWgPitch + 8 * dpg) = o;
+      }
+    }
+    if (has_a) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u4v o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(pa[dx + 2 * k][c], pa[dx + 2 * k + 1][c]);
+          *reinterpret_cast<u4v*>(lds_a + ((ady * 3 + dx) * 32 + 4 * acq + c) * kWgPitch + 8 * apg) = o;
+        }
+    }
+  };
+  if ((int64_t)blockIdx.z < a.n_chunks) {
+    fetch(blockIdx.z);
+    commit();
+  }
+  __syncthreads();
+  for (int64_t ch = blockIdx.z; ch < a.n_chunks; ch += gridDim.z) {
+    const bool more = ch + gridDim.z < a.n_chunks;
+    if (more) fetch(ch + gridDim.z);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {      // 32 pixels per k-step; lane (row / column i16, pixel octet kg)
+      const u4v av = *reinterpret_cast<const u4v*>(lds_dz + (16 * wave + i16) * kWgPitch + 32 * ks + 8 * kg);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const u4v bv = *reinterpret_cast<const u4v*>(lds_a + (t * 32 + 16 * cb + i16) * kWgPitch + 32 * ks + 8 * kg);
+          acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, av), __builtin_bit_cast(bf8v, bv), acc[t][cb], 0, 0, 0);
+        }
+    }
+    __syncthreads();            // everyone is done reading this chunk
+    if (more) {
+      commit();
+      __syncthreads();
+    }
+  }
+  // D[row = 4 kg + r -> co][col = i16 -> ci]
+  float* p = a.partial + (int64_t)blockIdx.z * a.cout * cin * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[((int64_t)(ct * 64 + 16 * wave + 4 * kg + r) * cin + cc * 32 + 16 * cb + i16) * 9 + t] = acc[t][cb][r];
+}
 // sum of the split-K partials in a fixed order: 64 elements per workgroup, four threads per element take every fourth partial
 __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
                                                                int64_t n) {
@@ -2599,7 +2711,8 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
       a.H = hh[lv]; a.W = ww[lv]; a.F = (int)F; a.chunks_x = (a.W + 63) / 64;
       a.n_chunks = F * a.H * a.chunks_x;
       a.partial = wpart;
-      const int tiles = (C / 64) * (cin / 16);
+      const bool w16 = packed16_raw != nullptr;      // bf16 precision: bf16 operands for the weight gradient too (32 input channels per workgroup)
+      const int tiles = (C / 64) * (cin / (w16 ? 32 : 16));
       // split K so that ~2048 workgroups exist (8 per CU), as far as the partial buffer reaches: it holds 32 partials of the
       // largest layer (256 x 128), i.e. 256 of a 64 x 64 one -- with a flat cap of 32 the two 64 -> 64 layers at full
       // resolution ran on 128 workgroups (0.30 of the MFMA peak; 0.6 with this)
@@ -2607,7 +2720,8 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
       const int cap = (int)(32 * (int64_t)256 * 128 / ((int64_t)C * cin));
       if (S > cap) S = cap;
       if (S > a.n_chunks) S = (int)a.n_chunks;
-      hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
+      if (w16) hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(C / 64, cin / 32, S), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
       const int64_t ne = (int64_t)C * cin * 9;
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, st, wpart, g, S, ne);
     }

@@ -757,8 +757,13 @@ def test_unet_train_mode_bf16_convolutions_vs_fp32(dev, fh, fw):
     assert rel(o16, o32) <= 2e-2 and cos(o16, o32) >= 0.9998 and not torch.equal(o16, o32), (rel(o16, o32), cos(o16, o32))
     # the input-gradient convolutions alone: the fp32 forward's state (identical ReLU / pooling decisions and statistics), bf16
     # operands in the backward
-    gm, _ = u32.backward_train((*c32[:4], c16[4]), d, want_param_grads=False)
+    gm, pm = u32.backward_train((*c32[:4], c16[4]), d)
     assert rel(gm, g32) <= 2.5e-2, rel(gm, g32)
+    # ... and the bf16-operand weight-gradient kernel (conv_wgrad_bf16_kernel) on that same state: every 3x3 layer's dW within operand
+    # rounding of the exact fp32 kernel's (the first layer and the BatchNorm / output-layer gradients stay fp32 kernels)
+    for k in p32:
+        assert rel(pm[k], p32[k]) <= 3e-2 and cos(pm[k], p32[k]) >= 0.9995, (k, rel(pm[k], p32[k]), cos(pm[k], p32[k]))
+    assert any(not torch.equal(pm[k], p32[k]) for k in p32 if k.endswith("double_conv.3.weight"))
     # end to end it is the gradient of the bf16 forward: ReLUs within bf16 rounding of zero resolve the other way (white-noise d)
     assert cos(g16, g32) >= 0.97 and rel(g16, g32) <= 0.3, (rel(g16, g32), cos(g16, g32))
     for k in p32:      # weight gradients: fp32 GEMMs over the bf16 forward's activations and the bf16 input-gradient chain
