@@ -2141,39 +2141,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   __syncthreads();
   if (pl == 0 && e < n) out[e] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
 }
-// first convolution (3 input channels): partial[blk][co][c*9 + t]; thread = (co, pixel lane of 4)
+// first convolution (3 input channels): partial[blk][co][c*9 + t] = sum over the block's pixels of dz[p][co] x[neighbour t of p][c], on
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chains): K = pixels, four per instruction; A = dz^T (lane (co within its 16-block, pixel q)),
+// B = the pixel's 27 inputs padded to 32 (lane (k within its 16-block, pixel q): one gathered value), 4 x 2 accumulators per wave.
+// (As a loop of 27 scalar-operand FMAs per pixel this kernel took 1.3 ms per 8 frames, 10 x the time of its HBM traffic.)
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                               float* __restrict__ partial, int H, int W, int64_t n_pix,
                                                               int64_t per_block) {
   __shared__ float red[4][64 * 27];
-  // a wave = one pixel at a time, lane = output channel: the pixel index is wave-uniform (readfirstlane), so the 27 input values
-  // of its 3x3 neighbourhood are scalar loads and reach the FMAs as scalar operands (as 27 vector loads of one address each
-  // this kernel took 1.8 ms per 8 frames, 12x the time of its HBM traffic)
-  const int co = threadIdx.x & 63, pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float acc[27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  f4 acc[4][2];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  for (int mb = 0; mb < 4; ++mb) acc[mb][0] = acc[mb][1] = (f4){0.f, 0.f, 0.f, 0.f};
+  // this lane's two input taps: k = 16 kb + i16 = c * 9 + t
+  int kc[2], kdy[2], kdx[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = 16 * kb + i16, c = k / 9, t = k - 9 * c;
+    kc[kb] = k < 27 ? c : -1;
+    kdy[kb] = t / 3 - 1;
+    kdx[kb] = t % 3 - 1;
+  }
   const int64_t p0 = (int64_t)blockIdx.x * per_block;
   int64_t p1 = p0 + per_block;
   if (p1 > n_pix) p1 = n_pix;
-  for (int64_t p = p0 + pl; p < p1; p += 4) {
-    const int xx = (int)(p % W);
-    const int64_t r = p / W;
+  for (int64_t pb = p0 + 4 * wave; pb < p1; pb += 16) {      // four pixels per wave and step
+    const int64_t p = pb + q;
+    const bool live = p < p1;
+    const int xx = live ? (int)(p % W) : 0;
+    const int64_t r = live ? p / W : 0;
     const int yy = (int)(r % H);
     const int64_t f = r / H;
-    const float g = dz[p * 64 + co];
+    float av[4], bv[2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int gy = yy + t / 3 - 1, gx = xx + t % 3 - 1;
-      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-        const float* s = x + ((f * H + gy) * (int64_t)W + gx) * 3;
+    for (int mb = 0; mb < 4; ++mb) av[mb] = live ? dz[p * 64 + 16 * mb + i16] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c * 9 + t] = fmaf(g, s[c], acc[c * 9 + t]);
-      }
+    for (int kb = 0; kb < 2; ++kb) {
+      const int gy = yy + kdy[kb], gx = xx + kdx[kb];
+      const bool ok = live && kc[kb] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      bv[kb] = ok ? x[((f * H + gy) * (int64_t)W + gx) * 3 + kc[kb]] : 0.f;
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 27; ++k) red[pl][co * 27 + k] = acc[k];
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) acc[mb][kb] = mfma16u(av[mb], bv[kb], acc[mb][kb]);
+  }
+  // D[row = 4 q + r -> co = 16 mb + 4 q + r][col = i16 -> k = 16 kb + i16]
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kb + i16;
+        if (k < 27) red[wave][(16 * mb + 4 * q + r) * 27 + k] = acc[mb][kb][r];
+      }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 27; i += 256)
     partial[(int64_t)blockIdx.x * 64 * 27 + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
