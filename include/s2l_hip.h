@@ -413,6 +413,13 @@ int s2l_unet_train_forward_frames_h(const float* packed_raw, const uint16_t* pac
 int s2l_unet_train_backward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                      const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x, int height, int width,
                                      int64_t n_frames, s2l_stream_t stream);
+/* s2l_unet_train_backward_frames_h for a net that still TRAINS (before `it > 100000`): also the parameter gradients of the F one-frame
+ * calls, summed over the frames (layout of `grads` as s2l_unet_train_backward); the 3x3 layers' weight gradients take bf16 operands
+ * straight from the bf16 planes.  x: the forward's input [F,H,W,3]; d_x may be NULL.  work: s2l_unet_train_frames_h_work_halves_grads. */
+int64_t s2l_unet_train_frames_h_work_halves_grads(int height, int width, int64_t n_frames);
+int s2l_unet_train_backward_frames_h_grads(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
+                                           const float* x, const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x, float* grads,
+                                           int height, int width, int64_t n_frames, s2l_stream_t stream);
 /* The EVAL-mode pair (s2l_unet_forward_saved_window / s2l_unet_backward_window with bf16 operands) on half-width tensors: BatchNorm
  * folded into the weights (packed16: s2l_unet_pack16 with the real eps; packed: s2l_unet_pack's blob for the first layer, the biases and
  * the output layer), bias + ReLU in the convolution's epilogue, every tensor between the kernels bf16 in 32-channel planes; window

@@ -102,6 +102,9 @@ EXPORTS = {
                                     c_void_p]),
     "s2l_unet_train_backward_frames_grads": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_frames_h_work_halves_grads": (c_int64, [c_int, c_int, c_int64]),
+    "s2l_unet_train_backward_frames_h_grads": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_set_unet_conv_kernel": (c_int, [c_int]),
     "s2l_set_unet_split_kernel": (c_int, [c_int]),
     "s2l_set_render_shape": (c_int, [c_int]),

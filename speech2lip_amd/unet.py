@@ -354,7 +354,23 @@ class SimpleUnetLight(nn.Module):
         table = self._table(tensors)
         dx = torch.empty_like(d)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        def named(flat):
+            params = dict(self.named_parameters())
+            grads, off = {}, 0
+            for name in self.grad_names():
+                n = params[name].numel()
+                grads[name] = flat[off:off + n].reshape(params[name].shape)
+                off += n
+            return grads
         if saved.dtype == torch.int16:      # the half-width chain (precision "bf16h")
+            if want_param_grads:
+                work = torch.empty(int(lib.s2l_unet_train_frames_h_work_halves_grads(H, W, F_)), dtype=torch.int16, device=dev)
+                flat = torch.empty(int(lib.s2l_unet_grad_floats()), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _abi.check(lib.s2l_unet_train_backward_frames_h_grads(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), p(flat),
+                                                                          H, W, F_, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                               "s2l_unet_train_backward_frames_h_grads")
+                return dx, named(flat)
             work = torch.empty(int(lib.s2l_unet_train_frames_h_work_halves(H, W, F_)), dtype=torch.int16, device=dev)
             with torch.cuda.device(dev):
                 _abi.check(lib.s2l_unet_train_backward_frames_h(p(raw), p(raw16), table, p(saved), p(d), p(work), p(dx), H, W, F_,
@@ -368,13 +384,7 @@ class SimpleUnetLight(nn.Module):
                 _abi.check(lib.s2l_unet_train_backward_frames_grads(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), p(flat), H, W, F_,
                                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                            "s2l_unet_train_backward_frames_grads")
-            params = dict(self.named_parameters())
-            grads, off = {}, 0
-            for name in self.grad_names():
-                n = params[name].numel()
-                grads[name] = flat[off:off + n].reshape(params[name].shape)
-                off += n
-            return dx, grads
+            return dx, named(flat)
         with torch.cuda.device(dev):
             _abi.check(lib.s2l_unet_train_backward_frames(p(raw), p(raw16), table, p(x), p(saved), p(d), p(work), p(dx), H, W, F_,
                                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -485,6 +495,8 @@ class SimpleUnetLight(nn.Module):
         if getattr(self, "batch_train_frames", True):
             F_, H, W = x.shape[0], x.shape[1], x.shape[2]
             lib = _abi.load()
+            if precision == "bf16" and getattr(self, "half_width_tensors", True) and H <= 255 * 32 and W <= 255 * 16:
+                precision = "bf16h"      # (bf16 tensors between the kernels, weight gradients straight from the bf16 planes)
             per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
             group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
             outs, ctxs = [], []

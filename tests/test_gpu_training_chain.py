@@ -862,6 +862,7 @@ def test_training_unet_frames_in_one_call_equal_one_call_per_frame(dev, precisio
         return u
     ua, ub = net(), net()
     ua.batch_train_frames = False
+    ua.half_width_tensors = ub.half_width_tensors = False      # (the fp32-TENSOR routes; the half-width one: tests/test_gpu_unet_half.py)
     F, fh, fw = 4, 44, 60
     rng = np.random.default_rng(11)
     x = T(rng.random((F, fh, fw, 3), dtype=np.float32)).to(dev)

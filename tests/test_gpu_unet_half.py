@@ -242,3 +242,49 @@ def test_eval_mode_chain_against_the_fp32_tensor_chain(dev, fh, fw, F):
     u.half_width_tensors = False
     _, ctx = u.forward_for_backward(x, precision="bf16")
     assert ctx[0].dtype == torch.float32
+
+
+def test_training_net_on_half_width_tensors(dev):
+    """A net that still trains (before `it > 100000`) in bf16 precision: forward_for_backward takes the half-width frames route with
+    parameter gradients (s2l_unet_train_backward_frames_h_grads: BatchNorm gradients summed over the frames, 3x3 weight gradients on
+    bf16 MFMAs straight from the bf16 planes, first / output layer gradients fp32).  Against the fp32-tensor bf16 chain and the exact fp32
+    chain on the same input; F frames in one call == the per-frame gradients summed (to summation-order accuracy)."""
+    def fresh():
+        return net(dev)
+    F, fh, fw = 3, 64, 80
+    x = T(W.synthetic_image((F, fh, fw, 3), 5, "x")).to(dev)
+    d = T(np.random.default_rng(2).standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    res = {}
+    for name, prec, half in (("fp32", "fp32", True), ("bf16", "bf16", False), ("half", "bf16", True)):
+        u = fresh()
+        u.half_width_tensors = half
+        o, ctx = u.forward_for_backward(x, precision=prec)
+        g = {}
+        dx = u.backward_to_input(ctx, d, param_grads=g)
+        res[name] = (o, dx, g, ctx, u)
+    assert res["half"][3][0] == "train_frames_grads" and res["half"][3][1][0][2][2].dtype == torch.int16
+    assert res["bf16"][3][1][0][2][2].dtype == torch.float32
+    o32, dx32, g32 = res["fp32"][:3]
+    oh, dxh, gh = res["half"][:3]
+    o16, dx16, g16 = res["bf16"][:3]
+    assert rel(oh, o32) <= 3.5e-2 and cos(dxh, dx32) >= 0.95
+    assert set(gh) == set(g32) and len(gh) == 32
+    for k in g32:      # parameter gradients: those of the rounded forward, like the fp32-tensor bf16 chain's (its bound there: cos >= 0.97)
+        assert cos(gh[k], g32[k]) >= 0.95, (k, cos(gh[k], g32[k]), cos(g16[k], g32[k]))
+        assert bool(torch.isfinite(gh[k]).all())
+    # frames in one call == per-frame calls, gradients summed
+    ua, ub = fresh(), fresh()
+    ga, gb = {}, {}
+    oa, ca = ua.forward_for_backward(x, precision="bf16")
+    dxa = ua.backward_to_input(ca, d, param_grads=ga)
+    dxs = []
+    for f in range(F):
+        o1, c1 = ub.forward_for_backward(x[f:f + 1], precision="bf16")
+        assert torch.equal(o1, oa[f:f + 1])
+        dxs.append(ub.backward_to_input(c1, d[f:f + 1], param_grads=gb))
+    assert torch.equal(torch.cat(dxs, 0), dxa)
+    for k in ga:
+        err = float((ga[k] - gb[k]).abs().max()) / (float(gb[k].abs().max()) + 1e-30)
+        assert err <= 5e-5, (k, err)
+    for k, v in ua.state_dict().items():
+        assert torch.equal(v, ub.state_dict()[k]), k
