@@ -694,6 +694,38 @@ def test_stage_one_step_follows_the_unet_mode(golden, syncnet, dev):
         pytest.approx(float(e["n_unet"]), rel=5e-4)
 
 
+@pytest.mark.parametrize("half", [True, False])
+def test_stage_one_step_bf16_against_the_reference_step_in_train_mode_batchnorm(golden, syncnet, dev, half):
+    """The reference's loop step after it > 100000 (golden G16: the frozen U-Net in train-mode BatchNorm) in the precision BASELINE
+    config 5 names, on the half-width chain (bf16 tensors between the U-Net's kernels, the default) and on fp32 tensors: against the
+    REFERENCE's own loss and gradients at the bounds bf16 operands allow (test_stage_one_step_bf16_vs_fp32 holds the eval-mode step to
+    1e-2 / 0.995); the running statistics move to within bf16 rounding of the reference's."""
+    _, data, eps, sync, face = _g11_device(golden, dev)
+    g = golden("g16_stage1_trainbn.npz")
+    m = full_model(dev, 16, 24).train()
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    m.post_fusion_unet.half_width_tensors = half
+    step = s2l.StageOneStep(m, 16, 24, syncnet=syncnet, precision="bf16", face_loss=True)
+    a, idx, tgt = data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev)
+    loss, grads, aux = step.loss_and_grads(a, idx, tgt, [eps[0]], sync=sync, face=face)
+    # measured (tools/g16_bf16_report.py): loss 2.4e-3 / 2.2e-3 relative (half-width / fp32 tensors), sync loss 1.5e-3 / 5.8e-4,
+    # worst gradient cosine 0.99988 / 0.99989
+    assert abs(float(loss) - float(g["loss"])) <= 5e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    assert abs(float(aux["loss_sync"]) - float(g["loss_sync"])) <= 4e-3 * abs(float(g["loss_sync"]))
+    worst = 1.0
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            x, y = grads[key[2:]].double().flatten().cpu(), T(np.asarray(g[key])).double().flatten()
+            worst = min(worst, float((x @ y) / (x.norm() * y.norm() + 1e-30)))
+        if key.startswith("s_") and "running" in key:
+            sd = m.post_fusion_unet.state_dict()[key[2:]].cpu().double()
+            ref = T(np.asarray(g[key])).double()
+            assert float((sd - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-4, key
+    assert worst >= 0.9995, worst
+    assert int(m.post_fusion_unet.inc.double_conv[1].num_batches_tracked) == int(g["tracked"])
+
+
 @pytest.mark.parametrize("fh,fw,F", [(64, 80, 2), (500, 500, 1)])
 def test_unet_bf16_convolutions_vs_fp32(dev, fh, fw, F):
     """precision="bf16" of the frozen U-Net (training chain, BASELINE config 5's precision): bf16 weights and staged inputs on the
