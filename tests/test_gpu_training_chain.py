@@ -726,6 +726,32 @@ def test_stage_one_step_bf16_against_the_reference_step_in_train_mode_batchnorm(
     assert int(m.post_fusion_unet.inc.double_conv[1].num_batches_tracked) == int(g["tracked"])
 
 
+@pytest.mark.parametrize("half", [True, False])
+def test_stage_one_step_bf16_against_the_reference_step_before_100000(golden, dev, half):
+    """The reference's step while the post-fusion net still trains (golden G14) in bf16 precision: the training net's batched frames
+    route on half-width tensors (bf16 planes, bf16-operand weight gradients) and on fp32 tensors, against the REFERENCE's loss and
+    gradients -- MLP and U-Net parameters."""
+    _, data, eps, sync, face = _g11_device(golden, dev)
+    e = golden("g14_stage1_early.npz")
+    m = full_model(dev, 16, 24).train()
+    m.post_fusion_unet.half_width_tensors = half
+    step = s2l.StageOneStep(m, 16, 24, syncnet=None, precision="bf16", face_loss=True)
+    a, idx, tgt = data["audio"].to(dev), [data["index"]], data["rgb"].reshape(1, -1, 3).to(dev)
+    face14 = dict(face, rgb_face_gt=T(e["rgb_face_ori"]).to(dev))
+    loss, grads, _ = step.loss_and_grads(a, idx, tgt, [float(e["eps"][0])], face=face14)
+    assert abs(float(loss) - float(e["loss"])) <= 5e-3 * abs(float(e["loss"])), (float(loss), float(e["loss"]))
+    worst = {"mlp": 1.0, "unet": 1.0}
+    for key in e:
+        if key.startswith("g_"):
+            x, y = grads[key[2:]].double().flatten().cpu(), T(np.asarray(e[key])).double().flatten()
+            kind = "unet" if key[2:].startswith("post_fusion_unet") else "mlp"
+            worst[kind] = min(worst[kind], float((x @ y) / (x.norm() * y.norm() + 1e-30)))
+    # (the U-Net's own weight gradients see every operand rounding of its forward AND backward; measured 0.983 in both tensor widths)
+    assert worst["mlp"] >= 0.995 and worst["unet"] >= 0.97, worst
+    n_unet = sum(float(v.abs().double().sum()) for k, v in grads.items() if k.startswith("post_fusion_unet"))
+    assert n_unet == pytest.approx(float(e["n_unet"]), rel=2e-2)
+
+
 @pytest.mark.parametrize("fh,fw,F", [(64, 80, 2), (500, 500, 1)])
 def test_unet_bf16_convolutions_vs_fp32(dev, fh, fw, F):
     """precision="bf16" of the frozen U-Net (training chain, BASELINE config 5's precision): bf16 weights and staged inputs on the
