@@ -76,6 +76,23 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_unet_train_forward_bf16(one, odd, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -3
     assert lib.s2l_unet_train_forward(one, tbl, 1e-5, 0.1, 0, one, one, one, one, 3, 8, 1, null) == -2             # H < 4
     assert lib.s2l_set_unet_split_kernel(3) == -2 and lib.s2l_set_unet_split_kernel(0) == 0
+    # round-4 entries: the half-width chains (bf16 tensors between the kernels), their selector, one layer on its own
+    assert lib.s2l_unet_train_forward_frames_h(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -1        # the bf16 blob is required
+    assert lib.s2l_unet_train_forward_frames_h(one, one, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 9000, null) == -2      # frames x planes > 65535
+    assert lib.s2l_unet_train_forward_frames_h(one, odd, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -3
+    assert lib.s2l_unet_train_backward_frames_h(one, one, tbl, one, one, one, null, 8, 8, 1, null) == -1                     # the input gradient is the output
+    assert lib.s2l_unet_train_backward_frames_h_grads(one, one, tbl, one, one, one, one, one, null, 8, 8, 1, null) == -1     # ... here the parameter gradients
+    assert lib.s2l_unet_train_backward_frames_h_grads(one, one, tbl, null, one, one, one, one, one, 8, 8, 1, null) == -1     # x is needed for the first layer's dW
+    assert lib.s2l_unet_train_backward_frames_grads(one, null, tbl, one, one, one, one, one, null, 8, 8, 1, null) == -1
+    assert lib.s2l_unet_forward_saved_h(one, one, one, one, one, 8, 8, 8, 8, 2, 0, 1, null) == -4                            # window origin not a multiple of 4
+    assert lib.s2l_unet_forward_saved_h(one, null, one, one, one, 8, 8, 8, 8, 0, 0, 1, null) == -1
+    assert lib.s2l_unet_forward_saved_h(one, one, one, one, one, 8, 8, 8, 8, 0, 0, 0, null) == 0                             # no frames: nothing to do
+    assert lib.s2l_unet_backward_h(one, one, one, one, one, null, 8, 8, 8, 8, 0, 0, 1, null) == -1
+    assert lib.s2l_convh_layer(one, 0, 0, one, 64, null, 0, null, one, 8, 8, 1, null) == -2                                  # layer 0 is the fp32-input convolution
+    assert lib.s2l_convh_layer(one, 1, 0, one, 32, null, 0, null, one, 8, 8, 1, null) == -2                                  # channel count of the layer
+    assert lib.s2l_set_unet_half_kernel(2) == -2 and lib.s2l_set_unet_half_kernel(0) == 0
+    assert lib.s2l_unet_train_frames_h_saved_halves(8, 8, 0) == 0 and lib.s2l_unet_train_frames_h_saved_halves(500, 500, 1) > 2 * 10 ** 8
+    assert lib.s2l_unet_saved_h_halves(500, 500, 1) == lib.s2l_unet_saved_floats(500, 500, 1)
     # F one-frame calls in one set of launches (every frame its own statistics group)
     assert lib.s2l_unet_train_backward_frames(one, null, tbl, one, one, one, one, null, 8, 8, 2, null) == -1     # input gradient is the output
     assert lib.s2l_unet_train_forward_frames(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 0, null) == -2
