@@ -326,12 +326,14 @@ int s2l_unet_backward_window(const float* packed, const uint16_t* packed16, cons
  * config 5 names for the training step; NULL = exact fp32 everywhere.  (The 3->64 first layer, 0.5 % of the work, stays fp32.) */
 int64_t s2l_unet_packed16_halves(void);
 int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, uint16_t* packed16, s2l_stream_t stream);
-/* Split-bf16 ("bf16x3") operand form of the nine 3x3 layers for INFERENCE (SimpleUnetLight.py:16-111 as called at tf_nerf.py:387):
- * every fp32 operand is carried as hi = bf16(x), lo = bf16(x - hi) and a product is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi
- * on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- ~2^-16 relative operand error (plain bf16: 2^-8), three MFMAs at 16x the
- * fp32-MFMA rate.  The result stays inside the north-star tolerance (PSNR >= 50 dB / RMSE <= 1e-4 against the exact fp32 network) by
- * orders of magnitude; the exact fp32 kernels remain the default.  s2l_unet_pack16x3 writes s2l_unet_packed16x3_halves() uint16
- * (same tensor table and BatchNorm fold as s2l_unet_pack); s2l_unet_forward_split = s2l_unet_forward with those layers in this form. */
+/* Split operand form of the nine 3x3 layers for INFERENCE (SimpleUnetLight.py:16-111 as called at tf_nerf.py:387): every fp32 operand is
+ * carried as two 16-bit parts, hi and lo = x - hi, and a product is evaluated as a_lo b_hi + a_hi b_lo + a_hi b_hi on a 16-bit MFMA
+ * (three MFMAs at 16x the fp32-MFMA rate) with fp32 accumulation.  Since round 4 the parts are IEEE halves (hi = f16(x) toward zero,
+ * lo = f16(x - hi) to nearest; v_mfma_f32_32x32x16_f16): 11 + 11 significant bits, 112 dB / RMSE 2.5e-6 against the exact fp32 network
+ * (bf16 parts, rounds 2-3: 99 dB; plain bf16: 46 dB); operands beyond +-65504 saturate.  The result stays inside the north-star
+ * tolerance (PSNR >= 50 dB / RMSE <= 1e-4) by orders of magnitude; the exact fp32 kernels remain the default.  s2l_unet_pack16x3 writes
+ * s2l_unet_packed16x3_halves() uint16 (same tensor table and BatchNorm fold as s2l_unet_pack); s2l_unet_forward_split = s2l_unet_forward
+ * with those layers in this form. */
 int64_t s2l_unet_packed16x3_halves(void);
 int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps, uint16_t* packed16x3, s2l_stream_t stream);
 int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, const float* x, float* work, float* out, int height,

@@ -179,7 +179,7 @@ class Body:
             for mb in range(2):
                 for nb in range(4):
                     a, b = self.opa(os_, pa, mb), self.opb(os_, pb, nb)
-                    self.e(f"v_mfma_f32_32x32x16_bf16 {self.acc(mb, nb)}, a[{a}:{a + 3}], a[{b}:{b + 3}], {self.acc(mb, nb)}")
+                    self.e(f"v_mfma_f32_32x32x16_f16 {self.acc(mb, nb)}, a[{a}:{a + 3}], a[{b}:{b + 3}], {self.acc(mb, nb)}")
                     self.emit_group(sprinkle[m])
                     m += 1
 
@@ -316,12 +316,15 @@ class Body:
             if i % 2:
                 h, l, t = V_T + 8, V_T + 10, V_T + 12
             g1 = [f"v_and_b32 v{p + j}, v{p + j}, v{V_MSK + i}" for j in range(4)]
-            g2 = [f"v_cvt_pk_bf16_f32 v{h}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{h + 1}, v{p + 2}, v{p + 3}",
-                  f"v_lshlrev_b32 v{t}, 16, v{h}", f"v_and_b32 v{t + 1}, 0xffff0000, v{h}"]
-            g3 = [f"v_lshlrev_b32 v{t + 2}, 16, v{h + 1}", f"v_and_b32 v{t + 3}, 0xffff0000, v{h + 1}",
+            # parts as IEEE halves, round toward zero (csrc/unet.hip: pack_f16x2): hi = f16(x), lo = f16(x - hi)
+            g2 = [f"v_cvt_pkrtz_f16_f32 v{h}, v{p}, v{p + 1}", f"v_cvt_pkrtz_f16_f32 v{h + 1}, v{p + 2}, v{p + 3}",
+                  f"v_cvt_f32_f16 v{t}, v{h}", f"v_cvt_f32_f16_sdwa v{t + 1}, v{h} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"]
+            g3 = [f"v_cvt_f32_f16 v{t + 2}, v{h + 1}", f"v_cvt_f32_f16_sdwa v{t + 3}, v{h + 1} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1",
                   f"v_sub_f32 v{p}, v{p}, v{t}", f"v_sub_f32 v{p + 1}, v{p + 1}, v{t + 1}"]
             g4 = [f"v_sub_f32 v{p + 2}, v{p + 2}, v{t + 2}", f"v_sub_f32 v{p + 3}, v{p + 3}, v{t + 3}",
-                  f"v_cvt_pk_bf16_f32 v{l}, v{p}, v{p + 1}", f"v_cvt_pk_bf16_f32 v{l + 1}, v{p + 2}, v{p + 3}"]
+                  f"v_cvt_f16_f32 v{p}, v{p}", f"v_cvt_f16_f32 v{p + 1}, v{p + 1}"]      # the lo parts round to nearest (unbiased)
+            g4b = [f"v_cvt_f16_f32 v{p + 2}, v{p + 2}", f"v_cvt_f16_f32 v{p + 3}, v{p + 3}",
+                   f"v_pack_b32_f16 v{l}, v{p}, v{p + 1}", f"v_pack_b32_f16 v{l + 1}, v{p + 2}, v{p + 3}"]
             wr = []
             if i == NQ - 1:
                 wr += [f"s_mov_b64 exec, {s2('M9')}"]
@@ -329,7 +332,7 @@ class Body:
                    (f"ds_write_b64 v{V_WLO[buf] + i}, v[{l}:{l + 1}]", ("W", i, 1))]
             if i == NQ - 1:
                 wr += ["s_mov_b64 exec, -1"]
-            items += [g1, g2, g3, g4, wr] if not EXP & 8 else []
+            items += [g1, g2, g3, g4, g4b, wr] if not EXP & 8 else []
         return items
 
     def store_tile(self):
@@ -384,10 +387,10 @@ class Body:
             if t in (1, 2):
                 for k, g in enumerate(req[(t - 1) * 5:t * 5]):
                     sprinkle[12 + 2 * k].extend(g)
-            if t >= 6 and com:                           # the 50 commit groups behind taps 6..8: 17 + 17 + 16
-                start = [0, 17, 34][t - 6]
-                for k, g in enumerate(com[start:start + (17 if t < 8 else 16)]):
-                    sprinkle[6 + k].extend(g)
+            if t >= 6 and com:                           # the 60 commit groups behind taps 6..8: 20 each
+                start = [0, 20, 40][t - 6]
+                for k, g in enumerate(com[start:start + 20]):
+                    sprinkle[3 + k].extend(g)
             if t == 6:
                 e("s_waitcnt vmcnt(0)")                  # the staged values (requested four taps ago) and the weight pieces have landed
             self.wait_lds(("R", t, 3, 1))

@@ -123,6 +123,7 @@ __global__ void unet_pack_conv16(UnetTensors t, int layer, uint16_t* __restrict_
       to_bf16(t.w[layer][((int64_t)co * cin + ci) * 9 + (transposed ? 8 - tap : tap)] * scale);
 }
 
+typedef _Float16 h2v_ __attribute__((ext_vector_type(2)));
 // split form (forward only): one thread per packed element, hi and lo parts of the BatchNorm-folded fp32 weight
 __global__ void unet_pack_conv16x3(UnetTensors t, int layer, uint16_t* __restrict__ packed, float eps) {
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
@@ -136,8 +137,14 @@ __global__ void unet_pack_conv16x3(UnetTensors t, int layer, uint16_t* __restric
   const int co = ct * 64 + mb * 32 + (lane & 31), ci = cc * 16 + 8 * (lane >> 5) + j;
   const float scale = t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   const float w = t.w[layer][((int64_t)co * cin + ci) * 9 + tap] * scale;      // the fp32 kernel's folded weight, bit for bit
-  const uint16_t hi = to_bf16(w);
-  packed[unet_w16x3_off(layer) + e] = part == 0 ? hi : to_bf16(w - __uint_as_float((uint32_t)hi << 16));
+  // (parts as IEEE halves, round toward zero: the same v_cvt_pkrtz_f16_f32 the kernels apply to the activations)
+  const uint32_t hi2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(w, 0.f));
+  const float hif = (float)__builtin_bit_cast(h2v_, hi2)[0];
+  h2v_ lov;
+  lov[0] = (_Float16)(w - hif);      // (the lo part rounds to nearest: unbiased)
+  lov[1] = (_Float16)0.f;
+  const uint32_t lo2 = __builtin_bit_cast(uint32_t, lov);
+  packed[unet_w16x3_off(layer) + e] = (uint16_t)((part == 0 ? hi2 : lo2) & 0xffffu);
 }
 
 // ---- first conv: 3 -> 64 on MFMA (0.5 % of the FLOPs, but 64 MB of output per frame: write-bound) -----------------------
@@ -500,6 +507,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, v);
 }
+// The SPLIT form's parts are IEEE halves (round 4; bf16 parts before: same MFMA rate, 11 + 11 instead of 8 + 8 significant bits --
+// RMSE vs the exact fp32 kernels 1.1e-5 -> ~1e-6): hi = f16(x) and lo = f16(x - hi), both by v_cvt_pkrtz_f16_f32 (round toward zero:
+// x - hi is exact and has x's sign; out-of-range values saturate at 65504, never inf), in EVERY split kernel and in the weight pack.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+// the lo parts round to NEAREST: with both parts rounded toward zero every operand came out 2^-21 too small on average, a bias the ten
+// layers add up coherently (measured: 102 dB instead of the bf16 parts' 99; nearest: see bench_unet)
+__device__ __forceinline__ uint32_t pack_f16x2_rne(float lo, float hi) {
+  h2v v;
+  v[0] = (_Float16)lo;
+  v[1] = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float f16_lo(uint32_t p) { return (float)__builtin_bit_cast(h2v, p)[0]; }
+__device__ __forceinline__ float f16_hi(uint32_t p) { return (float)__builtin_bit_cast(h2v, p)[1]; }
+__device__ __forceinline__ f16v mfma32_f16(u4v a, u4v b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f16v mfma32_bf16(u4v a, u4v b, f16v c) {
 #if S2L_UEXP & 1
   c[0] += __uint_as_float(a[0] ^ b[0]);      // keeps the operand reads alive
@@ -617,15 +643,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
       const int i = threadIdx.x + k * kThreads;
       if (i < kInQuads) {
         uint2 h;
-        h.x = pack_bf16x2(pin[k][0], pin[k][1]);
-        h.y = pack_bf16x2(pin[k][2], pin[k][3]);
-        *reinterpret_cast<uint2*>(lds_in + (i / kQ) * kPix16 + 4 * (i % kQ)) = h;
-        if (SPLIT) {      // lo = bf16(x - hi): the second 16 "channels" of the pixel
+        if (SPLIT) {      // hi = f16(x), lo = f16(x - hi): the second 16 "channels" of the pixel
+          h.x = pack_f16x2(pin[k][0], pin[k][1]);
+          h.y = pack_f16x2(pin[k][2], pin[k][3]);
           uint2 l;
-          l.x = pack_bf16x2(pin[k][0] - __uint_as_float(h.x << 16), pin[k][1] - __uint_as_float(h.x & 0xffff0000u));
-          l.y = pack_bf16x2(pin[k][2] - __uint_as_float(h.y << 16), pin[k][3] - __uint_as_float(h.y & 0xffff0000u));
+          l.x = pack_f16x2_rne(pin[k][0] - f16_lo(h.x), pin[k][1] - f16_hi(h.x));
+          l.y = pack_f16x2_rne(pin[k][2] - f16_lo(h.y), pin[k][3] - f16_hi(h.y));
           *reinterpret_cast<uint2*>(lds_in + (i / kQ) * kPix16 + 16 + 4 * (i % kQ)) = l;
+        } else {
+          h.x = pack_bf16x2(pin[k][0], pin[k][1]);
+          h.y = pack_bf16x2(pin[k][2], pin[k][3]);
         }
+        *reinterpret_cast<uint2*>(lds_in + (i / kQ) * kPix16 + 4 * (i % kQ)) = h;
       }
     }
     if constexpr (kDma) {
@@ -685,15 +714,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void conv3x3_bf16_k
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][1][mb], B[cur][0][nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_f16(A[cur][1][mb], B[cur][0][nb], acc[mb][nb]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][0][mb], B[cur][1][nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_f16(A[cur][0][mb], B[cur][1][nb], acc[mb][nb]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_bf16(A[cur][0][mb], B[cur][0][nb], acc[mb][nb]);
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma32_f16(A[cur][0][mb], B[cur][0][nb], acc[mb][nb]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (kDma) {
           if (cc + 1 < nchunks) {
@@ -977,16 +1006,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       f4 v = pin[set][k];
       if (!((pvalid[set] >> k) & 1)) v = (f4){0.f, 0.f, 0.f, 0.f};
       uint2 h;
-      h.x = pack_bf16x2(v[0], v[1]);
-      h.y = pack_bf16x2(v[2], v[3]);
       char* dst = lds_in + buf * kSwzIn;
       if constexpr (SPLIT) {
+        h.x = pack_f16x2(v[0], v[1]);
+        h.y = pack_f16x2(v[2], v[3]);
         uint2 l;
-        l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
-        l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+        l.x = pack_f16x2_rne(v[0] - f16_lo(h.x), v[1] - f16_hi(h.x));
+        l.y = pack_f16x2_rne(v[2] - f16_lo(h.y), v[3] - f16_hi(h.y));
         *reinterpret_cast<uint2*>(dst + coff[k]) = h;
         *reinterpret_cast<uint2*>(dst + (coff[k] ^ 32)) = l;
       } else {
+        h.x = pack_bf16x2(v[0], v[1]);
+        h.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(dst + (coff[k] ^ (set * 32))) = h;
       }
     }
@@ -1092,7 +1123,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_kernel(ConvArgs a) {
       for (int m = 0; m < 12; ++m) {      // smallest terms first: lo x hi, hi x lo, hi x hi
         const int g = m >> 2, mb = (m >> 1) & 1, nb = m & 1;
         const int pa = g == 0 ? 1 : 0, pb = g == 1 ? 1 : 0;
-        acc[mb][nb] = mfma32_bf16(A[cur][pa][mb], B[cur][pb][nb], acc[mb][nb]);
+        acc[mb][nb] = mfma32_f16(A[cur][pa][mb], B[cur][pb][nb], acc[mb][nb]);
         if (m < 8 && t + 1 < 9) read_one(t + 1, cur ^ 1, m);
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -109,7 +109,7 @@ class SimpleUnetLight(nn.Module):
         return self._packed16
 
     def packed_weights_split(self) -> torch.Tensor:
-        """The nine 3x3 layers in split-bf16 (hi, lo) operand form, for forward_nhwc(precision="split")."""
+        """The nine 3x3 layers in split (hi, lo IEEE halves) operand form, for forward_nhwc(precision="split")."""
         lib = _abi.load()
         tensors = self._tensors()
         key = tuple((t.data_ptr(), t._version) for t in tensors)
@@ -130,7 +130,7 @@ class SimpleUnetLight(nn.Module):
     def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None, precision: str = "fp32") -> torch.Tensor:
         """x [F,H,W,3] -> [F,H,W,3] (the layout the composite produces and the caller wants).  precision:
           "fp32"  (default) exact fp32 MFMA: the parity mode, bit-reproducible against the C++ kernel;
-          "split" split-bf16: every operand of the 3x3 convolutions as hi + lo bf16 parts, three bf16 MFMAs per product, fp32
+          "split": every operand of the 3x3 convolutions as hi + lo IEEE-half parts, three 16-bit MFMAs per product, fp32
                   accumulation -- ~1e-6 of the output scale from the fp32 result (far inside the north-star's PSNR >= 50 dB /
                   RMSE <= 1e-4) at a multiple of the fp32 rate: the inference speed mode;
           "bf16"  plain bf16 operands (~5e-3 relative error: 45 dB, OUTSIDE the inference tolerance; it exists for the training

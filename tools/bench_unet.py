@@ -34,7 +34,7 @@ print(json.dumps({"kernel": "s2l_unet_forward (conv3x3_kernel + ...)", "frames":
                   "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4)}}))
 
 ref = out.clone()
-modes = [("split", "s2l_unet_forward_split, split-bf16 operands hi + lo (conv3x3_bf16_kernel<.., SPLIT>): the inference speed mode")]
+modes = [("split", "s2l_unet_forward_split, split operands hi + lo as IEEE halves (conv3x3_split_kernel): the inference speed mode")]
 if "--bf16" in sys.argv:      # plain bf16 operands: the training chain's precision (outside the inference tolerance)
     modes.append(("bf16", "s2l_unet_forward, bf16 operands (conv3x3_bf16_kernel)"))
 for prec, label in modes:

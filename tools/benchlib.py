@@ -234,7 +234,7 @@ def bench_config3(dev, n=5000, batch=500, unet=False, check=True, unet_precision
     dt = time.perf_counter() - t0
     fl = lip_flops_per_frame(h * w)
     res = {"config": f"config 3: {n} frames, 128x128 lip + composite into 500x500"
-           + (f" + post-fusion U-Net ({'exact fp32 MFMA' if unet_precision == 'fp32' else 'split-bf16 operands hi+lo, fp32 accumulation' if unet_precision == 'split' else unet_precision})" if unet else "")
+           + (f" + post-fusion U-Net ({'exact fp32 MFMA' if unet_precision == 'fp32' else 'split operands hi+lo (IEEE halves), fp32 accumulation' if unet_precision == 'split' else unet_precision})" if unet else "")
            + (", lip renderer in its split-half speed mode" if lip_precision == "split" else "")
            + f", batches of {batch}", "seconds": round(dt, 3), "frames_per_s": round(n / dt, 1),
            "lip_gflop_per_frame": round(fl / 1e9, 3), "lip_tflops": round(fl * n / dt / 1e12, 1)}
@@ -290,7 +290,7 @@ def bench_unet(dev, F=16, H=500, Wd=500):
     res["forward_split_bf16"] = {"ms_per_frame": round(ms / F, 4), "frames_per_s": round(F / ms * 1e3, 1),
                                  "speedup_vs_fp32": round(res["forward"]["ms_per_frame"] / (ms / F), 2),
                                  "psnr_db_vs_fp32": round(10 * np.log10(1.0 / max(mse, 1e-30)), 1), "rmse_vs_fp32": float(f"{np.sqrt(mse):.3e}"),
-                                 "operands": "hi + lo bf16 parts of every fp32 operand; a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation"}
+                                 "operands": "hi + lo IEEE-half parts of every fp32 operand (hi toward zero, lo to nearest); a_lo b_hi + a_hi b_lo + a_hi b_hi on v_mfma_f32_32x32x16_f16, fp32 accumulation"}
     return res
 
 
