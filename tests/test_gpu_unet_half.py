@@ -288,3 +288,11 @@ def test_training_net_on_half_width_tensors(dev):
         assert err <= 5e-5, (k, err)
     for k, v in ua.state_dict().items():
         assert torch.equal(v, ub.state_dict()[k]), k
+
+
+def test_odd_tiny_and_ragged_sizes(dev):
+    """4 x 4 to 501 x 499, odd sizes, one to five frames: the three half-width routes (frozen train mode, training with parameter
+    gradients, eval mode) against the exact fp32 chains -- finite, consistent with each other, inside the bf16 bounds."""
+    from tools import odd_sizes_half
+    notes = []
+    assert odd_sizes_half.screen(log=notes.append) == 0, notes
