@@ -16,7 +16,7 @@ if "--full" in sys.argv:      # every term of the reference's stage-1 iteration 
 sync = [a for a in sys.argv[1:] if a.startswith("--sync")]
 if sync:      # --sync=S: the step with the lipsync_expert loss attached to S of the B samples
     print(json.dumps(benchlib.bench_train_sync(torch.device("cuda:0"), B, int(sync[0].split("=")[1]) if "=" in sync[0] else 8, PREC,
-                                               unet_train_mode="--trainbn" in sys.argv)))
+                                               unet_train_mode="--trainbn" in sys.argv, half_width_tensors="--fp32-tensors" not in sys.argv)))
     sys.exit(0)
 res = benchlib.bench_train(torch.device("cuda:0"), B, PREC)
 step, one = res.pop("_step"), res.pop("_one")
