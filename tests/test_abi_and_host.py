@@ -425,6 +425,12 @@ def test_no_kernel_spills_to_scratch():
     assert len(counted) >= 4 + 3 + 1 + 1 + 4, counted
     for k in counted:
         assert table[k]["vgprs"] + table[k].get("agprs", 0) <= 512
+    # the 8-wave half-width conv kernels (csrc/convh.hip) are sized for two waves per SIMD: 512-thread workgroups only fit a CU's
+    # register file at <= 128 VGPR + 128 AGPR, and the launch would fail (not slow down) beyond that
+    half = [k for k in table if "convh8_asm_kernel" in k or "convh8_relu_asm_kernel" in k]
+    assert len(half) == 2, half
+    for k in half:
+        assert table[k]["occupancy"] >= 2 and table[k]["vgprs"] <= 128 and table[k].get("agprs", 0) <= 128, (k, table[k])
 
 
 def test_staging_registers_of_the_persistent_conv_kernel_are_never_copied(tmp_path):
