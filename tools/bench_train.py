@@ -1,7 +1,7 @@
 """BASELINE config 5 timing: one training step = 4-tap ensemble forward + MSE + full backward for a
 batch of frames at 96x96 (fp32 exact-parity mode).  FLOPs per step (as-written
 model, fwd + dgrad + wgrad, 4 taps): 3 * 4 * 2 * 644,864 * HW * frames.
-    python tools/bench_train.py [frames=64] [fp32|bf16] [--profile] [--sync=S [--trainbn]] [--full [--trainbn | --early]]
+    python tools/bench_train.py [frames=64] [fp32|bf16] [--profile] [--sync=S [--trainbn] [--group=frames per U-Net launch]] [--full [--trainbn | --early]]
 bf16 = the precision BASELINE config 5 names (bf16 MFMA operands and saved state, fp32 accumulation and master weights)."""
 import json, os, sys, time
 import torch
@@ -16,7 +16,8 @@ if "--full" in sys.argv:      # every term of the reference's stage-1 iteration 
 sync = [a for a in sys.argv[1:] if a.startswith("--sync")]
 if sync:      # --sync=S: the step with the lipsync_expert loss attached to S of the B samples
     print(json.dumps(benchlib.bench_train_sync(torch.device("cuda:0"), B, int(sync[0].split("=")[1]) if "=" in sync[0] else 8, PREC,
-                                               unet_train_mode="--trainbn" in sys.argv, half_width_tensors="--fp32-tensors" not in sys.argv)))
+                                               unet_train_mode="--trainbn" in sys.argv, half_width_tensors="--fp32-tensors" not in sys.argv,
+                                               frames_per_group=next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--group=")), None))))
     sys.exit(0)
 res = benchlib.bench_train(torch.device("cuda:0"), B, PREC)
 step, one = res.pop("_step"), res.pop("_one")
