@@ -9,10 +9,10 @@
 //     u_l = a_l / (sqrt(sum_c a_l^2) + 1e-10)        for both images
 //     d   = sum_l mean_pixels( sum_c w_l[c] (u_l(in0) - u_l(in1))^2 )          -> [N,1,1,1]       (dropout is inactive in eval)
 // and adds the gradient with respect to in0 (the net and the linear heads are frozen: requires_grad=False in the package).
-// Both images go through the trunk as ONE batch of 2N; the convolutions are the implicit-GEMM kernel of csrc/conv_gemm.h
-// (fp32 MFMA), except the 64 -> 3 input gradient of conv1, which is a small VALU kernel (a 64-row GEMM tile would be 95 %
-// padding).  ~20 GFLOP per 500x500 image pair forward + backward against 315 for the U-Net next to it: written for
-// exactness and determinism (no atomics), not for speed.
+// Both images go through the trunk as ONE batch of 2N; conv2..conv5 are the implicit-GEMM kernel of csrc/conv_gemm.h (fp32 MFMA);
+// conv1 (k11 s4 on 3 channels, the largest launch at 500x500) and its 64 -> 3 input gradient have their own fp32-MFMA kernels
+// below (round 4: 1.0 -> ~0.1 ms and 0.64 -> ~0.15 ms for 16 / 8 images).  ~20 GFLOP per 500x500 image pair forward + backward
+// against 315 for the U-Net next to it; exact fp32 products, deterministic (no atomics).
 // Parity: weights of the real package are not available here (they come from torchvision + the package's own alex.pth):
 // tests compare with the CPU restatement of the same published algorithm on seeded weights -- structural parity, as for SyncNet.
 #include "conv_gemm.h"
@@ -25,7 +25,7 @@ constexpr int kAlexLayers = 5;
 constexpr float kLpipsEps = 1e-10f;
 
 struct LpipsPacked {
-  int64_t w[kAlexLayers], b[kAlexLayers], wt[kAlexLayers], lin[kAlexLayers], w1raw, shift, scale, total;
+  int64_t w[kAlexLayers], b[kAlexLayers], wt[kAlexLayers], lin[kAlexLayers], w1raw, wd1, shift, scale, total;
 };
 inline LpipsPacked lpips_packed() {
   LpipsPacked p;
@@ -43,6 +43,9 @@ inline LpipsPacked lpips_packed() {
   }
   p.w1raw = o;
   o += 64 * 3 * 11 * 11;               // conv1.weight as it is, [co][ci][ky][kx]
+  o = (o + 3) / 4 * 4;
+  p.wd1 = o;
+  o += 4 * 12288;                      // conv1's input-gradient operand (lpips_conv1_dgrad_pack_kernel)
   p.shift = o;
   o += 4;
   p.scale = o;
@@ -230,35 +233,163 @@ __global__ __launch_bounds__(256) void lpips_mean_kernel(const float* __restrict
   if (threadIdx.x == 0) out[n] = (accumulate ? out[n] : 0.f) + part[0] / (float)npix;
 }
 
-// input gradient of conv1 (3 <- 64 channels, k11 s4 p2): thread per input pixel, all three channels
-__global__ __launch_bounds__(256) void lpips_conv1_dgrad_kernel(const float* __restrict__ g1, const float* __restrict__ w,
-                                                               float* __restrict__ dxs, int H, int W, int h1, int w1, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int x = (int)(i % W);
-  int64_t r = i / W;
-  const int y = (int)(r % H);
-  const int64_t b = r / H;
-  float acc[3] = {0.f, 0.f, 0.f};
-  // outputs with ky = y + 2 - 4 oy in [0, 11)
-  const int oy_hi = min(h1 - 1, (y + 2) / 4), ox_hi = min(w1 - 1, (x + 2) / 4);
-  for (int oy = max(0, (y + 2 - 10 + 3) / 4); oy <= oy_hi; ++oy) {
-    const int ky = y + 2 - 4 * oy;
-    if (ky < 0 || ky > 10) continue;
-    for (int ox = max(0, (x + 2 - 10 + 3) / 4); ox <= ox_hi; ++ox) {
-      const int kx = x + 2 - 4 * ox;
-      if (kx < 0 || kx > 10) continue;
-      const float* g = g1 + ((b * h1 + oy) * (int64_t)w1 + ox) * 64;
-      for (int co = 0; co < 64; ++co) {
-        const float gv = g[co];
+// ---- conv1 (3 -> 64, k11 s4 p2) and its input gradient as their own fp32-MFMA kernels ------------------------------------------------
+// The generic implicit-GEMM kernel gathers conv1's K = 363 operand element by element (3 channels per pixel, stride 4): 11 TFLOP/s, the
+// largest launch of the perceptual term at 500 x 500 (1.0 ms of 2.4 for 16 images).  Here a workgroup stages the input patch of a 16 x 16
+// output tile in LDS once (71 rows x 72 pixels x 3), wave w keeps the weights of output channels 16 w .. 16 w + 15 in REGISTERS for
+// the whole launch (the A operand of v_mfma_f32_16x16x4_f32: a kernel row = 33 contiguous floats of the patch, padded to 36 so that a
+// k-step never straddles two rows -- the three pad weights are zeros and their B values the next pixel's, finite), and every MFMA needs
+// one 4-byte LDS read: lane (n, q) reads patch[(4 oy + ky) * pitch + 12 ox_n + j0 + q].  K order (ky, kx, c), one accumulator per
+// output element, k ascending.
+constexpr int kC1T = 16;                            // output tile edge
+constexpr int kC1Rows = (kC1T - 1) * 4 + 11;        // 71 patch rows
+constexpr int kC1Pitch = (kC1Rows + 1) * 3;         // 72 pixels x 3 floats per row
+constexpr int kC1Steps = 11 * 9;                    // k-steps: 11 kernel rows x 36 / 4
+
+__global__ __launch_bounds__(256, 2) void lpips_conv1_kernel(const float* __restrict__ xs, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W, int h1,
+                                                            int w1, int tiles_x, int tiles_y, int n_tiles) {
+  __shared__ float patch[kC1Rows * kC1Pitch];       // 61 344 B: two workgroups per CU
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+  float a[kC1Steps];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) acc[ci] = fmaf(gv, w[((co * 3 + ci) * 11 + ky) * 11 + kx], acc[ci]);
+  for (int s = 0; s < kC1Steps; ++s) {
+    const int ky = s / 9, j = 4 * (s % 9) + q;      // position in the padded kernel row: kx * 3 + c
+    a[s] = j < 33 ? w[((16 * wave + l16) * 3 + j % 3) * 121 + ky * 11 + j / 3] : 0.f;
+  }
+  const f4 bv = *reinterpret_cast<const f4*>(bias + 16 * wave + 4 * q);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    const int64_t img = tile / (tiles_x * tiles_y);
+    const int y0 = ty * kC1T * 4 - 2, c0 = (tx * kC1T * 4 - 2) * 3;      // patch origin: row, float column
+    __syncthreads();                                 // (the previous tile's reads)
+    for (int idx = threadIdx.x; idx < kC1Rows * kC1Pitch; idx += 256) {
+      const int r = idx / kC1Pitch, cc = idx % kC1Pitch;
+      const int gy = y0 + r, gc = c0 + cc;
+      patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gc < (unsigned)(3 * W)) ? xs[(img * H + gy) * (int64_t)W * 3 + gc] : 0.f;
+    }
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {                    // four output rows at a time
+      const float* pb = patch + g * 16 * kC1Pitch + 12 * l16 + q;
+      f4 acc[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rr] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < kC1Steps; ++s) {
+        const int off = (s / 9) * kC1Pitch + 4 * (s % 9);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = mfma16(a[s], pb[rr * 4 * kC1Pitch + off], acc[rr]);
+      }
+      const int ox = tx * kC1T + l16;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int oy = ty * kC1T + 4 * g + rr;
+        if (oy < h1 && ox < w1) {
+          f4 v = acc[rr] + bv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          *reinterpret_cast<f4*>(out + ((img * h1 + oy) * (int64_t)w1 + ox) * 64 + 16 * wave + 4 * q) = v;
+        }
       }
     }
   }
-  dxs[i * 3 + 0] = acc[0];
-  dxs[i * 3 + 1] = acc[1];
-  dxs[i * 3 + 2] = acc[2];
+}
+
+// The input gradient of conv1 as a GEMM per 4 x 4 block of input pixels (stride 4: a block's 48 values (ry, rx, c) depend on the 4 x 4
+// neighbourhood of output pixels (by + 1 - r, bx + 1 - cc), r, cc = 0..3, through taps ky = 4 r + ry - 2, kx = 4 cc + rx - 2 where
+// those are kernel positions, zero otherwise: 47 % of the 48 x 1024 operand is non-zero, the price of one dense shape):
+//     d_in[4 by + ry][4 bx + rx][c] = sum_{r, cc, co} Wd[(ry, rx, c)][(r, cc, co)] g[by + 1 - r][bx + 1 - cc][co].
+// A workgroup owns 8 x 16 blocks (32 x 64 input pixels): the gradient patch (11 x 19 output pixels x 64 channels, pixel stride 66
+// floats: the sixteen pixels x two k of a half-wave read land on 32 distinct banks) stays in LDS, Wd streams through two 48-KiB LDS
+// buffers in four passes (one per r, descending: r' = 3 - r, so that patch offsets grow), wave w computes block rows 2 w, 2 w + 1
+// for all 48 rows: six accumulator tiles, five LDS reads per six MFMAs.  The VALU kernel this replaces ran at 9 TFLOP/s.
+constexpr int kD1TH = 8, kD1TW = 16, kD1Rows = kD1TH + 3, kD1Cols = kD1TW + 3, kD1Pix = 66;
+constexpr int kD1B = 13824, kD1A = 12288;                       // floats: patch (11 x 19 x 66 = 13 794, rounded), one pass of Wd
+constexpr int kD1Lds = (kD1B + 2 * kD1A) * 4;                   // 153 600 B
+
+// wd[r'][k-step s][q][48]: Wd[m][k = 4 s + q of pass r'] with k = cc' * 64 + co, r = 3 - r', cc = 3 - cc'
+__global__ __launch_bounds__(256) void lpips_conv1_dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ wd) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 4 * kD1A) return;
+  const int rp = e / kD1A, rem = e % kD1A, k = rem / 48, m = rem % 48;
+  const int r = 3 - rp, cc = 3 - k / 64, co = k % 64;
+  const int ry = m / 12, rx = (m / 3) % 4, c = m % 3;
+  const int ky = 4 * r + ry - 2, kx = 4 * cc + rx - 2;
+  wd[e] = ((unsigned)ky < 11u && (unsigned)kx < 11u) ? w[((co * 3 + c) * 11 + ky) * 11 + kx] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void lpips_conv1_dgrad_mfma_kernel(const float* __restrict__ g1, const float* __restrict__ wd,
+                                                                    float* __restrict__ dxs, int H, int W, int h1, int w1, int tiles_x,
+                                                                    int tiles_y, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float d1_smem[];
+  float* Bt = d1_smem;
+  float* As = d1_smem + kD1B;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y;
+    const int64_t img = tile / (tiles_x * tiles_y);
+    const int by0 = ty * kD1TH, bx0 = tx * kD1TW;
+    __syncthreads();                                   // (the previous tile's reads)
+    for (int idx = threadIdx.x; idx < kD1Rows * kD1Cols * 32; idx += 256) {
+      const int pos = idx >> 5, h2 = idx & 31;
+      const int oy = by0 - 2 + pos / kD1Cols, ox = bx0 - 2 + pos % kD1Cols;
+      float2 v = make_float2(0.f, 0.f);
+      if ((unsigned)oy < (unsigned)h1 && (unsigned)ox < (unsigned)w1)
+        v = *reinterpret_cast<const float2*>(g1 + ((img * h1 + oy) * (int64_t)w1 + ox) * 64 + 2 * h2);
+      *reinterpret_cast<float2*>(Bt + pos * kD1Pix + 2 * h2) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      *reinterpret_cast<f4*>(As + 4 * (threadIdx.x + 256 * i)) = *reinterpret_cast<const f4*>(wd + 4 * (threadIdx.x + 256 * i));
+    __syncthreads();
+    f4 acc[2][3];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb) acc[jn][mb] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int rp = 0; rp < 4; ++rp) {
+      f4 nxt[12];
+      if (rp < 3) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) nxt[i] = *reinterpret_cast<const f4*>(wd + (rp + 1) * kD1A + 4 * (threadIdx.x + 256 * i));
+      }
+      const float* ab = As + (rp & 1) * kD1A + q * 48 + l16;
+      const float* bb = Bt + ((2 * wave + rp) * kD1Cols + l16) * kD1Pix + q;
+#pragma unroll
+      for (int s_ = 0; s_ < 64; ++s_) {
+        const int boff = (s_ / 16) * kD1Pix + 4 * (s_ % 16);
+        const float b0 = bb[boff], b1 = bb[kD1Cols * kD1Pix + boff];
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) {
+          const float av = ab[s_ * 192 + 16 * mb];
+          acc[0][mb] = mfma16(av, b0, acc[0][mb]);
+          acc[1][mb] = mfma16(av, b1, acc[1][mb]);
+        }
+      }
+      if (rp < 3) {
+        float* an = As + ((rp + 1) & 1) * kD1A;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) *reinterpret_cast<f4*>(an + 4 * (threadIdx.x + 256 * i)) = nxt[i];
+      }
+      __syncthreads();
+    }
+    // D[m = 16 mb + 4 q + r][block column l16]
+    const int bx = bx0 + l16;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+      const int by = by0 + 2 * wave + jn;
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb) {
+        const int m0 = 16 * mb + 4 * q, y = 4 * by + m0 / 12;
+        if (y >= H) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = (m0 + r) % 12, x = 4 * bx + mm / 3;
+          if (x < W) dxs[((img * H + y) * (int64_t)W + x) * 3 + mm % 3] = acc[jn][mb][r];
+        }
+      }
+    }
+  }
 }
 
 __global__ void lpips_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
@@ -312,6 +443,7 @@ extern "C" int s2l_lpips_pack(const float* const* tensors_host, float* packed, s
   }
   hipLaunchKernelGGL(lpips_copy_kernel, dim3((64 * 363 + 255) / 256), dim3(256), 0, st, tensors_host[0], packed + pl.w1raw,
                      (int64_t)64 * 363);
+  hipLaunchKernelGGL(lpips_conv1_dgrad_pack_kernel, dim3(4 * kD1A / 256), dim3(256), 0, st, tensors_host[0], packed + pl.wd1);
   hipLaunchKernelGGL(lpips_copy_kernel, dim3(1), dim3(64), 0, st, tensors_host[15], packed + pl.shift, (int64_t)3);
   hipLaunchKernelGGL(lpips_copy_kernel, dim3(1), dim3(64), 0, st, tensors_host[16], packed + pl.scale, (int64_t)3);
   return (int)hipGetLastError();
@@ -339,7 +471,14 @@ extern "C" int s2l_lpips_forward(const float* packed, const float* in0, const fl
     a.bias = packed + pl.b[l];
     a.out = work + wl.act[l];
     a.partial = work + wl.partial;
-    if ((rc = launch_conv<false>(a, 2 * N, st))) return rc;
+    if (l == 0) {
+      const int tiles_x = (wl.a[0].w + kC1T - 1) / kC1T, tiles_y = (wl.a[0].h + kC1T - 1) / kC1T;
+      const int64_t n_tiles = 2 * N * tiles_x * tiles_y;
+      hipLaunchKernelGGL(lpips_conv1_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 512)), dim3(256), 0, st, cur, packed + pl.w1raw,
+                         packed + pl.b[0], work + wl.act[0], height, width, wl.a[0].h, wl.a[0].w, tiles_x, tiles_y, (int)n_tiles);
+    } else if ((rc = launch_conv<false>(a, 2 * N, st))) {
+      return rc;
+    }
     sh = wl.a[l];
     cur = work + wl.act[l];
     const int64_t npix = (int64_t)sh.h * sh.w;
@@ -407,8 +546,16 @@ extern "C" int s2l_lpips_backward(const float* packed, float* work, const float*
   }
   const int64_t npx = N * height * width;
   float* dxs = bufs[g == bufs[0] ? 1 : 0];
-  hipLaunchKernelGGL(lpips_conv1_dgrad_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, g, packed + pl.w1raw, dxs, height,
-                     width, wl.a[0].h, wl.a[0].w, npx);
+  {
+    int dev = 0, n_cu = 0;
+    if ((rc = current_device_cus(&dev, &n_cu))) return rc;
+    static LdsOptIn flags;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(lpips_conv1_dgrad_mfma_kernel), kD1Lds, flags, dev))) return rc;
+    const int tiles_x = ((width + 3) / 4 + kD1TW - 1) / kD1TW, tiles_y = ((height + 3) / 4 + kD1TH - 1) / kD1TH;
+    const int64_t n_tiles = N * tiles_x * tiles_y;
+    hipLaunchKernelGGL(lpips_conv1_dgrad_mfma_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, n_cu)), dim3(256), kD1Lds, st, g,
+                       packed + pl.wd1, dxs, height, width, wl.a[0].h, wl.a[0].w, tiles_x, tiles_y, (int)n_tiles);
+  }
   hipLaunchKernelGGL(lpips_unscale_grad_kernel, dim3((unsigned)((npx * 3 + 255) / 256)), dim3(256), 0, st, dxs, packed + pl.scale, d_in0,
                      npx * 3, from01 ? 2.f : 1.f, accumulate);
   return (int)hipGetLastError();

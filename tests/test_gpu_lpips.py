@@ -46,10 +46,11 @@ def relerr(a, b):
     return float((a.detach().cpu().double() - b.double()).abs().max()) / (float(b.abs().max()) + 1e-30)
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 96, 96), (3, 64, 83), (2, 31, 31), (1, 500, 500)])
+@pytest.mark.parametrize("n,h,w", [(1, 96, 96), (3, 64, 83), (2, 31, 31), (1, 500, 500), (2, 131, 277)])
 def test_lpips_forward_and_gradient_vs_oracle(lp, sd, dev, n, h, w):
     """distance [N] and d distance / d in0 against fp64 autograd through the oracle: the lip size (96x96, training.py:420-421),
-    a ragged batch, the smallest image AlexNet's poolings admit, and the fused face (500x500, :453-456)."""
+    a ragged batch, the smallest image AlexNet's poolings admit, the fused face (500x500, :453-456), and a size whose conv1 tiles
+    (16 x 16 outputs; 8 x 16 blocks of 4 x 4 input pixels in the gradient) are ragged on both axes."""
     a, b = images(n, h, w, 5 + h)
     x0 = (a.double() * 2 - 1).permute(0, 3, 1, 2).requires_grad_(True)
     x1 = (b.double() * 2 - 1).permute(0, 3, 1, 2)
