@@ -1616,6 +1616,19 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
   const float sy = 2 * win.hf > 1 ? (float)(win.hf - 1) / (float)(2 * win.hf - 1) : 0.f;
   const float sx = 2 * win.wf > 1 ? (float)(win.wf - 1) / (float)(2 * win.wf - 1) : 0.f;
   f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+  // (the column weights of the eight candidate columns once: they do not depend on the row; same taps, same order, same bits)
+  float wxs[8];
+  int xos[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int xu = 2 * xif - 3 + k;
+    const float fx = sx * (float)xu;
+    const int x0 = (int)fx, x1 = x0 + (x0 < win.wf - 1 ? 1 : 0);
+    const float lx = fx - (float)x0;
+    const float wx = (x0 == xif ? 1.f - lx : 0.f) + (x1 == xif ? lx : 0.f);
+    xos[k] = xu + padL - win.oxo;
+    wxs[k] = (xu >= 0 && xu <= 2 * win.wf - 1 && (unsigned)xos[k] < (unsigned)Wo) ? wx : 0.f;
+  }
   for (int yu = max(2 * yif - 3, 0); yu <= min(2 * yif + 4, 2 * win.hf - 1); ++yu) {
     const float fy = sy * (float)yu;
     const int y0 = (int)fy, y1 = y0 + (y0 < win.hf - 1 ? 1 : 0);
@@ -1623,15 +1636,11 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
     const float wy = (y0 == yif ? 1.f - ly : 0.f) + (y1 == yif ? ly : 0.f);
     const int yo = yu + padT - win.oyo;                       // row of the (cropped) gradient tensor
     if (wy == 0.f || (unsigned)yo >= (unsigned)Ho) continue;
-    for (int xu = max(2 * xif - 3, 0); xu <= min(2 * xif + 4, 2 * win.wf - 1); ++xu) {
-      const float fx = sx * (float)xu;
-      const int x0 = (int)fx, x1 = x0 + (x0 < win.wf - 1 ? 1 : 0);
-      const float lx = fx - (float)x0;
-      const float wx = (x0 == xif ? 1.f - lx : 0.f) + (x1 == xif ? lx : 0.f);
-      const int xo = xu + padL - win.oxo;
-      if (wx == 0.f || (unsigned)xo >= (unsigned)Wo) continue;
-      const f4 v = *reinterpret_cast<const f4*>(g + ((f * Ho + yo) * (int64_t)Wo + xo) * ldg + coff + c4 * 4);
-      const float ww = wy * wx;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (wxs[k] == 0.f) continue;
+      const f4 v = *reinterpret_cast<const f4*>(g + ((f * Ho + yo) * (int64_t)Wo + xos[k]) * ldg + coff + c4 * 4);
+      const float ww = wy * wxs[k];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = fmaf(ww, v[r], acc[r]);
     }
