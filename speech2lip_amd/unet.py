@@ -529,8 +529,8 @@ class SimpleUnetLight(nn.Module):
                     continue
                 dx, grads = self.backward_train_frames(c, d_out[s0:s1], want_param_grads=True)
                 dxs.append(dx)
-                for k, v in grads.items():
-                    param_grads[k] = v.clone() if k not in param_grads else param_grads[k] + v
+                for k, v in grads.items():      # (views of this call's own flat gradient buffer: no copy needed to keep them)
+                    param_grads[k] = v if k not in param_grads else param_grads[k] + v
             return dxs[0] if len(dxs) == 1 else torch.cat(dxs, 0)
         if not (isinstance(ctx, tuple) and len(ctx) == 2 and ctx[0] == "train"):
             return self.backward_input(ctx, d_out)
