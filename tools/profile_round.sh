@@ -51,7 +51,7 @@ for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_tr
             "small_clips:tools/bench_small_clips.py" "config3_split:tools/bench_config3.py 1000 100 --split" \
             "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
-            "stage1_full:tools/bench_train.py 8 bf16 --full" "stage1_sync_trainbn:tools/bench_train.py 64 bf16 --sync=8 --trainbn"; do
+            "stage1_full:tools/bench_train.py 8 bf16 --full" "stage1_early:tools/bench_train.py 8 bf16 --full --early" "stage1_sync_trainbn:tools/bench_train.py 64 bf16 --sync=8 --trainbn"; do
   name=${spec%%:*}; cmd=${spec#*:}
   timeout 300 python $R/$cmd > $O/${name}_line.txt 2> $O/${name}.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_$name -o s -- python $R/$cmd > $O/x_$name.log 2>&1

@@ -84,6 +84,7 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
                     ("config3_nounet", "BASELINE config 3: lip 128x128 + composite, 5000 frames: python tools/bench_config3.py 5000 500"),
                     ("stage1_sync", "BASELINE config 5 with the sync loss: python tools/bench_train.py 64 bf16 --sync=8"),
                     ("stage1_full", "full stage-1 iteration (MSE + LPIPS on lip and face, U-Net, sync window): python tools/bench_train.py 8 bf16 --full"),
+                    ("stage1_early", "early-phase iteration (it <= 100000: the U-Net trains with the MLP, no sync loss): python tools/bench_train.py 8 bf16 --full --early"),
                     ("stage1_sync_trainbn", "config 5 with the sync loss, frozen U-Net in TRAIN-mode BatchNorm (the reference's loop, G16): python tools/bench_train.py 64 bf16 --sync=8 --trainbn")):
     rows = stats("x_" + name)
     if not rows:
