@@ -442,6 +442,12 @@ int s2l_debug_conv_layer_f32(const float* packed_raw, const uint16_t* packed16_r
                              const float* inB, int CB, const float* gate, float* out, int height, int width, int64_t n_frames,
                              s2l_stream_t stream);
 
+/* The 3x3 weight gradient of the half-width training chain on its own (a test aid; the reference's is autograd's conv2d weight gradient
+ * inside SimpleUnetLight.py:16-111's layers): dz [F][cout/32][H][W][32] bf16 planes, inputs inA (CA channels) and optionally inB (CB) as
+ * planes -- CA, CB, cout multiples of 64 --, dw [cout][CA + CB][9] fp32 (tap = 3 ky + kx), partial: 64*256*128*9 floats of scratch. */
+int s2l_debug_conv_wgrad_h(const uint16_t* dz, const uint16_t* inA, int CA, const uint16_t* inB, int CB, int cout, float* partial, float* dw,
+                           int height, int width, int64_t n_frames, s2l_stream_t stream);
+
 /* Measurement aid (tools/ubench_mfma.py): `waves` (4 or 8) waves per CU each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 on
  * registers and nothing else -- the rate the chip sustains under that load (the clock drops below its 2.4 GHz peak). */
 int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream);

@@ -296,3 +296,33 @@ def test_odd_tiny_and_ragged_sizes(dev):
     from tools import odd_sizes_half
     notes = []
     assert odd_sizes_half.screen(log=notes.append) == 0, notes
+
+
+@pytest.mark.parametrize("F,H,Wd,CA,CB,cout", [(1, 5, 7, 64, 0, 64), (2, 37, 53, 64, 0, 128), (1, 3, 130, 128, 128, 128), (3, 19, 64, 64, 64, 64),
+                                               (1, 70, 65, 128, 0, 64), (2, 1, 200, 64, 0, 64)])
+def test_weight_gradient_kernel_alone_vs_fp64_correlation(dev, F, H, Wd, CA, CB, cout):
+    """conv_wgrad_h_kernel (LDS transpose reads, a ring of three input rows down a 64-pixel column, split K) on its own: dW[co][ci][t] of
+    bf16 planes against the fp64 correlation of the SAME bf16 values -- ragged widths (one partial chunk, several chunks), heights of one
+    to many rows (column changes inside a workgroup's range), several frames, concatenated inputs.  Only the fp32 summation order differs:
+    1e-5 of the tensor's largest value.  (The reference's counterpart is autograd's conv2d weight gradient, SimpleUnetLight.py:16-45.)"""
+    lib = _abi.load()
+    g = torch.Generator(device="cpu").manual_seed(H * 131 + Wd)
+    dz = torch.randn(F, H, Wd, cout, generator=g).to(torch.bfloat16)
+    a = torch.randn(F, H, Wd, CA, generator=g).to(torch.bfloat16)
+    b = torch.randn(F, H, Wd, CB, generator=g).to(torch.bfloat16) if CB else None
+    x = torch.cat([a, b], -1) if CB else a
+    want = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (cout, CA + CB, 3, 3), dz.permute(0, 3, 1, 2).double(), padding=1)
+    dzp, ap, bp = nhwc_to_c32(dz.to(dev)), nhwc_to_c32(a.to(dev)), (nhwc_to_c32(b.to(dev)) if CB else None)
+    part = torch.empty(64 * 256 * 128 * 9, dtype=torch.float32, device=dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, CA + CB, 9), float("nan"), device=dev)
+        _abi.check(lib.s2l_debug_conv_wgrad_h(p(dzp), p(ap), CA, p(bp), CB, cout, p(part), p(dw), H, Wd, F,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_debug_conv_wgrad_h")
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].cpu().double().reshape(cout, CA + CB, 3, 3)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), float((got - want).abs().max()) / float(want.abs().max())
+    # argument errors
+    assert lib.s2l_debug_conv_wgrad_h(p(dzp), p(ap), 32, None, 0, cout, p(part), p(outs[0]), H, Wd, F, None) == -2
+    assert lib.s2l_debug_conv_wgrad_h(None, p(ap), CA, None, 0, cout, p(part), p(outs[0]), H, Wd, F, None) == -1
