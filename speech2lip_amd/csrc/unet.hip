@@ -1979,7 +1979,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 // channels, 16 input channels, all 9 taps), wave w owns output channels 16 w .. 16 w + 15 (9 accumulators of 4 registers).
 // K runs over chunks of 64 consecutive pixels of one image row; a chunk stages dz [64 px][64 co] and the 3 x 66-pixel halo of
 // the input [3][66][16 ci] in LDS.  The chunks are dealt round-robin to gridDim.z workgroups (split K); their partial results
-// are summed in a fixed order by wgrad_reduce_wide_kernel.
+// are summed in a fixed order by wgrad_reduce_lanes_kernel.
 struct WgradArgs {
   const float* dz;     // [F,H,W,cout]
   const float* inA;    // [F,H,W,CA]
@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // registers on the way into LDS: a thread fetches 8 (dz) or 10 (input, with the two neighbours the tap shifts need) consecutive pixels
 // of one channel quad, converts, and writes 16-byte pixel octets: dzT [co 64][px 64], aT [dy 3][dx 3][ci 32][px 64] -- one copy of the
 // input rows PER dx, so that every tap's operand is an aligned ds_read_b128 (a one-pixel shift of a packed octet would not be).
-// K chunks, split K and the partial layout as conv_wgrad_kernel (wgrad_reduce_wide_kernel sums them).  16 x the matrix rate of the
+// K chunks, split K and the partial layout as conv_wgrad_kernel (wgrad_reduce_lanes_kernel sums them).  16 x the matrix rate of the
 // fp32 form: the kernel is bound by reading dz (cin / 32 times) and the input (cout / 64 times).
 constexpr int kWgPitch = 72;      // halves per LDS row: 64 pixels + 8 of padding (144 bytes: rows stay 16-byte aligned)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
@@ -2176,18 +2176,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradArgs a) {
         p[((int64_t)(ct * 64 + 16 * wave + 4 * kg + r) * cin + cc * 32 + 16 * cb + i16) * 9 + t] = acc[t][cb][r];
 }
 // sum of the split-K partials in a fixed order: 64 elements per workgroup, four threads per element take every fourth partial
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
-                                                               int64_t n) {
-  __shared__ float red[4][64];
+// PL lanes of a block share an element: lane pl sums partials pl, pl + PL, ... in that order, the PL sums are added in lane order (fixed
+// orders: deterministic).  PL = 4 (256 threads) for the 3x3 layers, PL = 16 (1024 threads) for the small tensors of the first and the
+// output layer, whose ~1000 .. 2000 partials made the four-lane form a 125-us serial loop.
+template <int PL>
+__global__ __launch_bounds__(64 * PL) void wgrad_reduce_lanes_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
+                                                                    int64_t n) {
+  __shared__ float red[PL][64];
   const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + el;
   float s = 0.f;
   if (e < n)
-    for (int b = pl; b < n_parts; b += 4) s += partial[(int64_t)b * n + e];
+    for (int b = pl; b < n_parts; b += PL) s += partial[(int64_t)b * n + e];
   red[pl][el] = s;
   __syncthreads();
-  if (pl == 0 && e < n) out[e] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  if (pl == 0 && e < n) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < PL; ++k) t += red[k][el];
+    out[e] = t;
+  }
 }
+
 // first convolution (3 input channels): partial[blk][co][c*9 + t] = sum over the block's pixels of dz[p][co] x[neighbour t of p][c], on
 // v_mfma_f32_16x16x4_f32 (exact fp32 fma chains): K = pixels, four per instruction; A = dz^T (lane (co within its 16-block, pixel q)),
 // B = the pixel's 27 inputs padded to 32 (lane (k within its 16-block, pixel q): one gathered value), 4 x 2 accumulators per wave.
@@ -2774,7 +2784,7 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
       const int64_t perw = (p1 + 1023) / 1024;
       const int nbw = (int)((p1 + perw - 1) / perw);
       hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(nbw), dim3(256), 0, st, gy, x, wpart, H, W, p1, perw);
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(27), dim3(256), 0, st, wpart, g, nbw, (int64_t)64 * 27);
+      hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<16>, dim3(27), dim3(1024), 0, st, wpart, g, nbw, (int64_t)64 * 27);
     } else {
       WgradArgs a;
       a.dz = gy; a.inA = inA[l]; a.inB = inB[l]; a.CA = cA[l]; a.CB = cB[l]; a.cout = C;
@@ -2793,7 +2803,7 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
       if (w16) hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(C / 64, cin / 32, S), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(C / 64, cin / 16, S), dim3(256), 0, st, a);
       const int64_t ne = (int64_t)C * cin * 9;
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, st, wpart, g, S, ne);
+      hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3((unsigned)((ne + 63) / 64)), dim3(256), 0, st, wpart, g, S, ne);
     }
   };
 
@@ -2802,7 +2812,7 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
     const int64_t perw = (p1 + 2047) / 2048;
     const int nbw = (int)((p1 + perw - 1) / perw);
     hipLaunchKernelGGL(outc_wgrad_kernel, dim3(nbw), dim3(256), 0, st, d_out, b.act[9], wpart, p1, perw);
-    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(4), dim3(256), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<16>, dim3(4), dim3(1024), 0, st, wpart, grads + grad_off(10), nbw, (int64_t)195);
   }
   hipLaunchKernelGGL(outc_bwd_kernel, blocks(p1 * 16), dim3(256), 0, st, d_out, t.outw, b.act[9], zA, p1 * 16);
   layer_grads(9, zA);
