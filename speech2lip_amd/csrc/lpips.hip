@@ -263,10 +263,22 @@ __global__ __launch_bounds__(256, 2) void lpips_conv1_kernel(const float* __rest
     const int64_t img = tile / (tiles_x * tiles_y);
     const int y0 = ty * kC1T * 4 - 2, c0 = (tx * kC1T * 4 - 2) * 3;      // patch origin: row, float column
     __syncthreads();                                 // (the previous tile's reads)
-    for (int idx = threadIdx.x; idx < kC1Rows * kC1Pitch; idx += 256) {
-      const int r = idx / kC1Pitch, cc = idx % kC1Pitch;
-      const int gy = y0 + r, gc = c0 + cc;
-      patch[idx] = ((unsigned)gy < (unsigned)H && (unsigned)gc < (unsigned)(3 * W)) ? xs[(img * H + gy) * (int64_t)W * 3 + gc] : 0.f;
+    for (int base = 0; base < kC1Rows * kC1Pitch; base += 256 * 12) {      // (twelve loads in flight per thread, then their stores)
+      float tv[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int idx = base + threadIdx.x + 256 * k;
+        const int r = idx / kC1Pitch, cc = idx % kC1Pitch;
+        const int gy = y0 + r, gc = c0 + cc;
+        const bool in = idx < kC1Rows * kC1Pitch && (unsigned)gy < (unsigned)H && (unsigned)gc < (unsigned)(3 * W);
+        const float v = xs[in ? (img * H + gy) * (int64_t)W * 3 + gc : 0];
+        tv[k] = in ? v : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int idx = base + threadIdx.x + 256 * k;
+        if (idx < kC1Rows * kC1Pitch) patch[idx] = tv[k];
+      }
     }
     __syncthreads();
     for (int g = 0; g < 4; ++g) {                    // four output rows at a time
@@ -330,13 +342,22 @@ __global__ __launch_bounds__(256) void lpips_conv1_dgrad_mfma_kernel(const float
     const int64_t img = tile / (tiles_x * tiles_y);
     const int by0 = ty * kD1TH, bx0 = tx * kD1TW;
     __syncthreads();                                   // (the previous tile's reads)
-    for (int idx = threadIdx.x; idx < kD1Rows * kD1Cols * 32; idx += 256) {
-      const int pos = idx >> 5, h2 = idx & 31;
-      const int oy = by0 - 2 + pos / kD1Cols, ox = bx0 - 2 + pos % kD1Cols;
-      float2 v = make_float2(0.f, 0.f);
-      if ((unsigned)oy < (unsigned)h1 && (unsigned)ox < (unsigned)w1)
-        v = *reinterpret_cast<const float2*>(g1 + ((img * h1 + oy) * (int64_t)w1 + ox) * 64 + 2 * h2);
-      *reinterpret_cast<float2*>(Bt + pos * kD1Pix + 2 * h2) = v;
+    for (int base = 0; base < kD1Rows * kD1Cols * 32; base += 256 * 9) {      // (nine loads in flight per thread, then their stores)
+      float2 tv[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int idx = base + threadIdx.x + 256 * k;
+        const int pos = idx >> 5, h2 = idx & 31;
+        const int oy = by0 - 2 + pos / kD1Cols, ox = bx0 - 2 + pos % kD1Cols;
+        const bool in = idx < kD1Rows * kD1Cols * 32 && (unsigned)oy < (unsigned)h1 && (unsigned)ox < (unsigned)w1;
+        const float2 v = *reinterpret_cast<const float2*>(g1 + (in ? ((img * h1 + oy) * (int64_t)w1 + ox) * 64 + 2 * h2 : 0));
+        tv[k] = in ? v : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int idx = base + threadIdx.x + 256 * k;
+        if (idx < kD1Rows * kD1Cols * 32) *reinterpret_cast<float2*>(Bt + (idx >> 5) * kD1Pix + 2 * (idx & 31)) = tv[k];
+      }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i)
