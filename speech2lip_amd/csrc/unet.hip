@@ -164,10 +164,22 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
   const float* xf = x + frame * (int64_t)H * W * 3;
   float* yf = y + frame * (int64_t)H * W * 64;
-  for (int i = threadIdx.x; i < 18 * 66 * 3; i += 256) {
-    const int r = i / 198, rem = i - r * 198, cx = rem / 3;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + cx;
-    tile[i] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? xf[((int64_t)gy * W + gx) * 3 + (rem - cx * 3)] : 0.f;
+  {      // (the thread's 14 tile values are fetched together, then stored: one conditional load after the other is latency-bound)
+    float tv[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int r = i / 198, rem = i - r * 198, cx = rem / 3;
+      const int gy = y0 - 1 + r, gx = x0 - 1 + cx;
+      const bool in = i < 18 * 66 * 3 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const float v = xf[in ? ((int64_t)gy * W + gx) * 3 + (rem - cx * 3) : 0];
+      tv[k] = in ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < 18 * 66 * 3) tile[i] = tv[k];
+    }
   }
   // A operands: lane holds W[co = 16 mb + px][k = 4j + q]
   float wa[4][7];
