@@ -608,6 +608,10 @@ int s2l_out_grad_bf16(const float* drgb, const uint16_t* h7T, float* work, float
  * RGB->BGR swap only undoes cv2's BGR file convention).  rgb needs 4-byte alignment only (a frame slice of a clip starts at
  * any multiple of H*W*3 floats), out none. */
 int s2l_to8b(const float* rgb, uint8_t* out, int64_t n, s2l_stream_t stream);
+/* The reader's conversion of decoded 8-bit images (someones_lip_dataset.py:196-217: array / 255. in float64, then float32):
+ * out[i] = (float)((double)in[i] / 255.0), bit for bit what the host conversion yields, so that frames can cross PCIe as bytes.
+ * in: 4-byte aligned, out: 16-byte aligned. */
+int s2l_from8b(const uint8_t* in, float* out, int64_t n, s2l_stream_t stream);
 
 #ifdef __cplusplus
 }

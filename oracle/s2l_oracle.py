@@ -35,12 +35,12 @@ def to_sd(np_sd, dtype=torch.float32) -> SD:
 
 
 # --------------------------------------------------------------------------- A1
-def get_coords(width: int, height: int, dtype=torch.float32) -> torch.Tensor:
+def get_coords(width: int, height: int, dtype=torch.float32, device=None) -> torch.Tensor:
     """Row-major (u,v) pixel grid in [0,1], endpoints inclusive -> [H*W, 2].
     Reference: src/face_simple/rendering.py:9-28 (linspace x, linspace y, meshgrid ij,
     stack [u, v])."""
-    x = torch.linspace(0.0, 1.0, width, dtype=dtype)
-    y = torch.linspace(0.0, 1.0, height, dtype=dtype)
+    x = torch.linspace(0.0, 1.0, width, dtype=dtype, device=device)
+    y = torch.linspace(0.0, 1.0, height, dtype=dtype, device=device)
     u = x.unsqueeze(0).expand(height, width)
     v = y.unsqueeze(1).expand(height, width)
     return torch.stack([u, v], dim=-1).reshape(-1, 2).contiguous()
@@ -60,18 +60,18 @@ def embed_uv(uv: torch.Tensor, multires: int = 10) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- A3
-def time_div_term(out_dims: int = 20) -> torch.Tensor:
+def time_div_term(out_dims: int = 20, device=None) -> torch.Tensor:
     """fp32 constant of PositionalEncodingTime.__init__ (tf_nerf.py:431-432)."""
-    return torch.exp(torch.arange(0, out_dims, 2, dtype=torch.float32) * -(math.log(10000.0) / out_dims))
+    return torch.exp(torch.arange(0, out_dims, 2, dtype=torch.float32, device=device) * -(math.log(10000.0) / out_dims))
 
 
-def time_pe(index: int, out_dims: int = 20, dtype=torch.float32) -> torch.Tensor:
+def time_pe(index: int, out_dims: int = 20, dtype=torch.float32, device=None) -> torch.Tensor:
     """1-D [out_dims] encoding of ONE frame index: pe[0::2]=sin(i*div), pe[1::2]=cos(i*div).
     Reference: tf_nerf.py:434-442 (uses position[0] only, returns a vector that fc_time
     broadcasts over all pixels)."""
-    div = time_div_term(out_dims).to(dtype)
-    pos = torch.tensor(float(int(index)), dtype=torch.float32).to(dtype)
-    pe = torch.zeros(out_dims, dtype=dtype)
+    div = time_div_term(out_dims, device).to(dtype)
+    pos = torch.tensor(float(int(index)), dtype=torch.float32, device=device).to(dtype)
+    pe = torch.zeros(out_dims, dtype=dtype, device=device)
     pe[0::2] = torch.sin(pos * div)
     pe[1::2] = torch.cos(pos * div)
     return pe
@@ -100,7 +100,7 @@ def rgb_forward(sd: SD, uv_audio: torch.Tensor, time_index: int) -> torch.Tensor
     dt = uv_audio.dtype
     e = embed_uv(uv_audio[:, :2])
     a = uv_audio[:, 2:]
-    t = time_pe(time_index, 20, dt)
+    t = time_pe(time_index, 20, dt, uv_audio.device)
     lin = lambda n, x: F.linear(x, sd[n + ".weight"], sd[n + ".bias"])
     h = lin("fc_uv", e) + lin("fc_audio", a) + lin("fc_time", t)
     for i in range(8):
@@ -118,7 +118,7 @@ def render_frame_as_shipped(sd: SD, window: torch.Tensor, index: int, height: in
     window [16,29] -> [H,W,3]."""
     hw = height * width
     audio = window.unsqueeze(0).expand(hw, 16, 29).contiguous()
-    coords = get_coords(width, height, window.dtype)
+    coords = get_coords(width, height, window.dtype, window.device)
     feat = audio_encode(sd, audio)
     out = rgb_forward(sd, torch.cat([coords, feat], dim=-1), index)
     return out[:, :3].reshape(height, width, 3)
@@ -128,7 +128,7 @@ def render_clip(sd: SD, windows: torch.Tensor, indices, height: int, width: int)
     """Batched/factored CPU variant (encoder once per frame).  Same function of the inputs
     as `render_frame_as_shipped`; used as the fair CPU baseline and the large-case oracle.
     windows [F,16,29] -> [F,H,W,3]."""
-    coords = get_coords(width, height, windows.dtype)
+    coords = get_coords(width, height, windows.dtype, windows.device)
     feats = audio_encode(sd, windows)
     frames = []
     for f in range(windows.shape[0]):

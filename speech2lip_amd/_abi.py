@@ -180,6 +180,7 @@ EXPORTS = {
     "s2l_rows_to_tiles_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "s2l_out_grad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_to8b": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_from8b": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -101,9 +101,9 @@ def rgb_forward(model, rows, time_pts):
 
 class _PredictLipImage(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, audio, index, height, width, u01, *params):
+    def forward(ctx, model, audio, index, height, width, u01, precision, *params):
         from .training import LipTrainStep
-        step = LipTrainStep(model, height, width, "fp32")
+        step = LipTrainStep(model, height, width, precision)
         pred = step.forward(audio, [index], [u01])
         ctx.step = step
         return pred[0]
@@ -112,19 +112,20 @@ class _PredictLipImage(torch.autograd.Function):
     def backward(ctx, dpred):
         g, _ = ctx.step.backward(dpred.contiguous().float()[None])
         ctx.step = None
-        return (None, None, None, None, None, None, *[g[n] for n in _abi.TENSOR_ORDER])
+        return (None, None, None, None, None, None, None, *[g[n] for n in _abi.TENSOR_ORDER])
 
 
-def predict_lip_image(model, coords, audio, index, height, width, u01):
-    """The regular-grid 4-tap ensemble of one frame with a graph (fp32 parity mode).  `coords` must be the regular pixel grid
-    of (height, width) -- what Trainer.prepare_coords returns -- because the fused kernels rebuild it."""
+def predict_lip_image(model, coords, audio, index, height, width, u01, precision="fp32"):
+    """The regular-grid 4-tap ensemble of one frame with a graph (fp32 parity mode by default; precision="bf16": the bf16 MFMA
+    kernels of BASELINE config 5).  `coords` must be the regular pixel grid of (height, width) -- what Trainer.prepare_coords
+    returns -- because the fused kernels rebuild it."""
     from .rendering import get_coords
     if coords.shape[0] != height * width or not torch.equal(coords.to(torch.float32).cpu(), get_coords(width, height, "cpu")):
         raise ValueError("predict_lip_image with autograd supports the regular pixel grid of (height, width) only")
     if audio.shape[0] != 1:
         raise ValueError("predict_lip_image renders one frame: audio must be [1,16,29]")
     idx = int(index.reshape(-1)[0].item()) if isinstance(index, torch.Tensor) else int(index)
-    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), float(u01), *model._hot_tensors())
+    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), float(u01), precision, *model._hot_tensors())
 
 
 class _Composite(torch.autograd.Function):
@@ -148,8 +149,8 @@ def composite(model, lip, face, gt, mask, x0, y0, coord, holes=None):
 
 class _UnetEval(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, unet, x):
-        out, saved = unet.forward_saved_nhwc(x)
+    def forward(ctx, unet, x, precision):
+        out, saved = unet.forward_for_backward(x, precision=precision) if precision != "fp32" else unet.forward_saved_nhwc(x)
         ctx.unet, ctx.saved = unet, saved
         return out
 
@@ -157,36 +158,47 @@ class _UnetEval(torch.autograd.Function):
     def backward(ctx, d_out):
         dx = ctx.unet.backward_input(ctx.saved, d_out)
         ctx.saved = None
-        return None, dx
+        return None, dx, None
 
 
-def unet_eval(unet, x_nhwc):
+def unet_eval(unet, x_nhwc, precision="fp32"):
     """Frozen eval-mode post-fusion U-Net with an input gradient (no parameter gradients: the reference has set
-    requires_grad=False on them by the time this path is used, train.py:188-197)."""
-    return _UnetEval.apply(unet, x_nhwc)
+    requires_grad=False on them by the time this path is used, train.py:188-197).  precision "bf16": bf16 operands and
+    tensors between the kernels (the half-width chain)."""
+    return _UnetEval.apply(unet, x_nhwc, precision)
 
 
 class _UnetTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, unet, x, *params):
-        out, saved = unet.forward_train_nhwc(x, update_running=True)
-        ctx.unet, ctx.saved, ctx.need_dx = unet, saved, x.requires_grad
+    def forward(ctx, unet, x, precision, *params):
         ctx.need_params = any(p_.requires_grad for p_ in params)
+        ctx.unet, ctx.need_dx, ctx.route = unet, x.requires_grad, precision != "fp32"
+        if ctx.route:      # bf16: the mode-following frames route (half-width tensors; the bits of one call per frame)
+            out, ctx.saved = unet.forward_for_backward(x, precision=precision)
+            return out
+        out, saved = unet.forward_train_nhwc(x, update_running=True)
+        ctx.saved = saved
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         # a frozen net in train-mode BatchNorm (the reference's loop after it > 100000) needs no weight-gradient kernels
-        dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx, want_param_grads=ctx.need_params)
+        if ctx.route:
+            grads = {} if ctx.need_params else None
+            dx = ctx.unet.backward_to_input(ctx.saved, d_out, grads)
+            grads = grads or {}
+        else:
+            dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx, want_param_grads=ctx.need_params)
         ctx.saved = None
-        return (None, dx, *[grads.get(n) if ctx.need_params else None for n in ctx.unet.grad_names()])
+        return (None, dx, None, *[grads.get(n) if ctx.need_params else None for n in ctx.unet.grad_names()])
 
 
-def unet_train(unet, x_nhwc):
+def unet_train(unet, x_nhwc, precision="fp32"):
     """Post-fusion U-Net in TRAIN mode (BatchNorm batch statistics, running statistics updated) with gradients for its input
-    and every parameter -- the network as the reference trains it until `it > 100000` (train.py:188-197)."""
+    and every parameter -- the network as the reference trains it until `it > 100000` (train.py:188-197).  precision "bf16":
+    bf16 operands and tensors between the kernels (the half-width chain of csrc/unet_half.inc)."""
     params = dict(unet.named_parameters())
-    return _UnetTrain.apply(unet, x_nhwc, *[params[n] for n in unet.grad_names()])
+    return _UnetTrain.apply(unet, x_nhwc, precision, *[params[n] for n in unet.grad_names()])
 
 
 class _CropResize(torch.autograd.Function):

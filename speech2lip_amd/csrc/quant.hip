@@ -31,7 +31,33 @@ __global__ __launch_bounds__(256) void to8b_kernel(const float* __restrict__ x, 
   }
 }
 
+// The reader's conversion the other way (someones_lip_dataset.py:196-217 get_color: imageio array / 255. in float64, then
+// torch.Tensor(...) -> float32): out = (float)((double)u8 / 255.0), the same two roundings.  Lets decoded frames cross PCIe as
+// bytes (a quarter of the traffic) and land as the floats the reference's reader would have produced, bit for bit.
+__global__ __launch_bounds__(256) void from8b_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(in + i);
+    f4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (float)((double)((w >> (8 * k)) & 255u) / 255.0);
+    *reinterpret_cast<f4*>(out + i) = v;
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = (float)((double)in[j] / 255.0);
+  }
+}
+
 }  // namespace s2l
+
+extern "C" int s2l_from8b(const uint8_t* in, float* out, int64_t n, s2l_stream_t stream) {
+  if (n < 0) return S2L_E_SIZE;
+  if (n == 0) return S2L_OK;
+  if (!in || !out) return S2L_E_NULL;
+  if ((reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return S2L_E_ALIGN;
+  const unsigned blocks = (unsigned)((n + 1023) / 1024);
+  hipLaunchKernelGGL(s2l::from8b_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, n);
+  return (int)hipGetLastError();
+}
 
 extern "C" int s2l_to8b(const float* rgb, uint8_t* out, int64_t n, s2l_stream_t stream) {
   if (n < 0) return S2L_E_SIZE;

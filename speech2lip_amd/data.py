@@ -370,6 +370,209 @@ def to8b(frames: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def from8b(u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 device tensor -> float32, exactly the reader's `(array / 255.0).astype(float32)` (s2l_from8b): decoded frames cross
+    PCIe as bytes and become on the device the floats `_read_rgb` yields on the host, bit for bit."""
+    import ctypes
+    from . import _abi
+    if u8.device.type != "cuda" or u8.dtype != torch.uint8:
+        raise _abi.S2LError("from8b: a uint8 tensor on the GPU is required (no CPU fallback)")
+    x = u8.contiguous()
+    o = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _abi.check(_abi.load().s2l_from8b(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(o.data_ptr()), x.numel(),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_from8b")
+    return o
+
+
+class ClipStreamer:
+    """`SomeonesLipClip.load` as a pipeline (the clip-level counterpart of the reference's DataLoader, inference.py:129-140):
+    batches of `batch` frames are read by a pool of host threads (JPEG decode and `np.load` release the GIL) straight into
+    PINNED staging buffers -- observed frames as the decoded bytes, a quarter of the fp32 size -- and copied to the device on a
+    SIDE stream while the previous batch renders; `depth` batches are in flight.  Iterating yields `ClipTensors` whose tensors
+    are the same values `load` returns (frames converted on the device by s2l_from8b, bit for bit the host conversion); a
+    yielded batch stays valid until the iteration after the next one starts."""
+
+    def __init__(self, ds: "SomeonesLipClip", device, batch: int = 100, first: int = 0, count: Optional[int] = None,
+                 workers: Optional[int] = None, depth: int = 2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ds, self.dev, self.batch = ds, torch.device(device), int(batch)
+        n = len(ds)
+        self.first = int(first)
+        self.count = n - self.first if count is None else min(int(count), n - self.first)
+        self.depth = max(1, int(depth))
+        self.workers = int(workers) if workers else min(32, os.cpu_count() or 1)
+        self.pool = ThreadPoolExecutor(self.workers)
+        self.with_pose = ds.coord_files is not None and ds.mode != "test"
+        self.with_frames = ds.mode != "test"
+        ns, B, FH, FW = self.depth + 1, self.batch, ds.face_h, ds.face_w
+        pin = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype).pin_memory() for _ in range(ns)]
+        on = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype, device=self.dev) for _ in range(ns)]
+        self.h_coord = pin(B, FH, FW, 2, dtype=torch.float32) if self.with_pose else None
+        self.d_coord = on(B, FH, FW, 2, dtype=torch.float32) if self.with_pose else None
+        self.h_ori = pin(B, FH, FW, 3, dtype=torch.uint8) if self.with_frames else None
+        self.d_ori8 = on(B, FH, FW, 3, dtype=torch.uint8) if self.with_frames else None
+        self.d_ori = on(B, FH, FW, 3, dtype=torch.float32) if self.with_frames else None
+        self.side = torch.cuda.Stream(self.dev)
+        self.audio = torch.from_numpy(np.ascontiguousarray(ds.aud_features[self.first:self.first + self.count].astype(np.float32))).to(self.dev)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.face_zero, self.mask = up(ds.rgb_face_zero[None]), up(ds.mask_lip_canonical[None])
+
+    def _decode(self, slot: int, j: int, i: int) -> None:
+        ds = self.ds
+        if self.with_pose:
+            self.h_coord[slot][j].numpy()[...] = np.load(os.path.join(ds.dataset_folder, "coords", ds.coord_files[i]))
+        if self.with_frames:
+            from PIL import Image
+            with Image.open(os.path.join(ds.dataset_folder, "ori_images_face", ds.image_files[i])) as im:
+                self.h_ori[slot][j].numpy()[...] = np.asarray(im.convert("RGB"))
+
+    def __len__(self):
+        return -(-self.count // self.batch)
+
+    def __iter__(self):
+        from collections import deque
+        starts = list(range(self.first, self.first + self.count, self.batch))
+        ns = self.depth + 1
+        h2d_done, consumed = [None] * ns, [None] * ns
+        pending = deque()
+
+        def submit(k):
+            slot = k % ns
+            if h2d_done[slot] is not None:
+                h2d_done[slot].synchronize()          # the staging buffers of this slot have left for the device
+            s0 = starts[k]
+            cnt = min(self.batch, self.first + self.count - s0)
+            pending.append((k, slot, s0, cnt, [self.pool.submit(self._decode, slot, j, s0 + j) for j in range(cnt)]))
+        for k in range(min(self.depth, len(starts))):
+            submit(k)
+        nxt = len(pending)
+        while pending:
+            k, slot, s0, cnt, futs = pending.popleft()
+            for f in futs:
+                f.result()
+            cur = torch.cuda.current_stream(self.dev)
+            with torch.cuda.stream(self.side):
+                if consumed[slot] is not None:
+                    self.side.wait_event(consumed[slot])      # the previous user of this device slot has finished with it
+                if self.with_pose:
+                    self.d_coord[slot][:cnt].copy_(self.h_coord[slot][:cnt], non_blocking=True)
+                if self.with_frames:
+                    self.d_ori8[slot][:cnt].copy_(self.h_ori[slot][:cnt], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            h2d_done[slot] = ev
+            cur.wait_event(ev)
+            if nxt < len(starts):
+                submit(nxt)
+                nxt += 1
+            ori = from8b(self.d_ori8[slot][:cnt], out=self.d_ori[slot][:cnt]) if self.with_frames else None
+            off = s0 - self.first
+            idx = torch.arange(s0, s0 + cnt, dtype=torch.int64, device=self.dev)
+            yield ClipTensors(audio=self.audio[off:off + cnt], index=idx, coord=self.d_coord[slot][:cnt] if self.with_pose else None,
+                              rgb_face_ori=ori, rgb_face_zero=self.face_zero, mask_lip_canonical=self.mask,
+                              lip_lefttop_x=self.ds.lefttop_x, lip_lefttop_y=self.ds.lefttop_y, height=self.ds.lip_h, width=self.ds.lip_w,
+                              names=["{:05d}".format(i + 1) for i in range(s0, s0 + cnt)])
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.dev))
+            consumed[slot] = done
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+class FramePrefetcher:
+    """The reference's `DataLoader(num_workers > 0)` (train.py:136-140) for `load_one_frame`: the dictionaries of the frame
+    indices in `order` are prepared by a pool of host threads up to `depth` frames ahead (JPEG decode, `np.load` and the
+    8-bit resize release the GIL) and come out in order, collated (`collate_batch`) `per_step` at a time."""
+
+    def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
+        self.pool = ThreadPoolExecutor(int(workers) if workers else min(16, os.cpu_count() or 1))
+
+    def __iter__(self):
+        from collections import deque
+        q, it = deque(), iter(self.order)
+        for i in it:
+            q.append(self.pool.submit(self.ds.load_one_frame, i))
+            if len(q) >= self.depth:
+                break
+        group = []
+        while q:
+            group.append(q.popleft().result())
+            for i in it:
+                q.append(self.pool.submit(self.ds.load_one_frame, i))
+                break
+            if len(group) == self.per_step or not q:
+                yield collate_batch(group) if self.collate else group
+                group = []
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+class FrameWriter:
+    """`write_frames` as a pipeline: the 8-bit frames leave the device into a pinned buffer on a side stream, and a pool of host
+    threads encodes and writes the files (PIL's encoder releases the GIL) while the GPU renders the next batch.
+    `submit(frames, names)`; `close()` waits for every file."""
+
+    def __init__(self, out_dir: str, workers: Optional[int] = None, ext: str = ".jpg", depth: int = 3):
+        from concurrent.futures import ThreadPoolExecutor
+        os.makedirs(out_dir, exist_ok=True)
+        self.out_dir, self.ext = out_dir, ext
+        self.pool = ThreadPoolExecutor(int(workers) if workers else min(32, os.cpu_count() or 1))
+        self.slots, self.depth, self.k, self.side = [], max(1, int(depth)), 0, None
+        self.futs = []
+
+    def _save(self, arr, name):
+        from PIL import Image
+        Image.fromarray(arr, "RGB").save(os.path.join(self.out_dir, name + self.ext), quality=95)
+
+    def _drain(self, pinned, ev, names):
+        ev.synchronize()
+        a = pinned.numpy()
+        return [self.pool.submit(self._save, a[j], n) for j, n in enumerate(names)]
+
+    def submit(self, frames: torch.Tensor, names) -> None:
+        u8 = frames if frames.dtype == torch.uint8 else to8b(frames)
+        if u8.device.type != "cuda":
+            self.futs.append(self.pool.submit(lambda: [self._save(a, n) for a, n in zip(u8.numpy(), names)]))
+            return
+        if self.side is None:
+            self.side = torch.cuda.Stream(u8.device)
+        slot = self.k % self.depth
+        self.k += 1
+        if len(self.slots) <= slot:
+            self.slots.append([None, None])
+        buf, busy = self.slots[slot]
+        if busy is not None:
+            for f in busy.result():          # the files of the batch that used this staging buffer are written
+                f.result()
+        if buf is None or buf.shape[0] < u8.shape[0] or buf.shape[1:] != u8.shape[1:]:
+            buf = torch.empty(u8.shape, dtype=torch.uint8).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(u8.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            view = buf[:u8.shape[0]]
+            view.copy_(u8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        u8.record_stream(self.side)
+        job = self.pool.submit(self._drain, view, ev, list(names))
+        self.slots[slot] = [buf, job]
+        self.futs.append(job)
+
+    def close(self) -> None:
+        for f in self.futs:
+            r = f.result()
+            for g in (r if isinstance(r, list) else []):
+                if hasattr(g, "result"):
+                    g.result()
+        self.pool.shutdown(wait=True)
+
+
 def write_frames(frames: torch.Tensor, names, out_dir: str, ext: str = ".jpg") -> None:
     """rgb*255 -> 8-bit image files named %05d (inference.py:172-178; the reference converts to BGR only
     because cv2.imwrite expects it: the files hold the same RGB picture).  cv2.imwrite rounds and saturates."""

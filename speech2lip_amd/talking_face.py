@@ -312,22 +312,32 @@ class TalkingFace(nn.Module):
                                            lip_lefttop_y, coord, want_canonical=True, hole_noise=holes)
         if unet is None:
             return None, new, can
+        prec = getattr(self, "train_precision", "fp32")      # "bf16": set by Trainer(precision="bf16"); training calls only
         if unet.training:
             if torch.is_grad_enabled():
                 from .autograd import unet_train
-                return unet_train(unet, new), new, can
+                return unet_train(unet, new, prec), new, can
             return unet.forward_train_nhwc(new, update_running=True)[0], new, can
         if graph:
             from .autograd import unet_eval
-            return unet_eval(unet, new), new, can
+            return unet_eval(unet, new, prec), new, can
         return unet.forward_nhwc(new), new, can
 
-    @staticmethod
-    def draw_hole_noise(rgb_gt):
-        """The two N(0,1) fields of `add_black_hole` (tf_nerf.py:306-318), drawn the way the reference draws them --
-        `torch.randn(input_img.shape)` on the default (CPU) generator, channel 0 kept, moved to the device -- so that a
-        seeded run consumes the generator exactly like the reference: first for the merged image, then for rgb_gt."""
+    # where the two N(0,1) fields of the black-hole augmentation come from: "host" = the reference's own stream (below);
+    # "device" (opt-in) = one field of FH*FW draws each from the GPU's Philox generator: the same distribution, a different
+    # stream, and none of the 7.4 ms per frame that 2 x 750 000 CPU normal draws + their copy cost on an 8-core host
+    hole_noise = "host"
+
+    def draw_hole_noise(self, rgb_gt):
+        """The two N(0,1) fields of `add_black_hole` (tf_nerf.py:306-318).  hole_noise == "host" (default): drawn the way the
+        reference draws them -- `torch.randn(input_img.shape)` on the default (CPU) generator, channel 0 kept, moved to the
+        device -- so that a seeded run consumes the generator exactly like the reference: first for the merged image, then for
+        rgb_gt.  hole_noise == "device": `torch.randn(B, FH, FW, device=...)` twice on the device generator."""
         B, FH, FW = rgb_gt.shape[0], rgb_gt.shape[1], rgb_gt.shape[2]
+        if getattr(self, "hole_noise", "host") == "device":
+            return (torch.randn(B, FH, FW, device=rgb_gt.device), torch.randn(B, FH, FW, device=rgb_gt.device))
+        if self.hole_noise != "host":
+            raise ValueError(f"TalkingFace.hole_noise must be 'host' or 'device', got {self.hole_noise!r}")
         n1 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
         n2 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
         return n1.to(rgb_gt.device), n2.to(rgb_gt.device)

@@ -74,7 +74,11 @@ class Trainer:
         hand-written backward does not run through DDP's hooks): with an initialised process group `train_stage1` averages the
         gradients over the ranks in one bucket (`sharded.allreduce_grads`) before the optimizer step -- the same result.
         Extras of this build: `syncnet=`, `perceptual_loss_fn=` (pre-built frozen nets), `w_photometric_loss=` (alias of
-        the reference's `lambda_rgb`)."""
+        the reference's `lambda_rgb`); `precision="fp32"` (default: the exact kernels, what goldens G11 / G14 / G16 pin) or
+        `"bf16"` (BASELINE config 5's arithmetic: bf16 MFMA operands in the MLP and the post-fusion U-Net, fp32 accumulation
+        and master weights); `hole_noise="host"` (default: the black-hole fields come from the reference's CPU generator
+        stream, tf_nerf.py:306-318) or `"device"` (drawn on the GPU: same distribution, another stream, no 7 ms of host
+        `randn` per frame); and the method `train_steps` (K frames per optimisation step)."""
         if isinstance(device, dict) or isinstance(out_dir, dict):
             raise TypeError("Trainer(model, optimizer, device, out_dir, cfg=...): cfg is the FIFTH argument, as in the reference")
         self.model = model
@@ -93,6 +97,16 @@ class Trainer:
         self.width = int(self.cfg["data"]["width"])
         self.batch_rays = int(batch_rays if batch_rays is not None else tc.get("batch_rays", self.height * self.width))
         self.multi_gpu = bool(kwargs.pop("multi_gpu", False))
+        self.precision = kwargs.pop("precision", "fp32")
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"Trainer(precision=...) must be 'fp32' or 'bf16', got {self.precision!r}")
+        model.train_precision = self.precision
+        hn = kwargs.pop("hole_noise", None)
+        if hn is not None:
+            if hn not in ("host", "device"):
+                raise ValueError(f"Trainer(hole_noise=...) must be 'host' or 'device', got {hn!r}")
+            model.hole_noise = hn
+        self._stage_step = None
         self.use_audio = self.use_audio_net = self.use_time = True
         self.use_delta_uv = self.add_noise_audio = self.add_noise_uv = False
         self.use_head_pose = self.use_head_pose_net = self.use_coords2audio = self.use_coords_mapping = False
@@ -172,7 +186,7 @@ class Trainer:
         u01 = float(torch.rand(1, device=self.device))          # eps_shift draw (training.py:200)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model._hot_tensors()):
             from .autograd import predict_lip_image as predict_with_graph
-            return predict_with_graph(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
+            return predict_with_graph(self.model, chunk, audio, time_pts, self.height, self.width, u01, self.precision)[:, :3]
         return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
 
     def compute_rel_pose(self, canonical_euler, canonical_trans, euler, trans, img_batch_size=1, device=None):
@@ -350,11 +364,124 @@ class Trainer:
             loss["loss"] = loss["loss"] + loss_sync
         loss["loss"].backward()
         self._average_gradients_over_ranks()
-        for k, v in m.state_dict().items():          # check_weights (src/common.py:56-64)
-            if v.dtype.is_floating_point and torch.isnan(v).any():
-                import logging
-                logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
+        self._check_weights()
         self.optimizer.step()
+        return loss["loss_rgb"], loss
+
+    def _check_weights(self):
+        """check_weights (src/common.py:56-64): warn for every state-dict tensor that holds a NaN.  One multi-tensor norm and
+        ONE device synchronisation for the whole state dict (a NaN anywhere makes that tensor's norm NaN) instead of one
+        `isnan().any()` round trip per tensor (~100 with the U-Net: milliseconds of an 8-ms iteration)."""
+        named = [(k, v) for k, v in self.model.state_dict().items() if v.dtype.is_floating_point and v.numel()]
+        norms = torch.stack(torch._foreach_norm([v for _, v in named]))
+        bad = torch.isnan(norms)
+        if bool(bad.any()):
+            import logging
+            for (k, _), b in zip(named, bad.tolist()):
+                if b:
+                    logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
+
+    def train_steps(self, batch, it=None, seed=None):
+        """K frames of the reference's loop in ONE optimisation step: `batch` is a list of K `load_one_frame` dictionaries (or one
+        collated dictionary whose tensors carry a leading batch axis K).  Every frame is evaluated exactly as `train_step`
+        evaluates it alone -- its own 4-tap ensemble draw, its own black-hole coin and noise fields, its own 5-frame sync window
+        after `it > 100000`, its own one-frame BatchNorm statistics group in the post-fusion U-Net (running statistics move
+        frame by frame) -- but all K go through the fused engine (`StageOneStep`: one MLP forward / backward for the K main and
+        5 K window frames, one composite / U-Net / SyncNet pass per group of frames) and the optimizer steps ONCE on the mean of
+        the K per-frame losses (the gradient of K single calls averaged, as a batch_size-K DataLoader would give the reference
+        if its crop code supported it, training.py:536-537).  The random draws are made frame by frame in `train_step`'s order,
+        so K = 1 consumes the generators like one `train_step` call.  The canonical-depth photo loss is not part of this
+        entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames."""
+        import random
+        self.model.train()
+        tc, m, dev = self.cfg["training"], self.model, self.device
+        if self.optimizer is None:
+            raise ValueError("train_steps steps an optimizer: construct Trainer(model, optimizer=...)")
+        if bool(tc.get("use_canonical_depth_loss_photo_v2", False)):
+            raise NotImplementedError("train_steps: the canonical-depth photo loss (use_canonical_depth_loss_photo_v2) runs through train_step only")
+        if isinstance(batch, dict):
+            K = int(batch["rgb"].shape[0])
+            frames = [{k: (v[i] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == K else v) for k, v in batch.items()}
+                      for i in range(K)]
+        else:
+            frames = list(batch)
+            K = len(frames)
+        if K == 0:
+            raise ValueError("train_steps: empty batch")
+        on = lambda t: t.to(dev, non_blocking=True) if isinstance(t, torch.Tensor) else t
+        scalar = lambda v: int(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else int(v)
+        f0 = frames[0]
+        H, W = int(f0["rgb"].shape[-3]), int(f0["rgb"].shape[-2])
+        if self.batch_rays != H * W:
+            raise NotImplementedError("train_steps: batch_rays = H*W (the May configuration)")
+        self.height, self.width = H, W
+        x0, y0 = scalar(f0["lip_lefttop_x"]), scalar(f0["lip_lefttop_y"])
+        for fr in frames[1:]:
+            if (scalar(fr["lip_lefttop_x"]), scalar(fr["lip_lefttop_y"])) != (x0, y0) or fr["rgb"].shape != f0["rgb"].shape:
+                raise ValueError("train_steps: the frames of one step must come from one clip (same lip box and sizes)")
+        sync_on = bool(self.use_syncloss and it is not None and it > 100000 and tc.get("stage", "stage1") == "stage1")
+        face_on = bool(self.use_post_fusion)
+        lip_perc = self.use_perceptual_loss and tc.get("use_lip_perc_loss", "v1") == "v1"
+        face_perc = self.use_perceptual_loss and tc.get("use_face_perc_loss", True) is True
+        if tc.get("use_lip_photo_loss", "v1") != "v1" or (face_on and tc.get("use_face_photo_loss", True) is not True) or \
+                (self.use_perceptual_loss and face_on and lip_perc != face_perc):
+            raise NotImplementedError("train_steps implements the May loss set (lip + face photometric terms, LPIPS on both or neither)")
+        key = (H, W, self.precision, sync_on, face_on, bool(lip_perc))
+        if self._stage_step is None or self._stage_step[0] != key:
+            self._stage_step = (key, StageOneStep(m, H, W, syncnet=self.syncnet if sync_on else None, precision=self.precision,
+                                                  w_syncloss=self.w_syncloss, lambda_rgb=self.w_photometric_loss,
+                                                  w_post_fusion=self.w_post_fusion, face_loss=face_on,
+                                                  perceptual=self.perceptual_loss_fn if lip_perc else None,
+                                                  w_perceptual_loss=self.w_perceptual_loss))
+        step = self._stage_step[1]
+        # ---- the random draws, frame by frame in train_step's order: u01 of the main render (device generator, training.py:200),
+        # the black-hole coin (python's `random`, tf_nerf.py:371), its two noise fields, then the window's five u01 draws
+        u_main, u_win, n1s, n2s = [], [], [], []
+        ones = None
+        for fr in frames:
+            u_main.append(torch.rand(1, device=dev))
+            if face_on:
+                if random.random() > 0.5:
+                    a_, b_ = m.draw_hole_noise(fr["rgb_face_ori"].reshape(1, *fr["rgb_face_ori"].shape[-3:]))
+                else:      # a field of ones punches no hole: noise >= 1e-6 everywhere == the branch not taken
+                    if ones is None:
+                        ones = torch.ones(1, *fr["rgb_face_ori"].shape[-3:-1], device=dev)
+                    a_ = b_ = ones
+                n1s.append(a_)
+                n2s.append(b_)
+            if sync_on:
+                u_win.append(torch.cat([torch.rand(1, device=dev) for _ in range(int(fr["audio_window"].shape[-3]))]))
+        stack = lambda k: torch.stack([on(fr[k]).reshape(fr[k].shape[-3:] if fr[k].dim() > 3 else fr[k].shape) for fr in frames], 0)
+        audio = torch.stack([on(fr["audio"]).reshape(16, 29) for fr in frames], 0)
+        first = [scalar(fr["index"]) + (0 if seed is None else int(seed)) for fr in frames]
+        targets = torch.stack([on(fr["rgb"]).reshape(H * W, 3) for fr in frames], 0)
+        face = sync = None
+        if face_on:
+            face = dict(rgb_face_canonical=on(f0["rgb_face_zero"]).reshape(1, *f0["rgb_face_zero"].shape[-3:]),
+                        rgb_face_gt=stack("rgb_face_ori"), mask_lip_canonical=on(f0["mask_lip_canonical"]).reshape(1, *f0["mask_lip_canonical"].shape[-3:]),
+                        lip_lefttop_x=x0, lip_lefttop_y=y0, coord=stack("coord"), hole_noise=(torch.cat(n1s, 0), torch.cat(n2s, 0)))
+        if sync_on:
+            T = int(f0["audio_window"].shape[-3])
+            bbox = f0["canonical_face_bbox"][0] if isinstance(f0["canonical_face_bbox"], torch.Tensor) and f0["canonical_face_bbox"].dim() > 1 \
+                else f0["canonical_face_bbox"]
+            sync = dict(audio_window=torch.stack([on(fr["audio_window"]).reshape(T, 16, 29) for fr in frames], 0),
+                        u01=torch.stack(u_win, 0), total_frame=scalar(f0["total_frame"]),
+                        rgb_face_canonical=on(f0["rgb_face_zero"]).reshape(1, *f0["rgb_face_zero"].shape[-3:]), rgb_face_gt=stack("rgb_face_ori"),
+                        mask_lip_canonical=on(f0["mask_lip_canonical"]).reshape(1, *f0["mask_lip_canonical"].shape[-3:]),
+                        lip_lefttop_x=x0, lip_lefttop_y=y0,
+                        coord_window=torch.stack([on(fr["coord_window"]).reshape(T, *fr["coord_window"].shape[-3:]) for fr in frames], 0),
+                        canonical_face_bbox=[float(v) for v in bbox], mel=torch.stack([on(fr["mel"]).reshape(1, 80, 16) for fr in frames], 0),
+                        rgb_window_neg=torch.stack([on(fr["rgb_window_neg"]).reshape(3, T, 96, 96) for fr in frames], 0))
+        self.optimizer.zero_grad()
+        total, grads, aux = step.loss_and_grads(audio, first, targets, torch.cat(u_main), sync=sync, face=face)
+        apply_grads(m, grads)
+        self._average_gradients_over_ranks()
+        self._check_weights()
+        self.optimizer.step()
+        loss = {"loss": total, "loss_rgb": aux["loss_rgb"] + (aux["loss_face"] if "loss_face" in aux else 0)}
+        for k in ("loss_perceptual", "loss_sync"):
+            if k in aux:
+                loss[k] = aux[k]
         return loss["loss_rgb"], loss
 
 
@@ -514,14 +641,18 @@ class LipTrainStep:
         B, P = a32.shape[0], self.h * self.w
         N = 4 * P * B
         idx = [int(i) for i in (frame_idx.tolist() if isinstance(frame_idx, torch.Tensor) else frame_idx)]
-        u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
-        if len(idx) != B or len(u) != B:
+        if isinstance(u01, torch.Tensor) and u01.is_cuda:      # draws that never left the device (Trainer.train_steps): no round trip
+            t_u = u01.detach().to(dev, torch.float32).reshape(-1).contiguous()
+            n_u = t_u.numel()
+        else:
+            u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
+            t_u, n_u = torch.tensor(u, dtype=torch.float32).to(dev, non_blocking=True), len(u)
+        if len(idx) != B or n_u != B:
             raise ValueError("frame_idx and u01 need one entry per audio window")
         feat = m._audio_encode(a32)                                          # [B,64]
         st = MlpState(self.precision, N, dev, lib)
         areas, rgb, pred = _f(dev, N), _f(dev, N, 3), _f(dev, B * P, 3)
         t_idx = torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
-        t_u = torch.tensor(u, dtype=torch.float32).to(dev, non_blocking=True)
         with torch.cuda.device(dev):
             s = _stream()
             if self.precision == "bf16":     # the embedded rows of the whole batch in one launch, straight to the bf16 operand image
@@ -717,7 +848,8 @@ class StageOneStep:
         a = _dev_f32(audio, dev, "audio")
         B, P = a.shape[0], self.h * self.w
         idx = [int(i) for i in (frame_idx.tolist() if isinstance(frame_idx, torch.Tensor) else frame_idx)]
-        u = [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
+        on_device = isinstance(u01, torch.Tensor) and u01.is_cuda      # (Trainer.train_steps: the draws stay on the device)
+        u = u01.detach().float().reshape(-1) if on_device else [float(v) for v in (u01.tolist() if isinstance(u01, torch.Tensor) else u01)]
         S = 0
         if sync is not None:
             if self.chain is None:
@@ -727,11 +859,15 @@ class StageOneStep:
             if T != self.T or S > B:
                 raise ValueError("audio_window must be [S<=B,T,16,29]")
             total = int(sync["total_frame"])
-            uw = sync["u01"].tolist() if isinstance(sync["u01"], torch.Tensor) else sync["u01"]
+            if on_device:
+                u = torch.cat([u, sync["u01"].detach().to(dev, torch.float32).reshape(-1)])
+            else:
+                uw = sync["u01"].tolist() if isinstance(sync["u01"], torch.Tensor) else sync["u01"]
             for s in range(S):              # cur_data['index'] = index + t, clamped to the last frame (training.py:515-518)
                 for t in range(T):
                     idx.append(idx[s] + t if idx[s] + t < total else total - 1)
-                    u.append(float(uw[s][t]))
+                    if not on_device:
+                        u.append(float(uw[s][t]))
             a = torch.cat([a, aw.reshape(S * T, 16, 29)], 0)
         pred = self.step.forward(a, idx, u)                                   # [B + S*T, P, 3]
         dpred = torch.zeros_like(pred)

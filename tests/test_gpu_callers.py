@@ -1,0 +1,216 @@
+"""The callers either side of the hot path as the reference has them, un-bound from the host:
+the drop-in Trainer in bf16 precision, `hole_noise="device"`, `Trainer.train_steps` (K frames per optimisation step) against
+the reference's own step (goldens G11 / G14) and against K single `train_step` calls, the byte-wide loader (`from8b`,
+`ClipStreamer`) against `SomeonesLipClip.load`, and the pipelined file writer against `write_frames`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import speech2lip_amd as s2l
+from speech2lip_amd import weights as W
+from tests.test_gpu_training_chain import _g11_device, _patched_draws, full_model, relerr
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def syncnet(dev):
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: T(v) for k, v in W.make_syncnet_state_dict(0).items()}, strict=True)
+    return net
+
+
+def _cfg(m):
+    return {**m.cfg, "training": {**m.cfg["training"], "use_canonical_depth_loss_photo_v2": False, "use_perceptual_loss": False,
+                                  "use_sync_contrastive_loss": True, "stage": "stage1", "batch_rays": 16 * 24}}
+
+
+def _late_model(dev):
+    m = full_model(dev, 16, 24).train()
+    m.post_fusion_unet.eval()                                              # train.py:188-197
+    for p in m.post_fusion_unet.parameters():
+        p.requires_grad = False
+    return m
+
+
+def test_from8b_is_the_readers_conversion(dev):
+    """s2l_from8b == (u8 / 255.0).astype(float32) (someones_lip_dataset.py:196-217), every byte value, ragged length."""
+    u8 = np.concatenate([np.arange(256, dtype=np.uint8), np.random.default_rng(0).integers(0, 256, 1003, dtype=np.uint8)])
+    got = s2l.from8b(T(u8).to(dev)).cpu().numpy()
+    assert np.array_equal(got, (u8 / 255.0).astype(np.float32))
+    with pytest.raises(s2l._abi.S2LError):
+        s2l.from8b(T(u8))
+
+
+def test_train_steps_one_frame_reproduces_the_reference_step(golden, syncnet, dev):
+    """Trainer.train_steps with K = 1 on the G11 batch (it > 100000: frozen U-Net, sync window) and on the G14 batch (the U-Net
+    trains): the loss dictionary and the gradients the REFERENCE's train_stage1 produced, at train_stage1's own tolerances; the
+    random draws are consumed in train_step's order (six eps draws, the coin, two noise fields)."""
+    g, data, eps, _, face = _g11_device(golden, dev)
+    m = _late_model(dev)
+    tr = s2l.Trainer(m, torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True)
+    restore = _patched_draws(eps, face["hole_noise"], dev)
+    try:
+        loss_rgb, loss = tr.train_steps([data], it=100001)
+    finally:
+        eq, fq = restore()
+    assert not eq and not fq
+    assert abs(float(loss["loss"]) - float(g["loss"])) <= 3e-6 and abs(float(loss["loss_sync"]) - float(g["loss_sync"])) <= 2e-6
+    assert abs(float(loss_rgb) - float(g["loss_rgb"])) <= 2e-6
+    params = dict(m.named_parameters())
+    for key in g:
+        if key.startswith("g_") and key != "g_pts5_cols":
+            assert relerr(params[key[2:]].grad, g[key]) <= 5e-4, (key, relerr(params[key[2:]].grad, g[key]))
+    # G14: it = 50000, train-mode U-Net trained with the MLP; its parameter gradients arrive under post_fusion_unet.*
+    e = golden("g14_stage1_early.npz")
+    m = full_model(dev, 16, 24).train()
+    tr = s2l.Trainer(m, torch.optim.SGD(m.parameters(), lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True)
+    restore = _patched_draws(e["eps"], face["hole_noise"], dev)
+    try:
+        _, loss = tr.train_steps([dict(data, rgb_face_ori=T(e["rgb_face_ori"]))], it=50000)
+    finally:
+        eq, fq = restore()
+    assert not fq and "loss_sync" not in loss          # (the window's five draws are not made before it > 100000)
+    assert abs(float(loss["loss"]) - float(e["loss"])) <= 5e-6
+    params = dict(m.named_parameters())
+    n_unet = 0
+    for key in e:
+        if key.startswith("g_"):
+            got, ref = params[key[2:]].grad.cpu(), T(e[key])
+            assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), key
+            n_unet += key[2:].startswith("post_fusion_unet.")
+    assert n_unet > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_steps_K_frames_equal_K_single_calls(golden, syncnet, dev, precision):
+    """K = 3 frames in one train_steps call against three train_step calls at the same weights (lr = 0): the per-step loss is the
+    mean of the three single-call losses and the gradient their mean -- to summation-order accuracy in fp32 (the kernels and the
+    per-frame BatchNorm statistics groups are the same), to bf16 accuracy in bf16 (tile boundaries move with the batch)."""
+    g, data, eps, _, face = _g11_device(golden, dev)
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(3):
+        d = dict(data)
+        d["index"] = int(data["index"]) + 3 * k
+        d["rgb"] = T(rng.random(tuple(data["rgb"].shape), dtype=np.float32))
+        d["audio"] = T(W.synthetic_audio(1, seed=20 + k).astype(np.float32))
+        d["rgb_face_ori"] = T(rng.random(tuple(data["rgb_face_ori"].shape), dtype=np.float32))
+        frames.append(d)
+    draws = [[0.1 * (k + 1) + 0.05 * j for j in range(6)] for k in range(3)]
+    holes = [(torch.randn(1, *data["rgb_face_ori"].shape[1:3], generator=torch.Generator().manual_seed(40 + k)),
+              torch.randn(1, *data["rgb_face_ori"].shape[1:3], generator=torch.Generator().manual_seed(50 + k))) for k in range(3)]
+
+    def trainer():
+        m = _late_model(dev)
+        return m, s2l.Trainer(m, torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=_cfg(m), syncnet=syncnet,
+                              use_syncloss=True, precision=precision)
+    m1, t1 = trainer()
+    singles, grads = [], []
+    for k in range(3):
+        restore = _patched_draws(draws[k], (holes[k][0].to(dev), holes[k][1].to(dev)), dev)
+        try:
+            _, loss = t1.train_step(frames[k], it=100001)
+        finally:
+            restore()
+        singles.append(float(loss["loss"]))
+        grads.append({n: p.grad.clone() for n, p in m1.named_parameters() if p.grad is not None})
+    mK, tK = trainer()
+    # one call: the draws of frame 0, then frame 1, then frame 2 (train_step's order inside each frame)
+    import random
+    eq = [v for d in draws for v in d]
+    fq = [h.cpu()[:, None].repeat(1, 3, 1, 1) for pair in holes for h in pair]
+    # train_steps draws per frame: u01 main, coin, two fields, five window draws -> the patched queues must interleave the same way
+    order = []
+    for k in range(3):
+        order += [draws[k][0]] + draws[k][1:]
+    saved = (torch.rand, torch.randn, random.random)
+    torch.rand = lambda *a, **kw: torch.full((1,), order.pop(0), device=dev)
+    torch.randn = lambda *a, **kw: fq.pop(0)
+    random.random = lambda: 0.9
+    try:
+        _, lossK = tK.train_steps(frames, it=100001)
+    finally:
+        torch.rand, torch.randn, random.random = saved
+    assert not order and not fq
+    tol = 2e-5 if precision == "fp32" else 2e-2
+    assert abs(float(lossK["loss"]) - sum(singles) / 3) <= tol * max(1.0, abs(sum(singles) / 3))
+    pK = dict(mK.named_parameters())
+    for name in ("output_linear.weight", "pts_linears.3.weight", "pts_linears.5.weight", "fc_audio.weight", "encoder_conv.0.weight"):
+        mean = sum(gr[name] for gr in grads) / 3
+        assert relerr(pK[name].grad, mean.cpu()) <= (1e-4 if precision == "fp32" else 6e-2), (name, relerr(pK[name].grad, mean.cpu()))
+
+
+def test_trainer_bf16_and_device_noise(golden, syncnet, dev):
+    """Trainer(precision="bf16") -- train_step through the bf16 MLP kernels and the half-width U-Net chain -- stays within bf16
+    accuracy of the fp32 step on the G11 batch; hole_noise="device" draws the fields on the GPU (the CPU generator is not
+    touched) and punches about half of the face pixels' holes like the host stream does."""
+    g, data, eps, _, face = _g11_device(golden, dev)
+    m = _late_model(dev)
+    tr = s2l.Trainer(m, torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True,
+                     precision="bf16")
+    restore = _patched_draws(eps, face["hole_noise"], dev)
+    try:
+        _, loss = tr.train_step(data, it=100001)
+    finally:
+        restore()
+    assert abs(float(loss["loss"]) - float(g["loss"])) <= 2e-2 * abs(float(g["loss"]))
+    params = dict(m.named_parameters())
+    for key in ("g_output_linear.weight", "g_pts_linears.3.weight"):
+        a, b = params[key[2:]].grad.flatten().double().cpu(), T(g[key]).flatten().double()
+        assert float(a @ b / (a.norm() * b.norm())) >= 0.995, key
+    with pytest.raises(ValueError):
+        s2l.Trainer(m, None, cfg=_cfg(m), precision="fp16")
+    # device noise
+    m.hole_noise = "device"
+    state = torch.get_rng_state()
+    n1, n2 = m.draw_hole_noise(data["rgb_face_ori"].to(dev))
+    assert torch.equal(torch.get_rng_state(), state) and n1.is_cuda and n1.shape == data["rgb_face_ori"].shape[:3]
+    assert 0.4 < float((n1 < 1e-6).float().mean()) < 0.6 and not torch.equal(n1, n2)
+    tr2 = s2l.Trainer(m, torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True,
+                      hole_noise="device")
+    _, loss2 = tr2.train_step(data, it=100001)
+    assert np.isfinite(float(loss2["loss"]))
+    m.hole_noise = "bogus"
+    with pytest.raises(ValueError):
+        m.draw_hole_noise(data["rgb_face_ori"].to(dev))
+
+
+def test_clip_streamer_and_frame_writer_equal_the_serial_forms(dev, tmp_path):
+    """ClipStreamer (thread-pool decode into pinned bytes, H2D on a side stream, s2l_from8b on the device) yields the tensors
+    SomeonesLipClip.load returns, bit for bit, over ragged batches; FrameWriter writes the files write_frames writes."""
+    from tools.benchlib import write_synthetic_dataset
+    root = str(tmp_path / "may_face_crop_lip")
+    write_synthetic_dataset(root, 30, FH=40, FW=56, lh=8, lw=12, x0=20, y0=22, train=False, workers=4)
+    cfg = s2l.may_config(8, 12, data_path=root)
+    ds = s2l.SomeonesLipClip(root, "train", cfg)
+    n = len(ds)
+    assert n == 27 and (ds.lefttop_x, ds.lefttop_y) == (20, 22)
+    st = s2l.ClipStreamer(ds, dev, batch=8, first=3, count=21, workers=3)
+    seen = 0
+    for clip in st:
+        ref = ds.load(dev, 3 + seen, len(clip.names))
+        for f in ("audio", "index", "coord", "rgb_face_ori", "rgb_face_zero", "mask_lip_canonical"):
+            assert torch.equal(getattr(clip, f), getattr(ref, f)), f
+        assert clip.names == ref.names and (clip.lip_lefttop_x, clip.height, clip.width) == (ref.lip_lefttop_x, ref.height, ref.width)
+        seen += len(clip.names)
+    st.close()
+    assert seen == 21
+    frames = torch.rand(11, 40, 56, 3, device=dev)
+    names = ["%05d" % (k + 1) for k in range(11)]
+    s2l.write_frames(frames, names, str(tmp_path / "a"))
+    wr = s2l.FrameWriter(str(tmp_path / "b"), workers=3, depth=2)
+    for s0 in range(0, 11, 4):
+        wr.submit(s2l.to8b(frames[s0:s0 + 4]), names[s0:s0 + 4])
+    wr.close()
+    for nm in names:
+        assert open(tmp_path / "a" / (nm + ".jpg"), "rb").read() == open(tmp_path / "b" / (nm + ".jpg"), "rb").read(), nm

@@ -480,3 +480,200 @@ def bench_train(dev, B=64, precision="bf16", steps=5):
             "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / peak, 4), "loss_first": l0,
             "loss_last": float(l), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "_step": step,
             "_one": one}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The callers the reference actually has, fed from a dataset folder on disk (VERDICT r04 "missing" 2 and 4)
+def write_synthetic_dataset(root, n, FH=500, FW=500, lh=96, lw=96, x0=202, y0=316, seed=3, train=True, workers=16):
+    """A clip of `n` frames in the reference's on-disk layout (someones_lip_dataset.py:43-120; field list in
+    tools/make_dataset_fixture.py) at the REAL sizes: 500x500 face JPEGs, 96x96 lip JPEGs, float32 [500,500,2] pose grids
+    (identity + rigid perturbation + jitter), DeepSpeech windows, and -- `train` -- the sync-loss side inputs
+    (mel.npy, face_bbox_dict.npy).  Smooth random images (JPEG-friendly); written by a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    for sub in ("audio", "audio_test", "coords", "ori_images_face", "images", "landmarks"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    np.save(os.path.join(root, "audio", "audio.npy"), W.synthetic_audio(n, seed=1).astype(np.float64))
+    np.save(os.path.join(root, "audio_test", "audio.npy"), W.synthetic_audio(8, seed=2).astype(np.float64))
+    ys, xs = np.meshgrid(np.arange(FH), np.arange(FW), indexing="ij")
+    ident = np.stack([(2 * xs + 1) / FW - 1, (2 * ys + 1) / FH - 1], -1).astype(np.float32)
+    base = rng.random((FH // 10 + 1, FW // 10 + 1, 3)).astype(np.float32)
+    face0 = np.asarray(Image.fromarray((base * 255).astype(np.uint8)).resize((FW, FH), Image.BILINEAR))
+
+    def one(k):
+        r = np.random.default_rng(seed * 100003 + k)
+        ang = (r.random() - 0.5) * (6 * np.pi / 180)
+        rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]], np.float32)
+        grid = ident @ rot.T + ((r.random(2) - 0.5) * 0.04).astype(np.float32) + (r.standard_normal((FH, FW, 2)) * 1e-3).astype(np.float32)
+        np.save(os.path.join(root, "coords", "%05d.npy" % (k + 1)), np.clip(grid, -1, 1).astype(np.float32))
+        img = np.clip(face0.astype(np.int16) + r.integers(-20, 20, (1, 1, 3)), 1, 255).astype(np.uint8)      # > 0: inside the face mask
+        Image.fromarray(img).save(os.path.join(root, "ori_images_face", "%05d.jpg" % (k + 1)), quality=92)
+        Image.fromarray(img[y0:y0 + lh, x0:x0 + lw]).save(os.path.join(root, "images", "%05d.jpg" % (k + 1)), quality=92)
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, range(n)))
+    mask = np.zeros((FH, FW, 3), np.uint8)
+    mask[y0:y0 + lh, x0:x0 + lw] = 255
+    Image.fromarray(mask).save(os.path.join(root, "canonical_lip_mask.jpg"), quality=100)
+    # mouth landmarks whose bounding box centre gives the lip origin (x0, y0) through compute_mouth_bbox's 1.02 rule
+    # (someones_lip_dataset.py:173-193: boundingRect's centre, y scaled by 1.02, minus half the crop, truncated)
+    cx = int(x0 + lw / 2.0)
+    cy = next(c for c in range(1, FH) if int(c * 1.02 - lh / 2.0) == y0)
+    lms = np.full((68, 2), 1.0, np.float32)
+    lms[48:, 0] = np.linspace(cx - 20, cx + 19, 20)
+    lms[48:, 1] = np.linspace(cy - 10, cy + 9, 20)
+    np.savetxt(os.path.join(root, "landmarks", "00001.lms"), lms)
+    if train:
+        np.save(os.path.join(root, "audio", "mel.npy"), rng.standard_normal((80, 4 * n + 64)).astype(np.float32))
+        np.save(os.path.join(root, "face_bbox_dict.npy"), {"%05d.jpg" % (k + 1): np.array([110, 90, 390, 420, 0.99], np.float32) for k in range(n)})
+    return root
+
+
+def _dataset_tmp(name):
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix="s2l_bench_"), name)
+
+
+def bench_infer_clip(dev, n_total=640, batch=100):
+    """The inference driver END TO END with I/O, the loop `inference.py:140-178` replaced: dataset folder on disk (JPEG frames +
+    2-MB pose grids per frame) -> load -> lip render 96x96 -> composite into 500x500 -> post-fusion U-Net -> 8-bit -> JPEG files.
+    The folder's name contains `may`, so the validation split is the reference's: the LAST 598 frames (someones_lip_dataset.py
+    :143-145).  Three forms of tools/infer_clip.py's loop, frames/s each: serial (load, render, write one after the other),
+    pipelined (ClipStreamer + FrameWriter: decode and encode on host threads, byte-wide H2D on a side stream, beside the GPU
+    work), and pipelined with the split speed modes; plus the GPU-only rate of the same batches from resident inputs."""
+    import shutil
+    root = _dataset_tmp("may_face_crop_lip")
+    t0 = time.perf_counter()
+    write_synthetic_dataset(root, n_total, train=False)
+    t_write = time.perf_counter() - t0
+    cfg = s2l.may_config(96, 96, data_path=root)
+    ds = s2l.SomeonesLipClip(root, "val", cfg)
+    n = len(ds)
+    m = make_model(dev, ds.lip_h, ds.lip_w, unet=True)
+    m.data_path = root
+    out_dir = os.path.join(os.path.dirname(root), "out")
+    res = {"frames": n, "host_threads": min(32, os.cpu_count() or 1), "dataset_write_s": round(t_write, 2)}
+
+    def serial():
+        for first in range(0, n, batch):
+            clip = ds.load(dev, first, min(batch, n - first))
+            lip, recon, merged = s2l.render_clip_frames(m, clip)
+            s2l.write_frames(recon, clip.names, out_dir)
+
+    def piped(precision):
+        st, wr = s2l.ClipStreamer(ds, dev, batch), s2l.FrameWriter(out_dir)
+        for clip in st:
+            lip, recon, merged = s2l.render_clip_frames(m, clip, precision=precision)
+            wr.submit(s2l.to8b(recon), clip.names)
+        wr.close()
+        st.close()
+    # warm-up on a short prefix (kernel code objects, pinned allocations), then one timed pass each
+    clip0 = ds.load(dev, 0, min(batch, n))
+    s2l.render_clip_frames(m, clip0)
+    s2l.render_clip_frames(m, clip0, precision="split")
+    torch.cuda.synchronize()
+    for key, fn in (("serial", serial), ("pipelined", lambda: piped("fp32")), ("pipelined_split_modes", lambda: piped("split"))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        res[key + "_frames_per_s"] = round(n / (time.perf_counter() - t0), 1)
+    for key, prec in (("gpu_only", "fp32"), ("gpu_only_split_modes", "split")):
+        ms = _median_ms(lambda: s2l.to8b(s2l.render_clip_frames(m, clip0, precision=prec)[1]), reps=3, inner=1)
+        res[key + "_frames_per_s"] = round(clip0.audio.shape[0] / ms * 1e3, 1)
+    # the files of the pipelined pass hold the frames of the serial pass (same kernels, same quantisation): compare one decoded file
+    from PIL import Image
+    a = np.asarray(Image.open(os.path.join(out_dir, "%05d.jpg" % n)))
+    ref = s2l.to8b(s2l.render_clip_frames(m, ds.load(dev, n - 1, 1), precision="split")[1])[0].cpu().numpy()
+    res["last_file_mean_abs_diff_vs_frame_u8"] = round(float(np.abs(a.astype(np.int16) - ref.astype(np.int16)).mean()), 3)     # JPEG loss only
+    shutil.rmtree(os.path.dirname(root), ignore_errors=True)
+    return res
+
+
+def bench_dropin_trainer(dev, n_frames=48, iters=200):
+    """The training caller the reference has: train.py:173-199's loop body -- batch = next(DataLoader over SomeonesLipDataset),
+    `Trainer.train_step(batch, it=it)` -- through the drop-in `speech2lip_amd.Trainer`, one frame per iteration, bf16 precision,
+    the frozen post-fusion U-Net in train-mode BatchNorm (what `model.train()` in train_step leaves it in, training.py:150),
+    fed by `SomeonesLipClip.load_one_frame` on a 96x96-lip / 500x500-face folder on disk.  Reported per phase (`it` <= 100000:
+    the U-Net still trains, no sync loss; `it` > 100000: frozen U-Net + the 5-frame sync window): ms per iteration of
+      * `train_step` with the reference's CPU black-hole noise stream, data loaded in the loop (the loop as written),
+      * the same with a prefetching loader (FramePrefetcher = DataLoader workers) and `hole_noise="device"`,
+      * `train_steps` with K = 8 frames per optimisation step (ms per FRAME),
+    each with the GPU-busy share (sum of HIP-event spans around the step's GPU work / wall time), and the data loader alone."""
+    import shutil
+    root = _dataset_tmp("may_face_crop_lip")
+    write_synthetic_dataset(root, n_frames, train=True)
+    cfg = s2l.may_config(96, 96, data_path=root, train_flags=True)
+    cfg["model"]["use_canonical_depth"] = False
+    cfg["training"].update(use_sync_contrastive_loss=True, use_perceptual_loss=False, use_canonical_depth_loss_photo_v2=False,
+                           use_syncloss=True)
+    ds = s2l.SomeonesLipClip(root, "train", cfg=cfg)
+    n = len(ds)
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
+    for p in net.parameters():
+        p.requires_grad = False
+    res = {"frames_in_split": n, "iterations": iters, "loader_threads": min(16, os.cpu_count() or 1)}
+    t0 = time.perf_counter()
+    for i in range(8):
+        ds.load_one_frame(i % n)
+    res["load_one_frame_ms"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+
+    def build(late, hole_noise):
+        m = make_model(dev, 96, 96, unet=True, train=True)
+        m.data_path = root
+        if late:      # train.py:188-197
+            for p in m.post_fusion_unet.parameters():
+                p.requires_grad = False
+            m.post_fusion_unet.eval()
+        opt = torch.optim.Adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
+        return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, precision="bf16", hole_noise=hole_noise)
+
+    def run(tr, it0, batches, per_step):
+        torch.cuda.synchronize()
+        spans, k = [], 0
+        t0 = time.perf_counter()
+        for batch in batches:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if per_step == 1:
+                tr.train_step(batch, it=it0 + k)
+            else:
+                tr.train_steps(batch, it=it0 + k)
+            e1.record()
+            spans.append((e0, e1))
+            k += 1
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        busy = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
+        return {"ms_per_frame": round(wall / (k * per_step) * 1e3, 3), "gpu_span_share": round(busy / wall, 3)}
+
+    for phase, it0 in (("it_le_100000", 1000), ("it_gt_100000", 100001)):
+        late = it0 > 100000
+        entry = {}
+        order = [i % n for i in range(iters)]
+        # (1) the loop as written: load in the loop, host noise stream
+        tr = build(late, "host")
+        few = order[:max(8, iters // 8)]
+        gen = (s2l.data.collate_batch([ds.load_one_frame(i)]) for i in few)
+        run(tr, it0, (s2l.data.collate_batch([ds.load_one_frame(i)]) for i in few[:3]), 1)      # warm-up
+        entry["train_step_as_written"] = run(tr, it0, gen, 1)
+        # (2) prefetching loader + device noise
+        tr = build(late, "device")
+        pf = s2l.FramePrefetcher(ds, order[:3])
+        run(tr, it0, pf, 1)
+        pf = s2l.FramePrefetcher(ds, order)
+        entry["train_step_prefetch_device_noise"] = run(tr, it0, pf, 1)
+        pf.close()
+        # (3) K frames per optimisation step through the fused engine
+        K = 8
+        pf = s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False)
+        run(tr, it0, pf, K)
+        pf = s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False)
+        entry["train_steps_K8"] = run(tr, it0, pf, K)
+        pf.close()
+        res[phase] = entry
+        del tr
+        torch.cuda.empty_cache()
+    shutil.rmtree(os.path.dirname(root), ignore_errors=True)
+    return res

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--gather", action="store_true", help="multi-GPU: all-gather the 8-bit clip, rank 0 writes every file")
     ap.add_argument("--fast", action="store_true", help="the opt-in split speed modes of the lip renderer and the U-Net (fp32-grade output)")
     ap.add_argument("--lip-only", action="store_true", help="render only the lip crops (sharded.render_clip_sharded)")
+    ap.add_argument("--workers", type=int, default=None, help="host threads that decode the inputs and encode the outputs (default: min(32, cores))")
+    ap.add_argument("--serial", action="store_true", help="the un-pipelined loop (load -> render -> write, one after the other): the baseline "
+                    "bench.py's extra.infer_clip_end_to_end compares the pipeline with")
     args = ap.parse_args()
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     dev = torch.device("cuda", local_rank)
@@ -57,24 +60,37 @@ def main():
     names = ["%05d" % (i + 1) for i in range(n)]                              # inference.py:177
     if args.lip_only:
         audio = torch.from_numpy(ds.aud_features.astype("float32"))
-        lips = sharded.render_clip_sharded(model, audio, torch.arange(n), ds.lip_h, ds.lip_w, gather="u8")
+        lips = sharded.render_clip_sharded(model, audio, torch.arange(n), ds.lip_h, ds.lip_w, gather="u8",
+                                           precision="split" if args.fast else "fp32")
         if rank == 0:
             s2l.write_frames(lips, names, out_dir)
     else:
         first0, count, _ = sharded.shard_range(n, rank, world)               # this rank's contiguous block of the clip
-        blocks = []
-        for first in range(first0, first0 + count, args.batch):
-            clip = ds.load(dev, first, min(args.batch, first0 + count - first))
-            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=bool(cfg["model"].get("use_post_fusion", True)),
-                                                            precision="split" if args.fast else "fp32")
+        post = bool(cfg["model"].get("use_post_fusion", True))
+        blocks, writer = [], None
+        if args.serial:
+            batches = (ds.load(dev, first, min(args.batch, first0 + count - first)) for first in range(first0, first0 + count, args.batch))
+        else:     # decode + H2D of batch k+1 and encode + write of batch k-1 run beside the GPU work of batch k
+            batches = s2l.ClipStreamer(ds, dev, args.batch, first0, count, workers=args.workers)
+            writer = s2l.FrameWriter(out_dir, workers=args.workers)
+        for clip in batches:
+            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=post, precision="split" if args.fast else "fp32")
             frames = recon if recon is not None else (merged if merged is not None else lip)
             if args.gather and world > 1:
                 blocks.append(s2l.to8b(frames))
+            elif writer is not None:
+                writer.submit(s2l.to8b(frames), clip.names)
             else:
                 s2l.write_frames(frames, clip.names, out_dir)
-            print(f"[rank {rank}] frames {first + 1}..{first + len(clip.names)} of {n} -> {out_dir}", flush=True)
+            print(f"[rank {rank}] frames {clip.names[0]}..{clip.names[-1]} of {n} -> {out_dir}", flush=True)
+        if writer is not None:
+            writer.close()
         if args.gather and world > 1:
-            mine = torch.cat(blocks, 0) if blocks else torch.empty((0, ds.face_h, ds.face_w, 3), dtype=torch.uint8, device=dev)
+            # an empty shard still takes part in the collective: its block has the frame size the OTHER ranks gather (the face frame
+            # when the composite / U-Net ran, the lip crop otherwise)
+            has_face = post and ds.coord_files is not None and ds.mode != "test"
+            fh, fw = (ds.face_h, ds.face_w) if has_face else (ds.lip_h, ds.lip_w)
+            mine = torch.cat(blocks, 0) if blocks else torch.empty((0, fh, fw, 3), dtype=torch.uint8, device=dev)
             whole = sharded.gather_clip(mine, n)
             if rank == 0:
                 s2l.write_frames(whole, names, out_dir)
