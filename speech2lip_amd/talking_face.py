@@ -328,19 +328,22 @@ class TalkingFace(nn.Module):
     # stream, and none of the 7.4 ms per frame that 2 x 750 000 CPU normal draws + their copy cost on an 8-core host
     hole_noise = "host"
 
-    def draw_hole_noise(self, rgb_gt):
+    def draw_hole_noise(self, rgb_gt, device=None):
         """The two N(0,1) fields of `add_black_hole` (tf_nerf.py:306-318).  hole_noise == "host" (default): drawn the way the
         reference draws them -- `torch.randn(input_img.shape)` on the default (CPU) generator, channel 0 kept, moved to the
         device -- so that a seeded run consumes the generator exactly like the reference: first for the merged image, then for
         rgb_gt.  hole_noise == "device": `torch.randn(B, FH, FW, device=...)` twice on the device generator."""
         B, FH, FW = rgb_gt.shape[0], rgb_gt.shape[1], rgb_gt.shape[2]
+        dev = torch.device(device) if device is not None else rgb_gt.device
         if getattr(self, "hole_noise", "host") == "device":
-            return (torch.randn(B, FH, FW, device=rgb_gt.device), torch.randn(B, FH, FW, device=rgb_gt.device))
+            if dev.type != "cuda":
+                dev = self.packed_weights().device
+            return (torch.randn(B, FH, FW, device=dev), torch.randn(B, FH, FW, device=dev))
         if self.hole_noise != "host":
             raise ValueError(f"TalkingFace.hole_noise must be 'host' or 'device', got {self.hole_noise!r}")
         n1 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
         n2 = torch.randn(B, 3, FH, FW)[:, 0].contiguous()
-        return n1.to(rgb_gt.device), n2.to(rgb_gt.device)
+        return n1.to(dev), n2.to(dev)
 
     def _composite_geometry(self, lw):
         if self.expand_lip_mask:

@@ -442,7 +442,7 @@ class Trainer:
             u_main.append(torch.rand(1, device=dev))
             if face_on:
                 if random.random() > 0.5:
-                    a_, b_ = m.draw_hole_noise(fr["rgb_face_ori"].reshape(1, *fr["rgb_face_ori"].shape[-3:]))
+                    a_, b_ = m.draw_hole_noise(fr["rgb_face_ori"].reshape(1, *fr["rgb_face_ori"].shape[-3:]), device=dev)
                 else:      # a field of ones punches no hole: noise >= 1e-6 everywhere == the branch not taken
                     if ones is None:
                         ones = torch.ones(1, *fr["rgb_face_ori"].shape[-3:-1], device=dev)
