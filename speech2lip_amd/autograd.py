@@ -104,7 +104,7 @@ class _PredictLipImage(torch.autograd.Function):
     def forward(ctx, model, audio, index, height, width, u01, precision, *params):
         from .training import LipTrainStep
         step = LipTrainStep(model, height, width, precision)
-        pred = step.forward(audio, [index], [u01])
+        pred = step.forward(audio, [index], u01 if isinstance(u01, torch.Tensor) else [u01])
         ctx.step = step
         return pred[0]
 
@@ -115,17 +115,29 @@ class _PredictLipImage(torch.autograd.Function):
         return (None, None, None, None, None, None, None, *[g[n] for n in _abi.TENSOR_ORDER])
 
 
+_REGULAR_GRIDS = {}      # (data_ptr, shape) -> (height, width, the tensor: kept alive so that its address cannot be re-used)
+
+
+def register_regular_grid(coords, height, width):
+    """Declare `coords` (a tensor the caller will not modify) to be get_coords(width, height): Trainer.prepare_coords does, once
+    per size, which replaces a device-to-host copy and an element-wise comparison per rendered frame."""
+    _REGULAR_GRIDS[(coords.data_ptr(), tuple(coords.shape))] = (int(height), int(width), coords)
+
+
 def predict_lip_image(model, coords, audio, index, height, width, u01, precision="fp32"):
     """The regular-grid 4-tap ensemble of one frame with a graph (fp32 parity mode by default; precision="bf16": the bf16 MFMA
     kernels of BASELINE config 5).  `coords` must be the regular pixel grid of (height, width) -- what Trainer.prepare_coords
     returns -- because the fused kernels rebuild it."""
     from .rendering import get_coords
-    if coords.shape[0] != height * width or not torch.equal(coords.to(torch.float32).cpu(), get_coords(width, height, "cpu")):
+    known = _REGULAR_GRIDS.get((coords.data_ptr(), tuple(coords.shape)))
+    if not (known is not None and known[:2] == (int(height), int(width))) and \
+            (coords.shape[0] != height * width or not torch.equal(coords.to(torch.float32).cpu(), get_coords(width, height, "cpu"))):
         raise ValueError("predict_lip_image with autograd supports the regular pixel grid of (height, width) only")
     if audio.shape[0] != 1:
         raise ValueError("predict_lip_image renders one frame: audio must be [1,16,29]")
     idx = int(index.reshape(-1)[0].item()) if isinstance(index, torch.Tensor) else int(index)
-    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), float(u01), precision, *model._hot_tensors())
+    u = u01 if isinstance(u01, torch.Tensor) and u01.is_cuda else float(u01)      # a device draw stays on the device
+    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), u, precision, *model._hot_tensors())
 
 
 class _Composite(torch.autograd.Function):

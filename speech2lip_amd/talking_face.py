@@ -173,8 +173,24 @@ class TalkingFace(nn.Module):
 
     # ------------------------------------------------------------------ weights
     def _hot_tensors(self):
-        sd = dict(self.named_parameters())
-        return [sd[name] for name in _abi.TENSOR_ORDER]
+        """The 42 hot-path parameters in the C-ABI's order.  The owning sub-modules' `_parameters` dictionaries are looked up once
+        (walking `named_parameters()` -- the U-Net's tree included -- cost 0.2 ms per call and a training step makes ~50); a
+        parameter that is re-assigned is still found (the dictionary is the module's own), a sub-module that is replaced at the
+        top level drops the cache (`__setattr__`)."""
+        cache = self.__dict__.get("_hot_cache")
+        if cache is None:
+            mods = dict(self.named_modules())
+            cache = []
+            for name in _abi.TENSOR_ORDER:
+                mod, _, attr = name.rpartition(".")
+                cache.append((mods[mod]._parameters, attr))
+            self.__dict__["_hot_cache"] = cache
+        return [d[a] for d, a in cache]
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Module):
+            self.__dict__.pop("_hot_cache", None)
+        super().__setattr__(name, value)
 
     def packed_weights(self) -> torch.Tensor:
         """Device blob in kernel layout; rebuilt whenever a parameter was modified in place,
@@ -208,7 +224,8 @@ class TalkingFace(nn.Module):
             pb = torch.empty(int(lib.s2l_bf16_packed_halves()), dtype=torch.int16, device=dev)
             with torch.cuda.device(dev):
                 _abi.check(lib.s2l_pack_bf16(table, _ptr(packed), _ptr(pb), _stream()), "s2l_pack_bf16")
-                torch.cuda.current_stream().synchronize()
+            # (no synchronisation: `holders` are the parameters themselves -- or, for a non-fp32 / non-contiguous parameter, blocks of
+            # the stream-ordered caching allocator, which cannot be handed to another stream before this launch has run)
             self._packed_bf16 = pb
         return self._packed_bf16
 

@@ -174,20 +174,30 @@ class Trainer:
         return SyncLoss(self.syncnet, syncnet_T).get_sync_contrastive_loss(mel, g_rgb_pos, g_rgb_neg, want_grad=want_grad)
 
     def prepare_coords(self, coord, b):
-        """training.py:253-261 (use_coords_mapping off): the regular pixel grid, tiled b times."""
+        """training.py:253-261 (use_coords_mapping off): the regular pixel grid, tiled b times.  The tensor is built once per
+        (width, height, b) and registered as a known regular grid, so the fused renderer need not compare it with
+        `get_coords` element by element on every call (callers must not write into it -- the May flags never do)."""
         from .rendering import get_coords
-        return get_coords(int(self.width), int(self.height), self.device).tile(b, 1)
+        from . import autograd
+        key = (int(self.width), int(self.height), int(b))
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        if key not in cache:
+            c = get_coords(key[0], key[1], self.device).tile(b, 1)
+            cache[key] = c
+            if b == 1:
+                autograd.register_regular_grid(c, key[1], key[0])
+        return cache[key]
 
     def predict_lip_image(self, i, coords, audio, pose, data, rgb_zero, lms, seed):
         """Same arguments as the reference method; `pose`, `rgb_zero`, `lms` are unused under the May flags exactly as
         there.  One chunk = the whole lip image (batch_rays = H*W).  Differentiable when autograd is recording."""
         chunk = coords[i:i + self.batch_rays, :]
         time_pts = data["index"] if seed is None else data["index"] + seed
-        u01 = float(torch.rand(1, device=self.device))          # eps_shift draw (training.py:200)
+        u01 = torch.rand(1, device=self.device)                 # eps_shift draw (training.py:200); it never leaves the device
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.model._hot_tensors()):
             from .autograd import predict_lip_image as predict_with_graph
             return predict_with_graph(self.model, chunk, audio, time_pts, self.height, self.width, u01, self.precision)[:, :3]
-        return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, u01)[:, :3]
+        return predict_lip_image(self.model, chunk, audio, time_pts, self.height, self.width, float(u01))[:, :3]
 
     def compute_rel_pose(self, canonical_euler, canonical_trans, euler, trans, img_batch_size=1, device=None):
         """training.py:263-268."""
@@ -319,6 +329,10 @@ class Trainer:
         if depth_v2:
             loss["loss_canonical_depth_photo"] = 0
         dev = self.device
+        # every tensor of the batch crosses to the device ONCE (the window loop below reads the canonical face, the mask and the
+        # 10-MB pose-grid window five times each)
+        data = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 16 else v)
+                for k, v in data.items()}
         on = lambda t: t.to(dev) if isinstance(t, torch.Tensor) else t
         H, W = self.height, self.width
         coords = self.prepare_coords(data.get("coord"), b)
@@ -392,8 +406,15 @@ class Trainer:
         if its crop code supported it, training.py:536-537).  The random draws are made frame by frame in `train_step`'s order,
         so K = 1 consumes the generators like one `train_step` call.  The canonical-depth photo loss is not part of this
         entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames."""
+        self.model.train()                                  # training.py:150, as train_step
+        if self.cfg["training"].get("stage", "stage1") != "stage1":
+            raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
+        return self.train_stage1_frames(batch, it=it, seed=seed)
+
+    def train_stage1_frames(self, batch, it=None, seed=None):
+        """`train_steps` without the `model.train()` of training.py:150 -- the K-frame counterpart of `train_stage1`: the
+        post-fusion U-Net runs in whatever mode it is in."""
         import random
-        self.model.train()
         tc, m, dev = self.cfg["training"], self.model, self.device
         if self.optimizer is None:
             raise ValueError("train_steps steps an optimizer: construct Trainer(model, optimizer=...)")

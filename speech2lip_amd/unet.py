@@ -61,15 +61,29 @@ class SimpleUnetLight(nn.Module):
         self._packed_key = None
 
     def _tensors(self):
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
-        out = []
-        for name, _, _ in UNET_CONVS:
-            head, idx = name.rsplit(".", 1)
-            bn = f"{head}.{int(idx) + 1}"
-            out += [sd[f"{name}.weight"], sd[f"{bn}.weight"], sd[f"{bn}.bias"], sd[f"{bn}.running_mean"],
-                    sd[f"{bn}.running_var"]]
-        return out + [sd["outc.conv.weight"], sd["outc.conv.bias"]]
+        """Weights, BatchNorm parameters and running statistics in the C-ABI's order (looked up through the owning modules' own
+        `_parameters` / `_buffers` dictionaries, found once: see TalkingFace._hot_tensors)."""
+        cache = self.__dict__.get("_tensor_cache")
+        if cache is None:
+            mods = dict(self.named_modules())
+
+            def slot(full):
+                mod, _, attr = full.rpartition(".")
+                m = mods[mod]
+                return (m._parameters if attr in m._parameters else m._buffers), attr
+            cache = []
+            for name, _, _ in UNET_CONVS:
+                head, idx = name.rsplit(".", 1)
+                bn = f"{head}.{int(idx) + 1}"
+                cache += [slot(f"{name}.weight"), slot(f"{bn}.weight"), slot(f"{bn}.bias"), slot(f"{bn}.running_mean"), slot(f"{bn}.running_var")]
+            cache += [slot("outc.conv.weight"), slot("outc.conv.bias")]
+            self.__dict__["_tensor_cache"] = cache
+        return [d[a] for d, a in cache]
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Module):
+            self.__dict__.pop("_tensor_cache", None)
+        super().__setattr__(name, value)
 
     def packed_weights(self) -> torch.Tensor:
         lib = _abi.load()
@@ -104,7 +118,7 @@ class SimpleUnetLight(nn.Module):
             with torch.cuda.device(dev):
                 _abi.check(lib.s2l_unet_pack16(table, ctypes.c_float(float(self.inc.double_conv[1].eps)), ctypes.c_void_p(packed16.data_ptr()),
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "s2l_unet_pack16")
-                torch.cuda.current_stream().synchronize()      # `hold` may be temporaries
+                # (no synchronisation: temporaries in `hold` are blocks of the stream-ordered caching allocator)
             self._packed16, self._packed16_key = packed16, key
         return self._packed16
 

@@ -52,7 +52,7 @@ def test_from8b_is_the_readers_conversion(dev):
 
 
 def test_train_steps_one_frame_reproduces_the_reference_step(golden, syncnet, dev):
-    """Trainer.train_steps with K = 1 on the G11 batch (it > 100000: frozen U-Net, sync window) and on the G14 batch (the U-Net
+    """Trainer.train_stage1_frames (= train_steps without training.py:150's model.train(), as train_stage1 is to train_step) with K = 1 on the G11 batch (it > 100000: frozen U-Net, sync window) and on the G14 batch (the U-Net
     trains): the loss dictionary and the gradients the REFERENCE's train_stage1 produced, at train_stage1's own tolerances; the
     random draws are consumed in train_step's order (six eps draws, the coin, two noise fields)."""
     g, data, eps, _, face = _g11_device(golden, dev)
@@ -60,7 +60,7 @@ def test_train_steps_one_frame_reproduces_the_reference_step(golden, syncnet, de
     tr = s2l.Trainer(m, torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True)
     restore = _patched_draws(eps, face["hole_noise"], dev)
     try:
-        loss_rgb, loss = tr.train_steps([data], it=100001)
+        loss_rgb, loss = tr.train_stage1_frames([data], it=100001)
     finally:
         eq, fq = restore()
     assert not eq and not fq
@@ -76,7 +76,7 @@ def test_train_steps_one_frame_reproduces_the_reference_step(golden, syncnet, de
     tr = s2l.Trainer(m, torch.optim.SGD(m.parameters(), lr=0.0), cfg=_cfg(m), syncnet=syncnet, use_syncloss=True)
     restore = _patched_draws(e["eps"], face["hole_noise"], dev)
     try:
-        _, loss = tr.train_steps([dict(data, rgb_face_ori=T(e["rgb_face_ori"]))], it=50000)
+        _, loss = tr.train_stage1_frames([dict(data, rgb_face_ori=T(e["rgb_face_ori"]))], it=50000)
     finally:
         eq, fq = restore()
     assert not fq and "loss_sync" not in loss          # (the window's five draws are not made before it > 100000)
