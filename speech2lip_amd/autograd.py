@@ -104,13 +104,15 @@ class _PredictLipImage(torch.autograd.Function):
     def forward(ctx, model, audio, index, height, width, u01, precision, *params):
         from .training import LipTrainStep
         step = LipTrainStep(model, height, width, precision)
-        pred = step.forward(audio, [index], u01 if isinstance(u01, torch.Tensor) else [u01])
-        ctx.step = step
-        return pred[0]
+        many = isinstance(index, (list, tuple))
+        pred = step.forward(audio, list(index) if many else [index], u01 if isinstance(u01, torch.Tensor) else ([u01] if not many else u01))
+        ctx.step, ctx.many = step, many
+        return pred if many else pred[0]
 
     @staticmethod
     def backward(ctx, dpred):
-        g, _ = ctx.step.backward(dpred.contiguous().float()[None])
+        d = dpred.contiguous().float()
+        g, _ = ctx.step.backward(d if ctx.many else d[None])
         ctx.step = None
         return (None, None, None, None, None, None, None, *[g[n] for n in _abi.TENSOR_ORDER])
 
@@ -137,6 +139,22 @@ def predict_lip_image(model, coords, audio, index, height, width, u01, precision
         raise ValueError("predict_lip_image renders one frame: audio must be [1,16,29]")
     idx = int(index.reshape(-1)[0].item()) if isinstance(index, torch.Tensor) else int(index)
     u = u01 if isinstance(u01, torch.Tensor) and u01.is_cuda else float(u01)      # a device draw stays on the device
+    return _PredictLipImage.apply(model, audio, idx, int(height), int(width), u, precision, *model._hot_tensors())
+
+
+def predict_lip_images(model, coords, audio, indices, height, width, u01, precision="fp32"):
+    """`predict_lip_image` for B frames in one call: audio [B,16,29], B frame indices, B draws (a device tensor or floats) ->
+    [B,HW,3].  Every frame's rows are what its own call would compute (the rows of a frame never mix with another's); one MLP
+    forward / backward instead of B, which is what makes a 5-frame sync window cost one launch set."""
+    from .rendering import get_coords
+    known = _REGULAR_GRIDS.get((coords.data_ptr(), tuple(coords.shape)))
+    if not (known is not None and known[:2] == (int(height), int(width))) and \
+            (coords.shape[0] != height * width or not torch.equal(coords.to(torch.float32).cpu(), get_coords(width, height, "cpu"))):
+        raise ValueError("predict_lip_images with autograd supports the regular pixel grid of (height, width) only")
+    idx = [int(i) for i in indices]
+    if audio.shape[0] != len(idx):
+        raise ValueError("predict_lip_images: one audio window per frame index")
+    u = u01 if isinstance(u01, torch.Tensor) and u01.is_cuda else [float(v) for v in u01]
     return _PredictLipImage.apply(model, audio, idx, int(height), int(width), u, precision, *model._hot_tensors())
 
 
@@ -184,8 +202,10 @@ class _UnetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, unet, x, precision, *params):
         ctx.need_params = any(p_.requires_grad for p_ in params)
-        ctx.unet, ctx.need_dx, ctx.route = unet, x.requires_grad, precision != "fp32"
-        if ctx.route:      # bf16: the mode-following frames route (half-width tensors; the bits of one call per frame)
+        # the mode-following frames route (every frame its own statistics group: the bits of one call per frame) for bf16 (half-width
+        # tensors) and for several frames in one call; one fp32 frame keeps the original one-frame kernels
+        ctx.unet, ctx.need_dx, ctx.route = unet, x.requires_grad, precision != "fp32" or x.shape[0] > 1
+        if ctx.route:
             out, ctx.saved = unet.forward_for_backward(x, precision=precision)
             return out
         out, saved = unet.forward_train_nhwc(x, update_running=True)

@@ -363,16 +363,19 @@ class Trainer:
         if self.use_syncloss and it is not None and it > 100000 and tc.get("stage", "stage1") == "stage1":
             from .autograd import crop_resize
             total = int(data["total_frame"].reshape(-1)[0]) if isinstance(data["total_frame"], torch.Tensor) else int(data["total_frame"])
-            window = []
-            for t in range(int(data["audio_window"].shape[1])):
-                cur = {"index": torch.tensor([min(first + t, total - 1)]), "total_frame": data["total_frame"]}
-                lip = self.predict_lip_image(0, self.prepare_coords(None, b), on(data["audio_window"])[:, t], None, cur, None, None,
-                                             seed=seed).reshape(1, H, W, 3)
-                merged, _, _ = m.post_fusion2_onlylip(lip, on(data["rgb_face_zero"]), on(data["rgb_face_ori"]), on(data["mask_lip_canonical"]),
-                                                      x0, y0, on(data["coord_window"])[:, t], use_canonical_space=False)
-                bbox = data["canonical_face_bbox"][0] if isinstance(data["canonical_face_bbox"], torch.Tensor) else data["canonical_face_bbox"]
-                window.append(crop_resize(merged, [float(v) for v in bbox], (96, 96)).unsqueeze(0))
-            rgb_window = torch.cat(window, 0).permute(1, 4, 0, 2, 3)       # T,B,H,W,C -> B,C,T,H,W (:547-548)
+            # the T window frames in ONE call each of the renderer, the composite + U-Net and the crop: every frame is what its own
+            # call (training.py:504-548, one after the other) computes -- the draws are made in that loop's order, the train-mode
+            # U-Net treats each frame as its own statistics group in frame order -- at a fifth of the launches
+            from .autograd import predict_lip_images
+            Tn = int(data["audio_window"].shape[1])
+            u_win = torch.cat([torch.rand(1, device=dev) for _ in range(Tn)])            # eps_shift of each render (training.py:200)
+            idxs = [min(first + t, total - 1) + (0 if seed is None else int(seed)) for t in range(Tn)]
+            lips = predict_lip_images(m, self.prepare_coords(None, b), on(data["audio_window"])[0], idxs, H, W, u_win, self.precision)
+            gt_f = on(data["rgb_face_ori"]).expand(Tn, -1, -1, -1)
+            merged, _, _ = m.post_fusion2_onlylip(lips[:, :, :3].reshape(Tn, H, W, 3), on(data["rgb_face_zero"]), gt_f, on(data["mask_lip_canonical"]),
+                                                  x0, y0, on(data["coord_window"])[0], use_canonical_space=False)
+            bbox = data["canonical_face_bbox"][0] if isinstance(data["canonical_face_bbox"], torch.Tensor) else data["canonical_face_bbox"]
+            rgb_window = crop_resize(merged, [float(v) for v in bbox], (96, 96), window_t=Tn)      # [B,C,T,H,W] (:547-548)
             loss_sync = self.get_sync_contrastive_loss(on(data["mel"]), rgb_window, on(data["rgb_window_neg"])) * self.w_syncloss
             loss["loss_sync"] = loss["loss_sync"] + loss_sync
             loss["loss"] = loss["loss"] + loss_sync

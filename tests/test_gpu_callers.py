@@ -160,7 +160,7 @@ def test_trainer_bf16_and_device_noise(golden, syncnet, dev):
                      precision="bf16")
     restore = _patched_draws(eps, face["hole_noise"], dev)
     try:
-        _, loss = tr.train_step(data, it=100001)
+        _, loss = tr.train_stage1(data, it=100001)      # (G11 is train_stage1 itself: the frozen U-Net in eval mode)
     finally:
         restore()
     assert abs(float(loss["loss"]) - float(g["loss"])) <= 2e-2 * abs(float(g["loss"]))
