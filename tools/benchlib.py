@@ -605,10 +605,12 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
     write_synthetic_dataset(root, n_frames, train=True)
     cfg = s2l.may_config(96, 96, data_path=root, train_flags=True)
     cfg["model"]["use_canonical_depth"] = False
-    cfg["training"].update(use_sync_contrastive_loss=True, use_perceptual_loss=False, use_canonical_depth_loss_photo_v2=False,
+    cfg["training"].update(use_sync_contrastive_loss=True, use_perceptual_loss=True, use_canonical_depth_loss_photo_v2=False,
                            use_syncloss=True)
     ds = s2l.SomeonesLipClip(root, "train", cfg=cfg)
     n = len(ds)
+    lp = s2l.LPIPS(pretrained=False, net="alex", version="0.1").to(dev)      # seeded weights (the real ones are not in the reference repo)
+    lp.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_lpips_state_dict(0).items()})
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     for p in net.parameters():
@@ -627,7 +629,7 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
                 p.requires_grad = False
             m.post_fusion_unet.eval()
         opt = torch.optim.Adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
-        return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, precision="bf16", hole_noise=hole_noise)
+        return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, perceptual_loss_fn=lp, precision="bf16", hole_noise=hole_noise)
 
     def run(tr, it0, batches, per_step):
         torch.cuda.synchronize()
@@ -646,7 +648,7 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         busy = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
-        return {"ms_per_frame": round(wall / (k * per_step) * 1e3, 3), "gpu_span_share": round(busy / wall, 3)}
+        return {"ms_per_frame": round(wall / (k * per_step) * 1e3, 3), "gpu_span_share": round(busy / wall, 3), "frames_per_step": per_step}
 
     for phase, it0 in (("it_le_100000", 1000), ("it_gt_100000", 100001)):
         late = it0 > 100000
