@@ -200,15 +200,18 @@ def unet_eval(unet, x_nhwc, precision="fp32"):
 
 class _UnetTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, unet, x, precision, *params):
+    def forward(ctx, unet, x, precision, frames, *params):
         ctx.need_params = any(p_.requires_grad for p_ in params)
-        # the mode-following frames route (every frame its own statistics group: the bits of one call per frame) for bf16 (half-width
-        # tensors) and for several frames in one call; one fp32 frame keeps the original one-frame kernels
-        ctx.unet, ctx.need_dx, ctx.route = unet, x.requires_grad, precision != "fp32" or x.shape[0] > 1
+        # `frames`: every frame of x is its own statistics group, as if the net had been called once per frame in frame order (the
+        # mode-following frames route of forward_for_backward: the bits of those calls) -- what train_stage1's batched sync window
+        # asks for.  Otherwise x is ONE batch, statistics over all of it, as calling the module means in the reference; one bf16
+        # frame is the same thing either way and takes the half-width chain of the frames route
+        ctx.unet, ctx.need_dx = unet, x.requires_grad
+        ctx.route = bool(frames) or (precision != "fp32" and x.shape[0] == 1)
         if ctx.route:
             out, ctx.saved = unet.forward_for_backward(x, precision=precision)
             return out
-        out, saved = unet.forward_train_nhwc(x, update_running=True)
+        out, saved = unet.forward_train_nhwc(x, update_running=True, precision=precision)
         ctx.saved = saved
         return out
 
@@ -222,15 +225,17 @@ class _UnetTrain(torch.autograd.Function):
         else:
             dx, grads = ctx.unet.backward_train(ctx.saved, d_out, want_input_grad=ctx.need_dx, want_param_grads=ctx.need_params)
         ctx.saved = None
-        return (None, dx, None, *[grads.get(n) if ctx.need_params else None for n in ctx.unet.grad_names()])
+        return (None, dx, None, None, *[grads.get(n) if ctx.need_params else None for n in ctx.unet.grad_names()])
 
 
-def unet_train(unet, x_nhwc, precision="fp32"):
+def unet_train(unet, x_nhwc, precision="fp32", frames=False):
     """Post-fusion U-Net in TRAIN mode (BatchNorm batch statistics, running statistics updated) with gradients for its input
     and every parameter -- the network as the reference trains it until `it > 100000` (train.py:188-197).  precision "bf16":
-    bf16 operands and tensors between the kernels (the half-width chain of csrc/unet_half.inc)."""
+    bf16 operands (and, for one frame or `frames`, bf16 tensors between the kernels: the half-width chain of csrc/unet_half.inc).
+    frames=True: each frame of x is normalised with its own statistics and moves the running statistics once, in frame order --
+    x.shape[0] successive one-frame calls in one set of launches."""
     params = dict(unet.named_parameters())
-    return _UnetTrain.apply(unet, x_nhwc, precision, *[params[n] for n in unet.grad_names()])
+    return _UnetTrain.apply(unet, x_nhwc, precision, bool(frames), *[params[n] for n in unet.grad_names()])
 
 
 class _CropResize(torch.autograd.Function):

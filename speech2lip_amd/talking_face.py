@@ -301,7 +301,7 @@ class TalkingFace(nn.Module):
 
     def post_fusion2_onlylip(self, rgb_lip_warped, rgb_face_canonical, rgb_gt, mask_lip_canonical, lip_lefttop_x,
                              lip_lefttop_y, coord, use_canonical_space=False, change_pose=-1, mask_face_canonical=None,
-                             wav2lip=None, mask_head_observed=None, use_post_fusion_blackaug=False):
+                             wav2lip=None, mask_head_observed=None, use_post_fusion_blackaug=False, _frames_as_calls=False):
         """Paste the lip into the canonical face, warp by `coord`, blend with the observed frame.
         Reference: tf_nerf.py:287-304 -> post_fusion2_onlylip_light :320-389.
         Returns (rgb_recon, rgb_merged_new, rgb_merged_canonical), all [B,FH,FW,3]; rgb_recon is the post-fusion U-Net
@@ -333,7 +333,8 @@ class TalkingFace(nn.Module):
         if unet.training:
             if torch.is_grad_enabled():
                 from .autograd import unet_train
-                return unet_train(unet, new, prec), new, can
+                # (_frames_as_calls: B frames standing for B successive one-frame calls -- Trainer.train_stage1's sync window)
+                return unet_train(unet, new, prec, frames=_frames_as_calls), new, can
             return unet.forward_train_nhwc(new, update_running=True)[0], new, can
         if graph:
             from .autograd import unet_eval

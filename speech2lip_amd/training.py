@@ -373,7 +373,7 @@ class Trainer:
             lips = predict_lip_images(m, self.prepare_coords(None, b), on(data["audio_window"])[0], idxs, H, W, u_win, self.precision)
             gt_f = on(data["rgb_face_ori"]).expand(Tn, -1, -1, -1)
             merged, _, _ = m.post_fusion2_onlylip(lips[:, :, :3].reshape(Tn, H, W, 3), on(data["rgb_face_zero"]), gt_f, on(data["mask_lip_canonical"]),
-                                                  x0, y0, on(data["coord_window"])[0], use_canonical_space=False)
+                                                  x0, y0, on(data["coord_window"])[0], use_canonical_space=False, _frames_as_calls=True)
             bbox = data["canonical_face_bbox"][0] if isinstance(data["canonical_face_bbox"], torch.Tensor) else data["canonical_face_bbox"]
             rgb_window = crop_resize(merged, [float(v) for v in bbox], (96, 96), window_t=Tn)      # [B,C,T,H,W] (:547-548)
             loss_sync = self.get_sync_contrastive_loss(on(data["mel"]), rgb_window, on(data["rgb_window_neg"])) * self.w_syncloss

@@ -497,6 +497,8 @@ class SimpleUnetLight(nn.Module):
             group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
             if getattr(self, "train_frames_per_group", None):
                 group = max(1, min(F_, int(self.train_frames_per_group)))
+            if precision == "bf16h":
+                group = min(group, 8191)      # the half-width entry points take at most 8191 frames per call (S2L_E_SIZE beyond)
             outs, ctxs = [], []
             for s0 in range(0, F_, group):
                 o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)
@@ -513,6 +515,8 @@ class SimpleUnetLight(nn.Module):
                 precision = "bf16h"      # (bf16 tensors between the kernels, weight gradients straight from the bf16 planes)
             per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
             group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
+            if precision == "bf16h":
+                group = min(group, 8191)
             outs, ctxs = [], []
             for s0 in range(0, F_, group):
                 o, c = self.forward_train_frames_nhwc(x[s0:s0 + group], update_running=True, precision=precision)
