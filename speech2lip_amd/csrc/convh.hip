@@ -166,7 +166,29 @@ __global__ __launch_bounds__(512) void convh8_relu_asm_kernel(ConvHArgs a) {
 #include "convh8r_body.inc"
 }
 
-static std::atomic<int> g_convh_kind{0};      // 0: eight waves, 1: four waves (s2l_set_unet_half_kernel)
+// The alternating-roles form (gen_convhx_body.py): the same tile and the same per-lane constants as the eight-wave form, the two waves of a
+// SIMD taking turns between an MFMA-only segment and a load / request / epilogue segment.  Same arithmetic in the same order: the same bits.
+// No gate input (gated launches keep the interleaved kernel).
+__global__ __launch_bounds__(512) void convhx_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  ConvH8Ctx c;
+  if (!convh8_prologue(a, ch_smem, c)) return;
+  const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
+  const uint32_t lds0 = c.lds0;
+#include "convhx_body.inc"
+}
+__global__ __launch_bounds__(512) void convhx_relu_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  ConvH8Ctx c;
+  if (!convh8_prologue(a, ch_smem, c)) return;
+  const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
+  const uint32_t lds0 = c.lds0;
+#include "convhxr_body.inc"
+}
+
+static std::atomic<int> g_convh_kind{0};      // 0: alternating roles (gated launches: eight waves interleaved), 1: four waves, 2: eight waves interleaved (s2l_set_unet_half_kernel)
 
 // 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
 // (<= 256), tensors small enough for 31-bit pixel indices over all their planes.
@@ -188,8 +210,16 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
-  static LdsOptIn flag4, flag8, flag8r;
-  if (four) {
+  static LdsOptIn flag4, flag8, flag8r, flagx, flagxr;
+  const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 0 && a.gate == nullptr;
+  if (alternating) {
+    const void* fn = a.relu ? reinterpret_cast<const void*>(convhx_relu_asm_kernel) : reinterpret_cast<const void*>(convhx_asm_kernel);
+    if ((rc = ensure_dynamic_lds(fn, kCHLds, a.relu ? flagxr : flagx, dev))) return rc;
+    if (a.relu)
+      hipLaunchKernelGGL(convhx_relu_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
+    else
+      hipLaunchKernelGGL(convhx_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
+  } else if (four) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag4, dev))) return rc;
     hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
   } else if (a.relu) {
@@ -242,10 +272,10 @@ extern "C" int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s
   return (int)hipGetLastError();
 }
 
-// Which form runs the half-width convolutions: 0 (default) eight waves per workgroup, 1 four.  Same arithmetic in the same order: the same
-// bits (a test aid).
+// Which form runs the half-width convolutions: 0 (default) eight waves in alternating roles (gated launches: eight waves interleaved),
+// 1 four waves, 2 eight waves interleaved everywhere.  Same arithmetic in the same order: the same bits (a test aid).
 extern "C" int s2l_set_unet_half_kernel(int kind) {
-  if (kind != 0 && kind != 1) return S2L_E_SIZE;
+  if (kind < 0 || kind > 2) return S2L_E_SIZE;
   s2l::g_convh_kind.store(kind, std::memory_order_relaxed);
   return S2L_OK;
 }

@@ -81,6 +81,8 @@ def s2(n):
 
 
 class Body:
+    pfx = None                                                      # label prefix; None: the module's PFX (gen_convhx_body.py sets its own)
+
     def __init__(self):
         self.L, self.lds, self.nlabel = [], [], 0
 
@@ -89,7 +91,7 @@ class Body:
 
     def label(self, stem):
         self.nlabel += 1
-        return f"{PFX}_{stem}_{self.nlabel}"
+        return f"{self.pfx or PFX}_{stem}_{self.nlabel}"
 
     def lds_op(self, text, tag):
         self.e(text)
@@ -471,10 +473,11 @@ class Body:
         self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
 
 
-def generate():
-    b = Body()
+def emit_prologue(b, with_gate=True):
+    """everything before the tile loop: arguments, per-lane constants, the bias table, chunk 0 of the first tile staged into buffer 0
+    (shared with csrc/gen_convhx_body.py, whose register map is this one's without the gate pieces)"""
     e = b.e
-    # ================= prologue
+    PFX_ = b.pfx or PFX
     e(f"s_mov_b64 {s2('KARG')}, %[karg]")
     for dst, src in (("WAVE", "wave"), ("LDS0", "lds0"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"), ("FR", "fr0"), ("NTL", "ntl")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
@@ -511,7 +514,7 @@ def generate():
     e(f"v_mov_b32 v{V_FFFF}, -1")
     for k in range(4):
         e(f"v_mov_b32 v{V_Z + k}, 0")
-    for k in range(16 * NB):
+    for k in range(16 * NB if with_gate else 0):
         e(f"v_mov_b32 v{V_G + k}, 0x3f803f80")                          # no gate: every half passes
     e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 12")
     e(f"v_add_u32 v{V_DMA}, {s('T0')}, v{V_T}")                         # this lane's 16 B of the wave's four 1-KiB weight pieces 4 w .. (global offset)
@@ -566,12 +569,12 @@ def generate():
     e(f"v_mov_b32 v{V_T + 1}, 0")
     e(f"s_mov_b64 {s2('EX')}, exec")
     e(f"s_cmp_eq_u64 {s2('BIAS')}, 0")
-    e(f"s_cbranch_scc1 {PFX}_NOBIAS")
+    e(f"s_cbranch_scc1 {PFX_}_NOBIAS")
     e("s_and_b64 exec, exec, vcc")
     e(f"global_load_dword v{V_T + 1}, v{V_T}, {s2('BIAS')}")
     e(f"s_mov_b64 exec, {s2('EX')}")
     e("s_waitcnt vmcnt(0)")
-    e(f"{PFX}_NOBIAS:")
+    e(f"{PFX_}_NOBIAS:")
     e(f"s_add_u32 {s('T0')}, {s('LDS0')}, {BIAS_OFF}")
     e(f"v_add_u32 v{V_T}, {s('T0')}, v{V_T}")
     e(f"ds_write_b32 v{V_T}, v{V_T + 1}")
@@ -593,6 +596,11 @@ def generate():
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
 
+
+def generate():
+    b = Body()
+    e = b.e
+    emit_prologue(b)
     # ================= tile loop
     e(f"{PFX}_TILE:")
     b.tile_begin()

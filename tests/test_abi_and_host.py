@@ -90,7 +90,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_unet_backward_h(one, one, one, one, one, null, 8, 8, 8, 8, 0, 0, 1, null) == -1
     assert lib.s2l_convh_layer(one, 0, 0, one, 64, null, 0, null, one, 8, 8, 1, null) == -2                                  # layer 0 is the fp32-input convolution
     assert lib.s2l_convh_layer(one, 1, 0, one, 32, null, 0, null, one, 8, 8, 1, null) == -2                                  # channel count of the layer
-    assert lib.s2l_set_unet_half_kernel(2) == -2 and lib.s2l_set_unet_half_kernel(0) == 0
+    assert lib.s2l_set_unet_half_kernel(3) == -2 and lib.s2l_set_unet_half_kernel(0) == 0
     assert lib.s2l_unet_train_frames_h_saved_halves(8, 8, 0) == 0 and lib.s2l_unet_train_frames_h_saved_halves(500, 500, 1) > 2 * 10 ** 8
     assert lib.s2l_unet_saved_h_halves(500, 500, 1) == lib.s2l_unet_saved_floats(500, 500, 1)
     # F one-frame calls in one set of launches (every frame its own statistics group)

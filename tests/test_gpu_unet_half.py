@@ -82,9 +82,11 @@ def test_convolution_is_the_rounded_fp32_tensor_kernel(blobs, dev, layer, transp
 
 
 @pytest.mark.parametrize("layer,transposed,F,H,Wd,gate", [(1, 0, 2, 40, 40, False), (9, 1, 1, 33, 17, True), (6, 0, 2, 37, 53, False), (3, 1, 1, 125, 125, True),
-                                                          (8, 0, 2, 500, 500, False)])
+                                                          (8, 0, 2, 500, 500, False), (2, 0, 3, 250, 250, False), (4, 1, 2, 125, 125, False), (7, 0, 1, 16, 32, False),
+                                                          (5, 0, 5, 70, 41, False)])
 def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, transposed, F, H, Wd, gate):
-    """s2l_set_unet_half_kernel: 0 = eight waves per workgroup (default), 1 = four; same arithmetic in the same order."""
+    """s2l_set_unet_half_kernel: 0 = eight waves in alternating roles (default; gated launches: interleaved), 1 = four waves,
+    2 = eight waves interleaved; same arithmetic in the same order."""
     _, raw, raw16 = blobs
     lib = _abi.load()
     g = torch.Generator(device="cpu").manual_seed(7 * layer + H)
@@ -99,7 +101,7 @@ def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, tr
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     outs = []
     try:
-        for kind in (0, 1, 0):
+        for kind in (0, 1, 2, 0):
             assert lib.s2l_set_unet_half_kernel(kind) == 0
             out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
             _abi.check(lib.s2l_convh_layer(p(raw16), layer, transposed, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "s2l_convh_layer")
@@ -107,8 +109,8 @@ def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, tr
         torch.cuda.synchronize()
     finally:
         lib.s2l_set_unet_half_kernel(0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    assert lib.s2l_set_unet_half_kernel(2) == -2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert lib.s2l_set_unet_half_kernel(3) == -2
 
 
 def test_convolution_argument_errors(blobs, dev):
