@@ -451,9 +451,10 @@ int s2l_debug_conv_wgrad_h(const uint16_t* dz, const uint16_t* inA, int CA, cons
 /* Measurement aid (tools/ubench_mfma.py): `waves` (4 or 8) waves per CU each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 on
  * registers and nothing else -- the rate the chip sustains under that load (the clock drops below its 2.4 GHz peak). */
 int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream);
-/* Which form of the half-width convolution runs: 0 (default) eight waves per workgroup, the two waves of a SIMD alternating between an
- * MFMA-only segment and a load / request / epilogue segment (csrc/gen_convhx_body.py; launches with a gate input take form 2),
- * 1 four waves (one per SIMD), 2 eight waves that each interleave loads and MFMAs (round 4's default).
+/* Which form of the half-width convolution runs: 0 (default) eight waves per workgroup (two per SIMD), each interleaving its loads with its
+ * MFMAs, 1 four waves (one per SIMD), 2 eight waves with the two waves of a SIMD alternating between an MFMA-only segment and a load /
+ * epilogue segment (csrc/gen_convhx_body.py; launches with a gate input run as 0) -- measured equal to form 0 within +-3 %: the kernel is
+ * bound by the CU's vector-memory path, not by its instruction schedule (docs/LABNOTES.md §10).
  * Same arithmetic in the same order: the outputs are the same bits (a test aid).  Any other value: S2L_E_SIZE. */
 int s2l_set_unet_half_kernel(int kind);
 

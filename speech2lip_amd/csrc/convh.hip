@@ -95,6 +95,7 @@ struct ConvH8Ctx {
   int tx0, ty0, ct0, fr0, ntl, wave;
   uint32_t lds0;
 };
+template <int STAGE_OFF = kCHBuf>      // where the eight waves' 4-KiB store-staging blocks start (convh8: buffer 1's halo area)
 __device__ __forceinline__ bool convh8_prologue(const ConvHArgs& a, char* smem, ConvH8Ctx& c) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -134,7 +135,7 @@ __device__ __forceinline__ bool convh8_prologue(const ConvHArgs& a, char* smem, 
       const int col = pcol + dx, row = 4 * wave + prow;
       cst[(5 + dx * 2 + ks) * 512 + tid] = lds0 + (uint32_t)((row * 18 + col) * 64 + (((2 * ks + hh_) ^ ((col >> 2) & 3)) << 4));
     }
-  const uint32_t stg = lds0 + kCHBuf + wave * 4096;      // 8 x 4 KiB of buffer 1's halo area
+  const uint32_t stg = lds0 + STAGE_OFF + wave * 4096;      // 8 x 4 KiB
   const int pix = 16 * prow + pcol;
 #pragma unroll
   for (int pc = 0; pc < 8; ++pc)
@@ -168,12 +169,15 @@ __global__ __launch_bounds__(512) void convh8_relu_asm_kernel(ConvHArgs a) {
 
 // The alternating-roles form (gen_convhx_body.py): the same tile and the same per-lane constants as the eight-wave form, the two waves of a
 // SIMD taking turns between an MFMA-only segment and a load / request / epilogue segment.  Same arithmetic in the same order: the same bits.
-// No gate input (gated launches keep the interleaved kernel).
+// No gate input (gated launches keep the interleaved kernel).  Store staging: buffer 1's WEIGHT area (32 of its 36 KiB), so that the next
+// tile's halo requests into buffer 1 can leave while the partner group is still in its epilogue.
+constexpr int kCHStageX = kCHBuf + kCHHalo;
+static_assert(8 * 4096 <= kCHW, "the staging blocks fit the weight area");
 __global__ __launch_bounds__(512) void convhx_asm_kernel(ConvHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ch_smem[];
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
   ConvH8Ctx c;
-  if (!convh8_prologue(a, ch_smem, c)) return;
+  if (!convh8_prologue<kCHStageX>(a, ch_smem, c)) return;
   const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
   const uint32_t lds0 = c.lds0;
 #include "convhx_body.inc"
@@ -182,13 +186,13 @@ __global__ __launch_bounds__(512) void convhx_relu_asm_kernel(ConvHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ch_smem[];
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
   ConvH8Ctx c;
-  if (!convh8_prologue(a, ch_smem, c)) return;
+  if (!convh8_prologue<kCHStageX>(a, ch_smem, c)) return;
   const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
   const uint32_t lds0 = c.lds0;
 #include "convhxr_body.inc"
 }
 
-static std::atomic<int> g_convh_kind{0};      // 0: alternating roles (gated launches: eight waves interleaved), 1: four waves, 2: eight waves interleaved (s2l_set_unet_half_kernel)
+static std::atomic<int> g_convh_kind{0};      // 0: eight waves interleaved, 1: four waves, 2: eight waves in alternating roles (gated launches: 0) (s2l_set_unet_half_kernel)
 
 // 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
 // (<= 256), tensors small enough for 31-bit pixel indices over all their planes.
@@ -211,7 +215,7 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
   static LdsOptIn flag4, flag8, flag8r, flagx, flagxr;
-  const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 0 && a.gate == nullptr;
+  const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 2 && a.gate == nullptr;
   if (alternating) {
     const void* fn = a.relu ? reinterpret_cast<const void*>(convhx_relu_asm_kernel) : reinterpret_cast<const void*>(convhx_asm_kernel);
     if ((rc = ensure_dynamic_lds(fn, kCHLds, a.relu ? flagxr : flagx, dev))) return rc;
@@ -272,8 +276,9 @@ extern "C" int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s
   return (int)hipGetLastError();
 }
 
-// Which form runs the half-width convolutions: 0 (default) eight waves in alternating roles (gated launches: eight waves interleaved),
-// 1 four waves, 2 eight waves interleaved everywhere.  Same arithmetic in the same order: the same bits (a test aid).
+// Which form runs the half-width convolutions: 0 (default) eight waves per workgroup, each interleaving loads and MFMAs, 1 four waves,
+// 2 eight waves in alternating roles (gen_convhx_body.py; gated launches run as 0).  Same arithmetic in the same order: the same bits (a test
+// aid).  Form 2 was built to test whether the schedule inside a CU bounds this kernel: it does not (same time to +-3 %: LABNOTES §10).
 extern "C" int s2l_set_unet_half_kernel(int kind) {
   if (kind < 0 || kind > 2) return S2L_E_SIZE;
   s2l::g_convh_kind.store(kind, std::memory_order_relaxed);

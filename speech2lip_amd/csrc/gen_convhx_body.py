@@ -11,11 +11,12 @@ what NO wave covers: all eight waves reach the epilogue, the barrier behind it, 
 Here every such phase of one wave sits beside 768 cycles of its partner's MFMAs.
 
 Per chunk (one 32-channel plane, buffer p) and per SIMD, six barrier-separated intervals:
-    leader    L0 | C0 | L1 + halo DMA | C1 | L2 + weight DMA | C2, vmcnt(0)
-    follower  C2'| L0 + weight DMA | C0 | L1 + halo DMA | C1 | L2, vmcnt(0)            (C2' = the previous chunk's last segment)
-Lk reads the operands of taps 3k .. 3k+2 (96 AGPRs, no double buffering: a wave never loads while it computes); DMA requests go to buffer
-p ^ 1 from the second interval on (the first two intervals of a tile's first chunk are the two groups' epilogues, whose store staging is
-buffer 1's halo area); every wave drains vmcnt before the barrier that ends the chunk's last interval.  Barriers: leader 6 per chunk + 1 after
+    leader    L0 + halo DMA | C0 | L1 + weight DMA | C1 | L2 | C2, vmcnt(0)
+    follower  C2'| L0 + halo DMA | C0 | L1 + weight DMA | C1 | L2, vmcnt(0)            (C2' = the previous chunk's last segment)
+Lk reads the operands of taps 3k .. 3k+2 (96 AGPRs, no double buffering: a wave never loads while it computes); the next chunk's halo
+requests (HBM / L2 latency) leave in a group's FIRST load interval -- buffer p ^ 1's halo area is free from the chunk's first barrier on --
+its weight requests (L2-hot) in the second: at a tile's first chunk the first two intervals hold the two groups' epilogues, whose store
+staging is buffer 1's WEIGHT area (csrc/convh.hip: kCHStageX); every wave drains vmcnt before the barrier that ends the chunk's last interval.  Barriers: leader 6 per chunk + 1 after
 its last epilogue, follower 1 before its first chunk + 6 per chunk -- the same count, pairwise aligned.
 
 Register map: gen_convh8_body.py's without the gate pieces (the launcher sends gated launches -- the eval-mode chain's input gradients -- to the
@@ -31,6 +32,7 @@ OPS = (64, 96, 128)
 A_LAST, V_LAST = 159, G.V_G - 1
 s, s2, S = G.s, G.s2, G.S
 WITH_RELU = False
+DMA_IN_COMPUTE = os.environ.get("S2L_CHX_DMA", "compute") == "compute"      # where a wave issues its LDS-DMA requests: among its MFMAs | among its reads
 
 
 class BodyX(G.Body):
@@ -74,9 +76,22 @@ class BodyX(G.Body):
             x += 1
         self.wait_all_lds()
 
-    def compute_seg(self):
+    def compute_seg(self, extra=()):
+        """the 24 MFMAs of three taps; `extra` (instruction groups: this wave's DMA requests) behind every fourth one"""
+        extra = list(extra)
+        if G.EXP & 2048:                                             # (ablation: no MFMAs)
+            for g in extra:
+                self.emit_group(g)
+            self.wait_all_lds()
+            return
         for k in range(3):
-            self.tap_mfmas(k, [[] for _ in range(8)])
+            sprinkle = [[] for _ in range(8)]
+            for m in (2, 6):
+                if extra:
+                    sprinkle[m] = extra.pop(0)
+            self.tap_mfmas(k, sprinkle)
+        assert not extra
+        self.wait_all_lds()                                           # (the zeroes of border slots)
 
     def store_tile_nogate(self):
         """gen_convh8_body.py's store_tile without the gate: accumulators -> bf16 -> this wave's 4 KiB of LDS staging -> whole 1-KiB rows"""
@@ -99,30 +114,49 @@ class BodyX(G.Body):
             self.wait_all_lds()
             for j in range(4):
                 self.row_exec(2 * nb + (j >> 1), j & 1, "OUTF", nb == 0 and j == 0)
-                e(f"global_store_dwordx4 v{G.V_VS}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
+                if not G.EXP & 1:
+                    e(f"global_store_dwordx4 v{G.V_VS}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
             e("s_mov_b64 exec, -1")
 
     def epilogue(self):
         e = self.e
         e("s_nop 7")
         e("s_nop 7")                                                  # (MFMA results -> v_accvgpr_read)
-        self.store_tile_nogate()
+        if not G.EXP & 512:
+            self.store_tile_nogate()
         self.next_coords("", "CT")
 
     # ---- the two streams' chunk slots
     def leader_chunk(self, p):
         e = self.e
-        self.load_seg(0, p, [])
-        e("s_barrier")
-        self.compute_seg()
-        e("s_barrier")
+        if DMA_IN_COMPUTE:
+            self.load_seg(0, p, [])
+            e("s_barrier")
+            self.staging_source()
+            self.compute_seg(self.halo_items(p ^ 1))                  # (a request costs ~60 cycles of issue among MFMAs, 100-185 among reads)
+            e("s_barrier")
+            self.load_seg(1, p, [])
+            e("s_barrier")
+            self.compute_seg(self.dma_items(p ^ 1))                   # (weights: after both groups' epilogues, whose staging is buffer 1's weight area)
+            self.advance_staging()
+            e("s_barrier")
+            self.load_seg(2, p, [])
+            e("s_barrier")
+            self.compute_seg()
+            e("s_waitcnt vmcnt(0)")
+            e("s_barrier")
+            return
         self.staging_source()
-        self.load_seg(1, p, self.halo_items(p ^ 1))
+        self.load_seg(0, p, self.halo_items(p ^ 1))                   # (the long-latency requests first: five intervals to land)
         e("s_barrier")
         self.compute_seg()
         e("s_barrier")
-        self.load_seg(2, p, self.dma_items(p ^ 1))
+        self.load_seg(1, p, self.dma_items(p ^ 1))                    # (weights: after both groups' epilogues, whose staging is buffer 1's weight area)
         self.advance_staging()
+        e("s_barrier")
+        self.compute_seg()
+        e("s_barrier")
+        self.load_seg(2, p, [])
         e("s_barrier")
         self.compute_seg()
         e("s_waitcnt vmcnt(0)")
@@ -130,12 +164,29 @@ class BodyX(G.Body):
 
     def follower_chunk(self, p):
         e = self.e
+        if DMA_IN_COMPUTE:
+            self.load_seg(0, p, [])
+            e("s_barrier")
+            self.staging_source()
+            self.compute_seg(self.halo_items(p ^ 1))
+            e("s_barrier")
+            self.load_seg(1, p, [])
+            e("s_barrier")
+            self.compute_seg(self.dma_items(p ^ 1))
+            self.advance_staging()
+            e("s_barrier")
+            self.load_seg(2, p, [])
+            e("s_waitcnt vmcnt(0)")
+            e("s_barrier")
+            self.compute_seg()
+            e("s_barrier")
+            return
         self.staging_source()
-        self.load_seg(0, p, self.dma_items(p ^ 1))
+        self.load_seg(0, p, self.halo_items(p ^ 1))
         e("s_barrier")
         self.compute_seg()
         e("s_barrier")
-        self.load_seg(1, p, self.halo_items(p ^ 1))
+        self.load_seg(1, p, self.dma_items(p ^ 1))
         self.advance_staging()
         e("s_barrier")
         self.compute_seg()

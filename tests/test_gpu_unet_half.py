@@ -85,8 +85,8 @@ def test_convolution_is_the_rounded_fp32_tensor_kernel(blobs, dev, layer, transp
                                                           (8, 0, 2, 500, 500, False), (2, 0, 3, 250, 250, False), (4, 1, 2, 125, 125, False), (7, 0, 1, 16, 32, False),
                                                           (5, 0, 5, 70, 41, False)])
 def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, transposed, F, H, Wd, gate):
-    """s2l_set_unet_half_kernel: 0 = eight waves in alternating roles (default; gated launches: interleaved), 1 = four waves,
-    2 = eight waves interleaved; same arithmetic in the same order."""
+    """s2l_set_unet_half_kernel: 0 = eight waves interleaving loads and MFMAs (default), 1 = four waves, 2 = eight waves in alternating
+    roles (gated launches run as 0); same arithmetic in the same order."""
     _, raw, raw16 = blobs
     lib = _abi.load()
     g = torch.Generator(device="cpu").manual_seed(7 * layer + H)

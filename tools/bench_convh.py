@@ -1,5 +1,5 @@
 """Per-layer time of the half-width convolution kernel (csrc/convh.hip) at the training chain's shapes.
-    python tools/bench_convh.py [frames=20] [size=500] [kernel: 0 eight waves | 1 four]"""
+    python tools/bench_convh.py [frames=20] [size=500] [kernel: 0 eight waves interleaved | 1 four waves | 2 eight waves in alternating roles] [--nogate: the train-mode chain's launches]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,8 @@ CONVS = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128), (256,
 LVL = [0, 0, 1, 1, 2, 2, 1, 1, 0, 0]
 p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
 dev = torch.device("cuda:0")
+NOGATE = "--nogate" in sys.argv
+sys.argv = [a for a in sys.argv if not a.startswith("--")]
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 lib = _abi.load()
@@ -30,7 +32,7 @@ for tr in (0, 1):
         CA, CB = (cin // 2, cin // 2) if cat else (cin, 0)
         a = torch.randn(F, h, h, CA, device=dev).to(torch.bfloat16)
         b = torch.randn(F, h, h, CB, device=dev).to(torch.bfloat16) if CB else None
-        gate = tr and l in (1, 3, 5, 7, 9)
+        gate = tr and l in (1, 3, 5, 7, 9) and not NOGATE
         gt = torch.randn(F, h, h, cout, device=dev).clamp_min(0).to(torch.bfloat16) if gate else None
         out = torch.empty(F, h, h, cout, dtype=torch.int16, device=dev)
         call = lambda: _abi.check(lib.s2l_convh_layer(p(raw16), l, tr, p(a), CA, p(b), CB, p(gt), p(out), h, h, F, st), "convh")

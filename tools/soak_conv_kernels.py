@@ -176,7 +176,7 @@ def soak_convh(dev, rounds, seed=0, log=print):
         want = ref.to(torch.bfloat16).view(torch.int16)
         ah, bh, gh = nhwc_to_c32(a), (nhwc_to_c32(b) if cat else None), (nhwc_to_c32(gt) if gt is not None else None)
         ok = True
-        for kind in (0, 0, 1, 2):      # the alternating-roles form twice (gated launches: interleaved), the four-wave form, eight waves interleaved
+        for kind in (0, 0, 1, 2):      # the eight-wave form twice, the four-wave form, the alternating-roles form (gated launches: eight waves)
             _abi.check(lib.s2l_set_unet_half_kernel(kind), "s2l_set_unet_half_kernel")
             out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
             _abi.check(lib.s2l_convh_layer(p(raw16), layer, tr, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "convh")
