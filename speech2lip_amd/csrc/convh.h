@@ -16,9 +16,14 @@ struct ConvHArgs {
   int CA, CB, cout, H, W, tiles_x, tiles_y, n_ct;      // tiles of 32 rows x 16 columns
   int relu;                // 1: max(0, .) before the conversion
   int n_frames;
+  float* stat;             // or null: per-tile partial sums of BatchNorm's batch statistics of the STORED values, channel_stats_h_kernel's
+                           //   layout with block = tile: stat[((frame * tiles_xy + ty * tiles_x + tx) * 2 + {sum, sum of squares}) * cout + channel]
 };
+constexpr int kConvHStatBlocks = 1024;      // tiles per frame the statistics buffers hold (= kStatBlocks of csrc/unet.hip)
 
-// 0 if the launch was taken (*launched) or does not fit the kernel (!*launched)
-int launch_convh(const ConvHArgs& a, hipStream_t st, bool* launched);
+// 0 if the launch was taken (*launched) or does not fit the kernel (!*launched).  a.stat != null: *stats_done says whether the kernel that ran
+// left the statistics (the default eight-wave form, no gate, no ReLU, at most kConvHStatBlocks tiles per frame); otherwise the caller runs
+// its own pass.  *stat_blocks: tiles per frame.
+int launch_convh(const ConvHArgs& a, hipStream_t st, bool* launched, bool* stats_done = nullptr, int* stat_blocks = nullptr);
 
 }  // namespace s2l

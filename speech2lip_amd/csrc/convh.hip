@@ -12,12 +12,13 @@ static_assert(offsetof(ConvHArgs, inA) == 0 && offsetof(ConvHArgs, inB) == 8 && 
               offsetof(ConvHArgs, bias) == 24 && offsetof(ConvHArgs, out) == 32 && offsetof(ConvHArgs, gate) == 40 &&
               offsetof(ConvHArgs, CA) == 48 && offsetof(ConvHArgs, CB) == 52 && offsetof(ConvHArgs, cout) == 56 &&
               offsetof(ConvHArgs, H) == 60 && offsetof(ConvHArgs, W) == 64 && offsetof(ConvHArgs, tiles_x) == 68 &&
-              offsetof(ConvHArgs, tiles_y) == 72 && offsetof(ConvHArgs, n_ct) == 76 && offsetof(ConvHArgs, relu) == 80,
+              offsetof(ConvHArgs, tiles_y) == 72 && offsetof(ConvHArgs, n_ct) == 76 && offsetof(ConvHArgs, relu) == 80 &&
+              offsetof(ConvHArgs, stat) == 88,
               "gen_convh_body.py (ARG) loads these fields from the kernarg segment by offset");
 
 constexpr int kCHTileH = 32;      // tile = 32 rows x 16 columns (gen_convh_body.py: TILE_H)
 constexpr int kCHHalo = (kCHTileH + 2) * 18 * 64, kCHW = 9 * 2 * 2 * 64 * 16, kCHBuf = kCHHalo + kCHW;
-constexpr int kCHLds = 2 * kCHBuf + 1024;      // two buffers + the bias table (the store staging aliases buffer 1's halo area)
+constexpr int kCHLds = 2 * kCHBuf + 1024 + 4096;      // two buffers + the bias table + the eight waves' per-tile statistics (the store staging aliases buffer 1)
 static_assert(kCHLds <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
@@ -196,8 +197,9 @@ static std::atomic<int> g_convh_kind{0};      // 0: eight waves interleaved, 1: 
 
 // 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
 // (<= 256), tensors small enough for 31-bit pixel indices over all their planes.
-int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
+int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stats_done, int* stat_blocks) {
   *launched = false;
+  if (stats_done) *stats_done = false;
   ConvHArgs a = a0;
   a.tiles_x = (a.W + 15) / 16;
   a.tiles_y = (a.H + kCHTileH - 1) / kCHTileH;
@@ -216,6 +218,12 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched) {
   if (rc) return rc;
   static LdsOptIn flag4, flag8, flag8r, flagx, flagxr;
   const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 2 && a.gate == nullptr;
+  // the tile statistics exist in the default form only; a launch that cannot leave them says so and the caller runs its own pass
+  static const bool no_conv_stats = getenv("S2L_NO_CONV_STATS") != nullptr;      // (A/B switch of tools/bench_train.py)
+  const bool stats = a.stat && !alternating && !four && !a.relu && !a.gate && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !no_conv_stats;
+  if (!stats) a.stat = nullptr;
+  if (stats_done) *stats_done = stats;
+  if (stat_blocks) *stat_blocks = a.tiles_x * a.tiles_y;
   if (alternating) {
     const void* fn = a.relu ? reinterpret_cast<const void*>(convhx_relu_asm_kernel) : reinterpret_cast<const void*>(convhx_asm_kernel);
     if ((rc = ensure_dynamic_lds(fn, kCHLds, a.relu ? flagxr : flagx, dev))) return rc;

@@ -15,7 +15,8 @@ HALO_BYTES, W_BYTES = HALO_ROWS * 18 * 64, 9 * 2 * 2 * 64 * 16  # 39 168 + 36 86
 N_SLOTS = HALO_BYTES // 16                                      # 2 448
 BUF = HALO_BYTES + W_BYTES                                      # 76 032
 BIAS_OFF = 2 * BUF                                              # 256 floats
-LDS_BYTES = BIAS_OFF + 1024
+STAT_OFF = BIAS_OFF + 1024                                       # per-wave statistics of a tile: [8 waves][64 channels][sum, sum of squares] floats
+LDS_BYTES = STAT_OFF + 4096
 STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 8 waves x 4 KiB
 NW, NB = 8, 2                                                   # waves, N-blocks (2 rows x 16 pixels) per wave
 NI = 5                                                          # halo DMA instructions per wave (wave w: slots 320 w ..)
@@ -41,7 +42,8 @@ V_VS = 44                       # byte offset of this lane's 16 bytes in a store
 V_SWA = 46                      # 8: staging write addresses per piece mb * 4 + rq
 V_SRA = 54                      # 4: staging read addresses per store j
 V_T = 60                        # temporaries 60..87 (the store read-backs share the accumulator temporaries)
-V_G = 88                        # 32: gate pieces [nb][j][4]
+V_G = 88                        # 32: gate pieces [nb][j][4]; a launch that leaves the tile's statistics has no gate: the same registers then hold
+V_SH, V_SS, V_SQ, V_SA, V_SZ = V_G, V_G + 16, V_G + 17, V_G + 18, V_G + 22   # 16 loaded pixel pairs | sum | sum of squares | 4 staging addresses | 6 temporaries
 V_LAST = 119
 
 
@@ -64,12 +66,15 @@ S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA CHB WAVE LDS
                           "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0 RS GY0 LDSW2").split(),
              pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "FRA", "FRB", "OUTF", "GATEF",
                     "EX", "TA", "TB", "XM0", "ROWB"))
+for _n, _r in (("STATP", 98), ("STATP1", 99), ("NCOLS", 100)):      # the statistics' output pointer and the tile's valid columns
+    assert _r not in S.values()
+    S[_n] = _r
 S_LAST = max(S.values())
 assert S_LAST <= 101, S_LAST
 
 # byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
 ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
-       "tiles_y": 72, "n_ct": 76, "relu": 80}
+       "tiles_y": 72, "n_ct": 76, "relu": 80, "stat": 88}
 
 
 def s(n):
@@ -379,11 +384,130 @@ class Body:
                     e(f"v_and_b32 v{x}, v{x}, v{m}")
             e(f"{nogate}:")
             self.wait_all_lds()                               # (either path: the read-backs have arrived)
+            self.stats_block(nb)
             for j in range(4):
                 self.row_exec(2 * nb + (j >> 1), j & 1, "OUTF", nb == 0 and j == 0)
                 if not EXP & 1:
                     e(f"global_store_dwordx4 v{V_VS}, v[{tb + 4 * j}:{tb + 4 * j + 3}], {s2('ROWB')}")
             e("s_mov_b64 exec, -1")
+
+    # ---- per-channel statistics of the tile (the train-mode chain: BatchNorm's batch statistics without a pass over the stored tensor)
+    def stats_block(self, nb):
+        """STATP != 0: accumulate, per channel, the sum and the sum of squares of THIS N-block's stored (bf16-rounded) values over its
+        pixels inside the image.  The values are the ones the store staging holds ([M-block][pixel 32][32 channels] bf16, swizzled):
+        lane c reads channel c (M-block c >> 5) of every pixel -- two bytes each, pixel 2 i in the low half of register i, 2 i + 1 in the
+        high half -- and adds them in pixel order with a 0 / 1 weight per pixel (rows >= H, columns >= W).  After the second N-block the
+        pair (sum, sum of squares) of the wave's 4 rows x 16 columns goes to LDS (STAT_OFF); tile_end adds the eight waves' pairs."""
+        e = self.e
+        skip = self.label("nostat")
+        e(f"s_cmp_eq_u64 {s2('STATP')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        t0, t1, t2, t3, t4, t5 = (V_SZ + k for k in range(6))
+        if nb == 0:
+            e(f"v_mov_b32 v{V_SS}, 0")
+            e(f"v_mov_b32 v{V_SQ}, 0")
+            e(f"v_and_b32 v{t0}, 31, v{V_LANE}")                        # channel inside its M-block
+            e(f"v_lshrrev_b32 v{t1}, 3, v{t0}")                         # its 16-byte piece of a pixel
+            e(f"v_and_b32 v{t2}, 7, v{t0}")
+            e(f"v_lshlrev_b32 v{t2}, 1, v{t2}")                         # byte inside the piece
+            e(f"v_lshrrev_b32 v{t3}, 5, v{V_LANE}")
+            e(f"v_lshlrev_b32 v{t3}, 11, v{t3}")                        # M-block * 2048
+            e(f"v_add_u32 v{t2}, v{t2}, v{t3}")
+            e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 12")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {STG_OFF}")
+            e(f"v_add_u32 v{t2}, {s('T0')}, v{t2}")
+            for q in range(4):                                         # pixel p's pieces are swizzled by (p >> 1) & 3
+                e(f"v_xor_b32 v{t3}, {q}, v{t1}")
+                e(f"v_lshlrev_b32 v{t3}, 4, v{t3}")
+                e(f"v_add_u32 v{V_SA + q}, v{t2}, v{t3}")
+            e(f"s_sub_u32 {s('NCOLS')}, {s('W')}, {s('X0')}")            # valid columns of the tile (X0 < W)
+            e(f"s_min_u32 {s('NCOLS')}, {s('NCOLS')}, 16")
+        for k, dst in ((0, "T2"), (1, "T3")):                          # the N-block's two rows: weight 1.0 inside the image
+            e(f"s_add_u32 {s('T1')}, {s('GY0')}, {2 * nb + k}")
+            e(f"s_cmp_lt_u32 {s('T1')}, {s('H')}")
+            e(f"s_cselect_b32 {s(dst)}, 1.0, 0")
+
+        def reads(i):
+            for half, p in (("", 2 * i), ("_hi", 2 * i + 1)):
+                self.lds_op(f"ds_read_u16_d16{half} v{V_SH + i}, v{V_SA + (i & 3)} offset:{64 * p}", ("ST", nb, p))
+        ahead = 7                                                      # (14 reads in flight: lgkmcnt counts to 15)
+        for i in range(ahead):
+            reads(i)
+        for i in range(16):
+            self.wait_lds(("ST", nb, 2 * i + 1))
+            for half, p in ((0, 2 * i), (1, 2 * i + 1)):
+                e(f"s_cmp_gt_u32 {s('NCOLS')}, {p & 15}")
+                e(f"s_cselect_b32 {s('T0')}, {s('T2' if p < 16 else 'T3')}, 0")
+                if half == 0:
+                    e(f"v_lshlrev_b32 v{t0}, 16, v{V_SH + i}")
+                else:
+                    e(f"v_and_b32 v{t0}, 0xffff0000, v{V_SH + i}")
+                e(f"v_fmac_f32 v{V_SS}, {s('T0')}, v{t0}")
+                e(f"v_mul_f32 v{t1}, {s('T0')}, v{t0}")
+                e(f"v_fmac_f32 v{V_SQ}, v{t1}, v{t0}")
+            if i + ahead < 16:
+                reads(i + ahead)
+        if nb == NB - 1:
+            e(f"v_lshlrev_b32 v{t0}, 3, v{V_LANE}")
+            e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 9")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {STAT_OFF}")
+            e(f"v_add_u32 v{t0}, {s('T0')}, v{t0}")
+            e(f"v_mov_b32 v{t2}, v{V_SS}")
+            e(f"v_mov_b32 v{t3}, v{V_SQ}")
+            self.lds_op(f"ds_write_b64 v{t0}, v[{t2}:{t3}]", ("STW",))
+            self.wait_all_lds()
+        e(f"{skip}:")
+
+    def stats_reduce(self):
+        """after the tile's barrier: wave w adds, for channels 8 w .. 8 w + 7 (lanes 0..7), the eight waves' pairs in wave order and stores
+        them to stat[((frame * tiles + ty * tiles_x + tx) * 2 + {0, 1}) * cout + 64 ct + channel] (channel_stats_h_kernel's partial layout
+        with block = tile)"""
+        e = self.e
+        skip = self.label("nored")
+        e(f"s_cmp_eq_u64 {s2('STATP')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        t0 = V_SZ
+        e("s_mov_b64 exec, 0xff")
+        e(f"v_lshlrev_b32 v{t0}, 3, v{V_LANE}")
+        e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 6")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {STAT_OFF}")
+        e(f"v_add_u32 v{t0}, {s('T0')}, v{t0}")
+        for k in range(8):
+            self.lds_op(f"ds_read_b64 v[{V_SH + 2 * k}:{V_SH + 2 * k + 1}], v{t0} offset:{512 * k}", ("SRD", k))
+        # the tile's place in the partial buffer (64-bit frame offset)
+        e(f"s_mul_i32 {s('T0')}, {s('TILESX')}, {s('TILESY')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 3")                        # bytes per frame: tiles * 2 * cout * 4
+        e(f"s_mul_hi_u32 {s('T1')}, {s('FR')}, {s('T0')}")
+        e(f"s_mul_i32 {s('T0')}, {s('FR')}, {s('T0')}")
+        e(f"s_add_u32 {s('TA')}, {s('STATP')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('STATP1')}, {s('T1')}")
+        e(f"s_mul_i32 {s('T0')}, {s('TY')}, {s('TILESX')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('TX')}")
+        e(f"s_mul_i32 {s('T0')}, {s('T0')}, {s('COUT')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 1")
+        e(f"s_lshl_b32 {s('T1')}, {s('CT')}, 6")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+        e(f"s_lshl_b32 {s('T1')}, {s('WAVE')}, 3")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 2")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('TA1')}, 0")
+        e(f"v_lshlrev_b32 v{t0}, 2, v{V_LANE}")
+        self.wait_all_lds()
+        for k in range(1, 8):                                          # fixed order: wave 0 + wave 1 + ... + wave 7
+            e(f"v_add_f32 v{V_SH}, v{V_SH}, v{V_SH + 2 * k}")
+            e(f"v_add_f32 v{V_SH + 1}, v{V_SH + 1}, v{V_SH + 2 * k + 1}")
+        e(f"global_store_dword v{t0}, v{V_SH}, {s2('TA')}")
+        e(f"s_lshl_b32 {s('T0')}, {s('COUT')}, 2")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('TA1')}, 0")
+        e(f"global_store_dword v{t0}, v{V_SH + 1}, {s2('TA')}")
+        e("s_mov_b64 exec, -1")
+        e(f"{skip}:")
 
     # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
     def chunk(self, p):
@@ -470,7 +594,8 @@ class Body:
         if not EXP & 512:
             self.store_tile()
         e("s_barrier")                                                # (the staging area is buffer 1's halo region: nobody may stage the next
-        self.next_coords("", "CT")                                    #  tile's chunk 1 into it while another wave still stores)
+        self.stats_reduce()                                           #  tile's chunk 1 into it while another wave still stores)
+        self.next_coords("", "CT")
 
 
 def emit_prologue(b, with_gate=True):
@@ -481,7 +606,7 @@ def emit_prologue(b, with_gate=True):
     e(f"s_mov_b64 {s2('KARG')}, %[karg]")
     for dst, src in (("WAVE", "wave"), ("LDS0", "lds0"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"), ("FR", "fr0"), ("NTL", "ntl")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
-    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"), ("GATE", "gate")):
+    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"), ("GATE", "gate"), ("STATP", "stat")):
         e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, {ARG[field]}")
     for dst, field in (("CA", "CA"), ("CB", "CB"), ("COUT", "cout"), ("H", "H"), ("W", "W"), ("TILESX", "tiles_x"), ("TILESY", "tiles_y"),
                        ("NCT", "n_ct"), ("T3", "relu")):
