@@ -448,6 +448,13 @@ int s2l_debug_conv_layer_f32(const float* packed_raw, const uint16_t* packed16_r
 int s2l_debug_conv_wgrad_h(const uint16_t* dz, const uint16_t* inA, int CA, const uint16_t* inB, int CB, int cout, float* partial, float* dw,
                            int height, int width, int64_t n_frames, s2l_stream_t stream);
 
+/* Test aid: a forward 3x3 layer of the half-width chain that also leaves its tiles' partial sums of BatchNorm's batch statistics of the
+ * STORED (bf16-rounded) values -- stat[((frame * blocks + block) * 2 + {sum, sum of squares}) * cout + channel], *blocks_out blocks per frame
+ * (0: the kernel form that ran does not leave them) -- as s2l_unet_train_forward_frames_h consumes them in place of a pass over the tensor
+ * (nn.BatchNorm2d in train mode: SimpleUnetLight.py:16-40).  stat: n_frames * 1024 * 2 * cout floats. */
+int s2l_debug_convh_layer_stats(const uint16_t* packed16_raw, int layer, const uint16_t* inA, int CA, const uint16_t* inB, int CB,
+                                uint16_t* out, float* stat, int* blocks_out, int height, int width, int64_t n_frames, s2l_stream_t stream);
+
 /* Measurement aid (tools/ubench_mfma.py): `waves` (4 or 8) waves per CU each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 on
  * registers and nothing else -- the rate the chip sustains under that load (the clock drops below its 2.4 GHz peak). */
 int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream);

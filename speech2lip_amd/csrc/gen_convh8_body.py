@@ -395,8 +395,8 @@ class Body:
     def stats_block(self, nb):
         """STATP != 0: accumulate, per channel, the sum and the sum of squares of THIS N-block's stored (bf16-rounded) values over its
         pixels inside the image.  The values are the ones the store staging holds ([M-block][pixel 32][32 channels] bf16, swizzled):
-        lane c reads channel c (M-block c >> 5) of every pixel -- two bytes each, pixel 2 i in the low half of register i, 2 i + 1 in the
-        high half -- and adds them in pixel order with a 0 / 1 weight per pixel (rows >= H, columns >= W).  After the second N-block the
+        lane c reads channel c (M-block c >> 5) of every pixel -- two bytes each -- and adds them in pixel order with a 0 / 1 weight per
+        pixel (rows >= H, columns >= W).  After the second N-block the
         pair (sum, sum of squares) of the wave's 4 rows x 16 columns goes to LDS (STAT_OFF); tile_end adds the eight waves' pairs."""
         e = self.e
         skip = self.label("nostat")
@@ -428,26 +428,24 @@ class Body:
             e(f"s_cmp_lt_u32 {s('T1')}, {s('H')}")
             e(f"s_cselect_b32 {s(dst)}, 1.0, 0")
 
-        def reads(i):
-            for half, p in (("", 2 * i), ("_hi", 2 * i + 1)):
-                self.lds_op(f"ds_read_u16_d16{half} v{V_SH + i}, v{V_SA + (i & 3)} offset:{64 * p}", ("ST", nb, p))
-        ahead = 7                                                      # (14 reads in flight: lgkmcnt counts to 15)
-        for i in range(ahead):
-            reads(i)
-        for i in range(16):
-            self.wait_lds(("ST", nb, 2 * i + 1))
-            for half, p in ((0, 2 * i), (1, 2 * i + 1)):
-                e(f"s_cmp_gt_u32 {s('NCOLS')}, {p & 15}")
-                e(f"s_cselect_b32 {s('T0')}, {s('T2' if p < 16 else 'T3')}, 0")
-                if half == 0:
-                    e(f"v_lshlrev_b32 v{t0}, 16, v{V_SH + i}")
-                else:
-                    e(f"v_and_b32 v{t0}, 0xffff0000, v{V_SH + i}")
-                e(f"v_fmac_f32 v{V_SS}, {s('T0')}, v{t0}")
-                e(f"v_mul_f32 v{t1}, {s('T0')}, v{t0}")
-                e(f"v_fmac_f32 v{V_SQ}, v{t1}, v{t0}")
-            if i + ahead < 16:
-                reads(i + ahead)
+        # one pixel per register (zero-extended 16-bit reads): two d16 loads into the halves of ONE register may not be in flight together --
+        # the second merges with the register's value at issue time and the first half is lost (measured: only odd pixels were counted)
+        ring = 14                                                      # reads in flight (lgkmcnt counts to 15)
+
+        def read(p):
+            self.lds_op(f"ds_read_u16 v{V_SH + p % ring}, v{V_SA + ((p >> 1) & 3)} offset:{64 * p}", ("ST", nb, p))
+        for p in range(ring):
+            read(p)
+        for p in range(32):
+            self.wait_lds(("ST", nb, p))
+            e(f"s_cmp_gt_u32 {s('NCOLS')}, {p & 15}")
+            e(f"s_cselect_b32 {s('T0')}, {s('T2' if p < 16 else 'T3')}, 0")
+            e(f"v_lshlrev_b32 v{t0}, 16, v{V_SH + p % ring}")
+            e(f"v_fmac_f32 v{V_SS}, {s('T0')}, v{t0}")
+            e(f"v_mul_f32 v{t1}, {s('T0')}, v{t0}")
+            e(f"v_fmac_f32 v{V_SQ}, v{t1}, v{t0}")
+            if p + ring < 32:
+                read(p + ring)
         if nb == NB - 1:
             e(f"v_lshlrev_b32 v{t0}, 3, v{V_LANE}")
             e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 9")

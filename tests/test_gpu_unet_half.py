@@ -328,3 +328,38 @@ def test_weight_gradient_kernel_alone_vs_fp64_correlation(dev, F, H, Wd, CA, CB,
     # argument errors
     assert lib.s2l_debug_conv_wgrad_h(p(dzp), p(ap), 32, None, 0, cout, p(part), p(outs[0]), H, Wd, F, None) == -2
     assert lib.s2l_debug_conv_wgrad_h(None, p(ap), CA, None, 0, cout, p(part), p(outs[0]), H, Wd, F, None) == -1
+
+
+@pytest.mark.parametrize("layer,F,H,Wd", [(1, 2, 40, 40), (2, 1, 33, 17), (6, 2, 37, 53), (3, 1, 125, 125), (9, 2, 500, 500), (8, 3, 70, 41)])
+def test_convolution_leaves_its_tiles_batch_statistics(blobs, dev, layer, F, H, Wd):
+    """The forward convolution's own per-tile partial sums (csrc/gen_convh8_body.py stats_block: what the train-mode chain's BatchNorm
+    consumes instead of a pass over z): summed over the tiles they are the per-frame, per-channel sum and sum of squares of the STORED
+    bf16 values -- ragged tiles, rows and columns outside the image excluded -- to fp32 summation accuracy; the stored tensor is the
+    same bits as without statistics; two runs give the same partials bit for bit (fixed order, no atomics)."""
+    _, raw, raw16 = blobs
+    lib = _abi.load()
+    g = torch.Generator(device="cpu").manual_seed(11 * layer + H)
+    cin, cout = CONVS[layer]
+    cat = layer in (6, 8)
+    CA, CB = (cin // 2, cin // 2) if cat else (cin, 0)
+    ah = nhwc_to_c32(torch.randn(F, H, Wd, CA, generator=g).to(torch.bfloat16).to(dev))
+    bh = nhwc_to_c32(torch.randn(F, H, Wd, CB, generator=g).to(torch.bfloat16).to(dev)) if CB else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+    _abi.check(lib.s2l_convh_layer(p(raw16), layer, 0, p(ah), CA, p(bh), CB, None, p(ref), H, Wd, F, st), "s2l_convh_layer")
+    parts = []
+    for _ in range(2):
+        out = torch.full_like(ref, -1)
+        stat = torch.full((F * 1024 * 2 * cout,), float("nan"), device=dev)
+        blocks = ctypes.c_int(0)
+        _abi.check(lib.s2l_debug_convh_layer_stats(p(raw16), layer, p(ah), CA, p(bh), CB, p(out), p(stat), ctypes.byref(blocks), H, Wd, F, st),
+                   "s2l_debug_convh_layer_stats")
+        torch.cuda.synchronize()
+        assert blocks.value == ((Wd + 15) // 16) * ((H + 31) // 32) and torch.equal(out, ref)
+        parts.append(stat[:F * blocks.value * 2 * cout].reshape(F, blocks.value, 2, cout).clone())
+    assert torch.equal(parts[0], parts[1]) and bool(torch.isfinite(parts[0]).all())
+    z = c32_to_nhwc(ref).view(torch.bfloat16).double()                  # [F,H,W,cout]
+    s_ref, q_ref = z.sum((1, 2)), (z * z).sum((1, 2))
+    got = parts[0].double().sum(1)                                     # [F,2,cout]
+    assert float((got[:, 0] - s_ref).abs().max()) <= 2e-5 * float(z.abs().sum((1, 2)).max())
+    assert float((got[:, 1] - q_ref).abs().max()) <= 2e-5 * float(q_ref.max())
