@@ -29,6 +29,7 @@ enum {
   S2L_E_NULL = -1,     /* a required pointer is NULL            */
   S2L_E_SIZE = -2,     /* a size / count argument is invalid    */
   S2L_E_ALIGN = -3,    /* a pointer is not 16-byte aligned      */
+  S2L_E_UNSUPPORTED = -5,   /* a kernel form that only libs2l_hip_ref.so holds (the product library keeps one kernel per job) */
   S2L_E_GEOMETRY = -4  /* a box the reference cannot evaluate either: composite lip box ENTIRELY outside the face frame (F.pad raises; a partly-outside box is cropped as F.pad crops), crop/U-Net windows, LPIPS minimum size */
 };
 
@@ -339,7 +340,9 @@ int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps, uint16_t* 
 int s2l_unet_forward_split(const float* packed, const uint16_t* packed16x3, const float* x, float* work, float* out, int height,
                            int width, int64_t n_frames, s2l_stream_t stream);
 /* Which kernel runs the split-bf16 layers: 0 (default) the persistent form with a two-chunk-deep operand pipeline, 1 the
- * one-tile-per-workgroup form it replaced, 2 the generated-assembly form (csrc/conv16.hip; layers it does not cover run as 0).
+ * one-tile-per-workgroup form (the persistent kernel's fall-back for launches it does not take), 2 the generated-assembly form
+ * (csrc/conv16.hip; layers it does not cover run as 0) -- form 2 exists only in libs2l_hip_ref.so, the test-side build with
+ * -DS2L_WITH_REFERENCE_KERNELS; the product library answers S2L_E_UNSUPPORTED.
  * Same arithmetic in the same order: the outputs are the same bits (a test aid).  Any other value: S2L_E_SIZE. */
 int s2l_set_unet_split_kernel(int kind);
 
@@ -461,8 +464,9 @@ int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t
 /* Which form of the half-width convolution runs: 0 (default) eight waves per workgroup (two per SIMD), each interleaving its loads with its
  * MFMAs, 1 four waves (one per SIMD), 2 eight waves with the two waves of a SIMD alternating between an MFMA-only segment and a load /
  * epilogue segment (csrc/gen_convhx_body.py; launches with a gate input run as 0) -- measured equal to form 0 within +-3 %: the kernel is
- * bound by the CU's vector-memory path, not by its instruction schedule (docs/LABNOTES.md §10).
- * Same arithmetic in the same order: the outputs are the same bits (a test aid).  Any other value: S2L_E_SIZE. */
+ * bound by the CU's vector-memory path, not by its instruction schedule (docs/LABNOTES.md §10).  Forms 1 and 2 exist only in
+ * libs2l_hip_ref.so (-DS2L_WITH_REFERENCE_KERNELS: tests and tools/soak_conv_kernels.py load it); the product library answers
+ * S2L_E_UNSUPPORTED.  Same arithmetic in the same order: the outputs are the same bits.  Any other value: S2L_E_SIZE. */
 int s2l_set_unet_half_kernel(int kind);
 
 /* Crop + bilinear resize between the U-Net and the sync expert, and its adjoint (training.py:541-544:

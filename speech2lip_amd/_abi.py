@@ -32,7 +32,8 @@ TENSOR_ORDER = [
 assert len(TENSOR_ORDER) == S2L_NUM_TENSORS
 
 _ERRORS = {-1: "S2L_E_NULL (null pointer)", -2: "S2L_E_SIZE (bad size)", -3: "S2L_E_ALIGN (pointer not 16-byte aligned)",
-           -4: "S2L_E_GEOMETRY (geometry the reference cannot evaluate either, e.g. a lip box entirely outside the face frame)"}
+           -4: "S2L_E_GEOMETRY (geometry the reference cannot evaluate either, e.g. a lip box entirely outside the face frame)",
+           -5: "S2L_E_UNSUPPORTED (a kernel form only libs2l_hip_ref.so holds)"}
 
 EXPORTS = {
     "s2l_version": (c_char_p, []),
@@ -205,6 +206,43 @@ def load() -> ctypes.CDLL:
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+_ref_lib = None
+
+
+def load_reference() -> ctypes.CDLL:
+    """libs2l_hip_ref.so: the same ABI built with -DS2L_WITH_REFERENCE_KERNELS, i.e. WITH the non-default kernel forms that exist only
+    to pin the default ones bit for bit (the four-wave and the alternating-roles half-width convolutions, the generated-assembly
+    split convolution).  TEST INFRASTRUCTURE: only tests/ and tools/ may call this; nothing under speech2lip_amd/ does."""
+    global _ref_lib
+    if _ref_lib is None:
+        path = os.path.join(os.path.dirname(LIB), "libs2l_hip_ref.so")
+        if not os.path.exists(path):
+            raise S2LError(f"{path} not found: build it with `python -m speech2lip_amd.build --ref`")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _ref_lib = lib
+    return _ref_lib
+
+
+class reference_kernels:
+    """`with _abi.reference_kernels() as ref:` -- inside the block every call of the package goes to libs2l_hip_ref.so (selectors
+    set on `ref` take effect there); on exit the product library is back.  Tests and tools only."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.saved = _lib
+        _lib = load_reference()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def check(rc: int, what: str) -> None:

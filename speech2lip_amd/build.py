@@ -11,8 +11,12 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libs2l_hip.so")
+REF_LIB = os.path.join(PKG, "libs2l_hip_ref.so")      # the same ABI + the non-default kernel forms (-DS2L_WITH_REFERENCE_KERNELS): tests / tools only
 RESOURCES = os.path.join(PKG, "kernel_resources.json")      # per-kernel registers / spills / scratch / LDS of the last build
-SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip", "render16.hip", "conv16.hip", "convh.hip"]
+SOURCES = ["pack.hip", "frontend.hip", "rows.hip", "render.hip", "ensemble.hip", "train.hip", "composite.hip", "unet.hip", "warp.hip", "syncnet.hip", "lpips.hip", "syncchain.hip", "train_bf16.hip", "quant.hip", "render16.hip", "convh.hip"]
+# translation units that differ in the reference library: the split convolution's generated-assembly form (conv16.hip, its dispatch in
+# unet.hip) and the four-wave / alternating-roles forms of the half-width convolution (convh.hip).  Every other object is shared.
+REF_SOURCES = ["unet.hip", "convh.hip", "conv16.hip"]
 # -ffp-contract=off: parity needs the reference's separate roundings (x*y then +z); FMAs are explicit fmaf()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
@@ -45,7 +49,7 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(REF_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "s2l_hip.h")]
@@ -88,22 +92,30 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, *FLAGS, "-I", objdir, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    objs, resources = [], {}
-    for src, obj, p in procs:
+        procs.append((src, obj, False, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src in REF_SOURCES:      # the reference library's own objects, in the same pass
+        obj = os.path.join(objdir, "ref_" + src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-DS2L_WITH_REFERENCE_KERNELS", "-I", objdir, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, obj, True, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs, ref_objs, resources, ref_resources = [], [], {}, {}
+    for src, obj, is_ref, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        resources.update(_parse_resources(out))
+            raise RuntimeError(f"hipcc failed on {src}{' (reference build)' if is_ref else ''}:\n{out}")
+        (ref_resources if is_ref else resources).update(_parse_resources(out))
         rest = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
         if verbose and rest.strip():
             print(rest)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}")
-    os.replace(LIB + ".tmp", LIB)
+        (ref_objs if is_ref else objs).append(obj)
+    ref_names = {s.replace(".hip", ".o") for s in REF_SOURCES}
+    for out_lib, parts in ((LIB, objs), (REF_LIB, [o for o in objs if os.path.basename(o) not in ref_names] + ref_objs)):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib + ".tmp", *parts]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link of {os.path.basename(out_lib)} failed:\n{r.stdout}")
+        os.replace(out_lib + ".tmp", out_lib)
+    # per-kernel resources of the product library; the kernels only the reference library holds under "reference_only"
+    resources["reference_only"] = {k: v for k, v in ref_resources.items() if k not in resources}
     with open(RESOURCES, "w") as f:
         json.dump(resources, f, indent=0, sort_keys=True)
     return LIB

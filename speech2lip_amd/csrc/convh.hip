@@ -21,6 +21,7 @@ constexpr int kCHHalo = (kCHTileH + 2) * 18 * 64, kCHW = 9 * 2 * 2 * 64 * 16, kC
 constexpr int kCHLds = 2 * kCHBuf + 1024 + 4096;      // two buffers + the bias table + the eight waves' per-tile statistics (the store staging aliases buffer 1)
 static_assert(kCHLds <= 160 * 1024, "LDS budget");
 
+#ifdef S2L_WITH_REFERENCE_KERNELS      // (the four-wave form: libs2l_hip_ref.so only)
 __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ch_smem[];
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();   // the body loads the ConvHArgs fields itself (s_load)
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256) void convh_asm_kernel(ConvHArgs a) {
   __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the constants are in LDS (each lane reads back only its own words)
 #include "convh_body.inc"
 }
+
+#endif
 
 // The eight-wave form (gen_convh8_body.py): two waves per SIMD, wave w owns rows 4 w .. 4 w + 3 of the tile.  Same arithmetic, same bits.
 // Two bodies: linear (the train-mode chain) and max(0, .) before the conversion (the eval-mode chain's folded BatchNorm + ReLU).
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(512) void convh8_relu_asm_kernel(ConvHArgs a) {
 #include "convh8r_body.inc"
 }
 
+#ifdef S2L_WITH_REFERENCE_KERNELS
 // The alternating-roles form (gen_convhx_body.py): the same tile and the same per-lane constants as the eight-wave form, the two waves of a
 // SIMD taking turns between an MFMA-only segment and a load / request / epilogue segment.  Same arithmetic in the same order: the same bits.
 // No gate input (gated launches keep the interleaved kernel).  Store staging: buffer 1's WEIGHT area (32 of its 36 KiB), so that the next
@@ -193,6 +197,8 @@ __global__ __launch_bounds__(512) void convhx_relu_asm_kernel(ConvHArgs a) {
 #include "convhxr_body.inc"
 }
 
+#endif
+
 static std::atomic<int> g_convh_kind{0};      // 0: eight waves interleaved, 1: four waves, 2: eight waves in alternating roles (gated launches: 0) (s2l_set_unet_half_kernel)
 
 // 0 if the launch was taken.  Conditions: an even number of 32-channel planes in, whole planes per tensor, cout a multiple of 64
@@ -210,20 +216,29 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stat
       a.n_frames <= 0 || (int64_t)a.H * a.W * 64 >= 0x7fffffffLL || (int64_t)a.H * a.W * a.n_frames * (cmax / 32) >= 0x7fffffffLL / 2 ||
       a.H > 255 * 32 || a.W > 255 * 16)
     return S2L_OK;
+#ifdef S2L_WITH_REFERENCE_KERNELS
   const bool four = g_convh_kind.load(std::memory_order_relaxed) == 1 && a.relu == 0;      // (the four-wave body exists in the linear form only)
+#else
+  const bool four = false;
+#endif
   const int64_t total = (int64_t)a.tiles_x * a.tiles_y * a.n_ct * a.n_frames;
   if (total >= 0x7fffffff) return S2L_OK;
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
   static LdsOptIn flag4, flag8, flag8r, flagx, flagxr;
+#ifdef S2L_WITH_REFERENCE_KERNELS
   const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 2 && a.gate == nullptr;
+#else
+  const bool alternating = false;
+#endif
   // the tile statistics exist in the default form only; a launch that cannot leave them says so and the caller runs its own pass
   static const bool no_conv_stats = getenv("S2L_NO_CONV_STATS") != nullptr;      // (A/B switch of tools/bench_train.py)
   const bool stats = a.stat && !alternating && !four && !a.relu && !a.gate && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !no_conv_stats;
   if (!stats) a.stat = nullptr;
   if (stats_done) *stats_done = stats;
   if (stat_blocks) *stat_blocks = a.tiles_x * a.tiles_y;
+#ifdef S2L_WITH_REFERENCE_KERNELS
   if (alternating) {
     const void* fn = a.relu ? reinterpret_cast<const void*>(convhx_relu_asm_kernel) : reinterpret_cast<const void*>(convhx_asm_kernel);
     if ((rc = ensure_dynamic_lds(fn, kCHLds, a.relu ? flagxr : flagx, dev))) return rc;
@@ -234,7 +249,9 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stat
   } else if (four) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh_asm_kernel), kCHLds, flag4, dev))) return rc;
     hipLaunchKernelGGL(convh_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(256), kCHLds, st, a);
-  } else if (a.relu) {
+  } else
+#endif
+  if (a.relu) {
     if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh8_relu_asm_kernel), kCHLds, flag8r, dev))) return rc;
     hipLaunchKernelGGL(convh8_relu_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
   } else {
@@ -289,6 +306,9 @@ extern "C" int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s
 // aid).  Form 2 was built to test whether the schedule inside a CU bounds this kernel: it does not (same time to +-3 %: LABNOTES §10).
 extern "C" int s2l_set_unet_half_kernel(int kind) {
   if (kind < 0 || kind > 2) return S2L_E_SIZE;
+#ifndef S2L_WITH_REFERENCE_KERNELS
+  if (kind != 0) return S2L_E_UNSUPPORTED;      // (forms 1 and 2 live in libs2l_hip_ref.so)
+#endif
   s2l::g_convh_kind.store(kind, std::memory_order_relaxed);
   return S2L_OK;
 }

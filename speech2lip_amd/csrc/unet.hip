@@ -19,7 +19,9 @@
 // workgroups per CU overlap one another's staging.  The concat is virtual (two input pointers), the
 // final 1x1 convolution is fused into the last conv's epilogue.
 #include "s2l_common.h"
-#include "conv16.h"
+#ifdef S2L_WITH_REFERENCE_KERNELS
+#include "conv16.h"      // (the generated-assembly split convolution: libs2l_hip_ref.so only)
+#endif
 #include "convh.h"
 #include "unet_layout.h"
 
@@ -1380,6 +1382,9 @@ static std::atomic<int> g_conv_kernel_kind{0};
 static std::atomic<int> g_split_kernel_kind{0};      // 0: conv3x3_split_kernel (persistent), 1: conv3x3_bf16_kernel<.., true, 8> (one tile per workgroup)
 extern "C" int s2l_set_unet_split_kernel(int kind) {      // 2: conv16_asm_kernel (csrc/conv16.hip) where it applies, else kind 0
   if (kind != 0 && kind != 1 && kind != 2) return S2L_E_SIZE;
+#ifndef S2L_WITH_REFERENCE_KERNELS
+  if (kind == 2) return S2L_E_UNSUPPORTED;      // (that form lives in libs2l_hip_ref.so)
+#endif
   g_split_kernel_kind.store(kind, std::memory_order_relaxed);
   return S2L_OK;
 }
@@ -1459,6 +1464,7 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
   bool done = false;
   const int rc_asm = launch_conv_asm(a, F, st, &done);
   if (done) return rc_asm;
+#ifdef S2L_WITH_REFERENCE_KERNELS
   if (a.w16 && split && !out3 && g_split_kernel_kind.load(std::memory_order_relaxed) == 2) {
     // the generated-assembly split convolution (bias + ReLU; a pooled copy comes from maxpool2_kernel: max of the same fp32 values)
     Conv16Args c;
@@ -1468,6 +1474,7 @@ static int launch_conv(const float* inA, int CA, const float* inB, int CB, const
     const int rc = launch_conv16_asm(c, st, &launched);
     if (rc || launched) return rc;
   }
+#endif
   if (a.w16 && (split || g_split_kernel_kind.load(std::memory_order_relaxed) == 0)) {
     bool launched = false;
     const int rc = launch_conv_persistent(a, F, out3 != nullptr, split != 0, st, &launched);

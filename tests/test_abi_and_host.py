@@ -28,8 +28,28 @@ def test_header_symbols_are_all_exported(lib):
     raw = ctypes.CDLL(build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
+    ref = ctypes.CDLL(build.REF_LIB)      # the test-side build with the non-default kernel forms: the same ABI
+    for name in declared:
+        assert hasattr(ref, name), name
     assert lib.s2l_version().decode().startswith("s2l_hip") and b"gfx950" in lib.s2l_version()
     assert lib.s2l_packed_floats() > W.HOT_PATH_PARAM_COUNT  # blob holds every weight at least once
+
+
+def test_product_never_touches_the_reference_library_or_the_oracle():
+    """libs2l_hip_ref.so (the non-default kernel forms, -DS2L_WITH_REFERENCE_KERNELS) and oracle/ are test infrastructure: no module of
+    the product package loads, names or imports either -- `_abi.load_reference` / `reference_kernels` are DEFINED in _abi.py and
+    called from tests/ and tools/ only."""
+    pkg = os.path.join(ROOT, "speech2lip_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        text = open(os.path.join(pkg, fn)).read()
+        assert "oracle" not in text.replace("oracle's", "").replace("the oracle", "") or fn in ("build.py",), fn
+        if fn not in ("_abi.py", "build.py"):
+            assert "load_reference" not in text and "reference_kernels" not in text and "libs2l_hip_ref" not in text, fn
+    abi = open(os.path.join(pkg, "_abi.py")).read()
+    body = abi[abi.index("def load()"):abi.index("_ref_lib = None")]
+    assert "ref" not in body.lower().replace("prefer", "")      # load() itself knows nothing of the second library
 
 
 def test_tensor_order_matches_header_enum():
@@ -76,6 +96,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_unet_train_forward_bf16(one, odd, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -3
     assert lib.s2l_unet_train_forward(one, tbl, 1e-5, 0.1, 0, one, one, one, one, 3, 8, 1, null) == -2             # H < 4
     assert lib.s2l_set_unet_split_kernel(3) == -2 and lib.s2l_set_unet_split_kernel(0) == 0
+    assert lib.s2l_set_unet_split_kernel(2) == -5 and lib.s2l_set_unet_split_kernel(1) == 0 and lib.s2l_set_unet_split_kernel(0) == 0   # form 2: reference library only
     # round-4 entries: the half-width chains (bf16 tensors between the kernels), their selector, one layer on its own
     assert lib.s2l_unet_train_forward_frames_h(one, null, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 1, null) == -1        # the bf16 blob is required
     assert lib.s2l_unet_train_forward_frames_h(one, one, tbl, 1e-5, 0.1, 0, one, one, one, one, 8, 8, 9000, null) == -2      # frames x planes > 65535
@@ -91,6 +112,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.s2l_convh_layer(one, 0, 0, one, 64, null, 0, null, one, 8, 8, 1, null) == -2                                  # layer 0 is the fp32-input convolution
     assert lib.s2l_convh_layer(one, 1, 0, one, 32, null, 0, null, one, 8, 8, 1, null) == -2                                  # channel count of the layer
     assert lib.s2l_set_unet_half_kernel(3) == -2 and lib.s2l_set_unet_half_kernel(0) == 0
+    assert lib.s2l_set_unet_half_kernel(1) == -5 and lib.s2l_set_unet_half_kernel(2) == -5                                  # S2L_E_UNSUPPORTED in the product library
     assert lib.s2l_unet_train_frames_h_saved_halves(8, 8, 0) == 0 and lib.s2l_unet_train_frames_h_saved_halves(500, 500, 1) > 2 * 10 ** 8
     assert lib.s2l_unet_saved_h_halves(500, 500, 1) == lib.s2l_unet_saved_floats(500, 500, 1)
     # F one-frame calls in one set of launches (every frame its own statistics group)
@@ -418,6 +440,7 @@ def test_no_kernel_spills_to_scratch():
         build.build_library(force=True)
     table = json.load(open(build.RESOURCES))
     assert len(table) >= 100
+    table = {**{k: v for k, v in table.items() if k != "reference_only"}, **table.get("reference_only", {})}      # both libraries' kernels
     bad = {k: v for k, v in table.items() if v.get("scratch", 0) != 0 or v.get("vgpr_spill", 0) != 0}
     assert not bad, bad
     counted = [k for k in table if any(s in k for s in ("conv3x3_split_kernel", "render_tiles_kernel", "fwd_asm_bf16_kernel",

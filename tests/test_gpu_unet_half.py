@@ -100,16 +100,22 @@ def test_four_wave_and_eight_wave_forms_give_the_same_bits(blobs, dev, layer, tr
     gh = nhwc_to_c32(torch.randn(F, H, Wd, cout, generator=g).clamp_min(0).to(torch.bfloat16).to(dev)) if gate else None
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     outs = []
+
+    def run(L):
+        out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+        _abi.check(L.s2l_convh_layer(p(raw16), layer, transposed, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "s2l_convh_layer")
+        return out
+    outs.append(run(lib))                                       # the product library: one kernel per job
+    assert lib.s2l_set_unet_half_kernel(1) == -5 and lib.s2l_set_unet_half_kernel(2) == -5      # S2L_E_UNSUPPORTED
+    rlib = _abi.load_reference()                                # libs2l_hip_ref.so holds the other forms
     try:
         for kind in (0, 1, 2, 0):
-            assert lib.s2l_set_unet_half_kernel(kind) == 0
-            out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
-            _abi.check(lib.s2l_convh_layer(p(raw16), layer, transposed, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "s2l_convh_layer")
-            outs.append(out)
+            assert rlib.s2l_set_unet_half_kernel(kind) == 0
+            outs.append(run(rlib))
         torch.cuda.synchronize()
     finally:
-        lib.s2l_set_unet_half_kernel(0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+        rlib.s2l_set_unet_half_kernel(0)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert lib.s2l_set_unet_half_kernel(3) == -2
 
 

@@ -137,12 +137,14 @@ def test_generated_assembly_split_convolution_equals_the_cpp_kernel(unet, shape)
     dev = next(unet.parameters()).device
     x = torch.from_numpy(np.random.default_rng(H * 977 + Wd).random((F, H, Wd, 3), dtype=np.float32)).to(dev)
     lib = _abi.load()
-    try:
-        assert lib.s2l_set_unet_split_kernel(0) == 0
-        ref = unet.forward_nhwc(x, precision="split").clone()
-        assert lib.s2l_set_unet_split_kernel(2) == 0
-        for _ in range(3):
-            assert torch.equal(unet.forward_nhwc(x, precision="split"), ref)
-    finally:
-        lib.s2l_set_unet_split_kernel(0)
+    assert lib.s2l_set_unet_split_kernel(0) == 0
+    ref = unet.forward_nhwc(x, precision="split").clone()      # the product library's kernel
+    assert lib.s2l_set_unet_split_kernel(2) == -5              # ... which does not hold the assembly form (S2L_E_UNSUPPORTED)
+    with _abi.reference_kernels() as rlib:                     # libs2l_hip_ref.so (-DS2L_WITH_REFERENCE_KERNELS)
+        try:
+            assert rlib.s2l_set_unet_split_kernel(2) == 0
+            for _ in range(3):
+                assert torch.equal(unet.forward_nhwc(x, precision="split"), ref)
+        finally:
+            rlib.s2l_set_unet_split_kernel(0)
     assert float(ref.abs().max()) > 0

@@ -13,6 +13,8 @@ NOGATE = "--nogate" in sys.argv
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+if len(sys.argv) > 3 and int(sys.argv[3]) != 0 and "S2L_LIB" not in os.environ:
+    _abi.reference_kernels().__enter__()      # forms 1 and 2 live in libs2l_hip_ref.so
 lib = _abi.load()
 if len(sys.argv) > 3:
     _abi.check(lib.s2l_set_unet_half_kernel(int(sys.argv[3])), "s2l_set_unet_half_kernel")      # 0: eight waves, 1: four

@@ -7,7 +7,7 @@ src=$1; out=$2; shift 2
 R=$(cd "$(dirname "$0")/.." && pwd)
 obj=$(mktemp /tmp/variant_XXXX.o)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off "$@" -I$R/speech2lip_amd/build -c $R/speech2lip_amd/csrc/$src -o $obj
-others=$(ls $R/speech2lip_amd/build/*.o | grep -v "/${src%.hip}.o")
+others=$(ls $R/speech2lip_amd/build/*.o | grep -v "/${src%.hip}.o" | grep -v "/ref_")
 mkdir -p "$(dirname $out)"
 hipcc --offload-arch=gfx950 -shared -fPIC -o $out $obj $others
 rm -f $obj

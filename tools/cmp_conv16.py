@@ -6,6 +6,7 @@ import numpy as np, torch
 import speech2lip_amd as s2l
 from speech2lip_amd import weights as W, _abi
 dev = torch.device("cuda:0")
+_abi.reference_kernels().__enter__()      # the non-default forms live in libs2l_hip_ref.so
 lib = _abi.load()
 u = s2l.SimpleUnetLight().to(dev).eval()
 u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})

@@ -62,6 +62,7 @@ def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     Wd = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+        _abi.reference_kernels().__enter__()      # the non-default forms live in libs2l_hip_ref.so
     lib = _abi.load()
     u = s2l.SimpleUnetLight().to(dev).train()
     u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})

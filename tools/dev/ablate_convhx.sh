@@ -11,8 +11,8 @@ if [ "$1" = build ]; then
     d=$(mktemp -d /tmp/chx_XXXX)
     S2L_CH_EXP=$v python $R/speech2lip_amd/csrc/gen_convhx_body.py $d > /dev/null
     obj=$d/convh.o
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off -I$d -I$R/speech2lip_amd/build -c $R/speech2lip_amd/csrc/convh.hip -o $obj 2>/dev/null
-    others=$(ls $R/speech2lip_amd/build/*.o | grep -v "/convh.o")
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -ffp-contract=off -DS2L_WITH_REFERENCE_KERNELS -I$d -I$R/speech2lip_amd/build -c $R/speech2lip_amd/csrc/convh.hip -o $obj 2>/dev/null
+    others=$(ls $R/speech2lip_amd/build/*.o | grep -v "/convh.o" | grep -v "/ref_")
     mkdir -p $R/ab
     hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab/chx_$v.so $obj $others
     echo built ab/chx_$v.so

@@ -26,6 +26,16 @@ from speech2lip_amd import _abi, weights as W
 from speech2lip_amd.talking_face import _ptr, _stream
 
 
+def with_reference_library(fn):
+    """the non-default kernel forms these soaks compare against live in libs2l_hip_ref.so: inside the call `_abi.load()` is that library"""
+    def run(*a, **k):
+        with _abi.reference_kernels():
+            return fn(*a, **k)
+    run.__name__, run.__doc__ = fn.__name__, fn.__doc__
+    return run
+
+
+@with_reference_library
 def soak_conv(dev, rounds, seed=0, log=print):
     u = s2l.SimpleUnetLight().to(dev).eval()
     u.load_state_dict({k[len("post_fusion_unet."):]: torch.from_numpy(v) for k, v in W.make_unet_state_dict(0).items()})
@@ -55,6 +65,7 @@ def soak_conv(dev, rounds, seed=0, log=print):
     return bad
 
 
+@with_reference_library
 def soak_render(dev, rounds, seed=0, log=print):
     lib = _abi.load()
     rng = np.random.default_rng(seed + 1)
@@ -89,6 +100,7 @@ def soak_render(dev, rounds, seed=0, log=print):
     return bad
 
 
+@with_reference_library
 def soak_bf16(dev, rounds, seed=0, log=print):
     lib = _abi.load()
     rng = np.random.default_rng(seed + 2)
@@ -142,6 +154,7 @@ def soak_bf16(dev, rounds, seed=0, log=print):
     return bad
 
 
+@with_reference_library
 def soak_convh(dev, rounds, seed=0, log=print):
     """convh_asm_kernel (bf16 planes, csrc/convh.hip): random layer / direction / size / gate against the fp32-tensor kernel of the same
     arithmetic (its output rounded to bf16), each twice."""
