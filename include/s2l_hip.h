@@ -102,14 +102,17 @@ int s2l_pixel_tables(const float* packed, const float* coords, float* p0, float*
  * Replaces the per-frame driver inference.py:140-159 + rgb_forward (tf_nerf.py:225-285). */
 int s2l_render_lip(const float* packed, const float* p0, const float* p5, const float* q0,
                    const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
-/* OPT-IN split-bf16 speed mode of s2l_render_lip (same arguments + packed16; same tile shapes, ring and tables; csrc/render16.hip):
- * the seven 256x256 layers and the output layer on v_mfma_f32_16x16x32_bf16 with every fp32 operand x carried as
- * hi = bf16(x), lo = bf16(x - hi) and a product evaluated as W_lo a_hi + W_hi a_lo + W_hi a_hi, fp32 accumulation; the first
- * layer and the skip terms stay exact fp32 table sums.  ~1e-6 of the output scale from the exact kernel (north-star bar: RMSE
- * <= 1e-4), several times its frame rate.  The exact fp32 kernel is the default everywhere; this one runs only when a caller
+/* OPT-IN split-half speed mode of s2l_render_lip (same arguments + packed16; same tile shapes, ring and tables; csrc/render16.hip):
+ * the seven 256x256 layers and the output layer on v_mfma_f32_16x16x32_f16 with every fp32 operand x carried as two IEEE HALVES,
+ * hi = f16(x), lo = f16(x - hi) (11 + 11 significant bits; the activations' parts by v_cvt_pkrtz_f16_f32, the weights' to nearest),
+ * and a product evaluated as W_lo a_hi + W_hi a_lo + W_hi a_hi, fp32 accumulation; the first layer and the skip terms stay exact fp32
+ * table sums.  RANGE CONDITION the exact kernel does not have: every weight and every pre-activation must satisfy |x| < 65504 (the half
+ * range); beyond it the parts saturate -- the result is wrong but finite, never inf / NaN -- and values below 2^-14 keep only the
+ * subnormal halves' absolute precision (~6e-8).  Measured RMSE 1.4e-6 / 117 dB against the CPU oracle at 96x96 (north-star bar: RMSE
+ * <= 1e-4), 3.3 - 3.5 x the exact kernel's frame rate.  The exact fp32 kernel is the default everywhere; this one runs only when a caller
  * asks for it (TalkingFace.render_clip(precision="split")).  Replaces the same reference lines as s2l_render_lip
  * (inference.py:140-159, tf_nerf.py:225-285).
- * s2l_pack_render16: the bf16 (hi | lo) A-operand slabs, s2l_render16_packed_halves() uint16 values, from the fp32 blob. */
+ * s2l_pack_render16: the (hi | lo) half A-operand slabs, s2l_render16_packed_halves() uint16 values, from the fp32 blob. */
 int64_t s2l_render16_packed_halves(void);
 int s2l_pack_render16(const float* packed, void* packed16, s2l_stream_t stream);
 int s2l_render_lip_split(const float* packed, const void* packed16, const float* p0, const float* p5, const float* q0,

@@ -66,7 +66,7 @@ S = _scalars(16, singles=("CA CB COUT H W TILESX TILESY NCT NCH CHA CHB WAVE LDS
                           "TX TY CT FR X0 Y0 CC NTL LEFT NTX NTY NCT_ NFR NC NLEFT SX0 SY0 RS GY0 LDSW2").split(),
              pairs=("KARG", "INA", "INB", "W16", "WB", "BIAS", "OUT", "GATE", "SRC", "WCH", "FRA", "FRB", "OUTF", "GATEF",
                     "EX", "TA", "TB", "XM0", "ROWB"))
-for _n, _r in (("STATP", 98), ("STATP1", 99), ("NCOLS", 100)):      # the statistics' output pointer and the tile's valid columns
+for _n, _r in (("STATP", 98), ("STATP1", 99), ("NCOLS", 100), ("WLD", 101)):      # the statistics' output pointer, the tile's valid columns, weight loads left
     assert _r not in S.values()
     S[_n] = _r
 S_LAST = max(S.values())
@@ -284,20 +284,24 @@ class Body:
     # ---- instruction groups
     def dma_items(self, wbuf):
         """this wave's 1-KiB pieces of the staging chunk's 36 KiB of weights -> weight area of buffer wbuf: pieces 4 w .. 4 w + 3 and, for
-        waves 0..3, piece 32 + w"""
+        waves 0..3, piece 32 + w.  WLD counts the loads still to do: a layer of TWO chunks and ONE channel tile (64 -> 64 channels) finds
+        chunk 0's weights in buffer 0 and chunk 1's in buffer 1 on every tile after the first -- the store staging aliases a HALO area -- so
+        its requests stop after the first two (a fifth of those launches' LDS-DMA bytes per tile); every other layer keeps loading."""
         items = []
         for j in range(4):
             g = []
             if j == 0:
                 g += [f"s_add_u32 m0, {s('LDSW')}, {wbuf * BUF}", "s_nop 0"]
             if not EXP & 4:
-                g += [f"global_load_lds_dwordx4 v{V_DMA}, {s2('WCH')} offset:{1024 * j}"]
+                lab = self.label("wres")
+                g += [f"s_cmp_eq_u32 {s('WLD')}, 0", f"s_cbranch_scc1 {lab}",
+                      f"global_load_lds_dwordx4 v{V_DMA}, {s2('WCH')} offset:{1024 * j}", f"{lab}:"]
             items.append(g)
         skip = self.label("nox")
         g = [f"s_cmp_gt_u32 {s('WAVE')}, 3", f"s_cbranch_scc1 {skip}", f"s_add_u32 m0, {s('LDSW2')}, {wbuf * BUF}", "s_nop 0"]
         if not EXP & 4:
-            g += [f"global_load_lds_dwordx4 v{V_DMA2}, {s2('WCH')}"]
-        g += [f"{skip}:"]
+            g += [f"s_cmp_eq_u32 {s('WLD')}, 0", f"s_cbranch_scc1 {skip}", f"global_load_lds_dwordx4 v{V_DMA2}, {s2('WCH')}"]
+        g += [f"{skip}:", f"s_cmp_eq_u32 {s('WLD')}, 0", f"s_cselect_b32 {s('T0')}, 0, 1", f"s_sub_u32 {s('WLD')}, {s('WLD')}, {s('T0')}"]
         items.append(g)
         return items
 
@@ -707,6 +711,14 @@ def emit_prologue(b, with_gate=True):
     for n_, c_ in (("NTX", "TX"), ("NTY", "TY"), ("NCT_", "CT"), ("NFR", "FR")):
         e(f"s_mov_b32 {s(n_)}, {s(c_)}")
     e(f"s_mov_b32 {s('NC')}, 0")
+    # weight loads left: 2 for a layer of two chunks and one channel tile (its weights then stay in the two buffers), else unbounded
+    e(f"s_cmp_eq_u32 {s('NCH')}, 2")
+    e(f"s_cselect_b32 {s('T0')}, 1, 0")
+    e(f"s_cmp_eq_u32 {s('NCT')}, 1")
+    e(f"s_cselect_b32 {s('T1')}, 1, 0")
+    e(f"s_and_b32 {s('T0')}, {s('T0')}, {s('T1')}")
+    e(f"s_cmp_eq_u32 {s('T0')}, 1")
+    e(f"s_cselect_b32 {s('WLD')}, 2, 0x7fffffff")
     b.staging_tile_setup()
     # chunk 0 -> buffer 0, all exposed (once per workgroup)
     b.staging_source()

@@ -13,7 +13,9 @@
 namespace s2l {
 
 #ifndef S2L_RENDER16_BF16   // IEEE half parts (default); -DS2L_RENDER16_BF16 + S2L_RENDER16_HALF=bf16 for the generator: bf16 parts (A/B)
-__device__ __forceinline__ uint16_t r16_half(float x) { return __builtin_bit_cast(uint16_t, (_Float16)x); }
+__device__ __forceinline__ uint16_t r16_half(float x) {      // (clamped to the half range first: a part is never inf)
+  return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
+}
 __device__ __forceinline__ float r16_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 #else
 __device__ __forceinline__ uint16_t r16_half(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // round to nearest even

@@ -529,10 +529,13 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
 // the lo parts round to NEAREST: with both parts rounded toward zero every operand came out 2^-21 too small on average, a bias the ten
 // layers add up coherently (measured: 102 dB instead of the bf16 parts' 99; nearest: see bench_unet)
+// (the residual of an operand beyond the half range -- hi saturates at 65504, so x - hi can itself exceed it -- is clamped to the range
+// first: a value that large is already wrong in this mode, but it must stay FINITE; an inf part would turn the MFMA's sum into NaN.
+// One v_med3_f32 per value; in-range values are untouched.)  Valid operand range of the split mode: |x| < 65504 (include/s2l_hip.h).
 __device__ __forceinline__ uint32_t pack_f16x2_rne(float lo, float hi) {
   h2v v;
-  v[0] = (_Float16)lo;
-  v[1] = (_Float16)hi;
+  v[0] = (_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
+  v[1] = (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float f16_lo(uint32_t p) { return (float)__builtin_bit_cast(h2v, p)[0]; }

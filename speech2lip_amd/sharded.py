@@ -229,3 +229,27 @@ def allreduce_grads(grads: dict, group=None, average: bool = True) -> dict:
         grads[k] = flat[off:off + n].reshape(grads[k].shape)
         off += n
     return grads
+
+
+def broadcast_module_state(module, src: int = 0, group=None) -> None:
+    """What DistributedDataParallel does at construction (and, for buffers, before every forward) for the reference's
+    `Trainer(multi_gpu=True)` (training.py:41): every rank takes rank `src`'s parameters AND buffers -- the U-Net's BatchNorm
+    running statistics included -- so that ranks built or seeded differently start (and keep evaluating) as ONE replica.  One flattened
+    bucket per dtype; no-op without an initialised process group or with one rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    by_dtype = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel():
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for (dtype, dev), tensors in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].reshape(t.shape))
+                off += t.numel()
+

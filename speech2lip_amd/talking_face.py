@@ -481,7 +481,7 @@ class TalkingFace(nn.Module):
         return self._tables[key]
 
     def packed_weights_split(self) -> torch.Tensor:
-        """bf16 (hi | lo) A-operand slabs of the MLP for render_clip(precision="split") (csrc/render16.hip), rebuilt with the
+        """(hi | lo) IEEE-half A-operand slabs of the MLP for render_clip(precision="split") (csrc/render16.hip), rebuilt with the
         fp32 blob."""
         lib = _abi.load()
         packed = self.packed_weights()
@@ -496,7 +496,8 @@ class TalkingFace(nn.Module):
                     precision: str = "fp32"):
         """audio [F,16,29] + frame indices [F] -> lip frames [F,H,W,3].
         precision: "fp32" (default) the exact fp32-MFMA kernel -- the parity mode and the headline; "split" the opt-in speed
-        mode: every operand of the 256x256 layers as hi + lo bf16 parts, three bf16 MFMAs per product, fp32 accumulation
+        mode: every operand of the 256x256 layers as hi + lo IEEE-half parts (valid for |weight|, |pre-activation| < 65504; beyond it the
+        parts saturate: finite, wrong), three f16 MFMAs per product, fp32 accumulation
         (~1e-6 of the output scale from the exact frames, far inside the north-star's RMSE <= 1e-4).
 
         Same function of its inputs as running the reference's per-frame loop

@@ -97,6 +97,9 @@ class Trainer:
         self.width = int(self.cfg["data"]["width"])
         self.batch_rays = int(batch_rays if batch_rays is not None else tc.get("batch_rays", self.height * self.width))
         self.multi_gpu = bool(kwargs.pop("multi_gpu", False))
+        if self.multi_gpu:      # what wrapping the model in DistributedDataParallel does at construction (training.py:41)
+            from .sharded import broadcast_module_state
+            broadcast_module_state(model, src=0)
         self.precision = kwargs.pop("precision", "fp32")
         if self.precision not in ("fp32", "bf16"):
             raise ValueError(f"Trainer(precision=...) must be 'fp32' or 'bf16', got {self.precision!r}")
@@ -253,6 +256,11 @@ class Trainer:
         that U-Net with frozen parameters but BatchNorm batch statistics (and moving running statistics).  The drop-in does the
         same, because `post_fusion2_onlylip` follows the sub-module's own mode (golden G16)."""
         self.model.train()
+        if self.multi_gpu and getattr(self.model, "post_fusion_unet", None) is not None:
+            # DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers -- the BatchNorm running statistics -- to every rank
+            # before each forward: with per-rank frames they would otherwise drift apart rank by rank
+            from .sharded import broadcast_module_state
+            broadcast_module_state(self.model.post_fusion_unet, src=0)
         if self.cfg["training"].get("stage", "stage1") == "stage1":
             loss, loss_all = self.train_stage1(data, it=it, seed=seed)
         else:

@@ -574,3 +574,25 @@ def test_factories_accept_the_reference_may_yaml():
     tr = s2l.get_trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), cfg, "cpu")
     assert (tr.height, tr.width, tr.batch_rays) == (80, 120, 9600) and tr.multi_gpu is True
     assert tr.w_perceptual_loss == 0.01 and tr.w_syncloss == 0.01 and tr.use_post_fusion
+
+
+def test_bench_line_stays_inside_the_drivers_tail():
+    """bench.compact: the `extra` object that goes into the ONE JSON line keeps numbers only (descriptive strings live in
+    docs/BENCH_LEGEND.md, the uncut object in gpurun_out/bench_extra_full.json) -- a realistic full object shrinks below 6 KB."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    leg = {"config": "x" * 300, "ms_per_step": 41.4321987, "tflops": 642.81234, "loss_first": 0.7, "loss_last": 0.1, "peak_mem_gb": 39.6,
+           "roofline": {"bound": "hbm", "achieved": 5505.123456, "peak": 8000.0, "unit": "GB/s", "frac": 0.688140432},
+           "parity": {"rmse_vs_cpu": 1.418e-06, "psnr_db_vs_cpu": 117.0}, "error": "RuntimeError: " + "y" * 60}
+    full = {f"leg{i}": dict(leg) for i in range(20)}
+    small = bench.compact(full)
+    assert len(json.dumps(small, separators=(",", ":"))) < 6000 < len(json.dumps(full))
+    assert small["leg0"]["ms_per_step"] == 41.43 and small["leg0"]["roofline"] == {"achieved": 5505.0, "frac": 0.6881}
+    assert "config" not in small["leg0"] and "loss_last" not in small["leg0"] and small["leg0"]["error"].startswith("RuntimeError")
+    legend = open(os.path.join(ROOT, "docs", "BENCH_LEGEND.md")).read()
+    for name in ("composite", "render_split", "small_clips", "config3", "unet_fp32", "train_bf16", "dropin_trainer", "infer_clip_end_to_end",
+                 "eager_torch_gpu", "stage1_early_iteration_bf16"):
+        assert f"`{name}" in legend, name

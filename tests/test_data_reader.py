@@ -288,3 +288,22 @@ def test_reader_emits_the_negative_window_from_the_unmodified_may_config():
     assert tuple(one["rgb_window_neg"].shape) == (3, 5, 96, 96)
     off = D.SomeonesLipClip(folder, "train", cfg=C.may_config(6, 8))      # inference flags: no sync fields at all
     assert "rgb_window_neg" not in off.load_one_frame(3) and "mel" not in off.load_one_frame(3)
+
+
+def test_frame_prefetcher_keeps_order_and_collates(tmp_path):
+    """FramePrefetcher (the reference's DataLoader workers for `load_one_frame`, train.py:136-140): frames come out in the requested
+    order whatever the worker count, `per_step` at a time, collated like the DataLoader's batches or as raw dictionaries."""
+    import speech2lip_amd as s2l
+    from speech2lip_amd import data as D
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    ds = D.SomeonesLipClip(folder, "train")
+    order = [5, 1, 7, 2, 9, 0, 3]
+    got = [int(b["index"]) for b in s2l.FramePrefetcher(ds, order, workers=3, depth=2, pin_memory=False)]
+    assert got == order
+    pairs = [b["index"].tolist() for b in s2l.FramePrefetcher(ds, order, workers=2, depth=3, per_step=2, pin_memory=False)]
+    assert pairs == [[5, 1], [7, 2], [9, 0], [3]]
+    raw = list(s2l.FramePrefetcher(ds, order[:3], per_step=3, collate=False, pin_memory=False))
+    assert len(raw) == 1 and [f["index"] for f in raw[0]] == order[:3]
+    one = next(iter(s2l.FramePrefetcher(ds, [4], pin_memory=False)))
+    ref = D.collate_batch([ds.load_one_frame(4)])
+    assert set(one) == set(ref) and all(torch.equal(one[k], ref[k]) for k in ref)

@@ -148,3 +148,16 @@ def test_generated_assembly_split_convolution_equals_the_cpp_kernel(unet, shape)
         finally:
             rlib.s2l_set_unet_split_kernel(0)
     assert float(ref.abs().max()) > 0
+
+
+def test_split_mode_out_of_range_operands_stay_finite(unet):
+    """The split speed mode carries every operand as two IEEE halves: valid for |x| < 65504 (include/s2l_hip.h).  Beyond that range
+    the parts SATURATE -- hi by v_cvt_pkrtz_f16_f32, the residual x - hi by a clamp before its conversion -- so that the result is
+    wrong but FINITE (an inf part would make the MFMA's sum NaN); in range the mode keeps its accuracy."""
+    dev = next(unet.parameters()).device
+    x = torch.from_numpy(np.random.default_rng(3).random((1, 40, 56, 3), dtype=np.float32)).to(dev)
+    ok = unet.forward_nhwc(x, precision="split")
+    ref = unet.forward_nhwc(x)
+    assert float((ok - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    big = unet.forward_nhwc(x * 3e6, precision="split")           # activations of ~1e6 after the first layers
+    assert bool(torch.isfinite(big).all())
