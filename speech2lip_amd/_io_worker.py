@@ -1,0 +1,54 @@
+"""Decode worker of `data.ClipStreamer(mode="process")`: a STAND-ALONE SCRIPT run as a child process (`python _io_worker.py`; imports
+numpy and PIL only, never torch or the HIP library), because PIL's JPEG decoder keeps the interpreter lock -- 8 threads decode no
+faster than one (measured: 634 vs 560 images/s on 8 cores), which capped the inference driver at ~800 frames/s whatever the GPU did.
+One request per line on stdin (JSON): decode one observed frame (`ori_images_face/%05d.jpg`, someones_lip_dataset.py:272-275) and load one
+pose grid (`coords/%05d.npy`, :251-262) straight into the parent's shared-memory staging blocks; one "ok" / "err ..." line back."""
+import json
+import sys
+
+import numpy as np
+
+_blocks = {}
+
+
+def _attach(name):
+    from multiprocessing import shared_memory
+    b = _blocks.get(name)
+    if b is None:
+        # (the parent owns the block: keep this process's resource tracker from unlinking it at exit)
+        b = _blocks[name] = shared_memory.SharedMemory(name=name)
+        try:
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(b._name, "shared_memory")
+        except Exception:
+            pass
+    return b
+
+
+def decode_into(frames_shm, frames_shape, coords_shm, coords_shape, j, jpeg_path, npy_path):
+    if jpeg_path is not None:
+        from PIL import Image
+        dst = np.ndarray(tuple(frames_shape), dtype=np.uint8, buffer=_attach(frames_shm).buf)
+        with Image.open(jpeg_path) as im:
+            dst[j] = np.asarray(im.convert("RGB"))
+    if npy_path is not None:
+        dst = np.ndarray(tuple(coords_shape), dtype=np.float32, buffer=_attach(coords_shm).buf)
+        dst[j] = np.load(npy_path)
+    return j
+
+
+def main():
+    for line in sys.stdin:
+        line = line.strip()
+        if not line:
+            continue
+        try:
+            decode_into(*json.loads(line))
+            sys.stdout.write("ok\n")
+        except Exception as e:      # the parent raises with this text
+            sys.stdout.write("err " + repr(e).replace("\n", " ") + "\n")
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ NI = 5                                                          # halo DMA instr
 CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
 WITH_RELU = False                                               # main() generates both: convh8_body.inc (linear) and convh8r_body.inc (max(0, .))
 PFX = "S2L8"                                                    # label prefix (two bodies in one translation unit)
-EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier, 4096 / 8192 PRICING of BatchNorm's normalise + ReLU inside the consuming convolution (norm_items)
 
 # ---- registers
 A_ACC = 0
@@ -511,12 +511,43 @@ class Body:
         e("s_mov_b64 exec, -1")
         e(f"{skip}:")
 
+    # ---- PRICING ONLY (S2L_CH_EXP & 4096 / 8192): what would a = relu(z * scale + shift) cost INSIDE the convolution that consumes it?
+    def norm_items(self, buf):
+        """The work of normalising this wave's own five 1-KiB pieces of the staging chunk's halo tile in place (buffer buf), once they
+        have landed: per 16-byte slot one ds_read_b128, the 8 + 8 per-channel constants (4 ds_read_b128 of a table -- here: arbitrary LDS
+        words), 8 unpacks, 8 fma, 8 max, 4 packs, one ds_write_b128.  Arithmetic on whatever the slots hold: the results are wrong, the
+        instruction mix and its LDS traffic are what the real thing would issue.  Returns 25 groups for the sprinkle lists."""
+        d, c, u = V_T, V_T + 4, V_T + 20                               # data 4 | constants 16 | unpacked 8
+        items = []
+        for i in range(NI):
+            a = f"v{V_SLOT[buf]}"
+            g0 = [(f"ds_read_b128 v[{d}:{d + 3}], {a} offset:{1024 * i}", ("N", i, 0))]
+            for k in range(4):
+                g0.append((f"ds_read_b128 v[{c + 4 * k}:{c + 4 * k + 3}], v{V_BIASA} offset:{16 * k}", ("N", i, 1 + k)))
+            g1 = [("wait", ("N", i, 4))]
+            for k in range(4):
+                g1 += [f"v_lshlrev_b32 v{u + 2 * k}, 16, v{d + k}", f"v_and_b32 v{u + 2 * k + 1}, 0xffff0000, v{d + k}"]
+            # (identity arithmetic of the same instruction classes: the operands the MFMAs see -- and with them the power-governed clock --
+            #  stay those of the plain kernel; with real constants from an all-zero table the tile became zeros and the kernel 8 % FASTER)
+            g2 = [f"v_fma_f32 v{u + k}, v{u + k}, 1.0, 0" for k in range(8)] + [f"v_max_f32 v{c + k}, v{c + k}, v{c + 8 + k}" for k in range(2)]
+            g3 = [f"v_max_f32 v{u + k}, v{u + k}, v{u + k}" for k in range(8)]
+            g4 = [f"v_cvt_pk_bf16_f32 v{d + k}, v{u + 2 * k}, v{u + 2 * k + 1}" for k in range(4)]
+            g4.append((f"ds_write_b128 {a}, v[{d}:{d + 3}] offset:{1024 * i}", ("N", i, 9)))
+            items += [g0, g1, g2, g3, g4]
+        return items
+
     # ---- one chunk of the compute stream: reads buffer p, stages the next chunk into buffer p ^ 1
     def chunk(self, p):
         e = self.e
         self.staging_source()
         dma = self.dma_items(p ^ 1)
         hal = self.halo_items(p ^ 1)
+        if EXP & 8192:      # pricing, pessimistic placement: the chunk's own buffer is normalised right behind the barrier, by all waves at once
+            for g in self.norm_items(p):
+                self.emit_group(g)
+            self.wait_all_lds()
+            e("s_barrier")
+        norm = self.norm_items(p ^ 1) if EXP & 4096 else []
         for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
             self.lds_op(text, tag)
         for t in range(9):
@@ -534,6 +565,15 @@ class Body:
                     sprinkle[2 + 2 * k].extend(g)
             if t == 4 and p == 1:
                 self.gate_loads()
+            if norm and t == 6:      # pricing, optimistic placement: this wave's own pieces have landed (it waits for them), the work hides
+                e("s_waitcnt vmcnt(0)")      # behind the MFMAs of the last three taps
+            if norm and t >= 6:
+                for m in range(8):
+                    if norm:
+                        sprinkle[m].extend(norm.pop(0))
+                if t == 8:
+                    while norm:
+                        sprinkle[7].extend(norm.pop(0))
             if EXP & 96:
                 self.wait_all_lds()
             else:

@@ -394,7 +394,11 @@ class ClipStreamer:
     yielded batch stays valid until the iteration after the next one starts."""
 
     def __init__(self, ds: "SomeonesLipClip", device, batch: int = 100, first: int = 0, count: Optional[int] = None,
-                 workers: Optional[int] = None, depth: int = 2):
+                 workers: Optional[int] = None, depth: int = 2, mode: Optional[str] = None):
+        """mode: "thread" -- the decoders run in this process's threads -- or "process": in `workers` spawned processes that write
+        into shared-memory blocks (speech2lip_amd/_io_worker.py).  PIL's JPEG decoder holds the interpreter lock, so threads stop
+        scaling at one core's ~600 images/s; processes scale with the cores.  Default: "process" for clips of >= 256 frames (the
+        pool takes ~1 s to start), "thread" below."""
         from concurrent.futures import ThreadPoolExecutor
         self.ds, self.dev, self.batch = ds, torch.device(device), int(batch)
         n = len(ds)
@@ -405,7 +409,20 @@ class ClipStreamer:
         self.pool = ThreadPoolExecutor(self.workers)
         self.with_pose = ds.coord_files is not None and ds.mode != "test"
         self.with_frames = ds.mode != "test"
+        self.mode = mode if mode is not None else ("process" if self.count >= 256 and (self.with_pose or self.with_frames) else "thread")
+        if self.mode not in ("thread", "process"):
+            raise ValueError("ClipStreamer mode must be 'thread' or 'process'")
         ns, B, FH, FW = self.depth + 1, self.batch, ds.face_h, ds.face_w
+        self.procs = self.shm_frames = self.shm_coords = None
+        if self.mode == "process":
+            import threading
+            from multiprocessing import shared_memory
+            # one child process per pool thread, started on the thread's first task (plain `python _io_worker.py` children: they
+            # import numpy + PIL only and inherit nothing of this process's HIP state)
+            self.procs, self._tls, self._plock = [], threading.local(), threading.Lock()
+            self.fshape, self.cshape = (B, FH, FW, 3), (B, FH, FW, 2)
+            self.shm_frames = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 3) for _ in range(ns)] if self.with_frames else None
+            self.shm_coords = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 2 * 4) for _ in range(ns)] if self.with_pose else None
         pin = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype).pin_memory() for _ in range(ns)]
         on = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype, device=self.dev) for _ in range(ns)]
         self.h_coord = pin(B, FH, FW, 2, dtype=torch.float32) if self.with_pose else None
@@ -420,12 +437,39 @@ class ClipStreamer:
 
     def _decode(self, slot: int, j: int, i: int) -> None:
         ds = self.ds
+        if self.procs is not None:      # a worker PROCESS decodes into shared memory; this thread only waits and copies to the pinned block
+            jp = os.path.join(ds.dataset_folder, "ori_images_face", ds.image_files[i]) if self.with_frames else None
+            cp = os.path.join(ds.dataset_folder, "coords", ds.coord_files[i]) if self.with_pose else None
+            self._ask_worker([self.shm_frames[slot].name if self.with_frames else None, self.fshape,
+                              self.shm_coords[slot].name if self.with_pose else None, self.cshape, j, jp, cp])
+            if self.with_frames:
+                np.copyto(self.h_ori[slot][j].numpy(), np.ndarray(self.fshape, np.uint8, buffer=self.shm_frames[slot].buf)[j])
+            if self.with_pose:
+                np.copyto(self.h_coord[slot][j].numpy(), np.ndarray(self.cshape, np.float32, buffer=self.shm_coords[slot].buf)[j])
+            return
         if self.with_pose:
             self.h_coord[slot][j].numpy()[...] = np.load(os.path.join(ds.dataset_folder, "coords", ds.coord_files[i]))
         if self.with_frames:
             from PIL import Image
             with Image.open(os.path.join(ds.dataset_folder, "ori_images_face", ds.image_files[i])) as im:
                 self.h_ori[slot][j].numpy()[...] = np.asarray(im.convert("RGB"))
+
+    def _ask_worker(self, request) -> None:
+        import json
+        import subprocess
+        import sys
+        w = getattr(self._tls, "w", None)
+        if w is None:
+            w = subprocess.Popen([sys.executable, "-u", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_io_worker.py")],
+                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+            self._tls.w = w
+            with self._plock:
+                self.procs.append(w)
+        w.stdin.write(json.dumps(request) + "\n")
+        w.stdin.flush()
+        ans = w.stdout.readline().strip()
+        if ans != "ok":
+            raise RuntimeError(f"decode worker: {ans or 'died'}")
 
     def __len__(self):
         return -(-self.count // self.batch)
@@ -479,6 +523,18 @@ class ClipStreamer:
 
     def close(self):
         self.pool.shutdown(wait=True)
+        if self.procs is not None:
+            for w in self.procs:
+                try:
+                    w.stdin.close()
+                    w.wait(timeout=5)
+                except Exception:
+                    w.kill()
+            for blocks in (self.shm_frames, self.shm_coords):
+                for b in blocks or []:
+                    b.close()
+                    b.unlink()
+            self.procs = None
 
 
 class FramePrefetcher:

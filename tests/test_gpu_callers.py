@@ -195,16 +195,18 @@ def test_clip_streamer_and_frame_writer_equal_the_serial_forms(dev, tmp_path):
     ds = s2l.SomeonesLipClip(root, "train", cfg)
     n = len(ds)
     assert n == 27 and (ds.lefttop_x, ds.lefttop_y) == (20, 22)
-    st = s2l.ClipStreamer(ds, dev, batch=8, first=3, count=21, workers=3)
-    seen = 0
-    for clip in st:
-        ref = ds.load(dev, 3 + seen, len(clip.names))
-        for f in ("audio", "index", "coord", "rgb_face_ori", "rgb_face_zero", "mask_lip_canonical"):
-            assert torch.equal(getattr(clip, f), getattr(ref, f)), f
-        assert clip.names == ref.names and (clip.lip_lefttop_x, clip.height, clip.width) == (ref.lip_lefttop_x, ref.height, ref.width)
-        seen += len(clip.names)
-    st.close()
-    assert seen == 21
+    for mode in ("thread", "process"):      # decoders in this process's threads | in child processes writing shared memory (PIL holds the GIL)
+        st = s2l.ClipStreamer(ds, dev, batch=8, first=3, count=21, workers=3, mode=mode)
+        seen = 0
+        for clip in st:
+            ref = ds.load(dev, 3 + seen, len(clip.names))
+            for f in ("audio", "index", "coord", "rgb_face_ori", "rgb_face_zero", "mask_lip_canonical"):
+                assert torch.equal(getattr(clip, f), getattr(ref, f)), (mode, f)
+            assert clip.names == ref.names and (clip.lip_lefttop_x, clip.height, clip.width) == (ref.lip_lefttop_x, ref.height, ref.width)
+            seen += len(clip.names)
+        st.close()
+        assert seen == 21
+    assert s2l.ClipStreamer(ds, dev, batch=8).mode == "thread"      # (short clips: the child processes' start-up would not pay)
     frames = torch.rand(11, 40, 56, 3, device=dev)
     names = ["%05d" % (k + 1) for k in range(11)]
     s2l.write_frames(frames, names, str(tmp_path / "a"))

@@ -539,7 +539,8 @@ def bench_infer_clip(dev, n_total=640, batch=100):
     2-MB pose grids per frame) -> load -> lip render 96x96 -> composite into 500x500 -> post-fusion U-Net -> 8-bit -> JPEG files.
     The folder's name contains `may`, so the validation split is the reference's: the LAST 598 frames (someones_lip_dataset.py
     :143-145).  Three forms of tools/infer_clip.py's loop, frames/s each: serial (load, render, write one after the other),
-    pipelined (ClipStreamer + FrameWriter: decode and encode on host threads, byte-wide H2D on a side stream, beside the GPU
+    pipelined (ClipStreamer + FrameWriter: JPEG decode in child processes -- PIL's decoder holds the interpreter lock: `_decode_threads`
+    is the same pipeline with the decoders in threads --, encode on host threads, byte-wide H2D on a side stream, beside the GPU
     work), and pipelined with the split speed modes; plus the GPU-only rate of the same batches from resident inputs."""
     import shutil
     root = _dataset_tmp("may_face_crop_lip")
@@ -560,8 +561,8 @@ def bench_infer_clip(dev, n_total=640, batch=100):
             lip, recon, merged = s2l.render_clip_frames(m, clip)
             s2l.write_frames(recon, clip.names, out_dir)
 
-    def piped(precision):
-        st, wr = s2l.ClipStreamer(ds, dev, batch), s2l.FrameWriter(out_dir)
+    def piped(precision, mode="process"):
+        st, wr = s2l.ClipStreamer(ds, dev, batch, mode=mode), s2l.FrameWriter(out_dir)
         for clip in st:
             lip, recon, merged = s2l.render_clip_frames(m, clip, precision=precision)
             wr.submit(s2l.to8b(recon), clip.names)
@@ -572,7 +573,8 @@ def bench_infer_clip(dev, n_total=640, batch=100):
     s2l.render_clip_frames(m, clip0)
     s2l.render_clip_frames(m, clip0, precision="split")
     torch.cuda.synchronize()
-    for key, fn in (("serial", serial), ("pipelined", lambda: piped("fp32")), ("pipelined_split_modes", lambda: piped("split"))):
+    for key, fn in (("serial", serial), ("pipelined_decode_threads", lambda: piped("fp32", "thread")), ("pipelined", lambda: piped("fp32")),
+                    ("pipelined_split_modes", lambda: piped("split"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
