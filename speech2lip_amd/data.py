@@ -385,6 +385,36 @@ def from8b(u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor
     return o
 
 
+_DECODE_WORKERS = []      # child processes of ClipStreamer(mode="process"): started once per process, shared by every streamer
+_DECODE_FREE = None       # queue of idle workers
+
+
+def _decode_workers(n: int):
+    """At least `n` `_io_worker.py` children (started together on first use: each takes ~1 s to import numpy + PIL on a cold box;
+    they stay for the life of this process -- daemons that end when their stdin closes) and the queue a task takes an idle one from."""
+    import atexit
+    import queue
+    import subprocess
+    import sys
+    global _DECODE_FREE
+    if _DECODE_FREE is None:
+        _DECODE_FREE = queue.Queue()
+
+        def _stop():
+            for w in _DECODE_WORKERS:
+                try:
+                    w.stdin.close()
+                except Exception:
+                    pass
+        atexit.register(_stop)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_io_worker.py")
+    while len(_DECODE_WORKERS) < n:
+        w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+        _DECODE_WORKERS.append(w)
+        _DECODE_FREE.put(w)
+    return _DECODE_FREE
+
+
 class ClipStreamer:
     """`SomeonesLipClip.load` as a pipeline (the clip-level counterpart of the reference's DataLoader, inference.py:129-140):
     batches of `batch` frames are read by a pool of host threads (JPEG decode and `np.load` release the GIL) straight into
@@ -415,11 +445,10 @@ class ClipStreamer:
         ns, B, FH, FW = self.depth + 1, self.batch, ds.face_h, ds.face_w
         self.procs = self.shm_frames = self.shm_coords = None
         if self.mode == "process":
-            import threading
             from multiprocessing import shared_memory
-            # one child process per pool thread, started on the thread's first task (plain `python _io_worker.py` children: they
-            # import numpy + PIL only and inherit nothing of this process's HIP state)
-            self.procs, self._tls, self._plock = [], threading.local(), threading.Lock()
+            # plain `python _io_worker.py` children (they import numpy + PIL only and inherit nothing of this process's HIP state),
+            # started once per process and shared by every streamer; a pool thread borrows an idle one per task
+            self.procs = _decode_workers(self.workers)
             self.fshape, self.cshape = (B, FH, FW, 3), (B, FH, FW, 2)
             self.shm_frames = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 3) for _ in range(ns)] if self.with_frames else None
             self.shm_coords = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 2 * 4) for _ in range(ns)] if self.with_pose else None
@@ -456,18 +485,13 @@ class ClipStreamer:
 
     def _ask_worker(self, request) -> None:
         import json
-        import subprocess
-        import sys
-        w = getattr(self._tls, "w", None)
-        if w is None:
-            w = subprocess.Popen([sys.executable, "-u", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_io_worker.py")],
-                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
-            self._tls.w = w
-            with self._plock:
-                self.procs.append(w)
-        w.stdin.write(json.dumps(request) + "\n")
-        w.stdin.flush()
-        ans = w.stdout.readline().strip()
+        w = self.procs.get()
+        try:
+            w.stdin.write(json.dumps(request) + "\n")
+            w.stdin.flush()
+            ans = w.stdout.readline().strip()
+        finally:
+            self.procs.put(w)
         if ans != "ok":
             raise RuntimeError(f"decode worker: {ans or 'died'}")
 
@@ -523,13 +547,7 @@ class ClipStreamer:
 
     def close(self):
         self.pool.shutdown(wait=True)
-        if self.procs is not None:
-            for w in self.procs:
-                try:
-                    w.stdin.close()
-                    w.wait(timeout=5)
-                except Exception:
-                    w.kill()
+        if self.procs is not None:      # (the worker processes stay: the next streamer re-uses them)
             for blocks in (self.shm_frames, self.shm_coords):
                 for b in blocks or []:
                     b.close()

@@ -569,6 +569,12 @@ def bench_infer_clip(dev, n_total=640, batch=100):
         wr.close()
         st.close()
     # warm-up on a short prefix (kernel code objects, pinned allocations), then one timed pass each
+    t0 = time.perf_counter()
+    warm = s2l.ClipStreamer(ds, dev, 8, 0, 16, mode="process")      # starts the decode worker processes (once per process; ~1-3 s on a cold box)
+    for _ in warm:
+        pass
+    warm.close()
+    res["decode_workers_start_s"] = round(time.perf_counter() - t0, 2)
     clip0 = ds.load(dev, 0, min(batch, n))
     s2l.render_clip_frames(m, clip0)
     s2l.render_clip_frames(m, clip0, precision="split")
