@@ -557,20 +557,42 @@ class ClipStreamer:
             self.procs = None
 
 
+class _FrameDataset(torch.utils.data.Dataset):
+    """`SomeonesLipClip.load_one_frame` behind torch's Dataset protocol (what `SomeonesLipDataset.__getitem__` is to the reference's
+    DataLoader, someones_lip_dataset.py:416-420), in a fixed visiting order."""
+
+    def __init__(self, ds, order):
+        self.ds, self.order = ds, list(order)
+
+    def __len__(self):
+        return len(self.order)
+
+    def __getitem__(self, k):
+        return self.ds.load_one_frame(self.order[k])
+
+
 class FramePrefetcher:
     """The reference's `DataLoader(num_workers > 0)` (train.py:136-140) for `load_one_frame`: the dictionaries of the frame
-    indices in `order` are prepared by a pool of host threads up to `depth` frames ahead (JPEG decode, `np.load` and the
-    8-bit resize release the GIL) and come out in order, collated (`collate_batch`) `per_step` at a time."""
+    indices in `order` are prepared up to `depth` frames ahead and come out in order, collated (`collate_batch`) `per_step` at a time.
+    mode "process" (default with a GPU): torch's own DataLoader worker PROCESSES -- the reader's numpy / PIL work (JPEG decode, the
+    8-bit resize of the negative window: 10 - 18 ms per frame) holds the interpreter lock, so threads top out near one core;
+    mode "thread": a thread pool in this process (no start-up cost; what the CPU tests use)."""
 
     def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True,
-                 pin_memory: Optional[bool] = None):
-        """pin_memory (default: when a GPU is visible): the workers leave every tensor in page-locked memory, as
-        `DataLoader(pin_memory=True)` does -- the ~16 MB a frame with its sync window carries then cross PCIe by DMA at ~50 GB/s
-        instead of through a pageable staging copy (3.7 ms per frame measured)."""
-        from concurrent.futures import ThreadPoolExecutor
+                 pin_memory: Optional[bool] = None, mode: Optional[str] = None):
+        """pin_memory (default: when a GPU is visible): every tensor arrives in page-locked memory, as `DataLoader(pin_memory=True)`
+        does -- the ~16 MB a frame with its sync window carries then cross PCIe by DMA at ~50 GB/s instead of through a pageable
+        staging copy (3.7 ms per frame measured)."""
         self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
         self.pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
-        self.pool = ThreadPoolExecutor(int(workers) if workers else min(16, os.cpu_count() or 1))
+        self.workers = int(workers) if workers else min(16, os.cpu_count() or 1)
+        self.mode = mode if mode is not None else ("process" if torch.cuda.is_available() else "thread")
+        if self.mode not in ("thread", "process"):
+            raise ValueError("FramePrefetcher mode must be 'thread' or 'process'")
+        self.pool = None
+        if self.mode == "thread":
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(self.workers)
 
     def _load(self, i):
         d = self.ds.load_one_frame(i)
@@ -581,6 +603,13 @@ class FramePrefetcher:
         return d
 
     def __iter__(self):
+        if self.mode == "process":
+            w = max(1, min(self.workers, len(self.order)))
+            loader = torch.utils.data.DataLoader(_FrameDataset(self.ds, self.order), batch_size=self.per_step, shuffle=False, num_workers=w,
+                                                 collate_fn=collate_batch if self.collate else list, pin_memory=self.pin,
+                                                 prefetch_factor=max(1, -(-self.depth // (w * self.per_step))), drop_last=False)
+            yield from loader
+            return
         from collections import deque
         q, it = deque(), iter(self.order)
         for i in it:
@@ -598,7 +627,8 @@ class FramePrefetcher:
                 group = []
 
     def close(self):
-        self.pool.shutdown(wait=True)
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
 
 
 class FrameWriter:

@@ -298,12 +298,17 @@ def test_frame_prefetcher_keeps_order_and_collates(tmp_path):
     folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
     ds = D.SomeonesLipClip(folder, "train")
     order = [5, 1, 7, 2, 9, 0, 3]
-    got = [int(b["index"]) for b in s2l.FramePrefetcher(ds, order, workers=3, depth=2, pin_memory=False)]
+    got = [int(b["index"]) for b in s2l.FramePrefetcher(ds, order, workers=3, depth=2, pin_memory=False, mode="thread")]
     assert got == order
-    pairs = [b["index"].tolist() for b in s2l.FramePrefetcher(ds, order, workers=2, depth=3, per_step=2, pin_memory=False)]
+    pairs = [b["index"].tolist() for b in s2l.FramePrefetcher(ds, order, workers=2, depth=3, per_step=2, pin_memory=False, mode="thread")]
     assert pairs == [[5, 1], [7, 2], [9, 0], [3]]
-    raw = list(s2l.FramePrefetcher(ds, order[:3], per_step=3, collate=False, pin_memory=False))
+    raw = list(s2l.FramePrefetcher(ds, order[:3], per_step=3, collate=False, pin_memory=False, mode="thread"))
     assert len(raw) == 1 and [f["index"] for f in raw[0]] == order[:3]
-    one = next(iter(s2l.FramePrefetcher(ds, [4], pin_memory=False)))
+    one = next(iter(s2l.FramePrefetcher(ds, [4], pin_memory=False, mode="thread")))
     ref = D.collate_batch([ds.load_one_frame(4)])
     assert set(one) == set(ref) and all(torch.equal(one[k], ref[k]) for k in ref)
+    # worker PROCESSES (torch's DataLoader underneath, as the reference's loop has it): the same dictionaries in the same order
+    procs = list(s2l.FramePrefetcher(ds, order, workers=2, depth=4, per_step=2, pin_memory=False, mode="process"))
+    assert [b["index"].tolist() for b in procs] == [[5, 1], [7, 2], [9, 0], [3]]
+    refp = D.collate_batch([ds.load_one_frame(5), ds.load_one_frame(1)])
+    assert all(torch.equal(procs[0][k], refp[k]) for k in refp)
