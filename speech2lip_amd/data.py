@@ -574,9 +574,11 @@ class _FrameDataset(torch.utils.data.Dataset):
 class FramePrefetcher:
     """The reference's `DataLoader(num_workers > 0)` (train.py:136-140) for `load_one_frame`: the dictionaries of the frame
     indices in `order` are prepared up to `depth` frames ahead and come out in order, collated (`collate_batch`) `per_step` at a time.
-    mode "process" (default with a GPU): torch's own DataLoader worker PROCESSES -- the reader's numpy / PIL work (JPEG decode, the
-    8-bit resize of the negative window: 10 - 18 ms per frame) holds the interpreter lock, so threads top out near one core;
-    mode "thread": a thread pool in this process (no start-up cost; what the CPU tests use)."""
+    mode "thread" (default): a thread pool in this process; mode "process": torch's own DataLoader worker PROCESSES (what the reference's
+    loop uses).  The reader's numpy / PIL work (JPEG decode, the 8-bit resize of the negative window: 10 - 18 ms per frame) holds the
+    interpreter lock, so the thread pool tops out near one core -- but on the benchmark host the DataLoader's transport of a frame's ~16 MB
+    through shared memory cost far more than it saved (`extra.dropin_trainer` measured 19 - 268 ms per iteration with it against 12 - 14 with
+    threads), so threads stay the default."""
 
     def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True,
                  pin_memory: Optional[bool] = None, mode: Optional[str] = None):
@@ -586,7 +588,7 @@ class FramePrefetcher:
         self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
         self.pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.workers = int(workers) if workers else min(16, os.cpu_count() or 1)
-        self.mode = mode if mode is not None else ("process" if torch.cuda.is_available() else "thread")
+        self.mode = mode if mode is not None else "thread"
         if self.mode not in ("thread", "process"):
             raise ValueError("FramePrefetcher mode must be 'thread' or 'process'")
         self.pool = None
