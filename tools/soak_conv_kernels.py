@@ -195,6 +195,23 @@ def soak_convh(dev, rounds, seed=0, log=print):
             _abi.check(lib.s2l_convh_layer(p(raw16), layer, tr, p(ah), CA, p(bh), CB, p(gh), p(out), H, Wd, F, st), "convh")
             ok = ok and torch.equal(c32_to_nhwc(out), want)
         lib.s2l_set_unet_half_kernel(0)
+        if not tr and (H + 31) // 32 * ((Wd + 15) // 16) <= 1024:
+            # the forward launch that also leaves its tiles' batch statistics (the train-mode chain's): the same output bits, and the
+            # partial sums add up to the stored tensor's per-frame, per-channel sum / sum of squares; twice: the partials are the same bits
+            parts = []
+            for _ in range(2):
+                out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+                stat = torch.full((F * 1024 * 2 * cout,), float("nan"), device=dev)
+                blocks = ctypes.c_int(0)
+                _abi.check(lib.s2l_debug_convh_layer_stats(p(raw16), layer, p(ah), CA, p(bh), CB, p(out), p(stat), ctypes.byref(blocks), H, Wd, F, st),
+                           "convh stats")
+                ok = ok and torch.equal(c32_to_nhwc(out), want) and blocks.value == (H + 31) // 32 * ((Wd + 15) // 16)
+                parts.append(stat[:F * blocks.value * 2 * cout].reshape(F, blocks.value, 2, cout).clone())
+            z = want.view(torch.bfloat16).double()
+            got = parts[0].double().sum(1)
+            ok = ok and torch.equal(parts[0], parts[1])
+            ok = ok and float((got[:, 0] - z.sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float(z.abs().sum((1, 2)).max()))
+            ok = ok and float((got[:, 1] - (z * z).sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float((z * z).sum((1, 2)).max()))
         if not ok:
             bad.append(("convh", layer, tr, F, H, Wd, gate))
             log("MISMATCH convh", layer, tr, F, H, Wd, gate)
