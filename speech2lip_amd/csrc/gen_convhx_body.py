@@ -203,6 +203,9 @@ def generate():
     e = b.e
     pfx = b.pfx
     G.emit_prologue(b, with_gate=False)
+    # this form's store staging is buffer 1's WEIGHT area: the weights never stay resident across tiles, every chunk reloads them
+    # (a 3000-shape soak caught the eight-wave form's "two chunks, one channel tile" shortcut reaching this body through dma_items)
+    e(f"s_mov_b32 {s('WLD')}, 0x7fffffff")
     e(f"s_cmp_gt_u32 {s('WAVE')}, 3")
     e(f"s_cbranch_scc1 {pfx}_FOLLOW")
     # ================= leaders (waves 0-3)
