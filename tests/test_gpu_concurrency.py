@@ -165,14 +165,14 @@ def test_render_shape_switch_from_another_thread_keeps_the_bits(dev):
 
 
 def test_soak_slice_of_the_counted_wait_assembly_kernels(dev):
-    """100 random shapes: render_tiles_kernel<long|wide|single> against each other, fwd/bwd_asm_bf16 against the C++ kernels,
+    """300 random shapes: render_tiles_kernel<long|wide|single> against each other, fwd/bwd_asm_bf16 against the C++ kernels,
     conv3x3_split_kernel against the one-tile form -- bit for bit, each run twice."""
     from tools import soak_conv_kernels as soak
     notes = []
     bad = soak.soak_render(dev, 60, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_bf16(dev, 25, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_conv(dev, 15, seed=4, log=lambda *a: notes.append(a))
-    bad += soak.soak_convh(dev, 40, seed=4, log=lambda *a: notes.append(a))
+    bad += soak.soak_convh(dev, 200, seed=4, log=lambda *a: notes.append(a))      # (incl. the statistics-leaving launches; 200: the round-5 residency bug showed on ~2 % of shapes)
     torch.cuda.synchronize()
     assert not bad, notes
 
