@@ -557,61 +557,91 @@ class ClipStreamer:
             self.procs = None
 
 
-class _FrameDataset(torch.utils.data.Dataset):
-    """`SomeonesLipClip.load_one_frame` behind torch's Dataset protocol (what `SomeonesLipDataset.__getitem__` is to the reference's
-    DataLoader, someones_lip_dataset.py:416-420), in a fixed visiting order."""
-
-    def __init__(self, ds, order):
-        self.ds, self.order = ds, list(order)
-
-    def __len__(self):
-        return len(self.order)
-
-    def __getitem__(self, k):
-        return self.ds.load_one_frame(self.order[k])
-
-
 class FramePrefetcher:
     """The reference's `DataLoader(num_workers > 0)` (train.py:136-140) for `load_one_frame`: the dictionaries of the frame
     indices in `order` are prepared up to `depth` frames ahead and come out in order, collated (`collate_batch`) `per_step` at a time.
-    mode "thread" (default): a thread pool in this process; mode "process": torch's own DataLoader worker PROCESSES (what the reference's
-    loop uses).  The reader's numpy / PIL work (JPEG decode, the 8-bit resize of the negative window: 10 - 18 ms per frame) holds the
-    interpreter lock, so the thread pool tops out near one core -- but on the benchmark host the DataLoader's transport of a frame's ~16 MB
-    through shared memory cost far more than it saved (`extra.dropin_trainer` measured 19 - 268 ms per iteration with it against 12 - 14 with
-    threads), so threads stay the default."""
+    mode "thread" (default without a GPU; what the CPU tests use): a thread pool in this process; mode "process" (default with one):
+    `workers` child processes (`_reader_worker.py`, each with its own `SomeonesLipClip`) that write a frame's tensors into shared
+    memory -- the reader's PIL / numpy work (JPEG decode, the 8-bit resize of the negative window: 10 - 18 ms per frame) holds the
+    interpreter lock, so loader threads top out near one core.  (torch's own DataLoader processes were tried first: their transport of a
+    frame's ~16 MB measured 19 - 268 ms per iteration on the benchmark host.)"""
+
+    SLAB = 24 << 20      # bytes of shared memory per frame in flight (a May frame with its sync window: 16.3 MB)
 
     def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True,
                  pin_memory: Optional[bool] = None, mode: Optional[str] = None):
         """pin_memory (default: when a GPU is visible): every tensor arrives in page-locked memory, as `DataLoader(pin_memory=True)`
         does -- the ~16 MB a frame with its sync window carries then cross PCIe by DMA at ~50 GB/s instead of through a pageable
         staging copy (3.7 ms per frame measured)."""
+        from concurrent.futures import ThreadPoolExecutor
         self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
         self.pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
-        self.workers = int(workers) if workers else min(16, os.cpu_count() or 1)
-        self.mode = mode if mode is not None else "thread"
+        self.workers = int(workers) if workers else min(8, os.cpu_count() or 1)
+        self.mode = mode if mode is not None else ("process" if torch.cuda.is_available() else "thread")
         if self.mode not in ("thread", "process"):
             raise ValueError("FramePrefetcher mode must be 'thread' or 'process'")
-        self.pool = None
-        if self.mode == "thread":
-            from concurrent.futures import ThreadPoolExecutor
-            self.pool = ThreadPoolExecutor(self.workers)
+        self.pool = ThreadPoolExecutor(self.workers)
+        self.free = self.procs = self.slabs = None
+        if self.mode == "process":
+            import json
+            import queue
+            import subprocess
+            import sys
+            from multiprocessing import shared_memory
+            script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_reader_worker.py")
+            head = json.dumps({"folder": ds.dataset_folder, "mode": ds.mode, "cfg": ds.cfg}, default=lambda o: None)
+            self.procs, self.free, self.slabs = [], queue.Queue(), queue.Queue()
+            for _ in range(self.workers):      # started together; each builds its own reader (~2 s: python + torch import + the folder scan)
+                w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+                w.stdin.write(head + "\n")
+                w.stdin.flush()
+                self.procs.append(w)
+            for w in self.procs:
+                if w.stdout.readline().strip() != "ready":
+                    raise RuntimeError("FramePrefetcher: a reader process did not start")
+                self.free.put(w)
+            self._blocks = [shared_memory.SharedMemory(create=True, size=self.SLAB) for _ in range(self.depth + self.workers)]
+            for b in self._blocks:
+                self.slabs.put(b)
+
+    def _load_in_process(self, i):
+        import json
+        w, slab = self.free.get(), self.slabs.get()
+        try:
+            w.stdin.write(json.dumps({"index": int(i), "shm": slab.name}) + "\n")
+            w.stdin.flush()
+            man = json.loads(w.stdout.readline())
+        finally:
+            self.free.put(w)
+        try:
+            if "__error__" in man:
+                raise RuntimeError(f"reader process: {man['__error__']}")
+            d = {}
+            for k, m in man.items():
+                if "value" in m:
+                    d[k] = m["value"]
+                    continue
+                a = np.ndarray(tuple(m["shape"]), np.dtype(m["dtype"]), buffer=slab.buf, offset=m["off"])
+                if m["tensor"]:
+                    t = torch.empty(tuple(m["shape"]), dtype=torch.from_numpy(a[:0].copy() if a.ndim else a.copy()).dtype,
+                                    pin_memory=self.pin and a.nbytes > 16384)
+                    np.copyto(t.numpy(), a)      # (releases the interpreter lock for large arrays)
+                    d[k] = t
+                else:
+                    d[k] = a.copy()
+            return d
+        finally:
+            self.slabs.put(slab)
 
     def _load(self, i):
-        d = self.ds.load_one_frame(i)
+        d = self._load_in_process(i) if self.mode == "process" else self.ds.load_one_frame(i)
         if self.collate and self.per_step == 1:      # (collating stacks into fresh tensors: do it here, before pinning)
             d = collate_batch([d])
         if self.pin:
-            d = {k: (v.pin_memory() if isinstance(v, torch.Tensor) and v.numel() > 4096 else v) for k, v in d.items()}
+            d = {k: (v.pin_memory() if isinstance(v, torch.Tensor) and v.numel() > 4096 and not v.is_pinned() else v) for k, v in d.items()}
         return d
 
     def __iter__(self):
-        if self.mode == "process":
-            w = max(1, min(self.workers, len(self.order)))
-            loader = torch.utils.data.DataLoader(_FrameDataset(self.ds, self.order), batch_size=self.per_step, shuffle=False, num_workers=w,
-                                                 collate_fn=collate_batch if self.collate else list, pin_memory=self.pin,
-                                                 prefetch_factor=max(1, -(-self.depth // (w * self.per_step))), drop_last=False)
-            yield from loader
-            return
         from collections import deque
         q, it = deque(), iter(self.order)
         for i in it:
@@ -629,8 +659,18 @@ class FramePrefetcher:
                 group = []
 
     def close(self):
-        if self.pool is not None:
-            self.pool.shutdown(wait=True)
+        self.pool.shutdown(wait=True)
+        if self.procs is not None:
+            for w in self.procs:
+                try:
+                    w.stdin.close()
+                    w.wait(timeout=5)
+                except Exception:
+                    w.kill()
+            for b in self._blocks:
+                b.close()
+                b.unlink()
+            self.procs = None
 
 
 class FrameWriter:

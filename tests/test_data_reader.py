@@ -307,8 +307,10 @@ def test_frame_prefetcher_keeps_order_and_collates(tmp_path):
     one = next(iter(s2l.FramePrefetcher(ds, [4], pin_memory=False, mode="thread")))
     ref = D.collate_batch([ds.load_one_frame(4)])
     assert set(one) == set(ref) and all(torch.equal(one[k], ref[k]) for k in ref)
-    # worker PROCESSES (torch's DataLoader underneath, as the reference's loop has it): the same dictionaries in the same order
-    procs = list(s2l.FramePrefetcher(ds, order, workers=2, depth=4, per_step=2, pin_memory=False, mode="process"))
+    # reader PROCESSES (each with its own SomeonesLipClip, tensors through shared memory): the same dictionaries in the same order
+    pf = s2l.FramePrefetcher(ds, order, workers=2, depth=4, per_step=2, pin_memory=False, mode="process")
+    procs = list(pf)
+    pf.close()
     assert [b["index"].tolist() for b in procs] == [[5, 1], [7, 2], [9, 0], [3]]
     refp = D.collate_batch([ds.load_one_frame(5), ds.load_one_frame(1)])
-    assert all(torch.equal(procs[0][k], refp[k]) for k in refp)
+    assert set(procs[0]) == set(refp) and all(torch.equal(procs[0][k], refp[k]) and procs[0][k].dtype == refp[k].dtype for k in refp)
