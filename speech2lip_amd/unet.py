@@ -513,8 +513,15 @@ class SimpleUnetLight(nn.Module):
             lib = _abi.load()
             if precision == "bf16" and getattr(self, "half_width_tensors", True) and H <= 255 * 32 and W <= 255 * 16:
                 precision = "bf16h"      # (bf16 tensors between the kernels, weight gradients straight from the bf16 planes)
-            per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
-            group = max(1, min(F_, int(getattr(self, "train_frames_budget_bytes", 16 << 30)) // max(per_frame, 1)))
+            budget = int(getattr(self, "train_frames_budget_bytes", 16 << 30))
+            if precision == "bf16h":      # the half-width route's own sizes; its backward also allocates the split-K partials of the weight
+                # gradients once per call (the difference of the two work sizes at one frame: ~300 MB), which comes off the budget first
+                fixed = 2 * (int(lib.s2l_unet_train_frames_h_work_halves_grads(H, W, 1)) - int(lib.s2l_unet_train_frames_h_work_halves(H, W, 1)))
+                per_frame = 2 * (int(lib.s2l_unet_train_frames_h_saved_halves(H, W, 1)) + int(lib.s2l_unet_train_frames_h_work_halves(H, W, 1)))
+                budget = max(budget - fixed, per_frame)
+            else:
+                per_frame = 4 * (int(lib.s2l_unet_train_frames_saved_floats(H, W, 1)) + int(lib.s2l_unet_train_frames_work_floats(H, W, 1)))
+            group = max(1, min(F_, budget // max(per_frame, 1)))
             if precision == "bf16h":
                 group = min(group, 8191)
             outs, ctxs = [], []
