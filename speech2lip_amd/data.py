@@ -623,7 +623,7 @@ class FramePrefetcher:
                     continue
                 a = np.ndarray(tuple(m["shape"]), np.dtype(m["dtype"]), buffer=slab.buf, offset=m["off"])
                 if m["tensor"]:
-                    t = torch.empty(tuple(m["shape"]), dtype=torch.from_numpy(a[:0].copy() if a.ndim else a.copy()).dtype,
+                    t = torch.empty(tuple(m["shape"]), dtype=torch.from_numpy(np.empty(0, a.dtype)).dtype,
                                     pin_memory=self.pin and a.nbytes > 16384)
                     np.copyto(t.numpy(), a)      # (releases the interpreter lock for large arrays)
                     d[k] = t
