@@ -548,6 +548,15 @@ int s2l_syncnet_forward_pair(const float* packed, const float* mel, const float*
                              float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream);
 int s2l_syncnet_face_backward_prefix(const float* packed, const float* face, float* work, const float* d_face_emb,
                                      float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream);
+/* Opt-in speed mode of the two entry points above (round 5; the exact fp32 convolutions stay the default and are what the parity
+ * tests pin): the implicit-GEMM convolutions of 64-row tiles run with BOTH operands as hi + lo bf16 parts -- three
+ * v_mfma_f32_16x16x32_bf16 per product block, fp32 accumulation, ~1e-5 relative on a layer's output; fp32 range, so the gradients
+ * keep their small values (csrc/conv_gemm.h).  Same arguments, same `packed` blob (s2l_syncnet_pack writes the parts too), same
+ * `work`; a backward must use the form its forward used. */
+int s2l_syncnet_forward_pair_split(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                   float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream);
+int s2l_syncnet_face_backward_prefix_split(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                           float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream);
 int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,
                     s2l_stream_t stream);
 int s2l_sync_window_backward(const float* d_face, float* d_g_rgb, int n_frames_t, int height, int width,
@@ -572,6 +581,12 @@ int s2l_lpips_forward(const float* packed, const float* in0, const float* in1, i
                       int height, int width, int64_t batch, s2l_stream_t stream);
 int s2l_lpips_backward(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
                        int height, int width, int64_t batch, s2l_stream_t stream);
+/* The same two calls with conv2..conv5 and their input gradients in the split-operand form (see s2l_syncnet_forward_pair_split;
+ * conv1 and its input gradient keep their own exact kernels). */
+int s2l_lpips_forward_split(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
+                            int height, int width, int64_t batch, s2l_stream_t stream);
+int s2l_lpips_backward_split(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
+                             int height, int width, int64_t batch, s2l_stream_t stream);
 
 /* ---- bf16 mode of the training step (BASELINE config 5; same mathematics as s2l_train_forward / _backward /
  * s2l_wgrad, operands and saved state in bf16, fp32 accumulation, fp32 master weights and gradients) -------------

@@ -160,6 +160,8 @@ EXPORTS = {
     "s2l_lpips_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
     "s2l_lpips_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_lpips_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_lpips_forward_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_lpips_backward_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_syncnet_packed_floats": (c_int64, []),
     "s2l_syncnet_work_floats": (c_int64, [c_int64]),
     "s2l_syncnet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),
@@ -168,6 +170,8 @@ EXPORTS = {
     "s2l_syncnet_face_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_syncnet_forward_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_syncnet_face_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_syncnet_forward_pair_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "s2l_syncnet_face_backward_prefix_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_sync_window": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_sync_window_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "s2l_bf16_packed_halves": (c_int64, []),

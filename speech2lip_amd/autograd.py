@@ -317,23 +317,24 @@ def mse(prediction, target, weights: float = 1.0):
 
 class _LpipsDistance(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, in0, in1, from01):
+    def forward(ctx, module, in0, in1, from01, precision=None):
         need = in0.requires_grad
         if in1.requires_grad:
             raise NotImplementedError("LPIPS on the HIP path differentiates with respect to its first image only (the second is the "
                                       "ground truth in training.py:655-674)")
         if need:
-            out, ctx.state = module.distance_nhwc(in0, in1, from01, keep=True)
+            out, ctx.state = module.distance_nhwc(in0, in1, from01, keep=True, precision=precision)
         else:
-            out = module.distance_nhwc(in0, in1, from01)
+            out = module.distance_nhwc(in0, in1, from01, precision=precision)
         ctx.module, ctx.shape = module, in0.shape
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        return None, ctx.module.backward_nhwc(ctx.state, d_out).reshape(ctx.shape), None, None
+        return None, ctx.module.backward_nhwc(ctx.state, d_out).reshape(ctx.shape), None, None, None
 
 
-def lpips_distance(module, in0_nhwc, in1_nhwc, from01: bool = False):
-    """lpips.LPIPS(net='alex')(in0, in1) for NHWC images -> [N]; differentiable in in0 (csrc/lpips.hip)."""
-    return _LpipsDistance.apply(module, in0_nhwc, in1_nhwc, bool(from01))
+def lpips_distance(module, in0_nhwc, in1_nhwc, from01: bool = False, precision: str = None):
+    """lpips.LPIPS(net='alex')(in0, in1) for NHWC images -> [N]; differentiable in in0 (csrc/lpips.hip).  precision: None (the
+    module's `conv_precision`), "fp32" or "split" (conv2..conv5 on hi + lo bf16 operands)."""
+    return _LpipsDistance.apply(module, in0_nhwc, in1_nhwc, bool(from01), precision)

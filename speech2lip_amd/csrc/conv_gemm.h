@@ -68,6 +68,8 @@ struct ConvArgs {
   int hin, win, cin, hout, wout, cout, kh, kw, sy, sx, py, px;
   int rows, RP, kc, kcp, ncols, nchunks, chunks_per_split;
   int PR;             // row stride of the split-K partial tiles: rows rounded up to the tile height (16 / 32 / 64), <= RP
+  const uint16_t* w16;  // or null: the A operand as hi + lo bf16 parts in MFMA lane order (conv_pack16_kernel) -- the split form below
+  int nsteps, steps_per_split;      // split form: K in steps of 32
 };
 
 __device__ static __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -246,6 +248,193 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   }
 }
 
+// ---- the SPLIT form (round 5): the same GEMM with both operands as hi + lo bf16 parts, three v_mfma_f32_16x16x32_bf16 per product
+// block (lo x hi, hi x lo, hi x hi; lo x lo, <= 2^-18 of the product, is dropped), fp32 accumulation -- 16 significant bits per
+// operand, range of fp32 (so it serves the gradients too, which IEEE halves would flush).  An opt-in speed mode for the bf16-precision
+// training steps only: the exact fp32 kernel above stays the default and the one the parity tests pin.  64 x 64 tiles, rows > 32,
+// K channels a multiple of 8; other layers run the exact kernel.
+//   A: packed ONCE in MFMA lane order -- [k-step of 32][16-row block][hi | lo][lane 64][8 bf16]: a wave loads its operand with one
+//      coalesced 16-byte load per lane straight from global memory (1 KiB per instruction), no LDS;
+//   B: gathered as in the exact kernel, 8 channels (two 16-byte loads) per thread and k-step, split into parts on the way to LDS;
+//      LDS rows are K-contiguous (64 B per pixel and part), 16-byte pieces XOR-swizzled by the pixel so that both the commit and the
+//      operand reads are conflict-free.
+typedef short cg_bf8 __attribute__((ext_vector_type(8)));
+typedef uint32_t cg_u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cg_bf2 __attribute__((ext_vector_type(2)));
+
+__device__ static __forceinline__ uint32_t cg_pack_bf2(float x, float y) {
+  cg_bf2 v;
+  v[0] = (__bf16)x;
+  v[1] = (__bf16)y;
+  return __builtin_bit_cast(uint32_t, v);
+}
+// (x, y) -> hi parts (round to nearest even) and the parts of what they leave
+__device__ static __forceinline__ void cg_split2(float x, float y, uint32_t& hi, uint32_t& lo) {
+  hi = cg_pack_bf2(x, y);
+  lo = cg_pack_bf2(x - __uint_as_float(hi << 16), y - __uint_as_float(hi & 0xffff0000u));
+}
+
+// one thread per element of [k-step][row block][part][lane][8]
+__global__ static void conv_pack16_kernel(const float* __restrict__ w, uint16_t* __restrict__ dst, int K16, int RP, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)(i & 7), lane = (int)(i >> 3) & 63, part = (int)(i >> 9) & 1;
+  const int64_t blk = i >> 10;
+  const int RB = RP / 16, rb = (int)(blk % RB), ks = (int)(blk / RB);
+  const int k = ks * 32 + (lane >> 4) * 8 + e, row = rb * 16 + (lane & 15);
+  const float v = k < K16 ? w[(int64_t)k * RP + row] : 0.f;
+  uint32_t hi, lo;
+  cg_split2(v, 0.f, hi, lo);
+  dst[i] = (uint16_t)(part ? lo : hi);
+}
+
+constexpr int kGroup16 = 4;      // k-steps of 32 per barrier pair (LDS 32 KiB)
+
+template <bool DGRAD>
+__global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a) {
+  constexpr int G = kGroup16;
+  __shared__ cg_u4 Bs[G * 2 * 64 * 4];      // [g][part][pixel][piece ^ ((pixel >> 2) & 3)]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
+  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+  const int step_lo = blockIdx.z * a.steps_per_split;
+  const int step_hi = min(a.nsteps, step_lo + a.steps_per_split);
+  const int RB = a.RP / 16, K16 = a.nchunks * 16;
+
+  // B-load role: pixel pl of the tile, channel octet oct of the k-step
+  const int pl = t >> 2, oct = t & 3;
+  const int cw = DGRAD ? a.win : a.wout, chw = DGRAD ? a.hin * a.win : a.hout * a.wout;
+  const int col = col0 + pl;
+  const bool col_ok = col < a.ncols;
+  const int cc = col_ok ? col : 0;
+  const int pn = cc / chw, rem = cc - pn * chw, cy = rem / cw, cx = rem - cy * cw;
+
+  f4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  auto fetch_b = [&](int step, f4 (&bv)[2]) {
+    const int kidx0 = step * 32 + oct * 8;
+    const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    bool ok = col_ok && c0 < a.kc && kidx0 < K16;
+    const float* src;
+    if (!DGRAD) {
+      const int iy = cy * a.sy - a.py + ky, ix = cx * a.sx - a.px + kx;
+      ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      src = a.in + (((int64_t)pn * a.hin + iy) * a.win + ix) * a.cin + c0;
+    } else {
+      const int ty = cy + a.py - ky, tx = cx + a.px - kx;
+      const int oy = ty / a.sy, ox = tx / a.sx;
+      ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
+      src = a.in + (((int64_t)pn * a.hout + oy) * a.wout + ox) * a.cout + c0;
+    }
+    bv[0] = bv[1] = f4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      bv[0] = *reinterpret_cast<const f4*>(src);
+      bv[1] = *reinterpret_cast<const f4*>(src + 4);
+    }
+  };
+  // A operand of one k-step: [sub-tile i][part]
+  const uint16_t* abase = a.w16 + ((int64_t)(row0 / 16 + 2 * wm) * 2) * 512 + lane * 8;
+  auto fetch_a = [&](int step, cg_u4 (&av)[2][2]) {
+    const uint16_t* p = abase + (int64_t)step * RB * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) av[i][part] = *reinterpret_cast<const cg_u4*>(p + (i * 2 + part) * 512);
+  };
+
+  f4 bv[G][2];
+  cg_u4 av[2][2][2];
+  auto fetch_group_b = [&](int step) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (step + g < step_hi) fetch_b(step + g, bv[g]);
+  };
+  if (step_lo < step_hi) {
+    fetch_group_b(step_lo);
+    fetch_a(step_lo, av[0]);
+  }
+  const int sw = (pl >> 2) & 3;
+  for (int step = step_lo; step < step_hi; step += G) {
+    const int ng = min(G, step_hi - step);      // (uniform over the workgroup)
+    __syncthreads();  // the previous group's operand reads are done
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < ng) {
+        cg_u4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t h, l;
+          cg_split2(bv[g][e >> 1][2 * (e & 1)], bv[g][e >> 1][2 * (e & 1) + 1], h, l);
+          hi[e] = h, lo[e] = l;
+        }
+        Bs[((g * 2 + 0) * 64 + pl) * 4 + (oct ^ sw)] = hi;
+        Bs[((g * 2 + 1) * 64 + pl) * 4 + (oct ^ sw)] = lo;
+      }
+    }
+    __syncthreads();
+    if (step + G < step_hi) fetch_group_b(step + G);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < ng) {
+        if (step + g + 1 < step_hi) fetch_a(step + g + 1, av[(g + 1) & 1]);
+        cg_u4 bo[2][2];      // [sub-tile j][part]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int px = 32 * wn + 16 * j + l16;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) bo[j][part] = Bs[((g * 2 + part) * 64 + px) * 4 + (q ^ ((px >> 2) & 3))];
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {      // lo x hi, hi x lo, hi x hi
+          const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cg_bf8, av[g & 1][i][pa]),
+                                                                  __builtin_bit_cast(cg_bf8, bo[j][pb]), acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // D[row = 4q + r][col = l16] of sub-tile (i, j): the exact kernel's epilogue
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = col0 + 32 * wn + 16 * j + l16;
+    if (c >= a.ncols) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r0 = row0 + 32 * wm + 16 * i + 4 * q;
+      if (a.partial) {
+        *reinterpret_cast<f4*>(a.partial + ((int64_t)blockIdx.z * a.ncols + c) * a.PR + r0) = acc[i][j];
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + r;
+        if (row >= a.rows) continue;
+        const int64_t o = (int64_t)c * a.rows + row;
+        float v = acc[i][j][r];
+        if (!DGRAD) {
+          v += a.bias[row];
+          if (a.res) v += a.res[o];
+          v = fmaxf(v, 0.f);
+        } else {
+          if (a.res) v += a.res[o];
+          if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+        }
+        a.out[o] = v;
+      }
+    }
+  }
+}
+
 // split-K: sum the partial tiles in split order, then the same epilogue.  thread = (col, row quad)
 template <bool DGRAD>
 __global__ static __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int splits) {
@@ -307,9 +496,17 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   }
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  const bool split_form = a.w16 && TM == 64 && (a.kc & 7) == 0;
+  if (split_form) {
+    a.nsteps = (a.nchunks + 1) / 2;
+    a.steps_per_split = (a.nsteps + splits - 1) / splits;
+    splits = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+  }
   float* partial = a.partial;
   a.partial = splits > 1 ? partial : nullptr;
-  if (TM == 16) launch_conv_shape<DGRAD, 16>(a, splits, st);
+  if (split_form)
+    hipLaunchKernelGGL((conv_gemm_split_kernel<DGRAD>), dim3((a.ncols + 63) / 64, (a.rows + 63) / 64, splits), dim3(256), 0, st, a);
+  else if (TM == 16) launch_conv_shape<DGRAD, 16>(a, splits, st);
   else if (TM == 32) launch_conv_shape<DGRAD, 32>(a, splits, st);
   else launch_conv_shape<DGRAD, 64>(a, splits, st);
   if (splits > 1) {
@@ -317,6 +514,14 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
     hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
   }
   return (int)hipGetLastError();
+}
+
+// floats the split form's A operand takes (hi + lo bf16 parts of the [K16 -> ceil 32][RP] operand)
+inline int64_t packed16_floats(int taps, int kc, int rows) { return (int64_t)((taps * ceil_to(kc, 16) + 31) / 32) * 32 * ceil_to(rows, 64); }
+inline void launch_pack16(const float* w, float* dst, int taps, int kc, int rows, hipStream_t st) {
+  const int K16 = taps * ceil_to(kc, 16), RP = ceil_to(rows, 64);
+  const int64_t n = packed16_floats(taps, kc, rows) * 2;
+  hipLaunchKernelGGL(conv_pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, reinterpret_cast<uint16_t*>(dst), K16, RP, n);
 }
 
 inline ConvArgs base_args(const LayerSpec& s, Shape in, Shape out) {

@@ -25,7 +25,7 @@ constexpr int kAlexLayers = 5;
 constexpr float kLpipsEps = 1e-10f;
 
 struct LpipsPacked {
-  int64_t w[kAlexLayers], b[kAlexLayers], wt[kAlexLayers], lin[kAlexLayers], w1raw, wd1, shift, scale, total;
+  int64_t w[kAlexLayers], b[kAlexLayers], wt[kAlexLayers], lin[kAlexLayers], w1raw, wd1, shift, scale, w16[kAlexLayers], wt16[kAlexLayers], total;
 };
 inline LpipsPacked lpips_packed() {
   LpipsPacked p;
@@ -50,6 +50,15 @@ inline LpipsPacked lpips_packed() {
   o += 4;
   p.scale = o;
   o += 4;
+  o = (o + 3) / 4 * 4;
+  for (int l = 1; l < kAlexLayers; ++l) {      // the split form's operands (conv_gemm.h) of the layers the implicit GEMM runs
+    const LayerSpec& s = kAlex[l];
+    p.w16[l] = o;
+    o += packed16_floats(s.kh * s.kw, s.cin, s.cout);
+    p.wt16[l] = o;
+    o += packed16_floats(s.kh * s.kw, s.cout, s.cin);
+  }
+  p.w16[0] = p.wt16[0] = 0;
   p.total = (o + 3) / 4 * 4;
   return p;
 }
@@ -458,6 +467,8 @@ extern "C" int s2l_lpips_pack(const float* const* tensors_host, float* packed, s
       const int64_t nt = (int64_t)s.kh * s.kw * kcpt * RPt;
       hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tensors_host[2 * l], none, none, 0.f,
                          packed + pl.wt[l], s.cin, s.cout, s.kh, s.kw, kcpt, RPt, 1, nt);
+      launch_pack16(packed + pl.w[l], packed + pl.w16[l], s.kh * s.kw, s.cin, s.cout, st);
+      launch_pack16(packed + pl.wt[l], packed + pl.wt16[l], s.kh * s.kw, s.cout, s.cin, st);
     }
     hipLaunchKernelGGL(lpips_copy_kernel, dim3((s.cout + 255) / 256), dim3(256), 0, st, tensors_host[10 + l], packed + pl.lin[l],
                        (int64_t)s.cout);
@@ -470,8 +481,8 @@ extern "C" int s2l_lpips_pack(const float* const* tensors_host, float* packed, s
   return (int)hipGetLastError();
 }
 
-extern "C" int s2l_lpips_forward(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
-                                 int height, int width, int64_t batch, s2l_stream_t stream) {
+static int lpips_forward_impl(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
+                              int height, int width, int64_t batch, bool split, s2l_stream_t stream) {
   int rc = lpips_check(height, width, batch);
   if (rc || batch == 0) return rc;
   if (!packed || !in0 || !in1 || !work || !out) return S2L_E_NULL;
@@ -489,6 +500,7 @@ extern "C" int s2l_lpips_forward(const float* packed, const float* in0, const fl
     ConvArgs a = base_args(s, sh, wl.a[l]);
     a.in = cur;
     a.w = packed + pl.w[l];
+    a.w16 = split && l > 0 ? reinterpret_cast<const uint16_t*>(packed + pl.w16[l]) : nullptr;
     a.bias = packed + pl.b[l];
     a.out = work + wl.act[l];
     a.partial = work + wl.partial;
@@ -518,9 +530,18 @@ extern "C" int s2l_lpips_forward(const float* packed, const float* in0, const fl
   return (int)hipGetLastError();
 }
 
+extern "C" int s2l_lpips_forward(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
+                                 int height, int width, int64_t batch, s2l_stream_t stream) {
+  return lpips_forward_impl(packed, in0, in1, from01, work, out, height, width, batch, false, stream);
+}
+extern "C" int s2l_lpips_forward_split(const float* packed, const float* in0, const float* in1, int from01, float* work, float* out,
+                                       int height, int width, int64_t batch, s2l_stream_t stream) {
+  return lpips_forward_impl(packed, in0, in1, from01, work, out, height, width, batch, true, stream);
+}
+
 // `work` as s2l_lpips_forward left it; d_out [N] = d loss / d out[n]; d_in0 [N,H,W,3]
-extern "C" int s2l_lpips_backward(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
-                                  int height, int width, int64_t batch, s2l_stream_t stream) {
+static int lpips_backward_impl(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
+                               int height, int width, int64_t batch, bool split, s2l_stream_t stream) {
   int rc = lpips_check(height, width, batch);
   if (rc || batch == 0) return rc;
   if (!packed || !work || !d_out || !d_in0) return S2L_E_NULL;
@@ -542,6 +563,7 @@ extern "C" int s2l_lpips_backward(const float* packed, float* work, const float*
     ConvArgs a = base_args(kAlex[l], wl.a[l - 1], wl.a[l]);
     a.in = g;
     a.w = packed + pl.wt[l];
+    a.w16 = split ? reinterpret_cast<const uint16_t*>(packed + pl.wt16[l]) : nullptr;
     a.res = work + wl.tap[l - 1];
     a.mask = work + wl.act[l - 1];
     a.out = bufs[k];
@@ -555,6 +577,7 @@ extern "C" int s2l_lpips_backward(const float* packed, float* work, const float*
     ConvArgs a = base_args(kAlex[l], wl.p[l - 1], wl.a[l]);
     a.in = g;
     a.w = packed + pl.wt[l];
+    a.w16 = split ? reinterpret_cast<const uint16_t*>(packed + pl.wt16[l]) : nullptr;
     a.out = bufs[k];
     a.partial = work + wl.partial;
     if ((rc = launch_conv<true>(a, N, st))) return rc;
@@ -580,4 +603,12 @@ extern "C" int s2l_lpips_backward(const float* packed, float* work, const float*
   hipLaunchKernelGGL(lpips_unscale_grad_kernel, dim3((unsigned)((npx * 3 + 255) / 256)), dim3(256), 0, st, dxs, packed + pl.scale, d_in0,
                      npx * 3, from01 ? 2.f : 1.f, accumulate);
   return (int)hipGetLastError();
+}
+extern "C" int s2l_lpips_backward(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
+                                  int height, int width, int64_t batch, s2l_stream_t stream) {
+  return lpips_backward_impl(packed, work, d_out, from01, accumulate, d_in0, height, width, batch, false, stream);
+}
+extern "C" int s2l_lpips_backward_split(const float* packed, float* work, const float* d_out, int from01, int accumulate, float* d_in0,
+                                        int height, int width, int64_t batch, s2l_stream_t stream) {
+  return lpips_backward_impl(packed, work, d_out, from01, accumulate, d_in0, height, width, batch, true, stream);
 }

@@ -32,7 +32,7 @@ inline const LayerSpec& spec_of(int l) { return l < kNumFace ? kFace[l] : kAudio
 // packed blob: per layer {forward weights [kh*kw*ceil16(cin)][ceil64(cout)], bias [ceil64(cout)]}, then for the face
 // encoder the dgrad weights [kh*kw*ceil16(cout)][ceil64(cin)].
 struct PackedLayout {
-  int64_t w[kNumLayers], b[kNumLayers], wt[kNumFace], total;
+  int64_t w[kNumLayers], b[kNumLayers], wt[kNumFace], w16[kNumLayers], wt16[kNumFace], total;      // w16 / wt16: the split form's operands
 };
 inline PackedLayout packed_layout() {
   PackedLayout p;
@@ -48,6 +48,15 @@ inline PackedLayout packed_layout() {
     const LayerSpec& s = kFace[l];
     p.wt[l] = o;
     o += (int64_t)s.kh * s.kw * ceil_to(s.cout, 16) * ceil_to(s.cin, 64);
+  }
+  for (int l = 0; l < kNumLayers; ++l) {
+    const LayerSpec& s = spec_of(l);
+    p.w16[l] = o;
+    o += packed16_floats(s.kh * s.kw, s.cin, s.cout);
+    if (l < kNumFace) {
+      p.wt16[l] = o;
+      o += packed16_floats(s.kh * s.kw, s.cout, s.cin);
+    }
   }
   p.total = o;
   return p;
@@ -225,7 +234,9 @@ extern "C" int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, 
       const int64_t nt = (int64_t)s.kh * s.kw * kcpt * RPt;
       hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, t[0], t[2], t[5], bn_eps,
                          packed + pl.wt[l], s.cin, s.cout, s.kh, s.kw, kcpt, RPt, 1, nt);
+      launch_pack16(packed + pl.wt[l], packed + pl.wt16[l], s.kh * s.kw, s.cout, s.cin, st);
     }
+    launch_pack16(packed + pl.w[l], packed + pl.w16[l], s.kh * s.kw, s.cin, s.cout, st);
   }
   return (int)hipGetLastError();
 }
@@ -234,7 +245,7 @@ extern "C" int s2l_syncnet_pack(const float* const* tensors_host, float bn_eps, 
 // and the negative windows of the same audio, training.py:592-601: twice the columns per weight read for the face encoder, the
 // audio encoder once instead of twice).  The activations are laid out for face_batch.
 static int syncnet_forward_impl(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
-                                float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream) {
+                                float* face_emb, int64_t audio_batch, int64_t face_batch, bool split, s2l_stream_t stream) {
   if (face_batch < 0 || face_batch > 4096 || audio_batch < 0 || audio_batch > face_batch) return S2L_E_SIZE;
   if (face_batch == 0) return S2L_OK;
   if (!packed || !face || !work || !face_emb || (audio_batch && (!mel || !audio_emb))) return S2L_E_NULL;
@@ -249,6 +260,7 @@ static int syncnet_forward_impl(const float* packed, const float* mel, const flo
     ConvArgs a = base_args(s, wl.in_shape[l], wl.out_shape_[l]);
     a.in = l == 0 ? face : l == kNumFace ? mel : work + wl.act[l - 1];
     a.w = packed + pl.w[l];
+    a.w16 = split ? reinterpret_cast<const uint16_t*>(packed + pl.w16[l]) : nullptr;
     a.bias = packed + pl.b[l];
     a.res = s.res ? a.in : nullptr;
     a.out = work + wl.act[l];
@@ -266,11 +278,15 @@ static int syncnet_forward_impl(const float* packed, const float* mel, const flo
 extern "C" int s2l_syncnet_forward(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
                                    float* face_emb, int64_t batch, s2l_stream_t stream) {
   if (batch > 0 && (!mel || !audio_emb)) return S2L_E_NULL;
-  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, batch, batch, stream);
+  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, batch, batch, false, stream);
 }
 extern "C" int s2l_syncnet_forward_pair(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
                                         float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream) {
-  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, audio_batch, face_batch, stream);
+  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, audio_batch, face_batch, false, stream);
+}
+extern "C" int s2l_syncnet_forward_pair_split(const float* packed, const float* mel, const float* face, float* work, float* audio_emb,
+                                              float* face_emb, int64_t audio_batch, int64_t face_batch, s2l_stream_t stream) {
+  return syncnet_forward_impl(packed, mel, face, work, audio_emb, face_emb, audio_batch, face_batch, true, stream);
 }
 
 extern "C" int s2l_sync_loss(const float* audio_emb, const float* face_emb, const float* y, float weight, float* scratch,
@@ -288,7 +304,7 @@ extern "C" int s2l_sync_loss(const float* audio_emb, const float* face_emb, cons
 // the data gradient for the FIRST `batch` windows of a forward over work_batch windows (NHWC, batch outermost: a prefix of every
 // activation)
 static int syncnet_face_backward_impl(const float* packed, const float* face, float* work, const float* d_face_emb, float* d_face,
-                                      int64_t batch, int64_t work_batch, s2l_stream_t stream) {
+                                      int64_t batch, int64_t work_batch, bool split, s2l_stream_t stream) {
   if (batch < 0 || work_batch > 4096 || batch > work_batch) return S2L_E_SIZE;
   if (batch == 0) return S2L_OK;
   if (!packed || !face || !work || !d_face_emb || !d_face) return S2L_E_NULL;
@@ -305,6 +321,7 @@ static int syncnet_face_backward_impl(const float* packed, const float* face, fl
     ConvArgs a = base_args(s, wl.in_shape[l], wl.out_shape_[l]);
     a.in = g_cur;
     a.w = packed + pl.wt[l];
+    a.w16 = split ? reinterpret_cast<const uint16_t*>(packed + pl.wt16[l]) : nullptr;
     a.res = s.res ? g_cur : nullptr;
     a.mask = l > 0 ? work + wl.act[l - 1] : nullptr;
     a.out = l > 0 ? g_nxt : d_face;
@@ -319,11 +336,15 @@ static int syncnet_face_backward_impl(const float* packed, const float* face, fl
 }
 extern "C" int s2l_syncnet_face_backward(const float* packed, const float* face, float* work, const float* d_face_emb,
                                          float* d_face, int64_t batch, s2l_stream_t stream) {
-  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, batch, stream);
+  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, batch, false, stream);
 }
 extern "C" int s2l_syncnet_face_backward_prefix(const float* packed, const float* face, float* work, const float* d_face_emb,
                                                 float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream) {
-  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, work_batch, stream);
+  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, work_batch, false, stream);
+}
+extern "C" int s2l_syncnet_face_backward_prefix_split(const float* packed, const float* face, float* work, const float* d_face_emb,
+                                                      float* d_face, int64_t batch, int64_t work_batch, s2l_stream_t stream) {
+  return syncnet_face_backward_impl(packed, face, work, d_face_emb, d_face, batch, work_batch, true, stream);
 }
 
 extern "C" int s2l_sync_window(const float* g_rgb, float* face, int n_frames_t, int height, int width, int64_t batch,

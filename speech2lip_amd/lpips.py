@@ -98,6 +98,10 @@ class LPIPS(nn.Module):
                               f"{trunk_path!r}); the module holds RANDOM values there and will refuse to run until load_trunk / "
                               "load_lins / load_state_dict supplies them or allow_random_weights is set", RuntimeWarning, stacklevel=2)
         self._packed = self._packed_key = self._work = None
+        # what `precision=None` means in distance_nhwc.  "fp32": the exact-fp32 convolutions (default; what the parity tests pin).
+        # "split": conv2..conv5 and their input gradients with operands as hi + lo bf16 parts (csrc/conv_gemm.h: ~1e-5 relative) --
+        # the bf16-precision training steps ask for it per call.
+        self.conv_precision = "fp32"
         self.eval()
 
     def train(self, mode: bool = True):
@@ -177,7 +181,7 @@ class LPIPS(nn.Module):
         return self._packed
 
     # -- the raw entry points (NHWC) ------------------------------------------------------------------------------------
-    def distance_nhwc(self, in0: torch.Tensor, in1: torch.Tensor, from01: bool = False, keep: bool = False):
+    def distance_nhwc(self, in0: torch.Tensor, in1: torch.Tensor, from01: bool = False, keep: bool = False, precision: str = None):
         """in0, in1 [N,H,W,3] in [-1,1] (or [0,1] with from01: (x - 0.5) * 2 first, training.py:669-670) -> [N].
         keep=True: returns (out, state) where `state` owns the activations `backward_nhwc` needs (a workspace of its own,
         so that several calls can be pending, as the lip and the face term of one step are); otherwise the module's
@@ -203,15 +207,19 @@ class LPIPS(nn.Module):
                 self._work = torch.empty(n, dtype=torch.float32, device=dev)
             work = self._work
         out = torch.empty(N, dtype=torch.float32, device=dev)
+        precision = precision or self.conv_precision
+        if precision not in ("fp32", "split"):
+            raise ValueError(f"LPIPS precision must be 'fp32' or 'split', got {precision!r}")
+        split = precision == "split"
+        fn = "s2l_lpips_forward_split" if split else "s2l_lpips_forward"
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_lpips_forward(_p(packed), _p(in0), _p(in1), int(bool(from01)), _p(work), _p(out), H, W, N, _st()),
-                       "s2l_lpips_forward")
-        return (out, (work, N, H, W, bool(from01))) if keep else out
+            _abi.check(getattr(lib, fn)(_p(packed), _p(in0), _p(in1), int(bool(from01)), _p(work), _p(out), H, W, N, _st()), fn)
+        return (out, (work, N, H, W, bool(from01), split)) if keep else out
 
     def backward_nhwc(self, state, d_out: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """d loss / d in0 [N,H,W,3] for the `state` of a distance_nhwc(keep=True) call; added to `out` when given."""
         lib = _abi.load()
-        work, N, H, W, from01 = state
+        work, N, H, W, from01, split = state
         packed = self.packed_weights()
         dev = packed.device
         d = d_out.detach().to(device=dev, dtype=torch.float32).reshape(N).contiguous()
@@ -220,9 +228,9 @@ class LPIPS(nn.Module):
             out = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
         elif tuple(out.shape) != (N, H, W, 3) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != dev:
             raise ValueError("`out` must be a contiguous float32 [N,H,W,3] tensor on the module's GPU")
+        fn = "s2l_lpips_backward_split" if split else "s2l_lpips_backward"
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_lpips_backward(_p(packed), _p(work), _p(d), int(from01), int(acc), _p(out), H, W, N, _st()),
-                       "s2l_lpips_backward")
+            _abi.check(getattr(lib, fn)(_p(packed), _p(work), _p(d), int(from01), int(acc), _p(out), H, W, N, _st()), fn)
         return out
 
     # -- the package's signature ------------------------------------------------------------------------------------------

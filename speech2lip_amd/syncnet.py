@@ -51,6 +51,10 @@ class SyncNet_color(nn.Module):
         self._packed = None
         self._packed_key = None
         self._work = None
+        # what `precision=None` means in the embed calls.  "fp32": the exact-fp32 convolutions (default; what the parity tests pin).
+        # "split": operands as hi + lo bf16 parts, three bf16 MFMAs per product, fp32 accumulation (csrc/conv_gemm.h: ~1e-5 relative)
+        # -- the bf16-precision training steps ask for it per call.
+        self.conv_precision = "fp32"
         self.eval()
 
     def train(self, mode: bool = True):
@@ -88,7 +92,7 @@ class SyncNet_color(nn.Module):
             self._work = torch.empty(n, dtype=torch.float32, device=dev)
         return self._work
 
-    def embed_nhwc(self, mel: torch.Tensor, face_nhwc: torch.Tensor):
+    def embed_nhwc(self, mel: torch.Tensor, face_nhwc: torch.Tensor, precision: str = None):
         """mel [B,1,80,16] / [B,80,16]; face [B,48,96,15] -> (audio_emb [B,512], face_emb [B,512]), both L2-normalised.
         The activations stay in the module's workspace until the next call (face_backward uses them)."""
         lib = _abi.load()
@@ -104,13 +108,18 @@ class SyncNet_color(nn.Module):
         a = torch.empty(B, 512, dtype=torch.float32, device=dev)
         v = torch.empty(B, 512, dtype=torch.float32, device=dev)
         work = self._workspace(B, dev)
+        split = _conv_split(precision or self.conv_precision)
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_syncnet_forward(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, _st()),
-                       "s2l_syncnet_forward")
-        self._last = (face, B)
+            if split:
+                _abi.check(lib.s2l_syncnet_forward_pair_split(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, B, _st()),
+                           "s2l_syncnet_forward_pair_split")
+            else:
+                _abi.check(lib.s2l_syncnet_forward(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, _st()),
+                           "s2l_syncnet_forward")
+        self._last = (face, B, split)
         return a, v
 
-    def embed_pair_nhwc(self, mel: torch.Tensor, face_nhwc: torch.Tensor):
+    def embed_pair_nhwc(self, mel: torch.Tensor, face_nhwc: torch.Tensor, precision: str = None):
         """mel [B,...]; face [n B,48,96,15], n >= 1 (the generated windows first, then e.g. the negative ones of the same audio,
         training.py:592-601) -> (audio_emb [B,512], face_emb [n B,512]): each encoder runs ONCE (s2l_syncnet_forward_pair)."""
         lib = _abi.load()
@@ -126,29 +135,36 @@ class SyncNet_color(nn.Module):
         a = torch.empty(B, 512, dtype=torch.float32, device=dev)
         v = torch.empty(FB, 512, dtype=torch.float32, device=dev)
         work = self._workspace(FB, dev)
+        split = _conv_split(precision or self.conv_precision)
+        fn = "s2l_syncnet_forward_pair_split" if split else "s2l_syncnet_forward_pair"
         with torch.cuda.device(dev):
-            _abi.check(lib.s2l_syncnet_forward_pair(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, FB, _st()),
-                       "s2l_syncnet_forward_pair")
-        self._last = (face, FB)
+            _abi.check(getattr(lib, fn)(_p(packed), _p(mel), _p(face), _p(work), _p(a), _p(v), B, FB, _st()), fn)
+        self._last = (face, FB, split)
         return a, v
 
     def face_backward(self, d_face_emb: torch.Tensor) -> torch.Tensor:
         """d loss / d face [B,48,96,15] from d loss / d face_emb [B,512], for the FIRST B windows of the last embed call."""
         lib = _abi.load()
-        face, FB = self._last
+        face, FB, split = self._last
         d = d_face_emb.detach().to(torch.float32).contiguous()
         B = d.shape[0]
         if B > FB or d.shape[1:] != (512,):
             raise ValueError(f"d_face_emb must be [B <= {FB},512], got {tuple(d.shape)}")
         out = torch.empty(B, *face.shape[1:], dtype=torch.float32, device=face.device)
+        fn = "s2l_syncnet_face_backward_prefix_split" if split else "s2l_syncnet_face_backward_prefix"
         with torch.cuda.device(face.device):
-            _abi.check(lib.s2l_syncnet_face_backward_prefix(_p(self._packed), _p(face), _p(self._work), _p(d), _p(out), B, FB, _st()),
-                       "s2l_syncnet_face_backward_prefix")
+            _abi.check(getattr(lib, fn)(_p(self._packed), _p(face), _p(self._work), _p(d), _p(out), B, FB, _st()), fn)
         return out
 
     def forward(self, audio_sequences, face_sequences):
         """syncnet.py:57-67: ([B,1,80,16], [B,15,48,96] NCHW) -> (audio_embedding, face_embedding)."""
         return self.embed_nhwc(audio_sequences, face_sequences.permute(0, 2, 3, 1))
+
+
+def _conv_split(precision) -> bool:
+    if precision not in ("fp32", "split"):
+        raise ValueError(f"conv_precision must be 'fp32' or 'split', got {precision!r}")
+    return precision == "split"
 
 
 def sync_window(g_rgb: torch.Tensor, syncnet_T: int = 5, out: torch.Tensor = None) -> torch.Tensor:
@@ -184,8 +200,9 @@ def sync_window_backward(d_face: torch.Tensor, T: int, H: int, W: int) -> torch.
 class SyncLoss:
     """`Trainer.cosine_loss` + `Trainer.get_sync_contrastive_loss` (training.py:576-603) for a frozen `SyncNet_color`."""
 
-    def __init__(self, syncnet: SyncNet_color, syncnet_T: int = 5):
-        self.syncnet, self.syncnet_T = syncnet, syncnet_T
+    def __init__(self, syncnet: SyncNet_color, syncnet_T: int = 5, precision: str = None):
+        """precision: None (the module's `conv_precision`), "fp32" or "split" -- the form of the SyncNet's convolutions."""
+        self.syncnet, self.syncnet_T, self.precision = syncnet, syncnet_T, precision
 
     def cosine_loss(self, a, v, y, weight: float = 1.0, want_grad: bool = False):
         """BCELoss(cosine_similarity(a, v).unsqueeze(1), y) [* weight]; with want_grad also d loss / d v."""
@@ -217,7 +234,7 @@ class SyncLoss:
         face = torch.empty(2 * B, H - H // 2, W, 3 * T, dtype=torch.float32, device=dev)
         sync_window(g_rgb_pos, T, out=face[:B])
         sync_window(g_rgb_neg, T, out=face[B:])
-        a, v = self.syncnet.embed_pair_nhwc(mel, face)
+        a, v = self.syncnet.embed_pair_nhwc(mel, face, precision=self.precision)
         if want_grad:
             pos, dv = self.cosine_loss(a, v[:B], ones, weight, True)
             d_pos = sync_window_backward(self.syncnet.face_backward(dv), T, H, W)

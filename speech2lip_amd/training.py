@@ -55,6 +55,8 @@ def predict_lip_image(model: TalkingFace, coords, audio, index, height: int, wid
 class Trainer:
     """The slice of the reference `Trainer` (training.py:21-156) that sits on the hot path."""
 
+    _loss_conv_precision = None      # form of the frozen loss nets' convolutions: None = the nets' own default (exact fp32); "split" under precision="bf16"
+
     # keyword names of the reference constructor (training.py:21-37) whose May value is the only one the hot path implements:
     # passing anything else is an error, not a silently different model
     _MAY_ONLY = {"use_audio_net": True, "use_head_pose_net": False, "use_coords2audio": False, "use_delta_uv": False,
@@ -104,6 +106,7 @@ class Trainer:
         if self.precision not in ("fp32", "bf16"):
             raise ValueError(f"Trainer(precision=...) must be 'fp32' or 'bf16', got {self.precision!r}")
         model.train_precision = self.precision
+        self._loss_conv_precision = "split" if self.precision == "bf16" else "fp32"
         hn = kwargs.pop("hole_noise", None)
         if hn is not None:
             if hn not in ("host", "device"):
@@ -173,8 +176,8 @@ class Trainer:
         from .syncnet import SyncLoss
         if not want_grad and torch.is_grad_enabled() and isinstance(g_rgb_pos, torch.Tensor) and g_rgb_pos.requires_grad:
             from .autograd import sync_contrastive_loss
-            return sync_contrastive_loss(SyncLoss(self.syncnet, syncnet_T), mel, g_rgb_pos, g_rgb_neg)
-        return SyncLoss(self.syncnet, syncnet_T).get_sync_contrastive_loss(mel, g_rgb_pos, g_rgb_neg, want_grad=want_grad)
+            return sync_contrastive_loss(SyncLoss(self.syncnet, syncnet_T, self._loss_conv_precision), mel, g_rgb_pos, g_rgb_neg)
+        return SyncLoss(self.syncnet, syncnet_T, self._loss_conv_precision).get_sync_contrastive_loss(mel, g_rgb_pos, g_rgb_neg, want_grad=want_grad)
 
     def prepare_coords(self, coord, b):
         """training.py:253-261 (use_coords_mapping off): the regular pixel grid, tiled b times.  The tensor is built once per
@@ -243,7 +246,7 @@ class Trainer:
         if mask is not None:
             m = mask.permute(0, 2, 3, 1)
             prediction, target = m * prediction, m * target
-        d = lpips_distance(self.perceptual_loss_fn, prediction, target, from01=True)
+        d = lpips_distance(self.perceptual_loss_fn, prediction, target, from01=True, precision=self._loss_conv_precision)
         loss_perceptual = d.mean() * weights
         loss["loss"] = loss["loss"] + loss_perceptual
         loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + loss_perceptual.detach().cpu()
@@ -759,12 +762,12 @@ class SyncChain:
     UNET_RADIUS = 40   # pixels: >= the U-Net's dependency radius (32: 2 + 4 + 8 down, 4 + 4 + 2 + 2 up, pooling alignment) + slack
 
     def __init__(self, model: TalkingFace, syncnet, syncnet_T: int = 5, w_syncloss: float = 0.01, out_hw=(96, 96),
-                 max_frames_per_group: int = 40, window: bool = True, unet_precision: str = "fp32"):
+                 max_frames_per_group: int = 40, window: bool = True, unet_precision: str = "fp32", loss_conv_precision: str = None):
         from .syncnet import SyncLoss
         if getattr(model, "post_fusion_unet", None) is None:
             raise ValueError("SyncChain needs model.use_post_fusion (the window is the U-Net's output)")
         self.model, self.T, self.w = model, int(syncnet_T), float(w_syncloss)
-        self.sync = SyncLoss(syncnet, syncnet_T)
+        self.sync = SyncLoss(syncnet, syncnet_T, loss_conv_precision)      # (None: the SyncNet module's own `conv_precision`)
         self.out_hw = (int(out_hw[0]), int(out_hw[1]))
         self.group = max(1, int(max_frames_per_group) // self.T)
         # window=True: the U-Net runs on the canonical-face box dilated by its dependency radius, not on the whole frame -- the
@@ -865,7 +868,10 @@ class StageOneStep:
         self.step = LipTrainStep(model, height, width, precision)
         # precision "bf16" (BASELINE config 5): bf16 operands in the MLP kernels AND in the frozen U-Net's 3x3 convolutions
         self.unet_precision = "bf16" if precision == "bf16" else "fp32"
-        self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss, unet_precision=self.unet_precision) if syncnet is not None else None
+        # ... and hi + lo bf16 operands (three bf16 MFMAs per product, ~1e-5 relative) in the frozen loss nets' convolutions
+        self.loss_conv_precision = "split" if precision == "bf16" else "fp32"
+        self.chain = SyncChain(model, syncnet, syncnet_T, w_syncloss, unet_precision=self.unet_precision,
+                               loss_conv_precision=self.loss_conv_precision) if syncnet is not None else None
         self.T, self.lambda_rgb, self.w_post_fusion, self.face_loss = int(syncnet_T), float(lambda_rgb), float(w_post_fusion), face_loss
 
     def loss_and_grads(self, audio, frame_idx, targets, u01, sync=None, face=None):
@@ -920,7 +926,7 @@ class StageOneStep:
         total_loss = loss[0]
         if self.perceptual is not None:          # training.py:420-421 (use_lip_perc_loss 'v1')
             d, st = self.perceptual.distance_nhwc(pred[:B].reshape(B, self.h, self.w, 3), tgt.reshape(B, self.h, self.w, 3), from01=True,
-                                                  keep=True)
+                                                  keep=True, precision=self.loss_conv_precision)
             self.perceptual.backward_nhwc(st, torch.full((B,), self.w_perc / B, device=dev), out=dpred[:B].view(B, self.h, self.w, 3))
             losses["loss_perceptual"] = d.mean() * self.w_perc
             total_loss = total_loss + losses["loss_perceptual"]
@@ -939,7 +945,7 @@ class StageOneStep:
                                _ptr(floss), recon.numel(), _stream()), "s2l_mse")
             if self.perceptual is not None:      # training.py:453-456 (use_face_perc_loss; its mask is all ones)
                 wp = self.w_perc * self.w_post_fusion
-                d, st = self.perceptual.distance_nhwc(recon, gt, from01=True, keep=True)
+                d, st = self.perceptual.distance_nhwc(recon, gt, from01=True, keep=True, precision=self.loss_conv_precision)
                 self.perceptual.backward_nhwc(st, torch.full((B,), wp / B, device=dev), out=d_recon)
                 losses["loss_perceptual"] = losses["loss_perceptual"] + d.mean() * wp
                 total_loss = total_loss + d.mean() * wp

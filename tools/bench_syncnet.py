@@ -24,17 +24,19 @@ def timed(fn, iters=10):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # "split": hi + lo bf16 operands (csrc/conv_gemm.h)
     dev = torch.device("cuda:0")
     net = s2l.SyncNet_color().to(dev)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
     mel, pos, neg = (torch.from_numpy(x).to(dev) for x in W.synthetic_sync_batch(B, seed=1))
+    net.conv_precision = precision
     sl = s2l.SyncLoss(net)
     face = sync_window(pos)
     t_f = timed(lambda: net.embed_nhwc(mel, face))
     t_l = timed(lambda: sl.get_sync_contrastive_loss(mel, pos, neg))
     t_g = timed(lambda: sl.get_sync_contrastive_loss(mel, pos, neg, want_grad=True))
     gmac = 1.21 * B      # 1.21 GMAC per forward of both encoders
-    print(f"batch {B}: SyncNet forward {t_f * 1e3:.3f} ms ({2 * gmac / t_f / 1e3:.2f} TFLOP/s); "
+    print(f"batch {B} ({precision}): SyncNet forward {t_f * 1e3:.3f} ms ({2 * gmac / t_f / 1e3:.2f} TFLOP/s); "
           f"contrastive loss {t_l * 1e3:.3f} ms; loss + d/d window {t_g * 1e3:.3f} ms")
 
 

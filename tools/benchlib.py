@@ -375,6 +375,7 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
     audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
     target = torch.rand(B, H * Wd, 3, device=dev)
     step = s2l.StageOneStep(m, H, Wd, syncnet=net, precision=precision)
+    _loss_conv_ab(step)
     sync = sync_batch(dev, S) if S else None
     u01 = [0.5] * B
 
@@ -401,6 +402,15 @@ def bench_train_sync(dev, B=64, S=8, precision="bf16", steps=3, unet_train_mode=
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
+def _loss_conv_ab(step):
+    """S2L_BENCH_LOSS_CONV=fp32: the bf16 step with the loss nets' EXACT convolutions (the A/B of the split-operand form)."""
+    form = os.environ.get("S2L_BENCH_LOSS_CONV")
+    if form:
+        step.loss_conv_precision = form
+        if step.chain is not None:
+            step.chain.sync.precision = form
+
+
 def bench_stage1_full(dev, B=8, precision="bf16", steps=3, unet_train_mode=False, early=False):
     """One FULL stage-1 iteration of the reference per sample (training.py:347-574 after it > 100000, May flags), B samples per
     step: MSE + LPIPS on the 96x96 lip, MSE + LPIPS on the fused face (composite with black holes -> frozen U-Net @500x500), the
@@ -425,6 +435,7 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3, unet_train_mode=False
     audio = torch.from_numpy(W.synthetic_audio(B, 1).astype(np.float32)).to(dev)
     target = torch.rand(B, H * Wd, 3, device=dev)
     step = s2l.StageOneStep(m, H, Wd, syncnet=None if early else net, precision=precision, face_loss=True, perceptual=lp)
+    _loss_conv_ab(step)
     sync = sync_batch(dev, B)
     coord, g = device_warp_coords(dev, B, seed=5)
     face = dict(rgb_face_canonical=sync["rgb_face_canonical"], rgb_face_gt=sync["rgb_face_gt"], mask_lip_canonical=sync["mask_lip_canonical"],
