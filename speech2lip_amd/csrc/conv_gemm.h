@@ -72,6 +72,21 @@ struct ConvArgs {
   int nsteps, steps_per_split;      // split form: K in steps of 32
 };
 
+// one output value: bias / residual / ReLU (forward), pass-through / ReLU mask of the layer below (dgrad)
+template <bool DGRAD>
+__device__ static __forceinline__ void conv_store(const ConvArgs& a, int c, int row, float v) {
+  const int64_t o = (int64_t)c * a.rows + row;
+  if (!DGRAD) {
+    v += a.bias[row];
+    if (a.res) v += a.res[o];
+    v = fmaxf(v, 0.f);
+  } else {
+    if (a.res) v += a.res[o];
+    if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+  }
+  a.out[o] = v;
+}
+
 __device__ static __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // K advances in GROUPS of up to four 16-wide chunks per barrier pair (round 3): with one chunk per pair a wave issued 16 MFMAs
@@ -229,21 +244,8 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         continue;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + r;
-        if (row >= a.rows) continue;
-        const int64_t o = (int64_t)c * a.rows + row;
-        float v = acc[i][j][r];
-        if (!DGRAD) {
-          v += a.bias[row];
-          if (a.res) v += a.res[o];
-          v = fmaxf(v, 0.f);
-        } else {
-          if (a.res) v += a.res[o];
-          if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-        }
-        a.out[o] = v;
-      }
+      for (int r = 0; r < 4; ++r)
+        if (r0 + r < a.rows) conv_store<DGRAD>(a, c, r0 + r, acc[i][j][r]);
     }
   }
 }
@@ -251,8 +253,8 @@ __global__ static __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // ---- the SPLIT form (round 5): the same GEMM with both operands as hi + lo bf16 parts, three v_mfma_f32_16x16x32_bf16 per product
 // block (lo x hi, hi x lo, hi x hi; lo x lo, <= 2^-18 of the product, is dropped), fp32 accumulation -- 16 significant bits per
 // operand, range of fp32 (so it serves the gradients too, which IEEE halves would flush).  An opt-in speed mode for the bf16-precision
-// training steps only: the exact fp32 kernel above stays the default and the one the parity tests pin.  64 x 64 tiles, rows > 32,
-// K channels a multiple of 8; other layers run the exact kernel.
+// training steps only: the exact fp32 kernel above stays the default and the one the parity tests pin.  Every layer with
+// >= 8 K channels takes it (64 x 64 tiles, 32 x 128 for <= 32 rows); the one-channel mel window keeps the exact kernel.
 //   A: packed ONCE in MFMA lane order -- [k-step of 32][16-row block][hi | lo][lane 64][8 bf16]: a wave loads its operand with one
 //      coalesced 16-byte load per lane straight from global memory (1 KiB per instruction), no LDS;
 //   B: gathered as in the exact kernel, 8 channels (two 16-byte loads) per thread and k-step, split into parts on the way to LDS;
@@ -288,26 +290,40 @@ __global__ static void conv_pack16_kernel(const float* __restrict__ w, uint16_t*
   dst[i] = (uint16_t)(part ? lo : hi);
 }
 
-constexpr int kGroup16 = 4;      // k-steps of 32 per barrier pair (LDS 32 KiB)
+// Tile shapes of the split form: 64 x 64 (waves 2 x 2) or, for layers of <= 32 rows, 32 x 128 (waves 1 x 4); a wave owns 32 x 32.
+template <int TM> struct SplitShape {
+  static constexpr int WGM = TM == 64 ? 2 : 1, WGN = 4 / WGM, TN = 32 * WGN;
+  static constexpr int NB = TN / 64;                 // B pixels fetched per thread and k-step
+  static constexpr int G = TM == 64 ? 4 : 2;         // k-steps of 32 per barrier pair (LDS 32 KiB in both shapes)
+};
 
-template <bool DGRAD>
+template <bool DGRAD, int TM>
 __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a) {
-  constexpr int G = kGroup16;
-  __shared__ cg_u4 Bs[G * 2 * 64 * 4];      // [g][part][pixel][piece ^ ((pixel >> 2) & 3)]
+  using S = SplitShape<TM>;
+  constexpr int G = S::G, TN = S::TN, NB = S::NB;
+  __shared__ cg_u4 Bs[G * 2 * TN * 4];      // [g][part][pixel][piece ^ ((pixel >> 2) & 3)]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave & 1, wn = wave >> 1, q = lane >> 4, l16 = lane & 15;
-  const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+  const int wm = wave % S::WGM, wn = wave / S::WGM, q = lane >> 4, l16 = lane & 15;
+  const int col0 = blockIdx.x * TN, row0 = blockIdx.y * TM;
   const int step_lo = blockIdx.z * a.steps_per_split;
   const int step_hi = min(a.nsteps, step_lo + a.steps_per_split);
   const int RB = a.RP / 16, K16 = a.nchunks * 16;
 
-  // B-load role: pixel pl of the tile, channel octet oct of the k-step
+  // B-load role: pixels pl + 64 j of the tile, channel octet oct of the k-step
   const int pl = t >> 2, oct = t & 3;
   const int cw = DGRAD ? a.win : a.wout, chw = DGRAD ? a.hin * a.win : a.hout * a.wout;
-  const int col = col0 + pl;
-  const bool col_ok = col < a.ncols;
-  const int cc = col_ok ? col : 0;
-  const int pn = cc / chw, rem = cc - pn * chw, cy = rem / cw, cx = rem - cy * cw;
+  bool col_ok[NB];
+  int pn[NB], cy[NB], cx[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = col0 + pl + 64 * j;
+    col_ok[j] = col < a.ncols;
+    const int cc = col_ok[j] ? col : 0;
+    pn[j] = cc / chw;
+    const int rem = cc - pn[j] * chw;
+    cy[j] = rem / cw, cx[j] = rem - cy[j] * cw;
+  }
+  const bool vec = (a.kc & 7) == 0;      // else (the 15-channel face window): element loads, the tail of the last octet is zero
 
   f4 acc[2][2];
 #pragma unroll
@@ -315,26 +331,35 @@ __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  auto fetch_b = [&](int step, f4 (&bv)[2]) {
+  auto fetch_b = [&](int step, f4 (&bv)[NB][2]) {
     const int kidx0 = step * 32 + oct * 8;
     const int tap = kidx0 / a.kcp, c0 = kidx0 - tap * a.kcp;
     const int ky = tap / a.kw, kx = tap - ky * a.kw;
-    bool ok = col_ok && c0 < a.kc && kidx0 < K16;
-    const float* src;
-    if (!DGRAD) {
-      const int iy = cy * a.sy - a.py + ky, ix = cx * a.sx - a.px + kx;
-      ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-      src = a.in + (((int64_t)pn * a.hin + iy) * a.win + ix) * a.cin + c0;
-    } else {
-      const int ty = cy + a.py - ky, tx = cx + a.px - kx;
-      const int oy = ty / a.sy, ox = tx / a.sx;
-      ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
-      src = a.in + (((int64_t)pn * a.hout + oy) * a.wout + ox) * a.cout + c0;
-    }
-    bv[0] = bv[1] = f4{0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      bv[0] = *reinterpret_cast<const f4*>(src);
-      bv[1] = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      bool ok = col_ok[j] && c0 < a.kc && kidx0 < K16;
+      const float* src;
+      if (!DGRAD) {
+        const int iy = cy[j] * a.sy - a.py + ky, ix = cx[j] * a.sx - a.px + kx;
+        ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+        src = a.in + (((int64_t)pn[j] * a.hin + iy) * a.win + ix) * a.cin + c0;
+      } else {
+        const int ty = cy[j] + a.py - ky, tx = cx[j] + a.px - kx;
+        const int oy = ty / a.sy, ox = tx / a.sx;
+        ok = ok && ty >= 0 && tx >= 0 && oy * a.sy == ty && ox * a.sx == tx && oy < a.hout && ox < a.wout;
+        src = a.in + (((int64_t)pn[j] * a.hout + oy) * a.wout + ox) * a.cout + c0;
+      }
+      bv[j][0] = bv[j][1] = f4{0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        if (vec) {
+          bv[j][0] = *reinterpret_cast<const f4*>(src);
+          bv[j][1] = *reinterpret_cast<const f4*>(src + 4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < a.kc) bv[j][e >> 2][e & 3] = src[e];
+        }
+      }
     }
   };
   // A operand of one k-step: [sub-tile i][part]
@@ -347,7 +372,7 @@ __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a)
       for (int part = 0; part < 2; ++part) av[i][part] = *reinterpret_cast<const cg_u4*>(p + (i * 2 + part) * 512);
   };
 
-  f4 bv[G][2];
+  f4 bv[G][NB][2];
   cg_u4 av[2][2][2];
   auto fetch_group_b = [&](int step) {
 #pragma unroll
@@ -358,22 +383,25 @@ __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a)
     fetch_group_b(step_lo);
     fetch_a(step_lo, av[0]);
   }
-  const int sw = (pl >> 2) & 3;
   for (int step = step_lo; step < step_hi; step += G) {
     const int ng = min(G, step_hi - step);      // (uniform over the workgroup)
     __syncthreads();  // the previous group's operand reads are done
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (g < ng) {
-        cg_u4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t h, l;
-          cg_split2(bv[g][e >> 1][2 * (e & 1)], bv[g][e >> 1][2 * (e & 1) + 1], h, l);
-          hi[e] = h, lo[e] = l;
+        for (int j = 0; j < NB; ++j) {
+          cg_u4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t h, l;
+            cg_split2(bv[g][j][e >> 1][2 * (e & 1)], bv[g][j][e >> 1][2 * (e & 1) + 1], h, l);
+            hi[e] = h, lo[e] = l;
+          }
+          const int px = pl + 64 * j, piece = oct ^ ((px >> 2) & 3);
+          Bs[((g * 2 + 0) * TN + px) * 4 + piece] = hi;
+          Bs[((g * 2 + 1) * TN + px) * 4 + piece] = lo;
         }
-        Bs[((g * 2 + 0) * 64 + pl) * 4 + (oct ^ sw)] = hi;
-        Bs[((g * 2 + 1) * 64 + pl) * 4 + (oct ^ sw)] = lo;
       }
     }
     __syncthreads();
@@ -381,13 +409,13 @@ __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (g < ng) {
-        if (step + g + 1 < step_hi) fetch_a(step + g + 1, av[(g + 1) & 1]);
+        if (step + g + 1 < step_hi) fetch_a(step + g + 1, av[(g + 1) & 1]);      // (G is even: a group starts on set 0)
         cg_u4 bo[2][2];      // [sub-tile j][part]
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int px = 32 * wn + 16 * j + l16;
 #pragma unroll
-          for (int part = 0; part < 2; ++part) bo[j][part] = Bs[((g * 2 + part) * 64 + px) * 4 + (q ^ ((px >> 2) & 3))];
+          for (int part = 0; part < 2; ++part) bo[j][part] = Bs[((g * 2 + part) * TN + px) * 4 + (q ^ ((px >> 2) & 3))];
         }
 #pragma unroll
         for (int term = 0; term < 3; ++term) {      // lo x hi, hi x lo, hi x hi
@@ -416,26 +444,17 @@ __global__ static __launch_bounds__(256) void conv_gemm_split_kernel(ConvArgs a)
         continue;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + r;
-        if (row >= a.rows) continue;
-        const int64_t o = (int64_t)c * a.rows + row;
-        float v = acc[i][j][r];
-        if (!DGRAD) {
-          v += a.bias[row];
-          if (a.res) v += a.res[o];
-          v = fmaxf(v, 0.f);
-        } else {
-          if (a.res) v += a.res[o];
-          if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-        }
-        a.out[o] = v;
-      }
+      for (int r = 0; r < 4; ++r)
+        if (r0 + r < a.rows) conv_store<DGRAD>(a, c, r0 + r, acc[i][j][r]);
     }
   }
 }
 
 // split-K: sum the partial tiles in split order, then the same epilogue.  thread = (col, row quad)
+// (Tried in round 5 and dropped: the tile's last-arriving workgroup adding the partial sums itself.  Its workgroups sit on different
+//  XCDs; with agent-scope fences every workgroup wrote back / invalidated an L2 (SyncNet forward at batch 1: 0.49 -> 0.99 ms), with
+//  write-through stores + system-scope loads + an arrival counter it was correct and deterministic but still slower than this second
+//  launch: 0.49 -> 0.55 ms forward, 0.84 -> 1.01 ms loss + gradient.)
 template <bool DGRAD>
 __global__ static __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int splits) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -448,27 +467,8 @@ __global__ static __launch_bounds__(256) void conv_reduce_kernel(ConvArgs a, int
     s += p;
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r0 + r;
-    if (row >= a.rows) continue;
-    const int64_t o = (int64_t)c * a.rows + row;
-    float v = s[r];
-    if (!DGRAD) {
-      v += a.bias[row];
-      if (a.res) v += a.res[o];
-      v = fmaxf(v, 0.f);
-    } else {
-      if (a.res) v += a.res[o];
-      if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-    }
-    a.out[o] = v;
-  }
-}
-
-template <bool DGRAD, int TM>
-static void launch_conv_shape(const ConvArgs& a, int splits, hipStream_t st) {
-  constexpr int TN = TileShape<TM>::TN;
-  hipLaunchKernelGGL((conv_gemm_kernel<DGRAD, TM>), dim3((a.ncols + TN - 1) / TN, (a.rows + TM - 1) / TM, splits), dim3(256), 0, st, a);
+  for (int r = 0; r < 4; ++r)
+    if (r0 + r < a.rows) conv_store<DGRAD>(a, c, r0 + r, s[r]);
 }
 
 template <bool DGRAD>
@@ -479,7 +479,9 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   a.kc = DGRAD ? a.cout : a.cin;
   a.kcp = ceil_to(a.kc, 16);
   a.nchunks = a.kh * a.kw * a.kcp / 16;
-  const int TM = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : 64, TN = 4096 / TM;
+  // the split form (a.w16): 64 x 64 or 32 x 128 tiles; layers whose K is a single channel (the mel window) stay exact
+  const bool split_form = a.w16 && a.kc >= 8;
+  const int TM = split_form ? (a.rows <= 32 ? 32 : 64) : a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : 64, TN = 4096 / TM;
   a.PR = ceil_to(a.rows, TM);      // (narrow layers: a quarter / half of the 64-row padding, so their split-K fits the scratch)
   const int tiles = ((a.ncols + TN - 1) / TN) * ((a.rows + TM - 1) / TM);
   // One tile walks its K range alone, one workgroup of four waves: a CU that holds a single such workgroup streams its
@@ -489,14 +491,13 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   int splits = 1;
   if (tiles < 1024 && a.nchunks >= 16) {
     // few tiles (deep layers, small batches): fill the chip once, >= 8 chunks each; 128..1023 tiles: towards 4 per CU, but only
-    // while a workgroup keeps >= 32 chunks (below that the partial-sum pass costs more than the parallelism returns)
+    // while a workgroup keeps >= 32 chunks (below that the partial sums cost more than the parallelism returns)
     splits = tiles < 128 ? min(min(256 / tiles, a.nchunks / 8), 64) : min((1024 + tiles - 1) / tiles, a.nchunks / 32);
     splits = max(splits, 1);
     while (splits > 1 && (int64_t)splits * a.ncols * a.PR > kPartialFloats) --splits;
   }
   a.chunks_per_split = (a.nchunks + splits - 1) / splits;
   splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-  const bool split_form = a.w16 && TM == 64 && (a.kc & 7) == 0;
   if (split_form) {
     a.nsteps = (a.nchunks + 1) / 2;
     a.steps_per_split = (a.nsteps + splits - 1) / splits;
@@ -504,11 +505,12 @@ static int launch_conv(ConvArgs a, int64_t B, hipStream_t st) {
   }
   float* partial = a.partial;
   a.partial = splits > 1 ? partial : nullptr;
-  if (split_form)
-    hipLaunchKernelGGL((conv_gemm_split_kernel<DGRAD>), dim3((a.ncols + 63) / 64, (a.rows + 63) / 64, splits), dim3(256), 0, st, a);
-  else if (TM == 16) launch_conv_shape<DGRAD, 16>(a, splits, st);
-  else if (TM == 32) launch_conv_shape<DGRAD, 32>(a, splits, st);
-  else launch_conv_shape<DGRAD, 64>(a, splits, st);
+  const dim3 grid((a.ncols + TN - 1) / TN, (a.rows + TM - 1) / TM, splits);
+  if (split_form && TM == 64) hipLaunchKernelGGL((conv_gemm_split_kernel<DGRAD, 64>), grid, dim3(256), 0, st, a);
+  else if (split_form) hipLaunchKernelGGL((conv_gemm_split_kernel<DGRAD, 32>), grid, dim3(256), 0, st, a);
+  else if (TM == 16) hipLaunchKernelGGL((conv_gemm_kernel<DGRAD, 16>), grid, dim3(256), 0, st, a);
+  else if (TM == 32) hipLaunchKernelGGL((conv_gemm_kernel<DGRAD, 32>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_gemm_kernel<DGRAD, 64>), grid, dim3(256), 0, st, a);
   if (splits > 1) {
     const int64_t n = (int64_t)a.ncols * (a.PR / 4);
     hipLaunchKernelGGL(conv_reduce_kernel<DGRAD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, splits);
