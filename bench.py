@@ -217,6 +217,7 @@ def extra_measurements(dev):
                      ("stage1_full_iteration_bf16", lambda: benchlib.bench_stage1_full(dev, 8, "bf16")),
                      ("stage1_full_iteration_bf16_trainmode_bn", lambda: benchlib.bench_stage1_full(dev, 8, "bf16", unet_train_mode=True)),
                      ("stage1_early_iteration_bf16", lambda: benchlib.bench_stage1_full(dev, 8, "bf16", early=True)),
+                     ("sync_loss", lambda: benchlib.bench_sync_loss(dev, 16)),
                      ("train_fp32", lambda: benchlib.bench_train(dev, 64, "fp32", steps=3)),
                      ("dropin_trainer", lambda: benchlib.bench_dropin_trainer(dev)),
                      ("infer_clip_end_to_end", lambda: benchlib.bench_infer_clip(dev)),

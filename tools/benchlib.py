@@ -461,6 +461,26 @@ def bench_stage1_full(dev, B=8, precision="bf16", steps=3, unet_train_mode=False
             "loss_sync_last": float(aux.get("loss_sync", 0.0)), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
+def bench_sync_loss(dev, B=16, iters=10):
+    """T3 alone: SyncNet on B generated + B negative windows, cosine/BCE, gradient w.r.t. the generated window -- with the exact fp32
+    convolutions (default) and with the split-operand form the bf16-precision steps use (csrc/conv_gemm.h)."""
+    net = s2l.SyncNet_color().to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_syncnet_state_dict(0).items()})
+    mel, pos, neg = (torch.from_numpy(x).to(dev) for x in W.synthetic_sync_batch(B, seed=1))
+    out = {"config": f"sync loss alone: SyncNet_color on {B} generated + {B} negative windows, cosine/BCE, gradient w.r.t. the window", "batch": B}
+    for prec in ("fp32", "split"):
+        sl = s2l.SyncLoss(net, precision=prec)
+        fn = lambda: sl.get_sync_contrastive_loss(mel, pos, neg, want_grad=True)
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        out[f"ms_loss_and_grad_{prec}"] = round(a.elapsed_time(b) / iters, 3)
+    return out
+
+
 def bench_train(dev, B=64, precision="bf16", steps=5):
     """BASELINE config 5: one step = 4-tap ensemble forward + MSE + full backward + Adam for B frames at 96x96."""
     H = Wd = 96
