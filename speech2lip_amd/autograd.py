@@ -234,7 +234,8 @@ def unet_train(unet, x_nhwc, precision="fp32", frames=False):
     bf16 operands (and, for one frame or `frames`, bf16 tensors between the kernels: the half-width chain of csrc/unet_half.inc).
     frames=True: each frame of x is normalised with its own statistics and moves the running statistics once, in frame order --
     x.shape[0] successive one-frame calls in one set of launches."""
-    params = dict(unet.named_parameters())
+    from ._modcache import param_map
+    params = param_map(unet)
     return _UnetTrain.apply(unet, x_nhwc, precision, bool(frames), *[params[n] for n in unet.grad_names()])
 
 

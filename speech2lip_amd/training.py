@@ -20,6 +20,7 @@ import ctypes
 import torch
 
 from . import _abi
+from ._modcache import param_map, set_training, state_tensors
 from .talking_face import TalkingFace, _dev_f32, _ptr, _stream
 
 MLP_TENSORS = _abi.TENSOR_ORDER[12:]      # fc_* and pts_linears.* and output_linear.* (30 tensors)
@@ -258,7 +259,7 @@ class Trainer:
         U-Net that train.py:188-197 froze and switched to eval() when `it` passed 100000: from then on the reference's loop runs
         that U-Net with frozen parameters but BatchNorm batch statistics (and moving running statistics).  The drop-in does the
         same, because `post_fusion2_onlylip` follows the sub-module's own mode (golden G16)."""
-        self.model.train()
+        set_training(self.model, True)      # = self.model.train() (training.py:150) without the generator walk
         if self.multi_gpu and getattr(self.model, "post_fusion_unet", None) is not None:
             # DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers -- the BatchNorm running statistics -- to every rank
             # before each forward: with per-rank frames they would otherwise drift apart rank by rank
@@ -313,7 +314,7 @@ class Trainer:
         if not (self.multi_gpu and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
         from .sharded import allreduce_grads
-        named = {n: p for n, p in self.model.named_parameters() if p.grad is not None}
+        named = {n: p for n, p in param_map(self.model).items() if p.grad is not None}
         avg = allreduce_grads({n: p.grad for n, p in named.items()})
         for n, p in named.items():
             p.grad.copy_(avg[n])
@@ -400,7 +401,7 @@ class Trainer:
         """check_weights (src/common.py:56-64): warn for every state-dict tensor that holds a NaN.  One multi-tensor norm and
         ONE device synchronisation for the whole state dict (a NaN anywhere makes that tensor's norm NaN) instead of one
         `isnan().any()` round trip per tensor (~100 with the U-Net: milliseconds of an 8-ms iteration)."""
-        named = [(k, v) for k, v in self.model.state_dict().items() if v.dtype.is_floating_point and v.numel()]
+        named = [(k, v) for k, v in state_tensors(self.model) if v.dtype.is_floating_point and v.numel()]
         norms = torch.stack(torch._foreach_norm([v for _, v in named]))
         bad = torch.isnan(norms)
         if bool(bad.any()):
@@ -420,7 +421,7 @@ class Trainer:
         if its crop code supported it, training.py:536-537).  The random draws are made frame by frame in `train_step`'s order,
         so K = 1 consumes the generators like one `train_step` call.  The canonical-depth photo loss is not part of this
         entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames."""
-        self.model.train()                                  # training.py:150, as train_step
+        set_training(self.model, True)                      # self.model.train(): training.py:150, as train_step
         if self.cfg["training"].get("stage", "stage1") != "stage1":
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
         return self.train_stage1_frames(batch, it=it, seed=seed)
@@ -606,7 +607,7 @@ def mlp_backward(model: TalkingFace, st: MlpState, drgb: torch.Tensor, stream, t
     g["output_linear.weight"], g["output_linear.bias"] = dwout, dbout
 
     # un-fold G0 = W0 [Wuv|Wa|Wt], c0 = W0 (buv+ba+bt) + b0 (and the skip twins)
-    sd = dict(model.named_parameters())
+    sd = param_map(model)
     w = lambda name: _dev_f32(sd[name], dev, name)
 
     def unfold(first, ld, names, dG, dc, right):
@@ -635,7 +636,7 @@ def audio_backward(model: TalkingFace, audio32: torch.Tensor, dfeat: torch.Tenso
     awork, agrads = _f(dev, ((B + 3) // 4) * na), _f(dev, na)
     _abi.check(lib.s2l_audio_backward(_ptr(model.packed_weights()), _ptr(audio32), _ptr(dfeat), _ptr(awork), _ptr(agrads), B, stream),
                "s2l_audio_backward")
-    params, g, off = dict(model.named_parameters()), {}, 0
+    params, g, off = param_map(model), {}, 0
     for name in AUDIO_TENSORS:
         p_ = params[name]
         g[name] = agrads[off:off + p_.numel()].reshape(p_.shape)
@@ -741,10 +742,11 @@ class LipTrainStep:
 def apply_grads(model: TalkingFace, grads) -> None:
     """Install the gradients returned by `LipTrainStep` as `.grad` of the matching parameters, so a stock optimizer (the
     reference uses Adam(lr=1e-4), train.py:128) can step."""
-    params = dict(model.named_parameters())
+    params = param_map(model)
     for name, g in grads.items():
         p = params[name]
-        p.grad = g.reshape(p.shape).to(p.dtype).contiguous()
+        g = g.reshape(p.shape)
+        p.grad = (g if g.dtype == p.dtype else g.to(p.dtype)).contiguous()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi
+from ._modcache import param_map
 from .weights import UNET_CONVS
 
 
@@ -296,7 +297,7 @@ class SimpleUnetLight(nn.Module):
                                                             H, W, F_, st), "s2l_unet_train_backward_bf16")
         if not want_param_grads:
             return dx, {}
-        params = dict(self.named_parameters())
+        params = param_map(self)
         grads, off = {}, 0
         for name in self.grad_names():
             n = params[name].numel()
@@ -369,7 +370,7 @@ class SimpleUnetLight(nn.Module):
         dx = torch.empty_like(d)
         p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         def named(flat):
-            params = dict(self.named_parameters())
+            params = param_map(self)
             grads, off = {}, 0
             for name in self.grad_names():
                 n = params[name].numel()

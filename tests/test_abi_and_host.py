@@ -596,3 +596,54 @@ def test_bench_line_stays_inside_the_drivers_tail():
     for name in ("composite", "render_split", "small_clips", "config3", "unet_fp32", "train_bf16", "dropin_trainer", "infer_clip_end_to_end",
                  "eager_torch_gpu", "stage1_early_iteration_bf16"):
         assert f"`{name}" in legend, name
+
+
+def test_module_tree_cache_follows_the_tree():
+    """speech2lip_amd._modcache: the cached views equal named_parameters() / state_dict() / train() and notice re-assigned
+    parameters, replaced children (at any depth) and newly registered buffers."""
+    import torch.nn as nn
+    from speech2lip_amd._modcache import param_map, set_training, state_tensors
+
+    class Leaf(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nn.Linear(3, 2)
+            self.bn = nn.BatchNorm1d(2)
+            self.register_buffer("scratch", torch.zeros(1), persistent=False)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Leaf(), nn.Sequential(Leaf(), nn.ReLU())
+            self.shared = self.a.fc      # the same module under a second name
+
+    def same(net):
+        ref = dict(net.named_parameters())
+        got = param_map(net)
+        assert list(got) == list(ref) and all(got[k] is ref[k] for k in ref)
+        sd = net.state_dict()
+        st = dict(state_tensors(net))
+        assert set(st) <= set(sd) and all(st[k].data_ptr() == sd[k].data_ptr() for k in st)
+        assert {v.data_ptr() for v in sd.values()} == {v.data_ptr() for v in st.values()}      # (a shared module's tensors appear once)
+
+    net = Net()
+    same(net)
+    net.a.fc.weight = nn.Parameter(torch.ones(2, 3))          # re-assigned parameter
+    same(net)
+    net.b[0] = Leaf()                                        # replaced child two levels down
+    same(net)
+    net.b[0].register_buffer("extra", torch.ones(2))          # new persistent buffer
+    same(net)
+    net.eval()
+    net.b[0].bn.train()
+    assert set_training(net, True) is net and all(m.training for m in net.modules())
+    set_training(net, False)
+    assert not any(m.training for m in net.modules())
+
+    class Frozen(nn.Module):      # a module that overrides train(): the override is honoured
+        def train(self, mode=True):
+            return super().train(False)
+
+    net.c = Frozen()
+    set_training(net, True)
+    assert net.training and net.a.training and not net.c.training

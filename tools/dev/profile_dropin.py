@@ -16,6 +16,7 @@ from tools import benchlib
 dev = torch.device("cuda:0")
 late = "--early" not in sys.argv
 K = 8 if "--k8" in sys.argv else 1
+FUSED1 = "--fused1" in sys.argv      # one frame per step through train_steps (the StageOneStep route)
 root = benchlib._dataset_tmp("may_face_crop_lip")
 benchlib.write_synthetic_dataset(root, 24, train=True)
 cfg = s2l.may_config(96, 96, data_path=root, train_flags=True)
@@ -38,7 +39,9 @@ batches = [s2l.data.collate_batch([f]) for f in frames]
 
 
 def step(k):
-    if K == 1:
+    if FUSED1:
+        tr.train_steps([frames[k % 8]], it=it0 + k)
+    elif K == 1:
         tr.train_step(batches[k % 8], it=it0 + k)
     else:
         tr.train_steps(frames, it=it0 + k)
@@ -63,3 +66,8 @@ pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(45)
 st.sort_stats("tottime").print_stats(25)
+st.print_callers("_dev_f32")
+st.print_callers("method 'to' of")
+st.print_callers("named_parameters")
+st.print_callers("_named_members")
+st.print_callers("module.py.*parameters")
