@@ -49,7 +49,7 @@ ls $O
 # ---- the other rows: kernel-trace stats per tool (one rocprofv3 run each, no counters)
 for spec in "train_bf16:tools/bench_train.py 64 bf16" "train_fp32:tools/bench_train.py 64 fp32" "unet:tools/bench_unet.py 16 --bf16" \
             "small_clips:tools/bench_small_clips.py" "config3_split:tools/bench_config3.py 1000 100 --split" \
-            "syncnet:tools/bench_syncnet.py 16" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
+            "syncnet:tools/bench_syncnet.py 16" "syncnet_split:tools/bench_syncnet.py 16 split" "warp:tools/bench_warp.py 256" "config3:tools/bench_config3.py 1000 100 --unet" \
             "config3_nounet:tools/bench_config3.py 5000 500" "stage1_sync:tools/bench_train.py 64 bf16 --sync=8" \
             "stage1_full:tools/bench_train.py 8 bf16 --full" "stage1_early:tools/bench_train.py 8 bf16 --full --early" "stage1_sync_trainbn:tools/bench_train.py 64 bf16 --sync=8 --trainbn"; do
   name=${spec%%:*}; cmd=${spec#*:}

@@ -79,6 +79,7 @@ for name, title in (("train_bf16", "training step, bf16 mode: python tools/bench
                     ("small_clips", "one frame per call / 16-frame clips (tile shapes of the renderer): python tools/bench_small_clips.py"),
                     ("config3_split", "lip 128x128 + composite + U-Net in split-bf16 mode: python tools/bench_config3.py 1000 100 --split"),
                     ("syncnet", "sync loss (T3): python tools/bench_syncnet.py 16"),
+                    ("syncnet_split", "sync loss with the split-operand convolutions (what bf16-precision steps use): python tools/bench_syncnet.py 16 split"),
                     ("warp", "pose -> warp grid: python tools/bench_warp.py 256"),
                     ("config3", "lip 128x128 + composite + U-Net: python tools/bench_config3.py 1000 100 --unet"),
                     ("config3_nounet", "BASELINE config 3: lip 128x128 + composite, 5000 frames: python tools/bench_config3.py 5000 500"),
