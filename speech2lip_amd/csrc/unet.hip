@@ -2220,6 +2220,28 @@ __global__ __launch_bounds__(64 * PL) void wgrad_reduce_lanes_kernel(const float
   }
 }
 
+// the same sums for partials laid out [part][tap 9][n / 9] (conv_wgrad_h_kernel: a wave's store is then 128 contiguous bytes per row instead of
+// 64 pieces 36 bytes apart); out stays [n / 9][9]
+template <int PL>
+__global__ __launch_bounds__(64 * PL) void wgrad_reduce_taps_kernel(const float* __restrict__ partial, float* __restrict__ out, int n_parts,
+                                                                   int64_t n) {
+  __shared__ float red[PL][64];
+  const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < n)
+    for (int b = pl; b < n_parts; b += PL) s += partial[(int64_t)b * n + e];
+  red[pl][el] = s;
+  __syncthreads();
+  if (pl == 0 && e < n) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < PL; ++k) t += red[k][el];
+    const int64_t per_tap = n / 9;
+    out[(e % per_tap) * 9 + e / per_tap] = t;
+  }
+}
+
 // first convolution (3 input channels): partial[blk][co][c*9 + t] = sum over the block's pixels of dz[p][co] x[neighbour t of p][c], on
 // v_mfma_f32_16x16x4_f32 (exact fp32 fma chains): K = pixels, four per instruction; A = dz^T (lane (co within its 16-block, pixel q)),
 // B = the pixel's 27 inputs padded to 32 (lane (k within its 16-block, pixel q): one gathered value), 4 x 2 accumulators per wave.
