@@ -19,3 +19,17 @@ def get_coords(width, height, device, add_noise_uv=False, raw_noise_std=0.0):
     if add_noise_uv:
         coords = coords + torch.randn(coords.shape, device=coords.device) * raw_noise_std
     return coords
+
+
+_GRID_CACHE = {}
+
+
+def shared_coords(width, height, device):
+    """The same grid as `get_coords(width, height, device)`, built once per (size, device) and SHARED: for callers inside the package
+    that only read it (a training step rebuilt and re-uploaded it several times: a host-to-device copy from pageable memory is a
+    synchronisation each time)."""
+    key = (int(width), int(height), str(torch.device(device)))
+    grid = _GRID_CACHE.get(key)
+    if grid is None:
+        grid = _GRID_CACHE[key] = get_coords(width, height, device)
+    return grid

@@ -464,12 +464,12 @@ class TalkingFace(nn.Module):
     # ------------------------------------------------------------------ A6 (batched driver)
     def pixel_tables(self, height: int, width: int):
         """Per-clip tables p0/p5 [HW,256] for the regular pixel grid (cached per size)."""
-        from .rendering import get_coords
+        from .rendering import shared_coords
         lib = _abi.load()
         packed = self.packed_weights()
         key = (int(height), int(width))
         if key not in self._tables:
-            coords = get_coords(width, height, packed.device)
+            coords = shared_coords(width, height, packed.device)
             hw = coords.shape[0]
             rows = (hw + 15) // 16 * 16   # opaque renderer layout: 16-pixel groups
             p0 = torch.empty(rows, 256, dtype=torch.float32, device=packed.device)

@@ -81,7 +81,10 @@ class Trainer:
         `"bf16"` (BASELINE config 5's arithmetic: bf16 MFMA operands in the MLP and the post-fusion U-Net, fp32 accumulation
         and master weights); `hole_noise="host"` (default: the black-hole fields come from the reference's CPU generator
         stream, tf_nerf.py:306-318) or `"device"` (drawn on the GPU: same distribution, another stream, no 7 ms of host
-        `randn` per frame); and the method `train_steps` (K frames per optimisation step)."""
+        `randn` per frame); the method `train_steps` (K frames per optimisation step); and `fused_step=True` (with
+        `precision="bf16"`): `train_step` itself runs its one frame through that fused engine (`train_steps` with K = 1: the same
+        draws in the same order, the same losses and gradients within the bf16 tolerances of G11 / G14, a third less wall time
+        per iteration than the autograd route); flag sets the fused engine does not implement fall back to the autograd route."""
         if isinstance(device, dict) or isinstance(out_dir, dict):
             raise TypeError("Trainer(model, optimizer, device, out_dir, cfg=...): cfg is the FIFTH argument, as in the reference")
         self.model = model
@@ -113,6 +116,7 @@ class Trainer:
             if hn not in ("host", "device"):
                 raise ValueError(f"Trainer(hole_noise=...) must be 'host' or 'device', got {hn!r}")
             model.hole_noise = hn
+        self.fused_step = bool(kwargs.pop("fused_step", False))
         self._stage_step = None
         self.use_audio = self.use_audio_net = self.use_time = True
         self.use_delta_uv = self.add_noise_audio = self.add_noise_uv = False
@@ -222,13 +226,28 @@ class Trainer:
         from . import geometry
         return geometry.inverse_warping(self.cfg, tgt_depth, rel_pose, src_img, return_z=True)
 
+    _defer_host = False      # inside train_stage1: the loss terms stay on the device until the step has been launched (no mid-step sync)
+
+    def _term(self, t):
+        """A loss term for the bookkeeping entries of the loss dict: the reference's `.detach().cpu()` (training.py:617, 633, 673) --
+        a device synchronisation each -- or, while `train_stage1` is composing a step, the detached device tensor; `_loss_to_host`
+        moves the entries to the host once the whole step (backward, optimizer) is in the stream."""
+        return t.detach() if self._defer_host else t.detach().cpu()
+
+    @staticmethod
+    def _loss_to_host(loss):
+        for k, v in loss.items():
+            if k != "loss" and isinstance(v, torch.Tensor) and v.is_cuda:
+                loss[k] = v.cpu()
+        return loss
+
     def canonical_depth_photo_loss(self, tgt_depth, rel_pose, src_img, target, loss, mask=None, weights=1.0):
         """training.py:470-477 in one call: inverse_warping + add_loss_canonical_depth_photo (:621-634), fused on the device
         and differentiable w.r.t. `tgt_depth` (model.canonical_depth_head) when autograd is recording."""
         from . import geometry
         l = geometry.depth_photo_loss(self.cfg, tgt_depth, rel_pose, src_img, target, mask, weights)
         loss["loss"] = loss["loss"] + l
-        loss["loss_canonical_depth_photo"] = loss.get("loss_canonical_depth_photo", 0) + l.detach().cpu()
+        loss["loss_canonical_depth_photo"] = loss.get("loss_canonical_depth_photo", 0) + self._term(l)
         return l
 
     def add_photometric_loss(self, prediction, target, loss, coarse=False, mask=None, weights=1.0):
@@ -236,7 +255,7 @@ class Trainer:
         from .autograd import mse
         loss_rgb = mse(prediction, target, weights)
         loss["loss"] = loss["loss"] + loss_rgb
-        loss["loss_rgb"] = loss["loss_rgb"] + loss_rgb.detach().cpu()
+        loss["loss_rgb"] = loss["loss_rgb"] + self._term(loss_rgb)
 
 
     def add_perceptual_loss(self, prediction, target, loss, mask=None, weights=1.0):
@@ -250,7 +269,7 @@ class Trainer:
         d = lpips_distance(self.perceptual_loss_fn, prediction, target, from01=True, precision=self._loss_conv_precision)
         loss_perceptual = d.mean() * weights
         loss["loss"] = loss["loss"] + loss_perceptual
-        loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + loss_perceptual.detach().cpu()
+        loss["loss_perceptual"] = loss.get("loss_perceptual", 0) + self._term(loss_perceptual)
 
 
     def train_step(self, data, data_zero=None, it=None, seed=None):
@@ -266,10 +285,23 @@ class Trainer:
             from .sharded import broadcast_module_state
             broadcast_module_state(self.model.post_fusion_unet, src=0)
         if self.cfg["training"].get("stage", "stage1") == "stage1":
-            loss, loss_all = self.train_stage1(data, it=it, seed=seed)
+            if self.fused_step and self.precision == "bf16" and self._fused_step_covers():
+                loss, loss_all = self.train_stage1_frames(data, it=it, seed=seed)
+            else:
+                loss, loss_all = self.train_stage1(data, it=it, seed=seed)
         else:
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
         return float(loss), loss_all
+
+    def _fused_step_covers(self) -> bool:
+        """Whether `train_stage1_frames` implements the configured loss set (what it refuses with NotImplementedError)."""
+        tc = self.cfg["training"]
+        face_on = bool(self.use_post_fusion)
+        lip_perc = self.use_perceptual_loss and tc.get("use_lip_perc_loss", "v1") == "v1"
+        face_perc = self.use_perceptual_loss and tc.get("use_face_perc_loss", True) is True
+        return not (bool(tc.get("use_canonical_depth_loss_photo_v2", False)) or self.batch_rays != self.height * self.width
+                    or tc.get("use_lip_photo_loss", "v1") != "v1" or (face_on and tc.get("use_face_photo_loss", True) is not True)
+                    or (self.use_perceptual_loss and face_on and lip_perc != face_perc))
 
     def visualize(self, visualize, logger, it):
         """training.py:676-740 under the May flags: eval mode, the 4-tap ensemble render of the validation frame (`seed=0`, one
@@ -326,6 +358,13 @@ class Trainer:
         sync loss over the 5-frame window -> backward -> NaN check -> optimizer.step().  Returns (loss_rgb, loss dict) like the
         reference.  One frame per call (batch_size 1, batch_rays = H*W: the only case the reference's own crop code supports,
         :536-537)."""
+        self._defer_host = True
+        try:
+            return self._train_stage1(data, eval_model, it, seed)
+        finally:
+            self._defer_host = False
+
+    def _train_stage1(self, data, eval_model, it, seed):
         tc, m = self.cfg["training"], self.model
         if self.optimizer is None:
             raise ValueError("train_stage1 steps an optimizer: construct Trainer(model, optimizer=...)")
@@ -393,20 +432,42 @@ class Trainer:
             loss["loss"] = loss["loss"] + loss_sync
         loss["loss"].backward()
         self._average_gradients_over_ranks()
-        self._check_weights()
+        nan_check = self._check_weights_launch()
         self.optimizer.step()
+        self._check_weights_report(nan_check)      # (the step's only wait besides the values it returns)
+        self._loss_to_host(loss)
         return loss["loss_rgb"], loss
 
     def _check_weights(self):
         """check_weights (src/common.py:56-64): warn for every state-dict tensor that holds a NaN.  One multi-tensor norm and
         ONE device synchronisation for the whole state dict (a NaN anywhere makes that tensor's norm NaN) instead of one
         `isnan().any()` round trip per tensor (~100 with the U-Net: milliseconds of an 8-ms iteration)."""
+        self._check_weights_report(self._check_weights_launch())
+
+    def _check_weights_launch(self):
+        """The device half of `_check_weights`, where the reference calls it (before optimizer.step(), training.py:572): the norms, the
+        NaN flags and their copy to a pinned host buffer go into the stream; nothing waits."""
         named = [(k, v) for k, v in state_tensors(self.model) if v.dtype.is_floating_point and v.numel()]
-        norms = torch.stack(torch._foreach_norm([v for _, v in named]))
-        bad = torch.isnan(norms)
-        if bool(bad.any()):
+        bad = torch.isnan(torch.stack(torch._foreach_norm([v for _, v in named])))
+        host = self.__dict__.get("_nan_flags")
+        if host is None or host.numel() != bad.numel():
+            host = self._nan_flags = torch.empty(bad.numel(), dtype=torch.bool, pin_memory=bad.is_cuda)
+        host.copy_(bad, non_blocking=True)
+        done = None
+        if bad.is_cuda:
+            done = torch.cuda.Event()
+            done.record()
+        return named, host, done
+
+    @staticmethod
+    def _check_weights_report(pending):
+        """The host half: wait for the flags (by then the optimizer's kernels are queued behind them) and warn like the reference."""
+        named, host, done = pending
+        if done is not None:
+            done.synchronize()
+        if bool(host.any()):
             import logging
-            for (k, _), b in zip(named, bad.tolist()):
+            for (k, _), b in zip(named, host.tolist()):
                 if b:
                     logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
 
@@ -512,8 +573,9 @@ class Trainer:
         total, grads, aux = step.loss_and_grads(audio, first, targets, torch.cat(u_main), sync=sync, face=face)
         apply_grads(m, grads)
         self._average_gradients_over_ranks()
-        self._check_weights()
+        nan_check = self._check_weights_launch()
         self.optimizer.step()
+        self._check_weights_report(nan_check)
         loss = {"loss": total, "loss_rgb": aux["loss_rgb"] + (aux["loss_face"] if "loss_face" in aux else 0)}
         for k in ("loss_perceptual", "loss_sync"):
             if k in aux:
@@ -657,13 +719,13 @@ class LipTrainStep:
     def __init__(self, model: TalkingFace, height: int, width: int, precision: str = "fp32"):
         """precision: 'fp32' (parity mode: exact-fp32 MFMA, saved state in fp32) or 'bf16' (BASELINE config 5: bf16 MFMA
         operands and saved state, fp32 accumulation / master weights / gradients; csrc/train_bf16.hip)."""
-        from .rendering import get_coords
+        from .rendering import shared_coords
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         self.precision = precision
         self.model, self.h, self.w = model, int(height), int(width)
         self.lib = _abi.load()
-        self.coords = get_coords(width, height, model.packed_weights().device)
+        self.coords = shared_coords(width, height, model.packed_weights().device)      # (read only)
         self.bf16_backward_kernel = "asm"      # "cpp": always the C++ kernel (per-row audio gradient); same dz images bit for bit
         self._ctx = None
 

@@ -216,3 +216,33 @@ def test_clip_streamer_and_frame_writer_equal_the_serial_forms(dev, tmp_path):
     wr.close()
     for nm in names:
         assert open(tmp_path / "a" / (nm + ".jpg"), "rb").read() == open(tmp_path / "b" / (nm + ".jpg"), "rb").read(), nm
+
+
+@pytest.mark.parametrize("it", [50000, 100001])
+def test_fused_step_option_routes_train_step_through_the_fused_engine(golden, syncnet, dev, it):
+    """Trainer(precision="bf16", fused_step=True).train_step(frame) == Trainer(precision="bf16").train_steps([frame]): the same
+    generators, draws and kernels, both sides of it = 100000 -- losses bit for bit, gradients up to the composite adjoint's float
+    atomics (csrc/composite.hip: the last bit of d lip is not fixed, as for ATen's grid_sample backward); a loss set the fused
+    engine does not implement keeps the autograd route."""
+    import random
+    _, data, _, _, _ = _g11_device(golden, dev)
+
+    def run(fused):
+        m = _late_model(dev) if it > 100000 else full_model(dev, 16, 24).train()
+        opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.0)
+        tr = s2l.Trainer(m, opt, cfg=_cfg(m), syncnet=syncnet, use_syncloss=True, precision="bf16", hole_noise="device", fused_step=fused)
+        torch.manual_seed(7)
+        random.seed(7)
+        out = tr.train_step(data, it=it) if fused else tr.train_steps([data], it=it)
+        return out, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}, tr
+
+    (la, da), ga, tra = run(True)
+    (lb, db), gb, _ = run(False)
+    assert isinstance(la, float) and la == float(lb)
+    assert set(da) == set(db) and all(float(da[k]) == float(db[k]) for k in da if k != "rgb_window")
+    assert set(ga) == set(gb) and len(ga) >= 42
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-6 * float(gb[k].abs().max()), k
+    assert tra._fused_step_covers()
+    tra.cfg = {**tra.cfg, "training": {**tra.cfg["training"], "use_canonical_depth_loss_photo_v2": True}}
+    assert not tra._fused_step_covers()

@@ -69,12 +69,13 @@ def test_syncnet_default_is_the_exact_form(syncnet, dev):
 @pytest.mark.parametrize("shape", [(2, 96, 96), (3, 64, 80), (1, 200, 160)])
 def test_lpips_split_form_distance_and_gradient(dev, shape):
     N, H, Wd = shape
+    torch.manual_seed(1234)      # (the module's random weights: the linear heads may be negative, so a distance can be a small difference)
     lp = s2l.LPIPS(pretrained=False).to(dev)
     g = torch.Generator().manual_seed(N * 1000 + H)
     a, b = torch.rand(N, H, Wd, 3, generator=g).to(dev), torch.rand(N, H, Wd, 3, generator=g).to(dev)
     d0, st0 = lp.distance_nhwc(a, b, from01=True, keep=True)
     d1, st1 = lp.distance_nhwc(a, b, from01=True, keep=True, precision="split")
-    assert float(((d1 - d0).abs() / d0.abs()).max()) <= 5e-5      # (a distance of unit-normalised features: differences cancel)
+    assert float(((d1 - d0).abs() - 5e-5 * d0.abs()).max()) <= 3e-8      # (a distance of unit-normalised features: differences cancel)
     assert st0[-1] is False and st1[-1] is True
     w = torch.rand(N, generator=g).to(dev)
     g0 = lp.backward_nhwc(st0, w)
@@ -87,6 +88,7 @@ def test_lpips_split_form_distance_and_gradient(dev, shape):
 
 def test_lpips_autograd_surface_takes_the_precision(dev):
     from speech2lip_amd.autograd import lpips_distance
+    torch.manual_seed(1234)
     lp = s2l.LPIPS(pretrained=False).to(dev)
     g = torch.Generator().manual_seed(5)
     a = torch.rand(2, 64, 64, 3, generator=g).to(dev).requires_grad_(True)

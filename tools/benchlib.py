@@ -640,6 +640,7 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
     the U-Net still trains, no sync loss; `it` > 100000: frozen U-Net + the 5-frame sync window): ms per iteration of
       * `train_step` with the reference's CPU black-hole noise stream, data loaded in the loop (the loop as written),
       * the same with a prefetching loader (FramePrefetcher = DataLoader workers) and `hole_noise="device"`,
+      * the same with `Trainer(fused_step=True)` (train_step's one frame goes through the fused engine),
       * `train_steps` with K = 8 frames per optimisation step (ms per FRAME),
     each with the GPU-busy share (sum of HIP-event spans around the step's GPU work / wall time), and the data loader alone."""
     import shutil
@@ -663,7 +664,7 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         ds.load_one_frame(i % n)
     res["load_one_frame_ms"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
 
-    def build(late, hole_noise):
+    def build(late, hole_noise, fused_step=False):
         m = make_model(dev, 96, 96, unet=True, train=True)
         m.data_path = root
         if late:      # train.py:188-197
@@ -671,7 +672,8 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
                 p.requires_grad = False
             m.post_fusion_unet.eval()
         opt = torch.optim.Adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
-        return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, perceptual_loss_fn=lp, precision="bf16", hole_noise=hole_noise)
+        return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, perceptual_loss_fn=lp, precision="bf16", hole_noise=hole_noise,
+                           fused_step=fused_step)
 
     def run(tr, it0, batches, per_step):
         torch.cuda.synchronize()
@@ -708,6 +710,13 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         run(tr, it0, pf, 1)
         pf = s2l.FramePrefetcher(ds, order)
         entry["train_step_prefetch_device_noise"] = run(tr, it0, pf, 1)
+        pf.close()
+        # (2b) the same loop, `Trainer(fused_step=True)`: train_step sends its one frame through the fused engine
+        tr = build(late, "device", fused_step=True)
+        pf = s2l.FramePrefetcher(ds, order[:3])
+        run(tr, it0, pf, 1)
+        pf = s2l.FramePrefetcher(ds, order)
+        entry["train_step_fused_prefetch_device_noise"] = run(tr, it0, pf, 1)
         pf.close()
         # (3) K frames per optimisation step through the fused engine
         K = 8

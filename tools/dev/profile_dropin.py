@@ -50,6 +50,13 @@ def step(k):
 for k in range(4):
     step(k)
 torch.cuda.synchronize()
+if "--syncs" in sys.argv:      # where does the host wait for the device inside one step?
+    import warnings
+    warnings.simplefilter("always")
+    torch.cuda.set_sync_debug_mode("warn")
+    step(4)
+    torch.cuda.set_sync_debug_mode("default")
+    sys.exit(0)
 t0 = time.perf_counter()
 for k in range(10):
     step(k)
