@@ -39,7 +39,10 @@ struct UnetTensors {
 
 // one thread per packed weight element of a 3x3 layer (layer >= 1): BatchNorm folded in
 // eps < 0: RAW weights (no BatchNorm fold) for the train-mode network, whose BatchNorm uses batch statistics
-__global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
+// The pack kernels take the layer from blockIdx.y (+ 1) and the form from blockIdx.z: ONE launch packs all nine 3x3 layers, forward and
+// transposed (a training net re-packs after every optimizer step: 36 launches of a few microseconds each per iteration before).
+constexpr int64_t kPackMaxFloats = 2 * 16 * kChunkFloats;      // the largest layer (256 -> 128); smaller layers' surplus blocks return
+__device__ __forceinline__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
   const int64_t n = (int64_t)(cout / 64) * (cin / 16) * kChunkFloats;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -55,7 +58,7 @@ __global__ void unet_pack_conv(UnetTensors t, int layer, float* __restrict__ pac
 }
 
 // the transposed twin: output rows = the layer's INPUT channels, k = its OUTPUT channels, tap t reads forward tap 8 - t
-__global__ void unet_pack_conv_T(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
+__device__ __forceinline__ void unet_pack_conv_T(UnetTensors t, int layer, float* __restrict__ packed, float eps) {
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;      // forward roles
   const int64_t n = (int64_t)(cin / 64) * (cout / 16) * kChunkFloats;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -68,6 +71,12 @@ __global__ void unet_pack_conv_T(UnetTensors t, int layer, float* __restrict__ p
   const int co = cc * 16 + 4 * (lane >> 4) + ks;           // k = forward output channel
   const float scale = eps < 0.f ? 1.f : t.gamma[layer][co] / sqrtf(t.var[layer][co] + eps);
   packed[unet_wT_off(layer) + e] = t.w[layer][((int64_t)co * cin + ci) * 9 + (8 - tap)] * scale;
+}
+
+// grid (blocks of the largest layer, 9 layers, 2 forms)
+__global__ void unet_pack_convs_kernel(UnetTensors t, float* __restrict__ packed, float eps) {
+  if (blockIdx.z == 0) unet_pack_conv(t, blockIdx.y + 1, packed, eps);
+  else unet_pack_conv_T(t, blockIdx.y + 1, packed, eps);
 }
 
 __global__ void unet_pack_misc(UnetTensors t, float* __restrict__ packed, float eps) {
@@ -108,7 +117,9 @@ constexpr int64_t kUnetPacked16x3Halves = unet_w16x3_off(10);
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // round to nearest even
 
 // one thread per packed bf16 element; transposed = the input-gradient form (rows = forward input channels, taps mirrored)
-__global__ void unet_pack_conv16(UnetTensors t, int layer, uint16_t* __restrict__ packed16, float eps, int transposed) {
+// grid (blocks of the largest layer, 9 layers, 2 forms)
+__global__ void unet_pack_conv16(UnetTensors t, uint16_t* __restrict__ packed16, float eps) {
+  const int layer = blockIdx.y + 1, transposed = blockIdx.z;
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
   const int rows = transposed ? cin : cout, kdim = transposed ? cout : cin;
   const int64_t n = (int64_t)(rows / 64) * (kdim / 32) * kChunk16Halves;
@@ -127,7 +138,8 @@ __global__ void unet_pack_conv16(UnetTensors t, int layer, uint16_t* __restrict_
 
 typedef _Float16 h2v_ __attribute__((ext_vector_type(2)));
 // split form (forward only): one thread per packed element, hi and lo parts of the BatchNorm-folded fp32 weight
-__global__ void unet_pack_conv16x3(UnetTensors t, int layer, uint16_t* __restrict__ packed, float eps) {
+__global__ void unet_pack_conv16x3(UnetTensors t, uint16_t* __restrict__ packed, float eps) {      // grid (blocks of the largest layer, 9 layers)
+  const int layer = blockIdx.y + 1;
   const int cin = kUnetConvs[layer].cin, cout = kUnetConvs[layer].cout;
   const int64_t n = (int64_t)(cout / 64) * (cin / 16) * kChunk16Halves;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2397,11 +2409,7 @@ extern "C" int s2l_unet_pack(const float* const* tensors_host, float bn_eps, flo
   t.outw = tensors_host[50];
   t.outb = tensors_host[51];
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int l = 1; l < 10; ++l) {
-    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
-    hipLaunchKernelGGL(unet_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, bn_eps);
-    hipLaunchKernelGGL(unet_pack_conv_T, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, bn_eps);
-  }
+  hipLaunchKernelGGL(unet_pack_convs_kernel, dim3((unsigned)((kPackMaxFloats + 255) / 256), 9, 2), dim3(256), 0, st, t, packed, bn_eps);
   hipLaunchKernelGGL(unet_pack_misc, dim3(16), dim3(256), 0, st, t, packed, bn_eps);
   return (int)hipGetLastError();
 }
@@ -2591,11 +2599,8 @@ extern "C" int s2l_unet_pack16(const float* const* tensors_host, float bn_eps, u
   const int rc = unet_table(tensors_host, t);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int l = 1; l < 10; ++l) {
-    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 32) * kChunk16Halves;     // same count both ways
-    hipLaunchKernelGGL(unet_pack_conv16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16, bn_eps, 0);
-    hipLaunchKernelGGL(unet_pack_conv16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16, bn_eps, 1);
-  }
+  constexpr int64_t n_max = 2 * 8 * kChunk16Halves;      // (256 -> 128; the count is the same both ways)
+  hipLaunchKernelGGL(unet_pack_conv16, dim3((unsigned)((n_max + 255) / 256), 9, 2), dim3(256), 0, st, t, packed16, bn_eps);
   return (int)hipGetLastError();
 }
 
@@ -2608,10 +2613,8 @@ extern "C" int s2l_unet_pack16x3(const float* const* tensors_host, float bn_eps,
   const int rc = unet_table(tensors_host, t);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int l = 1; l < 10; ++l) {
-    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunk16Halves;
-    hipLaunchKernelGGL(unet_pack_conv16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed16x3, bn_eps);
-  }
+  constexpr int64_t n_max = 2 * 16 * kChunk16Halves;
+  hipLaunchKernelGGL(unet_pack_conv16x3, dim3((unsigned)((n_max + 255) / 256), 9), dim3(256), 0, st, t, packed16x3, bn_eps);
   return (int)hipGetLastError();
 }
 
@@ -2623,11 +2626,7 @@ extern "C" int s2l_unet_pack_raw(const float* const* tensors_host, float* packed
   const int rc = unet_table(tensors_host, t);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int l = 1; l < 10; ++l) {
-    const int64_t n = (int64_t)(kUnetConvs[l].cout / 64) * (kUnetConvs[l].cin / 16) * kChunkFloats;
-    hipLaunchKernelGGL(unet_pack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, -1.f);
-    hipLaunchKernelGGL(unet_pack_conv_T, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, l, packed, -1.f);
-  }
+  hipLaunchKernelGGL(unet_pack_convs_kernel, dim3((unsigned)((kPackMaxFloats + 255) / 256), 9, 2), dim3(256), 0, st, t, packed, -1.f);
   hipLaunchKernelGGL(unet_pack_misc, dim3(16), dim3(256), 0, st, t, packed, -1.f);
   return (int)hipGetLastError();
 }
