@@ -135,7 +135,9 @@ __device__ inline void conv_stage_bwd(const float* __restrict__ wT, const float*
 
 // Recomputes the encoder forward for kFB frames in LDS, then back-propagates dfeat [B,64] to every
 // encoder parameter; writes this block's partial sums (reduced over blocks by reduce_rows_kernel).
-__global__ __launch_bounds__(256) void audio_backward_kernel(const float* __restrict__ packed,
+// 1024 threads (round 5; 256 before: 130 us per call, a chain of strided item loops -- every item is still computed by one thread in the
+// same order, so the sums are the same bits); the (frame, output) sections below use the first 256.
+__global__ __launch_bounds__(1024) void audio_backward_kernel(const float* __restrict__ packed,
                                                             const float* __restrict__ windows,
                                                             const float* __restrict__ dfeat, float* __restrict__ partial,
                                                             int64_t n) {
@@ -159,8 +161,9 @@ __global__ __launch_bounds__(256) void audio_backward_kernel(const float* __rest
   conv_stage<32, 32, 8>(packed + OFF_C2W, packed + OFF_C2B, y1, y2);
   conv_stage<32, 64, 4>(packed + OFF_C4W, packed + OFF_C4B, y2, y3);
   conv_stage<64, 64, 2>(packed + OFF_C6W, packed + OFF_C6B, y3, y4);
-  const int fb = threadIdx.x >> 6, o = threadIdx.x & 63;
-  {
+  const int fb = (threadIdx.x >> 6) & 3, o = threadIdx.x & 63;
+  const bool fo = threadIdx.x < 256;      // the threads of the (frame, output) sections
+  if (fo) {
     float acc = packed[OFF_F0B + o];
     for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + k * 64 + o], y4[fb * 64 + k], acc);
     f1[fb * 64 + o] = lrelu(acc);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void audio_backward_kernel(const float* __rest
     for (int b = 0; b < nvalid; ++b) acc += gout[b * 64 + threadIdx.x];
     P[kAG_F2B + threadIdx.x] = acc;
   }
-  {
+  if (fo) {
     float acc = 0.f;   // d f1[fb][o] = sum_out W2[out][o] gout[fb][out], then through the LeakyReLU
     for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F2W + o * 64 + k], gout[fb * 64 + k], acc);
     gf1[fb * 64 + o] = acc * lrelu_slope(f1[fb * 64 + o]);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void audio_backward_kernel(const float* __rest
     for (int b = 0; b < nvalid; ++b) acc += gf1[b * 64 + threadIdx.x];
     P[kAG_F0B + threadIdx.x] = acc;
   }
-  {
+  if (fo) {
     float acc = 0.f;
     for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + o * 64 + k], gf1[fb * 64 + k], acc);
     g4[fb * 64 + o] = acc * lrelu_slope(y4[fb * 64 + o]);   // gradient w.r.t. conv6 pre-activation (T = 1)
@@ -425,7 +428,7 @@ extern "C" int s2l_audio_backward(const float* packed, const float* windows, con
   if (!packed || !windows || !dfeat || !work || !grads) return S2L_E_NULL;
   const int blocks = (int)((n + s2l::kFB - 1) / s2l::kFB);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(s2l::audio_backward_kernel, dim3(blocks), dim3(256), 0, st, packed, windows, dfeat, work, n);
+  hipLaunchKernelGGL(s2l::audio_backward_kernel, dim3(blocks), dim3(1024), 0, st, packed, windows, dfeat, work, n);
   hipLaunchKernelGGL(s2l::reduce_rows_kernel, dim3((s2l::kAudioGradFloats + 255) / 256), dim3(256), 0, st, work, grads,
                      blocks, (int)s2l::kAudioGradFloats);
   return (int)hipGetLastError();
