@@ -14,7 +14,7 @@ marks = [i for i, e in enumerate(ev) if marker in e[2]]
 
 
 def short(n):
-    n = re.sub(r"\(.*", "", n).replace("s2l::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("s2l::", "").replace("void ", "")
     return n[-48:]
 
 
