@@ -203,6 +203,7 @@ def extra_measurements(dev):
     for name, fn in (("composite", lambda: benchlib.bench_composite(dev, 256)),
                      ("render_split", lambda: benchlib.bench_render_split(dev)),
                      ("small_clips", lambda: benchlib.bench_small_clips(dev)),
+                     ("config4_rank_block", lambda: benchlib.bench_config4_rank_block(dev)),
                      ("config3", lambda: benchlib.bench_config3(dev, 5000, 500)),
                      ("config3_with_unet", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True)),
                      ("config3_with_unet_split_bf16", lambda: benchlib.bench_config3(dev, 1000, 100, unet=True, unet_precision="split")),
@@ -419,6 +420,15 @@ def main():
         def gather_only():
             dist.all_gather_into_tensor(clip, src)
         dt_gather, _ = timed(n_aux, gather_only)
+        # the ONE-GPU reference at THIS step size: every rank renders its F frames in one full-chip launch, no collective anywhere in
+        # the timed region (ranks are independent; barrier-bracketed, MAX over ranks).  The driver's N = 1 run is config 2 (1000-frame
+        # steps); weak-scaling efficiency at config 4's 5 000 frames per GPU is value / (N * this rate).
+        one = Schedule(1, 0)
+        one.activate()
+        one.step(gather=False)
+        dt_one, _ = timed(n_aux, lambda: one.step(gather=False))
+        del one
+        sched.activate()
         # cross-rank verification: rank 0 re-renders the LAST rank's block itself and compares with what the gather delivered
         step()
         torch.cuda.synchronize()
@@ -444,6 +454,8 @@ def main():
         multi = {"render_only_ms": round(dt_render / n_aux * 1e3, 3), "gather_only_ms": round(dt_gather / n_aux * 1e3, 3),
                  "gather_bytes_per_rank": int(src.numel() * src.element_size()),
                  "per_gpu_rate_with_gather_over_without": round((dt_render / n_aux) / (dt / args.steps), 4),
+                 "one_gpu_same_frames_per_step": {"frames_per_step": F, "ms_per_step": round(dt_one / n_aux * 1e3, 3),
+                                                  "frames_per_s": round(F * n_aux / dt_one, 1)},
                  "remote_block_bit_identical_to_local_render": verified,
                  "ragged_clip": {"frames": n_rag, "bit_identical_to_one_gpu_render": ragged_ok},
                  "schedule": sched.name, "schedule_selection": "auto (timed during warm-up, max over ranks)" if auto else "flags",

@@ -63,3 +63,52 @@ def state_tensors(root: nn.Module):
     out = [(name, owner[attr]) for name, owner, attr in tree["params"] if owner[attr] is not None]
     out += [(name, owner[attr]) for name, owner, attr, skip in tree["buffers"] if owner[attr] is not None and attr not in skip]
     return out
+
+
+class TensorSlots:
+    """The parameters / buffers `names` (dotted paths under `root`) resolved to (owning dictionary, key) pairs once, plus every
+    parent -> child link on the way there.  `valid()` re-checks those links by identity (a few dozen dictionary look-ups, ~3 us), so a
+    sub-module replaced at ANY depth -- `unet.inc.double_conv[1] = ...`, `nn.SyncBatchNorm.convert_sync_batchnorm(unet)`,
+    `model.audio_net.encoder_conv[0] = ...`, `add_module`, `del` -- is noticed and the slots are resolved again; a tensor re-assigned
+    inside an unchanged module is found because the dictionary is the module's own."""
+    __slots__ = ("links", "slots")
+
+    def __init__(self, root: nn.Module, names):
+        self.links, self.slots = [], []
+        seen = set()
+        for full in names:
+            path, _, attr = full.rpartition(".")
+            m = root
+            for key in (path.split(".") if path else ()):
+                child = m._modules[key]
+                if (id(m), key) not in seen:
+                    seen.add((id(m), key))
+                    self.links.append((m._modules, key, child))
+                m = child
+            if attr in m._parameters:
+                self.slots.append((m._parameters, attr))
+            elif attr in m._buffers:
+                self.slots.append((m._buffers, attr))
+            else:
+                raise KeyError(f"{type(root).__name__} has no parameter or buffer {full!r}")
+
+    def valid(self) -> bool:
+        for d, k, c in self.links:
+            if d.get(k) is not c:
+                return False
+        return True
+
+    def tensors(self):
+        return [d[a] for d, a in self.slots]
+
+
+def tensor_slots(root: nn.Module, names, key: str = "_s2l_slots"):
+    """`[tensor for name in names]` through a `TensorSlots` kept in `root.__dict__[key]` and rebuilt when the tree changed."""
+    slots = root.__dict__.get(key)
+    if slots is None or not slots.valid():
+        slots = root.__dict__[key] = TensorSlots(root, names)
+    try:
+        return slots.tensors()
+    except KeyError:      # a parameter was deleted and re-registered as the other kind (parameter <-> buffer): resolve again
+        slots = root.__dict__[key] = TensorSlots(root, names)
+        return slots.tensors()

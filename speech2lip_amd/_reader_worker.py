@@ -37,7 +37,7 @@ def main():
     sys.modules[spec.name] = D
     spec.loader.exec_module(D)
     head = json.loads(sys.stdin.readline())
-    ds = D.SomeonesLipClip(head["folder"], head["mode"], cfg=head["cfg"])
+    ds = D.SomeonesLipClip(head["folder"], head["mode"], cfg=head["cfg"], img_ext=head.get("img_ext", ".jpg"))
     sys.stdout.write("ready\n")
     sys.stdout.flush()
     for line in sys.stdin:

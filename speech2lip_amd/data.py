@@ -389,13 +389,18 @@ _DECODE_WORKERS = []      # child processes of ClipStreamer(mode="process"): sta
 _DECODE_FREE = None       # queue of idle workers
 
 
+def _spawn_decode_worker():
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_io_worker.py")
+    return subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
 def _decode_workers(n: int):
     """At least `n` `_io_worker.py` children (started together on first use: each takes ~1 s to import numpy + PIL on a cold box;
     they stay for the life of this process -- daemons that end when their stdin closes) and the queue a task takes an idle one from."""
     import atexit
     import queue
-    import subprocess
-    import sys
     global _DECODE_FREE
     if _DECODE_FREE is None:
         _DECODE_FREE = queue.Queue()
@@ -406,22 +411,187 @@ def _decode_workers(n: int):
                     w.stdin.close()
                 except Exception:
                     pass
+            for w in _DECODE_WORKERS:
+                try:
+                    w.wait(timeout=2)
+                except Exception:
+                    w.kill()
         atexit.register(_stop)
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_io_worker.py")
     while len(_DECODE_WORKERS) < n:
-        w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+        w = _spawn_decode_worker()
         _DECODE_WORKERS.append(w)
         _DECODE_FREE.put(w)
     return _DECODE_FREE
 
 
-class ClipStreamer:
+def shutdown_decode_workers() -> None:
+    """Ends the process-wide decode workers (they otherwise live until interpreter exit, shared by every `ClipStreamer`): a long-lived
+    service that has finished rendering calls this to give the processes back.  Streamers created afterwards start new ones; streamers
+    still open must be closed first."""
+    import queue
+    global _DECODE_FREE
+    workers, _DECODE_WORKERS[:] = list(_DECODE_WORKERS), []
+    if _DECODE_FREE is not None:
+        try:
+            while True:
+                _DECODE_FREE.get_nowait()
+        except queue.Empty:
+            pass
+    for w in workers:
+        try:
+            w.stdin.close()
+        except Exception:
+            pass
+    for w in workers:
+        try:
+            w.wait(timeout=5)
+        except Exception:
+            w.kill()
+            w.wait()
+        try:
+            w.stdout.close()
+        except Exception:
+            pass
+
+
+def _replace_decode_worker(dead):
+    """A worker that stopped answering (killed, crashed in a decoder) is reaped and a fresh one takes its place in the pool."""
+    try:
+        dead.kill()
+        dead.wait(timeout=2)
+    except Exception:
+        pass
+    w = _spawn_decode_worker()
+    try:
+        _DECODE_WORKERS[_DECODE_WORKERS.index(dead)] = w
+    except ValueError:
+        _DECODE_WORKERS.append(w)
+    return w
+
+
+def _ask_decode_worker(free, line: str) -> str:
+    """One request line to an idle worker, its one answer line back ("" = the worker died: it is replaced before the queue sees it)."""
+    w = free.get()
+    try:
+        try:
+            w.stdin.write(line + "\n")
+            w.stdin.flush()
+            ans = w.stdout.readline().strip()
+        except (BrokenPipeError, OSError, ValueError):
+            ans = ""
+        if not ans:
+            w = _replace_decode_worker(w)
+    finally:
+        free.put(w)
+    return ans
+
+
+def _release_shared(pool, blocks, free, readers):
+    """What a streamer / prefetcher owns outside the Python heap, given back exactly once (`close()`, `with`, garbage collection or
+    interpreter exit -- `weakref.finalize`; it must not reference the owner): the pool's threads, the reader processes, the decode
+    workers' mappings of the blocks, and the shared-memory blocks themselves."""
+    import json
+    import queue
+    try:
+        pool.shutdown(wait=True, cancel_futures=True)
+    except Exception:
+        pass
+    for w in readers or []:
+        try:
+            w.stdin.close()
+        except Exception:
+            pass
+    for w in readers or []:
+        try:
+            w.wait(timeout=5)
+        except Exception:
+            w.kill()
+            try:
+                w.wait(timeout=2)
+            except Exception:
+                pass
+        for f in (w.stdout, w.stdin):
+            try:
+                f.close()
+            except Exception:
+                pass
+    if free is not None and blocks:      # the shared decode workers drop their mappings (else an unlinked block stays resident in each)
+        line = json.dumps({"detach": [b.name for b in blocks]})
+        held = []
+        try:
+            for _ in range(len(_DECODE_WORKERS)):
+                held.append(free.get(timeout=5))      # (a worker busy for another streamer comes back within one decode)
+        except queue.Empty:
+            pass                                       # (the workers' own cap on cached mappings bounds what is left)
+        for i, w in enumerate(held):
+            try:
+                w.stdin.write(line + "\n")
+                w.stdin.flush()
+                if not w.stdout.readline().strip():
+                    held[i] = _replace_decode_worker(w)
+            except Exception:
+                held[i] = _replace_decode_worker(w)
+        for w in held:
+            free.put(w)
+    for b in blocks or []:
+        try:
+            b.close()
+        except Exception:
+            pass
+        try:
+            b.unlink()
+        except Exception:
+            pass
+
+
+def _weak_call(ref, name, *args):
+    """A pool task that does not keep its owner alive: queued / finished work items would otherwise hold the streamer through the bound
+    method, and the LAST reference could then die in a pool thread -- the finalizer would run there, late, joining its own pool."""
+    obj = ref()
+    if obj is None:
+        raise RuntimeError("the owner of this task was collected")
+    return getattr(obj, name)(*args)
+
+
+class _OwnsShared:
+    """Context-manager / finalizer plumbing shared by `ClipStreamer` and `FramePrefetcher` (the reference's `DataLoader(num_workers=8)`,
+    train.py:100-122, cleans up after itself: so do these)."""
+    _finalizer = None
+
+    def _own(self, pool, blocks=None, free=None, readers=None):
+        import weakref
+        self._finalizer = weakref.finalize(self, _release_shared, pool, list(blocks or []), free, list(readers or []))
+
+    def _submit(self, name, *args):
+        import weakref
+        return self.pool.submit(_weak_call, weakref.ref(self), name, *args)
+
+    def close(self):
+        """Idempotent; also runs when the object is collected and at interpreter exit."""
+        if self._finalizer is not None:
+            self._finalizer()
+
+    @property
+    def closed(self) -> bool:
+        return self._finalizer is None or not self._finalizer.alive
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+class ClipStreamer(_OwnsShared):
     """`SomeonesLipClip.load` as a pipeline (the clip-level counterpart of the reference's DataLoader, inference.py:129-140):
     batches of `batch` frames are read by a pool of host threads (JPEG decode and `np.load` release the GIL) straight into
     PINNED staging buffers -- observed frames as the decoded bytes, a quarter of the fp32 size -- and copied to the device on a
     SIDE stream while the previous batch renders; `depth` batches are in flight.  Iterating yields `ClipTensors` whose tensors
     are the same values `load` returns (frames converted on the device by s2l_from8b, bit for bit the host conversion); a
-    yielded batch stays valid until the iteration after the next one starts."""
+    yielded batch stays valid until the iteration after the next one starts (work queued on it on the current stream up to that
+    point is waited for before its device buffers are overwritten).  Owns threads, shared-memory blocks and (process mode) mappings
+    in the decode workers: use it as a context manager or call `close()`; garbage collection and interpreter exit release them too."""
 
     def __init__(self, ds: "SomeonesLipClip", device, batch: int = 100, first: int = 0, count: Optional[int] = None,
                  workers: Optional[int] = None, depth: int = 2, mode: Optional[str] = None):
@@ -438,22 +608,34 @@ class ClipStreamer:
         # (8, not "as many as there are cores": measured on a 256-core host the loader alone does 2 200 frames/s with 8 workers, 1 400
         #  with 32, 1 200 with 64 -- threads beyond what the interpreter lock can feed only fight over it)
         self.workers = int(workers) if workers else min(8, os.cpu_count() or 1)
-        self.pool = ThreadPoolExecutor(self.workers)
         self.with_pose = ds.coord_files is not None and ds.mode != "test"
         self.with_frames = ds.mode != "test"
         self.mode = mode if mode is not None else ("process" if self.count >= 256 and (self.with_pose or self.with_frames) else "thread")
         if self.mode not in ("thread", "process"):
             raise ValueError("ClipStreamer mode must be 'thread' or 'process'")
+        self.pool = ThreadPoolExecutor(self.workers)
         ns, B, FH, FW = self.depth + 1, self.batch, ds.face_h, ds.face_w
         self.procs = self.shm_frames = self.shm_coords = None
-        if self.mode == "process":
-            from multiprocessing import shared_memory
-            # plain `python _io_worker.py` children (they import numpy + PIL only and inherit nothing of this process's HIP state),
-            # started once per process and shared by every streamer; a pool thread borrows an idle one per task
-            self.procs = _decode_workers(self.workers)
-            self.fshape, self.cshape = (B, FH, FW, 3), (B, FH, FW, 2)
-            self.shm_frames = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 3) for _ in range(ns)] if self.with_frames else None
-            self.shm_coords = [shared_memory.SharedMemory(create=True, size=B * FH * FW * 2 * 4) for _ in range(ns)] if self.with_pose else None
+        blocks = []
+        try:
+            if self.mode == "process":
+                from multiprocessing import shared_memory
+                # plain `python _io_worker.py` children (they import numpy + PIL only and inherit nothing of this process's HIP state),
+                # started once per process and shared by every streamer; a pool thread borrows an idle one per task
+                self.procs = _decode_workers(self.workers)
+                self.fshape, self.cshape = (B, FH, FW, 3), (B, FH, FW, 2)
+                if self.with_frames:
+                    self.shm_frames = []
+                    for _ in range(ns):
+                        self.shm_frames.append(shared_memory.SharedMemory(create=True, size=B * FH * FW * 3))
+                        blocks.append(self.shm_frames[-1])
+                if self.with_pose:
+                    self.shm_coords = []
+                    for _ in range(ns):
+                        self.shm_coords.append(shared_memory.SharedMemory(create=True, size=B * FH * FW * 2 * 4))
+                        blocks.append(self.shm_coords[-1])
+        finally:
+            self._own(self.pool, blocks, self.procs)      # (from here on whatever exists is released, also when the rest of __init__ raises)
         pin = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype).pin_memory() for _ in range(ns)]
         on = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype, device=self.dev) for _ in range(ns)]
         self.h_coord = pin(B, FH, FW, 2, dtype=torch.float32) if self.with_pose else None
@@ -487,13 +669,10 @@ class ClipStreamer:
 
     def _ask_worker(self, request) -> None:
         import json
-        w = self.procs.get()
-        try:
-            w.stdin.write(json.dumps(request) + "\n")
-            w.stdin.flush()
-            ans = w.stdout.readline().strip()
-        finally:
-            self.procs.put(w)
+        line = json.dumps(request)
+        ans = _ask_decode_worker(self.procs, line)
+        if not ans:                      # the worker died under this request: it has been replaced; one more try on a live one
+            ans = _ask_decode_worker(self.procs, line)
         if ans != "ok":
             raise RuntimeError(f"decode worker: {ans or 'died'}")
 
@@ -502,9 +681,12 @@ class ClipStreamer:
 
     def __iter__(self):
         from collections import deque
+        if self.closed:
+            raise RuntimeError("ClipStreamer is closed")
         starts = list(range(self.first, self.first + self.count, self.batch))
         ns = self.depth + 1
-        h2d_done, consumed = [None] * ns, [None] * ns
+        h2d_done = [None] * ns
+        marks = deque(maxlen=max(1, ns - 1))      # marks[-1]: the consumer's stream at the start of this iteration, [-2]: of the previous ...
         pending = deque()
 
         def submit(k):
@@ -513,58 +695,71 @@ class ClipStreamer:
                 h2d_done[slot].synchronize()          # the staging buffers of this slot have left for the device
             s0 = starts[k]
             cnt = min(self.batch, self.first + self.count - s0)
-            pending.append((k, slot, s0, cnt, [self.pool.submit(self._decode, slot, j, s0 + j) for j in range(cnt)]))
-        for k in range(min(self.depth, len(starts))):
-            submit(k)
-        nxt = len(pending)
-        while pending:
-            k, slot, s0, cnt, futs = pending.popleft()
-            for f in futs:
-                f.result()
-            cur = torch.cuda.current_stream(self.dev)
-            with torch.cuda.stream(self.side):
-                if consumed[slot] is not None:
-                    self.side.wait_event(consumed[slot])      # the previous user of this device slot has finished with it
-                if self.with_pose:
-                    self.d_coord[slot][:cnt].copy_(self.h_coord[slot][:cnt], non_blocking=True)
-                if self.with_frames:
-                    self.d_ori8[slot][:cnt].copy_(self.h_ori[slot][:cnt], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-            h2d_done[slot] = ev
-            cur.wait_event(ev)
-            if nxt < len(starts):
-                submit(nxt)
-                nxt += 1
-            ori = from8b(self.d_ori8[slot][:cnt], out=self.d_ori[slot][:cnt]) if self.with_frames else None
-            off = s0 - self.first
-            idx = torch.arange(s0, s0 + cnt, dtype=torch.int64, device=self.dev)
-            yield ClipTensors(audio=self.audio[off:off + cnt], index=idx, coord=self.d_coord[slot][:cnt] if self.with_pose else None,
-                              rgb_face_ori=ori, rgb_face_zero=self.face_zero, mask_lip_canonical=self.mask,
-                              lip_lefttop_x=self.ds.lefttop_x, lip_lefttop_y=self.ds.lefttop_y, height=self.ds.lip_h, width=self.ds.lip_w,
-                              names=["{:05d}".format(i + 1) for i in range(s0, s0 + cnt)])
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self.dev))
-            consumed[slot] = done
+            pending.append((k, slot, s0, cnt, [self._submit("_decode", slot, j, s0 + j) for j in range(cnt)]))
+        try:
+            for k in range(min(self.depth, len(starts))):
+                submit(k)
+            nxt = len(pending)
+            while pending:
+                k, slot, s0, cnt, futs = pending.popleft()
+                for f in futs:
+                    f.result()
+                cur = torch.cuda.current_stream(self.dev)
+                mark = torch.cuda.Event()
+                mark.record(cur)                          # everything the consumer queued through iteration k-1
+                marks.append(mark)
+                with torch.cuda.stream(self.side):
+                    # This slot's device buffers held batch k-ns, promised valid through iteration k-ns+1: wait for the consumer's
+                    # stream as it stood at the start of iteration k-ns+2 (for the default depth 2: the previous iteration's start,
+                    # so this copy still overlaps the work queued on batch k-1).
+                    if k >= ns and len(marks) >= ns - 1:
+                        self.side.wait_event(marks[0])
+                    if self.with_pose:
+                        self.d_coord[slot][:cnt].copy_(self.h_coord[slot][:cnt], non_blocking=True)
+                    if self.with_frames:
+                        self.d_ori8[slot][:cnt].copy_(self.h_ori[slot][:cnt], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                h2d_done[slot] = ev
+                cur.wait_event(ev)
+                if nxt < len(starts):
+                    submit(nxt)
+                    nxt += 1
+                ori = from8b(self.d_ori8[slot][:cnt], out=self.d_ori[slot][:cnt]) if self.with_frames else None
+                off = s0 - self.first
+                idx = torch.arange(s0, s0 + cnt, dtype=torch.int64, device=self.dev)
+                yield ClipTensors(audio=self.audio[off:off + cnt], index=idx, coord=self.d_coord[slot][:cnt] if self.with_pose else None,
+                                  rgb_face_ori=ori, rgb_face_zero=self.face_zero, mask_lip_canonical=self.mask,
+                                  lip_lefttop_x=self.ds.lefttop_x, lip_lefttop_y=self.ds.lefttop_y, height=self.ds.lip_h, width=self.ds.lip_w,
+                                  names=["{:05d}".format(i + 1) for i in range(s0, s0 + cnt)])
+        finally:
+            # (an iteration abandoned half way -- an exception in the consumer, a `break` -- leaves decode tasks queued: drop those not
+            #  started, wait for the running ones, so that `close()` / the next iteration find idle staging buffers)
+            for _, _, _, _, futs in pending:
+                for f in futs:
+                    f.cancel()
+            for _, _, _, _, futs in pending:
+                for f in futs:
+                    if not f.cancelled():
+                        try:
+                            f.result()
+                        except Exception:
+                            pass
+            for ev in h2d_done:
+                if ev is not None:
+                    ev.synchronize()
 
-    def close(self):
-        self.pool.shutdown(wait=True)
-        if self.procs is not None:      # (the worker processes stay: the next streamer re-uses them)
-            for blocks in (self.shm_frames, self.shm_coords):
-                for b in blocks or []:
-                    b.close()
-                    b.unlink()
-            self.procs = None
 
-
-class FramePrefetcher:
+class FramePrefetcher(_OwnsShared):
     """The reference's `DataLoader(num_workers > 0)` (train.py:136-140) for `load_one_frame`: the dictionaries of the frame
     indices in `order` are prepared up to `depth` frames ahead and come out in order, collated (`collate_batch`) `per_step` at a time.
     mode "thread" (default without a GPU; what the CPU tests use): a thread pool in this process; mode "process" (default with one):
     `workers` child processes (`_reader_worker.py`, each with its own `SomeonesLipClip`) that write a frame's tensors into shared
     memory -- the reader's PIL / numpy work (JPEG decode, the 8-bit resize of the negative window: 10 - 18 ms per frame) holds the
     interpreter lock, so loader threads top out near one core.  (torch's own DataLoader processes were tried first: their transport of a
-    frame's ~16 MB measured 19 - 268 ms per iteration on the benchmark host.)"""
+    frame's ~16 MB measured 19 - 268 ms per iteration on the benchmark host.)  Owns threads, child processes and shared-memory slabs:
+    a context manager; `close()` is idempotent and also runs on garbage collection / interpreter exit (as the reference's DataLoader
+    reaps its workers, train.py:100-122)."""
 
     SLAB = 24 << 20      # bytes of shared memory per frame in flight (a May frame with its sync window: 16.3 MB)
 
@@ -580,40 +775,55 @@ class FramePrefetcher:
         self.mode = mode if mode is not None else ("process" if torch.cuda.is_available() else "thread")
         if self.mode not in ("thread", "process"):
             raise ValueError("FramePrefetcher mode must be 'thread' or 'process'")
-        self.pool = ThreadPoolExecutor(self.workers)
         self.free = self.procs = self.slabs = None
+        head = None
         if self.mode == "process":
             import json
-            import queue
-            import subprocess
-            import sys
-            from multiprocessing import shared_memory
-            script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_reader_worker.py")
-            head = json.dumps({"folder": ds.dataset_folder, "mode": ds.mode, "cfg": ds.cfg}, default=lambda o: None)
-            self.procs, self.free, self.slabs = [], queue.Queue(), queue.Queue()
-            for _ in range(self.workers):      # started together; each builds its own reader (~2 s: python + torch import + the folder scan)
-                w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
-                w.stdin.write(head + "\n")
-                w.stdin.flush()
-                self.procs.append(w)
-            for w in self.procs:
-                if w.stdout.readline().strip() != "ready":
-                    raise RuntimeError("FramePrefetcher: a reader process did not start")
-                self.free.put(w)
-            self._blocks = [shared_memory.SharedMemory(create=True, size=self.SLAB) for _ in range(self.depth + self.workers)]
-            for b in self._blocks:
-                self.slabs.put(b)
+
+            def plain(o):      # (a value the worker could not rebuild must not silently become None)
+                raise TypeError(f"FramePrefetcher(mode='process'): cfg value {o!r} of type {type(o).__name__} cannot be sent to the "
+                                "reader processes (JSON); use mode='thread' or plain numbers / strings / lists / dicts in cfg")
+            head = json.dumps({"folder": ds.dataset_folder, "mode": ds.mode, "cfg": ds.cfg, "img_ext": getattr(ds, "img_ext", ".jpg")},
+                              default=plain)
+        self.pool = ThreadPoolExecutor(self.workers)
+        self._blocks, procs = [], []
+        try:
+            if self.mode == "process":
+                import queue
+                import subprocess
+                import sys
+                from multiprocessing import shared_memory
+                script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_reader_worker.py")
+                self.free, self.slabs = queue.Queue(), queue.Queue()
+                for _ in range(self.workers):      # started together; each builds its own reader (~2 s: python + torch import + the folder scan)
+                    w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+                    procs.append(w)
+                    w.stdin.write(head + "\n")
+                    w.stdin.flush()
+                for _ in range(self.depth + self.workers):
+                    self._blocks.append(shared_memory.SharedMemory(create=True, size=self.SLAB))
+                    self.slabs.put(self._blocks[-1])
+                for w in procs:
+                    if w.stdout.readline().strip() != "ready":
+                        raise RuntimeError("FramePrefetcher: a reader process did not start")
+                    self.free.put(w)
+                self.procs = procs
+        finally:
+            self._own(self.pool, self._blocks, None, procs)
 
     def _load_in_process(self, i):
         import json
         w, slab = self.free.get(), self.slabs.get()
-        try:
-            w.stdin.write(json.dumps({"index": int(i), "shm": slab.name}) + "\n")
-            w.stdin.flush()
-            man = json.loads(w.stdout.readline())
-        finally:
-            self.free.put(w)
-        try:
+        try:      # (ONE finally for the slab: an empty or malformed reply line must not lose it)
+            try:
+                w.stdin.write(json.dumps({"index": int(i), "shm": slab.name}) + "\n")
+                w.stdin.flush()
+                line = w.stdout.readline()
+            finally:
+                self.free.put(w)
+            if not line.strip():
+                raise RuntimeError(f"reader process died (exit code {w.poll()}) while loading frame {int(i)}")
+            man = json.loads(line)
             if "__error__" in man:
                 raise RuntimeError(f"reader process: {man['__error__']}")
             d = {}
@@ -629,6 +839,7 @@ class FramePrefetcher:
                     d[k] = t
                 else:
                     d[k] = a.copy()
+                del a
             return d
         finally:
             self.slabs.put(slab)
@@ -643,48 +854,63 @@ class FramePrefetcher:
 
     def __iter__(self):
         from collections import deque
+        if self.closed:
+            raise RuntimeError("FramePrefetcher is closed")
         q, it = deque(), iter(self.order)
-        for i in it:
-            q.append(self.pool.submit(self._load, i))
-            if len(q) >= self.depth:
-                break
-        group = []
-        while q:
-            group.append(q.popleft().result())
+        try:
             for i in it:
-                q.append(self.pool.submit(self._load, i))
-                break
-            if len(group) == self.per_step or not q:
-                yield (group[0] if self.per_step == 1 else collate_batch(group)) if self.collate else group
-                group = []
-
-    def close(self):
-        self.pool.shutdown(wait=True)
-        if self.procs is not None:
-            for w in self.procs:
-                try:
-                    w.stdin.close()
-                    w.wait(timeout=5)
-                except Exception:
-                    w.kill()
-            for b in self._blocks:
-                b.close()
-                b.unlink()
-            self.procs = None
+                q.append(self._submit("_load", i))
+                if len(q) >= self.depth:
+                    break
+            group = []
+            while q:
+                group.append(q.popleft().result())
+                for i in it:
+                    q.append(self._submit("_load", i))
+                    break
+                if len(group) == self.per_step or not q:
+                    yield (group[0] if self.per_step == 1 else collate_batch(group)) if self.collate else group
+                    group = []
+        finally:      # an abandoned iteration: frames still in flight are dropped (not started) or waited for (running)
+            for f in q:
+                f.cancel()
+            for f in q:
+                if not f.cancelled():
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
 
 
 class FrameWriter:
     """`write_frames` as a pipeline: the 8-bit frames leave the device into a pinned buffer on a side stream, and a pool of host
     threads encodes and writes the files (PIL's encoder releases the GIL) while the GPU renders the next batch.
-    `submit(frames, names)`; `close()` waits for every file."""
+    `submit(frames, names)`; `close()` waits for every file (idempotent; `with FrameWriter(...) as w:` closes on the way out and
+    re-raises the first encoder error)."""
 
     def __init__(self, out_dir: str, workers: Optional[int] = None, ext: str = ".jpg", depth: int = 3):
+        import weakref
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(out_dir, exist_ok=True)
         self.out_dir, self.ext = out_dir, ext
         self.pool = ThreadPoolExecutor(int(workers) if workers else min(16, os.cpu_count() or 1))
         self.slots, self.depth, self.k, self.side = [], max(1, int(depth)), 0, None
         self.futs = []
+        self._closed = False
+        self._finalizer = weakref.finalize(self, self.pool.shutdown, wait=False)      # (threads only: nothing to unlink)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        else:                     # the caller is already unwinding: finish what was queued, do not mask its exception
+            try:
+                self.close()
+            except Exception:
+                pass
+        return False
 
     def _save(self, arr, name):
         from PIL import Image
@@ -696,6 +922,8 @@ class FrameWriter:
         return [self.pool.submit(self._save, a[j], n) for j, n in enumerate(names)]
 
     def submit(self, frames: torch.Tensor, names) -> None:
+        if self._closed:
+            raise RuntimeError("FrameWriter is closed")
         u8 = frames if frames.dtype == torch.uint8 else to8b(frames)
         if u8.device.type != "cuda":
             self.futs.append(self.pool.submit(lambda: [self._save(a, n) for a, n in zip(u8.numpy(), names)]))
@@ -726,12 +954,25 @@ class FrameWriter:
         self.futs.append(job)
 
     def close(self) -> None:
-        for f in self.futs:
-            r = f.result()
-            for g in (r if isinstance(r, list) else []):
-                if hasattr(g, "result"):
-                    g.result()
-        self.pool.shutdown(wait=True)
+        if self._closed:
+            return
+        self._closed = True
+        first = None
+        try:
+            for f in self.futs:
+                try:
+                    r = f.result()
+                    for g in (r if isinstance(r, list) else []):
+                        if hasattr(g, "result"):
+                            g.result()
+                except Exception as e:      # keep draining: every file that can be written is written
+                    first = first or e
+        finally:
+            self.futs = []
+            self.pool.shutdown(wait=True)
+            self._finalizer.detach()
+        if first is not None:
+            raise first
 
 
 def write_frames(frames: torch.Tensor, names, out_dir: str, ext: str = ".jpg") -> None:

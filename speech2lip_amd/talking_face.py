@@ -29,7 +29,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _abi
+from . import _abi, _modcache
 
 _UNSUPPORTED_TRUE = ("use_attention", "use_audio_mel", "use_head_pose", "use_head_pose_net", "use_lms", "use_text")
 
@@ -174,23 +174,10 @@ class TalkingFace(nn.Module):
     # ------------------------------------------------------------------ weights
     def _hot_tensors(self):
         """The 42 hot-path parameters in the C-ABI's order.  The owning sub-modules' `_parameters` dictionaries are looked up once
-        (walking `named_parameters()` -- the U-Net's tree included -- cost 0.2 ms per call and a training step makes ~50); a
-        parameter that is re-assigned is still found (the dictionary is the module's own), a sub-module that is replaced at the
-        top level drops the cache (`__setattr__`)."""
-        cache = self.__dict__.get("_hot_cache")
-        if cache is None:
-            mods = dict(self.named_modules())
-            cache = []
-            for name in _abi.TENSOR_ORDER:
-                mod, _, attr = name.rpartition(".")
-                cache.append((mods[mod]._parameters, attr))
-            self.__dict__["_hot_cache"] = cache
-        return [d[a] for d, a in cache]
-
-    def __setattr__(self, name, value):
-        if isinstance(value, nn.Module):
-            self.__dict__.pop("_hot_cache", None)
-        super().__setattr__(name, value)
+        (walking `named_parameters()` -- the U-Net's tree included -- cost 0.2 ms per call and a training step makes ~50) and the
+        parent -> child links to them are re-checked by identity on every call (`_modcache.TensorSlots`): a parameter that is
+        re-assigned is found (the dictionary is the module's own), a sub-module replaced at any depth resolves the slots again."""
+        return _modcache.tensor_slots(self, _abi.TENSOR_ORDER, "_hot_cache")
 
     def packed_weights(self) -> torch.Tensor:
         """Device blob in kernel layout; rebuilt whenever a parameter was modified in place,

@@ -279,11 +279,7 @@ class Trainer:
         that U-Net with frozen parameters but BatchNorm batch statistics (and moving running statistics).  The drop-in does the
         same, because `post_fusion2_onlylip` follows the sub-module's own mode (golden G16)."""
         set_training(self.model, True)      # = self.model.train() (training.py:150) without the generator walk
-        if self.multi_gpu and getattr(self.model, "post_fusion_unet", None) is not None:
-            # DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers -- the BatchNorm running statistics -- to every rank
-            # before each forward: with per-rank frames they would otherwise drift apart rank by rank
-            from .sharded import broadcast_module_state
-            broadcast_module_state(self.model.post_fusion_unet, src=0)
+        self._broadcast_buffers()
         if self.cfg["training"].get("stage", "stage1") == "stage1":
             if self.fused_step and self.precision == "bf16" and self._fused_step_covers():
                 loss, loss_all = self.train_stage1_frames(data, it=it, seed=seed)
@@ -292,6 +288,13 @@ class Trainer:
         else:
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
         return float(loss), loss_all
+
+    def _broadcast_buffers(self):
+        """DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers -- the BatchNorm running statistics -- to every rank
+        before each forward: with per-rank frames they would otherwise drift apart rank by rank.  No-op without `multi_gpu`."""
+        if self.multi_gpu and getattr(self.model, "post_fusion_unet", None) is not None:
+            from .sharded import broadcast_module_state
+            broadcast_module_state(self.model.post_fusion_unet, src=0)
 
     def _fused_step_covers(self) -> bool:
         """Whether `train_stage1_frames` implements the configured loss set (what it refuses with NotImplementedError)."""
@@ -483,6 +486,7 @@ class Trainer:
         so K = 1 consumes the generators like one `train_step` call.  The canonical-depth photo loss is not part of this
         entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames."""
         set_training(self.model, True)                      # self.model.train(): training.py:150, as train_step
+        self._broadcast_buffers()                           # (DDP's per-forward buffer broadcast, as train_step)
         if self.cfg["training"].get("stage", "stage1") != "stage1":
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
         return self.train_stage1_frames(batch, it=it, seed=seed)
@@ -550,7 +554,7 @@ class Trainer:
                 u_win.append(torch.cat([torch.rand(1, device=dev) for _ in range(int(fr["audio_window"].shape[-3]))]))
         stack = lambda k: torch.stack([on(fr[k]).reshape(fr[k].shape[-3:] if fr[k].dim() > 3 else fr[k].shape) for fr in frames], 0)
         audio = torch.stack([on(fr["audio"]).reshape(16, 29) for fr in frames], 0)
-        first = [scalar(fr["index"]) + (0 if seed is None else int(seed)) for fr in frames]
+        first = [scalar(fr["index"]) for fr in frames]      # (unseeded: the window's clamp sees the data index, the seed is added after it)
         targets = torch.stack([on(fr["rgb"]).reshape(H * W, 3) for fr in frames], 0)
         face = sync = None
         if face_on:
@@ -570,7 +574,8 @@ class Trainer:
                         canonical_face_bbox=[float(v) for v in bbox], mel=torch.stack([on(fr["mel"]).reshape(1, 80, 16) for fr in frames], 0),
                         rgb_window_neg=torch.stack([on(fr["rgb_window_neg"]).reshape(3, T, 96, 96) for fr in frames], 0))
         self.optimizer.zero_grad()
-        total, grads, aux = step.loss_and_grads(audio, first, targets, torch.cat(u_main), sync=sync, face=face)
+        total, grads, aux = step.loss_and_grads(audio, first, targets, torch.cat(u_main), sync=sync, face=face,
+                                                seed=0 if seed is None else int(seed))
         apply_grads(m, grads)
         self._average_gradients_over_ranks()
         nan_check = self._check_weights_launch()
@@ -580,6 +585,7 @@ class Trainer:
         for k in ("loss_perceptual", "loss_sync"):
             if k in aux:
                 loss[k] = aux[k]
+        self._loss_to_host(loss)      # host tensors, like `_train_stage1` and the reference (training.py:562-569)
         return loss["loss_rgb"], loss
 
 
@@ -938,8 +944,10 @@ class StageOneStep:
                                loss_conv_precision=self.loss_conv_precision) if syncnet is not None else None
         self.T, self.lambda_rgb, self.w_post_fusion, self.face_loss = int(syncnet_T), float(lambda_rgb), float(w_post_fusion), face_loss
 
-    def loss_and_grads(self, audio, frame_idx, targets, u01, sync=None, face=None):
-        """audio [B,16,29], frame_idx [B], targets [B,HW,3], u01 [B]: the main frames.
+    def loss_and_grads(self, audio, frame_idx, targets, u01, sync=None, face=None, seed: int = 0):
+        """audio [B,16,29], frame_idx [B], targets [B,HW,3], u01 [B]: the main frames.  `seed` is added to every frame index the
+        renderer sees AFTER the window's clamp to the last frame, as the reference does (training.py:515-518 clamp `index + t`,
+        then predict_lip_image adds the seed, :183-186).
         sync (optional): dict(audio_window [S,T,16,29], u01 [S,T], total_frame, rgb_face_canonical, rgb_face_gt [S,...],
         mask_lip_canonical, lip_lefttop_x, lip_lefttop_y, coord_window [S,T,FH,FW,2], canonical_face_bbox, mel, rgb_window_neg)
         -- sample s belongs to main frame s.
@@ -971,6 +979,8 @@ class StageOneStep:
                     if not on_device:
                         u.append(float(uw[s][t]))
             a = torch.cat([a, aw.reshape(S * T, 16, 29)], 0)
+        if seed:
+            idx = [i + int(seed) for i in idx]
         pred = self.step.forward(a, idx, u)                                   # [B + S*T, P, 3]
         dpred = torch.zeros_like(pred)
         losses = {}

@@ -13,9 +13,21 @@ import ctypes
 import torch
 import torch.nn as nn
 
-from . import _abi
+from . import _abi, _modcache
 from ._modcache import param_map
 from .weights import UNET_CONVS
+
+
+def _tensor_names():
+    names = []
+    for name, _, _ in UNET_CONVS:
+        head, idx = name.rsplit(".", 1)
+        bn = f"{head}.{int(idx) + 1}"
+        names += [f"{name}.weight", f"{bn}.weight", f"{bn}.bias", f"{bn}.running_mean", f"{bn}.running_var"]
+    return names + ["outc.conv.weight", "outc.conv.bias"]
+
+
+_TENSOR_NAMES = _tensor_names()      # the C-ABI's order (s2l_unet_pack): per 3x3 layer weight + its BatchNorm's four, then the 1x1 layer
 
 
 def nhwc_to_c32(x: torch.Tensor) -> torch.Tensor:
@@ -63,28 +75,8 @@ class SimpleUnetLight(nn.Module):
 
     def _tensors(self):
         """Weights, BatchNorm parameters and running statistics in the C-ABI's order (looked up through the owning modules' own
-        `_parameters` / `_buffers` dictionaries, found once: see TalkingFace._hot_tensors)."""
-        cache = self.__dict__.get("_tensor_cache")
-        if cache is None:
-            mods = dict(self.named_modules())
-
-            def slot(full):
-                mod, _, attr = full.rpartition(".")
-                m = mods[mod]
-                return (m._parameters if attr in m._parameters else m._buffers), attr
-            cache = []
-            for name, _, _ in UNET_CONVS:
-                head, idx = name.rsplit(".", 1)
-                bn = f"{head}.{int(idx) + 1}"
-                cache += [slot(f"{name}.weight"), slot(f"{bn}.weight"), slot(f"{bn}.bias"), slot(f"{bn}.running_mean"), slot(f"{bn}.running_var")]
-            cache += [slot("outc.conv.weight"), slot("outc.conv.bias")]
-            self.__dict__["_tensor_cache"] = cache
-        return [d[a] for d, a in cache]
-
-    def __setattr__(self, name, value):
-        if isinstance(value, nn.Module):
-            self.__dict__.pop("_tensor_cache", None)
-        super().__setattr__(name, value)
+        `_parameters` / `_buffers` dictionaries, found once and re-validated link by link: see TalkingFace._hot_tensors)."""
+        return _modcache.tensor_slots(self, _TENSOR_NAMES, "_tensor_cache")
 
     def packed_weights(self) -> torch.Tensor:
         lib = _abi.load()

@@ -593,7 +593,7 @@ def test_bench_line_stays_inside_the_drivers_tail():
     assert small["leg0"]["ms_per_step"] == 41.43 and small["leg0"]["roofline"] == {"achieved": 5505.0, "frac": 0.6881}
     assert "config" not in small["leg0"] and "loss_last" not in small["leg0"] and small["leg0"]["error"].startswith("RuntimeError")
     legend = open(os.path.join(ROOT, "docs", "BENCH_LEGEND.md")).read()
-    for name in ("composite", "render_split", "small_clips", "config3", "unet_fp32", "train_bf16", "dropin_trainer", "infer_clip_end_to_end",
+    for name in ("composite", "render_split", "small_clips", "config4_rank_block", "config3", "unet_fp32", "train_bf16", "dropin_trainer", "infer_clip_end_to_end",
                  "eager_torch_gpu", "stage1_early_iteration_bf16"):
         assert f"`{name}" in legend, name
 
@@ -647,3 +647,49 @@ def test_module_tree_cache_follows_the_tree():
     net.c = Frozen()
     set_training(net, True)
     assert net.training and net.a.training and not net.c.training
+
+
+def test_hot_tensor_slots_follow_nested_module_replacement():
+    """`TalkingFace._hot_tensors` / `SimpleUnetLight._tensors` (what `packed_weights()` keys on) must see a sub-module that is
+    replaced BELOW the top level -- `model.audio_net.encoder_conv[0] = ...`, `unet.inc.double_conv[1] = ...`,
+    `nn.SyncBatchNorm.convert_sync_batchnorm(unet)`, `add_module`, `del` + re-register -- not only a top-level `__setattr__`
+    (the reference resolves its parameters through the live module tree on every forward, tf_nerf.py:197-285)."""
+    import torch.nn as nn
+    from speech2lip_amd import _abi
+    m = s2l.TalkingFace(torch.device("cpu"), s2l.may_config(16, 16), mode="eval")
+    named = dict(m.named_parameters())
+    assert all(a is named[n] for a, n in zip(m._hot_tensors(), _abi.TENSOR_ORDER))
+    # a nested replacement (index into a Sequential two levels down)
+    name0 = next(n for n in _abi.TENSOR_ORDER if n.count(".") >= 2)
+    path, _, attr = name0.rpartition(".")
+    parent_path, _, key = path.rpartition(".")
+    parent = m.get_submodule(parent_path)
+    old = getattr(parent, key) if not key.isdigit() else parent[int(key)]
+    new = type(old)(*([old.in_channels, old.out_channels, old.kernel_size[0], old.stride[0], old.padding[0]] if isinstance(old, nn.Conv1d)
+                      else [old.in_features, old.out_features]))
+    parent.add_module(key, new)
+    named = dict(m.named_parameters())
+    got = dict(zip(_abi.TENSOR_ORDER, m._hot_tensors()))
+    assert got[name0] is named[name0] and got[name0] is getattr(new, attr)
+    assert all(got[n] is named[n] for n in _abi.TENSOR_ORDER)
+    # a re-assigned parameter inside an unchanged module
+    m.fc_uv.weight = nn.Parameter(torch.zeros_like(m.fc_uv.weight))
+    assert dict(zip(_abi.TENSOR_ORDER, m._hot_tensors()))["fc_uv.weight"] is m.fc_uv.weight
+    # a top-level replacement still works
+    m.fc_time = nn.Linear(m.fc_time.in_features, m.fc_time.out_features)
+    assert dict(zip(_abi.TENSOR_ORDER, m._hot_tensors()))["fc_time.weight"] is m.fc_time.weight
+
+    u = s2l.SimpleUnetLight()
+    from speech2lip_amd.unet import _TENSOR_NAMES
+    state = dict(u.state_dict(keep_vars=True))
+    assert all(t is state[n] for t, n in zip(u._tensors(), _TENSOR_NAMES))
+    u.inc.double_conv[1] = nn.BatchNorm2d(64)
+    state = dict(u.state_dict(keep_vars=True))
+    assert all(t is state[n] for t, n in zip(u._tensors(), _TENSOR_NAMES))
+    conv = nn.SyncBatchNorm.convert_sync_batchnorm(u)
+    state = dict(conv.state_dict(keep_vars=True))
+    assert conv is u and isinstance(u.inc.double_conv[1], nn.SyncBatchNorm)
+    assert all(t is state[n] for t, n in zip(u._tensors(), _TENSOR_NAMES))
+    del u.outc.conv
+    u.outc.conv = nn.Conv2d(64, 3, kernel_size=1)
+    assert u._tensors()[-1] is u.outc.conv.bias

@@ -314,3 +314,105 @@ def test_frame_prefetcher_keeps_order_and_collates(tmp_path):
     assert [b["index"].tolist() for b in procs] == [[5, 1], [7, 2], [9, 0], [3]]
     refp = D.collate_batch([ds.load_one_frame(5), ds.load_one_frame(1)])
     assert set(procs[0]) == set(refp) and all(torch.equal(procs[0][k], refp[k]) and procs[0][k].dtype == refp[k].dtype for k in refp)
+
+
+def _shm_exists(name: str) -> bool:
+    return os.path.exists(os.path.join("/dev/shm", name.lstrip("/")))
+
+
+def test_frame_prefetcher_owns_its_processes_and_shared_memory():
+    """What the reference's `DataLoader(num_workers=8)` (train.py:100-122) does for itself: a loader abandoned half way through a
+    clip -- an exception in the training loop -- leaves no shared-memory segment and no child process behind, whether it is closed
+    (`with`), closed twice, or only garbage-collected."""
+    import gc
+    import psutil
+    import speech2lip_amd as s2l
+    from speech2lip_amd import data as D
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    ds = D.SomeonesLipClip(folder, "train")
+    me = psutil.Process()
+    from multiprocessing import resource_tracker
+    resource_tracker.ensure_running()          # (python's own helper process for shared memory: it stays for the life of the interpreter)
+    before = {c.pid for c in me.children(recursive=True)}
+    order = list(range(8)) * 2
+
+    class Boom(RuntimeError):
+        pass
+
+    names, pids = [], []
+    with pytest.raises(Boom):
+        with s2l.FramePrefetcher(ds, order, workers=2, depth=4, pin_memory=False, mode="process") as pf:
+            names = [b.name for b in pf._blocks]
+            pids = [w.pid for w in pf.procs]
+            assert len(names) == 6 and all(_shm_exists(n) for n in names) and len(pids) == 2
+            for k, batch in enumerate(pf):
+                if k == 5:
+                    raise Boom()
+    assert pf.closed and not any(_shm_exists(n) for n in names)
+    assert not ({c.pid for c in me.children(recursive=True)} - before)
+    assert not any(psutil.pid_exists(p) and psutil.Process(p).status() != psutil.STATUS_ZOMBIE for p in pids)
+    pf.close()                                   # idempotent
+    with pytest.raises(RuntimeError):
+        iter(pf).__next__()                      # a closed loader says so instead of hanging on a dead pool
+
+    # never closed: the finalizer does it when the object goes
+    pf = s2l.FramePrefetcher(ds, order, workers=2, depth=2, pin_memory=False, mode="process")
+    names = [b.name for b in pf._blocks]
+    it = iter(pf)
+    next(it)
+    del it, pf
+    gc.collect()
+    assert not any(_shm_exists(n) for n in names)
+    assert not ({c.pid for c in me.children(recursive=True)} - before)
+
+    # a value the reader processes could not rebuild is an error, not a silent None
+    bad = D.SomeonesLipClip(folder, "train")
+    bad.cfg = {"data": {"path": folder, "thing": object()}}
+    with pytest.raises(TypeError):
+        s2l.FramePrefetcher(bad, [0], mode="process", pin_memory=False)
+    assert not ({c.pid for c in me.children(recursive=True)} - before)
+
+
+def test_decode_worker_detaches_and_caps_its_mappings(tmp_path):
+    """`_io_worker.py` (ClipStreamer's decode processes, shared by every streamer of the process): a {"detach": [...]} request unmaps the
+    named blocks, and without one the cache of mappings is capped -- a parent that renders many clips cannot grow the workers without
+    bound (each closed streamer used to stay mapped, ~0.8 GB, until exit)."""
+    import json
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    import numpy as np
+    from PIL import Image
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech2lip_amd", "_io_worker.py")
+    img = (np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3) * 3)
+    Image.fromarray(img, "RGB").save(tmp_path / "a.png")
+    np.save(tmp_path / "c.npy", np.full((4, 6, 2), 0.25, np.float32))
+    w = subprocess.Popen([sys.executable, "-u", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+    def ask(req):
+        w.stdin.write(json.dumps(req) + "\n")
+        w.stdin.flush()
+        return w.stdout.readline().strip()
+
+    def mapped():
+        with open(f"/proc/{w.pid}/maps") as f:
+            return [ln for ln in f if "psm_" in ln]
+    blocks = []
+    try:
+        for k in range(20):          # more blocks than the worker's cap
+            f, c = shared_memory.SharedMemory(create=True, size=2 * 4 * 6 * 3), shared_memory.SharedMemory(create=True, size=2 * 4 * 6 * 2 * 4)
+            blocks += [f, c]
+            assert ask([f.name, [2, 4, 6, 3], c.name, [2, 4, 6, 2], 1, str(tmp_path / "a.png"), str(tmp_path / "c.npy")]) == "ok"
+            assert np.array_equal(np.ndarray((2, 4, 6, 3), np.uint8, buffer=f.buf)[1], img)
+            assert np.all(np.ndarray((2, 4, 6, 2), np.float32, buffer=c.buf)[1] == 0.25)
+        assert 0 < len(mapped()) <= 16
+        assert ask({"detach": [b.name for b in blocks]}) == "ok"
+        assert mapped() == []
+        assert ask(["no_such_block", [1, 4, 6, 3], None, None, 0, str(tmp_path / "a.png"), None]).startswith("err")      # errors are answers
+        assert ask([blocks[0].name, [2, 4, 6, 3], None, None, 0, str(tmp_path / "a.png"), None]) == "ok"                 # ... and it lives on
+    finally:
+        w.stdin.close()
+        w.wait(timeout=10)
+        for b in blocks:
+            b.close()
+            b.unlink()

@@ -218,6 +218,87 @@ def test_clip_streamer_and_frame_writer_equal_the_serial_forms(dev, tmp_path):
         assert open(tmp_path / "a" / (nm + ".jpg"), "rb").read() == open(tmp_path / "b" / (nm + ".jpg"), "rb").read(), nm
 
 
+def test_clip_streamer_abandoned_mid_clip_leaves_nothing_behind(dev, tmp_path):
+    """An exception half way through a clip (what a failing kernel call or a full disk does to inference.py:140-178's loop): the
+    streamer's shared-memory blocks are unlinked, the decode workers drop their mappings of them and -- once the process-wide pool is
+    shut down -- no child process of this test is left; a worker that dies is replaced instead of poisoning the pool; the validity
+    promise of a yielded batch holds for work queued one iteration late."""
+    import gc
+    import os
+    import psutil
+    from speech2lip_amd import data as D
+    from tools.benchlib import write_synthetic_dataset
+    root = str(tmp_path / "may_face_crop_lip")
+    write_synthetic_dataset(root, 40, FH=40, FW=56, lh=8, lw=12, x0=20, y0=22, train=False, workers=4)
+    ds = s2l.SomeonesLipClip(root, "train", s2l.may_config(8, 12, data_path=root))
+    me = psutil.Process()
+    from multiprocessing import resource_tracker
+    resource_tracker.ensure_running()          # (python's own helper process for shared memory: it stays for the life of the interpreter)
+    before = {c.pid for c in me.children(recursive=True)}
+    shm = lambda name: os.path.exists("/dev/shm/" + name.lstrip("/"))
+
+    class Boom(RuntimeError):
+        pass
+
+    with pytest.raises(Boom):
+        with s2l.ClipStreamer(ds, dev, batch=4, workers=3, mode="process") as st:
+            names = [b.name for b in (st.shm_frames + st.shm_coords)]
+            assert len(names) == 6 and all(shm(n) for n in names)
+            for k, clip in enumerate(st):
+                if k == 3:
+                    raise Boom()
+    assert st.closed and not any(shm(n) for n in names)
+    workers = [w.pid for w in D._DECODE_WORKERS]
+    assert len(workers) == 3
+    for pid in workers:                      # the shared workers hold no mapping of the closed streamer's blocks
+        with open(f"/proc/{pid}/maps") as f:
+            assert not [ln for ln in f if any(n.lstrip("/") in ln for n in names)], pid
+    st.close()                               # idempotent
+    with pytest.raises(RuntimeError):
+        next(iter(st))
+
+    # garbage collection alone releases an un-closed streamer
+    st = s2l.ClipStreamer(ds, dev, batch=4, workers=3, mode="process")
+    names = [b.name for b in (st.shm_frames + st.shm_coords)]
+    it = iter(st)
+    next(it)
+    del it, st
+    gc.collect()
+    assert not any(shm(n) for n in names)
+
+    # a decode worker that dies is replaced; the clip still comes out right
+    psutil.Process(D._DECODE_WORKERS[0].pid).kill()
+    with s2l.ClipStreamer(ds, dev, batch=8, workers=3, mode="process") as st:
+        seen = 0
+        for clip in st:
+            ref = ds.load(dev, seen, len(clip.names))
+            assert torch.equal(clip.rgb_face_ori, ref.rgb_face_ori) and torch.equal(clip.coord, ref.coord)
+            seen += len(clip.names)
+    assert seen == len(ds) and len(D._DECODE_WORKERS) == 3 and all(w.poll() is None for w in D._DECODE_WORKERS)
+
+    # validity: batch k may still be read by work queued during iteration k+1 (a consumer one batch behind)
+    with s2l.ClipStreamer(ds, dev, batch=4, workers=3, mode="thread") as st:
+        prev, sums, refs, seen = None, [], [], 0
+        for clip in st:
+            if prev is not None:
+                torch.cuda._sleep(20_000_000)                               # a lagging consumer stream
+                sums.append((prev.rgb_face_ori.double().sum(), prev.coord.double().sum()))
+            refs.append(ds.load(dev, seen, len(clip.names)))
+            seen += len(clip.names)
+            prev = clip
+        sums.append((prev.rgb_face_ori.double().sum(), prev.coord.double().sum()))
+    torch.cuda.synchronize()
+    for (a, b), ref in zip(sums, refs):
+        assert float(a) == float(ref.rgb_face_ori.double().sum()) and float(b) == float(ref.coord.double().sum())
+
+    D.shutdown_decode_workers()
+    assert not ({c.pid for c in me.children(recursive=True)} - before)
+    with s2l.ClipStreamer(ds, dev, batch=8, first=0, count=8, workers=2, mode="process") as st:      # the pool comes back on demand
+        assert sum(len(c.names) for c in st) == 8
+    D.shutdown_decode_workers()
+    assert not ({c.pid for c in me.children(recursive=True)} - before)
+
+
 @pytest.mark.parametrize("it", [50000, 100001])
 def test_fused_step_option_routes_train_step_through_the_fused_engine(golden, syncnet, dev, it):
     """Trainer(precision="bf16", fused_step=True).train_step(frame) == Trainer(precision="bf16").train_steps([frame]): the same

@@ -99,6 +99,78 @@ def test_config4_frame_indices_near_40000(sd, dev):
     close(m.rgb_forward(rows, time_pts=torch.tensor([39999])), out[9].reshape(-1, 3).cpu())
 
 
+@pytest.fixture(scope="module")
+def one_rank_rccl(dev):
+    import os
+    import socket
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(dev)
+    created = not dist.is_initialized()
+    if created:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    yield dev
+    if created:
+        dist.destroy_process_group()
+
+
+def test_config4_rank_blocks_at_full_size_from_audio_npy_on_disk(sd, one_rank_rccl, tmp_path):
+    """BASELINE config 4 as far as ONE GPU can take it: the clip's wire format -- a 40 000-window float64 `audio.npy`
+    (deepspeech_features.py:65-75; read and cast as someones_lip_dataset.py:246 does) -- goes to disk, comes back through
+    `speech2lip_amd.data` (the `--use_new_audio` split, someones_lip_dataset.py:156-161), and the 5 000-frame blocks that rank 0 and
+    rank 7 of an 8-GPU job own (sharded.shard_range) are rendered through the product entry `sharded.render_clip_sharded` on a
+    one-rank RCCL group: determinism, sub-block bit equality across the tile-shape boundary (5 000 = 416 x 12 + 8), the oracle on
+    sampled frames including index 39 999, and the 8-bit gather.  What is left untested of config 4 is the N > 1 collective itself."""
+    import os
+    from speech2lip_amd import sharded
+    from tools.benchlib import write_synthetic_dataset
+    dev = one_rank_rccl
+    h = w = 96
+    N, G = 40_000, 8
+    root = str(tmp_path / "may_face_crop_lip")
+    write_synthetic_dataset(root, 3, FH=160, FW=176, lh=h, lw=w, x0=40, y0=30, train=False, workers=2)
+    wire = W.synthetic_audio(N, seed=1)
+    assert wire.dtype == np.float64 and wire.shape == (N, 16, 29)
+    assert not wire[0, :4].any() and not wire[-1, -4:].any() and wire[N // 2].all()      # the clip-end zero padding of the windowing
+    np.save(os.path.join(root, "audio_test", "audio.npy"), wire)
+    assert os.path.getsize(os.path.join(root, "audio_test", "audio.npy")) >= N * 16 * 29 * 8
+    ds = s2l.SomeonesLipClip(root, "test", s2l.may_config(h, w, data_path=root))
+    assert len(ds) == N and ds.aud_features.dtype == np.float64 and (ds.lip_h, ds.lip_w) == (h, w)
+    audio = T(ds.aud_features.astype(np.float32))                      # HOST tensor: 74 MB, every rank holds the whole clip's windows
+    idx = torch.arange(N)
+    m = make_model(dev, h, w)
+    first7 = None
+    for r in (0, G - 1):
+        first, count, per = sharded.shard_range(N, r, G)
+        assert (first, count, per) == (r * 5000, 5000, 5000)
+        a_r, i_r = audio[first:first + count], idx[first:first + count]
+        block = sharded.render_clip_sharded(m, a_r, i_r, h, w, force_collective=True)
+        again = sharded.render_clip_sharded(m, a_r, i_r, h, w, force_collective=True, n_chunks=4, quantum=48)
+        torch.cuda.synchronize()
+        assert block.shape == (count, h, w, 3) and block.dtype == torch.float32
+        assert torch.equal(block, again)                                # deterministic, and chunked gathers land in frame order
+        # sub-blocks: other launch sizes, other tile shapes (12-frame tiles | the 8-frame tail | single frames), same bits
+        for lo, hi in ((0, 12), (4984, 5000), (4992, 5000), (4999, 5000), (2500, 2600), (1234, 1235)):
+            sub = m.render_clip(a_r[lo:hi].to(dev), i_r[lo:hi].to(dev), h, w)
+            assert torch.equal(sub, block[lo:hi]), (r, lo, hi)
+        u8 = sharded.render_clip_sharded(m, a_r, i_r, h, w, gather="u8", force_collective=True)
+        assert u8.dtype == torch.uint8 and torch.equal(u8, s2l.to8b(block))
+        with torch.no_grad():
+            for k in ((0, 7, 2499) if r == 0 else (0, 4991, 4999)):
+                ref = O.render_clip(sd, a_r[k:k + 1], [int(i_r[k])], h, w)[0]
+                close(block[k], ref)
+                assert O.psnr(block[k].cpu(), ref) >= 90.0
+        if r == G - 1:
+            assert int(i_r[-1]) == 39_999
+            first7 = block[:4].clone()
+        del block, again, u8
+    # the two blocks are different frames of one clip: same audio seed, so only a wrong offset could make them equal
+    assert not torch.equal(first7, m.render_clip(audio[:4].to(dev), idx[:4].to(dev), h, w))
+
+
 def _config3_inputs(dev, F, seed=0):
     h = w = 128
     FH = FW = 500

@@ -174,7 +174,8 @@ def test_bench_n_ranks_bit_check(gather):
     assert abs(line["value"] - 480 * n * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) <= 0.01 * line["value"]
 
 
-@pytest.mark.parametrize("n,extra", [(2, ()), (3, ("--gather", "u8")), (2, ("--chunks", "3", "--reserve-cus", "8"))], ids=["2-auto", "3-u8-auto", "2-flags"])
+@pytest.mark.parametrize("n,extra", [(2, ()), (3, ("--gather", "u8")), (2, ("--chunks", "3", "--reserve-cus", "8")), (8, ())],
+                         ids=["2-auto", "3-u8-auto", "2-flags", "8-auto"])
 def test_bench_multi_rank_control_flow_on_one_gpu(n, extra):
     """The WHOLE N > 1 path of bench.py with N real ranks -- schedule selection timed during warm-up (max over ranks), per-chunk
     gathers, barriers, rank 0's re-render of the last rank's block, the ragged clip through sharded.render_clip_sharded (N % G != 0)
@@ -192,3 +193,5 @@ def test_bench_multi_rank_control_flow_on_one_gpu(n, extra):
         assert mg["schedule"] == min(mg["schedules_ms_per_step"], key=mg["schedules_ms_per_step"].get)
     assert mg["gather_bytes_per_rank"] == 96 * H * W_ * 3 * (1 if "u8" in extra else 4)
     assert line["config"]["frames_per_gpu"] == 96 and line["parity"]["psnr_db_vs_cpu"] >= 90.0
+    one = mg["one_gpu_same_frames_per_step"]      # the 1-GPU reference at THIS step size (the driver's N = 1 run uses 1000-frame steps)
+    assert one["frames_per_step"] == 96 and one["frames_per_s"] > 0 and one["ms_per_step"] > 0

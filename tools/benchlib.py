@@ -97,6 +97,44 @@ def bench_render_split(dev, frames=1000, h=96, w=96):
     return res
 
 
+def bench_config4_rank_block(dev, per_rank=5000, n_total=40_000, world=8):
+    """BASELINE config 4's per-rank workload on ONE GPU from its wire format: a 40 000-window float64 `audio.npy` written to disk
+    (deepspeech_features.py:65-75), read back and cast (someones_lip_dataset.py:246), the 5 000-frame block of the LAST rank of an
+    8-GPU job (frame indices 35 000 ... 39 999) uploaded and rendered at 96x96 in one launch.  `frames_per_s` is the one-GPU rate
+    at config 4's step size (the headline's steps are config 2's 1 000 frames): the denominator of a weak-scaling efficiency."""
+    import shutil
+    import tempfile
+    from speech2lip_amd import sharded
+    h = w = 96
+    tmp = tempfile.mkdtemp(prefix="s2l_c4_")
+    try:
+        path = os.path.join(tmp, "audio.npy")
+        t0 = time.perf_counter()
+        np.save(path, W.synthetic_audio(n_total, seed=1))
+        t_write = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        wire = np.load(path)
+        first, count, _ = sharded.shard_range(n_total, world - 1, world)
+        audio = torch.from_numpy(wire[first:first + count].astype(np.float32)).pin_memory().to(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        t_read = time.perf_counter() - t0
+        nbytes = os.path.getsize(path)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    m = make_model(dev, h, w)
+    idx = torch.arange(first, first + count, device=dev)
+    out = torch.empty(count, h, w, 3, device=dev)
+    m.render_clip(audio, idx, h, w, out=out)
+    ms = _median_ms(lambda: m.render_clip(audio, idx, h, w, out=out), reps=5, inner=1)
+    u8 = s2l.to8b(out)
+    ms_q = _median_ms(lambda: s2l.to8b(out), reps=5, inner=1)
+    assert torch.equal(m.render_clip(audio[-8:], idx[-8:], h, w), out[-8:])       # the tail tile: the same bits as its own call
+    return {"frames_per_step": count, "first_frame_index": first, "ms_per_step": round(ms, 3), "frames_per_s": round(count / ms * 1e3, 1),
+            "tflops": round(2 * 459_520 * h * w * count / ms / 1e9, 1), "to8b_ms": round(ms_q, 3), "audio_npy_mb": round(nbytes / 1e6, 1),
+            "audio_npy_write_s": round(t_write, 2), "audio_npy_read_cast_upload_s": round(t_read, 3),
+            "gather_mb_per_rank": {"f32": round(out.numel() * 4 / 1e6, 1), "u8": round(u8.numel() / 1e6, 1)}}
+
+
 def bench_small_clips(dev):
     """The reference's own operating point: ONE frame per call (inference.py:129 DataLoader batch 1, :140-159), and BASELINE
     config 1's 16-frame clip.  Per size: `render_clip` at F = 1 and F = 16 (per-call latency through the host wrapper as a caller
@@ -593,18 +631,15 @@ def bench_infer_clip(dev, n_total=640, batch=50):
             s2l.write_frames(recon, clip.names, out_dir)
 
     def piped(precision, mode="process"):
-        st, wr = s2l.ClipStreamer(ds, dev, batch, mode=mode), s2l.FrameWriter(out_dir)
-        for clip in st:
-            lip, recon, merged = s2l.render_clip_frames(m, clip, precision=precision)
-            wr.submit(s2l.to8b(recon), clip.names)
-        wr.close()
-        st.close()
+        with s2l.ClipStreamer(ds, dev, batch, mode=mode) as st, s2l.FrameWriter(out_dir) as wr:
+            for clip in st:
+                lip, recon, merged = s2l.render_clip_frames(m, clip, precision=precision)
+                wr.submit(s2l.to8b(recon), clip.names)
     # warm-up on a short prefix (kernel code objects, pinned allocations), then one timed pass each
     t0 = time.perf_counter()
-    warm = s2l.ClipStreamer(ds, dev, 8, 0, 16, mode="process")      # starts the decode worker processes (once per process; ~1-3 s on a cold box)
-    for _ in warm:
-        pass
-    warm.close()
+    with s2l.ClipStreamer(ds, dev, 8, 0, 16, mode="process") as warm:      # starts the decode worker processes (once per process; ~1-3 s on a cold box)
+        for _ in warm:
+            pass
     res["decode_workers_start_s"] = round(time.perf_counter() - t0, 2)
     clip0 = ds.load(dev, 0, min(batch, n))
     s2l.render_clip_frames(m, clip0)
@@ -706,25 +741,22 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         entry["train_step_as_written"] = run(tr, it0, gen, 1)
         # (2) prefetching loader + device noise
         tr = build(late, "device")
-        pf = s2l.FramePrefetcher(ds, order[:3])
-        run(tr, it0, pf, 1)
-        pf = s2l.FramePrefetcher(ds, order)
-        entry["train_step_prefetch_device_noise"] = run(tr, it0, pf, 1)
-        pf.close()
+        with s2l.FramePrefetcher(ds, order[:3]) as pf:
+            run(tr, it0, pf, 1)
+        with s2l.FramePrefetcher(ds, order) as pf:
+            entry["train_step_prefetch_device_noise"] = run(tr, it0, pf, 1)
         # (2b) the same loop, `Trainer(fused_step=True)`: train_step sends its one frame through the fused engine
         tr = build(late, "device", fused_step=True)
-        pf = s2l.FramePrefetcher(ds, order[:3])
-        run(tr, it0, pf, 1)
-        pf = s2l.FramePrefetcher(ds, order)
-        entry["train_step_fused_prefetch_device_noise"] = run(tr, it0, pf, 1)
-        pf.close()
+        with s2l.FramePrefetcher(ds, order[:3]) as pf:
+            run(tr, it0, pf, 1)
+        with s2l.FramePrefetcher(ds, order) as pf:
+            entry["train_step_fused_prefetch_device_noise"] = run(tr, it0, pf, 1)
         # (3) K frames per optimisation step through the fused engine
         K = 8
-        pf = s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False)
-        run(tr, it0, pf, K)
-        pf = s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False)
-        entry["train_steps_K8"] = run(tr, it0, pf, K)
-        pf.close()
+        with s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False) as pf:
+            run(tr, it0, pf, K)
+        with s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False) as pf:
+            entry["train_steps_K8"] = run(tr, it0, pf, K)
         res[phase] = entry
         del tr
         torch.cuda.empty_cache()

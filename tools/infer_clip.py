@@ -27,6 +27,19 @@ import speech2lip_amd as s2l
 from speech2lip_amd import sharded
 
 
+def _render_batches(args, s2l, model, batches, writer, blocks, post, rank, world, n, out_dir):
+    for clip in batches:
+        lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=post, precision="split" if args.fast else "fp32")
+        frames = recon if recon is not None else (merged if merged is not None else lip)
+        if args.gather and world > 1:
+            blocks.append(s2l.to8b(frames))
+        elif writer is not None:
+            writer.submit(s2l.to8b(frames), clip.names)
+        else:
+            s2l.write_frames(frames, clip.names, out_dir)
+        print(f"[rank {rank}] frames {clip.names[0]}..{clip.names[-1]} of {n} -> {out_dir}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True)
@@ -67,24 +80,18 @@ def main():
     else:
         first0, count, _ = sharded.shard_range(n, rank, world)               # this rank's contiguous block of the clip
         post = bool(cfg["model"].get("use_post_fusion", True))
-        blocks, writer = [], None
+        blocks, writer, streamer = [], None, None
         if args.serial:
             batches = (ds.load(dev, first, min(args.batch, first0 + count - first)) for first in range(first0, first0 + count, args.batch))
         else:     # decode + H2D of batch k+1 and encode + write of batch k-1 run beside the GPU work of batch k
-            batches = s2l.ClipStreamer(ds, dev, args.batch, first0, count, workers=args.workers)
+            batches = streamer = s2l.ClipStreamer(ds, dev, args.batch, first0, count, workers=args.workers)
             writer = s2l.FrameWriter(out_dir, workers=args.workers)
-        for clip in batches:
-            lip, recon, merged = s2l.render_clip_frames(model, clip, use_post_fusion=post, precision="split" if args.fast else "fp32")
-            frames = recon if recon is not None else (merged if merged is not None else lip)
-            if args.gather and world > 1:
-                blocks.append(s2l.to8b(frames))
-            elif writer is not None:
-                writer.submit(s2l.to8b(frames), clip.names)
-            else:
-                s2l.write_frames(frames, clip.names, out_dir)
-            print(f"[rank {rank}] frames {clip.names[0]}..{clip.names[-1]} of {n} -> {out_dir}", flush=True)
-        if writer is not None:
-            writer.close()
+        import contextlib
+        with contextlib.ExitStack() as owned:      # the streamer's shared-memory blocks / the writer's threads go whatever happens below
+            for res in (streamer, writer):
+                if res is not None:
+                    owned.enter_context(res)
+            _render_batches(args, s2l, model, batches, writer, blocks, post, rank, world, n, out_dir)
         if args.gather and world > 1:
             # an empty shard still takes part in the collective: its block has the frame size the OTHER ranks gather (the face frame
             # when the composite / U-Net ran, the lip crop otherwise)
