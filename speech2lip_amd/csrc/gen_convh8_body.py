@@ -23,7 +23,7 @@ NI = 5                                                          # halo DMA instr
 CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
 WITH_RELU = False                                               # main() generates both: convh8_body.inc (linear) and convh8r_body.inc (max(0, .))
 PFX = "S2L8"                                                    # label prefix (two bodies in one translation unit)
-EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier, 4096 / 8192 PRICING of BatchNorm's normalise + ReLU inside the consuming convolution (norm_items)
+EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier, 4096 / 8192 PRICING of BatchNorm's normalise + ReLU inside the consuming convolution (norm_items), 16384 the halo tile read as one contiguous 40-KiB block (access-pattern pricing)
 
 # ---- registers
 A_ACC = 0
@@ -580,7 +580,8 @@ class Body:
                 self.wait_lds(("R", t, 1, 1, NB - 1))
             self.tap_mfmas(os_, sprinkle)
         self.wait_all_lds()
-        e("s_waitcnt vmcnt(0)")
+        if not EXP & 32768:      # (pricing, results racy: nobody waits for the chunk's requests -- what is left of their cost is bandwidth / power, not latency)
+            e("s_waitcnt vmcnt(0)")
         if not EXP & 1024:
             e("s_barrier")
         self.advance_staging()
@@ -723,6 +724,15 @@ def emit_prologue(b, with_gate=True):
         e(f"v_mov_b32 v{t}, {1 << i}")
         e(f"v_cndmask_b32 v{t}, 0, v{t}, vcc")
         e(f"v_or_b32 v{V_INR}, v{V_INR}, v{t}")
+    if EXP & 16384:      # pricing (results wrong): the halo tile's 40 KiB as ONE contiguous block at the tile's origin instead of 34 strided rows
+        for i in range(NI):
+            e(f"s_mul_i32 {s('T0')}, {s('WAVE')}, {NI * 1024}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {1024 * i}")
+            e(f"s_add_u32 {s('T1')}, {s('W')}, 1")                      # (the tile's halo origin may lie (W + 1) pixels before the tensor)
+            e(f"s_lshl_b32 {s('T1')}, {s('T1')}, 6")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
+            e(f"v_lshlrev_b32 v{V_VOFF + i}, 4, v{V_LANE}")
+            e(f"v_add_u32 v{V_VOFF + i}, {s('T0')}, v{V_VOFF + i}")
     e(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
     e(f"s_lshl_b32 {s('HW64')}, {s('HW')}, 6")                          # bytes of one 32-channel plane (< 2^31: the launcher checks)
     e(f"s_lshl_b32 {s('RS')}, {s('W')}, 6")                             # bytes between rows of a plane

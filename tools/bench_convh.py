@@ -32,8 +32,9 @@ for tr in (0, 1):
         h = S >> LVL[l]
         cat = l in (6, 8) and not tr
         CA, CB = (cin // 2, cin // 2) if cat else (cin, 0)
-        a = torch.randn(F, h, h, CA, device=dev).to(torch.bfloat16)
-        b = torch.randn(F, h, h, CB, device=dev).to(torch.bfloat16) if CB else None
+        # (one frame of slack behind the tensors: the access-pattern pricing builds, S2L_CH_EXP & 16384, read up to 40 KiB past a tile's origin)
+        a = torch.randn(F + 1, h, h, CA, device=dev).to(torch.bfloat16)[:F]
+        b = torch.randn(F + 1, h, h, CB, device=dev).to(torch.bfloat16)[:F] if CB else None
         gate = tr and l in (1, 3, 5, 7, 9) and not NOGATE
         gt = torch.randn(F, h, h, cout, device=dev).clamp_min(0).to(torch.bfloat16) if gate else None
         out = torch.empty(F, h, h, cout, dtype=torch.int16, device=dev)

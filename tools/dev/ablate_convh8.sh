@@ -17,6 +17,6 @@ if [ "$1" = build ]; then
 else
   for v in $VARIANTS; do
     printf "EXP %5s: " $v
-    S2L_LIB=$R/ab/ch8_$v.so python $R/tools/bench_convh.py 20 500 0 --nogate 2>/dev/null | tail -1
+    S2L_LIB=$R/ab/ch8_$v.so python $R/tools/bench_convh.py 20 500 0 --nogate 2>/dev/null | awk '{ if ($1=="total") print; else printf "%s%s ", $1, ($2=="fwd"?"f":"d") ":" $(NF-3) }'
   done
 fi
