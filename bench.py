@@ -54,7 +54,8 @@ def render_kernel_digest():
 def measured_traffic(frames_per_launch):
     """HBM bytes per frame of the render kernel from the latest PMC passes (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3
     runs): tools/summarize_profiles.py writes profiles/render_traffic.json next to the profile summary it was computed from,
-    with the digest of the kernel text and the launch size it was measured on.  The PMC figure is NOT collected in this run
+    with the digest of the kernel text and the launch size it was measured on (and the figures of earlier profiles of the same kernel text:
+    the third return value is their [min, max] per launch -- the counter's spread, +- 20 % between two profiles).  The PMC figure is NOT collected in this run
     (counters need rocprofv3 around the process); it is reported only when it describes this build's kernel at this launch
     size -- otherwise traffic is null and `traffic_source` says why."""
     try:
@@ -62,13 +63,15 @@ def measured_traffic(frames_per_launch):
             t = json.load(f)
         per_frame = t["hbm_bytes_per_dispatch"] / t["frames_per_dispatch"]
     except (OSError, KeyError, ValueError):
-        return None, "no profiles/render_traffic.json"
+        return None, "no profiles/render_traffic.json", None
     now = render_kernel_digest()
     if t.get("kernel_text_sha256_16") not in (None, now):
-        return None, f"stale: {t['profile']} was taken on kernel text {t.get('kernel_text_sha256_16')}, this build is {now}"
+        return None, f"stale: {t['profile']} was taken on kernel text {t.get('kernel_text_sha256_16')}, this build is {now}", None
     if int(t["frames_per_dispatch"]) != int(round(frames_per_launch)):
-        return None, f"stale: {t['profile']} measured {t['frames_per_dispatch']} frames per launch, this run launches {frames_per_launch:g}"
-    return per_frame, t["profile"]
+        return None, f"stale: {t['profile']} measured {t['frames_per_dispatch']} frames per launch, this run launches {frames_per_launch:g}", None
+    # the counter is noisy (the same kernel text measured 2.03e8 and 2.44e8 bytes per launch in two profiles): quote the range of the figures on record
+    seen = [t["hbm_bytes_per_dispatch"]] + [p["hbm_bytes_per_dispatch"] for p in t.get("previous", [])]
+    return per_frame, t["profile"], [int(min(seen)), int(max(seen))]
 
 
 def cpu_baseline(frames_budget_s: float = 12.0):
@@ -142,6 +145,89 @@ def eager_torch_gpu(dev, budget_s: float = 6.0):
         ref = O.render_frame_as_shipped(O.to_sd(W.make_state_dict(0, "he")), win[0].cpu(), 0, H, W_)
         res["max_abs_diff_vs_cpu_oracle"] = float((O.render_frame_as_shipped(sd, win[0], 0, H, W_).cpu() - ref).abs().max())
     res.update(unit="frames/s", what="oracle (eager PyTorch ops) on cuda:0, 96x96, fp32, device->host copy of every frame included; context only")
+    return res
+
+
+def eager_torch_gpu_train(dev, budget_s: float = 10.0):
+    """CONTEXT, never `vs_baseline`: the reference's TRAINING step as eager PyTorch on cuda:0 of the same MI355X -- what the reference
+    runs (train.py:199 -> Trainer.train_step -> train_stage1, training.py:347-574: autograd over ATen / MIOpen / rocBLAS kernels), here
+    through the oracle's restatement of that step (oracle.stage_one_losses: one frame per iteration at 96x96 lip / 500x500 face, MSE on
+    lip and face, frozen or training post-fusion U-Net, the 5-frame sync window after it > 100000; no LPIPS -- the AlexNet weights are
+    not in the image) + loss.backward() + torch.optim.Adam.  Beside it the MLP-only step of config 5 (4-tap ensemble + MSE + backward
+    per frame).  NB the oracle's composite is a gather-based restatement of F.grid_sample, not the ATen kernel: its share is reported.
+    Compare with extra.train_bf16* (per sample = ms_per_step / frames) and extra.dropin_trainer (ms per frame)."""
+    from oracle import s2l_oracle as O
+    from speech2lip_amd import weights as W
+    from tools import benchlib
+    h = w = 96
+    sb = benchlib.sync_batch(dev, 1)
+    T = sb["audio_window"].shape[1]
+    leaf = lambda v: torch.from_numpy(v).to(dev).requires_grad_(True)
+    sd = {k: leaf(v) for k, v in W.make_state_dict(0, "he").items()}
+    usd_frozen = {k: v.to(dev) for k, v in O.to_sd(W.make_unet_state_dict(0)).items()}
+    usd_train = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "num_batches" not in k else v.clone())
+                 for k, v in usd_frozen.items()}
+    ssd = {k: v.to(dev) for k, v in O.to_sd(W.make_syncnet_state_dict(0)).items()}
+    g = torch.Generator(device=dev).manual_seed(3)
+    data = {"audio": torch.from_numpy(W.synthetic_audio(1, 1).astype(np.float32)).to(dev), "rgb": torch.rand(1, h, w, 3, device=dev, generator=g),
+            "index": 7, "total_frame": 100000, "rgb_face_zero": sb["rgb_face_canonical"], "rgb_face_ori": sb["rgb_face_gt"][:1],
+            "mask_lip_canonical": sb["mask_lip_canonical"], "lip_lefttop_x": sb["lip_lefttop_x"], "lip_lefttop_y": sb["lip_lefttop_y"],
+            "coord": sb["coord_window"][0, :1], "audio_window": sb["audio_window"][:1], "coord_window": sb["coord_window"][:1],
+            "canonical_face_bbox": [sb["canonical_face_bbox"]], "mel": sb["mel"][:1], "rgb_window_neg": sb["rgb_window_neg"][:1]}
+    eps = [0.5] * (1 + T)
+    res = {}
+
+    def timed(fn, cap):
+        for _ in range(2):
+            fn()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while n < cap and time.perf_counter() - t0 < budget_s / 3:
+            fn()
+            n += 1
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, n
+
+    # (1) after it > 100000: frozen U-Net in train-mode BatchNorm (what train_step leaves it in, G16), sync loss on
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+
+    def late():
+        opt.zero_grad(set_to_none=True)
+        out = O.stage_one_losses(sd, usd_frozen, ssd, W.SYNCNET_FACE, W.SYNCNET_AUDIO, data, eps, None, h, w, unet_training=True, with_sync=True)
+        out["loss"].backward()
+        opt.step()
+    ms, n = timed(late, 40)
+    res["stage1_iteration_it_gt_100000_ms_per_frame"] = round(ms, 2)
+    # (2) before: the U-Net trains too, no sync term
+    opt2 = torch.optim.Adam(list(sd.values()) + [v for v in usd_train.values() if v.requires_grad], lr=1e-4)
+
+    def early():
+        opt2.zero_grad(set_to_none=True)
+        out = O.stage_one_losses(sd, usd_train, None, None, None, data, eps[:1], None, h, w, unet_training=True, with_sync=False)
+        out["loss"].backward()
+        opt2.step()
+    ms, n = timed(early, 40)
+    res["stage1_iteration_it_le_100000_ms_per_frame"] = round(ms, 2)
+    # (3) config 5's MLP-only step, per frame: 4-tap ensemble + MSE + backward + Adam
+    coords = O.get_coords(w, h, device=dev)
+    target = data["rgb"].reshape(-1, 3)
+
+    def mlp():
+        opt.zero_grad(set_to_none=True)
+        pred = O.predict_lip_image(sd, coords, data["audio"][0], 7, h, w, 0.5)
+        O.mse_loss(pred, target).backward()
+        opt.step()
+    ms, n = timed(mlp, 100)
+    res["mlp_only_step_ms_per_frame"] = round(ms, 3)
+    # the composite's share of (1): the oracle restates grid_sample with gathers (the reference calls the ATen kernel)
+    with torch.no_grad():
+        lip = torch.rand(1, h, w, 3, device=dev)
+        ms_c, _ = timed(lambda: O.composite(lip, data["rgb_face_zero"], data["rgb_face_ori"], data["mask_lip_canonical"], int(data["lip_lefttop_x"]),
+                                            int(data["lip_lefttop_y"]), data["coord"]), 100)
+    res["composite_forward_ms_per_frame"] = round(ms_c, 3)
+    res.update(what="oracle's stage-1 step (eager PyTorch autograd) on cuda:0, one 96x96 / 500x500 frame per iteration, fp32, Adam; context only")
     return res
 
 
@@ -222,7 +308,8 @@ def extra_measurements(dev):
                      ("train_fp32", lambda: benchlib.bench_train(dev, 64, "fp32", steps=3)),
                      ("dropin_trainer", lambda: benchlib.bench_dropin_trainer(dev)),
                      ("infer_clip_end_to_end", lambda: benchlib.bench_infer_clip(dev)),
-                     ("eager_torch_gpu", lambda: eager_torch_gpu(dev))):
+                     ("eager_torch_gpu", lambda: eager_torch_gpu(dev)),
+                     ("eager_torch_gpu_train", lambda: eager_torch_gpu_train(dev))):
         try:
             torch.cuda.reset_peak_memory_stats()      # every leg's peak_mem_gb is its own
             r = fn()
@@ -471,7 +558,7 @@ def main():
         with torch.no_grad():
             ref = O.render_clip(O.to_sd(W.make_state_dict(0, "he")), audio[:1].cpu(), [int(gids[0])], H, W_)[0]
         got = local[0].cpu()
-        traffic_per_frame, traffic_src = measured_traffic(frames_per_launch)
+        traffic_per_frame, traffic_src, traffic_range = measured_traffic(frames_per_launch)
         line = {
             "metric": "rendered lip frames/sec (96x96)", "value": round(F * world * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -487,7 +574,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK, 4),
                          # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), see profiles/
                          "traffic": round(traffic_per_frame * frames_per_launch) if traffic_per_frame else None,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_range_of_profiles": traffic_range,
                          "kernel": "s2l::render_tiles_kernel (s2l_render_lip)", "kernel_ms": round(k_avg_s * 1e3, 4),
                          "frames_per_launch": frames_per_launch, "algorithmic_gflop_per_frame": round(FLOPS_PER_FRAME / 1e9, 4)},
             "parity": {"rmse_vs_cpu": float(f"{O.rmse(got, ref):.3e}"), "psnr_db_vs_cpu": round(O.psnr(got, ref), 1)},

@@ -228,7 +228,7 @@ def predict_lip_image(sd: SD, coords: torch.Tensor, window: torch.Tensor, index:
     feat = audio_encode(sd, window.unsqueeze(0))[0]
     rx, ry = 0.5 / width, 0.5 / height
     eps = torch.tensor(ry, dtype=torch.float32) * torch.tensor(eps_u01, dtype=torch.float32) / 2.0
-    eps = eps.to(dt)
+    eps = eps.to(device=coords.device, dtype=dt)
     preds, areas = [], []
     for vx in (-1, 1):
         for vy in (-1, 1):
@@ -469,9 +469,9 @@ def sync_contrastive_loss(sd: SD, mel, g_rgb_pos, g_rgb_neg, blocks_face, blocks
     negative window.  pos_margins: see syncnet_encoder (the face encoder on the generated window, the pass gradients flow through)."""
     B = mel.shape[0]
     a, v = syncnet_forward(sd, mel, sync_window(g_rgb_pos, syncnet_T), blocks_face, blocks_audio, face_margins=pos_margins)
-    pos = cosine_loss(a, v, torch.ones(B, 1, dtype=mel.dtype))
+    pos = cosine_loss(a, v, torch.ones(B, 1, dtype=mel.dtype, device=mel.device))
     a, v = syncnet_forward(sd, mel, sync_window(g_rgb_neg, syncnet_T), blocks_face, blocks_audio)
-    neg = cosine_loss(a, v, torch.zeros(B, 1, dtype=mel.dtype))
+    neg = cosine_loss(a, v, torch.zeros(B, 1, dtype=mel.dtype, device=mel.device))
     return pos + neg
 
 
@@ -533,7 +533,7 @@ def stage_one_losses(sd: SD, unet_sd: SD, sync_sd: SD, blocks_face, blocks_audio
     training.py:150 undoes train.py's post_fusion_unet.eval()): every one-frame U-Net call -- the main frame first, then
     the T window frames -- uses its own batch statistics; `new_stats` receives the running statistics after all 1 + T calls.
     Differentiable w.r.t. `sd` and `unet_sd` (build them with requires_grad tensors)."""
-    coords = get_coords(width, height)
+    coords = get_coords(width, height, device=data["audio"].device)
     idx = int(data["index"])
     x0, y0 = int(data["lip_lefttop_x"]), int(data["lip_lefttop_y"])
     pred = predict_lip_image(sd, coords, data["audio"][0], idx, height, width, eps_u01[0])

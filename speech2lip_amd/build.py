@@ -77,7 +77,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         import gen_convh8_body
         gen_convh8_body.main(objdir)           # convh8_body.inc: its eight-wave form (two waves per SIMD)
         import gen_convhx_body
-        gen_convhx_body.main(objdir)           # convhx_body.inc: the eight waves in alternating roles (the default)
+        gen_convhx_body.main(objdir)           # convhx_body.inc: the eight waves in alternating roles (reference library only; the default is convh8)
         import gen_conv_body               # ... and so are the U-Net's fp32 3x3 convolutions (unet.hip)
         gen_conv_body.main(objdir)
         import gen_fwd16_body              # ... and the bf16 training forward (train_bf16.hip)

@@ -594,7 +594,7 @@ def test_bench_line_stays_inside_the_drivers_tail():
     assert "config" not in small["leg0"] and "loss_last" not in small["leg0"] and small["leg0"]["error"].startswith("RuntimeError")
     legend = open(os.path.join(ROOT, "docs", "BENCH_LEGEND.md")).read()
     for name in ("composite", "render_split", "small_clips", "config4_rank_block", "config3", "unet_fp32", "train_bf16", "dropin_trainer", "infer_clip_end_to_end",
-                 "eager_torch_gpu", "stage1_early_iteration_bf16"):
+                 "eager_torch_gpu", "eager_torch_gpu_train", "stage1_early_iteration_bf16"):
         assert f"`{name}" in legend, name
 
 

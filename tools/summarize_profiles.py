@@ -36,12 +36,23 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
     out.append("HBM traffic per dispatch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE = %.4g bytes\n" % traffic)
-    # the figure bench.py's roofline.traffic carries: tracked next to the profile it comes from, read by bench.py
+    # the figure bench.py's roofline.traffic carries: tracked next to the profile it comes from, read by bench.py.  Earlier PMC figures of the
+    # SAME kernel text stay in `previous` (the counter moved 2.03e8 -> 2.44e8 between two profiles of one build: bench.py quotes the range)
+    digest = __import__("hashlib").sha256(open("speech2lip_amd/build/render_body.inc", "rb").read()).hexdigest()[:16]
+    previous = []
+    try:
+        old = json.load(open("profiles/render_traffic.json"))
+        if old.get("kernel_text_sha256_16") == digest and old.get("profile") != f"profiles/{tag}_rocprofv3_summary.txt":
+            previous = ([{"profile": old["profile"], "hbm_bytes_per_dispatch": old["hbm_bytes_per_dispatch"]}] + list(old.get("previous", [])))[:4]
+        elif old.get("profile") == f"profiles/{tag}_rocprofv3_summary.txt":
+            previous = list(old.get("previous", []))
+    except (OSError, ValueError, KeyError):
+        pass
     json.dump({"profile": f"profiles/{tag}_rocprofv3_summary.txt", "kernel": "s2l::render_tiles_kernel",
                "frames_per_dispatch": 1000, "height": 96, "width": 96, "render_shape": "long (3 x (1 x 12)), auto-picked for 1000 frames",
-               "kernel_text_sha256_16": __import__("hashlib").sha256(open("speech2lip_amd/build/render_body.inc", "rb").read()).hexdigest()[:16],
+               "kernel_text_sha256_16": digest,
                "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
-               "hbm_bytes_per_dispatch": round(traffic), "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024"},
+               "hbm_bytes_per_dispatch": round(traffic), "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024", "previous": previous},
               open("profiles/render_traffic.json", "w"), indent=1)
 p = f"{src}/render_split_line.json"
 if os.path.exists(p):
