@@ -223,6 +223,17 @@ int s2l_audio_backward(const float* packed, const float* windows, const float* d
 int s2l_mse(const float* pred, const float* target, float weight, float* dpred, float* work,
             float* loss, int64_t n_elems, s2l_stream_t stream);
 
+/* optimizer.step() of the reference's training loop (train.py:173-199 builds torch.optim.Adam; training.py:559-574 steps it after
+ * check_weights) for EVERY tensor of a parameter group in ONE launch: torch's _single_tensor_adam arithmetic, operation for operation in
+ * fp32 (no amsgrad, no maximize).  table: n_tensors records of four device pointers {param, grad, exp_avg, exp_avg_sq} (32 bytes each, fp32
+ * contiguous tensors); counts[t]: elements of tensor t; blocks: n_blocks records {int32 tensor, int32 first element}, one per workgroup,
+ * covering tensor t in pieces of s2l_adam_chunk() elements; the hyper-parameters are doubles, as torch holds them; step >= 1: the step number AFTER the increment (bias corrections 1 - beta^step).
+ * nan_flags: NULL or n_tensors ints, set to 1 (never cleared) when the parameter as read, i.e. BEFORE this update, holds a NaN -- the
+ * reference's check_weights (src/common.py:56-64, called at training.py:572) folded into the pass. */
+int64_t s2l_adam_chunk(void);
+int s2l_adam_step(const void* table, const void* blocks, const int64_t* counts, int64_t n_tensors, int64_t n_blocks, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, int* nan_flags, s2l_stream_t stream);
+
 /* Paste + head-pose warp composite, up to but not including the U-Net
  * (TalkingFace.post_fusion2_onlylip_light, tf_nerf.py:320-386):
  *   merged_c = mask * pad(lip) + (1-mask) * face_canon                        (:339-352)

@@ -10,7 +10,9 @@ from .unet import SimpleUnetLight
 from .syncnet import SyncLoss, SyncNet_color
 from .lpips import LPIPS
 from . import geometry
+from . import optim
+from .optim import FusedAdam
 
 __all__ = ["TalkingFace", "FrameGraph", "Embedder", "PositionalEncodingTime", "get_coords", "load_config", "may_config", "get_model", "get_trainer", "method_dict", "Trainer",
            "predict_lip_image", "LipTrainStep", "StageOneStep", "SyncChain", "training", "autograd",
-           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "from8b", "ClipStreamer", "FrameWriter", "FramePrefetcher", "SyncNet_color", "SyncLoss", "LPIPS", "geometry"]
+           "SimpleUnetLight", "SomeonesLipClip", "ClipTensors", "render_clip_frames", "write_frames", "to8b", "from8b", "ClipStreamer", "FrameWriter", "FramePrefetcher", "SyncNet_color", "SyncLoss", "LPIPS", "geometry", "optim", "FusedAdam"]

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p, POINTER
 
 from .build import LIB
 
@@ -142,6 +142,8 @@ EXPORTS = {
     "s2l_audio_grad_floats": (c_int64, []),
     "s2l_audio_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_mse": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_adam_chunk": (c_int64, []),
+    "s2l_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_double, c_double, c_double, c_double, c_int64, c_void_p, c_void_p]),
     "s2l_unet_packed_floats": (c_int64, []),
     "s2l_unet_work_floats": (c_int64, [c_int, c_int, c_int64]),
     "s2l_unet_pack": (c_int, [POINTER(c_void_p), c_float, c_void_p, c_void_p]),

@@ -364,6 +364,55 @@ extern "C" int s2l_mse(const float* pred, const float* target, float weight, flo
   return (int)hipGetLastError();
 }
 
+// ---- one launch of Adam over every tensor of a parameter group (train.py:173-199's optimizer.step(); torch/optim/adam.py _single_tensor_adam) ----
+// table: n_tensors records of {param, grad, exp_avg, exp_avg_sq} device pointers; blocks: one int2 per workgroup = {tensor, first element};
+// counts[t] = elements of tensor t.  The arithmetic is torch's, operation for operation in fp32 (built with -ffp-contract=off):
+//   g' = g + wd * p;  m = m + (g' - m) * (1 - b1)  [Tensor.lerp_];  v = v * b2 + ((1 - b2) * g') * g'  [mul_ + addcmul_];
+//   p = p + (-(lr / bc1)) * (m / (sqrt(v) / sqrt(bc2) + eps))  [addcdiv_]
+// nan_flags (optional, one int per tensor): set to 1 when the parameter AS READ holds a NaN -- check_weights (src/common.py:56-64), which
+// the reference calls right before optimizer.step() (training.py:572), folded into the pass that reads every parameter anyway.
+struct AdamRec { float* p; const float* g; float* m; float* v; };
+constexpr int kAdamChunk = 4096;      // elements per workgroup of 256 threads
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamRec* __restrict__ table, const int2* __restrict__ blocks,
+                                                        const int64_t* __restrict__ counts, float neg_step, float omb1, float b2, float omb2,
+                                                        float eps, float wd, float bc2_sqrt, int* __restrict__ nan_flags) {
+  const int2 blk = blocks[blockIdx.x];
+  const AdamRec r = table[blk.x];
+  const int64_t n = counts[blk.x];
+  bool bad = false;
+  for (int k = 0; k < kAdamChunk / 256; ++k) {
+    const int64_t i = (int64_t)blk.y + k * 256 + threadIdx.x;
+    if (i >= n) break;
+    const float p = r.p[i];
+    bad |= (p != p);
+    float g = r.g[i];
+    if (wd != 0.f) g = g + wd * p;
+    float m = r.m[i], v = r.v[i];
+    m = m + (g - m) * omb1;
+    v = v * b2 + (omb2 * g) * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    r.m[i] = m;
+    r.v[i] = v;
+    r.p[i] = p + neg_step * (m / denom);
+  }
+  if (nan_flags && bad) nan_flags[blk.x] = 1;      // (benign race: every writer stores the same value)
+}
+
+extern "C" int64_t s2l_adam_chunk(void) { return kAdamChunk; }
+
+extern "C" int s2l_adam_step(const void* table, const void* blocks, const int64_t* counts, int64_t n_tensors, int64_t n_blocks, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int64_t step, int* nan_flags, s2l_stream_t stream) {
+  if (n_tensors < 0 || n_blocks < 0 || n_blocks > 0x7fffffff || step < 1) return S2L_E_SIZE;
+  if (n_tensors == 0 || n_blocks == 0) return S2L_OK;
+  if (!table || !blocks || !counts) return S2L_E_NULL;
+  // the scalars as torch forms them: python doubles (1 - beta, 1 - beta ** step, -(lr / bc1), bc2 ** 0.5) that reach the kernels as floats
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const AdamRec*>(table), static_cast<const int2*>(blocks), counts, (float)(-(lr / bc1)), (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2), nan_flags);
+  return (int)hipGetLastError();
+}
+
 // out [S,c] = per-segment column sums of src [S*rows_per_segment, ld] (c <= 256 and a divisor of 256): the per-frame gradient
 // of the audio feature from dxa (frame b owns 4*HW consecutive rows).  work: S * 32 * c floats.  Fixed summation order.
 extern "C" int s2l_segment_colsums(const float* src, int ld, int c, int64_t rows_per_segment, int64_t n_segments, float* work,

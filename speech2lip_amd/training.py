@@ -435,8 +435,7 @@ class Trainer:
             loss["loss"] = loss["loss"] + loss_sync
         loss["loss"].backward()
         self._average_gradients_over_ranks()
-        nan_check = self._check_weights_launch()
-        self.optimizer.step()
+        nan_check = self._step_optimizer()
         self._check_weights_report(nan_check)      # (the step's only wait besides the values it returns)
         self._loss_to_host(loss)
         return loss["loss_rgb"], loss
@@ -447,34 +446,52 @@ class Trainer:
         `isnan().any()` round trip per tensor (~100 with the U-Net: milliseconds of an 8-ms iteration)."""
         self._check_weights_report(self._check_weights_launch())
 
-    def _check_weights_launch(self):
+    def _check_weights_launch(self, fused_optimizer=None):
         """The device half of `_check_weights`, where the reference calls it (before optimizer.step(), training.py:572): the norms, the
-        NaN flags and their copy to a pinned host buffer go into the stream; nothing waits."""
-        named = [(k, v) for k, v in state_tensors(self.model) if v.dtype.is_floating_point and v.numel()]
-        bad = torch.isnan(torch.stack(torch._foreach_norm([v for _, v in named])))
-        host = self.__dict__.get("_nan_flags")
-        if host is None or host.numel() != bad.numel():
-            host = self._nan_flags = torch.empty(bad.numel(), dtype=torch.bool, pin_memory=bad.is_cuda)
-        host.copy_(bad, non_blocking=True)
-        done = None
-        if bad.is_cuda:
-            done = torch.cuda.Event()
-            done.record()
-        return named, host, done
+        NaN flags and their copy to a pinned host buffer go into the stream; nothing waits.  With a `FusedAdam` the parameters it is about
+        to step are left to ITS pass (the kernel flags a parameter that holds a NaN as it reads it, i.e. at this very point of the step):
+        only the tensors it does not own -- buffers, frozen parameters -- take the norm scan."""
+        skip = fused_optimizer.covers() if fused_optimizer is not None else ()
+        every = [(k, v) for k, v in state_tensors(self.model) if v.dtype.is_floating_point and v.numel()]
+        named = [(k, v) for k, v in every if id(v) not in skip]
+        names = {id(v): k for k, v in every if id(v) in skip} if skip else {}
+        host = done = None
+        if named:
+            bad = torch.isnan(torch.stack(torch._foreach_norm([v for _, v in named])))
+            host = torch.empty(bad.numel(), dtype=torch.bool, pin_memory=bad.is_cuda)      # (per step: a pipelined caller reads it a step later)
+            host.copy_(bad, non_blocking=True)
+            if bad.is_cuda:
+                done = torch.cuda.Event()
+                done.record()
+        return [named, host, done, names, fused_optimizer, None]
 
     @staticmethod
     def _check_weights_report(pending):
         """The host half: wait for the flags (by then the optimizer's kernels are queued behind them) and warn like the reference."""
-        named, host, done = pending
+        named, host, done, names, fused, jobs = pending
+        bad_names = []
         if done is not None:
             done.synchronize()
-        if bool(host.any()):
+        if host is not None and bool(host.any()):
+            bad_names += [k for (k, _), b in zip(named, host.tolist()) if b]
+        if fused is not None:
+            bad_names += [names.get(id(p), "<parameter>") for p, b in fused.nan_report(jobs) if b]
+        if bad_names:
             import logging
-            for (k, _), b in zip(named, host.tolist()):
-                if b:
-                    logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
+            for k in bad_names:
+                logging.getLogger(__name__).warning("NaN Values detected in model weight %s." % k)
 
-    def train_steps(self, batch, it=None, seed=None):
+    def _step_optimizer(self):
+        """check_weights + optimizer.step() as training.py:572-573 orders them; returns what `_check_weights_report` needs."""
+        from .optim import FusedAdam
+        fused = self.optimizer if isinstance(self.optimizer, FusedAdam) else None
+        nan_check = self._check_weights_launch(fused)
+        self.optimizer.step()
+        if fused is not None:
+            nan_check[5] = fused.take_nan_jobs()
+        return nan_check
+
+    def train_steps(self, batch, it=None, seed=None, wait: bool = True):
         """K frames of the reference's loop in ONE optimisation step: `batch` is a list of K `load_one_frame` dictionaries (or one
         collated dictionary whose tensors carry a leading batch axis K).  Every frame is evaluated exactly as `train_step`
         evaluates it alone -- its own 4-tap ensemble draw, its own black-hole coin and noise fields, its own 5-frame sync window
@@ -484,14 +501,17 @@ class Trainer:
         the K per-frame losses (the gradient of K single calls averaged, as a batch_size-K DataLoader would give the reference
         if its crop code supported it, training.py:536-537).  The random draws are made frame by frame in `train_step`'s order,
         so K = 1 consumes the generators like one `train_step` call.  The canonical-depth photo loss is not part of this
-        entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames."""
+        entry.  Returns (loss_rgb, loss dict) like `train_step`, the values being means over the K frames.
+        `wait=False` returns a `PendingStep` instead: the step is queued and nothing has waited for the device; `.result()` gives the
+        same pair (and issues the NaN warnings) -- a loop that calls it AFTER queueing the next step keeps the GPU fed across the step
+        boundary (the synchronous form idles the device from the last kernel of a step to the first of the next)."""
         set_training(self.model, True)                      # self.model.train(): training.py:150, as train_step
         self._broadcast_buffers()                           # (DDP's per-forward buffer broadcast, as train_step)
         if self.cfg["training"].get("stage", "stage1") != "stage1":
             raise NotImplementedError("only training.stage == 'stage1' exists in the reference (training.py:152)")
-        return self.train_stage1_frames(batch, it=it, seed=seed)
+        return self.train_stage1_frames(batch, it=it, seed=seed, wait=wait)
 
-    def train_stage1_frames(self, batch, it=None, seed=None):
+    def train_stage1_frames(self, batch, it=None, seed=None, wait: bool = True):
         """`train_steps` without the `model.train()` of training.py:150 -- the K-frame counterpart of `train_stage1`: the
         post-fusion U-Net runs in whatever mode it is in."""
         import random
@@ -578,15 +598,29 @@ class Trainer:
                                                 seed=0 if seed is None else int(seed))
         apply_grads(m, grads)
         self._average_gradients_over_ranks()
-        nan_check = self._check_weights_launch()
-        self.optimizer.step()
-        self._check_weights_report(nan_check)
+        nan_check = self._step_optimizer()
         loss = {"loss": total, "loss_rgb": aux["loss_rgb"] + (aux["loss_face"] if "loss_face" in aux else 0)}
         for k in ("loss_perceptual", "loss_sync"):
             if k in aux:
                 loss[k] = aux[k]
-        self._loss_to_host(loss)      # host tensors, like `_train_stage1` and the reference (training.py:562-569)
-        return loss["loss_rgb"], loss
+        pending = PendingStep(self, nan_check, loss)
+        return pending.result() if wait else pending
+
+
+class PendingStep:
+    """A training step that has been queued (`Trainer.train_steps(..., wait=False)`): `result()` waits for it once, issues the reference's
+    NaN warnings (check_weights, training.py:572) and returns (loss_rgb, loss dict) with host tensors, like the synchronous call."""
+
+    def __init__(self, trainer, nan_check, loss):
+        self._trainer, self._nan_check, self._loss, self._out = trainer, nan_check, loss, None
+
+    def result(self):
+        if self._out is None:
+            self._trainer._check_weights_report(self._nan_check)
+            self._trainer._loss_to_host(self._loss)      # host tensors, like `_train_stage1` and the reference (training.py:562-569)
+            self._out = (self._loss["loss_rgb"], self._loss)
+            self._nan_check = None
+        return self._out
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -327,3 +327,141 @@ def test_fused_step_option_routes_train_step_through_the_fused_engine(golden, sy
     assert tra._fused_step_covers()
     tra.cfg = {**tra.cfg, "training": {**tra.cfg["training"], "use_canonical_depth_loss_photo_v2": True}}
     assert not tra._fused_step_covers()
+
+
+def test_fused_adam_is_torch_adam_in_one_launch(dev):
+    """speech2lip_amd.FusedAdam (s2l_adam_step: every tensor of the group in one launch) against torch.optim.Adam -- the optimizer the
+    reference builds (train.py:166) -- over ragged tensor sizes, several steps, with and without weight decay: parameters and both
+    moments to a few ulps (torch's kernels may contract a multiply-add the library is built not to), the same `state_dict()` layout
+    (a state written by either loads into the other and continues identically), and the NaN flags of check_weights
+    (src/common.py:56-64): a parameter that holds a NaN BEFORE a step is reported for that step."""
+    sizes = [(1,), (5, 7), (4096,), (4097,), (256, 259), (3, 64, 3, 3), (12289,)]
+    for wd in (0.0, 0.01):
+        g = torch.Generator(device=dev).manual_seed(11)
+        init = [torch.randn(s, device=dev, generator=g) for s in sizes]
+        pa = [torch.nn.Parameter(t.clone()) for t in init]
+        pb = [torch.nn.Parameter(t.clone()) for t in init]
+        oa = torch.optim.Adam(pa, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        ob = s2l.FusedAdam(pb, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        for step in range(1, 6):
+            grads = [torch.randn(s, device=dev, generator=g) * (0.1 if step % 2 else 3.0) for s in sizes]
+            for p, q, gr in zip(pa, pb, grads):
+                p.grad, q.grad = gr.clone(), gr.clone()
+            oa.step()
+            ob.step()
+            for k, (p, q) in enumerate(zip(pa, pb)):
+                tol = 4e-7 * float(p.detach().abs().max()) + 1e-9
+                assert float((p.detach() - q.detach()).abs().max()) <= tol, (wd, step, k)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    a, b = oa.state[p][key], ob.state[q][key]
+                    assert float((a - b).abs().max()) <= 4e-7 * float(a.abs().max()) + 1e-12, (wd, step, k, key)
+                assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == step
+            assert not any(bad for _, bad in ob.nan_report())
+        # state dicts are interchangeable: torch's state into the fused optimizer and back, then one more identical step
+        sa, sb = oa.state_dict(), ob.state_dict()
+        assert sa["param_groups"][0].keys() >= {"lr", "betas", "eps", "weight_decay"} and set(sb["state"][0]) == set(sa["state"][0])
+        ob2 = s2l.FusedAdam(pb, lr=1e-3, weight_decay=wd)
+        ob2.load_state_dict(sa)
+        oa2 = torch.optim.Adam(pa, lr=1e-3, weight_decay=wd)
+        oa2.load_state_dict(sb)
+        for p, q in zip(pa, pb):
+            q.data.copy_(p.data)
+            p.grad = q.grad = torch.ones_like(p)
+        oa2.step()
+        ob2.step()
+        for p, q in zip(pa, pb):
+            assert float((p.detach() - q.detach()).abs().max()) <= 4e-7 * float(p.detach().abs().max()) + 1e-9
+    # the NaN report: the value BEFORE the update is what counts (the reference checks before optimizer.step(), training.py:572)
+    pb[3].data[17] = float("nan")
+    for q in pb:
+        q.grad = torch.zeros_like(q)
+    ob2.step()
+    report = ob2.nan_report()
+    assert [bad for _, bad in report] == [k == 3 for k in range(len(pb))] and report[3][0] is pb[3]
+    with pytest.raises(s2l._abi.S2LError):
+        cpu = torch.nn.Parameter(torch.zeros(3))
+        cpu.grad = torch.zeros(3)
+        s2l.FusedAdam([cpu]).step()
+    with pytest.raises(NotImplementedError):
+        s2l.FusedAdam(pb, amsgrad=True)
+
+
+def test_pending_step_fused_adam_and_device_prefetch_equal_the_synchronous_route(golden, syncnet, dev, tmp_path):
+    """The three things `train_steps` gained for the loop that is not allowed to idle the device (train.py:173-199 with K frames per step):
+    `wait=False` (a PendingStep whose result() is read after the next step is queued), `FusedAdam` (with its NaN flags merged into the
+    check_weights warnings) and `FramePrefetcher(device=...)` (uploads on a side stream) -- same losses bit for bit, parameters after two
+    real optimisation steps equal to the torch.optim.Adam route's to rounding."""
+    import logging
+    import random
+    _, data, _, _, _ = _g11_device(golden, dev)
+    frames = [dict(data, index=int(data["index"]) + k) for k in range(2)]
+
+    def run(opt_cls, wait, on_device):
+        m = _late_model(dev)
+        opt = opt_cls([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        tr = s2l.Trainer(m, opt, cfg=_cfg(m), syncnet=syncnet, use_syncloss=True, precision="bf16", hole_noise="device")
+        torch.manual_seed(3)
+        random.seed(3)
+        batch = frames
+        if on_device:
+            batch = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 16 else v) for k, v in f.items()} for f in frames]
+        outs, pend = [], None
+        for it in (100001, 100002):
+            h = tr.train_steps(batch, it=it, wait=wait)
+            if wait:
+                outs.append(h)
+            else:
+                assert isinstance(h, s2l.training.PendingStep)
+                if pend is not None:
+                    outs.append(pend.result())
+                pend = h
+        if pend is not None:
+            outs.append(pend.result())
+            assert pend.result() is outs[-1]                      # idempotent
+        return outs, {n: p.detach().clone() for n, p in m.named_parameters()}, tr, m
+
+    (ref, pref, _, _) = run(torch.optim.Adam, True, False)
+    for opt_cls, wait, on_device in ((torch.optim.Adam, False, False), (s2l.FusedAdam, True, False), (s2l.FusedAdam, False, True)):
+        outs, params, tr, m = run(opt_cls, wait, on_device)
+        for (la, da), (lb, db) in zip(ref, outs):
+            assert isinstance(lb, torch.Tensor) and not lb.is_cuda and all(not v.is_cuda for v in db.values() if isinstance(v, torch.Tensor))
+            if opt_cls is torch.optim.Adam:
+                assert float(la) == float(lb) and all(float(da[k]) == float(db[k]) for k in da if k != "rgb_window")
+        assert abs(float(ref[0][1]["loss"]) - float(outs[0][1]["loss"])) == 0.0        # step 1 starts from the same weights whatever the optimizer
+        for n in pref:
+            assert float((pref[n] - params[n]).abs().max()) <= 2e-6 * float(pref[n].abs().max()) + 1e-9, (opt_cls.__name__, n)
+    # a NaN in a stepped parameter is reported through the optimizer's flags, with the state-dict name the reference prints
+    m.fc_time.bias.data[3] = float("nan")
+    records = []
+
+    class Catch(logging.Handler):
+        def emit(self, rec):
+            records.append(rec.getMessage())
+    log = logging.getLogger("speech2lip_amd.training")
+    h = Catch()
+    log.addHandler(h)
+    try:
+        tr.train_steps(frames, it=100003)
+    finally:
+        log.removeHandler(h)
+    assert any("fc_time.bias" in r for r in records), records
+
+    # FramePrefetcher(device=...): the same dictionaries, floating-point tensors already on the device
+    from tools.benchlib import write_synthetic_dataset
+    root = str(tmp_path / "may_face_crop_lip")
+    write_synthetic_dataset(root, 12, FH=40, FW=56, lh=8, lw=12, x0=20, y0=22, train=False, workers=4)
+    ds = s2l.SomeonesLipClip(root, "train", s2l.may_config(8, 12, data_path=root))
+    order = [3, 0, 7, 5]
+    with s2l.FramePrefetcher(ds, order, workers=2, depth=2, per_step=2, collate=False, mode="thread", device=dev) as pf:
+        groups = list(pf)
+    assert [len(g_) for g_ in groups] == [2, 2]
+    for got, i in zip([f for g_ in groups for f in g_], order):
+        ref_f = ds.load_one_frame(i)
+        assert set(got) == set(ref_f)
+        for k, v in ref_f.items():
+            if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 16:
+                assert got[k].is_cuda and torch.equal(got[k].cpu(), v), k
+            elif isinstance(v, torch.Tensor):
+                assert not got[k].is_cuda and torch.equal(got[k], v), k
+            else:
+                assert got[k] == v, k

@@ -699,31 +699,38 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         ds.load_one_frame(i % n)
     res["load_one_frame_ms"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
 
-    def build(late, hole_noise, fused_step=False):
+    def build(late, hole_noise, fused_step=False, adam=torch.optim.Adam):
         m = make_model(dev, 96, 96, unet=True, train=True)
         m.data_path = root
         if late:      # train.py:188-197
             for p in m.post_fusion_unet.parameters():
                 p.requires_grad = False
             m.post_fusion_unet.eval()
-        opt = torch.optim.Adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
+        opt = adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
         return s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, perceptual_loss_fn=lp, precision="bf16", hole_noise=hole_noise,
                            fused_step=fused_step)
 
-    def run(tr, it0, batches, per_step):
+    def run(tr, it0, batches, per_step, pipelined=False):
         torch.cuda.synchronize()
-        spans, k = [], 0
+        spans, k, pending = [], 0, None
         t0 = time.perf_counter()
         for batch in batches:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             if per_step == 1:
                 tr.train_step(batch, it=it0 + k)
+            elif pipelined:      # step k's losses / NaN report are read after step k + 1 has been queued
+                h = tr.train_steps(batch, it=it0 + k, wait=False)
+                if pending is not None:
+                    pending.result()
+                pending = h
             else:
                 tr.train_steps(batch, it=it0 + k)
             e1.record()
             spans.append((e0, e1))
             k += 1
+        if pending is not None:
+            pending.result()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         busy = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
@@ -751,12 +758,19 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
             run(tr, it0, pf, 1)
         with s2l.FramePrefetcher(ds, order) as pf:
             entry["train_step_fused_prefetch_device_noise"] = run(tr, it0, pf, 1)
-        # (3) K frames per optimisation step through the fused engine
+        # (3) K frames per optimisation step through the fused engine: (a) round 5's loop -- torch.optim.Adam, host tensors from the loader,
+        #     every step waited for; (b) the loop that keeps the device fed: FusedAdam (one launch, NaN flags folded in), the loader uploading on
+        #     a side stream, step k's results read after step k + 1 is queued
         K = 8
         with s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False) as pf:
             run(tr, it0, pf, K)
         with s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False) as pf:
-            entry["train_steps_K8"] = run(tr, it0, pf, K)
+            entry["train_steps_K8_sync_torch_adam"] = run(tr, it0, pf, K)
+        tr = build(late, "device", fused_step=True, adam=s2l.FusedAdam)
+        with s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False, device=dev) as pf:
+            run(tr, it0, pf, K, pipelined=True)
+        with s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False, device=dev) as pf:
+            entry["train_steps_K8"] = run(tr, it0, pf, K, pipelined=True)
         res[phase] = entry
         del tr
         torch.cuda.empty_cache()
