@@ -38,6 +38,7 @@ def main():
     spec.loader.exec_module(D)
     head = json.loads(sys.stdin.readline())
     ds = D.SomeonesLipClip(head["folder"], head["mode"], cfg=head["cfg"], img_ext=head.get("img_ext", ".jpg"))
+    ds.load_sync_fields = bool(head.get("sync_fields", True))
     sys.stdout.write("ready\n")
     sys.stdout.flush()
     for line in sys.stdin:

@@ -180,6 +180,10 @@ class SomeonesLipClip:
         self.dataset_folder, self.mode, self.cfg, self.img_ext = dataset_folder, mode, cfg, img_ext
         tc, mc = ((cfg or {}).get("training", {}), (cfg or {}).get("model", {}))
         self.use_syncloss = bool(tc.get("use_syncloss", False))                            # :34
+        # The reference reads the sync-loss side inputs of EVERY training frame once use_syncloss is configured (:328-385: five pose grids,
+        # five more JPEG decodes + resizes, the mel crop -- most of a frame's ~10 ms and 11 of its 16 MB), although train_stage1 only looks
+        # at them after it > 100000 (training.py:491).  False skips them (a loader for the early phase: FramePrefetcher(sync_fields=False)).
+        self.load_sync_fields = True
         self.use_sync_contrastive_loss = bool(tc.get("use_sync_contrastive_loss", False))
         self.use_canonical_depth = bool(mc.get("use_canonical_depth", False))
         self.use_post_fusion = bool(mc.get("use_post_fusion", True))
@@ -270,7 +274,7 @@ class SomeonesLipClip:
         inputs["rgb_zero"] = torch.from_numpy(self.rgb_zero)
         inputs["height"], inputs["width"] = rgb.shape[0], rgb.shape[1]
         inputs["face_h"], inputs["face_w"] = self.face_h, self.face_w
-        if self.use_syncloss and self.mode == "train":                                     # :328-385
+        if self.use_syncloss and self.mode == "train" and self.load_sync_fields:           # :328-385
             mel = crop_audio_window(self.orig_mel.copy(), index + 2)
             inputs["mel"] = torch.from_numpy(np.ascontiguousarray(mel.T).astype(np.float32)).unsqueeze(0)      # [1,80,16]
             # five consecutive frames; past the end of the split the last one that existed is repeated (:333-362)
@@ -764,7 +768,7 @@ class FramePrefetcher(_OwnsShared):
     SLAB = 24 << 20      # bytes of shared memory per frame in flight (a May frame with its sync window: 16.3 MB)
 
     def __init__(self, ds: "SomeonesLipClip", order, workers: Optional[int] = None, depth: int = 8, per_step: int = 1, collate: bool = True,
-                 pin_memory: Optional[bool] = None, mode: Optional[str] = None, device=None):
+                 pin_memory: Optional[bool] = None, mode: Optional[str] = None, device=None, sync_fields: Optional[bool] = None):
         """pin_memory (default: when a GPU is visible): every tensor arrives in page-locked memory, as `DataLoader(pin_memory=True)`
         does -- the ~16 MB a frame with its sync window carries then cross PCIe by DMA at ~50 GB/s instead of through a pageable
         staging copy (3.7 ms per frame measured).
@@ -772,8 +776,14 @@ class FramePrefetcher(_OwnsShared):
         frame are ALSO copied to that device, by the loader thread on a side stream, as soon as the frame is read -- the trainer's
         `.to(device)` then finds them there and the step's 40 - 130 MB of PCIe traffic runs beside the previous step's kernels instead
         of at the head of its own.  The consumer's current stream waits for the copy when the frame is yielded.  Integer entries and
-        scalars stay on the host (the trainer reads them as python numbers)."""
+        scalars stay on the host (the trainer reads them as python numbers).
+        sync_fields (default None = whatever `ds` is set to, i.e. the reference's behaviour): False leaves the sync-loss side inputs out of
+        every frame (`SomeonesLipClip.load_sync_fields`) -- the loader of the iterations before `it > 100000`, which never read them."""
         from concurrent.futures import ThreadPoolExecutor
+        if sync_fields is not None and bool(sync_fields) != ds.load_sync_fields:
+            import copy
+            ds = copy.copy(ds)              # (the caller's reader keeps its setting; the arrays are shared)
+            ds.load_sync_fields = bool(sync_fields)
         self.ds, self.order, self.depth, self.per_step, self.collate = ds, list(order), max(1, int(depth)), max(1, int(per_step)), collate
         self.pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
         self.device = torch.device(device) if device is not None else None
@@ -794,8 +804,8 @@ class FramePrefetcher(_OwnsShared):
             def plain(o):      # (a value the worker could not rebuild must not silently become None)
                 raise TypeError(f"FramePrefetcher(mode='process'): cfg value {o!r} of type {type(o).__name__} cannot be sent to the "
                                 "reader processes (JSON); use mode='thread' or plain numbers / strings / lists / dicts in cfg")
-            head = json.dumps({"folder": ds.dataset_folder, "mode": ds.mode, "cfg": ds.cfg, "img_ext": getattr(ds, "img_ext", ".jpg")},
-                              default=plain)
+            head = json.dumps({"folder": ds.dataset_folder, "mode": ds.mode, "cfg": ds.cfg, "img_ext": getattr(ds, "img_ext", ".jpg"),
+                               "sync_fields": bool(ds.load_sync_fields)}, default=plain)
         self.pool = ThreadPoolExecutor(self.workers)
         self._blocks, procs = [], []
         try:

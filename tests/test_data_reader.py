@@ -316,6 +316,33 @@ def test_frame_prefetcher_keeps_order_and_collates(tmp_path):
     assert set(procs[0]) == set(refp) and all(torch.equal(procs[0][k], refp[k]) and procs[0][k].dtype == refp[k].dtype for k in refp)
 
 
+def test_frame_prefetcher_can_leave_the_sync_fields_out(tmp_path):
+    """`FramePrefetcher(sync_fields=False)`: the frames of the early phase without the sync-loss side inputs the reference's reader attaches
+    to every training frame (someones_lip_dataset.py:328-385) and train_stage1 only reads after it > 100000 (training.py:491): the other
+    entries are unchanged, in thread and in process mode, and the caller's reader keeps its own setting."""
+    import speech2lip_amd as s2l
+    from speech2lip_amd import config as C, data as D
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_fixture", "may_face_crop_lip")
+    cfg = C.may_config(6, 8, train_flags=True)
+    cfg["model"]["use_canonical_depth"] = False
+    cfg["training"].update(use_sync_contrastive_loss=True, use_syncloss=True)
+    ds = D.SomeonesLipClip(folder, "train", cfg=cfg)
+    full = ds.load_one_frame(3)
+    sync_keys = {"mel", "coord_window", "audio_window", "canonical_face_bbox", "rgb_window_neg"}
+    assert sync_keys <= set(full)
+    for mode in ("thread", "process"):
+        with s2l.FramePrefetcher(ds, [3, 1], workers=2, depth=2, collate=False, pin_memory=False, mode=mode, sync_fields=False) as pf:
+            got = [f for group in pf for f in group]         # (collate=False: lists of `per_step` dictionaries)
+        assert [int(f["index"]) for f in got] == [3, 1]
+        assert set(got[0]) == set(full) - sync_keys
+        for k in got[0]:
+            a, b = got[0][k], full[k]
+            assert (torch.equal(a, b) if isinstance(b, torch.Tensor) else np.array_equal(a, b) if isinstance(b, np.ndarray) else a == b), (mode, k)
+        with s2l.FramePrefetcher(ds, [3], workers=1, collate=False, pin_memory=False, mode=mode) as pf:      # default: the reference's frames
+            assert set(next(iter(pf))[0]) == set(full)
+    assert ds.load_sync_fields and sync_keys <= set(ds.load_one_frame(3))
+
+
 def _shm_exists(name: str) -> bool:
     return os.path.exists(os.path.join("/dev/shm", name.lstrip("/")))
 

@@ -766,10 +766,13 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
             run(tr, it0, pf, K)
         with s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False) as pf:
             entry["train_steps_K8_sync_torch_adam"] = run(tr, it0, pf, K)
+        #     ... and a loader that leaves the sync-loss side inputs out of the frames while `it` <= 100000 (the reference reads them for every
+        #     frame once use_syncloss is configured -- most of a frame's load time -- and only looks at them after it > 100000, training.py:491)
         tr = build(late, "device", fused_step=True, adam=s2l.FusedAdam)
-        with s2l.FramePrefetcher(ds, order[:2 * K], per_step=K, depth=2 * K, collate=False, device=dev) as pf:
+        kw = dict(per_step=K, collate=False, device=dev, sync_fields=late, workers=int(os.environ.get("S2L_BENCH_K8_WORKERS", "0")) or None)
+        with s2l.FramePrefetcher(ds, order[:2 * K], depth=2 * K, **kw) as pf:
             run(tr, it0, pf, K, pipelined=True)
-        with s2l.FramePrefetcher(ds, order, per_step=K, depth=3 * K, collate=False, device=dev) as pf:
+        with s2l.FramePrefetcher(ds, order, depth=3 * K, **kw) as pf:
             entry["train_steps_K8"] = run(tr, it0, pf, K, pipelined=True)
         res[phase] = entry
         del tr

@@ -17,6 +17,9 @@ dev = torch.device("cuda:0")
 late = "--early" not in sys.argv
 K = 8 if "--k8" in sys.argv else 1
 FUSED1 = "--fused1" in sys.argv      # one frame per step through train_steps (the StageOneStep route)
+FADAM = "--fusedadam" in sys.argv    # speech2lip_amd.FusedAdam instead of torch.optim.Adam
+PIPE = "--pipelined" in sys.argv     # train_steps(wait=False): step k's result() after step k + 1 is queued
+ONDEV = "--device-frames" in sys.argv   # the frames' floating-point tensors already on the device (what FramePrefetcher(device=) hands over)
 root = benchlib._dataset_tmp("may_face_crop_lip")
 benchlib.write_synthetic_dataset(root, 24, train=True)
 cfg = s2l.may_config(96, 96, data_path=root, train_flags=True)
@@ -31,11 +34,14 @@ if late:
     for p in m.post_fusion_unet.parameters():
         p.requires_grad = False
     m.post_fusion_unet.eval()
-opt = torch.optim.Adam([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
+opt = (s2l.FusedAdam if FADAM else torch.optim.Adam)([p for nm, p in m.named_parameters() if p.requires_grad and not nm.startswith("coord_linears")], lr=1e-4)
 tr = s2l.Trainer(m, opt, dev, None, cfg=cfg, syncnet=net, precision="bf16", hole_noise="device")
 it0 = 100001 if late else 1000
 frames = [ds.load_one_frame(i) for i in range(8)]
+if ONDEV:
+    frames = [{k: (v.to(dev) if isinstance(v, torch.Tensor) and v.is_floating_point() and v.numel() > 16 else v) for k, v in f.items()} for f in frames]
 batches = [s2l.data.collate_batch([f]) for f in frames]
+pending = [None]
 
 
 def step(k):
@@ -43,6 +49,11 @@ def step(k):
         tr.train_steps([frames[k % 8]], it=it0 + k)
     elif K == 1:
         tr.train_step(batches[k % 8], it=it0 + k)
+    elif PIPE:
+        h = tr.train_steps(frames, it=it0 + k, wait=False)
+        if pending[0] is not None:
+            pending[0].result()
+        pending[0] = h
     else:
         tr.train_steps(frames, it=it0 + k)
 
