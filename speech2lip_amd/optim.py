@@ -106,6 +106,9 @@ class FusedAdam(torch.optim.Optimizer):
             self._flag_jobs.append((ps, flags_host, done, grads))      # (`grads` keeps converted copies alive until the launch has run)
             for p in ps:
                 self.state[p]["step"] += 1
+                # the kernel wrote through raw pointers: tell autograd the tensor changed in place, as torch's own in-place update would --
+                # the model's packed-weight caches (TalkingFace.packed_weights, SimpleUnetLight.packed_weights*) key on the version counters
+                torch.autograd.graph.increment_version(p)
         return loss
 
     def take_nan_jobs(self):

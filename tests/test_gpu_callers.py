@@ -347,8 +347,10 @@ def test_fused_adam_is_torch_adam_in_one_launch(dev):
             grads = [torch.randn(s, device=dev, generator=g) * (0.1 if step % 2 else 3.0) for s in sizes]
             for p, q, gr in zip(pa, pb, grads):
                 p.grad, q.grad = gr.clone(), gr.clone()
+            versions = [q._version for q in pb]
             oa.step()
             ob.step()
+            assert all(q._version > v for q, v in zip(pb, versions))      # an in-place update autograd (and the packed-weight caches) can see
             for k, (p, q) in enumerate(zip(pa, pb)):
                 tol = 4e-7 * float(p.detach().abs().max()) + 1e-9
                 assert float((p.detach() - q.detach()).abs().max()) <= tol, (wd, step, k)
@@ -389,8 +391,10 @@ def test_fused_adam_is_torch_adam_in_one_launch(dev):
 def test_pending_step_fused_adam_and_device_prefetch_equal_the_synchronous_route(golden, syncnet, dev, tmp_path):
     """The three things `train_steps` gained for the loop that is not allowed to idle the device (train.py:173-199 with K frames per step):
     `wait=False` (a PendingStep whose result() is read after the next step is queued), `FusedAdam` (with its NaN flags merged into the
-    check_weights warnings) and `FramePrefetcher(device=...)` (uploads on a side stream) -- same losses bit for bit, parameters after two
-    real optimisation steps equal to the torch.optim.Adam route's to rounding."""
+    check_weights warnings) and `FramePrefetcher(device=...)` (uploads on a side stream) -- same losses bit for bit; the parameters after two
+    real optimisation steps move the way the torch.optim.Adam route moves them (Adam's first steps are lr * sign(gradient): an element whose
+    gradient is at the level of the composite adjoint's float atomics may take the other sign from run to run, so the UPDATES are compared as
+    vectors; `test_fused_adam_is_torch_adam_in_one_launch` holds the optimizer itself to a few ulps on identical gradients)."""
     import logging
     import random
     _, data, _, _, _ = _g11_device(golden, dev)
@@ -418,9 +422,10 @@ def test_pending_step_fused_adam_and_device_prefetch_equal_the_synchronous_route
         if pend is not None:
             outs.append(pend.result())
             assert pend.result() is outs[-1]                      # idempotent
-        return outs, {n: p.detach().clone() for n, p in m.named_parameters()}, tr, m
+        return outs, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, tr, m
 
     (ref, pref, _, _) = run(torch.optim.Adam, True, False)
+    p0 = {n: p.detach().clone() for n, p in _late_model(dev).named_parameters() if p.requires_grad}      # (every run starts from these seeded weights)
     for opt_cls, wait, on_device in ((torch.optim.Adam, False, False), (s2l.FusedAdam, True, False), (s2l.FusedAdam, False, True)):
         outs, params, tr, m = run(opt_cls, wait, on_device)
         for (la, da), (lb, db) in zip(ref, outs):
@@ -429,8 +434,14 @@ def test_pending_step_fused_adam_and_device_prefetch_equal_the_synchronous_route
             if opt_cls is torch.optim.Adam:
                 assert float(la) == float(lb) and all(float(da[k]) == float(db[k]) for k in da if k != "rgb_window")
         assert abs(float(ref[0][1]["loss"]) - float(outs[0][1]["loss"])) == 0.0        # step 1 starts from the same weights whatever the optimizer
-        for n in pref:
-            assert float((pref[n] - params[n]).abs().max()) <= 2e-6 * float(pref[n].abs().max()) + 1e-9, (opt_cls.__name__, n)
+        # ... and step 2 sees the weights step 1 left (the packed-weight caches follow an update made through raw pointers)
+        assert abs(float(ref[1][1]["loss"]) - float(outs[1][1]["loss"])) <= 2e-3 * abs(float(ref[1][1]["loss"]))
+        assert float(outs[1][1]["loss"]) != float(outs[0][1]["loss"])
+        up_ref = torch.cat([(pref[n] - p0[n]).reshape(-1) for n in pref])
+        up = torch.cat([(params[n] - p0[n]).reshape(-1) for n in pref])
+        assert float(up.abs().max()) <= 2.1e-3 and float(up_ref.abs().max()) <= 2.1e-3      # two Adam steps move nothing much further than 2 lr
+        cos = float((up * up_ref).sum() / (up.norm() * up_ref.norm()))
+        assert cos >= 0.98 and float(((up - up_ref).abs() > 1e-5).float().mean()) <= 0.05, (opt_cls.__name__, cos)
     # a NaN in a stepped parameter is reported through the optimizer's flags, with the state-dict name the reference prints
     m.fc_time.bias.data[3] = float("nan")
     records = []
