@@ -429,6 +429,14 @@ int64_t s2l_unet_train_frames_h_work_halves(int height, int width, int64_t n_fra
 int s2l_unet_train_forward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
                                     float momentum, int update_running, const float* x, uint16_t* saved, float* scratch, float* out,
                                     int height, int width, int64_t n_frames, s2l_stream_t stream);
+/* ... for a FROZEN net (the backward is s2l_unet_train_backward_frames_h: no weight gradients): the BatchNorm + ReLU passes whose only
+ * reader is the next 3x3 convolution at the same resolution (a0, a2, a4, a6, a8 of SimpleUnetLight.py:16-111's DoubleConvs) are folded into
+ * that convolution -- it reads the pre-BatchNorm tensor and normalises its halo tiles in LDS with the per-frame scale / shift, the same
+ * expression and rounding -- so `out`, every stored z and the statistics are the bits of s2l_unet_train_forward_frames_h; those five
+ * activations' slots of `saved` are left unwritten. */
+int s2l_unet_train_forward_frames_h_fused(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
+                                          float momentum, int update_running, const float* x, uint16_t* saved, float* scratch, float* out,
+                                          int height, int width, int64_t n_frames, s2l_stream_t stream);
 int s2l_unet_train_backward_frames_h(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host,
                                      const uint16_t* saved, const float* d_out, uint16_t* work, float* d_x, int height, int width,
                                      int64_t n_frames, s2l_stream_t stream);

@@ -89,6 +89,8 @@ EXPORTS = {
     "s2l_unet_train_frames_h_work_halves": (c_int64, [c_int, c_int, c_int64]),
     "s2l_unet_train_forward_frames_h": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_unet_train_forward_frames_h_fused": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_unet_train_backward_frames_h": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                  c_int64, c_void_p]),
     "s2l_convh_layer": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),

@@ -18,6 +18,9 @@ struct ConvHArgs {
   int n_frames;
   float* stat;             // or null: per-tile partial sums of BatchNorm's batch statistics of the STORED values, channel_stats_h_kernel's
                            //   layout with block = tile: stat[((frame * tiles_xy + ty * tiles_x + tx) * 2 + {sum, sum of squares}) * cout + channel]
+  const float* norm;       // or null: inA is a PRE-BatchNorm tensor z and the convolution consumes a = relu(z * scale + shift): per frame 512 floats,
+                           //   scale at [c], shift at [CA + c] (bn_finalize_groups_kernel's row).  The halo tile is normalised in LDS with
+                           //   bn_relu_h_kernel's expression and rounding, so the output is the bits of the two-kernel route.  CB = 0, no gate, no ReLU.
 };
 constexpr int kConvHStatBlocks = 1024;      // tiles per frame the statistics buffers hold (= kStatBlocks of csrc/unet.hip)
 

@@ -13,12 +13,12 @@ static_assert(offsetof(ConvHArgs, inA) == 0 && offsetof(ConvHArgs, inB) == 8 && 
               offsetof(ConvHArgs, CA) == 48 && offsetof(ConvHArgs, CB) == 52 && offsetof(ConvHArgs, cout) == 56 &&
               offsetof(ConvHArgs, H) == 60 && offsetof(ConvHArgs, W) == 64 && offsetof(ConvHArgs, tiles_x) == 68 &&
               offsetof(ConvHArgs, tiles_y) == 72 && offsetof(ConvHArgs, n_ct) == 76 && offsetof(ConvHArgs, relu) == 80 &&
-              offsetof(ConvHArgs, stat) == 88,
+              offsetof(ConvHArgs, stat) == 88 && offsetof(ConvHArgs, norm) == 96,
               "gen_convh_body.py (ARG) loads these fields from the kernarg segment by offset");
 
 constexpr int kCHTileH = 32;      // tile = 32 rows x 16 columns (gen_convh_body.py: TILE_H)
 constexpr int kCHHalo = (kCHTileH + 2) * 18 * 64, kCHW = 9 * 2 * 2 * 64 * 16, kCHBuf = kCHHalo + kCHW;
-constexpr int kCHLds = 2 * kCHBuf + 1024 + 4096;      // two buffers + the bias table + the eight waves' per-tile statistics (the store staging aliases buffer 1)
+constexpr int kCHLds = 2 * kCHBuf + 1024 + 4096 + 2048;      // two buffers + the bias table + the eight waves' per-tile statistics + the normalising form's two [scale | shift] tables (the store staging aliases buffer 1)
 static_assert(kCHLds <= 160 * 1024, "LDS budget");
 
 #ifdef S2L_WITH_REFERENCE_KERNELS      // (the four-wave form: libs2l_hip_ref.so only)
@@ -171,6 +171,18 @@ __global__ __launch_bounds__(512) void convh8_relu_asm_kernel(ConvHArgs a) {
 #include "convh8r_body.inc"
 }
 
+// The normalising form (gen_convh8_body.py WITH_NORM): the input is the producing layer's PRE-BatchNorm tensor; the staged halo tile is normalised
+// (+ ReLU) in LDS with that layer's per-frame scale / shift before the MFMAs read it -- bn_relu_h_kernel folded into its consumer.
+__global__ __launch_bounds__(512) void convh8_norm_asm_kernel(ConvHArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ch_smem[];
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  ConvH8Ctx c;
+  if (!convh8_prologue(a, ch_smem, c)) return;
+  const int tid = threadIdx.x, wave = c.wave, tx0 = c.tx0, ty0 = c.ty0, ct0 = c.ct0, fr0 = c.fr0, ntl = c.ntl;
+  const uint32_t lds0 = c.lds0;
+#include "convh8n_body.inc"
+}
+
 #ifdef S2L_WITH_REFERENCE_KERNELS
 // The alternating-roles form (gen_convhx_body.py): the same tile and the same per-lane constants as the eight-wave form, the two waves of a
 // SIMD taking turns between an MFMA-only segment and a load / request / epilogue segment.  Same arithmetic in the same order: the same bits.
@@ -226,7 +238,18 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stat
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
-  static LdsOptIn flag4, flag8, flag8r, flagx, flagxr;
+  static LdsOptIn flag4, flag8, flag8r, flag8n, flagx, flagxr;
+  if (a.norm) {      // only the default eight-wave form normalises its input; a launch outside its conditions is refused (the caller keeps the two-kernel route)
+    if (a.CB != 0 || a.relu || a.gate || a.CA > 128 || misaligned16(a.norm)) return S2L_OK;
+    const bool stats_n = a.stat && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !getenv("S2L_NO_CONV_STATS");
+    if (!stats_n) a.stat = nullptr;
+    if (stats_done) *stats_done = stats_n;
+    if (stat_blocks) *stat_blocks = a.tiles_x * a.tiles_y;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(convh8_norm_asm_kernel), kCHLds, flag8n, dev))) return rc;
+    hipLaunchKernelGGL(convh8_norm_asm_kernel, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), kCHLds, st, a);
+    *launched = true;
+    return (int)hipGetLastError();
+  }
 #ifdef S2L_WITH_REFERENCE_KERNELS
   const bool alternating = g_convh_kind.load(std::memory_order_relaxed) == 2 && a.gate == nullptr;
 #else

@@ -16,12 +16,15 @@ N_SLOTS = HALO_BYTES // 16                                      # 2 448
 BUF = HALO_BYTES + W_BYTES                                      # 76 032
 BIAS_OFF = 2 * BUF                                              # 256 floats
 STAT_OFF = BIAS_OFF + 1024                                       # per-wave statistics of a tile: [8 waves][64 channels][sum, sum of squares] floats
-LDS_BYTES = STAT_OFF + 4096
+NORM_OFF = STAT_OFF + 4096                                       # (the normalising form) two tables [scale 128 | shift 128] floats, by frame parity
+LDS_BYTES = NORM_OFF + 2048
 STG_OFF = BUF                                                   # store staging = the start of buffer 1's halo area: 8 waves x 4 KiB
 NW, NB = 8, 2                                                   # waves, N-blocks (2 rows x 16 pixels) per wave
 NI = 5                                                          # halo DMA instructions per wave (wave w: slots 320 w ..)
 CONST_WORDS = 23                                                # per lane, from the C++ prologue: hrc[5], bofs[6], swa[8], sra[4]
 WITH_RELU = False                                               # main() generates both: convh8_body.inc (linear) and convh8r_body.inc (max(0, .))
+WITH_NORM = False                                               # ... and convh8n_body.inc: the input tensor is a PRE-BatchNorm tensor z; the chunk's halo tile is
+                                                                # normalised in LDS -- a = bf16(max(fma(z, scale, shift), 0)), bn_relu_h_kernel's expression -- before it is read
 PFX = "S2L8"                                                    # label prefix (two bodies in one translation unit)
 EXP = int(os.environ.get("S2L_CH_EXP", "0"))                   # ablation builds (results wrong): 1 no stores, 2 no halo DMA, 4 no weight DMA, 16 no gate loads, 32 no B operand reads, 64 no A operand reads, 128 no bias init, 512 no epilogue, 1024 no per-chunk barrier, 4096 / 8192 PRICING of BatchNorm's normalise + ReLU inside the consuming convolution (norm_items), 16384 the halo tile read as one contiguous 40-KiB block (access-pattern pricing)
 
@@ -45,6 +48,11 @@ V_T = 60                        # temporaries 60..87 (the store read-backs share
 V_G = 88                        # 32: gate pieces [nb][j][4]; a launch that leaves the tile's statistics has no gate: the same registers then hold
 V_SH, V_SS, V_SQ, V_SA, V_SZ = V_G, V_G + 16, V_G + 17, V_G + 18, V_G + 22   # 16 loaded pixel pairs | sum | sum of squares | 4 staging addresses | 6 temporaries
 V_LAST = 119
+# the normalising form has no gate: its work registers live where the gate pieces would (the statistics block, which runs at the tile's end,
+# uses the same ones), and five more hold each piece's constant offset into a chunk's table row
+V_ND, V_NC, V_NU, V_NA, V_NT = V_G, V_G + 4, V_G + 20, V_G + 28, V_G + 29
+V_NSEG = 120                    # 5: (logical segment of this lane's slot in piece i) * 32 bytes
+V_LAST_NORM = 124
 
 
 def _scalars(first, singles, pairs, skip=(32, 33)):
@@ -71,18 +79,21 @@ for _n, _r in (("STATP", 98), ("STATP1", 99), ("NCOLS", 100), ("WLD", 101)):    
     S[_n] = _r
 S_LAST = max(S.values())
 assert S_LAST <= 101, S_LAST
+# the normalising form has no gate input: the gate's scalars carry its table pointer, the staged chunk's table row and the table's frame
+S_NORM = {"NORMP": S["GATE"], "NORMP1": S["GATE1"], "NB": S["GATEF"], "NPREV": S["GATEF1"]}
 
 # byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
 ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
-       "tiles_y": 72, "n_ct": 76, "relu": 80, "stat": 88}
+       "tiles_y": 72, "n_ct": 76, "relu": 80, "stat": 88, "norm": 96}
 
 
 def s(n):
-    return f"s{S[n]}"
+    return f"s{S_NORM[n] if n in S_NORM else S[n]}"
 
 
 def s2(n):
-    return f"s[{S[n]}:{S[n] + 1}]"
+    r = S_NORM[n] if n in S_NORM else S[n]
+    return f"s[{r}:{r + 1}]"
 
 
 class Body:
@@ -279,6 +290,12 @@ class Body:
         e(f"s_mov_b32 {s('NC')}, 0")
         self.next_coords("N", "NCT_")
         self.staging_tile_setup()
+        if WITH_NORM:
+            keep = self.label("nsamefr")
+            e(f"s_cmp_eq_u32 {s('NFR')}, {s('NPREV')}")
+            e(f"s_cbranch_scc1 {keep}")
+            self.norm_table_load()
+            e(f"{keep}:")
         e(f"{same}:")
 
     # ---- instruction groups
@@ -375,18 +392,19 @@ class Body:
                     self.lds_op(f"ds_write_b64 v{V_SWA + mb * 4 + rq}, v[{tc + 2 * rq}:{tc + 2 * rq + 1}]", ("SW", nb, mb, rq))
             for j in range(4):
                 self.lds_op(f"ds_read_b128 v[{tb + 4 * j}:{tb + 4 * j + 3}], v{V_SRA + j}", ("SR", nb, j))
-            nogate = self.label("ng")
-            e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
-            e(f"s_cbranch_scc1 {nogate}")
-            self.wait_lds(("SR", nb, 3))
-            for j in range(4):
-                for d in range(4):
-                    g, m, x = V_G + 16 * nb + 4 * j + d, tm + d, tb + 4 * j + d
-                    e(f"v_pk_max_i16 v{m}, v{g}, v{V_Z}")
-                    e(f"v_pk_min_u16 v{m}, v{m}, v{V_ONES}")
-                    e(f"v_pk_mul_lo_u16 v{m}, v{m}, v{V_FFFF}")
-                    e(f"v_and_b32 v{x}, v{x}, v{m}")
-            e(f"{nogate}:")
+            if not WITH_NORM:
+                nogate = self.label("ng")
+                e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+                e(f"s_cbranch_scc1 {nogate}")
+                self.wait_lds(("SR", nb, 3))
+                for j in range(4):
+                    for d in range(4):
+                        g, m, x = V_G + 16 * nb + 4 * j + d, tm + d, tb + 4 * j + d
+                        e(f"v_pk_max_i16 v{m}, v{g}, v{V_Z}")
+                        e(f"v_pk_min_u16 v{m}, v{m}, v{V_ONES}")
+                        e(f"v_pk_mul_lo_u16 v{m}, v{m}, v{V_FFFF}")
+                        e(f"v_and_b32 v{x}, v{x}, v{m}")
+                e(f"{nogate}:")
             self.wait_all_lds()                               # (either path: the read-backs have arrived)
             self.stats_block(nb)
             for j in range(4):
@@ -511,6 +529,72 @@ class Body:
         e("s_mov_b64 exec, -1")
         e(f"{skip}:")
 
+    # ---- the normalising form (WITH_NORM): BatchNorm's a = relu(z * scale + shift) of the PRODUCING layer, applied to the staged halo tile in LDS
+    def norm_table_load(self):
+        """The staging stream's frame NFR has its own statistics (every frame is a group): scale[0..CA) | shift[0..CA) of that frame (the
+        row st[NFR * 512 ..] bn_finalize_groups_kernel wrote: scale at [c], shift at [CA + c]) -> LDS table NFR & 1 as [scale 128 | shift 128]
+        floats.  EVERY wave fetches and writes the whole kilobyte itself and waits for its own writes: whoever reads the table later finds its own
+        copy landed (the other waves write the same values), so no barrier is needed; the parity keeps the table of the frame that is still being
+        normalised by a slower... no: by this same wave one chunk earlier -- untouched.  Rare (a workgroup crosses a frame boundary a few times
+        per launch); its latency is exposed."""
+        e = self.e
+        t0, t1, d = V_NT, V_NA, V_ND
+        e(f"s_lshl_b32 {s('T0')}, {s('NFR')}, 11")                     # 512 floats per frame
+        e(f"s_add_u32 {s('TA')}, {s('NORMP')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('NORMP1')}, 0")
+        e(f"s_lshl_b32 {s('T1')}, {s('CA')}, 2")                        # the shifts start CA floats into the row
+        e(f"v_and_b32 v{t0}, 31, v{V_LANE}")
+        e(f"v_lshlrev_b32 v{t0}, 4, v{t0}")                             # lanes 0..31: 16 bytes of scale each, lanes 32..63: of shift
+        e(f"v_mov_b32 v{t1}, {s('T1')}")
+        e(f"v_cmp_lt_u32 vcc, 31, v{V_LANE}")
+        e(f"v_cndmask_b32 v{t1}, 0, v{t1}, vcc")
+        e(f"v_add_u32 v{t0}, v{t0}, v{t1}")
+        e(f"global_load_dwordx4 v[{d}:{d + 3}], v{t0}, {s2('TA')}")
+        e(f"s_and_b32 {s('T0')}, {s('NFR')}, 1")
+        e(f"s_lshl_b32 {s('T0')}, {s('T0')}, 10")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+        e(f"s_add_u32 {s('T0')}, {s('T0')}, {NORM_OFF}")
+        e(f"v_add_u32 v{t0}, {s('T0')}, v{V_VS}")                       # + lane * 16: [scale 128 | shift 128]
+        e("s_waitcnt vmcnt(0)")
+        e(f"ds_write_b128 v{t0}, v[{d}:{d + 3}]")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_mov_b32 {s('NPREV')}, {s('NFR')}")
+
+    def norm_row(self):
+        """NB = the LDS address of the staged chunk's 32 scales (its shifts: + 512): table NFR & 1, row NC"""
+        e = self.e
+        e(f"s_and_b32 {s('NB')}, {s('NFR')}, 1")
+        e(f"s_lshl_b32 {s('NB')}, {s('NB')}, 10")
+        e(f"s_lshl_b32 {s('T0')}, {s('NC')}, 7")
+        e(f"s_add_u32 {s('NB')}, {s('NB')}, {s('T0')}")
+        e(f"s_add_u32 {s('NB')}, {s('NB')}, {s('LDS0')}")
+        e(f"s_add_u32 {s('NB')}, {s('NB')}, {NORM_OFF}")
+
+    def norm_real_items(self, buf):
+        """This wave's own five 1-KiB pieces of the staged chunk's halo tile (buffer buf), once they have landed: per 16-byte slot (8 channels
+        of one pixel) a ds_read_b128, its 8 scales + 8 shifts (4 ds_read_b128 of the table row at the slot's logical segment), 8 unpacks,
+        8 v_fma_f32, 8 v_max_f32 with 0, 4 v_cvt_pk_bf16_f32 (round to nearest even) and the ds_write_b128 back -- under the lanes whose slot is
+        a pixel INSIDE the image: a padding pixel stays the zero the halo requests wrote (the convolution pads the ACTIVATION with zeros, not z),
+        a lane without a slot writes nothing.  25 groups for the sprinkle lists."""
+        d, c, u, a, t = V_ND, V_NC, V_NU, V_NA, V_NT
+        items = []
+        for i in range(NI):
+            slot = f"v{V_SLOT[buf]}"
+            g0 = [f"v_add_u32 v{a}, {s('NB')}, v{V_NSEG + i}",
+                  (f"ds_read_b128 v[{d}:{d + 3}], {slot} offset:{1024 * i}", ("N", i, 0)),
+                  (f"ds_read_b128 v[{c}:{c + 3}], v{a}", ("N", i, 1)), (f"ds_read_b128 v[{c + 4}:{c + 7}], v{a} offset:16", ("N", i, 2)),
+                  (f"ds_read_b128 v[{c + 8}:{c + 11}], v{a} offset:512", ("N", i, 3)), (f"ds_read_b128 v[{c + 12}:{c + 15}], v{a} offset:528", ("N", i, 4))]
+            g1 = [("wait", ("N", i, 4))]
+            for k in range(4):      # a dword = channels 2 k (low half) and 2 k + 1 (high half)
+                g1 += [f"v_lshlrev_b32 v{u + 2 * k}, 16, v{d + k}", f"v_and_b32 v{u + 2 * k + 1}, 0xffff0000, v{d + k}"]
+            g2 = [f"v_fma_f32 v{u + k}, v{u + k}, v{c + k}, v{c + 8 + k}" for k in range(8)]
+            g3 = [f"v_max_f32 v{u + k}, 0, v{u + k}" for k in range(8)]
+            g4 = [f"v_cvt_pk_bf16_f32 v{d + k}, v{u + 2 * k}, v{u + 2 * k + 1}" for k in range(4)]
+            g4 += [f"v_bfe_u32 v{t}, v{V_VALID}, {i}, 1", f"v_cmp_eq_u32 vcc, 1, v{t}", "s_nop 0", "s_mov_b64 exec, vcc",
+                   (f"ds_write_b128 {slot}, v[{d}:{d + 3}] offset:{1024 * i}", ("N", i, 9)), "s_mov_b64 exec, -1"]
+            items += [g0, g1, g2, g3, g4]
+        return items
+
     # ---- PRICING ONLY (S2L_CH_EXP & 4096 / 8192): what would a = relu(z * scale + shift) cost INSIDE the convolution that consumes it?
     def norm_items(self, buf):
         """The work of normalising this wave's own five 1-KiB pieces of the staging chunk's halo tile in place (buffer buf), once they
@@ -548,6 +632,9 @@ class Body:
             self.wait_all_lds()
             e("s_barrier")
         norm = self.norm_items(p ^ 1) if EXP & 4096 else []
+        if WITH_NORM:
+            self.norm_row()
+            norm = self.norm_real_items(p ^ 1)
         for text, tag in self.tap_reads(0, p, 0):        # operands of tap 0 (exposed after the barrier)
             self.lds_op(text, tag)
         for t in range(9):
@@ -563,7 +650,7 @@ class Body:
             if t in (1, 2):
                 for k, g in enumerate(hal[:3] if t == 1 else hal[3:]):
                     sprinkle[2 + 2 * k].extend(g)
-            if t == 4 and p == 1:
+            if t == 4 and p == 1 and not WITH_NORM:
                 self.gate_loads()
             if norm and t == 6:      # pricing, optimistic placement: this wave's own pieces have landed (it waits for them), the work hides
                 e("s_waitcnt vmcnt(0)")      # behind the MFMAs of the last three taps
@@ -623,7 +710,7 @@ class Body:
         e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('X0')}")                 # pixel index (< 2^31: the launcher checks)
         e(f"s_lshr_b32 {s('T3')}, {s('T0')}, 26")
         e(f"s_lshl_b32 {s('T2')}, {s('T0')}, 6")
-        for dst, src in (("OUTF", "OUT"), ("GATEF", "GATE")):
+        for dst, src in (("OUTF", "OUT"),) if WITH_NORM else (("OUTF", "OUT"), ("GATEF", "GATE")):
             e(f"s_add_u32 {s(dst)}, {s(src)}, {s('T2')}")
             e(f"s_addc_u32 {s(dst + '1')}, {s(src + '1')}, {s('T3')}")
         e(f"v_lshrrev_b32 v{V_T}, 2, v{V_LANE}")
@@ -649,7 +736,8 @@ def emit_prologue(b, with_gate=True):
     e(f"s_mov_b64 {s2('KARG')}, %[karg]")
     for dst, src in (("WAVE", "wave"), ("LDS0", "lds0"), ("TX", "tx0"), ("TY", "ty0"), ("CT", "ct0"), ("FR", "fr0"), ("NTL", "ntl")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
-    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"), ("GATE", "gate"), ("STATP", "stat")):
+    for dst, field in (("INA", "inA"), ("INB", "inB"), ("W16", "w16"), ("BIAS", "bias"), ("OUT", "out"),
+                       ("NORMP", "norm") if WITH_NORM else ("GATE", "gate"), ("STATP", "stat")):
         e(f"s_load_dwordx2 {s2(dst)}, {s2('KARG')}, {ARG[field]}")
     for dst, field in (("CA", "CA"), ("CB", "CB"), ("COUT", "cout"), ("H", "H"), ("W", "W"), ("TILESX", "tiles_x"), ("TILESY", "tiles_y"),
                        ("NCT", "n_ct"), ("T3", "relu")):
@@ -733,6 +821,10 @@ def emit_prologue(b, with_gate=True):
             e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('T1')}")
             e(f"v_lshlrev_b32 v{V_VOFF + i}, 4, v{V_LANE}")
             e(f"v_add_u32 v{V_VOFF + i}, {s('T0')}, v{V_VOFF + i}")
+    if WITH_NORM:
+        for i in range(NI):                                            # the slot's logical segment (channels 8 seg .. + 7 of the chunk) * 32 bytes
+            e(f"v_bfe_u32 v{V_NSEG + i}, v{V_HRC + i}, 16, 2")
+            e(f"v_lshlrev_b32 v{V_NSEG + i}, 5, v{V_NSEG + i}")
     e(f"s_mul_i32 {s('HW')}, {s('H')}, {s('W')}")
     e(f"s_lshl_b32 {s('HW64')}, {s('HW')}, 6")                          # bytes of one 32-channel plane (< 2^31: the launcher checks)
     e(f"s_lshl_b32 {s('RS')}, {s('W')}, 6")                             # bytes between rows of a plane
@@ -776,6 +868,13 @@ def emit_prologue(b, with_gate=True):
         b.emit_group(g)
     for g in b.halo_items(0):
         b.emit_group(g)
+    if WITH_NORM:      # the first frame's table, then chunk 0's own normalisation (exposed, once per workgroup)
+        b.wait_all_lds()
+        b.norm_table_load()
+        b.norm_row()
+        e("s_waitcnt vmcnt(0)")
+        for g in b.norm_real_items(0):
+            b.emit_group(g)
     b.advance_staging()
     b.wait_all_lds()
     e("s_waitcnt vmcnt(0)")
@@ -785,7 +884,7 @@ def emit_prologue(b, with_gate=True):
 def generate():
     b = Body()
     e = b.e
-    emit_prologue(b)
+    emit_prologue(b, with_gate=not WITH_NORM)
     # ================= tile loop
     e(f"{PFX}_TILE:")
     b.tile_begin()
@@ -812,12 +911,12 @@ OPERANDS = """      :
 
 
 def main(objdir):
-    global WITH_RELU, PFX
+    global WITH_RELU, WITH_NORM, PFX
     n = 0
-    for relu, pfx, name in ((False, "S2L8", "convh8_body.inc"), (True, "S2L9", "convh8r_body.inc")):
-        WITH_RELU, PFX = relu, pfx
+    for relu, norm, pfx, name in ((False, False, "S2L8", "convh8_body.inc"), (True, False, "S2L9", "convh8r_body.inc"), (False, True, "S2LN", "convh8n_body.inc")):
+        WITH_RELU, WITH_NORM, PFX = relu, norm, pfx
         lines = generate()
-        clob = [f"v{r}" for r in range(0, V_LAST + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
+        clob = [f"v{r}" for r in range(0, (V_LAST_NORM if norm else V_LAST) + 1)] + [f"a{r}" for r in range(0, A_LAST + 1)] + [f"s{r}" for r in range(16, S_LAST + 1) if r not in (32, 33)]
         clob += ["vcc", "scc", "memory"]
         out = ["// GENERATED by csrc/gen_convh8_body.py -- do not edit; the generator is the source.", "asm volatile("]
         out += [f'    "{x}\\n\\t"' for x in lines]
@@ -825,8 +924,8 @@ def main(objdir):
         out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
         with open(os.path.join(objdir, name), "w") as f:
             f.write("\n".join(out) + "\n")
-        n = len(lines)
-    WITH_RELU, PFX = False, "S2L8"
+        n = n or len(lines)
+    WITH_RELU, WITH_NORM, PFX = False, False, "S2L8"
     return n
 
 

@@ -9,6 +9,7 @@ in eval mode (BatchNorm folded with its running statistics at pack time).  Infer
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -297,13 +298,17 @@ class SimpleUnetLight(nn.Module):
             off += n
         return dx, grads
 
-    def forward_train_frames_nhwc(self, x: torch.Tensor, update_running: bool = True, precision: str = "fp32"):
+    def forward_train_frames_nhwc(self, x: torch.Tensor, update_running: bool = True, precision: str = "fp32", fuse_norm=None):
         """x [F,H,W,3] -> (out, ctx): F successive ONE-FRAME train-mode calls in one set of launches (s2l_unet_train_forward_frames):
         each frame normalised with its own batch statistics, the running statistics moved once per frame in frame order,
         num_batches_tracked += F -- what the reference's loop does to the (frozen) net, bit for bit what F calls of
         forward_train_nhwc(x[f:f+1]) compute.  ctx feeds backward_train_frames (input gradient only).
         precision "bf16h": bf16 operands AND bf16 tensors between the kernels (s2l_unet_train_forward_frames_h: half the memory
-        traffic of "bf16"; fp32 accumulation and statistics; x / out / gradients at the boundary stay fp32)."""
+        traffic of "bf16"; fp32 accumulation and statistics; x / out / gradients at the boundary stay fp32).
+        fuse_norm ("bf16h" only; default: on for a FROZEN net, i.e. when no parameter requires a gradient): the activations whose only
+        reader is the next convolution at the same resolution (a0, a2, a4, a6, a8) are never stored -- that convolution normalises its
+        input tiles itself (s2l_unet_train_forward_frames_h_fused: the same bits; `bn_relu_h_kernel` leaves the chain for those layers).
+        The state then serves the input gradient only: `backward_train_frames(..., want_param_grads=True)` refuses it."""
         lib = _abi.load()
         if precision not in ("fp32", "bf16", "bf16h"):
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16h'")
@@ -320,6 +325,10 @@ class SimpleUnetLight(nn.Module):
             raise ValueError(f"U-Net input must be [F>=1,H>=4,W>=4,3], got {tuple(x.shape)}")
         table = self._table(tensors)
         half = precision == "bf16h"
+        if fuse_norm is None:      # (S2L_NO_FUSE_NORM=1: the A/B switch of tools/bench_train.py)
+            fuse_norm = half and not any(t.requires_grad for t in tensors) and not os.environ.get("S2L_NO_FUSE_NORM")
+        if fuse_norm and not half:
+            raise ValueError("fuse_norm belongs to the half-width chain (precision 'bf16h')")
         raw, raw16 = self._raw_blobs(tensors, table, precision != "fp32")
         out = torch.empty(F_, H, W, 3, dtype=torch.float32, device=dev)
         if half:
@@ -334,9 +343,10 @@ class SimpleUnetLight(nn.Module):
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             if half:
-                _abi.check(lib.s2l_unet_train_forward_frames_h(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
-                                                               1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
-                           "s2l_unet_train_forward_frames_h")
+                entry = lib.s2l_unet_train_forward_frames_h_fused if fuse_norm else lib.s2l_unet_train_forward_frames_h
+                _abi.check(entry(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
+                                 1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
+                           "s2l_unet_train_forward_frames_h" + ("_fused" if fuse_norm else ""))
             else:
                 _abi.check(lib.s2l_unet_train_forward_frames(p(raw), p(raw16), table, ctypes.c_float(float(bn.eps)), ctypes.c_float(momentum),
                                                              1 if update_running else 0, p(x), p(saved), p(scratch), p(out), H, W, F_, st),
@@ -346,13 +356,16 @@ class SimpleUnetLight(nn.Module):
             self._packed = self._packed_key = None
             self._packed16 = self._packed16_key = None
             self._packed16x3 = self._packed16x3_key = None
-        return out, (raw, x, saved, (F_, H, W), raw16)
+        return out, (raw, x, saved, (F_, H, W), raw16, bool(fuse_norm))
 
     def backward_train_frames(self, ctx, d_out: torch.Tensor, want_param_grads: bool = False):
         """d loss / d x [F,H,W,3] for a forward_train_frames_nhwc state.  want_param_grads (a net that still trains; fp32 tensors only):
         returns (d_x, {state-dict name: gradient}) -- the parameter gradients of the F one-frame calls, summed."""
         lib = _abi.load()
-        raw, x, saved, (F_, H, W), raw16 = ctx
+        raw, x, saved, (F_, H, W), raw16 = ctx[:5]
+        if want_param_grads and len(ctx) > 5 and ctx[5]:
+            raise _abi.S2LError("this forward state was made with fuse_norm (a frozen net's: the activations the weight gradients read were "
+                                "never stored); run forward_train_frames_nhwc(..., fuse_norm=False) for a net that trains")
         dev = x.device
         d = d_out.detach().to(torch.float32).contiguous()
         if d.shape != (F_, H, W, 3) or d.device != dev:

@@ -162,6 +162,35 @@ def test_frames_in_one_call_equal_one_call_per_frame(dev, F, fh, fw):
     assert torch.equal(o_c, o_b) and torch.equal(uc.backward_train_frames(c_c, d), dx_b)
 
 
+@pytest.mark.parametrize("F,fh,fw", [(1, 4, 4), (3, 37, 45), (5, 64, 48), (2, 130, 70), (3, 500, 500)])
+def test_normalise_inside_the_consuming_convolution_gives_the_same_bits(dev, F, fh, fw):
+    """`fuse_norm` (s2l_unet_train_forward_frames_h_fused, the frozen net's forward): BatchNorm + ReLU of a0, a2, a4, a6, a8 folded into the
+    convolution that reads them (convh8_norm_asm_kernel normalises the pre-BatchNorm halo tile in LDS: bn_relu_h_kernel's fma / max / round to
+    nearest even, zero padding applied to the ACTIVATION) == the two-kernel route, bit for bit: the output, the input gradient (whose backward
+    never reads those activations), the running statistics -- at sizes with partial tiles on every side, sub-tile images, three resolutions,
+    several frames (each its own statistics group: the table changes at frame boundaries inside a workgroup's tile range)."""
+    ua, ub = net(dev), net(dev)
+    rng = np.random.default_rng(7 * F + fh)
+    x = T(rng.random((F, fh, fw, 3), dtype=np.float32)).to(dev)
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+    o_a, c_a = ua.forward_train_frames_nhwc(x, precision="bf16h", fuse_norm=False)
+    o_b, c_b = ub.forward_train_frames_nhwc(x, precision="bf16h", fuse_norm=True)
+    assert torch.equal(o_a, o_b), float((o_a - o_b).abs().max())
+    assert torch.equal(ua.backward_train_frames(c_a, d), ub.backward_train_frames(c_b, d))
+    sa, sb = ua.state_dict(), ub.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    with pytest.raises(s2l._abi.S2LError):      # the fused state has no activations for the weight gradients
+        ub.backward_train_frames(c_b, d, want_param_grads=True)
+    with pytest.raises(ValueError):
+        ub.forward_train_frames_nhwc(x, precision="bf16", fuse_norm=True)
+    # the default: fused exactly when the net is frozen
+    for p_ in ub.parameters():
+        p_.requires_grad = False
+    assert ub.forward_train_frames_nhwc(x, precision="bf16h", update_running=False)[1][5] is True
+    assert ua.forward_train_frames_nhwc(x, precision="bf16h", update_running=False)[1][5] is False
+
+
 @pytest.mark.parametrize("fh,fw", [(64, 80), (500, 500)])
 def test_chain_against_the_fp32_chain(dev, fh, fw):
     u32, u16, uh = net(dev), net(dev), net(dev)
