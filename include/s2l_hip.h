@@ -432,8 +432,9 @@ int s2l_unet_train_forward_frames_h(const float* packed_raw, const uint16_t* pac
 /* ... for a FROZEN net (the backward is s2l_unet_train_backward_frames_h: no weight gradients): the BatchNorm + ReLU passes whose only
  * reader is the next 3x3 convolution at the same resolution (a0, a2, a4, a6, a8 of SimpleUnetLight.py:16-111's DoubleConvs) are folded into
  * that convolution -- it reads the pre-BatchNorm tensor and normalises its halo tiles in LDS with the per-frame scale / shift, the same
- * expression and rounding -- so `out`, every stored z and the statistics are the bits of s2l_unet_train_forward_frames_h; those five
- * activations' slots of `saved` are left unwritten. */
+ * expression and rounding --, a5 and a7 are formed inside the up-sampling that reads them, so `out`, every stored z and the statistics are
+ * the bits of s2l_unet_train_forward_frames_h; those seven activations' slots of `saved` are left unwritten (the frozen net's backward
+ * re-forms the two masks it needs from z). */
 int s2l_unet_train_forward_frames_h_fused(const float* packed_raw, const uint16_t* packed16_raw, const float* const* tensors_host, float bn_eps,
                                           float momentum, int update_running, const float* x, uint16_t* saved, float* scratch, float* out,
                                           int height, int width, int64_t n_frames, s2l_stream_t stream);

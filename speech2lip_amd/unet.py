@@ -306,8 +306,8 @@ class SimpleUnetLight(nn.Module):
         precision "bf16h": bf16 operands AND bf16 tensors between the kernels (s2l_unet_train_forward_frames_h: half the memory
         traffic of "bf16"; fp32 accumulation and statistics; x / out / gradients at the boundary stay fp32).
         fuse_norm ("bf16h" only; default: on for a FROZEN net, i.e. when no parameter requires a gradient): the activations whose only
-        reader is the next convolution at the same resolution (a0, a2, a4, a6, a8) are never stored -- that convolution normalises its
-        input tiles itself (s2l_unet_train_forward_frames_h_fused: the same bits; `bn_relu_h_kernel` leaves the chain for those layers).
+        reader is the next convolution at the same resolution (a0, a2, a4, a6, a8) or the up-sampling (a5, a7) are never stored -- the
+        reader normalises its input itself (s2l_unet_train_forward_frames_h_fused: the same bits; `bn_relu_h_kernel` leaves the chain).
         The state then serves the input gradient only: `backward_train_frames(..., want_param_grads=True)` refuses it."""
         lib = _abi.load()
         if precision not in ("fp32", "bf16", "bf16h"):
