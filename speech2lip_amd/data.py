@@ -527,14 +527,20 @@ def _release_shared(pool, blocks, free, readers):
                 held.append(free.get(timeout=5))      # (a worker busy for another streamer comes back within one decode)
         except queue.Empty:
             pass                                       # (the workers' own cap on cached mappings bounds what is left)
-        for i, w in enumerate(held):
+        sent = []
+        for i, w in enumerate(held):              # ask every worker first, then collect: their munmaps (hundreds of MB each) run side by side
             try:
                 w.stdin.write(line + "\n")
                 w.stdin.flush()
-                if not w.stdout.readline().strip():
-                    held[i] = _replace_decode_worker(w)
+                sent.append(i)
             except Exception:
                 held[i] = _replace_decode_worker(w)
+        for i in sent:
+            try:
+                if not held[i].stdout.readline().strip():
+                    held[i] = _replace_decode_worker(held[i])
+            except Exception:
+                held[i] = _replace_decode_worker(held[i])
         for w in held:
             free.put(w)
     for b in blocks or []:

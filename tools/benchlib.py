@@ -772,8 +772,18 @@ def bench_dropin_trainer(dev, n_frames=48, iters=200):
         kw = dict(per_step=K, collate=False, device=dev, sync_fields=late, workers=int(os.environ.get("S2L_BENCH_K8_WORKERS", "0")) or None)
         with s2l.FramePrefetcher(ds, order[:2 * K], depth=2 * K, **kw) as pf:
             run(tr, it0, pf, K, pipelined=True)
-        with s2l.FramePrefetcher(ds, order, depth=3 * K, **kw) as pf:
-            entry["train_steps_K8"] = run(tr, it0, pf, K, pipelined=True)
+        # (the interpreter hands the lock over every 5 ms by default: with eight loader threads taking turns the training thread's launches
+        #  arrive in bursts: 200 us in this leg -- same-call A/B 1.90 -> 1.74 ms per frame early, 5.74 -> 5.41 late; S2L_BENCH_SWITCH_US=0 keeps
+        #  the default)
+        sw_old = sys.getswitchinterval()
+        sw_us = float(os.environ.get("S2L_BENCH_SWITCH_US", "200"))
+        if sw_us > 0:
+            sys.setswitchinterval(sw_us * 1e-6)
+        try:
+            with s2l.FramePrefetcher(ds, order, depth=3 * K, **kw) as pf:
+                entry["train_steps_K8"] = run(tr, it0, pf, K, pipelined=True)
+        finally:
+            sys.setswitchinterval(sw_old)
         res[phase] = entry
         del tr
         torch.cuda.empty_cache()
