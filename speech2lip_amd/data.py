@@ -434,6 +434,7 @@ def shutdown_decode_workers() -> None:
     still open must be closed first."""
     import queue
     global _DECODE_FREE
+    _drop_cached_blocks()                                         # (the blocks kept for the next streamer go with the workers that map them)
     workers, _DECODE_WORKERS[:] = list(_DECODE_WORKERS), []
     if _DECODE_FREE is not None:
         try:
@@ -490,7 +491,39 @@ def _ask_decode_worker(free, line: str) -> str:
     return ans
 
 
-def _release_shared(pool, blocks, free, readers):
+_SHM_CACHE = {}                 # size -> [SharedMemory]: blocks of closed streamers, kept for the next one (bounded)
+_SHM_CACHE_MAX = 1536 << 20     # bytes kept at most: three slots of a 100-frame 500 x 500 streamer are 0.8 GB
+
+
+def _take_block(size: int):
+    """A shared-memory block of `size` bytes: one a closed streamer gave back (already mapped in the decode workers, its pages already
+    faulted in -- creating 0.4 - 0.8 GB afresh per clip cost ~8 % of a 600-frame clip's time in zero-fills, mmaps and munmaps), or a new one."""
+    from multiprocessing import shared_memory
+    pool = _SHM_CACHE.get(size)
+    if pool:
+        return pool.pop()
+    return shared_memory.SharedMemory(create=True, size=size)
+
+
+def _cached_bytes() -> int:
+    return sum(size * len(v) for size, v in _SHM_CACHE.items())
+
+
+def _drop_cached_blocks() -> None:
+    for blocks in _SHM_CACHE.values():
+        for b in blocks:
+            try:
+                b.close()
+            except Exception:
+                pass
+            try:
+                b.unlink()
+            except Exception:
+                pass
+    _SHM_CACHE.clear()
+
+
+def _release_shared(pool, blocks, free, readers, keep=False):
     """What a streamer / prefetcher owns outside the Python heap, given back exactly once (`close()`, `with`, garbage collection or
     interpreter exit -- `weakref.finalize`; it must not reference the owner): the pool's threads, the reader processes, the decode
     workers' mappings of the blocks, and the shared-memory blocks themselves."""
@@ -519,6 +552,17 @@ def _release_shared(pool, blocks, free, readers):
                 f.close()
             except Exception:
                 pass
+    if keep and blocks:                  # a streamer's blocks go back to the cache while it has room (the workers keep their mappings of those)
+        import atexit
+        if not _SHM_CACHE:
+            atexit.register(_drop_cached_blocks)
+        rest = []
+        for b in blocks:
+            if _cached_bytes() + b.size <= _SHM_CACHE_MAX:
+                _SHM_CACHE.setdefault(b.size, []).append(b)
+            else:
+                rest.append(b)
+        blocks = rest
     if free is not None and blocks:      # the shared decode workers drop their mappings (else an unlinked block stays resident in each)
         line = json.dumps({"detach": [b.name for b in blocks]})
         held = []
@@ -568,9 +612,9 @@ class _OwnsShared:
     train.py:100-122, cleans up after itself: so do these)."""
     _finalizer = None
 
-    def _own(self, pool, blocks=None, free=None, readers=None):
+    def _own(self, pool, blocks=None, free=None, readers=None, keep=False):
         import weakref
-        self._finalizer = weakref.finalize(self, _release_shared, pool, list(blocks or []), free, list(readers or []))
+        self._finalizer = weakref.finalize(self, _release_shared, pool, list(blocks or []), free, list(readers or []), keep)
 
     def _submit(self, name, *args):
         import weakref
@@ -637,15 +681,15 @@ class ClipStreamer(_OwnsShared):
                 if self.with_frames:
                     self.shm_frames = []
                     for _ in range(ns):
-                        self.shm_frames.append(shared_memory.SharedMemory(create=True, size=B * FH * FW * 3))
+                        self.shm_frames.append(_take_block(B * FH * FW * 3))
                         blocks.append(self.shm_frames[-1])
                 if self.with_pose:
                     self.shm_coords = []
                     for _ in range(ns):
-                        self.shm_coords.append(shared_memory.SharedMemory(create=True, size=B * FH * FW * 2 * 4))
+                        self.shm_coords.append(_take_block(B * FH * FW * 2 * 4))
                         blocks.append(self.shm_coords[-1])
         finally:
-            self._own(self.pool, blocks, self.procs)      # (from here on whatever exists is released, also when the rest of __init__ raises)
+            self._own(self.pool, blocks, self.procs, keep=True)      # (from here on whatever exists is released, also when the rest of __init__ raises)
         pin = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype).pin_memory() for _ in range(ns)]
         on = lambda *shape, dtype: [torch.empty(*shape, dtype=dtype, device=self.dev) for _ in range(ns)]
         self.h_coord = pin(B, FH, FW, 2, dtype=torch.float32) if self.with_pose else None

@@ -220,9 +220,10 @@ def test_clip_streamer_and_frame_writer_equal_the_serial_forms(dev, tmp_path):
 
 def test_clip_streamer_abandoned_mid_clip_leaves_nothing_behind(dev, tmp_path):
     """An exception half way through a clip (what a failing kernel call or a full disk does to inference.py:140-178's loop): the
-    streamer's shared-memory blocks are unlinked, the decode workers drop their mappings of them and -- once the process-wide pool is
-    shut down -- no child process of this test is left; a worker that dies is replaced instead of poisoning the pool; the validity
-    promise of a yielded batch holds for work queued one iteration late."""
+    streamer's shared-memory blocks go back to the process's bounded cache (the next streamer takes the same blocks: no new segment, no
+    new mapping in the decode workers), whether it is closed or only collected; blocks beyond the cache's bound are detached and
+    unlinked; once the process-wide pool is shut down no segment and no child process of this test is left; a worker that dies is
+    replaced instead of poisoning the pool; the validity promise of a yielded batch holds for work queued one iteration late."""
     import gc
     import os
     import psutil
@@ -234,6 +235,7 @@ def test_clip_streamer_abandoned_mid_clip_leaves_nothing_behind(dev, tmp_path):
     me = psutil.Process()
     from multiprocessing import resource_tracker
     resource_tracker.ensure_running()          # (python's own helper process for shared memory: it stays for the life of the interpreter)
+    D.shutdown_decode_workers()                # (a clean slate: earlier tests of this process left workers and cached blocks)
     before = {c.pid for c in me.children(recursive=True)}
     shm = lambda name: os.path.exists("/dev/shm/" + name.lstrip("/"))
 
@@ -247,24 +249,35 @@ def test_clip_streamer_abandoned_mid_clip_leaves_nothing_behind(dev, tmp_path):
             for k, clip in enumerate(st):
                 if k == 3:
                     raise Boom()
-    assert st.closed and not any(shm(n) for n in names)
+    cached = lambda: sorted(b.name for v in D._SHM_CACHE.values() for b in v)
+    assert st.closed and cached() == sorted(names) and D._cached_bytes() <= D._SHM_CACHE_MAX
     workers = [w.pid for w in D._DECODE_WORKERS]
     assert len(workers) == 3
-    for pid in workers:                      # the shared workers hold no mapping of the closed streamer's blocks
-        with open(f"/proc/{pid}/maps") as f:
-            assert not [ln for ln in f if any(n.lstrip("/") in ln for n in names)], pid
     st.close()                               # idempotent
+    assert cached() == sorted(names)
     with pytest.raises(RuntimeError):
         next(iter(st))
 
-    # garbage collection alone releases an un-closed streamer
+    # garbage collection alone releases an un-closed streamer -- and it had taken the SAME blocks: nothing new was created or mapped
     st = s2l.ClipStreamer(ds, dev, batch=4, workers=3, mode="process")
-    names = [b.name for b in (st.shm_frames + st.shm_coords)]
+    assert sorted(b.name for b in (st.shm_frames + st.shm_coords)) == sorted(names) and cached() == []
     it = iter(st)
     next(it)
     del it, st
     gc.collect()
-    assert not any(shm(n) for n in names)
+    assert cached() == sorted(names)
+    # beyond the cache's bound a closed streamer's blocks are detached from the workers and unlinked
+    old_max, D._SHM_CACHE_MAX = D._SHM_CACHE_MAX, 0
+    try:
+        with s2l.ClipStreamer(ds, dev, batch=6, workers=3, mode="process") as big:      # (another batch size: other block sizes, new blocks)
+            extra = [b.name for b in (big.shm_frames + big.shm_coords)]
+            assert not set(extra) & set(names) and sum(len(c.names) for c in big) == len(ds)
+        assert not any(shm(n) for n in extra)
+        for pid in workers:
+            with open(f"/proc/{pid}/maps") as f:
+                assert not [ln for ln in f if any(n.lstrip("/") in ln for n in extra)], pid
+    finally:
+        D._SHM_CACHE_MAX = old_max
 
     # a decode worker that dies is replaced; the clip still comes out right
     psutil.Process(D._DECODE_WORKERS[0].pid).kill()
@@ -293,6 +306,7 @@ def test_clip_streamer_abandoned_mid_clip_leaves_nothing_behind(dev, tmp_path):
 
     D.shutdown_decode_workers()
     assert not ({c.pid for c in me.children(recursive=True)} - before)
+    assert cached() == [] and not any(shm(n) for n in names)                         # the cache goes with the workers that map it
     with s2l.ClipStreamer(ds, dev, batch=8, first=0, count=8, workers=2, mode="process") as st:      # the pool comes back on demand
         assert sum(len(c.names) for c in st) == 8
     D.shutdown_decode_workers()
