@@ -25,6 +25,9 @@ __device__ inline void conv_stage(const float* __restrict__ wT, const float* __r
     const int fb = item / (COUT * TOUT);
     const float* x = xin + fb * CIN * TIN;
     float acc = b[o];
+    // (x8: 24 weight loads in flight per thread instead of 3 -- the chain of fmas keeps its order, so the bits do; one frame per call is a
+    //  chain of dependent L2 round trips: 22 -> 11 us for the encoder at F = 1)
+#pragma unroll 8
     for (int c = 0; c < CIN; ++c) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -68,15 +71,68 @@ __global__ __launch_bounds__(256) void audio_encode_kernel(const float* __restri
     const bool mine = fb < FB;      // (FB = 1: one wave works, the others only keep the barrier)
     float acc = packed[OFF_F0B + o];
     if (mine) {
+#pragma unroll 16
       for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F0W + k * 64 + o], y4[fb * 64 + k], acc);
       f1[fb * 64 + o] = lrelu(acc);
     }
     __syncthreads();
     acc = packed[OFF_F2B + o];
     if (mine) {
+#pragma unroll 16
       for (int k = 0; k < 64; ++k) acc = fmaf(packed[OFF_F2W + k * 64 + o], f1[fb * 64 + k], acc);
       if (f0 + fb < n) feat[(f0 + fb) * 64 + o] = acc;
     }
+  }
+}
+
+// The encoder for calls of fewer than kFB frames (the reference's one-frame-per-call mode, inference.py:129-159): one frame per block, and
+// the block first brings ALL of the encoder's weights -- one contiguous 131-KB section of the packed blob -- into LDS with 16-byte loads
+// from every thread (one L2 round trip for the lot), then runs the same stages on them.  audio_encode_kernel<1> walked six stages of
+// dependent "load a weight from L2, fma" chains: 22.8 us per frame; the chains are the same here (same operands, same order: the same
+// bits) with LDS latencies in them.
+constexpr int kEncFloats = (int)(OFF_G0 - OFF_C0W);
+constexpr int kEncLds = (kEncFloats + 29 * 16 + 32 * 8 + 32 * 4 + 64 * 2 + 64 + 64) * 4;
+static_assert(OFF_C0W % 4 == 0 && kEncFloats % 4 == 0 && kEncLds <= 160 * 1024, "the encoder's section is whole 16-byte pieces and fits the LDS");
+__global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __restrict__ packed, const float* __restrict__ windows,
+                                                              float* __restrict__ feat, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) float enc_smem[];
+  float* const wl = enc_smem;                       // the section [OFF_C0W, OFF_G0) of `packed`
+  float* const x0 = wl + kEncFloats;
+  float* const y1 = x0 + 29 * 16;
+  float* const y2 = y1 + 32 * 8;
+  float* const y3 = y2 + 32 * 4;
+  float* const y4 = y3 + 64 * 2;
+  float* const f1 = y4 + 64;
+  const int64_t f = blockIdx.x;
+  {
+    const f4* src = reinterpret_cast<const f4*>(packed + OFF_C0W);
+    f4* dst = reinterpret_cast<f4*>(wl);
+    for (int i = threadIdx.x; i < kEncFloats / 4; i += 256) dst[i] = src[i];
+  }
+  for (int i = threadIdx.x; i < 16 * 29; i += 256) {      // windows [t 16][c 29] -> x0 [c][t]
+    const int t = i / 29, c = i - t * 29;
+    x0[c * 16 + t] = windows[f * 16 * 29 + i];
+  }
+  __syncthreads();
+  const float* w = wl - OFF_C0W;                      // so that the blob's offsets address the copy
+  conv_stage<29, 32, 16, 1>(w + OFF_C0W, w + OFF_C0B, x0, y1);
+  conv_stage<32, 32, 8, 1>(w + OFF_C2W, w + OFF_C2B, y1, y2);
+  conv_stage<32, 64, 4, 1>(w + OFF_C4W, w + OFF_C4B, y2, y3);
+  conv_stage<64, 64, 2, 1>(w + OFF_C6W, w + OFF_C6B, y3, y4);
+  const int o = threadIdx.x & 63;
+  const bool mine = threadIdx.x < 64;
+  float acc = w[OFF_F0B + o];
+  if (mine) {
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) acc = fmaf(w[OFF_F0W + k * 64 + o], y4[k], acc);
+    f1[o] = lrelu(acc);
+  }
+  __syncthreads();
+  acc = w[OFF_F2B + o];
+  if (mine) {
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) acc = fmaf(w[OFF_F2W + k * 64 + o], f1[k], acc);
+    feat[f * 64 + o] = acc;
   }
 }
 
@@ -223,17 +279,22 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 
 // q0[f] = W0 (Wa a_f + Wt PE(idx_f) + bsum0) + b0 ; q5[f] likewise with the skip projections.
 // 256 threads: thread n owns output feature n for kFB frames.
+// FB frames per block: kFB for clips, 1 for calls of fewer than kFB frames (as audio_encode_kernel: the same fma chains; with two
+// accumulators instead of eight the compiler keeps 32 pairs of weight loads in flight: 21 -> 9 us at one frame per call).
+template <int FB>
 __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restrict__ packed,
                                                            const float* __restrict__ feat,
                                                            const int64_t* __restrict__ frame_idx,
                                                            float* __restrict__ q0, float* __restrict__ q5, int64_t n) {
+  constexpr int kFB = FB;      // (shadows the namespace constant inside this kernel)
+  constexpr int kUnroll = FB == 1 ? 32 : 8;
   __shared__ float a[kFB][64];
   __shared__ float pe[kFB][20];
   __shared__ float s0[kFB][256];
   __shared__ float s5[kFB][256];
   const int64_t f0 = (int64_t)blockIdx.x * kFB;
   const int tid = threadIdx.x;
-  {
+  if ((tid >> 6) < kFB) {
     const int fb = tid >> 6, k = tid & 63;
     const int64_t f = f0 + fb < n ? f0 + fb : n - 1;
     a[fb][k] = feat[f * 64 + k];
@@ -252,7 +313,7 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
     acc5[fb] = packed[OFF_BSUM5 + tid];
   }
   // (x8: eight pairs of weight loads in flight per thread; the fma chains keep their order.  One frame per call: 28 -> 21 us)
-#pragma unroll 8
+#pragma unroll kUnroll
   for (int k = 0; k < 64; ++k) {
     const float w0 = packed[OFF_WAT + k * 256 + tid], w5 = packed[OFF_WAST + k * 256 + tid];
 #pragma unroll
@@ -261,6 +322,7 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
       acc5[fb] = fmaf(w5, a[fb][k], acc5[fb]);
     }
   }
+#pragma unroll kUnroll
   for (int k = 0; k < 20; ++k) {
     const float w0 = packed[OFF_WTT + k * 256 + tid], w5 = packed[OFF_WTST + k * 256 + tid];
 #pragma unroll
@@ -277,7 +339,7 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
     acc5[fb] = packed[OFF_B5 + tid];
   }
   __syncthreads();
-#pragma unroll 8
+#pragma unroll kUnroll
   for (int k = 0; k < 256; ++k) {
     const float w0 = packed[OFF_W0T + k * 256 + tid], w5 = packed[OFF_W5AT + k * 256 + tid];
 #pragma unroll
@@ -384,8 +446,13 @@ extern "C" int s2l_audio_encode(const float* packed, const float* windows, float
   if (n == 0) return S2L_OK;
   if (!packed || !windows || !feat) return S2L_E_NULL;
   if (n < s2l::kFB) {
-    hipLaunchKernelGGL(s2l::audio_encode_kernel<1>, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), packed, windows,
-                       feat, n);
+    static s2l::LdsOptIn flag;
+    int dev = 0, n_cu = 0;
+    int rc = s2l::current_device_cus(&dev, &n_cu);
+    if (rc) return rc;
+    if ((rc = s2l::ensure_dynamic_lds(reinterpret_cast<const void*>(s2l::audio_encode_lds_kernel), s2l::kEncLds, flag, dev))) return rc;
+    hipLaunchKernelGGL(s2l::audio_encode_lds_kernel, dim3((unsigned)n), dim3(256), s2l::kEncLds, static_cast<hipStream_t>(stream), packed,
+                       windows, feat, n);
   } else {
     const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
     hipLaunchKernelGGL(s2l::audio_encode_kernel<s2l::kFB>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -399,9 +466,14 @@ extern "C" int s2l_frame_vectors(const float* packed, const float* feat, const i
   if (n < 0) return S2L_E_SIZE;
   if (n == 0) return S2L_OK;
   if (!packed || !feat || !frame_idx || !q0 || !q5) return S2L_E_NULL;
-  const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
-  hipLaunchKernelGGL(s2l::frame_vectors_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     packed, feat, frame_idx, q0, q5, n);
+  if (n < s2l::kFB) {
+    hipLaunchKernelGGL(s2l::frame_vectors_kernel<1>, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), packed, feat,
+                       frame_idx, q0, q5, n);
+  } else {
+    const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
+    hipLaunchKernelGGL(s2l::frame_vectors_kernel<s2l::kFB>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       packed, feat, frame_idx, q0, q5, n);
+  }
   return (int)hipGetLastError();
 }
 
