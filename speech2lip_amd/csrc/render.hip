@@ -46,10 +46,12 @@ struct RenderArgs {
 //   kWide   3 groups, 12 x 1: one frame per tile -- no wasted frame slots when F is not a multiple of 12;
 //   kSingle 1 group,   4 x 1: 64 samples per tile, so that ONE frame spreads over the whole chip (the reference's per-frame mode).
 // Frames are bit-identical whichever shape rendered them (every sample column sees the same MFMA sequence).
-enum RenderShape { kLong = 0, kWide = 1, kSingle = 2 };
+//   kFeat   the feature-split tile (render_fs_kernel, gen_render_fs_body.py): 16 samples per tile, the four waves own 64 features each and
+//           exchange the activations through LDS: a tile is 7 x 256 MFMAs per wave instead of 7 x 1024 -- ONE frame in a third of the time.
+enum RenderShape { kLong = 0, kWide = 1, kSingle = 2, kFeat = 3 };
 struct ShapeDims { int g, pgt, ft; };
 __host__ __device__ constexpr ShapeDims shape_dims(int shape) {
-  return shape == kLong ? ShapeDims{3, 1, 12} : shape == kWide ? ShapeDims{3, 12, 1} : ShapeDims{1, 4, 1};
+  return shape == kLong ? ShapeDims{3, 1, 12} : shape == kWide ? ShapeDims{3, 12, 1} : shape == kSingle ? ShapeDims{1, 4, 1} : ShapeDims{1, 1, 1};
 }
 
 constexpr int kRing = 9;                       // 16 KiB steps resident in LDS (gen_render_body.py: KRING)
@@ -105,6 +107,27 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderArgs a) {
   }
 }
 
+// ---- the feature-split tile (csrc/gen_render_fs_body.py has the design): 16 samples per tile; wave w owns features 64 w .. 64 w + 63
+constexpr int kFsRingPerWave = 8 * 4096;                       // the wave's private ring of eight 4-KiB pieces of its own slabs
+constexpr int kFsExchange = 4 * kFsRingPerWave;                // two 16-KiB activation blocks [M-block][lane][4] behind the rings
+constexpr int kFsLdsBytes = kFsExchange + 2 * 16384;
+static_assert(kFsLdsBytes == 160 * 1024, "gen_render_fs_body.py: LDS_BYTES");
+__global__ __launch_bounds__(256) void render_fs_kernel(RenderArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * kFsRingPerWave);
+  const int nfg = __builtin_amdgcn_readfirstlane(a.nfg);
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * blockIdx.x / gridDim.x));
+  const int tile_end = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * (blockIdx.x + 1) / gridDim.x));
+  const int fg0 = __builtin_amdgcn_readfirstlane(tile0 % nfg), pg0 = __builtin_amdgcn_readfirstlane(tile0 / nfg);
+  const float* wb = a.packed + OFF_WMLP + (int64_t)wave * 4 * kSlab;      // the wave's four slabs of layer 0 (64 contiguous KiB per layer)
+  const float* wout = a.packed + OFF_WOUT;
+  const float* biasp = a.packed + OFF_BIAS;
+#include "render_fs_body.inc"
+}
+
 }  // namespace s2l
 
 // Workgroups the persistent renderer may occupy on each device (0 = one per CU).  A multi-GPU host that overlaps the RCCL
@@ -124,7 +147,7 @@ extern "C" int s2l_set_render_cus(int n_workgroups) {
 // 0 = choose per call (below), 1 + shape = always that shape (tests, A/B runs)
 static std::atomic<int> g_render_shape{0};
 extern "C" int s2l_set_render_shape(int mode) {
-  if (mode < 0 || mode > 3) return S2L_E_SIZE;
+  if (mode < 0 || mode > 4) return S2L_E_SIZE;
   g_render_shape.store(mode, std::memory_order_relaxed);
   return S2L_OK;
 }
@@ -139,8 +162,8 @@ extern "C" int s2l_render_cu_limit(int dev) { return (dev >= 0 && dev < s2l::kMa
 static int pick_render_shape(int64_t npg, int64_t n_frames, int n_cu) {
   double best = 0;
   int pick = s2l::kLong;
-  const double cost[3] = {1.0, 1.03, 0.36};
-  for (int shp = 0; shp < 3; ++shp) {
+  const double cost[4] = {1.0, 1.03, 0.36, 0.105};      // (a feature-split tile: a quarter of the single tile's MFMAs + a barrier pair per layer)
+  for (int shp = 0; shp < 4; ++shp) {
     const s2l::ShapeDims d = s2l::shape_dims(shp);
     const int64_t tiles = ((npg + d.pgt - 1) / d.pgt) * ((n_frames + d.ft - 1) / d.ft);
     // a persistent workgroup owns a contiguous range of ceil / floor(tiles / grid) tiles: the longest range sets the time
@@ -165,7 +188,7 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   a.npg = (int)((hw + kTilePixels - 1) / kTilePixels);
 
   // per-device one-time setup (CU count, >64 KiB dynamic-LDS opt-in), thread-safe: s2l_common.h
-  static LdsOptIn lds_flags[3];
+  static LdsOptIn lds_flags[4];
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
@@ -178,10 +201,11 @@ extern "C" int s2l_render_lip(const float* packed, const float* p0, const float*
   const int64_t ntiles = (int64_t)((a.npg + d.pgt - 1) / d.pgt) * a.nfg;
   if (ntiles > 0x7fffffff) return S2L_E_SIZE;
   a.ntiles = (int)ntiles;
-  void (*const kern[3])(RenderArgs) = {render_tiles_kernel<kLong>, render_tiles_kernel<kWide>, render_tiles_kernel<kSingle>};
-  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[shape]), kLdsBytes, lds_flags[shape], dev))) return rc;
-  // persistent: one workgroup per CU (151 KiB of LDS and 4 x 512 registers fill a CU)
+  void (*const kern[4])(RenderArgs) = {render_tiles_kernel<kLong>, render_tiles_kernel<kWide>, render_tiles_kernel<kSingle>, render_fs_kernel};
+  const int lds_bytes = shape == kFeat ? kFsLdsBytes : kLdsBytes;
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern[shape]), lds_bytes, lds_flags[shape], dev))) return rc;
+  // persistent: one workgroup per CU (151 - 160 KiB of LDS and 4 x 512 registers fill a CU)
   const int grid = a.ntiles < n_cu ? a.ntiles : n_cu;
-  hipLaunchKernelGGL(kern[shape], dim3(grid), dim3(256), kLdsBytes, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(kern[shape], dim3(grid), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }

@@ -148,7 +148,7 @@ extern "C" int s2l_render_lip_split(const float* packed, const void* packed16, c
     const double t = (double)((tiles + grid - 1) / grid) * cost[shp];
     if (shp == 0 || t < best * 0.97) best = t, shape = shp;
   }
-  if (const int forced = s2l_render_shape_mode()) shape = forced - 1;
+  if (const int forced = s2l_render_shape_mode(); forced >= 1 && forced <= 3) shape = forced - 1;      // (4 = the exact renderer's feature-split tile: not a shape of this kernel)
   const Shape16Dims d = shape16_dims(shape);
   a.nfg = (int)((n_frames + d.ft - 1) / d.ft);
   const int64_t ntiles = (int64_t)((a.npg + d.pgt - 1) / d.pgt) * a.nfg;

@@ -55,7 +55,8 @@ def test_config2_1000_frames_96(sd, dev):
 
 @pytest.mark.parametrize("h,w,frames", [(96, 96, (1, 5, 12, 16, 25)), (64, 64, (1, 16)), (5, 7, (1, 3, 13)), (1, 1, (1, 2)), (12, 20, (1, 7))])
 def test_render_tile_shapes_give_the_same_bits(sd, dev, h, w, frames):
-    """The three tile shapes of the renderer (16 px x 12 frames, 192 px x 1 frame, 64 px x 1 frame; csrc/gen_render_body.py)
+    """The tile shapes of the renderer (16 px x 12 frames, 192 px x 1 frame, 64 px x 1 frame: csrc/gen_render_body.py; and the feature-split
+    tile, 16 px x 1 frame with the four waves owning 64 features each: csrc/gen_render_fs_body.py, mode 4)
     render every frame to the same bits: each sample column sees the same MFMA sequence, only the tiling differs.  Includes
     images smaller than one tile block (5x7 = 3 pixel groups of a 12-group block: table rows are clamped, stores masked), the
     auto-selection, and -- for one frame per call, the reference's mode (inference.py:140-159) -- the CPU oracle."""
@@ -69,13 +70,13 @@ def test_render_tile_shapes_give_the_same_bits(sd, dev, h, w, frames):
         _abi.check(lib.s2l_set_render_shape(1), "s2l_set_render_shape")
         ref = m.render_clip(win, idx, h, w)
         for f in frames:
-            for mode in (2, 3, 0):
+            for mode in (2, 3, 4, 0):
                 _abi.check(lib.s2l_set_render_shape(mode), "s2l_set_render_shape")
                 got = m.render_clip(win[:f], idx[:f], h, w)
                 assert torch.equal(got, ref[:f]), (h, w, f, mode, float((got - ref[:f]).abs().max()))
     finally:
         lib.s2l_set_render_shape(0)
-    assert lib.s2l_set_render_shape(4) != 0
+    assert lib.s2l_set_render_shape(5) != 0
     with torch.no_grad():
         o = O.render_clip(sd, win[:1].cpu(), [100], h, w)[0]
     close(m.render_clip(win[:1], idx[:1], h, w)[0], o)
