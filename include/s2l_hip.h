@@ -117,11 +117,12 @@ int64_t s2l_render16_packed_halves(void);
 int s2l_pack_render16(const float* packed, void* packed16, s2l_stream_t stream);
 int s2l_render_lip_split(const float* packed, const void* packed16, const float* p0, const float* p5, const float* q0,
                          const float* q5, float* out, int64_t hw, int64_t n_frames, s2l_stream_t stream);
-/* The renderer has three tile shapes (4 waves x G groups of 16 samples): 16 pixels x 12 frames (clips), 192 pixels x 1 frame
- * (clip lengths that are not multiples of 12) and 64 pixels x 1 frame (one frame per call, the reference's own mode,
- * inference.py:129,140-159: the whole chip works on the one frame).  s2l_render_lip picks the one with the smallest estimated time;
- * frames are bit-identical whichever shape rendered them.  s2l_set_render_shape: 0 = choose per call (default), 1 / 2 / 3 = always
- * the 12-frame / 192-pixel / 64-pixel shape (tests and A/B measurements; process-wide). */
+/* The renderer has four tile shapes: 16 pixels x 12 frames (clips), 192 pixels x 1 frame (clip lengths that are not multiples of 12),
+ * 64 pixels x 1 frame (4 waves x 16 samples, every wave all 256 features) and the FEATURE-SPLIT tile of 16 pixels x 1 frame whose four
+ * waves own 64 features each and exchange the activations through LDS (one or a few frames per call, the reference's own mode,
+ * inference.py:129,140-159: a 64 x 64 frame takes 66 us instead of 140).  s2l_render_lip picks the one with the smallest estimated time;
+ * frames are bit-identical whichever shape rendered them.  s2l_set_render_shape: 0 = choose per call (default), 1 / 2 / 3 / 4 = always
+ * the 12-frame / 192-pixel / 64-pixel / feature-split shape (tests and A/B measurements; process-wide). */
 int s2l_set_render_shape(int mode);
 /* Cap on the persistent renderer's workgroups ON THE CURRENT DEVICE (hipGetDevice of the calling thread; 0 = one per CU, the
  * default).  A multi-GPU host that overlaps RCCL with rendering passes CUs - k so that k CUs stay free for RCCL's kernels;

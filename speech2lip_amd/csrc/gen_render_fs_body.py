@@ -30,6 +30,10 @@ import os
 import sys
 
 NLAYERS, RING, PIECE, NPOS, NREAL = 7, 8, 4096, 120, 116
+LOOK = int(os.environ.get("S2L_FS_LOOK", "6"))     # A quads requested ahead of the one the MFMAs are on (register sets: LOOK + 2)
+NSETS = LOOK + 2
+assert (NPOS - NREAL) * 4 % NSETS == 0 and NPOS * 4 % NSETS == 0, "the A sets rotate with the quad index: the skipped positions and a tile must be whole rotations"
+EXP = int(os.environ.get("S2L_FS_EXP", "0"))      # pricing builds (results wrong): 1 no exchange (writes, barrier, reads), 2 nobody waits for a piece, 4 no MFMAs
 LDS_RING_PER_WAVE = RING * PIECE                  # 32 KiB
 LDS_X = 4 * LDS_RING_PER_WAVE                     # two exchange blocks of 16 KiB behind the four rings
 LDS_BYTES = LDS_X + 2 * 16384                     # 163 840 = 160 KiB
@@ -38,7 +42,7 @@ V_IN, V_ACC, V_P0, V_Q0, V_P5, V_Q5 = 0, 64, 80, 144, 208, 224
 V_LANE16, V_QOFF, V_OWNQ, V_OWNP, V_RINGA, V_XW, V_XR, V_PIX, V_PIXOFF, V_TMP, V_ZERO = 240, 241, 242, 243, 244, 245, 246, 247, 248, 249, 250
 V_LAST = 250
 A_BIAS, A_BOUT, A_RGB, A_W = 0, 112, 116, 120
-A_LAST = 135
+A_LAST = A_W + 4 * NSETS - 1
 
 
 def _scalar_map(first, singles, pairs):
@@ -106,7 +110,8 @@ class Body:
             return
         last = len(self.vm) - 1 - self.vm[::-1].index(tag)      # the NEWEST operation that carries the tag
         newer = len(self.vm) - 1 - last
-        self.e(f"s_waitcnt vmcnt({min(newer, 63)})")
+        if not (EXP & 2 and tag[0] == "D"):
+            self.e(f"s_waitcnt vmcnt({min(newer, 63)})")
         self.vm = self.vm[len(self.vm) - newer:] if newer else []
 
     def wait_all_vm(self):
@@ -141,16 +146,17 @@ class Body:
     def a_read(self, p, quad):
         """A quad `quad` (0..3) of stream position p -> register set (global quad index) % 4"""
         g = p * 4 + quad
-        reg = A_W + 4 * (g % 4)
+        reg = A_W + 4 * (g % NSETS)
         if quad == 0:
             self.wait_vm(("D", p))                      # the piece has landed
         self.lds_op(f"ds_read_b128 a[{reg}:{reg + 3}], v{V_RINGA} offset:{(p % RING) * PIECE + quad * 1024}", ("A", g))
 
     # ---- one M-block (or the output layer): 16 quads = stream positions p0 .. p0 + 3
     def block(self, p0, dst, first_c, tucks=None):
-        """dst: 'v[..]' / 'a[..]' accumulator quad; first_c: srcC of the first MFMA (an MFMA's vdst and srcC are both VGPRs or both AGPRs: a
+        """(LOOK quads ahead: with two, an MFMA chain stood still whenever a piece's 4 KiB landing in LDS delayed its next A read.)
+        dst: 'v[..]' / 'a[..]' accumulator quad; first_c: srcC of the first MFMA (an MFMA's vdst and srcC are both VGPRs or both AGPRs: a
         VGPR accumulator takes its bias by four v_accvgpr_read first -- the same value enters the chain); tucks: {quad index: [emitters]} run
-        behind that quad's MFMAs (the previous M-block's ReLU + exchange write).  Precondition: A quads 0 and 1 of position p0 are in flight."""
+        behind that quad's MFMAs (the previous M-block's ReLU + exchange write).  Precondition: the first LOOK A quads from position p0 on are in flight."""
         e = self.e
         if dst.startswith("v[") and first_c.startswith("a["):
             d0, c0 = int(dst[2:].split(":")[0]), int(first_c[2:].split(":")[0])
@@ -162,17 +168,18 @@ class Body:
             p, quad = p0 + q // 4, q % 4
             g = p * 4 + quad
             # two quads ahead (into the next block / layer / tile as it comes: the caller says what follows)
-            nxt = self.following(p0, q + 2)
+            nxt = self.following(p0, q + LOOK)
             if nxt is not None:
                 self.a_read(*nxt)
             self.wait_lds(("A", g))
             if quad == 3:
                 self.dma(p + RING)                      # position p's last quad is in registers: its slot takes position p + 8
-            reg = A_W + 4 * (g % 4)
+            reg = A_W + 4 * (g % NSETS)
             for jj in range(4):
                 j = q * 4 + jj
                 c = first_c if j == 0 else dst
-                e(f"v_mfma_f32_16x16x4_f32 {dst}, a{reg + jj}, v{V_IN + j}, {c}")
+                if not EXP & 4:
+                    e(f"v_mfma_f32_16x16x4_f32 {dst}, a{reg + jj}, v{V_IN + j}, {c}")
             for t in (tucks or {}).get(q, []):
                 t()
 
@@ -294,8 +301,8 @@ def generate():
         load_p0q0("FGN", "PGN")
 
     head()
-    b.a_read(0, 0)
-    b.a_read(0, 1)
+    for q in range(LOOK):
+        b.a_read(q // 4, q % 4)
     e("S2LF_BODY:")
     vm_body, lds_body = list(b.vm), list(b.lds)
 
@@ -311,7 +318,8 @@ def generate():
                     e(f"v_pk_add_f32 v[{a0 + h}:{a0 + h + 1}], v[{a0 + h}:{a0 + h + 1}], v[{V_P5 + 4 * mbl + h}:{V_P5 + 4 * mbl + h + 1}]")
             for r in range(4):
                 e(f"v_max_f32 v{a0 + r}, 0, v{a0 + r}")
-            b.lds_op(f"ds_write_b128 v{V_XW}, v[{a0}:{a0 + 3}] offset:{(L & 1) * 16384 + mbl * 1024}", ("X", L, mbl))
+            if not EXP & 1:
+                b.lds_op(f"ds_write_b128 v{V_XW}, v[{a0}:{a0 + 3}] offset:{(L & 1) * 16384 + mbl * 1024}", ("X", L, mbl))
         return run
 
     for L in range(NLAYERS):
@@ -329,8 +337,9 @@ def generate():
         if L == 4:
             load_p5q5("FGN", "PGN")            # the next tile's skip rows
         b.wait_all_lds()                       # (this wave's four writes have landed; the next block's first two A quads too)
-        e("s_barrier")
-        for mb in range(16):
+        if not EXP & 1:
+            e("s_barrier")
+        for mb in range(16 if not EXP & 1 else 0):
             b.lds_op(f"ds_read_b128 v[{V_IN + 4 * mb}:{V_IN + 4 * mb + 3}], v{V_XR} offset:{(L & 1) * 16384 + mb * 1024}", ("H", mb))
             if mb == 13:                       # (lgkmcnt counts to 15)
                 b.wait_lds(("H", 0))

@@ -162,13 +162,16 @@ extern "C" int s2l_render_cu_limit(int dev) { return (dev >= 0 && dev < s2l::kMa
 static int pick_render_shape(int64_t npg, int64_t n_frames, int n_cu) {
   double best = 0;
   int pick = s2l::kLong;
-  const double cost[4] = {1.0, 1.03, 0.36, 0.105};      // (a feature-split tile: a quarter of the single tile's MFMAs + a barrier pair per layer)
+  // (measured, in units of the long tile's ~306 us: a single tile 0.38 at one frame per call; a feature-split tile 34 us while a workgroup
+  //  has <= 3 of them, 42 us in steady state -- 256 CUs x 4 waves then stream 1.8 MB of weights per tile from L2 side by side with the MFMAs)
+  const double cost[4] = {1.0, 1.03, 0.36, 0.112};
   for (int shp = 0; shp < 4; ++shp) {
     const s2l::ShapeDims d = s2l::shape_dims(shp);
     const int64_t tiles = ((npg + d.pgt - 1) / d.pgt) * ((n_frames + d.ft - 1) / d.ft);
     // a persistent workgroup owns a contiguous range of ceil / floor(tiles / grid) tiles: the longest range sets the time
     const int64_t grid = tiles < n_cu ? tiles : n_cu;
-    const double t = (double)((tiles + grid - 1) / grid) * cost[shp];
+    const int64_t rounds = (tiles + grid - 1) / grid;
+    const double t = shp == s2l::kFeat && rounds > 3 ? 3 * cost[shp] + (double)(rounds - 3) * 0.137 : (double)rounds * cost[shp];
     if (shp == 0 || t < best * 0.97) best = t, pick = shp;
   }
   return pick;

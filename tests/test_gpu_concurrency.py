@@ -144,7 +144,7 @@ def test_render_shape_switch_from_another_thread_keeps_the_bits(dev):
     def flipper():
         k = 0
         while not stop.is_set():
-            assert lib.s2l_set_render_shape(k % 4) == 0
+            assert lib.s2l_set_render_shape(k % 5) == 0
             k += 1
         flips[0] = k
 

@@ -88,7 +88,7 @@ def soak_render(dev, rounds, seed=0, log=print):
             idx = torch.from_numpy(rng.integers(0, 40000, F)).to(dev)
             for precision in ("fp32", "split"):             # the exact kernel and the split-half speed mode (render16.hip)
                 outs = []
-                for shape in (0, 1, 2, 3, 0, 1, 2, 3):      # 0 = auto; 1 + shape forces long / wide / single
+                for shape in (0, 1, 2, 3, 4, 0, 1, 2, 3, 4):   # 0 = auto; 1 + shape forces long / wide / single / feature-split
                     _abi.check(lib.s2l_set_render_shape(shape), "s2l_set_render_shape")
                     outs.append(m.render_clip(audio, idx, H, Wd, precision=precision).clone())
                 if not all(torch.equal(outs[0], o) for o in outs[1:]):
