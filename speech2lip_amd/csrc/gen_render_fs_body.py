@@ -25,7 +25,7 @@ computed without it is stricter for wave 0 and exact for the others.
 
 Register map (per wave):  v0-63 B operands in[j] | v64-79 acc[mbl][r] | v80-143 p0 of the NEXT tile | v144-207 q0 of the next tile | v208-223 p5,
                           v224-239 q5 (own features) | v240.. addresses
-                          a0-111 bias[L][mbl][r] | a112-115 output bias | a116-119 rgb accumulator | a120-135 four A-quad sets."""
+                          a0-111 bias[L][mbl][r] | a112-115 output bias | a116-119 rgb accumulator | a120.. NSETS A-quad sets (a120-151 at look-ahead 6)."""
 import os
 import sys
 
