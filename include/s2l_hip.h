@@ -482,6 +482,14 @@ int s2l_debug_conv_wgrad_h(const uint16_t* dz, const uint16_t* inA, int CA, cons
 int s2l_debug_convh_layer_stats(const uint16_t* packed16_raw, int layer, const uint16_t* inA, int CA, const uint16_t* inB, int CB,
                                 uint16_t* out, float* stat, int* blocks_out, int height, int width, int64_t n_frames, s2l_stream_t stream);
 
+/* Test aid: the INPUT-gradient convolution of a layer of the half-width chain (dz: cout channels in, cin channels out) that also leaves stage 1
+ * of the BatchNorm backward of the layer below it -- z: that layer's pre-BatchNorm tensor, st_rows: its per-frame rows of 512 floats (scale at
+ * [c], shift at [cin + c]) --: stat[((frame * blocks + block) * 2 + k) * cin + channel] with k = 0: sum g', k = 1: sum g' z, where
+ * g' = fma(z, scale, shift) > 0 ? g : 0 on the stored (bf16) g; out itself is stored unmasked.  What s2l_unet_train_backward_frames_h runs in
+ * place of its reduction pass over g and z (autograd's BatchNorm backward: SimpleUnetLight.py:16-40).  stat: n_frames * 1024 * 2 * cin floats. */
+int s2l_debug_convh_layer_bstats(const uint16_t* packed16_raw, int layer, const uint16_t* dz, const uint16_t* z, const float* st_rows,
+                                 uint16_t* out, float* stat, int* blocks_out, int height, int width, int64_t n_frames, s2l_stream_t stream);
+
 /* Measurement aid (tools/ubench_mfma.py): `waves` (4 or 8) waves per CU each issue iters x 8 independent v_mfma_f32_32x32x16_bf16 on
  * registers and nothing else -- the rate the chip sustains under that load (the clock drops below its 2.4 GHz peak). */
 int s2l_debug_bf16_mfma_rate(int64_t iters, int waves, float* sink, s2l_stream_t stream);

@@ -98,6 +98,7 @@ EXPORTS = {
                                          c_int64, c_void_p]),
     "s2l_set_unet_half_kernel": (c_int, [c_int]),
     "s2l_debug_convh_layer_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "s2l_debug_convh_layer_bstats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_debug_conv_wgrad_h": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "s2l_debug_bf16_mfma_rate": (c_int, [c_int64, c_int, c_void_p, c_void_p]),
     "s2l_unet_saved_h_halves": (c_int64, [c_int, c_int, c_int64]),

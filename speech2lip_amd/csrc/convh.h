@@ -21,6 +21,11 @@ struct ConvHArgs {
   const float* norm;       // or null: inA is a PRE-BatchNorm tensor z and the convolution consumes a = relu(z * scale + shift): per frame 512 floats,
                            //   scale at [c], shift at [CA + c] (bn_finalize_groups_kernel's row).  The halo tile is normalised in LDS with
                            //   bn_relu_h_kernel's expression and rounding, so the output is the bits of the two-kernel route.  CB = 0, no gate, no ReLU.
+  const uint16_t* bz;      // or null (with bst and stat: BACKWARD statistics): the pre-BatchNorm tensor z of the layer whose OUTPUT gradient this
+                           //   (input-gradient) convolution produces, out's shape.  The launch then leaves, per tile and channel, sum g' and sum g' z
+                           //   with g' = fma(z, scale, shift) > 0 ? g : 0 on the stored g (stage 1 of that layer's BatchNorm backward,
+                           //   bn_bwd_reduce_h_kernel's expressions) in stat's layout; out itself is stored unmasked.  No gate, no ReLU, no norm.
+  const float* bst;        //   that layer's per-frame rows (512 floats: scale at [c], shift at [cout + c])
 };
 constexpr int kConvHStatBlocks = 1024;      // tiles per frame the statistics buffers hold (= kStatBlocks of csrc/unet.hip)
 

@@ -13,7 +13,7 @@ static_assert(offsetof(ConvHArgs, inA) == 0 && offsetof(ConvHArgs, inB) == 8 && 
               offsetof(ConvHArgs, CA) == 48 && offsetof(ConvHArgs, CB) == 52 && offsetof(ConvHArgs, cout) == 56 &&
               offsetof(ConvHArgs, H) == 60 && offsetof(ConvHArgs, W) == 64 && offsetof(ConvHArgs, tiles_x) == 68 &&
               offsetof(ConvHArgs, tiles_y) == 72 && offsetof(ConvHArgs, n_ct) == 76 && offsetof(ConvHArgs, relu) == 80 &&
-              offsetof(ConvHArgs, stat) == 88 && offsetof(ConvHArgs, norm) == 96,
+              offsetof(ConvHArgs, stat) == 88 && offsetof(ConvHArgs, norm) == 96 && offsetof(ConvHArgs, bz) == 104 && offsetof(ConvHArgs, bst) == 112,
               "gen_convh_body.py (ARG) loads these fields from the kernarg segment by offset");
 
 constexpr int kCHTileH = 32;      // tile = 32 rows x 16 columns (gen_convh_body.py: TILE_H)
@@ -239,6 +239,7 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stat
   int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
   static LdsOptIn flag4, flag8, flag8r, flag8n, flagx, flagxr;
+  if (a.bz && (a.norm || a.gate || a.relu || !a.bst)) return S2L_E_SIZE;      // (backward statistics: a plain linear launch otherwise)
   if (a.norm) {      // only the default eight-wave form normalises its input; a launch outside its conditions is refused (the caller keeps the two-kernel route)
     if (a.CB != 0 || a.relu || a.gate || a.CA > 128 || misaligned16(a.norm)) return S2L_OK;
     const bool stats_n = a.stat && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !getenv("S2L_NO_CONV_STATS");
@@ -257,8 +258,11 @@ int launch_convh(const ConvHArgs& a0, hipStream_t st, bool* launched, bool* stat
 #endif
   // the tile statistics exist in the default form only; a launch that cannot leave them says so and the caller runs its own pass
   static const bool no_conv_stats = getenv("S2L_NO_CONV_STATS") != nullptr;      // (A/B switch of tools/bench_train.py)
-  const bool stats = a.stat && !alternating && !four && !a.relu && !a.gate && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !no_conv_stats;
+  const bool no_bwd_stats = getenv("S2L_NO_CONV_BSTATS") != nullptr;      // (read per launch: tests flip it inside one process)
+  const bool stats = a.stat && !alternating && !four && !a.relu && !a.gate && (int64_t)a.tiles_x * a.tiles_y <= kConvHStatBlocks && !no_conv_stats &&
+                     !(a.bz && no_bwd_stats);
   if (!stats) a.stat = nullptr;
+  if (stats && a.bz) a.gate = a.bz;      // the kernel's backward-statistics mode: stat and gate both set, the "gate" being z (gen_convh8_body.py: bstats_block)
   if (stats_done) *stats_done = stats;
   if (stat_blocks) *stat_blocks = a.tiles_x * a.tiles_y;
 #ifdef S2L_WITH_REFERENCE_KERNELS

@@ -47,7 +47,14 @@ V_SRA = 54                      # 4: staging read addresses per store j
 V_T = 60                        # temporaries 60..87 (the store read-backs share the accumulator temporaries)
 V_G = 88                        # 32: gate pieces [nb][j][4]; a launch that leaves the tile's statistics has no gate: the same registers then hold
 V_SH, V_SS, V_SQ, V_SA, V_SZ = V_G, V_G + 16, V_G + 17, V_G + 18, V_G + 22   # 16 loaded pixel pairs | sum | sum of squares | 4 staging addresses | 6 temporaries
-V_LAST = 119
+V_LAST = 123
+# backward-statistics mode (stage 1 of the NEXT layer's BatchNorm backward inside an input-gradient convolution: STATP != 0 and GATE != 0, the gate
+# pointer then being that layer's z): the gate registers hold z pieces, so its persistent registers live above them and its transients in the
+# accumulator temporaries the store staging is done with (V_T + 16 ..)
+V_BSS, V_BSQ, V_BSC = (58, 59), (120, 121), 122                  # sum g | sum g z: (even, odd pixels) | (scale, shift) of this lane's channel: even-aligned pairs
+V_BSA = (15, 45, V_T + 26, V_T + 27)                             # 4 staging addresses: holes of the map above, and two of the gating temporaries (tm: a
+                                                                 # backward-statistics launch never runs the gating code, nothing else touches them inside store_tile)
+ZSTG_DELTA = HALO_BYTES         # the z staging = the weight area of buffer 1 (spent at the tile's end: such launches reload their weights every tile)
 # the normalising form has no gate: its work registers live where the gate pieces would (the statistics block, which runs at the tile's end,
 # uses the same ones), and five more hold each piece's constant offset into a chunk's table row
 V_ND, V_NC, V_NU, V_NA, V_NT = V_G, V_G + 4, V_G + 20, V_G + 28, V_G + 29
@@ -84,15 +91,22 @@ S_NORM = {"NORMP": S["GATE"], "NORMP1": S["GATE1"], "NB": S["GATEF"], "NPREV": S
 
 # byte offsets of the fields of struct ConvHArgs (csrc/convh.hip static_asserts them)
 ARG = {"inA": 0, "inB": 8, "w16": 16, "bias": 24, "out": 32, "gate": 40, "CA": 48, "CB": 52, "cout": 56, "H": 60, "W": 64, "tiles_x": 68,
-       "tiles_y": 72, "n_ct": 76, "relu": 80, "stat": 88, "norm": 96}
+       "tiles_y": 72, "n_ct": 76, "relu": 80, "stat": 88, "norm": 96, "bz": 104, "bst": 112}
+# (the bias pointer is needed in the prologue only: afterwards its scalars carry bst, the per-frame rows [scale C | shift C | ...] of the layer
+#  whose gradient statistics a backward-statistics launch leaves)
+S_BST = {"BST": S["BIAS"], "BST1": S["BIAS1"]}
+
+
+def _sreg(n):
+    return S_NORM[n] if n in S_NORM else S_BST[n] if n in S_BST else S[n]
 
 
 def s(n):
-    return f"s{S_NORM[n] if n in S_NORM else S[n]}"
+    return f"s{_sreg(n)}"
 
 
 def s2(n):
-    r = S_NORM[n] if n in S_NORM else S[n]
+    r = _sreg(n)
     return f"s[{r}:{r + 1}]"
 
 
@@ -363,12 +377,33 @@ class Body:
         e(f"s_cbranch_scc1 {skip}")
         e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
         e(f"s_cbranch_scc1 {skip}")
+        noz = self.label("nozero")
+        e(f"s_cmp_eq_u64 {s2('STATP')}, 0")                             # backward statistics multiply by z: the pieces outside the image (not loaded)
+        e(f"s_cbranch_scc1 {noz}")                                      # must not hold stale bits (0 x Inf)
+        for k in range(16 * NB):
+            e(f"v_mov_b32 v{V_G + k}, 0")
+        e(f"{noz}:")
         for k in range(4 * NB):
             nb, j = k >> 2, k & 3
             self.row_exec(2 * nb + (j >> 1), j & 1, "GATEF", k == 0)
             if not EXP & 16:
                 e(f"global_load_dwordx4 v[{V_G + 4 * k}:{V_G + 4 * k + 3}], v{V_VS}, {s2('ROWB')}")
         e("s_mov_b64 exec, -1")
+        # backward statistics: the gate is z; lane c also fetches scale / shift of channel 64 CT + c of frame FR (the ReLU mask is fma(z, scale, shift) > 0)
+        e(f"s_cmp_eq_u64 {s2('STATP')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_lshl_b32 {s('T0')}, {s('FR')}, 11")                       # 512 floats per frame
+        e(f"s_add_u32 {s('TA')}, {s('BST')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('BST1')}, 0")
+        e(f"s_lshl_b32 {s('T0')}, {s('CT')}, 8")
+        e(f"s_add_u32 {s('TA')}, {s('TA')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TA1')}, {s('TA1')}, 0")
+        e(f"s_lshl_b32 {s('T0')}, {s('COUT')}, 2")
+        e(f"s_add_u32 {s('TB')}, {s('TA')}, {s('T0')}")
+        e(f"s_addc_u32 {s('TB1')}, {s('TA1')}, 0")
+        e(f"v_lshlrev_b32 v{V_BSC}, 2, v{V_LANE}")
+        e(f"global_load_dword v{V_BSC + 1}, v{V_BSC}, {s2('TB')}")
+        e(f"global_load_dword v{V_BSC}, v{V_BSC}, {s2('TA')}")          # (overwrites its own address last)
         e(f"{skip}:")
 
     def store_tile(self):
@@ -395,6 +430,8 @@ class Body:
             if not WITH_NORM:
                 nogate = self.label("ng")
                 e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+                e(f"s_cbranch_scc1 {nogate}")
+                e(f"s_cmp_lg_u64 {s2('STATP')}, 0")                   # backward statistics: the "gate" is z, nothing is masked here
                 e(f"s_cbranch_scc1 {nogate}")
                 self.wait_lds(("SR", nb, 3))
                 for j in range(4):
@@ -424,6 +461,10 @@ class Body:
         skip = self.label("nostat")
         e(f"s_cmp_eq_u64 {s2('STATP')}, 0")
         e(f"s_cbranch_scc1 {skip}")
+        if not WITH_NORM:
+            bwd = self.label("bstat")
+            e(f"s_cmp_lg_u64 {s2('GATE')}, 0")
+            e(f"s_cbranch_scc1 {bwd}")
         t0, t1, t2, t3, t4, t5 = (V_SZ + k for k in range(6))
         if nb == 0:
             e(f"v_mov_b32 v{V_SS}, 0")
@@ -478,7 +519,116 @@ class Body:
             e(f"v_mov_b32 v{t3}, v{V_SQ}")
             self.lds_op(f"ds_write_b64 v{t0}, v[{t2}:{t3}]", ("STW",))
             self.wait_all_lds()
+        if not WITH_NORM:
+            self.wait_all_lds()
+            e(f"s_branch {skip}")
+            e(f"{bwd}:")
+            self.bstats_block(nb)
         e(f"{skip}:")
+
+    def bstats_block(self, nb):
+        """Backward statistics (stage 1 of BatchNorm's backward for the layer whose output gradient this input-gradient convolution produces):
+        per channel, over the N-block's pixels inside the image, sum g' and sum g' z with g' = (fma(z, scale, shift) > 0 ? g : 0) -- bn_bwd_reduce_h_kernel's
+        expressions on the STORED (bf16-rounded) g.  z's tile arrived in the gate registers in the stores' layout; written to a second staging area
+        (buffer 1's weight area) at the read-backs' addresses it has the layout of the g staging, so lane c reads channel c of both: two pixels per
+        step, each bf16 straight into the upper half of a zeroed register (ds_read_u16_d16_hi: the fp32 value), packed fp32 arithmetic on the pair.
+        Tiles wholly inside the image (T1 = all ones) skip the per-pixel validity scalars.  The pair of sums leaves through the same LDS slots and
+        stats_reduce as the forward statistics; bn_bwd_finalize_kernel forms invstd (sum g z - mean sum g) from the tiles' raw sums."""
+        e = self.e
+        work = V_G + 16 * nb                                            # this N-block's z pieces are spent once staged: ring + temporaries live there
+        t0, t1, t2, t3 = work, work + 1, work + 2, work + 3
+        tf = work + 12                                                 # the fma results of a pixel pair (even-aligned)
+        for j in range(4):
+            self.lds_op(f"ds_write_b128 v{V_SRA + j}, v[{V_G + 16 * nb + 4 * j}:{V_G + 16 * nb + 4 * j + 3}] offset:{ZSTG_DELTA}", ("ZW", nb, j))
+        # T1 = bit p set: pixel p (row p >> 4, column p & 15) of the N-block is inside the image
+        if nb == 0:
+            e(f"s_sub_u32 {s('NCOLS')}, {s('W')}, {s('X0')}")
+            e(f"s_min_u32 {s('NCOLS')}, {s('NCOLS')}, 16")
+        e(f"s_lshl_b32 {s('T0')}, 1, {s('NCOLS')}")
+        e(f"s_sub_u32 {s('T0')}, {s('T0')}, 1")                          # NCOLS ones
+        e(f"s_mov_b32 {s('T1')}, 0")
+        for k in range(2):
+            e(f"s_add_u32 {s('T2')}, {s('GY0')}, {2 * nb + k}")
+            e(f"s_cmp_lt_u32 {s('T2')}, {s('H')}")
+            e(f"s_cselect_b32 {s('T2')}, {s('T0')}, 0")
+            if k:
+                e(f"s_lshl_b32 {s('T2')}, {s('T2')}, 16")
+            e(f"s_or_b32 {s('T1')}, {s('T1')}, {s('T2')}")
+        self.wait_all_lds()                                            # (z staged -- its registers are free now; this wave reads only its own 4 KiB)
+        if nb == 0:
+            for r in V_BSS + V_BSQ:
+                e(f"v_mov_b32 v{r}, 0")
+            e(f"v_and_b32 v{t0}, 31, v{V_LANE}")                        # (the addresses of stats_block, in this mode's registers)
+            e(f"v_lshrrev_b32 v{t1}, 3, v{t0}")
+            e(f"v_and_b32 v{t2}, 7, v{t0}")
+            e(f"v_lshlrev_b32 v{t2}, 1, v{t2}")
+            e(f"v_lshrrev_b32 v{t3}, 5, v{V_LANE}")
+            e(f"v_lshlrev_b32 v{t3}, 11, v{t3}")
+            e(f"v_add_u32 v{t2}, v{t2}, v{t3}")
+            e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 12")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {STG_OFF}")
+            e(f"v_add_u32 v{t2}, {s('T0')}, v{t2}")
+            for q in range(4):
+                e(f"v_xor_b32 v{t3}, {q}, v{t1}")
+                e(f"v_lshlrev_b32 v{t3}, 4, v{t3}")
+                e(f"v_add_u32 v{V_BSA[q]}, v{t2}, v{t3}")
+        for r in range(12):                                            # the ring's lower halves stay zero (d16_hi writes the upper ones; a masked g is 0 or g)
+            e(f"v_mov_b32 v{work + r}, 0")
+        slots = 3
+
+        def read(q):
+            r = work + 4 * (q % slots)
+            for h in range(2):
+                pix = 2 * q + h
+                a = V_BSA[(pix >> 1) & 3]
+                self.lds_op(f"ds_read_u16_d16_hi v{r + h}, v{a} offset:{64 * pix}", ("BG", nb, pix))
+                self.lds_op(f"ds_read_u16_d16_hi v{r + 2 + h}, v{a} offset:{64 * pix + ZSTG_DELTA}", ("BZ", nb, pix))
+
+        def loop(check):
+            for q in range(slots):
+                read(q)
+            for q in range(16):
+                r = work + 4 * (q % slots)
+                self.wait_lds(("BZ", nb, 2 * q + 1))
+                if check:
+                    e(f"s_bitcmp1_b32 {s('T1')}, {2 * q}")
+                    e(f"s_cselect_b64 {s2('TA')}, -1, 0")
+                    e(f"s_bitcmp1_b32 {s('T1')}, {2 * q + 1}")
+                    e(f"s_cselect_b64 {s2('TB')}, -1, 0")
+                e(f"v_pk_fma_f32 v[{tf}:{tf + 1}], v[{r + 2}:{r + 3}], v[{V_BSC}:{V_BSC + 1}], v[{V_BSC}:{V_BSC + 1}] op_sel:[0,0,1] op_sel_hi:[1,0,1]")
+                for h, m in ((0, "TA"), (1, "TB")):
+                    e(f"v_cmp_lt_f32 vcc, 0, v{tf + h}")
+                    if check:
+                        e(f"s_and_b64 vcc, vcc, {s2(m)}")
+                    e(f"v_cndmask_b32 v{r + h}, 0, v{r + h}, vcc")
+                e(f"v_pk_add_f32 v[{V_BSS[0]}:{V_BSS[1]}], v[{V_BSS[0]}:{V_BSS[1]}], v[{r}:{r + 1}]")
+                e(f"v_pk_fma_f32 v[{V_BSQ[0]}:{V_BSQ[1]}], v[{r}:{r + 1}], v[{r + 2}:{r + 3}], v[{V_BSQ[0]}:{V_BSQ[1]}]")
+                if q + slots < 16:
+                    read(q + slots)
+
+        slow, done = self.label("bedge"), self.label("bdone")
+        e(f"s_cmp_lg_u32 {s('T1')}, -1")
+        e(f"s_cbranch_scc1 {slow}")
+        saved = list(self.lds)
+        loop(False)
+        self.wait_all_lds()
+        e(f"s_branch {done}")
+        e(f"{slow}:")
+        self.lds = saved
+        loop(True)
+        self.wait_all_lds()
+        e(f"{done}:")
+        if nb == NB - 1:
+            e(f"v_lshlrev_b32 v{t0}, 3, v{V_LANE}")
+            e(f"s_lshl_b32 {s('T0')}, {s('WAVE')}, 9")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {s('LDS0')}")
+            e(f"s_add_u32 {s('T0')}, {s('T0')}, {STAT_OFF}")
+            e(f"v_add_u32 v{t0}, {s('T0')}, v{t0}")
+            e(f"v_add_f32 v{V_BSS[0]}, v{V_BSS[0]}, v{V_BSS[1]}")       # even + odd pixels
+            e(f"v_add_f32 v{V_BSS[1]}, v{V_BSQ[0]}, v{V_BSQ[1]}")
+            self.lds_op(f"ds_write_b64 v{t0}, v[{V_BSS[0]}:{V_BSS[1]}]", ("STW",))
+        self.wait_all_lds()
 
     def stats_reduce(self):
         """after the tile's barrier: wave w adds, for channels 8 w .. 8 w + 7 (lanes 0..7), the eight waves' pairs in wave order and stores
@@ -861,6 +1011,13 @@ def emit_prologue(b, with_gate=True):
     e(f"s_and_b32 {s('T0')}, {s('T0')}, {s('T1')}")
     e(f"s_cmp_eq_u32 {s('T0')}, 1")
     e(f"s_cselect_b32 {s('WLD')}, 2, 0x7fffffff")
+    if with_gate:      # backward statistics stage z in buffer 1's weight area at every tile's end: nothing persists there
+        e(f"s_cmp_eq_u64 {s2('STATP')}, 0")
+        e(f"s_cselect_b32 {s('T0')}, {s('WLD')}, 0x7fffffff")
+        e(f"s_cmp_eq_u64 {s2('GATE')}, 0")
+        e(f"s_cselect_b32 {s('WLD')}, {s('WLD')}, {s('T0')}")
+        e(f"s_load_dwordx2 {s2('BST')}, {s2('KARG')}, {ARG['bst']}")      # (the bias table is in LDS: its pointer's scalars are free)
+        e("s_waitcnt lgkmcnt(0)")
     b.staging_tile_setup()
     # chunk 0 -> buffer 0, all exposed (once per workgroup)
     b.staging_source()

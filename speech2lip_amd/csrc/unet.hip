@@ -1966,11 +1966,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // sums[C..2C) = s2/n)
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int n_blocks, int C, double n,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ sums) {
+                                                            float* __restrict__ sums, const float* __restrict__ st_raw) {
   const int c = blockIdx.x, g = blockIdx.y;      // (per group: its own sums; dgamma / dbeta are per-group scratch then)
   double s1, s2;
   channel_totals(partial + (int64_t)g * n_blocks * 2 * C, n_blocks, C, c, &s1, &s2);
   if (threadIdx.x != 0) return;
+  // st_raw: the blocks hold sum g and sum g z (a convolution's backward statistics): sum g zhat = invstd (sum g z - mean sum g) is formed here
+  if (st_raw) s2 = (s2 - (double)st_raw[g * 512 + 2 * C + c] * s1) * (double)st_raw[g * 512 + 3 * C + c];
   dgamma[g * 256 + c] = (float)s2;
   dbeta[g * 256 + c] = (float)s1;
   sums[g * 256 + c] = (float)(s1 / n);
@@ -2817,7 +2819,7 @@ static int unet_train_backward_impl(const float* packed_raw, const uint16_t* pac
     float* dgamma = via_scratch ? sums + 256 * groups : g + (int64_t)C * cin * 9;
     float* dbeta = via_scratch ? dgamma + 128 : dgamma + C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, gy, b.z[l], stl, C, n, per, rpart);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(64), 0, st, rpart, nb, C, (double)n, dgamma, dbeta, sums, (const float*)nullptr);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, blocks(pl[lv] * C / 4), dim3(256), 0, st, gy, b.z[l], stl, sums, C, pl[lv] * C / 4,
                        n * C / 4);
     if (!want_params) return;

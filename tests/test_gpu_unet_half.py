@@ -365,6 +365,50 @@ def test_weight_gradient_kernel_alone_vs_fp64_correlation(dev, F, H, Wd, CA, CB,
     assert lib.s2l_debug_conv_wgrad_h(None, p(ap), CA, None, 0, cout, p(part), p(outs[0]), H, Wd, F, None) == -1
 
 
+@pytest.mark.parametrize("layer,F,H,Wd", [(9, 2, 40, 40), (1, 1, 33, 17), (7, 2, 37, 53), (3, 1, 125, 125), (9, 2, 500, 500), (5, 3, 70, 41), (1, 2, 4, 4)])
+def test_input_gradient_convolution_leaves_stage_one_of_the_batchnorm_backward(blobs, dev, layer, F, H, Wd):
+    """The input-gradient convolution's backward statistics (csrc/gen_convh8_body.py bstats_block: what the frozen train-mode backward consumes
+    instead of bn_bwd_reduce_h_kernel's pass over g and z; autograd's BatchNorm backward of SimpleUnetLight.py:16-40): per tile and channel
+    sum g' and sum g' z with g' = fma(z, scale, shift) > 0 ? g : 0 on the STORED bf16 g -- ragged tiles excluded rows / columns -- to fp32
+    summation accuracy; the stored tensor is the same bits as the plain launch's (unmasked); two runs: the same partials bit for bit."""
+    _, raw, raw16 = blobs
+    lib = _abi.load()
+    g = torch.Generator(device="cpu").manual_seed(13 * layer + H)
+    cin, cout = CONVS[layer]
+    dz = nhwc_to_c32((0.25 * torch.randn(F, H, Wd, cout, generator=g)).to(torch.bfloat16).to(dev))
+    z_nhwc = torch.randn(F, H, Wd, cin, generator=g).to(torch.bfloat16)
+    z = nhwc_to_c32(z_nhwc.to(dev))
+    # scale / shift with 8-bit mantissas: fma(z, scale, shift) is then exact in fp32 and the mask is the same in any arithmetic
+    sc = (torch.randn(F, cin, generator=g) + 0.3).to(torch.bfloat16).float()
+    sh = (0.5 * torch.randn(F, cin, generator=g)).to(torch.bfloat16).float()
+    rows = torch.zeros(F, 512)
+    rows[:, :cin], rows[:, cin:2 * cin] = sc, sh
+    rows = rows.to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.full((F, cin // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+    _abi.check(lib.s2l_convh_layer(p(raw16), layer, 1, p(dz), cout, None, 0, None, p(ref), H, Wd, F, st), "s2l_convh_layer")
+    parts = []
+    for _ in range(2):
+        out = torch.full_like(ref, -1)
+        stat = torch.full((F * 1024 * 2 * cin,), float("nan"), device=dev)
+        blocks = ctypes.c_int(0)
+        _abi.check(lib.s2l_debug_convh_layer_bstats(p(raw16), layer, p(dz), p(z), p(rows), p(out), p(stat), ctypes.byref(blocks), H, Wd, F, st),
+                   "s2l_debug_convh_layer_bstats")
+        torch.cuda.synchronize()
+        assert blocks.value == ((Wd + 15) // 16) * ((H + 31) // 32) and torch.equal(out, ref)
+        parts.append(stat[:F * blocks.value * 2 * cin].reshape(F, blocks.value, 2, cin).clone())
+    assert torch.equal(parts[0], parts[1]) and bool(torch.isfinite(parts[0]).all())
+    gy = c32_to_nhwc(ref).view(torch.bfloat16).double().cpu()          # [F,H,W,cin]
+    zd = z_nhwc.double()
+    mask = (zd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]) > 0
+    gm = gy * mask
+    s_ref, q_ref = gm.sum((1, 2)), (gm * zd).sum((1, 2))
+    got = parts[0].double().sum(1).cpu()                               # [F,2,cin]
+    assert 0.2 < float(mask.double().mean()) < 0.8
+    assert float((got[:, 0] - s_ref).abs().max()) <= 2e-5 * float(gm.abs().sum((1, 2)).max())
+    assert float((got[:, 1] - q_ref).abs().max()) <= 2e-5 * float((gm * zd).abs().sum((1, 2)).max())
+
+
 @pytest.mark.parametrize("layer,F,H,Wd", [(1, 2, 40, 40), (2, 1, 33, 17), (6, 2, 37, 53), (3, 1, 125, 125), (9, 2, 500, 500), (8, 3, 70, 41)])
 def test_convolution_leaves_its_tiles_batch_statistics(blobs, dev, layer, F, H, Wd):
     """The forward convolution's own per-tile partial sums (csrc/gen_convh8_body.py stats_block: what the train-mode chain's BatchNorm

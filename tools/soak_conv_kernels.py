@@ -212,6 +212,30 @@ def soak_convh(dev, rounds, seed=0, log=print):
             ok = ok and torch.equal(parts[0], parts[1])
             ok = ok and float((got[:, 0] - z.sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float(z.abs().sum((1, 2)).max()))
             ok = ok and float((got[:, 1] - (z * z).sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float((z * z).sum((1, 2)).max()))
+        if tr and not gate and (H + 31) // 32 * ((Wd + 15) // 16) <= 1024:
+            # the input-gradient launch that also leaves stage 1 of the BatchNorm backward of the layer below (the frozen train-mode chain's):
+            # the same output bits; the partial sums add up to sum g' / sum g' z over the stored tensor; twice: the same partial bits
+            zt = torch.randn(F, H, Wd, cout, device=dev).to(torch.bfloat16)
+            sc = (torch.randn(F, cout, device=dev) + 0.3).to(torch.bfloat16).float()      # (8-bit mantissas: the mask is the same in any arithmetic)
+            sh = (0.5 * torch.randn(F, cout, device=dev)).to(torch.bfloat16).float()
+            rows = torch.zeros(F, 512, device=dev)
+            rows[:, :cout], rows[:, cout:2 * cout] = sc, sh
+            zh = nhwc_to_c32(zt)
+            parts = []
+            for _ in range(2):
+                out = torch.full((F, cout // 32, H, Wd, 32), -1, dtype=torch.int16, device=dev)
+                stat = torch.full((F * 1024 * 2 * cout,), float("nan"), device=dev)
+                blocks = ctypes.c_int(0)
+                _abi.check(lib.s2l_debug_convh_layer_bstats(p(raw16), layer, p(ah), p(zh), p(rows), p(out), p(stat), ctypes.byref(blocks), H, Wd, F, st),
+                           "convh bstats")
+                ok = ok and torch.equal(c32_to_nhwc(out), want) and blocks.value == (H + 31) // 32 * ((Wd + 15) // 16)
+                parts.append(stat[:F * blocks.value * 2 * cout].reshape(F, blocks.value, 2, cout).clone())
+            gy, zd = want.view(torch.bfloat16).double(), zt.double()
+            gm = gy * ((zd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]) > 0)
+            got = parts[0].double().sum(1)
+            ok = ok and torch.equal(parts[0], parts[1])
+            ok = ok and float((got[:, 0] - gm.sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float(gm.abs().sum((1, 2)).max()))
+            ok = ok and float((got[:, 1] - (gm * zd).sum((1, 2))).abs().max()) <= 2e-5 * max(1.0, float((gm * zd).abs().sum((1, 2)).max()))
         if not ok:
             bad.append(("convh", layer, tr, F, H, Wd, gate))
             log("MISMATCH convh", layer, tr, F, H, Wd, gate)
