@@ -582,6 +582,8 @@ class Body:
             for h in range(2):
                 pix = 2 * q + h
                 a = V_BSA[(pix >> 1) & 3]
+                if EXP & 65536:      # pricing (results wrong): the statistics loop without its LDS reads
+                    continue
                 self.lds_op(f"ds_read_u16_d16_hi v{r + h}, v{a} offset:{64 * pix}", ("BG", nb, pix))
                 self.lds_op(f"ds_read_u16_d16_hi v{r + 2 + h}, v{a} offset:{64 * pix + ZSTG_DELTA}", ("BZ", nb, pix))
 
@@ -591,6 +593,10 @@ class Body:
             for q in range(16):
                 r = work + 4 * (q % slots)
                 self.wait_lds(("BZ", nb, 2 * q + 1))
+                if EXP & 131072:      # pricing (results wrong): ... without its arithmetic
+                    if q + slots < 16:
+                        read(q + slots)
+                    continue
                 if check:
                     e(f"s_bitcmp1_b32 {s('T1')}, {2 * q}")
                     e(f"s_cselect_b64 {s2('TA')}, -1, 0")

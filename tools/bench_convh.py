@@ -1,5 +1,5 @@
 """Per-layer time of the half-width convolution kernel (csrc/convh.hip) at the training chain's shapes.
-    python tools/bench_convh.py [frames=20] [size=500] [kernel: 0 eight waves interleaved | 1 four waves | 2 eight waves in alternating roles] [--nogate: the train-mode chain's launches]"""
+    python tools/bench_convh.py [frames=20] [size=500] [kernel: 0 eight waves interleaved | 1 four waves | 2 eight waves in alternating roles] [--nogate: the train-mode chain's launches] [--bstats: also time the input-gradient launches that leave stage 1 of the BatchNorm backward]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,7 @@ LVL = [0, 0, 1, 1, 2, 2, 1, 1, 0, 0]
 p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
 dev = torch.device("cuda:0")
 NOGATE = "--nogate" in sys.argv
+BSTATS = "--bstats" in sys.argv
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 500
@@ -49,4 +50,17 @@ for tr in (0, 1):
         fl = 2 * 9 * cin * cout * h * h * F
         tot += us
         print(f"L{l} {'dgrad' if tr else 'fwd  '} {cin:3d}->{cout:3d} @{h:3d} gate={int(bool(gate))}: {us:7.0f} us  {fl / us / 1e6:6.0f} TFLOP/s", flush=True)
+        if BSTATS and tr and l in (1, 3, 5, 7, 9) and not gate:
+            z = torch.randn(F, h, h, cout, device=dev).to(torch.bfloat16)
+            rows = torch.randn(F, 512, device=dev)
+            stat = torch.empty(F * 1024 * 2 * cout, device=dev)
+            blocks = ctypes.c_int(0)
+            call = lambda: _abi.check(lib.s2l_debug_convh_layer_bstats(p(raw16), l, p(a), p(z), p(rows), p(out), p(stat), ctypes.byref(blocks), h, h, F, st), "bstats")
+            call(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                call()
+            e1.record(); torch.cuda.synchronize()
+            us2 = e0.elapsed_time(e1) / 5 * 1e3
+            print(f"   + backward statistics ({blocks.value} tiles per frame): {us2:7.0f} us  (+{us2 - us:.0f} us; z is {F * h * h * cout * 2 / 1e6:.0f} MB)", flush=True)
 print(f"total {tot / 1e3:.2f} ms per {F} frames")
