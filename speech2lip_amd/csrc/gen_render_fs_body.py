@@ -34,6 +34,7 @@ LOOK = int(os.environ.get("S2L_FS_LOOK", "6"))     # A quads requested ahead of 
 NSETS = LOOK + 2
 assert (NPOS - NREAL) * 4 % NSETS == 0 and NPOS * 4 % NSETS == 0, "the A sets rotate with the quad index: the skipped positions and a tile must be whole rotations"
 EXP = int(os.environ.get("S2L_FS_EXP", "0"))      # pricing builds (results wrong): 1 no exchange (writes, barrier, reads), 2 nobody waits for a piece, 4 no MFMAs
+TRACE = os.environ.get("S2L_FS_TRACE") == "1"     # experiment build (tools/dev/trace_render_fs.py; render.hip with -DS2L_EXP_TRACE): wave 0 stamps s_memtime per phase
 LDS_RING_PER_WAVE = RING * PIECE                  # 32 KiB
 LDS_X = 4 * LDS_RING_PER_WAVE                     # two exchange blocks of 16 KiB behind the four rings
 LDS_BYTES = LDS_X + 2 * 16384                     # 163 840 = 160 KiB
@@ -61,6 +62,10 @@ S = _scalar_map(36, singles="TILE TEND NFG FG PG FGN PGN HW WAVE LDSW T6 T7".spl
                 pairs=("WB", "WOUT", "P0", "P5", "Q0", "Q5", "OUT", "BIAS", "T4", "T8", "EX"))
 S.update(T5=S["T41"], T9=S["T81"])
 S_LAST = max(S.values())
+if TRACE:
+    S.update(TRACE=S_LAST + 1 + (S_LAST + 1) % 2)
+    S.update(TRACE1=S["TRACE"] + 1, TS=S["TRACE"] + 2, TS1=S["TRACE"] + 3)
+    S_LAST = S["TS1"]
 
 
 def s(n):
@@ -117,6 +122,34 @@ class Body:
     def wait_all_vm(self):
         self.e("s_waitcnt vmcnt(0)")
         self.vm = []
+
+    def stamp(self, slot, real=False):
+        """experiment builds: wave 0's lane 0 stores s_memtime (real: s_memrealtime, the constant 100 MHz clock) to trace[tile * 32 + slot].  Everything in
+        flight through LDS is waited for first (scalar loads return out of order with it): the phases are slightly serialised by the measurement."""
+        if not TRACE:
+            return
+        e = self.e
+        skip = self.label("notrace")
+        self.wait_all_lds()
+        e(f"{'s_memrealtime' if real else 's_memtime'} {s2('TS')}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cmp_eq_u64 {s2('TRACE')}, 0")
+        e(f"s_cbranch_scc1 {skip}")
+        e(f"s_cmp_eq_u32 {s('WAVE')}, 0")
+        e(f"s_cbranch_scc0 {skip}")
+        e(f"s_lshl_b32 {s('T6')}, {s('TILE')}, 5")
+        e(f"s_add_u32 {s('T6')}, {s('T6')}, {slot}")
+        e(f"s_mov_b32 {s('T7')}, 0")
+        e(f"s_lshl_b64 {s2('T6')}, {s2('T6')}, 3")
+        e(f"s_add_u32 {s('T6')}, {s('TRACE')}, {s('T6')}")
+        e(f"s_addc_u32 {s('T7')}, {s('TRACE1')}, {s('T7')}")
+        e(f"v_mov_b32 v{V_PIXOFF}, {s('TS')}")
+        e(f"v_mov_b32 v{V_TMP}, {s('TS1')}")
+        e(f"s_mov_b64 {s2('EX')}, exec")
+        e("s_mov_b64 exec, 1")
+        e(f"global_store_dwordx2 v{V_ZERO}, v[{V_PIXOFF}:{V_TMP}], {s2('T6')}")      # (never counted, like the rgb store)
+        e(f"s_mov_b64 exec, {s2('EX')}")
+        e(f"{skip}:")
 
     # ---- the weight stream
     @staticmethod
@@ -203,7 +236,7 @@ def generate():
     for dst, src in (("TILE", "tile0"), ("TEND", "tile_end"), ("NFG", "nfg"), ("FG", "fg0"), ("PG", "pg0"), ("HW", "hw"), ("WAVE", "wave"),
                      ("LDSW", "ldsw")):
         e(f"s_mov_b32 {s(dst)}, %[{src}]")
-    for dst, src in (("WB", "wb"), ("WOUT", "wout"), ("P0", "p0"), ("P5", "p5"), ("Q0", "q0"), ("Q5", "q5"), ("OUT", "out"), ("BIAS", "bias")):
+    for dst, src in (("WB", "wb"), ("WOUT", "wout"), ("P0", "p0"), ("P5", "p5"), ("Q0", "q0"), ("Q5", "q5"), ("OUT", "out"), ("BIAS", "bias")) + ((("TRACE", "trace"),) if TRACE else ()):
         e(f"s_mov_b64 {s2(dst)}, %[{src}]")
     # per-lane addresses from the lane number (one vector operand: the body owns v0 .. v250)
     e(f"v_mov_b32 v{V_TMP}, %[lane]")
@@ -305,6 +338,8 @@ def generate():
         b.a_read(q // 4, q % 4)
     e("S2LF_BODY:")
     vm_body, lds_body = list(b.vm), list(b.lds)
+    b.stamp(18, real=True)
+    b.stamp(0)
 
     def relu_write(L, mbl, skip):
         """ReLU of M-block mbl of layer L and its 1 KiB of the exchange block L & 1 ([M-block][lane][4]); the skip step first"""
@@ -333,6 +368,7 @@ def generate():
         # the layer's last M-block: nothing to hide behind
         e("s_nop 7")
         e("s_nop 7")
+        b.stamp(1 + 2 * L)
         relu_write(L, 3, L == 4)()
         if L == 4:
             load_p5q5("FGN", "PGN")            # the next tile's skip rows
@@ -345,10 +381,12 @@ def generate():
                 b.wait_lds(("H", 0))
         b.wait_all_lds()
         e("s_nop 1")
+        b.stamp(2 + 2 * L)
     # ---- output layer (3 rows padded to one M-block), every wave (only wave 0 stores): positions 112 .. 115
     b.block(112, f"a[{A_RGB}:{A_RGB + 3}]", f"a[{A_BOUT}:{A_BOUT + 3}]")
     for p in range(NPOS + 4, NPOS + RING):     # positions 116 .. 119 hold nothing: the next tile's 4 .. 7 take their slots now
         b.dma(p)
+    b.stamp(15)
     # ---- store: wave 0, lanes 0 .. 15 hold rgb of pixel 16 pg + lane of frame fg
     skip = b.label("nostore")
     e(f"s_cmp_eq_u32 {s('WAVE')}, 0")
@@ -375,6 +413,8 @@ def generate():
     e(f"{skip}:")
     # ---- next tile
     b.wait_vm(("Q5", 3))                       # (the next tile's skip rows, requested ten blocks ago: keeps the loop's state simple)
+    b.stamp(16)
+    b.stamp(17, real=True)
     e(f"s_add_u32 {s('TILE')}, {s('TILE')}, 1")
     e(f"s_mov_b32 {s('FG')}, {s('FGN')}")
     e(f"s_mov_b32 {s('PG')}, {s('PGN')}")
@@ -385,7 +425,7 @@ def generate():
     b.vm = [(t[0], t[1] - NPOS) if t[0] == "D" else t for t in b.vm]
     b.lds = [(t[0], t[1] - NPOS * 4) for t in b.lds]
     assert b.vm == vm_body, (b.vm[:6], vm_body[:6], len(b.vm), len(vm_body))
-    assert b.lds == lds_body, (b.lds, lds_body)
+    assert TRACE or b.lds == lds_body, (b.lds, lds_body)      # (a trace build has waited for everything: the body's waits are stricter than needed)
     e("s_branch S2LF_BODY")
     e("S2LF_END:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")      # run-ahead requests must land before the workgroup's LDS is released
@@ -395,7 +435,7 @@ def generate():
 OPERANDS = """      :
       : [tile0] "s"(tile0), [tile_end] "s"(tile_end), [nfg] "s"(nfg), [fg0] "s"(fg0), [pg0] "s"(pg0), [hw] "s"(a.hw), [wave] "s"(wave), [ldsw] "s"(ldsw),
         [wb] "s"(wb), [wout] "s"(wout), [p0] "s"(a.p0t), [p5] "s"(a.p5t), [q0] "s"(a.q0), [q5] "s"(a.q5), [out] "s"(a.out), [bias] "s"(biasp),
-        [lds0] "s"(lds0), [lane] "v"(lane)
+        [lds0] "s"(lds0), [lane] "v"(lane)TRACE_OPERAND
 """
 
 
@@ -406,7 +446,7 @@ def main(path):
     clob += ["vcc", "scc", "memory"]
     out = ["// GENERATED by csrc/gen_render_fs_body.py -- do not edit; the generator is the source.", "asm volatile("]
     out += [f'    "{x}\\n\\t"' for x in lines]
-    out.append(OPERANDS.rstrip("\n"))
+    out.append(OPERANDS.rstrip("\n").replace("TRACE_OPERAND", ', [trace] "s"(g_trace)' if TRACE else ""))
     out.append("      : " + ", ".join(f'"{c}"' for c in clob) + ");")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")

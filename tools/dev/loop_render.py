@@ -1,4 +1,4 @@
-"""Loops the lip renderer (1000 frames 96 x 96) for a few seconds (power / clock probing).  python tools/dev/loop_render.py <fp32|split> [seconds=7]"""
+"""Loops the lip renderer (1000 frames 96 x 96) for a few seconds (power / clock probing).  python tools/dev/loop_render.py <fp32|split> [seconds=7] [shape mode 0..4 = s2l_set_render_shape]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -7,6 +7,9 @@ from tools.benchlib import make_model
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 7.0
 dev = torch.device("cuda:0")
+if len(sys.argv) > 3:
+    from speech2lip_amd import _abi
+    _abi.check(_abi.load().s2l_set_render_shape(int(sys.argv[3])), "s2l_set_render_shape")
 m = make_model(dev, 96, 96)
 a = torch.from_numpy(W.synthetic_audio(1000, 1).astype(np.float32)).to(dev)
 i = torch.arange(1000, device=dev)
