@@ -15,7 +15,7 @@ __device__ inline float lrelu(float x) { return x > 0.f ? x : 0.02f * x; }
 
 // Conv1d(k=3, stride=2, pad=1) + LeakyReLU(0.02) over kFB frames held in LDS.
 // xin [kFB][CIN][TIN], yout [kFB][COUT][TIN/2], wT [CIN][3][COUT].
-template <int CIN, int COUT, int TIN, int FB = kFB>
+template <int CIN, int COUT, int TIN, int FB = kFB, int U = 8>
 __device__ inline void conv_stage(const float* __restrict__ wT, const float* __restrict__ b, const float* xin,
                                   float* yout) {
   constexpr int TOUT = TIN / 2;
@@ -27,13 +27,18 @@ __device__ inline void conv_stage(const float* __restrict__ wT, const float* __r
     float acc = b[o];
     // (x8: 24 weight loads in flight per thread instead of 3 -- the chain of fmas keeps its order, so the bits do; one frame per call is a
     //  chain of dependent L2 round trips: 22 -> 11 us for the encoder at F = 1)
-#pragma unroll 8
+    // Of the three taps t = 2 tau - 1, 2 tau, 2 tau + 1 only the first can fall into the padding (tau = 0; 2 tau + 1 <= TIN - 1 always): that
+    // step is SKIPPED, as before, but by a select on a loop-invariant flag instead of a lane-dependent branch around a load -- the branch
+    // cost 60 - 100 cycles per step in the stages with more than one tau per wave (3.5 + 1.3 + 2.5 us of a 15-us call; same bits).
+    static_assert(TIN == 2 * TOUT, "stride 2, k = 3, pad 1");
+    const bool first_ok = tau > 0;
+    const int t0 = first_ok ? 2 * tau - 1 : 0;
+#pragma unroll U
     for (int c = 0; c < CIN; ++c) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int t = 2 * tau + k - 1;
-        if (t >= 0 && t < TIN) acc = fmaf(wT[(c * 3 + k) * COUT + o], x[c * TIN + t], acc);
-      }
+      const float v = fmaf(wT[(c * 3 + 0) * COUT + o], x[c * TIN + t0], acc);
+      acc = first_ok ? v : acc;
+      acc = fmaf(wT[(c * 3 + 1) * COUT + o], x[c * TIN + 2 * tau], acc);
+      acc = fmaf(wT[(c * 3 + 2) * COUT + o], x[c * TIN + 2 * tau + 1], acc);
     }
     yout[(fb * COUT + o) * TOUT + tau] = lrelu(acc);
   }
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256) void audio_encode_kernel(const float* __restri
 // bits) with LDS latencies in them.
 constexpr int kEncFloats = (int)(OFF_G0 - OFF_C0W);
 constexpr int kEncLds = (kEncFloats + 29 * 16 + 32 * 8 + 32 * 4 + 64 * 2 + 64 + 64) * 4;
+static_assert(OFF_W0T % 4 == 0 && OFF_W5AT % 4 == 0, "16-byte loads of the frame vectors' second stage");
 static_assert(OFF_C0W % 4 == 0 && kEncFloats % 4 == 0 && kEncLds <= 160 * 1024, "the encoder's section is whole 16-byte pieces and fits the LDS");
 __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __restrict__ packed, const float* __restrict__ windows,
                                                               float* __restrict__ feat, int64_t n) {
@@ -115,22 +121,38 @@ __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __re
   }
   __syncthreads();
   const float* w = wl - OFF_C0W;                      // so that the blob's offsets address the copy
-  conv_stage<29, 32, 16, 1>(w + OFF_C0W, w + OFF_C0B, x0, y1);
-  conv_stage<32, 32, 8, 1>(w + OFF_C2W, w + OFF_C2B, y1, y2);
-  conv_stage<32, 64, 4, 1>(w + OFF_C4W, w + OFF_C4B, y2, y3);
-  conv_stage<64, 64, 2, 1>(w + OFF_C6W, w + OFF_C6B, y3, y4);
+#ifndef S2L_ENC_UNROLL
+#define S2L_ENC_UNROLL 8
+#endif
+#ifndef S2L_ENC_FC_UNROLL
+#define S2L_ENC_FC_UNROLL 16
+#endif
+#ifdef S2L_ENC_STOP      // pricing builds (tools/dev): leave after the staging (0) or after stage S2L_ENC_STOP
+#define S2L_ENC_STOP_AT(k) if (S2L_ENC_STOP == (k)) { if (threadIdx.x < 64) feat[f * 64 + threadIdx.x] = y1[threadIdx.x] + y2[threadIdx.x] + y3[threadIdx.x] + y4[threadIdx.x]; return; }
+#else
+#define S2L_ENC_STOP_AT(k)
+#endif
+  S2L_ENC_STOP_AT(0)
+  conv_stage<29, 32, 16, 1, S2L_ENC_UNROLL>(w + OFF_C0W, w + OFF_C0B, x0, y1);
+  S2L_ENC_STOP_AT(1)
+  conv_stage<32, 32, 8, 1, S2L_ENC_UNROLL>(w + OFF_C2W, w + OFF_C2B, y1, y2);
+  S2L_ENC_STOP_AT(2)
+  conv_stage<32, 64, 4, 1, S2L_ENC_UNROLL>(w + OFF_C4W, w + OFF_C4B, y2, y3);
+  S2L_ENC_STOP_AT(3)
+  conv_stage<64, 64, 2, 1, S2L_ENC_UNROLL>(w + OFF_C6W, w + OFF_C6B, y3, y4);
+  S2L_ENC_STOP_AT(4)
   const int o = threadIdx.x & 63;
   const bool mine = threadIdx.x < 64;
   float acc = w[OFF_F0B + o];
   if (mine) {
-#pragma unroll 16
+#pragma unroll S2L_ENC_FC_UNROLL
     for (int k = 0; k < 64; ++k) acc = fmaf(w[OFF_F0W + k * 64 + o], y4[k], acc);
     f1[o] = lrelu(acc);
   }
   __syncthreads();
   acc = w[OFF_F2B + o];
   if (mine) {
-#pragma unroll 16
+#pragma unroll S2L_ENC_FC_UNROLL
     for (int k = 0; k < 64; ++k) acc = fmaf(w[OFF_F2W + k * 64 + o], f1[k], acc);
     feat[f * 64 + o] = acc;
   }
@@ -356,6 +378,73 @@ __global__ __launch_bounds__(256) void frame_vectors_kernel(const float* __restr
     }
 }
 
+// One frame per call (fewer than kFB frames): frame_vectors_kernel<1> is one workgroup pulling 684 KB of weights through one CU in two
+// dependent stages (9 us).  Here a frame's 2 x 256 outputs are split over kFVSplit workgroups: each one repeats stage 1 (every workgroup
+// needs all 256 sums of both kinds; 172 KB, now from L2 lines its neighbours fetch too) and computes 32 + 32 outputs of stage 2, whose 64 KB
+// of weights all 256 threads request into LDS BEFORE stage 1 starts (16 16-byte loads per thread in one round trip, hidden behind stage 1).
+// Every output is the same chain of fmas in the same order on the same operands: the same bits.
+constexpr int kFVSplit = 8;
+__global__ __launch_bounds__(256) void frame_vectors_split_kernel(const float* __restrict__ packed, const float* __restrict__ feat,
+                                                                 const int64_t* __restrict__ frame_idx, float* __restrict__ q0,
+                                                                 float* __restrict__ q5, int64_t n) {
+  constexpr int kOut = 256 / kFVSplit;                // outputs of each kind per workgroup
+  __shared__ __attribute__((aligned(16))) float w0s[256 * kOut];      // [k][kOut]: the slice of W0T / W5AT
+  __shared__ __attribute__((aligned(16))) float w5s[256 * kOut];
+  __shared__ float a[64];
+  __shared__ float pe[20];
+  __shared__ float s0[256];
+  __shared__ float s5[256];
+  const int64_t f = blockIdx.x;
+  const int j = blockIdx.y, tid = threadIdx.x;
+  // stage 2's weights: the slice [k 256][kOut] of each matrix as 16-byte pieces, piece t + 256 i to thread t (lane-linear in LDS)
+  constexpr int kPieces = kOut / 4;                   // per row
+  f4 r0[kPieces], r5[kPieces];
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = tid + 256 * i, k = idx / kPieces, pc = idx % kPieces;
+    r0[i] = *reinterpret_cast<const f4*>(packed + OFF_W0T + k * 256 + j * kOut + 4 * pc);
+    r5[i] = *reinterpret_cast<const f4*>(packed + OFF_W5AT + k * 256 + j * kOut + 4 * pc);
+  }
+  if (tid < 64) {
+    a[tid] = feat[f * 64 + tid];
+    if (tid < 20) {
+      const float pos = (float)frame_idx[f];
+      const float arg = __fmul_rn(pos, packed[OFF_DIV + (tid >> 1)]);
+      pe[tid] = (tid & 1) ? cosf(arg) : sinf(arg);
+    }
+  }
+  __syncthreads();
+  float acc0 = packed[OFF_BSUM0 + tid], acc5 = packed[OFF_BSUM5 + tid];
+#pragma unroll 32
+  for (int k = 0; k < 64; ++k) {
+    acc0 = fmaf(packed[OFF_WAT + k * 256 + tid], a[k], acc0);
+    acc5 = fmaf(packed[OFF_WAST + k * 256 + tid], a[k], acc5);
+  }
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    acc0 = fmaf(packed[OFF_WTT + k * 256 + tid], pe[k], acc0);
+    acc5 = fmaf(packed[OFF_WTST + k * 256 + tid], pe[k], acc5);
+  }
+  s0[tid] = acc0;
+  s5[tid] = acc5;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    *reinterpret_cast<f4*>(w0s + 4 * (tid + 256 * i)) = r0[i];
+    *reinterpret_cast<f4*>(w5s + 4 * (tid + 256 * i)) = r5[i];
+  }
+  __syncthreads();
+  if (tid < 2 * kOut) {      // threads 0 .. kOut-1: q0's outputs, kOut .. 2 kOut-1: q5's
+    const bool five = tid >= kOut;
+    const int o = five ? tid - kOut : tid;
+    const float* ws = five ? w5s : w0s;
+    const float* sv = five ? s5 : s0;
+    float acc = packed[(five ? OFF_B5 : OFF_B0) + j * kOut + o];
+#pragma unroll 32
+    for (int k = 0; k < 256; ++k) acc = fmaf(ws[k * kOut + o], sv[k], acc);
+    (five ? q5 : q0)[f * 256 + j * kOut + o] = acc;
+  }
+}
+
 // Embedder(10, 2): [u, v, sin(u), sin(v), cos(u), cos(v), sin(2u), sin(2v), ..., cos(512v)].
 // The product x*freq is exact (power-of-two scale), sinf/cosf are the accurate OCML versions
 // (arguments reach 512: never the fast __sinf intrinsics).
@@ -467,8 +556,13 @@ extern "C" int s2l_frame_vectors(const float* packed, const float* feat, const i
   if (n == 0) return S2L_OK;
   if (!packed || !feat || !frame_idx || !q0 || !q5) return S2L_E_NULL;
   if (n < s2l::kFB) {
+#ifdef S2L_FV_ONE_BLOCK
     hipLaunchKernelGGL(s2l::frame_vectors_kernel<1>, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), packed, feat,
                        frame_idx, q0, q5, n);
+#else
+    hipLaunchKernelGGL(s2l::frame_vectors_split_kernel, dim3((unsigned)n, s2l::kFVSplit), dim3(256), 0, static_cast<hipStream_t>(stream), packed,
+                       feat, frame_idx, q0, q5, n);
+#endif
   } else {
     const int64_t blocks = (n + s2l::kFB - 1) / s2l::kFB;
     hipLaunchKernelGGL(s2l::frame_vectors_kernel<s2l::kFB>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
