@@ -88,6 +88,31 @@ def test_audio_encoder_is_the_same_function_for_any_batch(model, dev):
             assert torch.equal(model.audio_merge_forward(win[start:start + n]), full[start:start + n]), (n, start)
 
 
+def test_frame_vectors_are_the_same_function_for_any_batch(model, dev):
+    """q0 / q5 of a frame are pure functions of its audio feature and index: calls with fewer than four frames split a frame's outputs over eight
+    workgroups with the second stage's weights in LDS (frame_vectors_split_kernel), clips run four frames per workgroup -- the same fma chains,
+    so the SAME BITS (tf_nerf.py:247-281, :434-442; what keeps a one-frame call equal to the same frame inside a clip)."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    lib = _abi.load()
+    packed = model.packed_weights()
+    feat = model.audio_merge_forward(T(W.synthetic_audio(40, seed=5).astype(np.float32)).to(dev))
+    idx = torch.tensor([0, 7, 597, 12345, 39999] * 8, dtype=torch.int64, device=dev)
+
+    def run(lo, n):
+        q0 = torch.full((n, 256), float("nan"), device=dev)
+        q5 = torch.full((n, 256), float("nan"), device=dev)
+        _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat[lo:lo + n].contiguous()), _ptr(idx[lo:lo + n].contiguous()), _ptr(q0), _ptr(q5), n,
+                                         _stream()), "s2l_frame_vectors")
+        return q0, q5
+    full0, full5 = run(0, 40)
+    assert bool(torch.isfinite(full0).all()) and bool(torch.isfinite(full5).all())
+    for n in (1, 2, 3, 4, 5):
+        for lo in (0, 13, 40 - n):
+            q0, q5 = run(lo, n)
+            assert torch.equal(q0, full0[lo:lo + n]) and torch.equal(q5, full5[lo:lo + n]), (n, lo)
+
+
 def test_rgb_forward_golden_rows(model, golden, sd, dev):
     g = golden("g3_rgb.npz")
     close(model.rgb_forward(T(g["gen_rows"]).to(dev), time_pts=torch.tensor([12345], device=dev)), g["gen_out"])
