@@ -137,6 +137,13 @@ int s2l_set_render_cus(int n_workgroups);
 int s2l_rgb_forward(const float* packed, const float* uv_audio, int64_t time_index, float* xbuf,
                     float* out, int64_t n_rows, s2l_stream_t stream);
 
+/* Which kernel runs the general-row forward (s2l_rgb_forward, the ensemble's forward) when no activations are saved: 0 = chosen per call (default:
+ * up to three rounds of 16-row tiles whose four waves split the 256 features -- one frame of the reference's per-frame driver,
+ * inference.py:152-159, is 4 096 or 9 216 rows -- else 64- / 128-row tiles with a wave per 16-row column), 1 = always the column form, 2 = always the
+ * feature-split tile.  Every output is the same chain of MFMAs on the same operands in both: the same bits (a test and A/B aid). */
+int s2l_set_rows_kernel(int kind);
+
+
 /* The embedding half of s2l_rgb_forward on its own: x [N,128] = [E(uv) 42 | audio 64 | PE(time_index) 20 | 0 0] per row
  * (Embedder.__call__ tf_nerf.py:404-425 on the uv columns, PositionalEncodingTime :434-442), for callers that run
  * s2l_train_forward / _backward on it (the autograd of rgb_forward). */

@@ -114,6 +114,7 @@ EXPORTS = {
     "s2l_set_unet_conv_kernel": (c_int, [c_int]),
     "s2l_set_unet_split_kernel": (c_int, [c_int]),
     "s2l_set_render_shape": (c_int, [c_int]),
+    "s2l_set_rows_kernel": (c_int, [c_int]),
     "s2l_train_backward_bf16_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_set_bf16_forward_kernel": (c_int, [c_int]),
     "s2l_unet_packed16_halves": (c_int64, []),

@@ -70,6 +70,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         gen_render_body.main_all(objdir)       # render_body.inc (long shape), render_body_wide.inc, render_body_single.inc
         import gen_render_fs_body
         gen_render_fs_body.main(os.path.join(objdir, "render_fs_body.inc"))      # the feature-split tile (one frame per call)
+        import gen_rows_fs_body
+        gen_rows_fs_body.main(os.path.join(objdir, "rows_fs_body.inc"))          # ... and the general-row MLP's (rgb_forward on a few thousand rows)
         import gen_render16_body
         gen_render16_body.main_all(objdir)     # render16_body_{long,wide,single}.inc: the split-bf16 speed mode (render16.hip)
         import gen_conv16_body

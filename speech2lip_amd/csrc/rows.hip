@@ -14,6 +14,8 @@
 // Rows (x, saved activations, dz) move through ordinary global loads/stores issued by the compiler;
 // they only make the hand-counted vmcnt waits more conservative (see render.hip).
 #include "s2l_common.h"
+#include <algorithm>
+#include <atomic>
 
 namespace s2l {
 
@@ -369,6 +371,32 @@ __global__ __launch_bounds__(256) void rows_bwd_kernel(RowsBwdArgs a) {
   wait_vmcnt_r<0>();
 }
 
+// The feature-split tile of the forward (gen_rows_fs_body.py): 16 rows per workgroup, the four waves own 64 features each and exchange the
+// activations through LDS -- for calls of a few thousand rows (one frame of the reference's per-frame driver), where the column form above
+// leaves most CUs idle behind 100-us chains.  Same MFMA chains per output: the same bits.  No saved activations (inference only).
+constexpr int kRfsRingPerWave = 8 * 4096;
+constexpr int kRfsExchange = 4 * kRfsRingPerWave;
+constexpr int kRfsLdsBytes = kRfsExchange + 2 * 16384;
+static_assert(kRfsLdsBytes == 160 * 1024, "gen_rows_fs_body.py: LDS_BYTES");
+static_assert(OFF_WG5 == OFF_WG0 + 16 * (kSlab / 2) && OFF_BOUT == OFF_BIAS + kHidden * kW && OFF_BG0 == OFF_BOUT + 4 && OFF_BG5 == OFF_BG0 + kW,
+              "gen_rows_fs_body.py walks the folded matrices and the bias blocks by these strides");
+__global__ __launch_bounds__(256) void rows_fs_kernel(RowsFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * kRfsRingPerWave);
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * blockIdx.x / gridDim.x));
+  const int tile_end = __builtin_amdgcn_readfirstlane((int)((int64_t)a.ntiles * (blockIdx.x + 1) / gridDim.x));
+  const int total = __builtin_amdgcn_readfirstlane((int)a.total);
+  const float* wb = a.packed + OFF_WMLP + (int64_t)wave * 4 * kSlab;            // the wave's four slabs of a layer (64 contiguous KiB)
+  const float* wout = a.packed + OFF_WOUT;
+  const float* wg0 = a.packed + OFF_WG0 + (int64_t)wave * 4 * (kSlab / 2);      // ... and its four 8-KiB M-blocks of the folded matrices
+  const float* wg5 = a.packed + OFF_WG5 + (int64_t)wave * 4 * (kSlab / 2);
+  const float* biasp = a.packed + OFF_BIAS;
+#include "rows_fs_body.inc"
+}
+
 static int rows_grid(int ntiles, const void* kernel, LdsOptIn& flags, int* grid) {
   int dev = 0, n_cu = 0;
   int rc = current_device_cus(&dev, &n_cu);
@@ -391,6 +419,21 @@ static int launch_rows_fwd_g(const float* packed, const float* x, float* out, fl
   return (int)hipGetLastError();
 }
 
+static std::atomic<int> g_rows_kernel{0};      // 0: choose per call, 1: the column form, 2: the feature-split tile (s2l_set_rows_kernel)
+
+static int launch_rows_fs(const float* packed, const float* x, float* out, int64_t n_rows, hipStream_t st) {
+  const int64_t ntiles = (n_rows + 15) / 16;
+  if (ntiles > 0x7fffffff || n_rows * 512 >= 0x7fffffffLL) return S2L_E_SIZE;      // (the body addresses x by 32-bit byte offsets)
+  RowsFwdArgs a{packed, x, out, nullptr, n_rows, (int)ntiles};
+  int dev = 0, n_cu = 0;
+  int rc = current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  static LdsOptIn flags;
+  if ((rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&rows_fs_kernel), kRfsLdsBytes, flags, dev))) return rc;
+  hipLaunchKernelGGL(rows_fs_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kRfsLdsBytes, st, a);
+  return (int)hipGetLastError();
+}
+
 int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsave, int64_t n_rows, hipStream_t st) {
   // G = 2: 128-row tiles (x operands, 32 registers per group, live beside both 64-register arrays).  One frame of the reference's
   // per-frame call (inference.py:158: 9 216 rows at 96x96) is only 72 such tiles for 256 CUs: when the 128-row tiles do not fill
@@ -398,6 +441,15 @@ int launch_rows_fwd(const float* packed, const float* x, float* out, float* hsav
   int dev = 0, n_cu = 0;
   const int rc = current_device_cus(&dev, &n_cu);
   if (rc) return rc;
+  // A few thousand rows (one frame of the per-frame driver: 4 096 at 64 x 64, 9 216 at 96 x 96; the ensemble's 4 x 9 216): rounds of 16-row tiles
+  // whose waves split the features (~37 us each) against rounds of 64- / 128-row column tiles (~140 / ~270 us): whichever finishes first.  Long
+  // calls stay with the column form (a weight slab serves 32 rows per wave there: the least L2 traffic per row).
+  const int kind = g_rows_kernel.load(std::memory_order_relaxed);
+  if (!hsave && n_rows * 512 < 0x7fffffffLL && kind != 1) {
+    auto rounds = [&](int64_t rows_per_tile) { return (double)(((n_rows + rows_per_tile - 1) / rows_per_tile + n_cu - 1) / n_cu); };
+    const double t_fs = 37.0 * rounds(16), t_col = std::min(140.0 * rounds(64), 270.0 * rounds(128));
+    if (kind == 2 || t_fs < 0.95 * t_col) return launch_rows_fs(packed, x, out, n_rows, st);
+  }
   if ((n_rows + 127) / 128 < n_cu) return launch_rows_fwd_g<1>(packed, x, out, hsave, n_rows, st);
   return launch_rows_fwd_g<2>(packed, x, out, hsave, n_rows, st);
 }
@@ -417,6 +469,14 @@ int launch_rows_bwd(const float* packed, const float* drgb, const float* hsave, 
 }
 
 }  // namespace s2l
+
+// Which kernel runs the general-row forward when no activations are saved: 0 (default) chosen per call by the row count, 1 always the column
+// form (64- / 128-row tiles, a wave per 16 rows), 2 always the feature-split tile (16 rows per workgroup).  Same bits (a test and A/B aid).
+extern "C" int s2l_set_rows_kernel(int kind) {
+  if (kind < 0 || kind > 2) return S2L_E_SIZE;
+  s2l::g_rows_kernel.store(kind, std::memory_order_relaxed);
+  return S2L_OK;
+}
 
 // s2l_rgb_forward: the exact drop-in for TalkingFace.rgb_forward (tf_nerf.py:225-285) on arbitrary [N,66] rows: embed the
 // rows (frontend.hip), then the general-row MLP above.  The clip renderer (s2l_render_lip) lives in render.hip.

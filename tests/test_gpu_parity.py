@@ -113,6 +113,34 @@ def test_frame_vectors_are_the_same_function_for_any_batch(model, dev):
             assert torch.equal(q0, full0[lo:lo + n]) and torch.equal(q5, full5[lo:lo + n]), (n, lo)
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 100, 1000, 4096, 9216, 12300, 20000])
+def test_rows_feature_split_tile_is_the_column_form_bit_for_bit(model, dev, n):
+    """TalkingFace.rgb_forward on arbitrary rows (tf_nerf.py:225-285) has two kernels: a wave per 16-row column (rows_fwd_kernel) and, for calls
+    of a few thousand rows -- one frame of the reference's per-frame driver, inference.py:152-159 --, 16-row tiles whose four waves split the
+    features (rows_fs_kernel).  Every output is the same chain of MFMAs on the same operands: the SAME BITS, also for ragged last tiles, several
+    tiles per workgroup (20 000 rows) and whatever the automatic choice takes."""
+    from speech2lip_amd import _abi
+    lib = _abi.load()
+    g = torch.Generator(device="cpu").manual_seed(n)
+    rows = torch.cat([torch.rand(n, 2, generator=g) * 2 - 1, torch.randn(n, 64, generator=g)], -1).to(dev)
+    t = torch.tensor([4321], device=dev)
+    outs = {}
+    try:
+        for kind in (1, 2, 0, 2):
+            _abi.check(lib.s2l_set_rows_kernel(kind), "s2l_set_rows_kernel")
+            with torch.no_grad():
+                outs.setdefault(kind, []).append(model.rgb_forward(rows, time_pts=t).clone())
+    finally:
+        lib.s2l_set_rows_kernel(0)
+    ref = outs[1][0]
+    assert ref.shape == (n, 4) or ref.shape[0] == n
+    assert bool(torch.isfinite(ref).all())
+    for kind in (2, 0):
+        for o in outs[kind]:
+            assert torch.equal(o, ref), (kind, int((o != ref).any(-1).sum()), float((o - ref).abs().max()))
+    assert lib.s2l_set_rows_kernel(3) != 0 and lib.s2l_set_rows_kernel(-1) != 0
+
+
 def test_rgb_forward_golden_rows(model, golden, sd, dev):
     g = golden("g3_rgb.npz")
     close(model.rgb_forward(T(g["gen_rows"]).to(dev), time_pts=torch.tensor([12345], device=dev)), g["gen_out"])
