@@ -173,6 +173,7 @@ def test_soak_slice_of_the_counted_wait_assembly_kernels(dev):
     bad += soak.soak_bf16(dev, 25, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_conv(dev, 15, seed=4, log=lambda *a: notes.append(a))
     bad += soak.soak_convh(dev, 200, seed=4, log=lambda *a: notes.append(a))      # (incl. the statistics-leaving launches; 200: the round-5 residency bug showed on ~2 % of shapes)
+    bad += soak.soak_rows(dev, 60, seed=4, log=lambda *a: notes.append(a))        # rgb_forward's feature-split tile against the column form
     torch.cuda.synchronize()
     assert not bad, notes
 

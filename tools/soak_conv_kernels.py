@@ -8,9 +8,11 @@ arithmetic, and with a second run of itself.
           auto-picked one, each twice (every sample column sees the same MFMA sequence in every shape);
   convh   convh_asm_kernel (bf16 planes): random layer / direction / gate / size against the fp32-tensor kernel's rounded output;
   bf16    fwd_asm_bf16_kernel / bwd_asm_bf16_kernel: random (h, w, B) rows, assembly vs the C++ kernels (activation images,
-          ReLU mask words, rgb, dz images), each twice.
+          ReLU mask words, rgb, dz images), each twice;
+  rows    rows_fs_kernel (rgb_forward's feature-split tile, generated assembly) against the column form rows_fwd_kernel: random row counts,
+          each form twice and the automatic choice.
 
-    python tools/soak_conv_kernels.py [rounds=150] [conv|render|bf16|convh|all]
+    python tools/soak_conv_kernels.py [rounds=150] [conv|render|bf16|convh|rows|all]
 
 `tests/test_gpu_concurrency.py` runs a 100-shape slice of the three under `-m gpu`."""
 import ctypes
@@ -242,12 +244,37 @@ def soak_convh(dev, rounds, seed=0, log=print):
     return bad
 
 
+def soak_rows(dev, rounds, seed=0, log=print):
+    """rows_fs_kernel vs rows_fwd_kernel through TalkingFace.rgb_forward: the same bits for any row count (ragged tiles, one to ~8 tiles per workgroup)"""
+    lib = _abi.load()
+    rng = np.random.default_rng(seed + 5)
+    m = s2l.TalkingFace(dev, s2l.may_config(16, 16), mode="eval").eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_state_dict(0, "he", include_dead=True).items()})
+    bad = []
+    try:
+        for it in range(rounds):
+            n = int(rng.integers(1, 40)) if it % 5 == 0 else int(rng.integers(1, 6000)) if it % 5 < 4 else int(rng.integers(6000, 34000))
+            rows = torch.cat([torch.rand(n, 2, device=dev) * 2 - 1, torch.randn(n, 64, device=dev)], -1)
+            t = torch.tensor([int(rng.integers(0, 40000))], device=dev)
+            outs = []
+            with torch.no_grad():
+                for kind in (1, 2, 0, 2, 1):
+                    _abi.check(lib.s2l_set_rows_kernel(kind), "s2l_set_rows_kernel")
+                    outs.append(m.rgb_forward(rows, time_pts=t).clone())
+            if not all(torch.equal(outs[0], o) for o in outs[1:]) or not bool(torch.isfinite(outs[0]).all()):
+                bad.append(("rows", n))
+                log("MISMATCH rows", n, [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+    finally:
+        lib.s2l_set_rows_kernel(0)
+    return bad
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     which = sys.argv[2] if len(sys.argv) > 2 else "conv"
     bad = []
-    for name, fn in (("conv", soak_conv), ("render", soak_render), ("bf16", soak_bf16), ("convh", soak_convh)):
+    for name, fn in (("conv", soak_conv), ("render", soak_render), ("bf16", soak_bf16), ("convh", soak_convh), ("rows", soak_rows)):
         if which in (name, "all"):
             b = fn(dev, rounds)
             torch.cuda.synchronize()
