@@ -191,6 +191,46 @@ def test_normalise_inside_the_consuming_convolution_gives_the_same_bits(dev, F, 
     assert ua.forward_train_frames_nhwc(x, precision="bf16h", update_running=False)[1][5] is False
 
 
+@pytest.mark.parametrize("F,fh,fw,grads", [(2, 64, 80, False), (2, 130, 70, True), (2, 500, 500, False)])
+def test_backward_with_stage_one_from_the_convolution_matches_the_reduction_pass(dev, F, fh, fw, grads):
+    """The frozen (and the training) backward take stage 1 of five layers' BatchNorm backward from the input-gradient convolution that produces
+    their output gradient (gen_convh8_body.py bstats_block) instead of bn_bwd_reduce_h_kernel's pass over g and z (S2L_NO_CONV_BSTATS=1 restores
+    it; read per launch).  Same sums in another order, on a chain whose tensors are bf16: the two agree to a few bf16 roundings of dz (rel. L2
+    <= 2e-2, cosine >= 0.9999), and against the fp32-tensor chain (the parity reference of test_chain_against_the_fp32_chain; autograd of
+    SimpleUnetLight.py:16-111 in train mode behind it) the convolution's sums are no worse than the pass's."""
+    import os
+    u, u32 = net(dev), net(dev)
+    rng = np.random.default_rng(3 * F + fw)
+    x = T(W.synthetic_image((F, fh, fw, 3), 5, "x")).to(dev)      # (the image of test_chain_against_the_fp32_chain: the bf16 chain's own error is ~1e-2 there)
+    d = T(rng.standard_normal((F, fh, fw, 3)).astype(np.float32)).to(dev)
+
+    def flat(r):
+        return [t.double().flatten() for t in ([r[0]] + [r[1][k] for k in sorted(r[1])] if grads else [r])]
+    _, c32 = u32.forward_train_frames_nhwc(x, update_running=False)
+    ref = flat(u32.backward_train_frames(c32, d, want_param_grads=True) if grads else u32.backward_train_frames(c32, d))
+    res = []
+    for off in (False, True):
+        if off:
+            os.environ["S2L_NO_CONV_BSTATS"] = "1"
+        else:
+            os.environ.pop("S2L_NO_CONV_BSTATS", None)
+        try:
+            _, c = u.forward_train_frames_nhwc(x, precision="bf16h", fuse_norm=False, update_running=False)
+            res.append(flat(u.backward_train_frames(c, d, want_param_grads=True) if grads else u.backward_train_frames(c, d)))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("S2L_NO_CONV_BSTATS", None)
+    assert len(res[0]) == len(res[1]) == len(ref) >= 1
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for a, b, r in zip(res[0], res[1], ref):
+        assert bool(torch.isfinite(a).all())
+        e_on, e_off = rel(a, r), rel(b, r)
+        # (white-noise d: ReLUs within rounding of zero resolve the other way in a bf16 chain -- its own bound against the fp32 chain is 0.4, see
+        #  test_chain_against_the_fp32_chain; what matters here: the convolution's sums are no worse than the pass's, and the two agree closely)
+        assert e_on <= 1.25 * e_off + 1e-4 and e_on <= 0.4, (e_on, e_off, a.numel())
+        assert rel(a, b) <= 2e-2 and float(torch.dot(a, b) / (a.norm() * b.norm())) >= 0.9999, (rel(a, b), e_off)
+
+
 @pytest.mark.parametrize("fh,fw", [(64, 80), (500, 500)])
 def test_chain_against_the_fp32_chain(dev, fh, fw):
     u32, u16, uh = net(dev), net(dev), net(dev)
