@@ -88,6 +88,31 @@ def test_audio_encoder_is_the_same_function_for_any_batch(model, dev):
             assert torch.equal(model.audio_merge_forward(win[start:start + n]), full[start:start + n]), (n, start)
 
 
+def test_audio_encoder_on_thousands_of_copies_of_one_window(model, dev):
+    """The reference's per-frame driver encodes the frame's window once per PIXEL (inference.py:144, 151: the window tiled hw times).  From 2 048
+    windows on, s2l_audio_encode computes window 0's feature first and every block whose windows equal window 0 bitwise copies it; any other
+    block runs the stages: the output is the same function of each window, bit for bit -- all copies, copies mixed with other windows, window 0
+    appearing again late, a NaN window (bitwise comparison), a ragged last block."""
+    win = T(W.synthetic_audio(64, seed=11).astype(np.float32)).to(dev)
+    small = model.audio_merge_forward(win)                                   # 64 windows: the plain path
+    # (a) the driver's pattern
+    tiled = win[5:6].tile(4096, 1, 1)
+    got = model.audio_merge_forward(tiled)
+    assert torch.equal(got, small[5:6].expand(4096, 64))
+    # (b) mixed: copies of window 0 of the call, other windows, ragged count; reference = the same rows through calls below the threshold
+    idx = torch.randint(0, 64, (4099,), generator=torch.Generator().manual_seed(1))
+    idx[:1500] = 7
+    idx[3000:3100] = 7
+    idx[4098] = 7
+    mixed = win[idx.to(dev)]
+    mixed[2000, 3, 4] = float("nan")
+    ref = torch.cat([model.audio_merge_forward(mixed[k:k + 1000]) for k in range(0, 4099, 1000)])
+    got = model.audio_merge_forward(mixed)
+    same = (got == ref) | (torch.isnan(got) & torch.isnan(ref))
+    assert bool(same.all()), int((~same).any(-1).sum())
+    assert torch.equal(got[:1500], small[7:8].expand(1500, 64)) and bool(torch.isnan(got[2000]).any())
+
+
 def test_frame_vectors_are_the_same_function_for_any_batch(model, dev):
     """q0 / q5 of a frame are pure functions of its audio feature and index: calls with fewer than four frames split a frame's outputs over eight
     workgroups with the second stage's weights in LDS (frame_vectors_split_kernel), clips run four frames per workgroup -- the same fma chains,
