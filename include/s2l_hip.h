@@ -77,6 +77,12 @@ int s2l_pack_weights(const float* const* tensors_host, const float* div_term_hos
 int s2l_audio_encode(const float* packed, const float* windows, float* feat, int64_t n_windows,
                      s2l_stream_t stream);
 
+/* One frame per call (fewer than four frames): encoder + frame vectors in ONE launch -- windows [n,16,29] and frame indices [n] -> q0 / q5
+ * [n,256] for s2l_render_lip and, if feat != NULL, the features [n,64]; the bits of s2l_audio_encode followed by s2l_frame_vectors
+ * (tf_nerf.py:197-213, :247-281; inference.py:129-159 calls the model once per frame).  n >= 4: S2L_E_SIZE. */
+int s2l_frame_front(const float* packed, const float* windows, const int64_t* frame_idx, float* feat, float* q0, float* q5, int64_t n,
+                    s2l_stream_t stream);
+
 /* Per-frame (pixel-invariant) halves of the first and skip layers for the batched renderer:
  *   q0[f] = W0 (Wa a_f + Wt PE(idx_f) + b_uv + b_a + b_t) + b0
  *   q5[f] = W5[:, :256] (Wa' a_f + Wt' PE(idx_f) + b_uv' + b_a' + b_t') + b5

@@ -41,6 +41,7 @@ EXPORTS = {
     "s2l_pack_weights": (c_int, [POINTER(c_void_p), POINTER(c_float), c_void_p, c_void_p]),
     "s2l_audio_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_frame_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "s2l_frame_front": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_pixel_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "s2l_render_lip": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "s2l_render16_packed_halves": (c_int64, []),

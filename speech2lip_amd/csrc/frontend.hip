@@ -116,9 +116,9 @@ constexpr int kEncFloats = (int)(OFF_G0 - OFF_C0W);
 constexpr int kEncLds = (kEncFloats + 29 * 16 + 32 * 8 + 32 * 4 + 64 * 2 + 64 + 64) * 4;
 static_assert(OFF_W0T % 4 == 0 && OFF_W5AT % 4 == 0, "16-byte loads of the frame vectors' second stage");
 static_assert(OFF_C0W % 4 == 0 && kEncFloats % 4 == 0 && kEncLds <= 160 * 1024, "the encoder's section is whole 16-byte pieces and fits the LDS");
-__global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __restrict__ packed, const float* __restrict__ windows,
-                                                              float* __restrict__ feat, int64_t n) {
-  extern __shared__ __attribute__((aligned(16))) float enc_smem[];
+// The six stages of one frame on the LDS copy of the encoder's weights; returns output o = threadIdx.x & 63 of the final layer in the first
+// wave (`mine`); the other waves only keep the barriers.  dbg: pricing builds' way out (S2L_ENC_STOP).
+__device__ inline float encode_frame_in_lds(const float* __restrict__ packed, const float* __restrict__ window, float* enc_smem, float* dbg) {
   float* const wl = enc_smem;                       // the section [OFF_C0W, OFF_G0) of `packed`
   float* const x0 = wl + kEncFloats;
   float* const y1 = x0 + 29 * 16;
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __re
   float* const y3 = y2 + 32 * 4;
   float* const y4 = y3 + 64 * 2;
   float* const f1 = y4 + 64;
-  const int64_t f = blockIdx.x;
   {      // every thread's 32 pieces requested before the first is stored: one round trip, not eight (2.8 -> 1.3 us)
     const f4* src = reinterpret_cast<const f4*>(packed + OFF_C0W);
     f4* dst = reinterpret_cast<f4*>(wl);
@@ -143,9 +142,9 @@ __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __re
       if (i < kEncFloats / 4) dst[i] = r[k];
     }
   }
-  for (int i = threadIdx.x; i < 16 * 29; i += 256) {      // windows [t 16][c 29] -> x0 [c][t]
+  for (int i = threadIdx.x; i < 16 * 29; i += 256) {      // window [t 16][c 29] -> x0 [c][t]
     const int t = i / 29, c = i - t * 29;
-    x0[c * 16 + t] = windows[f * 16 * 29 + i];
+    x0[c * 16 + t] = window[i];
   }
   __syncthreads();
   const float* w = wl - OFF_C0W;                      // so that the blob's offsets address the copy
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __re
 #define S2L_ENC_FC_UNROLL 16
 #endif
 #ifdef S2L_ENC_STOP      // pricing builds (tools/dev): leave after the staging (0) or after stage S2L_ENC_STOP
-#define S2L_ENC_STOP_AT(k) if (S2L_ENC_STOP == (k)) { if (threadIdx.x < 64) feat[f * 64 + threadIdx.x] = y1[threadIdx.x] + y2[threadIdx.x] + y3[threadIdx.x] + y4[threadIdx.x]; return; }
+#define S2L_ENC_STOP_AT(k) if (S2L_ENC_STOP == (k)) { if (threadIdx.x < 64 && dbg) dbg[threadIdx.x] = y1[threadIdx.x] + y2[threadIdx.x] + y3[threadIdx.x] + y4[threadIdx.x]; return 0.f; }
 #else
 #define S2L_ENC_STOP_AT(k)
 #endif
@@ -182,8 +181,18 @@ __global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __re
   if (mine) {
 #pragma unroll S2L_ENC_FC_UNROLL
     for (int k = 0; k < 64; ++k) acc = fmaf(w[OFF_F2W + k * 64 + o], f1[k], acc);
-    feat[f * 64 + o] = acc;
   }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void audio_encode_lds_kernel(const float* __restrict__ packed, const float* __restrict__ windows,
+                                                              float* __restrict__ feat, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) float enc_smem[];
+  const int64_t f = blockIdx.x;
+  const float acc = encode_frame_in_lds(packed, windows + f * 16 * 29, enc_smem, feat + f * 64);
+#ifndef S2L_ENC_STOP
+  if (threadIdx.x < 64) feat[f * 64 + threadIdx.x] = acc;
+#endif
 }
 
 // ---- audio encoder backward (training) --------------------------------------------------------
@@ -473,6 +482,74 @@ __global__ __launch_bounds__(256) void frame_vectors_split_kernel(const float* _
   }
 }
 
+// One frame per call, one launch: the encoder and the frame vectors of a frame in the same workgroups (s2l_frame_front).  Each of the
+// kFVSplit workgroups of a frame runs the WHOLE encoder itself (the same 8 us whether one workgroup does it or eight, and no launch
+// boundary behind it: ~3 us of a 50-us call), then its share of the frame vectors exactly as frame_vectors_split_kernel; the second stage's
+// weights wait in registers through the encoder and land in the LDS the encoder's weights have left.  Workgroup 0 of the frame also
+// writes the feature row.  Same chains as the two kernels: the same bits.
+__global__ __launch_bounds__(256) void frame_front_kernel(const float* __restrict__ packed, const float* __restrict__ windows,
+                                                         const int64_t* __restrict__ frame_idx, float* __restrict__ feat,
+                                                         float* __restrict__ q0, float* __restrict__ q5, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) float enc_smem[];
+  constexpr int kOut = 256 / kFVSplit, kPieces = kOut / 4;
+  static_assert(2 * 256 * kOut <= kEncFloats, "the second stage's slices fit where the encoder's weights were");
+  float* const w0s = enc_smem;                      // (after the encoder is done with its weights)
+  float* const w5s = enc_smem + 256 * kOut;
+  __shared__ float a[64];
+  __shared__ float pe[20];
+  __shared__ float s0[256];
+  __shared__ float s5[256];
+  const int64_t f = blockIdx.x;
+  const int j = blockIdx.y, tid = threadIdx.x;
+  f4 r0[kPieces], r5[kPieces];
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = tid + 256 * i, k = idx / kPieces, pc = idx % kPieces;
+    r0[i] = *reinterpret_cast<const f4*>(packed + OFF_W0T + k * 256 + j * kOut + 4 * pc);
+    r5[i] = *reinterpret_cast<const f4*>(packed + OFF_W5AT + k * 256 + j * kOut + 4 * pc);
+  }
+  const float fv = encode_frame_in_lds(packed, windows + f * 16 * 29, enc_smem, nullptr);
+  if (tid < 64) {
+    a[tid] = fv;
+    if (feat && j == 0) feat[f * 64 + tid] = fv;
+    if (tid < 20) {
+      const float pos = (float)frame_idx[f];
+      const float arg = __fmul_rn(pos, packed[OFF_DIV + (tid >> 1)]);
+      pe[tid] = (tid & 1) ? cosf(arg) : sinf(arg);
+    }
+  }
+  __syncthreads();      // (also: every wave is past its last read of the encoder's weights)
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    *reinterpret_cast<f4*>(w0s + 4 * (tid + 256 * i)) = r0[i];
+    *reinterpret_cast<f4*>(w5s + 4 * (tid + 256 * i)) = r5[i];
+  }
+  float acc0 = packed[OFF_BSUM0 + tid], acc5 = packed[OFF_BSUM5 + tid];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    acc0 = fmaf(packed[OFF_WAT + k * 256 + tid], a[k], acc0);
+    acc5 = fmaf(packed[OFF_WAST + k * 256 + tid], a[k], acc5);
+  }
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    acc0 = fmaf(packed[OFF_WTT + k * 256 + tid], pe[k], acc0);
+    acc5 = fmaf(packed[OFF_WTST + k * 256 + tid], pe[k], acc5);
+  }
+  s0[tid] = acc0;
+  s5[tid] = acc5;
+  __syncthreads();
+  if (tid < 2 * kOut) {
+    const bool five = tid >= kOut;
+    const int o = five ? tid - kOut : tid;
+    const float* ws = five ? w5s : w0s;
+    const float* sv = five ? s5 : s0;
+    float acc = packed[(five ? OFF_B5 : OFF_B0) + j * kOut + o];
+#pragma unroll 32
+    for (int k = 0; k < 256; ++k) acc = fmaf(ws[k * kOut + o], sv[k], acc);
+    (five ? q5 : q0)[f * 256 + j * kOut + o] = acc;
+  }
+}
+
 // Embedder(10, 2): [u, v, sin(u), sin(v), cos(u), cos(v), sin(2u), sin(2v), ..., cos(512v)].
 // The product x*freq is exact (power-of-two scale), sinf/cosf are the accurate OCML versions
 // (arguments reach 512: never the fast __sinf intrinsics).
@@ -587,6 +664,24 @@ extern "C" int s2l_audio_encode(const float* packed, const float* windows, float
                          packed, windows, feat, n);
     }
   }
+  return (int)hipGetLastError();
+}
+
+// Encoder + frame vectors of a call of fewer than four frames in ONE launch (TalkingFace.render_clip's one-frame-per-call path, inference.py:129-159):
+// windows [n,16,29], frame_idx [n] -> q0 / q5 [n,256] and, if feat != null, the features [n,64] -- the bits of s2l_audio_encode followed by
+// s2l_frame_vectors.  n >= 4: S2L_E_SIZE (clips use the two entry points: their kernels serve four frames per workgroup).
+extern "C" int s2l_frame_front(const float* packed, const float* windows, const int64_t* frame_idx, float* feat, float* q0, float* q5,
+                               int64_t n, s2l_stream_t stream) {
+  if (n < 0 || n >= s2l::kFB) return S2L_E_SIZE;
+  if (n == 0) return S2L_OK;
+  if (!packed || !windows || !frame_idx || !q0 || !q5) return S2L_E_NULL;
+  static s2l::LdsOptIn flag;
+  int dev = 0, n_cu = 0;
+  int rc = s2l::current_device_cus(&dev, &n_cu);
+  if (rc) return rc;
+  if ((rc = s2l::ensure_dynamic_lds(reinterpret_cast<const void*>(s2l::frame_front_kernel), s2l::kEncLds, flag, dev))) return rc;
+  hipLaunchKernelGGL(s2l::frame_front_kernel, dim3((unsigned)n, s2l::kFVSplit), dim3(256), s2l::kEncLds, static_cast<hipStream_t>(stream), packed,
+                     windows, frame_idx, feat, q0, q5, n);
   return (int)hipGetLastError();
 }
 

@@ -511,14 +511,17 @@ class TalkingFace(nn.Module):
         elif (out.shape != (F, int(height), int(width), 3) or out.dtype != torch.float32 or not out.is_contiguous()
               or out.device != dev):
             raise ValueError(f"out must be a contiguous fp32 [F,H,W,3] tensor on {dev}")
-        feat = torch.empty(F, 64, dtype=torch.float32, device=dev)
         q0 = torch.empty(F, 256, dtype=torch.float32, device=dev)
         q5 = torch.empty_like(q0)
         with torch.cuda.device(dev):
             st = _stream()      # the current stream OF dev: read it inside the guard
-            _abi.check(lib.s2l_audio_encode(_ptr(packed), _ptr(a), _ptr(feat), F, st), "s2l_audio_encode")
-            _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat), _ptr(idx), _ptr(q0), _ptr(q5), F, st),
-                       "s2l_frame_vectors")
+            if F < 4:           # the reference's mode, one frame per call: encoder + frame vectors in one launch (the same bits)
+                _abi.check(lib.s2l_frame_front(_ptr(packed), _ptr(a), _ptr(idx), None, _ptr(q0), _ptr(q5), F, st), "s2l_frame_front")
+            else:
+                feat = torch.empty(F, 64, dtype=torch.float32, device=dev)
+                _abi.check(lib.s2l_audio_encode(_ptr(packed), _ptr(a), _ptr(feat), F, st), "s2l_audio_encode")
+                _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat), _ptr(idx), _ptr(q0), _ptr(q5), F, st),
+                           "s2l_frame_vectors")
             if _events is not None:   # bench: HIP events on the launch stream around the dominant kernel
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()

@@ -138,6 +138,38 @@ def test_frame_vectors_are_the_same_function_for_any_batch(model, dev):
             assert torch.equal(q0, full0[lo:lo + n]) and torch.equal(q5, full5[lo:lo + n]), (n, lo)
 
 
+def test_frame_front_in_one_launch_is_the_two_kernels_bit_for_bit(model, dev):
+    """s2l_frame_front (what render_clip runs for fewer than four frames: encoder + frame vectors of a frame in the same eight workgroups) ==
+    s2l_audio_encode followed by s2l_frame_vectors, bit for bit: features, q0, q5 (tf_nerf.py:197-213, :247-281); argument errors."""
+    from speech2lip_amd import _abi
+    from speech2lip_amd.talking_face import _ptr, _stream
+    lib = _abi.load()
+    packed = model.packed_weights()
+    win = T(W.synthetic_audio(9, seed=21).astype(np.float32)).to(dev)
+    idx = torch.tensor([0, 3, 597, 12345, 39999, 7, 8, 9, 10], dtype=torch.int64, device=dev)
+    feat_ref = model.audio_merge_forward(win)
+    q0_ref = torch.empty(9, 256, device=dev)
+    q5_ref = torch.empty(9, 256, device=dev)
+    _abi.check(lib.s2l_frame_vectors(_ptr(packed), _ptr(feat_ref), _ptr(idx), _ptr(q0_ref), _ptr(q5_ref), 9, _stream()), "s2l_frame_vectors")
+    for n in (1, 2, 3):
+        for lo in (0, 4, 9 - n):
+            feat = torch.full((n, 64), float("nan"), device=dev)
+            q0 = torch.full((n, 256), float("nan"), device=dev)
+            q5 = torch.full((n, 256), float("nan"), device=dev)
+            w_, i_ = win[lo:lo + n].contiguous(), idx[lo:lo + n].contiguous()
+            _abi.check(lib.s2l_frame_front(_ptr(packed), _ptr(w_), _ptr(i_), _ptr(feat), _ptr(q0), _ptr(q5), n, _stream()), "s2l_frame_front")
+            assert torch.equal(feat, feat_ref[lo:lo + n]) and torch.equal(q0, q0_ref[lo:lo + n]) and torch.equal(q5, q5_ref[lo:lo + n]), (n, lo)
+            q0b = torch.full_like(q0, float("nan"))
+            _abi.check(lib.s2l_frame_front(_ptr(packed), _ptr(w_), _ptr(i_), None, _ptr(q0b), _ptr(q5), n, _stream()), "s2l_frame_front")
+            assert torch.equal(q0b, q0)
+    assert lib.s2l_frame_front(_ptr(packed), _ptr(win), _ptr(idx), None, _ptr(q0_ref), _ptr(q5_ref), 4, _stream()) == -2
+    assert lib.s2l_frame_front(_ptr(packed), None, _ptr(idx), None, _ptr(q0_ref), _ptr(q5_ref), 1, _stream()) == -1
+    # through the module: a one-frame call is the same frame inside a clip
+    clip = model.render_clip(win, idx.tolist(), 20, 24)
+    for k in (0, 4, 8):
+        assert torch.equal(model.render_clip(win[k:k + 1], [int(idx[k])], 20, 24)[0], clip[k])
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 100, 1000, 4096, 9216, 12300, 20000])
 def test_rows_feature_split_tile_is_the_column_form_bit_for_bit(model, dev, n):
     """TalkingFace.rgb_forward on arbitrary rows (tf_nerf.py:225-285) has two kernels: a wave per 16-row column (rows_fwd_kernel) and, for calls
